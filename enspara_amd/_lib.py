@@ -1,0 +1,113 @@
+"""ctypes binding of include/enspara_hip.h (libenspara_hip.so, in-tree).
+
+There is no CPU fallback: if the library is missing, or no HIP device is
+visible when a device call is made, this raises.  torch is imported first so
+that the library binds to the HIP runtime torch already loaded (both carry
+the soname libamdhip64.so.7); torch itself is only plumbing here
+(torch.distributed for the multi-GPU exchange).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libenspara_hip.so")
+
+EK_TILE = 256
+EK_OK, EK_EARG, EK_EHIP, EK_ESTATE, EK_ENOMEM = 0, -1, -2, -3, -4
+
+# every symbol include/enspara_hip.h declares (tests check the export table)
+SYMBOLS = [
+    "ek_abi_version", "ek_last_error", "ek_device_count",
+    "ek_ctx_create", "ek_ctx_destroy", "ek_ctx_sync", "ek_ctx_stream",
+    "ek_load_frames", "ek_rmsd_to_center",
+    "ek_state_reset", "ek_state_download", "ek_state_upload",
+    "ek_record_bytes", "ek_local_candidate", "ek_own_record",
+    "ek_kcenters_step", "ek_kcenters_run",
+    "ek_history_download", "ek_history_reset",
+    "ek_assign_nearest",
+    "ek_set_frames_per_lane", "ek_last_run_timing",
+]
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+class HipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load libenspara_hip.so (once).  Raises HipLibraryMissing if it has not
+    been built (python -m enspara_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryMissing(
+            "%s not found: the HIP extension is not built "
+            "(run `python -m enspara_amd.build`); there is no CPU fallback."
+            % LIB_PATH)
+    try:
+        import torch  # noqa: F401  (loads libamdhip64.so.7 first)
+    except Exception:  # pragma: no cover - torch is plumbing, not required
+        pass
+    try:
+        L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    except OSError as e:
+        raise HipLibraryMissing("cannot load %s: %s" % (LIB_PATH, e))
+    vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+    f32p, i32p, i64p = (C.POINTER(C.c_float), C.POINTER(C.c_int32),
+                        C.POINTER(C.c_int64))
+    L.ek_abi_version.restype = C.c_int
+    L.ek_last_error.restype = C.c_char_p
+    L.ek_device_count.restype = C.c_int
+    L.ek_ctx_create.argtypes = [C.c_int, i64, i32, i64, vp, C.POINTER(vp)]
+    L.ek_ctx_destroy.argtypes = [vp]
+    L.ek_ctx_sync.argtypes = [vp]
+    L.ek_ctx_stream.restype = vp
+    L.ek_ctx_stream.argtypes = [vp]
+    L.ek_load_frames.argtypes = [vp, vp, i64, i64, C.c_int]
+    L.ek_rmsd_to_center.argtypes = [vp, i64, f32p, f32p]
+    L.ek_state_reset.argtypes = [vp]
+    L.ek_state_download.argtypes = [vp, f32p, i32p]
+    L.ek_state_upload.argtypes = [vp, f32p, i32p]
+    L.ek_record_bytes.restype = C.c_size_t
+    L.ek_record_bytes.argtypes = [i32]
+    L.ek_local_candidate.argtypes = [vp, vp]
+    L.ek_own_record.restype = vp
+    L.ek_own_record.argtypes = [vp]
+    L.ek_kcenters_step.argtypes = [vp, vp, i32, i32, C.c_double, vp]
+    L.ek_kcenters_run.argtypes = [vp, i32, i32, C.c_double, i32p, i64p, f32p, f32p]
+    L.ek_history_download.argtypes = [vp, i32, i32, i64p, f32p, i32p]
+    L.ek_history_reset.argtypes = [vp]
+    L.ek_assign_nearest.argtypes = [vp, f32p, i32]
+    L.ek_set_frames_per_lane.argtypes = [vp, C.c_int]
+    L.ek_last_run_timing.argtypes = [vp, f32p, i32p]
+    for name in SYMBOLS:
+        getattr(L, name)
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().ek_last_error().decode("utf-8", "replace")
+        raise HipError("enspara_hip error %d: %s" % (rc, msg))
+
+
+def f32p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def i32p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def i64p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int64))

@@ -1,0 +1,59 @@
+"""Build the gfx950 HIP library in-tree: enspara_amd/libenspara_hip.so.
+
+`python -m enspara_amd.build` (or __graft_entry__.build()).  hipcc
+cross-compiles for gfx950 without a GPU.  The library is linked without an
+rpath so that, inside a process that has already imported torch, the dynamic
+loader binds it to the HIP runtime torch loaded (both have the soname
+libamdhip64.so.7); outside such a process it resolves through the normal
+search path (/opt/rocm/lib).
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "_build")
+OUT = os.path.join(HERE, "libenspara_hip.so")
+SOURCES = ["ek_prepare.hip", "ek_kcenters.hip", "ek_assign.hip", "ek_api.hip"]
+HEADERS = ["ek_common.h", "ek_qcp.h", os.path.join("..", "..", "include",
+                                                   "enspara_hip.h")]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# -ffp-contract=off: FMAs are explicit in the sources (numerical contract,
+# csrc/ek_qcp.h); hipcc's default would fuse a*b+c on its own.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+         "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wextra",
+         "-Wno-unused-parameter"]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(d) <= t for d in deps)
+
+
+def build(force=False, verbose=False, extra_flags=()):
+    os.makedirs(OBJ, exist_ok=True)
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    objs = []
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        op = os.path.join(OBJ, src.replace(".hip", ".o"))
+        objs.append(op)
+        if not force and _newer(op, [sp] + hdrs):
+            continue
+        cmd = [HIPCC] + FLAGS + list(extra_flags) + ["-c", sp, "-o", op]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    if force or not _newer(OUT, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

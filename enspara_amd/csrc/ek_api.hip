@@ -1,0 +1,608 @@
+// ek_api.hip -- the C ABI of include/enspara_hip.h (host side).
+#include "ek_common.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+#include <vector>
+
+static thread_local char g_err[512] = "";
+
+static int ek_fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define EK_HIP(call)                                                           \
+    do {                                                                       \
+        hipError_t e_ = (call);                                                \
+        if (e_ != hipSuccess)                                                  \
+            return ek_fail(EK_EHIP, "%s failed: %s (%d) at %s:%d", #call,      \
+                           hipGetErrorString(e_), (int)e_, __FILE__,           \
+                           __LINE__);                                          \
+    } while (0)
+
+#define EK_CHECK_LAUNCH()                                                      \
+    do {                                                                       \
+        hipError_t e_ = hipGetLastError();                                     \
+        if (e_ != hipSuccess)                                                  \
+            return ek_fail(EK_EHIP, "kernel launch failed: %s (%d) at %s:%d",  \
+                           hipGetErrorString(e_), (int)e_, __FILE__,           \
+                           __LINE__);                                          \
+    } while (0)
+
+struct ek_ctx {
+    int device = 0;
+    int64_t n = 0;
+    int32_t A = 0;
+    int64_t goff = 0;
+    int64_t n_tiles = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    bool loaded = false;
+
+    float *tiles = nullptr;      // [n_tiles][3A][EK_TILE]
+    double *G = nullptr;         // [n]
+    float *dist = nullptr;       // [n]
+    int32_t *assign = nullptr;   // [n]
+    float *scratch = nullptr;    // [n]   distances-only output
+    unsigned char *rec = nullptr;     // own candidate record
+    unsigned char *rec_tmp = nullptr; // record of an explicit center
+    EkBlockMax *blockmax = nullptr;
+    int blockmax_cap = 0;
+    EkHist *hist = nullptr;
+    int32_t hist_cap = 0;
+    EkCtl *ctl = nullptr;
+
+    float *stage = nullptr;      // AoS staging for host uploads
+    int64_t stage_frames = 0;
+    float *cen_aos = nullptr;    // centred center-major centers
+    double *cen_G = nullptr;
+    int32_t cen_cap = 0;
+
+    int fpl = 0;                 // 0 = auto
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float last_ms = 0.f;
+    int32_t last_launches = 0;
+};
+
+static int ek_pick_fpl(const ek_ctx *c)
+{
+    if (c->fpl == 1 || c->fpl == 2 || c->fpl == 4)
+        return c->fpl;
+    // enough waves to cover 256 CUs x 4 SIMDs several times over, widest loads
+    // that still leave that many
+    const int64_t waves4 = (c->n + 255) / 256;
+    const int64_t waves2 = (c->n + 127) / 128;
+    if (waves4 >= 4096)
+        return 4;
+    if (waves2 >= 4096)
+        return 2;
+    return 1;
+}
+
+extern "C" int ek_abi_version(void) { return EK_ABI_VERSION; }
+extern "C" const char *ek_last_error(void) { return g_err; }
+
+extern "C" int ek_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess)
+        return ek_fail(EK_EHIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    return n;
+}
+
+extern "C" size_t ek_record_bytes(int32_t n_atoms) { return ek_rec_bytes(n_atoms); }
+
+static int ek_free_all(ek_ctx *c)
+{
+    if (!c)
+        return EK_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream)
+        (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(c->tiles);
+    (void)hipFree(c->G);
+    (void)hipFree(c->dist);
+    (void)hipFree(c->assign);
+    (void)hipFree(c->scratch);
+    (void)hipFree(c->rec);
+    (void)hipFree(c->rec_tmp);
+    (void)hipFree(c->blockmax);
+    (void)hipFree(c->hist);
+    (void)hipFree(c->ctl);
+    (void)hipFree(c->stage);
+    (void)hipFree(c->cen_aos);
+    (void)hipFree(c->cen_G);
+    if (c->ev0)
+        (void)hipEventDestroy(c->ev0);
+    if (c->ev1)
+        (void)hipEventDestroy(c->ev1);
+    if (c->own_stream && c->stream)
+        (void)hipStreamDestroy(c->stream);
+    delete c;
+    return EK_OK;
+}
+
+extern "C" int ek_ctx_create(int device, int64_t n_frames, int32_t n_atoms,
+                             int64_t global_offset, void *stream, ek_ctx **out)
+{
+    if (!out)
+        return ek_fail(EK_EARG, "ek_ctx_create: out is NULL");
+    *out = nullptr;
+    if (n_frames < 0 || n_frames > 0x7fffff00LL)
+        return ek_fail(EK_EARG, "ek_ctx_create: n_frames=%lld out of range",
+                       (long long)n_frames);
+    if (n_atoms < 1 || n_atoms > EK_MAX_ATOMS)
+        return ek_fail(EK_EARG, "ek_ctx_create: n_atoms=%d out of range [1,%d]",
+                       n_atoms, EK_MAX_ATOMS);
+    EK_HIP(hipSetDevice(device));
+    ek_ctx *c = new (std::nothrow) ek_ctx();
+    if (!c)
+        return ek_fail(EK_ENOMEM, "ek_ctx_create: out of host memory");
+    c->device = device;
+    c->n = n_frames;
+    c->A = n_atoms;
+    c->goff = global_offset;
+    c->n_tiles = (n_frames + EK_TILE - 1) / EK_TILE;
+    if (stream) {
+        c->stream = (hipStream_t)stream;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete c;
+            return ek_fail(EK_EHIP, "hipStreamCreate: %s", hipGetErrorString(e));
+        }
+        c->own_stream = true;
+    }
+    const size_t tile_floats = (size_t)3 * n_atoms * EK_TILE;
+    const size_t nn = (size_t)std::max<int64_t>(n_frames, 1);
+    const size_t nt = (size_t)std::max<int64_t>(c->n_tiles, 1);
+    const size_t recb = ek_rec_bytes(n_atoms);
+    c->blockmax_cap = (int)((n_frames + EK_BLOCK - 1) / EK_BLOCK) + 1;
+    c->hist_cap = 1024;
+    hipError_t e = hipSuccess;
+#define EK_ALLOC(ptr, bytes)                                                   \
+    if (e == hipSuccess)                                                       \
+        e = hipMalloc((void **)&(ptr), (bytes));
+    EK_ALLOC(c->tiles, nt * tile_floats * sizeof(float));
+    EK_ALLOC(c->G, nn * sizeof(double));
+    EK_ALLOC(c->dist, nn * sizeof(float));
+    EK_ALLOC(c->assign, nn * sizeof(int32_t));
+    EK_ALLOC(c->scratch, nn * sizeof(float));
+    EK_ALLOC(c->rec, recb);
+    EK_ALLOC(c->rec_tmp, recb);
+    EK_ALLOC(c->blockmax, (size_t)c->blockmax_cap * sizeof(EkBlockMax));
+    EK_ALLOC(c->hist, (size_t)c->hist_cap * sizeof(EkHist));
+    EK_ALLOC(c->ctl, sizeof(EkCtl));
+#undef EK_ALLOC
+    if (e == hipSuccess)
+        e = hipEventCreate(&c->ev0);
+    if (e == hipSuccess)
+        e = hipEventCreate(&c->ev1);
+    if (e == hipSuccess && c->n_tiles > 0)  // zero the (padded) last tile
+        e = hipMemsetAsync(c->tiles + (size_t)(c->n_tiles - 1) * tile_floats, 0,
+                           tile_floats * sizeof(float), c->stream);
+    if (e == hipSuccess)
+        e = hipMemsetAsync(c->hist, 0, (size_t)c->hist_cap * sizeof(EkHist),
+                           c->stream);
+    if (e == hipSuccess)
+        e = hipMemsetAsync(c->ctl, 0, sizeof(EkCtl), c->stream);
+    if (e == hipSuccess)
+        e = hipMemsetAsync(c->rec, 0, recb, c->stream);
+    if (e != hipSuccess) {
+        ek_free_all(c);
+        return ek_fail(e == hipErrorOutOfMemory ? EK_ENOMEM : EK_EHIP,
+                       "ek_ctx_create: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return EK_OK;
+}
+
+extern "C" int ek_ctx_destroy(ek_ctx *ctx) { return ek_free_all(ctx); }
+
+extern "C" int ek_ctx_sync(ek_ctx *c)
+{
+    if (!c)
+        return ek_fail(EK_EARG, "NULL context");
+    EK_HIP(hipSetDevice(c->device));
+    EK_HIP(hipStreamSynchronize(c->stream));
+    return EK_OK;
+}
+
+extern "C" void *ek_ctx_stream(ek_ctx *c) { return c ? (void *)c->stream : nullptr; }
+extern "C" void *ek_own_record(ek_ctx *c) { return c ? (void *)c->rec : nullptr; }
+
+extern "C" int ek_set_frames_per_lane(ek_ctx *c, int fpl)
+{
+    if (!c)
+        return ek_fail(EK_EARG, "NULL context");
+    if (fpl != 0 && fpl != 1 && fpl != 2 && fpl != 4)
+        return ek_fail(EK_EARG, "frames per lane must be 0, 1, 2 or 4");
+    c->fpl = fpl;
+    return EK_OK;
+}
+
+extern "C" int ek_last_run_timing(ek_ctx *c, float *ms, int32_t *launches)
+{
+    if (!c)
+        return ek_fail(EK_EARG, "NULL context");
+    if (ms)
+        *ms = c->last_ms;
+    if (launches)
+        *launches = c->last_launches;
+    return EK_OK;
+}
+
+// ---- loading ---------------------------------------------------------------
+extern "C" int ek_load_frames(ek_ctx *c, const float *xyz, int64_t first,
+                              int64_t count, int src_is_device)
+{
+    if (!c || (!xyz && count > 0))
+        return ek_fail(EK_EARG, "ek_load_frames: NULL argument");
+    if (first < 0 || count < 0 || first + count > c->n)
+        return ek_fail(EK_EARG, "ek_load_frames: [%lld,+%lld) outside [0,%lld)",
+                       (long long)first, (long long)count, (long long)c->n);
+    if (first % EK_TILE)
+        return ek_fail(EK_EARG, "ek_load_frames: first=%lld is not a multiple "
+                                "of %d", (long long)first, EK_TILE);
+    EK_HIP(hipSetDevice(c->device));
+    const size_t frame_floats = (size_t)3 * c->A;
+    if (src_is_device) {
+        ek_launch_prepare_tiles(xyz, count, c->A, c->tiles, c->G, first, c->n,
+                                c->stream);
+        EK_CHECK_LAUNCH();
+    } else {
+        // stage through a device buffer in tile-aligned chunks (<= 256 MiB)
+        int64_t chunk = (int64_t)((256u << 20) / (frame_floats * sizeof(float)));
+        chunk = std::max<int64_t>(EK_TILE, chunk / EK_TILE * EK_TILE);
+        chunk = std::min<int64_t>(chunk, (count + EK_TILE - 1) / EK_TILE * EK_TILE);
+        if (chunk > c->stage_frames) {
+            EK_HIP(hipStreamSynchronize(c->stream));
+            (void)hipFree(c->stage);
+            c->stage = nullptr;
+            c->stage_frames = 0;
+            EK_HIP(hipMalloc((void **)&c->stage,
+                             (size_t)chunk * frame_floats * sizeof(float)));
+            c->stage_frames = chunk;
+        }
+        for (int64_t done = 0; done < count; done += chunk) {
+            const int64_t cnt = std::min(chunk, count - done);
+            EK_HIP(hipMemcpyAsync(c->stage, xyz + (size_t)done * frame_floats,
+                                  (size_t)cnt * frame_floats * sizeof(float),
+                                  hipMemcpyHostToDevice, c->stream));
+            ek_launch_prepare_tiles(c->stage, cnt, c->A, c->tiles, c->G,
+                                    first + done, c->n, c->stream);
+            EK_CHECK_LAUNCH();
+            // the staging buffer is reused by the next chunk
+            EK_HIP(hipStreamSynchronize(c->stream));
+        }
+    }
+    c->loaded = true;
+    return EK_OK;
+}
+
+// ---- centers given as coordinates -----------------------------------------------
+static int ek_upload_centers(ek_ctx *c, const float *xyz, int32_t K)
+{
+    const size_t frame_floats = (size_t)3 * c->A;
+    if (K > c->cen_cap) {
+        EK_HIP(hipStreamSynchronize(c->stream));
+        (void)hipFree(c->cen_aos);
+        (void)hipFree(c->cen_G);
+        c->cen_aos = nullptr;
+        c->cen_G = nullptr;
+        c->cen_cap = 0;
+        // 2 buffers: raw (second half) and centred (first half)
+        EK_HIP(hipMalloc((void **)&c->cen_aos,
+                         (size_t)2 * K * frame_floats * sizeof(float)));
+        EK_HIP(hipMalloc((void **)&c->cen_G, (size_t)K * sizeof(double)));
+        c->cen_cap = K;
+    }
+    float *raw = c->cen_aos + (size_t)c->cen_cap * frame_floats;
+    EK_HIP(hipMemcpyAsync(raw, xyz, (size_t)K * frame_floats * sizeof(float),
+                          hipMemcpyHostToDevice, c->stream));
+    ek_launch_prepare_centers(raw, K, c->A, c->cen_aos, c->cen_G, c->stream);
+    EK_CHECK_LAUNCH();
+    return EK_OK;
+}
+
+// ---- metric parity ---------------------------------------------------------------
+extern "C" int ek_rmsd_to_center(ek_ctx *c, int64_t frame_index,
+                                 const float *center_xyz, float *out_host)
+{
+    if (!c || !out_host)
+        return ek_fail(EK_EARG, "ek_rmsd_to_center: NULL argument");
+    if (!c->loaded)
+        return ek_fail(EK_ESTATE, "ek_rmsd_to_center: no frames loaded");
+    EK_HIP(hipSetDevice(c->device));
+    if (frame_index >= 0) {
+        if (frame_index >= c->n)
+            return ek_fail(EK_EARG, "ek_rmsd_to_center: frame %lld >= %lld",
+                           (long long)frame_index, (long long)c->n);
+        ek_launch_record_from_frame(c->tiles, c->G, c->A, frame_index, c->goff,
+                                    c->rec_tmp, c->stream);
+    } else {
+        if (!center_xyz)
+            return ek_fail(EK_EARG, "ek_rmsd_to_center: no center given");
+        int rc = ek_upload_centers(c, center_xyz, 1);
+        if (rc)
+            return rc;
+        ek_launch_record_from_center(c->cen_aos, c->cen_G, c->A, c->rec_tmp,
+                                     c->stream);
+    }
+    EK_CHECK_LAUNCH();
+    ek_launch_step(ek_pick_fpl(c), 1, c->tiles, c->G, c->dist, c->assign,
+                   c->scratch, c->rec_tmp, 1, c->n, c->A, 0, 0.0, c->blockmax,
+                   c->hist, c->ctl, c->stream);
+    EK_CHECK_LAUNCH();
+    EK_HIP(hipMemcpyAsync(out_host, c->scratch, (size_t)c->n * sizeof(float),
+                          hipMemcpyDeviceToHost, c->stream));
+    EK_HIP(hipStreamSynchronize(c->stream));
+    return EK_OK;
+}
+
+// ---- state -----------------------------------------------------------------------
+extern "C" int ek_history_reset(ek_ctx *c)
+{
+    if (!c)
+        return ek_fail(EK_EARG, "NULL context");
+    EK_HIP(hipSetDevice(c->device));
+    EK_HIP(hipMemsetAsync(c->hist, 0, (size_t)c->hist_cap * sizeof(EkHist),
+                          c->stream));
+    EK_HIP(hipMemsetAsync(c->ctl, 0, sizeof(EkCtl), c->stream));
+    return EK_OK;
+}
+
+extern "C" int ek_state_reset(ek_ctx *c)
+{
+    if (!c)
+        return ek_fail(EK_EARG, "NULL context");
+    if (!c->loaded)
+        return ek_fail(EK_ESTATE, "ek_state_reset: no frames loaded");
+    EK_HIP(hipSetDevice(c->device));
+    ek_launch_fill_state(c->dist, c->assign, c->n, __builtin_inff(), -1,
+                         c->stream);
+    EK_CHECK_LAUNCH();
+    int rc = ek_history_reset(c);
+    if (rc)
+        return rc;
+    return ek_local_candidate(c, nullptr);
+}
+
+extern "C" int ek_state_download(ek_ctx *c, float *dist_host,
+                                 int32_t *assign_host)
+{
+    if (!c)
+        return ek_fail(EK_EARG, "NULL context");
+    EK_HIP(hipSetDevice(c->device));
+    if (dist_host && c->n)
+        EK_HIP(hipMemcpyAsync(dist_host, c->dist, (size_t)c->n * sizeof(float),
+                              hipMemcpyDeviceToHost, c->stream));
+    if (assign_host && c->n)
+        EK_HIP(hipMemcpyAsync(assign_host, c->assign,
+                              (size_t)c->n * sizeof(int32_t),
+                              hipMemcpyDeviceToHost, c->stream));
+    EK_HIP(hipStreamSynchronize(c->stream));
+    return EK_OK;
+}
+
+extern "C" int ek_state_upload(ek_ctx *c, const float *dist_host,
+                               const int32_t *assign_host)
+{
+    if (!c || !dist_host || !assign_host)
+        return ek_fail(EK_EARG, "ek_state_upload: NULL argument");
+    EK_HIP(hipSetDevice(c->device));
+    if (c->n) {
+        EK_HIP(hipMemcpyAsync(c->dist, dist_host, (size_t)c->n * sizeof(float),
+                              hipMemcpyHostToDevice, c->stream));
+        EK_HIP(hipMemcpyAsync(c->assign, assign_host,
+                              (size_t)c->n * sizeof(int32_t),
+                              hipMemcpyHostToDevice, c->stream));
+    }
+    EK_HIP(hipStreamSynchronize(c->stream));
+    return ek_local_candidate(c, nullptr);
+}
+
+// ---- records / k-centers ---------------------------------------------------------
+extern "C" int ek_local_candidate(ek_ctx *c, void *rec_dev)
+{
+    if (!c)
+        return ek_fail(EK_EARG, "NULL context");
+    if (!c->loaded)
+        return ek_fail(EK_ESTATE, "ek_local_candidate: no frames loaded");
+    EK_HIP(hipSetDevice(c->device));
+    unsigned char *rec = rec_dev ? (unsigned char *)rec_dev : c->rec;
+    ek_launch_pick(nullptr, 0, c->dist, c->tiles, c->G, c->n, c->A, c->goff,
+                   rec, c->ctl, c->stream);
+    EK_CHECK_LAUNCH();
+    return EK_OK;
+}
+
+static int ek_ensure_hist(ek_ctx *c, int32_t label)
+{
+    if (label < c->hist_cap)
+        return EK_OK;
+    int32_t cap = c->hist_cap;
+    while (cap <= label)
+        cap *= 2;
+    EkHist *h = nullptr;
+    EK_HIP(hipMalloc((void **)&h, (size_t)cap * sizeof(EkHist)));
+    EK_HIP(hipMemsetAsync(h, 0, (size_t)cap * sizeof(EkHist), c->stream));
+    EK_HIP(hipMemcpyAsync(h, c->hist, (size_t)c->hist_cap * sizeof(EkHist),
+                          hipMemcpyDeviceToDevice, c->stream));
+    EK_HIP(hipStreamSynchronize(c->stream));
+    (void)hipFree(c->hist);
+    c->hist = h;
+    c->hist_cap = cap;
+    return EK_OK;
+}
+
+extern "C" int ek_kcenters_step(ek_ctx *c, const void *recs_dev, int32_t n_recs,
+                                int32_t label, double dist_cutoff,
+                                void *own_rec_out)
+{
+    if (!c)
+        return ek_fail(EK_EARG, "NULL context");
+    if (!c->loaded)
+        return ek_fail(EK_ESTATE, "ek_kcenters_step: no frames loaded");
+    if (label < 0)
+        return ek_fail(EK_EARG, "ek_kcenters_step: negative label");
+    EK_HIP(hipSetDevice(c->device));
+    int rc = ek_ensure_hist(c, label);
+    if (rc)
+        return rc;
+    const unsigned char *recs =
+        recs_dev ? (const unsigned char *)recs_dev : c->rec;
+    if (!recs_dev)
+        n_recs = 1;
+    if (n_recs < 1)
+        return ek_fail(EK_EARG, "ek_kcenters_step: n_recs < 1");
+    unsigned char *own = own_rec_out ? (unsigned char *)own_rec_out : c->rec;
+    const int fpl = ek_pick_fpl(c);
+    if (c->n > 0) {
+        ek_launch_step(fpl, 0, c->tiles, c->G, c->dist, c->assign, c->scratch,
+                       recs, n_recs, c->n, c->A, label, dist_cutoff,
+                       c->blockmax, c->hist, c->ctl, c->stream);
+        EK_CHECK_LAUNCH();
+    }
+    ek_launch_pick(c->n > 0 ? c->blockmax : nullptr,
+                   ek_step_blocks(fpl, c->n), c->dist, c->tiles, c->G, c->n,
+                   c->A, c->goff, own, c->ctl, c->stream);
+    EK_CHECK_LAUNCH();
+    return EK_OK;
+}
+
+extern "C" int ek_history_download(ek_ctx *c, int32_t first, int32_t count,
+                                   int64_t *center_index_out,
+                                   float *center_dist_out, int32_t *n_done)
+{
+    if (!c)
+        return ek_fail(EK_EARG, "NULL context");
+    if (first < 0 || count < 0)
+        return ek_fail(EK_EARG, "ek_history_download: bad range");
+    EK_HIP(hipSetDevice(c->device));
+    EkCtl ctl;
+    EK_HIP(hipMemcpyAsync(&ctl, c->ctl, sizeof(ctl), hipMemcpyDeviceToHost,
+                          c->stream));
+    std::vector<EkHist> h;
+    const int32_t avail = std::max(0, std::min(count, c->hist_cap - first));
+    if (avail > 0) {
+        h.resize(avail);
+        EK_HIP(hipMemcpyAsync(h.data(), c->hist + first,
+                              (size_t)avail * sizeof(EkHist),
+                              hipMemcpyDeviceToHost, c->stream));
+    }
+    EK_HIP(hipStreamSynchronize(c->stream));
+    for (int32_t i = 0; i < count; ++i) {
+        const bool ok = i < avail && h[i].set;
+        if (center_index_out)
+            center_index_out[i] = ok ? h[i].gidx : -1;
+        if (center_dist_out)
+            center_dist_out[i] = ok ? h[i].dist : 0.f;
+    }
+    if (n_done)
+        *n_done = ctl.n_done;
+    return EK_OK;
+}
+
+extern "C" int ek_kcenters_run(ek_ctx *c, int32_t first_label, int32_t max_new,
+                               double dist_cutoff, int32_t *n_added,
+                               int64_t *center_index_out,
+                               float *center_dist_out, float *final_maxdist)
+{
+    if (!c)
+        return ek_fail(EK_EARG, "NULL context");
+    if (!c->loaded)
+        return ek_fail(EK_ESTATE, "ek_kcenters_run: no frames loaded");
+    if (first_label < 0 || max_new < 0)
+        return ek_fail(EK_EARG, "ek_kcenters_run: negative argument");
+    EK_HIP(hipSetDevice(c->device));
+    int rc = ek_ensure_hist(c, first_label + max_new);
+    if (rc)
+        return rc;
+    // the accepted-label counter restarts at first_label for this run
+    EkCtl ctl0;
+    memset(&ctl0, 0, sizeof(ctl0));
+    ctl0.n_done = first_label;
+    EK_HIP(hipMemcpyAsync(c->ctl, &ctl0, offsetof(EkCtl, last_max),
+                          hipMemcpyHostToDevice, c->stream));
+    EK_HIP(hipStreamSynchronize(c->stream));
+
+    // With no distance cut-off the trip count is known: enqueue everything.
+    // With a cut-off, enqueue in batches and look at the stop flag in between
+    // (steps enqueued past the stopping point are no-ops on the device).
+    const bool open_loop = !(dist_cutoff > 0.0);
+    const int32_t batch = open_loop ? max_new : 16;
+    int32_t issued = 0;
+    EkCtl ctl;
+    memset(&ctl, 0, sizeof(ctl));
+    ctl.n_done = first_label;
+    EK_HIP(hipEventRecord(c->ev0, c->stream));
+    while (issued < max_new) {
+        const int32_t todo = std::min(batch, max_new - issued);
+        for (int32_t i = 0; i < todo; ++i) {
+            rc = ek_kcenters_step(c, nullptr, 1, first_label + issued + i,
+                                  dist_cutoff, nullptr);
+            if (rc)
+                return rc;
+        }
+        issued += todo;
+        if (!open_loop) {
+            EK_HIP(hipMemcpyAsync(&ctl, c->ctl, sizeof(ctl),
+                                  hipMemcpyDeviceToHost, c->stream));
+            EK_HIP(hipStreamSynchronize(c->stream));
+            if (ctl.stopped)
+                break;
+        }
+    }
+    EK_HIP(hipEventRecord(c->ev1, c->stream));
+    EK_HIP(hipMemcpyAsync(&ctl, c->ctl, sizeof(ctl), hipMemcpyDeviceToHost,
+                          c->stream));
+    EK_HIP(hipStreamSynchronize(c->stream));
+    EK_HIP(hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
+    const int32_t added = std::max(0, ctl.n_done - first_label);
+    c->last_launches = added;
+    if (n_added)
+        *n_added = added;
+    if (final_maxdist)
+        *final_maxdist = ctl.last_max;
+    if (added > 0 && (center_index_out || center_dist_out)) {
+        rc = ek_history_download(c, first_label, added, center_index_out,
+                                 center_dist_out, nullptr);
+        if (rc)
+            return rc;
+    }
+    return EK_OK;
+}
+
+// ---- nearest-center assignment -------------------------------------------------------
+extern "C" int ek_assign_nearest(ek_ctx *c, const float *centers_xyz,
+                                 int32_t n_centers)
+{
+    if (!c || (!centers_xyz && n_centers > 0))
+        return ek_fail(EK_EARG, "ek_assign_nearest: NULL argument");
+    if (!c->loaded)
+        return ek_fail(EK_ESTATE, "ek_assign_nearest: no frames loaded");
+    if (n_centers < 0)
+        return ek_fail(EK_EARG, "ek_assign_nearest: negative n_centers");
+    EK_HIP(hipSetDevice(c->device));
+    if (n_centers > 0) {
+        int rc = ek_upload_centers(c, centers_xyz, n_centers);
+        if (rc)
+            return rc;
+    }
+    ek_launch_assign(c->tiles, c->G, c->n, c->A, c->cen_aos, c->cen_G,
+                     n_centers, c->dist, c->assign, c->stream);
+    EK_CHECK_LAUNCH();
+    return ek_local_candidate(c, nullptr);
+}

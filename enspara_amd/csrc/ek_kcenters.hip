@@ -1,0 +1,472 @@
+// ek_kcenters.hip -- the one-center-vs-all-frames distance pass of k-centers,
+// fused with the nearest-center update and the farthest-point reduction.
+//
+// Replaces, for metric 'rmsd' (reference paths relative to /root/reference):
+//   dist = distance_method(traj, new_center)        enspara/cluster/kcenters.py:298 / :366
+//   inds = dist < distances; distances[inds] = ...  kcenters.py:304-306 / :370-373
+//   np.argmax(distances), distances.max()           kcenters.py:282, :226, :332-338
+//
+// Mapping.  HBM-bound, 1.5 flop/byte: no MFMA.  One lane
+// owns FPL consecutive frames; a wave streams its 64*FPL-frame slice of a
+// 256-frame tile row by row, so every load instruction of a wave covers one
+// contiguous 256*FPL-byte run and a workgroup walks one contiguous tile.
+// The 3x3 inner-product matrix of a frame is accumulated by its own lane
+// sequentially over atoms (9 FMAs per atom, no cross-lane traffic), which
+// fixes the summation order the parity tests rely on.  The center is staged
+// once per workgroup in LDS and read back as wave-wide broadcasts.
+#include "ek_common.h"
+#include "ek_qcp.h"
+
+// ---------------------------------------------------------------------------
+// arg-max helpers: larger value wins, lower index wins ties (np.argmax)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ bool ek_better(float v, uint32_t i, float bv,
+                                          uint32_t bi)
+{
+    return (v > bv) || (v == bv && i < bi);
+}
+
+__device__ __forceinline__ void ek_wave_argmax(float &v, uint32_t &i)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ov = __shfl_xor(v, off, 64);
+        const uint32_t oi = __shfl_xor(i, off, 64);
+        if (ek_better(ov, oi, v, i)) {
+            v = ov;
+            i = oi;
+        }
+    }
+}
+
+template <int N> struct EkVec;
+template <> struct EkVec<1> { typedef float type; };
+template <> struct EkVec<2> { typedef float2 type; };
+template <> struct EkVec<4> { typedef float4 type; };
+
+template <int N>
+__device__ __forceinline__ void ek_unpack(const typename EkVec<N>::type &v,
+                                          float (&o)[N]);
+template <>
+__device__ __forceinline__ void ek_unpack<1>(const float &v, float (&o)[1])
+{
+    o[0] = v;
+}
+template <>
+__device__ __forceinline__ void ek_unpack<2>(const float2 &v, float (&o)[2])
+{
+    o[0] = v.x;
+    o[1] = v.y;
+}
+template <>
+__device__ __forceinline__ void ek_unpack<4>(const float4 &v, float (&o)[4])
+{
+    o[0] = v.x;
+    o[1] = v.y;
+    o[2] = v.z;
+    o[3] = v.w;
+}
+
+// ---------------------------------------------------------------------------
+// the distance pass
+//   FPL   frames per lane (1, 2, 4): load width 4/8/16 bytes per lane
+//   MODE  0 = fused k-centers step, 1 = distances only
+// A wave owns frames [gw*64*FPL, (gw+1)*64*FPL); a workgroup has 4 waves.
+// ---------------------------------------------------------------------------
+template <int FPL, int MODE>
+__global__ void __launch_bounds__(EK_BLOCK)
+ek_step_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
+               float *__restrict__ dist, int32_t *__restrict__ assign,
+               float *__restrict__ out_dist,
+               const unsigned char *__restrict__ recs, int n_recs, int64_t n,
+               int A, int label, double cutoff,
+               EkBlockMax *__restrict__ blockmax, EkHist *__restrict__ hist,
+               EkCtl *__restrict__ ctl)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *ctr = lds;                       // 3A floats, padded to 4 atoms
+    __shared__ float red_v[EK_BLOCK / EK_WAVE];
+    __shared__ uint32_t red_i[EK_BLOCK / EK_WAVE];
+
+    typedef typename EkVec<FPL>::type vec_t;
+    const int tid = threadIdx.x;
+    const int lane = tid & (EK_WAVE - 1);
+    const int wave = tid / EK_WAVE;
+
+    // ---- winner among the candidate records (kcenters.py:337) --------------
+    const size_t rstride = ek_rec_bytes(A);
+    int win = 0;
+    float wmax = ((const EkRecHdr *)recs)->valid
+                     ? ((const EkRecHdr *)recs)->maxdist
+                     : -__builtin_inff();
+    for (int r = 1; r < n_recs; ++r) {
+        const EkRecHdr *h = (const EkRecHdr *)(recs + (size_t)r * rstride);
+        const float m = h->valid ? h->maxdist : -__builtin_inff();
+        if (m > wmax) {
+            wmax = m;
+            win = r;
+        }
+    }
+    win = __builtin_amdgcn_readfirstlane(win);
+    const EkRecHdr *wh = (const EkRecHdr *)(recs + (size_t)win * rstride);
+    if (MODE == 0) {
+        // stop rule of kcenters.py:217: continue only while maxdist > cutoff
+        if (!((double)wmax > cutoff)) {
+            if (blockIdx.x == 0 && tid == 0)
+                ctl->stopped = 1;
+            return;
+        }
+    }
+    const double Gc = wh->trace;
+    {
+        const float *wc = (const float *)(wh + 1);
+        const int A4 = (A + 3) & ~3;
+        for (int j = tid; j < 3 * A4; j += EK_BLOCK)
+            ctr[j] = (j < 3 * A) ? wc[j] : 0.f;
+    }
+    if (MODE == 0 && blockIdx.x == 0 && tid == 0) {
+        hist[label].gidx = wh->gidx;
+        hist[label].dist = wmax;
+        hist[label].set = 1;
+        ctl->n_done = label + 1;
+    }
+    __syncthreads();
+
+    // ---- this wave's slice ---------------------------------------------------
+    const int64_t gw = (int64_t)blockIdx.x * (EK_BLOCK / EK_WAVE) + wave;
+    const int64_t fw = gw * (EK_WAVE * FPL);          // first frame of the wave
+    const int64_t f0 = fw + (int64_t)lane * FPL;      // first frame of the lane
+    float bestv = -__builtin_inff();
+    uint32_t besti = 0xffffffffu;
+
+    if (fw < n) {
+        const int64_t tile = fw / EK_TILE;
+        const int in_tile = (int)(fw % EK_TILE) + lane * FPL;
+        const float *p = tiles + (size_t)tile * 3 * (size_t)A * EK_TILE + in_tile;
+
+        float s[FPL][9];
+#pragma unroll
+        for (int q = 0; q < FPL; ++q)
+#pragma unroll
+            for (int j = 0; j < 9; ++j)
+                s[q][j] = 0.f;
+
+        // 4 atoms per trip: 12 row loads in flight, 3 broadcast LDS reads
+        const float4 *ctr4 = (const float4 *)ctr;
+        const int A4 = A & ~3;
+        int a = 0;
+        for (; a < A4; a += 4) {
+            vec_t v[12];
+#pragma unroll
+            for (int r = 0; r < 12; ++r)
+                v[r] = *(const vec_t *)(p + (size_t)(3 * a + r) * EK_TILE);
+            const float4 c0 = ctr4[(3 * a) / 4 + 0];
+            const float4 c1 = ctr4[(3 * a) / 4 + 1];
+            const float4 c2 = ctr4[(3 * a) / 4 + 2];
+            const float c[12] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y,
+                                 c1.z, c1.w, c2.x, c2.y, c2.z, c2.w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float x[FPL], y[FPL], z[FPL];
+                ek_unpack<FPL>(v[3 * u + 0], x);
+                ek_unpack<FPL>(v[3 * u + 1], y);
+                ek_unpack<FPL>(v[3 * u + 2], z);
+                const float cx = c[3 * u + 0], cy = c[3 * u + 1],
+                            cz = c[3 * u + 2];
+#pragma unroll
+                for (int q = 0; q < FPL; ++q) {
+                    s[q][0] = __builtin_fmaf(x[q], cx, s[q][0]);
+                    s[q][1] = __builtin_fmaf(x[q], cy, s[q][1]);
+                    s[q][2] = __builtin_fmaf(x[q], cz, s[q][2]);
+                    s[q][3] = __builtin_fmaf(y[q], cx, s[q][3]);
+                    s[q][4] = __builtin_fmaf(y[q], cy, s[q][4]);
+                    s[q][5] = __builtin_fmaf(y[q], cz, s[q][5]);
+                    s[q][6] = __builtin_fmaf(z[q], cx, s[q][6]);
+                    s[q][7] = __builtin_fmaf(z[q], cy, s[q][7]);
+                    s[q][8] = __builtin_fmaf(z[q], cz, s[q][8]);
+                }
+            }
+        }
+        for (; a < A; ++a) {
+            float x[FPL], y[FPL], z[FPL];
+            ek_unpack<FPL>(*(const vec_t *)(p + (size_t)(3 * a + 0) * EK_TILE), x);
+            ek_unpack<FPL>(*(const vec_t *)(p + (size_t)(3 * a + 1) * EK_TILE), y);
+            ek_unpack<FPL>(*(const vec_t *)(p + (size_t)(3 * a + 2) * EK_TILE), z);
+            const float cx = ctr[3 * a + 0], cy = ctr[3 * a + 1],
+                        cz = ctr[3 * a + 2];
+#pragma unroll
+            for (int q = 0; q < FPL; ++q) {
+                s[q][0] = __builtin_fmaf(x[q], cx, s[q][0]);
+                s[q][1] = __builtin_fmaf(x[q], cy, s[q][1]);
+                s[q][2] = __builtin_fmaf(x[q], cz, s[q][2]);
+                s[q][3] = __builtin_fmaf(y[q], cx, s[q][3]);
+                s[q][4] = __builtin_fmaf(y[q], cy, s[q][4]);
+                s[q][5] = __builtin_fmaf(y[q], cz, s[q][5]);
+                s[q][6] = __builtin_fmaf(z[q], cx, s[q][6]);
+                s[q][7] = __builtin_fmaf(z[q], cy, s[q][7]);
+                s[q][8] = __builtin_fmaf(z[q], cz, s[q][8]);
+            }
+        }
+
+        // ---- per-frame epilogue: quartic, update, running arg-max -----------
+#pragma unroll
+        for (int q = 0; q < FPL; ++q) {
+            const int64_t f = f0 + q;
+            if (f < n) {
+                const float d = ek_rmsd_from_S(s[q], G[f], Gc, A);
+                if (MODE == 1) {
+                    out_dist[f] = d;
+                } else {
+                    float cur = dist[f];
+                    if (d < cur) {              // strict <: kcenters.py:304
+                        cur = d;
+                        dist[f] = d;
+                        assign[f] = label;
+                    }
+                    if (ek_better(cur, (uint32_t)f, bestv, besti)) {
+                        bestv = cur;
+                        besti = (uint32_t)f;
+                    }
+                }
+            }
+        }
+    }
+
+    if (MODE == 0) {
+        ek_wave_argmax(bestv, besti);
+        if (lane == 0) {
+            red_v[wave] = bestv;
+            red_i[wave] = besti;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            float v = red_v[0];
+            uint32_t i = red_i[0];
+#pragma unroll
+            for (int w = 1; w < EK_BLOCK / EK_WAVE; ++w)
+                if (ek_better(red_v[w], red_i[w], v, i)) {
+                    v = red_v[w];
+                    i = red_i[w];
+                }
+            blockmax[blockIdx.x].val = v;
+            blockmax[blockIdx.x].idx = i;
+        }
+    }
+}
+
+int ek_step_blocks(int fpl, int64_t n)
+{
+    const int64_t per_block = (int64_t)EK_BLOCK * fpl;
+    return (int)((n + per_block - 1) / per_block);
+}
+
+template <int FPL, int MODE>
+static void ek_launch_step_t(const float *tiles, const double *G, float *dist,
+                             int32_t *assign, float *out_dist,
+                             const unsigned char *recs, int n_recs, int64_t n,
+                             int A, int label, double cutoff,
+                             EkBlockMax *blockmax, EkHist *hist, EkCtl *ctl,
+                             hipStream_t s)
+{
+    const int blocks = ek_step_blocks(FPL, n);
+    if (blocks <= 0)
+        return;
+    const size_t lds = (size_t)3 * ((A + 3) & ~3) * sizeof(float);
+    hipLaunchKernelGGL((ek_step_kernel<FPL, MODE>), dim3(blocks),
+                       dim3(EK_BLOCK), lds, s, tiles, G, dist, assign,
+                       out_dist, recs, n_recs, n, A, label, cutoff, blockmax,
+                       hist, ctl);
+}
+
+void ek_launch_step(int fpl, int mode, const float *tiles, const double *G,
+                    float *dist, int32_t *assign, float *out_dist,
+                    const unsigned char *recs, int n_recs, int64_t n, int A,
+                    int label, double cutoff, EkBlockMax *blockmax,
+                    EkHist *hist, EkCtl *ctl, hipStream_t s)
+{
+#define EK_GO(F, M)                                                            \
+    ek_launch_step_t<F, M>(tiles, G, dist, assign, out_dist, recs, n_recs, n,  \
+                           A, label, cutoff, blockmax, hist, ctl, s)
+    if (mode == 0) {
+        if (fpl == 4) EK_GO(4, 0);
+        else if (fpl == 2) EK_GO(2, 0);
+        else EK_GO(1, 0);
+    } else {
+        if (fpl == 4) EK_GO(4, 1);
+        else if (fpl == 2) EK_GO(2, 1);
+        else EK_GO(1, 1);
+    }
+#undef EK_GO
+}
+
+// ---------------------------------------------------------------------------
+// pick: reduce to the shard's (max, first index) and publish its record
+// ---------------------------------------------------------------------------
+#define EK_PICK_THREADS 1024
+
+__global__ void __launch_bounds__(EK_PICK_THREADS)
+ek_pick_kernel(const EkBlockMax *__restrict__ blockmax, int n_blocks,
+               const float *__restrict__ dist, const float *__restrict__ tiles,
+               const double *__restrict__ G, int64_t n, int A,
+               int64_t global_offset, unsigned char *__restrict__ rec,
+               EkCtl *__restrict__ ctl)
+{
+    __shared__ float red_v[EK_PICK_THREADS / EK_WAVE];
+    __shared__ uint32_t red_i[EK_PICK_THREADS / EK_WAVE];
+    __shared__ uint32_t win_i;
+    __shared__ float win_v;
+    const int tid = threadIdx.x;
+    // a stopped step wrote no partials: leave the record as it is
+    if (blockmax && ctl->stopped)
+        return;
+    float v = -__builtin_inff();
+    uint32_t i = 0xffffffffu;
+    if (blockmax) {
+        for (int b = tid; b < n_blocks; b += EK_PICK_THREADS) {
+            const EkBlockMax m = blockmax[b];
+            if (ek_better(m.val, m.idx, v, i)) {
+                v = m.val;
+                i = m.idx;
+            }
+        }
+    } else {
+        for (int64_t f = tid; f < n; f += EK_PICK_THREADS) {
+            const float d = dist[f];
+            if (ek_better(d, (uint32_t)f, v, i)) {
+                v = d;
+                i = (uint32_t)f;
+            }
+        }
+    }
+    ek_wave_argmax(v, i);
+    if ((tid & 63) == 0) {
+        red_v[tid / 64] = v;
+        red_i[tid / 64] = i;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        v = (tid < EK_PICK_THREADS / EK_WAVE) ? red_v[tid] : -__builtin_inff();
+        i = (tid < EK_PICK_THREADS / EK_WAVE) ? red_i[tid] : 0xffffffffu;
+        ek_wave_argmax(v, i);
+        if (tid == 0) {
+            win_v = v;
+            win_i = i;
+        }
+    }
+    __syncthreads();
+    const uint32_t wi = win_i;
+    EkRecHdr *h = (EkRecHdr *)rec;
+    float *coords = (float *)(h + 1);
+    if (n <= 0 || wi == 0xffffffffu) {
+        if (tid == 0) {
+            h->maxdist = -__builtin_inff();
+            h->valid = 0;
+            h->gidx = -1;
+            h->trace = 0.0;
+            h->reserved = 0;
+            ctl->last_max = -__builtin_inff();
+        }
+        return;
+    }
+    if (tid == 0) {
+        h->maxdist = win_v;
+        h->valid = 1;
+        h->gidx = global_offset + (int64_t)wi;
+        h->trace = G[wi];
+        h->reserved = 0;
+        ctl->last_max = win_v;
+    }
+    const float *p = tiles + (size_t)(wi / EK_TILE) * 3 * (size_t)A * EK_TILE +
+                     (wi % EK_TILE);
+    for (int r = tid; r < 3 * A; r += EK_PICK_THREADS)
+        coords[r] = p[(size_t)r * EK_TILE];
+}
+
+void ek_launch_pick(const EkBlockMax *blockmax, int n_blocks,
+                    const float *dist, const float *tiles, const double *G,
+                    int64_t n, int A, int64_t global_offset,
+                    unsigned char *rec, EkCtl *ctl, hipStream_t s)
+{
+    hipLaunchKernelGGL(ek_pick_kernel, dim3(1), dim3(EK_PICK_THREADS), 0, s,
+                       blockmax, n_blocks, dist, tiles, G, n, A, global_offset,
+                       rec, ctl);
+}
+
+// ---------------------------------------------------------------------------
+// records for explicitly chosen centers
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(EK_BLOCK)
+ek_record_from_frame_kernel(const float *__restrict__ tiles,
+                            const double *__restrict__ G, int A, int64_t idx,
+                            int64_t global_offset,
+                            unsigned char *__restrict__ rec)
+{
+    EkRecHdr *h = (EkRecHdr *)rec;
+    float *coords = (float *)(h + 1);
+    if (threadIdx.x == 0) {
+        h->maxdist = __builtin_inff();
+        h->valid = 1;
+        h->gidx = global_offset + idx;
+        h->trace = G[idx];
+        h->reserved = 0;
+    }
+    const float *p = tiles + (size_t)(idx / EK_TILE) * 3 * (size_t)A * EK_TILE +
+                     (idx % EK_TILE);
+    for (int r = threadIdx.x; r < 3 * A; r += EK_BLOCK)
+        coords[r] = p[(size_t)r * EK_TILE];
+}
+
+void ek_launch_record_from_frame(const float *tiles, const double *G, int A,
+                                 int64_t local_idx, int64_t global_offset,
+                                 unsigned char *rec, hipStream_t s)
+{
+    hipLaunchKernelGGL(ek_record_from_frame_kernel, dim3(1), dim3(EK_BLOCK), 0,
+                       s, tiles, G, A, local_idx, global_offset, rec);
+}
+
+__global__ void __launch_bounds__(EK_BLOCK)
+ek_record_from_center_kernel(const float *__restrict__ center_aos,
+                             const double *__restrict__ Gc, int A,
+                             unsigned char *__restrict__ rec)
+{
+    EkRecHdr *h = (EkRecHdr *)rec;
+    float *coords = (float *)(h + 1);
+    if (threadIdx.x == 0) {
+        h->maxdist = __builtin_inff();
+        h->valid = 1;
+        h->gidx = -1;
+        h->trace = Gc[0];
+        h->reserved = 0;
+    }
+    for (int r = threadIdx.x; r < 3 * A; r += EK_BLOCK)
+        coords[r] = center_aos[r];
+}
+
+void ek_launch_record_from_center(const float *center_aos, const double *Gc,
+                                  int A, unsigned char *rec, hipStream_t s)
+{
+    hipLaunchKernelGGL(ek_record_from_center_kernel, dim3(1), dim3(EK_BLOCK), 0,
+                       s, center_aos, Gc, A, rec);
+}
+
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(EK_BLOCK)
+ek_fill_state_kernel(float *__restrict__ dist, int32_t *__restrict__ assign,
+                     int64_t n, float d, int32_t a)
+{
+    const int64_t i = (int64_t)blockIdx.x * EK_BLOCK + threadIdx.x;
+    if (i < n) {
+        dist[i] = d;
+        assign[i] = a;
+    }
+}
+
+void ek_launch_fill_state(float *dist, int32_t *assign, int64_t n, float d,
+                          int32_t a, hipStream_t s)
+{
+    if (n <= 0)
+        return;
+    const int64_t blocks = (n + EK_BLOCK - 1) / EK_BLOCK;
+    hipLaunchKernelGGL(ek_fill_state_kernel, dim3((unsigned)blocks),
+                       dim3(EK_BLOCK), 0, s, dist, assign, n, d, a);
+}

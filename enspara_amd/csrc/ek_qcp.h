@@ -1,0 +1,97 @@
+// ek_qcp.h -- device-side QCP (Theobald) minimal RMSD from the 3x3 inner
+// product matrix and the two traces.  gfx950 only.
+//
+// Replaces the arithmetic of mdtraj.rmsd, which enspara binds as metric
+// 'rmsd' (reference enspara/cluster/util.py:289-291).  Operation order is a
+// contract: tests compare against a CPU checker bit for bit, so this file is
+// compiled with -ffp-contract=off and every fused multiply-add is explicit.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define EK_EVALPREC 1e-11
+#define EK_MAXIT 50
+
+// S is row-major: S[3*i+j] = sum_a x_ai * y_aj  (x = frame, y = center)
+__device__ __forceinline__ double ek_msd_from_S(const float (&S)[9], double Gx,
+                                                double Gy, int n_atoms)
+{
+    const double Sxx = S[0], Sxy = S[1], Sxz = S[2];
+    const double Syx = S[3], Syy = S[4], Syz = S[5];
+    const double Szx = S[6], Szy = S[7], Szz = S[8];
+
+    // C2 = -2 * sum S_ij^2
+    double q = Sxx * Sxx;
+    q = q + Sxy * Sxy;
+    q = q + Sxz * Sxz;
+    q = q + Syx * Syx;
+    q = q + Syy * Syy;
+    q = q + Syz * Syz;
+    q = q + Szx * Szx;
+    q = q + Szy * Szy;
+    q = q + Szz * Szz;
+    const double C2 = -2.0 * q;
+
+    // C1 = -8 * det(S)
+    const double m0 = Syy * Szz - Syz * Szy;
+    const double m1 = Syx * Szz - Syz * Szx;
+    const double m2 = Syx * Szy - Syy * Szx;
+    const double detS = (Sxx * m0 - Sxy * m1) + Sxz * m2;
+    const double C1 = -8.0 * detS;
+
+    // C0 = det(K), K = symmetric traceless 4x4 key matrix of S
+    const double k00 = (Sxx + Syy) + Szz;
+    const double k01 = Syz - Szy;
+    const double k02 = Szx - Sxz;
+    const double k03 = Sxy - Syx;
+    const double k11 = (Sxx - Syy) - Szz;
+    const double k12 = Sxy + Syx;
+    const double k13 = Szx + Sxz;
+    const double k22 = (Syy - Sxx) - Szz;
+    const double k23 = Syz + Szy;
+    const double k33 = (Szz - Sxx) - Syy;
+
+    const double s0 = k00 * k11 - k01 * k01;
+    const double s1 = k00 * k12 - k01 * k02;
+    const double s2 = k00 * k13 - k01 * k03;
+    const double s3 = k01 * k12 - k11 * k02;
+    const double s4 = k01 * k13 - k11 * k03;
+    const double s5 = k02 * k13 - k12 * k03;
+    const double c5 = k22 * k33 - k23 * k23;
+    const double c4 = k12 * k33 - k13 * k23;
+    const double c3 = k12 * k23 - k13 * k22;
+    const double c2 = k02 * k33 - k03 * k23;
+    const double c1 = k02 * k23 - k03 * k22;
+    const double c0 = k02 * k13 - k03 * k12;
+    double C0 = s0 * c5 - s1 * c4;
+    C0 = C0 + s2 * c3;
+    C0 = C0 + s3 * c2;
+    C0 = C0 - s4 * c1;
+    C0 = C0 + s5 * c0;
+
+    // largest root of l^4 + C2 l^2 + C1 l + C0 by Newton from the upper bound
+    const double Gsum = Gx + Gy;
+    double lam = 0.5 * Gsum;
+    for (int it = 0; it < EK_MAXIT; ++it) {
+        const double x2 = lam * lam;
+        const double b = (x2 + C2) * lam;
+        const double a = b + C1;
+        const double num = __builtin_fma(a, lam, C0);
+        const double den = __builtin_fma(2.0 * x2, lam, b + a);
+        if (den == 0.0)
+            break;
+        const double delta = num / den;
+        lam = lam - delta;
+        if (__builtin_fabs(delta) < __builtin_fabs(EK_EVALPREC * lam))
+            break;
+    }
+    double msd = (Gsum - 2.0 * lam) / (double)n_atoms;
+    if (!(msd > 0.0))
+        msd = 0.0;
+    return msd;
+}
+
+__device__ __forceinline__ float ek_rmsd_from_S(const float (&S)[9], double Gx,
+                                                double Gy, int n_atoms)
+{
+    return __builtin_sqrtf((float)ek_msd_from_S(S, Gx, Gy, n_atoms));
+}

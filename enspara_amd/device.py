@@ -1,0 +1,195 @@
+"""Device-resident frames: the Python face of one ``ek_ctx``.
+
+A :class:`FrameStore` holds one shard of a trajectory set in HBM (centred,
+frame-minor tiles) together with the k-centers state
+(distance and assignment per frame).  All arithmetic happens in the HIP
+library; this class only moves pointers and sizes across the C ABI
+(include/enspara_hip.h).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .exception import DataInvalid
+
+
+def as_xyz(X):
+    """Coordinates of ``X`` as a float32 C-contiguous [n, A, 3] array.
+
+    Accepts what the reference's clustering accepts for metric 'rmsd': an
+    object with ``.xyz`` (md.Trajectory; enspara/cluster/kcenters.py:283 indexes
+    it, mdtraj reads ``.xyz``), a RaggedArray of per-trajectory coordinate
+    blocks (its concatenated ``_data``), or a plain array."""
+    if hasattr(X, "xyz"):
+        X = X.xyz
+    elif hasattr(X, "_data") and hasattr(X, "lengths"):
+        X = X._data
+    X = np.asarray(X)
+    if X.ndim == 2 and X.shape[1] == 3:
+        X = X[None]
+    if X.ndim != 3 or X.shape[2] != 3:
+        raise DataInvalid(
+            "RMSD clustering needs coordinates shaped (n_frames, n_atoms, 3); "
+            "got %s" % (X.shape,))
+    return np.ascontiguousarray(X, dtype=np.float32)
+
+
+class FrameStore:
+    """One shard of frames on one GPU."""
+
+    def __init__(self, n_frames, n_atoms, device=0, global_offset=0,
+                 stream=None):
+        self.lib = _lib.load()
+        self.n = int(n_frames)
+        self.A = int(n_atoms)
+        self.device = int(device)
+        self.global_offset = int(global_offset)
+        h = C.c_void_p()
+        _lib.check(self.lib.ek_ctx_create(
+            self.device, self.n, self.A, self.global_offset,
+            C.c_void_p(stream) if stream else None, C.byref(h)))
+        self._h = h
+
+    # -- lifetime -----------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.ek_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @classmethod
+    def from_array(cls, X, device=0, global_offset=0, stream=None):
+        xyz = as_xyz(X)
+        st = cls(xyz.shape[0], xyz.shape[1], device, global_offset, stream)
+        st.load(xyz)
+        return st
+
+    # -- data ---------------------------------------------------------------
+    def load(self, xyz, first=0):
+        xyz = as_xyz(xyz)
+        if xyz.shape[1] != self.A:
+            raise DataInvalid("atom count %d != %d" % (xyz.shape[1], self.A))
+        _lib.check(self.lib.ek_load_frames(
+            self._h, xyz.ctypes.data_as(C.c_void_p), int(first), xyz.shape[0], 0))
+
+    def load_device(self, dev_ptr, count, first=0):
+        """xyz already in device memory (float32 [count, A, 3])."""
+        _lib.check(self.lib.ek_load_frames(
+            self._h, C.c_void_p(int(dev_ptr)), int(first), int(count), 1))
+
+    def sync(self):
+        _lib.check(self.lib.ek_ctx_sync(self._h))
+
+    @property
+    def stream(self):
+        return self.lib.ek_ctx_stream(self._h)
+
+    # -- metric -------------------------------------------------------------
+    def rmsd_to_frame(self, index):
+        out = np.empty(self.n, dtype=np.float32)
+        _lib.check(self.lib.ek_rmsd_to_center(self._h, int(index), None,
+                                              _lib.f32p(out)))
+        return out
+
+    def rmsd_to_xyz(self, center_xyz):
+        c = as_xyz(center_xyz)
+        if c.shape[0] != 1 or c.shape[1] != self.A:
+            raise DataInvalid("center must be one frame of %d atoms" % self.A)
+        out = np.empty(self.n, dtype=np.float32)
+        _lib.check(self.lib.ek_rmsd_to_center(self._h, -1, _lib.f32p(c),
+                                              _lib.f32p(out)))
+        return out
+
+    # -- k-centers state ------------------------------------------------------
+    def reset_state(self):
+        _lib.check(self.lib.ek_state_reset(self._h))
+
+    def download_state(self):
+        """-> (distances float32 [n], assignments int32 [n])"""
+        d = np.empty(self.n, dtype=np.float32)
+        a = np.empty(self.n, dtype=np.int32)
+        _lib.check(self.lib.ek_state_download(self._h, _lib.f32p(d),
+                                              _lib.i32p(a)))
+        return d, a
+
+    def upload_state(self, dist, assign):
+        d = np.ascontiguousarray(dist, dtype=np.float32)
+        a = np.ascontiguousarray(assign, dtype=np.int32)
+        if len(d) != self.n or len(a) != self.n:
+            raise DataInvalid("state arrays must have %d entries" % self.n)
+        _lib.check(self.lib.ek_state_upload(self._h, _lib.f32p(d),
+                                            _lib.i32p(a)))
+
+    def kcenters_run(self, first_label, max_new, dist_cutoff):
+        """The device-resident k-centers loop on this shard alone.
+        -> (center indices int64 [k], their pre-update distances float32 [k],
+            final max distance)"""
+        max_new = int(max_new)
+        idx = np.empty(max(max_new, 1), dtype=np.int64)
+        cd = np.empty(max(max_new, 1), dtype=np.float32)
+        n_added = C.c_int32()
+        fmax = C.c_float()
+        _lib.check(self.lib.ek_kcenters_run(
+            self._h, int(first_label), max_new, float(dist_cutoff),
+            C.byref(n_added), _lib.i64p(idx), _lib.f32p(cd), C.byref(fmax)))
+        k = n_added.value
+        return idx[:k].copy(), cd[:k].copy(), fmax.value
+
+    def assign_nearest(self, centers_xyz):
+        c = as_xyz(centers_xyz)
+        if c.shape[0] and c.shape[1] != self.A:
+            raise DataInvalid("centers have %d atoms, frames %d"
+                              % (c.shape[1], self.A))
+        _lib.check(self.lib.ek_assign_nearest(self._h, _lib.f32p(c),
+                                              c.shape[0]))
+
+    # -- multi-shard primitives ----------------------------------------------
+    @property
+    def record_bytes(self):
+        return int(self.lib.ek_record_bytes(self.A))
+
+    def local_candidate(self, rec_dev_ptr=None):
+        _lib.check(self.lib.ek_local_candidate(
+            self._h, C.c_void_p(int(rec_dev_ptr)) if rec_dev_ptr else None))
+
+    def kcenters_step(self, recs_dev_ptr, n_recs, label, dist_cutoff,
+                      own_rec_out=None):
+        _lib.check(self.lib.ek_kcenters_step(
+            self._h, C.c_void_p(int(recs_dev_ptr)) if recs_dev_ptr else None,
+            int(n_recs), int(label), float(dist_cutoff),
+            C.c_void_p(int(own_rec_out)) if own_rec_out else None))
+
+    def history(self, first, count):
+        idx = np.empty(max(count, 1), dtype=np.int64)
+        cd = np.empty(max(count, 1), dtype=np.float32)
+        nd = C.c_int32()
+        _lib.check(self.lib.ek_history_download(
+            self._h, int(first), int(count), _lib.i64p(idx), _lib.f32p(cd),
+            C.byref(nd)))
+        return idx[:count], cd[:count], nd.value
+
+    def reset_history(self):
+        _lib.check(self.lib.ek_history_reset(self._h))
+
+    # -- tuning ---------------------------------------------------------------
+    def set_frames_per_lane(self, fpl):
+        _lib.check(self.lib.ek_set_frames_per_lane(self._h, int(fpl)))
+
+    def last_run_timing(self):
+        ms = C.c_float()
+        k = C.c_int32()
+        _lib.check(self.lib.ek_last_run_timing(self._h, C.byref(ms),
+                                               C.byref(k)))
+        return ms.value, k.value

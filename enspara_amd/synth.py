@@ -1,0 +1,69 @@
+"""Synthetic trajectory generator for tests and bench.py.
+
+Frames are noisy, randomly rotated and translated copies of a small set of
+random-walk "C-alpha" templates, so pairwise RMSDs spread over a realistic
+range instead of the near-constant values iid coordinates would give.
+Seeding is counter based per chunk of CHUNK frames: any sharding of the frame
+axis that is aligned to CHUNK reproduces the same data.
+"""
+import numpy as np
+
+CHUNK = 65536
+BOND_NM = 0.38
+NOISE_NM = 0.05
+
+
+def templates(n_templates, n_atoms, seed):
+    """float64 [n_templates, n_atoms, 3] random-walk chains, bond 0.38 nm."""
+    rng = np.random.Generator(np.random.PCG64([seed, 0x7e3a]))
+    steps = rng.normal(size=(n_templates, n_atoms, 3))
+    steps /= np.linalg.norm(steps, axis=2, keepdims=True)
+    steps *= BOND_NM
+    steps[:, 0] = 0.0
+    return np.cumsum(steps, axis=1)
+
+
+def _quat_to_rot(q):
+    w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = np.empty((len(q), 3, 3))
+    R[:, 0, 0] = 1 - 2 * (y * y + z * z)
+    R[:, 0, 1] = 2 * (x * y - z * w)
+    R[:, 0, 2] = 2 * (x * z + y * w)
+    R[:, 1, 0] = 2 * (x * y + z * w)
+    R[:, 1, 1] = 1 - 2 * (x * x + z * z)
+    R[:, 1, 2] = 2 * (y * z - x * w)
+    R[:, 2, 0] = 2 * (x * z - y * w)
+    R[:, 2, 1] = 2 * (y * z + x * w)
+    R[:, 2, 2] = 1 - 2 * (x * x + y * y)
+    return R
+
+
+def synth_chunk(chunk_index, count, tmpl, seed):
+    """Frames [chunk_index*CHUNK, +count) as float32 [count, A, 3]."""
+    rng = np.random.Generator(np.random.PCG64([seed, 1 + chunk_index]))
+    T = len(tmpl)
+    which = rng.integers(0, T, size=count)
+    xyz = tmpl[which] + rng.normal(scale=NOISE_NM, size=(count,) + tmpl.shape[1:])
+    q = rng.normal(size=(count, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    R = _quat_to_rot(q)
+    xyz = np.einsum("nij,naj->nai", R, xyz)
+    xyz += rng.uniform(-5.0, 5.0, size=(count, 1, 3))
+    return xyz.astype(np.float32)
+
+
+def synth(n_frames, n_atoms, n_templates, seed, first_frame=0):
+    """float32 [n_frames, n_atoms, 3] starting at global frame ``first_frame``
+    (which must be a multiple of CHUNK)."""
+    if first_frame % CHUNK:
+        raise ValueError("first_frame must be a multiple of %d" % CHUNK)
+    tmpl = templates(n_templates, n_atoms, seed)
+    out = np.empty((n_frames, n_atoms, 3), dtype=np.float32)
+    done = 0
+    c = first_frame // CHUNK
+    while done < n_frames:
+        cnt = min(CHUNK, n_frames - done)
+        out[done:done + cnt] = synth_chunk(c, cnt, tmpl, seed)
+        done += cnt
+        c += 1
+    return out

@@ -1,0 +1,165 @@
+/*
+ * enspara_hip.h -- C ABI of the MI355X (gfx950) k-centers / RMSD hot path.
+ *
+ * Drop-in boundary.  The reference (bowman-lab/enspara) has no FFI for this
+ * path: its plug-in point is a Python callable `metric(X, y) -> distances`
+ * (enspara/cluster/kcenters.py:132-137, resolved from the string 'rmsd' to
+ * mdtraj.rmsd at enspara/cluster/util.py:289-291), driven by pure-Python /
+ * numpy loops.  This header is the binding a maintainer would add underneath
+ * those loops (INTEGRATION.md shows the ctypes stub).  Each entry point cites
+ * the reference code it replaces.  Paths are relative to /root/reference.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative EK_E* code otherwise;
+ *     ek_last_error() returns a thread-local human readable message;
+ *   - plain pointers and sizes only; "host" pointers are ordinary memory,
+ *     "dev" pointers are HIP device memory of the context's device;
+ *   - a context owns one shard of frames resident in HBM, its k-centers state
+ *     (float32 distance and int32 assignment per frame) and one HIP stream;
+ *     all work is enqueued on that stream; functions that return data to host
+ *     memory synchronise the stream, the others do not;
+ *   - a context is not thread-safe; different contexts are independent.
+ *
+ * Data layout in HBM: centred coordinates in tiles of
+ * EK_TILE frames, frame-minor: element (frame f, atom a, axis k) lives at
+ * float index ((f / EK_TILE) * 3A + 3a + k) * EK_TILE + f % EK_TILE.
+ */
+#ifndef ENSPARA_HIP_H
+#define ENSPARA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EK_ABI_VERSION 1
+#define EK_TILE 256
+
+#define EK_OK 0
+#define EK_EARG (-1)     /* bad argument */
+#define EK_EHIP (-2)     /* HIP runtime error (message has the hipError_t) */
+#define EK_ESTATE (-3)   /* call sequence error (e.g. frames not loaded) */
+#define EK_ENOMEM (-4)
+
+typedef struct ek_ctx ek_ctx;
+
+int ek_abi_version(void);
+const char *ek_last_error(void);
+/* number of visible HIP devices, or a negative error */
+int ek_device_count(void);
+
+/* ---- context ----------------------------------------------------------- */
+/* n_frames frames of n_atoms atoms will live on `device`.  `global_offset`
+ * is the index of this shard's first frame in the whole data set (0 on one
+ * GPU); candidate records carry global indices.  `stream` is a hipStream_t to
+ * enqueue on (e.g. torch.cuda.current_stream().cuda_stream) or NULL to let
+ * the context create its own. */
+int ek_ctx_create(int device, int64_t n_frames, int32_t n_atoms,
+                  int64_t global_offset, void *stream, ek_ctx **out);
+int ek_ctx_destroy(ek_ctx *ctx);
+int ek_ctx_sync(ek_ctx *ctx);
+/* the hipStream_t the context enqueues on */
+void *ek_ctx_stream(ek_ctx *ctx);
+
+/* ---- loading frames ---------------------------------------------------- */
+/* Replaces the per-call centring mdtraj.rmsd does (precentered=False) and
+ * the md.Trajectory.center_coordinates() enspara does once before
+ * reassignment (enspara/cluster/util.py:624-629).
+ * xyz: float32 [count][n_atoms][3] (the md.Trajectory.xyz layout,
+ * enspara/util/load.py:211-216), host or device memory.  Frames
+ * [first, first+count) of the shard are centred (float64 mean), their traces
+ * computed, and stored frame-minor.  `first` must be a multiple of EK_TILE
+ * unless it is 0. */
+int ek_load_frames(ek_ctx *ctx, const float *xyz, int64_t first,
+                   int64_t count, int src_is_device);
+
+/* ---- metric parity: one center vs all frames --------------------------- */
+/* Replaces `distance_method(traj, new_center)` (kcenters.py:298,
+ * kmedoids.py:637) for metric 'rmsd'.  The center is either frame
+ * `frame_index` of this shard (>= 0) or, if frame_index < 0, the float32
+ * [n_atoms][3] host coordinates `center_xyz` (centred here).  Writes float32
+ * [n_frames] RMSDs to out_host.  Does not touch the k-centers state. */
+int ek_rmsd_to_center(ek_ctx *ctx, int64_t frame_index,
+                      const float *center_xyz, float *out_host);
+
+/* ---- k-centers state ---------------------------------------------------- */
+/* kcenters.py:198-199: assignments = -1, distances = +inf */
+int ek_state_reset(ek_ctx *ctx);
+/* float32 distances / int32 assignments, [n_frames] each, host memory */
+int ek_state_download(ek_ctx *ctx, float *dist_host, int32_t *assign_host);
+int ek_state_upload(ek_ctx *ctx, const float *dist_host,
+                    const int32_t *assign_host);
+
+/* ---- candidate records --------------------------------------------------
+ * A record describes a shard's farthest frame: what one rank contributes to
+ * the exchange of kcenters.py:332-348 (two allgathers + Bcast of the frame)
+ * folded into one message.  Layout (little endian):
+ *   float  maxdist;  int32 valid;  int64 global_index;  double trace;
+ *   int64  reserved;  float centred_xyz[3 * n_atoms];   padded to 16 bytes.
+ */
+size_t ek_record_bytes(int32_t n_atoms);
+/* Reduce the shard's distances to (max, first index) -- np.argmax semantics,
+ * kcenters.py:282 -- gather that frame, write the record to rec_dev (device
+ * memory, ek_record_bytes long; NULL = the context's own slot). */
+int ek_local_candidate(ek_ctx *ctx, void *rec_dev);
+/* device address of the context's own record slot */
+void *ek_own_record(ek_ctx *ctx);
+
+/* One k-centers iteration on this shard (kcenters.py:243-311; the MPI
+ * variant :314-378): pick the winning record among n_recs contiguous records
+ * at recs_dev (largest maxdist, lowest position on ties = lowest rank,
+ * kcenters.py:337); if winner.maxdist <= dist_cutoff (stop rule,
+ * kcenters.py:217) do nothing; otherwise distance pass against the winner's
+ * frame, strict-< update of distances/assignments with `label`
+ * (kcenters.py:304-306), history[label] = winner, then refresh the context's
+ * own record (as ek_local_candidate(ctx, own_rec_out)).  recs_dev == NULL
+ * means "the context's own record" (single shard).  own_rec_out == NULL means
+ * the context's own slot.  Entirely asynchronous. */
+int ek_kcenters_step(ek_ctx *ctx, const void *recs_dev, int32_t n_recs,
+                     int32_t label, double dist_cutoff, void *own_rec_out);
+
+/* Single-shard driver: the whole loop of kcenters.py:217-231 on the device.
+ * Starts at label `first_label`, adds at most `max_new` centers, stops early
+ * when the maximum distance is <= dist_cutoff.  Returns the number of centers
+ * added in *n_added, their frame indices in center_index_out[0..n_added) and
+ * the distance each had to its nearest earlier center in
+ * center_dist_out[0..n_added) (either may be NULL).  *final_maxdist receives
+ * distances.max() after the last update (kcenters.py:226). */
+int ek_kcenters_run(ek_ctx *ctx, int32_t first_label, int32_t max_new,
+                    double dist_cutoff, int32_t *n_added,
+                    int64_t *center_index_out, float *center_dist_out,
+                    float *final_maxdist);
+
+/* history written by ek_kcenters_step: for labels [first, first+count) the
+ * global frame index and pre-update distance of each accepted center;
+ * *n_done = 1 + the highest label accepted so far (0 if none). */
+int ek_history_download(ek_ctx *ctx, int32_t first, int32_t count,
+                        int64_t *center_index_out, float *center_dist_out,
+                        int32_t *n_done);
+int ek_history_reset(ek_ctx *ctx);
+
+/* ---- nearest-center assignment ----------------------------------------- */
+/* Replaces assign_to_nearest_center (enspara/cluster/util.py:159-205,
+ * center-major branch :199-203; strict <, lowest center index wins ties,
+ * assignments start at 0) for metric 'rmsd': centers_xyz is float32
+ * [n_centers][n_atoms][3] host memory.  Overwrites the context's k-centers
+ * state with the result (so predict / warm start / reassign read it back
+ * with ek_state_download). */
+int ek_assign_nearest(ek_ctx *ctx, const float *centers_xyz,
+                      int32_t n_centers);
+
+/* ---- tuning knobs (benchmarks only) -------------------------------------- */
+/* frames per lane of the distance kernel: 1, 2 or 4; 0 = choose from the
+ * shard size */
+int ek_set_frames_per_lane(ek_ctx *ctx, int fpl);
+/* time of the last ek_kcenters_run loop measured with HIP events on the
+ * context's stream, milliseconds, and the number of distance-kernel launches
+ * it covered */
+int ek_last_run_timing(ek_ctx *ctx, float *ms, int32_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ENSPARA_HIP_H */

@@ -1,0 +1,446 @@
+/*
+ * oracle/qcp_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement of the arithmetic on enspara's clustering hot path: the
+ * minimal-RMSD-after-superposition metric that `enspara.cluster.util.
+ * _get_distance_method('rmsd')` binds (reference enspara/cluster/util.py:289-291,
+ * call sites kcenters.py:298, util.py:195-203, kmedoids.py:637,666), plus the
+ * strict-< nearest-center update of kcenters.py:304-306 / util.py:199-203 and
+ * the first-index arg-max of kcenters.py:282.
+ *
+ * The RMSD arithmetic itself lives in a third-party dependency that is NOT
+ * under /root/reference: mdtraj (pyproject.toml:41 `mdtraj>=1.7`, unpinned, no
+ * lock file).  This file restates the *published* algorithm mdtraj implements
+ * (Theobald, Acta Cryst. A61:478 (2005); Liu, Agrafiotis & Theobald,
+ * J. Comput. Chem. 31:1561 (2010)): centre both structures, accumulate the
+ * 3x3 inner-product matrix in float32, solve the characteristic quartic of the
+ * 4x4 key matrix for its largest root with Newton's method in float64 starting
+ * from (G_x+G_y)/2, msd = (G_x+G_y-2*lambda)/N.
+ *
+ * Pinning: see oracle/README.md.  The restatement is checked against
+ *   (1) an independent float64 SVD/Kabsch implementation (tests/test_oracle.py),
+ *   (2) the reference's own mdtraj-produced known-answer statistics on
+ *       enspara/test/data/frame0.xtc (test_cluster.py:209-218, :231-238),
+ *       through the XTC decoder in oracle/xtc.py.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library.  The product (enspara_amd/) never does.
+ *
+ * Numerical contract (shared bit-for-bit with the HIP kernels under enspara_amd/csrc):
+ *   - centring: per-frame mean in float64 by sequential addition in atom
+ *     order, subtraction in float64, result rounded to float32;
+ *   - trace G: g_k = sum_a c_ak*c_ak for k = x, y, z, each accumulated in
+ *     float32 with one fused multiply-add per atom, sequentially in atom order
+ *     (bit-identical to the diagonal of S when a frame is compared with
+ *     itself, so rmsd(x, x) cancels to ~1e-8 instead of ~1e-4);
+ *     G = ((double)g_x + (double)g_y) + (double)g_z, stored as float64;
+ *   - S_ij = sum_a x_ai * y_aj accumulated in float32 with one fused
+ *     multiply-add per term, sequentially in atom order (x = frame, y = center);
+ *   - quartic coefficients and Newton iteration in float64, no contraction
+ *     (build with -ffp-contract=off), explicit fma() only where written;
+ *   - rmsd = sqrtf((float)max(0, msd)).
+ */
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define EKO_TILE 256 /* frames per tile of the frame-minor layout */
+#define EKO_EVALPREC 1e-11
+#define EKO_MAXIT 50
+
+int eko_abi_version(void) { return 1; }
+
+int eko_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* ---- msd from the accumulated 3x3 matrix and the two traces -------------- */
+double eko_msd_from_S(const float S[9], double Gx, double Gy, int n_atoms)
+{
+    const double Sxx = S[0], Sxy = S[1], Sxz = S[2];
+    const double Syx = S[3], Syy = S[4], Syz = S[5];
+    const double Szx = S[6], Szy = S[7], Szz = S[8];
+
+    /* C2 = -2 * sum S_ij^2 */
+    double q = Sxx * Sxx;
+    q = q + Sxy * Sxy;
+    q = q + Sxz * Sxz;
+    q = q + Syx * Syx;
+    q = q + Syy * Syy;
+    q = q + Syz * Syz;
+    q = q + Szx * Szx;
+    q = q + Szy * Szy;
+    q = q + Szz * Szz;
+    const double C2 = -2.0 * q;
+
+    /* C1 = -8 * det(S) */
+    const double m0 = Syy * Szz - Syz * Szy;
+    const double m1 = Syx * Szz - Syz * Szx;
+    const double m2 = Syx * Szy - Syy * Szx;
+    const double detS = (Sxx * m0 - Sxy * m1) + Sxz * m2;
+    const double C1 = -8.0 * detS;
+
+    /* C0 = det(K), K the symmetric traceless 4x4 key matrix */
+    const double k00 = (Sxx + Syy) + Szz;
+    const double k01 = Syz - Szy;
+    const double k02 = Szx - Sxz;
+    const double k03 = Sxy - Syx;
+    const double k11 = (Sxx - Syy) - Szz;
+    const double k12 = Sxy + Syx;
+    const double k13 = Szx + Sxz;
+    const double k22 = (Syy - Sxx) - Szz;
+    const double k23 = Syz + Szy;
+    const double k33 = (Szz - Sxx) - Syy;
+
+    const double s0 = k00 * k11 - k01 * k01;
+    const double s1 = k00 * k12 - k01 * k02;
+    const double s2 = k00 * k13 - k01 * k03;
+    const double s3 = k01 * k12 - k11 * k02;
+    const double s4 = k01 * k13 - k11 * k03;
+    const double s5 = k02 * k13 - k12 * k03;
+    const double c5 = k22 * k33 - k23 * k23;
+    const double c4 = k12 * k33 - k13 * k23;
+    const double c3 = k12 * k23 - k13 * k22;
+    const double c2 = k02 * k33 - k03 * k23;
+    const double c1 = k02 * k23 - k03 * k22;
+    const double c0 = k02 * k13 - k03 * k12;
+    double C0 = s0 * c5 - s1 * c4;
+    C0 = C0 + s2 * c3;
+    C0 = C0 + s3 * c2;
+    C0 = C0 - s4 * c1;
+    C0 = C0 + s5 * c0;
+
+    const double Gsum = Gx + Gy;
+    double lam = 0.5 * Gsum;
+    for (int it = 0; it < EKO_MAXIT; ++it) {
+        const double x2 = lam * lam;
+        const double b = (x2 + C2) * lam;
+        const double a = b + C1;
+        const double num = fma(a, lam, C0);
+        const double den = fma(2.0 * x2, lam, b + a);
+        if (den == 0.0)
+            break;
+        const double delta = num / den;
+        lam = lam - delta;
+        if (fabs(delta) < fabs(EKO_EVALPREC * lam))
+            break;
+    }
+    double msd = (Gsum - 2.0 * lam) / (double)n_atoms;
+    if (!(msd > 0.0))
+        msd = 0.0;
+    return msd;
+}
+
+static inline float eko_rmsd_from_S(const float S[9], double Gx, double Gy, int A)
+{
+    return sqrtf((float)eko_msd_from_S(S, Gx, Gy, A));
+}
+
+/* ---- centring + trace (AoS in, AoS out) --------------------------------- */
+/* xyz: [n][A][3] float32.  out: same shape, centred.  G: [n] traces. */
+void eko_center_and_trace(const float *xyz, int64_t n, int A, float *out,
+                          double *G)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t f = 0; f < n; ++f) {
+        const float *p = xyz + (size_t)f * A * 3;
+        float *o = out + (size_t)f * A * 3;
+        double sx = 0.0, sy = 0.0, sz = 0.0;
+        for (int a = 0; a < A; ++a) {
+            sx = sx + (double)p[3 * a + 0];
+            sy = sy + (double)p[3 * a + 1];
+            sz = sz + (double)p[3 * a + 2];
+        }
+        const double mx = sx / (double)A, my = sy / (double)A,
+                     mz = sz / (double)A;
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+        for (int a = 0; a < A; ++a) {
+            const float cx = (float)((double)p[3 * a + 0] - mx);
+            const float cy = (float)((double)p[3 * a + 1] - my);
+            const float cz = (float)((double)p[3 * a + 2] - mz);
+            o[3 * a + 0] = cx;
+            o[3 * a + 1] = cy;
+            o[3 * a + 2] = cz;
+            gx = fmaf(cx, cx, gx);
+            gy = fmaf(cy, cy, gy);
+            gz = fmaf(cz, cz, gz);
+        }
+        G[f] = ((double)gx + (double)gy) + (double)gz;
+    }
+}
+
+/* ---- scalar one-center-vs-all RMSD on centred AoS frames ---------------- */
+static inline void eko_accum_S(const float *x, const float *y, int A,
+                               float S[9])
+{
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f,
+          s6 = 0.f, s7 = 0.f, s8 = 0.f;
+    for (int a = 0; a < A; ++a) {
+        const float xx = x[3 * a + 0], xy = x[3 * a + 1], xz = x[3 * a + 2];
+        const float yx = y[3 * a + 0], yy = y[3 * a + 1], yz = y[3 * a + 2];
+        s0 = fmaf(xx, yx, s0);
+        s1 = fmaf(xx, yy, s1);
+        s2 = fmaf(xx, yz, s2);
+        s3 = fmaf(xy, yx, s3);
+        s4 = fmaf(xy, yy, s4);
+        s5 = fmaf(xy, yz, s5);
+        s6 = fmaf(xz, yx, s6);
+        s7 = fmaf(xz, yy, s7);
+        s8 = fmaf(xz, yz, s8);
+    }
+    S[0] = s0; S[1] = s1; S[2] = s2;
+    S[3] = s3; S[4] = s4; S[5] = s5;
+    S[6] = s6; S[7] = s7; S[8] = s8;
+}
+
+/* frames: centred [n][A][3]; G: [n]; center: centred [A][3]; Gc its trace. */
+void eko_rmsd_one_to_many(const float *frames, const double *G, int64_t n,
+                          int A, const float *center, double Gc, float *out)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t f = 0; f < n; ++f) {
+        float S[9];
+        eko_accum_S(frames + (size_t)f * A * 3, center, A, S);
+        out[f] = eko_rmsd_from_S(S, G[f], Gc, A);
+    }
+}
+
+/* 3x3 matrix only (for tests of the accumulation order) */
+void eko_S_one_to_many(const float *frames, int64_t n, int A,
+                       const float *center, float *S_out /* [n][9] */)
+{
+    for (int64_t f = 0; f < n; ++f)
+        eko_accum_S(frames + (size_t)f * A * 3, center, A, S_out + 9 * f);
+}
+
+/* ---- frame-minor tiled layout (the timed CPU baseline uses this) --------- */
+/* element (f, a, k) lives at ((f / TILE) * 3A + 3a + k) * TILE + f % TILE    */
+int64_t eko_tiled_floats(int64_t n, int A)
+{
+    const int64_t nt = (n + EKO_TILE - 1) / EKO_TILE;
+    return nt * 3 * (int64_t)A * EKO_TILE;
+}
+
+void eko_to_tiled(const float *centered, int64_t n, int A, float *tiled)
+{
+    const int64_t nt = (n + EKO_TILE - 1) / EKO_TILE;
+#pragma omp parallel for schedule(static)
+    for (int64_t t = 0; t < nt; ++t) {
+        float *tb = tiled + (size_t)t * 3 * A * EKO_TILE;
+        for (int r = 0; r < 3 * A; ++r)
+            for (int l = 0; l < EKO_TILE; ++l) {
+                const int64_t f = t * EKO_TILE + l;
+                tb[(size_t)r * EKO_TILE + l] =
+                    (f < n) ? centered[(size_t)f * 3 * A + r] : 0.f;
+            }
+    }
+}
+
+#define EKO_W 16 /* frames per SIMD strip of the vectorised baseline */
+
+/* one k-centers iteration (kcenters.py:298-306 + the arg-max of :282 for the
+ * next iteration): dist_new = rmsd(all frames, center); strict-< update of
+ * dist/assign with `label`; returns the first index of the maximum of the
+ * updated dist through *out_max / *out_argmax. */
+void eko_kcenters_step_tiled(const float *tiled, const double *G, int64_t n,
+                             int A, const float *center, double Gc, int32_t label,
+                             float *dist, int32_t *assign, float *out_max,
+                             int64_t *out_argmax)
+{
+    const int64_t nt = (n + EKO_TILE - 1) / EKO_TILE;
+    int nthreads = 1;
+#ifdef _OPENMP
+    nthreads = omp_get_max_threads();
+#endif
+    float *tmax = (float *)malloc(sizeof(float) * nthreads);
+    int64_t *targ = (int64_t *)malloc(sizeof(int64_t) * nthreads);
+    for (int i = 0; i < nthreads; ++i) {
+        tmax[i] = -INFINITY;
+        targ[i] = -1;
+    }
+#pragma omp parallel
+    {
+        int tid = 0;
+#ifdef _OPENMP
+        tid = omp_get_thread_num();
+#endif
+        float bestv = -INFINITY;
+        int64_t besti = -1;
+#pragma omp for schedule(static)
+        for (int64_t t = 0; t < nt; ++t) {
+            const float *tb = tiled + (size_t)t * 3 * A * EKO_TILE;
+            for (int l0 = 0; l0 < EKO_TILE; l0 += EKO_W) {
+                float s[9][EKO_W];
+                for (int j = 0; j < 9; ++j)
+                    for (int l = 0; l < EKO_W; ++l)
+                        s[j][l] = 0.f;
+                for (int a = 0; a < A; ++a) {
+                    const float *px = tb + (size_t)(3 * a + 0) * EKO_TILE + l0;
+                    const float *py = tb + (size_t)(3 * a + 1) * EKO_TILE + l0;
+                    const float *pz = tb + (size_t)(3 * a + 2) * EKO_TILE + l0;
+                    const float cx = center[3 * a + 0], cy = center[3 * a + 1],
+                                cz = center[3 * a + 2];
+#pragma omp simd
+                    for (int l = 0; l < EKO_W; ++l) {
+                        const float x = px[l], y = py[l], z = pz[l];
+                        s[0][l] = fmaf(x, cx, s[0][l]);
+                        s[1][l] = fmaf(x, cy, s[1][l]);
+                        s[2][l] = fmaf(x, cz, s[2][l]);
+                        s[3][l] = fmaf(y, cx, s[3][l]);
+                        s[4][l] = fmaf(y, cy, s[4][l]);
+                        s[5][l] = fmaf(y, cz, s[5][l]);
+                        s[6][l] = fmaf(z, cx, s[6][l]);
+                        s[7][l] = fmaf(z, cy, s[7][l]);
+                        s[8][l] = fmaf(z, cz, s[8][l]);
+                    }
+                }
+                for (int l = 0; l < EKO_W; ++l) {
+                    const int64_t f = t * EKO_TILE + l0 + l;
+                    if (f >= n)
+                        break;
+                    float S[9];
+                    for (int j = 0; j < 9; ++j)
+                        S[j] = s[j][l];
+                    const float d = eko_rmsd_from_S(S, G[f], Gc, A);
+                    float cur = dist[f];
+                    if (d < cur) {
+                        cur = d;
+                        dist[f] = d;
+                        assign[f] = label;
+                    }
+                    if (cur > bestv || besti < 0) {
+                        bestv = cur;
+                        besti = f;
+                    }
+                }
+            }
+        }
+        tmax[tid] = bestv;
+        targ[tid] = besti;
+    }
+    /* static schedule => thread order is frame order: first max wins */
+    float bv = -INFINITY;
+    int64_t bi = -1;
+    for (int i = 0; i < nthreads; ++i) {
+        if (targ[i] < 0)
+            continue;
+        if (bi < 0 || tmax[i] > bv || (tmax[i] == bv && targ[i] < bi)) {
+            bv = tmax[i];
+            bi = targ[i];
+        }
+    }
+    *out_max = bv;
+    *out_argmax = bi;
+    free(tmax);
+    free(targ);
+}
+
+/* one-vs-all on the tiled layout, distances only (bitwise equal to
+ * eko_rmsd_one_to_many) */
+void eko_rmsd_one_to_many_tiled(const float *tiled, const double *G, int64_t n,
+                                int A, const float *center, double Gc,
+                                float *out)
+{
+    const int64_t nt = (n + EKO_TILE - 1) / EKO_TILE;
+#pragma omp parallel for schedule(static)
+    for (int64_t t = 0; t < nt; ++t) {
+        const float *tb = tiled + (size_t)t * 3 * A * EKO_TILE;
+        for (int l0 = 0; l0 < EKO_TILE; l0 += EKO_W) {
+            float s[9][EKO_W];
+            for (int j = 0; j < 9; ++j)
+                for (int l = 0; l < EKO_W; ++l)
+                    s[j][l] = 0.f;
+            for (int a = 0; a < A; ++a) {
+                const float *px = tb + (size_t)(3 * a + 0) * EKO_TILE + l0;
+                const float *py = tb + (size_t)(3 * a + 1) * EKO_TILE + l0;
+                const float *pz = tb + (size_t)(3 * a + 2) * EKO_TILE + l0;
+                const float cx = center[3 * a + 0], cy = center[3 * a + 1],
+                            cz = center[3 * a + 2];
+#pragma omp simd
+                for (int l = 0; l < EKO_W; ++l) {
+                    const float x = px[l], y = py[l], z = pz[l];
+                    s[0][l] = fmaf(x, cx, s[0][l]);
+                    s[1][l] = fmaf(x, cy, s[1][l]);
+                    s[2][l] = fmaf(x, cz, s[2][l]);
+                    s[3][l] = fmaf(y, cx, s[3][l]);
+                    s[4][l] = fmaf(y, cy, s[4][l]);
+                    s[5][l] = fmaf(y, cz, s[5][l]);
+                    s[6][l] = fmaf(z, cx, s[6][l]);
+                    s[7][l] = fmaf(z, cy, s[7][l]);
+                    s[8][l] = fmaf(z, cz, s[8][l]);
+                }
+            }
+            for (int l = 0; l < EKO_W; ++l) {
+                const int64_t f = t * EKO_TILE + l0 + l;
+                if (f >= n)
+                    break;
+                float S[9];
+                for (int j = 0; j < 9; ++j)
+                    S[j] = s[j][l];
+                out[f] = eko_rmsd_from_S(S, G[f], Gc, A);
+            }
+        }
+    }
+}
+
+/* ---- strict-< update and first-index arg-max on plain arrays ------------- */
+/* kcenters.py:304-306 / util.py:201-203 */
+void eko_min_update(const float *newd, int64_t n, int32_t label, float *dist,
+                    int32_t *assign)
+{
+    for (int64_t f = 0; f < n; ++f)
+        if (newd[f] < dist[f]) {
+            dist[f] = newd[f];
+            assign[f] = label;
+        }
+}
+
+/* np.argmax semantics on finite/inf data: first index of the maximum */
+int64_t eko_argmax_first(const float *v, int64_t n)
+{
+    if (n <= 0)
+        return -1;
+    int64_t bi = 0;
+    float bv = v[0];
+    for (int64_t i = 1; i < n; ++i)
+        if (v[i] > bv) {
+            bv = v[i];
+            bi = i;
+        }
+    return bi;
+}
+
+/* ---- assign_to_nearest_center, center-major branch (util.py:199-203) ----- */
+/* frames/G: centred AoS frames and traces; centers: centred [K][A][3], Gc[K] */
+void eko_assign_nearest(const float *frames, const double *G, int64_t n, int A,
+                        const float *centers, const double *Gc, int32_t K,
+                        int32_t *assign, float *dist)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t f = 0; f < n; ++f) {
+        const float *x = frames + (size_t)f * A * 3;
+        float best = INFINITY;
+        int32_t bi = 0; /* util.py:186 initialises assignments with zeros */
+        for (int32_t c = 0; c < K; ++c) {
+            float S[9];
+            eko_accum_S(x, centers + (size_t)c * A * 3, A, S);
+            const float d = eko_rmsd_from_S(S, G[f], Gc[c], A);
+            if (d < best) {
+                best = d;
+                bi = c;
+            }
+        }
+        assign[f] = bi;
+        dist[f] = best;
+    }
+}
