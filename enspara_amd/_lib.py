@@ -28,6 +28,7 @@ SYMBOLS = [
     "ek_history_download", "ek_history_reset",
     "ek_assign_nearest",
     "ek_set_frames_per_lane", "ek_last_run_timing",
+    "ek_timing_begin", "ek_timing_end",
 ]
 
 
@@ -89,6 +90,8 @@ def load():
     L.ek_assign_nearest.argtypes = [vp, f32p, i32]
     L.ek_set_frames_per_lane.argtypes = [vp, C.c_int]
     L.ek_last_run_timing.argtypes = [vp, f32p, i32p]
+    L.ek_timing_begin.argtypes = [vp, i32, i32]
+    L.ek_timing_end.argtypes = [vp, f32p, i32p]
     for name in SYMBOLS:
         getattr(L, name)
     _lib = L

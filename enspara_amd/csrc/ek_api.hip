@@ -69,6 +69,11 @@ struct ek_ctx {
     int32_t cen_cap = 0;
 
     int fpl = 0;                 // 0 = auto
+    // sampled per-launch timing of the distance kernel (bench only)
+    std::vector<hipEvent_t> samp_ev;
+    int samp_every = 0;
+    int samp_used = 0;
+    int64_t samp_count = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_ms = 0.f;
     int32_t last_launches = 0;
@@ -123,6 +128,8 @@ static int ek_free_all(ek_ctx *c)
     (void)hipFree(c->stage);
     (void)hipFree(c->cen_aos);
     (void)hipFree(c->cen_G);
+    for (hipEvent_t e : c->samp_ev)
+        (void)hipEventDestroy(e);
     if (c->ev0)
         (void)hipEventDestroy(c->ev0);
     if (c->ev1)
@@ -470,10 +477,19 @@ extern "C" int ek_kcenters_step(ek_ctx *c, const void *recs_dev, int32_t n_recs,
     unsigned char *own = own_rec_out ? (unsigned char *)own_rec_out : c->rec;
     const int fpl = ek_pick_fpl(c);
     if (c->n > 0) {
+        const bool sample =
+            c->samp_every > 0 && (c->samp_count++ % c->samp_every) == 0 &&
+            2 * (size_t)c->samp_used + 1 < c->samp_ev.size();
+        if (sample)
+            EK_HIP(hipEventRecord(c->samp_ev[2 * c->samp_used], c->stream));
         ek_launch_step(fpl, 0, c->tiles, c->G, c->dist, c->assign, c->scratch,
                        recs, n_recs, c->n, c->A, label, dist_cutoff,
                        c->blockmax, c->hist, c->ctl, c->stream);
         EK_CHECK_LAUNCH();
+        if (sample) {
+            EK_HIP(hipEventRecord(c->samp_ev[2 * c->samp_used + 1], c->stream));
+            c->samp_used++;
+        }
     }
     ek_launch_pick(c->n > 0 ? c->blockmax : nullptr,
                    ek_step_blocks(fpl, c->n), c->dist, c->tiles, c->G, c->n,
@@ -582,6 +598,45 @@ extern "C" int ek_kcenters_run(ek_ctx *c, int32_t first_label, int32_t max_new,
         if (rc)
             return rc;
     }
+    return EK_OK;
+}
+
+// ---- sampled timing of the distance kernel ---------------------------------------
+extern "C" int ek_timing_begin(ek_ctx *c, int32_t sample_every,
+                               int32_t max_samples)
+{
+    if (!c || sample_every < 1 || max_samples < 1)
+        return ek_fail(EK_EARG, "ek_timing_begin: bad argument");
+    EK_HIP(hipSetDevice(c->device));
+    while (c->samp_ev.size() < 2 * (size_t)max_samples) {
+        hipEvent_t e;
+        EK_HIP(hipEventCreate(&e));
+        c->samp_ev.push_back(e);
+    }
+    c->samp_every = sample_every;
+    c->samp_used = 0;
+    c->samp_count = 0;
+    return EK_OK;
+}
+
+extern "C" int ek_timing_end(ek_ctx *c, float *avg_ms, int32_t *n_samples)
+{
+    if (!c)
+        return ek_fail(EK_EARG, "NULL context");
+    EK_HIP(hipSetDevice(c->device));
+    EK_HIP(hipStreamSynchronize(c->stream));
+    double sum = 0.0;
+    for (int i = 0; i < c->samp_used; ++i) {
+        float ms = 0.f;
+        EK_HIP(hipEventElapsedTime(&ms, c->samp_ev[2 * i],
+                                   c->samp_ev[2 * i + 1]));
+        sum += ms;
+    }
+    if (avg_ms)
+        *avg_ms = c->samp_used ? (float)(sum / c->samp_used) : 0.f;
+    if (n_samples)
+        *n_samples = c->samp_used;
+    c->samp_every = 0;
     return EK_OK;
 }
 

@@ -193,3 +193,14 @@ class FrameStore:
         _lib.check(self.lib.ek_last_run_timing(self._h, C.byref(ms),
                                                C.byref(k)))
         return ms.value, k.value
+
+    def timing_begin(self, sample_every=32, max_samples=512):
+        _lib.check(self.lib.ek_timing_begin(self._h, int(sample_every),
+                                            int(max_samples)))
+
+    def timing_end(self):
+        """-> (mean ms per sampled distance-kernel launch, samples)"""
+        ms = C.c_float()
+        k = C.c_int32()
+        _lib.check(self.lib.ek_timing_end(self._h, C.byref(ms), C.byref(k)))
+        return ms.value, k.value

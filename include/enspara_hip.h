@@ -159,6 +159,14 @@ int ek_set_frames_per_lane(ek_ctx *ctx, int fpl);
  * it covered */
 int ek_last_run_timing(ek_ctx *ctx, float *ms, int32_t *launches);
 
+/* Sampled timing of the distance kernel alone: after ek_timing_begin, every
+ * `sample_every`-th ek_kcenters_step brackets its distance-kernel launch with
+ * a HIP event pair on the context's stream (at most max_samples pairs).
+ * ek_timing_end synchronises and returns the mean elapsed time per sampled
+ * launch in milliseconds. */
+int ek_timing_begin(ek_ctx *ctx, int32_t sample_every, int32_t max_samples);
+int ek_timing_end(ek_ctx *ctx, float *avg_ms, int32_t *n_samples);
+
 #ifdef __cplusplus
 }
 #endif
