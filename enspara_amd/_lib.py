@@ -27,6 +27,8 @@ SYMBOLS = [
     "ek_kcenters_step", "ek_kcenters_run",
     "ek_history_download", "ek_history_reset",
     "ek_assign_nearest",
+    "ek_pam_begin", "ek_pam_count_members", "ek_pam_select_member",
+    "ek_pam_propose", "ek_pam_commit",
     "ek_set_frames_per_lane", "ek_last_run_timing",
     "ek_timing_begin", "ek_timing_end",
 ]
@@ -88,6 +90,12 @@ def load():
     L.ek_history_download.argtypes = [vp, i32, i32, i64p, f32p, i32p]
     L.ek_history_reset.argtypes = [vp]
     L.ek_assign_nearest.argtypes = [vp, f32p, i32]
+    f64p = C.POINTER(C.c_double)
+    L.ek_pam_begin.argtypes = [vp, i64p, i32]
+    L.ek_pam_count_members.argtypes = [vp, i32, i64p]
+    L.ek_pam_select_member.argtypes = [vp, i32, i64, i64p]
+    L.ek_pam_propose.argtypes = [vp, i32, i64, f64p, f64p, i64p]
+    L.ek_pam_commit.argtypes = [vp, C.c_int]
     L.ek_set_frames_per_lane.argtypes = [vp, C.c_int]
     L.ek_last_run_timing.argtypes = [vp, f32p, i32p]
     L.ek_timing_begin.argtypes = [vp, i32, i32]

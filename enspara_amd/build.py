@@ -15,7 +15,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_build")
 OUT = os.path.join(HERE, "libenspara_hip.so")
-SOURCES = ["ek_prepare.hip", "ek_kcenters.hip", "ek_assign.hip", "ek_api.hip"]
+SOURCES = ["ek_prepare.hip", "ek_kcenters.hip", "ek_assign.hip", "ek_pam.hip",
+           "ek_api.hip"]
 HEADERS = ["ek_common.h", "ek_qcp.h", os.path.join("..", "..", "include",
                                                    "enspara_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

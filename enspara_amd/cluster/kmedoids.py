@@ -1,0 +1,255 @@
+"""k-medoids refinement by Partitioning Around Medoids, device resident.
+
+Surface follows the reference's enspara/cluster/kmedoids.py (KMedoids :28-105,
+kmedoids() :108-202, _kmedoids_iterations :410-476, _kmedoids_pam_update
+:520-699).  For metric 'rmsd' every O(n) pass of a proposal runs on the GPU
+(csrc/ek_pam.hip); the host keeps the random stream and the accept test so
+that proposals are drawn exactly as the reference draws them.  A callable
+metric runs the reference-shaped host loop.
+"""
+import logging
+import time
+
+import numpy as np
+
+from ..device import FrameStore, as_xyz
+from ..exception import DataInvalid, ImproperlyConfigured
+from . import util
+from .kcenters import BaseEstimator, ClusterMixin, check_random_state, _frame_of
+
+logger = logging.getLogger(__name__)
+
+
+class KMedoids(BaseEstimator, ClusterMixin, util.MolecularClusterMixin):
+    """reference kmedoids.py:28-105"""
+
+    def __init__(self, metric, n_clusters=None, n_iters=5, args=None,
+                 lengths=None, device=0):
+        self.metric = util._get_distance_method(metric)
+        self.n_clusters = n_clusters
+        self.n_iters = n_iters
+        self.args = args
+        self.lengths = lengths
+        self.device = device
+
+    def fit(self, X, assignments=None, distances=None,
+            cluster_center_inds=None, X_lengths=None, args=None):
+        t0 = time.perf_counter()
+        self.result_ = kmedoids(
+            X, distance_method=self.metric, n_clusters=self.n_clusters,
+            n_iters=self.n_iters, assignments=assignments,
+            distances=distances, cluster_center_inds=cluster_center_inds,
+            X_lengths=X_lengths, device=self.device)
+        self.runtime_ = time.perf_counter() - t0
+        return self
+
+
+def _resolve_inputs(X, distance_method, n_clusters, assignments, distances,
+                    cluster_center_inds, X_lengths, random_state):
+    """reference _kmedoids_inputs_tree, kmedoids.py:285-363"""
+    rng = np.random.default_rng(seed=random_state)
+    if (assignments is None) != (distances is None):
+        raise ImproperlyConfigured(
+            "Assignments and distances need to both be supplied, "
+            "or neither supplied.")
+    n = len(X._data) if hasattr(X, "_data") else len(X)
+    if cluster_center_inds is None:
+        if assignments is not None:
+            cluster_center_inds = util.find_cluster_centers(assignments,
+                                                            distances)
+        else:
+            cluster_center_inds = np.array([])
+            while len(np.unique(cluster_center_inds)) < n_clusters:
+                cluster_center_inds = rng.integers(0, n, n_clusters)
+    elif hasattr(cluster_center_inds[0], "__len__"):
+        cluster_center_inds = [
+            sum(X_lengths[:pair[0]]) + pair[1] for pair in cluster_center_inds]
+    return cluster_center_inds
+
+
+def kmedoids(X, distance_method, n_clusters=None, n_iters=5, assignments=None,
+             distances=None, cluster_center_inds=None, proposals=None,
+             X_lengths=None, args=None, lengths=None, random_state=None,
+             device=0):
+    """reference kmedoids.py:108-202 (single process)."""
+    if cluster_center_inds is not None:
+        if hasattr(cluster_center_inds[0], "__len__") and X_lengths is None:
+            raise ImproperlyConfigured(
+                "If cluster_center_inds is given as [[global_traj_id, "
+                "frame_id],...] then X_lengths also needs to be supplied")
+    if cluster_center_inds is None and n_clusters is None:
+        if assignments is None and distances is None:
+            raise ImproperlyConfigured(
+                "Must provide n_clusters or cluster_center_inds or "
+                " (assignments and distances) for KMedoids")
+    distance_method = util._get_distance_method(distance_method)
+    inds = _resolve_inputs(X, distance_method, n_clusters, assignments,
+                           distances, cluster_center_inds, X_lengths,
+                           random_state)
+    inds = [int(i) for i in inds]
+
+    if util.is_device_rmsd(distance_method):
+        xyz = as_xyz(X)
+        with FrameStore.from_array(xyz, device=device) as store:
+            if assignments is None:
+                store.assign_nearest(xyz[inds])              # :360-361
+            else:
+                store.upload_state(distances, assignments)
+            d0, _ = store.download_state()
+            # the medoids must sit at (numerically) zero distance (:197)
+            assert np.all(d0[inds] < 0.001)
+            return _kmedoids_iterations_device(
+                X, store, n_iters, inds, proposals, random_state)
+
+    if assignments is None:
+        assignments, distances = util.assign_to_nearest_center(
+            X, X[inds], distance_method)
+    assert np.all(np.asarray(distances)[inds] < 0.001)
+    return _kmedoids_iterations(X, distance_method, n_iters, inds,
+                                assignments, distances, proposals=proposals,
+                                random_state=random_state)
+
+
+def _kmedoids_iterations(X, distance_method, n_iters, cluster_center_inds,
+                         assignments, distances, proposals=None, args=None,
+                         lengths=None, random_state=None, store=None):
+    """reference kmedoids.py:410-476.  With metric 'rmsd' and a FrameStore
+    holding X and the current state, runs on the device."""
+    distance_method = util._get_distance_method(distance_method)
+    if util.is_device_rmsd(distance_method):
+        own = store is None
+        if own:
+            store = FrameStore.from_array(as_xyz(X))
+            store.upload_state(distances, assignments)
+        try:
+            return _kmedoids_iterations_device(
+                X, store, n_iters, cluster_center_inds, proposals,
+                random_state)
+        finally:
+            if own:
+                store.close()
+    result = None
+    for i in range(n_iters):
+        cluster_center_inds, distances, assignments, centers = \
+            _kmedoids_pam_update(X, distance_method, cluster_center_inds,
+                                 assignments, distances, proposals=proposals,
+                                 random_state=random_state)
+        result = util.ClusterResult(center_indices=cluster_center_inds,
+                                    assignments=assignments,
+                                    distances=distances, centers=centers)
+        logger.info("KMedoids update %s", i)
+    return result
+
+
+def _check_proposals(proposals, medoid_inds):
+    if proposals is None:
+        return
+    if len(proposals) != len(medoid_inds):
+        raise DataInvalid(
+            "Length of 'proposals' didn't match length of 'medoid_inds' "
+            "({} != {}).".format(len(proposals), len(medoid_inds)))
+    if hasattr(proposals[0], "__len__") != hasattr(medoid_inds[0], "__len__"):
+        raise DataInvalid(
+            "Depth of 'proposals' didn't match 'medoid_inds' "
+            "(proposals[0] == {}, whereas medoid_inds[0] == {})".format(
+                proposals[0], medoid_inds[0]))
+
+
+def _pam_sweep_device(store, medoid_inds, proposals, random_state):
+    """One sweep of kmedoids.py:575-699 against device-resident state."""
+    random_state = check_random_state(random_state)          # :579
+    _check_proposals(proposals, medoid_inds)
+    store.pam_begin(medoid_inds)
+    acceptances = 0
+    old_cost = new_cost = float("nan")
+    for cid in range(len(medoid_inds)):
+        if proposals is None:
+            m = store.pam_count_members(cid)                 # :611
+            # RandomState.choice(state_inds) == state_inds[choice(len)]
+            # (raises ValueError on an empty cluster, like the reference)
+            j = random_state.choice(m)                       # :514
+            prop = store.pam_select_member(cid, j)
+        else:
+            prop = int(proposals[cid])
+        old_cost, new_cost, n_amb = store.pam_propose(cid, prop)
+        accept = new_cost < old_cost                         # :683
+        store.pam_commit(accept)
+        if accept:
+            medoid_inds[cid] = prop
+            acceptances += 1
+        logger.debug("%s proposed center for k=%s: cost %.5f -> %.5f "
+                     "(%d ambiguous).", "Accepted" if accept else "Rejected",
+                     cid, old_cost, new_cost, n_amb)
+    logger.info("Kmedoid sweep reduced cost to %.7f (%.2f%% acceptance)",
+                min(old_cost, new_cost),
+                acceptances / len(medoid_inds) * 100)
+    return medoid_inds
+
+
+def _kmedoids_iterations_device(X, store, n_iters, cluster_center_inds,
+                                proposals, random_state):
+    medoid_inds = [int(i) for i in cluster_center_inds]
+    for i in range(n_iters):
+        medoid_inds = _pam_sweep_device(store, medoid_inds, proposals,
+                                        random_state)
+        logger.info("KMedoids update %s", i)
+    d, a = store.download_state()
+    return util.ClusterResult(
+        center_indices=medoid_inds, assignments=a.astype(np.int64),
+        distances=d.astype(np.float64),
+        centers=[_frame_of(X, i) for i in medoid_inds])
+
+
+def _msq(x):
+    """reference kmedoids.py:478-479 at one process"""
+    return np.square(x).mean()
+
+
+def _kmedoids_pam_update(X, metric, medoid_inds, assignments, distances,
+                         proposals=None, cost=_msq, random_state=None):
+    """One PAM sweep for a callable metric (reference kmedoids.py:520-699,
+    single-process branch).  For metric 'rmsd' the sweep runs on the device
+    and this wrapper moves the state there and back."""
+    metric = util._get_distance_method(metric)
+    assert np.issubdtype(type(assignments[0]), np.integer)
+    assert len(assignments) == len(X) and len(distances) == len(X)
+    if util.is_device_rmsd(metric):
+        with FrameStore.from_array(as_xyz(X)) as store:
+            store.upload_state(distances, assignments)
+            inds = _pam_sweep_device(store, [int(i) for i in medoid_inds],
+                                     proposals, random_state)
+            d, a = store.download_state()
+        return (inds, d.astype(np.float64), a.astype(np.int64),
+                [_frame_of(X, i) for i in inds])
+
+    random_state = check_random_state(random_state)
+    _check_proposals(proposals, medoid_inds)
+    medoid_coords = [X[i] for i in medoid_inds]
+    for cid in range(len(medoid_inds)):
+        state_inds = np.where(assignments == cid)[0]
+        if proposals is None:
+            prop = random_state.choice(state_inds)
+        else:
+            prop = proposals[cid]
+        proposed_center = X[prop]
+        nd = metric(X, proposed_center)
+        new_dist = np.zeros_like(distances) - 1
+        new_assig = np.zeros_like(assignments) - 1
+        down = distances > nd
+        new_assig[down] = cid
+        new_dist[down] = nd[down]
+        up_other = (distances <= nd) & (assignments != cid)
+        new_assig[up_other] = assignments[up_other]
+        new_dist[up_other] = distances[up_other]
+        up_this = (distances <= nd) & (assignments == cid)
+        trial = list(medoid_coords)
+        trial[cid] = proposed_center
+        amb_a, amb_d = util.assign_to_nearest_center(X[up_this], trial, metric)
+        new_assig[up_this] = amb_a
+        new_dist[up_this] = amb_d
+        assert np.all(new_assig >= 0) and np.all(new_dist >= 0)
+        if cost(new_dist) < cost(distances):
+            distances, assignments = new_dist, new_assig
+            medoid_coords = trial
+            medoid_inds[cid] = prop
+    return medoid_inds, distances, assignments, medoid_coords

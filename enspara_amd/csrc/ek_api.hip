@@ -68,6 +68,24 @@ struct ek_ctx {
     double *cen_G = nullptr;
     int32_t cen_cap = 0;
 
+    // PAM working set (allocated by ek_pam_begin)
+    float *ndist = nullptr;
+    int32_t *nassign = nullptr;
+    uint32_t *amb = nullptr;
+    unsigned long long *amb_best = nullptr;
+    unsigned int *amb_count = nullptr;
+    int32_t *blockcnt = nullptr;
+    int64_t *scan = nullptr;
+    int64_t *sel = nullptr;          // [0] member count, [1] selected frame
+    double *sq_part = nullptr;
+    double *sq_out = nullptr;
+    float *med_aos = nullptr;        // [K+1][3A]; row K = saved row
+    double *med_G = nullptr;
+    int64_t *med_idx = nullptr;      // [K+1] device copy of medoid frames
+    int32_t med_K = 0, med_cap = 0;
+    int32_t pam_cid = -1;            // proposal pending commit
+    int64_t pam_frame = -1;
+
     int fpl = 0;                 // 0 = auto
     // sampled per-launch timing of the distance kernel (bench only)
     std::vector<hipEvent_t> samp_ev;
@@ -128,6 +146,19 @@ static int ek_free_all(ek_ctx *c)
     (void)hipFree(c->stage);
     (void)hipFree(c->cen_aos);
     (void)hipFree(c->cen_G);
+    (void)hipFree(c->ndist);
+    (void)hipFree(c->nassign);
+    (void)hipFree(c->amb);
+    (void)hipFree(c->amb_best);
+    (void)hipFree(c->amb_count);
+    (void)hipFree(c->blockcnt);
+    (void)hipFree(c->scan);
+    (void)hipFree(c->sel);
+    (void)hipFree(c->sq_part);
+    (void)hipFree(c->sq_out);
+    (void)hipFree(c->med_aos);
+    (void)hipFree(c->med_G);
+    (void)hipFree(c->med_idx);
     for (hipEvent_t e : c->samp_ev)
         (void)hipEventDestroy(e);
     if (c->ev0)
@@ -660,4 +691,179 @@ extern "C" int ek_assign_nearest(ek_ctx *c, const float *centers_xyz,
                      n_centers, c->dist, c->assign, c->stream);
     EK_CHECK_LAUNCH();
     return ek_local_candidate(c, nullptr);
+}
+
+// ---- PAM (k-medoids) proposals ----------------------------------------------------------
+extern "C" int ek_pam_begin(ek_ctx *c, const int64_t *medoid_frames, int32_t K)
+{
+    if (!c || !medoid_frames || K < 1)
+        return ek_fail(EK_EARG, "ek_pam_begin: bad argument");
+    if (!c->loaded)
+        return ek_fail(EK_ESTATE, "ek_pam_begin: no frames loaded");
+    for (int32_t i = 0; i < K; ++i)
+        if (medoid_frames[i] < 0 || medoid_frames[i] >= c->n)
+            return ek_fail(EK_EARG, "ek_pam_begin: medoid %d = frame %lld out "
+                                    "of range", i, (long long)medoid_frames[i]);
+    EK_HIP(hipSetDevice(c->device));
+    const size_t nn = (size_t)std::max<int64_t>(c->n, 1);
+    const size_t nb = (nn + EK_BLOCK - 1) / EK_BLOCK;
+    if (!c->ndist) {
+        EK_HIP(hipMalloc((void **)&c->ndist, nn * sizeof(float)));
+        EK_HIP(hipMalloc((void **)&c->nassign, nn * sizeof(int32_t)));
+        EK_HIP(hipMalloc((void **)&c->amb, nn * sizeof(uint32_t)));
+        EK_HIP(hipMalloc((void **)&c->amb_best, nn * sizeof(unsigned long long)));
+        EK_HIP(hipMalloc((void **)&c->amb_count, sizeof(unsigned int)));
+        EK_HIP(hipMalloc((void **)&c->blockcnt, nb * sizeof(int32_t)));
+        EK_HIP(hipMalloc((void **)&c->scan, nb * sizeof(int64_t)));
+        EK_HIP(hipMalloc((void **)&c->sel, 2 * sizeof(int64_t)));
+        EK_HIP(hipMalloc((void **)&c->sq_part,
+                         EK_SUMSQ_PART_DOUBLES * sizeof(double)));
+        EK_HIP(hipMalloc((void **)&c->sq_out, 2 * sizeof(double)));
+    }
+    if (K > c->med_cap) {
+        EK_HIP(hipStreamSynchronize(c->stream));
+        (void)hipFree(c->med_aos);
+        (void)hipFree(c->med_G);
+        (void)hipFree(c->med_idx);
+        c->med_aos = nullptr;
+        c->med_G = nullptr;
+        c->med_idx = nullptr;
+        c->med_cap = 0;
+        EK_HIP(hipMalloc((void **)&c->med_aos,
+                         (size_t)(K + 1) * 3 * c->A * sizeof(float)));
+        EK_HIP(hipMalloc((void **)&c->med_G, (size_t)(K + 1) * sizeof(double)));
+        EK_HIP(hipMalloc((void **)&c->med_idx, (size_t)(K + 1) * sizeof(int64_t)));
+        c->med_cap = K;
+    }
+    c->med_K = K;
+    c->pam_cid = -1;
+    EK_HIP(hipMemcpyAsync(c->med_idx, medoid_frames, (size_t)K * sizeof(int64_t),
+                          hipMemcpyHostToDevice, c->stream));
+    EK_HIP(hipStreamSynchronize(c->stream));
+    ek_launch_gather_frames(c->tiles, c->G, c->A, c->med_idx, K, 0, c->med_aos,
+                            c->med_G, c->stream);
+    EK_CHECK_LAUNCH();
+    return EK_OK;
+}
+
+extern "C" int ek_pam_count_members(ek_ctx *c, int32_t cid, int64_t *count)
+{
+    if (!c || !count)
+        return ek_fail(EK_EARG, "ek_pam_count_members: NULL argument");
+    if (!c->ndist)
+        return ek_fail(EK_ESTATE, "ek_pam_count_members: call ek_pam_begin first");
+    EK_HIP(hipSetDevice(c->device));
+    ek_launch_count_members(c->assign, c->n, cid, c->blockcnt, c->scan, c->sel,
+                            c->stream);
+    EK_CHECK_LAUNCH();
+    EK_HIP(hipMemcpyAsync(count, c->sel, sizeof(int64_t), hipMemcpyDeviceToHost,
+                          c->stream));
+    EK_HIP(hipStreamSynchronize(c->stream));
+    return EK_OK;
+}
+
+extern "C" int ek_pam_select_member(ek_ctx *c, int32_t cid, int64_t j,
+                                    int64_t *frame_index)
+{
+    if (!c || !frame_index)
+        return ek_fail(EK_EARG, "ek_pam_select_member: NULL argument");
+    if (!c->ndist)
+        return ek_fail(EK_ESTATE, "ek_pam_select_member: call ek_pam_begin first");
+    EK_HIP(hipSetDevice(c->device));
+    // relies on the scan left by the preceding ek_pam_count_members(cid)
+    ek_launch_select_member(c->assign, c->n, cid, c->scan, j, c->sel + 1,
+                            c->stream);
+    EK_CHECK_LAUNCH();
+    EK_HIP(hipMemcpyAsync(frame_index, c->sel + 1, sizeof(int64_t),
+                          hipMemcpyDeviceToHost, c->stream));
+    EK_HIP(hipStreamSynchronize(c->stream));
+    if (*frame_index < 0)
+        return ek_fail(EK_EARG, "ek_pam_select_member: cluster %d has no "
+                                "member %lld", cid, (long long)j);
+    return EK_OK;
+}
+
+extern "C" int ek_pam_propose(ek_ctx *c, int32_t cid, int64_t frame_index,
+                              double *old_cost, double *new_cost,
+                              int64_t *n_ambiguous)
+{
+    if (!c)
+        return ek_fail(EK_EARG, "NULL context");
+    if (!c->ndist || c->med_K < 1)
+        return ek_fail(EK_ESTATE, "ek_pam_propose: call ek_pam_begin first");
+    if (c->pam_cid >= 0)
+        return ek_fail(EK_ESTATE, "ek_pam_propose: previous proposal not "
+                                  "committed");
+    if (cid < 0 || cid >= c->med_K || frame_index < 0 || frame_index >= c->n)
+        return ek_fail(EK_EARG, "ek_pam_propose: cid=%d frame=%lld out of range",
+                       cid, (long long)frame_index);
+    EK_HIP(hipSetDevice(c->device));
+    const int K = c->med_K;
+    // distances of every frame to the proposed medoid (kmedoids.py:637)
+    ek_launch_record_from_frame(c->tiles, c->G, c->A, frame_index, c->goff,
+                                c->rec_tmp, c->stream);
+    ek_launch_step(ek_pick_fpl(c), 1, c->tiles, c->G, c->dist, c->assign,
+                   c->scratch, c->rec_tmp, 1, c->n, c->A, 0, 0.0, c->blockmax,
+                   c->hist, c->ctl, c->stream);
+    EK_CHECK_LAUNCH();
+    // trial medoid table: save row cid in row K, put the proposal in row cid
+    ek_launch_copy_row(c->med_aos, c->med_G, c->A, cid, K, c->stream);
+    EK_HIP(hipMemcpyAsync(c->med_idx + K, &frame_index, sizeof(int64_t),
+                          hipMemcpyHostToDevice, c->stream));
+    ek_launch_gather_frames(c->tiles, c->G, c->A, c->med_idx + K, 1, cid,
+                            c->med_aos, c->med_G, c->stream);
+    EK_HIP(hipMemsetAsync(c->amb_count, 0, sizeof(unsigned int), c->stream));
+    ek_launch_pam_classify(c->dist, c->assign, c->scratch, c->n, cid, c->ndist,
+                           c->nassign, c->amb, c->amb_best, c->amb_count,
+                           c->stream);
+    EK_CHECK_LAUNCH();
+    unsigned int n_amb = 0;
+    EK_HIP(hipMemcpyAsync(&n_amb, c->amb_count, sizeof(n_amb),
+                          hipMemcpyDeviceToHost, c->stream));
+    EK_HIP(hipStreamSynchronize(c->stream));
+    if (n_amb) {
+        const size_t lds = (size_t)3 * c->A * 8 * sizeof(float);
+        if (lds > 160 * 1024)
+            return ek_fail(EK_EARG, "ek_pam_propose: %d atoms exceed the LDS "
+                                    "center tile", c->A);
+        ek_launch_subset_assign(c->tiles, c->G, c->A, c->amb, n_amb, c->med_aos,
+                                c->med_G, K, c->amb_best, c->stream);
+        ek_launch_pam_scatter(c->amb, c->amb_best, n_amb, c->ndist, c->nassign,
+                              c->stream);
+        EK_CHECK_LAUNCH();
+    }
+    ek_launch_sumsq2(c->dist, c->ndist, c->n, c->sq_part, c->sq_out, c->stream);
+    EK_CHECK_LAUNCH();
+    double sums[2] = {0.0, 0.0};
+    EK_HIP(hipMemcpyAsync(sums, c->sq_out, sizeof(sums), hipMemcpyDeviceToHost,
+                          c->stream));
+    EK_HIP(hipStreamSynchronize(c->stream));
+    if (old_cost)
+        *old_cost = sums[0] / (double)c->n;
+    if (new_cost)
+        *new_cost = sums[1] / (double)c->n;
+    if (n_ambiguous)
+        *n_ambiguous = n_amb;
+    c->pam_cid = cid;
+    c->pam_frame = frame_index;
+    return EK_OK;
+}
+
+extern "C" int ek_pam_commit(ek_ctx *c, int accept)
+{
+    if (!c)
+        return ek_fail(EK_EARG, "NULL context");
+    if (c->pam_cid < 0)
+        return ek_fail(EK_ESTATE, "ek_pam_commit: no proposal pending");
+    EK_HIP(hipSetDevice(c->device));
+    if (accept) {
+        std::swap(c->dist, c->ndist);
+        std::swap(c->assign, c->nassign);
+    } else {
+        ek_launch_copy_row(c->med_aos, c->med_G, c->A, c->med_K, c->pam_cid,
+                           c->stream);
+        EK_CHECK_LAUNCH();
+    }
+    c->pam_cid = -1;
+    return EK_OK;
 }

@@ -87,3 +87,32 @@ void ek_launch_fill_state(float *dist, int32_t *assign, int64_t n, float d,
 void ek_launch_assign(const float *tiles, const double *G, int64_t n, int A,
                       const float *centers_aos, const double *Gc, int32_t K,
                       float *dist, int32_t *assign, hipStream_t s);
+
+// ---- PAM (ek_pam.hip) ----------------------------------------------------------
+void ek_launch_gather_frames(const float *tiles, const double *G, int A,
+                             const int64_t *idx_dev, int count, int first_row,
+                             float *out_aos, double *outG, hipStream_t s);
+void ek_launch_copy_row(float *aos, double *Gm, int A, int src, int dst,
+                        hipStream_t s);
+void ek_launch_count_members(const int32_t *assign, int64_t n, int32_t cid,
+                             int32_t *blockcnt, int64_t *scan, int64_t *total,
+                             hipStream_t s);
+void ek_launch_select_member(const int32_t *assign, int64_t n, int32_t cid,
+                             const int64_t *scan, int64_t j, int64_t *out,
+                             hipStream_t s);
+void ek_launch_pam_classify(const float *dist, const int32_t *assign,
+                            const float *newd, int64_t n, int32_t cid,
+                            float *ndist, int32_t *nassign, uint32_t *amb,
+                            unsigned long long *amb_best,
+                            unsigned int *amb_count, hipStream_t s);
+void ek_launch_subset_assign(const float *tiles, const double *G, int A,
+                             const uint32_t *amb, unsigned int n_amb,
+                             const float *centers, const double *Gc, int K,
+                             unsigned long long *amb_best, hipStream_t s);
+void ek_launch_pam_scatter(const uint32_t *amb,
+                           const unsigned long long *amb_best,
+                           unsigned int n_amb, float *ndist, int32_t *nassign,
+                           hipStream_t s);
+#define EK_SUMSQ_PART_DOUBLES 2048
+void ek_launch_sumsq2(const float *a, const float *b, int64_t n, double *part,
+                      double *out, hipStream_t s);

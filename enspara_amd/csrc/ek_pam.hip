@@ -1,0 +1,397 @@
+// ek_pam.hip -- device side of one PAM (k-medoids) proposal.
+//
+// Replaces, for metric 'rmsd', the O(n) numpy passes of
+// _kmedoids_pam_update (reference enspara/cluster/kmedoids.py:610-690):
+//   state_inds = where(assignments == cid)            :611  -> count / select
+//   new_ctr_dist = metric(X, proposed_center)         :637  -> ek_step_kernel<.,1>
+//   dst_dn / dst_up_assig_other / dst_up_assig_this   :644-658 -> classify
+//   assign_to_nearest_center(X[ambiguous], medoids)   :666  -> subset assign
+//   cost = mean(dist^2) old vs new                    :478, :680-681 -> sumsq
+// The host keeps only the RNG and the accept/reject decision.
+#include "ek_common.h"
+#include "ek_qcp.h"
+
+// ---- medoid table: centred coordinates of chosen frames, center-major --------
+__global__ void __launch_bounds__(EK_BLOCK)
+ek_gather_frames_kernel(const float *__restrict__ tiles,
+                        const double *__restrict__ G, int A,
+                        const int64_t *__restrict__ idx, int first_row,
+                        float *__restrict__ out_aos, double *__restrict__ outG)
+{
+    const int64_t f = idx[blockIdx.x];
+    const int row = first_row + blockIdx.x;
+    const float *p = tiles + (size_t)(f / EK_TILE) * 3 * (size_t)A * EK_TILE +
+                     (f % EK_TILE);
+    float *o = out_aos + (size_t)row * 3 * A;
+    for (int r = threadIdx.x; r < 3 * A; r += EK_BLOCK)
+        o[r] = p[(size_t)r * EK_TILE];
+    if (threadIdx.x == 0)
+        outG[row] = G[f];
+}
+
+void ek_launch_gather_frames(const float *tiles, const double *G, int A,
+                             const int64_t *idx_dev, int count, int first_row,
+                             float *out_aos, double *outG, hipStream_t s)
+{
+    if (count <= 0)
+        return;
+    hipLaunchKernelGGL(ek_gather_frames_kernel, dim3(count), dim3(EK_BLOCK), 0,
+                       s, tiles, G, A, idx_dev, first_row, out_aos, outG);
+}
+
+__global__ void __launch_bounds__(EK_BLOCK)
+ek_copy_row_kernel(float *__restrict__ aos, double *__restrict__ Gm, int A,
+                   int src, int dst)
+{
+    for (int r = threadIdx.x; r < 3 * A; r += EK_BLOCK)
+        aos[(size_t)dst * 3 * A + r] = aos[(size_t)src * 3 * A + r];
+    if (threadIdx.x == 0)
+        Gm[dst] = Gm[src];
+}
+
+void ek_launch_copy_row(float *aos, double *Gm, int A, int src, int dst,
+                        hipStream_t s)
+{
+    hipLaunchKernelGGL(ek_copy_row_kernel, dim3(1), dim3(EK_BLOCK), 0, s, aos,
+                       Gm, A, src, dst);
+}
+
+// ---- members of one cluster, in ascending frame order --------------------------
+__global__ void __launch_bounds__(EK_BLOCK)
+ek_count_members_kernel(const int32_t *__restrict__ assign, int64_t n,
+                        int32_t cid, int32_t *__restrict__ blockcnt)
+{
+    const int64_t f = (int64_t)blockIdx.x * EK_BLOCK + threadIdx.x;
+    const int hit = (f < n && assign[f] == cid) ? 1 : 0;
+    const int c = __syncthreads_count(hit);
+    if (threadIdx.x == 0)
+        blockcnt[blockIdx.x] = c;
+}
+
+// exclusive scan of the per-block counts by one workgroup; total -> *total
+__global__ void __launch_bounds__(1024)
+ek_scan_counts_kernel(const int32_t *__restrict__ blockcnt, int nblocks,
+                      int64_t *__restrict__ scan, int64_t *__restrict__ total)
+{
+    __shared__ int64_t part[1024];
+    const int t = threadIdx.x;
+    const int per = (nblocks + 1023) / 1024;
+    const int lo = t * per, hi = min(nblocks, lo + per);
+    int64_t s = 0;
+    for (int b = lo; b < hi; ++b)
+        s += blockcnt[b];
+    part[t] = s;
+    __syncthreads();
+    if (t == 0) {
+        int64_t run = 0;
+        for (int i = 0; i < 1024; ++i) {
+            const int64_t v = part[i];
+            part[i] = run;
+            run += v;
+        }
+        *total = run;
+    }
+    __syncthreads();
+    int64_t run = part[t];
+    for (int b = lo; b < hi; ++b) {
+        scan[b] = run;
+        run += blockcnt[b];
+    }
+}
+
+// the j-th member (0-based, ascending frame index) -> *out
+__global__ void __launch_bounds__(EK_WAVE)
+ek_select_member_kernel(const int32_t *__restrict__ assign, int64_t n,
+                        int32_t cid, const int64_t *__restrict__ scan,
+                        int nblocks, int64_t j, int64_t *__restrict__ out)
+{
+    if (threadIdx.x != 0)
+        return;
+    int lo = 0, hi = nblocks - 1;     // last block whose scan <= j
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) / 2;
+        if (scan[mid] <= j)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    int64_t rank = j - scan[lo];
+    int64_t res = -1;
+    const int64_t f0 = (int64_t)lo * EK_BLOCK;
+    for (int i = 0; i < EK_BLOCK; ++i) {
+        const int64_t f = f0 + i;
+        if (f < n && assign[f] == cid) {
+            if (rank == 0) {
+                res = f;
+                break;
+            }
+            --rank;
+        }
+    }
+    *out = res;
+}
+
+void ek_launch_count_members(const int32_t *assign, int64_t n, int32_t cid,
+                             int32_t *blockcnt, int64_t *scan, int64_t *total,
+                             hipStream_t s)
+{
+    const int nblocks = (int)((n + EK_BLOCK - 1) / EK_BLOCK);
+    hipLaunchKernelGGL(ek_count_members_kernel, dim3(nblocks), dim3(EK_BLOCK),
+                       0, s, assign, n, cid, blockcnt);
+    hipLaunchKernelGGL(ek_scan_counts_kernel, dim3(1), dim3(1024), 0, s,
+                       blockcnt, nblocks, scan, total);
+}
+
+void ek_launch_select_member(const int32_t *assign, int64_t n, int32_t cid,
+                             const int64_t *scan, int64_t j, int64_t *out,
+                             hipStream_t s)
+{
+    const int nblocks = (int)((n + EK_BLOCK - 1) / EK_BLOCK);
+    hipLaunchKernelGGL(ek_select_member_kernel, dim3(1), dim3(EK_WAVE), 0, s,
+                       assign, n, cid, scan, nblocks, j, out);
+}
+
+// ---- classification (kmedoids.py:639-658) ---------------------------------------
+// newd: distance of every frame to the proposed medoid.
+//   dist > newd                      -> (newd, cid)
+//   dist <= newd and assign != cid   -> unchanged
+//   dist <= newd and assign == cid   -> ambiguous: listed, resolved below
+__global__ void __launch_bounds__(EK_BLOCK)
+ek_pam_classify_kernel(const float *__restrict__ dist,
+                       const int32_t *__restrict__ assign,
+                       const float *__restrict__ newd, int64_t n, int32_t cid,
+                       float *__restrict__ ndist, int32_t *__restrict__ nassign,
+                       uint32_t *__restrict__ amb,
+                       unsigned long long *__restrict__ amb_best,
+                       unsigned int *__restrict__ amb_count)
+{
+    const int64_t f = (int64_t)blockIdx.x * EK_BLOCK + threadIdx.x;
+    if (f >= n)
+        return;
+    const float d = dist[f], nd = newd[f];
+    const int32_t a = assign[f];
+    if (d > nd) {
+        ndist[f] = nd;
+        nassign[f] = cid;
+    } else if (a != cid) {
+        ndist[f] = d;
+        nassign[f] = a;
+    } else {
+        const unsigned int pos = atomicAdd(amb_count, 1u);
+        amb[pos] = (uint32_t)f;
+        amb_best[pos] = ~0ull;
+    }
+}
+
+void ek_launch_pam_classify(const float *dist, const int32_t *assign,
+                            const float *newd, int64_t n, int32_t cid,
+                            float *ndist, int32_t *nassign, uint32_t *amb,
+                            unsigned long long *amb_best,
+                            unsigned int *amb_count, hipStream_t s)
+{
+    const int nblocks = (int)((n + EK_BLOCK - 1) / EK_BLOCK);
+    hipLaunchKernelGGL(ek_pam_classify_kernel, dim3(nblocks), dim3(EK_BLOCK), 0,
+                       s, dist, assign, newd, n, cid, ndist, nassign, amb,
+                       amb_best, amb_count);
+}
+
+// ---- listed frames x all medoids (kmedoids.py:666) ---------------------------------
+// grid = (frame chunks of 256, center chunks of PCT).  Every (frame, center)
+// distance is folded into amb_best[i] with a 64-bit atomic min on
+// (float bits << 32 | center index): distances are >= 0 so the bit pattern is
+// monotonic, and equal distances resolve to the lowest center index -- the
+// result of util.py:199-203's strict-< scan in ascending center order,
+// independent of the order the chunks finish in.
+#define PCT 8
+
+__global__ void __launch_bounds__(EK_BLOCK)
+ek_subset_assign_kernel(const float *__restrict__ tiles,
+                        const double *__restrict__ G, int A,
+                        const uint32_t *__restrict__ amb, unsigned int n_amb,
+                        const float *__restrict__ centers,
+                        const double *__restrict__ Gc, int K,
+                        unsigned long long *__restrict__ amb_best)
+{
+    extern __shared__ __attribute__((aligned(16))) float ctile[];
+    __shared__ double gtile[PCT];
+    const int tid = threadIdx.x;
+    const unsigned int i = blockIdx.x * EK_BLOCK + tid;
+    const int k0 = blockIdx.y * PCT;
+    const int kc = (K - k0 < PCT) ? (K - k0) : PCT;
+    for (int j = tid; j < 3 * A * PCT; j += EK_BLOCK) {
+        const int a = j / (3 * PCT), rem = j % (3 * PCT);
+        const int c = rem / 3, k = rem % 3;
+        ctile[j] = (c < kc) ? centers[(size_t)(k0 + c) * 3 * A + 3 * a + k] : 0.f;
+    }
+    if (tid < PCT)
+        gtile[tid] = (tid < kc) ? Gc[k0 + tid] : 0.0;
+    __syncthreads();
+    if (i >= n_amb)
+        return;
+    const uint32_t f = amb[i];
+    const float *p = tiles + (size_t)(f / EK_TILE) * 3 * (size_t)A * EK_TILE +
+                     (f % EK_TILE);
+    float s[PCT][9];
+#pragma unroll
+    for (int c = 0; c < PCT; ++c)
+#pragma unroll
+        for (int j = 0; j < 9; ++j)
+            s[c][j] = 0.f;
+    const float4 *ct4 = (const float4 *)ctile;
+    for (int a = 0; a < A; ++a) {
+        const float x = p[(size_t)(3 * a + 0) * EK_TILE];
+        const float y = p[(size_t)(3 * a + 1) * EK_TILE];
+        const float z = p[(size_t)(3 * a + 2) * EK_TILE];
+        float cc[3 * PCT];
+#pragma unroll
+        for (int q = 0; q < 3 * PCT / 4; ++q) {
+            const float4 v = ct4[a * (3 * PCT / 4) + q];
+            cc[4 * q + 0] = v.x;
+            cc[4 * q + 1] = v.y;
+            cc[4 * q + 2] = v.z;
+            cc[4 * q + 3] = v.w;
+        }
+#pragma unroll
+        for (int c = 0; c < PCT; ++c) {
+            const float cx = cc[3 * c + 0], cy = cc[3 * c + 1],
+                        cz = cc[3 * c + 2];
+            s[c][0] = __builtin_fmaf(x, cx, s[c][0]);
+            s[c][1] = __builtin_fmaf(x, cy, s[c][1]);
+            s[c][2] = __builtin_fmaf(x, cz, s[c][2]);
+            s[c][3] = __builtin_fmaf(y, cx, s[c][3]);
+            s[c][4] = __builtin_fmaf(y, cy, s[c][4]);
+            s[c][5] = __builtin_fmaf(y, cz, s[c][5]);
+            s[c][6] = __builtin_fmaf(z, cx, s[c][6]);
+            s[c][7] = __builtin_fmaf(z, cy, s[c][7]);
+            s[c][8] = __builtin_fmaf(z, cz, s[c][8]);
+        }
+    }
+    const double Gf = G[f];
+    unsigned long long best = ~0ull;
+#pragma unroll
+    for (int c = 0; c < PCT; ++c) {
+        if (c < kc) {
+            const float d = ek_rmsd_from_S(s[c], Gf, gtile[c], A);
+            const unsigned long long key =
+                ((unsigned long long)__float_as_uint(d) << 32) |
+                (unsigned int)(k0 + c);
+            if (key < best)
+                best = key;
+        }
+    }
+    atomicMin(&amb_best[i], best);
+}
+
+void ek_launch_subset_assign(const float *tiles, const double *G, int A,
+                             const uint32_t *amb, unsigned int n_amb,
+                             const float *centers, const double *Gc, int K,
+                             unsigned long long *amb_best, hipStream_t s)
+{
+    if (n_amb == 0 || K <= 0)
+        return;
+    const dim3 grid((n_amb + EK_BLOCK - 1) / EK_BLOCK, (K + PCT - 1) / PCT);
+    const size_t lds = (size_t)3 * A * PCT * sizeof(float);
+    hipLaunchKernelGGL(ek_subset_assign_kernel, grid, dim3(EK_BLOCK), lds, s,
+                       tiles, G, A, amb, n_amb, centers, Gc, K, amb_best);
+}
+
+__global__ void __launch_bounds__(EK_BLOCK)
+ek_pam_scatter_kernel(const uint32_t *__restrict__ amb,
+                      const unsigned long long *__restrict__ amb_best,
+                      unsigned int n_amb, float *__restrict__ ndist,
+                      int32_t *__restrict__ nassign)
+{
+    const unsigned int i = blockIdx.x * EK_BLOCK + threadIdx.x;
+    if (i >= n_amb)
+        return;
+    const unsigned long long key = amb_best[i];
+    const uint32_t f = amb[i];
+    ndist[f] = __uint_as_float((unsigned int)(key >> 32));
+    nassign[f] = (int32_t)(key & 0xffffffffu);
+}
+
+void ek_launch_pam_scatter(const uint32_t *amb,
+                           const unsigned long long *amb_best,
+                           unsigned int n_amb, float *ndist, int32_t *nassign,
+                           hipStream_t s)
+{
+    if (n_amb == 0)
+        return;
+    hipLaunchKernelGGL(ek_pam_scatter_kernel,
+                       dim3((n_amb + EK_BLOCK - 1) / EK_BLOCK), dim3(EK_BLOCK),
+                       0, s, amb, amb_best, n_amb, ndist, nassign);
+}
+
+// ---- cost: sum of squares in float64, fixed reduction order -----------------------
+// (kmedoids.py:478-479 takes np.square(x).mean() in float64; each square of a
+// float32 is exact in float64, only the summation order differs from numpy's
+// pairwise sum, by a few ulp of the total)
+#define SQ_BLOCKS 1024
+
+__global__ void __launch_bounds__(EK_BLOCK)
+ek_sumsq_partial_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                        int64_t n, double *__restrict__ part)
+{
+    __shared__ double sa[EK_BLOCK], sb[EK_BLOCK];
+    const int t = threadIdx.x;
+    // contiguous slab per block, strided inside: fixed for given n
+    const int64_t per = (n + SQ_BLOCKS - 1) / SQ_BLOCKS;
+    const int64_t lo = (int64_t)blockIdx.x * per;
+    const int64_t hi = (lo + per < n) ? lo + per : n;
+    double xa = 0.0, xb = 0.0;
+    for (int64_t f = lo + t; f < hi; f += EK_BLOCK) {
+        const double va = a[f], vb = b[f];
+        xa = xa + va * va;
+        xb = xb + vb * vb;
+    }
+    sa[t] = xa;
+    sb[t] = xb;
+    __syncthreads();
+    for (int w = EK_BLOCK / 2; w > 0; w >>= 1) {
+        if (t < w) {
+            sa[t] = sa[t] + sa[t + w];
+            sb[t] = sb[t] + sb[t + w];
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        part[2 * blockIdx.x + 0] = sa[0];
+        part[2 * blockIdx.x + 1] = sb[0];
+    }
+}
+
+__global__ void __launch_bounds__(EK_BLOCK)
+ek_sumsq_final_kernel(const double *__restrict__ part, double *__restrict__ out)
+{
+    __shared__ double sa[EK_BLOCK], sb[EK_BLOCK];
+    const int t = threadIdx.x;
+    double xa = 0.0, xb = 0.0;
+    for (int i = t; i < SQ_BLOCKS; i += EK_BLOCK) {
+        xa = xa + part[2 * i + 0];
+        xb = xb + part[2 * i + 1];
+    }
+    sa[t] = xa;
+    sb[t] = xb;
+    __syncthreads();
+    for (int w = EK_BLOCK / 2; w > 0; w >>= 1) {
+        if (t < w) {
+            sa[t] = sa[t] + sa[t + w];
+            sb[t] = sb[t] + sb[t + w];
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        out[0] = sa[0];
+        out[1] = sb[0];
+    }
+}
+
+// out[0] = sum a^2, out[1] = sum b^2 ; part must hold 2*SQ_BLOCKS doubles
+void ek_launch_sumsq2(const float *a, const float *b, int64_t n, double *part,
+                      double *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(ek_sumsq_partial_kernel, dim3(SQ_BLOCKS), dim3(EK_BLOCK),
+                       0, s, a, b, n, part);
+    hipLaunchKernelGGL(ek_sumsq_final_kernel, dim3(1), dim3(EK_BLOCK), 0, s,
+                       part, out);
+}

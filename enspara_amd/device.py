@@ -155,6 +155,35 @@ class FrameStore:
         _lib.check(self.lib.ek_assign_nearest(self._h, _lib.f32p(c),
                                               c.shape[0]))
 
+    # -- PAM ------------------------------------------------------------------
+    def pam_begin(self, medoid_frames):
+        m = np.ascontiguousarray(medoid_frames, dtype=np.int64)
+        _lib.check(self.lib.ek_pam_begin(self._h, _lib.i64p(m), len(m)))
+
+    def pam_count_members(self, cid):
+        cnt = C.c_int64()
+        _lib.check(self.lib.ek_pam_count_members(self._h, int(cid),
+                                                 C.byref(cnt)))
+        return cnt.value
+
+    def pam_select_member(self, cid, j):
+        f = C.c_int64()
+        _lib.check(self.lib.ek_pam_select_member(self._h, int(cid), int(j),
+                                                 C.byref(f)))
+        return f.value
+
+    def pam_propose(self, cid, frame_index):
+        """-> (old cost, new cost, number of ambiguous frames)"""
+        oc, nc = C.c_double(), C.c_double()
+        na = C.c_int64()
+        _lib.check(self.lib.ek_pam_propose(
+            self._h, int(cid), int(frame_index), C.byref(oc), C.byref(nc),
+            C.byref(na)))
+        return oc.value, nc.value, na.value
+
+    def pam_commit(self, accept):
+        _lib.check(self.lib.ek_pam_commit(self._h, 1 if accept else 0))
+
     # -- multi-shard primitives ----------------------------------------------
     @property
     def record_bytes(self):

@@ -150,6 +150,31 @@ int ek_history_reset(ek_ctx *ctx);
 int ek_assign_nearest(ek_ctx *ctx, const float *centers_xyz,
                       int32_t n_centers);
 
+/* ---- PAM (k-medoids) proposals ------------------------------------------------
+ * Replace the O(n) passes of one proposal of _kmedoids_pam_update
+ * (enspara/cluster/kmedoids.py:610-690) for metric 'rmsd'.  The host keeps the
+ * random stream (RandomState.choice, :514) and the accept test (:683).
+ *
+ * ek_pam_begin: medoid_frames[K] are the current medoids (frame indices of
+ * this shard, :607); builds the device-side medoid table.  The k-centers
+ * state (distances / assignments) must already be consistent with them.
+ * ek_pam_count_members: len(where(assignments == cid)) (:611).
+ * ek_pam_select_member: the j-th such frame in ascending order, so that
+ * `state_inds[random_state.choice(len(state_inds))]` == the reference's
+ * `random_state.choice(state_inds)`; call right after count_members(cid).
+ * ek_pam_propose: distances to frame `frame_index` (:637), the three masks
+ * (:644-658), nearest-medoid search for the ambiguous frames against the
+ * trial medoid set (:666), and both costs mean(d^2) in float64 (:478,
+ * :680-681).  The new state is held aside until
+ * ek_pam_commit(accept != 0): adopt it (:687-689); accept == 0: drop it. */
+int ek_pam_begin(ek_ctx *ctx, const int64_t *medoid_frames, int32_t n_medoids);
+int ek_pam_count_members(ek_ctx *ctx, int32_t cid, int64_t *count);
+int ek_pam_select_member(ek_ctx *ctx, int32_t cid, int64_t j,
+                         int64_t *frame_index);
+int ek_pam_propose(ek_ctx *ctx, int32_t cid, int64_t frame_index,
+                   double *old_cost, double *new_cost, int64_t *n_ambiguous);
+int ek_pam_commit(ek_ctx *ctx, int accept);
+
 /* ---- tuning knobs (benchmarks only) -------------------------------------- */
 /* frames per lane of the distance kernel: 1, 2 or 4; 0 = choose from the
  * shard size */
