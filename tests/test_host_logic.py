@@ -1,0 +1,137 @@
+"""Host-side surface that needs no GPU: argument handling and exceptions
+(reference kcenters.py:58-73,177-193; hybrid.py:64-70; util.py:69-72,
+289-313), the callable-metric loops (the reference's plug-in contract,
+kcenters.py:132-137), center lookup and partitioning."""
+import numpy as np
+import pytest
+
+from enspara_amd.cluster import KCenters, KHybrid, KMedoids, util
+from enspara_amd.cluster.hybrid import hybrid
+from enspara_amd.cluster.kcenters import kcenters
+from enspara_amd.cluster.kmedoids import _kmedoids_pam_update, kmedoids
+from enspara_amd.exception import DataInvalid, ImproperlyConfigured
+
+
+def euc(X, y):
+    return np.sqrt(np.square(X - y).sum(axis=1))
+
+
+@pytest.fixture(scope="module")
+def blobs():
+    rng = np.random.RandomState(0)
+    cs = rng.uniform(-20, 20, size=(5, 3))
+    return np.concatenate([c + rng.normal(size=(60, 3)) for c in cs])
+
+
+def test_configuration_errors():
+    with pytest.raises(ImproperlyConfigured):
+        KCenters(metric=euc)
+    with pytest.raises(ImproperlyConfigured):
+        KHybrid(metric=euc, kmedoids_updates=10)
+    with pytest.raises(ImproperlyConfigured):
+        KCenters(metric="not-a-metric", n_clusters=3)
+    with pytest.raises(ImproperlyConfigured):
+        kcenters(np.zeros((4, 2)), euc)              # neither limit given
+    with pytest.raises(ImproperlyConfigured):
+        kcenters(np.zeros((4, 2)), euc, n_clusters=None, dist_cutoff=None)
+    with pytest.raises(NotImplementedError):
+        kcenters(np.zeros((4, 2)), euc, n_clusters=2, random_first_center=True)
+    with pytest.raises(ImproperlyConfigured):
+        KCenters(metric=euc, n_clusters=2).predict(np.zeros((4, 2)))
+    with pytest.raises(ImproperlyConfigured):
+        kmedoids(np.zeros((4, 2)), euc)
+    assert util._get_distance_method("rmsd") is util.rmsd
+    assert util._get_distance_method(euc) is euc
+
+
+def test_kcenters_callable_metric(blobs):
+    r = kcenters(blobs, euc, n_clusters=5)
+    assert r.center_indices[0] == 0                 # frame 0 is always first
+    assert len(np.unique(r.assignments)) == 5
+    assert r.assignments.dtype == np.int64 and r.distances.dtype == np.float64
+    # brute force
+    D = np.stack([euc(blobs, blobs[i]) for i in r.center_indices])
+    np.testing.assert_array_equal(r.assignments, D.argmin(0))
+    np.testing.assert_allclose(r.distances, D.min(0))
+    # each new center was the farthest point at its time
+    d = np.full(len(blobs), np.inf)
+    for i in r.center_indices:
+        assert i == int(np.argmax(d))
+        d = np.minimum(d, euc(blobs, blobs[i]))
+    r2 = kcenters(blobs, euc, dist_cutoff=4.0)
+    assert r2.distances.max() <= 4.0
+    r3 = kcenters(blobs, euc, n_clusters=3, dist_cutoff=0.1)
+    assert len(r3.center_indices) == 3
+
+
+def test_triangle_inequality_equals_plain(blobs):
+    """reference test_cluster.py:710-770"""
+    a = kcenters(blobs, euc, n_clusters=12)
+    b = kcenters(blobs, euc, n_clusters=12, use_triangle_inequality=True)
+    assert a.center_indices == b.center_indices
+    np.testing.assert_array_equal(a.assignments, b.assignments)
+    np.testing.assert_allclose(a.distances, b.distances)
+
+
+def test_assign_equals_bruteforce(blobs):
+    """reference test_cluster_util.py:88-123"""
+    centers = blobs[[3, 77, 140, 200, 290]]
+    a, d = util.assign_to_nearest_center(blobs, centers, euc)
+    D = np.stack([euc(blobs, c) for c in centers])
+    np.testing.assert_array_equal(a, D.argmin(0))
+    np.testing.assert_allclose(d, D.min(0))
+    # ties go to the lower center index
+    a2, _ = util.assign_to_nearest_center(blobs, [centers[0], centers[0]], euc)
+    assert not a2.any()
+
+
+def test_find_cluster_centers():
+    a = np.array([2, 0, 2, 0, 5, 5, 5])
+    d = np.array([.3, .2, .1, .2, .9, .4, .4])
+    np.testing.assert_array_equal(util.find_cluster_centers(a, d), [1, 2, 5])
+    with pytest.raises(DataInvalid):
+        util.find_cluster_centers(a, d[:3])
+    rng = np.random.RandomState(1)
+    a = rng.randint(0, 40, 5000)
+    d = rng.rand(5000).round(2)
+    want = [np.where(a == c)[0][np.argmin(d[a == c])] for c in np.unique(a)]
+    np.testing.assert_array_equal(util.find_cluster_centers(a, d), want)
+
+
+def test_hybrid_and_pam_callable_metric(blobs):
+    r0 = kcenters(blobs, euc, n_clusters=5)
+    r = hybrid(blobs, euc, n_clusters=5, n_iters=3, random_state=0)
+    assert np.square(r.distances).mean() <= np.square(r0.distances).mean()
+    for k, i in enumerate(r.center_indices):
+        assert r.assignments[i] == k and r.distances[i] == 0
+    # a proposal that is the current medoid changes nothing
+    inds = list(r.center_indices)
+    mi, d, a, _ = _kmedoids_pam_update(blobs, euc, list(inds),
+                                       r.assignments.copy(),
+                                       r.distances.copy(), proposals=inds)
+    assert mi == inds
+    np.testing.assert_array_equal(a, r.assignments)
+    with pytest.raises(DataInvalid):
+        _kmedoids_pam_update(blobs, euc, list(inds), r.assignments,
+                             r.distances, proposals=inds[:2])
+    est = KHybrid(euc, n_clusters=5, kmedoids_updates=2, random_state=1)
+    est.fit(blobs)
+    assert est.labels_.shape == (300,) and est.runtime_ > 0
+    p = est.predict(blobs[:50])
+    np.testing.assert_array_equal(p.assignments, est.labels_[:50])
+    km = KMedoids(euc, n_clusters=5, n_iters=2).fit(blobs)
+    assert len(km.center_indices_) == 5
+
+
+def test_partition():
+    res = util.ClusterResult(center_indices=[0, 7, 12],
+                             assignments=np.arange(15) % 3,
+                             distances=np.arange(15) / 10., centers=[])
+    p = res.partition([5, 5, 5])
+    assert isinstance(p.assignments, np.ndarray) and p.assignments.shape == (3, 5)
+    assert p.center_indices == [(0, 0), (1, 2), (2, 2)]
+    p = res.partition([4, 11])
+    assert p.center_indices == [(0, 0), (1, 3), (1, 8)]
+    np.testing.assert_array_equal(p.distances[1], np.arange(4, 15) / 10.)
+    with pytest.raises(DataInvalid):
+        res.partition([5, 11])

@@ -1,0 +1,104 @@
+"""The multi-rank k-centers driver (enspara_amd/sharded.py) with world_size 2
+on CPU: backend gloo, checker-backed shards (tests/_host_shard.py).  The
+sharded result must equal the single-process result exactly -- the property
+the reference's own MPI tests assert (enspara/test/test_cluster.py:241-275,
+:278-314)."""
+import os
+import socket
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, A, seed, n_clusters, cutoff, outdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["OMP_NUM_THREADS"] = "2"
+    from enspara_amd import sharded, synth
+    from _host_shard import HostShard
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port,
+                            rank=rank, world_size=world)
+    x = synth.synth(n, A, 9, seed=seed)
+    lo, cnt = sharded.shard_bounds(n, world, rank)
+    shard = HostShard(x[lo:lo + cnt], lo)
+    max_new = n_clusters if n_clusters else n
+    idx, cd = sharded.kcenters_sharded(shard, 0, max_new, cutoff,
+                                       check_every=4)
+    np.savez(os.path.join(outdir, "r%d.npz" % rank), idx=idx, cd=cd, lo=lo,
+             dist=shard.dist, assign=shard.assign)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(world, n, A, seed, n_clusters, cutoff):
+    from oracle import cluster as oc
+    from enspara_amd import synth
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(world, _free_port(), n, A, seed, n_clusters,
+                                cutoff, d), nprocs=world, join=True)
+        parts = [np.load(os.path.join(d, "r%d.npz" % r)) for r in range(world)]
+    x = synth.synth(n, A, 9, seed=seed)
+    inds, a, dd = oc.kcenters(x, n_clusters=n_clusters,
+                              dist_cutoff=cutoff if cutoff else None)
+    for p in parts:                      # every rank reports the same centers
+        np.testing.assert_array_equal(p["idx"], np.array(inds))
+    got_a = np.concatenate([p["assign"] for p in parts])
+    got_d = np.concatenate([p["dist"] for p in parts])
+    np.testing.assert_array_equal(got_a, a)
+    np.testing.assert_array_equal(got_d.astype(np.float64), dd)
+    return inds
+
+
+def test_two_ranks_fixed_count():
+    inds = _run(2, 1500, 20, 5, 11, 0.0)
+    assert len(inds) == 11
+
+
+def test_two_ranks_cutoff():
+    inds = _run(2, 1200, 15, 6, None, 0.45)
+    assert len(inds) > 2
+
+
+def test_three_ranks_one_empty():
+    # 2 tiles over 3 ranks: the last rank owns no frames
+    inds = _run(3, 500, 10, 7, 6, 0.0)
+    assert len(inds) == 6
+
+
+def test_shard_bounds():
+    from enspara_amd.sharded import shard_bounds
+    for n, w in [(1000, 2), (1_000_000, 8), (255, 4), (256 * 7 + 3, 3)]:
+        spans = [shard_bounds(n, w, r) for r in range(w)]
+        assert spans[0][0] == 0
+        assert sum(c for _, c in spans) == n
+        for (lo, c), (lo2, _) in zip(spans, spans[1:]):
+            assert lo + c == lo2
+            assert lo2 % 256 == 0 or lo2 == n
+
+
+def test_single_process_without_process_group():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _host_shard import HostShard
+    from enspara_amd import sharded, synth
+    from oracle import cluster as oc
+    x = synth.synth(700, 12, 5, seed=2)
+    sh = HostShard(x, 0)
+    idx, cd = sharded.kcenters_sharded(sh, 0, 8, 0.0)
+    inds, a, d = oc.kcenters(x, n_clusters=8)
+    np.testing.assert_array_equal(idx, np.array(inds))
+    np.testing.assert_array_equal(sh.assign, a)
