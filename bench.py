@@ -53,6 +53,9 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=15.0,
                    help="time budget of the CPU baseline leg (rank 0, N=1)")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--sharded", action="store_true",
+                   help="use the torch.distributed driver even with one rank "
+                        "(exercises the RCCL path on a 1-GPU box)")
     return p.parse_args()
 
 
@@ -122,6 +125,12 @@ def load_traffic(args):
 
 def main():
     args = parse()
+    # Libraries underneath (RCCL: "Librccl path : ...") print to stdout; the
+    # contract is ONE JSON line there.  Keep the real stdout aside and point
+    # fd 1 at stderr for everything else.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -141,9 +150,14 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: there is no CPU path")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.sharded
+    if use_dist:
+        if "MASTER_ADDR" not in os.environ:
+            os.environ["MASTER_ADDR"] = "127.0.0.1"
+            os.environ.setdefault("MASTER_PORT", "29541")
         dist.init_process_group(
-            "nccl", device_id=torch.device("cuda", local_rank))
+            "nccl", rank=rank, world_size=world,
+            device_id=torch.device("cuda", local_rank))
 
     if args.warmup + args.steps > args.frames:
         raise SystemExit("warmup + steps exceeds the number of frames")
@@ -154,7 +168,8 @@ def main():
     t_gen = time.perf_counter() - t0
     n_local = x.shape[0]
     offset = rank * n_local
-    stream = torch.cuda.current_stream().cuda_stream if world > 1 else None
+    tstream = torch.cuda.Stream(device=local_rank) if use_dist else None
+    stream = tstream.cuda_stream if use_dist else None
     t0 = time.perf_counter()
     store = FrameStore(n_local, args.atoms, device=local_rank,
                        global_offset=offset, stream=stream)
@@ -164,12 +179,13 @@ def main():
     store.set_frames_per_lane(args.fpl)
     store.reset_state()
 
-    shard = sharded.DeviceShard(store) if world > 1 else None
+    shard = sharded.DeviceShard(store) if use_dist else None
 
     def run(first_label, count, fresh):
-        if world > 1:
-            idx, _ = sharded.kcenters_sharded(shard, first_label, count, 0.0,
-                                              fresh=fresh)
+        if use_dist:
+            with torch.cuda.stream(tstream):
+                idx, _ = sharded.kcenters_sharded(shard, first_label, count,
+                                                  0.0, fresh=fresh)
         else:
             idx, _, _ = store.kcenters_run(first_label, count, 0.0)
         return idx
@@ -179,20 +195,20 @@ def main():
 
     # ---- timed region: exactly --steps iterations ---------------------------
     store.timing_begin(sample_every=max(1, args.steps // 256), max_samples=512)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     idx = run(args.warmup, args.steps, False)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if len(idx) != args.steps:
         raise SystemExit("only %d of %d steps ran" % (len(idx), args.steps))
     kern_ms, n_samp = store.timing_end()
 
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -229,7 +245,7 @@ def main():
             "atoms": args.atoms, "centers": args.warmup + args.steps,
             "templates": args.templates, "seed": args.seed,
             "sharding": "contiguous frame blocks, 1 record all-gather/step"
-                        if world > 1 else "single shard",
+                        if use_dist else "single shard",
         },
         "roofline": {
             "bound": "hbm",
@@ -256,11 +272,13 @@ def main():
     elif rank == 0:
         out["cpu_baseline"] = None
 
-    if rank == 0:
-        print(json.dumps(out), flush=True)
     store.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    os.close(real_stdout)
 
 
 if __name__ == "__main__":

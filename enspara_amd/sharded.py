@@ -27,9 +27,12 @@ class DeviceShard:
     """Shard protocol on top of a :class:`enspara_amd.device.FrameStore`.
 
     Records live in torch CUDA tensors so that torch.distributed can move
-    them; kernels are enqueued on torch's current stream (the FrameStore must
-    have been created with ``stream=torch.cuda.current_stream().cuda_stream``)
-    so the collective and the kernels are ordered without host syncs.
+    them.  The FrameStore must have been created on a non-default torch
+    stream (``s = torch.cuda.Stream(); FrameStore(..., stream=s.cuda_stream)``)
+    and the driver must run under ``with torch.cuda.stream(s)``: torch orders
+    its collectives against the current stream, so kernels and the all-gather
+    are then ordered on the device without host syncs.  (Handle 0, the legacy
+    default stream, means "create your own" to ek_ctx_create.)
     """
 
     def __init__(self, store):
@@ -85,9 +88,10 @@ def kcenters_sharded(shard, first_label, max_new, dist_cutoff=0.0, group=None,
     """
     import torch.distributed as dist
     world, _ = _world(group)
+    collective = dist.is_available() and dist.is_initialized()
     rb = shard.record_bytes
     mine = shard.new_buffer(rb)
-    everyone = shard.new_buffer(rb * world) if world > 1 else mine
+    everyone = shard.new_buffer(rb * world) if collective else mine
     if fresh:
         shard.reset_history()
     shard.local_candidate(mine)
@@ -97,7 +101,7 @@ def kcenters_sharded(shard, first_label, max_new, dist_cutoff=0.0, group=None,
         todo = (max_new - issued) if open_loop else min(check_every,
                                                         max_new - issued)
         for i in range(todo):
-            if world > 1:
+            if collective:
                 dist.all_gather_into_tensor(everyone, mine, group=group)
             shard.step(everyone, world, first_label + issued + i,
                        float(dist_cutoff), mine)
