@@ -29,6 +29,10 @@ SYMBOLS = [
     "ek_assign_nearest",
     "ek_pam_begin", "ek_pam_count_members", "ek_pam_select_member",
     "ek_pam_propose", "ek_pam_commit",
+    "ek_msm_counts", "ek_msm_row_normalize",
+    "ek_krylov_create", "ek_krylov_destroy", "ek_krylov_set_vector",
+    "ek_krylov_get_vector", "ek_krylov_step", "ek_krylov_rotate",
+    "ek_krylov_combine",
     "ek_set_frames_per_lane", "ek_last_run_timing",
     "ek_timing_begin", "ek_timing_end",
 ]
@@ -96,6 +100,17 @@ def load():
     L.ek_pam_select_member.argtypes = [vp, i32, i64, i64p]
     L.ek_pam_propose.argtypes = [vp, i32, i64, f64p, f64p, i64p]
     L.ek_pam_commit.argtypes = [vp, C.c_int]
+    L.ek_msm_counts.argtypes = [C.c_int, i32p, i64p, i64, i32, i32, i32, i64,
+                                i32p, i32p, i64p, i64p]
+    L.ek_msm_row_normalize.argtypes = [C.c_int, i64p, f64p, i64, f64p, f64p]
+    L.ek_krylov_create.argtypes = [C.c_int, i64, i64p, i32p, f64p, i32,
+                                   C.POINTER(vp)]
+    L.ek_krylov_destroy.argtypes = [vp]
+    L.ek_krylov_set_vector.argtypes = [vp, i32, f64p]
+    L.ek_krylov_get_vector.argtypes = [vp, i32, f64p]
+    L.ek_krylov_step.argtypes = [vp, i32, i32, f64p]
+    L.ek_krylov_rotate.argtypes = [vp, i32, i32, f64p, i32]
+    L.ek_krylov_combine.argtypes = [vp, i32, i32, f64p, f64p]
     L.ek_set_frames_per_lane.argtypes = [vp, C.c_int]
     L.ek_last_run_timing.argtypes = [vp, f32p, i32p]
     L.ek_timing_begin.argtypes = [vp, i32, i32]
@@ -118,6 +133,10 @@ def f32p(a):
 
 def i32p(a):
     return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def f64p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
 def i64p(a):

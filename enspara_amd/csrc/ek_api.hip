@@ -12,7 +12,8 @@
 
 static thread_local char g_err[512] = "";
 
-static int ek_fail(int code, const char *fmt, ...)
+// shared with ek_msm.hip
+int ek_set_error(int code, const char *fmt, ...)
 {
     va_list ap;
     va_start(ap, fmt);
@@ -20,6 +21,7 @@ static int ek_fail(int code, const char *fmt, ...)
     va_end(ap);
     return code;
 }
+#define ek_fail ek_set_error
 
 #define EK_HIP(call)                                                           \
     do {                                                                       \

@@ -1,0 +1,331 @@
+// ek_krylov.hip -- device primitives of an Arnoldi / Krylov-Schur eigensolver
+// for the leading eigenpairs of a sparse transition matrix.
+//
+// Replaces the O(nnz) and O(n*m) work of
+//   eigenspectrum   enspara/msm/transition_matrices.py:173-233
+//   eq_probs        enspara/msm/transition_matrices.py:304-307
+// (the reference calls ARPACK through scipy.sparse.linalg.eigs, or LAPACK for
+// fewer than 1000 states).  The basis and the operator live in HBM; the host
+// (enspara_amd/msm/transition_matrices.py) keeps only the small projected
+// m x m problem.  All float64; every reduction has a fixed order, so results
+// are reproducible run to run.
+#include "ek_common.h"
+
+#include <stdlib.h>
+
+#include <algorithm>
+#include <new>
+
+extern int ek_set_error(int code, const char *fmt, ...);
+
+struct ek_krylov {
+    int device = 0;
+    int64_t n = 0, nnz = 0;
+    int32_t m_max = 0;
+    hipStream_t s = nullptr;
+    int64_t *indptr = nullptr;
+    int32_t *indices = nullptr;
+    double *data = nullptr;
+    double *V = nullptr;      // [m_max + 1][n]
+    double *w = nullptr;      // [n]
+    double *tmp = nullptr;    // [m_max + 1][n] scratch for basis rotations
+    double *h = nullptr;      // [m_max + 2] coefficients of one pass
+    double *q = nullptr;      // [(m_max+1) * (m_max+1)] rotation matrix
+};
+
+#define KR_HIP(call)                                                           \
+    do {                                                                       \
+        hipError_t e_ = (call);                                                \
+        if (e_ != hipSuccess)                                                  \
+            return ek_set_error(EK_EHIP, "%s failed: %s at %s:%d", #call,      \
+                                hipGetErrorString(e_), __FILE__, __LINE__);    \
+    } while (0)
+
+// w = A v, one wave per row, fixed-order shuffle reduction
+__global__ void __launch_bounds__(EK_BLOCK)
+kr_spmv_kernel(const int64_t *__restrict__ indptr,
+               const int32_t *__restrict__ indices,
+               const double *__restrict__ data, const double *__restrict__ v,
+               int64_t n, double *__restrict__ w)
+{
+    const int64_t row = (int64_t)blockIdx.x * (EK_BLOCK / EK_WAVE) +
+                        threadIdx.x / EK_WAVE;
+    const int lane = threadIdx.x & (EK_WAVE - 1);
+    if (row >= n)
+        return;
+    double acc = 0.0;
+    for (int64_t j = indptr[row] + lane; j < indptr[row + 1]; j += EK_WAVE)
+        acc = __builtin_fma(data[j], v[indices[j]], acc);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+        acc = acc + __shfl_xor(acc, off, 64);
+    if (lane == 0)
+        w[row] = acc;
+}
+
+// h[i] = V[i] . w  for i = blockIdx.x (one workgroup per basis vector)
+__global__ void __launch_bounds__(EK_BLOCK)
+kr_dots_kernel(const double *__restrict__ V, const double *__restrict__ w,
+               int64_t n, double *__restrict__ h)
+{
+    __shared__ double sh[EK_BLOCK];
+    const double *v = V + (size_t)blockIdx.x * n;
+    double acc = 0.0;
+    for (int64_t e = threadIdx.x; e < n; e += EK_BLOCK)
+        acc = __builtin_fma(v[e], w[e], acc);
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = EK_BLOCK / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s)
+            sh[threadIdx.x] = sh[threadIdx.x] + sh[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        h[blockIdx.x] = sh[0];
+}
+
+// w -= sum_{i < cnt} h[i] V[i]
+__global__ void __launch_bounds__(EK_BLOCK)
+kr_axpy_kernel(const double *__restrict__ V, const double *__restrict__ h,
+               int cnt, int64_t n, double *__restrict__ w)
+{
+    const int64_t e = (int64_t)blockIdx.x * EK_BLOCK + threadIdx.x;
+    if (e >= n)
+        return;
+    double x = w[e];
+    for (int i = 0; i < cnt; ++i)
+        x = __builtin_fma(-h[i], V[(size_t)i * n + e], x);
+    w[e] = x;
+}
+
+__global__ void __launch_bounds__(EK_BLOCK)
+kr_scale_kernel(const double *__restrict__ w, double alpha, int64_t n,
+                double *__restrict__ out)
+{
+    const int64_t e = (int64_t)blockIdx.x * EK_BLOCK + threadIdx.x;
+    if (e < n)
+        out[e] = alpha * w[e];
+}
+
+// out[c][e] = sum_{r < m} V[r][e] * Q[r + c*m]   (Q column-major m x kk)
+__global__ void __launch_bounds__(EK_BLOCK)
+kr_rotate_kernel(const double *__restrict__ V, const double *__restrict__ Q,
+                 int m, int kk, int64_t n, double *__restrict__ out)
+{
+    const int64_t e = (int64_t)blockIdx.x * EK_BLOCK + threadIdx.x;
+    const int c = blockIdx.y;
+    if (e >= n || c >= kk)
+        return;
+    double x = 0.0;
+    for (int r = 0; r < m; ++r)
+        x = __builtin_fma(V[(size_t)r * n + e], Q[(size_t)c * m + r], x);
+    out[(size_t)c * n + e] = x;
+}
+
+static inline unsigned kr_blocks(int64_t n)
+{
+    return (unsigned)std::max<int64_t>(1, (n + EK_BLOCK - 1) / EK_BLOCK);
+}
+
+extern "C" int ek_krylov_destroy(ek_krylov *k)
+{
+    if (!k)
+        return EK_OK;
+    (void)hipSetDevice(k->device);
+    if (k->s)
+        (void)hipStreamSynchronize(k->s);
+    (void)hipFree(k->indptr);
+    (void)hipFree(k->indices);
+    (void)hipFree(k->data);
+    (void)hipFree(k->V);
+    (void)hipFree(k->w);
+    (void)hipFree(k->tmp);
+    (void)hipFree(k->h);
+    (void)hipFree(k->q);
+    if (k->s)
+        (void)hipStreamDestroy(k->s);
+    delete k;
+    return EK_OK;
+}
+
+extern "C" int ek_krylov_create(int device, int64_t n, const int64_t *indptr,
+                                const int32_t *indices, const double *data,
+                                int32_t m_max, ek_krylov **out)
+{
+    if (!out || !indptr || n < 1 || m_max < 1)
+        return ek_set_error(EK_EARG, "ek_krylov_create: bad argument");
+    *out = nullptr;
+    KR_HIP(hipSetDevice(device));
+    ek_krylov *k = new (std::nothrow) ek_krylov();
+    if (!k)
+        return ek_set_error(EK_ENOMEM, "ek_krylov_create: out of memory");
+    k->device = device;
+    k->n = n;
+    k->nnz = indptr[n];
+    k->m_max = m_max;
+    const size_t nz = (size_t)std::max<int64_t>(k->nnz, 1);
+    hipError_t e = hipStreamCreateWithFlags(&k->s, hipStreamNonBlocking);
+#define KA(ptr, bytes)                                                         \
+    if (e == hipSuccess)                                                       \
+        e = hipMalloc((void **)&(ptr), (bytes));
+    KA(k->indptr, (size_t)(n + 1) * sizeof(int64_t));
+    KA(k->indices, nz * sizeof(int32_t));
+    KA(k->data, nz * sizeof(double));
+    KA(k->V, (size_t)(m_max + 1) * n * sizeof(double));
+    KA(k->tmp, (size_t)(m_max + 1) * n * sizeof(double));
+    KA(k->w, (size_t)n * sizeof(double));
+    KA(k->h, (size_t)(m_max + 2) * sizeof(double));
+    KA(k->q, (size_t)(m_max + 1) * (m_max + 1) * sizeof(double));
+#undef KA
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(k->indptr, indptr, (size_t)(n + 1) * sizeof(int64_t),
+                           hipMemcpyHostToDevice, k->s);
+    if (e == hipSuccess && k->nnz > 0)
+        e = hipMemcpyAsync(k->indices, indices, (size_t)k->nnz * sizeof(int32_t),
+                           hipMemcpyHostToDevice, k->s);
+    if (e == hipSuccess && k->nnz > 0)
+        e = hipMemcpyAsync(k->data, data, (size_t)k->nnz * sizeof(double),
+                           hipMemcpyHostToDevice, k->s);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(k->s);
+    if (e != hipSuccess) {
+        ek_krylov_destroy(k);
+        return ek_set_error(e == hipErrorOutOfMemory ? EK_ENOMEM : EK_EHIP,
+                            "ek_krylov_create: %s", hipGetErrorString(e));
+    }
+    *out = k;
+    return EK_OK;
+}
+
+extern "C" int ek_krylov_set_vector(ek_krylov *k, int32_t j, const double *vec)
+{
+    if (!k || !vec || j < 0 || j > k->m_max)
+        return ek_set_error(EK_EARG, "ek_krylov_set_vector: bad argument");
+    KR_HIP(hipSetDevice(k->device));
+    KR_HIP(hipMemcpyAsync(k->V + (size_t)j * k->n, vec,
+                          (size_t)k->n * sizeof(double), hipMemcpyHostToDevice,
+                          k->s));
+    KR_HIP(hipStreamSynchronize(k->s));
+    return EK_OK;
+}
+
+extern "C" int ek_krylov_get_vector(ek_krylov *k, int32_t j, double *vec)
+{
+    if (!k || !vec || j < 0 || j > k->m_max)
+        return ek_set_error(EK_EARG, "ek_krylov_get_vector: bad argument");
+    KR_HIP(hipSetDevice(k->device));
+    KR_HIP(hipMemcpyAsync(vec, k->V + (size_t)j * k->n,
+                          (size_t)k->n * sizeof(double), hipMemcpyDeviceToHost,
+                          k->s));
+    KR_HIP(hipStreamSynchronize(k->s));
+    return EK_OK;
+}
+
+// One Arnoldi step.  apply != 0: w = A V[j]; apply == 0: w = V[j+1] as it
+// stands (used to orthogonalise a fresh start vector after a breakdown).
+// w is orthogonalised against V[0..j] by classical Gram-Schmidt done twice;
+// h_col[0..j] receives the summed coefficients, h_col[j+1] = ||w||, and
+// V[j+1] = w / ||w|| (left untouched when the norm is 0).
+extern "C" int ek_krylov_step(ek_krylov *k, int32_t j, int32_t apply,
+                              double *h_col)
+{
+    if (!k || !h_col || j < 0 || j >= k->m_max)
+        return ek_set_error(EK_EARG, "ek_krylov_step: bad argument");
+    KR_HIP(hipSetDevice(k->device));
+    const int64_t n = k->n;
+    const int cnt = j + 1;
+    if (apply) {
+        hipLaunchKernelGGL(kr_spmv_kernel, dim3((unsigned)((n + 3) / 4)),
+                           dim3(EK_BLOCK), 0, k->s, k->indptr, k->indices,
+                           k->data, k->V + (size_t)j * n, n, k->w);
+    } else {
+        KR_HIP(hipMemcpyAsync(k->w, k->V + (size_t)(j + 1) * n,
+                              (size_t)n * sizeof(double),
+                              hipMemcpyDeviceToDevice, k->s));
+    }
+    double *h1 = (double *)malloc(sizeof(double) * (size_t)(cnt + 1) * 2);
+    if (!h1)
+        return ek_set_error(EK_ENOMEM, "ek_krylov_step: out of memory");
+    double *h2 = h1 + cnt + 1;
+    for (int pass = 0; pass < 2; ++pass) {
+        hipLaunchKernelGGL(kr_dots_kernel, dim3(cnt), dim3(EK_BLOCK), 0, k->s,
+                           k->V, k->w, n, k->h);
+        hipLaunchKernelGGL(kr_axpy_kernel, dim3(kr_blocks(n)), dim3(EK_BLOCK), 0,
+                           k->s, k->V, k->h, cnt, n, k->w);
+        hipError_t e = hipMemcpyAsync(pass ? h2 : h1, k->h,
+                                      (size_t)cnt * sizeof(double),
+                                      hipMemcpyDeviceToHost, k->s);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(k->s);
+        if (e != hipSuccess) {
+            free(h1);
+            return ek_set_error(EK_EHIP, "ek_krylov_step: %s",
+                                hipGetErrorString(e));
+        }
+    }
+    for (int i = 0; i < cnt; ++i)
+        h_col[i] = h1[i] + h2[i];
+    free(h1);
+    // norm of what is left
+    hipLaunchKernelGGL(kr_dots_kernel, dim3(1), dim3(EK_BLOCK), 0, k->s, k->w,
+                       k->w, n, k->h);
+    double nn = 0.0;
+    KR_HIP(hipMemcpyAsync(&nn, k->h, sizeof(double), hipMemcpyDeviceToHost,
+                          k->s));
+    KR_HIP(hipStreamSynchronize(k->s));
+    const double nrm = sqrt(nn);
+    h_col[cnt] = nrm;
+    if (nrm > 0.0) {
+        hipLaunchKernelGGL(kr_scale_kernel, dim3(kr_blocks(n)), dim3(EK_BLOCK),
+                           0, k->s, k->w, 1.0 / nrm, n,
+                           k->V + (size_t)(j + 1) * n);
+        KR_HIP(hipGetLastError());
+    }
+    return EK_OK;
+}
+
+// V[0..kk) <- V[0..m) * Q (Q column-major m x kk, host); if move_last != 0
+// also V[kk] <- V[m] (the residual direction of a Krylov-Schur restart).
+extern "C" int ek_krylov_rotate(ek_krylov *k, int32_t m, int32_t kk,
+                                const double *Q, int32_t move_last)
+{
+    if (!k || !Q || m < 1 || m > k->m_max + 1 || kk < 1 || kk > m)
+        return ek_set_error(EK_EARG, "ek_krylov_rotate: bad argument");
+    KR_HIP(hipSetDevice(k->device));
+    const int64_t n = k->n;
+    KR_HIP(hipMemcpyAsync(k->q, Q, (size_t)m * kk * sizeof(double),
+                          hipMemcpyHostToDevice, k->s));
+    hipLaunchKernelGGL(kr_rotate_kernel, dim3(kr_blocks(n), kk), dim3(EK_BLOCK),
+                       0, k->s, k->V, k->q, m, kk, n, k->tmp);
+    KR_HIP(hipGetLastError());
+    if (move_last)
+        KR_HIP(hipMemcpyAsync(k->tmp + (size_t)kk * n, k->V + (size_t)m * n,
+                              (size_t)n * sizeof(double),
+                              hipMemcpyDeviceToDevice, k->s));
+    KR_HIP(hipMemcpyAsync(k->V, k->tmp,
+                          (size_t)(kk + (move_last ? 1 : 0)) * n * sizeof(double),
+                          hipMemcpyDeviceToDevice, k->s));
+    KR_HIP(hipStreamSynchronize(k->s));
+    return EK_OK;
+}
+
+// out[c] = V[0..m) * Q[:, c] for c < kk, copied to host memory ([kk][n]);
+// the basis is left untouched (final Ritz vectors).
+extern "C" int ek_krylov_combine(ek_krylov *k, int32_t m, int32_t kk,
+                                 const double *Q, double *out_host)
+{
+    if (!k || !Q || !out_host || m < 1 || m > k->m_max + 1 || kk < 1 ||
+        kk > k->m_max + 1)
+        return ek_set_error(EK_EARG, "ek_krylov_combine: bad argument");
+    KR_HIP(hipSetDevice(k->device));
+    const int64_t n = k->n;
+    KR_HIP(hipMemcpyAsync(k->q, Q, (size_t)m * kk * sizeof(double),
+                          hipMemcpyHostToDevice, k->s));
+    hipLaunchKernelGGL(kr_rotate_kernel, dim3(kr_blocks(n), kk), dim3(EK_BLOCK),
+                       0, k->s, k->V, k->q, m, kk, n, k->tmp);
+    KR_HIP(hipGetLastError());
+    KR_HIP(hipMemcpyAsync(out_host, k->tmp, (size_t)kk * n * sizeof(double),
+                          hipMemcpyDeviceToHost, k->s));
+    KR_HIP(hipStreamSynchronize(k->s));
+    return EK_OK;
+}

@@ -1,0 +1,294 @@
+"""Transition counting and spectra of transition matrices on the device.
+
+Surface follows the reference's enspara/msm/transition_matrices.py
+(assigns_to_counts :113-170, eigenspectrum :173-233, eq_probs :304-307).
+"""
+import ctypes as C
+import numbers
+
+import numpy as np
+import scipy.sparse
+
+from .. import _lib
+from ..exception import DataInvalid
+
+
+def _rows_of(assigns):
+    """-> (concatenated int32 states, int64 lengths)"""
+    if hasattr(assigns, "_data") and hasattr(assigns, "lengths"):
+        flat = np.asarray(assigns._data)
+        lengths = np.asarray(assigns.lengths, dtype=np.int64)
+    else:
+        if isinstance(assigns, np.ndarray) and assigns.dtype != object:
+            if assigns.ndim == 1:
+                raise DataInvalid(
+                    'The given assignments array has 1-dimensional shape %s. '
+                    'Two dimensional shapes = (n_trj, n_frames) are expected. '
+                    'If this is really what you want, try using '
+                    'assignments.reshape(1, -1) to create a single-row 2d '
+                    'array.' % (assigns.shape,))
+            flat = assigns.reshape(-1)
+            lengths = np.full(assigns.shape[0], assigns.shape[1],
+                              dtype=np.int64)
+        else:
+            rows = [np.asarray(r) for r in assigns]
+            lengths = np.array([len(r) for r in rows], dtype=np.int64)
+            flat = np.concatenate(rows) if rows else np.zeros(0, dtype=np.int64)
+    if flat.size and not np.issubdtype(flat.dtype, np.integer):
+        raise DataInvalid("assignments must be integers, got %s" % flat.dtype)
+    return flat, lengths
+
+
+def assigns_to_counts(assigns, lag_time, max_n_states=None,
+                      sliding_window=True, device=0):
+    """Count transitions (reference transition_matrices.py:113-170).
+
+    Returns a scipy.sparse.coo_matrix of int counts, shape
+    (max_n_states, max_n_states).  Unlike the reference's COO (one entry of 1
+    per observed transition, summed only on conversion) duplicates are already
+    summed and entries are sorted by (row, col); every derived quantity
+    (todense, tocsr, arithmetic) is identical.
+    """
+    if not isinstance(lag_time, numbers.Integral):
+        raise DataInvalid("The lag time must be an integer. Got %s type %s."
+                          % (lag_time, type(lag_time)))
+    if lag_time < 1:
+        raise DataInvalid("Lag times must be be strictly greater than 0. "
+                          "Got '%s'." % lag_time)
+    flat, lengths = _rows_of(assigns)
+    if max_n_states is None:
+        kept = flat[flat != -1]
+        max_n_states = int(kept.max()) + 1 if kept.size else 0
+    max_n_states = int(max_n_states)
+    if flat.size:
+        lo, hi = int(flat.min()), int(flat.max())
+        if lo < -1:
+            raise ValueError("negative row index found")   # scipy's wording
+        if hi >= max_n_states:
+            raise ValueError("row index exceeds matrix dimensions")
+    if max_n_states == 0 or flat.size == 0:
+        return scipy.sparse.coo_matrix((max_n_states, max_n_states), dtype=int)
+    a32 = np.ascontiguousarray(flat, dtype=np.int32)
+    cap = max(1, int(a32.size))
+    rows = np.empty(cap, dtype=np.int32)
+    cols = np.empty(cap, dtype=np.int32)
+    vals = np.empty(cap, dtype=np.int64)
+    nnz = C.c_int64()
+    L = _lib.load()
+    _lib.check(L.ek_msm_counts(
+        int(device), _lib.i32p(a32), _lib.i64p(lengths), len(lengths),
+        int(lag_time), 1 if sliding_window else 0, max_n_states, cap,
+        _lib.i32p(rows), _lib.i32p(cols), _lib.i64p(vals), C.byref(nnz)))
+    k = nnz.value
+    return scipy.sparse.coo_matrix(
+        (vals[:k].astype(int), (rows[:k], cols[:k])),
+        shape=(max_n_states, max_n_states))
+
+
+# ---------------------------------------------------------------------------
+# leading eigenpairs: Arnoldi / Krylov-Schur with the basis on the device
+# ---------------------------------------------------------------------------
+class DeviceKrylov:
+    """Krylov basis + sparse operator resident on one GPU (csrc/ek_krylov.hip).
+    The solver below talks to this small protocol only."""
+
+    def __init__(self, A_csr, m_max, device=0):
+        A = scipy.sparse.csr_matrix(A_csr).astype(np.float64)
+        A.sort_indices()
+        self.n = A.shape[0]
+        self.m_max = int(m_max)
+        self.L = _lib.load()
+        indptr = np.ascontiguousarray(A.indptr, dtype=np.int64)
+        indices = np.ascontiguousarray(A.indices, dtype=np.int32)
+        data = np.ascontiguousarray(A.data, dtype=np.float64)
+        h = C.c_void_p()
+        _lib.check(self.L.ek_krylov_create(
+            int(device), self.n, _lib.i64p(indptr), _lib.i32p(indices),
+            _lib.f64p(data), self.m_max, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.L.ek_krylov_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_vector(self, j, v):
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        _lib.check(self.L.ek_krylov_set_vector(self._h, int(j), _lib.f64p(v)))
+
+    def get_vector(self, j):
+        v = np.empty(self.n, dtype=np.float64)
+        _lib.check(self.L.ek_krylov_get_vector(self._h, int(j), _lib.f64p(v)))
+        return v
+
+    def step(self, j, apply=True):
+        h = np.empty(j + 2, dtype=np.float64)
+        _lib.check(self.L.ek_krylov_step(self._h, int(j), 1 if apply else 0,
+                                         _lib.f64p(h)))
+        return h
+
+    def rotate(self, m, Q, move_last):
+        Q = np.asfortranarray(Q, dtype=np.float64)
+        kk = Q.shape[1]
+        _lib.check(self.L.ek_krylov_rotate(
+            self._h, int(m), int(kk),
+            Q.ctypes.data_as(C.POINTER(C.c_double)), 1 if move_last else 0))
+
+
+    def combine(self, m, Q):
+        """-> [kk, n] rows = V[:m].T @ Q[:, c]; the basis is not modified"""
+        Q = np.asfortranarray(Q, dtype=np.float64)
+        kk = Q.shape[1]
+        out = np.empty((kk, self.n), dtype=np.float64)
+        step = self.m_max + 1
+        for c0 in range(0, kk, step):
+            c1 = min(kk, c0 + step)
+            Qc = np.asfortranarray(Q[:, c0:c1])
+            _lib.check(self.L.ek_krylov_combine(
+                self._h, int(m), c1 - c0,
+                Qc.ctypes.data_as(C.POINTER(C.c_double)),
+                out[c0:c1].ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
+
+def _start_vector(n, seed=0):
+    v = np.random.RandomState(seed).uniform(0.5, 1.5, size=n)
+    return v / np.linalg.norm(v)
+
+
+def _expand(space, H, j0, m, rng_seed=1):
+    """Arnoldi steps j0..m-1.  Returns the effective m (smaller only if the
+    basis became complete)."""
+    n = space.n
+    for j in range(j0, m):
+        h = space.step(j, True)
+        H[:j + 2, j] = h
+        scale = np.linalg.norm(h[:j + 1]) + h[j + 1]
+        if h[j + 1] <= 1e-13 * max(scale, 1e-300):
+            # invariant subspace: continue with a fresh direction (the
+            # projected matrix becomes block triangular, H[j+1, j] = 0)
+            H[j + 1, j] = 0.0
+            if j + 1 >= n:
+                return j + 1
+            for attempt in range(5):
+                space.set_vector(j + 1, _start_vector(n, rng_seed + 17 * j
+                                                      + attempt))
+                hh = space.step(j, False)
+                if hh[j + 1] > 1e-8:
+                    break
+            else:
+                return j + 1
+    return m
+
+
+def _leading_eigs(space, k, tol=1e-12, max_restarts=500):
+    """k eigenpairs of largest real part.  -> (vals complex [k], vecs [n, k])"""
+    import scipy.linalg
+    n = space.n
+    m = space.m_max
+    full = m >= n
+    if full:
+        m = n
+    H = np.zeros((m + 1, m))
+    space.set_vector(0, _start_vector(n))
+    j0 = 0
+    for restart in range(max_restarts):
+        m_eff = _expand(space, H, j0, m)
+        Hm = H[:m_eff, :m_eff]
+        b = H[m_eff, :m_eff].copy() if m_eff < H.shape[0] else np.zeros(m_eff)
+        if full or m_eff < m:
+            break                      # the basis spans an invariant subspace
+        vals = scipy.linalg.eigvals(Hm)
+        order = np.argsort(-vals.real, kind="stable")
+        # keep k wanted + some extra, never splitting a conjugate pair
+        p = min(m - 1, k + max(1, (m - k) // 2))
+        thr_set = set(order[:p].tolist())
+        last = order[p - 1]
+        if abs(vals[last].imag) > 0:
+            conj = [i for i in order[p:] if abs(vals[i] - np.conj(vals[last]))
+                    < 1e-12 * max(1.0, abs(vals[last]))]
+            if conj:
+                thr_set.add(conj[0])
+        keep_vals = vals[sorted(thr_set)]
+
+        def sel(re, im, kv=keep_vals):
+            z = re + 1j * im
+            return bool(np.min(np.abs(kv - z)) <= 1e-9 * max(1.0, abs(z)))
+        S, Z, sdim = scipy.linalg.schur(Hm, output="real", sort=sel)
+        p = int(sdim)
+        if p < 1 or p >= m:
+            p = max(1, min(m - 1, k))
+        bz = b @ Z
+        # residuals of the wanted Ritz pairs
+        sv, sy = scipy.linalg.eig(S[:p, :p])
+        o2 = np.argsort(-sv.real, kind="stable")[:k]
+        res = np.abs(bz[:p] @ sy[:, o2])
+        if np.all(res <= tol * np.maximum(np.abs(sv[o2]), 1e-3)):
+            break
+        # restart: V <- V Z[:, :p], residual direction moves to slot p
+        space.rotate(m, Z[:, :p], True)
+        H[:] = 0.0
+        H[:p, :p] = S[:p, :p]
+        H[p, :p] = bz[:p]
+        j0 = p
+    # Ritz pairs of the final projected matrix
+    Hm = H[:m_eff, :m_eff]
+    vals, Y = scipy.linalg.eig(Hm)
+    order = np.argsort(-vals.real, kind="stable")[:k]
+    vals = vals[order]
+    Y = Y[:, order]
+    # x = V y: real and imaginary parts through the device rotation
+    kk = len(order)
+    X = space.combine(m_eff, np.concatenate([Y.real, Y.imag], axis=1))
+    vecs = (X[:kk] + 1j * X[kk:]).T
+    return vals, vecs
+
+
+def eigenspectrum(T, n_eigs=None, left=True, maxiter=100000, tol=1E-30,
+                  device=0, _space_factory=None):
+    """Eigenvalues / eigenvectors of a transition probability matrix, sorted by
+    descending real part, first vector scaled to sum 1, real parts returned
+    (reference transition_matrices.py:173-233).  Matrices with up to 1000
+    states get a complete Arnoldi basis (all eigenpairs, like the reference's
+    dense branch); larger ones a thick-restarted Krylov-Schur iteration for
+    the ``n_eigs`` of largest real part (the reference's ARPACK ``which='LR'``
+    branch).  SpMV, orthogonalisation and basis rotations run on the GPU."""
+    n = T.shape[0]
+    if n_eigs is None:
+        n_eigs = n
+    elif n_eigs < 2:
+        raise ValueError('n_eig must be greater than or equal to 2')
+    n_eigs = min(int(n_eigs), n)
+    A = scipy.sparse.csr_matrix(T.T if left else T)
+    if n <= 1000:
+        m_max = n
+        k = n
+    else:
+        k = n_eigs
+        m_max = min(n - 1, max(2 * k + 1, 40))
+    make = _space_factory or (lambda A_, m_: DeviceKrylov(A_, m_, device))
+    space = make(A, m_max)
+    try:
+        vals, vecs = _leading_eigs(space, k, tol=max(tol, 1e-13),
+                                   max_restarts=max(10, min(maxiter, 2000)))
+    finally:
+        if hasattr(space, "close"):
+            space.close()
+    order = np.argsort(-np.real(vals), kind="stable")
+    vals = vals[order]
+    vecs = vecs[:, order]
+    vecs[:, 0] /= vecs[:, 0].sum()
+    return np.real(vals[:n_eigs]), np.real(vecs[:, :n_eigs])
+
+
+def eq_probs(T, maxiter=100000, tol=1E-30, device=0):
+    """reference transition_matrices.py:304-307"""
+    val, vec = eigenspectrum(T, n_eigs=3, left=True, maxiter=maxiter, tol=tol,
+                             device=device)
+    return vec[:, 0]

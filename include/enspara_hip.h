@@ -175,6 +175,52 @@ int ek_pam_propose(ek_ctx *ctx, int32_t cid, int64_t frame_index,
                    double *old_cost, double *new_cost, int64_t *n_ambiguous);
 int ek_pam_commit(ek_ctx *ctx, int accept);
 
+/* ---- MSM construction (secondary kernel) -------------------------------------
+ * ek_msm_counts replaces assigns_to_counts
+ * (enspara/msm/transition_matrices.py:113-170 with _transitions_helper
+ * :310-321).  assigns: int32 state index per frame, trajectories concatenated
+ * (host memory); lengths[n_trj]: frames per trajectory.  Frames equal to -1
+ * are removed from their trajectory first (:156), then state[t] is paired
+ * with state[t+lag_time] (sliding_window != 0) or every lag_time-th frame
+ * with the next (:316-319).  Every other state must lie in [0, n_states).
+ * Output: the count matrix as COO sorted by (row, col) with duplicates summed,
+ * at most `capacity` entries (the number of frames is always enough). */
+int ek_msm_counts(int device, const int32_t *assigns, const int64_t *lengths,
+                  int64_t n_trj, int32_t lag_time, int32_t sliding_window,
+                  int32_t n_states, int64_t capacity, int32_t *rows_out,
+                  int32_t *cols_out, int64_t *counts_out, int64_t *nnz_out);
+/* ek_msm_row_normalize replaces _row_normalize's sparse branch
+ * (enspara/msm/builders.py:188-196) on a CSR matrix (host arrays):
+ * probs = diag(1/rowsum) * data, empty rows stay zero.  rowsum_out may be
+ * NULL. */
+int ek_msm_row_normalize(int device, const int64_t *indptr, const double *data,
+                         int64_t n_rows, double *probs_out, double *rowsum_out);
+
+/* ---- leading eigenpairs of a sparse transition matrix ---------------------------
+ * Device primitives of an Arnoldi / Krylov-Schur solver replacing the ARPACK /
+ * LAPACK calls of eigenspectrum (enspara/msm/transition_matrices.py:173-233).
+ * The operator A is given in CSR (host arrays, copied to the device); the
+ * basis V[0..m_max] lives on the device.  The host keeps the projected
+ * (m x m) problem only.
+ *   ek_krylov_step(j, apply, h_col): w = A V[j] (apply != 0) or w = V[j+1]
+ *     (apply == 0); orthogonalise w against V[0..j] (classical Gram-Schmidt,
+ *     twice); h_col[0..j] = coefficients, h_col[j+1] = ||w||, V[j+1] = w/||w||.
+ *   ek_krylov_rotate(m, kk, Q, move_last): V[0..kk) = V[0..m) Q, Q column-major
+ *     m x kk; move_last != 0 also moves V[m] to V[kk] (restart). */
+typedef struct ek_krylov ek_krylov;
+int ek_krylov_create(int device, int64_t n, const int64_t *indptr,
+                     const int32_t *indices, const double *data, int32_t m_max,
+                     ek_krylov **out);
+int ek_krylov_destroy(ek_krylov *k);
+int ek_krylov_set_vector(ek_krylov *k, int32_t j, const double *vec);
+int ek_krylov_get_vector(ek_krylov *k, int32_t j, double *vec);
+int ek_krylov_step(ek_krylov *k, int32_t j, int32_t apply, double *h_col);
+int ek_krylov_rotate(ek_krylov *k, int32_t m, int32_t kk, const double *Q,
+                     int32_t move_last);
+/* out_host[c][0..n) = V[0..m) Q[:, c], c < kk <= m_max + 1; basis unchanged */
+int ek_krylov_combine(ek_krylov *k, int32_t m, int32_t kk, const double *Q,
+                      double *out_host);
+
 /* ---- tuning knobs (benchmarks only) -------------------------------------- */
 /* frames per lane of the distance kernel: 1, 2 or 4; 0 = choose from the
  * shard size */

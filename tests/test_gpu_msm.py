@@ -1,0 +1,130 @@
+"""MSM kernels on the GPU against outputs of the real reference
+(tests/golden/msm_golden.npz: enspara.msm.assigns_to_counts /
+builders.normalize / builders.transpose / eigenspectrum run here by
+tests/golden/make_golden.py) and against scipy at larger sizes."""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse
+import scipy.sparse.linalg
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def M(golden_dir):
+    return np.load(os.path.join(golden_dir, "msm_golden.npz"))
+
+
+def test_counts_match_reference(M):
+    from enspara_amd.msm import assigns_to_counts
+    from enspara_amd import ra
+    A = M["assigns"]
+    K = 60
+    for lag in (1, 5):
+        for sw in (True, False):
+            C = assigns_to_counts(A, lag_time=lag, max_n_states=K,
+                                  sliding_window=sw)
+            want = M["counts_lag%d_sw%d" % (lag, int(sw))]
+            assert C.shape == (K, K) and scipy.sparse.issparse(C)
+            np.testing.assert_array_equal(np.asarray(C.todense()), want)
+            assert np.issubdtype(C.dtype, np.integer)
+    lens = M["rag_lengths"]
+    flat = np.concatenate([A[i, :n] for i, n in enumerate(lens)])
+    R = ra.RaggedArray(flat, lengths=lens)
+    C = assigns_to_counts(R, lag_time=3, max_n_states=K)
+    np.testing.assert_array_equal(np.asarray(C.todense()),
+                                  M["rag_counts_lag3"])
+    # max_n_states inferred
+    C = assigns_to_counts(A, lag_time=1)
+    assert C.shape == (A.max() + 1, A.max() + 1)
+
+
+def test_counts_edge_cases():
+    from enspara_amd.msm import assigns_to_counts
+    from enspara_amd.exception import DataInvalid
+    a = np.array([[0, 1, -1, 1, 2, -1, -1, 0]])
+    # -1 frames are dropped first: 0 1 1 2 0
+    C = assigns_to_counts(a, lag_time=1).toarray()
+    want = np.zeros((3, 3), dtype=int)
+    for i, j in [(0, 1), (1, 1), (1, 2), (2, 0)]:
+        want[i, j] += 1
+    np.testing.assert_array_equal(C, want)
+    C = assigns_to_counts(a, lag_time=2, sliding_window=False).toarray()
+    want = np.zeros((3, 3), dtype=int)
+    for i, j in [(0, 1), (1, 0)]:
+        want[i, j] += 1
+    np.testing.assert_array_equal(C, want)
+    # trajectory shorter than the lag contributes nothing
+    C = assigns_to_counts([np.array([0, 1]), np.array([2, 2, 2, 2])],
+                          lag_time=3).toarray()
+    assert C.sum() == 1 and C[2, 2] == 1
+    with pytest.raises(DataInvalid):
+        assigns_to_counts(np.array([0, 1, 2]), lag_time=1)
+    with pytest.raises(DataInvalid):
+        assigns_to_counts(a, lag_time=0)
+    with pytest.raises(DataInvalid):
+        assigns_to_counts(a, lag_time=1.5)
+    with pytest.raises(ValueError):
+        assigns_to_counts(a, lag_time=1, max_n_states=2)
+
+
+def test_normalize_and_transpose_match_reference(M):
+    from enspara_amd.msm import assigns_to_counts, builders
+    C = assigns_to_counts(M["assigns"], lag_time=1, max_n_states=60)
+    C2, T, eq = builders.normalize(C, calculate_eq_probs=True)
+    assert type(T) is type(C)
+    np.testing.assert_array_equal(np.asarray(T.todense()), M["norm_T"])
+    np.testing.assert_allclose(eq, M["norm_eq"], atol=1e-10)
+    Cs, Tt, eqt = builders.transpose(C, calculate_eq_probs=True)
+    np.testing.assert_array_equal(np.asarray(Tt.todense()), M["transpose_T"])
+    np.testing.assert_allclose(eqt, M["transpose_eq"], atol=1e-14)
+    # dense input, zero rows stay zero
+    D = np.array([[2., 2., 0.], [0., 0., 0.], [1., 0., 3.]])
+    Tn = builders._row_normalize(D)
+    np.testing.assert_array_equal(Tn, [[.5, .5, 0], [0, 0, 0], [.25, 0, .75]])
+
+
+def test_eigenspectrum_matches_reference(M):
+    from enspara_amd.msm import eigenspectrum
+    T = scipy.sparse.csr_matrix(M["norm_T"])
+    vals, vecs = eigenspectrum(T, n_eigs=5)
+    np.testing.assert_allclose(vals, M["eig_vals"], atol=1e-9)
+    np.testing.assert_allclose(vecs[:, 0], M["eig_vecs"][:, 0], atol=1e-9)
+
+
+def test_msm_build_at_scale():
+    """seeded 2000-state, 1e6-frame synthetic assignments: counts equal a
+    scipy construction exactly; top-10 eigenvalues equal ARPACK's to 1e-8"""
+    from enspara_amd.msm import MSM, eigenspectrum
+    rng = np.random.RandomState(5)
+    K, n_trj, L = 2000, 100, 10000
+    # banded walk inside 20 metastable blocks of 100 states with rare hops
+    # between blocks: a spectrum with gaps (a plain ring walk has eigenvalues
+    # packed at 1 - O(1/K^2) that ARPACK itself does not resolve)
+    steps = rng.choice([-3, -2, -1, 0, 0, 1, 2, 3], size=(n_trj, L))
+    inblock = (rng.randint(100, size=(n_trj, 1)) + np.cumsum(steps, axis=1)) % 100
+    hops = np.cumsum(rng.rand(n_trj, L) < 0.002, axis=1)
+    block = (rng.randint(20, size=(n_trj, 1)) + hops * 7) % 20
+    A = block * 100 + inblock
+    A[rng.rand(n_trj, L) < 0.001] = -1
+    m = MSM(lag_time=2, method="normalize", max_n_states=K)
+    m.fit(A)
+    rows, cols = [], []
+    for a in A:
+        a = a[a != -1]
+        rows.append(a[:-2])
+        cols.append(a[2:])
+    ref = scipy.sparse.coo_matrix(
+        (np.ones(sum(len(r) for r in rows), dtype=int),
+         (np.concatenate(rows), np.concatenate(cols))), shape=(K, K)).tocsr()
+    assert (m.tcounts_.tocsr() != ref).nnz == 0
+    Tref = scipy.sparse.diags(1.0 / np.asarray(ref.sum(axis=1)).ravel()) @ ref
+    assert abs(m.tprobs_.tocsr() - Tref).max() < 1e-15
+    vals, vecs = eigenspectrum(m.tprobs_, n_eigs=10)
+    want = np.linalg.eigvals(Tref.toarray())
+    want = want[np.argsort(-want.real)][:10]
+    np.testing.assert_allclose(vals, want.real, atol=1e-8)
+    np.testing.assert_allclose(m.eq_probs_, vecs[:, 0], atol=1e-9)
+    assert abs(m.eq_probs_.sum() - 1) < 1e-12

@@ -1,0 +1,88 @@
+"""Host side of the MSM eigensolver (Arnoldi / Krylov-Schur driver in
+enspara_amd/msm/transition_matrices.py) with a numpy Krylov space standing in
+for the device, against scipy and the reference's outputs."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import scipy.sparse
+import scipy.sparse.linalg
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _numpy_krylov import NumpyKrylov  # noqa: E402
+from enspara_amd.msm import transition_matrices as tm  # noqa: E402
+
+
+def _factory(A, m):
+    return NumpyKrylov(A, m)
+
+
+def _rowstoch(n, density, seed):
+    rng = np.random.RandomState(seed)
+    C = scipy.sparse.random(n, n, density=density, random_state=rng,
+                            format="csr")
+    C = C + scipy.sparse.diags(np.ones(n)) + \
+        scipy.sparse.diags(np.ones(n - 1) * 0.5, 1) + \
+        scipy.sparse.diags(np.ones(n - 1) * 0.5, -1)
+    C = scipy.sparse.csr_matrix(C)
+    w = np.asarray(C.sum(axis=1)).ravel()
+    return scipy.sparse.diags(1.0 / w) @ C
+
+
+def test_small_dense_all_eigs_matches_reference(golden_dir):
+    M = np.load(os.path.join(golden_dir, "msm_golden.npz"))
+    T = scipy.sparse.csr_matrix(M["norm_T"])
+    vals, vecs = tm.eigenspectrum(T, n_eigs=5, _space_factory=_factory)
+    np.testing.assert_allclose(vals, M["eig_vals"], atol=1e-9)
+    np.testing.assert_allclose(vecs[:, 0], M["eig_vecs"][:, 0], atol=1e-9)
+    np.testing.assert_allclose(vecs[:, 0], M["norm_eq"], atol=1e-9)
+    # other vectors: eigenvectors of T^T where the eigenvalue is real (for a
+    # complex pair the real part of the vector depends on an arbitrary phase,
+    # in the reference's output as well)
+    w = np.linalg.eigvals(M["norm_T"].T)
+    w = w[np.argsort(-w.real)][:5]
+    for i in range(1, 5):
+        if abs(w[i].imag) > 1e-12:
+            continue
+        x = vecs[:, i]
+        r = T.T @ x - vals[i] * x
+        assert np.linalg.norm(r) <= 1e-9 * np.linalg.norm(x)
+
+
+def test_three_state_matrix():
+    """reference test_msm_funcs.py:96-117 style: tiny dense input"""
+    T = np.array([[0.9, 0.1, 0.0], [0.05, 0.9, 0.05], [0.0, 0.2, 0.8]])
+    vals, vecs = tm.eigenspectrum(T, n_eigs=3, _space_factory=_factory)
+    w, v = np.linalg.eig(T.T)
+    o = np.argsort(-w.real)
+    np.testing.assert_allclose(vals, w.real[o], atol=1e-12)
+    pi = v[:, o[0]].real
+    pi /= pi.sum()
+    np.testing.assert_allclose(vecs[:, 0], pi, atol=1e-12)
+    with pytest.raises(ValueError):
+        tm.eigenspectrum(T, n_eigs=1, _space_factory=_factory)
+
+
+def test_restarted_krylov_schur_matches_arpack():
+    T = _rowstoch(3000, 0.002, 3)
+    vals, vecs = tm.eigenspectrum(T, n_eigs=8, _space_factory=_factory)
+    ref = scipy.sparse.linalg.eigs(scipy.sparse.csr_matrix(T.T), 8,
+                                   which="LR", tol=1e-12)[0]
+    ref = np.sort(ref.real)[::-1]
+    np.testing.assert_allclose(vals, ref, atol=1e-8)
+    assert abs(vals[0] - 1.0) < 1e-10
+    pi = vecs[:, 0]
+    assert abs(pi.sum() - 1) < 1e-12 and np.all(pi > -1e-12)
+    np.testing.assert_allclose(T.T @ pi, pi, atol=1e-9)
+
+
+def test_reducible_matrix_breakdown():
+    # two disconnected blocks: Arnoldi breaks down, must continue
+    A = _rowstoch(40, 0.2, 1)
+    B = _rowstoch(30, 0.2, 2)
+    T = scipy.sparse.block_diag([A, B]).tocsr()
+    vals, _ = tm.eigenspectrum(T, n_eigs=4, _space_factory=_factory)
+    w = np.sort(np.linalg.eigvals(T.toarray().T).real)[::-1]
+    np.testing.assert_allclose(vals, w[:4], atol=1e-9)
+    assert abs(vals[1] - 1.0) < 1e-10          # eigenvalue 1 twice
