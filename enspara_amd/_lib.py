@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libenspara_hip.so")
+LIB_PATH = os.environ.get("ENSPARA_HIP_LIB",
+                          os.path.join(HERE, "libenspara_hip.so"))
 
 EK_TILE = 256
 EK_OK, EK_EARG, EK_EHIP, EK_ESTATE, EK_ENOMEM = 0, -1, -2, -3, -4
@@ -33,7 +34,7 @@ SYMBOLS = [
     "ek_krylov_create", "ek_krylov_destroy", "ek_krylov_set_vector",
     "ek_krylov_get_vector", "ek_krylov_step", "ek_krylov_rotate",
     "ek_krylov_combine",
-    "ek_set_frames_per_lane", "ek_last_run_timing",
+    "ek_set_frames_per_lane", "ek_set_option", "ek_last_run_timing",
     "ek_timing_begin", "ek_timing_end",
 ]
 
@@ -112,6 +113,7 @@ def load():
     L.ek_krylov_rotate.argtypes = [vp, i32, i32, f64p, i32]
     L.ek_krylov_combine.argtypes = [vp, i32, i32, f64p, f64p]
     L.ek_set_frames_per_lane.argtypes = [vp, C.c_int]
+    L.ek_set_option.argtypes = [vp, i32, i32]
     L.ek_last_run_timing.argtypes = [vp, f32p, i32p]
     L.ek_timing_begin.argtypes = [vp, i32, i32]
     L.ek_timing_end.argtypes = [vp, f32p, i32p]

@@ -34,7 +34,14 @@ def _newer(target, deps):
     return all(os.path.getmtime(d) <= t for d in deps)
 
 
-def build(force=False, verbose=False, extra_flags=()):
+def build(force=False, verbose=False, extra_flags=(), out=None, tag=""):
+    """``out``/``tag``/``extra_flags`` build an experimental variant next to
+    the default library (tools/ only)."""
+    global OBJ, OUT
+    if out:
+        OUT = out
+        OBJ = os.path.join(HERE, "_build" + tag)
+        force = True
     os.makedirs(OBJ, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objs = []

@@ -89,6 +89,7 @@ struct ek_ctx {
     int64_t pam_frame = -1;
 
     int fpl = 0;                 // 0 = auto
+    int nt = -1;                 // non-temporal frame loads: -1 = auto
     // sampled per-launch timing of the distance kernel (bench only)
     std::vector<hipEvent_t> samp_ev;
     int samp_every = 0;
@@ -112,6 +113,16 @@ static int ek_pick_fpl(const ek_ctx *c)
     if (waves2 >= 4096)
         return 2;
     return 1;
+}
+
+// Non-temporal loads for the frame stream unless the whole shard could stay
+// resident in the 256 MiB Infinity Cache between two passes.
+static int ek_pick_nt(const ek_ctx *c)
+{
+    if (c->nt >= 0)
+        return c->nt;
+    const size_t bytes = (size_t)c->n_tiles * 3 * (size_t)c->A * EK_TILE * 4;
+    return bytes > ((size_t)192 << 20) ? 1 : 0;
 }
 
 extern "C" int ek_abi_version(void) { return EK_ABI_VERSION; }
@@ -272,6 +283,19 @@ extern "C" int ek_set_frames_per_lane(ek_ctx *c, int fpl)
     return EK_OK;
 }
 
+extern "C" int ek_set_option(ek_ctx *c, int32_t key, int32_t value)
+{
+    if (!c)
+        return ek_fail(EK_EARG, "NULL context");
+    switch (key) {
+    case 1:
+        c->nt = value < 0 ? -1 : (value ? 1 : 0);
+        return EK_OK;
+    default:
+        return ek_fail(EK_EARG, "ek_set_option: unknown key %d", key);
+    }
+}
+
 extern "C" int ek_last_run_timing(ek_ctx *c, float *ms, int32_t *launches)
 {
     if (!c)
@@ -381,7 +405,7 @@ extern "C" int ek_rmsd_to_center(ek_ctx *c, int64_t frame_index,
                                      c->stream);
     }
     EK_CHECK_LAUNCH();
-    ek_launch_step(ek_pick_fpl(c), 1, c->tiles, c->G, c->dist, c->assign,
+    ek_launch_step(ek_pick_fpl(c), 1, ek_pick_nt(c), c->tiles, c->G, c->dist, c->assign,
                    c->scratch, c->rec_tmp, 1, c->n, c->A, 0, 0.0, c->blockmax,
                    c->hist, c->ctl, c->stream);
     EK_CHECK_LAUNCH();
@@ -515,7 +539,7 @@ extern "C" int ek_kcenters_step(ek_ctx *c, const void *recs_dev, int32_t n_recs,
             2 * (size_t)c->samp_used + 1 < c->samp_ev.size();
         if (sample)
             EK_HIP(hipEventRecord(c->samp_ev[2 * c->samp_used], c->stream));
-        ek_launch_step(fpl, 0, c->tiles, c->G, c->dist, c->assign, c->scratch,
+        ek_launch_step(fpl, 0, ek_pick_nt(c), c->tiles, c->G, c->dist, c->assign, c->scratch,
                        recs, n_recs, c->n, c->A, label, dist_cutoff,
                        c->blockmax, c->hist, c->ctl, c->stream);
         EK_CHECK_LAUNCH();
@@ -804,7 +828,7 @@ extern "C" int ek_pam_propose(ek_ctx *c, int32_t cid, int64_t frame_index,
     // distances of every frame to the proposed medoid (kmedoids.py:637)
     ek_launch_record_from_frame(c->tiles, c->G, c->A, frame_index, c->goff,
                                 c->rec_tmp, c->stream);
-    ek_launch_step(ek_pick_fpl(c), 1, c->tiles, c->G, c->dist, c->assign,
+    ek_launch_step(ek_pick_fpl(c), 1, ek_pick_nt(c), c->tiles, c->G, c->dist, c->assign,
                    c->scratch, c->rec_tmp, 1, c->n, c->A, 0, 0.0, c->blockmax,
                    c->hist, c->ctl, c->stream);
     EK_CHECK_LAUNCH();

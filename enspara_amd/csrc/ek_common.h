@@ -58,7 +58,8 @@ void ek_launch_prepare_centers(const float *src_aos, int32_t count, int A,
 // one-center-vs-all distance pass.
 //   mode 0: fused k-centers step (update dist/assign, per-block arg-max)
 //   mode 1: distances only -> out_dist
-void ek_launch_step(int fpl, int mode, const float *tiles, const double *G,
+void ek_launch_step(int fpl, int mode, int nt, const float *tiles,
+                    const double *G,
                     float *dist, int32_t *assign, float *out_dist,
                     const unsigned char *recs, int n_recs, int64_t n, int A,
                     int label, double cutoff, EkBlockMax *blockmax,

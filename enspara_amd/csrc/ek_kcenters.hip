@@ -17,6 +17,10 @@
 #include "ek_common.h"
 #include "ek_qcp.h"
 
+#ifndef EK_TRIP
+#define EK_TRIP 4      // atoms per loop trip (multiple of 4)
+#endif
+
 // ---------------------------------------------------------------------------
 // arg-max helpers: larger value wins, lower index wins ties (np.argmax)
 // ---------------------------------------------------------------------------
@@ -39,32 +43,35 @@ __device__ __forceinline__ void ek_wave_argmax(float &v, uint32_t &i)
     }
 }
 
+typedef float ek_f2 __attribute__((ext_vector_type(2)));
+typedef float ek_f4 __attribute__((ext_vector_type(4)));
 template <int N> struct EkVec;
 template <> struct EkVec<1> { typedef float type; };
-template <> struct EkVec<2> { typedef float2 type; };
-template <> struct EkVec<4> { typedef float4 type; };
+template <> struct EkVec<2> { typedef ek_f2 type; };
+template <> struct EkVec<4> { typedef ek_f4 type; };
+
+// one row load of FPL consecutive frames; NT = non-temporal hint (the frame
+// stream is read once per launch and is far larger than L2 + Infinity Cache)
+template <int N, bool NT>
+__device__ __forceinline__ typename EkVec<N>::type ek_ld(const float *p)
+{
+    typedef typename EkVec<N>::type vec_t;
+    if (NT)
+        return __builtin_nontemporal_load((const vec_t *)p);
+    return *(const vec_t *)p;
+}
 
 template <int N>
 __device__ __forceinline__ void ek_unpack(const typename EkVec<N>::type &v,
-                                          float (&o)[N]);
-template <>
-__device__ __forceinline__ void ek_unpack<1>(const float &v, float (&o)[1])
+                                          float (&o)[N])
 {
-    o[0] = v;
-}
-template <>
-__device__ __forceinline__ void ek_unpack<2>(const float2 &v, float (&o)[2])
-{
-    o[0] = v.x;
-    o[1] = v.y;
-}
-template <>
-__device__ __forceinline__ void ek_unpack<4>(const float4 &v, float (&o)[4])
-{
-    o[0] = v.x;
-    o[1] = v.y;
-    o[2] = v.z;
-    o[3] = v.w;
+    if constexpr (N == 1) {
+        o[0] = v;
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            o[i] = v[i];
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -73,7 +80,7 @@ __device__ __forceinline__ void ek_unpack<4>(const float4 &v, float (&o)[4])
 //   MODE  0 = fused k-centers step, 1 = distances only
 // A wave owns frames [gw*64*FPL, (gw+1)*64*FPL); a workgroup has 4 waves.
 // ---------------------------------------------------------------------------
-template <int FPL, int MODE>
+template <int FPL, int MODE, bool NT>
 __global__ void __launch_bounds__(EK_BLOCK)
 ek_step_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
                float *__restrict__ dist, int32_t *__restrict__ assign,
@@ -120,7 +127,7 @@ ek_step_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
     const double Gc = wh->trace;
     {
         const float *wc = (const float *)(wh + 1);
-        const int A4 = (A + 3) & ~3;
+        const int A4 = (A + EK_TRIP - 1) / EK_TRIP * EK_TRIP;
         for (int j = tid; j < 3 * A4; j += EK_BLOCK)
             ctr[j] = (j < 3 * A) ? wc[j] : 0.f;
     }
@@ -151,22 +158,30 @@ ek_step_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
             for (int j = 0; j < 9; ++j)
                 s[q][j] = 0.f;
 
-        // 4 atoms per trip: 12 row loads in flight, 3 broadcast LDS reads
+        // EK_TRIP atoms per trip: 3*EK_TRIP row loads in flight, broadcast
+        // LDS reads of the center (ds_read_b128)
         const float4 *ctr4 = (const float4 *)ctr;
-        const int A4 = A & ~3;
+        const int A4 = A - A % EK_TRIP;
         int a = 0;
-        for (; a < A4; a += 4) {
-            vec_t v[12];
+        for (; a < A4; a += EK_TRIP) {
+            vec_t v[3 * EK_TRIP];
 #pragma unroll
-            for (int r = 0; r < 12; ++r)
-                v[r] = *(const vec_t *)(p + (size_t)(3 * a + r) * EK_TILE);
-            const float4 c0 = ctr4[(3 * a) / 4 + 0];
-            const float4 c1 = ctr4[(3 * a) / 4 + 1];
-            const float4 c2 = ctr4[(3 * a) / 4 + 2];
-            const float c[12] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y,
-                                 c1.z, c1.w, c2.x, c2.y, c2.z, c2.w};
+            for (int r = 0; r < 3 * EK_TRIP; ++r)
+                v[r] = ek_ld<FPL, NT>(p + (size_t)(3 * a + r) * EK_TILE);
+#ifdef EK_SCHED_BARRIER
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            float c[3 * EK_TRIP];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int q = 0; q < 3 * EK_TRIP / 4; ++q) {
+                const float4 cq = ctr4[(3 * a) / 4 + q];
+                c[4 * q + 0] = cq.x;
+                c[4 * q + 1] = cq.y;
+                c[4 * q + 2] = cq.z;
+                c[4 * q + 3] = cq.w;
+            }
+#pragma unroll
+            for (int u = 0; u < EK_TRIP; ++u) {
                 float x[FPL], y[FPL], z[FPL];
                 ek_unpack<FPL>(v[3 * u + 0], x);
                 ek_unpack<FPL>(v[3 * u + 1], y);
@@ -189,9 +204,9 @@ ek_step_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
         }
         for (; a < A; ++a) {
             float x[FPL], y[FPL], z[FPL];
-            ek_unpack<FPL>(*(const vec_t *)(p + (size_t)(3 * a + 0) * EK_TILE), x);
-            ek_unpack<FPL>(*(const vec_t *)(p + (size_t)(3 * a + 1) * EK_TILE), y);
-            ek_unpack<FPL>(*(const vec_t *)(p + (size_t)(3 * a + 2) * EK_TILE), z);
+            ek_unpack<FPL>(ek_ld<FPL, NT>(p + (size_t)(3 * a + 0) * EK_TILE), x);
+            ek_unpack<FPL>(ek_ld<FPL, NT>(p + (size_t)(3 * a + 1) * EK_TILE), y);
+            ek_unpack<FPL>(ek_ld<FPL, NT>(p + (size_t)(3 * a + 2) * EK_TILE), z);
             const float cx = ctr[3 * a + 0], cy = ctr[3 * a + 1],
                         cz = ctr[3 * a + 2];
 #pragma unroll
@@ -260,7 +275,7 @@ int ek_step_blocks(int fpl, int64_t n)
     return (int)((n + per_block - 1) / per_block);
 }
 
-template <int FPL, int MODE>
+template <int FPL, int MODE, bool NT>
 static void ek_launch_step_t(const float *tiles, const double *G, float *dist,
                              int32_t *assign, float *out_dist,
                              const unsigned char *recs, int n_recs, int64_t n,
@@ -271,22 +286,30 @@ static void ek_launch_step_t(const float *tiles, const double *G, float *dist,
     const int blocks = ek_step_blocks(FPL, n);
     if (blocks <= 0)
         return;
-    const size_t lds = (size_t)3 * ((A + 3) & ~3) * sizeof(float);
-    hipLaunchKernelGGL((ek_step_kernel<FPL, MODE>), dim3(blocks),
+    const size_t lds = (size_t)3 * ((A + EK_TRIP - 1) / EK_TRIP * EK_TRIP) * sizeof(float);
+    hipLaunchKernelGGL((ek_step_kernel<FPL, MODE, NT>), dim3(blocks),
                        dim3(EK_BLOCK), lds, s, tiles, G, dist, assign,
                        out_dist, recs, n_recs, n, A, label, cutoff, blockmax,
                        hist, ctl);
 }
 
-void ek_launch_step(int fpl, int mode, const float *tiles, const double *G,
+void ek_launch_step(int fpl, int mode, int nt, const float *tiles, const double *G,
                     float *dist, int32_t *assign, float *out_dist,
                     const unsigned char *recs, int n_recs, int64_t n, int A,
                     int label, double cutoff, EkBlockMax *blockmax,
                     EkHist *hist, EkCtl *ctl, hipStream_t s)
 {
 #define EK_GO(F, M)                                                            \
-    ek_launch_step_t<F, M>(tiles, G, dist, assign, out_dist, recs, n_recs, n,  \
-                           A, label, cutoff, blockmax, hist, ctl, s)
+    do {                                                                       \
+        if (nt)                                                                \
+            ek_launch_step_t<F, M, true>(tiles, G, dist, assign, out_dist,     \
+                                         recs, n_recs, n, A, label, cutoff,    \
+                                         blockmax, hist, ctl, s);              \
+        else                                                                   \
+            ek_launch_step_t<F, M, false>(tiles, G, dist, assign, out_dist,    \
+                                          recs, n_recs, n, A, label, cutoff,   \
+                                          blockmax, hist, ctl, s);             \
+    } while (0)
     if (mode == 0) {
         if (fpl == 4) EK_GO(4, 0);
         else if (fpl == 2) EK_GO(2, 0);

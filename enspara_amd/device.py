@@ -216,6 +216,9 @@ class FrameStore:
     def set_frames_per_lane(self, fpl):
         _lib.check(self.lib.ek_set_frames_per_lane(self._h, int(fpl)))
 
+    def set_option(self, key, value):
+        _lib.check(self.lib.ek_set_option(self._h, int(key), int(value)))
+
     def last_run_timing(self):
         ms = C.c_float()
         k = C.c_int32()

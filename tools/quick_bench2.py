@@ -1,0 +1,65 @@
+"""Scratch benchmark: assign (predict), PAM sweep, MSM build."""
+import sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from enspara_amd import synth
+from enspara_amd.device import FrameStore
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
+A = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+K = int(sys.argv[3]) if len(sys.argv) > 3 else 5000
+what = sys.argv[4] if len(sys.argv) > 4 else "assign,pam,msm"
+if "assign" in what or "pam" in what:
+    t = time.time()
+    x = synth.synth(n, A, 5000, 1)
+    print("synth %.1fs" % (time.time() - t), flush=True)
+    st = FrameStore.from_array(x)
+    st.reset_state()
+    t = time.time()
+    idx, cd, mx = st.kcenters_run(0, K, 0.0)
+    print("kcenters K=%d: %.2fs  maxdist %.4f" % (K, time.time() - t, mx), flush=True)
+if "assign" in what:
+    ctr = x[idx]
+    for kk in (64, 512, K):
+        t = time.time()
+        st.assign_nearest(ctr[:kk]); st.sync()
+        dt = time.time() - t
+        print("assign n=%d K=%d: %.3fs  %.3e pairs/s  %.1f TFLOP/s(18A flop/pair)"
+              % (n, kk, dt, n * kk / dt, n * kk * 18 * A / dt / 1e12), flush=True)
+    d, a = st.download_state()
+    # restore kcenters state for pam: labels from assign with all K centers are the kcenters labels
+if "pam" in what:
+    rs = np.random.RandomState(0)
+    st.pam_begin(idx)
+    t0 = time.time(); acc = 0; amb = 0
+    P = min(K, 300)
+    for cid in range(P):
+        m = st.pam_count_members(cid)
+        j = rs.choice(m)
+        prop = st.pam_select_member(cid, j)
+        oc, nc, na = st.pam_propose(cid, prop)
+        st.pam_commit(nc < oc); acc += nc < oc; amb += na
+    dt = time.time() - t0
+    print("pam: %d proposals %.3fs  %.3f ms/proposal  accept %d  mean ambiguous %.1f -> est. sweep of %d: %.1fs"
+          % (P, dt, dt / P * 1e3, acc, amb / P, K, dt / P * K), flush=True)
+if "msm" in what:
+    from enspara_amd.msm import assigns_to_counts, builders, eigenspectrum
+    rng = np.random.RandomState(5)
+    Ks, n_trj, L = 20000, 1000, 10000
+    steps = rng.choice([-3, -2, -1, 0, 0, 1, 2, 3], size=(n_trj, L))
+    inblock = (rng.randint(100, size=(n_trj, 1)) + np.cumsum(steps, axis=1)) % 100
+    hops = np.cumsum(rng.rand(n_trj, L) < 0.002, axis=1)
+    block = (rng.randint(Ks // 100, size=(n_trj, 1)) + hops * 7) % (Ks // 100)
+    Aa = (block * 100 + inblock).astype(np.int32)
+    Aa[rng.rand(n_trj, L) < 0.001] = -1
+    for rep in range(2):
+        t = time.time(); C = assigns_to_counts(Aa, lag_time=1, max_n_states=Ks); t1 = time.time() - t
+    t = time.time(); T = builders._row_normalize(C); t2 = time.time() - t
+    t = time.time(); vals, vecs = eigenspectrum(T, n_eigs=20); t3 = time.time() - t
+    print("msm: %d frames, %d states, nnz %d: counts %.3fs (%.2e transitions/s)  normalize %.3fs  top-20 eig %.3fs  vals[:4]=%s"
+          % (Aa.size, Ks, C.nnz, t1, Aa.size / t1, t2, t3, vals[:4]), flush=True)
+    import scipy.sparse
+    t = time.time()
+    rows = np.concatenate([a[a != -1][:-1] for a in Aa]); cols = np.concatenate([a[a != -1][1:] for a in Aa])
+    ref = scipy.sparse.coo_matrix((np.ones(len(rows), dtype=int), (rows, cols)), shape=(Ks, Ks)).tocsr()
+    print("  scipy counts %.3fs  equal: %s" % (time.time() - t, (C.tocsr() != ref).nnz == 0))
