@@ -29,7 +29,7 @@ SYMBOLS = [
     "ek_history_download", "ek_history_reset",
     "ek_assign_nearest",
     "ek_pam_begin", "ek_pam_count_members", "ek_pam_select_member",
-    "ek_pam_propose", "ek_pam_commit",
+    "ek_pam_propose", "ek_pam_propose_member", "ek_pam_commit",
     "ek_msm_counts", "ek_msm_row_normalize",
     "ek_krylov_create", "ek_krylov_destroy", "ek_krylov_set_vector",
     "ek_krylov_get_vector", "ek_krylov_step", "ek_krylov_rotate",
@@ -100,6 +100,7 @@ def load():
     L.ek_pam_count_members.argtypes = [vp, i32, i64p]
     L.ek_pam_select_member.argtypes = [vp, i32, i64, i64p]
     L.ek_pam_propose.argtypes = [vp, i32, i64, f64p, f64p, i64p]
+    L.ek_pam_propose_member.argtypes = [vp, i32, i64, i64p, f64p, f64p, i64p]
     L.ek_pam_commit.argtypes = [vp, C.c_int]
     L.ek_msm_counts.argtypes = [C.c_int, i32p, i64p, i64, i32, i32, i32, i64,
                                 i32p, i32p, i64p, i64p]

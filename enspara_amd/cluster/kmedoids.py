@@ -168,10 +168,10 @@ def _pam_sweep_device(store, medoid_inds, proposals, random_state):
             # RandomState.choice(state_inds) == state_inds[choice(len)]
             # (raises ValueError on an empty cluster, like the reference)
             j = random_state.choice(m)                       # :514
-            prop = store.pam_select_member(cid, j)
+            prop, old_cost, new_cost, n_amb = store.pam_propose_member(cid, j)
         else:
             prop = int(proposals[cid])
-        old_cost, new_cost, n_amb = store.pam_propose(cid, prop)
+            old_cost, new_cost, n_amb = store.pam_propose(cid, prop)
         accept = new_cost < old_cost                         # :683
         store.pam_commit(accept)
         if accept:

@@ -84,8 +84,13 @@ struct ek_ctx {
     float *med_aos = nullptr;        // [K+1][3A]; row K = saved row
     double *med_G = nullptr;
     int64_t *med_idx = nullptr;      // [K+1] device copy of medoid frames
+    float *ambt = nullptr;           // [3A][ambt_cap] compacted ambiguous frames
+    double *ambG = nullptr;
+    int64_t ambt_cap = 0;
     int32_t med_K = 0, med_cap = 0;
     int32_t pam_cid = -1;            // proposal pending commit
+    int32_t cnt_cid = -1;            // cluster of the last member count
+    int64_t cnt_m = 0;
     int64_t pam_frame = -1;
 
     int fpl = 0;                 // 0 = auto
@@ -172,6 +177,8 @@ static int ek_free_all(ek_ctx *c)
     (void)hipFree(c->med_aos);
     (void)hipFree(c->med_G);
     (void)hipFree(c->med_idx);
+    (void)hipFree(c->ambt);
+    (void)hipFree(c->ambG);
     for (hipEvent_t e : c->samp_ev)
         (void)hipEventDestroy(e);
     if (c->ev0)
@@ -393,8 +400,8 @@ extern "C" int ek_rmsd_to_center(ek_ctx *c, int64_t frame_index,
         if (frame_index >= c->n)
             return ek_fail(EK_EARG, "ek_rmsd_to_center: frame %lld >= %lld",
                            (long long)frame_index, (long long)c->n);
-        ek_launch_record_from_frame(c->tiles, c->G, c->A, frame_index, c->goff,
-                                    c->rec_tmp, c->stream);
+        ek_launch_record_from_frame(c->tiles, c->G, c->A, frame_index, nullptr,
+                                    c->goff, c->rec_tmp, c->stream);
     } else {
         if (!center_xyz)
             return ek_fail(EK_EARG, "ek_rmsd_to_center: no center given");
@@ -785,6 +792,8 @@ extern "C" int ek_pam_count_members(ek_ctx *c, int32_t cid, int64_t *count)
     EK_HIP(hipMemcpyAsync(count, c->sel, sizeof(int64_t), hipMemcpyDeviceToHost,
                           c->stream));
     EK_HIP(hipStreamSynchronize(c->stream));
+    c->cnt_cid = cid;
+    c->cnt_m = *count;
     return EK_OK;
 }
 
@@ -809,60 +818,71 @@ extern "C" int ek_pam_select_member(ek_ctx *c, int32_t cid, int64_t j,
     return EK_OK;
 }
 
-extern "C" int ek_pam_propose(ek_ctx *c, int32_t cid, int64_t frame_index,
-                              double *old_cost, double *new_cost,
-                              int64_t *n_ambiguous)
+// shared tail of the two proposal entry points.  The proposed frame's index
+// is either `frame_index` (>= 0) or already on the device in c->sel[1].
+// max_amb bounds the ambiguous set (it is a subset of cluster cid's members),
+// so no host round trip is needed to size the follow-up launches.
+static int ek_pam_propose_impl(ek_ctx *c, int32_t cid, int64_t frame_index,
+                               int64_t max_amb, int64_t *frame_out,
+                               double *old_cost, double *new_cost,
+                               int64_t *n_ambiguous)
 {
-    if (!c)
-        return ek_fail(EK_EARG, "NULL context");
-    if (!c->ndist || c->med_K < 1)
-        return ek_fail(EK_ESTATE, "ek_pam_propose: call ek_pam_begin first");
-    if (c->pam_cid >= 0)
-        return ek_fail(EK_ESTATE, "ek_pam_propose: previous proposal not "
-                                  "committed");
-    if (cid < 0 || cid >= c->med_K || frame_index < 0 || frame_index >= c->n)
-        return ek_fail(EK_EARG, "ek_pam_propose: cid=%d frame=%lld out of range",
-                       cid, (long long)frame_index);
-    EK_HIP(hipSetDevice(c->device));
     const int K = c->med_K;
+    const int64_t *idx_dev = nullptr;
+    if (max_amb > c->ambt_cap) {
+        EK_HIP(hipStreamSynchronize(c->stream));
+        (void)hipFree(c->ambt);
+        (void)hipFree(c->ambG);
+        c->ambt = nullptr;
+        c->ambG = nullptr;
+        c->ambt_cap = 0;
+        const int64_t cap = std::max<int64_t>(
+            4096, (max_amb * 5 / 4 + EK_BLOCK - 1) / EK_BLOCK * EK_BLOCK);
+        EK_HIP(hipMalloc((void **)&c->ambt,
+                         (size_t)cap * 3 * c->A * sizeof(float)));
+        EK_HIP(hipMalloc((void **)&c->ambG, (size_t)cap * sizeof(double)));
+        c->ambt_cap = cap;
+    }
+    if (frame_index >= 0) {
+        EK_HIP(hipMemcpyAsync(c->med_idx + K, &frame_index, sizeof(int64_t),
+                              hipMemcpyHostToDevice, c->stream));
+    } else {
+        EK_HIP(hipMemcpyAsync(c->med_idx + K, c->sel + 1, sizeof(int64_t),
+                              hipMemcpyDeviceToDevice, c->stream));
+    }
+    idx_dev = c->med_idx + K;
     // distances of every frame to the proposed medoid (kmedoids.py:637)
-    ek_launch_record_from_frame(c->tiles, c->G, c->A, frame_index, c->goff,
+    ek_launch_record_from_frame(c->tiles, c->G, c->A, 0, idx_dev, c->goff,
                                 c->rec_tmp, c->stream);
-    ek_launch_step(ek_pick_fpl(c), 1, ek_pick_nt(c), c->tiles, c->G, c->dist, c->assign,
-                   c->scratch, c->rec_tmp, 1, c->n, c->A, 0, 0.0, c->blockmax,
-                   c->hist, c->ctl, c->stream);
+    ek_launch_step(ek_pick_fpl(c), 1, ek_pick_nt(c), c->tiles, c->G, c->dist,
+                   c->assign, c->scratch, c->rec_tmp, 1, c->n, c->A, 0, 0.0,
+                   c->blockmax, c->hist, c->ctl, c->stream);
     EK_CHECK_LAUNCH();
     // trial medoid table: save row cid in row K, put the proposal in row cid
     ek_launch_copy_row(c->med_aos, c->med_G, c->A, cid, K, c->stream);
-    EK_HIP(hipMemcpyAsync(c->med_idx + K, &frame_index, sizeof(int64_t),
-                          hipMemcpyHostToDevice, c->stream));
-    ek_launch_gather_frames(c->tiles, c->G, c->A, c->med_idx + K, 1, cid,
-                            c->med_aos, c->med_G, c->stream);
+    ek_launch_gather_frames(c->tiles, c->G, c->A, idx_dev, 1, cid, c->med_aos,
+                            c->med_G, c->stream);
     EK_HIP(hipMemsetAsync(c->amb_count, 0, sizeof(unsigned int), c->stream));
     ek_launch_pam_classify(c->dist, c->assign, c->scratch, c->n, cid, c->ndist,
                            c->nassign, c->amb, c->amb_best, c->amb_count,
                            c->stream);
-    EK_CHECK_LAUNCH();
-    unsigned int n_amb = 0;
-    EK_HIP(hipMemcpyAsync(&n_amb, c->amb_count, sizeof(n_amb),
-                          hipMemcpyDeviceToHost, c->stream));
-    EK_HIP(hipStreamSynchronize(c->stream));
-    if (n_amb) {
-        const size_t lds = (size_t)3 * c->A * 8 * sizeof(float);
-        if (lds > 160 * 1024)
-            return ek_fail(EK_EARG, "ek_pam_propose: %d atoms exceed the LDS "
-                                    "center tile", c->A);
-        ek_launch_subset_assign(c->tiles, c->G, c->A, c->amb, n_amb, c->med_aos,
-                                c->med_G, K, c->amb_best, c->stream);
-        ek_launch_pam_scatter(c->amb, c->amb_best, n_amb, c->ndist, c->nassign,
-                              c->stream);
-        EK_CHECK_LAUNCH();
-    }
+    ek_launch_subset_assign(c->tiles, c->G, c->A, c->amb, c->amb_count, max_amb,
+                            c->ambt, c->ambG, c->ambt_cap, c->med_aos, c->med_G,
+                            K, c->amb_best, c->stream);
+    ek_launch_pam_scatter(c->amb, c->amb_best, c->amb_count, max_amb, c->ndist,
+                          c->nassign, c->stream);
     ek_launch_sumsq2(c->dist, c->ndist, c->n, c->sq_part, c->sq_out, c->stream);
     EK_CHECK_LAUNCH();
     double sums[2] = {0.0, 0.0};
+    unsigned int n_amb = 0;
+    int64_t fidx = frame_index;
     EK_HIP(hipMemcpyAsync(sums, c->sq_out, sizeof(sums), hipMemcpyDeviceToHost,
                           c->stream));
+    EK_HIP(hipMemcpyAsync(&n_amb, c->amb_count, sizeof(n_amb),
+                          hipMemcpyDeviceToHost, c->stream));
+    if (frame_index < 0)
+        EK_HIP(hipMemcpyAsync(&fidx, c->med_idx + K, sizeof(int64_t),
+                              hipMemcpyDeviceToHost, c->stream));
     EK_HIP(hipStreamSynchronize(c->stream));
     if (old_cost)
         *old_cost = sums[0] / (double)c->n;
@@ -870,9 +890,74 @@ extern "C" int ek_pam_propose(ek_ctx *c, int32_t cid, int64_t frame_index,
         *new_cost = sums[1] / (double)c->n;
     if (n_ambiguous)
         *n_ambiguous = n_amb;
+    if (frame_out)
+        *frame_out = fidx;
     c->pam_cid = cid;
-    c->pam_frame = frame_index;
+    c->pam_frame = fidx;
     return EK_OK;
+}
+
+static int ek_pam_precheck(ek_ctx *c, int32_t cid, const char *who)
+{
+    if (!c)
+        return ek_fail(EK_EARG, "NULL context");
+    if (!c->ndist || c->med_K < 1)
+        return ek_fail(EK_ESTATE, "%s: call ek_pam_begin first", who);
+    if (c->pam_cid >= 0)
+        return ek_fail(EK_ESTATE, "%s: previous proposal not committed", who);
+    if (cid < 0 || cid >= c->med_K)
+        return ek_fail(EK_EARG, "%s: cid=%d out of range", who, cid);
+    if ((size_t)3 * c->A * 8 * sizeof(float) > 64 * 1024)
+        return ek_fail(EK_EARG, "%s: %d atoms exceed the LDS center tile", who,
+                       c->A);
+    return EK_OK;
+}
+
+extern "C" int ek_pam_propose(ek_ctx *c, int32_t cid, int64_t frame_index,
+                              double *old_cost, double *new_cost,
+                              int64_t *n_ambiguous)
+{
+    int rc = ek_pam_precheck(c, cid, "ek_pam_propose");
+    if (rc)
+        return rc;
+    if (frame_index < 0 || frame_index >= c->n)
+        return ek_fail(EK_EARG, "ek_pam_propose: frame %lld out of range",
+                       (long long)frame_index);
+    EK_HIP(hipSetDevice(c->device));
+    int64_t m = 0;
+    if (c->cnt_cid == cid) {
+        m = c->cnt_m;
+    } else {
+        rc = ek_pam_count_members(c, cid, &m);
+        if (rc)
+            return rc;
+    }
+    c->cnt_cid = -1;
+    return ek_pam_propose_impl(c, cid, frame_index, m, nullptr, old_cost,
+                               new_cost, n_ambiguous);
+}
+
+extern "C" int ek_pam_propose_member(ek_ctx *c, int32_t cid, int64_t j,
+                                     int64_t *frame_index, double *old_cost,
+                                     double *new_cost, int64_t *n_ambiguous)
+{
+    int rc = ek_pam_precheck(c, cid, "ek_pam_propose_member");
+    if (rc)
+        return rc;
+    if (c->cnt_cid != cid)
+        return ek_fail(EK_ESTATE, "ek_pam_propose_member: call "
+                                  "ek_pam_count_members(%d) first", cid);
+    if (j < 0 || j >= c->cnt_m)
+        return ek_fail(EK_EARG, "ek_pam_propose_member: member %lld of %lld",
+                       (long long)j, (long long)c->cnt_m);
+    EK_HIP(hipSetDevice(c->device));
+    ek_launch_select_member(c->assign, c->n, cid, c->scan, j, c->sel + 1,
+                            c->stream);
+    EK_CHECK_LAUNCH();
+    const int64_t m = c->cnt_m;
+    c->cnt_cid = -1;
+    return ek_pam_propose_impl(c, cid, -1, m, frame_index, old_cost, new_cost,
+                               n_ambiguous);
 }
 
 extern "C" int ek_pam_commit(ek_ctx *c, int accept)
@@ -891,5 +976,6 @@ extern "C" int ek_pam_commit(ek_ctx *c, int accept)
         EK_CHECK_LAUNCH();
     }
     c->pam_cid = -1;
+    c->cnt_cid = -1;
     return EK_OK;
 }

@@ -73,10 +73,12 @@ void ek_launch_pick(const EkBlockMax *blockmax, int n_blocks,
                     int64_t n, int A, int64_t global_offset,
                     unsigned char *rec, EkCtl *ctl, hipStream_t s);
 
-// record from a given local frame (center = frame index)
+// record from a given local frame (center = frame index; idx_dev != nullptr:
+// the index is read from device memory instead)
 void ek_launch_record_from_frame(const float *tiles, const double *G, int A,
-                                 int64_t local_idx, int64_t global_offset,
-                                 unsigned char *rec, hipStream_t s);
+                                 int64_t local_idx, const int64_t *idx_dev,
+                                 int64_t global_offset, unsigned char *rec,
+                                 hipStream_t s);
 // record from centred center-major coordinates (center = external structure)
 void ek_launch_record_from_center(const float *center_aos, const double *Gc,
                                   int A, unsigned char *rec, hipStream_t s);
@@ -106,14 +108,18 @@ void ek_launch_pam_classify(const float *dist, const int32_t *assign,
                             float *ndist, int32_t *nassign, uint32_t *amb,
                             unsigned long long *amb_best,
                             unsigned int *amb_count, hipStream_t s);
+// n_amb is read on the device; max_amb (a host-side upper bound) sizes the grid
+// ambt [3A][cap] / ambG [cap]: scratch for the compacted frames, cap >= max_amb
 void ek_launch_subset_assign(const float *tiles, const double *G, int A,
-                             const uint32_t *amb, unsigned int n_amb,
-                             const float *centers, const double *Gc, int K,
+                             const uint32_t *amb, const unsigned int *n_amb,
+                             int64_t max_amb, float *ambt, double *ambG,
+                             int64_t cap, const float *centers,
+                             const double *Gc, int K,
                              unsigned long long *amb_best, hipStream_t s);
 void ek_launch_pam_scatter(const uint32_t *amb,
                            const unsigned long long *amb_best,
-                           unsigned int n_amb, float *ndist, int32_t *nassign,
-                           hipStream_t s);
+                           const unsigned int *n_amb, int64_t max_amb,
+                           float *ndist, int32_t *nassign, hipStream_t s);
 #define EK_SUMSQ_PART_DOUBLES 2048
 void ek_launch_sumsq2(const float *a, const float *b, int64_t n, double *part,
                       double *out, hipStream_t s);

@@ -421,9 +421,12 @@ void ek_launch_pick(const EkBlockMax *blockmax, int n_blocks,
 __global__ void __launch_bounds__(EK_BLOCK)
 ek_record_from_frame_kernel(const float *__restrict__ tiles,
                             const double *__restrict__ G, int A, int64_t idx,
+                            const int64_t *__restrict__ idx_dev,
                             int64_t global_offset,
                             unsigned char *__restrict__ rec)
 {
+    if (idx_dev)
+        idx = *idx_dev;
     EkRecHdr *h = (EkRecHdr *)rec;
     float *coords = (float *)(h + 1);
     if (threadIdx.x == 0) {
@@ -440,11 +443,12 @@ ek_record_from_frame_kernel(const float *__restrict__ tiles,
 }
 
 void ek_launch_record_from_frame(const float *tiles, const double *G, int A,
-                                 int64_t local_idx, int64_t global_offset,
-                                 unsigned char *rec, hipStream_t s)
+                                 int64_t local_idx, const int64_t *idx_dev,
+                                 int64_t global_offset, unsigned char *rec,
+                                 hipStream_t s)
 {
     hipLaunchKernelGGL(ek_record_from_frame_kernel, dim3(1), dim3(EK_BLOCK), 0,
-                       s, tiles, G, A, local_idx, global_offset, rec);
+                       s, tiles, G, A, local_idx, idx_dev, global_offset, rec);
 }
 
 __global__ void __launch_bounds__(EK_BLOCK)

@@ -204,10 +204,32 @@ void ek_launch_pam_classify(const float *dist, const int32_t *assign,
 // independent of the order the chunks finish in.
 #define PCT 8
 
+// compact the listed frames into a frame-minor block ambt[3A][cap] (+ traces)
+// so that the pair kernel below reads them coalesced
 __global__ void __launch_bounds__(EK_BLOCK)
-ek_subset_assign_kernel(const float *__restrict__ tiles,
-                        const double *__restrict__ G, int A,
-                        const uint32_t *__restrict__ amb, unsigned int n_amb,
+ek_gather_amb_kernel(const float *__restrict__ tiles,
+                     const double *__restrict__ G, int A,
+                     const uint32_t *__restrict__ amb,
+                     const unsigned int *__restrict__ n_amb_p, int64_t cap,
+                     float *__restrict__ ambt, double *__restrict__ ambG)
+{
+    // one workgroup per listed frame: its 3A row loads go out in parallel
+    const unsigned int i = blockIdx.x;
+    if (i >= *n_amb_p)
+        return;
+    const uint32_t f = amb[i];
+    const float *p = tiles + (size_t)(f / EK_TILE) * 3 * (size_t)A * EK_TILE +
+                     (f % EK_TILE);
+    for (int r = threadIdx.x; r < 3 * A; r += EK_BLOCK)
+        ambt[(size_t)r * cap + i] = p[(size_t)r * EK_TILE];
+    if (threadIdx.x == 0)
+        ambG[i] = G[f];
+}
+
+__global__ void __launch_bounds__(EK_BLOCK)
+ek_subset_assign_kernel(const float *__restrict__ ambt,
+                        const double *__restrict__ ambG, int A, int64_t cap,
+                        const unsigned int *__restrict__ n_amb_p,
                         const float *__restrict__ centers,
                         const double *__restrict__ Gc, int K,
                         unsigned long long *__restrict__ amb_best)
@@ -215,22 +237,24 @@ ek_subset_assign_kernel(const float *__restrict__ tiles,
     extern __shared__ __attribute__((aligned(16))) float ctile[];
     __shared__ double gtile[PCT];
     const int tid = threadIdx.x;
+    const unsigned int n_amb = *n_amb_p;
+    if (blockIdx.x * EK_BLOCK >= n_amb)
+        return;                            // whole workgroup past the list
     const unsigned int i = blockIdx.x * EK_BLOCK + tid;
     const int k0 = blockIdx.y * PCT;
     const int kc = (K - k0 < PCT) ? (K - k0) : PCT;
+    // ctile[a][c][k]; global reads run along each center's row (coalesced)
     for (int j = tid; j < 3 * A * PCT; j += EK_BLOCK) {
-        const int a = j / (3 * PCT), rem = j % (3 * PCT);
-        const int c = rem / 3, k = rem % 3;
-        ctile[j] = (c < kc) ? centers[(size_t)(k0 + c) * 3 * A + 3 * a + k] : 0.f;
+        const int c = j / (3 * A), r = j % (3 * A);
+        ctile[(r / 3) * (3 * PCT) + c * 3 + (r % 3)] =
+            (c < kc) ? centers[(size_t)(k0 + c) * 3 * A + r] : 0.f;
     }
     if (tid < PCT)
         gtile[tid] = (tid < kc) ? Gc[k0 + tid] : 0.0;
     __syncthreads();
     if (i >= n_amb)
         return;
-    const uint32_t f = amb[i];
-    const float *p = tiles + (size_t)(f / EK_TILE) * 3 * (size_t)A * EK_TILE +
-                     (f % EK_TILE);
+    const float *p = ambt + i;
     float s[PCT][9];
 #pragma unroll
     for (int c = 0; c < PCT; ++c)
@@ -238,10 +262,11 @@ ek_subset_assign_kernel(const float *__restrict__ tiles,
         for (int j = 0; j < 9; ++j)
             s[c][j] = 0.f;
     const float4 *ct4 = (const float4 *)ctile;
+#pragma unroll 4
     for (int a = 0; a < A; ++a) {
-        const float x = p[(size_t)(3 * a + 0) * EK_TILE];
-        const float y = p[(size_t)(3 * a + 1) * EK_TILE];
-        const float z = p[(size_t)(3 * a + 2) * EK_TILE];
+        const float x = p[(size_t)(3 * a + 0) * cap];
+        const float y = p[(size_t)(3 * a + 1) * cap];
+        const float z = p[(size_t)(3 * a + 2) * cap];
         float cc[3 * PCT];
 #pragma unroll
         for (int q = 0; q < 3 * PCT / 4; ++q) {
@@ -266,7 +291,7 @@ ek_subset_assign_kernel(const float *__restrict__ tiles,
             s[c][8] = __builtin_fmaf(z, cz, s[c][8]);
         }
     }
-    const double Gf = G[f];
+    const double Gf = ambG[i];
     unsigned long long best = ~0ull;
 #pragma unroll
     for (int c = 0; c < PCT; ++c) {
@@ -283,26 +308,32 @@ ek_subset_assign_kernel(const float *__restrict__ tiles,
 }
 
 void ek_launch_subset_assign(const float *tiles, const double *G, int A,
-                             const uint32_t *amb, unsigned int n_amb,
-                             const float *centers, const double *Gc, int K,
+                             const uint32_t *amb, const unsigned int *n_amb,
+                             int64_t max_amb, float *ambt, double *ambG,
+                             int64_t cap, const float *centers,
+                             const double *Gc, int K,
                              unsigned long long *amb_best, hipStream_t s)
 {
-    if (n_amb == 0 || K <= 0)
+    if (max_amb <= 0 || K <= 0)
         return;
-    const dim3 grid((n_amb + EK_BLOCK - 1) / EK_BLOCK, (K + PCT - 1) / PCT);
+    const unsigned gx = (unsigned)((max_amb + EK_BLOCK - 1) / EK_BLOCK);
+    hipLaunchKernelGGL(ek_gather_amb_kernel, dim3((unsigned)max_amb),
+                       dim3(EK_BLOCK), 0, s, tiles, G, A, amb, n_amb, cap, ambt,
+                       ambG);
+    const dim3 grid(gx, (K + PCT - 1) / PCT);
     const size_t lds = (size_t)3 * A * PCT * sizeof(float);
     hipLaunchKernelGGL(ek_subset_assign_kernel, grid, dim3(EK_BLOCK), lds, s,
-                       tiles, G, A, amb, n_amb, centers, Gc, K, amb_best);
+                       ambt, ambG, A, cap, n_amb, centers, Gc, K, amb_best);
 }
 
 __global__ void __launch_bounds__(EK_BLOCK)
 ek_pam_scatter_kernel(const uint32_t *__restrict__ amb,
                       const unsigned long long *__restrict__ amb_best,
-                      unsigned int n_amb, float *__restrict__ ndist,
-                      int32_t *__restrict__ nassign)
+                      const unsigned int *__restrict__ n_amb_p,
+                      float *__restrict__ ndist, int32_t *__restrict__ nassign)
 {
     const unsigned int i = blockIdx.x * EK_BLOCK + threadIdx.x;
-    if (i >= n_amb)
+    if (i >= *n_amb_p)
         return;
     const unsigned long long key = amb_best[i];
     const uint32_t f = amb[i];
@@ -312,14 +343,15 @@ ek_pam_scatter_kernel(const uint32_t *__restrict__ amb,
 
 void ek_launch_pam_scatter(const uint32_t *amb,
                            const unsigned long long *amb_best,
-                           unsigned int n_amb, float *ndist, int32_t *nassign,
-                           hipStream_t s)
+                           const unsigned int *n_amb, int64_t max_amb,
+                           float *ndist, int32_t *nassign, hipStream_t s)
 {
-    if (n_amb == 0)
+    if (max_amb <= 0)
         return;
     hipLaunchKernelGGL(ek_pam_scatter_kernel,
-                       dim3((n_amb + EK_BLOCK - 1) / EK_BLOCK), dim3(EK_BLOCK),
-                       0, s, amb, amb_best, n_amb, ndist, nassign);
+                       dim3((unsigned)((max_amb + EK_BLOCK - 1) / EK_BLOCK)),
+                       dim3(EK_BLOCK), 0, s, amb, amb_best, n_amb, ndist,
+                       nassign);
 }
 
 // ---- cost: sum of squares in float64, fixed reduction order -----------------------

@@ -181,6 +181,16 @@ class FrameStore:
             C.byref(na)))
         return oc.value, nc.value, na.value
 
+    def pam_propose_member(self, cid, j):
+        """Propose the j-th member of cluster cid (after pam_count_members).
+        -> (frame index, old cost, new cost, number of ambiguous frames)"""
+        oc, nc = C.c_double(), C.c_double()
+        na, fi = C.c_int64(), C.c_int64()
+        _lib.check(self.lib.ek_pam_propose_member(
+            self._h, int(cid), int(j), C.byref(fi), C.byref(oc), C.byref(nc),
+            C.byref(na)))
+        return fi.value, oc.value, nc.value, na.value
+
     def pam_commit(self, accept):
         _lib.check(self.lib.ek_pam_commit(self._h, 1 if accept else 0))
 

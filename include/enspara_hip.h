@@ -173,6 +173,12 @@ int ek_pam_select_member(ek_ctx *ctx, int32_t cid, int64_t j,
                          int64_t *frame_index);
 int ek_pam_propose(ek_ctx *ctx, int32_t cid, int64_t frame_index,
                    double *old_cost, double *new_cost, int64_t *n_ambiguous);
+/* ek_pam_select_member + ek_pam_propose in one call (the selected frame index
+ * never leaves the device before the final read-back): propose the j-th member
+ * of cluster cid; needs ek_pam_count_members(cid) immediately before. */
+int ek_pam_propose_member(ek_ctx *ctx, int32_t cid, int64_t j,
+                          int64_t *frame_index, double *old_cost,
+                          double *new_cost, int64_t *n_ambiguous);
 int ek_pam_commit(ek_ctx *ctx, int accept);
 
 /* ---- MSM construction (secondary kernel) -------------------------------------

@@ -36,8 +36,7 @@ if "pam" in what:
     for cid in range(P):
         m = st.pam_count_members(cid)
         j = rs.choice(m)
-        prop = st.pam_select_member(cid, j)
-        oc, nc, na = st.pam_propose(cid, prop)
+        prop, oc, nc, na = st.pam_propose_member(cid, j)
         st.pam_commit(nc < oc); acc += nc < oc; amb += na
     dt = time.time() - t0
     print("pam: %d proposals %.3fs  %.3f ms/proposal  accept %d  mean ambiguous %.1f -> est. sweep of %d: %.1fs"
