@@ -714,6 +714,9 @@ extern "C" int ek_assign_nearest(ek_ctx *c, const float *centers_xyz,
         return ek_fail(EK_ESTATE, "ek_assign_nearest: no frames loaded");
     if (n_centers < 0)
         return ek_fail(EK_EARG, "ek_assign_nearest: negative n_centers");
+    if ((size_t)3 * c->A * 8 * sizeof(float) > 150 * 1024)
+        return ek_fail(EK_EARG, "ek_assign_nearest: %d atoms exceed the LDS "
+                                "center tile (limit 1600)", c->A);
     EK_HIP(hipSetDevice(c->device));
     if (n_centers > 0) {
         int rc = ek_upload_centers(c, centers_xyz, n_centers);
@@ -907,9 +910,9 @@ static int ek_pam_precheck(ek_ctx *c, int32_t cid, const char *who)
         return ek_fail(EK_ESTATE, "%s: previous proposal not committed", who);
     if (cid < 0 || cid >= c->med_K)
         return ek_fail(EK_EARG, "%s: cid=%d out of range", who, cid);
-    if ((size_t)3 * c->A * 8 * sizeof(float) > 64 * 1024)
-        return ek_fail(EK_EARG, "%s: %d atoms exceed the LDS center tile", who,
-                       c->A);
+    if ((size_t)3 * c->A * 8 * sizeof(float) > 150 * 1024)
+        return ek_fail(EK_EARG, "%s: %d atoms exceed the LDS center tile "
+                                "(limit 1600)", who, c->A);
     return EK_OK;
 }
 

@@ -114,6 +114,10 @@ void ek_launch_assign(const float *tiles, const double *G, int64_t n, int A,
         return;
     const int64_t blocks = (n + EK_BLOCK - 1) / EK_BLOCK;
     const size_t lds = (size_t)3 * A * CT * sizeof(float);
+    if (lds > 48 * 1024)   // beyond the default dynamic-LDS limit (<= 160 KiB/CU)
+        (void)hipFuncSetAttribute((const void *)ek_assign_kernel,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
     hipLaunchKernelGGL(ek_assign_kernel, dim3((unsigned)blocks), dim3(EK_BLOCK),
                        lds, s, tiles, G, n, A, centers_aos, Gc, K, dist,
                        assign);

@@ -322,6 +322,10 @@ void ek_launch_subset_assign(const float *tiles, const double *G, int A,
                        ambG);
     const dim3 grid(gx, (K + PCT - 1) / PCT);
     const size_t lds = (size_t)3 * A * PCT * sizeof(float);
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute((const void *)ek_subset_assign_kernel,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
     hipLaunchKernelGGL(ek_subset_assign_kernel, grid, dim3(EK_BLOCK), lds, s,
                        ambt, ambG, A, cap, n_amb, centers, Gc, K, amb_best);
 }

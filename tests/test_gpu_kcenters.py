@@ -109,3 +109,42 @@ def test_kcenters_warm_start(ocl):
     assert list(r.center_indices) == [int(i) for i in inds]
     np.testing.assert_array_equal(r.assignments, a)
     np.testing.assert_array_equal(r.distances, d)
+
+
+def test_large_atom_counts(qcp):
+    """LDS center tiles beyond the 48 KiB default (assign) and long rows"""
+    from enspara_amd.cluster.util import assign_to_nearest_center
+    x = synth.synth(300, 900, 4, seed=40)
+    ctrs = synth.synth(11, 900, 11, seed=41)
+    P = qcp.Prepared(x)
+    with _store(x) as st:
+        np.testing.assert_array_equal(st.rmsd_to_frame(7), P.rmsd_to_frame(7))
+    cc, Gc = qcp.center_and_trace(ctrs)
+    wa, wd = qcp.assign_nearest(P.c, P.G, cc, Gc)
+    a, d = assign_to_nearest_center(x, [c for c in ctrs], "rmsd")
+    np.testing.assert_array_equal(a, wa.astype(np.int64))
+    np.testing.assert_array_equal(d, wd.astype(np.float64))
+
+
+def test_sampled_parity_at_scale(qcp):
+    """200k frames x 300 atoms, 64 centers: every center index and a sample
+    of 2000 frames (label = arg-min over all centers, distance bit-equal)
+    against the checker"""
+    from enspara_amd.cluster.kcenters import kcenters
+    n, A, K = 200_000, 300, 64
+    x = synth.synth(n, A, 500, seed=77)
+    r = kcenters(x, "rmsd", n_clusters=K)
+    assert len(set(r.center_indices)) == K and r.center_indices[0] == 0
+    rng = np.random.RandomState(0)
+    sample = np.unique(np.concatenate([rng.randint(0, n, 2000),
+                                       np.array(r.center_indices)]))
+    cc, Gc = qcp.center_and_trace(x[r.center_indices])
+    cs, Gs = qcp.center_and_trace(x[sample])
+    wa, wd = qcp.assign_nearest(cs, Gs, cc, Gc)
+    np.testing.assert_array_equal(r.assignments[sample], wa)
+    np.testing.assert_array_equal(r.distances[sample], wd.astype(np.float64))
+    # farthest-point property: each center was at distance >= the final
+    # maximum from all earlier centers, and the final max is attained
+    assert r.distances.max() == r.distances[np.argmax(r.distances)]
+    for k, i in enumerate(r.center_indices):
+        assert r.assignments[i] == k
