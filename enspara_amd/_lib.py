@@ -33,7 +33,7 @@ SYMBOLS = [
     "ek_msm_counts", "ek_msm_row_normalize",
     "ek_krylov_create", "ek_krylov_destroy", "ek_krylov_set_vector",
     "ek_krylov_get_vector", "ek_krylov_step", "ek_krylov_rotate",
-    "ek_krylov_combine",
+    "ek_krylov_combine", "ek_krylov_expand",
     "ek_set_frames_per_lane", "ek_set_option", "ek_last_run_timing",
     "ek_timing_begin", "ek_timing_end",
 ]
@@ -113,6 +113,7 @@ def load():
     L.ek_krylov_step.argtypes = [vp, i32, i32, f64p]
     L.ek_krylov_rotate.argtypes = [vp, i32, i32, f64p, i32]
     L.ek_krylov_combine.argtypes = [vp, i32, i32, f64p, f64p]
+    L.ek_krylov_expand.argtypes = [vp, i32, i32, f64p, i32]
     L.ek_set_frames_per_lane.argtypes = [vp, C.c_int]
     L.ek_set_option.argtypes = [vp, i32, i32]
     L.ek_last_run_timing.argtypes = [vp, f32p, i32p]

@@ -31,6 +31,7 @@ struct ek_krylov {
     double *tmp = nullptr;    // [m_max + 1][n] scratch for basis rotations
     double *h = nullptr;      // [m_max + 2] coefficients of one pass
     double *q = nullptr;      // [(m_max+1) * (m_max+1)] rotation matrix
+    double *hcols = nullptr;  // [m_max][m_max + 2] Hessenberg columns (expand)
 };
 
 #define KR_HIP(call)                                                           \
@@ -142,6 +143,7 @@ extern "C" int ek_krylov_destroy(ek_krylov *k)
     (void)hipFree(k->tmp);
     (void)hipFree(k->h);
     (void)hipFree(k->q);
+    (void)hipFree(k->hcols);
     if (k->s)
         (void)hipStreamDestroy(k->s);
     delete k;
@@ -176,6 +178,7 @@ extern "C" int ek_krylov_create(int device, int64_t n, const int64_t *indptr,
     KA(k->w, (size_t)n * sizeof(double));
     KA(k->h, (size_t)(m_max + 2) * sizeof(double));
     KA(k->q, (size_t)(m_max + 1) * (m_max + 1) * sizeof(double));
+    KA(k->hcols, (size_t)m_max * (m_max + 2) * sizeof(double));
 #undef KA
     if (e == hipSuccess)
         e = hipMemcpyAsync(k->indptr, indptr, (size_t)(n + 1) * sizeof(int64_t),
@@ -326,6 +329,72 @@ extern "C" int ek_krylov_combine(ek_krylov *k, int32_t m, int32_t kk,
     KR_HIP(hipGetLastError());
     KR_HIP(hipMemcpyAsync(out_host, k->tmp, (size_t)kk * n * sizeof(double),
                           hipMemcpyDeviceToHost, k->s));
+    KR_HIP(hipStreamSynchronize(k->s));
+    return EK_OK;
+}
+
+// ---- a whole run of Arnoldi steps without host round trips ---------------------
+__global__ void kr_hsum_kernel(const double *__restrict__ h, int cnt, int first,
+                               double *__restrict__ col)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cnt)
+        col[i] = first ? h[i] : col[i] + h[i];
+}
+
+// V[j+1] = w / sqrt(nn[0]); col[cnt] = sqrt(nn[0])
+__global__ void __launch_bounds__(EK_BLOCK)
+kr_normalize_kernel(const double *__restrict__ w, const double *__restrict__ nn,
+                    int64_t n, double *__restrict__ out,
+                    double *__restrict__ col_last)
+{
+    const int64_t e = (int64_t)blockIdx.x * EK_BLOCK + threadIdx.x;
+    const double nrm = sqrt(nn[0]);
+    if (e == 0)
+        *col_last = nrm;
+    if (e < n)
+        out[e] = (nrm > 0.0) ? w[e] / nrm : 0.0;
+}
+
+// Steps j0 .. m-1 back to back.  H_out is column-major with leading dimension
+// ldh >= m + 1: column j receives h[0..j+1].  A (near-)zero sub-diagonal entry
+// signals a breakdown at that step; the caller then redoes the tail with
+// ek_krylov_step, which can insert a fresh direction.
+extern "C" int ek_krylov_expand(ek_krylov *k, int32_t j0, int32_t m,
+                                double *H_out, int32_t ldh)
+{
+    if (!k || !H_out || j0 < 0 || m > k->m_max || j0 > m || ldh < m + 1)
+        return ek_set_error(EK_EARG, "ek_krylov_expand: bad argument");
+    KR_HIP(hipSetDevice(k->device));
+    const int64_t n = k->n;
+    const int ld = k->m_max + 2;
+    for (int j = j0; j < m; ++j) {
+        const int cnt = j + 1;
+        double *col = k->hcols + (size_t)j * ld;
+        hipLaunchKernelGGL(kr_spmv_kernel, dim3((unsigned)((n + 3) / 4)),
+                           dim3(EK_BLOCK), 0, k->s, k->indptr, k->indices,
+                           k->data, k->V + (size_t)j * n, n, k->w);
+        for (int pass = 0; pass < 2; ++pass) {
+            hipLaunchKernelGGL(kr_dots_kernel, dim3(cnt), dim3(EK_BLOCK), 0,
+                               k->s, k->V, k->w, n, k->h);
+            hipLaunchKernelGGL(kr_axpy_kernel, dim3(kr_blocks(n)),
+                               dim3(EK_BLOCK), 0, k->s, k->V, k->h, cnt, n,
+                               k->w);
+            hipLaunchKernelGGL(kr_hsum_kernel, dim3((cnt + 255) / 256),
+                               dim3(256), 0, k->s, k->h, cnt, pass == 0, col);
+        }
+        hipLaunchKernelGGL(kr_dots_kernel, dim3(1), dim3(EK_BLOCK), 0, k->s,
+                           k->w, k->w, n, k->h);
+        hipLaunchKernelGGL(kr_normalize_kernel, dim3(kr_blocks(n)),
+                           dim3(EK_BLOCK), 0, k->s, k->w, k->h, n,
+                           k->V + (size_t)(j + 1) * n, col + cnt);
+    }
+    KR_HIP(hipGetLastError());
+    for (int j = j0; j < m; ++j)
+        KR_HIP(hipMemcpyAsync(H_out + (size_t)j * ldh,
+                              k->hcols + (size_t)j * ld,
+                              (size_t)(j + 2) * sizeof(double),
+                              hipMemcpyDeviceToHost, k->s));
     KR_HIP(hipStreamSynchronize(k->s));
     return EK_OK;
 }

@@ -133,6 +133,15 @@ class DeviceKrylov:
                                          _lib.f64p(h)))
         return h
 
+    def expand(self, j0, m):
+        """Steps j0..m-1 in one call -> Hessenberg columns [m+1, m] (only
+        columns j0.. are filled)."""
+        H = np.zeros((m + 1, m), dtype=np.float64, order="F")
+        _lib.check(self.L.ek_krylov_expand(
+            self._h, int(j0), int(m),
+            H.ctypes.data_as(C.POINTER(C.c_double)), m + 1))
+        return H
+
     def rotate(self, m, Q, move_last):
         Q = np.asfortranarray(Q, dtype=np.float64)
         kk = Q.shape[1]
@@ -166,6 +175,22 @@ def _expand(space, H, j0, m, rng_seed=1):
     """Arnoldi steps j0..m-1.  Returns the effective m (smaller only if the
     basis became complete)."""
     n = space.n
+    if hasattr(space, "expand") and m > j0:
+        # all steps enqueued at once; fall back to single steps from the
+        # first breakdown (tiny sub-diagonal), if any
+        Hn = space.expand(j0, m)
+        j_bad = None
+        for j in range(j0, m):
+            h = Hn[:j + 2, j]
+            scale = np.linalg.norm(h[:j + 1]) + h[j + 1]
+            if not np.all(np.isfinite(h)) or \
+                    h[j + 1] <= 1e-13 * max(scale, 1e-300):
+                j_bad = j
+                break
+            H[:j + 2, j] = h
+        if j_bad is None:
+            return m
+        j0 = j_bad
     for j in range(j0, m):
         h = space.step(j, True)
         H[:j + 2, j] = h

@@ -223,6 +223,11 @@ int ek_krylov_get_vector(ek_krylov *k, int32_t j, double *vec);
 int ek_krylov_step(ek_krylov *k, int32_t j, int32_t apply, double *h_col);
 int ek_krylov_rotate(ek_krylov *k, int32_t m, int32_t kk, const double *Q,
                      int32_t move_last);
+/* Arnoldi steps j0 .. m-1 enqueued back to back (one synchronisation at the
+ * end).  H_out: column-major, leading dimension ldh >= m + 1; column j gets
+ * h[0..j+1].  The caller checks the sub-diagonal for breakdowns. */
+int ek_krylov_expand(ek_krylov *k, int32_t j0, int32_t m, double *H_out,
+                     int32_t ldh);
 /* out_host[c][0..n) = V[0..m) Q[:, c], c < kk <= m_max + 1; basis unchanged */
 int ek_krylov_combine(ek_krylov *k, int32_t m, int32_t kk, const double *Q,
                       double *out_host);

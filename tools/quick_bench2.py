@@ -46,10 +46,12 @@ if "msm" in what:
     rng = np.random.RandomState(5)
     Ks, n_trj, L = 20000, 1000, 10000
     steps = rng.choice([-3, -2, -1, 0, 0, 1, 2, 3], size=(n_trj, L))
-    inblock = (rng.randint(100, size=(n_trj, 1)) + np.cumsum(steps, axis=1)) % 100
+    B = 1000
+    steps = rng.choice(np.arange(-40, 41), size=(n_trj, L))
+    inblock = (rng.randint(B, size=(n_trj, 1)) + np.cumsum(steps, axis=1)) % B
     hops = np.cumsum(rng.rand(n_trj, L) < 0.002, axis=1)
-    block = (rng.randint(Ks // 100, size=(n_trj, 1)) + hops * 7) % (Ks // 100)
-    Aa = (block * 100 + inblock).astype(np.int32)
+    block = (rng.randint(Ks // B, size=(n_trj, 1)) + hops * 7) % (Ks // B)
+    Aa = (block * B + inblock).astype(np.int32)
     Aa[rng.rand(n_trj, L) < 0.001] = -1
     for rep in range(2):
         t = time.time(); C = assigns_to_counts(Aa, lag_time=1, max_n_states=Ks); t1 = time.time() - t
@@ -62,3 +64,11 @@ if "msm" in what:
     rows = np.concatenate([a[a != -1][:-1] for a in Aa]); cols = np.concatenate([a[a != -1][1:] for a in Aa])
     ref = scipy.sparse.coo_matrix((np.ones(len(rows), dtype=int), (rows, cols)), shape=(Ks, Ks)).tocsr()
     print("  scipy counts %.3fs  equal: %s" % (time.time() - t, (C.tocsr() != ref).nnz == 0))
+    import scipy.sparse.linalg
+    t = time.time()
+    try:
+        w = scipy.sparse.linalg.eigs(scipy.sparse.csr_matrix(T.T), 20, which="LR", tol=1e-10)[0]
+        w = np.sort(w.real)[::-1]
+        print("  scipy ARPACK top-20: %.3fs  max |dval| %.2e" % (time.time() - t, np.abs(w - vals).max()))
+    except Exception as e:
+        print("  scipy ARPACK failed after %.1fs: %s" % (time.time() - t, str(e)[:80]))
