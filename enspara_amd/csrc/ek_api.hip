@@ -69,6 +69,10 @@ struct ek_ctx {
     float *cen_aos = nullptr;    // centred center-major centers
     double *cen_G = nullptr;
     int32_t cen_cap = 0;
+    float *cen_tiles = nullptr;  // the same centers, frame-minor tiles
+    int32_t cen_tiles_cap = 0;   // in centers (multiple of EK_TILE)
+    int assign_variant = 0;      // 0 auto, 1 vector FMA, 2 MFMA
+    int assign_ablate = 0;       // timing-only ablations (tools/)
 
     // PAM working set (allocated by ek_pam_begin)
     float *ndist = nullptr;
@@ -164,6 +168,7 @@ static int ek_free_all(ek_ctx *c)
     (void)hipFree(c->stage);
     (void)hipFree(c->cen_aos);
     (void)hipFree(c->cen_G);
+    (void)hipFree(c->cen_tiles);
     (void)hipFree(c->ndist);
     (void)hipFree(c->nassign);
     (void)hipFree(c->amb);
@@ -297,6 +302,14 @@ extern "C" int ek_set_option(ek_ctx *c, int32_t key, int32_t value)
     switch (key) {
     case 1:
         c->nt = value < 0 ? -1 : (value ? 1 : 0);
+        return EK_OK;
+    case 3:
+        c->assign_ablate = value;
+        return EK_OK;
+    case 2:
+        if (value < 0 || value > 2)
+            return ek_fail(EK_EARG, "ek_set_option: assign variant 0..2");
+        c->assign_variant = value;
         return EK_OK;
     default:
         return ek_fail(EK_EARG, "ek_set_option: unknown key %d", key);
@@ -723,8 +736,34 @@ extern "C" int ek_assign_nearest(ek_ctx *c, const float *centers_xyz,
         if (rc)
             return rc;
     }
-    ek_launch_assign(c->tiles, c->G, c->n, c->A, c->cen_aos, c->cen_G,
-                     n_centers, c->dist, c->assign, c->stream);
+    // frames x centers is a dense contraction: matrix cores unless the problem
+    // is too small to fill 32 x 32 tiles (results are bit-identical)
+    const bool mfma = c->assign_variant == 2 ||
+                      (c->assign_variant == 0 && n_centers >= 24 && c->n >= 64);
+    if (mfma && n_centers > 0) {
+        const int32_t need = (n_centers + EK_TILE - 1) / EK_TILE * EK_TILE;
+        if (need > c->cen_tiles_cap) {
+            EK_HIP(hipStreamSynchronize(c->stream));
+            (void)hipFree(c->cen_tiles);
+            c->cen_tiles = nullptr;
+            c->cen_tiles_cap = 0;
+            EK_HIP(hipMalloc((void **)&c->cen_tiles,
+                             (size_t)need * 3 * c->A * sizeof(float)));
+            c->cen_tiles_cap = need;
+        }
+        EK_HIP(hipMemsetAsync(c->cen_tiles, 0,
+                              (size_t)need * 3 * c->A * sizeof(float),
+                              c->stream));
+        const float *raw = c->cen_aos + (size_t)c->cen_cap * 3 * c->A;
+        ek_launch_prepare_tiles(raw, n_centers, c->A, c->cen_tiles, c->cen_G, 0,
+                                n_centers, c->stream);
+        ek_launch_assign_mfma(c->tiles, c->G, c->n, c->A, c->cen_tiles, c->cen_G,
+                              n_centers, c->dist, c->assign, c->assign_ablate,
+                              c->stream);
+    } else {
+        ek_launch_assign(c->tiles, c->G, c->n, c->A, c->cen_aos, c->cen_G,
+                         n_centers, c->dist, c->assign, c->stream);
+    }
     EK_CHECK_LAUNCH();
     return ek_local_candidate(c, nullptr);
 }

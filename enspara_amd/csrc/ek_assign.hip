@@ -122,3 +122,169 @@ void ek_launch_assign(const float *tiles, const double *G, int64_t n, int A,
                        lds, s, tiles, G, n, A, centers_aos, Gc, K, dist,
                        assign);
 }
+
+// ===========================================================================
+// MFMA variant.  Frames x centers IS a dense contraction: with rows (coord i,
+// frame f) and columns (coord j, center c),  S'[(i,f),(j,c)] = sum_a
+// x[f,a,i] * y[c,a,j]  is a GEMM with K = atoms.  v_mfma_f32_32x32x2_f32
+// accumulates exactly the k-ordered f32 FMA chain of the vector kernels
+// (one rounding per product, ascending atom order), so the 3x3 matrices --
+// and therefore distances and labels -- are bit-identical.
+//
+// One wave owns a 32-frame x 32-center tile: 3 x 3 MFMA tiles (coordinate
+// blocks), 144 accumulator registers.  Both operands come straight from the
+// frame-minor tile layout (the centers are laid out the same way): lane l
+// supplies frame/center (l & 31) of atom a0 + (l >> 5).  In every one of the
+// nine result tiles the pair (frame, center) sits in the same lane and the same
+// register index, so the per-pair 3x3 matrix needs no cross-lane traffic:
+// lane l, register r holds pair (f = (r&3) + 8(r>>2) + 4(l>>5), c = l&31).
+// A workgroup is 2 x 2 waves = 64 frames x 64 centers per pass over the atoms;
+// the running nearest center of each frame is a 64-bit LDS atomic min on
+// (distance bits, center index): lowest index wins ties, as util.py:199-203.
+// ===========================================================================
+typedef float ek_f16v __attribute__((ext_vector_type(16)));
+
+__global__ void __launch_bounds__(EK_BLOCK, 2)
+ek_assign_mfma_kernel(const float *__restrict__ tiles,
+                      const double *__restrict__ G, int64_t n, int A,
+                      const float *__restrict__ ctiles,
+                      const double *__restrict__ Gc, int K,
+                      float *__restrict__ dist, int32_t *__restrict__ assign,
+                      int ablate)
+{
+    __shared__ unsigned long long best[64];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wf = wave & 1, wc = wave >> 1;
+    const int fl = lane & 31, kh = lane >> 5;
+    if (tid < 64)
+        best[tid] = ~0ull;
+    __syncthreads();
+
+    const int64_t f0 = (int64_t)blockIdx.x * 64 + wf * 32;   // wave's frames
+    const float *pa = tiles + (size_t)(f0 / EK_TILE) * 3 * (size_t)A * EK_TILE +
+                      (f0 % EK_TILE) + fl;
+    const size_t kstride = (size_t)3 * EK_TILE;              // one atom
+    const int n_cg = (K + 63) / 64;
+
+    for (int cg = 0; cg < n_cg; ++cg) {
+        const int c0 = cg * 64 + wc * 32;                    // wave's centers
+        if (c0 < K) {
+            const float *pb = ctiles +
+                              (size_t)(c0 / EK_TILE) * 3 * (size_t)A * EK_TILE +
+                              (c0 % EK_TILE) + fl;
+            ek_f16v acc[3][3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        acc[i][j][r] = 0.f;
+
+            // software pipeline: the raw operands of step t+1 are requested
+            // before the nine MFMAs of step t issue and are only touched (the
+            // zeroing select for a missing last atom) at the top of step t+1,
+            // so the wait for them sits after a full MFMA block.  Loads are
+            // unconditional: the address is clamped to the last atom.
+            float rx[3], ry[3];
+            bool okc = kh < A;
+            {
+                const int a = okc ? kh : A - 1;
+                const float *qa = pa + (size_t)a * kstride;
+                const float *qb = pb + (size_t)a * kstride;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    rx[i] = qa[(size_t)i * EK_TILE];
+                    ry[i] = qb[(size_t)i * EK_TILE];
+                }
+            }
+            for (int a0 = 0; a0 < A; a0 += 2) {
+                float xa[3], yb[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    xa[i] = okc ? rx[i] : 0.f;
+                    yb[i] = okc ? ry[i] : 0.f;
+                }
+                if (ablate & 2) {      // timing only: no memory operands
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        xa[i] = 1.0f + 0.001f * (float)i;
+                        yb[i] = 1.0f - 0.001f * (float)i;
+                    }
+                }
+                const int an = a0 + 2 + kh;
+                okc = an < A;
+                {
+                    const int ac = okc ? an : A - 1;
+                    const float *qa = pa + (size_t)ac * kstride;
+                    const float *qb = pb + (size_t)ac * kstride;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        rx[i] = qa[(size_t)i * EK_TILE];
+                        ry[i] = qb[(size_t)i * EK_TILE];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                            xa[i], yb[j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+
+            const int c = c0 + fl;
+            const double gc = (c < K) ? Gc[c] : 0.0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int f_l = (r & 3) + 8 * (r >> 2) + 4 * kh;
+                const int64_t f = f0 + f_l;
+                if (f < n && c < K) {
+                    const float S[9] = {acc[0][0][r], acc[0][1][r], acc[0][2][r],
+                                        acc[1][0][r], acc[1][1][r], acc[1][2][r],
+                                        acc[2][0][r], acc[2][1][r], acc[2][2][r]};
+                    float d;
+                    if (ablate & 1)    // timing only: no quartic solve
+                        d = S[0] + S[1] + S[2] + S[3] + S[4] + S[5] + S[6] +
+                            S[7] + S[8];
+                    else
+                        d = ek_rmsd_from_S(S, G[f], gc, A);
+                    const unsigned long long key =
+                        ((unsigned long long)__float_as_uint(d) << 32) |
+                        (unsigned int)c;
+                    atomicMin(&best[wf * 32 + f_l], key);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int64_t f = (int64_t)blockIdx.x * 64 + tid;
+        if (f < n) {
+            const unsigned long long key = best[tid];
+            if (K > 0) {
+                dist[f] = __uint_as_float((unsigned int)(key >> 32));
+                assign[f] = (int32_t)(key & 0xffffffffu);
+            } else {
+                dist[f] = __builtin_inff();
+                assign[f] = 0;
+            }
+        }
+    }
+}
+
+void ek_launch_assign_mfma(const float *tiles, const double *G, int64_t n, int A,
+                           const float *ctiles, const double *Gc, int32_t K,
+                           float *dist, int32_t *assign, int ablate,
+                           hipStream_t s)
+{
+    if (n <= 0)
+        return;
+    const int64_t blocks = (n + 63) / 64;
+    hipLaunchKernelGGL(ek_assign_mfma_kernel, dim3((unsigned)blocks),
+                       dim3(EK_BLOCK), 0, s, tiles, G, n, A, ctiles, Gc, K, dist,
+                       assign, ablate);
+}

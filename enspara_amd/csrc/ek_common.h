@@ -91,6 +91,13 @@ void ek_launch_assign(const float *tiles, const double *G, int64_t n, int A,
                       const float *centers_aos, const double *Gc, int32_t K,
                       float *dist, int32_t *assign, hipStream_t s);
 
+// same result through the matrix cores; ctiles: centers in the frame-minor tile
+// layout (as produced by ek_launch_prepare_tiles)
+void ek_launch_assign_mfma(const float *tiles, const double *G, int64_t n, int A,
+                           const float *ctiles, const double *Gc, int32_t K,
+                           float *dist, int32_t *assign, int ablate,
+                           hipStream_t s);
+
 // ---- PAM (ek_pam.hip) ----------------------------------------------------------
 void ek_launch_gather_frames(const float *tiles, const double *G, int A,
                              const int64_t *idx_dev, int count, int first_row,

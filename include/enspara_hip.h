@@ -237,7 +237,9 @@ int ek_krylov_combine(ek_krylov *k, int32_t m, int32_t kk, const double *Q,
  * shard size */
 int ek_set_frames_per_lane(ek_ctx *ctx, int fpl);
 /* key 1: non-temporal loads of the frame stream (0/1; -1 = automatic:
- * on when the shard is larger than the Infinity Cache) */
+ * on when the shard is larger than the Infinity Cache)
+ * key 2: nearest-center kernel: 0 automatic, 1 vector FMA, 2 MFMA (identical
+ * results) */
 int ek_set_option(ek_ctx *ctx, int32_t key, int32_t value);
 /* time of the last ek_kcenters_run loop measured with HIP events on the
  * context's stream, milliseconds, and the number of distance-kernel launches

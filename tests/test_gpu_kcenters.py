@@ -148,3 +148,29 @@ def test_sampled_parity_at_scale(qcp):
     assert r.distances.max() == r.distances[np.argmax(r.distances)]
     for k, i in enumerate(r.center_indices):
         assert r.assignments[i] == k
+
+
+@pytest.mark.parametrize("n,A,K", [(1000, 35, 21), (64, 22, 32), (777, 301, 97),
+                                   (2500, 100, 64), (130, 7, 300), (5, 3, 2)])
+def test_assign_variants_bit_identical(qcp, n, A, K):
+    """vector-FMA and MFMA nearest-center kernels against the checker"""
+    x = synth.synth(n, A, 6, seed=n + K)
+    ctrs = synth.synth(K, A, K, seed=A + K)
+    P = qcp.Prepared(x)
+    cc, Gc = qcp.center_and_trace(ctrs)
+    wa, wd = qcp.assign_nearest(P.c, P.G, cc, Gc)
+    with _store(x) as st:
+        for variant in (1, 2, 0):
+            st.set_option(2, variant)
+            st.assign_nearest(ctrs)
+            d, a = st.download_state()
+            np.testing.assert_array_equal(a, wa)
+            np.testing.assert_array_equal(d, wd)
+    # duplicated centers: the lower index must win in both kernels
+    dup = np.concatenate([ctrs[:3], ctrs[:3], ctrs[3:]])
+    with _store(x) as st:
+        for variant in (1, 2):
+            st.set_option(2, variant)
+            st.assign_nearest(dup)
+            d, a = st.download_state()
+            assert not np.isin(a, [3, 4, 5]).any()

@@ -20,10 +20,13 @@ if "assign" in what or "pam" in what:
     print("kcenters K=%d: %.2fs  maxdist %.4f" % (K, time.time() - t, mx), flush=True)
 if "assign" in what:
     ctr = x[idx]
-    for kk in (64, 512, K):
+    for variant, kk, abl in [(2, K, 0), (2, K, 1), (2, K, 2), (2, K, 3)]:
+        st.set_option(2, variant); st.set_option(3, abl)
+        st.assign_nearest(ctr[:kk]); st.sync()
         t = time.time()
         st.assign_nearest(ctr[:kk]); st.sync()
         dt = time.time() - t
+        print("variant %d ablate %d " % (variant, abl), end="")
         print("assign n=%d K=%d: %.3fs  %.3e pairs/s  %.1f TFLOP/s(18A flop/pair)"
               % (n, kk, dt, n * kk / dt, n * kk * 18 * A / dt / 1e12), flush=True)
     d, a = st.download_state()
