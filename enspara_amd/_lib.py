@@ -34,6 +34,7 @@ SYMBOLS = [
     "ek_krylov_create", "ek_krylov_destroy", "ek_krylov_set_vector",
     "ek_krylov_get_vector", "ek_krylov_step", "ek_krylov_rotate",
     "ek_krylov_combine", "ek_krylov_expand",
+    "ek_feat_create", "ek_feat_destroy", "ek_feat_load", "ek_feat_distance",
     "ek_set_frames_per_lane", "ek_set_option", "ek_last_run_timing",
     "ek_timing_begin", "ek_timing_end",
 ]
@@ -114,6 +115,10 @@ def load():
     L.ek_krylov_rotate.argtypes = [vp, i32, i32, f64p, i32]
     L.ek_krylov_combine.argtypes = [vp, i32, i32, f64p, f64p]
     L.ek_krylov_expand.argtypes = [vp, i32, i32, f64p, i32]
+    L.ek_feat_create.argtypes = [C.c_int, i64, i32, i32, C.POINTER(vp)]
+    L.ek_feat_destroy.argtypes = [vp]
+    L.ek_feat_load.argtypes = [vp, vp, i64, i64]
+    L.ek_feat_distance.argtypes = [vp, i32, vp, f64p]
     L.ek_set_frames_per_lane.argtypes = [vp, C.c_int]
     L.ek_set_option.argtypes = [vp, i32, i32]
     L.ek_last_run_timing.argtypes = [vp, f32p, i32p]

@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_build")
 OUT = os.path.join(HERE, "libenspara_hip.so")
 SOURCES = ["ek_prepare.hip", "ek_kcenters.hip", "ek_assign.hip", "ek_pam.hip",
-           "ek_msm.hip", "ek_krylov.hip", "ek_api.hip"]
+           "ek_msm.hip", "ek_krylov.hip", "ek_features.hip", "ek_api.hip"]
 HEADERS = ["ek_common.h", "ek_qcp.h", os.path.join("..", "..", "include",
                                                    "enspara_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -154,6 +154,8 @@ def _kcenters_host(traj, distance_method, n_clusters, dist_cutoff,
                    init_centers, use_triangle_inequality):
     """The reference's loop for an arbitrary callable metric
     (kcenters.py:195-311)."""
+    if hasattr(distance_method, "bind"):     # device metric: upload traj once
+        distance_method = distance_method.bind(traj)
     if init_centers is None:
         ctr_inds, centers = [], []
         assignments = np.full(len(traj), -1, dtype=int)

@@ -224,6 +224,8 @@ def _kmedoids_pam_update(X, metric, medoid_inds, assignments, distances,
 
     random_state = check_random_state(random_state)
     _check_proposals(proposals, medoid_inds)
+    if hasattr(metric, "bind"):              # device metric: upload X once
+        metric = metric.bind(X)
     medoid_coords = [X[i] for i in medoid_inds]
     for cid in range(len(medoid_inds)):
         state_inds = np.where(assignments == cid)[0]

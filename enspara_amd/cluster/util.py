@@ -50,6 +50,12 @@ def _get_distance_method(metric):
     if isinstance(metric, str):
         if metric == "rmsd":
             return rmsd
+        if metric == "euclidean":
+            from ..geometry.libdist import euclidean
+            return euclidean
+        if metric in ("cityblock", "manhattan"):
+            from ..geometry.libdist import manhattan
+            return manhattan
         raise ImproperlyConfigured(
             "'{}' is not a recognized metric".format(metric))
     if callable(metric):
@@ -112,6 +118,8 @@ def assign_to_nearest_center(trajectory, cluster_centers, distance_method):
                 store.close()
         return a.astype(np.int64), d.astype(np.float64)
 
+    if hasattr(distance_method, "bind"):     # device metric: upload once
+        distance_method = distance_method.bind(trajectory)
     assignments = np.zeros(len(trajectory), dtype=int)
     distances = np.full(len(trajectory), np.inf, dtype=float)
     if len(cluster_centers) > len(trajectory) and hasattr(cluster_centers,

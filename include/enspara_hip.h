@@ -232,6 +232,25 @@ int ek_krylov_expand(ek_krylov *k, int32_t j0, int32_t m, double *H_out,
 int ek_krylov_combine(ek_krylov *k, int32_t m, int32_t kk, const double *Q,
                       double *out_host);
 
+/* ---- feature-space metrics --------------------------------------------------------
+ * Replace the reference's native distance kernels, enspara/geometry/libdist.pyx
+ * (_euclidean :122-145, _manhattan :100-117, _hamming :77-95; bound as metrics
+ * 'euclidean' / 'manhattan' at enspara/cluster/util.py:292-295).
+ * Samples: row-major [n_samples][n_features] host array of elem_kind
+ * 0 = float32, 1 = float64, 2 = int64 (hamming only).  ek_feat_distance
+ * computes metric 0 = euclidean, 1 = manhattan, 2 = hamming between every
+ * sample and the point y (n_features elements of the same kind) into
+ * float64 out_host[n_samples]; float32 samples use float32 differences and
+ * squares and a float64 running sum in feature order, exactly as the
+ * reference's generated C does. */
+typedef struct ek_feat ek_feat;
+int ek_feat_create(int device, int64_t n_samples, int32_t n_features,
+                   int32_t elem_kind, ek_feat **out);
+int ek_feat_destroy(ek_feat *k);
+int ek_feat_load(ek_feat *k, const void *X, int64_t first, int64_t count);
+int ek_feat_distance(ek_feat *k, int32_t metric, const void *y,
+                     double *out_host);
+
 /* ---- tuning knobs (benchmarks only) -------------------------------------- */
 /* frames per lane of the distance kernel: 1, 2 or 4; 0 = choose from the
  * shard size */

@@ -269,7 +269,43 @@ def main():
     msm["rag_lengths"] = np.array(lens)
     msm["rag_counts_lag3"] = np.asarray(C.todense())
     np.savez_compressed(os.path.join(HERE, "msm_golden.npz"), **msm)
-    for f in ("cluster_golden.npz", "ra_golden.npz", "msm_golden.npz"):
+    # ---- 9. feature-space metrics: the reference's own native kernels ----------
+    from enspara.geometry import libdist as rlib
+    feat = {}
+    rng = np.random.RandomState(11)
+    Xd = rng.normal(scale=3.0, size=(700, 37))
+    yd = rng.normal(scale=3.0, size=37)
+    for name, X_, y_ in (("f32", Xd.astype(np.float32), yd.astype(np.float32)),
+                         ("f64", Xd, yd),
+                         ("i64", (Xd * 10).astype(np.int64),
+                          (yd * 10).astype(np.int64))):
+        feat["X_" + name] = X_
+        feat["y_" + name] = y_
+        feat["euclidean_" + name] = rlib.euclidean(X_, y_)
+        feat["manhattan_" + name] = rlib.manhattan(X_, y_)
+    Xi = rng.randint(0, 4, size=(300, 21)).astype(np.int32)
+    yi = rng.randint(0, 4, size=21).astype(np.int32)
+    feat["X_ham"] = Xi
+    feat["y_ham"] = yi
+    feat["hamming"] = rlib.hamming(Xi, yi)
+    # clustering in feature space through the string metric
+    Xc = np.concatenate([c + rng.normal(size=(80, 6))
+                         for c in rng.uniform(-15, 15, size=(6, 6))]
+                        ).astype(np.float32)
+    r = rkc.kcenters(Xc, "euclidean", n_clusters=6)
+    feat["kc_X"] = Xc
+    feat["kc_idx"] = np.array(r.center_indices)
+    feat["kc_assign"] = r.assignments
+    feat["kc_dist"] = r.distances
+    r = rhy.hybrid(Xc, "euclidean", n_clusters=6, n_iters=2,
+                   random_state=np.random.RandomState(3))
+    feat["hy_idx"] = np.array(r.center_indices)
+    feat["hy_assign"] = r.assignments
+    feat["hy_dist"] = r.distances
+    np.savez_compressed(os.path.join(HERE, "features_golden.npz"), **feat)
+
+    for f in ("cluster_golden.npz", "ra_golden.npz", "msm_golden.npz",
+              "features_golden.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
 
 

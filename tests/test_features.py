@@ -1,0 +1,96 @@
+"""Feature-space metrics (the reference's libdist): the oracle against the
+reference's compiled module (CPU), the HIP kernels against both (GPU)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import features as of
+
+
+@pytest.fixture(scope="module")
+def F(golden_dir):
+    return np.load(os.path.join(golden_dir, "features_golden.npz"))
+
+
+def test_oracle_matches_reference_libdist(F):
+    for name in ("f32", "f64", "i64"):
+        X, y = F["X_" + name], F["y_" + name]
+        np.testing.assert_array_equal(of.euclidean(X, y), F["euclidean_" + name])
+        np.testing.assert_array_equal(of.manhattan(X, y), F["manhattan_" + name])
+    np.testing.assert_array_equal(of.hamming(F["X_ham"], F["y_ham"]),
+                                  F["hamming"])
+
+
+@pytest.mark.gpu
+def test_device_metrics_match_reference(F):
+    from enspara_amd.geometry import libdist
+    for name in ("f32", "f64", "i64"):
+        X, y = F["X_" + name], F["y_" + name]
+        d = libdist.euclidean(X, y)
+        assert d.dtype == np.float64 and d.shape == (len(X),)
+        np.testing.assert_array_equal(d, F["euclidean_" + name])
+        np.testing.assert_array_equal(libdist.manhattan(X, y),
+                                      F["manhattan_" + name])
+        b = libdist.euclidean.bind(X)
+        np.testing.assert_array_equal(b(X, y), F["euclidean_" + name])
+        np.testing.assert_array_equal(b(X[:50], y), F["euclidean_" + name][:50])
+    np.testing.assert_array_equal(libdist.hamming(F["X_ham"], F["y_ham"]),
+                                  F["hamming"])
+    out = np.zeros(len(F["X_f32"]))
+    r = libdist.manhattan(F["X_f32"], F["y_f32"], out=out)
+    assert r is out
+    np.testing.assert_array_equal(out, F["manhattan_f32"])
+
+
+@pytest.mark.gpu
+def test_device_metric_validation():
+    """reference test_libdist.py:36-89"""
+    from enspara_amd.geometry import libdist
+    from enspara_amd.exception import DataInvalid
+    X = np.array([[1, 1], [2, 2], [3, 3], [-1, 3]])
+    y = np.array([0, 0])
+    for f in (libdist.euclidean, libdist.manhattan):
+        with pytest.raises(DataInvalid):
+            f(X, y.reshape(1, -1))
+        with pytest.raises(DataInvalid):
+            f(X.flatten(), y)
+        with pytest.raises(DataInvalid):
+            f(X, y[1:])
+        with pytest.raises(DataInvalid):
+            f(X, y, out=np.zeros(4, dtype=np.float32))
+    np.testing.assert_array_equal(libdist.manhattan(X, y), [2, 4, 6, 4])
+    np.testing.assert_allclose(libdist.euclidean(X, y),
+                               np.sqrt([2, 8, 18, 10]), rtol=0, atol=0)
+    for dt in ("int8", "uint16", "int32", "uint64"):
+        Xh = np.array([[1, 3, 8], [3, 1, 8], [1, 1, 7]]).astype(dt)
+        yh = np.array([1, 2, 3]).astype(dt)
+        np.testing.assert_array_equal(libdist.hamming(Xh, yh),
+                                      [2 / 3, 1.0, 2 / 3])
+
+
+@pytest.mark.gpu
+def test_feature_clustering_matches_reference(F):
+    from enspara_amd.cluster.kcenters import kcenters
+    from enspara_amd.cluster.hybrid import hybrid
+    X = F["kc_X"]
+    r = kcenters(X, "euclidean", n_clusters=6)
+    np.testing.assert_array_equal(r.center_indices, F["kc_idx"])
+    np.testing.assert_array_equal(r.assignments, F["kc_assign"])
+    np.testing.assert_array_equal(r.distances, F["kc_dist"])
+    r = hybrid(X, "euclidean", n_clusters=6, n_iters=2,
+               random_state=np.random.RandomState(3))
+    np.testing.assert_array_equal(r.center_indices, F["hy_idx"])
+    np.testing.assert_array_equal(r.assignments, F["hy_assign"])
+    np.testing.assert_array_equal(r.distances, F["hy_dist"])
+
+
+@pytest.mark.gpu
+def test_feature_metric_many_features():
+    """more features than one LDS chunk; rows not a multiple of the tile"""
+    from enspara_amd.geometry import libdist
+    rng = np.random.RandomState(2)
+    X = rng.normal(size=(1031, 5000)).astype(np.float32)
+    y = rng.normal(size=5000).astype(np.float32)
+    np.testing.assert_array_equal(libdist.euclidean(X, y), of.euclidean(X, y))
+    np.testing.assert_array_equal(libdist.manhattan(X, y), of.manhattan(X, y))
