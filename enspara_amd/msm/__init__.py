@@ -4,3 +4,4 @@ from . import builders  # noqa: F401
 from . import transition_matrices  # noqa: F401
 from .transition_matrices import assigns_to_counts, eigenspectrum, eq_probs  # noqa: F401
 from .msm import MSM  # noqa: F401
+from .timescales import implied_timescales  # noqa: F401

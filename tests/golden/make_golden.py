@@ -268,6 +268,10 @@ def main():
     C = rtm.assigns_to_counts(ragA, lag_time=3, max_n_states=K)
     msm["rag_lengths"] = np.array(lens)
     msm["rag_counts_lag3"] = np.asarray(C.todense())
+    from enspara.msm import timescales as rts
+    msm["implied_lags"] = np.array([1, 2, 5, 10])
+    msm["implied_times"] = rts.implied_timescales(
+        assigns, [1, 2, 5, 10], rbuilders.normalize, n_times=4)
     np.savez_compressed(os.path.join(HERE, "msm_golden.npz"), **msm)
     # ---- 9. feature-space metrics: the reference's own native kernels ----------
     from enspara.geometry import libdist as rlib

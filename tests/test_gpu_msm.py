@@ -128,3 +128,11 @@ def test_msm_build_at_scale():
     np.testing.assert_allclose(vals, want.real, atol=1e-8)
     np.testing.assert_allclose(m.eq_probs_, vecs[:, 0], atol=1e-9)
     assert abs(m.eq_probs_.sum() - 1) < 1e-12
+
+
+def test_implied_timescales_match_reference(M):
+    from enspara_amd.msm import implied_timescales, builders
+    got = implied_timescales(M["assigns"], [int(t) for t in M["implied_lags"]],
+                             builders.normalize, n_times=4)
+    assert got.shape == M["implied_times"].shape
+    np.testing.assert_allclose(got, M["implied_times"], rtol=1e-7)
