@@ -15,15 +15,18 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_build")
 OUT = os.path.join(HERE, "libenspara_hip.so")
-SOURCES = ["ek_prepare.hip", "ek_kcenters.hip", "ek_assign.hip", "ek_pam.hip",
+SOURCES = ["ek_prepare.hip", "ek_kcenters.hip", "ek_spec.hip", "ek_assign.hip", "ek_pam.hip",
            "ek_msm.hip", "ek_krylov.hip", "ek_features.hip", "ek_api.hip"]
-HEADERS = ["ek_common.h", "ek_qcp.h", os.path.join("..", "..", "include",
+HEADERS = ["ek_common.h", "ek_qcp.h", "ek_reduce.h", os.path.join("..", "..", "include",
                                                    "enspara_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: FMAs are explicit in the sources (numerical contract,
 # csrc/ek_qcp.h); hipcc's default would fuse a*b+c on its own.
+# -fno-slp-vectorize: otherwise the FMA chains become v_pk_fma_f32 plus one
+# v_mov per operand pair, which measured slower than plain v_fmac_f32 here.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
-         "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wextra",
+         "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-Wall",
+         "-Wextra",
          "-Wno-unused-parameter"]
 
 

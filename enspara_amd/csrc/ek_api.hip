@@ -97,6 +97,15 @@ struct ek_ctx {
     int64_t cnt_m = 0;
     int64_t pam_frame = -1;
 
+    // multi-candidate rounds (ek_spec.hip)
+    int cands = -1;              // candidates per pass: -1 auto, 1 = one-center passes
+    unsigned char *recsT = nullptr;   // EK_MAX_CANDS records
+    EkPlan *plan = nullptr;
+    float *vecs = nullptr;       // [EK_MAX_CANDS-1][n_pad] stored distance vectors
+    EkMaxHdr *hdr = nullptr;
+    int64_t n_pad = 0;
+    int32_t last_passes = 0;
+
     int fpl = 0;                 // 0 = auto
     int nt = -1;                 // non-temporal frame loads: -1 = auto
     // sampled per-launch timing of the distance kernel (bench only)
@@ -134,6 +143,27 @@ static int ek_pick_nt(const ek_ctx *c)
     return bytes > ((size_t)192 << 20) ? 1 : 0;
 }
 
+// candidates per pass: as many as the LDS tile of centers allows (<= 8)
+static int ek_pick_cands(const ek_ctx *c)
+{
+    int t = c->cands;
+    if (t == -1)
+        t = 8;
+    while (t > 1 && ek_pass_lds_bytes(t, c->A) > (size_t)150 * 1024)
+        t /= 2;
+    return (t == 8 || t == 4) ? t : 1;
+}
+
+static int ek_spec_alloc(ek_ctx *c)
+{
+    if (!c->vecs) {
+        EK_HIP(hipMalloc((void **)&c->vecs, (size_t)(EK_MAX_CANDS - 1) *
+                                                std::max<int64_t>(c->n_pad, 1) *
+                                                sizeof(float)));
+    }
+    return EK_OK;
+}
+
 extern "C" int ek_abi_version(void) { return EK_ABI_VERSION; }
 extern "C" const char *ek_last_error(void) { return g_err; }
 
@@ -169,6 +199,10 @@ static int ek_free_all(ek_ctx *c)
     (void)hipFree(c->cen_aos);
     (void)hipFree(c->cen_G);
     (void)hipFree(c->cen_tiles);
+    (void)hipFree(c->recsT);
+    (void)hipFree(c->plan);
+    (void)hipFree(c->vecs);
+    (void)hipFree(c->hdr);
     (void)hipFree(c->ndist);
     (void)hipFree(c->nassign);
     (void)hipFree(c->amb);
@@ -247,7 +281,11 @@ extern "C" int ek_ctx_create(int device, int64_t n_frames, int32_t n_atoms,
     EK_ALLOC(c->blockmax, (size_t)c->blockmax_cap * sizeof(EkBlockMax));
     EK_ALLOC(c->hist, (size_t)c->hist_cap * sizeof(EkHist));
     EK_ALLOC(c->ctl, sizeof(EkCtl));
+    EK_ALLOC(c->recsT, recb * EK_MAX_CANDS);
+    EK_ALLOC(c->plan, sizeof(EkPlan));
+    EK_ALLOC(c->hdr, sizeof(EkMaxHdr));
 #undef EK_ALLOC
+    c->n_pad = (int64_t)nt * EK_TILE;
     if (e == hipSuccess)
         e = hipEventCreate(&c->ev0);
     if (e == hipSuccess)
@@ -305,6 +343,12 @@ extern "C" int ek_set_option(ek_ctx *c, int32_t key, int32_t value)
         return EK_OK;
     case 3:
         c->assign_ablate = value;
+        return EK_OK;
+    case 4:
+        if (value != -1 && value != 1 && value != 4 && value != 8)
+            return ek_fail(EK_EARG, "ek_set_option: candidates per pass must "
+                                    "be -1 (auto), 1, 4 or 8");
+        c->cands = value;
         return EK_OK;
     case 2:
         if (value < 0 || value > 2)
@@ -630,6 +674,98 @@ extern "C" int ek_kcenters_run(ek_ctx *c, int32_t first_label, int32_t max_new,
     EK_HIP(hipMemcpyAsync(c->ctl, &ctl0, offsetof(EkCtl, last_max),
                           hipMemcpyHostToDevice, c->stream));
     EK_HIP(hipStreamSynchronize(c->stream));
+
+    const int T = ek_pick_cands(c);
+    if (T > 1 && c->n > 0) {
+        // ---- multi-candidate rounds (ek_spec.hip) -------------------------------
+        rc = ek_spec_alloc(c);
+        if (rc)
+            return rc;
+        EkCtl ctlw;
+        memset(&ctlw, 0, sizeof(ctlw));
+        ctlw.n_done = first_label;
+        ctlw.limit = first_label + max_new;
+        EK_HIP(hipMemcpyAsync(c->ctl, &ctlw, sizeof(ctlw), hipMemcpyHostToDevice,
+                              c->stream));
+        EK_HIP(hipStreamSynchronize(c->stream));
+        const int nb = (int)((c->n + EK_BLOCK - 1) / EK_BLOCK);
+        EK_HIP(hipEventRecord(c->ev0, c->stream));
+        ek_launch_blockmax(c->dist, c->n, c->blockmax, c->stream);
+        ek_launch_pickT(c->blockmax, nb, c->tiles, c->G, c->assign, c->A, T, c->goff,
+                        c->recsT, c->ctl, c->stream);
+        EK_CHECK_LAUNCH();
+        EkCtl cr;
+        memset(&cr, 0, sizeof(cr));
+        cr.n_done = first_label;
+        int32_t passes = 0;
+        double per_round = 0.6 * T;        // centers per round, re-estimated
+        while (max_new > 0) {
+            // rounds enqueued per host check: enough for the remaining centers
+            // at the observed yield (steps past the goal are device no-ops)
+            const int32_t left = first_label + max_new - cr.n_done;
+            const int32_t rounds = std::max(
+                2, std::min(256, (int32_t)(left / per_round) + 1));
+            const int32_t before = cr.n_done;
+            for (int32_t r = 0; r < rounds; ++r) {
+                ek_launch_plan(c->recsT, T, c->A, T, dist_cutoff, c->plan,
+                               c->hist, c->ctl, c->stream);
+                const bool sample =
+                    c->samp_every > 0 &&
+                    (c->samp_count++ % c->samp_every) == 0 &&
+                    2 * (size_t)c->samp_used + 1 < c->samp_ev.size();
+                if (sample)
+                    EK_HIP(hipEventRecord(c->samp_ev[2 * c->samp_used],
+                                          c->stream));
+                ek_launch_pass(T, c->tiles, c->G, c->dist, c->assign, c->vecs,
+                               c->n, c->n_pad, c->A, c->recsT, c->plan,
+                               c->blockmax, c->stream);
+                if (sample) {
+                    EK_HIP(hipEventRecord(c->samp_ev[2 * c->samp_used + 1],
+                                          c->stream));
+                    c->samp_used++;
+                }
+                for (int j = 1; j < T; ++j) {
+                    ek_launch_localmax_check(c->blockmax, nb, c->goff,
+                                             dist_cutoff, c->plan, c->hist,
+                                             c->ctl, c->stream);
+                    ek_launch_apply(c->vecs, c->n, c->n_pad, c->dist, c->assign,
+                                    c->plan, c->blockmax, c->stream);
+                }
+                ek_launch_pickT(c->blockmax, nb, c->tiles, c->G, c->assign, c->A, T,
+                                c->goff, c->recsT, c->ctl, c->stream);
+                EK_CHECK_LAUNCH();
+            }
+            passes += rounds;
+            EK_HIP(hipMemcpyAsync(&cr, c->ctl, sizeof(cr), hipMemcpyDeviceToHost,
+                                  c->stream));
+            EK_HIP(hipStreamSynchronize(c->stream));
+            if (cr.stopped || cr.n_done >= first_label + max_new)
+                break;
+            per_round = std::max(1.0, (double)(cr.n_done - before) / rounds);
+        }
+        EK_HIP(hipEventRecord(c->ev1, c->stream));
+        EK_HIP(hipStreamSynchronize(c->stream));
+        EK_HIP(hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
+        // keep the single-record slot in step with the state (other entry
+        // points read it)
+        EK_HIP(hipMemcpyAsync(c->rec, c->recsT, ek_rec_bytes(c->A),
+                              hipMemcpyDeviceToDevice, c->stream));
+        EK_HIP(hipStreamSynchronize(c->stream));
+        const int32_t added_t = std::max(0, cr.n_done - first_label);
+        c->last_launches = passes;
+        c->last_passes = passes;
+        if (n_added)
+            *n_added = added_t;
+        if (final_maxdist)
+            *final_maxdist = cr.last_max;
+        if (added_t > 0 && (center_index_out || center_dist_out)) {
+            rc = ek_history_download(c, first_label, added_t, center_index_out,
+                                     center_dist_out, nullptr);
+            if (rc)
+                return rc;
+        }
+        return EK_OK;
+    }
 
     // With no distance cut-off the trip count is known: enqueue everything.
     // With a cut-off, enqueue in batches and look at the stop flag in between
@@ -1019,5 +1155,129 @@ extern "C" int ek_pam_commit(ek_ctx *c, int accept)
     }
     c->pam_cid = -1;
     c->cnt_cid = -1;
+    return EK_OK;
+}
+
+// ---- multi-candidate rounds across shards --------------------------------------------
+extern "C" int ek_spec_candidates(ek_ctx *c)
+{
+    return c ? ek_pick_cands(c) : 0;
+}
+
+extern "C" int ek_spec_begin(ek_ctx *c, int32_t first_label, int32_t limit,
+                             void *recs_out)
+{
+    if (!c)
+        return ek_fail(EK_EARG, "NULL context");
+    if (!c->loaded)
+        return ek_fail(EK_ESTATE, "ek_spec_begin: no frames loaded");
+    if (first_label < 0 || limit < first_label)
+        return ek_fail(EK_EARG, "ek_spec_begin: bad label range");
+    EK_HIP(hipSetDevice(c->device));
+    int rc = ek_ensure_hist(c, limit);
+    if (rc)
+        return rc;
+    rc = ek_spec_alloc(c);
+    if (rc)
+        return rc;
+    const int T = std::max(ek_pick_cands(c), 1);
+    EkCtl w;
+    memset(&w, 0, sizeof(w));
+    w.n_done = first_label;
+    w.limit = limit;
+    EK_HIP(hipMemcpyAsync(c->ctl, &w, sizeof(w), hipMemcpyHostToDevice,
+                          c->stream));
+    EK_HIP(hipStreamSynchronize(c->stream));
+    const int nb = (int)((c->n + EK_BLOCK - 1) / EK_BLOCK);
+    ek_launch_blockmax(c->dist, c->n, c->blockmax, c->stream);
+    ek_launch_pickT(c->blockmax, nb, c->tiles, c->G, c->assign, c->A, T, c->goff,
+                    recs_out ? (unsigned char *)recs_out : c->recsT, c->ctl,
+                    c->stream);
+    EK_CHECK_LAUNCH();
+    return EK_OK;
+}
+
+extern "C" int ek_spec_round(ek_ctx *c, const void *recs_all, int32_t n_recs,
+                             double dist_cutoff)
+{
+    if (!c || !recs_all || n_recs < 1 || n_recs > 64)
+        return ek_fail(EK_EARG, "ek_spec_round: bad argument (1..64 records)");
+    EK_HIP(hipSetDevice(c->device));
+    const int T = ek_pick_cands(c);
+    if (T < 4)
+        return ek_fail(EK_ESTATE, "ek_spec_round: multi-candidate rounds are "
+                                  "off (use ek_kcenters_step)");
+    if (!c->vecs)
+        return ek_fail(EK_ESTATE, "ek_spec_round: call ek_spec_begin first");
+    ek_launch_plan((const unsigned char *)recs_all, n_recs, c->A, T, dist_cutoff,
+                   c->plan, c->hist, c->ctl, c->stream);
+    const bool sample = c->samp_every > 0 &&
+                        (c->samp_count++ % c->samp_every) == 0 &&
+                        2 * (size_t)c->samp_used + 1 < c->samp_ev.size();
+    if (sample)
+        EK_HIP(hipEventRecord(c->samp_ev[2 * c->samp_used], c->stream));
+    ek_launch_pass(T, c->tiles, c->G, c->dist, c->assign, c->vecs,
+                   c->n, c->n_pad, c->A, (const unsigned char *)recs_all,
+                   c->plan, c->blockmax, c->stream);
+    if (sample) {
+        EK_HIP(hipEventRecord(c->samp_ev[2 * c->samp_used + 1], c->stream));
+        c->samp_used++;
+    }
+    EK_CHECK_LAUNCH();
+    return EK_OK;
+}
+
+extern "C" int ek_spec_localmax(ek_ctx *c, void *hdr_out)
+{
+    if (!c || !hdr_out)
+        return ek_fail(EK_EARG, "ek_spec_localmax: NULL argument");
+    EK_HIP(hipSetDevice(c->device));
+    const int nb = (int)((c->n + EK_BLOCK - 1) / EK_BLOCK);
+    ek_launch_localmax(c->blockmax, nb, c->goff, (EkMaxHdr *)hdr_out, c->stream);
+    EK_CHECK_LAUNCH();
+    return EK_OK;
+}
+
+extern "C" int ek_spec_apply(ek_ctx *c, const void *hdrs_all, int32_t n_hdrs,
+                             double dist_cutoff)
+{
+    if (!c || !hdrs_all || n_hdrs < 1)
+        return ek_fail(EK_EARG, "ek_spec_apply: bad argument");
+    EK_HIP(hipSetDevice(c->device));
+    ek_launch_check((const EkMaxHdr *)hdrs_all, n_hdrs, dist_cutoff, c->plan,
+                    c->hist, c->ctl, c->stream);
+    ek_launch_apply(c->vecs, c->n, c->n_pad, c->dist, c->assign, c->plan,
+                    c->blockmax, c->stream);
+    EK_CHECK_LAUNCH();
+    return EK_OK;
+}
+
+extern "C" int ek_spec_round_end(ek_ctx *c, void *recs_out)
+{
+    if (!c)
+        return ek_fail(EK_EARG, "NULL context");
+    EK_HIP(hipSetDevice(c->device));
+    const int T = std::max(ek_pick_cands(c), 1);
+    const int nb = (int)((c->n + EK_BLOCK - 1) / EK_BLOCK);
+    ek_launch_pickT(c->blockmax, nb, c->tiles, c->G, c->assign, c->A, T, c->goff,
+                    recs_out ? (unsigned char *)recs_out : c->recsT, c->ctl,
+                    c->stream);
+    EK_CHECK_LAUNCH();
+    return EK_OK;
+}
+
+extern "C" int ek_spec_progress(ek_ctx *c, int32_t *n_done, int32_t *stopped)
+{
+    if (!c)
+        return ek_fail(EK_EARG, "NULL context");
+    EK_HIP(hipSetDevice(c->device));
+    EkCtl r;
+    EK_HIP(hipMemcpyAsync(&r, c->ctl, sizeof(r), hipMemcpyDeviceToHost,
+                          c->stream));
+    EK_HIP(hipStreamSynchronize(c->stream));
+    if (n_done)
+        *n_done = r.n_done;
+    if (stopped)
+        *stopped = r.stopped;
     return EK_OK;
 }

@@ -43,7 +43,32 @@ struct EkCtl {
     int32_t n_done;     // 1 + highest accepted label
     int32_t stopped;    // a step saw maxdist <= cutoff
     float last_max;     // maxdist carried by the most recent own record
+    int32_t limit;      // multi-candidate rounds: stop once n_done == limit
+};
+
+// what a shard contributes to the per-center exchange between passes
+struct EkMaxHdr {
+    float maxdist;
+    int32_t valid;
+    int64_t gidx;
+};
+static_assert(sizeof(EkMaxHdr) == 16, "max header is 16 bytes");
+
+#define EK_MAX_CANDS 8
+// plan of one multi-candidate round (ek_spec.hip); written only by the
+// single-workgroup plan/check kernels, read by the kernels that follow
+struct EkPlan {
+    int32_t go;            // the round runs
+    int32_t teff;          // candidates in use
+    int32_t label;         // label of candidate 0
+    int32_t apply;         // candidate to apply next (>= 1) or -1
+    int32_t apply_label;
+    int32_t miss;          // the farthest point was not a stored candidate
+    uint32_t used;         // bitmask of candidates already applied
     int32_t pad;
+    int32_t src[EK_MAX_CANDS];      // record index of each candidate
+    int64_t gidx[EK_MAX_CANDS];
+    float maxdist[EK_MAX_CANDS];
 };
 
 // ---- kernel launchers (defined in the .hip files) ---------------------------
@@ -130,3 +155,30 @@ void ek_launch_pam_scatter(const uint32_t *amb,
 #define EK_SUMSQ_PART_DOUBLES 2048
 void ek_launch_sumsq2(const float *a, const float *b, int64_t n, double *part,
                       double *out, hipStream_t s);
+
+// ---- multi-candidate rounds (ek_spec.hip) ---------------------------------------
+void ek_launch_plan(const unsigned char *recs, int n_recs, int A, int T,
+                    double cutoff, EkPlan *plan, EkHist *hist, EkCtl *ctl,
+                    hipStream_t s);
+size_t ek_pass_lds_bytes(int T, int A);
+void ek_launch_pass(int T, const float *tiles, const double *G, float *dist,
+                    int32_t *assign, float *vecs, int64_t n, int64_t n_pad,
+                    int A, const unsigned char *recs, const EkPlan *plan,
+                    EkBlockMax *blockmax, hipStream_t s);
+void ek_launch_blockmax(const float *dist, int64_t n, EkBlockMax *blockmax,
+                        hipStream_t s);
+void ek_launch_localmax(const EkBlockMax *blockmax, int nb,
+                        int64_t global_offset, EkMaxHdr *out, hipStream_t s);
+void ek_launch_check(const EkMaxHdr *hdrs, int n_hdrs, double cutoff,
+                     EkPlan *plan, EkHist *hist, EkCtl *ctl, hipStream_t s);
+void ek_launch_apply(const float *vecs, int64_t n, int64_t n_pad, float *dist,
+                     int32_t *assign, const EkPlan *plan, EkBlockMax *blockmax,
+                     hipStream_t s);
+void ek_launch_pickT(const EkBlockMax *blockmax, int nb, const float *tiles,
+                     const double *G, const int32_t *assign, int A, int T,
+                     int64_t global_offset, unsigned char *recs, EkCtl *ctl,
+                     hipStream_t s);
+void ek_launch_localmax_check(const EkBlockMax *blockmax, int nb,
+                              int64_t global_offset, double cutoff,
+                              EkPlan *plan, EkHist *hist, EkCtl *ctl,
+                              hipStream_t s);

@@ -16,32 +16,11 @@
 // once per workgroup in LDS and read back as wave-wide broadcasts.
 #include "ek_common.h"
 #include "ek_qcp.h"
+#include "ek_reduce.h"
 
 #ifndef EK_TRIP
 #define EK_TRIP 4      // atoms per loop trip (multiple of 4)
 #endif
-
-// ---------------------------------------------------------------------------
-// arg-max helpers: larger value wins, lower index wins ties (np.argmax)
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ bool ek_better(float v, uint32_t i, float bv,
-                                          uint32_t bi)
-{
-    return (v > bv) || (v == bv && i < bi);
-}
-
-__device__ __forceinline__ void ek_wave_argmax(float &v, uint32_t &i)
-{
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const float ov = __shfl_xor(v, off, 64);
-        const uint32_t oi = __shfl_xor(i, off, 64);
-        if (ek_better(ov, oi, v, i)) {
-            v = ov;
-            i = oi;
-        }
-    }
-}
 
 typedef float ek_f2 __attribute__((ext_vector_type(2)));
 typedef float ek_f4 __attribute__((ext_vector_type(4)));

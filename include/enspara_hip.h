@@ -132,6 +132,32 @@ int ek_kcenters_run(ek_ctx *ctx, int32_t first_label, int32_t max_new,
                     int64_t *center_index_out, float *center_dist_out,
                     float *final_maxdist);
 
+/* ---- several candidate centers per pass ("speculative" rounds) ------------------
+ * The same sequential algorithm (identical centers, labels, distances) with
+ * the frames streamed once per ROUND against T candidates (DESIGN.md
+ * section 4a).  ek_kcenters_run uses it on one shard automatically.  Across
+ * shards the caller moves two kinds of messages:
+ *   per round:   T candidate records per rank (T * ek_record_bytes, T =
+ *                ek_spec_candidates) -> all-gather -> ek_spec_round
+ *   per center:  one 16-byte header {float maxdist; int32 valid; int64 global
+ *                index} per rank (ek_spec_localmax) -> all-gather ->
+ *                ek_spec_apply, T-1 times per round
+ * ek_spec_begin(first_label, limit): accept centers first_label..limit-1, then
+ * make every further call a no-op; writes this shard's first T records.
+ * ek_spec_round_end writes the records for the next round.  ek_spec_progress
+ * synchronises and reports how many centers exist and whether the stop rule
+ * (maximum distance <= dist_cutoff, kcenters.py:217) fired. */
+int ek_spec_candidates(ek_ctx *ctx);
+int ek_spec_begin(ek_ctx *ctx, int32_t first_label, int32_t limit,
+                  void *recs_out);
+int ek_spec_round(ek_ctx *ctx, const void *recs_all, int32_t n_recs,
+                  double dist_cutoff);
+int ek_spec_localmax(ek_ctx *ctx, void *hdr_out);
+int ek_spec_apply(ek_ctx *ctx, const void *hdrs_all, int32_t n_hdrs,
+                  double dist_cutoff);
+int ek_spec_round_end(ek_ctx *ctx, void *recs_out);
+int ek_spec_progress(ek_ctx *ctx, int32_t *n_done, int32_t *stopped);
+
 /* history written by ek_kcenters_step: for labels [first, first+count) the
  * global frame index and pre-update distance of each accepted center;
  * *n_done = 1 + the highest label accepted so far (0 if none). */
@@ -257,6 +283,8 @@ int ek_feat_distance(ek_feat *k, int32_t metric, const void *y,
 int ek_set_frames_per_lane(ek_ctx *ctx, int fpl);
 /* key 1: non-temporal loads of the frame stream (0/1; -1 = automatic:
  * on when the shard is larger than the Infinity Cache)
+ * key 4: candidate centers per pass of ek_kcenters_run / ek_spec_*: -1
+ * automatic (8, fewer for very large atom counts), 1 = one-center passes, 4, 8
  * key 2: nearest-center kernel: 0 automatic, 1 vector FMA, 2 MFMA (identical
  * results) */
 int ek_set_option(ek_ctx *ctx, int32_t key, int32_t value);

@@ -174,3 +174,46 @@ def test_assign_variants_bit_identical(qcp, n, A, K):
             st.assign_nearest(dup)
             d, a = st.download_state()
             assert not np.isin(a, [3, 4, 5]).any()
+
+
+@pytest.mark.parametrize("cands", [1, 4, 8])
+def test_candidates_per_pass_do_not_change_results(ocl, cands):
+    """multi-candidate rounds are the same algorithm: identical centers,
+    labels and distances whatever the number of candidates per pass"""
+    from enspara_amd.cluster import kcenters as kc
+    x = synth.synth(4000, 33, 40, seed=17)
+    inds, a, d = ocl.kcenters(x, n_clusters=120)
+    with _store(x) as st:
+        st.set_option(4, cands)
+        r = kc._kcenters_device(x, 120, 0, None, 0, store=st)
+    assert list(r.center_indices) == [int(i) for i in inds]
+    np.testing.assert_array_equal(r.assignments, a)
+    np.testing.assert_array_equal(r.distances, d)
+    # cut-off mode and a continuation from existing labels
+    inds, a, d = ocl.kcenters(x, dist_cutoff=0.4)
+    with _store(x) as st:
+        st.set_option(4, cands)
+        r = kc._kcenters_device(x, np.inf, 0.4, None, 0, store=st)
+    assert list(r.center_indices) == [int(i) for i in inds]
+    np.testing.assert_array_equal(r.assignments, a)
+    np.testing.assert_array_equal(r.distances, d)
+    init = [x[9], x[1234]]
+    inds, a, d = ocl.kcenters(x, n_clusters=31, init_centers=init)
+    with _store(x) as st:
+        st.set_option(4, cands)
+        r = kc._kcenters_device(x, 31, 0, init, 0, store=st)
+    assert list(r.center_indices) == [int(i) for i in inds]
+    np.testing.assert_array_equal(r.assignments, a)
+
+
+def test_duplicate_frames_and_exhaustion(ocl):
+    """fewer distinct frames than requested centers: the stop rule
+    (max distance 0 is not > 0) ends the run identically"""
+    from enspara_amd.cluster.kcenters import kcenters
+    base = synth.synth(7, 12, 7, seed=5)
+    x = np.concatenate([base] * 40)
+    inds, a, d = ocl.kcenters(x, n_clusters=50)
+    r = kcenters(x, "rmsd", n_clusters=50)
+    assert list(r.center_indices) == [int(i) for i in inds]
+    np.testing.assert_array_equal(r.assignments, a)
+    np.testing.assert_array_equal(r.distances, d)

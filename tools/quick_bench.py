@@ -19,17 +19,18 @@ st.sync()
 print("upload+prepare %.2fs" % (time.time() - t), flush=True)
 bpp = 12 * A + 20
 import itertools
-for nt, fpl in itertools.product((1,), (1, 2, 4)):
+for nt, fpl in [(1, 2), (4, 0), (8, 0)]:
     st.set_frames_per_lane(fpl)
-    st.set_option(1, nt)
+    st.set_option(4, nt)
     for rep in range(3):
         st.reset_state()
         t = time.time()
         idx, cd, mx = st.kcenters_run(0, K, 0.0)
         wall = time.time() - t
         ms, k = st.last_run_timing()
+        k = len(idx)
     pairs = n * k / (ms * 1e-3)
-    print("nt=%d " % nt, end="")
+    print("cands=%d passes=%d " % (nt, k if nt == 1 else st.last_run_timing()[1]), end="")
     print("fpl=%d  k=%d  dev %.2f ms (%.3f ms/iter)  wall %.2f ms  %.3e pairs/s  %.0f GB/s (%.1f%% of 8TB/s)"
           % (fpl, k, ms, ms / k, wall * 1e3, pairs, pairs * bpp / 1e9, pairs * bpp / 8e12 * 100), flush=True)
 print("centers", idx[:8], "max", mx)
