@@ -728,8 +728,8 @@ extern "C" int ek_kcenters_run(ek_ctx *c, int32_t first_label, int32_t max_new,
                     ek_launch_localmax_check(c->blockmax, nb, c->goff,
                                              dist_cutoff, c->plan, c->hist,
                                              c->ctl, c->stream);
-                    ek_launch_apply(c->vecs, c->n, c->n_pad, c->dist, c->assign,
-                                    c->plan, c->blockmax, c->stream);
+                    ek_launch_apply(c->vecs, c->G, c->n, c->n_pad, c->A, c->dist,
+                                    c->assign, c->plan, c->blockmax, c->stream);
                 }
                 ek_launch_pickT(c->blockmax, nb, c->tiles, c->G, c->assign, c->A, T,
                                 c->goff, c->recsT, c->ctl, c->stream);
@@ -838,17 +838,26 @@ extern "C" int ek_timing_end(ek_ctx *c, float *avg_ms, int32_t *n_samples)
         return ek_fail(EK_EARG, "NULL context");
     EK_HIP(hipSetDevice(c->device));
     EK_HIP(hipStreamSynchronize(c->stream));
-    double sum = 0.0;
+    // launches enqueued past the stopping point return immediately (device
+    // no-ops): only samples within 4x of the longest count as real launches
+    std::vector<float> t((size_t)c->samp_used);
+    float mx = 0.f;
     for (int i = 0; i < c->samp_used; ++i) {
-        float ms = 0.f;
-        EK_HIP(hipEventElapsedTime(&ms, c->samp_ev[2 * i],
+        EK_HIP(hipEventElapsedTime(&t[i], c->samp_ev[2 * i],
                                    c->samp_ev[2 * i + 1]));
-        sum += ms;
+        mx = std::max(mx, t[i]);
     }
+    double sum = 0.0;
+    int used = 0;
+    for (int i = 0; i < c->samp_used; ++i)
+        if (t[i] > 0.25f * mx) {
+            sum += t[i];
+            ++used;
+        }
     if (avg_ms)
-        *avg_ms = c->samp_used ? (float)(sum / c->samp_used) : 0.f;
+        *avg_ms = used ? (float)(sum / used) : 0.f;
     if (n_samples)
-        *n_samples = c->samp_used;
+        *n_samples = used;
     c->samp_every = 0;
     return EK_OK;
 }
@@ -1246,8 +1255,8 @@ extern "C" int ek_spec_apply(ek_ctx *c, const void *hdrs_all, int32_t n_hdrs,
     EK_HIP(hipSetDevice(c->device));
     ek_launch_check((const EkMaxHdr *)hdrs_all, n_hdrs, dist_cutoff, c->plan,
                     c->hist, c->ctl, c->stream);
-    ek_launch_apply(c->vecs, c->n, c->n_pad, c->dist, c->assign, c->plan,
-                    c->blockmax, c->stream);
+    ek_launch_apply(c->vecs, c->G, c->n, c->n_pad, c->A, c->dist, c->assign,
+                    c->plan, c->blockmax, c->stream);
     EK_CHECK_LAUNCH();
     return EK_OK;
 }

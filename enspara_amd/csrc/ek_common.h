@@ -69,6 +69,7 @@ struct EkPlan {
     int32_t src[EK_MAX_CANDS];      // record index of each candidate
     int64_t gidx[EK_MAX_CANDS];
     float maxdist[EK_MAX_CANDS];
+    double trace[EK_MAX_CANDS];
 };
 
 // ---- kernel launchers (defined in the .hip files) ---------------------------
@@ -171,9 +172,9 @@ void ek_launch_localmax(const EkBlockMax *blockmax, int nb,
                         int64_t global_offset, EkMaxHdr *out, hipStream_t s);
 void ek_launch_check(const EkMaxHdr *hdrs, int n_hdrs, double cutoff,
                      EkPlan *plan, EkHist *hist, EkCtl *ctl, hipStream_t s);
-void ek_launch_apply(const float *vecs, int64_t n, int64_t n_pad, float *dist,
-                     int32_t *assign, const EkPlan *plan, EkBlockMax *blockmax,
-                     hipStream_t s);
+void ek_launch_apply(const float *vecs, const double *G, int64_t n,
+                     int64_t n_pad, int A, float *dist, int32_t *assign,
+                     const EkPlan *plan, EkBlockMax *blockmax, hipStream_t s);
 void ek_launch_pickT(const EkBlockMax *blockmax, int nb, const float *tiles,
                      const double *G, const int32_t *assign, int A, int T,
                      int64_t global_offset, unsigned char *recs, EkCtl *ctl,

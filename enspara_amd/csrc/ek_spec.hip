@@ -6,12 +6,12 @@
 //
 //   round:  the frames are streamed ONCE against T candidate centers: the
 //           true farthest point (candidate 0, applied immediately, exactly as
-//           ek_step_kernel does) and T-1 further far points.  The T-1 extra
-//           distance vectors are kept (4 bytes per frame each).
+//           ek_step_kernel does) and T-1 further far points, whose distance
+//           vectors are kept (4 bytes per frame each).
 //   then:   the farthest point of the updated distances is found again
 //           (kcenters.py:282).  If it is one of the stored candidates its
-//           distance vector is already there: applying it is a 12-byte-per-
-//           frame update instead of a (12 A + 20)-byte pass.  This repeats
+//           distances are already there: applying them is a 16-byte-per-frame
+//           update instead of a (12 A + 20)-byte pass.  This repeats
 //           until the farthest point is not a stored candidate; then the next
 //           round starts.
 //
@@ -28,6 +28,9 @@
 
 #ifndef EK_SPEC_TRIP
 #define EK_SPEC_TRIP 4
+#endif
+#ifndef EK_SPEC_DB
+#define EK_SPEC_DB true
 #endif
 
 // ---------------------------------------------------------------------------
@@ -76,6 +79,8 @@ ek_plan_kernel(const unsigned char *__restrict__ recs, int n_recs, int A, int T,
         plan->src[j] = best;
         plan->gidx[j] = bg;
         plan->maxdist[j] = bv;
+        plan->trace[j] =
+            ((const EkRecHdr *)(recs + (size_t)best * rstride))->trace;
         ++teff;
     }
     if (teff == 0)
@@ -114,7 +119,7 @@ template <int T>
 __global__ void __launch_bounds__(EK_BLOCK, (T <= 4) ? 5 : 3)
 ek_pass_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
                float *__restrict__ dist, int32_t *__restrict__ assign,
-               float *__restrict__ vecs,   // [T-1][n_pad]
+               float *__restrict__ vecs,   // [T-1][n_pad] stored distance vectors
                int64_t n, int64_t n_pad, int A,
                const unsigned char *__restrict__ recs,
                const EkPlan *__restrict__ plan,
@@ -168,7 +173,7 @@ ek_pass_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
     // requested before the FMAs of trip t are issued (register double buffer).
     // (T = 8 has no registers to spare for that: it runs single-buffered with
     // twice the trip length instead.)
-    constexpr bool DB = (T <= 4);
+    constexpr bool DB = EK_SPEC_DB;
     constexpr int TRIP = DB ? EK_SPEC_TRIP : 2 * EK_SPEC_TRIP;   // atoms per trip
     const int n_trip = (A + TRIP - 1) / TRIP;
     float cx_[TRIP], cy_[TRIP], cz_[TRIP];  // current trip's rows
@@ -255,10 +260,10 @@ ek_pass_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
         }
         bestv = cur;
         besti = (uint32_t)f;
-        // the guesses: keep their distances for later
+        // the guesses: keep their distances for later (one quartic solve at a
+        // time: interleaving them costs registers)
 #pragma unroll
         for (int c = 1; c < T; ++c) {
-            // one solve at a time: interleaving them costs registers
             __builtin_amdgcn_sched_barrier(0);
             if (c < teff)
                 vecs[(size_t)(c - 1) * n_pad + f] =
@@ -564,11 +569,11 @@ void ek_launch_check(const EkMaxHdr *hdrs, int n_hdrs, double cutoff,
                        n_hdrs, cutoff, plan, hist, ctl);
 }
 
-// apply a stored distance vector (kcenters.py:304-306 on cached distances)
+// apply a stored distance vector (kcenters.py:304-306 on kept distances)
 __global__ void __launch_bounds__(EK_BLOCK)
-ek_apply_kernel(const float *__restrict__ vecs, int64_t n, int64_t n_pad,
-                float *__restrict__ dist, int32_t *__restrict__ assign,
-                const EkPlan *__restrict__ plan,
+ek_apply_kernel(const float *__restrict__ vecs, const double *__restrict__ G,
+                int64_t n, int64_t n_pad, int A, float *__restrict__ dist,
+                int32_t *__restrict__ assign, const EkPlan *__restrict__ plan,
                 EkBlockMax *__restrict__ blockmax)
 {
     __shared__ float red_v[EK_BLOCK / EK_WAVE];
@@ -609,16 +614,16 @@ ek_apply_kernel(const float *__restrict__ vecs, int64_t n, int64_t n_pad,
     }
 }
 
-void ek_launch_apply(const float *vecs, int64_t n, int64_t n_pad, float *dist,
-                     int32_t *assign, const EkPlan *plan, EkBlockMax *blockmax,
-                     hipStream_t s)
+void ek_launch_apply(const float *vecs, const double *G, int64_t n,
+                     int64_t n_pad, int A, float *dist, int32_t *assign,
+                     const EkPlan *plan, EkBlockMax *blockmax, hipStream_t s)
 {
     if (n <= 0)
         return;
     hipLaunchKernelGGL(ek_apply_kernel,
                        dim3((unsigned)((n + EK_BLOCK - 1) / EK_BLOCK)),
-                       dim3(EK_BLOCK), 0, s, vecs, n, n_pad, dist, assign, plan,
-                       blockmax);
+                       dim3(EK_BLOCK), 0, s, vecs, G, n, n_pad, A, dist, assign,
+                       plan, blockmax);
 }
 
 // the shard's T candidate records for the next round: record 0 is its
@@ -645,8 +650,10 @@ ek_pickT_kernel(const EkBlockMax *__restrict__ blockmax, int nb,
     if (tid == 0)
         n_sel = 0;
     __syncthreads();
-    // at most 3T looks: candidates rejected for a duplicate label are skipped
-    for (int look = 0; look < 3 * T; ++look) {
+    // at most T + 4 looks: a few candidates may be passed over for carrying a
+    // label that is already represented, as long as T can still be filled
+    const int max_looks = T + 4;
+    for (int look = 0; look < max_looks; ++look) {
         if (n_sel >= T)
             break;
         float v;
@@ -659,8 +666,8 @@ ek_pickT_kernel(const EkBlockMax *__restrict__ blockmax, int nb,
             skip[b >> 5] |= 1u << (b & 31);
             const int32_t lab = assign[i];
             bool dup = false;
-            // the last T looks take anything, so that T candidates are found
-            if (look < 2 * T && lab >= 0)
+            const bool can_skip = (max_looks - look - 1) >= (T - n_sel);
+            if (can_skip && lab >= 0)
                 for (int j = 0; j < n_sel; ++j)
                     dup = dup || (sel_lab[j] == lab);
             if (!dup || n_sel == 0) {

@@ -210,6 +210,39 @@ class FrameStore:
             int(n_recs), int(label), float(dist_cutoff),
             C.c_void_p(int(own_rec_out)) if own_rec_out else None))
 
+    # -- multi-candidate rounds across shards ----------------------------------
+    @property
+    def candidates(self):
+        return int(self.lib.ek_spec_candidates(self._h))
+
+    def spec_begin(self, first_label, limit, recs_out_ptr):
+        _lib.check(self.lib.ek_spec_begin(self._h, int(first_label), int(limit),
+                                          C.c_void_p(int(recs_out_ptr))))
+
+    def spec_round(self, recs_all_ptr, n_recs, dist_cutoff):
+        _lib.check(self.lib.ek_spec_round(
+            self._h, C.c_void_p(int(recs_all_ptr)), int(n_recs),
+            float(dist_cutoff)))
+
+    def spec_localmax(self, hdr_out_ptr):
+        _lib.check(self.lib.ek_spec_localmax(self._h,
+                                             C.c_void_p(int(hdr_out_ptr))))
+
+    def spec_apply(self, hdrs_all_ptr, n_hdrs, dist_cutoff):
+        _lib.check(self.lib.ek_spec_apply(
+            self._h, C.c_void_p(int(hdrs_all_ptr)), int(n_hdrs),
+            float(dist_cutoff)))
+
+    def spec_round_end(self, recs_out_ptr):
+        _lib.check(self.lib.ek_spec_round_end(self._h,
+                                              C.c_void_p(int(recs_out_ptr))))
+
+    def spec_progress(self):
+        nd, st = C.c_int32(), C.c_int32()
+        _lib.check(self.lib.ek_spec_progress(self._h, C.byref(nd),
+                                             C.byref(st)))
+        return nd.value, bool(st.value)
+
     def history(self, first, count):
         idx = np.empty(max(count, 1), dtype=np.int64)
         cd = np.empty(max(count, 1), dtype=np.float32)

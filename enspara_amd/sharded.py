@@ -57,9 +57,32 @@ class DeviceShard:
                                  own_rec.data_ptr())
 
     def progress(self):
-        """-> (n_done, stopped) ; synchronises"""
+        """-> number of centers so far; synchronises"""
         _, _, n_done = self.store.history(0, 0)
         return n_done
+
+    # multi-candidate rounds
+    @property
+    def candidates(self):
+        return self.store.candidates
+
+    def spec_begin(self, first_label, limit, recs):
+        self.store.spec_begin(first_label, limit, recs.data_ptr())
+
+    def spec_round(self, recs_all, n_recs, cutoff):
+        self.store.spec_round(recs_all.data_ptr(), n_recs, cutoff)
+
+    def spec_localmax(self, hdr):
+        self.store.spec_localmax(hdr.data_ptr())
+
+    def spec_apply(self, hdrs_all, n_hdrs, cutoff):
+        self.store.spec_apply(hdrs_all.data_ptr(), n_hdrs, cutoff)
+
+    def spec_round_end(self, recs):
+        self.store.spec_round_end(recs.data_ptr())
+
+    def spec_progress(self):
+        return self.store.spec_progress()
 
     def history(self, first, count):
         idx, cd, n_done = self.store.history(first, count)
@@ -89,6 +112,11 @@ def kcenters_sharded(shard, first_label, max_new, dist_cutoff=0.0, group=None,
     import torch.distributed as dist
     world, _ = _world(group)
     collective = dist.is_available() and dist.is_initialized()
+    T = getattr(shard, "candidates", 1)
+    if T > 1 and world * T <= 64:
+        return _kcenters_sharded_rounds(shard, first_label, max_new,
+                                        dist_cutoff, group, fresh, world, T,
+                                        collective)
     rb = shard.record_bytes
     mine = shard.new_buffer(rb)
     everyone = shard.new_buffer(rb * world) if collective else mine
@@ -110,6 +138,49 @@ def kcenters_sharded(shard, first_label, max_new, dist_cutoff=0.0, group=None,
             n_done = shard.progress()
             if n_done < first_label + issued:     # a step hit the stop rule
                 break
+    idx, cd, n_done = shard.history(first_label, max_new)
+    k = max(0, n_done - first_label)
+    return np.array(idx[:k], dtype=np.int64), np.array(cd[:k],
+                                                      dtype=np.float32)
+
+
+def _kcenters_sharded_rounds(shard, first_label, max_new, dist_cutoff, group,
+                             fresh, world, T, collective):
+    """Multi-candidate rounds (csrc/ek_spec.hip) across ranks.  Messages:
+    per round one all-gather of T candidate records per rank; per accepted
+    center one all-gather of a 16-byte (max distance, global index) header per
+    rank -- the same information the reference exchanges per iteration
+    (kcenters.py:332-335), while the frame Bcast (:345) is paid once per round
+    instead of once per center."""
+    import torch.distributed as dist
+    rb = shard.record_bytes
+    recs_mine = shard.new_buffer(rb * T)
+    recs_all = shard.new_buffer(rb * T * world) if collective else recs_mine
+    hdr_mine = shard.new_buffer(16)
+    hdr_all = shard.new_buffer(16 * world) if collective else hdr_mine
+    limit = first_label + max_new
+    if fresh:
+        shard.reset_history()
+    shard.spec_begin(first_label, limit, recs_mine)
+    n_done = first_label
+    per_round = 0.6 * T
+    while max_new > 0:
+        rounds = max(2, min(256, int((limit - n_done) / per_round) + 1))
+        before = n_done
+        for _ in range(rounds):
+            if collective:
+                dist.all_gather_into_tensor(recs_all, recs_mine, group=group)
+            shard.spec_round(recs_all, world * T, float(dist_cutoff))
+            for _j in range(1, T):
+                shard.spec_localmax(hdr_mine)
+                if collective:
+                    dist.all_gather_into_tensor(hdr_all, hdr_mine, group=group)
+                shard.spec_apply(hdr_all, world, float(dist_cutoff))
+            shard.spec_round_end(recs_mine)
+        n_done, stopped = shard.spec_progress()
+        if stopped or n_done >= limit:
+            break
+        per_round = max(1.0, (n_done - before) / rounds)
     idx, cd, n_done = shard.history(first_label, max_new)
     k = max(0, n_done - first_label)
     return np.array(idx[:k], dtype=np.int64), np.array(cd[:k],

@@ -15,7 +15,13 @@ HDR = np.dtype([("maxdist", "<f4"), ("valid", "<i4"), ("gidx", "<i8"),
 assert HDR.itemsize == 32
 
 
+MAXHDR = np.dtype([("maxdist", "<f4"), ("valid", "<i4"), ("gidx", "<i8")])
+assert MAXHDR.itemsize == 16
+
+
 class HostShard:
+    candidates = 1          # one-center protocol (ek_kcenters_step)
+
     def __init__(self, xyz, global_offset):
         self.P = qcp.Prepared(xyz) if len(xyz) else None
         self.n = len(xyz)
@@ -92,3 +98,116 @@ class HostShard:
         self.hist = {}
         self.n_done = 0
         self.stopped = False
+
+
+class HostShardRounds(HostShard):
+    """Same shard speaking the multi-candidate round protocol
+    (ek_spec_begin / _round / _localmax / _apply / _round_end / _progress)."""
+
+    def __init__(self, xyz, global_offset, candidates=4):
+        super().__init__(xyz, global_offset)
+        self.candidates = candidates
+        self.limit = 0
+        self.plan = None
+
+    def _hdr(self, buf, r):
+        rb = self.record_bytes
+        return buf[r * rb:r * rb + 32].view(HDR)[0]
+
+    def _records(self, recs):
+        """T candidate records: record 0 the local first-index arg-max, the
+        others simply the next largest distances"""
+        buf = recs.numpy()
+        rb = self.record_bytes
+        T = self.candidates
+        order = []
+        if self.n:
+            first = int(np.argmax(self.dist))
+            rest = [int(i) for i in np.argsort(-self.dist, kind="stable")
+                    if int(i) != first]
+            order = [first] + rest[:T - 1]
+        for j in range(T):
+            sub = recs[j * rb:(j + 1) * rb]
+            if j < len(order):
+                i = order[j]
+                self._write(sub, self.dist[i], 1, self.offset + i, self.P.G[i],
+                            self.P.c[i])
+            else:
+                self._write(sub, -np.inf, 0, -1, 0.0, None)
+
+    def spec_begin(self, first_label, limit, recs):
+        self.n_done = first_label
+        self.limit = limit
+        self.stopped = False
+        self._records(recs)
+
+    def spec_round(self, recs_all, n_recs, cutoff):
+        buf = recs_all.numpy()
+        rb = self.record_bytes
+        self.plan = None
+        if self.stopped or self.n_done >= self.limit:
+            return
+        hs = [(r, self._hdr(buf, r)) for r in range(n_recs)]
+        hs = [(r, h) for r, h in hs if h["valid"]]
+        hs.sort(key=lambda t: (-float(t[1]["maxdist"]), int(t[1]["gidx"])))
+        hs = hs[:self.candidates]
+        if not hs:
+            return
+        if not (float(hs[0][1]["maxdist"]) > cutoff):
+            self.stopped = True
+            return
+        cands = []
+        for r, h in hs:
+            coords = buf[r * rb + 32:r * rb + 32 + 12 * self.A].view(
+                np.float32).reshape(self.A, 3).copy()
+            vec = (qcp.rmsd_centered(self.P.c, self.P.G, coords,
+                                     float(h["trace"]))
+                   if self.n else np.zeros(0, np.float32))
+            cands.append(dict(gidx=int(h["gidx"]), vec=vec, used=False))
+        self.plan = dict(cands=cands, miss=False)
+        self._accept(cands[0], float(hs[0][1]["maxdist"]))
+
+    def _accept(self, cand, maxdist):
+        label = self.n_done
+        cand["used"] = True
+        upd = cand["vec"] < self.dist
+        self.dist[upd] = cand["vec"][upd]
+        self.assign[upd] = label
+        self.hist[label] = (cand["gidx"], maxdist)
+        self.n_done = label + 1
+
+    def spec_localmax(self, hdr):
+        h = np.zeros(1, dtype=MAXHDR)
+        if self.n:
+            i = int(np.argmax(self.dist))
+            h["maxdist"], h["valid"], h["gidx"] = self.dist[i], 1, self.offset + i
+        else:
+            h["maxdist"], h["valid"], h["gidx"] = -np.inf, 0, -1
+        hdr.numpy()[:16] = h.view(np.uint8)
+
+    def spec_apply(self, hdrs_all, n_hdrs, cutoff):
+        if self.plan is None or self.plan["miss"]:
+            return
+        self.plan["miss"] = True
+        if self.stopped or self.n_done >= self.limit:
+            return
+        hs = hdrs_all.numpy()[:16 * n_hdrs].view(MAXHDR)
+        hs = [h for h in hs if h["valid"]]
+        if not hs:
+            return
+        hs.sort(key=lambda h: (-float(h["maxdist"]), int(h["gidx"])))
+        w = hs[0]
+        if not (float(w["maxdist"]) > cutoff):
+            self.stopped = True
+            return
+        for c in self.plan["cands"][1:]:
+            if c["gidx"] == int(w["gidx"]) and not c["used"]:
+                self.plan["miss"] = False
+                self._accept(c, float(w["maxdist"]))
+                return
+
+    def spec_round_end(self, recs):
+        self._records(recs)
+
+    def spec_progress(self):
+        return self.n_done, self.stopped

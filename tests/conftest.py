@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# the CPU checker runs thousands of tiny OpenMP regions in these tests; on a
+# many-core host a small team is much faster than one thread per core
+os.environ.setdefault("OMP_NUM_THREADS", "8")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
