@@ -3,13 +3,20 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
-A "step" is one k-centers iteration: one new center against every frame of the
-shard (distance pass + strict-< update + farthest-point reduction), i.e.
+A "step" is one k-centers iteration: one new center, its RMSD to every frame of
+the shard, the strict-< update and the farthest-point reduction, i.e.
 n_frames RMSD pairs per GPU.  Workload at N=1 is BASELINE.json configs[1]:
 1,000,000 synthetic frames x 300 atoms, 5000 centers (steps default to 5000,
 the whole fit).  For N>1 (launched by torch.distributed.run, one rank per
-GPU, RCCL) every rank holds its own 1,000,000-frame shard (weak scaling) and
-the ranks exchange one candidate record per step (enspara_amd/sharded.py).
+GPU, RCCL) every rank holds its own 1,000,000-frame shard (weak scaling).
+
+By default the frames are streamed once per ROUND against --candidates (8)
+candidate centers and further centers are accepted from the stored distances
+while the farthest point is one of them (csrc/ek_spec.hip): the
+same sequential algorithm and bit-identical results with fewer passes over
+HBM.  `--candidates 1` runs one pass per center (the HBM roofline case of
+BASELINE.md).  Every reported pair is a distance that was computed; guesses
+that were never used are not counted ("pairs_computed" has the total).
 
 Inputs are resident in HBM (already centred and laid out frame-minor) when the
 timed region starts; generation, upload and layout are reported separately in
@@ -32,10 +39,16 @@ HBM_COPY_CEILING_GBS = 6290.0  # measured float4 copy on MI355X (same guide)
 
 
 def bytes_per_pair(n_atoms):
-    """Algorithmic HBM bytes per frame x center pair of the k-centers pass
+    """Algorithmic HBM bytes per frame x center pair of the one-center pass
     (DESIGN.md section 5): coordinates 12*A, trace 8 (f64), distance
     read+write 8, label write 4."""
     return 12 * n_atoms + 20
+
+
+def bytes_per_frame_pass(n_atoms, cands):
+    """Algorithmic HBM bytes per frame of one multi-candidate pass: the same
+    stream plus one stored float32 distance per extra candidate."""
+    return 12 * n_atoms + 20 + 4 * (cands - 1)
 
 
 def parse():
@@ -49,7 +62,9 @@ def parse():
     p.add_argument("--templates", type=int, default=5000)
     p.add_argument("--seed", type=int, default=1)
     p.add_argument("--fpl", type=int, default=0,
-                   help="frames per lane of the distance kernel (0 = auto)")
+                   help="frames per lane of the one-center kernel (0 = auto)")
+    p.add_argument("--candidates", type=int, default=-1,
+                   help="candidate centers per pass: -1 auto (8), 1, 4 or 8")
     p.add_argument("--cpu-seconds", type=float, default=15.0,
                    help="time budget of the CPU baseline leg (rank 0, N=1)")
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -109,13 +124,15 @@ def cpu_baseline(x, gpu_centers, seconds):
     }
 
 
-def load_traffic(args):
+def load_traffic(args, cands):
     """HBM bytes per distance-kernel launch from committed rocprofv3 --pmc
     runs of this same command (profiles/traffic.json), or None."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as fh:
             t = json.load(fh)
+        key = "cands%d" % cands
+        t = t.get(key, t if cands == 1 else {})
         if (t.get("frames") == args.frames and t.get("atoms") == args.atoms):
             return t.get("hbm_bytes_per_launch")
     except Exception:
@@ -177,6 +194,8 @@ def main():
     store.sync()
     t_load = time.perf_counter() - t0
     store.set_frames_per_lane(args.fpl)
+    store.set_option(4, args.candidates)
+    cands = store.candidates
     store.reset_state()
 
     shard = sharded.DeviceShard(store) if use_dist else None
@@ -194,7 +213,8 @@ def main():
     warm_idx = run(0, args.warmup, True)
 
     # ---- timed region: exactly --steps iterations ---------------------------
-    store.timing_begin(sample_every=max(1, args.steps // 256), max_samples=512)
+    store.timing_begin(sample_every=max(1, args.steps // (64 * max(cands, 4))),
+                       max_samples=512)
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -207,6 +227,7 @@ def main():
     if len(idx) != args.steps:
         raise SystemExit("only %d of %d steps ran" % (len(idx), args.steps))
     kern_ms, n_samp = store.timing_end()
+    rounds = store.spec_rounds() if cands > 1 else args.steps
 
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -221,7 +242,9 @@ def main():
     pairs = float(n_total) * args.steps
     value = pairs / elapsed
     bpp = bytes_per_pair(args.atoms)
-    achieved = (n_local * bpp / (kern_ms * 1e-3)) / 1e9 if kern_ms > 0 else None
+    launch_bytes = n_local * (bytes_per_frame_pass(args.atoms, cands)
+                              if cands > 1 else bpp)
+    achieved = (launch_bytes / (kern_ms * 1e-3)) / 1e9 if kern_ms > 0 else None
 
     out = {
         "metric": "frame x center RMSD pairs/sec in k-centers assign",
@@ -243,25 +266,35 @@ def main():
                            world),
             "frames_per_gpu": n_local, "frames_total": n_total,
             "atoms": args.atoms, "centers": args.warmup + args.steps,
+            "candidates_per_pass": cands,
+            "algorithm": ("k-centers, %d candidate centers per pass over the "
+                          "frames, results identical to one pass per center"
+                          % cands) if cands > 1 else
+                         "k-centers, one pass over the frames per center",
             "templates": args.templates, "seed": args.seed,
             "sharding": "contiguous frame blocks, 1 record all-gather/step"
                         if use_dist else "single shard",
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "ek_step_kernel<FPL,0>",
+            "kernel": ("ek_pass_kernel<%d>" % cands) if cands > 1
+                      else "ek_step_kernel<FPL,0,NT>",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
             "frac_of_measured_copy_ceiling":
                 (achieved / HBM_COPY_CEILING_GBS) if achieved else None,
-            "algorithmic_bytes_per_launch": n_local * bpp,
-            "bytes_per_pair": bpp,
+            "algorithmic_bytes_per_launch": launch_bytes,
+            "bytes_per_pair_one_center_pass": bpp,
+            "pairs_per_launch": n_local * cands,
             "avg_launch_ms": kern_ms,
             "launches_sampled": n_samp,
-            "traffic": load_traffic(args),
+            "traffic": load_traffic(args, cands),
         },
+        "passes_over_frames": rounds,
+        "centers_per_pass": args.steps / rounds if rounds else None,
+        "pairs_computed": float(n_total) * rounds * cands,
         "setup": {"synth_s": t_gen, "upload_center_layout_s": t_load,
                   "host_to_hbm_GBps": x.nbytes / t_load / 1e9},
     }

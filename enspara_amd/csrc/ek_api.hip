@@ -752,8 +752,9 @@ extern "C" int ek_kcenters_run(ek_ctx *c, int32_t first_label, int32_t max_new,
                               hipMemcpyDeviceToDevice, c->stream));
         EK_HIP(hipStreamSynchronize(c->stream));
         const int32_t added_t = std::max(0, cr.n_done - first_label);
-        c->last_launches = passes;
-        c->last_passes = passes;
+        c->last_launches = cr.n_rounds;
+        c->last_passes = cr.n_rounds;
+        (void)passes;
         if (n_added)
             *n_added = added_t;
         if (final_maxdist)
@@ -1272,6 +1273,19 @@ extern "C" int ek_spec_round_end(ek_ctx *c, void *recs_out)
                     recs_out ? (unsigned char *)recs_out : c->recsT, c->ctl,
                     c->stream);
     EK_CHECK_LAUNCH();
+    return EK_OK;
+}
+
+extern "C" int ek_spec_rounds(ek_ctx *c, int32_t *rounds)
+{
+    if (!c || !rounds)
+        return ek_fail(EK_EARG, "ek_spec_rounds: NULL argument");
+    EK_HIP(hipSetDevice(c->device));
+    EkCtl r;
+    EK_HIP(hipMemcpyAsync(&r, c->ctl, sizeof(r), hipMemcpyDeviceToHost,
+                          c->stream));
+    EK_HIP(hipStreamSynchronize(c->stream));
+    *rounds = r.n_rounds;
     return EK_OK;
 }
 

@@ -44,6 +44,8 @@ struct EkCtl {
     int32_t stopped;    // a step saw maxdist <= cutoff
     float last_max;     // maxdist carried by the most recent own record
     int32_t limit;      // multi-candidate rounds: stop once n_done == limit
+    int32_t n_rounds;   // rounds (passes over the frames) that really ran
+    int32_t pad[3];
 };
 
 // what a shard contributes to the per-center exchange between passes

@@ -100,6 +100,7 @@ ek_plan_kernel(const unsigned char *__restrict__ recs, int n_recs, int A, int T,
     hist[label].dist = plan->maxdist[0];
     hist[label].set = 1;
     ctl->n_done = label + 1;
+    ctl->n_rounds = ctl->n_rounds + 1;
 }
 
 void ek_launch_plan(const unsigned char *recs, int n_recs, int A, int T,

@@ -243,6 +243,11 @@ class FrameStore:
                                              C.byref(st)))
         return nd.value, bool(st.value)
 
+    def spec_rounds(self):
+        r = C.c_int32()
+        _lib.check(self.lib.ek_spec_rounds(self._h, C.byref(r)))
+        return r.value
+
     def history(self, first, count):
         idx = np.empty(max(count, 1), dtype=np.int64)
         cd = np.empty(max(count, 1), dtype=np.float32)

@@ -157,6 +157,9 @@ int ek_spec_apply(ek_ctx *ctx, const void *hdrs_all, int32_t n_hdrs,
                   double dist_cutoff);
 int ek_spec_round_end(ek_ctx *ctx, void *recs_out);
 int ek_spec_progress(ek_ctx *ctx, int32_t *n_done, int32_t *stopped);
+/* rounds (passes over the frames) that really ran since ek_spec_begin /
+ * ek_kcenters_run started */
+int ek_spec_rounds(ek_ctx *ctx, int32_t *rounds);
 
 /* history written by ek_kcenters_step: for labels [first, first+count) the
  * global frame index and pre-update distance of each accepted center;
