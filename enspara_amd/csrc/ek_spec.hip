@@ -645,40 +645,136 @@ ek_pickT_kernel(const EkBlockMax *__restrict__ blockmax, int nb,
     __shared__ float sel_v[EK_MAX_CANDS];
     __shared__ int32_t sel_lab[EK_MAX_CANDS];
     __shared__ int n_sel;
+    __shared__ uint32_t top_i[EK_MAX_CANDS + 4];
+    __shared__ float top_v[EK_MAX_CANDS + 4];
+    __shared__ int32_t top_lab[EK_MAX_CANDS + 4];
+    __shared__ int n_top;
     const int tid = threadIdx.x;
     for (int w = tid; w < (nb + 31) / 32; w += EK_RED_THREADS)
         skip[w] = 0;
-    if (tid == 0)
+    if (tid == 0) {
         n_sel = 0;
+        n_top = 0;
+    }
     __syncthreads();
     // at most T + 4 looks: a few candidates may be passed over for carrying a
-    // label that is already represented, as long as T can still be filled
+    // label that is already represented, as long as T can still be filled.
+    // The per-workgroup maxima are read once: every thread keeps its (up to
+    // PICK_PER) entries in registers across the looks; larger shards fall back
+    // to re-reading them.
+    constexpr int PICK_PER = 8;
+    const bool cached = nb <= PICK_PER * EK_RED_THREADS;
+    float cv[PICK_PER];
+    uint32_t ci[PICK_PER];
+    if (cached) {
+#pragma unroll
+        for (int k = 0; k < PICK_PER; ++k) {
+            const int bb = tid + k * EK_RED_THREADS;
+            cv[k] = -__builtin_inff();
+            ci[k] = 0xffffffffu;
+            if (bb < nb) {
+                const EkBlockMax m = blockmax[bb];
+                cv[k] = m.val;
+                ci[k] = m.idx;
+            }
+        }
+    }
+    __shared__ float r_v[EK_RED_THREADS / EK_WAVE];
+    __shared__ uint32_t r_i[EK_RED_THREADS / EK_WAVE];
+    __shared__ int r_b[EK_RED_THREADS / EK_WAVE];
+    __shared__ int w_b;
+    __shared__ uint32_t w_i;
+    __shared__ float w_v;
     const int max_looks = T + 4;
     for (int look = 0; look < max_looks; ++look) {
-        if (n_sel >= T)
-            break;
         float v;
         uint32_t i;
         int b;
-        ek_block_argmax(blockmax, nb, skip, v, i, b);
+        if (cached) {
+            v = -__builtin_inff();
+            i = 0xffffffffu;
+            b = -1;
+#pragma unroll
+            for (int k = 0; k < PICK_PER; ++k)
+                if (ci[k] != 0xffffffffu && ek_better(cv[k], ci[k], v, i)) {
+                    v = cv[k];
+                    i = ci[k];
+                    b = tid + k * EK_RED_THREADS;
+                }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const float ov = __shfl_xor(v, off, 64);
+                const uint32_t oi = __shfl_xor(i, off, 64);
+                const int ob = __shfl_xor(b, off, 64);
+                if (ek_better(ov, oi, v, i)) {
+                    v = ov;
+                    i = oi;
+                    b = ob;
+                }
+            }
+            if ((tid & 63) == 0) {
+                r_v[tid / 64] = v;
+                r_i[tid / 64] = i;
+                r_b[tid / 64] = b;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                for (int w = 1; w < EK_RED_THREADS / EK_WAVE; ++w)
+                    if (ek_better(r_v[w], r_i[w], v, i)) {
+                        v = r_v[w];
+                        i = r_i[w];
+                        b = r_b[w];
+                    }
+                w_v = v;
+                w_i = i;
+                w_b = b;
+            }
+            __syncthreads();
+            v = w_v;
+            i = w_i;
+            b = w_b;
+            // the owner of that entry retires it
+            if (b >= 0 && (b % EK_RED_THREADS) == tid) {
+#pragma unroll
+                for (int k = 0; k < PICK_PER; ++k)
+                    if (k == b / EK_RED_THREADS)
+                        ci[k] = 0xffffffffu;
+            }
+        } else {
+            ek_block_argmax(blockmax, nb, skip, v, i, b);
+        }
         if (b < 0)
             break;
         if (tid == 0) {
-            skip[b >> 5] |= 1u << (b & 31);
-            const int32_t lab = assign[i];
+            if (!cached)
+                skip[b >> 5] |= 1u << (b & 31);
+            top_i[n_top] = i;
+            top_v[n_top] = v;
+            n_top = n_top + 1;
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    // labels of the looked-at frames, fetched in parallel
+    if (tid < n_top)
+        top_lab[tid] = assign[top_i[tid]];
+    __syncthreads();
+    if (tid == 0) {
+        const int nt = n_top;
+        for (int look = 0; look < nt && n_sel < T; ++look) {
+            const int32_t lab = top_lab[look];
             bool dup = false;
-            const bool can_skip = (max_looks - look - 1) >= (T - n_sel);
+            const bool can_skip = (nt - look - 1) >= (T - n_sel);
             if (can_skip && lab >= 0)
                 for (int j = 0; j < n_sel; ++j)
                     dup = dup || (sel_lab[j] == lab);
             if (!dup || n_sel == 0) {
-                sel_i[n_sel] = i;
-                sel_v[n_sel] = v;
+                sel_i[n_sel] = top_i[look];
+                sel_v[n_sel] = top_v[look];
                 sel_lab[n_sel] = lab;
                 n_sel = n_sel + 1;
             }
         }
-        __syncthreads();
     }
     __syncthreads();
     const int ns = n_sel;
