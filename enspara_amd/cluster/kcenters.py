@@ -131,8 +131,17 @@ def _kcenters_device(traj, n_clusters, dist_cutoff, init_centers, device,
             ctr_inds = list(util.find_cluster_centers(a0.astype(np.int64),
                                                       d0.astype(np.float64)))
         budget = n_clusters - len(ctr_inds)
-        # a frame can usefully become a center once: cap an unbounded request
-        max_new = int(min(budget, n)) if budget > 0 else 0
+        # A finite n_clusters is honoured exactly (the reference keeps adding
+        # centers -- repeats of the frame with the largest residual
+        # self-distance -- once every frame is a center).  With only a
+        # distance cut-off the reference would loop forever if the cut-off lay
+        # below that residual; the request is capped at 2n + 16 here.
+        if budget <= 0:
+            max_new = 0
+        elif np.isinf(budget):
+            max_new = 2 * n + 16
+        else:
+            max_new = int(budget)
         new_idx, new_d, maxdist = store.kcenters_run(
             len(ctr_inds), max_new, float(dist_cutoff))
         d, a = store.download_state()

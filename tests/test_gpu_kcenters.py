@@ -217,3 +217,17 @@ def test_duplicate_frames_and_exhaustion(ocl):
     assert list(r.center_indices) == [int(i) for i in inds]
     np.testing.assert_array_equal(r.assignments, a)
     np.testing.assert_array_equal(r.distances, d)
+
+
+@pytest.mark.parametrize("n,A,k", [(1, 5, 3), (3, 4, 10), (9, 7, 9), (257, 3, 40),
+                                   (600, 11, 600)])
+def test_tiny_and_exhaustive_runs(ocl, n, A, k):
+    """fewer frames than candidates per pass, more centers requested than
+    frames, every frame becoming a center"""
+    from enspara_amd.cluster.kcenters import kcenters
+    x = synth.synth(n, A, max(1, n // 2), seed=3 * n + A)
+    inds, a, d = ocl.kcenters(x, n_clusters=k)
+    r = kcenters(x, "rmsd", n_clusters=k)
+    assert list(r.center_indices) == [int(i) for i in inds]
+    np.testing.assert_array_equal(r.assignments, a)
+    np.testing.assert_array_equal(r.distances, d)
