@@ -32,6 +32,8 @@ SYMBOLS = [
     "ek_assign_nearest",
     "ek_pam_begin", "ek_pam_count_members", "ek_pam_select_member",
     "ek_pam_propose", "ek_pam_propose_member", "ek_pam_commit",
+    "ek_pam_count_members_batch", "ek_pam_select_members_batch",
+    "ek_pam_prefetch", "ek_pam_propose_ex", "ek_pam_prefetch_stats",
     "ek_msm_counts", "ek_msm_row_normalize",
     "ek_krylov_create", "ek_krylov_destroy", "ek_krylov_set_vector",
     "ek_krylov_get_vector", "ek_krylov_step", "ek_krylov_rotate",
@@ -113,6 +115,12 @@ def load():
     L.ek_pam_propose.argtypes = [vp, i32, i64, f64p, f64p, i64p]
     L.ek_pam_propose_member.argtypes = [vp, i32, i64, i64p, f64p, f64p, i64p]
     L.ek_pam_commit.argtypes = [vp, C.c_int]
+    L.ek_pam_count_members_batch.argtypes = [vp, i32, i32, i64p]
+    L.ek_pam_select_members_batch.argtypes = [vp, i32, i32, i64p, i64p]
+    L.ek_pam_prefetch.argtypes = [vp, i64p, i32]
+    L.ek_pam_propose_ex.argtypes = [vp, i32, i64, i64, i32, i32, f64p, f64p,
+                                    i64p, C.POINTER(C.c_uint32)]
+    L.ek_pam_prefetch_stats.argtypes = [vp, i64p, i64p]
     L.ek_msm_counts.argtypes = [C.c_int, i32p, i64p, i64, i32, i32, i32, i64,
                                 i32p, i32p, i64p, i64p]
     L.ek_msm_row_normalize.argtypes = [C.c_int, i64p, f64p, i64, f64p, f64p]

@@ -155,28 +155,95 @@ def _check_proposals(proposals, medoid_inds):
                 proposals[0], medoid_inds[0]))
 
 
+# Proposals drawn ahead per pass over the frames (1..8; 1 = one distance pass
+# per proposal).  The results do not depend on it: every guess is checked
+# against the state and the random stream when its turn comes.
+PAM_PREFETCH = 8
+
+
+class _Window:
+    """Clusters [lo, hi) of a sweep with their member counts, the proposals
+    guessed for them and the bit mask of clusters whose membership has changed
+    since the guesses were made."""
+    __slots__ = ("lo", "hi", "m", "j", "frame", "stale")
+
+
+def _open_window(store, lo, hi, proposals, random_state):
+    w = _Window()
+    w.lo, w.hi, w.stale = lo, hi, 0
+    w.m = [int(x) for x in store.pam_count_members_batch(lo, hi - lo)]
+    if proposals is None:
+        # draw from a copy of the stream: the real draws happen in order below
+        ahead = np.random.RandomState()
+        ahead.set_state(random_state.get_state())
+        w.j = []
+        for m in w.m:
+            if m <= 0:          # the real draw raises when its turn comes
+                break
+            w.j.append(int(ahead.choice(m)))
+        w.frame = ([int(f) for f in
+                    store.pam_select_members_batch(lo, w.j)] if w.j else [])
+    else:
+        w.j = None
+        w.frame = [int(p) for p in proposals[lo:hi]]
+    store.pam_prefetch(w.frame)
+    return w
+
+
 def _pam_sweep_device(store, medoid_inds, proposals, random_state):
     """One sweep of kmedoids.py:575-699 against device-resident state."""
     random_state = check_random_state(random_state)          # :579
     _check_proposals(proposals, medoid_inds)
     store.pam_begin(medoid_inds)
+    K = len(medoid_inds)
+    width = max(1, min(int(PAM_PREFETCH), 8))
     acceptances = 0
     old_cost = new_cost = float("nan")
-    for cid in range(len(medoid_inds)):
-        if proposals is None:
-            m = store.pam_count_members(cid)                 # :611
-            # RandomState.choice(state_inds) == state_inds[choice(len)]
-            # (raises ValueError on an empty cluster, like the reference)
-            j = random_state.choice(m)                       # :514
-            prop, old_cost, new_cost, n_amb = store.pam_propose_member(cid, j)
+    win = None
+    for cid in range(K):
+        if width == 1:
+            if proposals is None:
+                m = store.pam_count_members(cid)             # :611
+                # RandomState.choice(state_inds) == state_inds[choice(len)]
+                # (raises ValueError on an empty cluster, like the reference)
+                j = random_state.choice(m)                   # :514
+                prop, old_cost, new_cost, n_amb = \
+                    store.pam_propose_member(cid, j)
+            else:
+                prop = int(proposals[cid])
+                old_cost, new_cost, n_amb = store.pam_propose(cid, prop)
+            moved = 0
         else:
-            prop = int(proposals[cid])
-            old_cost, new_cost, n_amb = store.pam_propose(cid, prop)
+            if win is None or cid >= win.hi:
+                win = _open_window(store, cid, min(K, cid + width), proposals,
+                                   random_state)
+            slot = cid - win.lo
+            exact = not ((win.stale >> slot) & 1)
+            counted = False
+            if exact:
+                m = win.m[slot]
+            else:
+                m = store.pam_count_members(cid)             # :611
+                counted = True
+            if proposals is None:
+                j = random_state.choice(m)                   # :514
+                if exact and slot < len(win.j) and j == win.j[slot]:
+                    prop = win.frame[slot]
+                else:
+                    if not counted:
+                        store.pam_count_members(cid)
+                    prop = store.pam_select_member(cid, j)
+            else:
+                prop = win.frame[slot]
+            old_cost, new_cost, n_amb, moved = store.pam_propose_ex(
+                cid, prop, m, win.lo, win.hi - win.lo)
         accept = new_cost < old_cost                         # :683
         store.pam_commit(accept)
         if accept:
             medoid_inds[cid] = prop
             acceptances += 1
+            if win is not None:
+                win.stale |= moved
         logger.debug("%s proposed center for k=%s: cost %.5f -> %.5f "
                      "(%d ambiguous).", "Accepted" if accept else "Rejected",
                      cid, old_cost, new_cost, n_amb)

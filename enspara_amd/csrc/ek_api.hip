@@ -96,6 +96,19 @@ struct ek_ctx {
     int32_t cnt_cid = -1;            // cluster of the last member count
     int64_t cnt_m = 0;
     int64_t pam_frame = -1;
+    // proposal prefetch: member lists of a window of clusters and the distance
+    // vectors of up to EK_MAX_CANDS proposed frames
+    int32_t *bat_blockcnt = nullptr; // [EK_MAX_CANDS][nb]
+    int64_t *bat_scan = nullptr;     // [EK_MAX_CANDS][nb]
+    int64_t *bat_sel = nullptr;      // [0..8) counts, [8..16) selected frames
+    int32_t bat_cid0 = -1, bat_count = 0;
+    float *pam_vecs = nullptr;       // [EK_MAX_CANDS][n_pad]
+    unsigned char *pam_recs = nullptr;
+    EkPlan *pam_plan = nullptr;
+    unsigned int *moved = nullptr;
+    int64_t pf_frames[EK_MAX_CANDS];
+    int32_t pf_count = 0;
+    int64_t pf_hits = 0, pf_misses = 0;
 
     // multi-candidate rounds (ek_spec.hip)
     int cands = -1;              // candidates per pass: -1 auto, 1 = one-center passes
@@ -199,6 +212,13 @@ static int ek_free_all(ek_ctx *c)
     (void)hipFree(c->cen_aos);
     (void)hipFree(c->cen_G);
     (void)hipFree(c->cen_tiles);
+    (void)hipFree(c->bat_blockcnt);
+    (void)hipFree(c->bat_scan);
+    (void)hipFree(c->bat_sel);
+    (void)hipFree(c->pam_vecs);
+    (void)hipFree(c->pam_recs);
+    (void)hipFree(c->pam_plan);
+    (void)hipFree(c->moved);
     (void)hipFree(c->recsT);
     (void)hipFree(c->plan);
     (void)hipFree(c->vecs);
@@ -940,7 +960,17 @@ extern "C" int ek_pam_begin(ek_ctx *c, const int64_t *medoid_frames, int32_t K)
         EK_HIP(hipMalloc((void **)&c->sq_part,
                          EK_SUMSQ_PART_DOUBLES * sizeof(double)));
         EK_HIP(hipMalloc((void **)&c->sq_out, 2 * sizeof(double)));
+        EK_HIP(hipMalloc((void **)&c->bat_blockcnt,
+                         (size_t)EK_MAX_CANDS * nb * sizeof(int32_t)));
+        EK_HIP(hipMalloc((void **)&c->bat_scan,
+                         (size_t)EK_MAX_CANDS * nb * sizeof(int64_t)));
+        EK_HIP(hipMalloc((void **)&c->bat_sel,
+                         2 * EK_MAX_CANDS * sizeof(int64_t)));
+        EK_HIP(hipMalloc((void **)&c->moved, sizeof(unsigned int)));
     }
+    c->bat_cid0 = -1;
+    c->bat_count = 0;
+    c->pf_count = 0;
     if (K > c->med_cap) {
         EK_HIP(hipStreamSynchronize(c->stream));
         (void)hipFree(c->med_aos);
@@ -1013,9 +1043,24 @@ extern "C" int ek_pam_select_member(ek_ctx *c, int32_t cid, int64_t j,
 static int ek_pam_propose_impl(ek_ctx *c, int32_t cid, int64_t frame_index,
                                int64_t max_amb, int64_t *frame_out,
                                double *old_cost, double *new_cost,
-                               int64_t *n_ambiguous)
+                               int64_t *n_ambiguous, int32_t win_lo = 0,
+                               int32_t win_count = 0,
+                               uint32_t *moved_mask = nullptr)
 {
     const int K = c->med_K;
+    // a prefetched distance vector for this frame (ek_pam_prefetch)?
+    const float *newd = c->scratch;
+    if (frame_index >= 0) {
+        for (int32_t j = 0; j < c->pf_count; ++j)
+            if (c->pf_frames[j] == frame_index) {
+                newd = c->pam_vecs + (size_t)j * c->n_pad;
+                break;
+            }
+        if (newd == c->scratch)
+            ++c->pf_misses;
+        else
+            ++c->pf_hits;
+    }
     const int64_t *idx_dev = nullptr;
     if (max_amb > c->ambt_cap) {
         EK_HIP(hipStreamSynchronize(c->stream));
@@ -1040,18 +1085,20 @@ static int ek_pam_propose_impl(ek_ctx *c, int32_t cid, int64_t frame_index,
     }
     idx_dev = c->med_idx + K;
     // distances of every frame to the proposed medoid (kmedoids.py:637)
-    ek_launch_record_from_frame(c->tiles, c->G, c->A, 0, idx_dev, c->goff,
-                                c->rec_tmp, c->stream);
-    ek_launch_step(ek_pick_fpl(c), 1, ek_pick_nt(c), c->tiles, c->G, c->dist,
-                   c->assign, c->scratch, c->rec_tmp, 1, c->n, c->A, 0, 0.0,
-                   c->blockmax, c->hist, c->ctl, c->stream);
-    EK_CHECK_LAUNCH();
+    if (newd == c->scratch) {
+        ek_launch_record_from_frame(c->tiles, c->G, c->A, 0, idx_dev, c->goff,
+                                    c->rec_tmp, c->stream);
+        ek_launch_step(ek_pick_fpl(c), 1, ek_pick_nt(c), c->tiles, c->G, c->dist,
+                       c->assign, c->scratch, c->rec_tmp, 1, c->n, c->A, 0, 0.0,
+                       c->blockmax, c->hist, c->ctl, c->stream);
+        EK_CHECK_LAUNCH();
+    }
     // trial medoid table: save row cid in row K, put the proposal in row cid
     ek_launch_copy_row(c->med_aos, c->med_G, c->A, cid, K, c->stream);
     ek_launch_gather_frames(c->tiles, c->G, c->A, idx_dev, 1, cid, c->med_aos,
                             c->med_G, c->stream);
     EK_HIP(hipMemsetAsync(c->amb_count, 0, sizeof(unsigned int), c->stream));
-    ek_launch_pam_classify(c->dist, c->assign, c->scratch, c->n, cid, c->ndist,
+    ek_launch_pam_classify(c->dist, c->assign, newd, c->n, cid, c->ndist,
                            c->nassign, c->amb, c->amb_best, c->amb_count,
                            c->stream);
     ek_launch_subset_assign(c->tiles, c->G, c->A, c->amb, c->amb_count, max_amb,
@@ -1060,10 +1107,16 @@ static int ek_pam_propose_impl(ek_ctx *c, int32_t cid, int64_t frame_index,
     ek_launch_pam_scatter(c->amb, c->amb_best, c->amb_count, max_amb, c->ndist,
                           c->nassign, c->stream);
     ek_launch_sumsq2(c->dist, c->ndist, c->n, c->sq_part, c->sq_out, c->stream);
+    if (moved_mask)
+        ek_launch_pam_moved(c->assign, c->nassign, c->n, win_lo, win_count,
+                            c->moved, c->stream);
     EK_CHECK_LAUNCH();
     double sums[2] = {0.0, 0.0};
     unsigned int n_amb = 0;
     int64_t fidx = frame_index;
+    if (moved_mask)
+        EK_HIP(hipMemcpyAsync(moved_mask, c->moved, sizeof(uint32_t),
+                              hipMemcpyDeviceToHost, c->stream));
     EK_HIP(hipMemcpyAsync(sums, c->sq_out, sizeof(sums), hipMemcpyDeviceToHost,
                           c->stream));
     EK_HIP(hipMemcpyAsync(&n_amb, c->amb_count, sizeof(n_amb),
@@ -1072,6 +1125,10 @@ static int ek_pam_propose_impl(ek_ctx *c, int32_t cid, int64_t frame_index,
         EK_HIP(hipMemcpyAsync(&fidx, c->med_idx + K, sizeof(int64_t),
                               hipMemcpyDeviceToHost, c->stream));
     EK_HIP(hipStreamSynchronize(c->stream));
+    if ((int64_t)n_amb > max_amb)
+        return ek_fail(EK_EARG, "PAM proposal: cluster %d has %u members that "
+                                "stay put, more than the %lld members declared",
+                       cid, n_amb, (long long)max_amb);
     if (old_cost)
         *old_cost = sums[0] / (double)c->n;
     if (new_cost)
@@ -1165,6 +1222,142 @@ extern "C" int ek_pam_commit(ek_ctx *c, int accept)
     }
     c->pam_cid = -1;
     c->cnt_cid = -1;
+    return EK_OK;
+}
+
+// ---- PAM proposal prefetch ------------------------------------------------------------
+// A sweep visits clusters 0..K-1 in order and an accepted proposal rarely
+// touches the clusters visited next, so the host draws the next few proposals
+// ahead of time, gets their distance vectors from ONE pass over the frames
+// (ek_pass_kernel<T,false>), and checks each guess when its turn comes.
+extern "C" int ek_pam_count_members_batch(ek_ctx *c, int32_t cid0, int32_t count,
+                                          int64_t *counts)
+{
+    if (!c || !counts)
+        return ek_fail(EK_EARG, "ek_pam_count_members_batch: NULL argument");
+    if (!c->ndist || c->med_K < 1)
+        return ek_fail(EK_ESTATE, "ek_pam_count_members_batch: call ek_pam_begin "
+                                  "first");
+    if (count < 1 || count > EK_MAX_CANDS || cid0 < 0 || cid0 + count > c->med_K)
+        return ek_fail(EK_EARG, "ek_pam_count_members_batch: clusters [%d,+%d) "
+                                "outside [0,%d) or more than %d", cid0, count,
+                       c->med_K, EK_MAX_CANDS);
+    EK_HIP(hipSetDevice(c->device));
+    const size_t nb = ((size_t)std::max<int64_t>(c->n, 1) + EK_BLOCK - 1) / EK_BLOCK;
+    for (int32_t j = 0; j < count; ++j)
+        ek_launch_count_members(c->assign, c->n, cid0 + j, c->bat_blockcnt + j * nb,
+                                c->bat_scan + j * nb, c->bat_sel + j, c->stream);
+    EK_CHECK_LAUNCH();
+    EK_HIP(hipMemcpyAsync(counts, c->bat_sel, (size_t)count * sizeof(int64_t),
+                          hipMemcpyDeviceToHost, c->stream));
+    EK_HIP(hipStreamSynchronize(c->stream));
+    c->bat_cid0 = cid0;
+    c->bat_count = count;
+    return EK_OK;
+}
+
+extern "C" int ek_pam_select_members_batch(ek_ctx *c, int32_t cid0, int32_t count,
+                                           const int64_t *js, int64_t *frames)
+{
+    if (!c || !js || !frames)
+        return ek_fail(EK_EARG, "ek_pam_select_members_batch: NULL argument");
+    if (c->bat_cid0 != cid0 || count < 1 || count > c->bat_count)
+        return ek_fail(EK_ESTATE, "ek_pam_select_members_batch: call "
+                                  "ek_pam_count_members_batch(%d, >=%d) first",
+                       cid0, count);
+    EK_HIP(hipSetDevice(c->device));
+    const size_t nb = ((size_t)std::max<int64_t>(c->n, 1) + EK_BLOCK - 1) / EK_BLOCK;
+    for (int32_t j = 0; j < count; ++j)
+        ek_launch_select_member(c->assign, c->n, cid0 + j, c->bat_scan + j * nb,
+                                js[j], c->bat_sel + EK_MAX_CANDS + j, c->stream);
+    EK_CHECK_LAUNCH();
+    EK_HIP(hipMemcpyAsync(frames, c->bat_sel + EK_MAX_CANDS,
+                          (size_t)count * sizeof(int64_t), hipMemcpyDeviceToHost,
+                          c->stream));
+    EK_HIP(hipStreamSynchronize(c->stream));
+    // the scans describe the state at count time only
+    c->bat_cid0 = -1;
+    c->bat_count = 0;
+    for (int32_t j = 0; j < count; ++j)
+        if (frames[j] < 0)
+            return ek_fail(EK_EARG, "ek_pam_select_members_batch: cluster %d has "
+                                    "no member %lld", cid0 + j, (long long)js[j]);
+    return EK_OK;
+}
+
+extern "C" int ek_pam_prefetch(ek_ctx *c, const int64_t *frames, int32_t count)
+{
+    if (!c || (!frames && count > 0))
+        return ek_fail(EK_EARG, "ek_pam_prefetch: NULL argument");
+    if (!c->ndist || c->med_K < 1)
+        return ek_fail(EK_ESTATE, "ek_pam_prefetch: call ek_pam_begin first");
+    if (count < 0 || count > EK_MAX_CANDS)
+        return ek_fail(EK_EARG, "ek_pam_prefetch: count=%d outside [0,%d]", count,
+                       EK_MAX_CANDS);
+    for (int32_t j = 0; j < count; ++j)
+        if (frames[j] < 0 || frames[j] >= c->n)
+            return ek_fail(EK_EARG, "ek_pam_prefetch: frame %lld out of range",
+                           (long long)frames[j]);
+    if ((size_t)3 * c->A * EK_MAX_CANDS * sizeof(float) > 150 * 1024)
+        return ek_fail(EK_EARG, "ek_pam_prefetch: %d atoms exceed the LDS center "
+                                "tile (limit 1600)", c->A);
+    EK_HIP(hipSetDevice(c->device));
+    c->pf_count = 0;
+    if (count == 0)
+        return EK_OK;
+    if (!c->pam_vecs) {
+        EK_HIP(hipMalloc((void **)&c->pam_vecs,
+                         (size_t)EK_MAX_CANDS * std::max<int64_t>(c->n_pad, 1) *
+                             sizeof(float)));
+        EK_HIP(hipMalloc((void **)&c->pam_recs,
+                         (size_t)EK_MAX_CANDS * ek_rec_bytes(c->A)));
+        EK_HIP(hipMalloc((void **)&c->pam_plan, sizeof(EkPlan)));
+    }
+    const size_t rstride = ek_rec_bytes(c->A);
+    for (int32_t j = 0; j < count; ++j)
+        ek_launch_record_from_frame(c->tiles, c->G, c->A, frames[j], nullptr,
+                                    c->goff, c->pam_recs + j * rstride, c->stream);
+    ek_launch_pass_dist(count, c->tiles, c->G, c->pam_vecs, c->n, c->n_pad, c->A,
+                        c->pam_recs, c->pam_plan, c->stream);
+    EK_CHECK_LAUNCH();
+    for (int32_t j = 0; j < count; ++j)
+        c->pf_frames[j] = frames[j];
+    c->pf_count = count;
+    return EK_OK;
+}
+
+extern "C" int ek_pam_propose_ex(ek_ctx *c, int32_t cid, int64_t frame_index,
+                                 int64_t n_members, int32_t win_lo,
+                                 int32_t win_count, double *old_cost,
+                                 double *new_cost, int64_t *n_ambiguous,
+                                 uint32_t *moved_mask)
+{
+    int rc = ek_pam_precheck(c, cid, "ek_pam_propose_ex");
+    if (rc)
+        return rc;
+    if (frame_index < 0 || frame_index >= c->n)
+        return ek_fail(EK_EARG, "ek_pam_propose_ex: frame %lld out of range",
+                       (long long)frame_index);
+    if (n_members < 0 || n_members > c->n)
+        return ek_fail(EK_EARG, "ek_pam_propose_ex: n_members=%lld",
+                       (long long)n_members);
+    if (win_count < 0 || win_count > 32 || (win_count > 0 && !moved_mask))
+        return ek_fail(EK_EARG, "ek_pam_propose_ex: bad window");
+    EK_HIP(hipSetDevice(c->device));
+    c->cnt_cid = -1;
+    return ek_pam_propose_impl(c, cid, frame_index, n_members, nullptr, old_cost,
+                               new_cost, n_ambiguous, win_lo, win_count,
+                               win_count > 0 ? moved_mask : nullptr);
+}
+
+extern "C" int ek_pam_prefetch_stats(ek_ctx *c, int64_t *hits, int64_t *misses)
+{
+    if (!c)
+        return ek_fail(EK_EARG, "NULL context");
+    if (hits)
+        *hits = c->pf_hits;
+    if (misses)
+        *misses = c->pf_misses;
     return EK_OK;
 }
 

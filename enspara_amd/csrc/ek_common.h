@@ -155,6 +155,9 @@ void ek_launch_pam_scatter(const uint32_t *amb,
                            const unsigned long long *amb_best,
                            const unsigned int *n_amb, int64_t max_amb,
                            float *ndist, int32_t *nassign, hipStream_t s);
+void ek_launch_pam_moved(const int32_t *assign, const int32_t *nassign,
+                         int64_t n, int32_t win_lo, int32_t win_count,
+                         unsigned int *mask, hipStream_t s);
 #define EK_SUMSQ_PART_DOUBLES 2048
 void ek_launch_sumsq2(const float *a, const float *b, int64_t n, double *part,
                       double *out, hipStream_t s);
@@ -168,6 +171,10 @@ void ek_launch_pass(int T, const float *tiles, const double *G, float *dist,
                     int32_t *assign, float *vecs, int64_t n, int64_t n_pad,
                     int A, const unsigned char *recs, const EkPlan *plan,
                     EkBlockMax *blockmax, hipStream_t s);
+// distances only: vecs[j][f] = rmsd(frame f, record j), j < count <= 8
+void ek_launch_pass_dist(int count, const float *tiles, const double *G,
+                         float *vecs, int64_t n, int64_t n_pad, int A,
+                         const unsigned char *recs, EkPlan *plan, hipStream_t s);
 void ek_launch_blockmax(const float *dist, int64_t n, EkBlockMax *blockmax,
                         hipStream_t s);
 void ek_launch_localmax(const EkBlockMax *blockmax, int nb,

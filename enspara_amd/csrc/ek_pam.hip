@@ -358,6 +358,54 @@ void ek_launch_pam_scatter(const uint32_t *amb,
                        nassign);
 }
 
+// ---- which clusters of a window would change membership on acceptance -----------
+// bit i of *mask is set when some frame enters or leaves cluster win_lo + i in
+// going from assign to nassign.  The host uses it to tell which prefetched
+// member lists (ek_pam_count_members_batch) are still exact after an accepted
+// proposal.
+__global__ void __launch_bounds__(EK_BLOCK)
+ek_pam_moved_kernel(const int32_t *__restrict__ assign,
+                    const int32_t *__restrict__ nassign, int64_t n,
+                    int32_t win_lo, int32_t win_count,
+                    unsigned int *__restrict__ mask)
+{
+    const int64_t f = (int64_t)blockIdx.x * EK_BLOCK + threadIdx.x;
+    unsigned int m = 0;
+    if (f < n) {
+        const int32_t a = assign[f], b = nassign[f];
+        if (a != b) {
+            const int32_t ia = a - win_lo, ib = b - win_lo;
+            if (ia >= 0 && ia < win_count)
+                m |= 1u << ia;
+            if (ib >= 0 && ib < win_count)
+                m |= 1u << ib;
+        }
+    }
+    if (__syncthreads_or((int)m)) {
+        __shared__ unsigned int acc;
+        if (threadIdx.x == 0)
+            acc = 0;
+        __syncthreads();
+        if (m)
+            atomicOr(&acc, m);
+        __syncthreads();
+        if (threadIdx.x == 0)
+            atomicOr(mask, acc);
+    }
+}
+
+void ek_launch_pam_moved(const int32_t *assign, const int32_t *nassign,
+                         int64_t n, int32_t win_lo, int32_t win_count,
+                         unsigned int *mask, hipStream_t s)
+{
+    (void)hipMemsetAsync(mask, 0, sizeof(unsigned int), s);
+    if (n <= 0 || win_count <= 0)
+        return;
+    const int nblocks = (int)((n + EK_BLOCK - 1) / EK_BLOCK);
+    hipLaunchKernelGGL(ek_pam_moved_kernel, dim3(nblocks), dim3(EK_BLOCK), 0, s,
+                       assign, nassign, n, win_lo, win_count, mask);
+}
+
 // ---- cost: sum of squares in float64, fixed reduction order -----------------------
 // (kmedoids.py:478-479 takes np.square(x).mean() in float64; each square of a
 // float32 is exact in float64, only the summation order differs from numpy's

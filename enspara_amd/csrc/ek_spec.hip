@@ -116,7 +116,10 @@ void ek_launch_plan(const unsigned char *recs, int n_recs, int A, int T,
 // one lane = one frame; candidates staged in LDS as ctile[atom][cand][xyz]
 // ---------------------------------------------------------------------------
 // waves per SIMD asked of the register allocator: 5 at T = 4, 3 at T = 8
-template <int T>
+// UPD = true: a k-centers round (candidate 0 updates the state, the others'
+// distances go to vecs[0..T-2]).  UPD = false: distances only, all T of them to
+// vecs[0..T-1] (PAM proposal prefetch); dist / assign / blockmax are not touched.
+template <int T, bool UPD>
 __global__ void __launch_bounds__(EK_BLOCK, (T <= 4) ? 5 : 3)
 ek_pass_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
                float *__restrict__ dist, int32_t *__restrict__ assign,
@@ -247,6 +250,19 @@ ek_pass_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
         }
     }
 
+    if (!UPD) {
+        if (f < n) {
+            const double Gf = G[f];
+#pragma unroll
+            for (int c = 0; c < T; ++c) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (c < teff)
+                    vecs[(size_t)c * n_pad + f] =
+                        ek_rmsd_from_S(s[c], Gf, gtile[c], A);
+            }
+        }
+        return;
+    }
     float bestv = -__builtin_inff();
     uint32_t besti = 0xffffffffu;
     if (f < n) {
@@ -307,17 +323,58 @@ void ek_launch_pass(int T, const float *tiles, const double *G, float *dist,
     do {                                                                       \
         if (lds > 48 * 1024)                                                   \
             (void)hipFuncSetAttribute(                                         \
-                (const void *)ek_pass_kernel<TT>,                              \
+                (const void *)ek_pass_kernel<TT, true>,                        \
                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \
-        hipLaunchKernelGGL(ek_pass_kernel<TT>, dim3(blocks), dim3(EK_BLOCK),   \
-                           lds, s, tiles, G, dist, assign, vecs, n, n_pad, A,  \
-                           recs, plan, blockmax);                              \
+        hipLaunchKernelGGL((ek_pass_kernel<TT, true>), dim3(blocks),           \
+                           dim3(EK_BLOCK), lds, s, tiles, G, dist, assign,     \
+                           vecs, n, n_pad, A, recs, plan, blockmax);           \
     } while (0)
     if (T == 8)
         EK_PASS(8);
     else
         EK_PASS(4);
 #undef EK_PASS
+}
+
+// distances of every frame to `count` records (count <= 8), nothing else:
+// vecs[j][f] = rmsd(frame f, record j).  Used to prefetch PAM proposals.
+__global__ void ek_plan_fixed_kernel(EkPlan *__restrict__ plan, int count)
+{
+    if (threadIdx.x != 0)
+        return;
+    plan->go = 1;
+    plan->teff = count;
+    plan->label = 0;
+    for (int j = 0; j < EK_MAX_CANDS; ++j)
+        plan->src[j] = j;
+}
+
+void ek_launch_pass_dist(int count, const float *tiles, const double *G,
+                         float *vecs, int64_t n, int64_t n_pad, int A,
+                         const unsigned char *recs, EkPlan *plan, hipStream_t s)
+{
+    if (n <= 0 || count <= 0)
+        return;
+    hipLaunchKernelGGL(ek_plan_fixed_kernel, dim3(1), dim3(EK_WAVE), 0, s, plan,
+                       count);
+    const unsigned blocks = (unsigned)((n + EK_BLOCK - 1) / EK_BLOCK);
+    const int T = (count <= 4) ? 4 : 8;
+    const size_t lds = ek_pass_lds_bytes(T, A);
+#define EK_PASSD(TT)                                                           \
+    do {                                                                       \
+        if (lds > 48 * 1024)                                                   \
+            (void)hipFuncSetAttribute(                                         \
+                (const void *)ek_pass_kernel<TT, false>,                       \
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \
+        hipLaunchKernelGGL((ek_pass_kernel<TT, false>), dim3(blocks),          \
+                           dim3(EK_BLOCK), lds, s, tiles, G, nullptr, nullptr, \
+                           vecs, n, n_pad, A, recs, plan, nullptr);            \
+    } while (0)
+    if (T == 8)
+        EK_PASSD(8);
+    else
+        EK_PASSD(4);
+#undef EK_PASSD
 }
 
 // ---------------------------------------------------------------------------

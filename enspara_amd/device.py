@@ -194,6 +194,46 @@ class FrameStore:
     def pam_commit(self, accept):
         _lib.check(self.lib.ek_pam_commit(self._h, 1 if accept else 0))
 
+    def pam_count_members_batch(self, cid0, count):
+        """Member counts of clusters cid0..cid0+count-1 (count <= 8)."""
+        out = np.zeros(count, dtype=np.int64)
+        _lib.check(self.lib.ek_pam_count_members_batch(
+            self._h, int(cid0), int(count), _lib.i64p(out)))
+        return out
+
+    def pam_select_members_batch(self, cid0, js):
+        """frames[i] = js[i]-th member of cluster cid0+i (right after
+        pam_count_members_batch(cid0, >= len(js)))."""
+        js = np.ascontiguousarray(js, dtype=np.int64)
+        out = np.zeros(len(js), dtype=np.int64)
+        _lib.check(self.lib.ek_pam_select_members_batch(
+            self._h, int(cid0), len(js), _lib.i64p(js), _lib.i64p(out)))
+        return out
+
+    def pam_prefetch(self, frames):
+        """Compute and keep the distances of every frame to frames[0..8)."""
+        f = np.ascontiguousarray(frames, dtype=np.int64)
+        _lib.check(self.lib.ek_pam_prefetch(self._h, _lib.i64p(f), len(f)))
+
+    def pam_propose_ex(self, cid, frame_index, n_members, win_lo=0,
+                       win_count=0):
+        """-> (old cost, new cost, number of ambiguous frames, moved mask)"""
+        oc, nc = C.c_double(), C.c_double()
+        na = C.c_int64()
+        mask = C.c_uint32()
+        _lib.check(self.lib.ek_pam_propose_ex(
+            self._h, int(cid), int(frame_index), int(n_members), int(win_lo),
+            int(win_count), C.byref(oc), C.byref(nc), C.byref(na),
+            C.byref(mask)))
+        return oc.value, nc.value, na.value, mask.value
+
+    def pam_prefetch_stats(self):
+        """-> (proposals served from a prefetched vector, not served)"""
+        h, m = C.c_int64(), C.c_int64()
+        _lib.check(self.lib.ek_pam_prefetch_stats(self._h, C.byref(h),
+                                                  C.byref(m)))
+        return h.value, m.value
+
     # -- multi-shard primitives ----------------------------------------------
     @property
     def record_bytes(self):

@@ -210,6 +210,39 @@ int ek_pam_propose_member(ek_ctx *ctx, int32_t cid, int64_t j,
                           double *new_cost, int64_t *n_ambiguous);
 int ek_pam_commit(ek_ctx *ctx, int accept);
 
+/* Proposal prefetch.  A sweep (kmedoids.py:575-699) visits clusters 0..K-1 in
+ * order, and an accepted proposal rarely changes the clusters visited next, so
+ * the host may draw the next `count` (<= 8) proposals ahead of time and have
+ * their distance vectors computed by ONE pass over the frames instead of one
+ * pass each; every guess is verified when its turn comes, so the sweep's
+ * results do not change.
+ *  ek_pam_count_members_batch: member counts of clusters cid0..cid0+count-1 in
+ *    the current state (one read-back);
+ *  ek_pam_select_members_batch: frames[i] = the js[i]-th member of cluster
+ *    cid0+i, from the scans the batch count left (call it right after);
+ *  ek_pam_prefetch: distances of every frame to frames[0..count) are computed
+ *    and kept until the next ek_pam_prefetch / ek_pam_begin (count = 0 drops
+ *    them); no read-back;
+ *  ek_pam_propose_ex: ek_pam_propose with the member count of cluster cid
+ *    supplied by the caller (n_members; it bounds the ambiguous set, the call
+ *    fails if it was too small) and, when frame_index was prefetched, without
+ *    the distance pass.  With win_count > 0 (<= 32), bit i of *moved_mask tells
+ *    whether accepting the proposal changes the membership of cluster
+ *    win_lo + i, i.e. whether member lists obtained earlier for that cluster
+ *    are stale after ek_pam_commit(ctx, 1).
+ *  ek_pam_prefetch_stats: proposals served from / not from a prefetched vector
+ *    since the context was created. */
+int ek_pam_count_members_batch(ek_ctx *ctx, int32_t cid0, int32_t count,
+                               int64_t *counts);
+int ek_pam_select_members_batch(ek_ctx *ctx, int32_t cid0, int32_t count,
+                                const int64_t *js, int64_t *frames);
+int ek_pam_prefetch(ek_ctx *ctx, const int64_t *frames, int32_t count);
+int ek_pam_propose_ex(ek_ctx *ctx, int32_t cid, int64_t frame_index,
+                      int64_t n_members, int32_t win_lo, int32_t win_count,
+                      double *old_cost, double *new_cost, int64_t *n_ambiguous,
+                      uint32_t *moved_mask);
+int ek_pam_prefetch_stats(ek_ctx *ctx, int64_t *hits, int64_t *misses);
+
 /* ---- MSM construction (secondary kernel) -------------------------------------
  * ek_msm_counts replaces assigns_to_counts
  * (enspara/msm/transition_matrices.py:113-170 with _transitions_helper

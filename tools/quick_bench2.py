@@ -32,18 +32,44 @@ if "assign" in what:
     d, a = st.download_state()
     # restore kcenters state for pam: labels from assign with all K centers are the kcenters labels
 if "pam" in what:
-    rs = np.random.RandomState(0)
-    st.pam_begin(idx)
-    t0 = time.time(); acc = 0; amb = 0
-    P = min(K, 300)
-    for cid in range(P):
-        m = st.pam_count_members(cid)
-        j = rs.choice(m)
-        prop, oc, nc, na = st.pam_propose_member(cid, j)
-        st.pam_commit(nc < oc); acc += nc < oc; amb += na
-    dt = time.time() - t0
-    print("pam: %d proposals %.3fs  %.3f ms/proposal  accept %d  mean ambiguous %.1f -> est. sweep of %d: %.1fs"
-          % (P, dt, dt / P * 1e3, acc, amb / P, K, dt / P * K), flush=True)
+    from enspara_amd.cluster import kmedoids as km
+    d0, a0 = st.download_state()
+    P = min(K, int(os.environ.get("PAM_PROPOSALS", "600")))
+    for width in (1, 4, 8):
+        km.PAM_PREFETCH = width
+        st.upload_state(d0, a0)
+        # time the first P clusters of a sweep through the product code path
+        med = [int(i) for i in idx]
+        rs = np.random.RandomState(0)
+        h0, m0 = st.pam_prefetch_stats()
+        st.pam_begin(med)
+        t0 = time.time()
+        win = None; acc = 0
+        for cid in range(P):
+            if width == 1:
+                m = st.pam_count_members(cid); j = rs.choice(m)
+                prop, oc, nc, na = st.pam_propose_member(cid, j)
+            else:
+                if win is None or cid >= win.hi:
+                    win = km._open_window(st, cid, min(K, cid + width), None, rs)
+                slot = cid - win.lo
+                exact = not ((win.stale >> slot) & 1)
+                m = win.m[slot] if exact else st.pam_count_members(cid)
+                j = rs.choice(m)
+                if exact and slot < len(win.j) and j == win.j[slot]:
+                    prop = win.frame[slot]
+                else:
+                    if exact:
+                        st.pam_count_members(cid)
+                    prop = st.pam_select_member(cid, j)
+                oc, nc, na, moved = st.pam_propose_ex(cid, prop, m, win.lo, win.hi - win.lo)
+                if nc < oc:
+                    win.stale |= moved
+            st.pam_commit(nc < oc); acc += nc < oc
+        dt = time.time() - t0
+        h1, m1 = st.pam_prefetch_stats()
+        print("pam width %d: %d proposals %.3fs  %.3f ms/proposal  accept %d  hits %d misses %d -> est. sweep of %d: %.1fs"
+              % (width, P, dt, dt / P * 1e3, acc, h1 - h0, m1 - m0, K, dt / P * K), flush=True)
 if "msm" in what:
     from enspara_amd.msm import assigns_to_counts, builders, eigenspectrum
     rng = np.random.RandomState(5)
