@@ -34,6 +34,8 @@ SYMBOLS = [
     "ek_pam_propose", "ek_pam_propose_member", "ek_pam_commit",
     "ek_pam_count_members_batch", "ek_pam_select_members_batch",
     "ek_pam_prefetch", "ek_pam_propose_ex", "ek_pam_prefetch_stats",
+    "ek_centered_frames", "ek_pam_begin_table", "ek_pam_prefetch_centers",
+    "ek_pam_propose_center",
     "ek_msm_counts", "ek_msm_row_normalize",
     "ek_krylov_create", "ek_krylov_destroy", "ek_krylov_set_vector",
     "ek_krylov_get_vector", "ek_krylov_step", "ek_krylov_rotate",
@@ -121,6 +123,10 @@ def load():
     L.ek_pam_propose_ex.argtypes = [vp, i32, i64, i64, i32, i32, f64p, f64p,
                                     i64p, C.POINTER(C.c_uint32)]
     L.ek_pam_prefetch_stats.argtypes = [vp, i64p, i64p]
+    L.ek_centered_frames.argtypes = [vp, i64p, i32p, i32, vp, vp]
+    L.ek_pam_begin_table.argtypes = [vp, vp, vp, i32]
+    L.ek_pam_prefetch_centers.argtypes = [vp, vp, vp, i32]
+    L.ek_pam_propose_center.argtypes = [vp, i32, i32, vp, vp, i64, i32, i32, vp]
     L.ek_msm_counts.argtypes = [C.c_int, i32p, i64p, i64, i32, i32, i32, i64,
                                 i32p, i32p, i64p, i64p]
     L.ek_msm_row_normalize.argtypes = [C.c_int, i64p, f64p, i64, f64p, f64p]

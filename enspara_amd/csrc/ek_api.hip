@@ -108,6 +108,9 @@ struct ek_ctx {
     unsigned int *moved = nullptr;
     int64_t pf_frames[EK_MAX_CANDS];
     int32_t pf_count = 0;
+    bool pf_external = false;        // slots hold caller-supplied centers
+    int64_t *tmp_idx = nullptr;      // scratch for index lists
+    int64_t tmp_idx_cap = 0;
     int64_t pf_hits = 0, pf_misses = 0;
 
     // multi-candidate rounds (ek_spec.hip)
@@ -219,6 +222,7 @@ static int ek_free_all(ek_ctx *c)
     (void)hipFree(c->pam_recs);
     (void)hipFree(c->pam_plan);
     (void)hipFree(c->moved);
+    (void)hipFree(c->tmp_idx);
     (void)hipFree(c->recsT);
     (void)hipFree(c->plan);
     (void)hipFree(c->vecs);
@@ -935,17 +939,9 @@ extern "C" int ek_assign_nearest(ek_ctx *c, const float *centers_xyz,
 }
 
 // ---- PAM (k-medoids) proposals ----------------------------------------------------------
-extern "C" int ek_pam_begin(ek_ctx *c, const int64_t *medoid_frames, int32_t K)
+// working set of a sweep over K medoids
+static int ek_pam_alloc(ek_ctx *c, int32_t K)
 {
-    if (!c || !medoid_frames || K < 1)
-        return ek_fail(EK_EARG, "ek_pam_begin: bad argument");
-    if (!c->loaded)
-        return ek_fail(EK_ESTATE, "ek_pam_begin: no frames loaded");
-    for (int32_t i = 0; i < K; ++i)
-        if (medoid_frames[i] < 0 || medoid_frames[i] >= c->n)
-            return ek_fail(EK_EARG, "ek_pam_begin: medoid %d = frame %lld out "
-                                    "of range", i, (long long)medoid_frames[i]);
-    EK_HIP(hipSetDevice(c->device));
     const size_t nn = (size_t)std::max<int64_t>(c->n, 1);
     const size_t nb = (nn + EK_BLOCK - 1) / EK_BLOCK;
     if (!c->ndist) {
@@ -967,10 +963,12 @@ extern "C" int ek_pam_begin(ek_ctx *c, const int64_t *medoid_frames, int32_t K)
         EK_HIP(hipMalloc((void **)&c->bat_sel,
                          2 * EK_MAX_CANDS * sizeof(int64_t)));
         EK_HIP(hipMalloc((void **)&c->moved, sizeof(unsigned int)));
+        EK_HIP(hipMemsetAsync(c->moved, 0, sizeof(unsigned int), c->stream));
     }
     c->bat_cid0 = -1;
     c->bat_count = 0;
     c->pf_count = 0;
+    c->pf_external = false;
     if (K > c->med_cap) {
         EK_HIP(hipStreamSynchronize(c->stream));
         (void)hipFree(c->med_aos);
@@ -988,12 +986,97 @@ extern "C" int ek_pam_begin(ek_ctx *c, const int64_t *medoid_frames, int32_t K)
     }
     c->med_K = K;
     c->pam_cid = -1;
+    c->cnt_cid = -1;
+    return EK_OK;
+}
+
+static int ek_tmp_idx(ek_ctx *c, int64_t count)
+{
+    if (count <= c->tmp_idx_cap)
+        return EK_OK;
+    EK_HIP(hipStreamSynchronize(c->stream));
+    (void)hipFree(c->tmp_idx);
+    c->tmp_idx = nullptr;
+    c->tmp_idx_cap = 0;
+    const int64_t cap = std::max<int64_t>(1024, count);
+    EK_HIP(hipMalloc((void **)&c->tmp_idx, (size_t)cap * sizeof(int64_t)));
+    c->tmp_idx_cap = cap;
+    return EK_OK;
+}
+
+extern "C" int ek_pam_begin(ek_ctx *c, const int64_t *medoid_frames, int32_t K)
+{
+    if (!c || !medoid_frames || K < 1)
+        return ek_fail(EK_EARG, "ek_pam_begin: bad argument");
+    if (!c->loaded)
+        return ek_fail(EK_ESTATE, "ek_pam_begin: no frames loaded");
+    for (int32_t i = 0; i < K; ++i)
+        if (medoid_frames[i] < 0 || medoid_frames[i] >= c->n)
+            return ek_fail(EK_EARG, "ek_pam_begin: medoid %d = frame %lld out "
+                                    "of range", i, (long long)medoid_frames[i]);
+    EK_HIP(hipSetDevice(c->device));
+    int rc = ek_pam_alloc(c, K);
+    if (rc)
+        return rc;
     EK_HIP(hipMemcpyAsync(c->med_idx, medoid_frames, (size_t)K * sizeof(int64_t),
                           hipMemcpyHostToDevice, c->stream));
     EK_HIP(hipStreamSynchronize(c->stream));
     ek_launch_gather_frames(c->tiles, c->G, c->A, c->med_idx, K, 0, c->med_aos,
                             c->med_G, c->stream);
     EK_CHECK_LAUNCH();
+    return EK_OK;
+}
+
+// ---- PAM with medoids / proposals that live on other shards ---------------------------
+extern "C" int ek_centered_frames(ek_ctx *c, const int64_t *local_frames,
+                                  const int32_t *rows, int32_t count,
+                                  float *aos_dev, double *G_dev)
+{
+    if (!c || count < 0 || (count > 0 && (!local_frames || !rows)) || !aos_dev ||
+        !G_dev)
+        return ek_fail(EK_EARG, "ek_centered_frames: bad argument");
+    if (!c->loaded)
+        return ek_fail(EK_ESTATE, "ek_centered_frames: no frames loaded");
+    if (count == 0)
+        return EK_OK;
+    for (int32_t i = 0; i < count; ++i)
+        if (local_frames[i] < 0 || local_frames[i] >= c->n || rows[i] < 0)
+            return ek_fail(EK_EARG, "ek_centered_frames: item %d (frame %lld, "
+                                    "row %d) out of range", i,
+                           (long long)local_frames[i], rows[i]);
+    EK_HIP(hipSetDevice(c->device));
+    int rc = ek_tmp_idx(c, 2 * (int64_t)count);
+    if (rc)
+        return rc;
+    std::vector<int64_t> h(2 * (size_t)count);
+    for (int32_t i = 0; i < count; ++i) {
+        h[i] = local_frames[i];
+        h[(size_t)count + i] = rows[i];
+    }
+    EK_HIP(hipMemcpyAsync(c->tmp_idx, h.data(), h.size() * sizeof(int64_t),
+                          hipMemcpyHostToDevice, c->stream));
+    EK_HIP(hipStreamSynchronize(c->stream));
+    ek_launch_gather_rows(c->tiles, c->G, c->A, c->tmp_idx, c->tmp_idx + count,
+                          count, aos_dev, G_dev, c->stream);
+    EK_CHECK_LAUNCH();
+    return EK_OK;
+}
+
+extern "C" int ek_pam_begin_table(ek_ctx *c, const float *aos_dev,
+                                  const double *G_dev, int32_t K)
+{
+    if (!c || !aos_dev || !G_dev || K < 1)
+        return ek_fail(EK_EARG, "ek_pam_begin_table: bad argument");
+    if (!c->loaded)
+        return ek_fail(EK_ESTATE, "ek_pam_begin_table: no frames loaded");
+    EK_HIP(hipSetDevice(c->device));
+    int rc = ek_pam_alloc(c, K);
+    if (rc)
+        return rc;
+    EK_HIP(hipMemcpyAsync(c->med_aos, aos_dev, (size_t)K * 3 * c->A * sizeof(float),
+                          hipMemcpyDeviceToDevice, c->stream));
+    EK_HIP(hipMemcpyAsync(c->med_G, G_dev, (size_t)K * sizeof(double),
+                          hipMemcpyDeviceToDevice, c->stream));
     return EK_OK;
 }
 
@@ -1036,32 +1119,16 @@ extern "C" int ek_pam_select_member(ek_ctx *c, int32_t cid, int64_t j,
     return EK_OK;
 }
 
-// shared tail of the two proposal entry points.  The proposed frame's index
-// is either `frame_index` (>= 0) or already on the device in c->sel[1].
-// max_amb bounds the ambiguous set (it is a subset of cluster cid's members),
-// so no host round trip is needed to size the follow-up launches.
-static int ek_pam_propose_impl(ek_ctx *c, int32_t cid, int64_t frame_index,
-                               int64_t max_amb, int64_t *frame_out,
-                               double *old_cost, double *new_cost,
-                               int64_t *n_ambiguous, int32_t win_lo = 0,
-                               int32_t win_count = 0,
-                               uint32_t *moved_mask = nullptr)
+// Everything of a proposal after the distance vector `newd` is known and the
+// trial medoid table holds the proposal in row cid: classification, the
+// ambiguous subset against all medoids, both cost sums and (optionally) the
+// moved-cluster mask.  No read-back.  max_amb bounds the ambiguous set (a
+// subset of cluster cid's members) and sizes the follow-up launches.
+static int ek_pam_tail(ek_ctx *c, int32_t cid, const float *newd,
+                       int64_t max_amb, int32_t win_lo, int32_t win_count,
+                       bool want_moved)
 {
     const int K = c->med_K;
-    // a prefetched distance vector for this frame (ek_pam_prefetch)?
-    const float *newd = c->scratch;
-    if (frame_index >= 0) {
-        for (int32_t j = 0; j < c->pf_count; ++j)
-            if (c->pf_frames[j] == frame_index) {
-                newd = c->pam_vecs + (size_t)j * c->n_pad;
-                break;
-            }
-        if (newd == c->scratch)
-            ++c->pf_misses;
-        else
-            ++c->pf_hits;
-    }
-    const int64_t *idx_dev = nullptr;
     if (max_amb > c->ambt_cap) {
         EK_HIP(hipStreamSynchronize(c->stream));
         (void)hipFree(c->ambt);
@@ -1076,27 +1143,6 @@ static int ek_pam_propose_impl(ek_ctx *c, int32_t cid, int64_t frame_index,
         EK_HIP(hipMalloc((void **)&c->ambG, (size_t)cap * sizeof(double)));
         c->ambt_cap = cap;
     }
-    if (frame_index >= 0) {
-        EK_HIP(hipMemcpyAsync(c->med_idx + K, &frame_index, sizeof(int64_t),
-                              hipMemcpyHostToDevice, c->stream));
-    } else {
-        EK_HIP(hipMemcpyAsync(c->med_idx + K, c->sel + 1, sizeof(int64_t),
-                              hipMemcpyDeviceToDevice, c->stream));
-    }
-    idx_dev = c->med_idx + K;
-    // distances of every frame to the proposed medoid (kmedoids.py:637)
-    if (newd == c->scratch) {
-        ek_launch_record_from_frame(c->tiles, c->G, c->A, 0, idx_dev, c->goff,
-                                    c->rec_tmp, c->stream);
-        ek_launch_step(ek_pick_fpl(c), 1, ek_pick_nt(c), c->tiles, c->G, c->dist,
-                       c->assign, c->scratch, c->rec_tmp, 1, c->n, c->A, 0, 0.0,
-                       c->blockmax, c->hist, c->ctl, c->stream);
-        EK_CHECK_LAUNCH();
-    }
-    // trial medoid table: save row cid in row K, put the proposal in row cid
-    ek_launch_copy_row(c->med_aos, c->med_G, c->A, cid, K, c->stream);
-    ek_launch_gather_frames(c->tiles, c->G, c->A, idx_dev, 1, cid, c->med_aos,
-                            c->med_G, c->stream);
     EK_HIP(hipMemsetAsync(c->amb_count, 0, sizeof(unsigned int), c->stream));
     ek_launch_pam_classify(c->dist, c->assign, newd, c->n, cid, c->ndist,
                            c->nassign, c->amb, c->amb_best, c->amb_count,
@@ -1107,10 +1153,67 @@ static int ek_pam_propose_impl(ek_ctx *c, int32_t cid, int64_t frame_index,
     ek_launch_pam_scatter(c->amb, c->amb_best, c->amb_count, max_amb, c->ndist,
                           c->nassign, c->stream);
     ek_launch_sumsq2(c->dist, c->ndist, c->n, c->sq_part, c->sq_out, c->stream);
-    if (moved_mask)
+    if (want_moved)
         ek_launch_pam_moved(c->assign, c->nassign, c->n, win_lo, win_count,
                             c->moved, c->stream);
     EK_CHECK_LAUNCH();
+    return EK_OK;
+}
+
+// the prefetched distance vector of a local frame, or nullptr
+static const float *ek_pam_prefetched(ek_ctx *c, int64_t frame_index)
+{
+    if (frame_index < 0 || c->pf_external)
+        return nullptr;
+    for (int32_t j = 0; j < c->pf_count; ++j)
+        if (c->pf_frames[j] == frame_index)
+            return c->pam_vecs + (size_t)j * c->n_pad;
+    return nullptr;
+}
+
+// shared body of the local-frame proposal entry points.  The proposed frame's
+// index is either `frame_index` (>= 0) or already on the device in c->sel[1].
+static int ek_pam_propose_impl(ek_ctx *c, int32_t cid, int64_t frame_index,
+                               int64_t max_amb, int64_t *frame_out,
+                               double *old_cost, double *new_cost,
+                               int64_t *n_ambiguous, int32_t win_lo = 0,
+                               int32_t win_count = 0,
+                               uint32_t *moved_mask = nullptr)
+{
+    const int K = c->med_K;
+    const float *newd = ek_pam_prefetched(c, frame_index);
+    if (frame_index >= 0) {
+        if (newd)
+            ++c->pf_hits;
+        else
+            ++c->pf_misses;
+    }
+    if (frame_index >= 0) {
+        EK_HIP(hipMemcpyAsync(c->med_idx + K, &frame_index, sizeof(int64_t),
+                              hipMemcpyHostToDevice, c->stream));
+    } else {
+        EK_HIP(hipMemcpyAsync(c->med_idx + K, c->sel + 1, sizeof(int64_t),
+                              hipMemcpyDeviceToDevice, c->stream));
+    }
+    const int64_t *idx_dev = c->med_idx + K;
+    if (!newd) {
+        // distances of every frame to the proposed medoid (kmedoids.py:637)
+        ek_launch_record_from_frame(c->tiles, c->G, c->A, 0, idx_dev, c->goff,
+                                    c->rec_tmp, c->stream);
+        ek_launch_step(ek_pick_fpl(c), 1, ek_pick_nt(c), c->tiles, c->G, c->dist,
+                       c->assign, c->scratch, c->rec_tmp, 1, c->n, c->A, 0, 0.0,
+                       c->blockmax, c->hist, c->ctl, c->stream);
+        EK_CHECK_LAUNCH();
+        newd = c->scratch;
+    }
+    // trial medoid table: save row cid in row K, put the proposal in row cid
+    ek_launch_copy_row(c->med_aos, c->med_G, c->A, cid, K, c->stream);
+    ek_launch_gather_frames(c->tiles, c->G, c->A, idx_dev, 1, cid, c->med_aos,
+                            c->med_G, c->stream);
+    int rc = ek_pam_tail(c, cid, newd, max_amb, win_lo, win_count,
+                         moved_mask != nullptr);
+    if (rc)
+        return rc;
     double sums[2] = {0.0, 0.0};
     unsigned int n_amb = 0;
     int64_t fidx = frame_index;
@@ -1125,6 +1228,8 @@ static int ek_pam_propose_impl(ek_ctx *c, int32_t cid, int64_t frame_index,
         EK_HIP(hipMemcpyAsync(&fidx, c->med_idx + K, sizeof(int64_t),
                               hipMemcpyDeviceToHost, c->stream));
     EK_HIP(hipStreamSynchronize(c->stream));
+    c->pam_cid = cid;           // pending even if the check below fails
+    c->pam_frame = fidx;
     if ((int64_t)n_amb > max_amb)
         return ek_fail(EK_EARG, "PAM proposal: cluster %d has %u members that "
                                 "stay put, more than the %lld members declared",
@@ -1137,8 +1242,6 @@ static int ek_pam_propose_impl(ek_ctx *c, int32_t cid, int64_t frame_index,
         *n_ambiguous = n_amb;
     if (frame_out)
         *frame_out = fidx;
-    c->pam_cid = cid;
-    c->pam_frame = fidx;
     return EK_OK;
 }
 
@@ -1267,9 +1370,13 @@ extern "C" int ek_pam_select_members_batch(ek_ctx *c, int32_t cid0, int32_t coun
                        cid0, count);
     EK_HIP(hipSetDevice(c->device));
     const size_t nb = ((size_t)std::max<int64_t>(c->n, 1) + EK_BLOCK - 1) / EK_BLOCK;
+    EK_HIP(hipMemsetAsync(c->bat_sel + EK_MAX_CANDS, 0xff,
+                          EK_MAX_CANDS * sizeof(int64_t), c->stream));
     for (int32_t j = 0; j < count; ++j)
-        ek_launch_select_member(c->assign, c->n, cid0 + j, c->bat_scan + j * nb,
-                                js[j], c->bat_sel + EK_MAX_CANDS + j, c->stream);
+        if (js[j] >= 0)     // negative: that member lives on another shard
+            ek_launch_select_member(c->assign, c->n, cid0 + j,
+                                    c->bat_scan + j * nb, js[j],
+                                    c->bat_sel + EK_MAX_CANDS + j, c->stream);
     EK_CHECK_LAUNCH();
     EK_HIP(hipMemcpyAsync(frames, c->bat_sel + EK_MAX_CANDS,
                           (size_t)count * sizeof(int64_t), hipMemcpyDeviceToHost,
@@ -1279,9 +1386,22 @@ extern "C" int ek_pam_select_members_batch(ek_ctx *c, int32_t cid0, int32_t coun
     c->bat_cid0 = -1;
     c->bat_count = 0;
     for (int32_t j = 0; j < count; ++j)
-        if (frames[j] < 0)
+        if (frames[j] < 0 && js[j] >= 0)
             return ek_fail(EK_EARG, "ek_pam_select_members_batch: cluster %d has "
                                     "no member %lld", cid0 + j, (long long)js[j]);
+    return EK_OK;
+}
+
+static int ek_pam_vecs_alloc(ek_ctx *c)
+{
+    if (!c->pam_vecs) {
+        EK_HIP(hipMalloc((void **)&c->pam_vecs,
+                         (size_t)EK_MAX_CANDS * std::max<int64_t>(c->n_pad, 1) *
+                             sizeof(float)));
+        EK_HIP(hipMalloc((void **)&c->pam_recs,
+                         (size_t)EK_MAX_CANDS * ek_rec_bytes(c->A)));
+        EK_HIP(hipMalloc((void **)&c->pam_plan, sizeof(EkPlan)));
+    }
     return EK_OK;
 }
 
@@ -1305,13 +1425,10 @@ extern "C" int ek_pam_prefetch(ek_ctx *c, const int64_t *frames, int32_t count)
     c->pf_count = 0;
     if (count == 0)
         return EK_OK;
-    if (!c->pam_vecs) {
-        EK_HIP(hipMalloc((void **)&c->pam_vecs,
-                         (size_t)EK_MAX_CANDS * std::max<int64_t>(c->n_pad, 1) *
-                             sizeof(float)));
-        EK_HIP(hipMalloc((void **)&c->pam_recs,
-                         (size_t)EK_MAX_CANDS * ek_rec_bytes(c->A)));
-        EK_HIP(hipMalloc((void **)&c->pam_plan, sizeof(EkPlan)));
+    {
+        int rc = ek_pam_vecs_alloc(c);
+        if (rc)
+            return rc;
     }
     const size_t rstride = ek_rec_bytes(c->A);
     for (int32_t j = 0; j < count; ++j)
@@ -1323,6 +1440,7 @@ extern "C" int ek_pam_prefetch(ek_ctx *c, const int64_t *frames, int32_t count)
     for (int32_t j = 0; j < count; ++j)
         c->pf_frames[j] = frames[j];
     c->pf_count = count;
+    c->pf_external = false;
     return EK_OK;
 }
 
@@ -1348,6 +1466,95 @@ extern "C" int ek_pam_propose_ex(ek_ctx *c, int32_t cid, int64_t frame_index,
     return ek_pam_propose_impl(c, cid, frame_index, n_members, nullptr, old_cost,
                                new_cost, n_ambiguous, win_lo, win_count,
                                win_count > 0 ? moved_mask : nullptr);
+}
+
+extern "C" int ek_pam_prefetch_centers(ek_ctx *c, const float *aos_dev,
+                                       const double *G_dev, int32_t count)
+{
+    if (!c || (count > 0 && (!aos_dev || !G_dev)))
+        return ek_fail(EK_EARG, "ek_pam_prefetch_centers: NULL argument");
+    if (!c->ndist || c->med_K < 1)
+        return ek_fail(EK_ESTATE, "ek_pam_prefetch_centers: call ek_pam_begin[_table] "
+                                  "first");
+    if (count < 0 || count > EK_MAX_CANDS)
+        return ek_fail(EK_EARG, "ek_pam_prefetch_centers: count=%d outside [0,%d]",
+                       count, EK_MAX_CANDS);
+    if ((size_t)3 * c->A * EK_MAX_CANDS * sizeof(float) > 150 * 1024)
+        return ek_fail(EK_EARG, "ek_pam_prefetch_centers: %d atoms exceed the LDS "
+                                "center tile (limit 1600)", c->A);
+    EK_HIP(hipSetDevice(c->device));
+    c->pf_count = 0;
+    c->pf_external = true;
+    if (count == 0)
+        return EK_OK;
+    int rc = ek_pam_vecs_alloc(c);
+    if (rc)
+        return rc;
+    const size_t rstride = ek_rec_bytes(c->A);
+    for (int32_t j = 0; j < count; ++j)
+        ek_launch_record_from_center(aos_dev + (size_t)j * 3 * c->A, G_dev + j, c->A,
+                                     c->pam_recs + j * rstride, c->stream);
+    ek_launch_pass_dist(count, c->tiles, c->G, c->pam_vecs, c->n, c->n_pad, c->A,
+                        c->pam_recs, c->pam_plan, c->stream);
+    EK_CHECK_LAUNCH();
+    for (int32_t j = 0; j < count; ++j)
+        c->pf_frames[j] = -1;
+    c->pf_count = count;
+    return EK_OK;
+}
+
+extern "C" int ek_pam_propose_center(ek_ctx *c, int32_t cid, int32_t slot,
+                                     const float *center_aos_dev,
+                                     const double *center_G_dev,
+                                     int64_t n_members_local, int32_t win_lo,
+                                     int32_t win_count, void *out_dev)
+{
+    int rc = ek_pam_precheck(c, cid, "ek_pam_propose_center");
+    if (rc)
+        return rc;
+    if (!center_aos_dev || !center_G_dev || !out_dev)
+        return ek_fail(EK_EARG, "ek_pam_propose_center: NULL argument");
+    if (n_members_local < 0 || n_members_local > c->n)
+        return ek_fail(EK_EARG, "ek_pam_propose_center: n_members_local=%lld",
+                       (long long)n_members_local);
+    if (win_count < 0 || win_count > 32)
+        return ek_fail(EK_EARG, "ek_pam_propose_center: bad window");
+    if (slot >= 0 && (!c->pf_external || slot >= c->pf_count))
+        return ek_fail(EK_ESTATE, "ek_pam_propose_center: slot %d was not "
+                                  "prefetched", slot);
+    EK_HIP(hipSetDevice(c->device));
+    c->cnt_cid = -1;
+    const int K = c->med_K;
+    const float *newd;
+    if (slot >= 0) {
+        newd = c->pam_vecs + (size_t)slot * c->n_pad;
+        ++c->pf_hits;
+    } else {
+        ek_launch_record_from_center(center_aos_dev, center_G_dev, c->A, c->rec_tmp,
+                                     c->stream);
+        ek_launch_step(ek_pick_fpl(c), 1, ek_pick_nt(c), c->tiles, c->G, c->dist,
+                       c->assign, c->scratch, c->rec_tmp, 1, c->n, c->A, 0, 0.0,
+                       c->blockmax, c->hist, c->ctl, c->stream);
+        EK_CHECK_LAUNCH();
+        newd = c->scratch;
+        ++c->pf_misses;
+    }
+    ek_launch_copy_row(c->med_aos, c->med_G, c->A, cid, K, c->stream);
+    EK_HIP(hipMemcpyAsync(c->med_aos + (size_t)cid * 3 * c->A, center_aos_dev,
+                          (size_t)3 * c->A * sizeof(float), hipMemcpyDeviceToDevice,
+                          c->stream));
+    EK_HIP(hipMemcpyAsync(c->med_G + cid, center_G_dev, sizeof(double),
+                          hipMemcpyDeviceToDevice, c->stream));
+    rc = ek_pam_tail(c, cid, newd, n_members_local, win_lo, win_count,
+                     win_count > 0);
+    if (rc)
+        return rc;
+    ek_launch_pam_pack(c->sq_out, c->amb_count, win_count > 0 ? c->moved : nullptr,
+                       c->n, (EkPamOut *)out_dev, c->stream);
+    EK_CHECK_LAUNCH();
+    c->pam_cid = cid;
+    c->pam_frame = -1;
+    return EK_OK;
 }
 
 extern "C" int ek_pam_prefetch_stats(ek_ctx *c, int64_t *hits, int64_t *misses)

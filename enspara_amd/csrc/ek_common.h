@@ -155,6 +155,21 @@ void ek_launch_pam_scatter(const uint32_t *amb,
                            const unsigned long long *amb_best,
                            const unsigned int *n_amb, int64_t max_amb,
                            float *ndist, int32_t *nassign, hipStream_t s);
+// one shard's share of a proposal's outcome (ek_pam_propose_center)
+struct EkPamOut {
+    double sum_old;      // sum of squared distances, current state
+    double sum_new;      // ... trial state
+    int64_t n_frames;    // frames of this shard
+    uint32_t n_amb;      // members of the cluster that stayed with it or left
+    uint32_t moved;      // bit i: membership of cluster win_lo + i would change
+};
+static_assert(sizeof(EkPamOut) == 32, "EkPamOut layout");
+void ek_launch_pam_pack(const double *sq, const unsigned int *n_amb,
+                        const unsigned int *moved, int64_t n, EkPamOut *out,
+                        hipStream_t s);
+void ek_launch_gather_rows(const float *tiles, const double *G, int A,
+                           const int64_t *idx_dev, const int64_t *rows_dev,
+                           int count, float *out_aos, double *outG, hipStream_t s);
 void ek_launch_pam_moved(const int32_t *assign, const int32_t *nassign,
                          int64_t n, int32_t win_lo, int32_t win_count,
                          unsigned int *mask, hipStream_t s);

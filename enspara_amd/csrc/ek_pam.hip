@@ -39,6 +39,35 @@ void ek_launch_gather_frames(const float *tiles, const double *G, int A,
                        s, tiles, G, A, idx_dev, first_row, out_aos, outG);
 }
 
+// same, for arbitrary destination rows (rows[i] of out_aos / outG)
+__global__ void __launch_bounds__(EK_BLOCK)
+ek_gather_rows_kernel(const float *__restrict__ tiles,
+                      const double *__restrict__ G, int A,
+                      const int64_t *__restrict__ idx,
+                      const int64_t *__restrict__ rows,
+                      float *__restrict__ out_aos, double *__restrict__ outG)
+{
+    const int64_t f = idx[blockIdx.x];
+    const int64_t row = rows[blockIdx.x];
+    const float *p = tiles + (size_t)(f / EK_TILE) * 3 * (size_t)A * EK_TILE +
+                     (f % EK_TILE);
+    float *o = out_aos + (size_t)row * 3 * A;
+    for (int r = threadIdx.x; r < 3 * A; r += EK_BLOCK)
+        o[r] = p[(size_t)r * EK_TILE];
+    if (threadIdx.x == 0)
+        outG[row] = G[f];
+}
+
+void ek_launch_gather_rows(const float *tiles, const double *G, int A,
+                           const int64_t *idx_dev, const int64_t *rows_dev,
+                           int count, float *out_aos, double *outG, hipStream_t s)
+{
+    if (count <= 0)
+        return;
+    hipLaunchKernelGGL(ek_gather_rows_kernel, dim3(count), dim3(EK_BLOCK), 0, s,
+                       tiles, G, A, idx_dev, rows_dev, out_aos, outG);
+}
+
 __global__ void __launch_bounds__(EK_BLOCK)
 ek_copy_row_kernel(float *__restrict__ aos, double *__restrict__ Gm, int A,
                    int src, int dst)
@@ -478,4 +507,27 @@ void ek_launch_sumsq2(const float *a, const float *b, int64_t n, double *part,
                        0, s, a, b, n, part);
     hipLaunchKernelGGL(ek_sumsq_final_kernel, dim3(1), dim3(EK_BLOCK), 0, s,
                        part, out);
+}
+
+// one shard's share of a proposal's outcome, for the cross-shard exchange
+__global__ void ek_pam_pack_kernel(const double *__restrict__ sq,
+                                   const unsigned int *__restrict__ n_amb,
+                                   const unsigned int *__restrict__ moved,
+                                   int64_t n, EkPamOut *__restrict__ out)
+{
+    if (threadIdx.x != 0)
+        return;
+    out->sum_old = sq[0];
+    out->sum_new = sq[1];
+    out->n_frames = n;
+    out->n_amb = *n_amb;
+    out->moved = moved ? *moved : 0u;
+}
+
+void ek_launch_pam_pack(const double *sq, const unsigned int *n_amb,
+                        const unsigned int *moved, int64_t n, EkPamOut *out,
+                        hipStream_t s)
+{
+    hipLaunchKernelGGL(ek_pam_pack_kernel, dim3(1), dim3(EK_WAVE), 0, s, sq, n_amb,
+                       moved, n, out);
 }

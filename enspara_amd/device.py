@@ -227,6 +227,34 @@ class FrameStore:
             C.byref(mask)))
         return oc.value, nc.value, na.value, mask.value
 
+    # -- PAM across shards (device pointers are plain ints) ----------------------
+    def centered_frames(self, local_frames, rows, aos_ptr, G_ptr):
+        """rows[i] of the device arrays at aos_ptr ([.., 3A] float32) / G_ptr
+        (float64) := centred coordinates / trace of local frame
+        local_frames[i]."""
+        f = np.ascontiguousarray(local_frames, dtype=np.int64)
+        r = np.ascontiguousarray(rows, dtype=np.int32)
+        if len(f) != len(r):
+            raise DataInvalid("centered_frames: %d frames, %d rows"
+                              % (len(f), len(r)))
+        _lib.check(self.lib.ek_centered_frames(
+            self._h, _lib.i64p(f), _lib.i32p(r), len(f), int(aos_ptr),
+            int(G_ptr)))
+
+    def pam_begin_table(self, aos_ptr, G_ptr, n_medoids):
+        _lib.check(self.lib.ek_pam_begin_table(self._h, int(aos_ptr),
+                                               int(G_ptr), int(n_medoids)))
+
+    def pam_prefetch_centers(self, aos_ptr, G_ptr, count):
+        _lib.check(self.lib.ek_pam_prefetch_centers(self._h, int(aos_ptr),
+                                                    int(G_ptr), int(count)))
+
+    def pam_propose_center(self, cid, slot, aos_ptr, G_ptr, n_members_local,
+                           win_lo, win_count, out_ptr):
+        _lib.check(self.lib.ek_pam_propose_center(
+            self._h, int(cid), int(slot), int(aos_ptr), int(G_ptr),
+            int(n_members_local), int(win_lo), int(win_count), int(out_ptr)))
+
     def pam_prefetch_stats(self):
         """-> (proposals served from a prefetched vector, not served)"""
         h, m = C.c_int64(), C.c_int64()

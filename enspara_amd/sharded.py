@@ -91,6 +91,68 @@ class DeviceShard:
     def reset_history(self):
         self.store.reset_history()
 
+    # PAM across shards: centers travel as centred coordinates + trace
+    @property
+    def n_atoms(self):
+        return self.store.A
+
+    @property
+    def n_local(self):
+        return self.store.n
+
+    @property
+    def offset(self):
+        return self.store.global_offset
+
+    def host_to_buffer(self, arr):
+        """int64 numpy array -> tensor a collective can move"""
+        return self.torch.from_numpy(np.ascontiguousarray(
+            arr, dtype=np.int64)).to(self.device)
+
+    def new_table(self, rows):
+        """-> (coords float32 [rows, 3A], meta int64 [2 * rows]), zeroed;
+        meta[:rows] holds the traces' float64 bit patterns, meta[rows:] is
+        free for the caller (global frame indices)."""
+        t = self.torch
+        return (t.zeros((rows, 3 * self.n_atoms), dtype=t.float32,
+                        device=self.device),
+                t.zeros(2 * rows, dtype=t.int64, device=self.device))
+
+    def fill_rows(self, local_frames, rows, coords, meta):
+        if len(local_frames):
+            self.store.centered_frames(local_frames, rows, coords.data_ptr(),
+                                       meta.data_ptr())
+
+    def pam_begin_table(self, coords, meta, n_medoids):
+        self.store.pam_begin_table(coords.data_ptr(), meta.data_ptr(),
+                                   n_medoids)
+
+    def pam_count_batch(self, cid0, count):
+        return self.store.pam_count_members_batch(cid0, count)
+
+    def pam_select_batch(self, cid0, js):
+        return self.store.pam_select_members_batch(cid0, js)
+
+    def pam_count(self, cid):
+        return self.store.pam_count_members(cid)
+
+    def pam_select(self, cid, j):
+        return self.store.pam_select_member(cid, j)
+
+    def pam_prefetch_centers(self, coords, meta, count):
+        self.store.pam_prefetch_centers(coords.data_ptr(), meta.data_ptr(),
+                                        count)
+
+    def pam_propose_center(self, cid, slot, coords, meta, row, n_members_local,
+                           win_lo, win_count, out):
+        self.store.pam_propose_center(
+            cid, slot, coords.data_ptr() + 12 * self.n_atoms * row,
+            meta.data_ptr() + 8 * row, n_members_local, win_lo, win_count,
+            out.data_ptr())
+
+    def pam_commit(self, accept):
+        self.store.pam_commit(accept)
+
 
 def _world(group):
     import torch.distributed as dist
@@ -197,3 +259,222 @@ def shard_bounds(n_total, world, rank, align=256):
     lo = min(n_total, t0 * align)
     hi = min(n_total, t1 * align)
     return lo, hi - lo
+
+
+# ---------------------------------------------------------------------------
+# PAM (k-medoids) sweeps over sharded frames
+# ---------------------------------------------------------------------------
+PAM_OUT = np.dtype([("sum_old", "<f8"), ("sum_new", "<f8"),
+                    ("n_frames", "<i8"), ("n_amb", "<u4"), ("moved", "<u4")])
+assert PAM_OUT.itemsize == 32
+
+
+def _gather_i64(shard, values, group, world, collective):
+    """Every rank's small int64 vector -> ndarray [world, len(values)]."""
+    import torch
+    import torch.distributed as dist
+    values = np.ascontiguousarray(values, dtype=np.int64)
+    if not collective:
+        return values[None, :].copy()
+    mine = shard.host_to_buffer(values)
+    everyone = torch.empty(world * len(values), dtype=torch.int64,
+                           device=mine.device)
+    dist.all_gather_into_tensor(everyone, mine, group=group)
+    return everyone.cpu().numpy().reshape(world, len(values))
+
+
+def _share_rows(coords, meta, group, collective):
+    """Each row was filled by exactly one rank and is zero elsewhere: an
+    integer sum over ranks of the raw bit patterns reproduces it exactly on
+    every rank (x + 0 + ... + 0 in two's complement), for the float32
+    coordinates, the float64 traces and the int64 indices alike."""
+    if not collective:
+        return
+    import torch
+    import torch.distributed as dist
+    dist.all_reduce(coords.view(torch.int32), op=dist.ReduceOp.SUM,
+                    group=group)
+    dist.all_reduce(meta, op=dist.ReduceOp.SUM, group=group)
+
+
+class _ShardWindow:
+    __slots__ = ("lo", "hi", "m", "m_local", "before", "j", "gidx", "stale")
+
+
+def pam_sweep_sharded(shard, medoids, proposals=None, random_state=None,
+                      group=None, prefetch=8):
+    """One PAM sweep (reference kmedoids.py:575-699, MPI branch) over all
+    ranks' shards.  ``medoids``: global frame index of every cluster's medoid,
+    the same list on every rank; ``random_state`` must also be the same on
+    every rank (an int seed or identically seeded RandomState).  Returns the
+    updated list -- identical on every rank and identical to what the
+    single-GPU sweep returns for the concatenated frames; the per-frame state
+    stays on the shards.
+
+    Messages: per window of ``prefetch`` clusters one all-gather of member
+    counts and one exchange of the proposed frames' coordinates (3.6 KB each
+    at 300 atoms); per proposal one all-gather of a 32-byte record per rank
+    (cost sums, moved-cluster mask) -- against the reference's pickled
+    allgather + Bcast of the frame + two allreduces per proposal
+    (kmedoids.py:482-517, mpi/ops.py:143-212)."""
+    import torch.distributed as dist
+    from .cluster.kcenters import check_random_state
+    world, rank = _world(group)
+    collective = dist.is_available() and dist.is_initialized()
+    if collective and world > 1 and random_state is None and proposals is None:
+        raise ValueError("pam_sweep_sharded needs a random_state shared by "
+                         "all ranks")
+    rs = check_random_state(random_state)
+    medoids = [int(g) for g in medoids]
+    K = len(medoids)
+    if proposals is not None and len(proposals) != K:
+        raise ValueError("Length of 'proposals' didn't match length of "
+                         "'medoids' (%d != %d)." % (len(proposals), K))
+    width = max(1, min(int(prefetch), 8))
+    lay = _gather_i64(shard, [shard.offset, shard.n_local], group, world,
+                      collective)
+    n_total = int(lay[:, 1].sum())
+    lo_mine, hi_mine = shard.offset, shard.offset + shard.n_local
+
+    def owned(g):
+        return lo_mine <= g < hi_mine
+
+    # medoid table, assembled from the owners' rows
+    coords, meta = shard.new_table(K)
+    rows = [r for r, g in enumerate(medoids) if owned(g)]
+    shard.fill_rows([medoids[r] - lo_mine for r in rows], rows, coords, meta)
+    _share_rows(coords, meta, group, collective)
+    shard.pam_begin_table(coords, meta, K)
+
+    pc, pm = shard.new_table(width)            # window proposals
+    oc, om = shard.new_table(1)                # a proposal outside the window
+    out_mine = shard.new_buffer(PAM_OUT.itemsize)
+    out_all = (shard.new_buffer(PAM_OUT.itemsize * world) if collective
+               else out_mine)
+    win = None
+    acceptances = 0
+    for cid in range(K):
+        if win is None or cid >= win.hi:
+            win = _ShardWindow()
+            win.lo, win.hi, win.stale = cid, min(K, cid + width), 0
+            cnt = win.hi - win.lo
+            mine = shard.pam_count_batch(win.lo, cnt)
+            allc = _gather_i64(shard, mine, group, world, collective)
+            win.m = [int(x) for x in allc.sum(axis=0)]
+            win.m_local = [int(x) for x in mine]
+            win.before = [int(x) for x in allc[:rank].sum(axis=0)]
+            pc.zero_()
+            pm.zero_()
+            if proposals is None:
+                ahead = np.random.RandomState()
+                ahead.set_state(rs.get_state())
+                win.j = []
+                for m in win.m:
+                    if m <= 0:
+                        break
+                    win.j.append(int(ahead.choice(m)))
+                jl = [j - b for j, b in zip(win.j, win.before)]
+                jl = [x if 0 <= x < ml else -1
+                      for x, ml in zip(jl, win.m_local)]
+                slots = [s for s, x in enumerate(jl) if x >= 0]
+                if slots:
+                    fl = shard.pam_select_batch(win.lo, jl)
+                    shard.fill_rows([int(fl[s]) for s in slots], slots, pc, pm)
+                    idx = np.zeros(width, dtype=np.int64)
+                    for s in slots:
+                        idx[s] = lo_mine + int(fl[s])
+                    pm[width:] = shard.host_to_buffer(idx)
+                n_guess = len(win.j)
+            else:
+                win.j = None
+                want = [int(g) for g in proposals[win.lo:win.hi]]
+                slots = [s for s, g in enumerate(want) if owned(g)]
+                shard.fill_rows([want[s] - lo_mine for s in slots], slots, pc,
+                                pm)
+                idx = np.zeros(width, dtype=np.int64)
+                for s in slots:
+                    idx[s] = want[s]
+                pm[width:] = shard.host_to_buffer(idx)
+                n_guess = cnt
+            _share_rows(pc, pm, group, collective)
+            win.gidx = [int(g) for g in pm[width:width + n_guess].cpu().numpy()]
+            shard.pam_prefetch_centers(pc, pm, n_guess)
+        slot = cid - win.lo
+        exact = not ((win.stale >> slot) & 1)
+        if exact:
+            m, m_local, before = win.m[slot], win.m_local[slot], win.before[slot]
+            counted = False
+        else:
+            m_local = int(shard.pam_count(cid))
+            allc = _gather_i64(shard, [m_local], group, world, collective)
+            m, before = int(allc.sum()), int(allc[:rank].sum())
+            counted = True
+        use_slot = -1
+        if proposals is None:
+            j = int(rs.choice(m))                            # kmedoids.py:514
+            if exact and slot < len(win.j) and j == win.j[slot]:
+                use_slot, g = slot, win.gidx[slot]
+        else:
+            use_slot, g = slot, win.gidx[slot]
+        if use_slot < 0:
+            oc.zero_()
+            om.zero_()
+            jl = j - before
+            if 0 <= jl < m_local:
+                if not counted:
+                    shard.pam_count(cid)         # leaves the scan for select
+                f = int(shard.pam_select(cid, jl))
+                shard.fill_rows([f], [0], oc, om)
+                om[1:] = shard.host_to_buffer([lo_mine + f])
+            _share_rows(oc, om, group, collective)
+            g = int(om[1:].cpu().numpy()[0])
+            shard.pam_propose_center(cid, -1, oc, om, 0, m_local, win.lo,
+                                     win.hi - win.lo, out_mine)
+        else:
+            shard.pam_propose_center(cid, use_slot, pc, pm, use_slot, m_local,
+                                     win.lo, win.hi - win.lo, out_mine)
+        if collective:
+            dist.all_gather_into_tensor(out_all, out_mine, group=group)
+        recs = out_all.cpu().numpy().view(PAM_OUT)
+        if int(recs[rank]["n_amb"]) > m_local:
+            raise RuntimeError("PAM proposal for cluster %d: %d ambiguous "
+                               "members on this shard, %d declared"
+                               % (cid, int(recs[rank]["n_amb"]), m_local))
+        s_old = s_new = 0.0
+        moved = 0
+        for r in range(len(recs)):               # fixed order: deterministic
+            s_old += float(recs[r]["sum_old"])
+            s_new += float(recs[r]["sum_new"])
+            moved |= int(recs[r]["moved"])
+        accept = (s_new / n_total) < (s_old / n_total)       # kmedoids.py:683
+        shard.pam_commit(accept)
+        if accept:
+            medoids[cid] = g
+            acceptances += 1
+            win.stale |= moved
+    return medoids
+
+
+def khybrid_sharded(shard, n_clusters, dist_cutoff=0.0, n_iters=5,
+                    random_state=None, group=None):
+    """k-centers then ``n_iters`` PAM sweeps over all ranks' shards (reference
+    hybrid.py:112-162 in MPI mode).  ``random_state`` is wrapped once, so an
+    int seed gives one stream across the sweeps -- what the KHybrid estimator
+    does (hybrid.py:78,103).  Returns the medoids' global frame indices;
+    labels and distances stay on the shards."""
+    from .cluster.kcenters import check_random_state
+    import torch.distributed as dist
+    rs = check_random_state(random_state)
+    if n_clusters is None or np.isinf(n_clusters):
+        # cut-off only: same cap as the single-GPU path (cluster/kcenters.py)
+        world, _ = _world(group)
+        lay = _gather_i64(shard, [shard.n_local], group, world,
+                          dist.is_available() and dist.is_initialized())
+        n_clusters = 2 * int(lay.sum()) + 16
+    idx, _ = kcenters_sharded(shard, 0, int(n_clusters), dist_cutoff,
+                              group=group)
+    medoids = [int(i) for i in idx]
+    for _ in range(int(n_iters)):
+        medoids = pam_sweep_sharded(shard, medoids, random_state=rs,
+                                    group=group)
+    return medoids

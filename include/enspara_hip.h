@@ -220,6 +220,7 @@ int ek_pam_commit(ek_ctx *ctx, int accept);
  *    the current state (one read-back);
  *  ek_pam_select_members_batch: frames[i] = the js[i]-th member of cluster
  *    cid0+i, from the scans the batch count left (call it right after);
+ *    js[i] < 0 skips cluster cid0+i (frames[i] = -1);
  *  ek_pam_prefetch: distances of every frame to frames[0..count) are computed
  *    and kept until the next ek_pam_prefetch / ek_pam_begin (count = 0 drops
  *    them); no read-back;
@@ -242,6 +243,40 @@ int ek_pam_propose_ex(ek_ctx *ctx, int32_t cid, int64_t frame_index,
                       double *old_cost, double *new_cost, int64_t *n_ambiguous,
                       uint32_t *moved_mask);
 int ek_pam_prefetch_stats(ek_ctx *ctx, int64_t *hits, int64_t *misses);
+
+/* PAM when the frames are sharded over several contexts (one per GPU; the
+ * reference's MPI branch of kmedoids.py:575-699 with mpi/ops.py:143-212).  A
+ * medoid or a proposal may then be a frame of another shard, so centers are
+ * passed as centred center-major coordinates [3 * n_atoms] float32 + trace
+ * (float64) in DEVICE memory -- the form ek_centered_frames produces and a
+ * collective can move between ranks.
+ *  ek_centered_frames: for i < count, row rows[i] of aos_dev / G_dev := centred
+ *    coordinates and trace of LOCAL frame local_frames[i];
+ *  ek_pam_begin_table: like ek_pam_begin, the medoid table given as
+ *    n_medoids rows of aos_dev / G_dev;
+ *  ek_pam_prefetch_centers: like ek_pam_prefetch for `count` centers given as
+ *    rows of aos_dev / G_dev; the vectors are addressed by slot = row;
+ *  ek_pam_propose_center: this shard's part of a proposal (distances of its
+ *    frames to the center -- from prefetch slot `slot`, or computed when
+ *    slot < 0 --, classification, ambiguous members against the trial table,
+ *    cost sums).  n_members_local: members of cluster cid among this shard's
+ *    frames.  No read-back: the 32-byte result
+ *      { double sum_old, sum_new; int64 n_frames; uint32 n_ambiguous, moved }
+ *    is written to out_dev (device memory) for the caller to exchange; the
+ *    caller adds the sums over shards (cost = sum / total frames, kmedoids.py:
+ *    478-479 with mpi/ops.py:143-166), ORs `moved`, checks n_ambiguous <=
+ *    n_members_local, and then calls ek_pam_commit on every shard. */
+int ek_centered_frames(ek_ctx *ctx, const int64_t *local_frames,
+                       const int32_t *rows, int32_t count, float *aos_dev,
+                       double *G_dev);
+int ek_pam_begin_table(ek_ctx *ctx, const float *aos_dev, const double *G_dev,
+                       int32_t n_medoids);
+int ek_pam_prefetch_centers(ek_ctx *ctx, const float *aos_dev,
+                            const double *G_dev, int32_t count);
+int ek_pam_propose_center(ek_ctx *ctx, int32_t cid, int32_t slot,
+                          const float *center_aos_dev,
+                          const double *center_G_dev, int64_t n_members_local,
+                          int32_t win_lo, int32_t win_count, void *out_dev);
 
 /* ---- MSM construction (secondary kernel) -------------------------------------
  * ek_msm_counts replaces assigns_to_counts

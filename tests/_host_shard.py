@@ -19,7 +19,121 @@ MAXHDR = np.dtype([("maxdist", "<f4"), ("valid", "<i4"), ("gidx", "<i8")])
 assert MAXHDR.itemsize == 16
 
 
-class HostShard:
+PAM_OUT = np.dtype([("sum_old", "<f8"), ("sum_new", "<f8"),
+                    ("n_frames", "<i8"), ("n_amb", "<u4"), ("moved", "<u4")])
+
+
+class _PamMixin:
+    """Checker-backed PAM shard protocol (ek_centered_frames,
+    ek_pam_begin_table, ek_pam_count/select[_batch], ek_pam_prefetch_centers,
+    ek_pam_propose_center, ek_pam_commit)."""
+
+    @property
+    def n_atoms(self):
+        return self.A
+
+    @property
+    def n_local(self):
+        return self.n
+
+    def host_to_buffer(self, arr):
+        return torch.from_numpy(np.array(arr, dtype=np.int64))
+
+    def new_table(self, rows):
+        return (torch.zeros((rows, 3 * self.A), dtype=torch.float32),
+                torch.zeros(2 * rows, dtype=torch.int64))
+
+    @staticmethod
+    def _traces(meta):
+        return meta.numpy()[:len(meta) // 2].view(np.float64)
+
+    def fill_rows(self, local_frames, rows, coords, meta):
+        for f, r in zip(local_frames, rows):
+            coords.numpy()[r] = self.P.c[f].ravel()
+            self._traces(meta)[r] = self.P.G[f]
+
+    def _vec(self, c, g):
+        if not self.n:
+            return np.zeros(0, dtype=np.float32)
+        return qcp.rmsd_centered(self.P.c, self.P.G,
+                                 np.ascontiguousarray(c.reshape(self.A, 3)),
+                                 float(g))
+
+    def pam_begin_table(self, coords, meta, K):
+        self.med_c = coords.numpy()[:K].copy()
+        self.med_G = self._traces(meta)[:K].copy()
+        self.pending = None
+        self.pf = []
+
+    def pam_count_batch(self, cid0, count):
+        return np.array([np.count_nonzero(self.assign == cid0 + i)
+                         for i in range(count)], dtype=np.int64)
+
+    def pam_select_batch(self, cid0, js):
+        return np.array([-1 if j < 0 else
+                         np.flatnonzero(self.assign == cid0 + i)[j]
+                         for i, j in enumerate(js)], dtype=np.int64)
+
+    def pam_count(self, cid):
+        return int(np.count_nonzero(self.assign == cid))
+
+    def pam_select(self, cid, j):
+        return int(np.flatnonzero(self.assign == cid)[j])
+
+    def pam_prefetch_centers(self, coords, meta, count):
+        g = self._traces(meta)
+        self.pf = [self._vec(coords.numpy()[j], g[j]) for j in range(count)]
+
+    def pam_propose_center(self, cid, slot, coords, meta, row,
+                           n_members_local, win_lo, win_count, out):
+        c = coords.numpy()[row].copy()
+        g = float(self._traces(meta)[row])
+        nd = self.pf[slot] if slot >= 0 else self._vec(c, g)
+        d, a = self.dist, self.assign
+        nd_, na_ = d.copy(), a.copy()
+        down = d > nd                                   # kmedoids.py:644
+        nd_[down] = nd[down]
+        na_[down] = cid
+        amb = np.flatnonzero((d <= nd) & (a == cid))    # :658
+        trial_c, trial_G = self.med_c.copy(), self.med_G.copy()
+        trial_c[cid], trial_G[cid] = c, g
+        if len(amb):
+            best = np.full(len(amb), np.inf, dtype=np.float32)
+            lab = np.zeros(len(amb), dtype=np.int32)
+            sub_c = np.ascontiguousarray(self.P.c[amb])
+            sub_G = np.ascontiguousarray(self.P.G[amb])
+            for k in range(len(trial_G)):               # util.py:199-203
+                v = qcp.rmsd_centered(
+                    sub_c, sub_G,
+                    np.ascontiguousarray(trial_c[k].reshape(self.A, 3)),
+                    float(trial_G[k]))
+                closer = v < best
+                best[closer] = v[closer]
+                lab[closer] = k
+            nd_[amb] = best
+            na_[amb] = lab
+        rec = np.zeros(1, dtype=PAM_OUT)
+        rec["sum_old"] = np.square(d.astype(np.float64)).sum()
+        rec["sum_new"] = np.square(nd_.astype(np.float64)).sum()
+        rec["n_frames"] = self.n
+        rec["n_amb"] = len(amb)
+        moved = 0
+        ch = a != na_
+        for i in range(win_count):
+            k = win_lo + i
+            if np.any(ch & ((a == k) | (na_ == k))):
+                moved |= 1 << i
+        rec["moved"] = moved
+        out.numpy()[:32] = rec.view(np.uint8)
+        self.pending = (nd_, na_, trial_c, trial_G)
+
+    def pam_commit(self, accept):
+        if accept:
+            self.dist, self.assign, self.med_c, self.med_G = self.pending
+        self.pending = None
+
+
+class HostShard(_PamMixin):
     candidates = 1          # one-center protocol (ek_kcenters_step)
 
     def __init__(self, xyz, global_offset):

@@ -1,0 +1,123 @@
+"""The product shard (enspara_amd.sharded.DeviceShard: torch tensors + the C
+ABI) under the multi-rank drivers, on the one GPU of the test box: without a
+process group, and as a 1-rank RCCL job in a child process.  Results must
+equal the oracle's single-process k-centers / PAM exactly.  (world_size > 1 is
+covered on CPU by tests/test_sharded_gloo.py with the same drivers.)"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from enspara_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _expected(x, K, n_iters, seed, cutoff=None):
+    from oracle import cluster as oc
+    inds, a, d = oc.kcenters(x, n_clusters=K, dist_cutoff=cutoff)
+    rs = np.random.RandomState(seed)
+    for _ in range(n_iters):
+        inds, d, a = oc.pam_update(x, inds, a, d, random_state=rs)
+    return inds, a, d
+
+
+@pytest.mark.parametrize("n,A,K,prefetch", [(3000, 20, 40, 8), (1500, 9, 6, 3),
+                                            (2000, 33, 25, 1)])
+def test_device_shard_khybrid_no_group(n, A, K, prefetch):
+    import torch
+    from enspara_amd import sharded
+    from enspara_amd.device import FrameStore
+    x = synth.synth(n, A, 7, seed=n)
+    ts = torch.cuda.Stream(device=0)
+    with FrameStore(n, A, device=0, stream=ts.cuda_stream) as st:
+        st.load(x)
+        st.reset_state()
+        sh = sharded.DeviceShard(st)
+        with torch.cuda.stream(ts):
+            idx, _ = sharded.kcenters_sharded(sh, 0, K, 0.0)
+            med = [int(i) for i in idx]
+            rs = np.random.RandomState(3)
+            for _ in range(2):
+                med = sharded.pam_sweep_sharded(sh, med, random_state=rs,
+                                                prefetch=prefetch)
+        d, a = st.download_state()
+    inds, wa, wd = _expected(x, K, 2, 3)
+    np.testing.assert_array_equal(med, inds)
+    np.testing.assert_array_equal(a, wa)
+    np.testing.assert_array_equal(d.astype(np.float64), wd)
+
+
+def test_device_shard_explicit_proposals_match_single_gpu_sweep():
+    import torch
+    from enspara_amd import sharded
+    from enspara_amd.cluster import kmedoids as km
+    from enspara_amd.device import FrameStore
+    n, A, K = 2500, 16, 30
+    x = synth.synth(n, A, 5, seed=77)
+    props = [int(p) for p in np.random.RandomState(1).randint(0, n, size=K)]
+    with FrameStore.from_array(x) as st:
+        st.reset_state()
+        idx, _, _ = st.kcenters_run(0, K, 0.0)
+        want = km._pam_sweep_device(st, [int(i) for i in idx], props, None)
+        wd, wa = st.download_state()
+    ts = torch.cuda.Stream(device=0)
+    with FrameStore(n, A, device=0, stream=ts.cuda_stream) as st:
+        st.load(x)
+        st.reset_state()
+        sh = sharded.DeviceShard(st)
+        with torch.cuda.stream(ts):
+            idx2, _ = sharded.kcenters_sharded(sh, 0, K, 0.0)
+            got = sharded.pam_sweep_sharded(sh, list(idx2), proposals=props)
+        d, a = st.download_state()
+    np.testing.assert_array_equal(idx2, idx)
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(a, wa)
+    np.testing.assert_array_equal(d, wd)
+
+
+_CHILD = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+import torch
+import torch.distributed as dist
+from enspara_amd import sharded, synth
+from enspara_amd.device import FrameStore
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", sys.argv[3])
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1,
+                        device_id=torch.device("cuda", 0))
+n, A, K = 3000, 20, 40
+x = synth.synth(n, A, 7, seed=n)
+ts = torch.cuda.Stream(device=0)
+with FrameStore(n, A, device=0, stream=ts.cuda_stream) as st:
+    st.load(x)
+    st.reset_state()
+    sh = sharded.DeviceShard(st)
+    with torch.cuda.stream(ts):
+        med = sharded.khybrid_sharded(sh, K, 0.0, 2, random_state=3)
+    d, a = st.download_state()
+np.savez(sys.argv[2], med=np.array(med), d=d, a=a)
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_device_shard_khybrid_one_rank_rccl(tmp_path):
+    out = str(tmp_path / "r.npz")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run([sys.executable, "-c", _CHILD, ROOT, out, "29613"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    r = np.load(out)
+    x = synth.synth(3000, 20, 7, seed=3000)
+    inds, wa, wd = _expected(x, 40, 2, 3)
+    np.testing.assert_array_equal(r["med"], inds)
+    np.testing.assert_array_equal(r["a"], wa)
+    np.testing.assert_array_equal(r["d"].astype(np.float64), wd)

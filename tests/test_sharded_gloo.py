@@ -120,3 +120,89 @@ def test_single_process_without_process_group():
         np.testing.assert_array_equal(idx, np.array(inds))
         np.testing.assert_array_equal(sh.assign, a)
         np.testing.assert_array_equal(sh.dist.astype(np.float64), d)
+
+
+# ---- PAM sweeps / k-hybrid across ranks -------------------------------------
+def _hybrid_worker(rank, world, port, n, A, seed, K, n_iters, outdir, cands,
+                   explicit, prefetch):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["OMP_NUM_THREADS"] = "2"
+    from enspara_amd import sharded, synth
+    from _host_shard import HostShard, HostShardRounds
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port,
+                            rank=rank, world_size=world)
+    x = synth.synth(n, A, 9, seed=seed)
+    lo, cnt = sharded.shard_bounds(n, world, rank)
+    shard = (HostShard(x[lo:lo + cnt], lo) if cands == 1 else
+             HostShardRounds(x[lo:lo + cnt], lo, cands))
+    if explicit:
+        idx, _ = sharded.kcenters_sharded(shard, 0, K, 0.0)
+        props = np.random.RandomState(seed).randint(0, n, size=K)
+        med = sharded.pam_sweep_sharded(shard, list(idx), proposals=props,
+                                        prefetch=prefetch)
+    else:
+        med = sharded.khybrid_sharded(shard, K, 0.0, n_iters, random_state=4)
+    np.savez(os.path.join(outdir, "r%d.npz" % rank), med=np.array(med), lo=lo,
+             dist=shard.dist, assign=shard.assign)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_hybrid(world, n, A, seed, K, n_iters, cands=1, explicit=False,
+                prefetch=8):
+    from oracle import cluster as oc
+    from enspara_amd import synth
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_hybrid_worker,
+                 args=(world, _free_port(), n, A, seed, K, n_iters, d, cands,
+                       explicit, prefetch), nprocs=world, join=True)
+        parts = [np.load(os.path.join(d, "r%d.npz" % r)) for r in range(world)]
+    x = synth.synth(n, A, 9, seed=seed)
+    inds, a, dd = oc.kcenters(x, n_clusters=K)
+    if explicit:
+        props = np.random.RandomState(seed).randint(0, n, size=K)
+        inds, dd, a = oc.pam_update(x, inds, a, dd, proposals=props)
+    else:
+        rs = np.random.RandomState(4)
+        for _ in range(n_iters):
+            inds, dd, a = oc.pam_update(x, inds, a, dd, random_state=rs)
+    for p in parts:
+        np.testing.assert_array_equal(p["med"], np.array(inds))
+    np.testing.assert_array_equal(
+        np.concatenate([p["assign"] for p in parts]), a)
+    np.testing.assert_array_equal(
+        np.concatenate([p["dist"] for p in parts]).astype(np.float64), dd)
+
+
+def test_two_ranks_khybrid():
+    _run_hybrid(2, 1500, 15, 5, 12, 2)
+
+
+def test_three_ranks_one_empty_khybrid_rounds():
+    _run_hybrid(3, 500, 10, 7, 6, 2, cands=4)
+
+
+def test_two_ranks_pam_explicit_proposals():
+    _run_hybrid(2, 1200, 12, 3, 20, 1, explicit=True, prefetch=3)
+
+
+def test_pam_sweep_without_process_group():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _host_shard import HostShard
+    from enspara_amd import sharded, synth
+    from oracle import cluster as oc
+    x = synth.synth(900, 12, 6, seed=12)
+    inds, a, d = oc.kcenters(x, n_clusters=30)
+    for width in (1, 8):
+        sh = HostShard(x, 0)
+        idx, _ = sharded.kcenters_sharded(sh, 0, 30, 0.0)
+        rs_a, rs_b = np.random.RandomState(9), np.random.RandomState(9)
+        med, wi, wd, wa = list(idx), list(inds), d.copy(), a.copy()
+        for _ in range(2):
+            med = sharded.pam_sweep_sharded(sh, med, random_state=rs_a,
+                                            prefetch=width)
+            wi, wd, wa = oc.pam_update(x, wi, wa, wd, random_state=rs_b)
+        np.testing.assert_array_equal(med, wi)
+        np.testing.assert_array_equal(sh.assign, wa)
+        np.testing.assert_array_equal(sh.dist.astype(np.float64), wd)
