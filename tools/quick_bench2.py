@@ -31,7 +31,7 @@ if "assign" in what:
               % (n, kk, dt, n * kk / dt, n * kk * 18 * A / dt / 1e12), flush=True)
     d, a = st.download_state()
     # restore kcenters state for pam: labels from assign with all K centers are the kcenters labels
-if "pam" in what:
+if "pam" in what.split(","):
     from enspara_amd.cluster import kmedoids as km
     d0, a0 = st.download_state()
     P = min(K, int(os.environ.get("PAM_PROPOSALS", "600")))
@@ -70,6 +70,30 @@ if "pam" in what:
         h1, m1 = st.pam_prefetch_stats()
         print("pam width %d: %d proposals %.3fs  %.3f ms/proposal  accept %d  hits %d misses %d -> est. sweep of %d: %.1fs"
               % (width, P, dt, dt / P * 1e3, acc, h1 - h0, m1 - m0, K, dt / P * K), flush=True)
+if "shpam" in what:
+    # the multi-rank PAM driver on this one GPU (1-rank RCCL group if SHPAM_RCCL=1)
+    import torch, torch.distributed as dist
+    from enspara_amd import sharded
+    if os.environ.get("SHPAM_RCCL") == "1":
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29655")
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    ts = torch.cuda.Stream(device=0)
+    st2 = FrameStore(n, A, device=0, stream=ts.cuda_stream); st2.load(x); st2.reset_state()
+    sh = sharded.DeviceShard(st2)
+    P = min(K, int(os.environ.get("PAM_PROPOSALS", "600")))
+    with torch.cuda.stream(ts):
+        t = time.time(); idx2, _ = sharded.kcenters_sharded(sh, 0, K, 0.0); torch.cuda.synchronize()
+        print("sharded kcenters K=%d: %.2fs" % (K, time.time() - t), flush=True)
+        # sweep over the first P clusters only: medoid list truncated would change K; time a full sweep if P == K
+        med = [int(i) for i in idx2]
+        t = time.time()
+        import enspara_amd.sharded as S
+        # monkeypatch range to stop after P proposals is awkward: run a full sweep when asked
+        if P >= K:
+            med = sharded.pam_sweep_sharded(sh, med, random_state=np.random.RandomState(0))
+            torch.cuda.synchronize(); dt = time.time() - t
+            print("sharded pam sweep: %d proposals %.3fs  %.3f ms/proposal  hits/misses %s" % (K, dt, dt / K * 1e3, st2.pam_prefetch_stats()), flush=True)
 if "msm" in what:
     from enspara_amd.msm import assigns_to_counts, builders, eigenspectrum
     rng = np.random.RandomState(5)
