@@ -24,7 +24,8 @@ ek_assign_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
                  const double *__restrict__ Gc, int K,
                  float *__restrict__ dist, int32_t *__restrict__ assign)
 {
-    // ctile[a][c][k]: the CT centers' coordinates of atom a are contiguous
+    // ctile[a][pair][k][2]: the CT centers' coordinates of atom a are contiguous,
+    // centers in pairs so that one packed FMA (v_pk_fma_f32) serves two
     extern __shared__ __attribute__((aligned(16))) float ctile[];
     __shared__ double gtile[CT];
     const int tid = threadIdx.x;
@@ -43,26 +44,26 @@ ek_assign_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
         for (int j = tid; j < 3 * A * CT; j += EK_BLOCK) {
             const int a = j / (3 * CT), rem = j % (3 * CT);
             const int c = rem / 3, k = rem % 3;
-            ctile[j] = (c < kc) ? centers[(size_t)(k0 + c) * 3 * A + 3 * a + k]
-                                : 0.f;
+            ctile[a * (3 * CT) + (c / 2) * 6 + k * 2 + (c & 1)] =
+                (c < kc) ? centers[(size_t)(k0 + c) * 3 * A + 3 * a + k] : 0.f;
         }
         if (tid < CT)
             gtile[tid] = (tid < kc) ? Gc[k0 + tid] : 0.0;
         __syncthreads();
 
-        float s[CT][9];
+        ek_v2f s2[CT / 2][9];   // (center 2p, center 2p+1): independent FMA chains
 #pragma unroll
-        for (int c = 0; c < CT; ++c)
+        for (int c = 0; c < CT / 2; ++c)
 #pragma unroll
             for (int j = 0; j < 9; ++j)
-                s[c][j] = 0.f;
+                s2[c][j] = (ek_v2f){0.f, 0.f};
 
         const float4 *ct4 = (const float4 *)ctile;
 #pragma unroll 2
         for (int a = 0; a < A; ++a) {
-            const float x = p[(size_t)(3 * a + 0) * EK_TILE];
-            const float y = p[(size_t)(3 * a + 1) * EK_TILE];
-            const float z = p[(size_t)(3 * a + 2) * EK_TILE];
+            const float xs = p[(size_t)(3 * a + 0) * EK_TILE];
+            const float ys = p[(size_t)(3 * a + 1) * EK_TILE];
+            const float zs = p[(size_t)(3 * a + 2) * EK_TILE];
             float cc[3 * CT];
 #pragma unroll
             for (int q = 0; q < 3 * CT / 4; ++q) {
@@ -72,26 +73,33 @@ ek_assign_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
                 cc[4 * q + 2] = v.z;
                 cc[4 * q + 3] = v.w;
             }
+            const ek_v2f x = (ek_v2f){xs, xs}, y = (ek_v2f){ys, ys},
+                         z = (ek_v2f){zs, zs};
 #pragma unroll
-            for (int c = 0; c < CT; ++c) {
-                const float cx = cc[3 * c + 0], cy = cc[3 * c + 1],
-                            cz = cc[3 * c + 2];
-                s[c][0] = __builtin_fmaf(x, cx, s[c][0]);
-                s[c][1] = __builtin_fmaf(x, cy, s[c][1]);
-                s[c][2] = __builtin_fmaf(x, cz, s[c][2]);
-                s[c][3] = __builtin_fmaf(y, cx, s[c][3]);
-                s[c][4] = __builtin_fmaf(y, cy, s[c][4]);
-                s[c][5] = __builtin_fmaf(y, cz, s[c][5]);
-                s[c][6] = __builtin_fmaf(z, cx, s[c][6]);
-                s[c][7] = __builtin_fmaf(z, cy, s[c][7]);
-                s[c][8] = __builtin_fmaf(z, cz, s[c][8]);
+            for (int c = 0; c < CT / 2; ++c) {
+                const ek_v2f cx = (ek_v2f){cc[6 * c + 0], cc[6 * c + 1]},
+                             cy = (ek_v2f){cc[6 * c + 2], cc[6 * c + 3]},
+                             cz = (ek_v2f){cc[6 * c + 4], cc[6 * c + 5]};
+                s2[c][0] = __builtin_elementwise_fma(x, cx, s2[c][0]);
+                s2[c][1] = __builtin_elementwise_fma(x, cy, s2[c][1]);
+                s2[c][2] = __builtin_elementwise_fma(x, cz, s2[c][2]);
+                s2[c][3] = __builtin_elementwise_fma(y, cx, s2[c][3]);
+                s2[c][4] = __builtin_elementwise_fma(y, cy, s2[c][4]);
+                s2[c][5] = __builtin_elementwise_fma(y, cz, s2[c][5]);
+                s2[c][6] = __builtin_elementwise_fma(z, cx, s2[c][6]);
+                s2[c][7] = __builtin_elementwise_fma(z, cy, s2[c][7]);
+                s2[c][8] = __builtin_elementwise_fma(z, cz, s2[c][8]);
             }
         }
         if (live) {
 #pragma unroll
             for (int c = 0; c < CT; ++c) {
                 if (c < kc) {
-                    const float d = ek_rmsd_from_S(s[c], Gf, gtile[c], A);
+                    float S[9];
+#pragma unroll
+                    for (int j = 0; j < 9; ++j)
+                        S[j] = s2[c / 2][j][c & 1];
+                    const float d = ek_rmsd_from_S(S, Gf, gtile[c], A);
                     if (d < best) {          // strict <: util.py:201
                         best = d;
                         besti = k0 + c;

@@ -56,6 +56,7 @@ struct EkMaxHdr {
 };
 static_assert(sizeof(EkMaxHdr) == 16, "max header is 16 bytes");
 
+typedef float ek_v2f __attribute__((ext_vector_type(2)));
 #define EK_MAX_CANDS 8
 // plan of one multi-candidate round (ek_spec.hip); written only by the
 // single-workgroup plan/check kernels, read by the kernels that follow

@@ -275,7 +275,8 @@ ek_subset_assign_kernel(const float *__restrict__ ambt,
     // ctile[a][c][k]; global reads run along each center's row (coalesced)
     for (int j = tid; j < 3 * A * PCT; j += EK_BLOCK) {
         const int c = j / (3 * A), r = j % (3 * A);
-        ctile[(r / 3) * (3 * PCT) + c * 3 + (r % 3)] =
+        // centers in pairs, [atom][pair][xyz][2]: one packed FMA serves two
+        ctile[(r / 3) * (3 * PCT) + (c / 2) * 6 + (r % 3) * 2 + (c & 1)] =
             (c < kc) ? centers[(size_t)(k0 + c) * 3 * A + r] : 0.f;
     }
     if (tid < PCT)
@@ -284,18 +285,18 @@ ek_subset_assign_kernel(const float *__restrict__ ambt,
     if (i >= n_amb)
         return;
     const float *p = ambt + i;
-    float s[PCT][9];
+    ek_v2f s2[PCT / 2][9];      // (center 2p, center 2p+1): independent FMA chains
 #pragma unroll
-    for (int c = 0; c < PCT; ++c)
+    for (int c = 0; c < PCT / 2; ++c)
 #pragma unroll
         for (int j = 0; j < 9; ++j)
-            s[c][j] = 0.f;
+            s2[c][j] = (ek_v2f){0.f, 0.f};
     const float4 *ct4 = (const float4 *)ctile;
 #pragma unroll 4
     for (int a = 0; a < A; ++a) {
-        const float x = p[(size_t)(3 * a + 0) * cap];
-        const float y = p[(size_t)(3 * a + 1) * cap];
-        const float z = p[(size_t)(3 * a + 2) * cap];
+        const float xs = p[(size_t)(3 * a + 0) * cap];
+        const float ys = p[(size_t)(3 * a + 1) * cap];
+        const float zs = p[(size_t)(3 * a + 2) * cap];
         float cc[3 * PCT];
 #pragma unroll
         for (int q = 0; q < 3 * PCT / 4; ++q) {
@@ -305,19 +306,22 @@ ek_subset_assign_kernel(const float *__restrict__ ambt,
             cc[4 * q + 2] = v.z;
             cc[4 * q + 3] = v.w;
         }
+        const ek_v2f x = (ek_v2f){xs, xs}, y = (ek_v2f){ys, ys},
+                     z = (ek_v2f){zs, zs};
 #pragma unroll
-        for (int c = 0; c < PCT; ++c) {
-            const float cx = cc[3 * c + 0], cy = cc[3 * c + 1],
-                        cz = cc[3 * c + 2];
-            s[c][0] = __builtin_fmaf(x, cx, s[c][0]);
-            s[c][1] = __builtin_fmaf(x, cy, s[c][1]);
-            s[c][2] = __builtin_fmaf(x, cz, s[c][2]);
-            s[c][3] = __builtin_fmaf(y, cx, s[c][3]);
-            s[c][4] = __builtin_fmaf(y, cy, s[c][4]);
-            s[c][5] = __builtin_fmaf(y, cz, s[c][5]);
-            s[c][6] = __builtin_fmaf(z, cx, s[c][6]);
-            s[c][7] = __builtin_fmaf(z, cy, s[c][7]);
-            s[c][8] = __builtin_fmaf(z, cz, s[c][8]);
+        for (int c = 0; c < PCT / 2; ++c) {
+            const ek_v2f cx = (ek_v2f){cc[6 * c + 0], cc[6 * c + 1]},
+                         cy = (ek_v2f){cc[6 * c + 2], cc[6 * c + 3]},
+                         cz = (ek_v2f){cc[6 * c + 4], cc[6 * c + 5]};
+            s2[c][0] = __builtin_elementwise_fma(x, cx, s2[c][0]);
+            s2[c][1] = __builtin_elementwise_fma(x, cy, s2[c][1]);
+            s2[c][2] = __builtin_elementwise_fma(x, cz, s2[c][2]);
+            s2[c][3] = __builtin_elementwise_fma(y, cx, s2[c][3]);
+            s2[c][4] = __builtin_elementwise_fma(y, cy, s2[c][4]);
+            s2[c][5] = __builtin_elementwise_fma(y, cz, s2[c][5]);
+            s2[c][6] = __builtin_elementwise_fma(z, cx, s2[c][6]);
+            s2[c][7] = __builtin_elementwise_fma(z, cy, s2[c][7]);
+            s2[c][8] = __builtin_elementwise_fma(z, cz, s2[c][8]);
         }
     }
     const double Gf = ambG[i];
@@ -325,7 +329,11 @@ ek_subset_assign_kernel(const float *__restrict__ ambt,
 #pragma unroll
     for (int c = 0; c < PCT; ++c) {
         if (c < kc) {
-            const float d = ek_rmsd_from_S(s[c], Gf, gtile[c], A);
+            float S[9];
+#pragma unroll
+            for (int j = 0; j < 9; ++j)
+                S[j] = s2[c / 2][j][c & 1];
+            const float d = ek_rmsd_from_S(S, Gf, gtile[c], A);
             const unsigned long long key =
                 ((unsigned long long)__float_as_uint(d) << 32) |
                 (unsigned int)(k0 + c);

@@ -26,11 +26,17 @@
 #include "ek_qcp.h"
 #include "ek_reduce.h"
 
+// atoms per trip of the pass kernel's main loop, and how many trips ahead of
+// the FMAs the row loads are issued (register ring of DIST + 1 trips)
 #ifndef EK_SPEC_TRIP
 #define EK_SPEC_TRIP 4
 #endif
-#ifndef EK_SPEC_DB
-#define EK_SPEC_DB true
+#ifndef EK_SPEC_DIST
+#define EK_SPEC_DIST 1
+#endif
+// waves per SIMD asked of the register allocator for the 8-candidate kernel
+#ifndef EK_SPEC_WAVES8
+#define EK_SPEC_WAVES8 3
 #endif
 
 // ---------------------------------------------------------------------------
@@ -120,7 +126,7 @@ void ek_launch_plan(const unsigned char *recs, int n_recs, int A, int T,
 // distances go to vecs[0..T-2]).  UPD = false: distances only, all T of them to
 // vecs[0..T-1] (PAM proposal prefetch); dist / assign / blockmax are not touched.
 template <int T, bool UPD>
-__global__ void __launch_bounds__(EK_BLOCK, (T <= 4) ? 5 : 3)
+__global__ void __launch_bounds__(EK_BLOCK, (T <= 4) ? 5 : EK_SPEC_WAVES8)
 ek_pass_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
                float *__restrict__ dist, int32_t *__restrict__ assign,
                float *__restrict__ vecs,   // [T-1][n_pad] stored distance vectors
@@ -149,7 +155,9 @@ ek_pass_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
                 (size_t)plan->src[c] * rstride + sizeof(EkRecHdr));
             v = src[r];
         }
-        ctile[(r / 3) * (3 * T) + c * 3 + (r % 3)] = v;
+        // candidates in pairs: [atom][pair][xyz][2], so that one packed FMA
+        // (v_pk_fma_f32) serves candidates 2p and 2p+1
+        ctile[(r / 3) * (3 * T) + (c / 2) * 6 + (r % 3) * 2 + (c & 1)] = v;
     }
     if (tid < T) {
         double g = 0.0;
@@ -161,94 +169,86 @@ ek_pass_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
     __syncthreads();
 
     const int64_t f = (int64_t)blockIdx.x * EK_BLOCK + tid;
-    const float *p = tiles + (size_t)(f / EK_TILE) * 3 * (size_t)A * EK_TILE +
-                     (f % EK_TILE);
-    float s[T][9];
+    // one workgroup = one tile: a wave-uniform base (scalar registers) plus the
+    // lane's 32-bit offset, so the row addresses cost no vector registers
+    static_assert(EK_BLOCK == EK_TILE, "one workgroup per tile");
+    const float *tb = tiles + (size_t)blockIdx.x * 3 * (size_t)A * EK_TILE;
+    // s2[p][j] = (S_j of candidate 2p, S_j of candidate 2p+1): each component is
+    // its own IEEE FMA chain in ascending atom order, exactly as the one-center
+    // kernels compute it; packing only doubles the FMA rate (the T = 8 pass was
+    // bound by the vector ALU, not by HBM, with scalar FMAs).
+    ek_v2f s2[T / 2][9];
 #pragma unroll
-    for (int c = 0; c < T; ++c)
+    for (int c = 0; c < T / 2; ++c)
 #pragma unroll
         for (int j = 0; j < 9; ++j)
-            s[c][j] = 0.f;
+            s2[c][j] = (ek_v2f){0.f, 0.f};
 
     const float4 *ct4 = (const float4 *)ctile;
     constexpr int Q = 3 * T / 4;            // float4 per atom (T multiple of 4)
-    // Occupancy is only 3-5 waves per SIMD here (9*T accumulators), so each
-    // wave keeps two trips of row loads in flight: the rows of trip t+1 are
-    // requested before the FMAs of trip t are issued (register double buffer).
-    // (T = 8 has no registers to spare for that: it runs single-buffered with
-    // twice the trip length instead.)
-    constexpr bool DB = EK_SPEC_DB;
-    constexpr int TRIP = DB ? EK_SPEC_TRIP : 2 * EK_SPEC_TRIP;   // atoms per trip
+    // Occupancy is only 3-4 waves per SIMD here (9*T accumulators), and a trip's
+    // FMAs take a fraction of the HBM latency, so the rows of trip t + DIST are
+    // requested before the FMAs of trip t are issued: a ring of DIST + 1
+    // register buffers, unrolled so that every buffer index is a constant.
+    constexpr int TRIP = EK_SPEC_TRIP;      // atoms per trip
+    constexpr int DIST = EK_SPEC_DIST;
+    constexpr int NB = DIST + 1;
     const int n_trip = (A + TRIP - 1) / TRIP;
-    float cx_[TRIP], cy_[TRIP], cz_[TRIP];  // current trip's rows
-#pragma unroll
-    for (int u = 0; u < TRIP; ++u) {
-        const int au = (u < A) ? u : A - 1;     // clamp: in-bounds, masked below
-        cx_[u] = __builtin_nontemporal_load(p + (size_t)(3 * au + 0) * EK_TILE);
-        cy_[u] = __builtin_nontemporal_load(p + (size_t)(3 * au + 1) * EK_TILE);
-        cz_[u] = __builtin_nontemporal_load(p + (size_t)(3 * au + 2) * EK_TILE);
+    float bx[NB][TRIP], by[NB][TRIP], bz[NB][TRIP];
+#define EK_ROWS(BUF, TRIP_INDEX)                                               \
+    _Pragma("unroll") for (int u = 0; u < TRIP; ++u) {                         \
+        int au = (TRIP_INDEX) * TRIP + u;                                      \
+        au = (au < A) ? au : A - 1;     /* clamp: in-bounds, masked below */   \
+        const float *row = tb + (size_t)(3 * au) * EK_TILE;                    \
+        bx[BUF][u] = __builtin_nontemporal_load(row + tid);                    \
+        by[BUF][u] = __builtin_nontemporal_load(row + EK_TILE + tid);          \
+        bz[BUF][u] = __builtin_nontemporal_load(row + 2 * EK_TILE + tid);      \
     }
-    for (int t = 0; t < n_trip; ++t) {
-        const int a0 = t * TRIP;
-        float nx[TRIP], ny[TRIP], nz[TRIP];
-        if (DB) {
+#pragma unroll
+    for (int k = 0; k < DIST; ++k)
+        EK_ROWS(k, k)
+    for (int t0 = 0; t0 < n_trip; t0 += NB) {
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int t = t0 + k;
+            EK_ROWS((k + DIST) % NB, t + DIST)
+            const int a0 = t * TRIP;
 #pragma unroll
             for (int u = 0; u < TRIP; ++u) {
-                int au = a0 + TRIP + u;
-                au = (au < A) ? au : A - 1;
-                nx[u] = __builtin_nontemporal_load(p + (size_t)(3 * au + 0) * EK_TILE);
-                ny[u] = __builtin_nontemporal_load(p + (size_t)(3 * au + 1) * EK_TILE);
-                nz[u] = __builtin_nontemporal_load(p + (size_t)(3 * au + 2) * EK_TILE);
-            }
-        }
+                const int a = a0 + u;
+                if (a < A) {                        // wave-uniform
+                    float cc[3 * T];
 #pragma unroll
-        for (int u = 0; u < TRIP; ++u) {
-            const int a = a0 + u;
-            if (a < A) {                        // wave-uniform
-                float cc[3 * T];
+                    for (int q = 0; q < Q; ++q) {
+                        const float4 v = ct4[a * Q + q];
+                        cc[4 * q + 0] = v.x;
+                        cc[4 * q + 1] = v.y;
+                        cc[4 * q + 2] = v.z;
+                        cc[4 * q + 3] = v.w;
+                    }
+                    const ek_v2f x = (ek_v2f){bx[k][u], bx[k][u]},
+                                 y = (ek_v2f){by[k][u], by[k][u]},
+                                 z = (ek_v2f){bz[k][u], bz[k][u]};
 #pragma unroll
-                for (int q = 0; q < Q; ++q) {
-                    const float4 v = ct4[a * Q + q];
-                    cc[4 * q + 0] = v.x;
-                    cc[4 * q + 1] = v.y;
-                    cc[4 * q + 2] = v.z;
-                    cc[4 * q + 3] = v.w;
+                    for (int c = 0; c < T / 2; ++c) {
+                        const ek_v2f cx = (ek_v2f){cc[6 * c + 0], cc[6 * c + 1]},
+                                     cy = (ek_v2f){cc[6 * c + 2], cc[6 * c + 3]},
+                                     cz = (ek_v2f){cc[6 * c + 4], cc[6 * c + 5]};
+                        s2[c][0] = __builtin_elementwise_fma(x, cx, s2[c][0]);
+                        s2[c][1] = __builtin_elementwise_fma(x, cy, s2[c][1]);
+                        s2[c][2] = __builtin_elementwise_fma(x, cz, s2[c][2]);
+                        s2[c][3] = __builtin_elementwise_fma(y, cx, s2[c][3]);
+                        s2[c][4] = __builtin_elementwise_fma(y, cy, s2[c][4]);
+                        s2[c][5] = __builtin_elementwise_fma(y, cz, s2[c][5]);
+                        s2[c][6] = __builtin_elementwise_fma(z, cx, s2[c][6]);
+                        s2[c][7] = __builtin_elementwise_fma(z, cy, s2[c][7]);
+                        s2[c][8] = __builtin_elementwise_fma(z, cz, s2[c][8]);
+                    }
                 }
-                const float x = cx_[u], y = cy_[u], z = cz_[u];
-#pragma unroll
-                for (int c = 0; c < T; ++c) {
-                    const float cx = cc[3 * c + 0], cy = cc[3 * c + 1],
-                                cz = cc[3 * c + 2];
-                    s[c][0] = __builtin_fmaf(x, cx, s[c][0]);
-                    s[c][1] = __builtin_fmaf(x, cy, s[c][1]);
-                    s[c][2] = __builtin_fmaf(x, cz, s[c][2]);
-                    s[c][3] = __builtin_fmaf(y, cx, s[c][3]);
-                    s[c][4] = __builtin_fmaf(y, cy, s[c][4]);
-                    s[c][5] = __builtin_fmaf(y, cz, s[c][5]);
-                    s[c][6] = __builtin_fmaf(z, cx, s[c][6]);
-                    s[c][7] = __builtin_fmaf(z, cy, s[c][7]);
-                    s[c][8] = __builtin_fmaf(z, cz, s[c][8]);
-                }
-            }
-        }
-        if (DB) {
-#pragma unroll
-            for (int u = 0; u < TRIP; ++u) {
-                cx_[u] = nx[u];
-                cy_[u] = ny[u];
-                cz_[u] = nz[u];
-            }
-        } else if (t + 1 < n_trip) {
-#pragma unroll
-            for (int u = 0; u < TRIP; ++u) {
-                int au = a0 + TRIP + u;
-                au = (au < A) ? au : A - 1;
-                cx_[u] = __builtin_nontemporal_load(p + (size_t)(3 * au + 0) * EK_TILE);
-                cy_[u] = __builtin_nontemporal_load(p + (size_t)(3 * au + 1) * EK_TILE);
-                cz_[u] = __builtin_nontemporal_load(p + (size_t)(3 * au + 2) * EK_TILE);
             }
         }
     }
+#undef EK_ROWS
 
     if (!UPD) {
         if (f < n) {
@@ -256,9 +256,14 @@ ek_pass_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
 #pragma unroll
             for (int c = 0; c < T; ++c) {
                 __builtin_amdgcn_sched_barrier(0);
-                if (c < teff)
+                if (c < teff) {
+                    float S[9];
+#pragma unroll
+                    for (int j = 0; j < 9; ++j)
+                        S[j] = s2[c / 2][j][c & 1];
                     vecs[(size_t)c * n_pad + f] =
-                        ek_rmsd_from_S(s[c], Gf, gtile[c], A);
+                        ek_rmsd_from_S(S, Gf, gtile[c], A);
+                }
             }
         }
         return;
@@ -268,7 +273,11 @@ ek_pass_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
     if (f < n) {
         const double Gf = G[f];
         // candidate 0: the new center of this iteration (kcenters.py:298-306)
-        const float d0 = ek_rmsd_from_S(s[0], Gf, gtile[0], A);
+        float S0[9];
+#pragma unroll
+        for (int j = 0; j < 9; ++j)
+            S0[j] = s2[0][j][0];
+        const float d0 = ek_rmsd_from_S(S0, Gf, gtile[0], A);
         float cur = dist[f];
         if (d0 < cur) {
             cur = d0;
@@ -282,9 +291,14 @@ ek_pass_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
 #pragma unroll
         for (int c = 1; c < T; ++c) {
             __builtin_amdgcn_sched_barrier(0);
-            if (c < teff)
+            if (c < teff) {
+                float S[9];
+#pragma unroll
+                for (int j = 0; j < 9; ++j)
+                    S[j] = s2[c / 2][j][c & 1];
                 vecs[(size_t)(c - 1) * n_pad + f] =
-                    ek_rmsd_from_S(s[c], Gf, gtile[c], A);
+                    ek_rmsd_from_S(S, Gf, gtile[c], A);
+            }
         }
     }
     ek_wave_argmax(bestv, besti);
