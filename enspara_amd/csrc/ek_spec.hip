@@ -750,80 +750,93 @@ ek_pickT_kernel(const EkBlockMax *__restrict__ blockmax, int nb,
             }
         }
     }
-    __shared__ float r_v[EK_RED_THREADS / EK_WAVE];
-    __shared__ uint32_t r_i[EK_RED_THREADS / EK_WAVE];
-    __shared__ int r_b[EK_RED_THREADS / EK_WAVE];
-    __shared__ int w_b;
-    __shared__ uint32_t w_i;
-    __shared__ float w_v;
+    constexpr int NWV = EK_RED_THREADS / EK_WAVE;
+    constexpr int LMAX = EK_MAX_CANDS + 4;
+    __shared__ float wt_v[NWV * LMAX];
+    __shared__ uint32_t wt_i[NWV * LMAX];
     const int max_looks = T + 4;
-    for (int look = 0; look < max_looks; ++look) {
-        float v;
-        uint32_t i;
-        int b;
-        if (cached) {
-            v = -__builtin_inff();
-            i = 0xffffffffu;
-            b = -1;
+    if (cached) {
+        // Two levels, no workgroup barrier inside the looks: every wave takes the
+        // top max_looks of its own entries with wave-wide arg-max steps, then
+        // wave 0 takes the top max_looks of those NWV lists -- the same ordered
+        // list as max_looks arg-max passes over all entries.
+        const int lane = tid & (EK_WAVE - 1), wv = tid / EK_WAVE;
+        for (int look = 0; look < max_looks; ++look) {
+            float v = -__builtin_inff();
+            uint32_t i = 0xffffffffu;
 #pragma unroll
             for (int k = 0; k < PICK_PER; ++k)
                 if (ci[k] != 0xffffffffu && ek_better(cv[k], ci[k], v, i)) {
                     v = cv[k];
                     i = ci[k];
-                    b = tid + k * EK_RED_THREADS;
                 }
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                const float ov = __shfl_xor(v, off, 64);
-                const uint32_t oi = __shfl_xor(i, off, 64);
-                const int ob = __shfl_xor(b, off, 64);
-                if (ek_better(ov, oi, v, i)) {
-                    v = ov;
-                    i = oi;
-                    b = ob;
-                }
-            }
-            if ((tid & 63) == 0) {
-                r_v[tid / 64] = v;
-                r_i[tid / 64] = i;
-                r_b[tid / 64] = b;
-            }
-            __syncthreads();
-            if (tid == 0) {
-                for (int w = 1; w < EK_RED_THREADS / EK_WAVE; ++w)
-                    if (ek_better(r_v[w], r_i[w], v, i)) {
-                        v = r_v[w];
-                        i = r_i[w];
-                        b = r_b[w];
-                    }
-                w_v = v;
-                w_i = i;
-                w_b = b;
-            }
-            __syncthreads();
-            v = w_v;
-            i = w_i;
-            b = w_b;
-            // the owner of that entry retires it
-            if (b >= 0 && (b % EK_RED_THREADS) == tid) {
+            ek_wave_argmax(v, i);            // every lane holds the winner
+            if (i != 0xffffffffu) {          // its owner retires it (indices are unique)
 #pragma unroll
                 for (int k = 0; k < PICK_PER; ++k)
-                    if (k == b / EK_RED_THREADS)
+                    if (ci[k] == i)
                         ci[k] = 0xffffffffu;
             }
-        } else {
-            ek_block_argmax(blockmax, nb, skip, v, i, b);
-        }
-        if (b < 0)
-            break;
-        if (tid == 0) {
-            if (!cached)
-                skip[b >> 5] |= 1u << (b & 31);
-            top_i[n_top] = i;
-            top_v[n_top] = v;
-            n_top = n_top + 1;
+            if (lane == 0) {
+                wt_v[wv * LMAX + look] = v;
+                wt_i[wv * LMAX + look] = i;
+            }
         }
         __syncthreads();
+        if (wv == 0) {
+            constexpr int PER2 = (NWV * LMAX + EK_WAVE - 1) / EK_WAVE;
+            float ev[PER2];
+            uint32_t ei[PER2];
+#pragma unroll
+            for (int k = 0; k < PER2; ++k) {
+                const int e = lane + k * EK_WAVE;
+                const int w = e / LMAX, l = e % LMAX;
+                const bool ok = w < NWV && l < max_looks;
+                ev[k] = ok ? wt_v[w * LMAX + l] : -__builtin_inff();
+                ei[k] = ok ? wt_i[w * LMAX + l] : 0xffffffffu;
+            }
+            int cnt = 0;
+            for (int look = 0; look < max_looks; ++look) {
+                float v = -__builtin_inff();
+                uint32_t i = 0xffffffffu;
+#pragma unroll
+                for (int k = 0; k < PER2; ++k)
+                    if (ei[k] != 0xffffffffu && ek_better(ev[k], ei[k], v, i)) {
+                        v = ev[k];
+                        i = ei[k];
+                    }
+                ek_wave_argmax(v, i);
+                if (i == 0xffffffffu)
+                    break;
+#pragma unroll
+                for (int k = 0; k < PER2; ++k)
+                    if (ei[k] == i)
+                        ei[k] = 0xffffffffu;
+                if (lane == 0) {
+                    top_i[cnt] = i;
+                    top_v[cnt] = v;
+                }
+                ++cnt;
+            }
+            if (lane == 0)
+                n_top = cnt;
+        }
+    } else {
+        for (int look = 0; look < max_looks; ++look) {
+            float v;
+            uint32_t i;
+            int b;
+            ek_block_argmax(blockmax, nb, skip, v, i, b);
+            if (b < 0)
+                break;
+            if (tid == 0) {
+                skip[b >> 5] |= 1u << (b & 31);
+                top_i[n_top] = i;
+                top_v[n_top] = v;
+                n_top = n_top + 1;
+            }
+            __syncthreads();
+        }
     }
     __syncthreads();
     // labels of the looked-at frames, fetched in parallel
@@ -868,14 +881,33 @@ ek_pickT_kernel(const EkBlockMax *__restrict__ blockmax, int nb,
     }
     if (tid == 0)
         ctl->last_max = (ns > 0) ? sel_v[0] : -__builtin_inff();
-    // all gathers at once
-    for (int k = tid; k < ns * 3 * A; k += EK_RED_THREADS) {
-        const int j = k / (3 * A), r = k % (3 * A);
-        const uint32_t i = sel_i[j];
-        const float *p = tiles + (size_t)(i / EK_TILE) * 3 * (size_t)A * EK_TILE +
-                         (i % EK_TILE);
-        float *coords = (float *)(recs + (size_t)j * rstride + sizeof(EkRecHdr));
-        coords[r] = p[(size_t)r * EK_TILE];
+    // the gathers: every read is its own cache line, so each thread issues a
+    // batch of them before it touches any result
+    constexpr int GB = 8;
+    const int total = ns * 3 * A;
+    for (int k0 = 0; k0 < total; k0 += GB * EK_RED_THREADS) {
+        float val[GB];
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+            int k = k0 + u * EK_RED_THREADS + tid;
+            k = (k < total) ? k : total - 1;
+            const int j = k / (3 * A), r = k % (3 * A);
+            const uint32_t i = sel_i[j];
+            const float *p = tiles +
+                             (size_t)(i / EK_TILE) * 3 * (size_t)A * EK_TILE +
+                             (i % EK_TILE);
+            val[u] = p[(size_t)r * EK_TILE];
+        }
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+            const int k = k0 + u * EK_RED_THREADS + tid;
+            if (k < total) {
+                const int j = k / (3 * A), r = k % (3 * A);
+                float *coords =
+                    (float *)(recs + (size_t)j * rstride + sizeof(EkRecHdr));
+                coords[r] = val[u];
+            }
+        }
     }
 }
 
