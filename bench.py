@@ -68,6 +68,12 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=15.0,
                    help="time budget of the CPU baseline leg (rank 0, N=1)")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--pam-sweeps", type=int, default=None,
+                   help="after the timed k-centers region, time this many PAM "
+                        "(k-medoids) sweeps over the centers found -- the "
+                        "k-hybrid refinement of BASELINE.json configs[2]; "
+                        "reported beside the metric, never part of it "
+                        "(default: 1 on one GPU, 0 on several)")
     p.add_argument("--sharded", action="store_true",
                    help="use the torch.distributed driver even with one rank "
                         "(exercises the RCCL path on a 1-GPU box)")
@@ -122,6 +128,11 @@ def cpu_baseline(x, gpu_centers, seconds):
                   % (n, k, wall, prep),
         "centers_match_gpu": bool(ok),
     }
+
+
+def km_width():
+    from enspara_amd.cluster import kmedoids as km
+    return int(km.PAM_PREFETCH)
 
 
 def load_traffic(args, cands):
@@ -298,6 +309,42 @@ def main():
         "setup": {"synth_s": t_gen, "upload_center_layout_s": t_load,
                   "host_to_hbm_GBps": x.nbytes / t_load / 1e9},
     }
+
+    # ---- k-hybrid refinement (configs[2]), outside the timed region -----------
+    if args.pam_sweeps is None:
+        args.pam_sweeps = 1 if world == 1 else 0
+    if args.pam_sweeps > 0:
+        med = [int(i) for i in np.concatenate([warm_idx, idx])]
+        rs = np.random.RandomState(args.seed)
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        t0 = time.perf_counter()
+        if use_dist:
+            with torch.cuda.stream(tstream):
+                for _ in range(args.pam_sweeps):
+                    med = sharded.pam_sweep_sharded(shard, med,
+                                                    random_state=rs)
+        else:
+            from enspara_amd.cluster import kmedoids as km
+            for _ in range(args.pam_sweeps):
+                med = km._pam_sweep_device(store, med, None, rs)
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        t_pam = time.perf_counter() - t0
+        hits, misses = store.pam_prefetch_stats()
+        out["khybrid"] = {
+            "workload": "PAM sweeps over the %d centers of the run above "
+                        "(k-hybrid = k-centers + k-medoids, BASELINE.json "
+                        "configs[2])" % len(med),
+            "sweeps": args.pam_sweeps,
+            "s_per_sweep": t_pam / args.pam_sweeps,
+            "ms_per_proposal": t_pam / args.pam_sweeps / len(med) * 1e3,
+            "proposals_per_pass_over_frames": km_width(),
+            "prefetched_proposals_used": hits,
+            "proposals_with_own_pass": misses,
+        }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         all_idx = np.concatenate([warm_idx, idx])

@@ -170,6 +170,19 @@ static int ek_pick_cands(const ek_ctx *c)
     return (t == 8 || t == 4) ? t : 1;
 }
 
+// Wait for the stream by polling.  The PAM entry points read a few bytes back
+// once or twice per proposal; hipStreamSynchronize may put the thread to sleep
+// and a wake-up costs anything from 0.1 ms to tens of ms on a busy host --
+// more than the proposal itself.
+static hipError_t ek_wait(ek_ctx *c)
+{
+    for (;;) {
+        const hipError_t e = hipStreamQuery(c->stream);
+        if (e != hipErrorNotReady)
+            return e;
+    }
+}
+
 static int ek_spec_alloc(ek_ctx *c)
 {
     if (!c->vecs) {
@@ -1020,7 +1033,7 @@ extern "C" int ek_pam_begin(ek_ctx *c, const int64_t *medoid_frames, int32_t K)
         return rc;
     EK_HIP(hipMemcpyAsync(c->med_idx, medoid_frames, (size_t)K * sizeof(int64_t),
                           hipMemcpyHostToDevice, c->stream));
-    EK_HIP(hipStreamSynchronize(c->stream));
+    EK_HIP(ek_wait(c));
     ek_launch_gather_frames(c->tiles, c->G, c->A, c->med_idx, K, 0, c->med_aos,
                             c->med_G, c->stream);
     EK_CHECK_LAUNCH();
@@ -1055,7 +1068,7 @@ extern "C" int ek_centered_frames(ek_ctx *c, const int64_t *local_frames,
     }
     EK_HIP(hipMemcpyAsync(c->tmp_idx, h.data(), h.size() * sizeof(int64_t),
                           hipMemcpyHostToDevice, c->stream));
-    EK_HIP(hipStreamSynchronize(c->stream));
+    EK_HIP(ek_wait(c));
     ek_launch_gather_rows(c->tiles, c->G, c->A, c->tmp_idx, c->tmp_idx + count,
                           count, aos_dev, G_dev, c->stream);
     EK_CHECK_LAUNCH();
@@ -1092,7 +1105,7 @@ extern "C" int ek_pam_count_members(ek_ctx *c, int32_t cid, int64_t *count)
     EK_CHECK_LAUNCH();
     EK_HIP(hipMemcpyAsync(count, c->sel, sizeof(int64_t), hipMemcpyDeviceToHost,
                           c->stream));
-    EK_HIP(hipStreamSynchronize(c->stream));
+    EK_HIP(ek_wait(c));
     c->cnt_cid = cid;
     c->cnt_m = *count;
     return EK_OK;
@@ -1112,7 +1125,7 @@ extern "C" int ek_pam_select_member(ek_ctx *c, int32_t cid, int64_t j,
     EK_CHECK_LAUNCH();
     EK_HIP(hipMemcpyAsync(frame_index, c->sel + 1, sizeof(int64_t),
                           hipMemcpyDeviceToHost, c->stream));
-    EK_HIP(hipStreamSynchronize(c->stream));
+    EK_HIP(ek_wait(c));
     if (*frame_index < 0)
         return ek_fail(EK_EARG, "ek_pam_select_member: cluster %d has no "
                                 "member %lld", cid, (long long)j);
@@ -1130,7 +1143,7 @@ static int ek_pam_tail(ek_ctx *c, int32_t cid, const float *newd,
 {
     const int K = c->med_K;
     if (max_amb > c->ambt_cap) {
-        EK_HIP(hipStreamSynchronize(c->stream));
+        EK_HIP(ek_wait(c));
         (void)hipFree(c->ambt);
         (void)hipFree(c->ambG);
         c->ambt = nullptr;
@@ -1227,7 +1240,7 @@ static int ek_pam_propose_impl(ek_ctx *c, int32_t cid, int64_t frame_index,
     if (frame_index < 0)
         EK_HIP(hipMemcpyAsync(&fidx, c->med_idx + K, sizeof(int64_t),
                               hipMemcpyDeviceToHost, c->stream));
-    EK_HIP(hipStreamSynchronize(c->stream));
+    EK_HIP(ek_wait(c));
     c->pam_cid = cid;           // pending even if the check below fails
     c->pam_frame = fidx;
     if ((int64_t)n_amb > max_amb)
@@ -1353,7 +1366,7 @@ extern "C" int ek_pam_count_members_batch(ek_ctx *c, int32_t cid0, int32_t count
     EK_CHECK_LAUNCH();
     EK_HIP(hipMemcpyAsync(counts, c->bat_sel, (size_t)count * sizeof(int64_t),
                           hipMemcpyDeviceToHost, c->stream));
-    EK_HIP(hipStreamSynchronize(c->stream));
+    EK_HIP(ek_wait(c));
     c->bat_cid0 = cid0;
     c->bat_count = count;
     return EK_OK;
@@ -1381,7 +1394,7 @@ extern "C" int ek_pam_select_members_batch(ek_ctx *c, int32_t cid0, int32_t coun
     EK_HIP(hipMemcpyAsync(frames, c->bat_sel + EK_MAX_CANDS,
                           (size_t)count * sizeof(int64_t), hipMemcpyDeviceToHost,
                           c->stream));
-    EK_HIP(hipStreamSynchronize(c->stream));
+    EK_HIP(ek_wait(c));
     // the scans describe the state at count time only
     c->bat_cid0 = -1;
     c->bat_count = 0;

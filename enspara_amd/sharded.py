@@ -109,6 +109,19 @@ class DeviceShard:
         return self.torch.from_numpy(np.ascontiguousarray(
             arr, dtype=np.int64)).to(self.device)
 
+    def to_host(self, t):
+        """Small device tensor -> numpy, waiting by polling an event: a
+        blocking synchronize can cost far more than the proposal it guards
+        when the host thread is put to sleep."""
+        torch = self.torch
+        h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        h.copy_(t, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        while not ev.query():
+            pass
+        return h.numpy()
+
     def new_table(self, rows):
         """-> (coords float32 [rows, 3A], meta int64 [2 * rows]), zeroed;
         meta[:rows] holds the traces' float64 bit patterns, meta[rows:] is
@@ -152,6 +165,11 @@ class DeviceShard:
 
     def pam_commit(self, accept):
         self.store.pam_commit(accept)
+
+
+def _to_host(shard, t):
+    f = getattr(shard, "to_host", None)
+    return f(t) if f is not None else t.cpu().numpy()
 
 
 def _world(group):
@@ -280,7 +298,7 @@ def _gather_i64(shard, values, group, world, collective):
     everyone = torch.empty(world * len(values), dtype=torch.int64,
                            device=mine.device)
     dist.all_gather_into_tensor(everyone, mine, group=group)
-    return everyone.cpu().numpy().reshape(world, len(values))
+    return _to_host(shard, everyone).reshape(world, len(values)).copy()
 
 
 def _share_rows(coords, meta, group, collective):
@@ -397,7 +415,8 @@ def pam_sweep_sharded(shard, medoids, proposals=None, random_state=None,
                 pm[width:] = shard.host_to_buffer(idx)
                 n_guess = cnt
             _share_rows(pc, pm, group, collective)
-            win.gidx = [int(g) for g in pm[width:width + n_guess].cpu().numpy()]
+            win.gidx = [int(g) for g in
+                        _to_host(shard, pm[width:width + n_guess])]
             shard.pam_prefetch_centers(pc, pm, n_guess)
         slot = cid - win.lo
         exact = not ((win.stale >> slot) & 1)
@@ -427,7 +446,7 @@ def pam_sweep_sharded(shard, medoids, proposals=None, random_state=None,
                 shard.fill_rows([f], [0], oc, om)
                 om[1:] = shard.host_to_buffer([lo_mine + f])
             _share_rows(oc, om, group, collective)
-            g = int(om[1:].cpu().numpy()[0])
+            g = int(_to_host(shard, om[1:])[0])
             shard.pam_propose_center(cid, -1, oc, om, 0, m_local, win.lo,
                                      win.hi - win.lo, out_mine)
         else:
@@ -435,7 +454,7 @@ def pam_sweep_sharded(shard, medoids, proposals=None, random_state=None,
                                      win.lo, win.hi - win.lo, out_mine)
         if collective:
             dist.all_gather_into_tensor(out_all, out_mine, group=group)
-        recs = out_all.cpu().numpy().view(PAM_OUT)
+        recs = _to_host(shard, out_all).view(PAM_OUT)
         if int(recs[rank]["n_amb"]) > m_local:
             raise RuntimeError("PAM proposal for cluster %d: %d ambiguous "
                                "members on this shard, %d declared"
