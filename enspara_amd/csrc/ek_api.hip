@@ -134,6 +134,19 @@ struct ek_ctx {
     int32_t last_launches = 0;
 };
 
+// Wait for the stream by polling.  The loops that read a few bytes back per
+// step (PAM proposals, the k-centers progress checks) use this:
+// hipStreamSynchronize may put the thread to sleep and a wake-up costs anything
+// from 0.1 ms to tens of ms on a busy host -- more than the step itself.
+static hipError_t ek_wait(ek_ctx *c)
+{
+    for (;;) {
+        const hipError_t e = hipStreamQuery(c->stream);
+        if (e != hipErrorNotReady)
+            return e;
+    }
+}
+
 static int ek_pick_fpl(const ek_ctx *c)
 {
     if (c->fpl == 1 || c->fpl == 2 || c->fpl == 4)
@@ -168,19 +181,6 @@ static int ek_pick_cands(const ek_ctx *c)
     while (t > 1 && ek_pass_lds_bytes(t, c->A) > (size_t)150 * 1024)
         t /= 2;
     return (t == 8 || t == 4) ? t : 1;
-}
-
-// Wait for the stream by polling.  The PAM entry points read a few bytes back
-// once or twice per proposal; hipStreamSynchronize may put the thread to sleep
-// and a wake-up costs anything from 0.1 ms to tens of ms on a busy host --
-// more than the proposal itself.
-static hipError_t ek_wait(ek_ctx *c)
-{
-    for (;;) {
-        const hipError_t e = hipStreamQuery(c->stream);
-        if (e != hipErrorNotReady)
-            return e;
-    }
 }
 
 static int ek_spec_alloc(ek_ctx *c)
@@ -676,7 +676,7 @@ extern "C" int ek_history_download(ek_ctx *c, int32_t first, int32_t count,
                               (size_t)avail * sizeof(EkHist),
                               hipMemcpyDeviceToHost, c->stream));
     }
-    EK_HIP(hipStreamSynchronize(c->stream));
+    EK_HIP(ek_wait(c));
     for (int32_t i = 0; i < count; ++i) {
         const bool ok = i < avail && h[i].set;
         if (center_index_out)
@@ -710,7 +710,7 @@ extern "C" int ek_kcenters_run(ek_ctx *c, int32_t first_label, int32_t max_new,
     ctl0.n_done = first_label;
     EK_HIP(hipMemcpyAsync(c->ctl, &ctl0, offsetof(EkCtl, last_max),
                           hipMemcpyHostToDevice, c->stream));
-    EK_HIP(hipStreamSynchronize(c->stream));
+    EK_HIP(ek_wait(c));
 
     const int T = ek_pick_cands(c);
     if (T > 1 && c->n > 0) {
@@ -724,7 +724,7 @@ extern "C" int ek_kcenters_run(ek_ctx *c, int32_t first_label, int32_t max_new,
         ctlw.limit = first_label + max_new;
         EK_HIP(hipMemcpyAsync(c->ctl, &ctlw, sizeof(ctlw), hipMemcpyHostToDevice,
                               c->stream));
-        EK_HIP(hipStreamSynchronize(c->stream));
+        EK_HIP(ek_wait(c));
         const int nb = (int)((c->n + EK_BLOCK - 1) / EK_BLOCK);
         EK_HIP(hipEventRecord(c->ev0, c->stream));
         ek_launch_blockmax(c->dist, c->n, c->blockmax, c->stream);
@@ -775,19 +775,19 @@ extern "C" int ek_kcenters_run(ek_ctx *c, int32_t first_label, int32_t max_new,
             passes += rounds;
             EK_HIP(hipMemcpyAsync(&cr, c->ctl, sizeof(cr), hipMemcpyDeviceToHost,
                                   c->stream));
-            EK_HIP(hipStreamSynchronize(c->stream));
+            EK_HIP(ek_wait(c));
             if (cr.stopped || cr.n_done >= first_label + max_new)
                 break;
             per_round = std::max(1.0, (double)(cr.n_done - before) / rounds);
         }
         EK_HIP(hipEventRecord(c->ev1, c->stream));
-        EK_HIP(hipStreamSynchronize(c->stream));
+        EK_HIP(ek_wait(c));
         EK_HIP(hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
         // keep the single-record slot in step with the state (other entry
         // points read it)
         EK_HIP(hipMemcpyAsync(c->rec, c->recsT, ek_rec_bytes(c->A),
                               hipMemcpyDeviceToDevice, c->stream));
-        EK_HIP(hipStreamSynchronize(c->stream));
+        EK_HIP(ek_wait(c));
         const int32_t added_t = std::max(0, cr.n_done - first_label);
         c->last_launches = cr.n_rounds;
         c->last_passes = cr.n_rounds;
@@ -827,7 +827,7 @@ extern "C" int ek_kcenters_run(ek_ctx *c, int32_t first_label, int32_t max_new,
         if (!open_loop) {
             EK_HIP(hipMemcpyAsync(&ctl, c->ctl, sizeof(ctl),
                                   hipMemcpyDeviceToHost, c->stream));
-            EK_HIP(hipStreamSynchronize(c->stream));
+            EK_HIP(ek_wait(c));
             if (ctl.stopped)
                 break;
         }
@@ -835,7 +835,7 @@ extern "C" int ek_kcenters_run(ek_ctx *c, int32_t first_label, int32_t max_new,
     EK_HIP(hipEventRecord(c->ev1, c->stream));
     EK_HIP(hipMemcpyAsync(&ctl, c->ctl, sizeof(ctl), hipMemcpyDeviceToHost,
                           c->stream));
-    EK_HIP(hipStreamSynchronize(c->stream));
+    EK_HIP(ek_wait(c));
     EK_HIP(hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
     const int32_t added = std::max(0, ctl.n_done - first_label);
     c->last_launches = added;
@@ -875,7 +875,7 @@ extern "C" int ek_timing_end(ek_ctx *c, float *avg_ms, int32_t *n_samples)
     if (!c)
         return ek_fail(EK_EARG, "NULL context");
     EK_HIP(hipSetDevice(c->device));
-    EK_HIP(hipStreamSynchronize(c->stream));
+    EK_HIP(ek_wait(c));
     // launches enqueued past the stopping point return immediately (device
     // no-ops): only samples within 4x of the longest count as real launches
     std::vector<float> t((size_t)c->samp_used);
@@ -926,7 +926,7 @@ extern "C" int ek_assign_nearest(ek_ctx *c, const float *centers_xyz,
     if (mfma && n_centers > 0) {
         const int32_t need = (n_centers + EK_TILE - 1) / EK_TILE * EK_TILE;
         if (need > c->cen_tiles_cap) {
-            EK_HIP(hipStreamSynchronize(c->stream));
+            EK_HIP(ek_wait(c));
             (void)hipFree(c->cen_tiles);
             c->cen_tiles = nullptr;
             c->cen_tiles_cap = 0;
@@ -983,7 +983,7 @@ static int ek_pam_alloc(ek_ctx *c, int32_t K)
     c->pf_count = 0;
     c->pf_external = false;
     if (K > c->med_cap) {
-        EK_HIP(hipStreamSynchronize(c->stream));
+        EK_HIP(ek_wait(c));
         (void)hipFree(c->med_aos);
         (void)hipFree(c->med_G);
         (void)hipFree(c->med_idx);
@@ -1007,7 +1007,7 @@ static int ek_tmp_idx(ek_ctx *c, int64_t count)
 {
     if (count <= c->tmp_idx_cap)
         return EK_OK;
-    EK_HIP(hipStreamSynchronize(c->stream));
+    EK_HIP(ek_wait(c));
     (void)hipFree(c->tmp_idx);
     c->tmp_idx = nullptr;
     c->tmp_idx_cap = 0;
@@ -1610,7 +1610,7 @@ extern "C" int ek_spec_begin(ek_ctx *c, int32_t first_label, int32_t limit,
     w.limit = limit;
     EK_HIP(hipMemcpyAsync(c->ctl, &w, sizeof(w), hipMemcpyHostToDevice,
                           c->stream));
-    EK_HIP(hipStreamSynchronize(c->stream));
+    EK_HIP(ek_wait(c));
     const int nb = (int)((c->n + EK_BLOCK - 1) / EK_BLOCK);
     ek_launch_blockmax(c->dist, c->n, c->blockmax, c->stream);
     ek_launch_pickT(c->blockmax, nb, c->tiles, c->G, c->assign, c->A, T, c->goff,
@@ -1697,7 +1697,7 @@ extern "C" int ek_spec_rounds(ek_ctx *c, int32_t *rounds)
     EkCtl r;
     EK_HIP(hipMemcpyAsync(&r, c->ctl, sizeof(r), hipMemcpyDeviceToHost,
                           c->stream));
-    EK_HIP(hipStreamSynchronize(c->stream));
+    EK_HIP(ek_wait(c));
     *rounds = r.n_rounds;
     return EK_OK;
 }
@@ -1710,7 +1710,7 @@ extern "C" int ek_spec_progress(ek_ctx *c, int32_t *n_done, int32_t *stopped)
     EkCtl r;
     EK_HIP(hipMemcpyAsync(&r, c->ctl, sizeof(r), hipMemcpyDeviceToHost,
                           c->stream));
-    EK_HIP(hipStreamSynchronize(c->stream));
+    EK_HIP(ek_wait(c));
     if (n_done)
         *n_done = r.n_done;
     if (stopped)
