@@ -1,10 +1,10 @@
-"""sklearn-style MSM wrapper (reference enspara/msm/msm.py:27-120; fit :60-88).
-Ergodic trimming (trim=True) is not part of this build."""
+"""sklearn-style MSM wrapper (reference enspara/msm/msm.py:27-120; fit :60-88)."""
 import numpy as np
 
 from ..exception import ImproperlyConfigured
 from . import builders
 from .transition_matrices import assigns_to_counts
+from .trimming import TrimMapping, trim_disconnected
 
 
 class MSM(object):
@@ -25,16 +25,56 @@ class MSM(object):
         return m
 
     def fit(self, assigns):
-        if self.trim:
-            raise ImproperlyConfigured(
-                "ergodic trimming is not available in this build")
         tcounts = assigns_to_counts(
             assigns, max_n_states=self.max_n_states, lag_time=self.lag_time,
             sliding_window=self.sliding_window, device=self.device)
-        self.mapping_ = dict(zip(range(tcounts.shape[0]),
-                                 range(tcounts.shape[0])))
+        if self.trim:                                        # msm.py:74-79
+            self.mapping_, tcounts = trim_disconnected(tcounts)
+        else:
+            self.mapping_ = TrimMapping(zip(range(tcounts.shape[0]),
+                                            range(tcounts.shape[0])))
         self.tcounts_, self.tprobs_, self.eq_probs_ = self.method(tcounts)
         return self
+
+    @property
+    def config(self):
+        """reference msm.py:101-111"""
+        return {"lag_time": self.lag_time,
+                "sliding_window": self.sliding_window,
+                "trim": self.trim, "method": self.method}
+
+    @property
+    def result_(self):
+        """reference msm.py:113-134 (None before fit)"""
+        if getattr(self, "tcounts_", None) is None:
+            return None
+        return {"tcounts_": self.tcounts_, "tprobs_": self.tprobs_,
+                "eq_probs_": self.eq_probs_, "mapping_": self.mapping_}
+
+    def __eq__(self, other):
+        """reference msm.py:136-177: same configuration and, if fit, the same
+        counts, probabilities, equilibrium populations and mapping."""
+        if self is other:
+            return True
+        if not isinstance(other, MSM) or self.config != other.config:
+            return False
+        if self.result_ is None or other.result_ is None:
+            return self.result_ is None and other.result_ is None
+        if not np.all(self.eq_probs_ == other.eq_probs_):
+            return False
+        if self.mapping_ != other.mapping_:
+            return False
+        if (self.tcounts_.shape != other.tcounts_.shape or
+                self.tprobs_.shape != other.tprobs_.shape):
+            return False
+        if (self.tcounts_ != other.tcounts_).nnz != 0:
+            return False
+        return (self.tprobs_ != other.tprobs_).nnz == 0
+
+    __hash__ = None
+
+    def __repr__(self):
+        return "MSM:" + str({"config": self.config, "fit": self.result_})
 
     @property
     def n_states_(self):

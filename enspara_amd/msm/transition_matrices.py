@@ -11,6 +11,7 @@ import scipy.sparse
 
 from .. import _lib
 from ..exception import DataInvalid
+from .trimming import TrimMapping, trim_disconnected  # noqa: F401  (reference module layout)
 
 
 def _rows_of(assigns):

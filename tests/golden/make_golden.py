@@ -79,7 +79,59 @@ class FakeTraj:
             yield self[i]
 
 
+def make_trim_golden(rtm, rbuilders):
+    """Ergodic trimming (transition_matrices.py:236-301) and MSM(trim=True):
+    a count matrix with a large component, a closed small one, a source-only
+    and a sink-only state."""
+    import scipy.sparse
+    from enspara.msm.msm import MSM as RMSM
+    out = {}
+    rng = np.random.RandomState(21)
+    K = 40
+    big, small = list(range(0, 30)), list(range(30, 36))
+    rows = []
+    for _ in range(30):
+        comp = big if rng.rand() < 0.8 else small
+        s = comp[rng.randint(len(comp))]
+        t = []
+        for _ in range(200):
+            t.append(s)
+            s = comp[(comp.index(s) + rng.choice([-1, 0, 1, 2])) % len(comp)]
+        rows.append(t)
+    rows[0] = [36] + rows[0][1:]             # 36: left once, never entered
+    rows[1] = rows[1][:-1] + [37]            # 37: entered once, never left
+    rows[2] = rows[2][:100] + [38, 38, 39, 39, 38] + rows[2][105:]
+    assigns = np.array(rows, dtype=np.int64)
+    out["assigns"] = assigns
+    C = rtm.assigns_to_counts(assigns, lag_time=1, max_n_states=K)
+    out["counts"] = np.asarray(C.todense())
+    for thr in (1, 2, 5):
+        for ren in (True, False):
+            m, tc = rtm.trim_disconnected(C, threshold=thr,
+                                          renumber_states=ren)
+            key = "thr%d_ren%d" % (thr, int(ren))
+            out[key + "_counts"] = np.asarray(tc.todense())
+            out[key + "_map"] = np.array(sorted(m.to_original.items()))
+            assert type(tc) is type(C)
+    m = RMSM(lag_time=1, method=rbuilders.normalize, trim=True,
+             max_n_states=K)
+    m.fit(assigns)
+    out["msm_tcounts"] = np.asarray(m.tcounts_.todense())
+    out["msm_tprobs"] = np.asarray(m.tprobs_.todense())
+    out["msm_eq"] = np.asarray(m.eq_probs_)
+    out["msm_map"] = np.array(sorted(m.mapping_.to_original.items()))
+    np.savez_compressed(os.path.join(HERE, "trim_golden.npz"), **out)
+    print("trim_golden.npz", os.path.getsize(
+        os.path.join(HERE, "trim_golden.npz")) // 1024, "KiB")
+
+
 def main():
+    if "--only-trim" in sys.argv:
+        import_reference()
+        from enspara.msm import builders as rbuilders
+        from enspara.msm import transition_matrices as rtm
+        make_trim_golden(rtm, rbuilders)
+        return
     import_reference()
     import logging
     logging.disable(logging.CRITICAL)
@@ -273,6 +325,7 @@ def main():
     msm["implied_times"] = rts.implied_timescales(
         assigns, [1, 2, 5, 10], rbuilders.normalize, n_times=4)
     np.savez_compressed(os.path.join(HERE, "msm_golden.npz"), **msm)
+    make_trim_golden(rtm, rbuilders)
     # ---- 9. feature-space metrics: the reference's own native kernels ----------
     from enspara.geometry import libdist as rlib
     feat = {}

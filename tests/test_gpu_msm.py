@@ -136,3 +136,26 @@ def test_implied_timescales_match_reference(M):
                              builders.normalize, n_times=4)
     assert got.shape == M["implied_times"].shape
     np.testing.assert_allclose(got, M["implied_times"], rtol=1e-7)
+
+
+def test_msm_with_ergodic_trimming(golden_dir):
+    """MSM(trim=True).fit against the reference's MSM on the same assignments
+    (tests/golden/trim_golden.npz): counts exact, probabilities to 1e-12."""
+    from enspara_amd.msm import MSM, TrimMapping
+    G = np.load(os.path.join(golden_dir, "trim_golden.npz"))
+    m = MSM(lag_time=1, method="normalize", trim=True, max_n_states=40)
+    m.fit(G["assigns"])
+    np.testing.assert_array_equal(np.asarray(m.tcounts_.todense()),
+                                  G["msm_tcounts"])
+    np.testing.assert_allclose(np.asarray(m.tprobs_.todense()),
+                               G["msm_tprobs"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(m.eq_probs_, G["msm_eq"], rtol=0, atol=1e-10)
+    assert m.mapping_ == TrimMapping([(int(o), int(t))
+                                      for t, o in G["msm_map"]])
+    assert m.n_states_ == 32
+    same = MSM(lag_time=1, method="normalize", trim=True, max_n_states=40)
+    same.fit(G["assigns"])
+    assert m == same
+    other = MSM(lag_time=1, method="normalize", trim=False, max_n_states=40)
+    assert not (m == other)
+    assert other.result_ is None

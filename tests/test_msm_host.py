@@ -86,3 +86,69 @@ def test_reducible_matrix_breakdown():
     w = np.sort(np.linalg.eigvals(T.toarray().T).real)[::-1]
     np.testing.assert_allclose(vals, w[:4], atol=1e-9)
     assert abs(vals[1] - 1.0) < 1e-10          # eigenvalue 1 twice
+
+
+# ---- ergodic trimming (host-side graph work) ----------------------------------
+TRIM_ARR_TYPES = [np.array, scipy.sparse.lil_matrix, scipy.sparse.csr_matrix,
+                  scipy.sparse.coo_matrix, scipy.sparse.csc_matrix,
+                  scipy.sparse.dia_matrix, scipy.sparse.dok_matrix]
+
+
+def _dense(m):
+    return m.toarray() if hasattr(m, "toarray") else np.asarray(m)
+
+
+@pytest.mark.parametrize("arr_type", TRIM_ARR_TYPES)
+def test_trim_disconnected_known_answers(arr_type):
+    """inputs and expected outputs of the reference's own test
+    (enspara/test/test_msm_funcs.py:273-311)"""
+    from enspara_amd.msm import trim_disconnected, TrimMapping
+    given = arr_type([[1, 2, 0, 0],
+                      [2, 1, 0, 1],
+                      [0, 0, 1, 0],
+                      [0, 1, 0, 2]])
+    mapping, trimmed = trim_disconnected(given)
+    assert type(trimmed) is type(given)
+    np.testing.assert_array_equal(_dense(trimmed), [[1, 2, 0], [2, 1, 1],
+                                                    [0, 1, 2]])
+    assert mapping == TrimMapping([(0, 0), (1, 1), (3, 2)])
+    mapping, trimmed = trim_disconnected(given, threshold=2)
+    np.testing.assert_array_equal(_dense(trimmed), [[1, 2], [2, 1]])
+    assert mapping == TrimMapping([(0, 0), (1, 1)])
+
+
+def test_trim_mapping_surface(tmp_path):
+    """construction, inverse, CSV round trip (test_msm_funcs.py:26-60)"""
+    from enspara_amd.msm import TrimMapping
+    a = TrimMapping()
+    a.to_original = {0: 0, 1: 1, 2: 3, 3: 7}
+    b = TrimMapping()
+    b.to_mapped = {0: 0, 1: 1, 3: 2, 7: 3}
+    assert a == b
+    tm = TrimMapping([(0, 0), (1, -1), (2, 1), (3, 2)])
+    path = tmp_path / "m.csv"
+    tm.save(str(path))
+    assert path.read_text().split("\n") == ["original,mapped", "0,0", "1,-1",
+                                            "2,1", "3,2", ""]
+    assert TrimMapping.load(str(path)) == tm
+    assert tm == [(0, 0), (1, -1), (2, 1), (3, 2)]
+    assert not (tm == TrimMapping([(0, 0)]))
+
+
+def test_trim_disconnected_matches_reference_outputs(golden_dir):
+    """tests/golden/trim_golden.npz: outputs of the real trim_disconnected on a
+    40-state count matrix with a closed small component, a source-only and a
+    sink-only state, for three thresholds, renumbered or not."""
+    from enspara_amd.msm import trim_disconnected
+    G = np.load(os.path.join(golden_dir, "trim_golden.npz"))
+    C = scipy.sparse.coo_matrix(G["counts"])
+    for thr in (1, 2, 5):
+        for ren in (True, False):
+            key = "thr%d_ren%d" % (thr, int(ren))
+            for given in (C, C.tocsr(), G["counts"]):
+                m, tc = trim_disconnected(given, threshold=thr,
+                                          renumber_states=ren)
+                assert type(tc) is type(given)
+                np.testing.assert_array_equal(_dense(tc), G[key + "_counts"])
+                np.testing.assert_array_equal(
+                    np.array(sorted(m.to_original.items())), G[key + "_map"])
