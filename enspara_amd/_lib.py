@@ -29,6 +29,8 @@ SYMBOLS = [
     "ek_history_download", "ek_history_reset",
     "ek_spec_candidates", "ek_spec_begin", "ek_spec_round", "ek_spec_localmax",
     "ek_spec_apply", "ek_spec_round_end", "ek_spec_progress", "ek_spec_rounds",
+    "ek_spec_chain_bytes", "ek_spec_chain_rows", "ek_spec_chain_max",
+    "ek_spec_chain_apply",
     "ek_assign_nearest",
     "ek_pam_begin", "ek_pam_count_members", "ek_pam_select_member",
     "ek_pam_propose", "ek_pam_propose_member", "ek_pam_commit",
@@ -106,6 +108,10 @@ def load():
     L.ek_spec_round.argtypes = [vp, vp, i32, C.c_double]
     L.ek_spec_localmax.argtypes = [vp, vp]
     L.ek_spec_apply.argtypes = [vp, vp, i32, C.c_double]
+    L.ek_spec_chain_bytes.argtypes = [i32p, i32p]
+    L.ek_spec_chain_rows.argtypes = [vp, vp]
+    L.ek_spec_chain_max.argtypes = [vp, vp, i32, vp]
+    L.ek_spec_chain_apply.argtypes = [vp, vp, i32, C.c_double]
     L.ek_spec_round_end.argtypes = [vp, vp]
     L.ek_spec_progress.argtypes = [vp, i32p, i32p]
     L.ek_spec_rounds.argtypes = [vp, i32p]

@@ -119,6 +119,8 @@ struct ek_ctx {
     EkPlan *plan = nullptr;
     float *vecs = nullptr;       // [EK_MAX_CANDS-1][n_pad] stored distance vectors
     EkMaxHdr *hdr = nullptr;
+    EkBlockMax *pm = nullptr;    // [EK_MAX_CANDS-1][nb] per-prefix maxima (ek_chain.hip)
+    int chain = 1;               // 1: chained cheap steps, 0: one launch pair per center
     int64_t n_pad = 0;
     int32_t last_passes = 0;
 
@@ -185,6 +187,12 @@ static int ek_pick_cands(const ek_ctx *c)
 
 static int ek_spec_alloc(ek_ctx *c)
 {
+    if (!c->pm) {
+        const size_t nb = ((size_t)std::max<int64_t>(c->n, 1) + EK_BLOCK - 1) /
+                          EK_BLOCK;
+        EK_HIP(hipMalloc((void **)&c->pm,
+                         (size_t)(EK_MAX_CANDS - 1) * nb * sizeof(EkBlockMax)));
+    }
     if (!c->vecs) {
         EK_HIP(hipMalloc((void **)&c->vecs, (size_t)(EK_MAX_CANDS - 1) *
                                                 std::max<int64_t>(c->n_pad, 1) *
@@ -240,6 +248,7 @@ static int ek_free_all(ek_ctx *c)
     (void)hipFree(c->plan);
     (void)hipFree(c->vecs);
     (void)hipFree(c->hdr);
+    (void)hipFree(c->pm);
     (void)hipFree(c->ndist);
     (void)hipFree(c->nassign);
     (void)hipFree(c->amb);
@@ -386,6 +395,11 @@ extern "C" int ek_set_option(ek_ctx *c, int32_t key, int32_t value)
             return ek_fail(EK_EARG, "ek_set_option: candidates per pass must "
                                     "be -1 (auto), 1, 4 or 8");
         c->cands = value;
+        return EK_OK;
+    case 5:
+        if (value != 0 && value != 1)
+            return ek_fail(EK_EARG, "ek_set_option: chained rounds 0 or 1");
+        c->chain = value;
         return EK_OK;
     case 2:
         if (value < 0 || value > 2)
@@ -761,12 +775,26 @@ extern "C" int ek_kcenters_run(ek_ctx *c, int32_t first_label, int32_t max_new,
                                           c->stream));
                     c->samp_used++;
                 }
-                for (int j = 1; j < T; ++j) {
-                    ek_launch_localmax_check(c->blockmax, nb, c->goff,
-                                             dist_cutoff, c->plan, c->hist,
-                                             c->ctl, c->stream);
-                    ek_launch_apply(c->vecs, c->G, c->n, c->n_pad, c->A, c->dist,
-                                    c->assign, c->plan, c->blockmax, c->stream);
+                if (c->chain) {
+                    ek_launch_chain_order(nullptr, 1, c->plan, c->dist, c->vecs,
+                                          c->n, c->n_pad, c->goff, c->stream);
+                    ek_launch_chain_max(c->dist, c->vecs, c->n, c->n_pad, c->plan,
+                                        c->pm, c->stream);
+                    ek_launch_chain_decide_local(c->blockmax, c->pm, nb, c->goff,
+                                                 dist_cutoff, c->plan, c->hist,
+                                                 c->ctl, c->stream);
+                    ek_launch_chain_apply(c->vecs, c->n, c->n_pad, c->dist,
+                                          c->assign, c->plan, c->blockmax,
+                                          c->stream);
+                } else {
+                    for (int j = 1; j < T; ++j) {
+                        ek_launch_localmax_check(c->blockmax, nb, c->goff,
+                                                 dist_cutoff, c->plan, c->hist,
+                                                 c->ctl, c->stream);
+                        ek_launch_apply(c->vecs, c->G, c->n, c->n_pad, c->A,
+                                        c->dist, c->assign, c->plan, c->blockmax,
+                                        c->stream);
+                    }
                 }
                 ek_launch_pickT(c->blockmax, nb, c->tiles, c->G, c->assign, c->A, T,
                                 c->goff, c->recsT, c->ctl, c->stream);
@@ -1672,6 +1700,65 @@ extern "C" int ek_spec_apply(ek_ctx *c, const void *hdrs_all, int32_t n_hdrs,
     ek_launch_apply(c->vecs, c->G, c->n, c->n_pad, c->A, c->dist, c->assign,
                     c->plan, c->blockmax, c->stream);
     EK_CHECK_LAUNCH();
+    return EK_OK;
+}
+
+// chained form of the cheap steps (ek_chain.hip): rows -> [all-gather] -> order +
+// per-prefix maxima -> [all-gather] -> decide + apply
+extern "C" int ek_spec_chain_rows(ek_ctx *c, void *rows_out)
+{
+    if (!c || !rows_out)
+        return ek_fail(EK_EARG, "ek_spec_chain_rows: NULL argument");
+    if (!c->vecs || !c->pm)
+        return ek_fail(EK_ESTATE, "ek_spec_chain_rows: call ek_spec_begin first");
+    EK_HIP(hipSetDevice(c->device));
+    ek_launch_chain_rows(c->plan, c->dist, c->vecs, c->n, c->n_pad, c->goff,
+                         (EkChainRow *)rows_out, c->stream);
+    EK_CHECK_LAUNCH();
+    return EK_OK;
+}
+
+extern "C" int ek_spec_chain_max(ek_ctx *c, const void *rows_all, int32_t n_shards,
+                                 void *hdrs_out)
+{
+    if (!c || !rows_all || !hdrs_out || n_shards < 1)
+        return ek_fail(EK_EARG, "ek_spec_chain_max: bad argument");
+    if (!c->vecs || !c->pm)
+        return ek_fail(EK_ESTATE, "ek_spec_chain_max: call ek_spec_begin first");
+    EK_HIP(hipSetDevice(c->device));
+    const int nb = (int)((c->n + EK_BLOCK - 1) / EK_BLOCK);
+    ek_launch_chain_order((const EkChainRow *)rows_all, n_shards, c->plan, c->dist,
+                          c->vecs, c->n, c->n_pad, c->goff, c->stream);
+    ek_launch_chain_max(c->dist, c->vecs, c->n, c->n_pad, c->plan, c->pm,
+                        c->stream);
+    ek_launch_chain_localmax(c->blockmax, c->pm, nb, c->goff, c->plan,
+                             (EkMaxHdr *)hdrs_out, c->stream);
+    EK_CHECK_LAUNCH();
+    return EK_OK;
+}
+
+extern "C" int ek_spec_chain_apply(ek_ctx *c, const void *hdrs_all,
+                                   int32_t n_shards, double dist_cutoff)
+{
+    if (!c || !hdrs_all || n_shards < 1)
+        return ek_fail(EK_EARG, "ek_spec_chain_apply: bad argument");
+    if (!c->vecs || !c->pm)
+        return ek_fail(EK_ESTATE, "ek_spec_chain_apply: call ek_spec_begin first");
+    EK_HIP(hipSetDevice(c->device));
+    ek_launch_chain_decide((const EkMaxHdr *)hdrs_all, n_shards, dist_cutoff,
+                           c->plan, c->hist, c->ctl, c->stream);
+    ek_launch_chain_apply(c->vecs, c->n, c->n_pad, c->dist, c->assign, c->plan,
+                          c->blockmax, c->stream);
+    EK_CHECK_LAUNCH();
+    return EK_OK;
+}
+
+extern "C" int ek_spec_chain_bytes(int32_t *rows_bytes, int32_t *hdrs_bytes)
+{
+    if (rows_bytes)
+        *rows_bytes = (int32_t)(EK_MAX_CANDS * sizeof(EkChainRow));
+    if (hdrs_bytes)
+        *hdrs_bytes = (int32_t)(EK_MAX_CANDS * sizeof(EkMaxHdr));
     return EK_OK;
 }
 

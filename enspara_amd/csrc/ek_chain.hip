@@ -1,0 +1,497 @@
+// ek_chain.hip -- the cheap steps of a multi-candidate k-centers round, chained.
+//
+// After the pass of a round (ek_spec.hip) the shard holds the distance vectors
+// of candidates 1..T-1.  The sequential algorithm (reference
+// enspara/cluster/kcenters.py:217-231, :282, :298-306) now repeats: take the
+// first-index arg-max of the current distances; if it is a stored, unused
+// candidate, apply its vector with the next label; otherwise the round ends.
+// One launch pair (and, across GPUs, one exchange) per accepted center is what
+// that costs when done literally.  Here the whole chain is decided at once:
+//
+//  1. order   -- if every next farthest point IS a stored candidate, the order in
+//     which the candidates are taken depends only on the candidates' own current
+//     distances and their distances to one another (a (T-1) x (T-1) table read
+//     from the stored vectors): take the unused candidate with the largest
+//     current distance, lower the others' by their distance to it, repeat.
+//  2. maxima  -- one pass over the distance vectors gives, for every prefix of
+//     that order, the first-index arg-max of the state the prefix would leave.
+//  3. decide  -- walk the prefixes: the k-th candidate of the order is accepted
+//     iff the arg-max of the state before it is that candidate's frame (and the
+//     stop rules allow); the first failure ends the round.  If the true farthest
+//     point is an unused candidate it is necessarily the one step 1 presumed,
+//     so this accepts exactly what the literal loop accepts.
+//  4. apply   -- one pass applies the accepted prefix (strict <, labels in order)
+//     and leaves the per-workgroup maxima for the next round's candidate pick.
+//
+// Across shards steps 1 and 3 work on all-gathered rows / per-prefix maxima: two
+// small exchanges per round instead of one per accepted center.
+#include "ek_common.h"
+#include "ek_reduce.h"
+
+#define EK_CHAIN_THREADS 1024
+
+// ---- 1. order ---------------------------------------------------------------------
+// the rows of the candidate frames this shard owns
+__device__ __forceinline__ void ek_chain_row(const EkPlan *plan, int j,
+                                             const float *dist, const float *vecs,
+                                             int64_t n, int64_t n_pad,
+                                             int64_t global_offset,
+                                             EkChainRow *row)
+{
+    row->valid = 0;
+    row->cur = 0.f;
+    for (int u = 0; u < EK_MAX_CANDS; ++u)
+        row->d[u] = 0.f;
+    if (!plan->go || j < 1 || j >= plan->teff)
+        return;
+    const int64_t local = plan->gidx[j] - global_offset;
+    if (local < 0 || local >= n)
+        return;
+    row->valid = 1;
+    row->cur = dist[local];
+    for (int u = 1; u < plan->teff; ++u)
+        row->d[u] = vecs[(size_t)(u - 1) * n_pad + local];
+}
+
+__global__ void __launch_bounds__(EK_WAVE)
+ek_chain_rows_kernel(const EkPlan *__restrict__ plan,
+                     const float *__restrict__ dist,
+                     const float *__restrict__ vecs, int64_t n, int64_t n_pad,
+                     int64_t global_offset, EkChainRow *__restrict__ rows_out)
+{
+    const int j = threadIdx.x;
+    if (j < EK_MAX_CANDS)
+        ek_chain_row(plan, j, dist, vecs, n, n_pad, global_offset, &rows_out[j]);
+}
+
+void ek_launch_chain_rows(const EkPlan *plan, const float *dist,
+                          const float *vecs, int64_t n, int64_t n_pad,
+                          int64_t global_offset, EkChainRow *rows_out,
+                          hipStream_t s)
+{
+    hipLaunchKernelGGL(ek_chain_rows_kernel, dim3(1), dim3(EK_WAVE), 0, s, plan,
+                       dist, vecs, n, n_pad, global_offset, rows_out);
+}
+
+__global__ void __launch_bounds__(EK_WAVE)
+ek_chain_order_kernel(const EkChainRow *__restrict__ rows_all, int n_shards,
+                      EkPlan *__restrict__ plan, const float *__restrict__ dist,
+                      const float *__restrict__ vecs, int64_t n, int64_t n_pad,
+                      int64_t global_offset)
+{
+    __shared__ EkChainRow rows[EK_MAX_CANDS];
+    const int tid = threadIdx.x;
+    if (tid < EK_MAX_CANDS) {
+        if (rows_all) {                 // the owner's row among the shards'
+            rows[tid].valid = 0;
+            for (int sh = 0; sh < n_shards; ++sh) {
+                const EkChainRow *r = &rows_all[(size_t)sh * EK_MAX_CANDS + tid];
+                if (r->valid) {
+                    rows[tid] = *r;
+                    break;
+                }
+            }
+        }
+    }
+    if (!rows_all) {
+        // single shard: thread (j, u) fetches one entry of row j, all at once
+        const int j = tid / EK_MAX_CANDS, u = tid % EK_MAX_CANDS;
+        const bool live = plan->go && j >= 1 && j < plan->teff;
+        const int64_t local = live ? plan->gidx[j] - global_offset : -1;
+        const bool mine = live && local >= 0 && local < n;
+        float val = 0.f;
+        if (mine) {
+            if (u == 0)
+                val = dist[local];
+            else if (u < plan->teff)
+                val = vecs[(size_t)(u - 1) * n_pad + local];
+        }
+        if (u == 0) {
+            rows[j].cur = val;
+            rows[j].valid = mine ? 1 : 0;
+            rows[j].d[0] = 0.f;
+        } else {
+            rows[j].d[u] = val;
+        }
+    }
+    __syncthreads();
+    if (tid != 0)
+        return;
+    plan->chain_n = 0;
+    plan->napply = 0;
+    plan->chain_label0 = 0;
+    if (!plan->go)
+        return;
+    const int teff = plan->teff;
+    float cur[EK_MAX_CANDS];
+    bool open[EK_MAX_CANDS];
+    for (int j = 0; j < EK_MAX_CANDS; ++j) {
+        open[j] = j >= 1 && j < teff && rows[j].valid;
+        cur[j] = open[j] ? rows[j].cur : 0.f;
+    }
+    int cn = 0;
+    for (;;) {
+        int best = -1;
+        float bestv = 0.f;
+        long long bestg = 0;
+        for (int j = 1; j < teff; ++j) {
+            if (!open[j])
+                continue;
+            const float vj = cur[j];
+            const long long gj = plan->gidx[j];
+            if (best < 0 || vj > bestv || (vj == bestv && gj < bestg)) {
+                best = j;
+                bestv = vj;
+                bestg = gj;
+            }
+        }
+        if (best < 0)
+            break;
+        open[best] = false;
+        plan->chain[cn++] = best;
+        for (int j = 1; j < teff; ++j) {        // kcenters.py:304: strict <
+            const float dj = rows[j].d[best];
+            if (open[j] && dj < cur[j])
+                cur[j] = dj;
+        }
+    }
+    plan->chain_n = cn;
+}
+
+void ek_launch_chain_order(const EkChainRow *rows_all, int n_shards,
+                           EkPlan *plan, const float *dist, const float *vecs,
+                           int64_t n, int64_t n_pad, int64_t global_offset,
+                           hipStream_t s)
+{
+    hipLaunchKernelGGL(ek_chain_order_kernel, dim3(1), dim3(EK_WAVE), 0, s,
+                       rows_all, n_shards, plan, dist, vecs, n, n_pad,
+                       global_offset);
+}
+
+// ---- 2. maxima of the states the prefixes would leave --------------------------------
+// pm[(k - 1) * nb + workgroup] = first-index arg-max over the workgroup's frames
+// of min(dist, vec[chain[0]], .., vec[chain[k-1]]), k = 1 .. chain_n - 1.
+// (State 0, before any of them, is what the pass kernel left in blockmax.)
+__global__ void __launch_bounds__(EK_BLOCK)
+ek_chain_max_kernel(const float *__restrict__ dist,
+                    const float *__restrict__ vecs, int64_t n, int64_t n_pad,
+                    const EkPlan *__restrict__ plan, EkBlockMax *__restrict__ pm)
+{
+    __shared__ float red_v[EK_MAX_CANDS][EK_BLOCK / EK_WAVE];
+    __shared__ uint32_t red_i[EK_MAX_CANDS][EK_BLOCK / EK_WAVE];
+    const int cn = plan->chain_n;
+    if (cn <= 1)
+        return;
+    const int tid = threadIdx.x;
+    const int64_t f = (int64_t)blockIdx.x * EK_BLOCK + tid;
+    const int nb = gridDim.x;
+    // all loads first: the running minimum would otherwise serialise them
+    float run = 0.f;
+    float dv[EK_MAX_CANDS];
+#pragma unroll
+    for (int k = 1; k < EK_MAX_CANDS - 1; ++k) {
+        dv[k] = 0.f;
+        if (k < cn && f < n)
+            dv[k] = vecs[(size_t)(plan->chain[k - 1] - 1) * n_pad + f];
+    }
+    if (f < n)
+        run = dist[f];
+#pragma unroll
+    for (int k = 1; k < EK_MAX_CANDS - 1; ++k) {
+        if (k < cn) {                       // uniform
+            float v = -__builtin_inff();
+            uint32_t i = 0xffffffffu;
+            if (f < n) {
+                if (dv[k] < run)
+                    run = dv[k];
+                v = run;
+                i = (uint32_t)f;
+            }
+            ek_wave_argmax(v, i);
+            if ((tid & (EK_WAVE - 1)) == 0) {
+                red_v[k][tid / EK_WAVE] = v;
+                red_i[k][tid / EK_WAVE] = i;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid >= 1 && tid < cn) {
+        const int k = tid;
+        float v = red_v[k][0];
+        uint32_t i = red_i[k][0];
+        for (int w = 1; w < EK_BLOCK / EK_WAVE; ++w)
+            if (ek_better(red_v[k][w], red_i[k][w], v, i)) {
+                v = red_v[k][w];
+                i = red_i[k][w];
+            }
+        pm[(size_t)(k - 1) * nb + blockIdx.x].val = v;
+        pm[(size_t)(k - 1) * nb + blockIdx.x].idx = i;
+    }
+}
+
+void ek_launch_chain_max(const float *dist, const float *vecs, int64_t n,
+                         int64_t n_pad, const EkPlan *plan, EkBlockMax *pm,
+                         hipStream_t s)
+{
+    if (n <= 0)
+        return;
+    hipLaunchKernelGGL(ek_chain_max_kernel,
+                       dim3((unsigned)((n + EK_BLOCK - 1) / EK_BLOCK)),
+                       dim3(EK_BLOCK), 0, s, dist, vecs, n, n_pad, plan, pm);
+}
+
+// ---- 3. decide ----------------------------------------------------------------------
+// waves 2w and 2w+1 of the workgroup reduce state w's per-workgroup maxima;
+// the loads of a trip are issued together (the entries are independent)
+__device__ __forceinline__ void ek_chain_reduce(const EkBlockMax *blockmax,
+                                                const EkBlockMax *pm, int nb,
+                                                int cn, float *out_v,
+                                                uint32_t *out_i)
+{
+    __shared__ float half_v[2 * EK_MAX_CANDS];
+    __shared__ uint32_t half_i[2 * EK_MAX_CANDS];
+    const int tid = threadIdx.x;
+    const int wv = tid / EK_WAVE, lane = tid & (EK_WAVE - 1);
+    const int w = wv >> 1, part = wv & 1;
+    constexpr int U = 8;
+    if (w < cn) {
+        const EkBlockMax *src = (w == 0) ? blockmax : pm + (size_t)(w - 1) * nb;
+        float v = -__builtin_inff();
+        uint32_t i = 0xffffffffu;
+        for (int b0 = part * EK_WAVE + lane; b0 < nb; b0 += 2 * EK_WAVE * U) {
+            EkBlockMax m[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int b = b0 + u * 2 * EK_WAVE;
+                m[u] = src[b < nb ? b : nb - 1];
+                if (b >= nb)
+                    m[u].idx = 0xffffffffu;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (m[u].idx != 0xffffffffu && ek_better(m[u].val, m[u].idx, v, i)) {
+                    v = m[u].val;
+                    i = m[u].idx;
+                }
+        }
+        ek_wave_argmax(v, i);
+        if (lane == 0) {
+            half_v[wv] = v;
+            half_i[wv] = i;
+        }
+    }
+    __syncthreads();
+    if (tid < cn) {
+        float v = half_v[2 * tid];
+        uint32_t i = half_i[2 * tid];
+        const float v2 = half_v[2 * tid + 1];
+        const uint32_t i2 = half_i[2 * tid + 1];
+        if (i == 0xffffffffu || (i2 != 0xffffffffu && ek_better(v2, i2, v, i))) {
+            v = v2;
+            i = i2;
+        }
+        out_v[tid] = v;
+        out_i[tid] = i;
+    }
+}
+
+__global__ void __launch_bounds__(EK_CHAIN_THREADS)
+ek_chain_localmax_kernel(const EkBlockMax *__restrict__ blockmax,
+                         const EkBlockMax *__restrict__ pm, int nb,
+                         int64_t global_offset, const EkPlan *__restrict__ plan,
+                         EkMaxHdr *__restrict__ hdrs_out)
+{
+    __shared__ float sv[EK_MAX_CANDS];
+    __shared__ uint32_t si[EK_MAX_CANDS];
+    const int cn = plan->chain_n;
+    ek_chain_reduce(blockmax, pm, nb, cn, sv, si);
+    __syncthreads();
+    const int k = threadIdx.x;
+    if (k < EK_MAX_CANDS) {
+        const bool ok = k < cn && si[k] != 0xffffffffu;
+        hdrs_out[k].maxdist = ok ? sv[k] : -__builtin_inff();
+        hdrs_out[k].valid = ok ? 1 : 0;
+        hdrs_out[k].gidx = ok ? global_offset + (int64_t)si[k] : -1;
+    }
+}
+
+void ek_launch_chain_localmax(const EkBlockMax *blockmax, const EkBlockMax *pm,
+                              int nb, int64_t global_offset, const EkPlan *plan,
+                              EkMaxHdr *hdrs_out, hipStream_t s)
+{
+    hipLaunchKernelGGL(ek_chain_localmax_kernel, dim3(1), dim3(EK_CHAIN_THREADS),
+                       0, s, blockmax, pm, nb, global_offset, plan, hdrs_out);
+}
+
+// state k's global maximum is (v[k], g[k]) (ok[k] false: no frames anywhere)
+__device__ __forceinline__ void ek_chain_walk(const float *v, const long long *g,
+                                              const bool *ok, double cutoff,
+                                              EkPlan *plan, EkHist *hist,
+                                              EkCtl *ctl)
+{
+    const int cn = plan->chain_n;
+    int napply = 0;
+    plan->chain_label0 = ctl->n_done;
+    for (int k = 0; k < cn; ++k) {
+        if (ctl->stopped || ctl->n_done >= ctl->limit || !ok[k])
+            break;
+        ctl->last_max = v[k];
+        if (!((double)v[k] > cutoff)) {     // kcenters.py:217
+            ctl->stopped = 1;
+            break;
+        }
+        const int j = plan->chain[k];
+        if (g[k] != plan->gidx[j])
+            break;                          // the farthest point is not stored
+        const int label = ctl->n_done;
+        hist[label].gidx = g[k];
+        hist[label].dist = v[k];
+        hist[label].set = 1;
+        ctl->n_done = label + 1;
+        plan->used |= 1u << j;
+        ++napply;
+    }
+    plan->napply = napply;
+}
+
+__global__ void __launch_bounds__(EK_WAVE)
+ek_chain_decide_kernel(const EkMaxHdr *__restrict__ hdrs_all, int n_shards,
+                       double cutoff, EkPlan *__restrict__ plan,
+                       EkHist *__restrict__ hist, EkCtl *__restrict__ ctl)
+{
+    if (threadIdx.x != 0)
+        return;
+    plan->napply = 0;
+    if (!plan->go)
+        return;
+    float v[EK_MAX_CANDS];
+    long long g[EK_MAX_CANDS];
+    bool ok[EK_MAX_CANDS];
+    for (int k = 0; k < EK_MAX_CANDS; ++k) {
+        ok[k] = false;
+        v[k] = 0.f;
+        g[k] = 0;
+        for (int sh = 0; sh < n_shards; ++sh) {   // largest, lowest index on ties
+            const EkMaxHdr h = hdrs_all[(size_t)sh * EK_MAX_CANDS + k];
+            if (!h.valid)
+                continue;
+            if (!ok[k] || h.maxdist > v[k] ||
+                (h.maxdist == v[k] && h.gidx < g[k])) {
+                ok[k] = true;
+                v[k] = h.maxdist;
+                g[k] = h.gidx;
+            }
+        }
+    }
+    ek_chain_walk(v, g, ok, cutoff, plan, hist, ctl);
+}
+
+void ek_launch_chain_decide(const EkMaxHdr *hdrs_all, int n_shards, double cutoff,
+                            EkPlan *plan, EkHist *hist, EkCtl *ctl, hipStream_t s)
+{
+    hipLaunchKernelGGL(ek_chain_decide_kernel, dim3(1), dim3(EK_WAVE), 0, s,
+                       hdrs_all, n_shards, cutoff, plan, hist, ctl);
+}
+
+__global__ void __launch_bounds__(EK_CHAIN_THREADS)
+ek_chain_decide_local_kernel(const EkBlockMax *__restrict__ blockmax,
+                             const EkBlockMax *__restrict__ pm, int nb,
+                             int64_t global_offset, double cutoff,
+                             EkPlan *__restrict__ plan, EkHist *__restrict__ hist,
+                             EkCtl *__restrict__ ctl)
+{
+    __shared__ float sv[EK_MAX_CANDS];
+    __shared__ uint32_t si[EK_MAX_CANDS];
+    if (!plan->go) {
+        if (threadIdx.x == 0)
+            plan->napply = 0;
+        return;
+    }
+    const int cn = plan->chain_n;
+    ek_chain_reduce(blockmax, pm, nb, cn, sv, si);
+    __syncthreads();
+    if (threadIdx.x != 0)
+        return;
+    float v[EK_MAX_CANDS];
+    long long g[EK_MAX_CANDS];
+    bool ok[EK_MAX_CANDS];
+    for (int k = 0; k < EK_MAX_CANDS; ++k) {
+        ok[k] = k < cn && si[k] != 0xffffffffu;
+        v[k] = ok[k] ? sv[k] : 0.f;
+        g[k] = ok[k] ? global_offset + (long long)si[k] : -1;
+    }
+    ek_chain_walk(v, g, ok, cutoff, plan, hist, ctl);
+}
+
+void ek_launch_chain_decide_local(const EkBlockMax *blockmax, const EkBlockMax *pm,
+                                  int nb, int64_t global_offset, double cutoff,
+                                  EkPlan *plan, EkHist *hist, EkCtl *ctl,
+                                  hipStream_t s)
+{
+    hipLaunchKernelGGL(ek_chain_decide_local_kernel, dim3(1),
+                       dim3(EK_CHAIN_THREADS), 0, s, blockmax, pm, nb,
+                       global_offset, cutoff, plan, hist, ctl);
+}
+
+// ---- 4. apply the accepted prefix -----------------------------------------------------
+__global__ void __launch_bounds__(EK_BLOCK)
+ek_chain_apply_kernel(const float *__restrict__ vecs, int64_t n, int64_t n_pad,
+                      float *__restrict__ dist, int32_t *__restrict__ assign,
+                      const EkPlan *__restrict__ plan,
+                      EkBlockMax *__restrict__ blockmax)
+{
+    __shared__ float red_v[EK_BLOCK / EK_WAVE];
+    __shared__ uint32_t red_i[EK_BLOCK / EK_WAVE];
+    const int na = plan->napply;
+    if (na < 1)
+        return;                 // blockmax still describes the state
+    const int label0 = plan->chain_label0;
+    const int tid = threadIdx.x;
+    const int64_t f = (int64_t)blockIdx.x * EK_BLOCK + tid;
+    float v = -__builtin_inff();
+    uint32_t i = 0xffffffffu;
+    if (f < n) {
+        float cur = dist[f];
+        int32_t lab = -1;
+        for (int k = 0; k < na; ++k) {      // kcenters.py:304-306, in order
+            const float d = vecs[(size_t)(plan->chain[k] - 1) * n_pad + f];
+            if (d < cur) {
+                cur = d;
+                lab = label0 + k;
+            }
+        }
+        if (lab >= 0) {
+            dist[f] = cur;
+            assign[f] = lab;
+        }
+        v = cur;
+        i = (uint32_t)f;
+    }
+    ek_wave_argmax(v, i);
+    if ((tid & (EK_WAVE - 1)) == 0) {
+        red_v[tid / EK_WAVE] = v;
+        red_i[tid / EK_WAVE] = i;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < EK_BLOCK / EK_WAVE; ++w)
+            if (ek_better(red_v[w], red_i[w], v, i)) {
+                v = red_v[w];
+                i = red_i[w];
+            }
+        blockmax[blockIdx.x].val = v;
+        blockmax[blockIdx.x].idx = i;
+    }
+}
+
+void ek_launch_chain_apply(const float *vecs, int64_t n, int64_t n_pad, float *dist,
+                           int32_t *assign, const EkPlan *plan,
+                           EkBlockMax *blockmax, hipStream_t s)
+{
+    if (n <= 0)
+        return;
+    hipLaunchKernelGGL(ek_chain_apply_kernel,
+                       dim3((unsigned)((n + EK_BLOCK - 1) / EK_BLOCK)),
+                       dim3(EK_BLOCK), 0, s, vecs, n, n_pad, dist, assign, plan,
+                       blockmax);
+}

@@ -73,7 +73,24 @@ struct EkPlan {
     int64_t gidx[EK_MAX_CANDS];
     float maxdist[EK_MAX_CANDS];
     double trace[EK_MAX_CANDS];
+    // chained rounds (ek_chain.hip): the order in which candidates 1.. would be
+    // accepted if each next farthest point is a stored candidate, how many of
+    // them really were, and the label of the first
+    int32_t chain_n;
+    int32_t napply;
+    int32_t chain_label0;
+    int32_t pad2;
+    int32_t chain[EK_MAX_CANDS];
 };
+
+// one candidate frame as seen by the shard that owns it: its current distance
+// and its distance to every candidate of the round (ek_chain.hip)
+struct EkChainRow {
+    float cur;
+    int32_t valid;
+    float d[EK_MAX_CANDS];
+};
+static_assert(sizeof(EkChainRow) == 40, "EkChainRow layout");
 
 // ---- kernel launchers (defined in the .hip files) ---------------------------
 // centring + trace + frame-minor transposition of `count` AoS frames
@@ -191,6 +208,37 @@ void ek_launch_pass(int T, const float *tiles, const double *G, float *dist,
 void ek_launch_pass_dist(int count, const float *tiles, const double *G,
                          float *vecs, int64_t n, int64_t n_pad, int A,
                          const unsigned char *recs, EkPlan *plan, hipStream_t s);
+// ---- chained rounds (ek_chain.hip) --------------------------------------------------
+// rows_out[EK_MAX_CANDS]: this shard's view of the candidate frames it owns
+void ek_launch_chain_rows(const EkPlan *plan, const float *dist,
+                          const float *vecs, int64_t n, int64_t n_pad,
+                          int64_t global_offset, EkChainRow *rows_out,
+                          hipStream_t s);
+// presumed acceptance order from all shards' rows; rows_all == nullptr: single
+// shard, the rows are computed in place
+void ek_launch_chain_order(const EkChainRow *rows_all, int n_shards,
+                           EkPlan *plan, const float *dist, const float *vecs,
+                           int64_t n, int64_t n_pad, int64_t global_offset,
+                           hipStream_t s);
+// per-workgroup maxima of the states after applying chain[0..k-1], k = 1..
+void ek_launch_chain_max(const float *dist, const float *vecs, int64_t n,
+                         int64_t n_pad, const EkPlan *plan, EkBlockMax *pm,
+                         hipStream_t s);
+// this shard's (max, global index) for each of those states -> hdrs_out[8]
+void ek_launch_chain_localmax(const EkBlockMax *blockmax, const EkBlockMax *pm,
+                              int nb, int64_t global_offset, const EkPlan *plan,
+                              EkMaxHdr *hdrs_out, hipStream_t s);
+// accept the longest verified prefix of the chain (hdrs_all[shard][8])
+void ek_launch_chain_decide(const EkMaxHdr *hdrs_all, int n_shards, double cutoff,
+                            EkPlan *plan, EkHist *hist, EkCtl *ctl, hipStream_t s);
+// single shard: the two above in one launch
+void ek_launch_chain_decide_local(const EkBlockMax *blockmax, const EkBlockMax *pm,
+                                  int nb, int64_t global_offset, double cutoff,
+                                  EkPlan *plan, EkHist *hist, EkCtl *ctl,
+                                  hipStream_t s);
+void ek_launch_chain_apply(const float *vecs, int64_t n, int64_t n_pad, float *dist,
+                           int32_t *assign, const EkPlan *plan,
+                           EkBlockMax *blockmax, hipStream_t s);
 void ek_launch_blockmax(const float *dist, int64_t n, EkBlockMax *blockmax,
                         hipStream_t s);
 void ek_launch_localmax(const EkBlockMax *blockmax, int nb,

@@ -881,34 +881,28 @@ ek_pickT_kernel(const EkBlockMax *__restrict__ blockmax, int nb,
     }
     if (tid == 0)
         ctl->last_max = (ns > 0) ? sel_v[0] : -__builtin_inff();
-    // the gathers: every read is its own cache line, so each thread issues a
-    // batch of them before it touches any result
-    constexpr int GB = 8;
-    const int total = ns * 3 * A;
-    for (int k0 = 0; k0 < total; k0 += GB * EK_RED_THREADS) {
-        float val[GB];
-#pragma unroll
-        for (int u = 0; u < GB; ++u) {
-            int k = k0 + u * EK_RED_THREADS + tid;
-            k = (k < total) ? k : total - 1;
-            const int j = k / (3 * A), r = k % (3 * A);
-            const uint32_t i = sel_i[j];
-            const float *p = tiles +
-                             (size_t)(i / EK_TILE) * 3 * (size_t)A * EK_TILE +
-                             (i % EK_TILE);
-            val[u] = p[(size_t)r * EK_TILE];
-        }
-#pragma unroll
-        for (int u = 0; u < GB; ++u) {
-            const int k = k0 + u * EK_RED_THREADS + tid;
-            if (k < total) {
-                const int j = k / (3 * A), r = k % (3 * A);
-                float *coords =
-                    (float *)(recs + (size_t)j * rstride + sizeof(EkRecHdr));
-                coords[r] = val[u];
-            }
-        }
-    }
+}
+
+// the candidates' coordinates: every read is its own cache line, so they are
+// spread over many workgroups (one thread per value) instead of being queued
+// behind the selection in its single workgroup
+__global__ void __launch_bounds__(EK_BLOCK)
+ek_record_gather_kernel(const float *__restrict__ tiles, int A,
+                        int64_t global_offset, unsigned char *__restrict__ recs)
+{
+    const size_t rstride = ek_rec_bytes(A);
+    const int j = blockIdx.y;
+    const EkRecHdr *h = (const EkRecHdr *)(recs + (size_t)j * rstride);
+    if (!h->valid)
+        return;
+    const int r = blockIdx.x * EK_BLOCK + threadIdx.x;
+    if (r >= 3 * A)
+        return;
+    const int64_t i = h->gidx - global_offset;
+    const float *p = tiles + (size_t)(i / EK_TILE) * 3 * (size_t)A * EK_TILE +
+                     (i % EK_TILE);
+    float *coords = (float *)(recs + (size_t)j * rstride + sizeof(EkRecHdr));
+    coords[r] = p[(size_t)r * EK_TILE];
 }
 
 void ek_launch_pickT(const EkBlockMax *blockmax, int nb, const float *tiles,
@@ -920,4 +914,8 @@ void ek_launch_pickT(const EkBlockMax *blockmax, int nb, const float *tiles,
     hipLaunchKernelGGL(ek_pickT_kernel, dim3(1), dim3(EK_RED_THREADS), lds, s,
                        blockmax, nb, tiles, G, assign, A, T, global_offset, recs,
                        ctl);
+    hipLaunchKernelGGL(ek_record_gather_kernel,
+                       dim3((unsigned)((3 * A + EK_BLOCK - 1) / EK_BLOCK),
+                            (unsigned)T),
+                       dim3(EK_BLOCK), 0, s, tiles, A, global_offset, recs);
 }

@@ -301,6 +301,26 @@ class FrameStore:
             self._h, C.c_void_p(int(hdrs_all_ptr)), int(n_hdrs),
             float(dist_cutoff)))
 
+    def spec_chain_bytes(self):
+        """-> (bytes of a shard's candidate rows, of its per-prefix headers)"""
+        a, b = C.c_int32(), C.c_int32()
+        _lib.check(self.lib.ek_spec_chain_bytes(C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def spec_chain_rows(self, rows_out_ptr):
+        _lib.check(self.lib.ek_spec_chain_rows(
+            self._h, C.c_void_p(int(rows_out_ptr))))
+
+    def spec_chain_max(self, rows_all_ptr, n_shards, hdrs_out_ptr):
+        _lib.check(self.lib.ek_spec_chain_max(
+            self._h, C.c_void_p(int(rows_all_ptr)), int(n_shards),
+            C.c_void_p(int(hdrs_out_ptr))))
+
+    def spec_chain_apply(self, hdrs_all_ptr, n_shards, dist_cutoff):
+        _lib.check(self.lib.ek_spec_chain_apply(
+            self._h, C.c_void_p(int(hdrs_all_ptr)), int(n_shards),
+            float(dist_cutoff)))
+
     def spec_round_end(self, recs_out_ptr):
         _lib.check(self.lib.ek_spec_round_end(self._h,
                                               C.c_void_p(int(recs_out_ptr))))

@@ -78,6 +78,20 @@ class DeviceShard:
     def spec_apply(self, hdrs_all, n_hdrs, cutoff):
         self.store.spec_apply(hdrs_all.data_ptr(), n_hdrs, cutoff)
 
+    # chained cheap steps (csrc/ek_chain.hip)
+    def spec_chain_bytes(self):
+        return self.store.spec_chain_bytes()
+
+    def spec_chain_rows(self, rows):
+        self.store.spec_chain_rows(rows.data_ptr())
+
+    def spec_chain_max(self, rows_all, n_shards, hdrs):
+        self.store.spec_chain_max(rows_all.data_ptr(), n_shards,
+                                  hdrs.data_ptr())
+
+    def spec_chain_apply(self, hdrs_all, n_shards, cutoff):
+        self.store.spec_chain_apply(hdrs_all.data_ptr(), n_shards, cutoff)
+
     def spec_round_end(self, recs):
         self.store.spec_round_end(recs.data_ptr())
 
@@ -226,12 +240,14 @@ def kcenters_sharded(shard, first_label, max_new, dist_cutoff=0.0, group=None,
 
 def _kcenters_sharded_rounds(shard, first_label, max_new, dist_cutoff, group,
                              fresh, world, T, collective):
-    """Multi-candidate rounds (csrc/ek_spec.hip) across ranks.  Messages:
-    per round one all-gather of T candidate records per rank; per accepted
-    center one all-gather of a 16-byte (max distance, global index) header per
-    rank -- the same information the reference exchanges per iteration
-    (kcenters.py:332-335), while the frame Bcast (:345) is paid once per round
-    instead of once per center."""
+    """Multi-candidate rounds (csrc/ek_spec.hip) across ranks.  Messages per
+    round: one all-gather of T candidate records per rank, then -- chained
+    cheap steps, csrc/ek_chain.hip -- one all-gather of each rank's view of
+    the candidate frames it owns (320 B) and one of its per-prefix (max
+    distance, global index) headers (128 B): three exchanges per round of
+    ~6 centers, against the reference's two allgathers + Bcast + allreduce per
+    center (kcenters.py:332-348).  A shard without the chained entry points
+    falls back to one 16-byte header all-gather per accepted center."""
     import torch.distributed as dist
     rb = shard.record_bytes
     recs_mine = shard.new_buffer(rb * T)
@@ -239,6 +255,13 @@ def _kcenters_sharded_rounds(shard, first_label, max_new, dist_cutoff, group,
     hdr_mine = shard.new_buffer(16)
     hdr_all = shard.new_buffer(16 * world) if collective else hdr_mine
     limit = first_label + max_new
+    chained = hasattr(shard, "spec_chain_rows")
+    if chained:
+        rows_b, hdrs_b = shard.spec_chain_bytes()
+        rows_mine = shard.new_buffer(rows_b)
+        rows_all = shard.new_buffer(rows_b * world) if collective else rows_mine
+        chdr_mine = shard.new_buffer(hdrs_b)
+        chdr_all = shard.new_buffer(hdrs_b * world) if collective else chdr_mine
     if fresh:
         shard.reset_history()
     shard.spec_begin(first_label, limit, recs_mine)
@@ -251,11 +274,23 @@ def _kcenters_sharded_rounds(shard, first_label, max_new, dist_cutoff, group,
             if collective:
                 dist.all_gather_into_tensor(recs_all, recs_mine, group=group)
             shard.spec_round(recs_all, world * T, float(dist_cutoff))
-            for _j in range(1, T):
-                shard.spec_localmax(hdr_mine)
+            if chained:
+                shard.spec_chain_rows(rows_mine)
                 if collective:
-                    dist.all_gather_into_tensor(hdr_all, hdr_mine, group=group)
-                shard.spec_apply(hdr_all, world, float(dist_cutoff))
+                    dist.all_gather_into_tensor(rows_all, rows_mine,
+                                                group=group)
+                shard.spec_chain_max(rows_all, world, chdr_mine)
+                if collective:
+                    dist.all_gather_into_tensor(chdr_all, chdr_mine,
+                                                group=group)
+                shard.spec_chain_apply(chdr_all, world, float(dist_cutoff))
+            else:
+                for _j in range(1, T):
+                    shard.spec_localmax(hdr_mine)
+                    if collective:
+                        dist.all_gather_into_tensor(hdr_all, hdr_mine,
+                                                    group=group)
+                    shard.spec_apply(hdr_all, world, float(dist_cutoff))
             shard.spec_round_end(recs_mine)
         n_done, stopped = shard.spec_progress()
         if stopped or n_done >= limit:

@@ -157,6 +157,33 @@ int ek_spec_apply(ek_ctx *ctx, const void *hdrs_all, int32_t n_hdrs,
                   double dist_cutoff);
 int ek_spec_round_end(ek_ctx *ctx, void *recs_out);
 int ek_spec_progress(ek_ctx *ctx, int32_t *n_done, int32_t *stopped);
+/*
+ * The cheap steps of a round can also be taken all at once ("chained",
+ * csrc/ek_chain.hip): between ek_spec_round and ek_spec_round_end, instead of
+ * up to T-1 times (ek_spec_localmax, all-gather, ek_spec_apply),
+ *   ek_spec_chain_rows(ctx, my_rows)      this shard's view of the candidate
+ *                                         frames it owns: current distance and
+ *                                         distance to every candidate
+ *   all-gather my_rows -> all_rows        (rows_bytes per shard)
+ *   ek_spec_chain_max(ctx, all_rows, n_shards, my_hdrs)
+ *                                         the order in which the candidates
+ *                                         would be accepted, and this shard's
+ *                                         (max distance, global index) of the
+ *                                         state each prefix of it would leave
+ *   all-gather my_hdrs -> all_hdrs        (hdrs_bytes per shard)
+ *   ek_spec_chain_apply(ctx, all_hdrs, n_shards, dist_cutoff)
+ *                                         accept the longest prefix whose every
+ *                                         member is the farthest point when its
+ *                                         turn comes, and apply it
+ * -- two exchanges per round instead of one per accepted center, same centers,
+ * labels and distances.  Buffers are device memory; ek_spec_chain_bytes gives
+ * their per-shard sizes (320 and 128 bytes). */
+int ek_spec_chain_bytes(int32_t *rows_bytes, int32_t *hdrs_bytes);
+int ek_spec_chain_rows(ek_ctx *ctx, void *rows_out);
+int ek_spec_chain_max(ek_ctx *ctx, const void *rows_all, int32_t n_shards,
+                      void *hdrs_out);
+int ek_spec_chain_apply(ek_ctx *ctx, const void *hdrs_all, int32_t n_shards,
+                        double dist_cutoff);
 /* rounds (passes over the frames) that really ran since ek_spec_begin /
  * ek_kcenters_run started */
 int ek_spec_rounds(ek_ctx *ctx, int32_t *rounds);
@@ -357,7 +384,9 @@ int ek_set_frames_per_lane(ek_ctx *ctx, int fpl);
  * key 4: candidate centers per pass of ek_kcenters_run / ek_spec_*: -1
  * automatic (8, fewer for very large atom counts), 1 = one-center passes, 4, 8
  * key 2: nearest-center kernel: 0 automatic, 1 vector FMA, 2 MFMA (identical
- * results) */
+ * results)
+ * key 5: cheap steps of a round in ek_kcenters_run: 1 chained (default), 0 one
+ * launch pair per accepted center (identical results) */
 int ek_set_option(ek_ctx *ctx, int32_t key, int32_t value);
 /* time of the last ek_kcenters_run loop measured with HIP events on the
  * context's stream, milliseconds, and the number of distance-kernel launches

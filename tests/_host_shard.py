@@ -325,3 +325,82 @@ class HostShardRounds(HostShard):
 
     def spec_progress(self):
         return self.n_done, self.stopped
+
+
+CHAIN_ROW = np.dtype([("cur", "<f4"), ("valid", "<i4"), ("d", "<f4", (8,))])
+assert CHAIN_ROW.itemsize == 40
+
+
+class HostShardChain(HostShardRounds):
+    """HostShardRounds plus the chained cheap steps (ek_spec_chain_rows / _max
+    / _apply): same record and header layouts as the device."""
+
+    def spec_chain_bytes(self):
+        return 8 * CHAIN_ROW.itemsize, 8 * MAXHDR.itemsize
+
+    def spec_chain_rows(self, rows):
+        r = np.zeros(8, dtype=CHAIN_ROW)
+        if self.plan is not None:
+            cands = self.plan["cands"]
+            for j in range(1, len(cands)):
+                local = cands[j]["gidx"] - self.offset
+                if 0 <= local < self.n:
+                    r[j]["valid"] = 1
+                    r[j]["cur"] = self.dist[local]
+                    for u in range(1, len(cands)):
+                        r[j]["d"][u] = cands[u]["vec"][local]
+        rows.numpy()[:r.nbytes] = r.view(np.uint8)
+
+    def spec_chain_max(self, rows_all, n_shards, hdrs):
+        out = np.zeros(8, dtype=MAXHDR)
+        out["maxdist"], out["gidx"] = -np.inf, -1
+        if self.plan is not None:
+            cands = self.plan["cands"]
+            allr = rows_all.numpy()[:n_shards * 8 * CHAIN_ROW.itemsize].view(
+                CHAIN_ROW).reshape(n_shards, 8)
+            row = {}
+            for j in range(1, len(cands)):
+                for s in range(n_shards):
+                    if allr[s, j]["valid"]:
+                        row[j] = allr[s, j]
+                        break
+            cur = {j: np.float32(row[j]["cur"]) for j in row}
+            chain = []
+            while cur:
+                best = sorted(cur, key=lambda j: (-float(cur[j]),
+                                                  cands[j]["gidx"]))[0]
+                chain.append(best)
+                del cur[best]
+                for j in cur:
+                    d = np.float32(row[j]["d"][best])
+                    if d < cur[j]:
+                        cur[j] = d
+            self.plan["chain"] = chain
+            if self.n:
+                run = self.dist.copy()
+                for k in range(len(chain)):
+                    if k > 0:
+                        run = np.minimum(run, cands[chain[k - 1]]["vec"])
+                    i = int(np.argmax(run))
+                    out[k]["maxdist"], out[k]["valid"] = run[i], 1
+                    out[k]["gidx"] = self.offset + i
+        hdrs.numpy()[:out.nbytes] = out.view(np.uint8)
+
+    def spec_chain_apply(self, hdrs_all, n_shards, cutoff):
+        if self.plan is None:
+            return
+        cands = self.plan["cands"]
+        allh = hdrs_all.numpy()[:n_shards * 8 * MAXHDR.itemsize].view(
+            MAXHDR).reshape(n_shards, 8)
+        for k, j in enumerate(self.plan.get("chain", [])):
+            hs = [h for h in allh[:, k] if h["valid"]]
+            if self.stopped or self.n_done >= self.limit or not hs:
+                break
+            hs.sort(key=lambda h: (-float(h["maxdist"]), int(h["gidx"])))
+            w = hs[0]
+            if not (float(w["maxdist"]) > cutoff):
+                self.stopped = True
+                break
+            if int(w["gidx"]) != cands[j]["gidx"]:
+                break
+            self._accept(cands[j], float(w["maxdist"]))

@@ -177,7 +177,8 @@ def test_assign_variants_bit_identical(qcp, n, A, K):
 
 
 @pytest.mark.parametrize("cands", [1, 4, 8])
-def test_candidates_per_pass_do_not_change_results(ocl, cands):
+@pytest.mark.parametrize("chain", [1, 0])
+def test_candidates_per_pass_do_not_change_results(ocl, cands, chain):
     """multi-candidate rounds are the same algorithm: identical centers,
     labels and distances whatever the number of candidates per pass"""
     from enspara_amd.cluster import kcenters as kc
@@ -185,6 +186,7 @@ def test_candidates_per_pass_do_not_change_results(ocl, cands):
     inds, a, d = ocl.kcenters(x, n_clusters=120)
     with _store(x) as st:
         st.set_option(4, cands)
+        st.set_option(5, chain)       # chained or one-by-one cheap steps
         r = kc._kcenters_device(x, 120, 0, None, 0, store=st)
     assert list(r.center_indices) == [int(i) for i in inds]
     np.testing.assert_array_equal(r.assignments, a)
@@ -193,6 +195,7 @@ def test_candidates_per_pass_do_not_change_results(ocl, cands):
     inds, a, d = ocl.kcenters(x, dist_cutoff=0.4)
     with _store(x) as st:
         st.set_option(4, cands)
+        st.set_option(5, chain)
         r = kc._kcenters_device(x, np.inf, 0.4, None, 0, store=st)
     assert list(r.center_indices) == [int(i) for i in inds]
     np.testing.assert_array_equal(r.assignments, a)
@@ -201,6 +204,7 @@ def test_candidates_per_pass_do_not_change_results(ocl, cands):
     inds, a, d = ocl.kcenters(x, n_clusters=31, init_centers=init)
     with _store(x) as st:
         st.set_option(4, cands)
+        st.set_option(5, chain)
         r = kc._kcenters_device(x, 31, 0, init, 0, store=st)
     assert list(r.center_indices) == [int(i) for i in inds]
     np.testing.assert_array_equal(r.assignments, a)

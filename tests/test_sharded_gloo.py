@@ -26,18 +26,19 @@ def _free_port():
 
 
 def _worker(rank, world, port, n, A, seed, n_clusters, cutoff, outdir,
-            cands=1):
+            cands=1, chain=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["OMP_NUM_THREADS"] = "2"
     from enspara_amd import sharded, synth
-    from _host_shard import HostShard, HostShardRounds
+    from _host_shard import HostShard, HostShardRounds, HostShardChain
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port,
                             rank=rank, world_size=world)
     x = synth.synth(n, A, 9, seed=seed)
     lo, cnt = sharded.shard_bounds(n, world, rank)
     shard = (HostShard(x[lo:lo + cnt], lo) if cands == 1 else
-             HostShardRounds(x[lo:lo + cnt], lo, cands))
+             (HostShardChain if chain else HostShardRounds)(
+                 x[lo:lo + cnt], lo, cands))
     max_new = n_clusters if n_clusters else n
     idx, cd = sharded.kcenters_sharded(shard, 0, max_new, cutoff,
                                        check_every=4)
@@ -47,12 +48,13 @@ def _worker(rank, world, port, n, A, seed, n_clusters, cutoff, outdir,
     dist.destroy_process_group()
 
 
-def _run(world, n, A, seed, n_clusters, cutoff, cands=1):
+def _run(world, n, A, seed, n_clusters, cutoff, cands=1, chain=False):
     from oracle import cluster as oc
     from enspara_amd import synth
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_worker, args=(world, _free_port(), n, A, seed, n_clusters,
-                                cutoff, d, cands), nprocs=world, join=True)
+                                cutoff, d, cands, chain), nprocs=world,
+                 join=True)
         parts = [np.load(os.path.join(d, "r%d.npz" % r)) for r in range(world)]
     x = synth.synth(n, A, 9, seed=seed)
     inds, a, dd = oc.kcenters(x, n_clusters=n_clusters,
@@ -97,6 +99,21 @@ def test_three_ranks_one_empty_multi_candidate():
     assert len(inds) == 9
 
 
+def test_two_ranks_chained_rounds():
+    inds = _run(2, 1500, 20, 5, 23, 0.0, cands=8, chain=True)
+    assert len(inds) == 23
+
+
+def test_two_ranks_chained_rounds_cutoff():
+    inds = _run(2, 1200, 15, 6, None, 0.45, cands=8, chain=True)
+    assert len(inds) > 2
+
+
+def test_three_ranks_one_empty_chained_rounds():
+    inds = _run(3, 500, 10, 7, 9, 0.0, cands=4, chain=True)
+    assert len(inds) == 9
+
+
 def test_shard_bounds():
     from enspara_amd.sharded import shard_bounds
     for n, w in [(1000, 2), (1_000_000, 8), (255, 4), (256 * 7 + 3, 3)]:
@@ -110,12 +127,13 @@ def test_shard_bounds():
 
 def test_single_process_without_process_group():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from _host_shard import HostShard, HostShardRounds
+    from _host_shard import HostShard, HostShardRounds, HostShardChain
     from enspara_amd import sharded, synth
     from oracle import cluster as oc
     x = synth.synth(700, 12, 5, seed=2)
     inds, a, d = oc.kcenters(x, n_clusters=8)
-    for sh in (HostShard(x, 0), HostShardRounds(x, 0, 4)):
+    for sh in (HostShard(x, 0), HostShardRounds(x, 0, 4),
+               HostShardChain(x, 0, 8)):
         idx, cd = sharded.kcenters_sharded(sh, 0, 8, 0.0)
         np.testing.assert_array_equal(idx, np.array(inds))
         np.testing.assert_array_equal(sh.assign, a)
