@@ -109,6 +109,9 @@ struct ek_ctx {
     int64_t pf_frames[EK_MAX_CANDS];
     int32_t pf_count = 0;
     bool pf_external = false;        // slots hold caller-supplied centers
+    EkPamOut *pam_out_dev = nullptr; // result record of a proposal
+    EkPamOut *pam_out_host = nullptr;    // pinned copy the host polls for
+    int32_t pam_restore = -1;        // row of the trial table a rejected proposal left
     int64_t *tmp_idx = nullptr;      // scratch for index lists
     int64_t tmp_idx_cap = 0;
     int64_t pf_hits = 0, pf_misses = 0;
@@ -244,6 +247,9 @@ static int ek_free_all(ek_ctx *c)
     (void)hipFree(c->pam_plan);
     (void)hipFree(c->moved);
     (void)hipFree(c->tmp_idx);
+    (void)hipFree(c->pam_out_dev);
+    if (c->pam_out_host)
+        (void)hipHostFree(c->pam_out_host);
     (void)hipFree(c->recsT);
     (void)hipFree(c->plan);
     (void)hipFree(c->vecs);
@@ -1005,7 +1011,11 @@ static int ek_pam_alloc(ek_ctx *c, int32_t K)
                          2 * EK_MAX_CANDS * sizeof(int64_t)));
         EK_HIP(hipMalloc((void **)&c->moved, sizeof(unsigned int)));
         EK_HIP(hipMemsetAsync(c->moved, 0, sizeof(unsigned int), c->stream));
+        EK_HIP(hipMalloc((void **)&c->pam_out_dev, sizeof(EkPamOut)));
+        EK_HIP(hipHostMalloc((void **)&c->pam_out_host, sizeof(EkPamOut),
+                             hipHostMallocDefault));
     }
+    c->pam_restore = -1;
     c->bat_cid0 = -1;
     c->bat_count = 0;
     c->pf_count = 0;
@@ -1161,30 +1171,16 @@ extern "C" int ek_pam_select_member(ek_ctx *c, int32_t cid, int64_t j,
 }
 
 // Everything of a proposal after the distance vector `newd` is known and the
-// trial medoid table holds the proposal in row cid: classification, the
-// ambiguous subset against all medoids, both cost sums and (optionally) the
-// moved-cluster mask.  No read-back.  max_amb bounds the ambiguous set (a
-// subset of cluster cid's members) and sizes the follow-up launches.
+// trial medoid table holds the proposal in row cid (ek_pam_trial_kernel, which
+// also clears the counters): classification, the ambiguous subset against all
+// medoids, both cost sums and the moved-cluster mask, packed into *out (device).
+// No read-back.  max_amb bounds the ambiguous set (a subset of cluster cid's
+// members) and sizes the follow-up launches.
 static int ek_pam_tail(ek_ctx *c, int32_t cid, const float *newd,
                        int64_t max_amb, int32_t win_lo, int32_t win_count,
-                       bool want_moved)
+                       EkPamOut *out)
 {
     const int K = c->med_K;
-    if (max_amb > c->ambt_cap) {
-        EK_HIP(ek_wait(c));
-        (void)hipFree(c->ambt);
-        (void)hipFree(c->ambG);
-        c->ambt = nullptr;
-        c->ambG = nullptr;
-        c->ambt_cap = 0;
-        const int64_t cap = std::max<int64_t>(
-            4096, (max_amb * 5 / 4 + EK_BLOCK - 1) / EK_BLOCK * EK_BLOCK);
-        EK_HIP(hipMalloc((void **)&c->ambt,
-                         (size_t)cap * 3 * c->A * sizeof(float)));
-        EK_HIP(hipMalloc((void **)&c->ambG, (size_t)cap * sizeof(double)));
-        c->ambt_cap = cap;
-    }
-    EK_HIP(hipMemsetAsync(c->amb_count, 0, sizeof(unsigned int), c->stream));
     ek_launch_pam_classify(c->dist, c->assign, newd, c->n, cid, c->ndist,
                            c->nassign, c->amb, c->amb_best, c->amb_count,
                            c->stream);
@@ -1193,11 +1189,30 @@ static int ek_pam_tail(ek_ctx *c, int32_t cid, const float *newd,
                             K, c->amb_best, c->stream);
     ek_launch_pam_scatter(c->amb, c->amb_best, c->amb_count, max_amb, c->ndist,
                           c->nassign, c->stream);
-    ek_launch_sumsq2(c->dist, c->ndist, c->n, c->sq_part, c->sq_out, c->stream);
-    if (want_moved)
-        ek_launch_pam_moved(c->assign, c->nassign, c->n, win_lo, win_count,
-                            c->moved, c->stream);
+    ek_launch_sumsq_pack(c->dist, c->ndist, c->assign, c->nassign, c->n, win_lo,
+                         win_count, c->sq_part, c->amb_count, c->moved, out,
+                         c->stream);
     EK_CHECK_LAUNCH();
+    return EK_OK;
+}
+
+// room for the compacted ambiguous members (before anything of the proposal is
+// enqueued: growing it synchronises)
+static int ek_pam_amb_room(ek_ctx *c, int64_t max_amb)
+{
+    if (max_amb <= c->ambt_cap)
+        return EK_OK;
+    EK_HIP(ek_wait(c));
+    (void)hipFree(c->ambt);
+    (void)hipFree(c->ambG);
+    c->ambt = nullptr;
+    c->ambG = nullptr;
+    c->ambt_cap = 0;
+    const int64_t cap = std::max<int64_t>(
+        4096, (max_amb * 5 / 4 + EK_BLOCK - 1) / EK_BLOCK * EK_BLOCK);
+    EK_HIP(hipMalloc((void **)&c->ambt, (size_t)cap * 3 * c->A * sizeof(float)));
+    EK_HIP(hipMalloc((void **)&c->ambG, (size_t)cap * sizeof(double)));
+    c->ambt_cap = cap;
     return EK_OK;
 }
 
@@ -1222,6 +1237,9 @@ static int ek_pam_propose_impl(ek_ctx *c, int32_t cid, int64_t frame_index,
                                uint32_t *moved_mask = nullptr)
 {
     const int K = c->med_K;
+    int rc = ek_pam_amb_room(c, max_amb);
+    if (rc)
+        return rc;
     const float *newd = ek_pam_prefetched(c, frame_index);
     if (frame_index >= 0) {
         if (newd)
@@ -1229,17 +1247,12 @@ static int ek_pam_propose_impl(ek_ctx *c, int32_t cid, int64_t frame_index,
         else
             ++c->pf_misses;
     }
-    if (frame_index >= 0) {
-        EK_HIP(hipMemcpyAsync(c->med_idx + K, &frame_index, sizeof(int64_t),
-                              hipMemcpyHostToDevice, c->stream));
-    } else {
-        EK_HIP(hipMemcpyAsync(c->med_idx + K, c->sel + 1, sizeof(int64_t),
-                              hipMemcpyDeviceToDevice, c->stream));
-    }
-    const int64_t *idx_dev = c->med_idx + K;
+    const int64_t *idx_dev = c->sel + 1;    // read only when frame_index < 0
     if (!newd) {
         // distances of every frame to the proposed medoid (kmedoids.py:637)
-        ek_launch_record_from_frame(c->tiles, c->G, c->A, 0, idx_dev, c->goff,
+        ek_launch_record_from_frame(c->tiles, c->G, c->A,
+                                    frame_index >= 0 ? frame_index : 0,
+                                    frame_index >= 0 ? nullptr : idx_dev, c->goff,
                                     c->rec_tmp, c->stream);
         ek_launch_step(ek_pick_fpl(c), 1, ek_pick_nt(c), c->tiles, c->G, c->dist,
                        c->assign, c->scratch, c->rec_tmp, 1, c->n, c->A, 0, 0.0,
@@ -1247,40 +1260,37 @@ static int ek_pam_propose_impl(ek_ctx *c, int32_t cid, int64_t frame_index,
         EK_CHECK_LAUNCH();
         newd = c->scratch;
     }
-    // trial medoid table: save row cid in row K, put the proposal in row cid
-    ek_launch_copy_row(c->med_aos, c->med_G, c->A, cid, K, c->stream);
-    ek_launch_gather_frames(c->tiles, c->G, c->A, idx_dev, 1, cid, c->med_aos,
-                            c->med_G, c->stream);
-    int rc = ek_pam_tail(c, cid, newd, max_amb, win_lo, win_count,
-                         moved_mask != nullptr);
+    // trial medoid table (undoing a rejected proposal's row first), counters
+    ek_launch_pam_trial(c->tiles, c->G, c->A, c->med_aos, c->med_G, K, cid,
+                        c->pam_restore, frame_index, idx_dev, nullptr, nullptr,
+                        c->amb_count, c->moved, c->stream);
+    c->pam_restore = -1;
+    rc = ek_pam_tail(c, cid, newd, max_amb, win_lo, moved_mask ? win_count : 0,
+                     c->pam_out_dev);
     if (rc)
         return rc;
-    double sums[2] = {0.0, 0.0};
-    unsigned int n_amb = 0;
     int64_t fidx = frame_index;
-    if (moved_mask)
-        EK_HIP(hipMemcpyAsync(moved_mask, c->moved, sizeof(uint32_t),
-                              hipMemcpyDeviceToHost, c->stream));
-    EK_HIP(hipMemcpyAsync(sums, c->sq_out, sizeof(sums), hipMemcpyDeviceToHost,
-                          c->stream));
-    EK_HIP(hipMemcpyAsync(&n_amb, c->amb_count, sizeof(n_amb),
+    EK_HIP(hipMemcpyAsync(c->pam_out_host, c->pam_out_dev, sizeof(EkPamOut),
                           hipMemcpyDeviceToHost, c->stream));
     if (frame_index < 0)
-        EK_HIP(hipMemcpyAsync(&fidx, c->med_idx + K, sizeof(int64_t),
+        EK_HIP(hipMemcpyAsync(&fidx, idx_dev, sizeof(int64_t),
                               hipMemcpyDeviceToHost, c->stream));
     EK_HIP(ek_wait(c));
+    const EkPamOut r = *c->pam_out_host;
     c->pam_cid = cid;           // pending even if the check below fails
     c->pam_frame = fidx;
-    if ((int64_t)n_amb > max_amb)
+    if ((int64_t)r.n_amb > max_amb)
         return ek_fail(EK_EARG, "PAM proposal: cluster %d has %u members that "
                                 "stay put, more than the %lld members declared",
-                       cid, n_amb, (long long)max_amb);
+                       cid, r.n_amb, (long long)max_amb);
     if (old_cost)
-        *old_cost = sums[0] / (double)c->n;
+        *old_cost = r.sum_old / (double)c->n;
     if (new_cost)
-        *new_cost = sums[1] / (double)c->n;
+        *new_cost = r.sum_new / (double)c->n;
     if (n_ambiguous)
-        *n_ambiguous = n_amb;
+        *n_ambiguous = r.n_amb;
+    if (moved_mask)
+        *moved_mask = r.moved;
     if (frame_out)
         *frame_out = fidx;
     return EK_OK;
@@ -1360,9 +1370,8 @@ extern "C" int ek_pam_commit(ek_ctx *c, int accept)
         std::swap(c->dist, c->ndist);
         std::swap(c->assign, c->nassign);
     } else {
-        ek_launch_copy_row(c->med_aos, c->med_G, c->A, c->med_K, c->pam_cid,
-                           c->stream);
-        EK_CHECK_LAUNCH();
+        // the trial row is put back by the next proposal's first kernel
+        c->pam_restore = c->pam_cid;
     }
     c->pam_cid = -1;
     c->cnt_cid = -1;
@@ -1565,6 +1574,9 @@ extern "C" int ek_pam_propose_center(ek_ctx *c, int32_t cid, int32_t slot,
                                   "prefetched", slot);
     EK_HIP(hipSetDevice(c->device));
     c->cnt_cid = -1;
+    rc = ek_pam_amb_room(c, n_members_local);
+    if (rc)
+        return rc;
     const int K = c->med_K;
     const float *newd;
     if (slot >= 0) {
@@ -1580,19 +1592,14 @@ extern "C" int ek_pam_propose_center(ek_ctx *c, int32_t cid, int32_t slot,
         newd = c->scratch;
         ++c->pf_misses;
     }
-    ek_launch_copy_row(c->med_aos, c->med_G, c->A, cid, K, c->stream);
-    EK_HIP(hipMemcpyAsync(c->med_aos + (size_t)cid * 3 * c->A, center_aos_dev,
-                          (size_t)3 * c->A * sizeof(float), hipMemcpyDeviceToDevice,
-                          c->stream));
-    EK_HIP(hipMemcpyAsync(c->med_G + cid, center_G_dev, sizeof(double),
-                          hipMemcpyDeviceToDevice, c->stream));
+    ek_launch_pam_trial(c->tiles, c->G, c->A, c->med_aos, c->med_G, K, cid,
+                        c->pam_restore, -1, nullptr, center_aos_dev, center_G_dev,
+                        c->amb_count, c->moved, c->stream);
+    c->pam_restore = -1;
     rc = ek_pam_tail(c, cid, newd, n_members_local, win_lo, win_count,
-                     win_count > 0);
+                     (EkPamOut *)out_dev);
     if (rc)
         return rc;
-    ek_launch_pam_pack(c->sq_out, c->amb_count, win_count > 0 ? c->moved : nullptr,
-                       c->n, (EkPamOut *)out_dev, c->stream);
-    EK_CHECK_LAUNCH();
     c->pam_cid = cid;
     c->pam_frame = -1;
     return EK_OK;

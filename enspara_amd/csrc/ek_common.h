@@ -185,6 +185,17 @@ static_assert(sizeof(EkPamOut) == 32, "EkPamOut layout");
 void ek_launch_pam_pack(const double *sq, const unsigned int *n_amb,
                         const unsigned int *moved, int64_t n, EkPamOut *out,
                         hipStream_t s);
+void ek_launch_pam_trial(const float *tiles, const double *G, int A, float *aos,
+                         double *Gm, int K, int cid, int restore_cid,
+                         int64_t frame_index, const int64_t *idx_dev,
+                         const float *ext_aos, const double *ext_G,
+                         unsigned int *amb_count, unsigned int *moved,
+                         hipStream_t s);
+void ek_launch_sumsq_pack(const float *a, const float *b, const int32_t *assign,
+                          const int32_t *nassign, int64_t n, int32_t win_lo,
+                          int32_t win_count, double *part,
+                          const unsigned int *n_amb, unsigned int *moved,
+                          EkPamOut *out, hipStream_t s);
 void ek_launch_gather_rows(const float *tiles, const double *G, int A,
                            const int64_t *idx_dev, const int64_t *rows_dev,
                            int count, float *out_aos, double *outG, hipStream_t s);

@@ -539,3 +539,156 @@ void ek_launch_pam_pack(const double *sq, const unsigned int *n_amb,
     hipLaunchKernelGGL(ek_pam_pack_kernel, dim3(1), dim3(EK_WAVE), 0, s, sq, n_amb,
                        moved, n, out);
 }
+
+// ---- fewer launches per proposal ---------------------------------------------------------
+// One workgroup prepares the trial medoid table and the counters of a proposal:
+// (a) a row left modified by a rejected proposal is restored from row K,
+// (b) row cid is saved in row K, (c) the proposal goes into row cid -- either a
+// local frame (index by value, or read from idx_dev) or a center given as
+// centred coordinates --, (d) the ambiguous-member counter and the moved-cluster
+// mask are cleared.  Thread t owns elements t, t + 256, .. of every row, so the
+// three steps need no barrier even when restore_cid == cid.
+__global__ void __launch_bounds__(EK_BLOCK)
+ek_pam_trial_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
+                    int A, float *__restrict__ aos, double *__restrict__ Gm, int K,
+                    int cid, int restore_cid, int64_t frame_index,
+                    const int64_t *__restrict__ idx_dev,
+                    const float *__restrict__ ext_aos,
+                    const double *__restrict__ ext_G,
+                    unsigned int *__restrict__ amb_count,
+                    unsigned int *__restrict__ moved)
+{
+    const int tid = threadIdx.x;
+    const float *p = nullptr;
+    int64_t f = -1;
+    if (!ext_aos) {
+        f = (frame_index >= 0) ? frame_index : idx_dev[0];
+        p = tiles + (size_t)(f / EK_TILE) * 3 * (size_t)A * EK_TILE + (f % EK_TILE);
+    }
+    for (int r = tid; r < 3 * A; r += EK_BLOCK) {
+        if (restore_cid >= 0)
+            aos[(size_t)restore_cid * 3 * A + r] = aos[(size_t)K * 3 * A + r];
+        aos[(size_t)K * 3 * A + r] = aos[(size_t)cid * 3 * A + r];
+        aos[(size_t)cid * 3 * A + r] = ext_aos ? ext_aos[r] : p[(size_t)r * EK_TILE];
+    }
+    if (tid == 0) {
+        if (restore_cid >= 0)
+            Gm[restore_cid] = Gm[K];
+        Gm[K] = Gm[cid];
+        Gm[cid] = ext_aos ? ext_G[0] : G[f];
+        *amb_count = 0;
+        *moved = 0;
+    }
+}
+
+void ek_launch_pam_trial(const float *tiles, const double *G, int A, float *aos,
+                         double *Gm, int K, int cid, int restore_cid,
+                         int64_t frame_index, const int64_t *idx_dev,
+                         const float *ext_aos, const double *ext_G,
+                         unsigned int *amb_count, unsigned int *moved,
+                         hipStream_t s)
+{
+    hipLaunchKernelGGL(ek_pam_trial_kernel, dim3(1), dim3(EK_BLOCK), 0, s, tiles, G,
+                       A, aos, Gm, K, cid, restore_cid, frame_index, idx_dev,
+                       ext_aos, ext_G, amb_count, moved);
+}
+
+// cost sums (as ek_sumsq_partial_kernel) and the moved-cluster mask (as
+// ek_pam_moved_kernel) from one read of the old and the trial state
+__global__ void __launch_bounds__(EK_BLOCK)
+ek_sumsq_moved_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                      const int32_t *__restrict__ assign,
+                      const int32_t *__restrict__ nassign, int64_t n,
+                      int32_t win_lo, int32_t win_count,
+                      double *__restrict__ part, unsigned int *__restrict__ mask)
+{
+    __shared__ double sa[EK_BLOCK], sb[EK_BLOCK];
+    __shared__ unsigned int acc;
+    const int t = threadIdx.x;
+    if (t == 0)
+        acc = 0;
+    const int64_t per = (n + SQ_BLOCKS - 1) / SQ_BLOCKS;
+    const int64_t lo = (int64_t)blockIdx.x * per;
+    const int64_t hi = (lo + per < n) ? lo + per : n;
+    double xa = 0.0, xb = 0.0;
+    unsigned int m = 0;
+    for (int64_t f = lo + t; f < hi; f += EK_BLOCK) {
+        const double va = a[f], vb = b[f];
+        xa = xa + va * va;
+        xb = xb + vb * vb;
+        if (win_count > 0) {
+            const int32_t oa = assign[f], na = nassign[f];
+            if (oa != na) {
+                const int32_t ia = oa - win_lo, ib = na - win_lo;
+                if (ia >= 0 && ia < win_count)
+                    m |= 1u << ia;
+                if (ib >= 0 && ib < win_count)
+                    m |= 1u << ib;
+            }
+        }
+    }
+    sa[t] = xa;
+    sb[t] = xb;
+    __syncthreads();
+    if (m)
+        atomicOr(&acc, m);
+    for (int w = EK_BLOCK / 2; w > 0; w >>= 1) {
+        if (t < w) {
+            sa[t] = sa[t] + sa[t + w];
+            sb[t] = sb[t] + sb[t + w];
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        part[2 * blockIdx.x + 0] = sa[0];
+        part[2 * blockIdx.x + 1] = sb[0];
+        if (acc)
+            atomicOr(mask, acc);
+    }
+}
+
+// final sums (as ek_sumsq_final_kernel) packed with the counters into the one
+// record the host reads back
+__global__ void __launch_bounds__(EK_BLOCK)
+ek_sumsq_pack_kernel(const double *__restrict__ part,
+                     const unsigned int *__restrict__ n_amb,
+                     const unsigned int *__restrict__ moved, int64_t n,
+                     EkPamOut *__restrict__ out)
+{
+    __shared__ double sa[EK_BLOCK], sb[EK_BLOCK];
+    const int t = threadIdx.x;
+    double xa = 0.0, xb = 0.0;
+    for (int i = t; i < SQ_BLOCKS; i += EK_BLOCK) {
+        xa = xa + part[2 * i + 0];
+        xb = xb + part[2 * i + 1];
+    }
+    sa[t] = xa;
+    sb[t] = xb;
+    __syncthreads();
+    for (int w = EK_BLOCK / 2; w > 0; w >>= 1) {
+        if (t < w) {
+            sa[t] = sa[t] + sa[t + w];
+            sb[t] = sb[t] + sb[t + w];
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        out->sum_old = sa[0];
+        out->sum_new = sb[0];
+        out->n_frames = n;
+        out->n_amb = *n_amb;
+        out->moved = *moved;
+    }
+}
+
+void ek_launch_sumsq_pack(const float *a, const float *b, const int32_t *assign,
+                          const int32_t *nassign, int64_t n, int32_t win_lo,
+                          int32_t win_count, double *part,
+                          const unsigned int *n_amb, unsigned int *moved,
+                          EkPamOut *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(ek_sumsq_moved_kernel, dim3(SQ_BLOCKS), dim3(EK_BLOCK), 0, s,
+                       a, b, assign, nassign, n, win_lo, win_count, part, moved);
+    hipLaunchKernelGGL(ek_sumsq_pack_kernel, dim3(1), dim3(EK_BLOCK), 0, s, part,
+                       n_amb, moved, n, out);
+}
