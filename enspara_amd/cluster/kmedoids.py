@@ -93,6 +93,9 @@ def kmedoids(X, distance_method, n_clusters=None, n_iters=5, assignments=None,
         with FrameStore.from_array(xyz, device=device) as store:
             if assignments is None:
                 store.assign_nearest(xyz[inds])              # :360-361
+                # the centers were the medoid frames themselves: every frame's
+                # distance is the distance to the medoid its label names
+                store.set_option(7, 1)
             else:
                 store.upload_state(distances, assignments)
             d0, _ = store.download_state()

@@ -112,6 +112,9 @@ struct ek_ctx {
     EkPamOut *pam_out_dev = nullptr; // result record of a proposal
     EkPamOut *pam_out_host = nullptr;    // pinned copy the host polls for
     int32_t pam_restore = -1;        // row of the trial table a rejected proposal left
+    int32_t *med_list = nullptr;     // [med_cap] medoids within reach (ek_pam_prune_kernel)
+    int prune = 1;                   // use it (option key 6)
+    bool state_exact = true;         // dist[f] IS the distance to medoid assign[f]
     int64_t *tmp_idx = nullptr;      // scratch for index lists
     int64_t tmp_idx_cap = 0;
     int64_t pf_hits = 0, pf_misses = 0;
@@ -248,6 +251,7 @@ static int ek_free_all(ek_ctx *c)
     (void)hipFree(c->moved);
     (void)hipFree(c->tmp_idx);
     (void)hipFree(c->pam_out_dev);
+    (void)hipFree(c->med_list);
     if (c->pam_out_host)
         (void)hipHostFree(c->pam_out_host);
     (void)hipFree(c->recsT);
@@ -407,6 +411,16 @@ extern "C" int ek_set_option(ek_ctx *c, int32_t key, int32_t value)
             return ek_fail(EK_EARG, "ek_set_option: chained rounds 0 or 1");
         c->chain = value;
         return EK_OK;
+    case 6:
+        if (value != 0 && value != 1)
+            return ek_fail(EK_EARG, "ek_set_option: PAM medoid pruning 0 or 1");
+        c->prune = value;
+        return EK_OK;
+    case 7:
+        if (value != 0 && value != 1)
+            return ek_fail(EK_EARG, "ek_set_option: state-is-exact flag 0 or 1");
+        c->state_exact = value != 0;
+        return EK_OK;
     case 2:
         if (value < 0 || value > 2)
             return ek_fail(EK_EARG, "ek_set_option: assign variant 0..2");
@@ -558,6 +572,7 @@ extern "C" int ek_state_reset(ek_ctx *c)
     ek_launch_fill_state(c->dist, c->assign, c->n, __builtin_inff(), -1,
                          c->stream);
     EK_CHECK_LAUNCH();
+    c->state_exact = true;      // k-centers labels name frames, at their distance
     int rc = ek_history_reset(c);
     if (rc)
         return rc;
@@ -595,6 +610,7 @@ extern "C" int ek_state_upload(ek_ctx *c, const float *dist_host,
                               hipMemcpyHostToDevice, c->stream));
     }
     EK_HIP(hipStreamSynchronize(c->stream));
+    c->state_exact = false;     // the caller's numbers: taken as they are
     return ek_local_candidate(c, nullptr);
 }
 
@@ -948,6 +964,7 @@ extern "C" int ek_assign_nearest(ek_ctx *c, const float *centers_xyz,
         return ek_fail(EK_EARG, "ek_assign_nearest: %d atoms exceed the LDS "
                                 "center tile (limit 1600)", c->A);
     EK_HIP(hipSetDevice(c->device));
+    c->state_exact = false;     // labels name the caller's centers, not frames
     if (n_centers > 0) {
         int rc = ek_upload_centers(c, centers_xyz, n_centers);
         if (rc)
@@ -996,7 +1013,8 @@ static int ek_pam_alloc(ek_ctx *c, int32_t K)
         EK_HIP(hipMalloc((void **)&c->nassign, nn * sizeof(int32_t)));
         EK_HIP(hipMalloc((void **)&c->amb, nn * sizeof(uint32_t)));
         EK_HIP(hipMalloc((void **)&c->amb_best, nn * sizeof(unsigned long long)));
-        EK_HIP(hipMalloc((void **)&c->amb_count, sizeof(unsigned int)));
+        // [0] ambiguous members, [1] their reach (float bits), [2] listed medoids
+        EK_HIP(hipMalloc((void **)&c->amb_count, 4 * sizeof(unsigned int)));
         EK_HIP(hipMalloc((void **)&c->blockcnt, nb * sizeof(int32_t)));
         EK_HIP(hipMalloc((void **)&c->scan, nb * sizeof(int64_t)));
         EK_HIP(hipMalloc((void **)&c->sel, 2 * sizeof(int64_t)));
@@ -1025,6 +1043,8 @@ static int ek_pam_alloc(ek_ctx *c, int32_t K)
         (void)hipFree(c->med_aos);
         (void)hipFree(c->med_G);
         (void)hipFree(c->med_idx);
+        (void)hipFree(c->med_list);
+        c->med_list = nullptr;
         c->med_aos = nullptr;
         c->med_G = nullptr;
         c->med_idx = nullptr;
@@ -1033,6 +1053,7 @@ static int ek_pam_alloc(ek_ctx *c, int32_t K)
                          (size_t)(K + 1) * 3 * c->A * sizeof(float)));
         EK_HIP(hipMalloc((void **)&c->med_G, (size_t)(K + 1) * sizeof(double)));
         EK_HIP(hipMalloc((void **)&c->med_idx, (size_t)(K + 1) * sizeof(int64_t)));
+        EK_HIP(hipMalloc((void **)&c->med_list, (size_t)(K + 1) * sizeof(int32_t)));
         c->med_cap = K;
     }
     c->med_K = K;
@@ -1183,10 +1204,18 @@ static int ek_pam_tail(ek_ctx *c, int32_t cid, const float *newd,
     const int K = c->med_K;
     ek_launch_pam_classify(c->dist, c->assign, newd, c->n, cid, c->ndist,
                            c->nassign, c->amb, c->amb_best, c->amb_count,
-                           c->stream);
+                           c->amb_count + 1, c->stream);
+    // only when dist[f] is known to be the distance to medoid assign[f] (a state
+    // this library produced; not one uploaded by the caller) may the search skip
+    // medoids out of the members' reach
+    const bool prune = c->prune && c->state_exact;
+    if (prune)
+        ek_launch_pam_prune(c->med_aos, c->med_G, c->A, K, cid, c->amb_count + 1,
+                            c->med_list, c->amb_count + 2, c->stream);
     ek_launch_subset_assign(c->tiles, c->G, c->A, c->amb, c->amb_count, max_amb,
                             c->ambt, c->ambG, c->ambt_cap, c->med_aos, c->med_G,
-                            K, c->amb_best, c->stream);
+                            K, prune ? c->med_list : nullptr, c->amb_count + 2,
+                            newd, cid, c->amb_best, c->stream);
     ek_launch_pam_scatter(c->amb, c->amb_best, c->amb_count, max_amb, c->ndist,
                           c->nassign, c->stream);
     ek_launch_sumsq_pack(c->dist, c->ndist, c->assign, c->nassign, c->n, win_lo,

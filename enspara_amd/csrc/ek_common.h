@@ -160,15 +160,22 @@ void ek_launch_pam_classify(const float *dist, const int32_t *assign,
                             const float *newd, int64_t n, int32_t cid,
                             float *ndist, int32_t *nassign, uint32_t *amb,
                             unsigned long long *amb_best,
-                            unsigned int *amb_count, hipStream_t s);
+                            unsigned int *amb_count, unsigned int *reach,
+                            hipStream_t s);
+// medoids within reach of the ambiguous members -> list / n_list
+void ek_launch_pam_prune(const float *aos, const double *Gm, int A, int K, int cid,
+                         const unsigned int *reach, int32_t *list,
+                         unsigned int *n_list, hipStream_t s);
 // n_amb is read on the device; max_amb (a host-side upper bound) sizes the grid
 // ambt [3A][cap] / ambG [cap]: scratch for the compacted frames, cap >= max_amb
 void ek_launch_subset_assign(const float *tiles, const double *G, int A,
                              const uint32_t *amb, const unsigned int *n_amb,
                              int64_t max_amb, float *ambt, double *ambG,
                              int64_t cap, const float *centers,
-                             const double *Gc, int K,
-                             unsigned long long *amb_best, hipStream_t s);
+                             const double *Gc, int K, const int32_t *list,
+                             const unsigned int *n_list, const float *newd,
+                             int cid, unsigned long long *amb_best,
+                             hipStream_t s);
 void ek_launch_pam_scatter(const uint32_t *amb,
                            const unsigned long long *amb_best,
                            const unsigned int *n_amb, int64_t max_amb,

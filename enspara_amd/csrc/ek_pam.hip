@@ -192,7 +192,8 @@ ek_pam_classify_kernel(const float *__restrict__ dist,
                        float *__restrict__ ndist, int32_t *__restrict__ nassign,
                        uint32_t *__restrict__ amb,
                        unsigned long long *__restrict__ amb_best,
-                       unsigned int *__restrict__ amb_count)
+                       unsigned int *__restrict__ amb_count,
+                       unsigned int *__restrict__ reach)
 {
     const int64_t f = (int64_t)blockIdx.x * EK_BLOCK + threadIdx.x;
     if (f >= n)
@@ -209,6 +210,9 @@ ek_pam_classify_kernel(const float *__restrict__ dist,
         const unsigned int pos = atomicAdd(amb_count, 1u);
         amb[pos] = (uint32_t)f;
         amb_best[pos] = ~0ull;
+        // how far a medoid may be from the old one and still matter to this
+        // frame (ek_pam_prune_kernel); non-negative floats order like their bits
+        atomicMax(reach, __float_as_uint(d + nd));
     }
 }
 
@@ -216,12 +220,69 @@ void ek_launch_pam_classify(const float *dist, const int32_t *assign,
                             const float *newd, int64_t n, int32_t cid,
                             float *ndist, int32_t *nassign, uint32_t *amb,
                             unsigned long long *amb_best,
-                            unsigned int *amb_count, hipStream_t s)
+                            unsigned int *amb_count, unsigned int *reach,
+                            hipStream_t s)
 {
     const int nblocks = (int)((n + EK_BLOCK - 1) / EK_BLOCK);
     hipLaunchKernelGGL(ek_pam_classify_kernel, dim3(nblocks), dim3(EK_BLOCK), 0,
                        s, dist, assign, newd, n, cid, ndist, nassign, amb,
-                       amb_best, amb_count);
+                       amb_best, amb_count, reach);
+}
+
+// ---- which medoids can matter to the ambiguous members --------------------------------
+// An ambiguous member f of cluster cid sat at distance d_old(f) from the old
+// medoid and sits at nd(f) from the proposal, which is in the trial set, so its
+// new nearest medoid is at most nd(f) away.  Minimal RMSD is a metric, hence a
+// medoid c with  D(old medoid, c) - d_old(f) > nd(f)  for every such f -- i.e.
+// D(old, c) > reach = max_f (d_old(f) + nd(f)) -- is farther from every one of
+// them than the proposal and cannot be anybody's nearest: the list-all-medoids
+// search of kmedoids.py:666 returns the same labels and distances without it.
+// (The comparison carries a margin four orders of magnitude above the rounding
+// error of a distance; D itself is only compared, so its summation order is
+// free: one wave per medoid, lanes strided over the atoms.)  Row K of the table
+// holds the old medoid, row cid the proposal (always kept).
+__global__ void __launch_bounds__(EK_BLOCK)
+ek_pam_prune_kernel(const float *__restrict__ aos, const double *__restrict__ Gm,
+                    int A, int K, int cid, const unsigned int *__restrict__ reach,
+                    int32_t *__restrict__ list, unsigned int *__restrict__ n_list)
+{
+    const int lane = threadIdx.x & (EK_WAVE - 1);
+    const int c = blockIdx.x * (EK_BLOCK / EK_WAVE) + threadIdx.x / EK_WAVE;
+    if (c >= K)
+        return;
+    bool keep = (c == cid);
+    if (!keep) {
+        const float *x = aos + (size_t)c * 3 * A;
+        const float *y = aos + (size_t)K * 3 * A;
+        float S[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int a = lane; a < A; a += EK_WAVE) {
+            const float x0 = x[3 * a], x1 = x[3 * a + 1], x2 = x[3 * a + 2];
+            const float y0 = y[3 * a], y1 = y[3 * a + 1], y2 = y[3 * a + 2];
+            S[0] += x0 * y0; S[1] += x0 * y1; S[2] += x0 * y2;
+            S[3] += x1 * y0; S[4] += x1 * y1; S[5] += x1 * y2;
+            S[6] += x2 * y0; S[7] += x2 * y1; S[8] += x2 * y2;
+        }
+#pragma unroll
+        for (int j = 0; j < 9; ++j)
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1)
+                S[j] += __shfl_xor(S[j], off, 64);
+        const float D = ek_rmsd_from_S(S, Gm[c], Gm[K], A);
+        const float R = __uint_as_float(*reach);
+        keep = !(D > R * 1.001f + 1e-3f);
+    }
+    if (keep && lane == 0)
+        list[atomicAdd(n_list, 1u)] = c;
+}
+
+void ek_launch_pam_prune(const float *aos, const double *Gm, int A, int K, int cid,
+                         const unsigned int *reach, int32_t *list,
+                         unsigned int *n_list, hipStream_t s)
+{
+    const int per = EK_BLOCK / EK_WAVE;
+    hipLaunchKernelGGL(ek_pam_prune_kernel, dim3((K + per - 1) / per),
+                       dim3(EK_BLOCK), 0, s, aos, Gm, A, K, cid, reach, list,
+                       n_list);
 }
 
 // ---- listed frames x all medoids (kmedoids.py:666) ---------------------------------
@@ -240,12 +301,15 @@ ek_gather_amb_kernel(const float *__restrict__ tiles,
                      const double *__restrict__ G, int A,
                      const uint32_t *__restrict__ amb,
                      const unsigned int *__restrict__ n_amb_p, int64_t cap,
+                     const unsigned int *__restrict__ n_list,
                      float *__restrict__ ambt, double *__restrict__ ambG)
 {
     // one workgroup per listed frame: its 3A row loads go out in parallel
     const unsigned int i = blockIdx.x;
     if (i >= *n_amb_p)
         return;
+    if (n_list && *n_list == 1)
+        return;                 // ek_subset_assign_kernel will not need them
     const uint32_t f = amb[i];
     const float *p = tiles + (size_t)(f / EK_TILE) * 3 * (size_t)A * EK_TILE +
                      (f % EK_TILE);
@@ -261,26 +325,48 @@ ek_subset_assign_kernel(const float *__restrict__ ambt,
                         const unsigned int *__restrict__ n_amb_p,
                         const float *__restrict__ centers,
                         const double *__restrict__ Gc, int K,
+                        const int32_t *__restrict__ list,
+                        const unsigned int *__restrict__ n_list,
+                        const uint32_t *__restrict__ amb,
+                        const float *__restrict__ newd, int cid,
                         unsigned long long *__restrict__ amb_best)
 {
     extern __shared__ __attribute__((aligned(16))) float ctile[];
     __shared__ double gtile[PCT];
+    __shared__ int32_t ktile[PCT];
     const int tid = threadIdx.x;
     const unsigned int n_amb = *n_amb_p;
     if (blockIdx.x * EK_BLOCK >= n_amb)
         return;                            // whole workgroup past the list
     const unsigned int i = blockIdx.x * EK_BLOCK + tid;
+    // the medoids to try: all K of them, or those ek_pam_prune_kernel listed
+    const int Kl = list ? (int)*n_list : K;
     const int k0 = blockIdx.y * PCT;
-    const int kc = (K - k0 < PCT) ? (K - k0) : PCT;
+    if (k0 >= Kl)
+        return;
+    if (list && Kl == 1) {
+        // only the proposal itself is within reach (the usual case): the
+        // distance to it is the one the proposal's pass already computed, by the
+        // same FMA chain from the same coordinates
+        if (i < n_amb)
+            atomicMin(&amb_best[i],
+                      ((unsigned long long)__float_as_uint(newd[amb[i]]) << 32) |
+                          (unsigned int)cid);
+        return;
+    }
+    const int kc = (Kl - k0 < PCT) ? (Kl - k0) : PCT;
+    if (tid < PCT)
+        ktile[tid] = (tid < kc) ? (list ? list[k0 + tid] : k0 + tid) : 0;
+    __syncthreads();
     // ctile[a][c][k]; global reads run along each center's row (coalesced)
     for (int j = tid; j < 3 * A * PCT; j += EK_BLOCK) {
         const int c = j / (3 * A), r = j % (3 * A);
         // centers in pairs, [atom][pair][xyz][2]: one packed FMA serves two
         ctile[(r / 3) * (3 * PCT) + (c / 2) * 6 + (r % 3) * 2 + (c & 1)] =
-            (c < kc) ? centers[(size_t)(k0 + c) * 3 * A + r] : 0.f;
+            (c < kc) ? centers[(size_t)ktile[c] * 3 * A + r] : 0.f;
     }
     if (tid < PCT)
-        gtile[tid] = (tid < kc) ? Gc[k0 + tid] : 0.0;
+        gtile[tid] = (tid < kc) ? Gc[ktile[tid]] : 0.0;
     __syncthreads();
     if (i >= n_amb)
         return;
@@ -336,7 +422,7 @@ ek_subset_assign_kernel(const float *__restrict__ ambt,
             const float d = ek_rmsd_from_S(S, Gf, gtile[c], A);
             const unsigned long long key =
                 ((unsigned long long)__float_as_uint(d) << 32) |
-                (unsigned int)(k0 + c);
+                (unsigned int)ktile[c];
             if (key < best)
                 best = key;
         }
@@ -348,15 +434,17 @@ void ek_launch_subset_assign(const float *tiles, const double *G, int A,
                              const uint32_t *amb, const unsigned int *n_amb,
                              int64_t max_amb, float *ambt, double *ambG,
                              int64_t cap, const float *centers,
-                             const double *Gc, int K,
-                             unsigned long long *amb_best, hipStream_t s)
+                             const double *Gc, int K, const int32_t *list,
+                             const unsigned int *n_list, const float *newd,
+                             int cid, unsigned long long *amb_best,
+                             hipStream_t s)
 {
     if (max_amb <= 0 || K <= 0)
         return;
     const unsigned gx = (unsigned)((max_amb + EK_BLOCK - 1) / EK_BLOCK);
     hipLaunchKernelGGL(ek_gather_amb_kernel, dim3((unsigned)max_amb),
-                       dim3(EK_BLOCK), 0, s, tiles, G, A, amb, n_amb, cap, ambt,
-                       ambG);
+                       dim3(EK_BLOCK), 0, s, tiles, G, A, amb, n_amb, cap,
+                       list ? n_list : nullptr, ambt, ambG);
     const dim3 grid(gx, (K + PCT - 1) / PCT);
     const size_t lds = (size_t)3 * A * PCT * sizeof(float);
     if (lds > 48 * 1024)
@@ -364,7 +452,8 @@ void ek_launch_subset_assign(const float *tiles, const double *G, int A,
                                   hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
     hipLaunchKernelGGL(ek_subset_assign_kernel, grid, dim3(EK_BLOCK), lds, s,
-                       ambt, ambG, A, cap, n_amb, centers, Gc, K, amb_best);
+                       ambt, ambG, A, cap, n_amb, centers, Gc, K, list, n_list,
+                       amb, newd, cid, amb_best);
 }
 
 __global__ void __launch_bounds__(EK_BLOCK)
@@ -558,6 +647,7 @@ ek_pam_trial_kernel(const float *__restrict__ tiles, const double *__restrict__ 
                     unsigned int *__restrict__ amb_count,
                     unsigned int *__restrict__ moved)
 {
+    // amb_count[0] ambiguous members, [1] reach bits, [2] listed medoids
     const int tid = threadIdx.x;
     const float *p = nullptr;
     int64_t f = -1;
@@ -576,7 +666,9 @@ ek_pam_trial_kernel(const float *__restrict__ tiles, const double *__restrict__ 
             Gm[restore_cid] = Gm[K];
         Gm[K] = Gm[cid];
         Gm[cid] = ext_aos ? ext_G[0] : G[f];
-        *amb_count = 0;
+        amb_count[0] = 0;
+        amb_count[1] = 0;
+        amb_count[2] = 0;
         *moved = 0;
     }
 }

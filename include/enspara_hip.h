@@ -386,7 +386,14 @@ int ek_set_frames_per_lane(ek_ctx *ctx, int fpl);
  * key 2: nearest-center kernel: 0 automatic, 1 vector FMA, 2 MFMA (identical
  * results)
  * key 5: cheap steps of a round in ek_kcenters_run: 1 chained (default), 0 one
- * launch pair per accepted center (identical results) */
+ * launch pair per accepted center (identical results)
+ * key 6: PAM proposals search the ambiguous members' new medoid only among
+ * the medoids within their reach (triangle inequality, identical results):
+ * 1 (default) / 0.  Used only while the state is known to hold, for every
+ * frame, the distance to the medoid its label names: true after
+ * ek_state_reset + k-centers, false after ek_state_upload / ek_assign_nearest
+ * key 7: assert (1) or withdraw (0) that property, e.g. after
+ * ek_assign_nearest with the medoid frames themselves as centers */
 int ek_set_option(ek_ctx *ctx, int32_t key, int32_t value);
 /* time of the last ek_kcenters_run loop measured with HIP events on the
  * context's stream, milliseconds, and the number of distance-kernel launches

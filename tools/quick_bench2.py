@@ -37,7 +37,7 @@ if "pam" in what.split(","):
     P = min(K, int(os.environ.get("PAM_PROPOSALS", "600")))
     for width in (1, 4, 8):
         km.PAM_PREFETCH = width
-        st.upload_state(d0, a0)
+        st.upload_state(d0, a0); st.set_option(7, 1)   # a k-centers state: exact
         # time the first P clusters of a sweep through the product code path
         med = [int(i) for i in idx]
         rs = np.random.RandomState(0)
