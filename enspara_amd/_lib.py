@@ -36,6 +36,8 @@ SYMBOLS = [
     "ek_pam_propose", "ek_pam_propose_member", "ek_pam_commit",
     "ek_pam_count_members_batch", "ek_pam_select_members_batch",
     "ek_pam_prefetch", "ek_pam_propose_ex", "ek_pam_prefetch_stats",
+    "ek_pam_prefetch_window", "ek_pam_prefetch_passes",
+    "ek_pam_prefetch_centers_window",
     "ek_centered_frames", "ek_pam_begin_table", "ek_pam_prefetch_centers",
     "ek_pam_propose_center",
     "ek_msm_counts", "ek_msm_row_normalize",
@@ -129,6 +131,9 @@ def load():
     L.ek_pam_propose_ex.argtypes = [vp, i32, i64, i64, i32, i32, f64p, f64p,
                                     i64p, C.POINTER(C.c_uint32)]
     L.ek_pam_prefetch_stats.argtypes = [vp, i64p, i64p]
+    L.ek_pam_prefetch_window.argtypes = [vp, i64p, i32, i32, i32]
+    L.ek_pam_prefetch_passes.argtypes = [vp, i64p, i64p]
+    L.ek_pam_prefetch_centers_window.argtypes = [vp, vp, vp, i32, i32, i32]
     L.ek_centered_frames.argtypes = [vp, i64p, i32p, i32, vp, vp]
     L.ek_pam_begin_table.argtypes = [vp, vp, vp, i32]
     L.ek_pam_prefetch_centers.argtypes = [vp, vp, vp, i32]

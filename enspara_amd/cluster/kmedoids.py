@@ -189,7 +189,7 @@ def _open_window(store, lo, hi, proposals, random_state):
     else:
         w.j = None
         w.frame = [int(p) for p in proposals[lo:hi]]
-    store.pam_prefetch(w.frame)
+    store.pam_prefetch(w.frame, lo, hi - lo)
     return w
 
 

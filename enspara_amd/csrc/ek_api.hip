@@ -113,6 +113,13 @@ struct ek_ctx {
     EkPamOut *pam_out_host = nullptr;    // pinned copy the host polls for
     int32_t pam_restore = -1;        // row of the trial table a rejected proposal left
     int32_t *med_list = nullptr;     // [med_cap] medoids within reach (ek_pam_prune_kernel)
+    float *dtab = nullptr;           // [EK_MAX_CANDS][med_cap] medoid-to-proposal distances
+    float *act_tiles = nullptr;      // frames needing exact distances, tile layout
+    double *act_G = nullptr;
+    float *act_vecs = nullptr;       // [EK_MAX_CANDS][act_cap]
+    int64_t act_cap = 0;
+    unsigned int *act_n_host = nullptr;  // pinned
+    int64_t pf_sparse = 0, pf_full = 0;  // prefetch passes of either kind
     int prune = 1;                   // use it (option key 6)
     bool state_exact = true;         // dist[f] IS the distance to medoid assign[f]
     int64_t *tmp_idx = nullptr;      // scratch for index lists
@@ -252,6 +259,12 @@ static int ek_free_all(ek_ctx *c)
     (void)hipFree(c->tmp_idx);
     (void)hipFree(c->pam_out_dev);
     (void)hipFree(c->med_list);
+    (void)hipFree(c->dtab);
+    (void)hipFree(c->act_tiles);
+    (void)hipFree(c->act_G);
+    (void)hipFree(c->act_vecs);
+    if (c->act_n_host)
+        (void)hipHostFree(c->act_n_host);
     if (c->pam_out_host)
         (void)hipHostFree(c->pam_out_host);
     (void)hipFree(c->recsT);
@@ -1044,7 +1057,9 @@ static int ek_pam_alloc(ek_ctx *c, int32_t K)
         (void)hipFree(c->med_G);
         (void)hipFree(c->med_idx);
         (void)hipFree(c->med_list);
+        (void)hipFree(c->dtab);
         c->med_list = nullptr;
+        c->dtab = nullptr;
         c->med_aos = nullptr;
         c->med_G = nullptr;
         c->med_idx = nullptr;
@@ -1054,6 +1069,8 @@ static int ek_pam_alloc(ek_ctx *c, int32_t K)
         EK_HIP(hipMalloc((void **)&c->med_G, (size_t)(K + 1) * sizeof(double)));
         EK_HIP(hipMalloc((void **)&c->med_idx, (size_t)(K + 1) * sizeof(int64_t)));
         EK_HIP(hipMalloc((void **)&c->med_list, (size_t)(K + 1) * sizeof(int32_t)));
+        EK_HIP(hipMalloc((void **)&c->dtab,
+                         (size_t)EK_MAX_CANDS * (K + 1) * sizeof(float)));
         c->med_cap = K;
     }
     c->med_K = K;
@@ -1484,7 +1501,88 @@ static int ek_pam_vecs_alloc(ek_ctx *c)
     return EK_OK;
 }
 
+// The distance vectors of the `count` records in c->pam_recs.  When the state is
+// exact (every frame's distance is the distance to the medoid its label names)
+// and the window of clusters being worked through is known, only the frames a
+// proposal can touch get exact distances (ek_pam.hip, "proposal prefetch
+// restricted ..."): the others get +inf.
+static int ek_pam_prefetch_vectors(ek_ctx *c, int count, int32_t win_lo,
+                                   int32_t win_count)
+{
+    const int K = c->med_K;
+    if (c->prune && c->state_exact && win_count > 0 && c->n >= 16384) {
+        if (!c->act_n_host)
+            EK_HIP(hipHostMalloc((void **)&c->act_n_host, sizeof(unsigned int),
+                                 hipHostMallocDefault));
+        ek_launch_pam_dtab(c->med_aos, c->med_G, c->A, K, c->pam_restore,
+                           c->pam_recs, count, c->dtab, c->stream);
+        ek_launch_pam_active(c->dist, c->assign, c->n, c->dtab, K, count, win_lo,
+                             win_count, c->amb, c->amb_count + 3, c->stream);
+        EK_CHECK_LAUNCH();
+        EK_HIP(hipMemcpyAsync(c->act_n_host, c->amb_count + 3, sizeof(unsigned int),
+                              hipMemcpyDeviceToHost, c->stream));
+        EK_HIP(ek_wait(c));
+        const int64_t n_act = *c->act_n_host;
+        if (n_act * 8 <= c->n) {
+            const int64_t need = (n_act + EK_TILE - 1) / EK_TILE * EK_TILE;
+            if (need > c->act_cap) {
+                (void)hipFree(c->act_tiles);
+                (void)hipFree(c->act_G);
+                (void)hipFree(c->act_vecs);
+                c->act_tiles = nullptr;
+                c->act_G = nullptr;
+                c->act_vecs = nullptr;
+                c->act_cap = 0;
+                const int64_t cap = std::max<int64_t>(16384, need * 3 / 2 /
+                                                      EK_TILE * EK_TILE + EK_TILE);
+                EK_HIP(hipMalloc((void **)&c->act_tiles,
+                                 (size_t)cap * 3 * c->A * sizeof(float)));
+                EK_HIP(hipMalloc((void **)&c->act_G, (size_t)cap * sizeof(double)));
+                EK_HIP(hipMalloc((void **)&c->act_vecs,
+                                 (size_t)EK_MAX_CANDS * cap * sizeof(float)));
+                c->act_cap = cap;
+            }
+            EK_HIP(hipMemsetD32Async((hipDeviceptr_t)c->pam_vecs, 0x7f800000,
+                                     (size_t)count * c->n_pad, c->stream));
+            ek_launch_gather_tiles(c->tiles, c->G, c->A, c->amb, n_act,
+                                   c->act_tiles, c->act_G, c->stream);
+            ek_launch_pass_dist(count, c->act_tiles, c->act_G, c->act_vecs, n_act,
+                                c->act_cap, c->A, c->pam_recs, c->pam_plan,
+                                c->stream);
+            ek_launch_scatter_vecs(c->amb, n_act, c->act_vecs, c->act_cap, count,
+                                   c->pam_vecs, c->n_pad, c->stream);
+            EK_CHECK_LAUNCH();
+            ++c->pf_sparse;
+            return EK_OK;
+        }
+    }
+    ek_launch_pass_dist(count, c->tiles, c->G, c->pam_vecs, c->n, c->n_pad, c->A,
+                        c->pam_recs, c->pam_plan, c->stream);
+    EK_CHECK_LAUNCH();
+    ++c->pf_full;
+    return EK_OK;
+}
+
+static int ek_pam_prefetch_frames(ek_ctx *c, const int64_t *frames, int32_t count,
+                                  int32_t win_lo, int32_t win_count);
+
+extern "C" int ek_pam_prefetch_window(ek_ctx *c, const int64_t *frames,
+                                      int32_t count, int32_t win_lo,
+                                      int32_t win_count)
+{
+    if (c && (win_lo < 0 || win_count < 0 || win_lo + win_count > c->med_K))
+        return ek_fail(EK_EARG, "ek_pam_prefetch_window: clusters [%d,+%d) outside "
+                                "[0,%d)", win_lo, win_count, c->med_K);
+    return ek_pam_prefetch_frames(c, frames, count, win_lo, win_count);
+}
+
 extern "C" int ek_pam_prefetch(ek_ctx *c, const int64_t *frames, int32_t count)
+{
+    return ek_pam_prefetch_frames(c, frames, count, 0, 0);
+}
+
+static int ek_pam_prefetch_frames(ek_ctx *c, const int64_t *frames, int32_t count,
+                                  int32_t win_lo, int32_t win_count)
 {
     if (!c || (!frames && count > 0))
         return ek_fail(EK_EARG, "ek_pam_prefetch: NULL argument");
@@ -1513,9 +1611,11 @@ extern "C" int ek_pam_prefetch(ek_ctx *c, const int64_t *frames, int32_t count)
     for (int32_t j = 0; j < count; ++j)
         ek_launch_record_from_frame(c->tiles, c->G, c->A, frames[j], nullptr,
                                     c->goff, c->pam_recs + j * rstride, c->stream);
-    ek_launch_pass_dist(count, c->tiles, c->G, c->pam_vecs, c->n, c->n_pad, c->A,
-                        c->pam_recs, c->pam_plan, c->stream);
-    EK_CHECK_LAUNCH();
+    {
+        int rc = ek_pam_prefetch_vectors(c, count, win_lo, win_count);
+        if (rc)
+            return rc;
+    }
     for (int32_t j = 0; j < count; ++j)
         c->pf_frames[j] = frames[j];
     c->pf_count = count;
@@ -1547,8 +1647,29 @@ extern "C" int ek_pam_propose_ex(ek_ctx *c, int32_t cid, int64_t frame_index,
                                win_count > 0 ? moved_mask : nullptr);
 }
 
+static int ek_pam_prefetch_centers_impl(ek_ctx *c, const float *aos_dev,
+                                        const double *G_dev, int32_t count,
+                                        int32_t win_lo, int32_t win_count);
+
 extern "C" int ek_pam_prefetch_centers(ek_ctx *c, const float *aos_dev,
                                        const double *G_dev, int32_t count)
+{
+    return ek_pam_prefetch_centers_impl(c, aos_dev, G_dev, count, 0, 0);
+}
+
+extern "C" int ek_pam_prefetch_centers_window(ek_ctx *c, const float *aos_dev,
+                                              const double *G_dev, int32_t count,
+                                              int32_t win_lo, int32_t win_count)
+{
+    if (c && (win_lo < 0 || win_count < 0 || win_lo + win_count > c->med_K))
+        return ek_fail(EK_EARG, "ek_pam_prefetch_centers_window: clusters [%d,+%d) "
+                                "outside [0,%d)", win_lo, win_count, c->med_K);
+    return ek_pam_prefetch_centers_impl(c, aos_dev, G_dev, count, win_lo, win_count);
+}
+
+static int ek_pam_prefetch_centers_impl(ek_ctx *c, const float *aos_dev,
+                                        const double *G_dev, int32_t count,
+                                        int32_t win_lo, int32_t win_count)
 {
     if (!c || (count > 0 && (!aos_dev || !G_dev)))
         return ek_fail(EK_EARG, "ek_pam_prefetch_centers: NULL argument");
@@ -1573,9 +1694,9 @@ extern "C" int ek_pam_prefetch_centers(ek_ctx *c, const float *aos_dev,
     for (int32_t j = 0; j < count; ++j)
         ek_launch_record_from_center(aos_dev + (size_t)j * 3 * c->A, G_dev + j, c->A,
                                      c->pam_recs + j * rstride, c->stream);
-    ek_launch_pass_dist(count, c->tiles, c->G, c->pam_vecs, c->n, c->n_pad, c->A,
-                        c->pam_recs, c->pam_plan, c->stream);
-    EK_CHECK_LAUNCH();
+    rc = ek_pam_prefetch_vectors(c, count, win_lo, win_count);
+    if (rc)
+        return rc;
     for (int32_t j = 0; j < count; ++j)
         c->pf_frames[j] = -1;
     c->pf_count = count;
@@ -1631,6 +1752,18 @@ extern "C" int ek_pam_propose_center(ek_ctx *c, int32_t cid, int32_t slot,
         return rc;
     c->pam_cid = cid;
     c->pam_frame = -1;
+    return EK_OK;
+}
+
+extern "C" int ek_pam_prefetch_passes(ek_ctx *c, int64_t *restricted,
+                                      int64_t *full)
+{
+    if (!c)
+        return ek_fail(EK_EARG, "NULL context");
+    if (restricted)
+        *restricted = c->pf_sparse;
+    if (full)
+        *full = c->pf_full;
     return EK_OK;
 }
 

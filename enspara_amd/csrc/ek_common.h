@@ -192,6 +192,20 @@ static_assert(sizeof(EkPamOut) == 32, "EkPamOut layout");
 void ek_launch_pam_pack(const double *sq, const unsigned int *n_amb,
                         const unsigned int *moved, int64_t n, EkPamOut *out,
                         hipStream_t s);
+// active-set proposal prefetch (ek_pam.hip)
+void ek_launch_pam_dtab(const float *aos, const double *Gm, int A, int K, int held,
+                        const unsigned char *recs, int count, float *Dtab,
+                        hipStream_t s);
+void ek_launch_pam_active(const float *dist, const int32_t *assign, int64_t n,
+                          const float *Dtab, int K, int count, int32_t win_lo,
+                          int32_t win_count, uint32_t *list, unsigned int *n_list,
+                          hipStream_t s);
+void ek_launch_gather_tiles(const float *tiles, const double *G, int A,
+                            const uint32_t *list, int64_t count, float *ctiles,
+                            double *cG, hipStream_t s);
+void ek_launch_scatter_vecs(const uint32_t *list, int64_t count,
+                            const float *cvecs, int64_t cpad, int nvec,
+                            float *vecs, int64_t n_pad, hipStream_t s);
 void ek_launch_pam_trial(const float *tiles, const double *G, int A, float *aos,
                          double *Gm, int K, int cid, int restore_cid,
                          int64_t frame_index, const int64_t *idx_dev,

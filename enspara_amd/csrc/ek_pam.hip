@@ -784,3 +784,167 @@ void ek_launch_sumsq_pack(const float *a, const float *b, const int32_t *assign,
     hipLaunchKernelGGL(ek_sumsq_pack_kernel, dim3(1), dim3(EK_BLOCK), 0, s, part,
                        n_amb, moved, n, out);
 }
+
+// ---- proposal prefetch restricted to the frames a proposal can touch ------------------
+// A frame f with label a at distance d(f) from its medoid m_a cannot come closer
+// to a proposed medoid p than D(m_a, p) - d(f) (minimal RMSD is a metric), so if
+// D(m_a, p) >= 2 d(f) it stays where it is whatever the exact distance: the
+// classification of kmedoids.py:644-658 only asks "is it closer than d(f)?".
+// Exact distances are therefore needed only for the frames that fail that test
+// for some proposal of the window, and for the members of the window's own
+// clusters -- the only frames whose distance can GROW while the window is worked
+// through (as ambiguous members of an accepted proposal), which would invalidate
+// a test made at prefetch time.  Every other frame gets +inf.  The comparison
+// carries a margin far above the rounding of a distance; D is only compared, so
+// its summation order is free.
+
+// Dtab[j * K + c] = rmsd(medoid c, proposal j); one wave per medoid, lanes
+// strided over the atoms.  `held` is the row a rejected proposal still occupies
+// (its medoid is in row K), or -1.
+__global__ void __launch_bounds__(EK_BLOCK)
+ek_pam_dtab_kernel(const float *__restrict__ aos, const double *__restrict__ Gm,
+                   int A, int K, int held, const unsigned char *__restrict__ recs,
+                   int count, float *__restrict__ Dtab)
+{
+    const int lane = threadIdx.x & (EK_WAVE - 1);
+    const int c = blockIdx.x * (EK_BLOCK / EK_WAVE) + threadIdx.x / EK_WAVE;
+    if (c >= K)
+        return;
+    const int row = (c == held) ? K : c;
+    const float *x = aos + (size_t)row * 3 * A;
+    const size_t rstride = ek_rec_bytes(A);
+    for (int j = 0; j < count; ++j) {
+        const EkRecHdr *h = (const EkRecHdr *)(recs + (size_t)j * rstride);
+        const float *y = (const float *)(recs + (size_t)j * rstride +
+                                         sizeof(EkRecHdr));
+        float S[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int a = lane; a < A; a += EK_WAVE) {
+            const float x0 = x[3 * a], x1 = x[3 * a + 1], x2 = x[3 * a + 2];
+            const float y0 = y[3 * a], y1 = y[3 * a + 1], y2 = y[3 * a + 2];
+            S[0] += x0 * y0; S[1] += x0 * y1; S[2] += x0 * y2;
+            S[3] += x1 * y0; S[4] += x1 * y1; S[5] += x1 * y2;
+            S[6] += x2 * y0; S[7] += x2 * y1; S[8] += x2 * y2;
+        }
+#pragma unroll
+        for (int q = 0; q < 9; ++q)
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1)
+                S[q] += __shfl_xor(S[q], off, 64);
+        if (lane == 0)
+            Dtab[(size_t)j * K + c] = ek_rmsd_from_S(S, Gm[row], h->trace, A);
+    }
+}
+
+void ek_launch_pam_dtab(const float *aos, const double *Gm, int A, int K, int held,
+                        const unsigned char *recs, int count, float *Dtab,
+                        hipStream_t s)
+{
+    const int per = EK_BLOCK / EK_WAVE;
+    hipLaunchKernelGGL(ek_pam_dtab_kernel, dim3((K + per - 1) / per),
+                       dim3(EK_BLOCK), 0, s, aos, Gm, A, K, held, recs, count,
+                       Dtab);
+}
+
+// the frames that need exact distances -> list (any order), *n_list
+__global__ void __launch_bounds__(EK_BLOCK)
+ek_pam_active_kernel(const float *__restrict__ dist,
+                     const int32_t *__restrict__ assign, int64_t n,
+                     const float *__restrict__ Dtab, int K, int count,
+                     int32_t win_lo, int32_t win_count,
+                     uint32_t *__restrict__ list, unsigned int *__restrict__ n_list)
+{
+    const int64_t f = (int64_t)blockIdx.x * EK_BLOCK + threadIdx.x;
+    bool act = false;
+    if (f < n) {
+        const int32_t a = assign[f];
+        const float d = dist[f];
+        if (a < 0 || a >= K || (a >= win_lo && a < win_lo + win_count)) {
+            act = true;
+        } else {
+            float dmin = __builtin_inff();
+            for (int j = 0; j < count; ++j)
+                dmin = fminf(dmin, Dtab[(size_t)j * K + a]);
+            act = !(dmin > 2.f * d * 1.001f + 1e-3f);
+        }
+    }
+    const unsigned long long m = __ballot(act);
+    if (m == 0)
+        return;
+    const int lane = threadIdx.x & (EK_WAVE - 1);
+    unsigned int base = 0;
+    if (lane == 0)
+        base = atomicAdd(n_list, (unsigned int)__popcll(m));
+    base = __shfl(base, 0, 64);
+    if (act)
+        list[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)f;
+}
+
+void ek_launch_pam_active(const float *dist, const int32_t *assign, int64_t n,
+                          const float *Dtab, int K, int count, int32_t win_lo,
+                          int32_t win_count, uint32_t *list, unsigned int *n_list,
+                          hipStream_t s)
+{
+    (void)hipMemsetAsync(n_list, 0, sizeof(unsigned int), s);
+    if (n <= 0)
+        return;
+    hipLaunchKernelGGL(ek_pam_active_kernel,
+                       dim3((unsigned)((n + EK_BLOCK - 1) / EK_BLOCK)),
+                       dim3(EK_BLOCK), 0, s, dist, assign, n, Dtab, K, count,
+                       win_lo, win_count, list, n_list);
+}
+
+// the listed frames, packed into the frame-minor tile layout of the frame store
+// (so that the pass kernel can run over them); one workgroup per frame
+__global__ void __launch_bounds__(EK_BLOCK)
+ek_gather_tiles_kernel(const float *__restrict__ tiles,
+                       const double *__restrict__ G, int A,
+                       const uint32_t *__restrict__ list,
+                       float *__restrict__ ctiles, double *__restrict__ cG)
+{
+    const unsigned int i = blockIdx.x;
+    const uint32_t f = list[i];
+    const float *p = tiles + (size_t)(f / EK_TILE) * 3 * (size_t)A * EK_TILE +
+                     (f % EK_TILE);
+    float *o = ctiles + (size_t)(i / EK_TILE) * 3 * (size_t)A * EK_TILE +
+               (i % EK_TILE);
+    for (int r = threadIdx.x; r < 3 * A; r += EK_BLOCK)
+        o[(size_t)r * EK_TILE] = p[(size_t)r * EK_TILE];
+    if (threadIdx.x == 0)
+        cG[i] = G[f];
+}
+
+void ek_launch_gather_tiles(const float *tiles, const double *G, int A,
+                            const uint32_t *list, int64_t count, float *ctiles,
+                            double *cG, hipStream_t s)
+{
+    if (count <= 0)
+        return;
+    hipLaunchKernelGGL(ek_gather_tiles_kernel, dim3((unsigned)count),
+                       dim3(EK_BLOCK), 0, s, tiles, G, A, list, ctiles, cG);
+}
+
+// vecs[j][list[i]] = cvecs[j][i]
+__global__ void __launch_bounds__(EK_BLOCK)
+ek_scatter_vecs_kernel(const uint32_t *__restrict__ list, int64_t count,
+                       const float *__restrict__ cvecs, int64_t cpad, int nvec,
+                       float *__restrict__ vecs, int64_t n_pad)
+{
+    const int64_t i = (int64_t)blockIdx.x * EK_BLOCK + threadIdx.x;
+    if (i >= count)
+        return;
+    const uint32_t f = list[i];
+    for (int j = 0; j < nvec; ++j)
+        vecs[(size_t)j * n_pad + f] = cvecs[(size_t)j * cpad + i];
+}
+
+void ek_launch_scatter_vecs(const uint32_t *list, int64_t count,
+                            const float *cvecs, int64_t cpad, int nvec,
+                            float *vecs, int64_t n_pad, hipStream_t s)
+{
+    if (count <= 0)
+        return;
+    hipLaunchKernelGGL(ek_scatter_vecs_kernel,
+                       dim3((unsigned)((count + EK_BLOCK - 1) / EK_BLOCK)),
+                       dim3(EK_BLOCK), 0, s, list, count, cvecs, cpad, nvec, vecs,
+                       n_pad);
+}

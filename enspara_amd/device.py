@@ -210,10 +210,21 @@ class FrameStore:
             self._h, int(cid0), len(js), _lib.i64p(js), _lib.i64p(out)))
         return out
 
-    def pam_prefetch(self, frames):
-        """Compute and keep the distances of every frame to frames[0..8)."""
+    def pam_prefetch(self, frames, win_lo=0, win_count=0):
+        """Compute and keep the distances of every frame to frames[0..8).
+        With the window of clusters the caller works through next (their
+        proposals are `frames`), only frames a proposal can touch get exact
+        distances while the state allows the triangle-inequality test."""
         f = np.ascontiguousarray(frames, dtype=np.int64)
-        _lib.check(self.lib.ek_pam_prefetch(self._h, _lib.i64p(f), len(f)))
+        _lib.check(self.lib.ek_pam_prefetch_window(
+            self._h, _lib.i64p(f), len(f), int(win_lo), int(win_count)))
+
+    def pam_prefetch_passes(self):
+        """-> (prefetches restricted to the touched frames, over all frames)"""
+        a, b = C.c_int64(), C.c_int64()
+        _lib.check(self.lib.ek_pam_prefetch_passes(self._h, C.byref(a),
+                                                   C.byref(b)))
+        return a.value, b.value
 
     def pam_propose_ex(self, cid, frame_index, n_members, win_lo=0,
                        win_count=0):
@@ -245,9 +256,11 @@ class FrameStore:
         _lib.check(self.lib.ek_pam_begin_table(self._h, int(aos_ptr),
                                                int(G_ptr), int(n_medoids)))
 
-    def pam_prefetch_centers(self, aos_ptr, G_ptr, count):
-        _lib.check(self.lib.ek_pam_prefetch_centers(self._h, int(aos_ptr),
-                                                    int(G_ptr), int(count)))
+    def pam_prefetch_centers(self, aos_ptr, G_ptr, count, win_lo=0,
+                             win_count=0):
+        _lib.check(self.lib.ek_pam_prefetch_centers_window(
+            self._h, int(aos_ptr), int(G_ptr), int(count), int(win_lo),
+            int(win_count)))
 
     def pam_propose_center(self, cid, slot, aos_ptr, G_ptr, n_members_local,
                            win_lo, win_count, out_ptr):

@@ -166,9 +166,9 @@ class DeviceShard:
     def pam_select(self, cid, j):
         return self.store.pam_select_member(cid, j)
 
-    def pam_prefetch_centers(self, coords, meta, count):
+    def pam_prefetch_centers(self, coords, meta, count, win_lo=0, win_count=0):
         self.store.pam_prefetch_centers(coords.data_ptr(), meta.data_ptr(),
-                                        count)
+                                        count, win_lo, win_count)
 
     def pam_propose_center(self, cid, slot, coords, meta, row, n_members_local,
                            win_lo, win_count, out):
@@ -452,7 +452,8 @@ def pam_sweep_sharded(shard, medoids, proposals=None, random_state=None,
             _share_rows(pc, pm, group, collective)
             win.gidx = [int(g) for g in
                         _to_host(shard, pm[width:width + n_guess])]
-            shard.pam_prefetch_centers(pc, pm, n_guess)
+            shard.pam_prefetch_centers(pc, pm, n_guess, win.lo,
+                                       win.hi - win.lo)
         slot = cid - win.lo
         exact = not ((win.stale >> slot) & 1)
         if exact:

@@ -265,6 +265,18 @@ int ek_pam_count_members_batch(ek_ctx *ctx, int32_t cid0, int32_t count,
 int ek_pam_select_members_batch(ek_ctx *ctx, int32_t cid0, int32_t count,
                                 const int64_t *js, int64_t *frames);
 int ek_pam_prefetch(ek_ctx *ctx, const int64_t *frames, int32_t count);
+/* The same when the caller works through clusters win_lo..win_lo+win_count-1
+ * before the next prefetch (the sweep's window; the prefetched frames are
+ * their proposals).  While the state is exact (ek_set_option key 6/7) exact
+ * distances are then computed only for the frames a proposal can touch -- the
+ * members of the window's clusters and every frame f with
+ * D(its medoid, proposal) < 2 d(f) for some proposal; for the rest "not closer
+ * than now" follows from the triangle inequality and the vector holds +inf --
+ * instead of for all of them.  Same sweep results.  ek_pam_prefetch_passes
+ * counts the prefetches of either kind. */
+int ek_pam_prefetch_window(ek_ctx *ctx, const int64_t *frames, int32_t count,
+                           int32_t win_lo, int32_t win_count);
+int ek_pam_prefetch_passes(ek_ctx *ctx, int64_t *restricted, int64_t *full);
 int ek_pam_propose_ex(ek_ctx *ctx, int32_t cid, int64_t frame_index,
                       int64_t n_members, int32_t win_lo, int32_t win_count,
                       double *old_cost, double *new_cost, int64_t *n_ambiguous,
@@ -300,6 +312,9 @@ int ek_pam_begin_table(ek_ctx *ctx, const float *aos_dev, const double *G_dev,
                        int32_t n_medoids);
 int ek_pam_prefetch_centers(ek_ctx *ctx, const float *aos_dev,
                             const double *G_dev, int32_t count);
+int ek_pam_prefetch_centers_window(ek_ctx *ctx, const float *aos_dev,
+                                   const double *G_dev, int32_t count,
+                                   int32_t win_lo, int32_t win_count);
 int ek_pam_propose_center(ek_ctx *ctx, int32_t cid, int32_t slot,
                           const float *center_aos_dev,
                           const double *center_G_dev, int64_t n_members_local,

@@ -80,7 +80,7 @@ class _PamMixin:
     def pam_select(self, cid, j):
         return int(np.flatnonzero(self.assign == cid)[j])
 
-    def pam_prefetch_centers(self, coords, meta, count):
+    def pam_prefetch_centers(self, coords, meta, count, win_lo=0, win_count=0):
         g = self._traces(meta)
         self.pf = [self._vec(coords.numpy()[j], g[j]) for j in range(count)]
 
