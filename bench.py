@@ -334,6 +334,7 @@ def main():
             dist.barrier()
         t_pam = time.perf_counter() - t0
         hits, misses = store.pam_prefetch_stats()
+        pf_restricted, pf_full = store.pam_prefetch_passes()
         out["khybrid"] = {
             "workload": "PAM sweeps over the %d centers of the run above "
                         "(k-hybrid = k-centers + k-medoids, BASELINE.json "
@@ -344,6 +345,8 @@ def main():
             "proposals_per_pass_over_frames": km_width(),
             "prefetched_proposals_used": hits,
             "proposals_with_own_pass": misses,
+            "prefetch_passes_over_touched_frames_only": pf_restricted,
+            "prefetch_passes_over_all_frames": pf_full,
         }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
