@@ -148,8 +148,6 @@ void ek_launch_assign_mfma(const float *tiles, const double *G, int64_t n, int A
 void ek_launch_gather_frames(const float *tiles, const double *G, int A,
                              const int64_t *idx_dev, int count, int first_row,
                              float *out_aos, double *outG, hipStream_t s);
-void ek_launch_copy_row(float *aos, double *Gm, int A, int src, int dst,
-                        hipStream_t s);
 void ek_launch_count_members(const int32_t *assign, int64_t n, int32_t cid,
                              int32_t *blockcnt, int64_t *scan, int64_t *total,
                              hipStream_t s);
@@ -189,9 +187,6 @@ struct EkPamOut {
     uint32_t moved;      // bit i: membership of cluster win_lo + i would change
 };
 static_assert(sizeof(EkPamOut) == 32, "EkPamOut layout");
-void ek_launch_pam_pack(const double *sq, const unsigned int *n_amb,
-                        const unsigned int *moved, int64_t n, EkPamOut *out,
-                        hipStream_t s);
 // active-set proposal prefetch (ek_pam.hip)
 void ek_launch_pam_dtab(const float *aos, const double *Gm, int A, int K, int held,
                         const unsigned char *recs, int count, float *Dtab,
@@ -220,12 +215,7 @@ void ek_launch_sumsq_pack(const float *a, const float *b, const int32_t *assign,
 void ek_launch_gather_rows(const float *tiles, const double *G, int A,
                            const int64_t *idx_dev, const int64_t *rows_dev,
                            int count, float *out_aos, double *outG, hipStream_t s);
-void ek_launch_pam_moved(const int32_t *assign, const int32_t *nassign,
-                         int64_t n, int32_t win_lo, int32_t win_count,
-                         unsigned int *mask, hipStream_t s);
 #define EK_SUMSQ_PART_DOUBLES 2048
-void ek_launch_sumsq2(const float *a, const float *b, int64_t n, double *part,
-                      double *out, hipStream_t s);
 
 // ---- multi-candidate rounds (ek_spec.hip) ---------------------------------------
 void ek_launch_plan(const unsigned char *recs, int n_recs, int A, int T,

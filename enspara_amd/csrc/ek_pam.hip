@@ -68,23 +68,6 @@ void ek_launch_gather_rows(const float *tiles, const double *G, int A,
                        tiles, G, A, idx_dev, rows_dev, out_aos, outG);
 }
 
-__global__ void __launch_bounds__(EK_BLOCK)
-ek_copy_row_kernel(float *__restrict__ aos, double *__restrict__ Gm, int A,
-                   int src, int dst)
-{
-    for (int r = threadIdx.x; r < 3 * A; r += EK_BLOCK)
-        aos[(size_t)dst * 3 * A + r] = aos[(size_t)src * 3 * A + r];
-    if (threadIdx.x == 0)
-        Gm[dst] = Gm[src];
-}
-
-void ek_launch_copy_row(float *aos, double *Gm, int A, int src, int dst,
-                        hipStream_t s)
-{
-    hipLaunchKernelGGL(ek_copy_row_kernel, dim3(1), dim3(EK_BLOCK), 0, s, aos,
-                       Gm, A, src, dst);
-}
-
 // ---- members of one cluster, in ascending frame order --------------------------
 __global__ void __launch_bounds__(EK_BLOCK)
 ek_count_members_kernel(const int32_t *__restrict__ assign, int64_t n,
@@ -484,152 +467,14 @@ void ek_launch_pam_scatter(const uint32_t *amb,
                        nassign);
 }
 
-// ---- which clusters of a window would change membership on acceptance -----------
-// bit i of *mask is set when some frame enters or leaves cluster win_lo + i in
-// going from assign to nassign.  The host uses it to tell which prefetched
-// member lists (ek_pam_count_members_batch) are still exact after an accepted
-// proposal.
-__global__ void __launch_bounds__(EK_BLOCK)
-ek_pam_moved_kernel(const int32_t *__restrict__ assign,
-                    const int32_t *__restrict__ nassign, int64_t n,
-                    int32_t win_lo, int32_t win_count,
-                    unsigned int *__restrict__ mask)
-{
-    const int64_t f = (int64_t)blockIdx.x * EK_BLOCK + threadIdx.x;
-    unsigned int m = 0;
-    if (f < n) {
-        const int32_t a = assign[f], b = nassign[f];
-        if (a != b) {
-            const int32_t ia = a - win_lo, ib = b - win_lo;
-            if (ia >= 0 && ia < win_count)
-                m |= 1u << ia;
-            if (ib >= 0 && ib < win_count)
-                m |= 1u << ib;
-        }
-    }
-    if (__syncthreads_or((int)m)) {
-        __shared__ unsigned int acc;
-        if (threadIdx.x == 0)
-            acc = 0;
-        __syncthreads();
-        if (m)
-            atomicOr(&acc, m);
-        __syncthreads();
-        if (threadIdx.x == 0)
-            atomicOr(mask, acc);
-    }
-}
-
-void ek_launch_pam_moved(const int32_t *assign, const int32_t *nassign,
-                         int64_t n, int32_t win_lo, int32_t win_count,
-                         unsigned int *mask, hipStream_t s)
-{
-    (void)hipMemsetAsync(mask, 0, sizeof(unsigned int), s);
-    if (n <= 0 || win_count <= 0)
-        return;
-    const int nblocks = (int)((n + EK_BLOCK - 1) / EK_BLOCK);
-    hipLaunchKernelGGL(ek_pam_moved_kernel, dim3(nblocks), dim3(EK_BLOCK), 0, s,
-                       assign, nassign, n, win_lo, win_count, mask);
-}
-
 // ---- cost: sum of squares in float64, fixed reduction order -----------------------
 // (kmedoids.py:478-479 takes np.square(x).mean() in float64; each square of a
 // float32 is exact in float64, only the summation order differs from numpy's
-// pairwise sum, by a few ulp of the total)
+// pairwise sum, by a few ulp of the total; kernels: ek_sumsq_moved_kernel,
+// ek_sumsq_pack_kernel below)
 #define SQ_BLOCKS 1024
 
-__global__ void __launch_bounds__(EK_BLOCK)
-ek_sumsq_partial_kernel(const float *__restrict__ a, const float *__restrict__ b,
-                        int64_t n, double *__restrict__ part)
-{
-    __shared__ double sa[EK_BLOCK], sb[EK_BLOCK];
-    const int t = threadIdx.x;
-    // contiguous slab per block, strided inside: fixed for given n
-    const int64_t per = (n + SQ_BLOCKS - 1) / SQ_BLOCKS;
-    const int64_t lo = (int64_t)blockIdx.x * per;
-    const int64_t hi = (lo + per < n) ? lo + per : n;
-    double xa = 0.0, xb = 0.0;
-    for (int64_t f = lo + t; f < hi; f += EK_BLOCK) {
-        const double va = a[f], vb = b[f];
-        xa = xa + va * va;
-        xb = xb + vb * vb;
-    }
-    sa[t] = xa;
-    sb[t] = xb;
-    __syncthreads();
-    for (int w = EK_BLOCK / 2; w > 0; w >>= 1) {
-        if (t < w) {
-            sa[t] = sa[t] + sa[t + w];
-            sb[t] = sb[t] + sb[t + w];
-        }
-        __syncthreads();
-    }
-    if (t == 0) {
-        part[2 * blockIdx.x + 0] = sa[0];
-        part[2 * blockIdx.x + 1] = sb[0];
-    }
-}
-
-__global__ void __launch_bounds__(EK_BLOCK)
-ek_sumsq_final_kernel(const double *__restrict__ part, double *__restrict__ out)
-{
-    __shared__ double sa[EK_BLOCK], sb[EK_BLOCK];
-    const int t = threadIdx.x;
-    double xa = 0.0, xb = 0.0;
-    for (int i = t; i < SQ_BLOCKS; i += EK_BLOCK) {
-        xa = xa + part[2 * i + 0];
-        xb = xb + part[2 * i + 1];
-    }
-    sa[t] = xa;
-    sb[t] = xb;
-    __syncthreads();
-    for (int w = EK_BLOCK / 2; w > 0; w >>= 1) {
-        if (t < w) {
-            sa[t] = sa[t] + sa[t + w];
-            sb[t] = sb[t] + sb[t + w];
-        }
-        __syncthreads();
-    }
-    if (t == 0) {
-        out[0] = sa[0];
-        out[1] = sb[0];
-    }
-}
-
-// out[0] = sum a^2, out[1] = sum b^2 ; part must hold 2*SQ_BLOCKS doubles
-void ek_launch_sumsq2(const float *a, const float *b, int64_t n, double *part,
-                      double *out, hipStream_t s)
-{
-    hipLaunchKernelGGL(ek_sumsq_partial_kernel, dim3(SQ_BLOCKS), dim3(EK_BLOCK),
-                       0, s, a, b, n, part);
-    hipLaunchKernelGGL(ek_sumsq_final_kernel, dim3(1), dim3(EK_BLOCK), 0, s,
-                       part, out);
-}
-
-// one shard's share of a proposal's outcome, for the cross-shard exchange
-__global__ void ek_pam_pack_kernel(const double *__restrict__ sq,
-                                   const unsigned int *__restrict__ n_amb,
-                                   const unsigned int *__restrict__ moved,
-                                   int64_t n, EkPamOut *__restrict__ out)
-{
-    if (threadIdx.x != 0)
-        return;
-    out->sum_old = sq[0];
-    out->sum_new = sq[1];
-    out->n_frames = n;
-    out->n_amb = *n_amb;
-    out->moved = moved ? *moved : 0u;
-}
-
-void ek_launch_pam_pack(const double *sq, const unsigned int *n_amb,
-                        const unsigned int *moved, int64_t n, EkPamOut *out,
-                        hipStream_t s)
-{
-    hipLaunchKernelGGL(ek_pam_pack_kernel, dim3(1), dim3(EK_WAVE), 0, s, sq, n_amb,
-                       moved, n, out);
-}
-
-// ---- fewer launches per proposal ---------------------------------------------------------
+// ---- the trial medoid table ---------------------------------------------------------------
 // One workgroup prepares the trial medoid table and the counters of a proposal:
 // (a) a row left modified by a rejected proposal is restored from row K,
 // (b) row cid is saved in row K, (c) the proposal goes into row cid -- either a
@@ -685,8 +530,11 @@ void ek_launch_pam_trial(const float *tiles, const double *G, int A, float *aos,
                        ext_aos, ext_G, amb_count, moved);
 }
 
-// cost sums (as ek_sumsq_partial_kernel) and the moved-cluster mask (as
-// ek_pam_moved_kernel) from one read of the old and the trial state
+// Cost sums of the old and the trial state (slab per workgroup, fixed order),
+// and -- for the clusters win_lo..win_lo+win_count-1 the host has drawn
+// proposals for ahead of time -- bit i of *mask set when some frame enters or
+// leaves cluster win_lo + i in going from assign to nassign (their member lists
+// are then stale after an acceptance); one read of both states
 __global__ void __launch_bounds__(EK_BLOCK)
 ek_sumsq_moved_kernel(const float *__restrict__ a, const float *__restrict__ b,
                       const int32_t *__restrict__ assign,
@@ -739,8 +587,8 @@ ek_sumsq_moved_kernel(const float *__restrict__ a, const float *__restrict__ b,
     }
 }
 
-// final sums (as ek_sumsq_final_kernel) packed with the counters into the one
-// record the host reads back
+// final sums packed with the counters into the one record the host reads back
+// (or, across shards, exchanges)
 __global__ void __launch_bounds__(EK_BLOCK)
 ek_sumsq_pack_kernel(const double *__restrict__ part,
                      const unsigned int *__restrict__ n_amb,
