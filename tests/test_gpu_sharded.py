@@ -121,3 +121,74 @@ def test_device_shard_khybrid_one_rank_rccl(tmp_path):
     np.testing.assert_array_equal(r["med"], inds)
     np.testing.assert_array_equal(r["a"], wa)
     np.testing.assert_array_equal(r["d"].astype(np.float64), wd)
+
+
+# Two ranks, each with its own FrameStore on the one GPU of the test box.  RCCL
+# refuses two ranks on one device, so the collectives of this test go through
+# gloo with the payload staged in host memory (patched in the child only); what
+# is under test is the device side of the multi-shard protocol: candidate
+# records and chained rounds across shards, the PAM table / proposal exchange,
+# per-rank propose + the gathered decision.
+_CHILD2 = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+import torch
+import torch.distributed as dist
+rank, world, port, out = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + port,
+                        rank=rank, world_size=world)
+_agit, _ar = dist.all_gather_into_tensor, dist.all_reduce
+def agit(out_t, in_t, group=None):
+    torch.cuda.current_stream().synchronize()
+    o = torch.empty(out_t.shape, dtype=out_t.dtype)
+    _agit(o, in_t.cpu(), group=group)
+    out_t.copy_(o)
+def ar(t, op=dist.ReduceOp.SUM, group=None):
+    torch.cuda.current_stream().synchronize()
+    h = t.cpu()
+    _ar(h, op=op, group=group)
+    t.copy_(h)
+dist.all_gather_into_tensor, dist.all_reduce = agit, ar
+from enspara_amd import sharded, synth
+from enspara_amd.device import FrameStore
+n, A, K = 6000, 14, 45
+x = synth.synth(n, A, 9, seed=21)
+lo, cnt = sharded.shard_bounds(n, world, rank)
+torch.cuda.set_device(0)
+ts = torch.cuda.Stream(device=0)
+with FrameStore(cnt, A, device=0, global_offset=lo, stream=ts.cuda_stream) as st:
+    st.load(x[lo:lo + cnt])
+    st.reset_state()
+    sh = sharded.DeviceShard(st)
+    with torch.cuda.stream(ts):
+        med = sharded.khybrid_sharded(sh, K, 0.0, 2, random_state=5)
+    d, a = st.download_state()
+np.savez(out + ".%d.npz" % rank, med=np.array(med), d=d, a=a, lo=lo)
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_two_device_shards_on_one_gpu(tmp_path):
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = str(s.getsockname()[1])
+    s.close()
+    out = str(tmp_path / "r")
+    procs = [subprocess.Popen([sys.executable, "-c", _CHILD2, ROOT, str(r), "2",
+                               port, out], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True)
+             for r in range(2)]
+    logs = [p.communicate(timeout=900)[0] for p in procs]
+    for p, log in zip(procs, logs):
+        assert p.returncode == 0, log[-4000:]
+    parts = [np.load(out + ".%d.npz" % r) for r in range(2)]
+    x = synth.synth(6000, 14, 9, seed=21)
+    inds, wa, wd = _expected(x, 45, 2, 5)
+    for p in parts:
+        np.testing.assert_array_equal(p["med"], inds)
+    np.testing.assert_array_equal(np.concatenate([p["a"] for p in parts]), wa)
+    np.testing.assert_array_equal(
+        np.concatenate([p["d"] for p in parts]).astype(np.float64), wd)
