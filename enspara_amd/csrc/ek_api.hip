@@ -120,6 +120,7 @@ struct ek_ctx {
     int64_t act_cap = 0;
     unsigned int *act_n_host = nullptr;  // pinned
     int64_t pf_sparse = 0, pf_full = 0;  // prefetch passes of either kind
+    int32_t pf_backoff = 0;          // windows to go before the restricted form is tried again
     int prune = 1;                   // use it (option key 6)
     bool state_exact = true;         // dist[f] IS the distance to medoid assign[f]
     int64_t *tmp_idx = nullptr;      // scratch for index lists
@@ -1047,6 +1048,7 @@ static int ek_pam_alloc(ek_ctx *c, int32_t K)
                              hipHostMallocDefault));
     }
     c->pam_restore = -1;
+    c->pf_backoff = 0;
     c->bat_cid0 = -1;
     c->bat_count = 0;
     c->pf_count = 0;
@@ -1510,7 +1512,9 @@ static int ek_pam_prefetch_vectors(ek_ctx *c, int count, int32_t win_lo,
                                    int32_t win_count)
 {
     const int K = c->med_K;
-    if (c->prune && c->state_exact && win_count > 0 && c->n >= 16384) {
+    if (c->pf_backoff > 0)
+        --c->pf_backoff;
+    else if (c->prune && c->state_exact && win_count > 0 && c->n >= 16384) {
         if (!c->act_n_host)
             EK_HIP(hipHostMalloc((void **)&c->act_n_host, sizeof(unsigned int),
                                  hipHostMallocDefault));
@@ -1555,6 +1559,9 @@ static int ek_pam_prefetch_vectors(ek_ctx *c, int count, int32_t win_lo,
             ++c->pf_sparse;
             return EK_OK;
         }
+        // too many frames within reach (large clusters): the test cost a table,
+        // a scan and a read-back for nothing -- leave it out for a while
+        c->pf_backoff = 15;
     }
     ek_launch_pass_dist(count, c->tiles, c->G, c->pam_vecs, c->n, c->n_pad, c->A,
                         c->pam_recs, c->pam_plan, c->stream);
