@@ -134,6 +134,7 @@ struct ek_ctx {
     float *vecs = nullptr;       // [EK_MAX_CANDS-1][n_pad] stored distance vectors
     EkMaxHdr *hdr = nullptr;
     EkBlockMax *pm = nullptr;    // [EK_MAX_CANDS-1][nb] per-prefix maxima (ek_chain.hip)
+    unsigned char *top = nullptr;    // scratch of the candidate pick (ek_spec.hip)
     int chain = 1;               // 1: chained cheap steps, 0: one launch pair per center
     int64_t n_pad = 0;
     int32_t last_passes = 0;
@@ -201,6 +202,8 @@ static int ek_pick_cands(const ek_ctx *c)
 
 static int ek_spec_alloc(ek_ctx *c)
 {
+    if (!c->top)
+        EK_HIP(hipMalloc((void **)&c->top, ek_top_scratch_bytes(c->A)));
     if (!c->pm) {
         const size_t nb = ((size_t)std::max<int64_t>(c->n, 1) + EK_BLOCK - 1) /
                           EK_BLOCK;
@@ -273,6 +276,7 @@ static int ek_free_all(ek_ctx *c)
     (void)hipFree(c->vecs);
     (void)hipFree(c->hdr);
     (void)hipFree(c->pm);
+    (void)hipFree(c->top);
     (void)hipFree(c->ndist);
     (void)hipFree(c->nassign);
     (void)hipFree(c->amb);
@@ -779,7 +783,7 @@ extern "C" int ek_kcenters_run(ek_ctx *c, int32_t first_label, int32_t max_new,
         EK_HIP(hipEventRecord(c->ev0, c->stream));
         ek_launch_blockmax(c->dist, c->n, c->blockmax, c->stream);
         ek_launch_pickT(c->blockmax, nb, c->tiles, c->G, c->assign, c->A, T, c->goff,
-                        c->recsT, c->ctl, c->stream);
+                        c->recsT, c->ctl, c->top, c->stream);
         EK_CHECK_LAUNCH();
         EkCtl cr;
         memset(&cr, 0, sizeof(cr));
@@ -833,7 +837,7 @@ extern "C" int ek_kcenters_run(ek_ctx *c, int32_t first_label, int32_t max_new,
                     }
                 }
                 ek_launch_pickT(c->blockmax, nb, c->tiles, c->G, c->assign, c->A, T,
-                                c->goff, c->recsT, c->ctl, c->stream);
+                                c->goff, c->recsT, c->ctl, c->top, c->stream);
                 EK_CHECK_LAUNCH();
             }
             passes += rounds;
@@ -1818,7 +1822,7 @@ extern "C" int ek_spec_begin(ek_ctx *c, int32_t first_label, int32_t limit,
     const int nb = (int)((c->n + EK_BLOCK - 1) / EK_BLOCK);
     ek_launch_blockmax(c->dist, c->n, c->blockmax, c->stream);
     ek_launch_pickT(c->blockmax, nb, c->tiles, c->G, c->assign, c->A, T, c->goff,
-                    recs_out ? (unsigned char *)recs_out : c->recsT, c->ctl,
+                    recs_out ? (unsigned char *)recs_out : c->recsT, c->ctl, c->top,
                     c->stream);
     EK_CHECK_LAUNCH();
     return EK_OK;
@@ -1946,7 +1950,7 @@ extern "C" int ek_spec_round_end(ek_ctx *c, void *recs_out)
     const int T = std::max(ek_pick_cands(c), 1);
     const int nb = (int)((c->n + EK_BLOCK - 1) / EK_BLOCK);
     ek_launch_pickT(c->blockmax, nb, c->tiles, c->G, c->assign, c->A, T, c->goff,
-                    recs_out ? (unsigned char *)recs_out : c->recsT, c->ctl,
+                    recs_out ? (unsigned char *)recs_out : c->recsT, c->ctl, c->top,
                     c->stream);
     EK_CHECK_LAUNCH();
     return EK_OK;

@@ -270,10 +270,11 @@ void ek_launch_check(const EkMaxHdr *hdrs, int n_hdrs, double cutoff,
 void ek_launch_apply(const float *vecs, const double *G, int64_t n,
                      int64_t n_pad, int A, float *dist, int32_t *assign,
                      const EkPlan *plan, EkBlockMax *blockmax, hipStream_t s);
+size_t ek_top_scratch_bytes(int A);
 void ek_launch_pickT(const EkBlockMax *blockmax, int nb, const float *tiles,
                      const double *G, const int32_t *assign, int A, int T,
                      int64_t global_offset, unsigned char *recs, EkCtl *ctl,
-                     hipStream_t s);
+                     unsigned char *scratch, hipStream_t s);
 void ek_launch_localmax_check(const EkBlockMax *blockmax, int nb,
                               int64_t global_offset, double cutoff,
                               EkPlan *plan, EkHist *hist, EkCtl *ctl,

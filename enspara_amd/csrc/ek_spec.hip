@@ -700,38 +700,65 @@ void ek_launch_apply(const float *vecs, const double *G, int64_t n,
                        plan, blockmax);
 }
 
-// the shard's T candidate records for the next round: record 0 is its
-// first-index arg-max, records 1.. the best frames of the next-best
-// workgroups, preferring frames whose current label differs from the labels of
-// the candidates already chosen (two far frames of one cluster tend to be
-// near each other, and then only one of them can become a center).  Any far
-// frames would do: correctness never depends on the guesses.
+// ---------------------------------------------------------------------------
+// the shard's T candidate records for the next round
+// ---------------------------------------------------------------------------
+// Any far frames would do -- correctness never depends on the guesses -- but the
+// more of the following farthest points are among them, the fewer passes the
+// fit needs.  So the pick plays the k-centers game ahead on the shard's
+// EK_TOP_M farthest workgroup maxima: their pairwise distances are computed
+// (EK_TOP_M^2/2 pairs, nothing next to a pass), and the candidates are taken
+// greedily -- the frame with the largest remaining distance, after which every
+// other one's distance is lowered by its distance to it -- exactly the order in
+// which the fit itself would take them if no frame outside the set interfered.
+// Record 0 is therefore the shard's first-index arg-max, as the protocol needs.
+// (In a CPU model of the rounds this raised the centers per pass from 5.1 to 6.6
+// against picking the top maxima with distinct labels.)
+#define EK_TOP_M 32
+
+struct EkTop {
+    int32_t n;
+    int32_t pad;
+    uint32_t idx[EK_TOP_M];
+    float val[EK_TOP_M];
+};
+
+size_t ek_top_scratch_bytes(int A)
+{
+    // EkTop | coords [M][3A] f32 | traces [M] f64 | D [M][M] f32
+    return 1024 + (size_t)EK_TOP_M * 3 * A * sizeof(float) +
+           EK_TOP_M * sizeof(double) + (size_t)EK_TOP_M * EK_TOP_M * sizeof(float);
+}
+
+__device__ __forceinline__ float *ek_top_coords(unsigned char *scr)
+{
+    return (float *)(scr + 1024);
+}
+__device__ __forceinline__ double *ek_top_traces(unsigned char *scr, int A)
+{
+    return (double *)(scr + 1024 + (size_t)EK_TOP_M * 3 * A * sizeof(float));
+}
+__device__ __forceinline__ float *ek_top_D(unsigned char *scr, int A)
+{
+    return (float *)(scr + 1024 + (size_t)EK_TOP_M * 3 * A * sizeof(float) +
+                     EK_TOP_M * sizeof(double));
+}
+
+// the EK_TOP_M largest per-workgroup maxima, ordered (value desc, index asc)
 __global__ void __launch_bounds__(EK_RED_THREADS)
-ek_pickT_kernel(const EkBlockMax *__restrict__ blockmax, int nb,
-                const float *__restrict__ tiles, const double *__restrict__ G,
-                const int32_t *__restrict__ assign, int A, int T,
-                int64_t global_offset, unsigned char *__restrict__ recs,
-                EkCtl *__restrict__ ctl)
+ek_pick_top_kernel(const EkBlockMax *__restrict__ blockmax, int nb,
+                   EkTop *__restrict__ top)
 {
     extern __shared__ uint32_t skip[];       // bitmap over workgroups
-    __shared__ uint32_t sel_i[EK_MAX_CANDS];
-    __shared__ float sel_v[EK_MAX_CANDS];
-    __shared__ int32_t sel_lab[EK_MAX_CANDS];
-    __shared__ int n_sel;
-    __shared__ uint32_t top_i[EK_MAX_CANDS + 4];
-    __shared__ float top_v[EK_MAX_CANDS + 4];
-    __shared__ int32_t top_lab[EK_MAX_CANDS + 4];
+    __shared__ uint32_t top_i[EK_TOP_M];
+    __shared__ float top_v[EK_TOP_M];
     __shared__ int n_top;
     const int tid = threadIdx.x;
     for (int w = tid; w < (nb + 31) / 32; w += EK_RED_THREADS)
         skip[w] = 0;
-    if (tid == 0) {
-        n_sel = 0;
+    if (tid == 0)
         n_top = 0;
-    }
     __syncthreads();
-    // at most T + 4 looks: a few candidates may be passed over for carrying a
-    // label that is already represented, as long as T can still be filled.
     // The per-workgroup maxima are read once: every thread keeps its (up to
     // PICK_PER) entries in registers across the looks; larger shards fall back
     // to re-reading them.
@@ -753,17 +780,20 @@ ek_pickT_kernel(const EkBlockMax *__restrict__ blockmax, int nb,
         }
     }
     constexpr int NWV = EK_RED_THREADS / EK_WAVE;
-    constexpr int LMAX = EK_MAX_CANDS + 4;
-    __shared__ float wt_v[NWV * LMAX];
-    __shared__ uint32_t wt_i[NWV * LMAX];
-    const int max_looks = T + 4;
+    constexpr int LW = 6;                // looks per wave
+    __shared__ float wt_v[NWV * LW];
+    __shared__ uint32_t wt_i[NWV * LW];
+    const int max_looks = EK_TOP_M;
     if (cached) {
-        // Two levels, no workgroup barrier inside the looks: every wave takes the
-        // top max_looks of its own entries with wave-wide arg-max steps, then
-        // wave 0 takes the top max_looks of those NWV lists -- the same ordered
-        // list as max_looks arg-max passes over all entries.
+        // Level 1: every wave takes the LW best of its own entries with wave-wide
+        // arg-max steps (no workgroup barrier).  Level 2: the NWV * LW survivors
+        // are ranked against one another, one thread each, and the best EK_TOP_M
+        // land in order.  The workgroups' maxima are spread over the waves at
+        // random, so this is the true top list except when more than LW of it
+        // fall into one wave -- which only costs a slightly worse guess; entry 0
+        // is always the overall first-index arg-max.
         const int lane = tid & (EK_WAVE - 1), wv = tid / EK_WAVE;
-        for (int look = 0; look < max_looks; ++look) {
+        for (int look = 0; look < LW; ++look) {
             float v = -__builtin_inff();
             uint32_t i = 0xffffffffu;
 #pragma unroll
@@ -780,49 +810,31 @@ ek_pickT_kernel(const EkBlockMax *__restrict__ blockmax, int nb,
                         ci[k] = 0xffffffffu;
             }
             if (lane == 0) {
-                wt_v[wv * LMAX + look] = v;
-                wt_i[wv * LMAX + look] = i;
+                wt_v[wv * LW + look] = v;
+                wt_i[wv * LW + look] = i;
             }
         }
         __syncthreads();
-        if (wv == 0) {
-            constexpr int PER2 = (NWV * LMAX + EK_WAVE - 1) / EK_WAVE;
-            float ev[PER2];
-            uint32_t ei[PER2];
-#pragma unroll
-            for (int k = 0; k < PER2; ++k) {
-                const int e = lane + k * EK_WAVE;
-                const int w = e / LMAX, l = e % LMAX;
-                const bool ok = w < NWV && l < max_looks;
-                ev[k] = ok ? wt_v[w * LMAX + l] : -__builtin_inff();
-                ei[k] = ok ? wt_i[w * LMAX + l] : 0xffffffffu;
-            }
-            int cnt = 0;
-            for (int look = 0; look < max_looks; ++look) {
-                float v = -__builtin_inff();
-                uint32_t i = 0xffffffffu;
-#pragma unroll
-                for (int k = 0; k < PER2; ++k)
-                    if (ei[k] != 0xffffffffu && ek_better(ev[k], ei[k], v, i)) {
-                        v = ev[k];
-                        i = ei[k];
-                    }
-                ek_wave_argmax(v, i);
-                if (i == 0xffffffffu)
-                    break;
-#pragma unroll
-                for (int k = 0; k < PER2; ++k)
-                    if (ei[k] == i)
-                        ei[k] = 0xffffffffu;
-                if (lane == 0) {
-                    top_i[cnt] = i;
-                    top_v[cnt] = v;
+        if (tid < NWV * LW) {
+            const float v = wt_v[tid];
+            const uint32_t i = wt_i[tid];
+            if (i != 0xffffffffu) {
+                int rank = 0;
+                for (int e = 0; e < NWV * LW; ++e) {
+                    const uint32_t oi = wt_i[e];
+                    if (oi != 0xffffffffu && ek_better(wt_v[e], oi, v, i))
+                        ++rank;
                 }
-                ++cnt;
+                if (rank < EK_TOP_M) {
+                    top_i[rank] = i;
+                    top_v[rank] = v;
+                }
+                atomicAdd(&n_top, 1);
             }
-            if (lane == 0)
-                n_top = cnt;
         }
+        __syncthreads();
+        if (tid == 0 && n_top > EK_TOP_M)
+            n_top = EK_TOP_M;
     } else {
         for (int look = 0; look < max_looks; ++look) {
             float v;
@@ -841,25 +853,125 @@ ek_pickT_kernel(const EkBlockMax *__restrict__ blockmax, int nb,
         }
     }
     __syncthreads();
-    // labels of the looked-at frames, fetched in parallel
-    if (tid < n_top)
-        top_lab[tid] = assign[top_i[tid]];
+    if (tid < EK_TOP_M) {
+        top->idx[tid] = (tid < n_top) ? top_i[tid] : 0xffffffffu;
+        top->val[tid] = (tid < n_top) ? top_v[tid] : -__builtin_inff();
+    }
+    if (tid == 0)
+        top->n = n_top;
+}
+
+// their centred coordinates and traces; every read is its own cache line, so
+// they are spread over many workgroups (one thread per value)
+__global__ void __launch_bounds__(EK_BLOCK)
+ek_top_gather_kernel(const float *__restrict__ tiles,
+                     const double *__restrict__ G, int A,
+                     unsigned char *__restrict__ scr)
+{
+    const EkTop *top = (const EkTop *)scr;
+    const int j = blockIdx.y;
+    if (j >= top->n)
+        return;
+    const int r = blockIdx.x * EK_BLOCK + threadIdx.x;
+    const uint32_t i = top->idx[j];
+    if (r == 0)
+        ek_top_traces(scr, A)[j] = G[i];
+    if (r >= 3 * A)
+        return;
+    const float *p = tiles + (size_t)(i / EK_TILE) * 3 * (size_t)A * EK_TILE +
+                     (i % EK_TILE);
+    ek_top_coords(scr)[(size_t)j * 3 * A + r] = p[(size_t)r * EK_TILE];
+}
+
+// their pairwise distances, one wave per pair (lanes strided over the atoms: the
+// values only steer the guesses, their summation order is free)
+__global__ void __launch_bounds__(EK_BLOCK)
+ek_top_pair_kernel(int A, unsigned char *__restrict__ scr)
+{
+    const EkTop *top = (const EkTop *)scr;
+    const int lane = threadIdx.x & (EK_WAVE - 1);
+    const int w = blockIdx.x * (EK_BLOCK / EK_WAVE) + threadIdx.x / EK_WAVE;
+    const int i = w / EK_TOP_M, j = w % EK_TOP_M;
+    if (i >= j || j >= top->n)
+        return;
+    const float *x = ek_top_coords(scr) + (size_t)i * 3 * A;
+    const float *y = ek_top_coords(scr) + (size_t)j * 3 * A;
+    float S[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int a = lane; a < A; a += EK_WAVE) {
+        const float x0 = x[3 * a], x1 = x[3 * a + 1], x2 = x[3 * a + 2];
+        const float y0 = y[3 * a], y1 = y[3 * a + 1], y2 = y[3 * a + 2];
+        S[0] += x0 * y0; S[1] += x0 * y1; S[2] += x0 * y2;
+        S[3] += x1 * y0; S[4] += x1 * y1; S[5] += x1 * y2;
+        S[6] += x2 * y0; S[7] += x2 * y1; S[8] += x2 * y2;
+    }
+#pragma unroll
+    for (int q = 0; q < 9; ++q)
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1)
+            S[q] += __shfl_xor(S[q], off, 64);
+    if (lane == 0) {
+        const double *Gt = ek_top_traces(scr, A);
+        const float d = ek_rmsd_from_S(S, Gt[i], Gt[j], A);
+        float *D = ek_top_D(scr, A);
+        D[i * EK_TOP_M + j] = d;
+        D[j * EK_TOP_M + i] = d;
+    }
+}
+
+// the greedy order, and the records of its first T frames
+__global__ void __launch_bounds__(EK_BLOCK)
+ek_top_records_kernel(int A, int T, int64_t global_offset,
+                      unsigned char *__restrict__ scr,
+                      unsigned char *__restrict__ recs, EkCtl *__restrict__ ctl)
+{
+    __shared__ int sel[EK_MAX_CANDS];
+    __shared__ int n_sel;
+    __shared__ float sD[EK_TOP_M * EK_TOP_M];
+    __shared__ float sval[EK_TOP_M];
+    __shared__ uint32_t sidx[EK_TOP_M];
+    const EkTop *top = (const EkTop *)scr;
+    const int tid = threadIdx.x;
+    {   // the table into LDS first: the greedy loop is one thread's dependent reads
+        const float *D = ek_top_D(scr, A);
+        for (int k = tid; k < EK_TOP_M * EK_TOP_M; k += EK_BLOCK)
+            sD[k] = D[k];
+        if (tid < EK_TOP_M) {
+            sval[tid] = top->val[tid];
+            sidx[tid] = top->idx[tid];
+        }
+    }
     __syncthreads();
-    if (tid == 0) {
-        const int nt = n_top;
-        for (int look = 0; look < nt && n_sel < T; ++look) {
-            const int32_t lab = top_lab[look];
-            bool dup = false;
-            const bool can_skip = (nt - look - 1) >= (T - n_sel);
-            if (can_skip && lab >= 0)
-                for (int j = 0; j < n_sel; ++j)
-                    dup = dup || (sel_lab[j] == lab);
-            if (!dup || n_sel == 0) {
-                sel_i[n_sel] = top_i[look];
-                sel_v[n_sel] = top_v[look];
-                sel_lab[n_sel] = lab;
-                n_sel = n_sel + 1;
+    if (tid < EK_WAVE) {
+        // the greedy order, one wave: lane l holds entry l's remaining distance
+        static_assert(EK_TOP_M <= EK_WAVE, "one lane per entry");
+        const int nt = top->n;
+        const int lane = tid;
+        bool open = lane < nt;
+        float cur = open ? sval[lane] : 0.f;
+        const uint32_t ix = (lane < EK_TOP_M) ? sidx[lane] : 0xffffffffu;
+        int ns = 0;
+        while (ns < T) {
+            float v = open ? cur : -__builtin_inff();
+            uint32_t i = open ? ix : 0xffffffffu;
+            ek_wave_argmax(v, i);
+            if (i == 0xffffffffu)
+                break;
+            const unsigned long long who = __ballot(open && ix == i);
+            const int best = __ffsll((long long)who) - 1;
+            if (lane == best)
+                open = false;
+            if (lane == 0)
+                sel[ns] = best;
+            ++ns;
+            if (lane < EK_TOP_M) {
+                const float d = sD[best * EK_TOP_M + lane];
+                if (open && d < cur)
+                    cur = d;
             }
+        }
+        if (lane == 0) {
+            n_sel = ns;
+            ctl->last_max = (ns > 0) ? sval[sel[0]] : -__builtin_inff();
         }
     }
     __syncthreads();
@@ -868,10 +980,11 @@ ek_pickT_kernel(const EkBlockMax *__restrict__ blockmax, int nb,
     if (tid < T) {
         EkRecHdr *h = (EkRecHdr *)(recs + (size_t)tid * rstride);
         if (tid < ns) {
-            h->maxdist = sel_v[tid];
+            const int s = sel[tid];
+            h->maxdist = top->val[s];
             h->valid = 1;
-            h->gidx = global_offset + (int64_t)sel_i[tid];
-            h->trace = G[sel_i[tid]];
+            h->gidx = global_offset + (int64_t)top->idx[s];
+            h->trace = ek_top_traces(scr, A)[s];
             h->reserved = 0;
         } else {
             h->maxdist = -__builtin_inff();
@@ -881,43 +994,31 @@ ek_pickT_kernel(const EkBlockMax *__restrict__ blockmax, int nb,
             h->reserved = 0;
         }
     }
-    if (tid == 0)
-        ctl->last_max = (ns > 0) ? sel_v[0] : -__builtin_inff();
-}
-
-// the candidates' coordinates: every read is its own cache line, so they are
-// spread over many workgroups (one thread per value) instead of being queued
-// behind the selection in its single workgroup
-__global__ void __launch_bounds__(EK_BLOCK)
-ek_record_gather_kernel(const float *__restrict__ tiles, int A,
-                        int64_t global_offset, unsigned char *__restrict__ recs)
-{
-    const size_t rstride = ek_rec_bytes(A);
-    const int j = blockIdx.y;
-    const EkRecHdr *h = (const EkRecHdr *)(recs + (size_t)j * rstride);
-    if (!h->valid)
-        return;
-    const int r = blockIdx.x * EK_BLOCK + threadIdx.x;
-    if (r >= 3 * A)
-        return;
-    const int64_t i = h->gidx - global_offset;
-    const float *p = tiles + (size_t)(i / EK_TILE) * 3 * (size_t)A * EK_TILE +
-                     (i % EK_TILE);
-    float *coords = (float *)(recs + (size_t)j * rstride + sizeof(EkRecHdr));
-    coords[r] = p[(size_t)r * EK_TILE];
+    const float *tc = ek_top_coords(scr);
+    for (int k = tid; k < ns * 3 * A; k += EK_BLOCK) {
+        const int j = k / (3 * A), r = k % (3 * A);
+        float *coords = (float *)(recs + (size_t)j * rstride + sizeof(EkRecHdr));
+        coords[r] = tc[(size_t)sel[j] * 3 * A + r];
+    }
 }
 
 void ek_launch_pickT(const EkBlockMax *blockmax, int nb, const float *tiles,
                      const double *G, const int32_t *assign, int A, int T,
                      int64_t global_offset, unsigned char *recs, EkCtl *ctl,
-                     hipStream_t s)
+                     unsigned char *scratch, hipStream_t s)
 {
+    (void)assign;
     const size_t lds = (size_t)((nb + 31) / 32 + 1) * sizeof(uint32_t);
-    hipLaunchKernelGGL(ek_pickT_kernel, dim3(1), dim3(EK_RED_THREADS), lds, s,
-                       blockmax, nb, tiles, G, assign, A, T, global_offset, recs,
-                       ctl);
-    hipLaunchKernelGGL(ek_record_gather_kernel,
+    hipLaunchKernelGGL(ek_pick_top_kernel, dim3(1), dim3(EK_RED_THREADS), lds, s,
+                       blockmax, nb, (EkTop *)scratch);
+    hipLaunchKernelGGL(ek_top_gather_kernel,
                        dim3((unsigned)((3 * A + EK_BLOCK - 1) / EK_BLOCK),
-                            (unsigned)T),
-                       dim3(EK_BLOCK), 0, s, tiles, A, global_offset, recs);
+                            (unsigned)EK_TOP_M),
+                       dim3(EK_BLOCK), 0, s, tiles, G, A, scratch);
+    hipLaunchKernelGGL(ek_top_pair_kernel,
+                       dim3((unsigned)(EK_TOP_M * EK_TOP_M /
+                                       (EK_BLOCK / EK_WAVE))),
+                       dim3(EK_BLOCK), 0, s, A, scratch);
+    hipLaunchKernelGGL(ek_top_records_kernel, dim3(1), dim3(EK_BLOCK), 0, s, A, T,
+                       global_offset, scratch, recs, ctl);
 }
