@@ -135,6 +135,7 @@ struct ek_ctx {
     EkMaxHdr *hdr = nullptr;
     EkBlockMax *pm = nullptr;    // [EK_MAX_CANDS-1][nb] per-prefix maxima (ek_chain.hip)
     unsigned char *top = nullptr;    // scratch of the candidate pick (ek_spec.hip)
+    float *planD = nullptr;          // [64][64] distances between the records on offer
     int chain = 1;               // 1: chained cheap steps, 0: one launch pair per center
     int64_t n_pad = 0;
     int32_t last_passes = 0;
@@ -204,6 +205,8 @@ static int ek_spec_alloc(ek_ctx *c)
 {
     if (!c->top)
         EK_HIP(hipMalloc((void **)&c->top, ek_top_scratch_bytes(c->A)));
+    if (!c->planD)
+        EK_HIP(hipMalloc((void **)&c->planD, 64 * 64 * sizeof(float)));
     if (!c->pm) {
         const size_t nb = ((size_t)std::max<int64_t>(c->n, 1) + EK_BLOCK - 1) /
                           EK_BLOCK;
@@ -277,6 +280,7 @@ static int ek_free_all(ek_ctx *c)
     (void)hipFree(c->hdr);
     (void)hipFree(c->pm);
     (void)hipFree(c->top);
+    (void)hipFree(c->planD);
     (void)hipFree(c->ndist);
     (void)hipFree(c->nassign);
     (void)hipFree(c->amb);
@@ -798,7 +802,7 @@ extern "C" int ek_kcenters_run(ek_ctx *c, int32_t first_label, int32_t max_new,
                 2, std::min(256, (int32_t)(left / per_round) + 1));
             const int32_t before = cr.n_done;
             for (int32_t r = 0; r < rounds; ++r) {
-                ek_launch_plan(c->recsT, T, c->A, T, dist_cutoff, c->plan,
+                ek_launch_plan(c->recsT, T, c->A, T, dist_cutoff, c->planD, c->plan,
                                c->hist, c->ctl, c->stream);
                 const bool sample =
                     c->samp_every > 0 &&
@@ -1840,7 +1844,7 @@ extern "C" int ek_spec_round(ek_ctx *c, const void *recs_all, int32_t n_recs,
                                   "off (use ek_kcenters_step)");
     if (!c->vecs)
         return ek_fail(EK_ESTATE, "ek_spec_round: call ek_spec_begin first");
-    ek_launch_plan((const unsigned char *)recs_all, n_recs, c->A, T, dist_cutoff,
+    ek_launch_plan((const unsigned char *)recs_all, n_recs, c->A, T, dist_cutoff, c->planD,
                    c->plan, c->hist, c->ctl, c->stream);
     const bool sample = c->samp_every > 0 &&
                         (c->samp_count++ % c->samp_every) == 0 &&

@@ -219,8 +219,8 @@ void ek_launch_gather_rows(const float *tiles, const double *G, int A,
 
 // ---- multi-candidate rounds (ek_spec.hip) ---------------------------------------
 void ek_launch_plan(const unsigned char *recs, int n_recs, int A, int T,
-                    double cutoff, EkPlan *plan, EkHist *hist, EkCtl *ctl,
-                    hipStream_t s);
+                    double cutoff, float *D, EkPlan *plan, EkHist *hist,
+                    EkCtl *ctl, hipStream_t s);
 size_t ek_pass_lds_bytes(int T, int A);
 void ek_launch_pass(int T, const float *tiles, const double *G, float *dist,
                     int32_t *assign, float *vecs, int64_t n, int64_t n_pad,

@@ -45,54 +45,91 @@
 // index asc) -- position 0 is the global first-index arg-max (kcenters.py:337:
 // lowest rank wins ties; ranks own ascending contiguous blocks).
 // ---------------------------------------------------------------------------
+// D (optional): pairwise distances of the records on offer, [64][64].  With it
+// the candidates after the first are taken greedily like ek_top_records_kernel
+// does within one shard -- the record with the largest remaining distance, then
+// every other one's is lowered by its distance to it -- instead of by their own
+// distances alone: records offered by different shards may be close to one
+// another.  One wave, lane r = record r.
 __global__ void __launch_bounds__(EK_WAVE)
 ek_plan_kernel(const unsigned char *__restrict__ recs, int n_recs, int A, int T,
-               double cutoff, EkPlan *__restrict__ plan,
-               EkHist *__restrict__ hist, EkCtl *__restrict__ ctl)
+               double cutoff, const float *__restrict__ D,
+               EkPlan *__restrict__ plan, EkHist *__restrict__ hist,
+               EkCtl *__restrict__ ctl)
 {
-    if (threadIdx.x != 0)
-        return;
+    const int lane = threadIdx.x;
     const size_t rstride = ek_rec_bytes(A);
-    plan->go = 0;
-    plan->apply = -1;
-    plan->miss = 1;
-    plan->used = 0;
-    plan->teff = 0;
+    if (lane == 0) {
+        plan->go = 0;
+        plan->apply = -1;
+        plan->miss = 1;
+        plan->used = 0;
+        plan->teff = 0;
+        plan->chain_n = 0;
+        plan->napply = 0;
+    }
     if (ctl->stopped || ctl->n_done >= ctl->limit)
         return;
-    unsigned long long taken = 0;          // n_recs <= 64
+    bool open = false;
+    float orig = -__builtin_inff();
+    long long g = 0x7fffffffffffffffLL;
+    double tr = 0.0;
+    if (lane < n_recs) {
+        const EkRecHdr *h = (const EkRecHdr *)(recs + (size_t)lane * rstride);
+        if (h->valid) {
+            open = true;
+            orig = h->maxdist;
+            g = h->gidx;
+            tr = h->trace;
+        }
+    }
+    float cur = orig;
     int teff = 0;
+    float first_max = 0.f;
+    long long first_g = 0;
     for (int j = 0; j < T; ++j) {
-        int best = -1;
-        float bv = 0.f;
-        long long bg = 0;
-        for (int r = 0; r < n_recs; ++r) {
-            if (taken & (1ull << r))
-                continue;
-            const EkRecHdr *h = (const EkRecHdr *)(recs + (size_t)r * rstride);
-            if (!h->valid)
-                continue;
-            if (best < 0 || h->maxdist > bv ||
-                (h->maxdist == bv && h->gidx < bg)) {
-                best = r;
-                bv = h->maxdist;
-                bg = h->gidx;
+        // arg-max over the open records: largest remaining distance, lowest
+        // global index on ties (kcenters.py:337 for position 0)
+        float v = open ? cur : -__builtin_inff();
+        long long bg = open ? g : 0x7fffffffffffffffLL;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float ov = __shfl_xor(v, off, 64);
+            const long long og = __shfl_xor(bg, off, 64);
+            if (ov > v || (ov == v && og < bg)) {
+                v = ov;
+                bg = og;
             }
         }
-        if (best < 0)
+        const unsigned long long who = __ballot(open && g == bg);
+        if (who == 0)
             break;
-        taken |= 1ull << best;
-        plan->src[j] = best;
-        plan->gidx[j] = bg;
-        plan->maxdist[j] = bv;
-        plan->trace[j] =
-            ((const EkRecHdr *)(recs + (size_t)best * rstride))->trace;
+        const int w = __ffsll((long long)who) - 1;
+        const float w_orig = __shfl(orig, w, 64);
+        const double w_tr = __shfl(tr, w, 64);
+        if (lane == 0) {
+            plan->src[j] = w;
+            plan->gidx[j] = bg;
+            plan->maxdist[j] = w_orig;
+            plan->trace[j] = w_tr;
+        }
+        if (j == 0) {
+            first_max = w_orig;
+            first_g = bg;
+        }
+        if (lane == w)
+            open = false;
+        if (D) {
+            const float d = D[w * 64 + lane];
+            if (open && d < cur)
+                cur = d;
+        }
         ++teff;
     }
-    if (teff == 0)
+    if (teff == 0 || lane != 0)
         return;
     // stop rule of kcenters.py:217
-    if (!((double)plan->maxdist[0] > cutoff)) {
+    if (!((double)first_max > cutoff)) {
         ctl->stopped = 1;
         return;
     }
@@ -102,19 +139,65 @@ ek_plan_kernel(const unsigned char *__restrict__ recs, int n_recs, int A, int T,
     plan->label = label;
     plan->used = 1;
     plan->miss = 0;
-    hist[label].gidx = plan->gidx[0];
-    hist[label].dist = plan->maxdist[0];
+    hist[label].gidx = first_g;
+    hist[label].dist = first_max;
     hist[label].set = 1;
     ctl->n_done = label + 1;
     ctl->n_rounds = ctl->n_rounds + 1;
 }
 
-void ek_launch_plan(const unsigned char *recs, int n_recs, int A, int T,
-                    double cutoff, EkPlan *plan, EkHist *hist, EkCtl *ctl,
-                    hipStream_t s)
+// pairwise distances of the valid records on offer (one wave per pair; used only
+// to steer the choice of guesses, so the summation order is free -- but it is
+// the same on every rank, and so is the choice)
+__global__ void __launch_bounds__(EK_BLOCK)
+ek_rec_pair_kernel(const unsigned char *__restrict__ recs, int n_recs, int A,
+                   float *__restrict__ D)
 {
+    const int lane = threadIdx.x & (EK_WAVE - 1);
+    const int w = blockIdx.x * (EK_BLOCK / EK_WAVE) + threadIdx.x / EK_WAVE;
+    const int i = w / 64, j = w % 64;
+    if (i >= j || j >= n_recs)
+        return;
+    const size_t rstride = ek_rec_bytes(A);
+    const EkRecHdr *hi = (const EkRecHdr *)(recs + (size_t)i * rstride);
+    const EkRecHdr *hj = (const EkRecHdr *)(recs + (size_t)j * rstride);
+    if (!hi->valid || !hj->valid)
+        return;
+    const float *x = (const float *)(recs + (size_t)i * rstride + sizeof(EkRecHdr));
+    const float *y = (const float *)(recs + (size_t)j * rstride + sizeof(EkRecHdr));
+    float S[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int a = lane; a < A; a += EK_WAVE) {
+        const float x0 = x[3 * a], x1 = x[3 * a + 1], x2 = x[3 * a + 2];
+        const float y0 = y[3 * a], y1 = y[3 * a + 1], y2 = y[3 * a + 2];
+        S[0] += x0 * y0; S[1] += x0 * y1; S[2] += x0 * y2;
+        S[3] += x1 * y0; S[4] += x1 * y1; S[5] += x1 * y2;
+        S[6] += x2 * y0; S[7] += x2 * y1; S[8] += x2 * y2;
+    }
+#pragma unroll
+    for (int q = 0; q < 9; ++q)
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1)
+            S[q] += __shfl_xor(S[q], off, 64);
+    if (lane == 0) {
+        const float d = ek_rmsd_from_S(S, hi->trace, hj->trace, A);
+        D[i * 64 + j] = d;
+        D[j * 64 + i] = d;
+    }
+}
+
+// D != nullptr and more records than candidates: greedy choice among them
+void ek_launch_plan(const unsigned char *recs, int n_recs, int A, int T,
+                    double cutoff, float *D, EkPlan *plan, EkHist *hist,
+                    EkCtl *ctl, hipStream_t s)
+{
+    const bool greedy = D != nullptr && n_recs > T;
+    if (greedy)
+        hipLaunchKernelGGL(ek_rec_pair_kernel,
+                           dim3(64 * 64 / (EK_BLOCK / EK_WAVE)), dim3(EK_BLOCK),
+                           0, s, recs, n_recs, A, D);
     hipLaunchKernelGGL(ek_plan_kernel, dim3(1), dim3(EK_WAVE), 0, s, recs,
-                       n_recs, A, T, cutoff, plan, hist, ctl);
+                       n_recs, A, T, cutoff, greedy ? D : nullptr, plan, hist,
+                       ctl);
 }
 
 // ---------------------------------------------------------------------------
