@@ -796,8 +796,9 @@ void ek_launch_apply(const float *vecs, const double *G, int64_t n,
 // which the fit itself would take them if no frame outside the set interfered.
 // Record 0 is therefore the shard's first-index arg-max, as the protocol needs.
 // (In a CPU model of the rounds this raised the centers per pass from 5.1 to 6.6
-// against picking the top maxima with distinct labels.)
-#define EK_TOP_M 32
+// with 32 maxima and 6.8 with 64, against picking the top maxima with distinct
+// labels.)
+#define EK_TOP_M 64
 
 struct EkTop {
     int32_t n;
@@ -863,7 +864,7 @@ ek_pick_top_kernel(const EkBlockMax *__restrict__ blockmax, int nb,
         }
     }
     constexpr int NWV = EK_RED_THREADS / EK_WAVE;
-    constexpr int LW = 6;                // looks per wave
+    constexpr int LW = 8;                // looks per wave
     __shared__ float wt_v[NWV * LW];
     __shared__ uint32_t wt_i[NWV * LW];
     const int max_looks = EK_TOP_M;
