@@ -824,7 +824,8 @@ extern "C" int ek_kcenters_run(ek_ctx *c, int32_t first_label, int32_t max_new,
                                           c->n, c->n_pad, c->goff, c->stream);
                     ek_launch_chain_max(c->dist, c->vecs, c->n, c->n_pad, c->plan,
                                         c->pm, c->stream);
-                    ek_launch_chain_decide_local(c->blockmax, c->pm, nb, c->goff,
+                    ek_launch_chain_decide_local(c->blockmax, c->pm, nb,
+                                                 ek_chain_max_blocks(c->n), c->goff,
                                                  dist_cutoff, c->plan, c->hist,
                                                  c->ctl, c->stream);
                     ek_launch_chain_apply(c->vecs, c->n, c->n_pad, c->dist,
@@ -1915,8 +1916,8 @@ extern "C" int ek_spec_chain_max(ek_ctx *c, const void *rows_all, int32_t n_shar
                           c->vecs, c->n, c->n_pad, c->goff, c->stream);
     ek_launch_chain_max(c->dist, c->vecs, c->n, c->n_pad, c->plan, c->pm,
                         c->stream);
-    ek_launch_chain_localmax(c->blockmax, c->pm, nb, c->goff, c->plan,
-                             (EkMaxHdr *)hdrs_out, c->stream);
+    ek_launch_chain_localmax(c->blockmax, c->pm, nb, ek_chain_max_blocks(c->n),
+                             c->goff, c->plan, (EkMaxHdr *)hdrs_out, c->stream);
     EK_CHECK_LAUNCH();
     return EK_OK;
 }

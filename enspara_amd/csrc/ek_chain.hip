@@ -172,6 +172,8 @@ void ek_launch_chain_order(const EkChainRow *rows_all, int n_shards,
 // pm[(k - 1) * nb + workgroup] = first-index arg-max over the workgroup's frames
 // of min(dist, vec[chain[0]], .., vec[chain[k-1]]), k = 1 .. chain_n - 1.
 // (State 0, before any of them, is what the pass kernel left in blockmax.)
+#define EK_CHAIN_FPT 4      // frames per thread in ek_chain_max_kernel
+
 __global__ void __launch_bounds__(EK_BLOCK)
 ek_chain_max_kernel(const float *__restrict__ dist,
                     const float *__restrict__ vecs, int64_t n, int64_t n_pad,
@@ -183,29 +185,53 @@ ek_chain_max_kernel(const float *__restrict__ dist,
     if (cn <= 1)
         return;
     const int tid = threadIdx.x;
-    const int64_t f = (int64_t)blockIdx.x * EK_BLOCK + tid;
-    const int nb = gridDim.x;
+    const int64_t f0 = ((int64_t)blockIdx.x * EK_BLOCK + tid) * EK_CHAIN_FPT;
+    const int nbp = gridDim.x;
+    const bool whole = f0 + EK_CHAIN_FPT <= n;      // 16-byte loads
     // all loads first: the running minimum would otherwise serialise them
-    float run = 0.f;
-    float dv[EK_MAX_CANDS];
+    float run[EK_CHAIN_FPT];
+    float dv[EK_MAX_CANDS][EK_CHAIN_FPT];
 #pragma unroll
     for (int k = 1; k < EK_MAX_CANDS - 1; ++k) {
-        dv[k] = 0.f;
-        if (k < cn && f < n)
-            dv[k] = vecs[(size_t)(plan->chain[k - 1] - 1) * n_pad + f];
+#pragma unroll
+        for (int q = 0; q < EK_CHAIN_FPT; ++q)
+            dv[k][q] = __builtin_inff();
+        if (k < cn) {
+            const float *v = vecs + (size_t)(plan->chain[k - 1] - 1) * n_pad + f0;
+            if (whole) {
+                const float4 t = *(const float4 *)v;
+                dv[k][0] = t.x; dv[k][1] = t.y; dv[k][2] = t.z; dv[k][3] = t.w;
+            } else {
+#pragma unroll
+                for (int q = 0; q < EK_CHAIN_FPT; ++q)
+                    if (f0 + q < n)
+                        dv[k][q] = v[q];
+            }
+        }
     }
-    if (f < n)
-        run = dist[f];
+    if (whole) {
+        const float4 t = *(const float4 *)(dist + f0);
+        run[0] = t.x; run[1] = t.y; run[2] = t.z; run[3] = t.w;
+    } else {
+#pragma unroll
+        for (int q = 0; q < EK_CHAIN_FPT; ++q)
+            run[q] = (f0 + q < n) ? dist[f0 + q] : 0.f;
+    }
 #pragma unroll
     for (int k = 1; k < EK_MAX_CANDS - 1; ++k) {
         if (k < cn) {                       // uniform
             float v = -__builtin_inff();
             uint32_t i = 0xffffffffu;
-            if (f < n) {
-                if (dv[k] < run)
-                    run = dv[k];
-                v = run;
-                i = (uint32_t)f;
+#pragma unroll
+            for (int q = 0; q < EK_CHAIN_FPT; ++q) {
+                if (f0 + q < n) {
+                    if (dv[k][q] < run[q])
+                        run[q] = dv[k][q];
+                    if (ek_better(run[q], (uint32_t)(f0 + q), v, i)) {
+                        v = run[q];
+                        i = (uint32_t)(f0 + q);
+                    }
+                }
             }
             ek_wave_argmax(v, i);
             if ((tid & (EK_WAVE - 1)) == 0) {
@@ -224,9 +250,16 @@ ek_chain_max_kernel(const float *__restrict__ dist,
                 v = red_v[k][w];
                 i = red_i[k][w];
             }
-        pm[(size_t)(k - 1) * nb + blockIdx.x].val = v;
-        pm[(size_t)(k - 1) * nb + blockIdx.x].idx = i;
+        pm[(size_t)(k - 1) * nbp + blockIdx.x].val = v;
+        pm[(size_t)(k - 1) * nbp + blockIdx.x].idx = i;
     }
+}
+
+// workgroups of ek_chain_max_kernel (= entries per prefix in pm)
+int ek_chain_max_blocks(int64_t n)
+{
+    const int64_t per = (int64_t)EK_BLOCK * EK_CHAIN_FPT;
+    return (int)((n + per - 1) / per);
 }
 
 void ek_launch_chain_max(const float *dist, const float *vecs, int64_t n,
@@ -235,8 +268,7 @@ void ek_launch_chain_max(const float *dist, const float *vecs, int64_t n,
 {
     if (n <= 0)
         return;
-    hipLaunchKernelGGL(ek_chain_max_kernel,
-                       dim3((unsigned)((n + EK_BLOCK - 1) / EK_BLOCK)),
+    hipLaunchKernelGGL(ek_chain_max_kernel, dim3((unsigned)ek_chain_max_blocks(n)),
                        dim3(EK_BLOCK), 0, s, dist, vecs, n, n_pad, plan, pm);
 }
 
@@ -245,7 +277,7 @@ void ek_launch_chain_max(const float *dist, const float *vecs, int64_t n,
 // the loads of a trip are issued together (the entries are independent)
 __device__ __forceinline__ void ek_chain_reduce(const EkBlockMax *blockmax,
                                                 const EkBlockMax *pm, int nb,
-                                                int cn, float *out_v,
+                                                int nbp, int cn, float *out_v,
                                                 uint32_t *out_i)
 {
     __shared__ float half_v[2 * EK_MAX_CANDS];
@@ -255,16 +287,17 @@ __device__ __forceinline__ void ek_chain_reduce(const EkBlockMax *blockmax,
     const int w = wv >> 1, part = wv & 1;
     constexpr int U = 8;
     if (w < cn) {
-        const EkBlockMax *src = (w == 0) ? blockmax : pm + (size_t)(w - 1) * nb;
+        const EkBlockMax *src = (w == 0) ? blockmax : pm + (size_t)(w - 1) * nbp;
+        const int cnt = (w == 0) ? nb : nbp;
         float v = -__builtin_inff();
         uint32_t i = 0xffffffffu;
-        for (int b0 = part * EK_WAVE + lane; b0 < nb; b0 += 2 * EK_WAVE * U) {
+        for (int b0 = part * EK_WAVE + lane; b0 < cnt; b0 += 2 * EK_WAVE * U) {
             EkBlockMax m[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int b = b0 + u * 2 * EK_WAVE;
-                m[u] = src[b < nb ? b : nb - 1];
-                if (b >= nb)
+                m[u] = src[b < cnt ? b : cnt - 1];
+                if (b >= cnt)
                     m[u].idx = 0xffffffffu;
             }
 #pragma unroll
@@ -297,14 +330,14 @@ __device__ __forceinline__ void ek_chain_reduce(const EkBlockMax *blockmax,
 
 __global__ void __launch_bounds__(EK_CHAIN_THREADS)
 ek_chain_localmax_kernel(const EkBlockMax *__restrict__ blockmax,
-                         const EkBlockMax *__restrict__ pm, int nb,
+                         const EkBlockMax *__restrict__ pm, int nb, int nbp,
                          int64_t global_offset, const EkPlan *__restrict__ plan,
                          EkMaxHdr *__restrict__ hdrs_out)
 {
     __shared__ float sv[EK_MAX_CANDS];
     __shared__ uint32_t si[EK_MAX_CANDS];
     const int cn = plan->chain_n;
-    ek_chain_reduce(blockmax, pm, nb, cn, sv, si);
+    ek_chain_reduce(blockmax, pm, nb, nbp, cn, sv, si);
     __syncthreads();
     const int k = threadIdx.x;
     if (k < EK_MAX_CANDS) {
@@ -316,11 +349,11 @@ ek_chain_localmax_kernel(const EkBlockMax *__restrict__ blockmax,
 }
 
 void ek_launch_chain_localmax(const EkBlockMax *blockmax, const EkBlockMax *pm,
-                              int nb, int64_t global_offset, const EkPlan *plan,
-                              EkMaxHdr *hdrs_out, hipStream_t s)
+                              int nb, int nbp, int64_t global_offset,
+                              const EkPlan *plan, EkMaxHdr *hdrs_out, hipStream_t s)
 {
     hipLaunchKernelGGL(ek_chain_localmax_kernel, dim3(1), dim3(EK_CHAIN_THREADS),
-                       0, s, blockmax, pm, nb, global_offset, plan, hdrs_out);
+                       0, s, blockmax, pm, nb, nbp, global_offset, plan, hdrs_out);
 }
 
 // state k's global maximum is (v[k], g[k]) (ok[k] false: no frames anywhere)
@@ -395,7 +428,7 @@ void ek_launch_chain_decide(const EkMaxHdr *hdrs_all, int n_shards, double cutof
 
 __global__ void __launch_bounds__(EK_CHAIN_THREADS)
 ek_chain_decide_local_kernel(const EkBlockMax *__restrict__ blockmax,
-                             const EkBlockMax *__restrict__ pm, int nb,
+                             const EkBlockMax *__restrict__ pm, int nb, int nbp,
                              int64_t global_offset, double cutoff,
                              EkPlan *__restrict__ plan, EkHist *__restrict__ hist,
                              EkCtl *__restrict__ ctl)
@@ -408,7 +441,7 @@ ek_chain_decide_local_kernel(const EkBlockMax *__restrict__ blockmax,
         return;
     }
     const int cn = plan->chain_n;
-    ek_chain_reduce(blockmax, pm, nb, cn, sv, si);
+    ek_chain_reduce(blockmax, pm, nb, nbp, cn, sv, si);
     __syncthreads();
     if (threadIdx.x != 0)
         return;
@@ -424,12 +457,12 @@ ek_chain_decide_local_kernel(const EkBlockMax *__restrict__ blockmax,
 }
 
 void ek_launch_chain_decide_local(const EkBlockMax *blockmax, const EkBlockMax *pm,
-                                  int nb, int64_t global_offset, double cutoff,
-                                  EkPlan *plan, EkHist *hist, EkCtl *ctl,
-                                  hipStream_t s)
+                                  int nb, int nbp, int64_t global_offset,
+                                  double cutoff, EkPlan *plan, EkHist *hist,
+                                  EkCtl *ctl, hipStream_t s)
 {
     hipLaunchKernelGGL(ek_chain_decide_local_kernel, dim3(1),
-                       dim3(EK_CHAIN_THREADS), 0, s, blockmax, pm, nb,
+                       dim3(EK_CHAIN_THREADS), 0, s, blockmax, pm, nb, nbp,
                        global_offset, cutoff, plan, hist, ctl);
 }
 

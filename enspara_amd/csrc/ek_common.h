@@ -247,17 +247,18 @@ void ek_launch_chain_max(const float *dist, const float *vecs, int64_t n,
                          int64_t n_pad, const EkPlan *plan, EkBlockMax *pm,
                          hipStream_t s);
 // this shard's (max, global index) for each of those states -> hdrs_out[8]
+int ek_chain_max_blocks(int64_t n);     // entries per prefix in pm
 void ek_launch_chain_localmax(const EkBlockMax *blockmax, const EkBlockMax *pm,
-                              int nb, int64_t global_offset, const EkPlan *plan,
-                              EkMaxHdr *hdrs_out, hipStream_t s);
+                              int nb, int nbp, int64_t global_offset,
+                              const EkPlan *plan, EkMaxHdr *hdrs_out, hipStream_t s);
 // accept the longest verified prefix of the chain (hdrs_all[shard][8])
 void ek_launch_chain_decide(const EkMaxHdr *hdrs_all, int n_shards, double cutoff,
                             EkPlan *plan, EkHist *hist, EkCtl *ctl, hipStream_t s);
 // single shard: the two above in one launch
 void ek_launch_chain_decide_local(const EkBlockMax *blockmax, const EkBlockMax *pm,
-                                  int nb, int64_t global_offset, double cutoff,
-                                  EkPlan *plan, EkHist *hist, EkCtl *ctl,
-                                  hipStream_t s);
+                                  int nb, int nbp, int64_t global_offset,
+                                  double cutoff, EkPlan *plan, EkHist *hist,
+                                  EkCtl *ctl, hipStream_t s);
 void ek_launch_chain_apply(const float *vecs, int64_t n, int64_t n_pad, float *dist,
                            int32_t *assign, const EkPlan *plan,
                            EkBlockMax *blockmax, hipStream_t s);
