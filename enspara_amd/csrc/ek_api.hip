@@ -1048,8 +1048,9 @@ static int ek_pam_alloc(ek_ctx *c, int32_t K)
                          (size_t)EK_MAX_CANDS * nb * sizeof(int32_t)));
         EK_HIP(hipMalloc((void **)&c->bat_scan,
                          (size_t)EK_MAX_CANDS * nb * sizeof(int64_t)));
+        // [0,8) counts, [8,16) selected frames, [16,24) requested member ranks
         EK_HIP(hipMalloc((void **)&c->bat_sel,
-                         2 * EK_MAX_CANDS * sizeof(int64_t)));
+                         3 * EK_MAX_CANDS * sizeof(int64_t)));
         EK_HIP(hipMalloc((void **)&c->moved, sizeof(unsigned int)));
         EK_HIP(hipMemsetAsync(c->moved, 0, sizeof(unsigned int), c->stream));
         EK_HIP(hipMalloc((void **)&c->pam_out_dev, sizeof(EkPamOut)));
@@ -1454,9 +1455,9 @@ extern "C" int ek_pam_count_members_batch(ek_ctx *c, int32_t cid0, int32_t count
                        c->med_K, EK_MAX_CANDS);
     EK_HIP(hipSetDevice(c->device));
     const size_t nb = ((size_t)std::max<int64_t>(c->n, 1) + EK_BLOCK - 1) / EK_BLOCK;
-    for (int32_t j = 0; j < count; ++j)
-        ek_launch_count_members(c->assign, c->n, cid0 + j, c->bat_blockcnt + j * nb,
-                                c->bat_scan + j * nb, c->bat_sel + j, c->stream);
+    (void)nb;
+    ek_launch_count_members_multi(c->assign, c->n, cid0, count, c->bat_blockcnt,
+                                  c->bat_scan, c->bat_sel, c->stream);
     EK_CHECK_LAUNCH();
     EK_HIP(hipMemcpyAsync(counts, c->bat_sel, (size_t)count * sizeof(int64_t),
                           hipMemcpyDeviceToHost, c->stream));
@@ -1477,13 +1478,14 @@ extern "C" int ek_pam_select_members_batch(ek_ctx *c, int32_t cid0, int32_t coun
                        cid0, count);
     EK_HIP(hipSetDevice(c->device));
     const size_t nb = ((size_t)std::max<int64_t>(c->n, 1) + EK_BLOCK - 1) / EK_BLOCK;
-    EK_HIP(hipMemsetAsync(c->bat_sel + EK_MAX_CANDS, 0xff,
-                          EK_MAX_CANDS * sizeof(int64_t), c->stream));
-    for (int32_t j = 0; j < count; ++j)
-        if (js[j] >= 0)     // negative: that member lives on another shard
-            ek_launch_select_member(c->assign, c->n, cid0 + j,
-                                    c->bat_scan + j * nb, js[j],
-                                    c->bat_sel + EK_MAX_CANDS + j, c->stream);
+    (void)nb;
+    // (a negative rank: that member lives on another shard)
+    EK_HIP(hipMemcpyAsync(c->bat_sel + 2 * EK_MAX_CANDS, js,
+                          (size_t)count * sizeof(int64_t), hipMemcpyHostToDevice,
+                          c->stream));
+    ek_launch_select_member_multi(c->assign, c->n, cid0, count, c->bat_scan,
+                                  c->bat_sel + 2 * EK_MAX_CANDS,
+                                  c->bat_sel + EK_MAX_CANDS, c->stream);
     EK_CHECK_LAUNCH();
     EK_HIP(hipMemcpyAsync(frames, c->bat_sel + EK_MAX_CANDS,
                           (size_t)count * sizeof(int64_t), hipMemcpyDeviceToHost,

@@ -163,6 +163,144 @@ void ek_launch_select_member(const int32_t *assign, int64_t n, int32_t cid,
                        assign, n, cid, scan, nblocks, j, out);
 }
 
+// the same for `count` consecutive clusters cid0.. at once (proposal windows):
+// blockcnt[j][workgroup], scan[j][workgroup], total[j]
+__global__ void __launch_bounds__(EK_BLOCK)
+ek_count_members_multi_kernel(const int32_t *__restrict__ assign, int64_t n,
+                              int32_t cid0, int count, int nblocks,
+                              int32_t *__restrict__ blockcnt)
+{
+    __shared__ int cnt[EK_MAX_CANDS];
+    if (threadIdx.x < EK_MAX_CANDS)
+        cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t f = (int64_t)blockIdx.x * EK_BLOCK + threadIdx.x;
+    if (f < n) {
+        const int j = assign[f] - cid0;
+        if (j >= 0 && j < count)
+            atomicAdd(&cnt[j], 1);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < count)
+        blockcnt[(size_t)threadIdx.x * nblocks + blockIdx.x] = cnt[threadIdx.x];
+}
+
+__global__ void __launch_bounds__(1024)
+ek_scan_counts_multi_kernel(const int32_t *__restrict__ blockcnt, int nblocks,
+                            int64_t *__restrict__ scan,
+                            int64_t *__restrict__ total)
+{
+    __shared__ int64_t part[1024];
+    const int j = blockIdx.x;
+    const int32_t *bc = blockcnt + (size_t)j * nblocks;
+    int64_t *sc = scan + (size_t)j * nblocks;
+    const int t = threadIdx.x;
+    const int per = (nblocks + 1023) / 1024;
+    const int lo = t * per, hi = min(nblocks, lo + per);
+    int64_t s = 0;
+    for (int b = lo; b < hi; ++b)
+        s += bc[b];
+    part[t] = s;
+    __syncthreads();
+    // exclusive scan of the 1024 partial sums by the first wave
+    if (t < EK_WAVE) {
+        int64_t loc[1024 / EK_WAVE];
+        int64_t sum = 0;
+#pragma unroll
+        for (int q = 0; q < 1024 / EK_WAVE; ++q) {
+            loc[q] = sum;
+            sum += part[t * (1024 / EK_WAVE) + q];
+        }
+        int64_t incl = sum;               // inclusive scan over the lanes
+#pragma unroll
+        for (int off = 1; off < EK_WAVE; off <<= 1) {
+            const int64_t o = __shfl_up(incl, off, 64);
+            if (t >= off)
+                incl += o;
+        }
+        const int64_t excl = incl - sum;
+#pragma unroll
+        for (int q = 0; q < 1024 / EK_WAVE; ++q)
+            part[t * (1024 / EK_WAVE) + q] = excl + loc[q];
+        if (t == EK_WAVE - 1)
+            total[j] = incl;
+    }
+    __syncthreads();
+    int64_t run = part[t];
+    for (int b = lo; b < hi; ++b) {
+        sc[b] = run;
+        run += bc[b];
+    }
+}
+
+// the js[j]-th member of cluster cid0 + j -> out[j] (-1: none; js[j] < 0: skipped)
+__global__ void __launch_bounds__(EK_BLOCK)
+ek_select_member_multi_kernel(const int32_t *__restrict__ assign, int64_t n,
+                              int32_t cid0, const int64_t *__restrict__ scan,
+                              int nblocks, const int64_t *__restrict__ js,
+                              int64_t *__restrict__ out)
+{
+    __shared__ int lo_s;
+    __shared__ int wcnt[EK_BLOCK / EK_WAVE];
+    const int j = blockIdx.x;
+    const int64_t want = js[j];
+    if (want < 0) {
+        if (threadIdx.x == 0)
+            out[j] = -1;
+        return;
+    }
+    const int32_t cid = cid0 + j;
+    const int64_t *sc = scan + (size_t)j * nblocks;
+    if (threadIdx.x == 0) {
+        int lo = 0, hi = nblocks - 1;     // last workgroup whose scan <= want
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) / 2;
+            if (sc[mid] <= want)
+                lo = mid;
+            else
+                hi = mid - 1;
+        }
+        lo_s = lo;
+        out[j] = -1;
+    }
+    __syncthreads();
+    const int lo = lo_s;
+    const int64_t rank = want - sc[lo];
+    const int64_t f = (int64_t)lo * EK_BLOCK + threadIdx.x;
+    const bool hit = f < n && assign[f] == cid;
+    const unsigned long long m = __ballot(hit);
+    const int lane = threadIdx.x & (EK_WAVE - 1), wv = threadIdx.x / EK_WAVE;
+    if (lane == 0)
+        wcnt[wv] = __popcll(m);
+    __syncthreads();
+    int before = 0;
+    for (int w = 0; w < wv; ++w)
+        before += wcnt[w];
+    if (hit && before + __popcll(m & ((1ull << lane) - 1ull)) == rank)
+        out[j] = f;
+}
+
+void ek_launch_count_members_multi(const int32_t *assign, int64_t n, int32_t cid0,
+                                   int count, int32_t *blockcnt, int64_t *scan,
+                                   int64_t *total, hipStream_t s)
+{
+    const int nblocks = (int)((n + EK_BLOCK - 1) / EK_BLOCK);
+    hipLaunchKernelGGL(ek_count_members_multi_kernel, dim3(nblocks), dim3(EK_BLOCK),
+                       0, s, assign, n, cid0, count, nblocks, blockcnt);
+    hipLaunchKernelGGL(ek_scan_counts_multi_kernel, dim3(count), dim3(1024), 0, s,
+                       blockcnt, nblocks, scan, total);
+}
+
+void ek_launch_select_member_multi(const int32_t *assign, int64_t n, int32_t cid0,
+                                   int count, const int64_t *scan,
+                                   const int64_t *js_dev, int64_t *out,
+                                   hipStream_t s)
+{
+    const int nblocks = (int)((n + EK_BLOCK - 1) / EK_BLOCK);
+    hipLaunchKernelGGL(ek_select_member_multi_kernel, dim3(count), dim3(EK_BLOCK),
+                       0, s, assign, n, cid0, scan, nblocks, js_dev, out);
+}
+
 // ---- classification (kmedoids.py:639-658) ---------------------------------------
 // newd: distance of every frame to the proposed medoid.
 //   dist > newd                      -> (newd, cid)
