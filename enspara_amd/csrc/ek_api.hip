@@ -820,10 +820,8 @@ extern "C" int ek_kcenters_run(ek_ctx *c, int32_t first_label, int32_t max_new,
                     c->samp_used++;
                 }
                 if (c->chain) {
-                    ek_launch_chain_order(nullptr, 1, c->plan, c->dist, c->vecs,
-                                          c->n, c->n_pad, c->goff, c->stream);
                     ek_launch_chain_max(c->dist, c->vecs, c->n, c->n_pad, c->plan,
-                                        c->pm, c->stream);
+                                        c->pm, 1, c->goff, c->stream);
                     ek_launch_chain_decide_local(c->blockmax, c->pm, nb,
                                                  ek_chain_max_blocks(c->n), c->goff,
                                                  dist_cutoff, c->plan, c->hist,
@@ -1916,8 +1914,8 @@ extern "C" int ek_spec_chain_max(ek_ctx *c, const void *rows_all, int32_t n_shar
     const int nb = (int)((c->n + EK_BLOCK - 1) / EK_BLOCK);
     ek_launch_chain_order((const EkChainRow *)rows_all, n_shards, c->plan, c->dist,
                           c->vecs, c->n, c->n_pad, c->goff, c->stream);
-    ek_launch_chain_max(c->dist, c->vecs, c->n, c->n_pad, c->plan, c->pm,
-                        c->stream);
+    ek_launch_chain_max(c->dist, c->vecs, c->n, c->n_pad, c->plan, c->pm, 0,
+                        c->goff, c->stream);
     ek_launch_chain_localmax(c->blockmax, c->pm, nb, ek_chain_max_blocks(c->n),
                              c->goff, c->plan, (EkMaxHdr *)hdrs_out, c->stream);
     EK_CHECK_LAUNCH();

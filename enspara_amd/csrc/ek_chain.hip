@@ -73,55 +73,11 @@ void ek_launch_chain_rows(const EkPlan *plan, const float *dist,
                        dist, vecs, n, n_pad, global_offset, rows_out);
 }
 
-__global__ void __launch_bounds__(EK_WAVE)
-ek_chain_order_kernel(const EkChainRow *__restrict__ rows_all, int n_shards,
-                      EkPlan *__restrict__ plan, const float *__restrict__ dist,
-                      const float *__restrict__ vecs, int64_t n, int64_t n_pad,
-                      int64_t global_offset)
+// the presumed order from the candidate rows (one thread); returns its length
+__device__ __forceinline__ int ek_chain_simulate(const EkPlan *plan,
+                                                 const EkChainRow *rows,
+                                                 int *chain_out)
 {
-    __shared__ EkChainRow rows[EK_MAX_CANDS];
-    const int tid = threadIdx.x;
-    if (tid < EK_MAX_CANDS) {
-        if (rows_all) {                 // the owner's row among the shards'
-            rows[tid].valid = 0;
-            for (int sh = 0; sh < n_shards; ++sh) {
-                const EkChainRow *r = &rows_all[(size_t)sh * EK_MAX_CANDS + tid];
-                if (r->valid) {
-                    rows[tid] = *r;
-                    break;
-                }
-            }
-        }
-    }
-    if (!rows_all) {
-        // single shard: thread (j, u) fetches one entry of row j, all at once
-        const int j = tid / EK_MAX_CANDS, u = tid % EK_MAX_CANDS;
-        const bool live = plan->go && j >= 1 && j < plan->teff;
-        const int64_t local = live ? plan->gidx[j] - global_offset : -1;
-        const bool mine = live && local >= 0 && local < n;
-        float val = 0.f;
-        if (mine) {
-            if (u == 0)
-                val = dist[local];
-            else if (u < plan->teff)
-                val = vecs[(size_t)(u - 1) * n_pad + local];
-        }
-        if (u == 0) {
-            rows[j].cur = val;
-            rows[j].valid = mine ? 1 : 0;
-            rows[j].d[0] = 0.f;
-        } else {
-            rows[j].d[u] = val;
-        }
-    }
-    __syncthreads();
-    if (tid != 0)
-        return;
-    plan->chain_n = 0;
-    plan->napply = 0;
-    plan->chain_label0 = 0;
-    if (!plan->go)
-        return;
     const int teff = plan->teff;
     float cur[EK_MAX_CANDS];
     bool open[EK_MAX_CANDS];
@@ -148,13 +104,80 @@ ek_chain_order_kernel(const EkChainRow *__restrict__ rows_all, int n_shards,
         if (best < 0)
             break;
         open[best] = false;
-        plan->chain[cn++] = best;
+        chain_out[cn++] = best;
         for (int j = 1; j < teff; ++j) {        // kcenters.py:304: strict <
             const float dj = rows[j].d[best];
             if (open[j] && dj < cur[j])
                 cur[j] = dj;
         }
     }
+    return cn;
+}
+
+// this shard's rows, one entry per thread (tid < 64), into LDS
+__device__ __forceinline__ void ek_chain_rows_local(const EkPlan *plan,
+                                                    const float *dist,
+                                                    const float *vecs, int64_t n,
+                                                    int64_t n_pad,
+                                                    int64_t global_offset,
+                                                    EkChainRow *rows, int tid)
+{
+    if (tid >= EK_MAX_CANDS * EK_MAX_CANDS)
+        return;
+    const int j = tid / EK_MAX_CANDS, u = tid % EK_MAX_CANDS;
+    const bool live = plan->go && j >= 1 && j < plan->teff;
+    const int64_t local = live ? plan->gidx[j] - global_offset : -1;
+    const bool mine = live && local >= 0 && local < n;
+    float val = 0.f;
+    if (mine) {
+        if (u == 0)
+            val = dist[local];
+        else if (u < plan->teff)
+            val = vecs[(size_t)(u - 1) * n_pad + local];
+    }
+    if (u == 0) {
+        rows[j].cur = val;
+        rows[j].valid = mine ? 1 : 0;
+        rows[j].d[0] = 0.f;
+    } else {
+        rows[j].d[u] = val;
+    }
+}
+
+__global__ void __launch_bounds__(EK_WAVE)
+ek_chain_order_kernel(const EkChainRow *__restrict__ rows_all, int n_shards,
+                      EkPlan *__restrict__ plan, const float *__restrict__ dist,
+                      const float *__restrict__ vecs, int64_t n, int64_t n_pad,
+                      int64_t global_offset)
+{
+    __shared__ EkChainRow rows[EK_MAX_CANDS];
+    const int tid = threadIdx.x;
+    if (rows_all) {                     // the owner's row among the shards'
+        if (tid < EK_MAX_CANDS) {
+            rows[tid].valid = 0;
+            for (int sh = 0; sh < n_shards; ++sh) {
+                const EkChainRow *r = &rows_all[(size_t)sh * EK_MAX_CANDS + tid];
+                if (r->valid) {
+                    rows[tid] = *r;
+                    break;
+                }
+            }
+        }
+    } else {
+        ek_chain_rows_local(plan, dist, vecs, n, n_pad, global_offset, rows, tid);
+    }
+    __syncthreads();
+    if (tid != 0)
+        return;
+    plan->chain_n = 0;
+    plan->napply = 0;
+    plan->chain_label0 = 0;
+    if (!plan->go)
+        return;
+    int chain[EK_MAX_CANDS];
+    const int cn = ek_chain_simulate(plan, rows, chain);
+    for (int k = 0; k < cn; ++k)
+        plan->chain[k] = chain[k];
     plan->chain_n = cn;
 }
 
@@ -177,14 +200,48 @@ void ek_launch_chain_order(const EkChainRow *rows_all, int n_shards,
 __global__ void __launch_bounds__(EK_BLOCK)
 ek_chain_max_kernel(const float *__restrict__ dist,
                     const float *__restrict__ vecs, int64_t n, int64_t n_pad,
-                    const EkPlan *__restrict__ plan, EkBlockMax *__restrict__ pm)
+                    EkPlan *plan, EkBlockMax *__restrict__ pm, int local_order,
+                    int64_t global_offset)
 {
     __shared__ float red_v[EK_MAX_CANDS][EK_BLOCK / EK_WAVE];
     __shared__ uint32_t red_i[EK_MAX_CANDS][EK_BLOCK / EK_WAVE];
-    const int cn = plan->chain_n;
+    __shared__ EkChainRow rows[EK_MAX_CANDS];
+    __shared__ int s_chain[EK_MAX_CANDS];
+    __shared__ int s_cn;
+    const int tid = threadIdx.x;
+    if (local_order) {
+        // single shard: every workgroup works the presumed order out for itself
+        // (64 reads and a few hundred scalar steps) instead of waiting for a
+        // launch that does it once; workgroup 0 records it for the kernels that
+        // follow.  Nobody reads plan->chain* in this launch.
+        ek_chain_rows_local(plan, dist, vecs, n, n_pad, global_offset, rows, tid);
+        __syncthreads();
+        if (tid == 0) {
+            int chain[EK_MAX_CANDS];
+            const int c = plan->go ? ek_chain_simulate(plan, rows, chain) : 0;
+            for (int k = 0; k < c; ++k)
+                s_chain[k] = chain[k];
+            s_cn = c;
+            if (blockIdx.x == 0) {
+                for (int k = 0; k < c; ++k)
+                    plan->chain[k] = chain[k];
+                plan->chain_n = c;
+                plan->napply = 0;
+                plan->chain_label0 = 0;
+            }
+        }
+        __syncthreads();
+    } else {
+        if (tid == 0) {
+            s_cn = plan->chain_n;
+            for (int k = 0; k < EK_MAX_CANDS; ++k)
+                s_chain[k] = plan->chain[k];
+        }
+        __syncthreads();
+    }
+    const int cn = s_cn;
     if (cn <= 1)
         return;
-    const int tid = threadIdx.x;
     const int64_t f0 = ((int64_t)blockIdx.x * EK_BLOCK + tid) * EK_CHAIN_FPT;
     const int nbp = gridDim.x;
     const bool whole = f0 + EK_CHAIN_FPT <= n;      // 16-byte loads
@@ -197,7 +254,7 @@ ek_chain_max_kernel(const float *__restrict__ dist,
         for (int q = 0; q < EK_CHAIN_FPT; ++q)
             dv[k][q] = __builtin_inff();
         if (k < cn) {
-            const float *v = vecs + (size_t)(plan->chain[k - 1] - 1) * n_pad + f0;
+            const float *v = vecs + (size_t)(s_chain[k - 1] - 1) * n_pad + f0;
             if (whole) {
                 const float4 t = *(const float4 *)v;
                 dv[k][0] = t.x; dv[k][1] = t.y; dv[k][2] = t.z; dv[k][3] = t.w;
@@ -262,14 +319,17 @@ int ek_chain_max_blocks(int64_t n)
     return (int)((n + per - 1) / per);
 }
 
+// local_order != 0: single shard, the order is worked out here (no
+// ek_launch_chain_order before it)
 void ek_launch_chain_max(const float *dist, const float *vecs, int64_t n,
-                         int64_t n_pad, const EkPlan *plan, EkBlockMax *pm,
-                         hipStream_t s)
+                         int64_t n_pad, EkPlan *plan, EkBlockMax *pm,
+                         int local_order, int64_t global_offset, hipStream_t s)
 {
     if (n <= 0)
         return;
     hipLaunchKernelGGL(ek_chain_max_kernel, dim3((unsigned)ek_chain_max_blocks(n)),
-                       dim3(EK_BLOCK), 0, s, dist, vecs, n, n_pad, plan, pm);
+                       dim3(EK_BLOCK), 0, s, dist, vecs, n, n_pad, plan, pm,
+                       local_order, global_offset);
 }
 
 // ---- 3. decide ----------------------------------------------------------------------

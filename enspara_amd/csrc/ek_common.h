@@ -251,8 +251,8 @@ void ek_launch_chain_order(const EkChainRow *rows_all, int n_shards,
                            hipStream_t s);
 // per-workgroup maxima of the states after applying chain[0..k-1], k = 1..
 void ek_launch_chain_max(const float *dist, const float *vecs, int64_t n,
-                         int64_t n_pad, const EkPlan *plan, EkBlockMax *pm,
-                         hipStream_t s);
+                         int64_t n_pad, EkPlan *plan, EkBlockMax *pm,
+                         int local_order, int64_t global_offset, hipStream_t s);
 // this shard's (max, global index) for each of those states -> hdrs_out[8]
 int ek_chain_max_blocks(int64_t n);     // entries per prefix in pm
 void ek_launch_chain_localmax(const EkBlockMax *blockmax, const EkBlockMax *pm,
