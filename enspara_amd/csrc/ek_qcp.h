@@ -95,89 +95,3 @@ __device__ __forceinline__ float ek_rmsd_from_S(const float (&S)[9], double Gx,
 {
     return __builtin_sqrtf((float)ek_msd_from_S(S, Gx, Gy, n_atoms));
 }
-
-// The same distance for a caller that will only ever ask "is it < cur?" with
-// cur at most `cur_now` (k-centers: a frame's distance never grows).  Newton
-// starts at (Gx+Gy)/2 >= lambda_max and, the quartic being convex and increasing
-// beyond its largest root, comes down onto lambda_max from above: every iterate
-// gives a LOWER bound (Gx+Gy-2*lam)/n of the mean square deviation.  As soon as
-// that bound exceeds cur_now^2 (by a relative 2e-6, far above the rounding of
-// the iteration) the answer to the question is settled for good and the bound
-// is returned instead of the exact value: a float > cur_now that the exact
-// distance is not below.  Otherwise the result is ek_rmsd_from_S's, bit for bit
-// (same operations in the same order).
-__device__ __forceinline__ float ek_rmsd_from_S_above(const float (&S)[9],
-                                                      double Gx, double Gy,
-                                                      int n_atoms, float cur_now)
-{
-    const double Sxx = S[0], Sxy = S[1], Sxz = S[2];
-    const double Syx = S[3], Syy = S[4], Syz = S[5];
-    const double Szx = S[6], Szy = S[7], Szz = S[8];
-    double q = Sxx * Sxx;
-    q = q + Sxy * Sxy;
-    q = q + Sxz * Sxz;
-    q = q + Syx * Syx;
-    q = q + Syy * Syy;
-    q = q + Syz * Syz;
-    q = q + Szx * Szx;
-    q = q + Szy * Szy;
-    q = q + Szz * Szz;
-    const double C2 = -2.0 * q;
-    const double m0 = Syy * Szz - Syz * Szy;
-    const double m1 = Syx * Szz - Syz * Szx;
-    const double m2 = Syx * Szy - Syy * Szx;
-    const double detS = (Sxx * m0 - Sxy * m1) + Sxz * m2;
-    const double C1 = -8.0 * detS;
-    const double k00 = (Sxx + Syy) + Szz;
-    const double k01 = Syz - Szy;
-    const double k02 = Szx - Sxz;
-    const double k03 = Sxy - Syx;
-    const double k11 = (Sxx - Syy) - Szz;
-    const double k12 = Sxy + Syx;
-    const double k13 = Szx + Sxz;
-    const double k22 = (Syy - Sxx) - Szz;
-    const double k23 = Syz + Szy;
-    const double k33 = (Szz - Sxx) - Syy;
-    const double s0 = k00 * k11 - k01 * k01;
-    const double s1 = k00 * k12 - k01 * k02;
-    const double s2 = k00 * k13 - k01 * k03;
-    const double s3 = k01 * k12 - k11 * k02;
-    const double s4 = k01 * k13 - k11 * k03;
-    const double s5 = k02 * k13 - k12 * k03;
-    const double c5 = k22 * k33 - k23 * k23;
-    const double c4 = k12 * k33 - k13 * k23;
-    const double c3 = k12 * k23 - k13 * k22;
-    const double c2 = k02 * k33 - k03 * k23;
-    const double c1 = k02 * k23 - k03 * k22;
-    const double c0 = k02 * k13 - k03 * k12;
-    double C0 = s0 * c5 - s1 * c4;
-    C0 = C0 + s2 * c3;
-    C0 = C0 + s3 * c2;
-    C0 = C0 - s4 * c1;
-    C0 = C0 + s5 * c0;
-
-    const double Gsum = Gx + Gy;
-    // n * cur^2 * (1 + 2e-6); +inf for an unassigned frame: never reached
-    const double settled =
-        (double)n_atoms * ((double)cur_now * (double)cur_now) * 1.000002;
-    double lam = 0.5 * Gsum;
-    for (int it = 0; it < EK_MAXIT; ++it) {
-        const double x2 = lam * lam;
-        const double b = (x2 + C2) * lam;
-        const double a = b + C1;
-        const double num = __builtin_fma(a, lam, C0);
-        const double den = __builtin_fma(2.0 * x2, lam, b + a);
-        if (den == 0.0)
-            break;
-        const double delta = num / den;
-        lam = lam - delta;
-        if (__builtin_fabs(delta) < __builtin_fabs(EK_EVALPREC * lam))
-            break;
-        if (Gsum - 2.0 * lam > settled)
-            break;
-    }
-    double msd = (Gsum - 2.0 * lam) / (double)n_atoms;
-    if (!(msd > 0.0))
-        msd = 0.0;
-    return __builtin_sqrtf((float)msd);
-}

@@ -379,10 +379,8 @@ ek_pass_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
 #pragma unroll
                 for (int j = 0; j < 9; ++j)
                     S[j] = s2[c / 2][j][c & 1];
-                // only "< the frame's distance" will ever be asked of it, and
-                // that distance never grows: stop the solve once that is settled
                 vecs[(size_t)(c - 1) * n_pad + f] =
-                    ek_rmsd_from_S_above(S, Gf, gtile[c], A, cur);
+                    ek_rmsd_from_S(S, Gf, gtile[c], A);
             }
         }
     }
