@@ -83,7 +83,9 @@ struct ek_ctx {
     int32_t *blockcnt = nullptr;
     int64_t *scan = nullptr;
     int64_t *sel = nullptr;          // [0] member count, [1] selected frame
-    double *sq_part = nullptr;
+    double *sq_part = nullptr;       // leaf sums + chunk sums (ek_pam.hip, numpy's order)
+    EkPwShape *pw_shapes = nullptr;  // [2]: a full chunk, the last chunk
+    int pw_n_full = 0, pw_leaves = 0, pw_chunks = 0;
     double *sq_out = nullptr;
     float *med_aos = nullptr;        // [K+1][3A]; row K = saved row
     double *med_G = nullptr;
@@ -290,6 +292,7 @@ static int ek_free_all(ek_ctx *c)
     (void)hipFree(c->scan);
     (void)hipFree(c->sel);
     (void)hipFree(c->sq_part);
+    (void)hipFree(c->pw_shapes);
     (void)hipFree(c->sq_out);
     (void)hipFree(c->med_aos);
     (void)hipFree(c->med_G);
@@ -1039,8 +1042,22 @@ static int ek_pam_alloc(ek_ctx *c, int32_t K)
         EK_HIP(hipMalloc((void **)&c->blockcnt, nb * sizeof(int32_t)));
         EK_HIP(hipMalloc((void **)&c->scan, nb * sizeof(int64_t)));
         EK_HIP(hipMalloc((void **)&c->sel, 2 * sizeof(int64_t)));
-        EK_HIP(hipMalloc((void **)&c->sq_part,
-                         EK_SUMSQ_PART_DOUBLES * sizeof(double)));
+        {
+            EkPwShape hs[2];
+            const int64_t n_full = c->n / EK_PW_CHUNK;
+            const int last_len = (int)(c->n - n_full * EK_PW_CHUNK);
+            ek_pw_build_shape(n_full > 0 ? EK_PW_CHUNK : 0, &hs[0]);
+            ek_pw_build_shape(last_len, &hs[1]);
+            c->pw_n_full = (int)n_full;
+            c->pw_leaves = (int)n_full * EK_PW_FULL_LEAVES + hs[1].n_leaves;
+            c->pw_chunks = (int)n_full + (last_len > 0 ? 1 : 0);
+            EK_HIP(hipMalloc((void **)&c->pw_shapes, sizeof(hs)));
+            EK_HIP(hipMemcpy(c->pw_shapes, hs, sizeof(hs), hipMemcpyHostToDevice));
+            EK_HIP(hipMalloc((void **)&c->sq_part,
+                             (2 * (size_t)std::max(c->pw_leaves, 1) +
+                              2 * (size_t)std::max(c->pw_chunks, 1)) *
+                                 sizeof(double)));
+        }
         EK_HIP(hipMalloc((void **)&c->sq_out, 2 * sizeof(double)));
         EK_HIP(hipMalloc((void **)&c->bat_blockcnt,
                          (size_t)EK_MAX_CANDS * nb * sizeof(int32_t)));
@@ -1246,7 +1263,8 @@ static int ek_pam_tail(ek_ctx *c, int32_t cid, const float *newd,
     ek_launch_pam_scatter(c->amb, c->amb_best, c->amb_count, max_amb, c->ndist,
                           c->nassign, c->stream);
     ek_launch_sumsq_pack(c->dist, c->ndist, c->assign, c->nassign, c->n, win_lo,
-                         win_count, c->sq_part, c->amb_count, c->moved, out,
+                         win_count, c->pw_shapes, c->pw_n_full, c->pw_leaves,
+                         c->pw_chunks, c->sq_part, c->amb_count, c->moved, out,
                          c->stream);
     EK_CHECK_LAUNCH();
     return EK_OK;

@@ -214,15 +214,28 @@ void ek_launch_pam_trial(const float *tiles, const double *G, int A, float *aos,
                          const float *ext_aos, const double *ext_G,
                          unsigned int *amb_count, unsigned int *moved,
                          hipStream_t s);
+// numpy's summation order (ek_pam.hip, "cost sums in numpy's order")
+#define EK_PW_CHUNK 8192            // numpy's reduction buffer, in elements
+#define EK_PW_FULL_LEAVES 64        // leaves of a full chunk (128 elements each)
+#define EK_PW_MAX_LEAVES 128        // leaves (and internal nodes) of any chunk
+struct EkPwShape {
+    int32_t n_leaves, n_nodes, n_levels, pad;
+    int32_t leaf_off[EK_PW_MAX_LEAVES];   // relative to the chunk
+    int32_t leaf_len[EK_PW_MAX_LEAVES];
+    int32_t node_l[EK_PW_MAX_LEAVES];     // children: < n_leaves a leaf, else
+    int32_t node_r[EK_PW_MAX_LEAVES];     //   n_leaves + node index
+    int32_t level_start[16];              // nodes of level i: [start[i], start[i+1])
+};
+void ek_pw_build_shape(int len, EkPwShape *sh);      // host
 void ek_launch_sumsq_pack(const float *a, const float *b, const int32_t *assign,
                           const int32_t *nassign, int64_t n, int32_t win_lo,
-                          int32_t win_count, double *part,
+                          int32_t win_count, const EkPwShape *shapes, int n_full,
+                          int n_leaves_total, int n_chunks, double *part,
                           const unsigned int *n_amb, unsigned int *moved,
                           EkPamOut *out, hipStream_t s);
 void ek_launch_gather_rows(const float *tiles, const double *G, int A,
                            const int64_t *idx_dev, const int64_t *rows_dev,
                            int count, float *out_aos, double *outG, hipStream_t s);
-#define EK_SUMSQ_PART_DOUBLES 2048
 
 // ---- multi-candidate rounds (ek_spec.hip) ---------------------------------------
 void ek_launch_plan(const unsigned char *recs, int n_recs, int A, int T,

@@ -608,9 +608,8 @@ void ek_launch_pam_scatter(const uint32_t *amb,
 // ---- cost: sum of squares in float64, fixed reduction order -----------------------
 // (kmedoids.py:478-479 takes np.square(x).mean() in float64; each square of a
 // float32 is exact in float64, only the summation order differs from numpy's
-// pairwise sum, by a few ulp of the total; kernels: ek_sumsq_moved_kernel,
-// ek_sumsq_pack_kernel below)
-#define SQ_BLOCKS 1024
+// pairwise sum, by a few ulp of the total -- unless the order is numpy's own:
+// see "cost sums in numpy's order" below)
 
 // ---- the trial medoid table ---------------------------------------------------------------
 // One workgroup prepares the trial medoid table and the counters of a proposal:
@@ -668,107 +667,235 @@ void ek_launch_pam_trial(const float *tiles, const double *G, int A, float *aos,
                        ext_aos, ext_G, amb_count, moved);
 }
 
-// Cost sums of the old and the trial state (slab per workgroup, fixed order),
-// and -- for the clusters win_lo..win_lo+win_count-1 the host has drawn
-// proposals for ahead of time -- bit i of *mask set when some frame enters or
-// leaves cluster win_lo + i in going from assign to nassign (their member lists
-// are then stale after an acceptance); one read of both states
+// ---- cost sums in numpy's order ------------------------------------------------------------
+// The reference compares np.square(d).mean() of the old and the trial
+// distances (kmedoids.py:478-479, :680-683).  When a proposal only permutes
+// distances -- a two-member cluster swapping its medoid -- the two means are
+// equal in exact arithmetic and the comparison is decided by the rounding of the
+// summation, so the sum has to be taken in numpy's own order: the array is cut
+// into buffer chunks of 8192 elements; each chunk is summed pairwise -- halves
+// (the left one rounded down to a multiple of 8) down to leaves of <= 128
+// elements, a leaf being eight interleaved running sums combined as
+// ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) plus a sequential tail -- and the chunk
+// sums are added up left to right.  (numpy/_core/src/umath/loops_utils.h.src,
+// pairwise sum; checked against numpy for lengths 1..1.3e6.)  The shapes of a
+// full chunk and of the last, shorter one are tabulated by the host
+// (ek_pw_build_shape) and shared by every launch.
+
+// one 8-lane group per leaf; moved-cluster mask as a by-product of the same read
 __global__ void __launch_bounds__(EK_BLOCK)
-ek_sumsq_moved_kernel(const float *__restrict__ a, const float *__restrict__ b,
-                      const int32_t *__restrict__ assign,
-                      const int32_t *__restrict__ nassign, int64_t n,
-                      int32_t win_lo, int32_t win_count,
-                      double *__restrict__ part, unsigned int *__restrict__ mask)
+ek_pw_leaf_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                  const int32_t *__restrict__ assign,
+                  const int32_t *__restrict__ nassign, int64_t n, int32_t win_lo,
+                  int32_t win_count, const EkPwShape *__restrict__ shapes,
+                  int n_full, int n_leaves_total, double *__restrict__ leafsum,
+                  unsigned int *__restrict__ mask)
 {
-    __shared__ double sa[EK_BLOCK], sb[EK_BLOCK];
     __shared__ unsigned int acc;
-    const int t = threadIdx.x;
-    if (t == 0)
+    if (threadIdx.x == 0)
         acc = 0;
-    const int64_t per = (n + SQ_BLOCKS - 1) / SQ_BLOCKS;
-    const int64_t lo = (int64_t)blockIdx.x * per;
-    const int64_t hi = (lo + per < n) ? lo + per : n;
-    double xa = 0.0, xb = 0.0;
+    __syncthreads();
+    const int g = blockIdx.x * (EK_BLOCK / 8) + threadIdx.x / 8;
+    const int l8 = threadIdx.x & 7;
     unsigned int m = 0;
-    for (int64_t f = lo + t; f < hi; f += EK_BLOCK) {
-        const double va = a[f], vb = b[f];
-        xa = xa + va * va;
-        xb = xb + vb * vb;
-        if (win_count > 0) {
-            const int32_t oa = assign[f], na = nassign[f];
-            if (oa != na) {
-                const int32_t ia = oa - win_lo, ib = na - win_lo;
-                if (ia >= 0 && ia < win_count)
-                    m |= 1u << ia;
-                if (ib >= 0 && ib < win_count)
-                    m |= 1u << ib;
+    if (g < n_leaves_total) {
+        const EkPwShape *sh = &shapes[0];
+        int chunk = g / EK_PW_FULL_LEAVES, leaf = g % EK_PW_FULL_LEAVES;
+        if (chunk >= n_full) {
+            chunk = n_full;
+            leaf = g - n_full * EK_PW_FULL_LEAVES;
+            sh = &shapes[1];
+        }
+        const int64_t off = (int64_t)chunk * EK_PW_CHUNK + sh->leaf_off[leaf];
+        const int len = sh->leaf_len[leaf];
+        double ra = 0.0, rb = 0.0;
+        const int body = (len < 8) ? 0 : len - (len % 8);
+        if (body > 0) {
+            for (int i = 0; i < body; i += 8) {
+                const int64_t f = off + i + l8;
+                const double va = a[f], vb = b[f];
+                if (i == 0) {
+                    ra = va * va;
+                    rb = vb * vb;
+                } else {
+                    ra = ra + va * va;
+                    rb = rb + vb * vb;
+                }
+                if (win_count > 0) {
+                    const int32_t oa = assign[f], na = nassign[f];
+                    if (oa != na) {
+                        const int32_t ia = oa - win_lo, ib = na - win_lo;
+                        if (ia >= 0 && ia < win_count)
+                            m |= 1u << ia;
+                        if (ib >= 0 && ib < win_count)
+                            m |= 1u << ib;
+                    }
+                }
+            }
+#pragma unroll
+            for (int off8 = 1; off8 < 8; off8 <<= 1) {   // (r0+r1)+(r2+r3) ...
+                ra = ra + __shfl_xor(ra, off8, 8);
+                rb = rb + __shfl_xor(rb, off8, 8);
             }
         }
+        if (l8 == 0) {
+            for (int i = body; i < len; ++i) {          // sequential tail
+                const int64_t f = off + i;
+                const double va = a[f], vb = b[f];
+                ra = ra + va * va;
+                rb = rb + vb * vb;
+                if (win_count > 0) {
+                    const int32_t oa = assign[f], na = nassign[f];
+                    if (oa != na) {
+                        const int32_t ia = oa - win_lo, ib = na - win_lo;
+                        if (ia >= 0 && ia < win_count)
+                            m |= 1u << ia;
+                        if (ib >= 0 && ib < win_count)
+                            m |= 1u << ib;
+                    }
+                }
+            }
+            leafsum[2 * (size_t)g + 0] = ra;
+            leafsum[2 * (size_t)g + 1] = rb;
+        }
     }
-    sa[t] = xa;
-    sb[t] = xb;
-    __syncthreads();
     if (m)
         atomicOr(&acc, m);
-    for (int w = EK_BLOCK / 2; w > 0; w >>= 1) {
-        if (t < w) {
-            sa[t] = sa[t] + sa[t + w];
-            sb[t] = sb[t] + sb[t + w];
+    __syncthreads();
+    if (threadIdx.x == 0 && acc)
+        atomicOr(mask, acc);
+}
+
+// one workgroup per chunk: the pairwise tree over its leaves, level by level
+__global__ void __launch_bounds__(128)
+ek_pw_chunk_kernel(const double *__restrict__ leafsum,
+                   const EkPwShape *__restrict__ shapes, int n_full,
+                   double *__restrict__ chunksum)
+{
+    __shared__ double va[2 * EK_PW_MAX_LEAVES], vb[2 * EK_PW_MAX_LEAVES];
+    const int chunk = blockIdx.x;
+    const EkPwShape *sh = (chunk < n_full) ? &shapes[0] : &shapes[1];
+    const int first = (chunk < n_full) ? chunk * EK_PW_FULL_LEAVES
+                                       : n_full * EK_PW_FULL_LEAVES;
+    const int nl = sh->n_leaves, t = threadIdx.x;
+    for (int i = t; i < nl; i += 128) {
+        va[i] = leafsum[2 * (size_t)(first + i) + 0];
+        vb[i] = leafsum[2 * (size_t)(first + i) + 1];
+    }
+    __syncthreads();
+    for (int lev = 0; lev < sh->n_levels; ++lev) {
+        const int k0 = sh->level_start[lev], k1 = sh->level_start[lev + 1];
+        for (int k = k0 + t; k < k1; k += 128) {
+            const int l = sh->node_l[k], r = sh->node_r[k];
+            va[nl + k] = va[l] + va[r];
+            vb[nl + k] = vb[l] + vb[r];
         }
         __syncthreads();
     }
     if (t == 0) {
-        part[2 * blockIdx.x + 0] = sa[0];
-        part[2 * blockIdx.x + 1] = sb[0];
-        if (acc)
-            atomicOr(mask, acc);
+        const int root = (sh->n_nodes > 0) ? nl + sh->n_nodes - 1 : 0;
+        chunksum[2 * (size_t)chunk + 0] = va[root];
+        chunksum[2 * (size_t)chunk + 1] = vb[root];
     }
 }
 
-// final sums packed with the counters into the one record the host reads back
-// (or, across shards, exchanges)
-__global__ void __launch_bounds__(EK_BLOCK)
-ek_sumsq_pack_kernel(const double *__restrict__ part,
-                     const unsigned int *__restrict__ n_amb,
-                     const unsigned int *__restrict__ moved, int64_t n,
-                     EkPamOut *__restrict__ out)
+// chunk sums left to right, packed with the counters into the one record the
+// host reads back (or, across shards, exchanges)
+__global__ void ek_pw_pack_kernel(const double *__restrict__ chunksum, int n_chunks,
+                                  const unsigned int *__restrict__ n_amb,
+                                  const unsigned int *__restrict__ moved, int64_t n,
+                                  EkPamOut *__restrict__ out)
 {
-    __shared__ double sa[EK_BLOCK], sb[EK_BLOCK];
-    const int t = threadIdx.x;
-    double xa = 0.0, xb = 0.0;
-    for (int i = t; i < SQ_BLOCKS; i += EK_BLOCK) {
-        xa = xa + part[2 * i + 0];
-        xb = xb + part[2 * i + 1];
+    if (threadIdx.x != 0)
+        return;
+    double sa = 0.0, sb = 0.0;
+    for (int c = 0; c < n_chunks; ++c) {
+        sa = sa + chunksum[2 * (size_t)c + 0];
+        sb = sb + chunksum[2 * (size_t)c + 1];
     }
-    sa[t] = xa;
-    sb[t] = xb;
-    __syncthreads();
-    for (int w = EK_BLOCK / 2; w > 0; w >>= 1) {
-        if (t < w) {
-            sa[t] = sa[t] + sa[t + w];
-            sb[t] = sb[t] + sb[t + w];
-        }
-        __syncthreads();
-    }
-    if (t == 0) {
-        out->sum_old = sa[0];
-        out->sum_new = sb[0];
-        out->n_frames = n;
-        out->n_amb = *n_amb;
-        out->moved = *moved;
-    }
+    out->sum_old = sa;
+    out->sum_new = sb;
+    out->n_frames = n;
+    out->n_amb = *n_amb;
+    out->moved = *moved;
 }
 
 void ek_launch_sumsq_pack(const float *a, const float *b, const int32_t *assign,
                           const int32_t *nassign, int64_t n, int32_t win_lo,
-                          int32_t win_count, double *part,
+                          int32_t win_count, const EkPwShape *shapes, int n_full,
+                          int n_leaves_total, int n_chunks, double *part,
                           const unsigned int *n_amb, unsigned int *moved,
                           EkPamOut *out, hipStream_t s)
 {
-    hipLaunchKernelGGL(ek_sumsq_moved_kernel, dim3(SQ_BLOCKS), dim3(EK_BLOCK), 0, s,
-                       a, b, assign, nassign, n, win_lo, win_count, part, moved);
-    hipLaunchKernelGGL(ek_sumsq_pack_kernel, dim3(1), dim3(EK_BLOCK), 0, s, part,
-                       n_amb, moved, n, out);
+    double *leafsum = part;
+    double *chunksum = part + 2 * (size_t)n_leaves_total;
+    if (n_leaves_total > 0) {
+        const int per = EK_BLOCK / 8;
+        hipLaunchKernelGGL(ek_pw_leaf_kernel, dim3((n_leaves_total + per - 1) / per),
+                           dim3(EK_BLOCK), 0, s, a, b, assign, nassign, n, win_lo,
+                           win_count, shapes, n_full, n_leaves_total, leafsum,
+                           moved);
+        hipLaunchKernelGGL(ek_pw_chunk_kernel, dim3(n_chunks), dim3(128), 0, s,
+                           leafsum, shapes, n_full, chunksum);
+    }
+    hipLaunchKernelGGL(ek_pw_pack_kernel, dim3(1), dim3(EK_WAVE), 0, s, chunksum,
+                       n_chunks, n_amb, moved, n, out);
+}
+
+// host: the pairwise tree of a chunk of `len` elements (len <= EK_PW_CHUNK)
+static int ek_pw_rec(int off, int len, EkPwShape *sh, int *node_level,
+                     int *tmp_l, int *tmp_r, int *n_tmp)
+{
+    if (len <= 128) {
+        const int id = sh->n_leaves++;
+        sh->leaf_off[id] = off;
+        sh->leaf_len[id] = len;
+        return id;                              // leaves: ids 0..
+    }
+    int n2 = len / 2;
+    n2 -= n2 % 8;
+    const int l = ek_pw_rec(off, n2, sh, node_level, tmp_l, tmp_r, n_tmp);
+    const int r = ek_pw_rec(off + n2, len - n2, sh, node_level, tmp_l, tmp_r, n_tmp);
+    const int k = (*n_tmp)++;
+    tmp_l[k] = l;
+    tmp_r[k] = r;
+    const int ll = (l >= 1000) ? node_level[l - 1000] : 0;
+    const int lr = (r >= 1000) ? node_level[r - 1000] : 0;
+    node_level[k] = 1 + (ll > lr ? ll : lr);
+    return 1000 + k;                            // internal nodes: ids 1000..
+}
+
+void ek_pw_build_shape(int len, EkPwShape *sh)
+{
+    *sh = EkPwShape();
+    if (len <= 0)
+        return;
+    int node_level[EK_PW_MAX_LEAVES], tmp_l[EK_PW_MAX_LEAVES], tmp_r[EK_PW_MAX_LEAVES];
+    int n_tmp = 0;
+    ek_pw_rec(0, len, sh, node_level, tmp_l, tmp_r, &n_tmp);
+    // order the internal nodes by level (children before parents), root last
+    int order[EK_PW_MAX_LEAVES], pos[EK_PW_MAX_LEAVES], cnt = 0, max_level = 0;
+    for (int k = 0; k < n_tmp; ++k)
+        if (node_level[k] > max_level)
+            max_level = node_level[k];
+    sh->n_levels = max_level;
+    for (int lev = 1; lev <= max_level; ++lev) {
+        sh->level_start[lev - 1] = cnt;
+        for (int k = 0; k < n_tmp; ++k)
+            if (node_level[k] == lev) {
+                pos[k] = cnt;
+                order[cnt++] = k;
+            }
+    }
+    sh->level_start[max_level] = cnt;
+    sh->n_nodes = cnt;
+    const int nl = sh->n_leaves;
+    for (int q = 0; q < cnt; ++q) {
+        const int k = order[q];
+        const int l = tmp_l[k], r = tmp_r[k];
+        sh->node_l[q] = (l >= 1000) ? nl + pos[l - 1000] : l;
+        sh->node_r[q] = (r >= 1000) ? nl + pos[r - 1000] : r;
+    }
 }
 
 // ---- proposal prefetch restricted to the frames a proposal can touch ------------------
