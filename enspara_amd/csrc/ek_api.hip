@@ -1252,7 +1252,10 @@ static int ek_pam_tail(ek_ctx *c, int32_t cid, const float *newd,
     // only when dist[f] is known to be the distance to medoid assign[f] (a state
     // this library produced; not one uploaded by the caller) may the search skip
     // medoids out of the members' reach
-    const bool prune = c->prune && c->state_exact;
+    // (and not for 1- or 2-atom "structures": collinear points make the largest
+    // root of the QCP quartic a double root, the computed distances are then too
+    // erratic to be treated as a metric)
+    const bool prune = c->prune && c->state_exact && c->A >= 3;
     if (prune)
         ek_launch_pam_prune(c->med_aos, c->med_G, c->A, K, cid, c->amb_count + 1,
                             c->med_list, c->amb_count + 2, c->stream);
@@ -1541,7 +1544,8 @@ static int ek_pam_prefetch_vectors(ek_ctx *c, int count, int32_t win_lo,
     const int K = c->med_K;
     if (c->pf_backoff > 0)
         --c->pf_backoff;
-    else if (c->prune && c->state_exact && win_count > 0 && c->n >= 16384) {
+    else if (c->prune && c->state_exact && c->A >= 3 && win_count > 0 &&
+             c->n >= 16384) {
         if (!c->act_n_host)
             EK_HIP(hipHostMalloc((void **)&c->act_n_host, sizeof(unsigned int),
                                  hipHostMallocDefault));
