@@ -801,18 +801,35 @@ ek_pw_chunk_kernel(const double *__restrict__ leafsum,
 
 // chunk sums left to right, packed with the counters into the one record the
 // host reads back (or, across shards, exchanges)
-__global__ void ek_pw_pack_kernel(const double *__restrict__ chunksum, int n_chunks,
-                                  const unsigned int *__restrict__ n_amb,
-                                  const unsigned int *__restrict__ moved, int64_t n,
-                                  EkPamOut *__restrict__ out)
+__global__ void __launch_bounds__(EK_BLOCK)
+ek_pw_pack_kernel(const double *__restrict__ chunksum, int n_chunks,
+                  const unsigned int *__restrict__ n_amb,
+                  const unsigned int *__restrict__ moved, int64_t n,
+                  EkPamOut *__restrict__ out)
 {
-    if (threadIdx.x != 0)
-        return;
+    // the chunk sums come in with one parallel read; the additions stay in
+    // numpy's left-to-right order
+    __shared__ double sa_s[EK_BLOCK], sb_s[EK_BLOCK];
+    const int t = threadIdx.x;
     double sa = 0.0, sb = 0.0;
-    for (int c = 0; c < n_chunks; ++c) {
-        sa = sa + chunksum[2 * (size_t)c + 0];
-        sb = sb + chunksum[2 * (size_t)c + 1];
+    for (int c0 = 0; c0 < n_chunks; c0 += EK_BLOCK) {
+        const int c = c0 + t;
+        if (c < n_chunks) {
+            sa_s[t] = chunksum[2 * (size_t)c + 0];
+            sb_s[t] = chunksum[2 * (size_t)c + 1];
+        }
+        __syncthreads();
+        if (t == 0) {
+            const int m = (n_chunks - c0 < EK_BLOCK) ? n_chunks - c0 : EK_BLOCK;
+            for (int k = 0; k < m; ++k) {
+                sa = sa + sa_s[k];
+                sb = sb + sb_s[k];
+            }
+        }
+        __syncthreads();
     }
+    if (t != 0)
+        return;
     out->sum_old = sa;
     out->sum_new = sb;
     out->n_frames = n;
@@ -838,7 +855,7 @@ void ek_launch_sumsq_pack(const float *a, const float *b, const int32_t *assign,
         hipLaunchKernelGGL(ek_pw_chunk_kernel, dim3(n_chunks), dim3(128), 0, s,
                            leafsum, shapes, n_full, chunksum);
     }
-    hipLaunchKernelGGL(ek_pw_pack_kernel, dim3(1), dim3(EK_WAVE), 0, s, chunksum,
+    hipLaunchKernelGGL(ek_pw_pack_kernel, dim3(1), dim3(EK_BLOCK), 0, s, chunksum,
                        n_chunks, n_amb, moved, n, out);
 }
 
