@@ -3,17 +3,16 @@ calc_imp_times :12-42, implied_timescales :45-100), composed from the device
 kernels: counts -> normalise -> leading eigenvalues, once per lag time."""
 import numpy as np
 
-from ..exception import ImproperlyConfigured
 from .transition_matrices import assigns_to_counts, eigenspectrum
+from .trimming import trim_disconnected
 
 
 def calc_imp_times(assigns, lag_time, n_states, n_times, method,
                    sliding_window, trim, device=0):
-    if trim:
-        raise ImproperlyConfigured(
-            "ergodic trimming is not available in this build")
     C = assigns_to_counts(assigns, max_n_states=n_states, lag_time=lag_time,
                           sliding_window=sliding_window, device=device)
+    if trim:                                              # timescales.py:26-27
+        _, C = trim_disconnected(C)
     _, T, _ = method(C)
     n_times += 1                       # +1 accounts for the stationary mode
     e_vals, _ = eigenspectrum(T, n_eigs=n_times, device=device)

@@ -120,6 +120,10 @@ def make_trim_golden(rtm, rbuilders):
     out["msm_tprobs"] = np.asarray(m.tprobs_.todense())
     out["msm_eq"] = np.asarray(m.eq_probs_)
     out["msm_map"] = np.array(sorted(m.mapping_.to_original.items()))
+    from enspara.msm import timescales as rts
+    out["implied_lags"] = np.array([1, 2, 4])
+    out["implied_times_trim"] = rts.implied_timescales(
+        assigns, [1, 2, 4], rbuilders.normalize, n_times=3, trim=True)
     np.savez_compressed(os.path.join(HERE, "trim_golden.npz"), **out)
     print("trim_golden.npz", os.path.getsize(
         os.path.join(HERE, "trim_golden.npz")) // 1024, "KiB")

@@ -159,3 +159,11 @@ def test_msm_with_ergodic_trimming(golden_dir):
     other = MSM(lag_time=1, method="normalize", trim=False, max_n_states=40)
     assert not (m == other)
     assert other.result_ is None
+
+
+def test_implied_timescales_with_trimming(golden_dir):
+    from enspara_amd.msm import builders, implied_timescales
+    G = np.load(os.path.join(golden_dir, "trim_golden.npz"))
+    got = implied_timescales(G["assigns"], [int(t) for t in G["implied_lags"]],
+                             builders.normalize, n_times=3, trim=True)
+    np.testing.assert_allclose(got, G["implied_times_trim"], rtol=1e-8)
