@@ -84,7 +84,14 @@ def hybrid(X, distance_method, n_iters=5, n_clusters=np.inf, dist_cutoff=0,
         raise NotImplementedError(
             "We haven't implemented kcenters 'random_first_center' yet.")
     if mpi_mode:
-        raise ImproperlyConfigured("mpi_mode is not available on this build")
+        # hybrid.py:112-162 in MPI mode: every rank passes its own frames
+        if init_centers is not None:
+            raise ImproperlyConfigured(
+                "mpi_mode does not take init_centers in this build")
+        from .. import sharded
+        return sharded.fit_sharded(
+            X, n_clusters=n_clusters, dist_cutoff=dist_cutoff, n_iters=n_iters,
+            random_state=random_state)
 
     with FrameStore.from_array(as_xyz(X), device=device) as store:
         result = _kc._kcenters_device(X, n_clusters, dist_cutoff, init_centers,

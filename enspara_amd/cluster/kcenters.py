@@ -91,9 +91,15 @@ def kcenters(traj, distance_method, n_clusters=np.inf, dist_cutoff=0,
         raise NotImplementedError(
             "We haven't implemented kcenters 'random_first_center' yet.")
     if mpi_mode:
-        raise ImproperlyConfigured(
-            "mpi_mode is not available: shard frames over GPUs with "
-            "enspara_amd.sharded.kcenters_sharded instead.")
+        # every rank of the torch.distributed group passes its own frames
+        # (kcenters.py:314-378); RMSD only, no warm start
+        if not util.is_device_rmsd(distance_method) or init_centers is not None:
+            raise ImproperlyConfigured(
+                "mpi_mode is available for metric 'rmsd' without init_centers "
+                "(one process per GPU over torch.distributed)")
+        from .. import sharded
+        return sharded.fit_sharded(
+            traj, n_clusters=n_clusters, dist_cutoff=dist_cutoff, n_iters=0)
 
     if util.is_device_rmsd(distance_method):
         return _kcenters_device(traj, n_clusters, dist_cutoff, init_centers,

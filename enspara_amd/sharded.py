@@ -533,3 +533,88 @@ def khybrid_sharded(shard, n_clusters, dist_cutoff=0.0, n_iters=5,
         medoids = pam_sweep_sharded(shard, medoids, random_state=rs,
                                     group=group)
     return medoids
+
+
+# ---------------------------------------------------------------------------
+# estimator-level entry: the reference's mpi_mode
+# ---------------------------------------------------------------------------
+def fit_sharded(traj, n_clusters=None, dist_cutoff=0.0, n_iters=0,
+                random_state=None, group=None):
+    """k-centers (+ ``n_iters`` PAM sweeps) where every rank of the initialised
+    ``torch.distributed`` group passes ITS OWN frames -- what ``mpi_mode=True``
+    means in the reference (kcenters.py:314-378, kmedoids.py MPI branch): rank
+    r's frames follow rank r-1's in the global order, ties go to the lowest
+    rank.  One process per GPU; the current CUDA device holds the shard.
+
+    Returns a ClusterResult like the reference's MPI mode: ``center_indices``
+    as (rank, local frame index) pairs (kcenters.py:375-376), ``assignments`` /
+    ``distances`` for this rank's frames, ``centers`` = the centers'
+    coordinates (float32 [A, 3] each), the same list on every rank.
+    ``random_state`` must be the same on every rank."""
+    import torch
+    import torch.distributed as dist
+    from .cluster import util
+    from .cluster.kcenters import check_random_state
+    from .device import FrameStore, as_xyz
+    from .exception import ImproperlyConfigured
+    if not (dist.is_available() and dist.is_initialized()):
+        raise ImproperlyConfigured(
+            "mpi_mode needs an initialised torch.distributed process group "
+            "(one process per GPU, e.g. under torchrun)")
+    xyz = as_xyz(traj)
+    n_local, A = int(xyz.shape[0]), int(xyz.shape[1])
+    world, rank = _world(group)
+    device = torch.cuda.current_device()
+    tstream = torch.cuda.Stream(device=device)
+    rs = check_random_state(random_state)
+    with torch.cuda.stream(tstream):
+        # where this rank's block starts in the global order
+        mine = torch.tensor([n_local], dtype=torch.int64, device="cuda")
+        everyone = torch.empty(world, dtype=torch.int64, device="cuda")
+        dist.all_gather_into_tensor(everyone, mine, group=group)
+        counts = [int(c) for c in everyone.cpu().numpy()]
+    starts = np.concatenate([[0], np.cumsum(counts)])
+    n_total = int(starts[-1])
+    if n_total == 0:
+        raise ValueError("cannot cluster an empty trajectory")
+    if n_clusters is None or np.isinf(n_clusters):
+        if not dist_cutoff:
+            raise ImproperlyConfigured("Either n_clusters or cluster_radius "
+                                       "is required for KHybrid clustering")
+        max_new = 2 * n_total + 16
+    else:
+        max_new = int(n_clusters)
+    with FrameStore(n_local, A, device=device, global_offset=int(starts[rank]),
+                    stream=tstream.cuda_stream) as store:
+        store.load(xyz)
+        store.reset_state()
+        shard = DeviceShard(store)
+        with torch.cuda.stream(tstream):
+            idx, _ = kcenters_sharded(shard, 0, max_new,
+                                      float(dist_cutoff or 0.0), group=group)
+            med = [int(g) for g in idx]
+            for _ in range(int(n_iters)):
+                med = pam_sweep_sharded(shard, med, random_state=rs,
+                                        group=group)
+            # the centers' own coordinates, from their owners
+            K = len(med)
+            tab = torch.zeros((max(K, 1), 3 * A), dtype=torch.float32,
+                              device="cuda")
+            lo, hi = int(starts[rank]), int(starts[rank + 1])
+            rows = [r for r, g in enumerate(med) if lo <= g < hi]
+            if rows:
+                loc = torch.from_numpy(np.ascontiguousarray(
+                    xyz[[med[r] - lo for r in rows]].reshape(len(rows), -1)))
+                tab[torch.tensor(rows, device="cuda")] = loc.to("cuda")
+            dist.all_reduce(tab.view(torch.int32), op=dist.ReduceOp.SUM,
+                            group=group)
+            centers_xyz = tab.cpu().numpy()
+        d, a = store.download_state()
+    pairs = []
+    for g in med:
+        r = int(np.searchsorted(starts, g, side="right") - 1)
+        pairs.append((r, int(g - starts[r])))
+    return util.ClusterResult(
+        center_indices=pairs, assignments=a.astype(np.int64),
+        distances=d.astype(np.float64),
+        centers=[centers_xyz[k].reshape(A, 3).copy() for k in range(len(med))])

@@ -192,3 +192,91 @@ def test_two_device_shards_on_one_gpu(tmp_path):
     np.testing.assert_array_equal(np.concatenate([p["a"] for p in parts]), wa)
     np.testing.assert_array_equal(
         np.concatenate([p["d"] for p in parts]).astype(np.float64), wd)
+
+
+# ---- the estimators' mpi_mode=True (every rank passes its own frames) ------------
+_CHILD3 = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+import torch
+import torch.distributed as dist
+rank, world, port, out, backend = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5], sys.argv[6]
+torch.cuda.set_device(0)
+if backend == "nccl":
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", port)
+    dist.init_process_group("nccl", rank=rank, world_size=world,
+                            device_id=torch.device("cuda", 0))
+else:
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + port,
+                            rank=rank, world_size=world)
+    _agit, _ar = dist.all_gather_into_tensor, dist.all_reduce
+    def agit(out_t, in_t, group=None):
+        torch.cuda.current_stream().synchronize()
+        o = torch.empty(out_t.shape, dtype=out_t.dtype)
+        _agit(o, in_t.cpu(), group=group)
+        out_t.copy_(o)
+    def ar(t, op=dist.ReduceOp.SUM, group=None):
+        torch.cuda.current_stream().synchronize()
+        h = t.cpu()
+        _ar(h, op=op, group=group)
+        t.copy_(h)
+    dist.all_gather_into_tensor, dist.all_reduce = agit, ar
+from enspara_amd import sharded, synth
+from enspara_amd.cluster import KCenters, KHybrid
+n, A, K = 5000, 12, 30
+x = synth.synth(n, A, 7, seed=13)
+lo, cnt = sharded.shard_bounds(n, world, rank)
+mine = x[lo:lo + cnt]
+kc = KCenters("rmsd", n_clusters=K, mpi_mode=True).fit(mine)
+hy = KHybrid("rmsd", n_clusters=K, kmedoids_updates=2, random_state=3,
+             mpi_mode=True).fit(mine)
+np.savez(out + ".%d.npz" % rank, lo=lo,
+         kc_ci=np.array(kc.center_indices_), kc_a=kc.labels_, kc_d=kc.distances_,
+         kc_c=np.array(kc.centers_),
+         hy_ci=np.array(hy.center_indices_), hy_a=hy.labels_, hy_d=hy.distances_,
+         hy_c=np.array(hy.centers_))
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("world,backend", [(1, "nccl"), (2, "gloo")])
+def test_estimators_in_mpi_mode(tmp_path, world, backend):
+    import socket
+    from enspara_amd import sharded
+    from oracle import cluster as oc
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = str(s.getsockname()[1])
+    s.close()
+    out = str(tmp_path / "r")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = [subprocess.Popen([sys.executable, "-c", _CHILD3, ROOT, str(r),
+                               str(world), port, out, backend], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                              text=True) for r in range(world)]
+    logs = [p.communicate(timeout=900)[0] for p in procs]
+    for p, log in zip(procs, logs):
+        assert p.returncode == 0, log[-4000:]
+    parts = [np.load(out + ".%d.npz" % r) for r in range(world)]
+    n, K = 5000, 30
+    x = synth.synth(n, 12, 7, seed=13)
+    starts = [sharded.shard_bounds(n, world, r)[0] for r in range(world)]
+    inds, a, d = oc.kcenters(x, n_clusters=K)
+    rs = np.random.RandomState(3)
+    wi, wd, wa = list(inds), d.copy(), a.copy()
+    for _ in range(2):
+        wi, wd, wa = oc.pam_update(x, wi, wa, wd, random_state=rs)
+    for key, want_i, want_a, want_d in (("kc", inds, a, d), ("hy", wi, wa, wd)):
+        for p in parts:             # (rank, local index) pairs, kcenters.py:375-376
+            got = [starts[int(r)] + int(i) for r, i in p[key + "_ci"]]
+            assert got == [int(i) for i in want_i]
+            np.testing.assert_array_equal(p[key + "_c"],
+                                          x[[int(i) for i in want_i]])
+        np.testing.assert_array_equal(
+            np.concatenate([p[key + "_a"] for p in parts]), want_a)
+        np.testing.assert_array_equal(
+            np.concatenate([p[key + "_d"] for p in parts]), want_d)
