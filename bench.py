@@ -283,8 +283,9 @@ def main():
                           % cands) if cands > 1 else
                          "k-centers, one pass over the frames per center",
             "templates": args.templates, "seed": args.seed,
-            "sharding": "contiguous frame blocks, 1 record all-gather/step"
-                        if use_dist else "single shard",
+            "sharding": ("contiguous frame blocks; per round of ~7 centers: "
+                         "all-gather of 8 candidate records + 320 B + 128 B "
+                         "per rank") if use_dist else "single shard",
         },
         "roofline": {
             "bound": "hbm",
