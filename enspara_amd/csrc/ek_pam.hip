@@ -148,8 +148,9 @@ void ek_launch_count_members(const int32_t *assign, int64_t n, int32_t cid,
                              hipStream_t s)
 {
     const int nblocks = (int)((n + EK_BLOCK - 1) / EK_BLOCK);
-    hipLaunchKernelGGL(ek_count_members_kernel, dim3(nblocks), dim3(EK_BLOCK),
-                       0, s, assign, n, cid, blockcnt);
+    if (nblocks > 0)            // an empty shard: the scan alone reports 0 members
+        hipLaunchKernelGGL(ek_count_members_kernel, dim3(nblocks), dim3(EK_BLOCK),
+                           0, s, assign, n, cid, blockcnt);
     hipLaunchKernelGGL(ek_scan_counts_kernel, dim3(1), dim3(1024), 0, s,
                        blockcnt, nblocks, scan, total);
 }
@@ -285,8 +286,10 @@ void ek_launch_count_members_multi(const int32_t *assign, int64_t n, int32_t cid
                                    int64_t *total, hipStream_t s)
 {
     const int nblocks = (int)((n + EK_BLOCK - 1) / EK_BLOCK);
-    hipLaunchKernelGGL(ek_count_members_multi_kernel, dim3(nblocks), dim3(EK_BLOCK),
-                       0, s, assign, n, cid0, count, nblocks, blockcnt);
+    if (nblocks > 0)
+        hipLaunchKernelGGL(ek_count_members_multi_kernel, dim3(nblocks),
+                           dim3(EK_BLOCK), 0, s, assign, n, cid0, count, nblocks,
+                           blockcnt);
     hipLaunchKernelGGL(ek_scan_counts_multi_kernel, dim3(count), dim3(1024), 0, s,
                        blockcnt, nblocks, scan, total);
 }
@@ -345,7 +348,8 @@ void ek_launch_pam_classify(const float *dist, const int32_t *assign,
                             hipStream_t s)
 {
     const int nblocks = (int)((n + EK_BLOCK - 1) / EK_BLOCK);
-    hipLaunchKernelGGL(ek_pam_classify_kernel, dim3(nblocks), dim3(EK_BLOCK), 0,
+    if (nblocks > 0)
+        hipLaunchKernelGGL(ek_pam_classify_kernel, dim3(nblocks), dim3(EK_BLOCK), 0,
                        s, dist, assign, newd, n, cid, ndist, nassign, amb,
                        amb_best, amb_count, reach);
 }

@@ -225,7 +225,7 @@ else:
     dist.all_gather_into_tensor, dist.all_reduce = agit, ar
 from enspara_amd import sharded, synth
 from enspara_amd.cluster import KCenters, KHybrid
-n, A, K = 5000, 12, 30
+n, A, K = int(sys.argv[7]), 12, int(sys.argv[8])
 x = synth.synth(n, A, 7, seed=13)
 lo, cnt = sharded.shard_bounds(n, world, rank)
 mine = x[lo:lo + cnt]
@@ -242,8 +242,11 @@ dist.destroy_process_group()
 """
 
 
-@pytest.mark.parametrize("world,backend", [(1, "nccl"), (2, "gloo")])
-def test_estimators_in_mpi_mode(tmp_path, world, backend):
+@pytest.mark.parametrize("world,backend,n,K", [(1, "nccl", 5000, 30),
+                                               (2, "gloo", 5000, 30),
+                                               (3, "gloo", 500, 12)])
+def test_estimators_in_mpi_mode(tmp_path, world, backend, n, K):
+    # (3 ranks over 500 frames = 2 tiles: the last rank owns no frames)
     import socket
     from enspara_amd import sharded
     from oracle import cluster as oc
@@ -255,14 +258,14 @@ def test_estimators_in_mpi_mode(tmp_path, world, backend):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     procs = [subprocess.Popen([sys.executable, "-c", _CHILD3, ROOT, str(r),
-                               str(world), port, out, backend], env=env,
+                               str(world), port, out, backend, str(n), str(K)],
+                              env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                               text=True) for r in range(world)]
     logs = [p.communicate(timeout=900)[0] for p in procs]
     for p, log in zip(procs, logs):
         assert p.returncode == 0, log[-4000:]
     parts = [np.load(out + ".%d.npz" % r) for r in range(world)]
-    n, K = 5000, 30
     x = synth.synth(n, 12, 7, seed=13)
     starts = [sharded.shard_bounds(n, world, r)[0] for r in range(world)]
     inds, a, d = oc.kcenters(x, n_clusters=K)

@@ -3,7 +3,7 @@ collectives) vs the oracle.  usage: mpi_mode_check.py <rank> <world> <port> <out
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-n, A, K = 9000, 10, 40
+n, A, K = [int(v) for v in os.environ.get("MM_SHAPE", "9000,10,40").split(",")]
 if sys.argv[1] == "check":
     from enspara_amd import sharded, synth
     from oracle import cluster as oc
