@@ -1,5 +1,13 @@
-"""sklearn-style MSM wrapper (reference enspara/msm/msm.py:27-120; fit :60-88)."""
+"""sklearn-style MSM wrapper (reference enspara/msm/msm.py:27-120; fit :60-88;
+load/save :190-281)."""
+import json
+import os
+import pickle
+import shutil
+import tempfile
+
 import numpy as np
+from scipy.io import mmread, mmwrite
 
 from ..exception import ImproperlyConfigured
 from . import builders
@@ -35,6 +43,56 @@ class MSM(object):
                                             range(tcounts.shape[0])))
         self.tcounts_, self.tprobs_, self.eq_probs_ = self.method(tcounts)
         return self
+
+    @classmethod
+    def load(cls, path, manifest="manifest.json"):
+        """Read back a directory written by ``save`` (reference msm.py:190-221):
+        the manifest names the files holding the mapping (csv), counts and
+        probabilities (MatrixMarket), equilibrium populations (text) and the
+        pickled configuration."""
+        if not os.path.isdir(path):
+            raise NotImplementedError("MSMs don't handle zip archives yet.")
+        with open(os.path.join(path, manifest)) as f:
+            names = json.load(f)
+        names = {k: os.path.join(path, v) for k, v in names.items()}
+        with open(names["config"], "rb") as f:
+            config = pickle.load(f)
+        m = cls(**config)
+        m.tcounts_ = mmread(names["tcounts_"])
+        m.tprobs_ = mmread(names["tprobs_"])
+        m.mapping_ = TrimMapping.load(names["mapping_"])
+        m.eq_probs_ = np.loadtxt(names["eq_probs_"])
+        return m
+
+    def save(self, path, force=False, zipfile=False, **filenames):
+        """Write the fitted model as a directory (reference msm.py:223-281;
+        same file names, formats and manifest).  ``force`` replaces an existing
+        directory (the reference calls ``os.remove`` on it, which cannot
+        succeed; here the directory is removed)."""
+        names = {"mapping_": "mapping.csv", "tcounts_": "tcounts.mtx",
+                 "tprobs_": "tprobs.mtx", "eq_probs_": "eq-probs.dat",
+                 "config": "config.pkl"}
+        names.update(filenames)
+        if zipfile:
+            raise NotImplementedError("MSMs don't do zip archives yet.")
+        with tempfile.TemporaryDirectory(prefix=os.path.basename(path)) as tmp:
+            with open(os.path.join(tmp, "manifest.json"), "w") as f:
+                json.dump(names, f, sort_keys=True, indent=4,
+                          separators=(",", ": "))
+            with open(os.path.join(tmp, names["mapping_"]), "w") as f:
+                self.mapping_.write(f)
+            with open(os.path.join(tmp, names["tcounts_"]), "wb") as f:
+                mmwrite(f, self.tcounts_)
+            with open(os.path.join(tmp, names["tprobs_"]), "wb") as f:
+                # 20 digits: the probabilities must survive the round trip
+                mmwrite(f, self.tprobs_, precision=20)
+            with open(os.path.join(tmp, names["eq_probs_"]), "wb") as f:
+                np.savetxt(f, np.array(self.eq_probs_))
+            with open(os.path.join(tmp, names["config"]), "wb") as f:
+                pickle.dump(self.config, f)
+            if force and os.path.isdir(path):
+                shutil.rmtree(path)
+            shutil.copytree(tmp, path)
 
     @property
     def config(self):

@@ -5,8 +5,10 @@ length go in as a RaggedArray of per-trajectory coordinate blocks and
 per-frame results come back partitioned the same way
 (reference enspara/ra/ra.py:487-855 for the class, :223-242 partition_indices,
 :361-376 partition_list, :27-43 where; behaviour pinned by the reference's
-enspara/test/test_ra.py).  Pure numpy; HDF5 save/load is out of scope here
-(PyTables is not part of this build).
+enspara/test/test_ra.py).  Pure numpy; ``save``/``load`` (reference
+ra.py:45-89, :117-220) read and write the same one-dataset-per-row HDF5 files
+through the package's own format implementation (``h5lite``), PyTables not
+being part of this build.
 
 Design differs from the reference: only ``_data`` (concatenated) and
 ``lengths`` are stored; rows are views into ``_data`` computed on demand from
@@ -17,6 +19,7 @@ import operator
 
 import numpy as np
 
+from . import h5lite
 from .exception import DataInvalid, ImproperlyConfigured
 
 
@@ -67,6 +70,71 @@ def where(mask):
         cols = flat - mask.starts[rows] if len(flat) else flat
         return (np.asarray(rows), np.asarray(cols))
     return np.where(mask)
+
+
+def save(filename, array, compression_level=1, tag='arr'):
+    """Write a RaggedArray (one dataset per row, ``<tag>_<zero-padded row>``) or
+    an ndarray (``<tag>_0``) to an HDF5 file, chunked with shuffle + zlib at
+    ``compression_level`` (reference ra.py:45-89)."""
+    if hasattr(array, "lengths"):
+        n_zeros = len(str(len(array.lengths))) + 1
+        dtype = array._data.dtype
+        rows = [np.asarray(array[i], dtype=dtype) for i in range(len(array))]
+    else:
+        n_zeros = 1
+        rows = [np.asarray(array)]
+    named = {}
+    for i, row in enumerate(rows):
+        named[tag + '_' + str(i).zfill(n_zeros)] = row
+    h5lite.write(filename, named, compression_level=compression_level)
+    return filename
+
+
+def load(input_name, keys=..., stride=1):
+    """Read a RaggedArray back (reference ra.py:117-220).  ``keys=...`` takes
+    every dataset of the file as a row, in name order; a single key comes back
+    as a plain ndarray; ``keys=None`` reads the old ``array``+``lengths`` (or
+    lone ``arr_0``) layout.  ``stride`` keeps every stride-th entry of each
+    row."""
+    with h5lite.File(input_name) as handle:
+        if keys is None:
+            if 'lengths' in handle:
+                a = RaggedArray(handle['array'].read(),
+                                lengths=handle['lengths'].read())
+                return a[::stride]
+            return handle['arr_0'].read()[::stride]
+        if keys is Ellipsis:
+            keys = handle.keys()
+        keys = [k.lstrip('/') for k in keys]
+        try:
+            nodes = [handle[k] for k in keys]
+        except KeyError as e:
+            raise KeyError("no dataset %s in %s" % (e, input_name))
+        if len(nodes) == 1:
+            return nodes[0].read()
+        shapes = [node.shape for node in nodes]
+        if not all(len(shapes[0]) == len(shape) for shape in shapes):
+            raise DataInvalid(
+                "Loading a RaggedArray using HDF5 file keys requires that all "
+                "input arrays have the same dimension. Got shapes: %s" % shapes)
+        for dim in range(1, len(shapes[0])):
+            if not all(shapes[0][dim] == shape[dim] for shape in shapes):
+                raise DataInvalid(
+                    "Loading a RaggedArray using HDF5 file keys requires that "
+                    "all input arrays share nonragged dimensions. Dimension "
+                    "%s didn't match. Got shapes: %s" % (dim, shapes))
+        dtype = nodes[0].dtype
+        if not all(dtype == node.dtype for node in nodes):
+            raise DataInvalid(
+                "Can't load keys in %s because the keys didn't have all the "
+                "same dtype. Keys were: %s" % (dtype, keys))
+        lengths = [(shape[0] + stride - 1) // stride for shape in shapes]
+        concat = np.zeros((sum(lengths),) + tuple(shapes[0][1:]), dtype=dtype)
+        start = 0
+        for node, n in zip(nodes, lengths):
+            concat[start:start + n] = node.read()[::stride]
+            start += n
+        return RaggedArray(array=concat, lengths=lengths, copy=False)
 
 
 def zeros_like(array, *args, **kwargs):

@@ -161,6 +161,21 @@ def test_msm_with_ergodic_trimming(golden_dir):
     assert other.result_ is None
 
 
+def test_fitted_msm_save_load(golden_dir, tmp_path):
+    """fit on the device -> save -> load gives an equal model (reference
+    test_msm_obj.py:60-111), for a trimmed and an untrimmed fit."""
+    from enspara_amd.msm import MSM
+    G = np.load(os.path.join(golden_dir, "trim_golden.npz"))
+    for trim, method in ((True, "normalize"), (False, "transpose")):
+        m = MSM(lag_time=1, method=method, trim=trim, max_n_states=40)
+        m.fit(G["assigns"])
+        d = str(tmp_path / ("msm_%d" % trim))
+        m.save(d)
+        back = MSM.load(d)
+        assert back == m
+        assert back.n_states_ == m.n_states_
+
+
 def test_implied_timescales_with_trimming(golden_dir):
     from enspara_amd.msm import builders, implied_timescales
     G = np.load(os.path.join(golden_dir, "trim_golden.npz"))

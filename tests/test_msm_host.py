@@ -152,3 +152,63 @@ def test_trim_disconnected_matches_reference_outputs(golden_dir):
                 np.testing.assert_array_equal(_dense(tc), G[key + "_counts"])
                 np.testing.assert_array_equal(
                     np.array(sorted(m.to_original.items())), G[key + "_map"])
+
+
+def _hand_fitted_msm():
+    """An MSM whose fitted fields are filled in on the host (fit itself runs
+    the device count kernel; tests/test_gpu_msm.py covers fit -> save -> load)."""
+    from enspara_amd.msm import MSM, builders
+    from enspara_amd.msm.trimming import TrimMapping
+    m = MSM(lag_time=3, method=builders.normalize, trim=True)
+    rng = np.random.default_rng(5)
+    C = scipy.sparse.random(40, 40, density=0.2, random_state=rng,
+                            format="csr", dtype=np.float64)
+    C.data = np.ceil(C.data * 20)
+    C = C + scipy.sparse.identity(40, format="csr")
+    w = np.asarray(C.sum(axis=1)).ravel()
+    m.tcounts_ = C
+    m.tprobs_ = scipy.sparse.diags(1.0 / w) @ C
+    m.eq_probs_ = w / w.sum()
+    m.mapping_ = TrimMapping(zip(range(2, 42), range(40)))
+    return m
+
+
+def test_msm_save_load_roundtrip(tmp_path):
+    """reference test_msm_obj.py:60-111"""
+    from enspara_amd.msm import MSM
+    m = _hand_fitted_msm()
+    d = str(tmp_path / "model")
+    m.save(d)
+    assert sorted(os.listdir(d)) == ["config.pkl", "eq-probs.dat",
+                                     "manifest.json", "mapping.csv",
+                                     "tcounts.mtx", "tprobs.mtx"]
+    back = MSM.load(d)
+    assert back == m and back.lag_time == 3 and back.trim is True
+    assert (back.tprobs_ != m.tprobs_).nnz == 0          # bit-for-bit
+
+    os.rename(os.path.join(d, "manifest.json"), os.path.join(d, "other.json"))
+    assert MSM.load(d, manifest="other.json") == m
+
+    d2 = str(tmp_path / "renamed")
+    names = {"tprobs_": "p.mtx", "tcounts_": "c.mtx", "eq_probs_": "pi.dat",
+             "mapping_": "map.csv"}
+    m.save(d2, **names)
+    for name in names.values():
+        assert os.path.isfile(os.path.join(d2, name))
+    assert MSM.load(d2) == m
+
+    with pytest.raises(FileExistsError):
+        m.save(d2)
+    m.save(d2, force=True)
+    assert MSM.load(d2) == m
+    with pytest.raises(NotImplementedError):
+        m.save(str(tmp_path / "z"), zipfile=True)
+    with pytest.raises(NotImplementedError):
+        MSM.load(os.path.join(d2, "p.mtx"))
+
+
+def test_msm_pickle_roundtrip():
+    """reference test_msm_obj.py:114-127"""
+    import pickle
+    m = _hand_fitted_msm()
+    assert pickle.loads(pickle.dumps(m)) == m
