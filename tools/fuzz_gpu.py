@@ -16,6 +16,8 @@ only = int(sys.argv[3]) if len(sys.argv) > 3 else -1
 bad = 0
 t0 = time.time()
 for case in (range(cases) if only < 0 else [only]):
+    if case and case % 200 == 0:
+        print("... %d cases, %d mismatches, %.0f s" % (case, bad, time.time() - t0), flush=True)
     rng = np.random.RandomState(base * 100003 + case)
     n = int(rng.choice([1, 2, 3, 5, 17, 63, 64, 65, 255, 256, 257, 1000, 1023, 4099, 20011]))
     A = int(rng.choice([1, 2, 3, 4, 7, 16, 33, 100]))

@@ -16,6 +16,8 @@ bad = 0
 t0 = time.time()
 ts = torch.cuda.Stream(device=0)
 for case in range(cases):
+    if case and case % 200 == 0:
+        print("... %d cases, %d mismatches, %.0f s" % (case, bad, time.time() - t0), flush=True)
     rng = np.random.RandomState(base * 100003 + case)
     n = int(rng.choice([1, 3, 63, 64, 65, 255, 257, 1000, 1025, 4099]))
     A = int(rng.choice([1, 2, 3, 5, 16, 33, 100]))

@@ -11,6 +11,8 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 base = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 bad = 0; t0 = time.time(); tot_r = tot_f = 0
 for case in range(cases):
+    if case and case % 5 == 0:
+        print("... %d cases, %d mismatches, %.0f s" % (case, bad, time.time() - t0), flush=True)
     rng = np.random.RandomState(base * 7919 + case)
     n = int(rng.randint(16384, 42000)); A = int(rng.choice([3, 4, 8, 20, 40]))
     nt = int(rng.choice([2, 10, 100, 400])); K = int(rng.choice([150, 300, 600, 900]))
