@@ -57,7 +57,9 @@ struct EkMaxHdr {
 static_assert(sizeof(EkMaxHdr) == 16, "max header is 16 bytes");
 
 typedef float ek_v2f __attribute__((ext_vector_type(2)));
-#define EK_MAX_CANDS 8
+#ifndef EK_MAX_CANDS
+#define EK_MAX_CANDS 8      // 16 only in measurement builds (tools/pass16_probe.py)
+#endif
 // plan of one multi-candidate round (ek_spec.hip); written only by the
 // single-workgroup plan/check kernels, read by the kernels that follow
 struct EkPlan {
@@ -90,7 +92,7 @@ struct EkChainRow {
     int32_t valid;
     float d[EK_MAX_CANDS];
 };
-static_assert(sizeof(EkChainRow) == 40, "EkChainRow layout");
+static_assert(sizeof(EkChainRow) == 8 + 4 * EK_MAX_CANDS, "EkChainRow layout");
 
 // ---- kernel launchers (defined in the .hip files) ---------------------------
 // centring + trace + frame-minor transposition of `count` AoS frames

@@ -209,7 +209,8 @@ void ek_launch_plan(const unsigned char *recs, int n_recs, int A, int T,
 // distances go to vecs[0..T-2]).  UPD = false: distances only, all T of them to
 // vecs[0..T-1] (PAM proposal prefetch); dist / assign / blockmax are not touched.
 template <int T, bool UPD>
-__global__ void __launch_bounds__(EK_BLOCK, (T <= 4) ? 5 : EK_SPEC_WAVES8)
+__global__ void __launch_bounds__(EK_BLOCK,
+                                  (T <= 4) ? 5 : (T <= 8 ? EK_SPEC_WAVES8 : 2))
 ek_pass_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
                float *__restrict__ dist, int32_t *__restrict__ assign,
                float *__restrict__ vecs,   // [T-1][n_pad] stored distance vectors
@@ -455,7 +456,7 @@ void ek_launch_pass_dist(int count, const float *tiles, const double *G,
     hipLaunchKernelGGL(ek_plan_fixed_kernel, dim3(1), dim3(EK_WAVE), 0, s, plan,
                        count);
     const unsigned blocks = (unsigned)((n + EK_BLOCK - 1) / EK_BLOCK);
-    const int T = (count <= 4) ? 4 : 8;
+    const int T = (count <= 4) ? 4 : (count <= 8 ? 8 : 16);
     const size_t lds = ek_pass_lds_bytes(T, A);
 #define EK_PASSD(TT)                                                           \
     do {                                                                       \
@@ -467,6 +468,11 @@ void ek_launch_pass_dist(int count, const float *tiles, const double *G,
                            dim3(EK_BLOCK), lds, s, tiles, G, nullptr, nullptr, \
                            vecs, n, n_pad, A, recs, plan, nullptr);            \
     } while (0)
+#if EK_MAX_CANDS >= 16
+    if (T == 16)
+        EK_PASSD(16);       // measurement builds only
+    else
+#endif
     if (T == 8)
         EK_PASSD(8);
     else
