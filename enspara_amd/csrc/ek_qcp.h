@@ -95,3 +95,102 @@ __device__ __forceinline__ float ek_rmsd_from_S(const float (&S)[9], double Gx,
 {
     return __builtin_sqrtf((float)ek_msd_from_S(S, Gx, Gy, n_atoms));
 }
+
+// The same solve, abandoned as soon as its result is known to be >= `cur`.
+// Beyond its largest root the quartic and its first two derivatives are
+// positive, so the Newton iterates fall monotonically from the upper bound
+// (Gx+Gy)/2 towards that root and (Gsum - 2*lam)/n_atoms, evaluated at any
+// iterate, is a lower bound of the final msd.  Once that bound exceeds cur^2 by
+// a margin far above every rounding involved (1e-4 relative, 1e-9 of Gsum
+// absolute; the arithmetic errs by ~1e-7 relative at most) the distance cannot
+// be below `cur`, which is all a strict "<" update (kcenters.py:304) asks, and
+// +inf is returned.  Otherwise the iteration is the one above, operation for
+// operation, and the result has the same bits.  cur = +inf never abandons, nor
+// does a quartic whose largest root is (nearly) double, see below.
+__device__ __forceinline__ float ek_rmsd_from_S_below(const float (&S)[9],
+                                                      double Gx, double Gy,
+                                                      int n_atoms, float cur)
+{
+    const double Sxx = S[0], Sxy = S[1], Sxz = S[2];
+    const double Syx = S[3], Syy = S[4], Syz = S[5];
+    const double Szx = S[6], Szy = S[7], Szz = S[8];
+
+    double q = Sxx * Sxx;
+    q = q + Sxy * Sxy;
+    q = q + Sxz * Sxz;
+    q = q + Syx * Syx;
+    q = q + Syy * Syy;
+    q = q + Syz * Syz;
+    q = q + Szx * Szx;
+    q = q + Szy * Szy;
+    q = q + Szz * Szz;
+    const double C2 = -2.0 * q;
+
+    const double m0 = Syy * Szz - Syz * Szy;
+    const double m1 = Syx * Szz - Syz * Szx;
+    const double m2 = Syx * Szy - Syy * Szx;
+    const double detS = (Sxx * m0 - Sxy * m1) + Sxz * m2;
+    const double C1 = -8.0 * detS;
+
+    const double k00 = (Sxx + Syy) + Szz;
+    const double k01 = Syz - Szy;
+    const double k02 = Szx - Sxz;
+    const double k03 = Sxy - Syx;
+    const double k11 = (Sxx - Syy) - Szz;
+    const double k12 = Sxy + Syx;
+    const double k13 = Szx + Sxz;
+    const double k22 = (Syy - Sxx) - Szz;
+    const double k23 = Syz + Szy;
+    const double k33 = (Szz - Sxx) - Syy;
+
+    const double s0 = k00 * k11 - k01 * k01;
+    const double s1 = k00 * k12 - k01 * k02;
+    const double s2 = k00 * k13 - k01 * k03;
+    const double s3 = k01 * k12 - k11 * k02;
+    const double s4 = k01 * k13 - k11 * k03;
+    const double s5 = k02 * k13 - k12 * k03;
+    const double c5 = k22 * k33 - k23 * k23;
+    const double c4 = k12 * k33 - k13 * k23;
+    const double c3 = k12 * k23 - k13 * k22;
+    const double c2 = k02 * k33 - k03 * k23;
+    const double c1 = k02 * k23 - k03 * k22;
+    const double c0 = k02 * k13 - k03 * k12;
+    double C0 = s0 * c5 - s1 * c4;
+    C0 = C0 + s2 * c3;
+    C0 = C0 + s3 * c2;
+    C0 = C0 - s4 * c1;
+    C0 = C0 + s5 * c0;
+
+    const double Gsum = Gx + Gy;
+    // The argument needs a simple largest root.  With singular values
+    // s1 >= s2 >= s3 of S the roots are s1+s2+s3, s1-s2-s3, -s1+s2-s3, -s1-s2+s3
+    // and C2^2 - 4 C0 = 16 (s1^2 s2^2 + s1^2 s3^2 + s2^2 s3^2): when that is tiny
+    // against C2^2 = 4 (s1^2+s2^2+s3^2)^2 (S of rank one: two-atom or collinear
+    // structures) the top root is double, the iteration ends in rounding noise
+    // and only the full solve reproduces it.  1e-4 keeps the gap above 1 % of s1.
+    const bool simple = C2 * C2 - 4.0 * C0 > 1e-4 * (C2 * C2);
+    const double far =
+        simple ? (double)n_atoms * (((double)cur * (double)cur) * 1.0001) +
+                     1e-9 * Gsum
+               : __builtin_inf();
+    double lam = 0.5 * Gsum;
+    for (int it = 0; it < EK_MAXIT; ++it) {
+        const double x2 = lam * lam;
+        const double b = (x2 + C2) * lam;
+        const double a = b + C1;
+        const double num = __builtin_fma(a, lam, C0);
+        const double den = __builtin_fma(2.0 * x2, lam, b + a);
+        if (den == 0.0)
+            break;
+        const double delta = num / den;
+        lam = lam - delta;
+        if (__builtin_fabs(delta) < __builtin_fabs(EK_EVALPREC * lam))
+            break;
+        if (Gsum - 2.0 * lam > far)
+            return __builtin_inff();
+    }
+    double msd = (Gsum - 2.0 * lam) / (double)n_atoms;
+    if (!(msd > 0.0))
+        msd = 0.0;
+    return __builtin_sqrtf((float)msd);
+}

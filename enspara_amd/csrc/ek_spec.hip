@@ -361,8 +361,9 @@ ek_pass_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
 #pragma unroll
         for (int j = 0; j < 9; ++j)
             S0[j] = s2[0][j][0];
-        const float d0 = ek_rmsd_from_S(S0, Gf, gtile[0], A);
         float cur = dist[f];
+        // (+inf when d0 >= cur is certain before the quartic has converged)
+        const float d0 = ek_rmsd_from_S_below(S0, Gf, gtile[0], A, cur);
         if (d0 < cur) {
             cur = d0;
             dist[f] = d0;
@@ -380,8 +381,10 @@ ek_pass_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
 #pragma unroll
                 for (int j = 0; j < 9; ++j)
                     S[j] = s2[c / 2][j][c & 1];
+                // every later use of a kept distance is a strict "<" against
+                // this frame's distance, which only shrinks from here on
                 vecs[(size_t)(c - 1) * n_pad + f] =
-                    ek_rmsd_from_S(S, Gf, gtile[c], A);
+                    ek_rmsd_from_S_below(S, Gf, gtile[c], A, cur);
             }
         }
     }
