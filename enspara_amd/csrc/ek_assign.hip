@@ -99,7 +99,8 @@ ek_assign_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
 #pragma unroll
                     for (int j = 0; j < 9; ++j)
                         S[j] = s2[c / 2][j][c & 1];
-                    const float d = ek_rmsd_from_S(S, Gf, gtile[c], A);
+                    // +inf once d >= best is certain (ek_qcp.h)
+                    const float d = ek_rmsd_from_S_below(S, Gf, gtile[c], A, best);
                     if (d < best) {          // strict <: util.py:201
                         best = d;
                         besti = k0 + c;
@@ -258,8 +259,15 @@ ek_assign_mfma_kernel(const float *__restrict__ tiles,
                     if (ablate & 1)    // timing only: no quartic solve
                         d = S[0] + S[1] + S[2] + S[3] + S[4] + S[5] + S[6] +
                             S[7] + S[8];
-                    else
-                        d = ek_rmsd_from_S(S, G[f], gc, A);
+                    else {
+                        // the frame's best so far only shrinks, so a stale
+                        // read is a valid bound; +inf once d >= it is certain
+                        // (ek_qcp.h; equal distances are never abandoned, the
+                        // lower center index must still win them)
+                        const float seen = __uint_as_float(
+                            ((volatile unsigned int *)&best[wf * 32 + f_l])[1]);
+                        d = ek_rmsd_from_S_below(S, G[f], gc, A, seen);
+                    }
                     const unsigned long long key =
                         ((unsigned long long)__float_as_uint(d) << 32) |
                         (unsigned int)c;

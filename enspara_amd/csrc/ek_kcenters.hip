@@ -207,11 +207,12 @@ ek_step_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
         for (int q = 0; q < FPL; ++q) {
             const int64_t f = f0 + q;
             if (f < n) {
-                const float d = ek_rmsd_from_S(s[q], G[f], Gc, A);
                 if (MODE == 1) {
-                    out_dist[f] = d;
+                    out_dist[f] = ek_rmsd_from_S(s[q], G[f], Gc, A);
                 } else {
                     float cur = dist[f];
+                    // +inf once d >= cur is certain (ek_qcp.h)
+                    const float d = ek_rmsd_from_S_below(s[q], G[f], Gc, A, cur);
                     if (d < cur) {              // strict <: kcenters.py:304
                         cur = d;
                         dist[f] = d;
