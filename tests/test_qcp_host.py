@@ -1,0 +1,122 @@
+"""The device header enspara_amd/csrc/ek_qcp.h compiled for the host (g++,
+-ffp-contract=off as in the device build) against the oracle, on the CPU.
+
+ * ek_rmsd_from_S gives the oracle's bits (oracle/qcp_oracle.c eko_msd_from_S:
+   same inner-product matrix in, same float32 distance out);
+ * ek_rmsd_from_S_below(.., cur) returns either those bits or +inf, and +inf
+   only where the distance is not below `cur` -- for generic structures, for
+   two- and three-atom ones, and for nearly collinear ones, where the largest
+   root of the quartic is (nearly) double and the early stop must not apply.
+"""
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import qcp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(os.path.dirname(HERE), "enspara_amd", "csrc")
+
+SHIM = r'''
+#define __device__
+#define __forceinline__ inline
+#include <cstdint>
+#include "ek_qcp.h"
+extern "C" void h_batch(const float *S, const double *Gx, const double *Gy,
+                        int n_atoms, const float *cur, int64_t m, float *full,
+                        float *below)
+{
+    for (int64_t i = 0; i < m; ++i) {
+        float s[9];
+        for (int j = 0; j < 9; ++j)
+            s[j] = S[9 * i + j];
+        full[i] = ek_rmsd_from_S(s, Gx[i], Gy[i], n_atoms);
+        below[i] = ek_rmsd_from_S_below(s, Gx[i], Gy[i], n_atoms, cur[i]);
+    }
+}
+'''
+
+
+@pytest.fixture(scope="module")
+def host(tmp_path_factory):
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    d = tmp_path_factory.mktemp("qcp_host")
+    os.makedirs(d / "hip")
+    (d / "hip" / "hip_runtime.h").write_text("")
+    (d / "shim.cpp").write_text(SHIM)
+    so = str(d / "qcp_host.so")
+    subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-shared", "-fPIC",
+                           "-I", str(d), "-I", CSRC, str(d / "shim.cpp"),
+                           "-o", so])
+    lib = C.CDLL(so)
+    lib.h_batch.restype = None
+    return lib
+
+
+def _pairs(rng, A, m, squash):
+    """m (frame, center) pairs of A atoms; squash < 1 flattens y and z."""
+    scale = rng.uniform(0.5, 3.5, size=(m, 1, 1))
+    shape = np.array([1.0, squash, squash])
+    x = rng.normal(size=(m, A, 3)) * scale * shape
+    similar = rng.random(m) < 0.5
+    y = np.where(similar[:, None, None],
+                 x + 0.05 * rng.normal(size=(m, A, 3)) * shape,
+                 rng.normal(size=(m, A, 3)) * scale * shape)
+    return x.astype(np.float32), y.astype(np.float32)
+
+
+def _run(host, rng, A, m, squash=1.0):
+    x, y = _pairs(rng, A, m, squash)
+    cx, Gx = qcp.center_and_trace(x)
+    cy, Gy = qcp.center_and_trace(y)
+    S = np.empty((m, 9), dtype=np.float32)
+    for i in range(m):
+        S[i] = qcp.S_matrices(cx[i:i + 1], cy[i])[0]
+    want = np.array([np.sqrt(np.float32(qcp.msd_from_S(S[i], Gx[i], Gy[i], A)))
+                     for i in range(m)], dtype=np.float32)
+    out = []
+    for factor in (0.2, 0.7, 0.999, 1.0, 1.001, 1.5, np.inf):
+        with np.errstate(invalid="ignore"):      # 0 * inf: a NaN bound, never stops
+            cur = (want * np.float32(factor)).astype(np.float32)
+        full = np.empty(m, dtype=np.float32)
+        below = np.empty(m, dtype=np.float32)
+        host.h_batch(S.ctypes.data_as(C.c_void_p), Gx.ctypes.data_as(C.c_void_p),
+                     Gy.ctypes.data_as(C.c_void_p), A,
+                     cur.ctypes.data_as(C.c_void_p), C.c_int64(m),
+                     full.ctypes.data_as(C.c_void_p),
+                     below.ctypes.data_as(C.c_void_p))
+        np.testing.assert_array_equal(full.view(np.uint32), want.view(np.uint32))
+        gave_up = np.isinf(below) & ~np.isinf(full)
+        kept = ~gave_up
+        np.testing.assert_array_equal(below[kept].view(np.uint32),
+                                      want[kept].view(np.uint32))
+        with np.errstate(invalid="ignore"):
+            assert not np.any(want[gave_up] < cur[gave_up])  # never a winner
+        if factor >= 1.0 and np.isfinite(factor):
+            assert not np.any(gave_up & (want > 0))          # d <= cur: solved
+        if not np.isfinite(factor):
+            assert not gave_up.any()
+        out.append(gave_up.mean())
+    return out
+
+
+@pytest.mark.parametrize("A", [1, 2, 3, 4, 7, 30])
+def test_host_compiled_device_quartic(host, A):
+    rng = np.random.default_rng(100 + A)
+    rates = _run(host, rng, A, 3000)
+    if A >= 4:
+        assert rates[0] > 0.9          # cur = 0.2 d: almost every solve stops early
+    if A <= 2:
+        assert max(rates) == 0.0       # rank-one S: always the full solve
+
+
+@pytest.mark.parametrize("squash", [1e-1, 1e-2, 1e-3, 1e-5, 0.0])
+def test_nearly_collinear_structures(host, squash):
+    rng = np.random.default_rng(int(-np.log10(squash + 1e-9) * 10))
+    for A in (3, 5, 12):
+        _run(host, rng, A, 1500, squash)
