@@ -118,16 +118,39 @@ def cpu_baseline(x, gpu_centers, seconds):
     wall = time.perf_counter() - t0
     k = len(centers)
     ok = [int(c) for c in gpu_centers[:k]] == centers
-    return {
+    cores = qcp.num_threads()
+    # the same loop on one thread, for a fifth of the budget
+    one = None
+    if cores > 1:
+        qcp.set_num_threads(1)
+        try:
+            d1 = np.full(n, np.inf, dtype=np.float32)
+            a1 = np.full(n, -1, dtype=np.int32)
+            k1, nxt = 0, 0
+            t0 = time.perf_counter()
+            while k1 < max(1, len(gpu_centers)):
+                mx, nxt = P.kcenters_step(P.c[nxt], P.G[nxt], k1, d1, a1)
+                k1 += 1
+                if time.perf_counter() - t0 > seconds / 5.0:
+                    break
+            w1 = time.perf_counter() - t0
+            one = {"value": n * k1 / w1,
+                   "sample": "%d iterations, %.1f s" % (k1, w1)}
+        finally:
+            qcp.set_num_threads(cores)
+    out = {
         "value": n * k / wall,
         "unit": "pairs/s",
-        "cores": qcp.num_threads(),
+        "cores": cores,
         "kind": "port",
         "sample": "all %d frames x first %d k-centers iterations "
                   "(%.1f s; centring+layout %.1f s not included)"
                   % (n, k, wall, prep),
         "centers_match_gpu": bool(ok),
     }
+    if one:
+        out["one_thread"] = one
+    return out
 
 
 def km_width():

@@ -25,6 +25,8 @@ def lib():
         i64p = C.POINTER(C.c_int64)
         L.eko_abi_version.restype = C.c_int
         L.eko_num_threads.restype = C.c_int
+        L.eko_set_num_threads.argtypes = [C.c_int]
+        L.eko_set_num_threads.restype = None
         L.eko_msd_from_S.restype = C.c_double
         f64p = C.POINTER(C.c_double)
         L.eko_msd_from_S.argtypes = [f32p, C.c_double, C.c_double, C.c_int]
@@ -63,6 +65,11 @@ def _i32(a):
 
 def num_threads():
     return lib().eko_num_threads()
+
+
+def set_num_threads(n):
+    """OpenMP threads for the calls that follow (bench.py's 1-thread figure)."""
+    lib().eko_set_num_threads(int(n))
 
 
 def as_xyz(X):

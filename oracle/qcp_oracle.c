@@ -64,6 +64,16 @@ int eko_num_threads(void)
 #endif
 }
 
+void eko_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0)
+        omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 /* ---- msd from the accumulated 3x3 matrix and the two traces -------------- */
 double eko_msd_from_S(const float S[9], double Gx, double Gy, int n_atoms)
 {
