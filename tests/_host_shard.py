@@ -215,6 +215,7 @@ class HostShard(_PamMixin):
 
 
 class HostShardRounds(HostShard):
+    far_as_inf = False
     """Same shard speaking the multi-candidate round protocol
     (ek_spec_begin / _round / _localmax / _apply / _round_end / _progress)."""
 
@@ -280,6 +281,12 @@ class HostShardRounds(HostShard):
             cands.append(dict(gidx=int(h["gidx"]), vec=vec, used=False))
         self.plan = dict(cands=cands, miss=False)
         self._accept(cands[0], float(hs[0][1]["maxdist"]))
+        if self.far_as_inf:
+            # what the device pass stores (ek_qcp.h ek_rmsd_from_S_below): a
+            # kept distance that is not below the frame's current one is +inf
+            for cand in cands[1:]:
+                cand["vec"] = np.where(cand["vec"] < self.dist, cand["vec"],
+                                       np.float32(np.inf)).astype(np.float32)
 
     def _accept(self, cand, maxdist):
         label = self.n_done

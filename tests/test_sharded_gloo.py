@@ -140,6 +140,28 @@ def test_single_process_without_process_group():
         np.testing.assert_array_equal(sh.dist.astype(np.float64), d)
 
 
+@pytest.mark.parametrize("cls_name,cands", [("HostShardRounds", 4),
+                                            ("HostShardChain", 8)])
+def test_rounds_only_compare_kept_distances(cls_name, cands):
+    """The device pass keeps +inf instead of a candidate's distance wherever that
+    distance is not below the frame's current one (ek_rmsd_from_S_below stops
+    the quartic early).  The round protocol only ever asks "is it smaller": the
+    same run with such vectors gives the same centers, labels and distances."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _host_shard
+    from enspara_amd import sharded, synth
+    from oracle import cluster as oc
+    for seed, n, K in ((2, 700, 40), (5, 1500, 120)):
+        x = synth.synth(n, 12, 7, seed=seed)
+        inds, a, d = oc.kcenters(x, n_clusters=K)
+        sh = getattr(_host_shard, cls_name)(x, 0, cands)
+        sh.far_as_inf = True
+        idx, cd = sharded.kcenters_sharded(sh, 0, K, 0.0)
+        np.testing.assert_array_equal(idx, np.array(inds))
+        np.testing.assert_array_equal(sh.assign, a)
+        np.testing.assert_array_equal(sh.dist.astype(np.float64), d)
+
+
 # ---- PAM sweeps / k-hybrid across ranks -------------------------------------
 def _hybrid_worker(rank, world, port, n, A, seed, K, n_iters, outdir, cands,
                    explicit, prefetch):
