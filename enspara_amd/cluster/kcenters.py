@@ -70,6 +70,12 @@ class KCenters(BaseEstimator, ClusterMixin, util.MolecularClusterMixin):
         return self
 
 
+def kcenters_mpi(*args, **kwargs):
+    """reference kcenters.py:103-105"""
+    kwargs.pop('mpi_mode', None)
+    return kcenters(*args, mpi_mode=True, **kwargs)
+
+
 def kcenters(traj, distance_method, n_clusters=np.inf, dist_cutoff=0,
              init_centers=None, random_first_center=False,
              use_triangle_inequality=False, mpi_mode=False, device=0):
