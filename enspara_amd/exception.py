@@ -6,7 +6,7 @@ code written against enspara catches the same things.
 
 
 class ImproperlyConfigured(Exception):
-    """The given configuration is incomplete or otherwise not usable."""
+    """Arguments that cannot be combined into a runnable configuration."""
 
 
 class DataInvalid(Exception):
