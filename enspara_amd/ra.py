@@ -115,19 +115,18 @@ def load(input_name, keys=..., stride=1):
         shapes = [node.shape for node in nodes]
         if not all(len(shapes[0]) == len(shape) for shape in shapes):
             raise DataInvalid(
-                "Loading a RaggedArray using HDF5 file keys requires that all "
-                "input arrays have the same dimension. Got shapes: %s" % shapes)
+                "The datasets to stack as rows differ in their number of "
+                "dimensions: shapes %s" % shapes)
         for dim in range(1, len(shapes[0])):
             if not all(shapes[0][dim] == shape[dim] for shape in shapes):
                 raise DataInvalid(
-                    "Loading a RaggedArray using HDF5 file keys requires that "
-                    "all input arrays share nonragged dimensions. Dimension "
-                    "%s didn't match. Got shapes: %s" % (dim, shapes))
+                    "The datasets to stack as rows must agree in every "
+                    "dimension but the first; dimension %s differs: shapes %s"
+                    % (dim, shapes))
         dtype = nodes[0].dtype
         if not all(dtype == node.dtype for node in nodes):
             raise DataInvalid(
-                "Can't load keys in %s because the keys didn't have all the "
-                "same dtype. Keys were: %s" % (dtype, keys))
+                "The datasets %s do not all have dtype %s" % (keys, dtype))
         lengths = [(shape[0] + stride - 1) // stride for shape in shapes]
         concat = np.zeros((sum(lengths),) + tuple(shapes[0][1:]), dtype=dtype)
         start = 0

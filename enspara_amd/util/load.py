@@ -97,15 +97,15 @@ def load_as_concatenated(filenames, lengths=None, processes=None, args=None,
     filenames = list(filenames)
     if kwargs and args:
         raise ImproperlyConfigured(
-            "Additional unnamed args can only be supplied iff no additonal "
-            "keyword args are supplied")
+            "Give the load options either once as keyword arguments or per "
+            "file in `args`, not both")
     elif kwargs:
         args = [kwargs] * len(filenames)
     elif args:
         if len(args) != len(filenames):
             raise ImproperlyConfigured(
-                "When add'l unnamed args are provided, len(args) == "
-                "len(filenames), but %s != %s." % (len(args), len(filenames)))
+                "`args` needs one dict per file: %s dicts for %s files"
+                % (len(args), len(filenames)))
     else:
         args = [{}] * len(filenames)
     for kw in args:
@@ -122,8 +122,8 @@ def load_as_concatenated(filenames, lengths=None, processes=None, args=None,
         lengths = [int(v) for v in lengths]
         if len(lengths) != len(filenames):
             raise ImproperlyConfigured(
-                "Lengths list (len %s) didn't match length of filenames list "
-                "(len %s)" % (len(lengths), len(filenames)))
+                "%s lengths were given for %s files"
+                % (len(lengths), len(filenames)))
     else:
         lengths = [_selected_length(_open_coordinates(f)[0], kw)
                    for f, kw in zip(filenames, args)]
@@ -142,7 +142,6 @@ def load_as_concatenated(filenames, lengths=None, processes=None, args=None,
         got = [_load_one(job) for job in jobs]
     if got != lengths:
         raise DataInvalid(
-            "The provided lengths (n=%s, total frames %s) weren't correct. "
-            "The correct total number of frames was %s."
-            % (len(lengths), sum(lengths), sum(got)))
+            "The given lengths add up to %s frames but the %s files hold %s."
+            % (sum(lengths), len(lengths), sum(got)))
     return lengths, xyz
