@@ -51,7 +51,8 @@ class MSM(object):
         probabilities (MatrixMarket), equilibrium populations (text) and the
         pickled configuration."""
         if not os.path.isdir(path):
-            raise NotImplementedError("MSMs don't handle zip archives yet.")
+            raise NotImplementedError(
+                "%s is not a directory; archived models are not supported" % path)
         with open(os.path.join(path, manifest)) as f:
             names = json.load(f)
         names = {k: os.path.join(path, v) for k, v in names.items()}
@@ -74,7 +75,7 @@ class MSM(object):
                  "config": "config.pkl"}
         names.update(filenames)
         if zipfile:
-            raise NotImplementedError("MSMs don't do zip archives yet.")
+            raise NotImplementedError("archived models are not supported")
         with tempfile.TemporaryDirectory(prefix=os.path.basename(path)) as tmp:
             with open(os.path.join(tmp, "manifest.json"), "w") as f:
                 json.dump(names, f, sort_keys=True, indent=4,
