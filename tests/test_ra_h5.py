@@ -237,6 +237,14 @@ def test_deep_trees_read_by_libhdf5(tmp_path, monkeypatch):
     b = ra.load(name)
     np.testing.assert_array_equal(b.lengths, a.lengths)
     np.testing.assert_array_equal(b._data, a._data)
+    # the same content with both kinds of tree rebuilt by libhdf5
+    again = str(tmp_path / "deep_repacked.h5")
+    r = subprocess.run([H5REPACK, "-l", "CHUNK=32x2", "-f", "GZIP=1", name, again],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    c = ra.load(again)
+    np.testing.assert_array_equal(c.lengths, a.lengths)
+    np.testing.assert_array_equal(c._data, a._data)
 
 
 @needs_tools
