@@ -129,6 +129,22 @@ __device__ __forceinline__ float ek_rmsd_from_S_below(const float (&S)[9],
     const double m0 = Syy * Szz - Syz * Szy;
     const double m1 = Syx * Szz - Syz * Szx;
     const double m2 = Syx * Szy - Syy * Szx;
+
+    // Before the remaining coefficients: the largest root is at most
+    // s1+s2+s3 <= sqrt(3 q), so 2 sqrt(3 q) < Gsum - far already settles it --
+    // provided that root is simple, which three of the nine 2x2 minors of S can
+    // certify (their squares sum to at most s1^2 s2^2 + s1^2 s3^2 + s2^2 s3^2;
+    // the full test below is the fallback when these three happen to be small).
+    const double Gsum = Gx + Gy;
+    const double far_if_simple =
+        (double)n_atoms * (((double)cur * (double)cur) * 1.0001) + 1e-9 * Gsum;
+    {
+        const double t = Gsum - far_if_simple;
+        if (t > 0.0 && t * t > 12.000001 * q &&
+            16.0 * ((m0 * m0 + m1 * m1) + m2 * m2) > 1e-4 * (C2 * C2))
+            return __builtin_inff();
+    }
+
     const double detS = (Sxx * m0 - Sxy * m1) + Sxz * m2;
     const double C1 = -8.0 * detS;
 
@@ -161,7 +177,6 @@ __device__ __forceinline__ float ek_rmsd_from_S_below(const float (&S)[9],
     C0 = C0 - s4 * c1;
     C0 = C0 + s5 * c0;
 
-    const double Gsum = Gx + Gy;
     // The argument needs a simple largest root.  With singular values
     // s1 >= s2 >= s3 of S the roots are s1+s2+s3, s1-s2-s3, -s1+s2-s3, -s1-s2+s3
     // and C2^2 - 4 C0 = 16 (s1^2 s2^2 + s1^2 s3^2 + s2^2 s3^2): when that is tiny
@@ -169,10 +184,7 @@ __device__ __forceinline__ float ek_rmsd_from_S_below(const float (&S)[9],
     // structures) the top root is double, the iteration ends in rounding noise
     // and only the full solve reproduces it.  1e-4 keeps the gap above 1 % of s1.
     const bool simple = C2 * C2 - 4.0 * C0 > 1e-4 * (C2 * C2);
-    const double far =
-        simple ? (double)n_atoms * (((double)cur * (double)cur) * 1.0001) +
-                     1e-9 * Gsum
-               : __builtin_inf();
+    const double far = simple ? far_if_simple : __builtin_inf();
     double lam = 0.5 * Gsum;
     for (int it = 0; it < EK_MAXIT; ++it) {
         const double x2 = lam * lam;
