@@ -97,16 +97,31 @@ __device__ __forceinline__ float ek_rmsd_from_S(const float (&S)[9], double Gx,
 }
 
 // The same solve, abandoned as soon as its result is known to be >= `cur`.
+//
 // Beyond its largest root the quartic and its first two derivatives are
 // positive, so the Newton iterates fall monotonically from the upper bound
 // (Gx+Gy)/2 towards that root and (Gsum - 2*lam)/n_atoms, evaluated at any
-// iterate, is a lower bound of the final msd.  Once that bound exceeds cur^2 by
-// a margin far above every rounding involved (1e-4 relative, 1e-9 of Gsum
-// absolute; the arithmetic errs by ~1e-7 relative at most) the distance cannot
-// be below `cur`, which is all a strict "<" update (kcenters.py:304) asks, and
-// +inf is returned.  Otherwise the iteration is the one above, operation for
-// operation, and the result has the same bits.  cur = +inf never abandons, nor
-// does a quartic whose largest root is (nearly) double, see below.
+// iterate, is a lower bound of the final msd; so is the value at sqrt(3 q),
+// q = sum S_ij^2, because the largest root is s1+s2+s3 <= sqrt(3 q) (singular
+// values of S).  Once such a bound exceeds cur^2 by a margin far above the
+// rounding involved (1e-4 relative: the float32 roundings of the result err by
+// ~1e-7; 1e-9 of Gsum absolute: see below) the distance cannot be below `cur`,
+// which is all a strict "<" update (kcenters.py:304) asks, and +inf is returned.
+// Otherwise the iteration is the one above, operation for operation, and the
+// result has the same bits.
+//
+// That reasoning is about the exact roots; the reference iteration follows it
+// only while the largest root is well separated.  Near a multiple root Newton's
+// steps wander in rounding noise and now and then jump (measured: a largest
+// root doubled to 1e-7 relative sends ~1e-6 of the solves far off), and then
+// only the full iteration reproduces what the reference returns.  The roots are
+// s1+s2+s3, s1-s2-s3, -s1+s2-s3, -s1-s2+s3 (s3 signed like det S) and the
+// discriminant of the quartic is 4096 [(s2+s3)(s1+s3)(s1+s2)(s1-s2)(s1-s3)(s2-s3)]^2;
+// abandoning is allowed only when it exceeds 1e-6 C2^6 = 6.4e-5 (s1^2+s2^2+s3^2)^6,
+// which keeps every pair of roots at least ~1e-4 s1 apart (a rank-one S, two-atom
+// or collinear structures, has discriminant 0).  The largest root is then found
+// to ~1e-11 of its size, far inside the absolute margin.  cur = +inf never
+// abandons.
 __device__ __forceinline__ float ek_rmsd_from_S_below(const float (&S)[9],
                                                       double Gx, double Gy,
                                                       int n_atoms, float cur)
@@ -129,22 +144,6 @@ __device__ __forceinline__ float ek_rmsd_from_S_below(const float (&S)[9],
     const double m0 = Syy * Szz - Syz * Szy;
     const double m1 = Syx * Szz - Syz * Szx;
     const double m2 = Syx * Szy - Syy * Szx;
-
-    // Before the remaining coefficients: the largest root is at most
-    // s1+s2+s3 <= sqrt(3 q), so 2 sqrt(3 q) < Gsum - far already settles it --
-    // provided that root is simple, which three of the nine 2x2 minors of S can
-    // certify (their squares sum to at most s1^2 s2^2 + s1^2 s3^2 + s2^2 s3^2;
-    // the full test below is the fallback when these three happen to be small).
-    const double Gsum = Gx + Gy;
-    const double far_if_simple =
-        (double)n_atoms * (((double)cur * (double)cur) * 1.0001) + 1e-9 * Gsum;
-    {
-        const double t = Gsum - far_if_simple;
-        if (t > 0.0 && t * t > 12.000001 * q &&
-            16.0 * ((m0 * m0 + m1 * m1) + m2 * m2) > 1e-4 * (C2 * C2))
-            return __builtin_inff();
-    }
-
     const double detS = (Sxx * m0 - Sxy * m1) + Sxz * m2;
     const double C1 = -8.0 * detS;
 
@@ -177,14 +176,22 @@ __device__ __forceinline__ float ek_rmsd_from_S_below(const float (&S)[9],
     C0 = C0 - s4 * c1;
     C0 = C0 + s5 * c0;
 
-    // The argument needs a simple largest root.  With singular values
-    // s1 >= s2 >= s3 of S the roots are s1+s2+s3, s1-s2-s3, -s1+s2-s3, -s1-s2+s3
-    // and C2^2 - 4 C0 = 16 (s1^2 s2^2 + s1^2 s3^2 + s2^2 s3^2): when that is tiny
-    // against C2^2 = 4 (s1^2+s2^2+s3^2)^2 (S of rank one: two-atom or collinear
-    // structures) the top root is double, the iteration ends in rounding noise
-    // and only the full solve reproduces it.  1e-4 keeps the gap above 1 % of s1.
-    const bool simple = C2 * C2 - 4.0 * C0 > 1e-4 * (C2 * C2);
-    const double far = simple ? far_if_simple : __builtin_inf();
+    const double Gsum = Gx + Gy;
+    // discriminant of l^4 + p l^2 + r1 l + r0 (only its size matters here)
+    const double p2 = C2 * C2, r12 = C1 * C1, r02 = C0 * C0;
+    const double disc = 16.0 * p2 * p2 * C0 - 4.0 * p2 * C2 * r12 -
+                        128.0 * p2 * r02 + 144.0 * C2 * r12 * C0 -
+                        27.0 * r12 * r12 + 256.0 * r02 * C0;
+    const bool separated = disc > 1e-6 * (p2 * p2 * p2);
+    const double far =
+        separated ? (double)n_atoms * (((double)cur * (double)cur) * 1.0001) +
+                        1e-9 * Gsum
+                  : __builtin_inf();
+    {
+        const double t = Gsum - far;            // 2 sqrt(3 q) < t ?
+        if (t > 0.0 && t * t > 12.000001 * q)
+            return __builtin_inff();
+    }
     double lam = 0.5 * Gsum;
     for (int it = 0; it < EK_MAXIT; ++it) {
         const double x2 = lam * lam;

@@ -5,8 +5,10 @@
    same inner-product matrix in, same float32 distance out);
  * ek_rmsd_from_S_below(.., cur) returns either those bits or +inf, and +inf
    only where the distance is not below `cur` -- for generic structures, for
-   two- and three-atom ones, and for nearly collinear ones, where the largest
-   root of the quartic is (nearly) double and the early stop must not apply.
+   two- and three-atom ones, for nearly collinear ones, and for inner-product
+   matrices built to have a (nearly) double largest root (singular values
+   s1, s2, -s2): there the reference iteration ends in rounding noise or jumps,
+   its result is whatever it is, and the early stop must not apply.
 """
 import ctypes as C
 import os
@@ -120,3 +122,56 @@ def test_nearly_collinear_structures(host, squash):
     rng = np.random.default_rng(int(-np.log10(squash + 1e-9) * 10))
     for A in (3, 5, 12):
         _run(host, rng, A, 1500, squash)
+
+
+def _rotations(rng, m):
+    q = rng.normal(size=(m, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    w, x, y, z = q.T
+    return np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                     2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                     2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)],
+                    axis=1).reshape(m, 3, 3)
+
+
+@pytest.mark.parametrize("eps", [0.0, 1e-12, 1e-9, 1e-7, 1e-5, 1e-3, 1e-1])
+def test_coincident_largest_roots(host, eps):
+    """S = U diag(s1, s2, -s2 (1+eps)) V^T: the two largest roots of the quartic,
+    s1+s2+s3 and s1-s2-s3, differ by 2 s2 eps.  A version of the early stop that
+    trusted the iterates here returned +inf for ~1e-6 of these pairs although the
+    full iteration ends below `cur`."""
+    rng = np.random.default_rng(int(eps * 1e13) + 5)
+    m, A = 200000, 30
+    s1 = A * rng.uniform(0.5, 3.5, m)
+    s2 = s1 * rng.random(m)
+    s3 = -s2 * (1 + eps)
+    sig = np.stack([s1, s2, s3], axis=1)
+    S = np.einsum("mik,mk,mjk->mij", _rotations(rng, m), sig, _rotations(rng, m))
+    S = np.ascontiguousarray(S.reshape(m, 9), dtype=np.float32)
+    top = np.maximum(s1 + s2 + s3, s1 - s2 - s3)
+    Gsum = 2 * top + A * 10.0 ** rng.uniform(-6, 0.5, m)
+    Gx = np.ascontiguousarray(Gsum / 2)
+    Gy = Gx.copy()
+    full = np.empty(m, dtype=np.float32)
+    below = np.empty(m, dtype=np.float32)
+    inf = np.full(m, np.inf, dtype=np.float32)
+    args = (S.ctypes.data_as(C.c_void_p), Gx.ctypes.data_as(C.c_void_p),
+            Gy.ctypes.data_as(C.c_void_p), A)
+    host.h_batch(*args, inf.ctypes.data_as(C.c_void_p), C.c_int64(m),
+                 full.ctypes.data_as(C.c_void_p), below.ctypes.data_as(C.c_void_p))
+    np.testing.assert_array_equal(full.view(np.uint32), below.view(np.uint32))
+    stops = 0
+    for factor in (0.6, 0.9, 1.05, 1.2):
+        cur = (full * np.float32(factor)).astype(np.float32)
+        host.h_batch(*args, cur.ctypes.data_as(C.c_void_p), C.c_int64(m),
+                     full.ctypes.data_as(C.c_void_p),
+                     below.ctypes.data_as(C.c_void_p))
+        gave_up = np.isinf(below) & ~np.isinf(full)
+        np.testing.assert_array_equal(below[~gave_up].view(np.uint32),
+                                      full[~gave_up].view(np.uint32))
+        assert not np.any(full[gave_up] < cur[gave_up])
+        stops += int(gave_up.sum())
+    if eps <= 1e-5:
+        assert stops == 0          # never trusted
+    if eps >= 1e-1:
+        assert stops > m           # separated again: most far solves stop early
