@@ -1,30 +1,43 @@
 #!/usr/bin/env python3
 """bench.py -- frame x center RMSD pairs/s of the k-centers hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps S] [--warmup W]
 
-A "step" is one k-centers iteration: one new center, its RMSD to every frame of
-the shard, the strict-< update and the farthest-point reduction, i.e.
-n_frames RMSD pairs per GPU.  Workload at N=1 is BASELINE.json configs[1]:
-1,000,000 synthetic frames x 300 atoms, 5000 centers (steps default to 5000,
-the whole fit).  For N>1 (launched by torch.distributed.run, one rank per
-GPU, RCCL) every rank holds its own 1,000,000-frame shard (weak scaling).
+Workload: BASELINE.json configs[1] -- 1,000,000 synthetic frames x 300 atoms,
+5000 centers -- whatever S is.  The timed region is the WHOLE fit, from the
+untouched state (every distance +inf) to 5000 centers; a "step" is
+5000 / S consecutive centers of it (250 with the driver's --steps 20; one
+center with --steps 5000), each center being its RMSD to every frame, the
+strict-< update and the farthest-point reduction: n_frames pairs.
+`value` = n_frames * 5000 / elapsed; `ms_per_step` = elapsed / S.
+The W warm-up steps are W * (5000 / S) centers of a throw-away fit from the
+same untouched state; the state is reset before the clock starts.
 
-By default the frames are streamed once per ROUND against --candidates (8)
-candidate centers and further centers are accepted from the stored distances
-while the farthest point is one of them (csrc/ek_spec.hip): the
-same sequential algorithm and bit-identical results with fewer passes over
-HBM.  `--candidates 1` runs one pass per center (the HBM roofline case of
-BASELINE.md).  Every reported pair is a distance that was computed; guesses
-that were never used are not counted ("pairs_computed" has the total).
+N > 1: `python bench.py --gpus N` starts N worker processes itself (one per
+GPU, RCCL) before touching any GPU; under `torch.distributed.run` the ranks
+it started are used as they are.  Default there is STRONG scaling -- the same
+1,000,000 frames split into N contiguous blocks --
+`--scaling weak` holds 1,000,000 frames per GPU instead.
+
+The frames are streamed once per ROUND against up to 8 candidate centers and
+further centers are accepted from the stored distances while the farthest
+point is one of them (csrc/ek_spec.hip): the same sequential
+algorithm and bit-identical results with fewer passes over HBM.  The fit moves
+between 1, 4 and 8 candidates per pass by the centers per millisecond each
+achieves (`--candidates 1|4|8` pins one form; 1 is the HBM roofline case of
+BASELINE.md).  Every reported pair is a distance the result depends on;
+guesses that were never used are not counted ("pairs_computed" has the total).
 
 Inputs are resident in HBM (already centred and laid out frame-minor) when the
 timed region starts; generation, upload and layout are reported separately in
 "setup".  Rank 0 prints ONE JSON line.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -54,17 +67,23 @@ def bytes_per_frame_pass(n_atoms, cands):
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=5000)
-    p.add_argument("--warmup", type=int, default=20)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--centers", type=int, default=5000,
+                   help="centers of the fit (BASELINE.json configs[1]: 5000)")
     p.add_argument("--frames", type=int, default=1_000_000,
-                   help="frames per GPU (weak scaling)")
+                   help="frames in total (strong scaling) or per GPU (weak)")
+    p.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                   help="N > 1: split --frames over the GPUs (strong, the "
+                        "target of BASELINE.md) or hold --frames on each")
     p.add_argument("--atoms", type=int, default=300)
     p.add_argument("--templates", type=int, default=5000)
     p.add_argument("--seed", type=int, default=1)
     p.add_argument("--fpl", type=int, default=0,
                    help="frames per lane of the one-center kernel (0 = auto)")
     p.add_argument("--candidates", type=int, default=-1,
-                   help="candidate centers per pass: -1 auto (8), 1, 4 or 8")
+                   help="candidate centers per pass: -1 by measured rate "
+                        "(1, 4, 8), or pin 1, 4 or 8")
     p.add_argument("--cpu-seconds", type=float, default=15.0,
                    help="time budget of the CPU baseline leg (rank 0, N=1)")
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -80,16 +99,98 @@ def parse():
     return p.parse_args()
 
 
-def make_shard(args, rank):
-    """This rank's frames, float32 [frames, atoms, 3], and its global offset.
-    Shards start on synth.CHUNK boundaries so the data of rank r does not
-    depend on the number of ranks."""
+# ---------------------------------------------------------------------------
+# N > 1 without a launcher: start the ranks here, before any GPU is touched
+# ---------------------------------------------------------------------------
+def spawn_ranks(args):
+    """Start --gpus worker processes of this same script (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in their environment), forward rank 0's JSON line
+    and exit non-zero if any of them failed.  The parent never initialises
+    HIP: it does not import torch."""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r),
+                    "WORLD_SIZE": str(args.gpus), "LOCAL_WORLD_SIZE": str(args.gpus),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+                    "HSA_ENABLE_IPC_MODE_LEGACY":
+                        os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+            env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c]
+    if bad:
+        raise SystemExit("ranks failed (rank, exit code): %s" % bad)
+
+
+def rank_frames(args, rank, world):
+    """(first frame of the generator's stream, global offset, count) of this
+    rank's contiguous block."""
+    from enspara_amd import sharded, synth
+    if world == 1:
+        return 0, 0, args.frames
+    if args.scaling == "strong":
+        lo, cnt = sharded.shard_bounds(args.frames, world, rank)
+        return lo, lo, cnt
+    # weak: every rank its own --frames, generated from a chunk boundary on
+    per = (args.frames + synth.CHUNK - 1) // synth.CHUNK * synth.CHUNK
+    return rank * per, rank * args.frames, args.frames
+
+
+def stream_length(args, rank, world):
+    """Length of the generator stream this rank's block is cut from."""
     from enspara_amd import synth
-    chunks_per_rank = (args.frames + synth.CHUNK - 1) // synth.CHUNK
-    first = rank * chunks_per_rank * synth.CHUNK
-    x = synth.synth(args.frames, args.atoms, args.templates, args.seed,
-                    first_frame=first)
-    return x
+    if world == 1 or args.scaling == "strong":
+        return args.frames
+    per = (args.frames + synth.CHUNK - 1) // synth.CHUNK * synth.CHUNK
+    return rank * per + args.frames
+
+
+def make_shard(args, lo, count, n_stream):
+    """Frames [lo, lo + count) of the synthetic stream of n_stream frames,
+    float32 [count, atoms, 3].  The generator is seeded per 65,536-frame chunk
+    and a chunk's draws depend on its length, so every chunk is generated at
+    the length it has in the whole stream and then cut: a block is the same
+    data whatever the number of ranks."""
+    from enspara_amd import synth
+    tmpl = synth.templates(args.templates, args.atoms, args.seed)
+    out = np.empty((count, args.atoms, 3), dtype=np.float32)
+    c = lo // synth.CHUNK
+    done = 0
+    while done < count:
+        c_lo = c * synth.CHUNK
+        c_len = min(synth.CHUNK, n_stream - c_lo)
+        chunk = synth.synth_chunk(c, c_len, tmpl, args.seed)
+        a = max(lo, c_lo) - c_lo
+        b = min(lo + count, c_lo + c_len) - c_lo
+        out[done:done + b - a] = chunk[a:b]
+        done += b - a
+        c += 1
+    return out
+
+
+def host_threads():
+    """Threads the CPU leg may really use: the affinity mask and the cgroup
+    CPU quota, not the machine's core count."""
+    n = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            q, per = fh.read().split()
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n, len(os.sched_getaffinity(0)), quota
 
 
 def cpu_baseline(x, gpu_centers, seconds):
@@ -99,9 +200,11 @@ def cpu_baseline(x, gpu_centers, seconds):
     centers for those iterations against it.  The oracle is the checker and
     the reported baseline, never the product path."""
     from oracle import qcp
+    usable, affinity, quota = host_threads()
+    qcp.set_num_threads(usable)
     t0 = time.perf_counter()
     P = qcp.Prepared(x)
-    _ = P.tiled
+    _ = P.tiled          # written by the threads that read it later (first touch)
     prep = time.perf_counter() - t0
     n = P.n
     dist = np.full(n, np.inf, dtype=np.float32)
@@ -147,10 +250,51 @@ def cpu_baseline(x, gpu_centers, seconds):
                   "(%.1f s; centring+layout %.1f s not included)"
                   % (n, k, wall, prep),
         "centers_match_gpu": bool(ok),
+        "host": {"logical_cpus": os.cpu_count(), "affinity_cpus": affinity,
+                 "cgroup_cpu_quota": quota,
+                 "threads_policy": "OpenMP static schedule over tiles; the "
+                                   "tiled copy is first-touched by the threads "
+                                   "that stream it; no explicit NUMA binding"},
     }
     if one:
         out["one_thread"] = one
+    out["mdtraj"] = mdtraj_leg(x, centers, min(seconds, 10.0))
     return out
+
+
+def mdtraj_leg(x, centers, seconds):
+    """If mdtraj happens to be importable on this box, time the reference's own
+    metric -- md.rmsd(traj, traj, frame, precentered=True), what enspara
+    binds as 'rmsd' (enspara/cluster/util.py:289-291, :629) -- through the same
+    leading iterations.  Probed at run time, never assumed."""
+    try:
+        import mdtraj as md
+    except Exception as e:
+        return {"available": False, "why": "%s: %s" % (type(e).__name__, e)}
+    try:
+        top = md.Topology()
+        ch = top.add_chain()
+        for _ in range(x.shape[1]):
+            r = top.add_residue("ALA", ch)
+            top.add_atom("CA", md.element.carbon, r)
+        t = md.Trajectory(x, top)
+        t.center_coordinates()
+        dist = np.full(len(x), np.inf)
+        k = 0
+        t0 = time.perf_counter()
+        for c in centers:
+            d = md.rmsd(t, t, int(c), precentered=True)
+            m = d < dist
+            dist[m] = d[m]
+            k += 1
+            if time.perf_counter() - t0 > seconds:
+                break
+        wall = time.perf_counter() - t0
+        return {"available": True, "label": "enspara/mdtraj",
+                "version": md.__version__, "value": len(x) * k / wall,
+                "unit": "pairs/s", "sample": "%d iterations, %.1f s" % (k, wall)}
+    except Exception as e:      # an installed but unusable mdtraj is not fatal
+        return {"available": False, "why": "%s: %s" % (type(e).__name__, e)}
 
 
 def km_width():
@@ -158,24 +302,49 @@ def km_width():
     return int(km.PAM_PREFETCH)
 
 
-def load_traffic(args, cands):
-    """HBM bytes per distance-kernel launch from committed rocprofv3 --pmc
-    runs of this same command (profiles/traffic.json), or None."""
+def kernel_source_hash():
+    """Identifies the code the distance kernels were built from: the traffic
+    figure below is only quoted for the sources it was measured on."""
+    h = hashlib.sha256()
+    for f in ("ek_spec.hip", "ek_kcenters.hip", "ek_qcp.h", "ek_common.h",
+              "ek_reduce.h"):
+        with open(os.path.join(ROOT, "enspara_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def load_traffic(args, n_local, cands):
+    """HBM bytes per distance-kernel launch from the committed rocprofv3 --pmc
+    runs of this same command (profiles/traffic.json) -- but only if that file
+    was produced from the kernel sources in this tree and for this shape;
+    otherwise null.  -> (bytes or None, provenance dict)"""
     path = os.path.join(ROOT, "profiles", "traffic.json")
+    src = kernel_source_hash()
+    why = None
     try:
         with open(path) as fh:
-            t = json.load(fh)
-        key = "cands%d" % cands
-        t = t.get(key, t if cands == 1 else {})
-        if (t.get("frames") == args.frames and t.get("atoms") == args.atoms):
-            return t.get("hbm_bytes_per_launch")
-    except Exception:
-        pass
-    return None
+            t = json.load(fh).get("cands%d" % cands)
+        if t is None:
+            why = "no entry for %d candidates per pass" % cands
+        elif t.get("frames") != n_local or t.get("atoms") != args.atoms:
+            why = "measured at another shape"
+        elif t.get("kernel_source_sha256_16") != src:
+            why = ("measured on other kernel sources (%s, tree has %s)"
+                   % (t.get("kernel_source_sha256_16"), src))
+        else:
+            return t.get("hbm_bytes_per_launch"), {
+                "file": "profiles/traffic.json", "profile": t.get("profile"),
+                "kernel_source_sha256_16": src}
+    except Exception as e:
+        why = "%s: %s" % (type(e).__name__, e)
+    return None, {"file": "profiles/traffic.json", "unused_because": why,
+                  "kernel_source_sha256_16": src}
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args)
     # Libraries underneath (RCCL: "Librccl path : ...") print to stdout; the
     # contract is ONE JSON line there.  Keep the real stdout aside and point
     # fd 1 at stderr for everything else.
@@ -187,11 +356,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit(
-            "launch N>1 with: python -m torch.distributed.run --nnodes=1 "
-            "--nproc-per-node N --master-addr 127.0.0.1 --master-port P "
-            "bench.py --gpus N ...")
+    if args.steps < 1 or args.warmup < 0:
+        raise SystemExit("--steps >= 1 and --warmup >= 0")
 
     import torch
     import torch.distributed as dist
@@ -210,75 +376,94 @@ def main():
             "nccl", rank=rank, world_size=world,
             device_id=torch.device("cuda", local_rank))
 
-    if args.warmup + args.steps > args.frames:
-        raise SystemExit("warmup + steps exceeds the number of frames")
+    # a step = cps consecutive centers of the one fit
+    cps = max(1, args.centers // args.steps)
+    centers_total = cps * args.steps
+    warm_centers = min(cps * args.warmup, centers_total)
+    data_lo, lo, n_local = rank_frames(args, rank, world)
+    n_stream = stream_length(args, rank, world)
+    n_total = args.frames if (world == 1 or args.scaling == "strong") \
+        else args.frames * world
+    if centers_total > n_total:
+        raise SystemExit("more centers than frames")
 
     # ---- setup: synthetic frames -> HBM (centred, frame-minor) ------------
     t0 = time.perf_counter()
-    x = make_shard(args, rank)
+    x = make_shard(args, data_lo, n_local, n_stream)
     t_gen = time.perf_counter() - t0
-    n_local = x.shape[0]
-    offset = rank * n_local
     tstream = torch.cuda.Stream(device=local_rank) if use_dist else None
     stream = tstream.cuda_stream if use_dist else None
     t0 = time.perf_counter()
     store = FrameStore(n_local, args.atoms, device=local_rank,
-                       global_offset=offset, stream=stream)
+                       global_offset=lo, stream=stream)
     store.load(x)
     store.sync()
     t_load = time.perf_counter() - t0
     store.set_frames_per_lane(args.fpl)
     store.set_option(4, args.candidates)
     cands = store.candidates
-    store.reset_state()
 
     shard = sharded.DeviceShard(store) if use_dist else None
 
-    def run(first_label, count, fresh):
+    def run(count):
+        """`count` centers from the untouched state"""
+        store.reset_state()
         if use_dist:
             with torch.cuda.stream(tstream):
-                idx, _ = sharded.kcenters_sharded(shard, first_label, count,
-                                                  0.0, fresh=fresh)
+                idx, _ = sharded.kcenters_sharded(shard, 0, count, 0.0,
+                                                  fresh=True)
         else:
-            idx, _, _ = store.kcenters_run(first_label, count, 0.0)
+            store.sync()
+            idx, _, _ = store.kcenters_run(0, count, 0.0)
         return idx
 
-    # ---- warmup ---------------------------------------------------------------
-    warm_idx = run(0, args.warmup, True)
+    # ---- warm-up: W steps of a throw-away fit ----------------------------------
+    if warm_centers:
+        run(warm_centers)
 
-    # ---- timed region: exactly --steps iterations ---------------------------
-    store.timing_begin(sample_every=max(1, args.steps // (64 * max(cands, 4))),
-                       max_samples=512)
+    # ---- timed region: the whole fit, --steps steps of cps centers --------------
+    store.reset_state()
+    store.sync()
+    store.timing_begin(sample_every=2, max_samples=1024)
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    idx = run(args.warmup, args.steps, False)
+    if use_dist:
+        with torch.cuda.stream(tstream):
+            idx, _ = sharded.kcenters_sharded(shard, 0, centers_total, 0.0,
+                                              fresh=True)
+    else:
+        idx, _, _ = store.kcenters_run(0, centers_total, 0.0)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if len(idx) != args.steps:
-        raise SystemExit("only %d of %d steps ran" % (len(idx), args.steps))
+    if len(idx) != centers_total:
+        raise SystemExit("only %d of %d centers" % (len(idx), centers_total))
     kern_ms, n_samp = store.timing_end()
-    rounds = store.spec_rounds() if cands > 1 else args.steps
+    if use_dist:
+        rounds = store.spec_rounds() if cands > 1 else centers_total
+        mix = {cands: (rounds, centers_total)}
+    else:
+        mix = {T: pc for T, pc in store.run_stats().items() if pc[0]} \
+            if cands > 1 else {1: (centers_total, centers_total)}
+        rounds = sum(p for p, _ in mix.values())
 
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        tot = torch.tensor([n_local], dtype=torch.int64, device="cuda")
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        n_total = int(tot.item())
-    else:
-        n_total = n_local
 
-    pairs = float(n_total) * args.steps
+    pairs = float(n_total) * centers_total
     value = pairs / elapsed
     bpp = bytes_per_pair(args.atoms)
-    launch_bytes = n_local * (bytes_per_frame_pass(args.atoms, cands)
-                              if cands > 1 else bpp)
+    # the dominant kernel: the widest pass the run used
+    dom = cands if (use_dist or cands == 1) else max(mix)
+    launch_bytes = n_local * (bytes_per_frame_pass(args.atoms, dom)
+                              if dom > 1 else bpp)
     achieved = (launch_bytes / (kern_ms * 1e-3)) / 1e9 if kern_ms > 0 else None
+    traffic, traffic_src = load_traffic(args, n_local, dom)
 
     out = {
         "metric": "frame x center RMSD pairs/sec in k-centers assign",
@@ -289,30 +474,37 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "weak" if (world > 1 and args.scaling == "weak")
+                   else "strong",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": "k-centers RMSD, %d frames x %d atoms per GPU, "
-                        "%d centers (BASELINE.json configs[1]), %d GPU(s)"
-                        % (n_local, args.atoms, args.warmup + args.steps,
-                           world),
+            "workload": "k-centers RMSD, %d frames x %d atoms, %d centers "
+                        "(BASELINE.json configs[1]), whole fit timed, "
+                        "%d GPU(s)" % (n_total, args.atoms, centers_total,
+                                       world),
             "frames_per_gpu": n_local, "frames_total": n_total,
-            "atoms": args.atoms, "centers": args.warmup + args.steps,
+            "atoms": args.atoms, "centers": centers_total,
+            "centers_per_step": cps,
+            "warmup_centers": warm_centers,
             "candidates_per_pass": cands,
-            "algorithm": ("k-centers, %d candidate centers per pass over the "
-                          "frames, results identical to one pass per center"
-                          % cands) if cands > 1 else
+            "passes_by_candidates": {str(T): {"passes": p, "centers": k}
+                                     for T, (p, k) in sorted(mix.items())},
+            "algorithm": "k-centers, up to %d candidate centers per pass over "
+                         "the frames (1, 4 or 8 by measured centers/ms), "
+                         "results identical to one pass per center" % cands
+                         if cands > 1 else
                          "k-centers, one pass over the frames per center",
             "templates": args.templates, "seed": args.seed,
+            "world_size": (dist.get_world_size() if use_dist else 1),
             "sharding": ("contiguous frame blocks; per round of ~7 centers: "
                          "all-gather of 8 candidate records + 320 B + 128 B "
                          "per rank") if use_dist else "single shard",
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": ("ek_pass_kernel<%d>" % cands) if cands > 1
+            "kernel": ("ek_pass_kernel<%d,true>" % dom) if dom > 1
                       else "ek_step_kernel<FPL,0,NT>",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
@@ -322,14 +514,16 @@ def main():
                 (achieved / HBM_COPY_CEILING_GBS) if achieved else None,
             "algorithmic_bytes_per_launch": launch_bytes,
             "bytes_per_pair_one_center_pass": bpp,
-            "pairs_per_launch": n_local * cands,
+            "pairs_per_launch": n_local * dom,
             "avg_launch_ms": kern_ms,
             "launches_sampled": n_samp,
-            "traffic": load_traffic(args, cands),
+            "traffic": traffic,
+            "traffic_source": traffic_src,
         },
         "passes_over_frames": rounds,
-        "centers_per_pass": args.steps / rounds if rounds else None,
-        "pairs_computed": float(n_total) * rounds * cands,
+        "centers_per_pass": centers_total / rounds if rounds else None,
+        "pairs_computed": float(n_total) * sum(T * p for T, (p, _) in
+                                               mix.items()),
         "setup": {"synth_s": t_gen, "upload_center_layout_s": t_load,
                   "host_to_hbm_GBps": x.nbytes / t_load / 1e9},
     }
@@ -338,7 +532,7 @@ def main():
     if args.pam_sweeps is None:
         args.pam_sweeps = 1 if world == 1 else 0
     if args.pam_sweeps > 0:
-        med = [int(i) for i in np.concatenate([warm_idx, idx])]
+        med = [int(i) for i in idx]
         rs = np.random.RandomState(args.seed)
         torch.cuda.synchronize()
         if use_dist:
@@ -374,8 +568,7 @@ def main():
         }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        all_idx = np.concatenate([warm_idx, idx])
-        out["cpu_baseline"] = cpu_baseline(x, all_idx, args.cpu_seconds)
+        out["cpu_baseline"] = cpu_baseline(x, idx, args.cpu_seconds)
     elif rank == 0:
         out["cpu_baseline"] = None
 

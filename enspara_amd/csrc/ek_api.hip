@@ -141,6 +141,10 @@ struct ek_ctx {
     int chain = 1;               // 1: chained cheap steps, 0: one launch pair per center
     int64_t n_pad = 0;
     int32_t last_passes = 0;
+    int adapt = 1;               // choose the candidates per pass from measured rates
+    int64_t st_rounds[3] = {0, 0, 0};   // passes run as 1 / 4 / 8 candidates (last run)
+    int64_t st_centers[3] = {0, 0, 0};  // centers they accepted
+    hipEvent_t evb0 = nullptr, evb1 = nullptr;   // per-batch timing
 
     int fpl = 0;                 // 0 = auto
     int nt = -1;                 // non-temporal frame loads: -1 = auto
@@ -305,6 +309,10 @@ static int ek_free_all(ek_ctx *c)
         (void)hipEventDestroy(c->ev0);
     if (c->ev1)
         (void)hipEventDestroy(c->ev1);
+    if (c->evb0)
+        (void)hipEventDestroy(c->evb0);
+    if (c->evb1)
+        (void)hipEventDestroy(c->evb1);
     if (c->own_stream && c->stream)
         (void)hipStreamDestroy(c->stream);
     delete c;
@@ -445,6 +453,11 @@ extern "C" int ek_set_option(ek_ctx *c, int32_t key, int32_t value)
         if (value != 0 && value != 1)
             return ek_fail(EK_EARG, "ek_set_option: state-is-exact flag 0 or 1");
         c->state_exact = value != 0;
+        return EK_OK;
+    case 8:
+        if (value != 0 && value != 1)
+            return ek_fail(EK_EARG, "ek_set_option: adaptive candidates 0 or 1");
+        c->adapt = value;
         return EK_OK;
     case 2:
         if (value < 0 || value > 2)
@@ -750,6 +763,225 @@ extern "C" int ek_history_download(ek_ctx *c, int32_t first, int32_t count,
     return EK_OK;
 }
 
+// ---- k-centers rounds with the candidates per pass chosen from what pays ----------
+// A round with T candidates costs more than a one-center step (more FMAs per
+// byte and the small kernels that decide the chain) and accepts between 1 and T
+// centers.  Early in a fit the guesses rarely hit -- each new center reshapes
+// the distances of most frames -- and one-center steps are the fastest way
+// forward; later nearly every guess is accepted.  The three forms (one-center
+// step, 4 and 8 candidates) produce the same centers, labels and distances, so
+// the choice is free: each batch is timed on the device (centers per
+// millisecond), the fit runs in the form with the best recent rate, and a
+// neighbouring form is tried for a short batch whenever its figure is stale,
+// at intervals that double while it keeps losing.
+struct EkModeStat {
+    double rate = 0.0;          // centers per ms, recent batches
+    int64_t seen_at = -1;       // centers done when last measured
+    int64_t gap = 16;           // centers between probes while it loses
+};
+
+static int ek_mode_T(int m) { return m == 0 ? 1 : (m == 1 ? 4 : 8); }
+
+static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
+                         int32_t max_new, double dist_cutoff, int32_t *n_added,
+                         int64_t *center_index_out, float *center_dist_out,
+                         float *final_maxdist)
+{
+    int rc = ek_spec_alloc(c);
+    if (rc)
+        return rc;
+    if (!c->evb0) {
+        EK_HIP(hipEventCreate(&c->evb0));
+        EK_HIP(hipEventCreate(&c->evb1));
+    }
+    EkCtl ctlw;
+    memset(&ctlw, 0, sizeof(ctlw));
+    ctlw.n_done = first_label;
+    ctlw.limit = first_label + max_new;
+    EK_HIP(hipMemcpyAsync(c->ctl, &ctlw, sizeof(ctlw), hipMemcpyHostToDevice,
+                          c->stream));
+    EK_HIP(ek_wait(c));
+    for (int m = 0; m < 3; ++m)
+        c->st_rounds[m] = c->st_centers[m] = 0;
+    const int nb = (int)((c->n + EK_BLOCK - 1) / EK_BLOCK);
+    const int top_mode = Tmax == 8 ? 2 : 1;
+    // an explicit request (option key 4 = 4 or 8) pins the form
+    const bool adaptive = c->cands == -1 && c->adapt;
+    const int fpl = ek_pick_fpl(c);
+    const int nt = ek_pick_nt(c);
+    EkModeStat ms[3];
+    int mode = adaptive ? 0 : top_mode;
+    int held = -1;              // form the candidate records were picked for
+    bool probing = false;
+    int home = mode;            // form to return to after a probe
+    EK_HIP(hipEventRecord(c->ev0, c->stream));
+    EkCtl cr;
+    memset(&cr, 0, sizeof(cr));
+    cr.n_done = first_label;
+    const int32_t goal = first_label + max_new;
+    double per_round = 0.6 * Tmax;
+    int32_t rounds_before = 0;
+    while (cr.n_done < goal) {
+        const int Tm = ek_mode_T(mode);
+        const int32_t left = goal - cr.n_done;
+        // ---- records for this form ----------------------------------------------
+        if (held != mode) {
+            if (held == 0 || held < 0)      // the step kernel's partials are per FPL
+                ek_launch_blockmax(c->dist, c->n, c->blockmax, c->stream);
+            if (Tm == 1)
+                ek_launch_pick(c->blockmax, nb, c->dist, c->tiles, c->G, c->n,
+                               c->A, c->goff, c->recsT, c->ctl, c->stream);
+            else
+                ek_launch_pickT(c->blockmax, nb, c->tiles, c->G, c->assign, c->A,
+                                Tm, c->goff, c->recsT, c->ctl, c->top, c->stream);
+            EK_CHECK_LAUNCH();
+            held = mode;
+        }
+        // ---- one batch ------------------------------------------------------------
+        int32_t batch;      // steps (form 0) or rounds
+        if (Tm == 1) {
+            batch = probing ? 4 : (adaptive ? (int32_t)std::min<int64_t>(
+                                                  std::max<int64_t>(8, ms[1].gap), 256)
+                                            : 256);
+            batch = std::min(batch, left);
+        } else {
+            batch = std::max(2, std::min(256, (int32_t)(left / per_round) + 1));
+            if (probing)
+                batch = 2;
+            else if (adaptive)      // come back in time to try the neighbours
+                batch = std::min(batch, std::max(4, (int32_t)(256 / per_round)));
+        }
+        EK_HIP(hipEventRecord(c->evb0, c->stream));
+        for (int32_t r = 0; r < batch; ++r) {
+            // sampled timing of the dominant kernel (bench.py): the widest pass
+            const bool sample =
+                Tm == Tmax && c->samp_every > 0 &&
+                (c->samp_count++ % c->samp_every) == 0 &&
+                2 * (size_t)c->samp_used + 1 < c->samp_ev.size();
+            if (Tm == 1) {
+                ek_launch_step(fpl, 0, nt, c->tiles, c->G, c->dist, c->assign,
+                               c->scratch, c->recsT, 1, c->n, c->A,
+                               cr.n_done + r, dist_cutoff, c->blockmax, c->hist,
+                               c->ctl, c->stream);
+                ek_launch_pick(c->blockmax, ek_step_blocks(fpl, c->n), c->dist,
+                               c->tiles, c->G, c->n, c->A, c->goff, c->recsT,
+                               c->ctl, c->stream);
+                EK_CHECK_LAUNCH();
+                continue;
+            }
+            ek_launch_plan(c->recsT, Tm, c->A, Tm, dist_cutoff, c->planD, c->plan,
+                           c->hist, c->ctl, c->stream);
+            if (sample)
+                EK_HIP(hipEventRecord(c->samp_ev[2 * c->samp_used], c->stream));
+            ek_launch_pass(Tm, c->tiles, c->G, c->dist, c->assign, c->vecs, c->n,
+                           c->n_pad, c->A, c->recsT, c->plan, c->blockmax,
+                           c->stream);
+            if (sample) {
+                EK_HIP(hipEventRecord(c->samp_ev[2 * c->samp_used + 1],
+                                      c->stream));
+                c->samp_used++;
+            }
+            if (c->chain) {
+                ek_launch_chain_max(c->dist, c->vecs, c->n, c->n_pad, c->plan,
+                                    c->pm, 1, c->goff, c->stream);
+                ek_launch_chain_decide_local(c->blockmax, c->pm, nb,
+                                             ek_chain_max_blocks(c->n), c->goff,
+                                             dist_cutoff, c->plan, c->hist,
+                                             c->ctl, c->stream);
+                ek_launch_chain_apply(c->vecs, c->n, c->n_pad, c->dist, c->assign,
+                                      c->plan, c->blockmax, c->stream);
+            } else {
+                for (int j = 1; j < Tm; ++j) {
+                    ek_launch_localmax_check(c->blockmax, nb, c->goff, dist_cutoff,
+                                             c->plan, c->hist, c->ctl, c->stream);
+                    ek_launch_apply(c->vecs, c->G, c->n, c->n_pad, c->A, c->dist,
+                                    c->assign, c->plan, c->blockmax, c->stream);
+                }
+            }
+            ek_launch_pickT(c->blockmax, nb, c->tiles, c->G, c->assign, c->A, Tm,
+                            c->goff, c->recsT, c->ctl, c->top, c->stream);
+            EK_CHECK_LAUNCH();
+        }
+        EK_HIP(hipEventRecord(c->evb1, c->stream));
+        const int32_t before = cr.n_done;
+        EK_HIP(hipMemcpyAsync(&cr, c->ctl, sizeof(cr), hipMemcpyDeviceToHost,
+                              c->stream));
+        EK_HIP(ek_wait(c));
+        const int32_t got = cr.n_done - before;
+        // passes that really ran: a step that found the stop rule met returns at once
+        const int32_t ran = Tm == 1 ? got : cr.n_rounds - rounds_before;
+        rounds_before = cr.n_rounds;
+        c->st_rounds[mode] += ran;
+        c->st_centers[mode] += got;
+        if (cr.stopped || cr.n_done >= goal)
+            break;
+        if (Tm > 1)
+            per_round = std::max(1.0, (double)got / std::max(ran, 1));
+        if (!adaptive)
+            continue;
+        // ---- which form next --------------------------------------------------------
+        float bms = 0.f;
+        EK_HIP(hipEventElapsedTime(&bms, c->evb0, c->evb1));
+        const double rate = got / std::max((double)bms, 1e-6);
+        ms[mode].rate = (ms[mode].seen_at < 0 || probing)
+                            ? rate
+                            : 0.5 * ms[mode].rate + 0.5 * rate;
+        ms[mode].seen_at = cr.n_done;
+        if (probing) {
+            probing = false;
+            if (ms[mode].rate > ms[home].rate) {
+                ms[mode].gap = 16;          // it wins: stay, and re-check the loser soon
+                ms[home].gap = 16;
+            } else {
+                ms[mode].gap = std::min<int64_t>(ms[mode].gap * 2, 2048);
+                mode = home;
+                continue;
+            }
+        }
+        home = mode;
+        // a neighbour whose figure is stale gets a short batch
+        int cand = -1;
+        for (int d = -1; d <= 1; d += 2) {
+            const int m2 = mode + d;
+            if (m2 < 0 || m2 > top_mode)
+                continue;
+            if (ms[m2].seen_at < 0 || cr.n_done - ms[m2].seen_at >= ms[m2].gap)
+                if (cand < 0 || ms[m2].seen_at < ms[cand].seen_at)
+                    cand = m2;
+        }
+        if (cand >= 0) {
+            mode = cand;
+            probing = true;
+        }
+    }
+    EK_HIP(hipEventRecord(c->ev1, c->stream));
+    EK_HIP(ek_wait(c));
+    EK_HIP(hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
+    // leave the records describing the state: [0] = the shard's farthest point
+    if (held == 0 && Tmax > 1) {
+        ek_launch_blockmax(c->dist, c->n, c->blockmax, c->stream);
+        EK_CHECK_LAUNCH();
+    }
+    EK_HIP(hipMemcpyAsync(c->rec, c->recsT, ek_rec_bytes(c->A),
+                          hipMemcpyDeviceToDevice, c->stream));
+    EK_HIP(ek_wait(c));
+    const int32_t added_t = std::max(0, cr.n_done - first_label);
+    const int64_t passes = c->st_rounds[0] + c->st_rounds[1] + c->st_rounds[2];
+    c->last_launches = (int32_t)passes;
+    c->last_passes = (int32_t)passes;
+    if (n_added)
+        *n_added = added_t;
+    if (final_maxdist)
+        *final_maxdist = cr.last_max;
+    if (added_t > 0 && (center_index_out || center_dist_out)) {
+        rc = ek_history_download(c, first_label, added_t, center_index_out,
+                                 center_dist_out, nullptr);
+        if (rc)
+            return rc;
+    }
+    return EK_OK;
+}
+
 extern "C" int ek_kcenters_run(ek_ctx *c, int32_t first_label, int32_t max_new,
                                double dist_cutoff, int32_t *n_added,
                                int64_t *center_index_out,
@@ -774,110 +1006,9 @@ extern "C" int ek_kcenters_run(ek_ctx *c, int32_t first_label, int32_t max_new,
     EK_HIP(ek_wait(c));
 
     const int T = ek_pick_cands(c);
-    if (T > 1 && c->n > 0) {
-        // ---- multi-candidate rounds (ek_spec.hip) -------------------------------
-        rc = ek_spec_alloc(c);
-        if (rc)
-            return rc;
-        EkCtl ctlw;
-        memset(&ctlw, 0, sizeof(ctlw));
-        ctlw.n_done = first_label;
-        ctlw.limit = first_label + max_new;
-        EK_HIP(hipMemcpyAsync(c->ctl, &ctlw, sizeof(ctlw), hipMemcpyHostToDevice,
-                              c->stream));
-        EK_HIP(ek_wait(c));
-        const int nb = (int)((c->n + EK_BLOCK - 1) / EK_BLOCK);
-        EK_HIP(hipEventRecord(c->ev0, c->stream));
-        ek_launch_blockmax(c->dist, c->n, c->blockmax, c->stream);
-        ek_launch_pickT(c->blockmax, nb, c->tiles, c->G, c->assign, c->A, T, c->goff,
-                        c->recsT, c->ctl, c->top, c->stream);
-        EK_CHECK_LAUNCH();
-        EkCtl cr;
-        memset(&cr, 0, sizeof(cr));
-        cr.n_done = first_label;
-        int32_t passes = 0;
-        double per_round = 0.6 * T;        // centers per round, re-estimated
-        while (max_new > 0) {
-            // rounds enqueued per host check: enough for the remaining centers
-            // at the observed yield (steps past the goal are device no-ops)
-            const int32_t left = first_label + max_new - cr.n_done;
-            const int32_t rounds = std::max(
-                2, std::min(256, (int32_t)(left / per_round) + 1));
-            const int32_t before = cr.n_done;
-            for (int32_t r = 0; r < rounds; ++r) {
-                ek_launch_plan(c->recsT, T, c->A, T, dist_cutoff, c->planD, c->plan,
-                               c->hist, c->ctl, c->stream);
-                const bool sample =
-                    c->samp_every > 0 &&
-                    (c->samp_count++ % c->samp_every) == 0 &&
-                    2 * (size_t)c->samp_used + 1 < c->samp_ev.size();
-                if (sample)
-                    EK_HIP(hipEventRecord(c->samp_ev[2 * c->samp_used],
-                                          c->stream));
-                ek_launch_pass(T, c->tiles, c->G, c->dist, c->assign, c->vecs,
-                               c->n, c->n_pad, c->A, c->recsT, c->plan,
-                               c->blockmax, c->stream);
-                if (sample) {
-                    EK_HIP(hipEventRecord(c->samp_ev[2 * c->samp_used + 1],
-                                          c->stream));
-                    c->samp_used++;
-                }
-                if (c->chain) {
-                    ek_launch_chain_max(c->dist, c->vecs, c->n, c->n_pad, c->plan,
-                                        c->pm, 1, c->goff, c->stream);
-                    ek_launch_chain_decide_local(c->blockmax, c->pm, nb,
-                                                 ek_chain_max_blocks(c->n), c->goff,
-                                                 dist_cutoff, c->plan, c->hist,
-                                                 c->ctl, c->stream);
-                    ek_launch_chain_apply(c->vecs, c->n, c->n_pad, c->dist,
-                                          c->assign, c->plan, c->blockmax,
-                                          c->stream);
-                } else {
-                    for (int j = 1; j < T; ++j) {
-                        ek_launch_localmax_check(c->blockmax, nb, c->goff,
-                                                 dist_cutoff, c->plan, c->hist,
-                                                 c->ctl, c->stream);
-                        ek_launch_apply(c->vecs, c->G, c->n, c->n_pad, c->A,
-                                        c->dist, c->assign, c->plan, c->blockmax,
-                                        c->stream);
-                    }
-                }
-                ek_launch_pickT(c->blockmax, nb, c->tiles, c->G, c->assign, c->A, T,
-                                c->goff, c->recsT, c->ctl, c->top, c->stream);
-                EK_CHECK_LAUNCH();
-            }
-            passes += rounds;
-            EK_HIP(hipMemcpyAsync(&cr, c->ctl, sizeof(cr), hipMemcpyDeviceToHost,
-                                  c->stream));
-            EK_HIP(ek_wait(c));
-            if (cr.stopped || cr.n_done >= first_label + max_new)
-                break;
-            per_round = std::max(1.0, (double)(cr.n_done - before) / rounds);
-        }
-        EK_HIP(hipEventRecord(c->ev1, c->stream));
-        EK_HIP(ek_wait(c));
-        EK_HIP(hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
-        // keep the single-record slot in step with the state (other entry
-        // points read it)
-        EK_HIP(hipMemcpyAsync(c->rec, c->recsT, ek_rec_bytes(c->A),
-                              hipMemcpyDeviceToDevice, c->stream));
-        EK_HIP(ek_wait(c));
-        const int32_t added_t = std::max(0, cr.n_done - first_label);
-        c->last_launches = cr.n_rounds;
-        c->last_passes = cr.n_rounds;
-        (void)passes;
-        if (n_added)
-            *n_added = added_t;
-        if (final_maxdist)
-            *final_maxdist = cr.last_max;
-        if (added_t > 0 && (center_index_out || center_dist_out)) {
-            rc = ek_history_download(c, first_label, added_t, center_index_out,
-                                     center_dist_out, nullptr);
-            if (rc)
-                return rc;
-        }
-        return EK_OK;
-    }
+    if (T > 1 && c->n > 0)
+        return ek_run_rounds(c, T, first_label, max_new, dist_cutoff, n_added,
+                             center_index_out, center_dist_out, final_maxdist);
 
     // With no distance cut-off the trip count is known: enqueue everything.
     // With a cut-off, enqueue in batches and look at the stop flag in between
@@ -1993,6 +2124,17 @@ extern "C" int ek_spec_rounds(ek_ctx *c, int32_t *rounds)
                           c->stream));
     EK_HIP(ek_wait(c));
     *rounds = r.n_rounds;
+    return EK_OK;
+}
+
+extern "C" int ek_run_stats(ek_ctx *c, int64_t *passes, int64_t *centers)
+{
+    if (!c || !passes || !centers)
+        return ek_fail(EK_EARG, "ek_run_stats: NULL argument");
+    for (int m = 0; m < 3; ++m) {
+        passes[m] = c->st_rounds[m];
+        centers[m] = c->st_centers[m];
+    }
     return EK_OK;
 }
 

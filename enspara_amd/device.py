@@ -349,6 +349,15 @@ class FrameStore:
         _lib.check(self.lib.ek_spec_rounds(self._h, C.byref(r)))
         return r.value
 
+    def run_stats(self):
+        """How the last kcenters_run spent its passes over the frames:
+        -> {candidates per pass: (passes, centers accepted)}"""
+        p = np.zeros(3, dtype=np.int64)
+        k = np.zeros(3, dtype=np.int64)
+        _lib.check(self.lib.ek_run_stats(self._h, _lib.i64p(p), _lib.i64p(k)))
+        return {1: (int(p[0]), int(k[0])), 4: (int(p[1]), int(k[1])),
+                8: (int(p[2]), int(k[2]))}
+
     def history(self, first, count):
         idx = np.empty(max(count, 1), dtype=np.int64)
         cd = np.empty(max(count, 1), dtype=np.float32)

@@ -187,6 +187,13 @@ int ek_spec_chain_apply(ek_ctx *ctx, const void *hdrs_all, int32_t n_shards,
 /* rounds (passes over the frames) that really ran since ek_spec_begin /
  * ek_kcenters_run started */
 int ek_spec_rounds(ek_ctx *ctx, int32_t *rounds);
+/* How the last ek_kcenters_run spent its passes over the frames:
+ * passes[i] / centers[i] = passes run with 1, 4, 8 candidate centers
+ * (i = 0, 1, 2) and the centers those passes accepted.  The loop of
+ * kcenters.py:217-231 has no such notion (one metric call per center); the
+ * three forms give identical centers, labels and distances, and the run moves
+ * between them by the centers per millisecond each achieves. */
+int ek_run_stats(ek_ctx *ctx, int64_t *passes, int64_t *centers);
 
 /* history written by ek_kcenters_step: for labels [first, first+count) the
  * global frame index and pre-update distance of each accepted center;
@@ -408,7 +415,10 @@ int ek_set_frames_per_lane(ek_ctx *ctx, int fpl);
  * frame, the distance to the medoid its label names: true after
  * ek_state_reset + k-centers, false after ek_state_upload / ek_assign_nearest
  * key 7: assert (1) or withdraw (0) that property, e.g. after
- * ek_assign_nearest with the medoid frames themselves as centers */
+ * ek_assign_nearest with the medoid frames themselves as centers
+ * key 8: with key 4 = -1, let ek_kcenters_run move between 1, 4 and 8
+ * candidates per pass by measured centers per millisecond: 1 (default) / 0
+ * (always the widest form); identical results either way */
 int ek_set_option(ek_ctx *ctx, int32_t key, int32_t value);
 /* time of the last ek_kcenters_run loop measured with HIP events on the
  * context's stream, milliseconds, and the number of distance-kernel launches
