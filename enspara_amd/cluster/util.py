@@ -189,3 +189,103 @@ class MolecularClusterMixin:
     @property
     def centers_(self):
         return self.result_.centers
+
+
+# ---------------------------------------------------------------------------
+# result files (reference enspara/cluster/util.py:464-547): what the clustering
+# workflow leaves on disk after a fit -- center indices (.npy), the centers
+# themselves, and per-trajectory assignments / distances (ra.save: HDF5)
+# ---------------------------------------------------------------------------
+def _intermediate_path(path, intermediate_n):
+    """<dir>/intermediate-<n>/<basename>, directory created (util.py:467-470)"""
+    import os
+    d = os.path.join(os.path.dirname(path), "intermediate-%s" % intermediate_n)
+    os.makedirs(d, exist_ok=True)
+    return os.path.join(d, os.path.basename(path))
+
+
+def write_centers_indices(path, indices, intermediate_n=None):
+    """reference util.py:464-478: np.save of the center indices ((trajectory,
+    frame) pairs after ClusterResult.partition); a falsy path writes nothing."""
+    if not path:
+        logger.info("--center-indices not provided, not writing center "
+                    "indices to file.")
+        return
+    if intermediate_n is not None:
+        path = _intermediate_path(path, intermediate_n)
+    with open(path, "wb") as f:
+        np.save(f, indices)
+
+
+def write_centers(result, args, intermediate_n=None, load_center_frames=None):
+    """reference util.py:481-508.  ``args`` carries ``features``,
+    ``center_features`` and (coordinates only) ``trajectories`` /
+    ``topologies`` / ``subsample``.
+
+    Feature clustering: the centers array is saved (np.save; ra.save for an
+    intermediate result, as the reference does).  Coordinate clustering: the
+    reference re-reads the center frames from the trajectory files with mdtraj
+    (load_asymm_frames) and pickles the list of md.Trajectory objects;
+    ``load_center_frames(center_indices, args)`` is that reader when the
+    caller has one, otherwise ``result.centers`` -- the centers' coordinates
+    as the fit returned them -- is what gets pickled."""
+    import os
+    import pickle
+    if getattr(args, "features", None):
+        if intermediate_n is not None:
+            ra.save(_intermediate_path(args.center_features, intermediate_n),
+                    result.centers)
+        else:
+            np.save(args.center_features, result.centers)
+        return
+    if intermediate_n is not None:
+        outdir = os.path.join(os.path.dirname(args.center_features),
+                              "intermediate-%s" % intermediate_n)
+    else:
+        outdir = os.path.dirname(args.center_features)
+    logger.info("Saving cluster centers at %s", outdir)
+    if outdir:
+        os.makedirs(outdir, exist_ok=True)
+    if load_center_frames is not None:
+        centers = load_center_frames(result.center_indices, args)
+    else:
+        centers = list(result.centers)
+    # (the reference writes to args.center_features in both cases, :506)
+    with open(args.center_features, "wb") as f:
+        pickle.dump(centers, f)
+
+
+def write_assignments_and_distances_with_reassign(result, args,
+                                                  intermediate_n=None,
+                                                  load_targets=None):
+    """reference util.py:511-547.  With ``args.subsample == 1`` the fit's own
+    per-frame results are saved (ra.save, ndarray or RaggedArray).  With
+    subsampling, unless ``args.no_reassign``, every frame of every trajectory
+    is assigned to its nearest center on the device first (cluster.reassign);
+    ``load_targets(args)`` supplies the trajectories to reassign -- arrays of
+    coordinates or zero-argument callables returning them -- where the
+    reference reads args.trajectories with mdtraj."""
+    if args.subsample == 1:
+        logger.debug("Subsampling was 1, not reassigning.")
+        dist, assig = result.distances, result.assignments
+        final = intermediate_n is None
+    elif not getattr(args, "no_reassign", False):
+        logger.debug("Reassigning data from subsampling of %s", args.subsample)
+        if load_targets is None:
+            raise ImproperlyConfigured(
+                "reassignment after subsampled clustering needs the "
+                "trajectories: pass load_targets(args) (the reference reads "
+                "args.trajectories with mdtraj, which this build does not "
+                "depend on)")
+        from .reassign import reassign
+        assig, dist = reassign(load_targets(args), centers=result.centers)
+        final = True            # :544-545: the final files are written as well
+    else:
+        logger.debug("Got --no-reassign, not doing reassigment")
+        return
+    if intermediate_n is not None:
+        ra.save(_intermediate_path(args.distances, intermediate_n), dist)
+        ra.save(_intermediate_path(args.assignments, intermediate_n), assig)
+    if final:
+        ra.save(args.distances, dist)
+        ra.save(args.assignments, assig)

@@ -10,6 +10,10 @@
 #include <new>
 #include <vector>
 
+#ifndef EK_PASS_FORM_DEFAULT
+#define EK_PASS_FORM_DEFAULT 1
+#endif
+
 static thread_local char g_err[512] = "";
 
 // shared with ek_msm.hip
@@ -138,6 +142,9 @@ struct ek_ctx {
     EkBlockMax *pm = nullptr;    // [EK_MAX_CANDS-1][nb] per-prefix maxima (ek_chain.hip)
     unsigned char *top = nullptr;    // scratch of the candidate pick (ek_spec.hip)
     float *planD = nullptr;          // [64][64] distances between the records on offer
+    int pass_form = EK_PASS_FORM_DEFAULT;  // 0: candidates through LDS, 1: as scalar operands
+    float *ctile = nullptr;      // the round's candidates, [atom][pair][xyz][2]
+    double *ctrace = nullptr;    // their traces
     int chain = 1;               // 1: chained cheap steps, 0: one launch pair per center
     int64_t n_pad = 0;
     int32_t last_passes = 0;
@@ -281,6 +288,8 @@ static int ek_free_all(ek_ctx *c)
     if (c->pam_out_host)
         (void)hipHostFree(c->pam_out_host);
     (void)hipFree(c->recsT);
+    (void)hipFree(c->ctile);
+    (void)hipFree(c->ctrace);
     (void)hipFree(c->plan);
     (void)hipFree(c->vecs);
     (void)hipFree(c->hdr);
@@ -373,6 +382,8 @@ extern "C" int ek_ctx_create(int device, int64_t n_frames, int32_t n_atoms,
     EK_ALLOC(c->recsT, recb * EK_MAX_CANDS);
     EK_ALLOC(c->plan, sizeof(EkPlan));
     EK_ALLOC(c->hdr, sizeof(EkMaxHdr));
+    EK_ALLOC(c->ctile, ek_ctile_bytes(n_atoms));
+    EK_ALLOC(c->ctrace, EK_MAX_CANDS * sizeof(double));
 #undef EK_ALLOC
     c->n_pad = (int64_t)nt * EK_TILE;
     if (e == hipSuccess)
@@ -453,6 +464,11 @@ extern "C" int ek_set_option(ek_ctx *c, int32_t key, int32_t value)
         if (value != 0 && value != 1)
             return ek_fail(EK_EARG, "ek_set_option: state-is-exact flag 0 or 1");
         c->state_exact = value != 0;
+        return EK_OK;
+    case 9:
+        if (value != 0 && value != 1)
+            return ek_fail(EK_EARG, "ek_set_option: pass kernel form 0 or 1");
+        c->pass_form = value;
         return EK_OK;
     case 8:
         if (value != 0 && value != 1)
@@ -875,7 +891,7 @@ static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
                 EK_HIP(hipEventRecord(c->samp_ev[2 * c->samp_used], c->stream));
             ek_launch_pass(Tm, c->tiles, c->G, c->dist, c->assign, c->vecs, c->n,
                            c->n_pad, c->A, c->recsT, c->plan, c->blockmax,
-                           c->stream);
+                           c->pass_form, c->ctile, c->ctrace, c->stream);
             if (sample) {
                 EK_HIP(hipEventRecord(c->samp_ev[2 * c->samp_used + 1],
                                       c->stream));
@@ -1714,7 +1730,7 @@ static int ek_pam_prefetch_vectors(ek_ctx *c, int count, int32_t win_lo,
                                    c->act_tiles, c->act_G, c->stream);
             ek_launch_pass_dist(count, c->act_tiles, c->act_G, c->act_vecs, n_act,
                                 c->act_cap, c->A, c->pam_recs, c->pam_plan,
-                                c->stream);
+                                c->pass_form, c->ctile, c->ctrace, c->stream);
             ek_launch_scatter_vecs(c->amb, n_act, c->act_vecs, c->act_cap, count,
                                    c->pam_vecs, c->n_pad, c->stream);
             EK_CHECK_LAUNCH();
@@ -1726,7 +1742,8 @@ static int ek_pam_prefetch_vectors(ek_ctx *c, int count, int32_t win_lo,
         c->pf_backoff = 15;
     }
     ek_launch_pass_dist(count, c->tiles, c->G, c->pam_vecs, c->n, c->n_pad, c->A,
-                        c->pam_recs, c->pam_plan, c->stream);
+                        c->pam_recs, c->pam_plan, c->pass_form, c->ctile,
+                        c->ctrace, c->stream);
     EK_CHECK_LAUNCH();
     ++c->pf_full;
     return EK_OK;
@@ -2007,7 +2024,8 @@ extern "C" int ek_spec_round(ek_ctx *c, const void *recs_all, int32_t n_recs,
         EK_HIP(hipEventRecord(c->samp_ev[2 * c->samp_used], c->stream));
     ek_launch_pass(T, c->tiles, c->G, c->dist, c->assign, c->vecs,
                    c->n, c->n_pad, c->A, (const unsigned char *)recs_all,
-                   c->plan, c->blockmax, c->stream);
+                   c->plan, c->blockmax, c->pass_form, c->ctile, c->ctrace,
+                   c->stream);
     if (sample) {
         EK_HIP(hipEventRecord(c->samp_ev[2 * c->samp_used + 1], c->stream));
         c->samp_used++;

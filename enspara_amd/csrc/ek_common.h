@@ -244,14 +244,19 @@ void ek_launch_plan(const unsigned char *recs, int n_recs, int A, int T,
                     double cutoff, float *D, EkPlan *plan, EkHist *hist,
                     EkCtl *ctl, hipStream_t s);
 size_t ek_pass_lds_bytes(int T, int A);
+// form 0: candidates staged in LDS; form 1: candidates laid out in `ctile`
+// (ek_ctile_bytes) / `ctrace` ([EK_MAX_CANDS] f64) and read as scalar operands
+size_t ek_ctile_bytes(int A);
 void ek_launch_pass(int T, const float *tiles, const double *G, float *dist,
                     int32_t *assign, float *vecs, int64_t n, int64_t n_pad,
                     int A, const unsigned char *recs, const EkPlan *plan,
-                    EkBlockMax *blockmax, hipStream_t s);
+                    EkBlockMax *blockmax, int form, float *ctile, double *ctrace,
+                    hipStream_t s);
 // distances only: vecs[j][f] = rmsd(frame f, record j), j < count <= 8
 void ek_launch_pass_dist(int count, const float *tiles, const double *G,
                          float *vecs, int64_t n, int64_t n_pad, int A,
-                         const unsigned char *recs, EkPlan *plan, hipStream_t s);
+                         const unsigned char *recs, EkPlan *plan, int form,
+                         float *ctile, double *ctrace, hipStream_t s);
 // ---- chained rounds (ek_chain.hip) --------------------------------------------------
 // rows_out[EK_MAX_CANDS]: this shard's view of the candidate frames it owns
 void ek_launch_chain_rows(const EkPlan *plan, const float *dist,

@@ -409,16 +409,353 @@ ek_pass_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
     }
 }
 
+// ---------------------------------------------------------------------------
+// the pass, second form: candidates as SCALAR operands
+// ---------------------------------------------------------------------------
+// The candidates are the same for every lane, so they do not need vector
+// registers or LDS at all: ek_ctile_kernel lays the round's candidates out once
+// in global memory as [atom][pair][xyz][2] and every wave reads an atom's 3T
+// floats with scalar loads (s_load_dwordx8/x16, through the scalar cache) one
+// atom ahead of the FMAs; v_pk_fma_f32 takes the (candidate 2p, candidate 2p+1)
+// pair straight from an SGPR pair.  The frame rows come through buffer loads
+// (SGPR descriptor of the tile + scalar row offset + the lane's constant
+// offset: no address registers; rows past the tile's end read as 0) into the
+// two halves of register pairs, atoms a and a+1 of a coordinate sharing a pair
+// and op_sel picking the half -- the compiler left the odd half of every pair
+// unused.  That is 72 accumulators + 12 row registers per trip in flight and
+// nothing else: 4 waves per SIMD with the rows two trips ahead, where the LDS
+// form had 3 waves and one trip.  Each component is still its own IEEE FMA
+// chain in ascending atom order: same bits as every other kernel here.
+typedef const float __attribute__((address_space(4))) *ek_cfp;
+
+#ifndef EK_PASS2_DIST
+#define EK_PASS2_DIST 2
+#endif
+#ifndef EK_PASS2_WAVES8
+#define EK_PASS2_WAVES8 4
+#endif
+#define EK_CTILE_PAD 8      // atoms of zeros after the last one (read-ahead)
+
+static inline __host__ __device__ size_t ek_ctile_floats(int A)
+{
+    return (size_t)(A + EK_CTILE_PAD) * 3 * EK_MAX_CANDS;
+}
+
+// acc += x.lo * c  /  x.hi * c  (per component; c = an SGPR pair)
+__device__ __forceinline__ void ek_pkfma_lo(ek_v2f &acc, ek_v2f x, ek_v2f c)
+{
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]"
+        : "+v"(acc) : "v"(x), "s"(c));
+}
+__device__ __forceinline__ void ek_pkfma_hi(ek_v2f &acc, ek_v2f x, ek_v2f c)
+{
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]"
+        : "+v"(acc) : "v"(x), "s"(c));
+}
+
+template <int T> struct EkCAtom { float v[3 * T]; };
+
+template <int T>
+__device__ __forceinline__ void ek_ld_catom(EkCAtom<T> &o, ek_cfp p)
+{
+#pragma unroll
+    for (int i = 0; i < 3 * T; ++i)
+        o.v[i] = p[i];
+}
+
+// FMAs [from, to) of the 9 T / 2 of one atom (order: pair, then S row-major)
+template <int T, bool HI>
+__device__ __forceinline__ void ek_atom_fma(ek_v2f (&s2)[T / 2][9], ek_v2f X,
+                                            ek_v2f Y, ek_v2f Z,
+                                            const EkCAtom<T> &c, int from, int to)
+{
+#pragma unroll
+    for (int p = 0; p < T / 2; ++p) {
+        const ek_v2f cx = (ek_v2f){c.v[6 * p + 0], c.v[6 * p + 1]};
+        const ek_v2f cy = (ek_v2f){c.v[6 * p + 2], c.v[6 * p + 3]};
+        const ek_v2f cz = (ek_v2f){c.v[6 * p + 4], c.v[6 * p + 5]};
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const int k = 9 * p + j;
+            if (k < from || k >= to)
+                continue;
+            const ek_v2f r = (j / 3 == 0) ? X : (j / 3 == 1 ? Y : Z);
+            const ek_v2f cc = (j % 3 == 0) ? cx : (j % 3 == 1 ? cy : cz);
+            if (HI)
+                ek_pkfma_hi(s2[p][j], r, cc);
+            else
+                ek_pkfma_lo(s2[p][j], r, cc);
+        }
+    }
+}
+
+// the round's candidates, interleaved for the kernel below; zeros for unused
+// slots and for the EK_CTILE_PAD atoms after the last
+template <int T>
+__global__ void __launch_bounds__(EK_BLOCK)
+ek_ctile_kernel(const unsigned char *__restrict__ recs,
+                const EkPlan *__restrict__ plan, int A,
+                float *__restrict__ ctile, double *__restrict__ ctrace)
+{
+    if (!plan->go)
+        return;
+    const int teff = plan->teff;
+    const size_t rstride = ek_rec_bytes(A);
+    const int total = (A + EK_CTILE_PAD) * 3 * T;
+    for (int j = blockIdx.x * EK_BLOCK + threadIdx.x; j < total;
+         j += gridDim.x * EK_BLOCK) {
+        // destination order: [atom][pair][xyz][2]
+        const int a = j / (3 * T), w = j % (3 * T);
+        const int c = (w / 6) * 2 + (w & 1), k = (w % 6) / 2;
+        float v = 0.f;
+        if (a < A && c < teff)
+            v = ((const float *)(recs + (size_t)plan->src[c] * rstride +
+                                 sizeof(EkRecHdr)))[3 * a + k];
+        ctile[j] = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < T) {
+        const int c = threadIdx.x;
+        ctrace[c] = c < teff ? ((const EkRecHdr *)(recs + (size_t)plan->src[c] *
+                                                   rstride))->trace
+                             : 0.0;
+    }
+}
+
+template <int T, bool UPD>
+__global__ void __launch_bounds__(EK_BLOCK,
+                                  (T <= 4) ? 5 : EK_PASS2_WAVES8)
+ek_pass2_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
+                float *__restrict__ dist, int32_t *__restrict__ assign,
+                float *__restrict__ vecs, int64_t n, int64_t n_pad, int A,
+                const float *__restrict__ ctile,
+                const double *__restrict__ ctrace,
+                const EkPlan *__restrict__ plan,
+                EkBlockMax *__restrict__ blockmax)
+{
+    __shared__ float red_v[EK_BLOCK / EK_WAVE];
+    __shared__ uint32_t red_i[EK_BLOCK / EK_WAVE];
+    if (!plan->go)
+        return;
+    const int tid = threadIdx.x;
+    const int teff = plan->teff;
+    const int label = plan->label;
+    static_assert(EK_BLOCK == EK_TILE, "one workgroup per tile");
+    const int64_t f = (int64_t)blockIdx.x * EK_BLOCK + tid;
+    // what the epilogue needs from memory is requested now, not after the loop
+    double Gf = 0.0;
+    float cur0 = 0.f;
+    if (f < n) {
+        Gf = G[f];
+        if (UPD)
+            cur0 = dist[f];
+    }
+
+    const float *tb = tiles + (size_t)blockIdx.x * 3 * (size_t)A * EK_TILE;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)tb, 0, 3 * A * EK_TILE * 4, 0x00020000);
+    const int vo = tid * 4;
+    // non-temporal: the frame stream is read once per pass
+#define EK_LD(SO, K)                                                           \
+    __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(            \
+                                  rs, vo + (K) * (EK_TILE * 4), (SO), 2))
+    ek_v2f s2[T / 2][9];
+#pragma unroll
+    for (int c = 0; c < T / 2; ++c)
+#pragma unroll
+        for (int j = 0; j < 9; ++j)
+            s2[c][j] = (ek_v2f){0.f, 0.f};
+
+    constexpr int DIST = EK_PASS2_DIST;
+    constexpr int NB = DIST + 1;
+    // X[b][h] = (x of atom 4t + 2h, x of atom 4t + 2h + 1) of the trip in buffer b
+    ek_v2f X[NB][2], Y[NB][2], Z[NB][2];
+#define EK_ROWS2(B, TR)                                                        \
+    _Pragma("unroll") for (int h = 0; h < 2; ++h)                              \
+    _Pragma("unroll") for (int e = 0; e < 2; ++e) {                            \
+        const int so = ((TR) * 4 + 2 * h + e) * (3 * EK_TILE * 4);             \
+        X[B][h][e] = EK_LD(so, 0);                                             \
+        Y[B][h][e] = EK_LD(so, 1);                                             \
+        Z[B][h][e] = EK_LD(so, 2);                                             \
+        __builtin_amdgcn_sched_barrier(0);  /* same issue order everywhere */  \
+    }
+    const int n_trip = A / 4;           // whole trips; A % 4 atoms follow
+    const ek_cfp cp = (ek_cfp)ctile;
+#pragma unroll
+    for (int k = 0; k < DIST; ++k)
+        EK_ROWS2(k, k)
+    EkCAtom<T> c0, c1;
+    ek_ld_catom<T>(c0, cp);
+    constexpr int NF = 9 * T / 2;       // packed FMAs per atom
+    // One trip: request the rows of trip t + DIST, then the 4 * NF FMAs of trip
+    // t.  The first FMA of an atom waits for that atom's scalar loads (they
+    // return out of order, so the wait is for all of them); the next atom's are
+    // issued right after it and have the other NF - 1 FMAs to arrive.
+#define EK_TRIP2(K, TT)                                                        \
+    {                                                                          \
+        EK_ROWS2(((K) + DIST) % NB, (TT) + DIST)                               \
+        const ek_cfp ca = cp + (size_t)(4 * (TT)) * (3 * T);                   \
+        ek_atom_fma<T, false>(s2, X[K][0], Y[K][0], Z[K][0], c0, 0, 1);        \
+        __builtin_amdgcn_sched_barrier(0);                                     \
+        ek_ld_catom<T>(c1, ca + 1 * 3 * T);                                    \
+        __builtin_amdgcn_sched_barrier(0);                                     \
+        ek_atom_fma<T, false>(s2, X[K][0], Y[K][0], Z[K][0], c0, 1, NF);       \
+        ek_atom_fma<T, true>(s2, X[K][0], Y[K][0], Z[K][0], c1, 0, 1);         \
+        __builtin_amdgcn_sched_barrier(0);                                     \
+        ek_ld_catom<T>(c0, ca + 2 * 3 * T);                                    \
+        __builtin_amdgcn_sched_barrier(0);                                     \
+        ek_atom_fma<T, true>(s2, X[K][0], Y[K][0], Z[K][0], c1, 1, NF);        \
+        ek_atom_fma<T, false>(s2, X[K][1], Y[K][1], Z[K][1], c0, 0, 1);        \
+        __builtin_amdgcn_sched_barrier(0);                                     \
+        ek_ld_catom<T>(c1, ca + 3 * 3 * T);                                    \
+        __builtin_amdgcn_sched_barrier(0);                                     \
+        ek_atom_fma<T, false>(s2, X[K][1], Y[K][1], Z[K][1], c0, 1, NF);       \
+        ek_atom_fma<T, true>(s2, X[K][1], Y[K][1], Z[K][1], c1, 0, 1);         \
+        __builtin_amdgcn_sched_barrier(0);                                     \
+        ek_ld_catom<T>(c0, ca + 4 * 3 * T);   /* next trip's first atom */     \
+        __builtin_amdgcn_sched_barrier(0);                                     \
+        ek_atom_fma<T, true>(s2, X[K][1], Y[K][1], Z[K][1], c1, 1, NF);        \
+    }
+    // Whole groups of NB trips run without a branch inside, and the first group
+    // is peeled: the loop is then entered in the very state it leaves at its
+    // end, so the load-counter waits the compiler derives at the loop head are
+    // the exact ones (rows two trips ahead stay in flight) instead of the
+    // cautious join of prologue and loop states.
+    const int n_grp = n_trip / NB;
+    int t0 = 0;
+    if (n_grp > 0) {
+#pragma unroll
+        for (int k = 0; k < NB; ++k)
+            EK_TRIP2(k, k)
+        t0 = NB;
+        for (int g = 1; g < n_grp; ++g) {
+#pragma unroll
+            for (int k = 0; k < NB; ++k)
+                EK_TRIP2(k, t0 + k)
+            t0 += NB;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NB - 1; ++k) {
+        if (t0 + k < n_trip)            // wave-uniform
+            EK_TRIP2(k, t0 + k)
+    }
+#undef EK_TRIP2
+    // the A % 4 atoms after the last whole trip (c0 holds the first of them)
+    for (int a = 4 * n_trip; a < A; ++a) {
+        const int so = a * (3 * EK_TILE * 4);
+        ek_v2f x, y, z;
+        x[0] = EK_LD(so, 0);
+        y[0] = EK_LD(so, 1);
+        z[0] = EK_LD(so, 2);
+        x[1] = 0.f;
+        y[1] = 0.f;
+        z[1] = 0.f;
+        ek_ld_catom<T>(c0, cp + (size_t)a * (3 * T));
+        ek_atom_fma<T, false>(s2, x, y, z, c0, 0, NF);
+    }
+#undef EK_ROWS2
+#undef EK_LD
+
+    if (!UPD) {
+        if (f < n) {
+#pragma unroll
+            for (int c = 0; c < T; ++c) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (c < teff) {
+                    float S[9];
+#pragma unroll
+                    for (int j = 0; j < 9; ++j)
+                        S[j] = s2[c / 2][j][c & 1];
+                    vecs[(size_t)c * n_pad + f] =
+                        ek_rmsd_from_S(S, Gf, ctrace[c], A);
+                }
+            }
+        }
+        return;
+    }
+    float bestv = -__builtin_inff();
+    uint32_t besti = 0xffffffffu;
+    if (f < n) {
+        // candidate 0: the new center of this iteration (kcenters.py:298-306)
+        float S0[9];
+#pragma unroll
+        for (int j = 0; j < 9; ++j)
+            S0[j] = s2[0][j][0];
+        float cur = cur0;
+        const float d0 = ek_rmsd_from_S_below(S0, Gf, ctrace[0], A, cur);
+        if (d0 < cur) {
+            cur = d0;
+            dist[f] = d0;
+            assign[f] = label;
+        }
+        bestv = cur;
+        besti = (uint32_t)f;
+#pragma unroll
+        for (int c = 1; c < T; ++c) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (c < teff) {
+                float S[9];
+#pragma unroll
+                for (int j = 0; j < 9; ++j)
+                    S[j] = s2[c / 2][j][c & 1];
+                vecs[(size_t)(c - 1) * n_pad + f] =
+                    ek_rmsd_from_S_below(S, Gf, ctrace[c], A, cur);
+            }
+        }
+    }
+    ek_wave_argmax(bestv, besti);
+    const int lane = tid & (EK_WAVE - 1), wave = tid / EK_WAVE;
+    if (lane == 0) {
+        red_v[wave] = bestv;
+        red_i[wave] = besti;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float v = red_v[0];
+        uint32_t i = red_i[0];
+#pragma unroll
+        for (int w = 1; w < EK_BLOCK / EK_WAVE; ++w)
+            if (ek_better(red_v[w], red_i[w], v, i)) {
+                v = red_v[w];
+                i = red_i[w];
+            }
+        blockmax[blockIdx.x].val = v;
+        blockmax[blockIdx.x].idx = i;
+    }
+}
+
+size_t ek_ctile_bytes(int A) { return ek_ctile_floats(A) * sizeof(float); }
+
 size_t ek_pass_lds_bytes(int T, int A) { return (size_t)3 * A * T * sizeof(float); }
 
 void ek_launch_pass(int T, const float *tiles, const double *G, float *dist,
                     int32_t *assign, float *vecs, int64_t n, int64_t n_pad,
                     int A, const unsigned char *recs, const EkPlan *plan,
-                    EkBlockMax *blockmax, hipStream_t s)
+                    EkBlockMax *blockmax, int form, float *ctile, double *ctrace,
+                    hipStream_t s)
 {
     if (n <= 0)
         return;
     const unsigned blocks = (unsigned)((n + EK_BLOCK - 1) / EK_BLOCK);
+    if (form == 1 && ctile) {
+        // scalar-operand form: lay the candidates out, then stream the frames
+        const unsigned cb = (unsigned)(((A + EK_CTILE_PAD) * 3 * T + EK_BLOCK - 1) /
+                                       EK_BLOCK);
+        if (T == 8) {
+            hipLaunchKernelGGL((ek_ctile_kernel<8>), dim3(cb), dim3(EK_BLOCK), 0, s,
+                               recs, plan, A, ctile, ctrace);
+            hipLaunchKernelGGL((ek_pass2_kernel<8, true>), dim3(blocks),
+                               dim3(EK_BLOCK), 0, s, tiles, G, dist, assign, vecs,
+                               n, n_pad, A, ctile, ctrace, plan, blockmax);
+        } else {
+            hipLaunchKernelGGL((ek_ctile_kernel<4>), dim3(cb), dim3(EK_BLOCK), 0, s,
+                               recs, plan, A, ctile, ctrace);
+            hipLaunchKernelGGL((ek_pass2_kernel<4, true>), dim3(blocks),
+                               dim3(EK_BLOCK), 0, s, tiles, G, dist, assign, vecs,
+                               n, n_pad, A, ctile, ctrace, plan, blockmax);
+        }
+        return;
+    }
     const size_t lds = ek_pass_lds_bytes(T, A);
 #define EK_PASS(TT)                                                            \
     do {                                                                       \
@@ -452,7 +789,8 @@ __global__ void ek_plan_fixed_kernel(EkPlan *__restrict__ plan, int count)
 
 void ek_launch_pass_dist(int count, const float *tiles, const double *G,
                          float *vecs, int64_t n, int64_t n_pad, int A,
-                         const unsigned char *recs, EkPlan *plan, hipStream_t s)
+                         const unsigned char *recs, EkPlan *plan, int form,
+                         float *ctile, double *ctrace, hipStream_t s)
 {
     if (n <= 0 || count <= 0)
         return;
@@ -460,6 +798,24 @@ void ek_launch_pass_dist(int count, const float *tiles, const double *G,
                        count);
     const unsigned blocks = (unsigned)((n + EK_BLOCK - 1) / EK_BLOCK);
     const int T = (count <= 4) ? 4 : (count <= 8 ? 8 : 16);
+    if (form == 1 && ctile && T <= 8) {
+        const unsigned cb = (unsigned)(((A + EK_CTILE_PAD) * 3 * T + EK_BLOCK - 1) /
+                                       EK_BLOCK);
+        if (T == 8) {
+            hipLaunchKernelGGL((ek_ctile_kernel<8>), dim3(cb), dim3(EK_BLOCK), 0, s,
+                               recs, plan, A, ctile, ctrace);
+            hipLaunchKernelGGL((ek_pass2_kernel<8, false>), dim3(blocks),
+                               dim3(EK_BLOCK), 0, s, tiles, G, nullptr, nullptr,
+                               vecs, n, n_pad, A, ctile, ctrace, plan, nullptr);
+        } else {
+            hipLaunchKernelGGL((ek_ctile_kernel<4>), dim3(cb), dim3(EK_BLOCK), 0, s,
+                               recs, plan, A, ctile, ctrace);
+            hipLaunchKernelGGL((ek_pass2_kernel<4, false>), dim3(blocks),
+                               dim3(EK_BLOCK), 0, s, tiles, G, nullptr, nullptr,
+                               vecs, n, n_pad, A, ctile, ctrace, plan, nullptr);
+        }
+        return;
+    }
     const size_t lds = ek_pass_lds_bytes(T, A);
 #define EK_PASSD(TT)                                                           \
     do {                                                                       \

@@ -418,7 +418,10 @@ int ek_set_frames_per_lane(ek_ctx *ctx, int fpl);
  * ek_assign_nearest with the medoid frames themselves as centers
  * key 8: with key 4 = -1, let ek_kcenters_run move between 1, 4 and 8
  * candidates per pass by measured centers per millisecond: 1 (default) / 0
- * (always the widest form); identical results either way */
+ * (always the widest form); identical results either way
+ * key 9: multi-candidate pass kernel: 1 (default) candidates as scalar
+ * operands read through the scalar cache, 0 candidates staged in LDS;
+ * identical results */
 int ek_set_option(ek_ctx *ctx, int32_t key, int32_t value);
 /* time of the last ek_kcenters_run loop measured with HIP events on the
  * context's stream, milliseconds, and the number of distance-kernel launches
