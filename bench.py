@@ -504,7 +504,7 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": ("ek_pass_kernel<%d,true>" % dom) if dom > 1
+            "kernel": ("ek_pass2_kernel<%d,true>" % dom) if dom > 1
                       else "ek_step_kernel<FPL,0,NT>",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,

@@ -56,6 +56,7 @@ struct ek_ctx {
     bool loaded = false;
 
     float *tiles = nullptr;      // [n_tiles][3A][EK_TILE]
+    float *aos = nullptr;        // [n][3A] the same centred frames, frame-major
     double *G = nullptr;         // [n]
     float *dist = nullptr;       // [n]
     int32_t *assign = nullptr;   // [n]
@@ -76,7 +77,6 @@ struct ek_ctx {
     float *cen_tiles = nullptr;  // the same centers, frame-minor tiles
     int32_t cen_tiles_cap = 0;   // in centers (multiple of EK_TILE)
     int assign_variant = 0;      // 0 auto, 1 vector FMA, 2 MFMA
-    int assign_ablate = 0;       // timing-only ablations (tools/)
 
     // PAM working set (allocated by ek_pam_begin)
     float *ndist = nullptr;
@@ -143,6 +143,11 @@ struct ek_ctx {
     unsigned char *top = nullptr;    // scratch of the candidate pick (ek_spec.hip)
     float *planD = nullptr;          // [64][64] distances between the records on offer
     int pass_form = EK_PASS_FORM_DEFAULT;  // 0: candidates through LDS, 1: as scalar operands
+    int fused = 1;               // single-shard rounds in three launches (ek_round.hip)
+    EkPend *pend = nullptr;      // accepted chain not yet applied
+    EkChainOrd *ord = nullptr;
+    EkChainRow *rows = nullptr;      // [EK_MAX_CANDS] candidate frames' rows
+    unsigned int *tick = nullptr;    // [4] arrival counters
     float *ctile = nullptr;      // the round's candidates, [atom][pair][xyz][2]
     double *ctrace = nullptr;    // their traces
     int chain = 1;               // 1: chained cheap steps, 0: one launch pair per center
@@ -256,6 +261,7 @@ static int ek_free_all(ek_ctx *c)
     if (c->stream)
         (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->tiles);
+    (void)hipFree(c->aos);
     (void)hipFree(c->G);
     (void)hipFree(c->dist);
     (void)hipFree(c->assign);
@@ -290,6 +296,10 @@ static int ek_free_all(ek_ctx *c)
     (void)hipFree(c->recsT);
     (void)hipFree(c->ctile);
     (void)hipFree(c->ctrace);
+    (void)hipFree(c->pend);
+    (void)hipFree(c->ord);
+    (void)hipFree(c->tick);
+    (void)hipFree(c->rows);
     (void)hipFree(c->plan);
     (void)hipFree(c->vecs);
     (void)hipFree(c->hdr);
@@ -370,6 +380,7 @@ extern "C" int ek_ctx_create(int device, int64_t n_frames, int32_t n_atoms,
     if (e == hipSuccess)                                                       \
         e = hipMalloc((void **)&(ptr), (bytes));
     EK_ALLOC(c->tiles, nt * tile_floats * sizeof(float));
+    EK_ALLOC(c->aos, nn * (size_t)3 * n_atoms * sizeof(float));
     EK_ALLOC(c->G, nn * sizeof(double));
     EK_ALLOC(c->dist, nn * sizeof(float));
     EK_ALLOC(c->assign, nn * sizeof(int32_t));
@@ -382,6 +393,10 @@ extern "C" int ek_ctx_create(int device, int64_t n_frames, int32_t n_atoms,
     EK_ALLOC(c->recsT, recb * EK_MAX_CANDS);
     EK_ALLOC(c->plan, sizeof(EkPlan));
     EK_ALLOC(c->hdr, sizeof(EkMaxHdr));
+    EK_ALLOC(c->pend, sizeof(EkPend));
+    EK_ALLOC(c->ord, sizeof(EkChainOrd));
+    EK_ALLOC(c->tick, 4 * sizeof(unsigned int));
+    EK_ALLOC(c->rows, EK_MAX_CANDS * sizeof(EkChainRow));
     EK_ALLOC(c->ctile, ek_ctile_bytes(n_atoms));
     EK_ALLOC(c->ctrace, EK_MAX_CANDS * sizeof(double));
 #undef EK_ALLOC
@@ -400,6 +415,15 @@ extern "C" int ek_ctx_create(int device, int64_t n_frames, int32_t n_atoms,
         e = hipMemsetAsync(c->ctl, 0, sizeof(EkCtl), c->stream);
     if (e == hipSuccess)
         e = hipMemsetAsync(c->rec, 0, recb, c->stream);
+    if (e == hipSuccess)
+        e = hipMemsetAsync(c->pend, 0, sizeof(EkPend), c->stream);
+    if (e == hipSuccess)
+        e = hipMemsetAsync(c->ord, 0, sizeof(EkChainOrd), c->stream);
+    if (e == hipSuccess)
+        e = hipMemsetAsync(c->tick, 0, 4 * sizeof(unsigned int), c->stream);
+    if (e == hipSuccess)
+        e = hipMemsetAsync(c->rows, 0, EK_MAX_CANDS * sizeof(EkChainRow),
+                           c->stream);
     if (e != hipSuccess) {
         ek_free_all(c);
         return ek_fail(e == hipErrorOutOfMemory ? EK_ENOMEM : EK_EHIP,
@@ -441,9 +465,6 @@ extern "C" int ek_set_option(ek_ctx *c, int32_t key, int32_t value)
     case 1:
         c->nt = value < 0 ? -1 : (value ? 1 : 0);
         return EK_OK;
-    case 3:
-        c->assign_ablate = value;
-        return EK_OK;
     case 4:
         if (value != -1 && value != 1 && value != 4 && value != 8)
             return ek_fail(EK_EARG, "ek_set_option: candidates per pass must "
@@ -464,6 +485,11 @@ extern "C" int ek_set_option(ek_ctx *c, int32_t key, int32_t value)
         if (value != 0 && value != 1)
             return ek_fail(EK_EARG, "ek_set_option: state-is-exact flag 0 or 1");
         c->state_exact = value != 0;
+        return EK_OK;
+    case 10:
+        if (value != 0 && value != 1)
+            return ek_fail(EK_EARG, "ek_set_option: fused rounds 0 or 1");
+        c->fused = value;
         return EK_OK;
     case 9:
         if (value != 0 && value != 1)
@@ -512,7 +538,7 @@ extern "C" int ek_load_frames(ek_ctx *c, const float *xyz, int64_t first,
     const size_t frame_floats = (size_t)3 * c->A;
     if (src_is_device) {
         ek_launch_prepare_tiles(xyz, count, c->A, c->tiles, c->G, first, c->n,
-                                c->stream);
+                                c->aos, c->stream);
         EK_CHECK_LAUNCH();
     } else {
         // stage through a device buffer in tile-aligned chunks (<= 256 MiB)
@@ -534,7 +560,7 @@ extern "C" int ek_load_frames(ek_ctx *c, const float *xyz, int64_t first,
                                   (size_t)cnt * frame_floats * sizeof(float),
                                   hipMemcpyHostToDevice, c->stream));
             ek_launch_prepare_tiles(c->stage, cnt, c->A, c->tiles, c->G,
-                                    first + done, c->n, c->stream);
+                                    first + done, c->n, c->aos, c->stream);
             EK_CHECK_LAUNCH();
             // the staging buffer is reused by the next chunk
             EK_HIP(hipStreamSynchronize(c->stream));
@@ -779,25 +805,15 @@ extern "C" int ek_history_download(ek_ctx *c, int32_t first, int32_t count,
     return EK_OK;
 }
 
-// ---- k-centers rounds with the candidates per pass chosen from what pays ----------
+// ---- k-centers rounds, in the form that pays ---------------------------------------
 // A round with T candidates costs more than a one-center step (more FMAs per
-// byte and the small kernels that decide the chain) and accepts between 1 and T
-// centers.  Early in a fit the guesses rarely hit -- each new center reshapes
-// the distances of most frames -- and one-center steps are the fastest way
-// forward; later nearly every guess is accepted.  The three forms (one-center
-// step, 4 and 8 candidates) produce the same centers, labels and distances, so
-// the choice is free: each batch is timed on the device (centers per
-// millisecond), the fit runs in the form with the best recent rate, and a
-// neighbouring form is tried for a short batch whenever its figure is stale,
-// at intervals that double while it keeps losing.
-struct EkModeStat {
-    double rate = 0.0;          // centers per ms, recent batches
-    int64_t seen_at = -1;       // centers done when last measured
-    int64_t gap = 16;           // centers between probes while it loses
-};
-
-static int ek_mode_T(int m) { return m == 0 ? 1 : (m == 1 ? 4 : 8); }
-
+// byte, the small kernels that decide the chain) and accepts between 1 and T
+// centers.  At the very start of a fit the guesses rarely hit -- every new
+// center reshapes the distances of most frames -- and one-center steps are the
+// faster way forward; soon after, nearly every guess is accepted.  Both forms
+// produce the same centers, labels and distances, so the choice is free: every
+// batch is timed on the device (centers per millisecond) and the other form is
+// tried for a short batch at intervals that double while it keeps losing.
 static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
                          int32_t max_new, double dist_cutoff, int32_t *n_added,
                          int64_t *center_index_out, float *center_dist_out,
@@ -820,16 +836,47 @@ static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
     for (int m = 0; m < 3; ++m)
         c->st_rounds[m] = c->st_centers[m] = 0;
     const int nb = (int)((c->n + EK_BLOCK - 1) / EK_BLOCK);
-    const int top_mode = Tmax == 8 ? 2 : 1;
-    // an explicit request (option key 4 = 4 or 8) pins the form
+    const int wide = Tmax == 8 ? 2 : 1;     // index into st_* of the wide form
+    // an explicit request (option key 4 = 4 or 8) pins the wide form
     const bool adaptive = c->cands == -1 && c->adapt;
     const int fpl = ek_pick_fpl(c);
     const int nt = ek_pick_nt(c);
-    EkModeStat ms[3];
-    int mode = adaptive ? 0 : top_mode;
-    int held = -1;              // form the candidate records were picked for
+    bool one = adaptive;        // current form: one-center steps / wide rounds
+    int held = -1;              // form the candidate record(s) were picked for
     bool probing = false;
-    int home = mode;            // form to return to after a probe
+    double rate_home = 0.0;     // centers per ms of the form being run
+    int32_t gap = 8;            // centers until the other form is tried again
+    int32_t since = 0;          // centers since it last was
+    // three launches per round (ek_round.hip) when the pieces it is built from
+    // are the ones selected
+    const bool fused = c->fused && c->pass_form == 1 && c->chain == 1;
+    EkRound R;
+    R.dist = c->dist;
+    R.assign = c->assign;
+    R.vecs = c->vecs;
+    R.n = c->n;
+    R.n_pad = c->n_pad;
+    R.goff = c->goff;
+    R.A = c->A;
+    R.T = Tmax;
+    R.tiles = c->tiles;
+    R.aos = c->aos;
+    R.G = c->G;
+    R.recs = c->recsT;
+    R.plan = c->plan;
+    R.pend = c->pend;
+    R.ord = c->ord;
+    R.blockmax = c->blockmax;
+    R.pm = c->pm;
+    R.top = c->top;
+    R.ctile = c->ctile;
+    R.ctrace = c->ctrace;
+    R.hist = c->hist;
+    R.ctl = c->ctl;
+    R.tick = c->tick;
+    R.rows = c->rows;
+    R.cutoff = dist_cutoff;
+    bool pending = false;       // a fused round may have left a chain to apply
     EK_HIP(hipEventRecord(c->ev0, c->stream));
     EkCtl cr;
     memset(&cr, 0, sizeof(cr));
@@ -838,43 +885,45 @@ static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
     double per_round = 0.6 * Tmax;
     int32_t rounds_before = 0;
     while (cr.n_done < goal) {
-        const int Tm = ek_mode_T(mode);
         const int32_t left = goal - cr.n_done;
-        // ---- records for this form ----------------------------------------------
-        if (held != mode) {
-            if (held == 0 || held < 0)      // the step kernel's partials are per FPL
+        // ---- the record(s) this form starts from -------------------------------------
+        if (held != (one ? 1 : Tmax)) {
+            if (pending) {      // leaving the fused form: the state as it stands
+                ek_launch_round_flush(R, c->stream);
+                pending = false;
+            } else if (held <= 1) {
+                // the step kernel's partials are per FPL frames
                 ek_launch_blockmax(c->dist, c->n, c->blockmax, c->stream);
-            if (Tm == 1)
+            }
+            if (one) {
                 ek_launch_pick(c->blockmax, nb, c->dist, c->tiles, c->G, c->n,
                                c->A, c->goff, c->recsT, c->ctl, c->stream);
-            else
+            } else if (fused) {
+                ek_launch_round_chain(R, 1, c->stream);
+                ek_launch_round_next(R, 1, c->stream);
+            } else {
                 ek_launch_pickT(c->blockmax, nb, c->tiles, c->G, c->assign, c->A,
-                                Tm, c->goff, c->recsT, c->ctl, c->top, c->stream);
+                                Tmax, c->goff, c->recsT, c->ctl, c->top,
+                                c->stream);
+            }
             EK_CHECK_LAUNCH();
-            held = mode;
+            held = one ? 1 : Tmax;
         }
-        // ---- one batch ------------------------------------------------------------
-        int32_t batch;      // steps (form 0) or rounds
-        if (Tm == 1) {
-            batch = probing ? 4 : (adaptive ? (int32_t)std::min<int64_t>(
-                                                  std::max<int64_t>(8, ms[1].gap), 256)
-                                            : 256);
-            batch = std::min(batch, left);
-        } else {
-            batch = std::max(2, std::min(256, (int32_t)(left / per_round) + 1));
-            if (probing)
-                batch = 2;
-            else if (adaptive)      // come back in time to try the neighbours
-                batch = std::min(batch, std::max(4, (int32_t)(256 / per_round)));
-        }
+        // ---- one batch: steps (one-center form) or rounds ----------------------------
+        // long enough to amortise the host's look at the control word, short
+        // enough to come back when the other form is due
+        const int32_t due = adaptive ? std::max(gap - since, 1) : left;
+        int32_t batch;
+        if (one)
+            batch = probing ? 4 : std::min(left, std::min(due, 256));
+        else if (probing)
+            batch = 2;
+        else
+            batch = std::max(2, std::min(256, (int32_t)(std::min(left, due) /
+                                                        per_round) + 1));
         EK_HIP(hipEventRecord(c->evb0, c->stream));
         for (int32_t r = 0; r < batch; ++r) {
-            // sampled timing of the dominant kernel (bench.py): the widest pass
-            const bool sample =
-                Tm == Tmax && c->samp_every > 0 &&
-                (c->samp_count++ % c->samp_every) == 0 &&
-                2 * (size_t)c->samp_used + 1 < c->samp_ev.size();
-            if (Tm == 1) {
+            if (one) {
                 ek_launch_step(fpl, 0, nt, c->tiles, c->G, c->dist, c->assign,
                                c->scratch, c->recsT, 1, c->n, c->A,
                                cr.n_done + r, dist_cutoff, c->blockmax, c->hist,
@@ -885,11 +934,31 @@ static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
                 EK_CHECK_LAUNCH();
                 continue;
             }
-            ek_launch_plan(c->recsT, Tm, c->A, Tm, dist_cutoff, c->planD, c->plan,
-                           c->hist, c->ctl, c->stream);
+            // sampled timing of the dominant kernel (bench.py)
+            const bool sample =
+                c->samp_every > 0 && (c->samp_count++ % c->samp_every) == 0 &&
+                2 * (size_t)c->samp_used + 1 < c->samp_ev.size();
+            if (fused) {
+                if (sample)
+                    EK_HIP(hipEventRecord(c->samp_ev[2 * c->samp_used],
+                                          c->stream));
+                ek_launch_round_pass(R, c->stream);
+                if (sample) {
+                    EK_HIP(hipEventRecord(c->samp_ev[2 * c->samp_used + 1],
+                                          c->stream));
+                    c->samp_used++;
+                }
+                ek_launch_round_chain(R, 0, c->stream);
+                ek_launch_round_next(R, 0, c->stream);
+                EK_CHECK_LAUNCH();
+                pending = true;
+                continue;
+            }
+            ek_launch_plan(c->recsT, Tmax, c->A, Tmax, dist_cutoff, c->planD,
+                           c->plan, c->hist, c->ctl, c->stream);
             if (sample)
                 EK_HIP(hipEventRecord(c->samp_ev[2 * c->samp_used], c->stream));
-            ek_launch_pass(Tm, c->tiles, c->G, c->dist, c->assign, c->vecs, c->n,
+            ek_launch_pass(Tmax, c->tiles, c->G, c->dist, c->assign, c->vecs, c->n,
                            c->n_pad, c->A, c->recsT, c->plan, c->blockmax,
                            c->pass_form, c->ctile, c->ctrace, c->stream);
             if (sample) {
@@ -907,14 +976,14 @@ static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
                 ek_launch_chain_apply(c->vecs, c->n, c->n_pad, c->dist, c->assign,
                                       c->plan, c->blockmax, c->stream);
             } else {
-                for (int j = 1; j < Tm; ++j) {
+                for (int j = 1; j < Tmax; ++j) {
                     ek_launch_localmax_check(c->blockmax, nb, c->goff, dist_cutoff,
                                              c->plan, c->hist, c->ctl, c->stream);
                     ek_launch_apply(c->vecs, c->G, c->n, c->n_pad, c->A, c->dist,
                                     c->assign, c->plan, c->blockmax, c->stream);
                 }
             }
-            ek_launch_pickT(c->blockmax, nb, c->tiles, c->G, c->assign, c->A, Tm,
+            ek_launch_pickT(c->blockmax, nb, c->tiles, c->G, c->assign, c->A, Tmax,
                             c->goff, c->recsT, c->ctl, c->top, c->stream);
             EK_CHECK_LAUNCH();
         }
@@ -924,57 +993,56 @@ static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
                               c->stream));
         EK_HIP(ek_wait(c));
         const int32_t got = cr.n_done - before;
-        // passes that really ran: a step that found the stop rule met returns at once
-        const int32_t ran = Tm == 1 ? got : cr.n_rounds - rounds_before;
+        // passes that really ran (a step that finds the stop rule met returns at once)
+        const int32_t ran = one ? got : cr.n_rounds - rounds_before;
         rounds_before = cr.n_rounds;
-        c->st_rounds[mode] += ran;
-        c->st_centers[mode] += got;
+        c->st_rounds[one ? 0 : wide] += ran;
+        c->st_centers[one ? 0 : wide] += got;
         if (cr.stopped || cr.n_done >= goal)
             break;
-        if (Tm > 1)
+        if (!one)
             per_round = std::max(1.0, (double)got / std::max(ran, 1));
         if (!adaptive)
             continue;
-        // ---- which form next --------------------------------------------------------
+        // ---- which form next ---------------------------------------------------------
         float bms = 0.f;
         EK_HIP(hipEventElapsedTime(&bms, c->evb0, c->evb1));
         const double rate = got / std::max((double)bms, 1e-6);
-        ms[mode].rate = (ms[mode].seen_at < 0 || probing)
-                            ? rate
-                            : 0.5 * ms[mode].rate + 0.5 * rate;
-        ms[mode].seen_at = cr.n_done;
         if (probing) {
             probing = false;
-            if (ms[mode].rate > ms[home].rate) {
-                ms[mode].gap = 16;          // it wins: stay, and re-check the loser soon
-                ms[home].gap = 16;
+            since = 0;
+            if (rate > rate_home) {     // the other form wins: it is home now
+                rate_home = rate;
+                gap = 8;
+            } else {                    // back, and wait twice as long
+                one = !one;
+                gap = std::min(gap * 2, 1024);
+            }
+            continue;
+        }
+        rate_home = rate;
+        since += got;
+        if (since >= gap) {
+            // one-center steps can only win while rounds accept fewer than ~1.4
+            // centers (the cost ratio of the two forms): no need to try them
+            // while the yield is far above that
+            if (one || per_round < 1.8) {
+                one = !one;
+                probing = true;
             } else {
-                ms[mode].gap = std::min<int64_t>(ms[mode].gap * 2, 2048);
-                mode = home;
-                continue;
+                since = 0;
             }
         }
-        home = mode;
-        // a neighbour whose figure is stale gets a short batch
-        int cand = -1;
-        for (int d = -1; d <= 1; d += 2) {
-            const int m2 = mode + d;
-            if (m2 < 0 || m2 > top_mode)
-                continue;
-            if (ms[m2].seen_at < 0 || cr.n_done - ms[m2].seen_at >= ms[m2].gap)
-                if (cand < 0 || ms[m2].seen_at < ms[cand].seen_at)
-                    cand = m2;
-        }
-        if (cand >= 0) {
-            mode = cand;
-            probing = true;
-        }
+    }
+    if (pending) {              // the last round's accepted chain
+        ek_launch_round_flush(R, c->stream);
+        EK_CHECK_LAUNCH();
     }
     EK_HIP(hipEventRecord(c->ev1, c->stream));
     EK_HIP(ek_wait(c));
     EK_HIP(hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
     // leave the records describing the state: [0] = the shard's farthest point
-    if (held == 0 && Tmax > 1) {
+    if (held == 1) {
         ek_launch_blockmax(c->dist, c->n, c->blockmax, c->stream);
         EK_CHECK_LAUNCH();
     }
@@ -1161,10 +1229,9 @@ extern "C" int ek_assign_nearest(ek_ctx *c, const float *centers_xyz,
                               c->stream));
         const float *raw = c->cen_aos + (size_t)c->cen_cap * 3 * c->A;
         ek_launch_prepare_tiles(raw, n_centers, c->A, c->cen_tiles, c->cen_G, 0,
-                                n_centers, c->stream);
+                                n_centers, nullptr, c->stream);
         ek_launch_assign_mfma(c->tiles, c->G, c->n, c->A, c->cen_tiles, c->cen_G,
-                              n_centers, c->dist, c->assign, c->assign_ablate,
-                              c->stream);
+                              n_centers, c->dist, c->assign, c->stream);
     } else {
         ek_launch_assign(c->tiles, c->G, c->n, c->A, c->cen_aos, c->cen_G,
                          n_centers, c->dist, c->assign, c->stream);

@@ -158,17 +158,26 @@ ek_assign_mfma_kernel(const float *__restrict__ tiles,
                       const double *__restrict__ G, int64_t n, int A,
                       const float *__restrict__ ctiles,
                       const double *__restrict__ Gc, int K,
-                      float *__restrict__ dist, int32_t *__restrict__ assign,
-                      int ablate)
+                      float *__restrict__ dist, int32_t *__restrict__ assign)
 {
+    // timing-only ablations (bit 0: no quartic solve, bit 1: no memory
+    // operands) exist in measurement builds alone: tools/ builds a variant
+    // with -DEK_ASSIGN_ABLATE=n; the shipped kernel has none of it
+#ifndef EK_ASSIGN_ABLATE
+#define EK_ASSIGN_ABLATE 0
+#endif
+    constexpr int ablate = EK_ASSIGN_ABLATE;
     __shared__ unsigned long long best[64];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wf = wave & 1, wc = wave >> 1;
     const int fl = lane & 31, kh = lane >> 5;
+    // (+inf, no center): every real key is smaller, and the first look at a
+    // frame's best-so-far reads +inf -- which ek_rmsd_from_S_below never
+    // abandons against -- not a NaN bit pattern
     if (tid < 64)
-        best[tid] = ~0ull;
+        best[tid] = 0x7f800000ffffffffull;
     __syncthreads();
 
     const int64_t f0 = (int64_t)blockIdx.x * 64 + wf * 32;   // wave's frames
@@ -294,13 +303,12 @@ ek_assign_mfma_kernel(const float *__restrict__ tiles,
 
 void ek_launch_assign_mfma(const float *tiles, const double *G, int64_t n, int A,
                            const float *ctiles, const double *Gc, int32_t K,
-                           float *dist, int32_t *assign, int ablate,
-                           hipStream_t s)
+                           float *dist, int32_t *assign, hipStream_t s)
 {
     if (n <= 0)
         return;
     const int64_t blocks = (n + 63) / 64;
     hipLaunchKernelGGL(ek_assign_mfma_kernel, dim3((unsigned)blocks),
                        dim3(EK_BLOCK), 0, s, tiles, G, n, A, ctiles, Gc, K, dist,
-                       assign, ablate);
+                       assign);
 }

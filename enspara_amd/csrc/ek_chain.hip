@@ -27,8 +27,7 @@
 // small exchanges per round instead of one per accepted center.
 #include "ek_common.h"
 #include "ek_reduce.h"
-
-#define EK_CHAIN_THREADS 1024
+#include "ek_chain_dev.h"
 
 // ---- 1. order ---------------------------------------------------------------------
 // the rows of the candidate frames this shard owns
@@ -71,77 +70,6 @@ void ek_launch_chain_rows(const EkPlan *plan, const float *dist,
 {
     hipLaunchKernelGGL(ek_chain_rows_kernel, dim3(1), dim3(EK_WAVE), 0, s, plan,
                        dist, vecs, n, n_pad, global_offset, rows_out);
-}
-
-// the presumed order from the candidate rows (one thread); returns its length
-__device__ __forceinline__ int ek_chain_simulate(const EkPlan *plan,
-                                                 const EkChainRow *rows,
-                                                 int *chain_out)
-{
-    const int teff = plan->teff;
-    float cur[EK_MAX_CANDS];
-    bool open[EK_MAX_CANDS];
-    for (int j = 0; j < EK_MAX_CANDS; ++j) {
-        open[j] = j >= 1 && j < teff && rows[j].valid;
-        cur[j] = open[j] ? rows[j].cur : 0.f;
-    }
-    int cn = 0;
-    for (;;) {
-        int best = -1;
-        float bestv = 0.f;
-        long long bestg = 0;
-        for (int j = 1; j < teff; ++j) {
-            if (!open[j])
-                continue;
-            const float vj = cur[j];
-            const long long gj = plan->gidx[j];
-            if (best < 0 || vj > bestv || (vj == bestv && gj < bestg)) {
-                best = j;
-                bestv = vj;
-                bestg = gj;
-            }
-        }
-        if (best < 0)
-            break;
-        open[best] = false;
-        chain_out[cn++] = best;
-        for (int j = 1; j < teff; ++j) {        // kcenters.py:304: strict <
-            const float dj = rows[j].d[best];
-            if (open[j] && dj < cur[j])
-                cur[j] = dj;
-        }
-    }
-    return cn;
-}
-
-// this shard's rows, one entry per thread (tid < 64), into LDS
-__device__ __forceinline__ void ek_chain_rows_local(const EkPlan *plan,
-                                                    const float *dist,
-                                                    const float *vecs, int64_t n,
-                                                    int64_t n_pad,
-                                                    int64_t global_offset,
-                                                    EkChainRow *rows, int tid)
-{
-    if (tid >= EK_MAX_CANDS * EK_MAX_CANDS)
-        return;
-    const int j = tid / EK_MAX_CANDS, u = tid % EK_MAX_CANDS;
-    const bool live = plan->go && j >= 1 && j < plan->teff;
-    const int64_t local = live ? plan->gidx[j] - global_offset : -1;
-    const bool mine = live && local >= 0 && local < n;
-    float val = 0.f;
-    if (mine) {
-        if (u == 0)
-            val = dist[local];
-        else if (u < plan->teff)
-            val = vecs[(size_t)(u - 1) * n_pad + local];
-    }
-    if (u == 0) {
-        rows[j].cur = val;
-        rows[j].valid = mine ? 1 : 0;
-        rows[j].d[0] = 0.f;
-    } else {
-        rows[j].d[u] = val;
-    }
 }
 
 __global__ void __launch_bounds__(EK_WAVE)
@@ -333,61 +261,6 @@ void ek_launch_chain_max(const float *dist, const float *vecs, int64_t n,
 }
 
 // ---- 3. decide ----------------------------------------------------------------------
-// waves 2w and 2w+1 of the workgroup reduce state w's per-workgroup maxima;
-// the loads of a trip are issued together (the entries are independent)
-__device__ __forceinline__ void ek_chain_reduce(const EkBlockMax *blockmax,
-                                                const EkBlockMax *pm, int nb,
-                                                int nbp, int cn, float *out_v,
-                                                uint32_t *out_i)
-{
-    __shared__ float half_v[2 * EK_MAX_CANDS];
-    __shared__ uint32_t half_i[2 * EK_MAX_CANDS];
-    const int tid = threadIdx.x;
-    const int wv = tid / EK_WAVE, lane = tid & (EK_WAVE - 1);
-    const int w = wv >> 1, part = wv & 1;
-    constexpr int U = 8;
-    if (w < cn) {
-        const EkBlockMax *src = (w == 0) ? blockmax : pm + (size_t)(w - 1) * nbp;
-        const int cnt = (w == 0) ? nb : nbp;
-        float v = -__builtin_inff();
-        uint32_t i = 0xffffffffu;
-        for (int b0 = part * EK_WAVE + lane; b0 < cnt; b0 += 2 * EK_WAVE * U) {
-            EkBlockMax m[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int b = b0 + u * 2 * EK_WAVE;
-                m[u] = src[b < cnt ? b : cnt - 1];
-                if (b >= cnt)
-                    m[u].idx = 0xffffffffu;
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (m[u].idx != 0xffffffffu && ek_better(m[u].val, m[u].idx, v, i)) {
-                    v = m[u].val;
-                    i = m[u].idx;
-                }
-        }
-        ek_wave_argmax(v, i);
-        if (lane == 0) {
-            half_v[wv] = v;
-            half_i[wv] = i;
-        }
-    }
-    __syncthreads();
-    if (tid < cn) {
-        float v = half_v[2 * tid];
-        uint32_t i = half_i[2 * tid];
-        const float v2 = half_v[2 * tid + 1];
-        const uint32_t i2 = half_i[2 * tid + 1];
-        if (i == 0xffffffffu || (i2 != 0xffffffffu && ek_better(v2, i2, v, i))) {
-            v = v2;
-            i = i2;
-        }
-        out_v[tid] = v;
-        out_i[tid] = i;
-    }
-}
-
 __global__ void __launch_bounds__(EK_CHAIN_THREADS)
 ek_chain_localmax_kernel(const EkBlockMax *__restrict__ blockmax,
                          const EkBlockMax *__restrict__ pm, int nb, int nbp,
@@ -414,37 +287,6 @@ void ek_launch_chain_localmax(const EkBlockMax *blockmax, const EkBlockMax *pm,
 {
     hipLaunchKernelGGL(ek_chain_localmax_kernel, dim3(1), dim3(EK_CHAIN_THREADS),
                        0, s, blockmax, pm, nb, nbp, global_offset, plan, hdrs_out);
-}
-
-// state k's global maximum is (v[k], g[k]) (ok[k] false: no frames anywhere)
-__device__ __forceinline__ void ek_chain_walk(const float *v, const long long *g,
-                                              const bool *ok, double cutoff,
-                                              EkPlan *plan, EkHist *hist,
-                                              EkCtl *ctl)
-{
-    const int cn = plan->chain_n;
-    int napply = 0;
-    plan->chain_label0 = ctl->n_done;
-    for (int k = 0; k < cn; ++k) {
-        if (ctl->stopped || ctl->n_done >= ctl->limit || !ok[k])
-            break;
-        ctl->last_max = v[k];
-        if (!((double)v[k] > cutoff)) {     // kcenters.py:217
-            ctl->stopped = 1;
-            break;
-        }
-        const int j = plan->chain[k];
-        if (g[k] != plan->gidx[j])
-            break;                          // the farthest point is not stored
-        const int label = ctl->n_done;
-        hist[label].gidx = g[k];
-        hist[label].dist = v[k];
-        hist[label].set = 1;
-        ctl->n_done = label + 1;
-        plan->used |= 1u << j;
-        ++napply;
-    }
-    plan->napply = napply;
 }
 
 __global__ void __launch_bounds__(EK_WAVE)

@@ -94,11 +94,67 @@ struct EkChainRow {
 };
 static_assert(sizeof(EkChainRow) == 8 + 4 * EK_MAX_CANDS, "EkChainRow layout");
 
+// ---- fused single-shard rounds (ek_round.hip) ----------------------------------
+// the accepted part of a round's chain, not yet applied to dist / assign: the
+// next pass applies it on the fly (its labels are label0, label0 + 1, ..)
+struct EkPend {
+    int32_t n;
+    int32_t label0;
+    int32_t slot[EK_MAX_CANDS];     // stored distance vector of each
+};
+// the presumed acceptance order of a round's candidates 1.. (ek_chain.hip, step 1)
+struct EkChainOrd {
+    int32_t n;
+    int32_t cand[EK_MAX_CANDS];
+};
+// what the pass kernel needs for its part of a fused round
+struct EkFuse {
+    const EkPend *pend = nullptr;
+    EkChainOrd *ord = nullptr;
+    unsigned int *tick = nullptr;
+    int64_t goff = 0;
+    EkHist *hist = nullptr;
+    EkCtl *ctl = nullptr;
+    EkChainRow *rows = nullptr;     // [EK_MAX_CANDS] the candidate frames' rows
+};
+// everything a fused round works on besides the frames
+struct EkRound {
+    float *dist;
+    int32_t *assign;
+    float *vecs;
+    int64_t n, n_pad, goff;
+    int A, T;
+    const float *tiles;
+    const float *aos;           // the centred frames, frame-major [n][3A]
+    const double *G;
+    unsigned char *recs;        // T records (kept for the other entry points)
+    EkPlan *plan;
+    EkPend *pend;
+    EkChainOrd *ord;
+    EkBlockMax *blockmax;       // per 256 frames, state after the pass
+    EkBlockMax *pm;             // [EK_MAX_CANDS][nb] states after each chain prefix
+    unsigned char *top;         // scratch of the candidate pick
+    float *ctile;
+    double *ctrace;
+    EkHist *hist;
+    EkCtl *ctl;
+    EkChainRow *rows;           // [EK_MAX_CANDS], see EkFuse
+    unsigned int *tick;         // [3] arrival counters of the three kernels
+    double cutoff;
+};
+void ek_launch_round_pass(const EkRound &r, hipStream_t s);
+// bootstrap != 0: no chain to decide, candidates from blockmax as it is
+void ek_launch_round_chain(const EkRound &r, int bootstrap, hipStream_t s);
+void ek_launch_round_next(const EkRound &r, int bootstrap, hipStream_t s);
+// apply what is pending (end of a run, or before leaving the fused form)
+void ek_launch_round_flush(const EkRound &r, hipStream_t s);
+
 // ---- kernel launchers (defined in the .hip files) ---------------------------
 // centring + trace + frame-minor transposition of `count` AoS frames
+// aos_copy (optional): the centred coordinates once more, frame-major [n][3A]
 void ek_launch_prepare_tiles(const float *src_aos, int64_t count, int A,
                              float *tiles, double *G, int64_t first_frame,
-                             int64_t n_total, hipStream_t s);
+                             int64_t n_total, float *aos_copy, hipStream_t s);
 // centring + trace of `count` AoS structures into center-major AoS
 void ek_launch_prepare_centers(const float *src_aos, int32_t count, int A,
                                float *out_aos, double *Gc, hipStream_t s);
@@ -143,8 +199,7 @@ void ek_launch_assign(const float *tiles, const double *G, int64_t n, int A,
 // layout (as produced by ek_launch_prepare_tiles)
 void ek_launch_assign_mfma(const float *tiles, const double *G, int64_t n, int A,
                            const float *ctiles, const double *Gc, int32_t K,
-                           float *dist, int32_t *assign, int ablate,
-                           hipStream_t s);
+                           float *dist, int32_t *assign, hipStream_t s);
 
 // ---- PAM (ek_pam.hip) ----------------------------------------------------------
 void ek_launch_gather_frames(const float *tiles, const double *G, int A,

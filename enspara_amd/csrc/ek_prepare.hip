@@ -20,7 +20,8 @@ template <bool TILED>
 __global__ void __launch_bounds__(EK_BLOCK)
 ek_prepare_kernel(const float *__restrict__ src, int64_t count, int A,
                   float *__restrict__ out, double *__restrict__ G,
-                  int64_t first_frame, int64_t n_total)
+                  int64_t first_frame, int64_t n_total,
+                  float *__restrict__ aos_copy)
 {
     __shared__ float stage[EK_BLOCK * ROWF];
     const int t = threadIdx.x;
@@ -82,6 +83,11 @@ ek_prepare_kernel(const float *__restrict__ src, int64_t count, int A,
                     obase[(size_t)(r + 0) * EK_TILE] = cx;
                     obase[(size_t)(r + 1) * EK_TILE] = cy;
                     obase[(size_t)(r + 2) * EK_TILE] = cz;
+                    if (aos_copy) {         // back into the stage, centred
+                        stage[t * ROWF + j + 0] = cx;
+                        stage[t * ROWF + j + 1] = cy;
+                        stage[t * ROWF + j + 2] = cz;
+                    }
                 } else {
                     obase[r + 0] = cx;
                     obase[r + 1] = cy;
@@ -90,6 +96,18 @@ ek_prepare_kernel(const float *__restrict__ src, int64_t count, int A,
             }
         }
         __syncthreads();
+        if (TILED && aos_copy) {
+            // the same centred coordinates frame-major (one frame = 12 A
+            // contiguous bytes): what picks a single frame out of the shard --
+            // candidate records, the pairwise distances of the candidate pick --
+            // reads instead of 3 A cache lines of the tiles
+            for (int64_t i = t; i < total; i += EK_BLOCK) {
+                const int r = (int)(i / w), j = (int)(i % w);
+                aos_copy[(size_t)(first_frame + f0 + r) * 3 * (size_t)A + 3 * a0 +
+                         j] = stage[r * ROWF + j];
+            }
+            __syncthreads();
+        }
     }
     if (live)
         G[gf] = ((double)gx + (double)gy) + (double)gz;
@@ -97,7 +115,7 @@ ek_prepare_kernel(const float *__restrict__ src, int64_t count, int A,
 
 void ek_launch_prepare_tiles(const float *src_aos, int64_t count, int A,
                              float *tiles, double *G, int64_t first_frame,
-                             int64_t n_total, hipStream_t s)
+                             int64_t n_total, float *aos_copy, hipStream_t s)
 {
     if (count <= 0)
         return;
@@ -105,7 +123,7 @@ void ek_launch_prepare_tiles(const float *src_aos, int64_t count, int A,
     const int64_t blocks = (count + EK_BLOCK - 1) / EK_BLOCK;
     hipLaunchKernelGGL(ek_prepare_kernel<true>, dim3((unsigned)blocks),
                        dim3(EK_BLOCK), 0, s, src_aos, count, A, tiles, G,
-                       first_frame, n_total);
+                       first_frame, n_total, aos_copy);
 }
 
 void ek_launch_prepare_centers(const float *src_aos, int32_t count, int A,
@@ -116,5 +134,5 @@ void ek_launch_prepare_centers(const float *src_aos, int32_t count, int A,
     const int blocks = (count + EK_BLOCK - 1) / EK_BLOCK;
     hipLaunchKernelGGL(ek_prepare_kernel<false>, dim3(blocks), dim3(EK_BLOCK),
                        0, s, src_aos, (int64_t)count, A, out_aos, Gc,
-                       (int64_t)0, (int64_t)count);
+                       (int64_t)0, (int64_t)count, (float *)nullptr);
 }

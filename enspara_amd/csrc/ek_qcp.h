@@ -11,13 +11,21 @@
 #define EK_EVALPREC 1e-11
 #define EK_MAXIT 50
 
+// coefficients of the quartic l^4 + C2 l^2 + C1 l + C0 whose largest root is
+// the sum of the (signed) singular values of S; q = sum S_ij^2 = -C2 / 2.
+// One copy, shared by the full and the early-stopped solve: the operation
+// order below is the one the CPU checker follows.
+struct EkQuartic {
+    double q, C2, C1, C0;
+};
+
 // S is row-major: S[3*i+j] = sum_a x_ai * y_aj  (x = frame, y = center)
-__device__ __forceinline__ double ek_msd_from_S(const float (&S)[9], double Gx,
-                                                double Gy, int n_atoms)
+__device__ __forceinline__ EkQuartic ek_quartic_from_S(const float (&S)[9])
 {
     const double Sxx = S[0], Sxy = S[1], Sxz = S[2];
     const double Syx = S[3], Syy = S[4], Syz = S[5];
     const double Szx = S[6], Szy = S[7], Szz = S[8];
+    EkQuartic r;
 
     // C2 = -2 * sum S_ij^2
     double q = Sxx * Sxx;
@@ -29,14 +37,15 @@ __device__ __forceinline__ double ek_msd_from_S(const float (&S)[9], double Gx,
     q = q + Szx * Szx;
     q = q + Szy * Szy;
     q = q + Szz * Szz;
-    const double C2 = -2.0 * q;
+    r.q = q;
+    r.C2 = -2.0 * q;
 
     // C1 = -8 * det(S)
     const double m0 = Syy * Szz - Syz * Szy;
     const double m1 = Syx * Szz - Syz * Szx;
     const double m2 = Syx * Szy - Syy * Szx;
     const double detS = (Sxx * m0 - Sxy * m1) + Sxz * m2;
-    const double C1 = -8.0 * detS;
+    r.C1 = -8.0 * detS;
 
     // C0 = det(K), K = symmetric traceless 4x4 key matrix of S
     const double k00 = (Sxx + Syy) + Szz;
@@ -67,6 +76,15 @@ __device__ __forceinline__ double ek_msd_from_S(const float (&S)[9], double Gx,
     C0 = C0 + s3 * c2;
     C0 = C0 - s4 * c1;
     C0 = C0 + s5 * c0;
+    r.C0 = C0;
+    return r;
+}
+
+__device__ __forceinline__ double ek_msd_from_S(const float (&S)[9], double Gx,
+                                                double Gy, int n_atoms)
+{
+    const EkQuartic p = ek_quartic_from_S(S);
+    const double C2 = p.C2, C1 = p.C1, C0 = p.C0;
 
     // largest root of l^4 + C2 l^2 + C1 l + C0 by Newton from the upper bound
     const double Gsum = Gx + Gy;
@@ -120,61 +138,19 @@ __device__ __forceinline__ float ek_rmsd_from_S(const float (&S)[9], double Gx,
 // abandoning is allowed only when it exceeds 1e-6 C2^6 = 6.4e-5 (s1^2+s2^2+s3^2)^6,
 // which keeps every pair of roots at least ~1e-4 s1 apart (a rank-one S, two-atom
 // or collinear structures, has discriminant 0).  The largest root is then found
-// to ~1e-11 of its size, far inside the absolute margin.  cur = +inf never
-// abandons.
+// to ~1e-11 of its size, far inside the absolute margin.  cur = +inf or NaN
+// never abandons (and skips the test).
 __device__ __forceinline__ float ek_rmsd_from_S_below(const float (&S)[9],
                                                       double Gx, double Gy,
                                                       int n_atoms, float cur)
 {
-    const double Sxx = S[0], Sxy = S[1], Sxz = S[2];
-    const double Syx = S[3], Syy = S[4], Syz = S[5];
-    const double Szx = S[6], Szy = S[7], Szz = S[8];
-
-    double q = Sxx * Sxx;
-    q = q + Sxy * Sxy;
-    q = q + Sxz * Sxz;
-    q = q + Syx * Syx;
-    q = q + Syy * Syy;
-    q = q + Syz * Syz;
-    q = q + Szx * Szx;
-    q = q + Szy * Szy;
-    q = q + Szz * Szz;
-    const double C2 = -2.0 * q;
-
-    const double m0 = Syy * Szz - Syz * Szy;
-    const double m1 = Syx * Szz - Syz * Szx;
-    const double m2 = Syx * Szy - Syy * Szx;
-    const double detS = (Sxx * m0 - Sxy * m1) + Sxz * m2;
-    const double C1 = -8.0 * detS;
-
-    const double k00 = (Sxx + Syy) + Szz;
-    const double k01 = Syz - Szy;
-    const double k02 = Szx - Sxz;
-    const double k03 = Sxy - Syx;
-    const double k11 = (Sxx - Syy) - Szz;
-    const double k12 = Sxy + Syx;
-    const double k13 = Szx + Sxz;
-    const double k22 = (Syy - Sxx) - Szz;
-    const double k23 = Syz + Szy;
-    const double k33 = (Szz - Sxx) - Syy;
-
-    const double s0 = k00 * k11 - k01 * k01;
-    const double s1 = k00 * k12 - k01 * k02;
-    const double s2 = k00 * k13 - k01 * k03;
-    const double s3 = k01 * k12 - k11 * k02;
-    const double s4 = k01 * k13 - k11 * k03;
-    const double s5 = k02 * k13 - k12 * k03;
-    const double c5 = k22 * k33 - k23 * k23;
-    const double c4 = k12 * k33 - k13 * k23;
-    const double c3 = k12 * k23 - k13 * k22;
-    const double c2 = k02 * k33 - k03 * k23;
-    const double c1 = k02 * k23 - k03 * k22;
-    const double c0 = k02 * k13 - k03 * k12;
-    double C0 = s0 * c5 - s1 * c4;
-    C0 = C0 + s2 * c3;
-    C0 = C0 + s3 * c2;
-    C0 = C0 - s4 * c1;
-    C0 = C0 + s5 * c0;
+    // nothing can be abandoned against +inf (a frame's first distance) or a
+    // NaN (never produced here, but then nothing is known): the plain solve,
+    // without the separation test
+    if (!(cur < __builtin_inff()))
+        return ek_rmsd_from_S(S, Gx, Gy, n_atoms);
+    const EkQuartic p = ek_quartic_from_S(S);
+    const double q = p.q, C2 = p.C2, C1 = p.C1, C0 = p.C0;
 
     const double Gsum = Gx + Gy;
     // discriminant of l^4 + p l^2 + r1 l + r0 (only its size matters here)

@@ -23,3 +23,65 @@ __device__ __forceinline__ void ek_wave_argmax(float &v, uint32_t &i)
         }
     }
 }
+
+// ---- handing small results from all workgroups of a launch to its last one ------
+// (ek_round.hip).  An agent-scope fence costs a write-back / invalidate of the
+// whole L2 on gfx950 (eight XCDs, one L2 each) -- per workgroup that doubled the
+// pass kernel's time -- so nothing here fences: the few values that cross
+// workgroups are written and read with agent-scope relaxed atomics (write-through
+// / L2-coherent accesses, `sc1`), every thread waits for its own stores to be
+// acknowledged before the workgroup takes its arrival ticket, and the workgroup
+// that draws the last ticket therefore finds all of them in place.
+__device__ __forceinline__ void ek_coh_store(float *p, float v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void ek_coh_store(int32_t *p, int32_t v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ek_coh_load(const float *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int32_t ek_coh_load(const int32_t *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// (value, index) pairs travel as one 64-bit word
+template <bool COH, typename BM>
+__device__ __forceinline__ BM ek_ld_bm(const BM *p)
+{
+    static_assert(sizeof(BM) == 8, "EkBlockMax is 8 bytes");
+    if (COH) {
+        const unsigned long long w = __hip_atomic_load(
+            (const unsigned long long *)p, __ATOMIC_RELAXED,
+            __HIP_MEMORY_SCOPE_AGENT);
+        return __builtin_bit_cast(BM, w);
+    }
+    return *p;
+}
+template <typename BM>
+__device__ __forceinline__ void ek_coh_store_bm(BM *p, float v, uint32_t i)
+{
+    static_assert(sizeof(BM) == 8, "EkBlockMax is 8 bytes");
+    BM m;
+    m.val = v;
+    m.idx = i;
+    __hip_atomic_store((unsigned long long *)p,
+                       __builtin_bit_cast(unsigned long long, m),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// arrival of this workgroup at `tick`; true in all threads of the last one
+__device__ __forceinline__ bool ek_arrive_last(unsigned int *tick)
+{
+    __shared__ bool ek_last_flag;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this thread's stores
+    __syncthreads();                                    // ... and everybody's
+    if (threadIdx.x == 0)
+        ek_last_flag = __hip_atomic_fetch_add(tick, 1u, __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_AGENT) ==
+                       gridDim.x - 1;
+    __syncthreads();
+    return ek_last_flag;
+}

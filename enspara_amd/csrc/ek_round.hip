@@ -1,0 +1,452 @@
+// ek_round.hip -- a k-centers round of ONE shard in three launches.
+//
+// What a round of candidates does (reference enspara/cluster/kcenters.py:217-231,
+// :282, :298-306, reorganised as ek_spec.hip / ek_chain.hip describe) was ten
+// launches on a single shard: plan, candidate tile, pass, per-prefix maxima,
+// decide, apply, and four for the next round's candidate pick.  Seven of them are
+// single-workgroup or tiny and each cost 5-19 us of mostly latency -- 13 % of a
+// round at 10^6 frames, half of it at the 125 k frames per GPU of an 8-way
+// split.  Here the single-workgroup steps ride at the end of the launch that
+// produces their input: the LAST workgroup of a launch to finish (arrival
+// counter; what it reads of the others' results travels as coherent stores /
+// loads, ek_reduce.h) does them, so no workgroup ever waits for another.  A round is then
+//
+//   pass    ek_pass2_kernel<T, true, true> (ek_spec.hip): applies the chain the
+//           previous round accepted on the way in (no apply pass), candidate 0,
+//           stores the guesses' distances; its last workgroup: presumed
+//           acceptance order of the guesses (ek_chain.hip step 1).
+//   chain   per-256-frame maxima of the states every prefix of that order would
+//           leave (one pass over the distance vectors); last workgroup: decide
+//           the accepted prefix (steps 2-3, exactly ek_chain_walk), then the 64
+//           farthest block maxima of the resulting state.
+//   next    their pairwise distances (one wave per pair); last workgroup: greedy
+//           choice of the next candidates, their records, the next plan (stop
+//           rule kcenters.py:217, label, history) and the candidate tile the
+//           next pass reads.
+//
+// Same decisions as the per-step kernels, taken from the same numbers: centers,
+// labels and distances are unchanged.  The accepted chain stays pending between
+// rounds (EkPend); ek_launch_round_flush applies it at the end of a run.
+#include "ek_common.h"
+#include "ek_qcp.h"
+#include "ek_reduce.h"
+#include "ek_chain_dev.h"
+#include "ek_top_dev.h"
+
+#define EK_ROUND_THREADS 1024       // chain kernel: also the width of its tail
+#define EK_ROUND_FPT 4              // frames per thread there (16-byte loads)
+
+// ---------------------------------------------------------------------------
+// chain: states after the prefixes, decide, farthest block maxima + gather
+// ---------------------------------------------------------------------------
+// pm[(k - 1) * nb + w] = first-index arg-max over frames [256 w, 256 w + 256) of
+// min(dist, vec[order[0]], .., vec[order[k-1]]), k = 1 .. cn (state 0 is what the
+// pass left in blockmax).  A wave covers 256 consecutive frames.
+__global__ void __launch_bounds__(EK_ROUND_THREADS)
+ek_round_chain_kernel(EkRound r, int bootstrap)
+{
+    __shared__ float sv[EK_MAX_CANDS];
+    __shared__ uint32_t si[EK_MAX_CANDS];
+    __shared__ int s_napply;
+    extern __shared__ uint32_t skip[];      // pick fallback for very large shards
+    const int tid = threadIdx.x;
+    const int nb = (int)((r.n + EK_BLOCK - 1) / EK_BLOCK);
+    if (!bootstrap) {
+        if (!r.plan->go)
+            return;             // the run is over: nothing changes any more
+        const int cn = r.ord->n;
+        if (cn > 0) {
+            const int64_t f0 = ((int64_t)blockIdx.x * EK_ROUND_THREADS + tid) *
+                               EK_ROUND_FPT;
+            const bool whole = f0 + EK_ROUND_FPT <= r.n;
+            float run[EK_ROUND_FPT];
+            float dv[EK_MAX_CANDS][EK_ROUND_FPT];
+            // all loads first: the running minimum would serialise them
+#pragma unroll
+            for (int k = 1; k < EK_MAX_CANDS; ++k) {
+#pragma unroll
+                for (int q = 0; q < EK_ROUND_FPT; ++q)
+                    dv[k][q] = __builtin_inff();
+                if (k <= cn) {
+                    const float *v = r.vecs +
+                                     (size_t)(r.ord->cand[k - 1] - 1) * r.n_pad + f0;
+                    if (whole) {
+                        const float4 t = *(const float4 *)v;
+                        dv[k][0] = t.x; dv[k][1] = t.y; dv[k][2] = t.z; dv[k][3] = t.w;
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < EK_ROUND_FPT; ++q)
+                            if (f0 + q < r.n)
+                                dv[k][q] = v[q];
+                    }
+                }
+            }
+            if (whole) {
+                const float4 t = *(const float4 *)(r.dist + f0);
+                run[0] = t.x; run[1] = t.y; run[2] = t.z; run[3] = t.w;
+            } else {
+#pragma unroll
+                for (int q = 0; q < EK_ROUND_FPT; ++q)
+                    run[q] = (f0 + q < r.n) ? r.dist[f0 + q] : 0.f;
+            }
+            const int64_t wg = ((int64_t)blockIdx.x * EK_ROUND_THREADS + tid) /
+                               EK_WAVE;        // = 256-frame block of this wave
+#pragma unroll
+            for (int k = 1; k < EK_MAX_CANDS; ++k) {
+                if (k <= cn) {                  // uniform
+                    float v = -__builtin_inff();
+                    uint32_t i = 0xffffffffu;
+#pragma unroll
+                    for (int q = 0; q < EK_ROUND_FPT; ++q) {
+                        if (f0 + q < r.n) {
+                            if (dv[k][q] < run[q])      // kcenters.py:304
+                                run[q] = dv[k][q];
+                            if (ek_better(run[q], (uint32_t)(f0 + q), v, i)) {
+                                v = run[q];
+                                i = (uint32_t)(f0 + q);
+                            }
+                        }
+                    }
+                    ek_wave_argmax(v, i);
+                    // (read by the last workgroup of this launch: coherent store)
+                    if ((tid & (EK_WAVE - 1)) == 0 && wg < nb)
+                        ek_coh_store_bm(&r.pm[(size_t)(k - 1) * nb + wg], v, i);
+                }
+            }
+        }
+        if (!ek_arrive_last(r.tick + 1))
+            return;
+        // ---- decide (ek_chain.hip steps 2-3) ------------------------------------
+        // states 0 .. cn - 1 are what the walk looks at
+        __shared__ long long s_gidx[EK_MAX_CANDS];
+        __shared__ int s_ord[EK_MAX_CANDS];
+        if (tid < EK_MAX_CANDS) {
+            s_gidx[tid] = r.plan->gidx[tid];
+            s_ord[tid] = tid < cn ? r.ord->cand[tid] : 0;
+        }
+        ek_chain_reduce<true>(r.blockmax, r.pm, nb, nb, cn, sv, si);
+        __syncthreads();
+        if (tid == 0) {
+            // ek_chain_walk on a register copy of the control words: one read,
+            // one write-back, no dependent global reads in between
+            EkCtl c = *r.ctl;
+            const int label0 = c.n_done;
+            uint32_t used = r.plan->used;
+            int na = 0;
+            for (int k = 0; k < cn; ++k) {
+                const bool ok = si[k] != 0xffffffffu;
+                if (c.stopped || c.n_done >= c.limit || !ok)
+                    break;
+                c.last_max = sv[k];
+                if (!((double)sv[k] > r.cutoff)) {      // kcenters.py:217
+                    c.stopped = 1;
+                    break;
+                }
+                const int j = s_ord[k];
+                const long long g = r.goff + (long long)si[k];
+                if (g != s_gidx[j])
+                    break;                      // the farthest point is not stored
+                const int label = c.n_done;
+                r.hist[label].gidx = g;
+                r.hist[label].dist = sv[k];
+                r.hist[label].set = 1;
+                c.n_done = label + 1;
+                used |= 1u << j;
+                r.pend->slot[na] = j - 1;
+                ++na;
+            }
+            r.ctl->n_done = c.n_done;
+            r.ctl->stopped = c.stopped;
+            r.ctl->last_max = c.last_max;
+            r.plan->used = used;
+            r.plan->napply = na;
+            r.plan->chain_label0 = label0;
+            r.pend->n = na;
+            r.pend->label0 = label0;
+            s_napply = na;
+            r.tick[1] = 0;
+        }
+        __syncthreads();
+    } else {
+        if (blockIdx.x != 0)
+            return;
+        if (tid == 0) {
+            r.pend->n = 0;
+            s_napply = 0;
+        }
+        __syncthreads();
+    }
+    // ---- the farthest block maxima of the state the accepted prefix leaves -------
+    const int na = s_napply;
+    const EkBlockMax *state = na == 0 ? r.blockmax : r.pm + (size_t)(na - 1) * nb;
+    EkTop *top = (EkTop *)r.top;
+    ek_pick_top_body<true>(state, nb, top, skip);
+}
+
+void ek_launch_round_chain(const EkRound &r, int bootstrap, hipStream_t s)
+{
+    if (r.n <= 0)
+        return;
+    const int64_t per = (int64_t)EK_ROUND_THREADS * EK_ROUND_FPT;
+    const unsigned blocks = bootstrap ? 1u : (unsigned)((r.n + per - 1) / per);
+    const int nb = (int)((r.n + EK_BLOCK - 1) / EK_BLOCK);
+    const size_t lds = (size_t)((nb + 31) / 32 + 1) * sizeof(uint32_t);
+    hipLaunchKernelGGL(ek_round_chain_kernel, dim3(blocks), dim3(EK_ROUND_THREADS),
+                       lds, s, r, bootstrap);
+}
+
+// ---------------------------------------------------------------------------
+// next: pairwise distances of the farthest frames, the next round's plan
+// ---------------------------------------------------------------------------
+template <int T>
+__global__ void __launch_bounds__(EK_BLOCK)
+ek_round_next_kernel(EkRound r, int bootstrap)
+{
+    // the run is over (a stop rule, or the goal was reached): nothing to prepare.
+    // (go is cleared below, by the last workgroup of the launch that notices.)
+    if (!bootstrap && !r.plan->go)
+        return;
+    const int tid = threadIdx.x;
+    const EkTop *top = (const EkTop *)r.top;
+    const bool done = r.ctl->stopped || r.ctl->n_done >= r.ctl->limit;
+    if (!done) {
+        // one wave per pair; the values only steer the guesses, so the lanes may
+        // stride over the atoms (summation order is free)
+        const int lane = tid & (EK_WAVE - 1);
+        const int w = blockIdx.x * (EK_BLOCK / EK_WAVE) + tid / EK_WAVE;
+        const int i = w / EK_TOP_M, j = w % EK_TOP_M;
+        if (i < j && j < top->n) {
+            const int A = r.A;
+            // straight from the frame-major copy: 12 A contiguous bytes each
+            const float *x = r.aos + (size_t)top->idx[i] * 3 * A;
+            const float *y = r.aos + (size_t)top->idx[j] * 3 * A;
+            float S[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int a = lane; a < A; a += EK_WAVE) {
+                const float x0 = x[3 * a], x1 = x[3 * a + 1], x2 = x[3 * a + 2];
+                const float y0 = y[3 * a], y1 = y[3 * a + 1], y2 = y[3 * a + 2];
+                S[0] += x0 * y0; S[1] += x0 * y1; S[2] += x0 * y2;
+                S[3] += x1 * y0; S[4] += x1 * y1; S[5] += x1 * y2;
+                S[6] += x2 * y0; S[7] += x2 * y1; S[8] += x2 * y2;
+            }
+#pragma unroll
+            for (int q = 0; q < 9; ++q)
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1)
+                    S[q] += __shfl_xor(S[q], off, 64);
+            if (lane == 0) {
+                const float d = ek_rmsd_from_S(S, r.G[top->idx[i]],
+                                               r.G[top->idx[j]], A);
+                // (read by the last workgroup of this launch: coherent stores)
+                float *D = ek_top_D(r.top, A);
+                ek_coh_store(&D[i * EK_TOP_M + j], d);
+                ek_coh_store(&D[j * EK_TOP_M + i], d);
+            }
+        }
+    }
+    if (!ek_arrive_last(r.tick + 2))
+        return;
+    // ---- the next round ----------------------------------------------------------
+    __shared__ float sD[EK_TOP_M * EK_TOP_M];
+    __shared__ float sval[EK_TOP_M];
+    __shared__ uint32_t sidx[EK_TOP_M];
+    __shared__ int sel[EK_MAX_CANDS];
+    __shared__ int n_sel;
+    {
+        // the table of pairwise distances: 16 coherent loads per thread, all in
+        // flight before the first is used
+        const float *D = ek_top_D(r.top, r.A);
+        constexpr int PER = EK_TOP_M * EK_TOP_M / EK_BLOCK;
+        float dreg[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u)
+            dreg[u] = ek_coh_load(&D[tid + u * EK_BLOCK]);
+        if (tid < EK_TOP_M) {
+            sval[tid] = top->val[tid];
+            sidx[tid] = top->idx[tid];
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u)
+            sD[tid + u * EK_BLOCK] = dreg[u];
+    }
+    __syncthreads();
+    if (tid < EK_WAVE) {
+        // greedy order (ek_top_records_kernel): the frame with the largest
+        // remaining distance, then every other one's is lowered by its distance
+        // to it.  Entry 0 is the shard's first-index arg-max whatever D says.
+        const int nt = top->n;
+        const int lane = tid;
+        bool open = lane < nt;
+        float cur = open ? sval[lane] : 0.f;
+        const uint32_t ix = sidx[lane];
+        int ns = 0;
+        while (ns < T) {
+            float v = open ? cur : -__builtin_inff();
+            uint32_t i = open ? ix : 0xffffffffu;
+            ek_wave_argmax(v, i);
+            if (i == 0xffffffffu)
+                break;
+            const unsigned long long who = __ballot(open && ix == i);
+            const int best = __ffsll((long long)who) - 1;
+            if (lane == best)
+                open = false;
+            if (lane == 0)
+                sel[ns] = best;
+            ++ns;
+            const float d = sD[best * EK_TOP_M + lane];
+            if (open && d < cur)
+                cur = d;
+        }
+        if (lane == 0)
+            n_sel = ns;
+    }
+    __syncthreads();
+    const int ns = n_sel;
+    const size_t rstride = ek_rec_bytes(r.A);
+    const float first_max = ns > 0 ? sval[sel[0]] : -__builtin_inff();
+    // the round runs unless a stop rule says otherwise (kcenters.py:217)
+    const bool go = !done && ns > 0 && (double)first_max > r.cutoff;
+    // the records (kept for the other entry points: [0] = the shard's farthest
+    // point, its distance = distances.max(), kcenters.py:226) ...
+    if (tid < T) {
+        EkRecHdr *h = (EkRecHdr *)(r.recs + (size_t)tid * rstride);
+        EkPlan *plan = r.plan;
+        if (tid < ns) {
+            const uint32_t fi = sidx[sel[tid]];
+            const double tr = r.G[fi];
+            h->maxdist = sval[sel[tid]];
+            h->valid = 1;
+            h->gidx = r.goff + (int64_t)fi;
+            h->trace = tr;
+            h->reserved = 0;
+            plan->src[tid] = tid;
+            plan->gidx[tid] = r.goff + (int64_t)fi;
+            plan->maxdist[tid] = sval[sel[tid]];
+            plan->trace[tid] = tr;
+            r.ctrace[tid] = tr;
+        } else {
+            h->maxdist = -__builtin_inff();
+            h->valid = 0;
+            h->gidx = -1;
+            h->trace = 0.0;
+            h->reserved = 0;
+            r.ctrace[tid] = 0.0;
+        }
+    }
+    // ... and, from the same reads, the candidate tile of the next pass:
+    // [atom][pair][xyz][2], zeros for unused slots and the atoms of padding
+    const int A3 = 3 * r.A;
+    for (int e = tid; e < ns * A3; e += EK_BLOCK) {
+        const int c = e / A3, row = e % A3;
+        const float v = r.aos[(size_t)sidx[sel[c]] * A3 + row];
+        ((float *)(r.recs + (size_t)c * rstride + sizeof(EkRecHdr)))[row] = v;
+        if (go) {
+            const int a = row / 3, k = row % 3;
+            r.ctile[a * (3 * T) + (c / 2) * 6 + k * 2 + (c & 1)] = v;
+        }
+    }
+    if (go) {
+        const int total = (r.A + 8) * 3 * T;
+        for (int j = tid; j < total; j += EK_BLOCK) {
+            const int a = j / (3 * T), w = j % (3 * T);
+            const int c = (w / 6) * 2 + (w & 1);
+            if (a >= r.A || c >= ns)
+                r.ctile[j] = 0.f;
+        }
+    }
+    if (tid == 0) {
+        EkPlan *plan = r.plan;
+        r.ctl->last_max = first_max;
+        plan->apply = -1;
+        plan->chain_n = 0;
+        plan->napply = 0;
+        if (go) {
+            // (the pass counts candidate 0 and writes its history entry once
+            // its distances are in)
+            plan->go = 1;
+            plan->teff = ns;
+            plan->label = r.ctl->n_done;
+            plan->used = 1;
+            plan->miss = 0;
+        } else {
+            plan->go = 0;
+            plan->teff = 0;
+            plan->used = 0;
+            plan->miss = 1;
+            if (!done && ns > 0)
+                r.ctl->stopped = 1;     // maxdist <= cutoff
+        }
+        r.tick[2] = 0;
+    }
+}
+
+void ek_launch_round_next(const EkRound &r, int bootstrap, hipStream_t s)
+{
+    if (r.n <= 0)
+        return;
+    const unsigned blocks = (unsigned)(EK_TOP_M * EK_TOP_M / (EK_BLOCK / EK_WAVE));
+    if (r.T == 8)
+        hipLaunchKernelGGL((ek_round_next_kernel<8>), dim3(blocks), dim3(EK_BLOCK), 0,
+                           s, r, bootstrap);
+    else
+        hipLaunchKernelGGL((ek_round_next_kernel<4>), dim3(blocks), dim3(EK_BLOCK), 0,
+                           s, r, bootstrap);
+}
+
+// ---------------------------------------------------------------------------
+// flush: apply what is pending, leave blockmax describing the state
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(EK_BLOCK)
+ek_round_flush_kernel(EkRound r)
+{
+    __shared__ float red_v[EK_BLOCK / EK_WAVE];
+    __shared__ uint32_t red_i[EK_BLOCK / EK_WAVE];
+    const int na = r.pend->n;
+    const int label0 = r.pend->label0;
+    const int tid = threadIdx.x;
+    const int64_t f = (int64_t)blockIdx.x * EK_BLOCK + tid;
+    float v = -__builtin_inff();
+    uint32_t i = 0xffffffffu;
+    if (f < r.n) {
+        float cur = r.dist[f];
+        int32_t lab = -1;
+        for (int k = 0; k < na; ++k) {      // kcenters.py:304-306, in order
+            const float d = r.vecs[(size_t)r.pend->slot[k] * r.n_pad + f];
+            if (d < cur) {
+                cur = d;
+                lab = label0 + k;
+            }
+        }
+        if (lab >= 0) {
+            r.dist[f] = cur;
+            r.assign[f] = lab;
+        }
+        v = cur;
+        i = (uint32_t)f;
+    }
+    ek_wave_argmax(v, i);
+    if ((tid & (EK_WAVE - 1)) == 0) {
+        red_v[tid / EK_WAVE] = v;
+        red_i[tid / EK_WAVE] = i;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < EK_BLOCK / EK_WAVE; ++w)
+            if (ek_better(red_v[w], red_i[w], v, i)) {
+                v = red_v[w];
+                i = red_i[w];
+            }
+        r.blockmax[blockIdx.x].val = v;
+        r.blockmax[blockIdx.x].idx = i;
+    }
+}
+
+void ek_launch_round_flush(const EkRound &r, hipStream_t s)
+{
+    if (r.n <= 0)
+        return;
+    hipLaunchKernelGGL(ek_round_flush_kernel,
+                       dim3((unsigned)((r.n + EK_BLOCK - 1) / EK_BLOCK)),
+                       dim3(EK_BLOCK), 0, s, r);
+    // nothing is pending any more
+    (void)hipMemsetAsync(&r.pend->n, 0, sizeof(int32_t), s);
+}

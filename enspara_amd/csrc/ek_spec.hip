@@ -25,6 +25,8 @@
 #include "ek_common.h"
 #include "ek_qcp.h"
 #include "ek_reduce.h"
+#include "ek_top_dev.h"
+#include "ek_chain_dev.h"
 
 // atoms per trip of the pass kernel's main loop, and how many trips ahead of
 // the FMAs the row loads are issued (register ring of DIST + 1 trips)
@@ -435,6 +437,11 @@ typedef const float __attribute__((address_space(4))) *ek_cfp;
 #define EK_PASS2_WAVES8 4
 #endif
 #define EK_CTILE_PAD 8      // atoms of zeros after the last one (read-ahead)
+// measurement builds only (tools/lab_pass.py): 1 = no quartic solves, 2 = the
+// candidates are read once (no scalar loads in the loop), 4 = no FMAs
+#ifndef EK_PASS2_ABLATE
+#define EK_PASS2_ABLATE 0
+#endif
 
 static inline __host__ __device__ size_t ek_ctile_floats(int A)
 {
@@ -458,6 +465,9 @@ template <int T> struct EkCAtom { float v[3 * T]; };
 template <int T>
 __device__ __forceinline__ void ek_ld_catom(EkCAtom<T> &o, ek_cfp p)
 {
+#if EK_PASS2_ABLATE & 2
+    return;
+#endif
 #pragma unroll
     for (int i = 0; i < 3 * T; ++i)
         o.v[i] = p[i];
@@ -481,6 +491,10 @@ __device__ __forceinline__ void ek_atom_fma(ek_v2f (&s2)[T / 2][9], ek_v2f X,
                 continue;
             const ek_v2f r = (j / 3 == 0) ? X : (j / 3 == 1 ? Y : Z);
             const ek_v2f cc = (j % 3 == 0) ? cx : (j % 3 == 1 ? cy : cz);
+#if EK_PASS2_ABLATE & 4
+            if (p != 0 || j % 3 != 0)
+                continue;
+#endif
             if (HI)
                 ek_pkfma_hi(s2[p][j], r, cc);
             else
@@ -521,7 +535,11 @@ ek_ctile_kernel(const unsigned char *__restrict__ recs,
     }
 }
 
-template <int T, bool UPD>
+// FUSE (single-shard rounds, ek_round.hip): the accepted chain of the previous
+// round (`pend`) is applied to the frame's state on the way in instead of by a
+// pass of its own, and the last workgroup to finish works out the presumed
+// acceptance order of this round's candidates (`ord`).
+template <int T, bool UPD, bool FUSE>
 __global__ void __launch_bounds__(EK_BLOCK,
                                   (T <= 4) ? 5 : EK_PASS2_WAVES8)
 ek_pass2_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
@@ -530,8 +548,9 @@ ek_pass2_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
                 const float *__restrict__ ctile,
                 const double *__restrict__ ctrace,
                 const EkPlan *__restrict__ plan,
-                EkBlockMax *__restrict__ blockmax)
+                EkBlockMax *__restrict__ blockmax, EkFuse fz)
 {
+    const EkPend *__restrict__ pend = fz.pend;
     __shared__ float red_v[EK_BLOCK / EK_WAVE];
     __shared__ uint32_t red_i[EK_BLOCK / EK_WAVE];
     if (!plan->go)
@@ -541,13 +560,49 @@ ek_pass2_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
     const int label = plan->label;
     static_assert(EK_BLOCK == EK_TILE, "one workgroup per tile");
     const int64_t f = (int64_t)blockIdx.x * EK_BLOCK + tid;
+    // FUSE: the last workgroup does a little more at the end (see there), and
+    // "last" is decided by arrival tickets.  Only the workgroups that own one of
+    // the round's guesses produce something it reads; every other workgroup
+    // draws its ticket right here, where the atomic's latency costs nothing --
+    // the one that draws the last ticket does so after every owner has finished.
+    bool owner_blk = false;
+    unsigned int ticket = 0;
+    if (UPD && FUSE) {
+#pragma unroll
+        for (int j = 1; j < T; ++j) {
+            const int64_t l = plan->gidx[j] - fz.goff - (int64_t)blockIdx.x * EK_BLOCK;
+            owner_blk |= j < teff && l >= 0 && l < EK_BLOCK;
+        }
+        if (!owner_blk && tid == 0)
+            ticket = __hip_atomic_fetch_add(fz.tick, 1u, __ATOMIC_RELAXED,
+                                            __HIP_MEMORY_SCOPE_AGENT);
+    }
     // what the epilogue needs from memory is requested now, not after the loop
     double Gf = 0.0;
     float cur0 = 0.f;
+    int32_t lab = -1;           // >= 0: the frame's state changes in this pass
+    int own = 0;                // FUSE: this frame is candidate `own` (>= 1)
     if (f < n) {
         Gf = G[f];
         if (UPD)
             cur0 = dist[f];
+        if (UPD && FUSE) {
+            // is this frame one of the round's guesses?  (its row of the new
+            // distance vectors decides the presumed order, see the end)
+#pragma unroll
+            for (int j = 1; j < T; ++j)
+                if (j < teff && plan->gidx[j] - fz.goff == f)
+                    own = j;
+            // kcenters.py:304-306 for the pending chain, in order
+            const int pn = pend->n;
+            for (int k = 0; k < pn; ++k) {
+                const float d = vecs[(size_t)pend->slot[k] * n_pad + f];
+                if (d < cur0) {
+                    cur0 = d;
+                    lab = pend->label0 + k;
+                }
+            }
+        }
     }
 
     const float *tb = tiles + (size_t)blockIdx.x * 3 * (size_t)A * EK_TILE;
@@ -584,6 +639,11 @@ ek_pass2_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
     for (int k = 0; k < DIST; ++k)
         EK_ROWS2(k, k)
     EkCAtom<T> c0, c1;
+#if EK_PASS2_ABLATE & 2
+#pragma unroll
+    for (int i = 0; i < 3 * T; ++i)
+        c0.v[i] = c1.v[i] = cp[i];
+#endif
     ek_ld_catom<T>(c0, cp);
     constexpr int NF = 9 * T / 2;       // packed FMAs per atom
     // One trip: request the rows of trip t + DIST, then the 4 * NF FMAs of trip
@@ -682,14 +742,25 @@ ek_pass2_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
         for (int j = 0; j < 9; ++j)
             S0[j] = s2[0][j][0];
         float cur = cur0;
+#if EK_PASS2_ABLATE & 1
+        const float d0 = S0[0] + S0[4] + S0[8] + (float)Gf;
+#else
         const float d0 = ek_rmsd_from_S_below(S0, Gf, ctrace[0], A, cur);
+#endif
         if (d0 < cur) {
             cur = d0;
-            dist[f] = d0;
-            assign[f] = label;
+            lab = label;
+        }
+        if (lab >= 0) {
+            dist[f] = cur;
+            assign[f] = lab;
         }
         bestv = cur;
         besti = (uint32_t)f;
+        if (FUSE && own) {
+            ek_coh_store(&fz.rows[own].cur, cur);
+            ek_coh_store(&fz.rows[own].valid, 1);
+        }
 #pragma unroll
         for (int c = 1; c < T; ++c) {
             __builtin_amdgcn_sched_barrier(0);
@@ -698,8 +769,15 @@ ek_pass2_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
 #pragma unroll
                 for (int j = 0; j < 9; ++j)
                     S[j] = s2[c / 2][j][c & 1];
-                vecs[(size_t)(c - 1) * n_pad + f] =
-                    ek_rmsd_from_S_below(S, Gf, ctrace[c], A, cur);
+#if EK_PASS2_ABLATE & 1
+                const float dc =
+                    S[0] + S[1] + S[2] + S[3] + S[4] + S[5] + S[6] + S[7] + S[8];
+#else
+                const float dc = ek_rmsd_from_S_below(S, Gf, ctrace[c], A, cur);
+#endif
+                vecs[(size_t)(c - 1) * n_pad + f] = dc;
+                if (FUSE && own)
+                    ek_coh_store(&fz.rows[own].d[c], dc);
             }
         }
     }
@@ -722,9 +800,85 @@ ek_pass2_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
         blockmax[blockIdx.x].val = v;
         blockmax[blockIdx.x].idx = i;
     }
+    if (FUSE) {
+        // The last workgroup to get here sees everything the others wrote
+        // (release fence, counter, acquire fence) and works out the order in
+        // which the candidates would be accepted (ek_chain.hip, step 1) from the
+        // candidate frames' own rows of the new distance vectors.
+        // (the rows were written by the workgroups that own the candidate
+        // frames, as coherent stores: ek_reduce.h)
+        __shared__ EkChainRow rows[EK_MAX_CANDS];
+        __shared__ bool early_last;
+        bool last;
+        if (owner_blk) {            // after its rows are in place
+            last = ek_arrive_last(fz.tick);
+        } else {
+            if (tid == 0)
+                early_last = ticket == gridDim.x - 1;
+            __syncthreads();
+            last = early_last;
+        }
+        if (!last)
+            return;
+        if (tid < EK_MAX_CANDS * (EK_MAX_CANDS + 2)) {
+            const int j = tid / (EK_MAX_CANDS + 2), u = tid % (EK_MAX_CANDS + 2);
+            const bool live = j >= 1 && j < teff;
+            if (u == 0)
+                rows[j].cur = live ? ek_coh_load(&fz.rows[j].cur) : 0.f;
+            else if (u == 1)
+                rows[j].valid = live ? ek_coh_load(&fz.rows[j].valid) : 0;
+            else
+                rows[j].d[u - 2] = (live && u - 2 >= 1 && u - 2 < teff)
+                                       ? ek_coh_load(&fz.rows[j].d[u - 2])
+                                       : 0.f;
+        }
+        __syncthreads();
+        if (tid < EK_MAX_CANDS)     // the rows are one round's: clear them
+            fz.rows[tid].valid = 0;
+        if (tid == 0) {
+            int chain[EK_MAX_CANDS];
+            const int cn = ek_chain_simulate(plan, rows, chain);
+            for (int k = 0; k < cn; ++k)
+                fz.ord->cand[k] = chain[k];
+            fz.ord->n = cn;
+            // candidate 0 is a center now (kcenters.py:306-309): the count and
+            // the history move when its distances are in, not when it was planned
+            fz.hist[label].gidx = plan->gidx[0];
+            fz.hist[label].dist = plan->maxdist[0];
+            fz.hist[label].set = 1;
+            fz.ctl->n_done = label + 1;
+            fz.ctl->n_rounds = fz.ctl->n_rounds + 1;
+            *fz.tick = 0;
+        }
+    }
 }
 
 size_t ek_ctile_bytes(int A) { return ek_ctile_floats(A) * sizeof(float); }
+
+void ek_launch_round_pass(const EkRound &r, hipStream_t s)
+{
+    if (r.n <= 0)
+        return;
+    const unsigned blocks = (unsigned)((r.n + EK_BLOCK - 1) / EK_BLOCK);
+    EkFuse fz;
+    fz.pend = r.pend;
+    fz.ord = r.ord;
+    fz.tick = r.tick + 0;
+    fz.goff = r.goff;
+    fz.hist = r.hist;
+    fz.ctl = r.ctl;
+    fz.rows = r.rows;
+    if (r.T == 8)
+        hipLaunchKernelGGL((ek_pass2_kernel<8, true, true>), dim3(blocks),
+                           dim3(EK_BLOCK), 0, s, r.tiles, r.G, r.dist, r.assign,
+                           r.vecs, r.n, r.n_pad, r.A, r.ctile, r.ctrace, r.plan,
+                           r.blockmax, fz);
+    else
+        hipLaunchKernelGGL((ek_pass2_kernel<4, true, true>), dim3(blocks),
+                           dim3(EK_BLOCK), 0, s, r.tiles, r.G, r.dist, r.assign,
+                           r.vecs, r.n, r.n_pad, r.A, r.ctile, r.ctrace, r.plan,
+                           r.blockmax, fz);
+}
 
 size_t ek_pass_lds_bytes(int T, int A) { return (size_t)3 * A * T * sizeof(float); }
 
@@ -744,15 +898,15 @@ void ek_launch_pass(int T, const float *tiles, const double *G, float *dist,
         if (T == 8) {
             hipLaunchKernelGGL((ek_ctile_kernel<8>), dim3(cb), dim3(EK_BLOCK), 0, s,
                                recs, plan, A, ctile, ctrace);
-            hipLaunchKernelGGL((ek_pass2_kernel<8, true>), dim3(blocks),
+            hipLaunchKernelGGL((ek_pass2_kernel<8, true, false>), dim3(blocks),
                                dim3(EK_BLOCK), 0, s, tiles, G, dist, assign, vecs,
-                               n, n_pad, A, ctile, ctrace, plan, blockmax);
+                               n, n_pad, A, ctile, ctrace, plan, blockmax, EkFuse());
         } else {
             hipLaunchKernelGGL((ek_ctile_kernel<4>), dim3(cb), dim3(EK_BLOCK), 0, s,
                                recs, plan, A, ctile, ctrace);
-            hipLaunchKernelGGL((ek_pass2_kernel<4, true>), dim3(blocks),
+            hipLaunchKernelGGL((ek_pass2_kernel<4, true, false>), dim3(blocks),
                                dim3(EK_BLOCK), 0, s, tiles, G, dist, assign, vecs,
-                               n, n_pad, A, ctile, ctrace, plan, blockmax);
+                               n, n_pad, A, ctile, ctrace, plan, blockmax, EkFuse());
         }
         return;
     }
@@ -804,15 +958,17 @@ void ek_launch_pass_dist(int count, const float *tiles, const double *G,
         if (T == 8) {
             hipLaunchKernelGGL((ek_ctile_kernel<8>), dim3(cb), dim3(EK_BLOCK), 0, s,
                                recs, plan, A, ctile, ctrace);
-            hipLaunchKernelGGL((ek_pass2_kernel<8, false>), dim3(blocks),
+            hipLaunchKernelGGL((ek_pass2_kernel<8, false, false>), dim3(blocks),
                                dim3(EK_BLOCK), 0, s, tiles, G, nullptr, nullptr,
-                               vecs, n, n_pad, A, ctile, ctrace, plan, nullptr);
+                               vecs, n, n_pad, A, ctile, ctrace, plan, nullptr,
+                               EkFuse());
         } else {
             hipLaunchKernelGGL((ek_ctile_kernel<4>), dim3(cb), dim3(EK_BLOCK), 0, s,
                                recs, plan, A, ctile, ctrace);
-            hipLaunchKernelGGL((ek_pass2_kernel<4, false>), dim3(blocks),
+            hipLaunchKernelGGL((ek_pass2_kernel<4, false, false>), dim3(blocks),
                                dim3(EK_BLOCK), 0, s, tiles, G, nullptr, nullptr,
-                               vecs, n, n_pad, A, ctile, ctrace, plan, nullptr);
+                               vecs, n, n_pad, A, ctile, ctrace, plan, nullptr,
+                               EkFuse());
         }
         return;
     }
@@ -886,73 +1042,6 @@ void ek_launch_blockmax(const float *dist, int64_t n, EkBlockMax *blockmax,
 // ---------------------------------------------------------------------------
 // single-workgroup reductions over the per-workgroup maxima
 // ---------------------------------------------------------------------------
-#define EK_RED_THREADS 1024
-
-// (max, first index) over blockmax[0..nb) skipping entries whose block is
-// marked in `skip` (LDS bitmap, may be null) -> all threads get the result
-__device__ __forceinline__ void ek_block_argmax(const EkBlockMax *blockmax,
-                                                int nb, const uint32_t *skip,
-                                                float &out_v, uint32_t &out_i,
-                                                int &out_b)
-{
-    __shared__ float r_v[EK_RED_THREADS / EK_WAVE];
-    __shared__ uint32_t r_i[EK_RED_THREADS / EK_WAVE];
-    __shared__ int r_b[EK_RED_THREADS / EK_WAVE];
-    __shared__ float w_v;
-    __shared__ uint32_t w_i;
-    __shared__ int w_b;
-    const int tid = threadIdx.x;
-    float v = -__builtin_inff();
-    uint32_t i = 0xffffffffu;
-    int bsel = -1;
-    for (int b = tid; b < nb; b += EK_RED_THREADS) {
-        if (skip && (skip[b >> 5] & (1u << (b & 31))))
-            continue;
-        const EkBlockMax m = blockmax[b];
-        if (m.idx == 0xffffffffu)
-            continue;
-        if (ek_better(m.val, m.idx, v, i)) {
-            v = m.val;
-            i = m.idx;
-            bsel = b;
-        }
-    }
-    // wave reduce carrying the block id along
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const float ov = __shfl_xor(v, off, 64);
-        const uint32_t oi = __shfl_xor(i, off, 64);
-        const int ob = __shfl_xor(bsel, off, 64);
-        if (ek_better(ov, oi, v, i)) {
-            v = ov;
-            i = oi;
-            bsel = ob;
-        }
-    }
-    if ((tid & 63) == 0) {
-        r_v[tid / 64] = v;
-        r_i[tid / 64] = i;
-        r_b[tid / 64] = bsel;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        for (int w = 1; w < EK_RED_THREADS / EK_WAVE; ++w)
-            if (ek_better(r_v[w], r_i[w], v, i)) {
-                v = r_v[w];
-                i = r_i[w];
-                bsel = r_b[w];
-            }
-        w_v = v;
-        w_i = i;
-        w_b = bsel;
-    }
-    __syncthreads();
-    out_v = w_v;
-    out_i = w_i;
-    out_b = w_b;
-    __syncthreads();
-}
-
 // local farthest point -> 16-byte header (what a rank contributes to the
 // per-center exchange)
 __global__ void __launch_bounds__(EK_RED_THREADS)
@@ -1161,15 +1250,6 @@ void ek_launch_apply(const float *vecs, const double *G, int64_t n,
 // (In a CPU model of the rounds this raised the centers per pass from 5.1 to 6.6
 // with 32 maxima and 6.8 with 64, against picking the top maxima with distinct
 // labels.)
-#define EK_TOP_M 64
-
-struct EkTop {
-    int32_t n;
-    int32_t pad;
-    uint32_t idx[EK_TOP_M];
-    float val[EK_TOP_M];
-};
-
 size_t ek_top_scratch_bytes(int A)
 {
     // EkTop | coords [M][3A] f32 | traces [M] f64 | D [M][M] f32
@@ -1177,135 +1257,12 @@ size_t ek_top_scratch_bytes(int A)
            EK_TOP_M * sizeof(double) + (size_t)EK_TOP_M * EK_TOP_M * sizeof(float);
 }
 
-__device__ __forceinline__ float *ek_top_coords(unsigned char *scr)
-{
-    return (float *)(scr + 1024);
-}
-__device__ __forceinline__ double *ek_top_traces(unsigned char *scr, int A)
-{
-    return (double *)(scr + 1024 + (size_t)EK_TOP_M * 3 * A * sizeof(float));
-}
-__device__ __forceinline__ float *ek_top_D(unsigned char *scr, int A)
-{
-    return (float *)(scr + 1024 + (size_t)EK_TOP_M * 3 * A * sizeof(float) +
-                     EK_TOP_M * sizeof(double));
-}
-
-// the EK_TOP_M largest per-workgroup maxima, ordered (value desc, index asc)
 __global__ void __launch_bounds__(EK_RED_THREADS)
 ek_pick_top_kernel(const EkBlockMax *__restrict__ blockmax, int nb,
                    EkTop *__restrict__ top)
 {
     extern __shared__ uint32_t skip[];       // bitmap over workgroups
-    __shared__ uint32_t top_i[EK_TOP_M];
-    __shared__ float top_v[EK_TOP_M];
-    __shared__ int n_top;
-    const int tid = threadIdx.x;
-    for (int w = tid; w < (nb + 31) / 32; w += EK_RED_THREADS)
-        skip[w] = 0;
-    if (tid == 0)
-        n_top = 0;
-    __syncthreads();
-    // The per-workgroup maxima are read once: every thread keeps its (up to
-    // PICK_PER) entries in registers across the looks; larger shards fall back
-    // to re-reading them.
-    constexpr int PICK_PER = 8;
-    const bool cached = nb <= PICK_PER * EK_RED_THREADS;
-    float cv[PICK_PER];
-    uint32_t ci[PICK_PER];
-    if (cached) {
-#pragma unroll
-        for (int k = 0; k < PICK_PER; ++k) {
-            const int bb = tid + k * EK_RED_THREADS;
-            cv[k] = -__builtin_inff();
-            ci[k] = 0xffffffffu;
-            if (bb < nb) {
-                const EkBlockMax m = blockmax[bb];
-                cv[k] = m.val;
-                ci[k] = m.idx;
-            }
-        }
-    }
-    constexpr int NWV = EK_RED_THREADS / EK_WAVE;
-    constexpr int LW = 8;                // looks per wave
-    __shared__ float wt_v[NWV * LW];
-    __shared__ uint32_t wt_i[NWV * LW];
-    const int max_looks = EK_TOP_M;
-    if (cached) {
-        // Level 1: every wave takes the LW best of its own entries with wave-wide
-        // arg-max steps (no workgroup barrier).  Level 2: the NWV * LW survivors
-        // are ranked against one another, one thread each, and the best EK_TOP_M
-        // land in order.  The workgroups' maxima are spread over the waves at
-        // random, so this is the true top list except when more than LW of it
-        // fall into one wave -- which only costs a slightly worse guess; entry 0
-        // is always the overall first-index arg-max.
-        const int lane = tid & (EK_WAVE - 1), wv = tid / EK_WAVE;
-        for (int look = 0; look < LW; ++look) {
-            float v = -__builtin_inff();
-            uint32_t i = 0xffffffffu;
-#pragma unroll
-            for (int k = 0; k < PICK_PER; ++k)
-                if (ci[k] != 0xffffffffu && ek_better(cv[k], ci[k], v, i)) {
-                    v = cv[k];
-                    i = ci[k];
-                }
-            ek_wave_argmax(v, i);            // every lane holds the winner
-            if (i != 0xffffffffu) {          // its owner retires it (indices are unique)
-#pragma unroll
-                for (int k = 0; k < PICK_PER; ++k)
-                    if (ci[k] == i)
-                        ci[k] = 0xffffffffu;
-            }
-            if (lane == 0) {
-                wt_v[wv * LW + look] = v;
-                wt_i[wv * LW + look] = i;
-            }
-        }
-        __syncthreads();
-        if (tid < NWV * LW) {
-            const float v = wt_v[tid];
-            const uint32_t i = wt_i[tid];
-            if (i != 0xffffffffu) {
-                int rank = 0;
-                for (int e = 0; e < NWV * LW; ++e) {
-                    const uint32_t oi = wt_i[e];
-                    if (oi != 0xffffffffu && ek_better(wt_v[e], oi, v, i))
-                        ++rank;
-                }
-                if (rank < EK_TOP_M) {
-                    top_i[rank] = i;
-                    top_v[rank] = v;
-                }
-                atomicAdd(&n_top, 1);
-            }
-        }
-        __syncthreads();
-        if (tid == 0 && n_top > EK_TOP_M)
-            n_top = EK_TOP_M;
-    } else {
-        for (int look = 0; look < max_looks; ++look) {
-            float v;
-            uint32_t i;
-            int b;
-            ek_block_argmax(blockmax, nb, skip, v, i, b);
-            if (b < 0)
-                break;
-            if (tid == 0) {
-                skip[b >> 5] |= 1u << (b & 31);
-                top_i[n_top] = i;
-                top_v[n_top] = v;
-                n_top = n_top + 1;
-            }
-            __syncthreads();
-        }
-    }
-    __syncthreads();
-    if (tid < EK_TOP_M) {
-        top->idx[tid] = (tid < n_top) ? top_i[tid] : 0xffffffffu;
-        top->val[tid] = (tid < n_top) ? top_v[tid] : -__builtin_inff();
-    }
-    if (tid == 0)
-        top->n = n_top;
+    ek_pick_top_body(blockmax, nb, top, skip);
 }
 
 // their centred coordinates and traces; every read is its own cache line, so
@@ -1365,88 +1322,12 @@ ek_top_pair_kernel(int A, unsigned char *__restrict__ scr)
     }
 }
 
-// the greedy order, and the records of its first T frames
 __global__ void __launch_bounds__(EK_BLOCK)
 ek_top_records_kernel(int A, int T, int64_t global_offset,
                       unsigned char *__restrict__ scr,
                       unsigned char *__restrict__ recs, EkCtl *__restrict__ ctl)
 {
-    __shared__ int sel[EK_MAX_CANDS];
-    __shared__ int n_sel;
-    __shared__ float sD[EK_TOP_M * EK_TOP_M];
-    __shared__ float sval[EK_TOP_M];
-    __shared__ uint32_t sidx[EK_TOP_M];
-    const EkTop *top = (const EkTop *)scr;
-    const int tid = threadIdx.x;
-    {   // the table into LDS first: the greedy loop is one thread's dependent reads
-        const float *D = ek_top_D(scr, A);
-        for (int k = tid; k < EK_TOP_M * EK_TOP_M; k += EK_BLOCK)
-            sD[k] = D[k];
-        if (tid < EK_TOP_M) {
-            sval[tid] = top->val[tid];
-            sidx[tid] = top->idx[tid];
-        }
-    }
-    __syncthreads();
-    if (tid < EK_WAVE) {
-        // the greedy order, one wave: lane l holds entry l's remaining distance
-        static_assert(EK_TOP_M <= EK_WAVE, "one lane per entry");
-        const int nt = top->n;
-        const int lane = tid;
-        bool open = lane < nt;
-        float cur = open ? sval[lane] : 0.f;
-        const uint32_t ix = (lane < EK_TOP_M) ? sidx[lane] : 0xffffffffu;
-        int ns = 0;
-        while (ns < T) {
-            float v = open ? cur : -__builtin_inff();
-            uint32_t i = open ? ix : 0xffffffffu;
-            ek_wave_argmax(v, i);
-            if (i == 0xffffffffu)
-                break;
-            const unsigned long long who = __ballot(open && ix == i);
-            const int best = __ffsll((long long)who) - 1;
-            if (lane == best)
-                open = false;
-            if (lane == 0)
-                sel[ns] = best;
-            ++ns;
-            if (lane < EK_TOP_M) {
-                const float d = sD[best * EK_TOP_M + lane];
-                if (open && d < cur)
-                    cur = d;
-            }
-        }
-        if (lane == 0) {
-            n_sel = ns;
-            ctl->last_max = (ns > 0) ? sval[sel[0]] : -__builtin_inff();
-        }
-    }
-    __syncthreads();
-    const int ns = n_sel;
-    const size_t rstride = ek_rec_bytes(A);
-    if (tid < T) {
-        EkRecHdr *h = (EkRecHdr *)(recs + (size_t)tid * rstride);
-        if (tid < ns) {
-            const int s = sel[tid];
-            h->maxdist = top->val[s];
-            h->valid = 1;
-            h->gidx = global_offset + (int64_t)top->idx[s];
-            h->trace = ek_top_traces(scr, A)[s];
-            h->reserved = 0;
-        } else {
-            h->maxdist = -__builtin_inff();
-            h->valid = 0;
-            h->gidx = -1;
-            h->trace = 0.0;
-            h->reserved = 0;
-        }
-    }
-    const float *tc = ek_top_coords(scr);
-    for (int k = tid; k < ns * 3 * A; k += EK_BLOCK) {
-        const int j = k / (3 * A), r = k % (3 * A);
-        float *coords = (float *)(recs + (size_t)j * rstride + sizeof(EkRecHdr));
-        coords[r] = tc[(size_t)sel[j] * 3 * A + r];
-    }
+    ek_top_records_body(A, T, global_offset, scr, recs, ctl);
 }
 
 void ek_launch_pickT(const EkBlockMax *blockmax, int nb, const float *tiles,

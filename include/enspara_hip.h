@@ -419,6 +419,9 @@ int ek_set_frames_per_lane(ek_ctx *ctx, int fpl);
  * key 8: with key 4 = -1, let ek_kcenters_run move between 1, 4 and 8
  * candidates per pass by measured centers per millisecond: 1 (default) / 0
  * (always the widest form); identical results either way
+ * key 10: ek_kcenters_run's rounds in three launches (the single-workgroup
+ * steps ride at the end of the launch that produces their input): 1 (default)
+ * / 0 (one launch per step); identical results
  * key 9: multi-candidate pass kernel: 1 (default) candidates as scalar
  * operands read through the scalar cache, 0 candidates staged in LDS;
  * identical results */

@@ -6,7 +6,7 @@ For every library given (default: the in-tree build) a child process loads the
 same frames and times a k-centers run of K centers for each combination of
   form   0 = candidates through LDS, 1 = candidates as scalar operands
   adapt  0 = always 8 candidates per pass, 1 = 1/4/8 by measured rate
-printing seconds per run, the mean pass-kernel time (HIP events), the passes
+(LAB_CONFIGS="form,adapt,cands[,fused];..." picks the combinations) printing seconds per run, the mean pass-kernel time (HIP events), the passes
 by candidates per pass, and a checksum of centers + final state (all
 combinations must agree: the forms are bit-identical by construction).
 Variants are built with enspara_amd.build.build(out=..., tag=..., extra_flags=[...]).
@@ -28,8 +28,14 @@ def child(path, K):
     st = FrameStore.from_array(np.ascontiguousarray(x))
     name = os.path.basename(os.environ.get("ENSPARA_HIP_LIB", "default"))
     sums = set()
-    for form, adapt, cands in ((0, 0, -1), (1, 0, -1), (1, 1, -1), (0, 1, -1),
-                               (1, 0, 4), (0, 0, 4), (1, 0, 1)):
+    configs = os.environ.get("LAB_CONFIGS")
+    configs = ([tuple(int(v) for v in c.split(",")) for c in configs.split(";")]
+               if configs else [(0, 0, -1), (1, 0, -1), (1, 1, -1), (0, 1, -1),
+                                (1, 0, 4), (0, 0, 4), (1, 0, 1)])
+    for cfg in configs:
+        form, adapt, cands = cfg[:3]
+        fused = cfg[3] if len(cfg) > 3 else 1
+        st.set_option(10, fused)
         st.set_option(9, form)
         st.set_option(8, adapt)
         st.set_option(4, cands)
@@ -48,9 +54,9 @@ def child(path, K):
         h = hashlib.sha256(idx.tobytes() + d.tobytes() + a.tobytes()).hexdigest()[:12]
         sums.add(h)
         stats = st.run_stats() if cands != 1 else {}
-        print("%-28s form %d adapt %d cands %2d: %.4f s  %.4f ms/center  pass %.4f ms "
+        print("%-28s form %d adapt %d cands %2d fused %d: %.4f s  %.4f ms/center  pass %.4f ms "
               "(%d samples)  %s  sum %s"
-              % (name, form, adapt, cands, best[0], best[0] / K * 1e3, best[1], best[2],
+              % (name, form, adapt, cands, fused, best[0], best[0] / K * 1e3, best[1], best[2],
                  {T: pc for T, pc in stats.items() if pc[0]}, h), flush=True)
     print("%-28s checksums agree: %s" % (name, len(sums) == 1), flush=True)
 
