@@ -306,8 +306,8 @@ def kernel_source_hash():
     """Identifies the code the distance kernels were built from: the traffic
     figure below is only quoted for the sources it was measured on."""
     h = hashlib.sha256()
-    for f in ("ek_spec.hip", "ek_kcenters.hip", "ek_qcp.h", "ek_common.h",
-              "ek_reduce.h"):
+    for f in ("ek_spec.hip", "ek_round.hip", "ek_kcenters.hip", "ek_qcp.h",
+              "ek_common.h", "ek_reduce.h", "ek_chain_dev.h", "ek_top_dev.h"):
         with open(os.path.join(ROOT, "enspara_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]

@@ -147,6 +147,7 @@ struct ek_ctx {
     EkPend *pend = nullptr;      // accepted chain not yet applied
     EkChainOrd *ord = nullptr;
     EkChainRow *rows = nullptr;      // [EK_MAX_CANDS] candidate frames' rows
+    uint32_t *vmask = nullptr;       // [n_pad / 64] which vectors a wave stored
     unsigned int *tick = nullptr;    // [4] arrival counters
     float *ctile = nullptr;      // the round's candidates, [atom][pair][xyz][2]
     double *ctrace = nullptr;    // their traces
@@ -300,6 +301,7 @@ static int ek_free_all(ek_ctx *c)
     (void)hipFree(c->ord);
     (void)hipFree(c->tick);
     (void)hipFree(c->rows);
+    (void)hipFree(c->vmask);
     (void)hipFree(c->plan);
     (void)hipFree(c->vecs);
     (void)hipFree(c->hdr);
@@ -397,6 +399,7 @@ extern "C" int ek_ctx_create(int device, int64_t n_frames, int32_t n_atoms,
     EK_ALLOC(c->ord, sizeof(EkChainOrd));
     EK_ALLOC(c->tick, 4 * sizeof(unsigned int));
     EK_ALLOC(c->rows, EK_MAX_CANDS * sizeof(EkChainRow));
+    EK_ALLOC(c->vmask, (nt * EK_TILE / EK_WAVE) * sizeof(uint32_t));
     EK_ALLOC(c->ctile, ek_ctile_bytes(n_atoms));
     EK_ALLOC(c->ctrace, EK_MAX_CANDS * sizeof(double));
 #undef EK_ALLOC
@@ -875,6 +878,7 @@ static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
     R.ctl = c->ctl;
     R.tick = c->tick;
     R.rows = c->rows;
+    R.vmask = c->vmask;
     R.cutoff = dist_cutoff;
     bool pending = false;       // a fused round may have left a chain to apply
     EK_HIP(hipEventRecord(c->ev0, c->stream));

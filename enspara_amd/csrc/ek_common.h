@@ -116,6 +116,7 @@ struct EkFuse {
     EkHist *hist = nullptr;
     EkCtl *ctl = nullptr;
     EkChainRow *rows = nullptr;     // [EK_MAX_CANDS] the candidate frames' rows
+    uint32_t *vmask = nullptr;      // per 64 frames: bit c = vector c - 1 stored
 };
 // everything a fused round works on besides the frames
 struct EkRound {
@@ -139,6 +140,7 @@ struct EkRound {
     EkHist *hist;
     EkCtl *ctl;
     EkChainRow *rows;           // [EK_MAX_CANDS], see EkFuse
+    uint32_t *vmask;            // [n_pad / 64], see EkFuse
     unsigned int *tick;         // [3] arrival counters of the three kernels
     double cutoff;
 };

@@ -61,13 +61,15 @@ ek_round_chain_kernel(EkRound r, int bootstrap)
             const bool whole = f0 + EK_ROUND_FPT <= r.n;
             float run[EK_ROUND_FPT];
             float dv[EK_MAX_CANDS][EK_ROUND_FPT];
+            const uint32_t vm = f0 < r.n ? r.vmask[f0 >> 6] : 0u;
             // all loads first: the running minimum would serialise them
 #pragma unroll
             for (int k = 1; k < EK_MAX_CANDS; ++k) {
 #pragma unroll
                 for (int q = 0; q < EK_ROUND_FPT; ++q)
                     dv[k][q] = __builtin_inff();
-                if (k <= cn) {
+                // (a vector the pass did not store for these frames is all +inf)
+                if (k <= cn && ((vm >> r.ord->cand[k - 1]) & 1u)) {
                     const float *v = r.vecs +
                                      (size_t)(r.ord->cand[k - 1] - 1) * r.n_pad + f0;
                     if (whole) {
@@ -409,7 +411,10 @@ ek_round_flush_kernel(EkRound r)
     if (f < r.n) {
         float cur = r.dist[f];
         int32_t lab = -1;
+        const uint32_t vm = na > 0 ? r.vmask[f >> 6] : 0u;
         for (int k = 0; k < na; ++k) {      // kcenters.py:304-306, in order
+            if (!((vm >> (r.pend->slot[k] + 1)) & 1u))
+                continue;                   // not stored: +inf
             const float d = r.vecs[(size_t)r.pend->slot[k] * r.n_pad + f];
             if (d < cur) {
                 cur = d;

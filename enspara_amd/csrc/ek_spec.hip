@@ -593,10 +593,16 @@ ek_pass2_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
             for (int j = 1; j < T; ++j)
                 if (j < teff && plan->gidx[j] - fz.goff == f)
                     own = j;
-            // kcenters.py:304-306 for the pending chain, in order
+            // kcenters.py:304-306 for the pending chain, in order.  A vector is
+            // only stored where some frame of the wave got a finite distance
+            // (see the end): elsewhere it is +inf and changes nothing.
             const int pn = pend->n;
+            const uint32_t vm = pn > 0 ? fz.vmask[f >> 6] : 0u;
             for (int k = 0; k < pn; ++k) {
-                const float d = vecs[(size_t)pend->slot[k] * n_pad + f];
+                const int slot = pend->slot[k];
+                if (!((vm >> (slot + 1)) & 1u))
+                    continue;
+                const float d = vecs[(size_t)slot * n_pad + f];
                 if (d < cur0) {
                     cur0 = d;
                     lab = pend->label0 + k;
@@ -610,9 +616,18 @@ ek_pass2_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
         (void *)tb, 0, 3 * A * EK_TILE * 4, 0x00020000);
     const int vo = tid * 4;
     // non-temporal: the frame stream is read once per pass
+#ifndef EK_PASS2_LDMODE
+#define EK_PASS2_LDMODE 0   // measurement builds: 1 = no nt hint, 2 = global loads
+#endif
+#if EK_PASS2_LDMODE == 2
+#define EK_LD(SO, K)                                                           \
+    __builtin_nontemporal_load(tb + (size_t)((SO) / 4) + (K) * EK_TILE + tid)
+#else
 #define EK_LD(SO, K)                                                           \
     __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(            \
-                                  rs, vo + (K) * (EK_TILE * 4), (SO), 2))
+                                  rs, vo + (K) * (EK_TILE * 4), (SO),          \
+                                  EK_PASS2_LDMODE == 1 ? 0 : 2))
+#endif
     ek_v2f s2[T / 2][9];
 #pragma unroll
     for (int c = 0; c < T / 2; ++c)
@@ -761,6 +776,13 @@ ek_pass2_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
             ek_coh_store(&fz.rows[own].cur, cur);
             ek_coh_store(&fz.rows[own].valid, 1);
         }
+        // FUSE: almost every kept distance is +inf (abandoned: it cannot be below
+        // the frame's own), and 4-byte-per-frame stores trickling into seven
+        // arrays cost the pass 12 % (28 MB of writes against 3.6 GB of reads:
+        // every small write burst turns the HBM bus around).  So a wave stores a
+        // vector only if one of its frames has a finite value, and one word per
+        // wave says which it stored; readers take the others as +inf.
+        uint32_t wmask = 0;
 #pragma unroll
         for (int c = 1; c < T; ++c) {
             __builtin_amdgcn_sched_barrier(0);
@@ -775,11 +797,25 @@ ek_pass2_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
 #else
                 const float dc = ek_rmsd_from_S_below(S, Gf, ctrace[c], A, cur);
 #endif
-                vecs[(size_t)(c - 1) * n_pad + f] = dc;
+#if !(EK_PASS2_ABLATE & 8)
+                if (FUSE) {
+                    if (__ballot(dc != __builtin_inff())) {     // wave-uniform
+                        vecs[(size_t)(c - 1) * n_pad + f] = dc;
+                        wmask |= 1u << c;
+                    }
+                } else {
+                    vecs[(size_t)(c - 1) * n_pad + f] = dc;
+                }
+#else
+                if (dc == 12345.f)
+                    vecs[(size_t)(c - 1) * n_pad + f] = dc;
+#endif
                 if (FUSE && own)
                     ek_coh_store(&fz.rows[own].d[c], dc);
             }
         }
+        if (FUSE && (f & (EK_WAVE - 1)) == 0)
+            fz.vmask[f >> 6] = wmask;
     }
     ek_wave_argmax(bestv, besti);
     const int lane = tid & (EK_WAVE - 1), wave = tid / EK_WAVE;
@@ -868,6 +904,7 @@ void ek_launch_round_pass(const EkRound &r, hipStream_t s)
     fz.hist = r.hist;
     fz.ctl = r.ctl;
     fz.rows = r.rows;
+    fz.vmask = r.vmask;
     if (r.T == 8)
         hipLaunchKernelGGL((ek_pass2_kernel<8, true, true>), dim3(blocks),
                            dim3(EK_BLOCK), 0, s, r.tiles, r.G, r.dist, r.assign,

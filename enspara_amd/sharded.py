@@ -207,10 +207,16 @@ def kcenters_sharded(shard, first_label, max_new, dist_cutoff=0.0, group=None,
     world, _ = _world(group)
     collective = dist.is_available() and dist.is_initialized()
     T = getattr(shard, "candidates", 1)
-    if T > 1 and world * T <= 64:
+    if T > 1 and world <= MAX_ROUND_RECORDS:
         return _kcenters_sharded_rounds(shard, first_label, max_new,
                                         dist_cutoff, group, fresh, world, T,
                                         collective)
+    if T > 1:
+        import logging
+        logging.getLogger(__name__).warning(
+            "%d ranks: more than the %d candidate records a round can choose "
+            "from; falling back to one exchange per center", world,
+            MAX_ROUND_RECORDS)
     rb = shard.record_bytes
     mine = shard.new_buffer(rb)
     everyone = shard.new_buffer(rb * world) if collective else mine
@@ -238,6 +244,11 @@ def kcenters_sharded(shard, first_label, max_new, dist_cutoff=0.0, group=None,
                                                       dtype=np.float32)
 
 
+# records a round's plan can choose its candidates from (the device keeps a
+# 64 x 64 table of their pairwise distances, csrc/ek_spec.hip)
+MAX_ROUND_RECORDS = 64
+
+
 def _kcenters_sharded_rounds(shard, first_label, max_new, dist_cutoff, group,
                              fresh, world, T, collective):
     """Multi-candidate rounds (csrc/ek_spec.hip) across ranks.  Messages per
@@ -250,8 +261,12 @@ def _kcenters_sharded_rounds(shard, first_label, max_new, dist_cutoff, group,
     falls back to one 16-byte header all-gather per accepted center."""
     import torch.distributed as dist
     rb = shard.record_bytes
+    # every rank offers its first `offer` records (they are ordered: record 0 is
+    # its farthest point): all T while world * T fits the plan's table, fewer
+    # per rank in larger groups -- the round still runs T candidates
+    offer = min(T, max(1, MAX_ROUND_RECORDS // world))
     recs_mine = shard.new_buffer(rb * T)
-    recs_all = shard.new_buffer(rb * T * world) if collective else recs_mine
+    recs_all = shard.new_buffer(rb * offer * world) if collective else recs_mine
     hdr_mine = shard.new_buffer(16)
     hdr_all = shard.new_buffer(16 * world) if collective else hdr_mine
     limit = first_label + max_new
@@ -272,8 +287,10 @@ def _kcenters_sharded_rounds(shard, first_label, max_new, dist_cutoff, group,
         before = n_done
         for _ in range(rounds):
             if collective:
-                dist.all_gather_into_tensor(recs_all, recs_mine, group=group)
-            shard.spec_round(recs_all, world * T, float(dist_cutoff))
+                dist.all_gather_into_tensor(recs_all, recs_mine[:rb * offer],
+                                            group=group)
+            shard.spec_round(recs_all, world * offer if collective else T,
+                             float(dist_cutoff))
             if chained:
                 shard.spec_chain_rows(rows_mine)
                 if collective:

@@ -152,17 +152,18 @@ def ar(t, op=dist.ReduceOp.SUM, group=None):
 dist.all_gather_into_tensor, dist.all_reduce = agit, ar
 from enspara_amd import sharded, synth
 from enspara_amd.device import FrameStore
-n, A, K = 6000, 14, 45
-x = synth.synth(n, A, 9, seed=21)
+n, A, K, tmpl, iters, form = [int(v) for v in sys.argv[6:12]]
+x = synth.synth(n, A, tmpl, seed=21)
 lo, cnt = sharded.shard_bounds(n, world, rank)
 torch.cuda.set_device(0)
 ts = torch.cuda.Stream(device=0)
 with FrameStore(cnt, A, device=0, global_offset=lo, stream=ts.cuda_stream) as st:
     st.load(x[lo:lo + cnt])
+    st.set_option(9, form)
     st.reset_state()
     sh = sharded.DeviceShard(st)
     with torch.cuda.stream(ts):
-        med = sharded.khybrid_sharded(sh, K, 0.0, 2, random_state=5)
+        med = sharded.khybrid_sharded(sh, K, 0.0, iters, random_state=5)
     d, a = st.download_state()
 np.savez(out + ".%d.npz" % rank, med=np.array(med), d=d, a=a, lo=lo)
 dist.barrier()
@@ -170,7 +171,15 @@ dist.destroy_process_group()
 """
 
 
-def test_two_device_shards_on_one_gpu(tmp_path):
+@pytest.mark.parametrize("n,A,K,tmpl,iters,form", [
+    (6000, 14, 45, 9, 2, 1),
+    # the shape of BASELINE.json configs[3] as far as one GPU allows: 500 atoms
+    # (the LDS form's candidate tile is 8 x 6000 B = 48 000 B, right at the
+    # 48 KiB boundary), two shards, ~200 centers -- both pass-kernel forms
+    (40000, 500, 200, 300, 0, 1),
+    (40000, 500, 200, 300, 0, 0),
+])
+def test_two_device_shards_on_one_gpu(tmp_path, n, A, K, tmpl, iters, form):
     import socket
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -178,15 +187,16 @@ def test_two_device_shards_on_one_gpu(tmp_path):
     s.close()
     out = str(tmp_path / "r")
     procs = [subprocess.Popen([sys.executable, "-c", _CHILD2, ROOT, str(r), "2",
-                               port, out], stdout=subprocess.PIPE,
+                               port, out, str(n), str(A), str(K), str(tmpl),
+                               str(iters), str(form)], stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT, text=True)
              for r in range(2)]
     logs = [p.communicate(timeout=900)[0] for p in procs]
     for p, log in zip(procs, logs):
         assert p.returncode == 0, log[-4000:]
     parts = [np.load(out + ".%d.npz" % r) for r in range(2)]
-    x = synth.synth(6000, 14, 9, seed=21)
-    inds, wa, wd = _expected(x, 45, 2, 5)
+    x = synth.synth(n, A, tmpl, seed=21)
+    inds, wa, wd = _expected(x, K, iters, 5)
     for p in parts:
         np.testing.assert_array_equal(p["med"], inds)
     np.testing.assert_array_equal(np.concatenate([p["a"] for p in parts]), wa)

@@ -29,7 +29,7 @@ def _worker(rank, world, port, n, A, seed, n_clusters, cutoff, outdir,
             cands=1, chain=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    os.environ["OMP_NUM_THREADS"] = "2"
+    os.environ["OMP_NUM_THREADS"] = "2" if world <= 3 else "1"
     from enspara_amd import sharded, synth
     from _host_shard import HostShard, HostShardRounds, HostShardChain
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port,
@@ -112,6 +112,19 @@ def test_two_ranks_chained_rounds_cutoff():
 def test_three_ranks_one_empty_chained_rounds():
     inds = _run(3, 500, 10, 7, 9, 0.0, cands=4, chain=True)
     assert len(inds) == 9
+
+
+@pytest.mark.parametrize("world,n,K", [
+    (4, 2600, 40),      # 4 x 8 = 32 records on offer per round
+    (8, 4200, 60),      # 8 x 8 = 64: exactly the plan's table
+    (10, 5200, 50),     # more ranks than 64 / 8: every rank offers 6 records
+])
+def test_larger_groups_chained_rounds(world, n, K):
+    """BASELINE.json configs[3] runs 8 ranks; the round protocol with 8
+    candidates per pass there sits at the plan's limit of 64 records on offer,
+    and larger groups offer fewer per rank instead of leaving the protocol."""
+    inds = _run(world, n, 12, 31 + world, K, 0.0, cands=8, chain=True)
+    assert len(inds) == K
 
 
 def test_shard_bounds():
