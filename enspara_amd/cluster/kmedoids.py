@@ -193,6 +193,29 @@ def _open_window(store, lo, hi, proposals, random_state):
     return w
 
 
+# 1: a window's proposals are decided and committed on the device, one
+# read-back per window (FrameStore.pam_window_run); 0: one read-back per
+# proposal.  Same results.
+PAM_DEVICE_DECISIONS = 1
+
+
+def _one_proposal(store, cid, proposals, random_state):
+    """kmedoids.py:597-699 for one cluster, counted and drawn right now.
+    -> (proposed frame, accepted, old cost, new cost, ambiguous members)"""
+    if proposals is None:
+        m = store.pam_count_members(cid)                     # :611
+        # RandomState.choice(state_inds) == state_inds[choice(len)]
+        # (raises ValueError on an empty cluster, like the reference)
+        j = random_state.choice(m)                           # :514
+        prop, old_cost, new_cost, n_amb = store.pam_propose_member(cid, j)
+    else:
+        prop = int(proposals[cid])
+        old_cost, new_cost, n_amb = store.pam_propose(cid, prop)
+    accept = new_cost < old_cost                             # :683
+    store.pam_commit(accept)
+    return prop, accept, old_cost, new_cost, n_amb
+
+
 def _pam_sweep_device(store, medoid_inds, proposals, random_state):
     """One sweep of kmedoids.py:575-699 against device-resident state."""
     random_state = check_random_state(random_state)          # :579
@@ -202,54 +225,93 @@ def _pam_sweep_device(store, medoid_inds, proposals, random_state):
     width = max(1, min(int(PAM_PREFETCH), 8))
     acceptances = 0
     old_cost = new_cost = float("nan")
+
+    def note(cid, accept, oc, nc, n_amb):
+        logger.debug("%s proposed center for k=%s: cost %.5f -> %.5f "
+                     "(%d ambiguous).", "Accepted" if accept else "Rejected",
+                     cid, oc, nc, n_amb)
+
+    cid = 0
     win = None
-    for cid in range(K):
+    while cid < K:
         if width == 1:
-            if proposals is None:
-                m = store.pam_count_members(cid)             # :611
-                # RandomState.choice(state_inds) == state_inds[choice(len)]
-                # (raises ValueError on an empty cluster, like the reference)
-                j = random_state.choice(m)                   # :514
-                prop, old_cost, new_cost, n_amb = \
-                    store.pam_propose_member(cid, j)
-            else:
-                prop = int(proposals[cid])
-                old_cost, new_cost, n_amb = store.pam_propose(cid, prop)
-            moved = 0
+            prop, accept, old_cost, new_cost, n_amb = _one_proposal(
+                store, cid, proposals, random_state)
+            if accept:
+                medoid_inds[cid] = prop
+                acceptances += 1
+            note(cid, accept, old_cost, new_cost, n_amb)
+            cid += 1
+            continue
+        if PAM_DEVICE_DECISIONS:
+            # ---- a window decided on the device ---------------------------------
+            win = _open_window(store, cid, min(K, cid + width), proposals,
+                               random_state)
+            n_slots = len(win.frame)     # short if an empty cluster is in the way
+            n_done = 0
+            if n_slots:
+                n_done, acc, ocs, ncs, nas = store.pam_window_run(
+                    win.lo, win.frame[:n_slots], win.m[:n_slots],
+                    win.hi - win.lo)
+                for s in range(n_done):
+                    if proposals is None:
+                        # the real draws, in order: the member lists are the ones
+                        # the guesses were drawn from, so they are the same draws
+                        j = random_state.choice(win.m[s])    # :514
+                        if j != win.j[s]:
+                            raise RuntimeError("PAM window: draw %d for cluster "
+                                               "%d, guessed %d"
+                                               % (j, win.lo + s, win.j[s]))
+                    if acc[s]:
+                        medoid_inds[win.lo + s] = win.frame[s]
+                        acceptances += 1
+                    old_cost, new_cost = float(ocs[s]), float(ncs[s])
+                    note(win.lo + s, bool(acc[s]), old_cost, new_cost, int(nas[s]))
+            cid = win.lo + n_done
+            if cid < win.hi:
+                # the window stopped here: this cluster's members changed under an
+                # accepted proposal (or it is empty: the draw raises, as the
+                # reference's does) -- counted and drawn now, on its own pass
+                prop, accept, old_cost, new_cost, n_amb = _one_proposal(
+                    store, cid, proposals, random_state)
+                if accept:
+                    medoid_inds[cid] = prop
+                    acceptances += 1
+                note(cid, accept, old_cost, new_cost, n_amb)
+                cid += 1
+            continue
+        # ---- one read-back per proposal ---------------------------------------------
+        if win is None or cid >= win.hi:
+            win = _open_window(store, cid, min(K, cid + width), proposals,
+                               random_state)
+        slot = cid - win.lo
+        exact = not ((win.stale >> slot) & 1)
+        counted = False
+        if exact:
+            m = win.m[slot]
         else:
-            if win is None or cid >= win.hi:
-                win = _open_window(store, cid, min(K, cid + width), proposals,
-                                   random_state)
-            slot = cid - win.lo
-            exact = not ((win.stale >> slot) & 1)
-            counted = False
-            if exact:
-                m = win.m[slot]
-            else:
-                m = store.pam_count_members(cid)             # :611
-                counted = True
-            if proposals is None:
-                j = random_state.choice(m)                   # :514
-                if exact and slot < len(win.j) and j == win.j[slot]:
-                    prop = win.frame[slot]
-                else:
-                    if not counted:
-                        store.pam_count_members(cid)
-                    prop = store.pam_select_member(cid, j)
-            else:
+            m = store.pam_count_members(cid)             # :611
+            counted = True
+        if proposals is None:
+            j = random_state.choice(m)                   # :514
+            if exact and slot < len(win.j) and j == win.j[slot]:
                 prop = win.frame[slot]
-            old_cost, new_cost, n_amb, moved = store.pam_propose_ex(
-                cid, prop, m, win.lo, win.hi - win.lo)
+            else:
+                if not counted:
+                    store.pam_count_members(cid)
+                prop = store.pam_select_member(cid, j)
+        else:
+            prop = win.frame[slot]
+        old_cost, new_cost, n_amb, moved = store.pam_propose_ex(
+            cid, prop, m, win.lo, win.hi - win.lo)
         accept = new_cost < old_cost                         # :683
         store.pam_commit(accept)
         if accept:
             medoid_inds[cid] = prop
             acceptances += 1
-            if win is not None:
-                win.stale |= moved
-        logger.debug("%s proposed center for k=%s: cost %.5f -> %.5f "
-                     "(%d ambiguous).", "Accepted" if accept else "Rejected",
-                     cid, old_cost, new_cost, n_amb)
+            win.stale |= moved
+        note(cid, accept, old_cost, new_cost, n_amb)
+        cid += 1
     logger.info("Kmedoid sweep reduced cost to %.7f (%.2f%% acceptance)",
                 min(old_cost, new_cost),
                 acceptances / len(medoid_inds) * 100)

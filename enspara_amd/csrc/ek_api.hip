@@ -117,6 +117,8 @@ struct ek_ctx {
     bool pf_external = false;        // slots hold caller-supplied centers
     EkPamOut *pam_out_dev = nullptr; // result record of a proposal
     EkPamOut *pam_out_host = nullptr;    // pinned copy the host polls for
+    EkPamWin *pam_win_dev = nullptr;     // a window of proposals decided on the device
+    EkPamWin *pam_win_host = nullptr;    // pinned
     int32_t pam_restore = -1;        // row of the trial table a rejected proposal left
     int32_t *med_list = nullptr;     // [med_cap] medoids within reach (ek_pam_prune_kernel)
     float *dtab = nullptr;           // [EK_MAX_CANDS][med_cap] medoid-to-proposal distances
@@ -294,6 +296,9 @@ static int ek_free_all(ek_ctx *c)
         (void)hipHostFree(c->act_n_host);
     if (c->pam_out_host)
         (void)hipHostFree(c->pam_out_host);
+    (void)hipFree(c->pam_win_dev);
+    if (c->pam_win_host)
+        (void)hipHostFree(c->pam_win_host);
     (void)hipFree(c->recsT);
     (void)hipFree(c->ctile);
     (void)hipFree(c->ctrace);
@@ -1289,6 +1294,9 @@ static int ek_pam_alloc(ek_ctx *c, int32_t K)
         EK_HIP(hipMalloc((void **)&c->pam_out_dev, sizeof(EkPamOut)));
         EK_HIP(hipHostMalloc((void **)&c->pam_out_host, sizeof(EkPamOut),
                              hipHostMallocDefault));
+        EK_HIP(hipMalloc((void **)&c->pam_win_dev, sizeof(EkPamWin)));
+        EK_HIP(hipHostMalloc((void **)&c->pam_win_host, sizeof(EkPamWin),
+                             hipHostMallocDefault));
     }
     c->pam_restore = -1;
     c->pf_backoff = 0;
@@ -1536,12 +1544,10 @@ static int ek_pam_propose_impl(ek_ctx *c, int32_t cid, int64_t frame_index,
     if (rc)
         return rc;
     const float *newd = ek_pam_prefetched(c, frame_index);
-    if (frame_index >= 0) {
-        if (newd)
-            ++c->pf_hits;
-        else
-            ++c->pf_misses;
-    }
+    if (newd)
+        ++c->pf_hits;
+    else
+        ++c->pf_misses;
     const int64_t *idx_dev = c->sel + 1;    // read only when frame_index < 0
     if (!newd) {
         // distances of every frame to the proposed medoid (kmedoids.py:637)
@@ -1877,6 +1883,100 @@ static int ek_pam_prefetch_frames(ek_ctx *c, const int64_t *frames, int32_t coun
         c->pf_frames[j] = frames[j];
     c->pf_count = count;
     c->pf_external = false;
+    return EK_OK;
+}
+
+// A window of proposals without a host round trip each (reference
+// kmedoids.py:575-699 for clusters cid0 .. cid0 + count - 1, in order).  frames[i]
+// is the frame proposed for cluster cid0 + i -- the caller drew it from the
+// member list as it stood when the window was opened -- and n_members[i] that
+// list's length; all of them must have been prefetched (ek_pam_prefetch_window).
+// Every proposal's kernels are enqueued at once; the device decides each
+// (mean of squares, float64, strict <), commits or undoes it, and stops the
+// window at the first cluster whose membership an accepted proposal changed:
+// *n_done slots were decided, the caller handles slot *n_done one at a time
+// (its member list has to be counted again) and opens a new window after it.
+extern "C" int ek_pam_window_run(ek_ctx *c, int32_t cid0, int32_t count,
+                                 const int64_t *frames, const int64_t *n_members,
+                                 int32_t win_lo, int32_t win_count,
+                                 int32_t *n_done, int32_t *accept,
+                                 double *old_cost, double *new_cost,
+                                 int64_t *n_ambiguous)
+{
+    int rc = ek_pam_precheck(c, cid0, "ek_pam_window_run");
+    if (rc)
+        return rc;
+    if (count < 1 || count > EK_MAX_CANDS || cid0 + count > c->med_K || !frames ||
+        !n_members || !n_done || !accept)
+        return ek_fail(EK_EARG, "ek_pam_window_run: bad window [%d,+%d)", cid0,
+                       count);
+    // bit i of a proposal's moved-cluster mask is cluster win_lo + i, and the
+    // device reads it as slot i of this run
+    if (win_lo != cid0 || win_count < count || win_count > 32)
+        return ek_fail(EK_EARG, "ek_pam_window_run: the stale-mask window "
+                                "[%d,+%d) must start at cid0 = %d and cover the "
+                                "%d slots", win_lo, win_count, cid0, count);
+    EK_HIP(hipSetDevice(c->device));
+    int64_t max_m = 0;
+    const float *newd[EK_MAX_CANDS];
+    for (int32_t i = 0; i < count; ++i) {
+        if (frames[i] < 0 || frames[i] >= c->n || n_members[i] < 0 ||
+            n_members[i] > c->n)
+            return ek_fail(EK_EARG, "ek_pam_window_run: slot %d: frame %lld, %lld "
+                                    "members", i, (long long)frames[i],
+                           (long long)n_members[i]);
+        newd[i] = ek_pam_prefetched(c, frames[i]);
+        if (!newd[i])
+            return ek_fail(EK_ESTATE, "ek_pam_window_run: frame %lld was not "
+                                      "prefetched", (long long)frames[i]);
+        max_m = std::max(max_m, n_members[i]);
+    }
+    rc = ek_pam_amb_room(c, max_m);      // may synchronise: before anything is enqueued
+    if (rc)
+        return rc;
+    EkPamWin w0;
+    memset(&w0, 0, sizeof(w0));
+    w0.stop = count;
+    EK_HIP(hipMemcpyAsync(c->pam_win_dev, &w0, sizeof(w0), hipMemcpyHostToDevice,
+                          c->stream));
+    const int K = c->med_K;
+    for (int32_t i = 0; i < count; ++i) {
+        const int32_t cid = cid0 + i;
+        ek_launch_pam_trial(c->tiles, c->G, c->A, c->med_aos, c->med_G, K, cid,
+                            c->pam_restore, frames[i], nullptr, nullptr, nullptr,
+                            c->amb_count, c->moved, c->stream);
+        c->pam_restore = -1;
+        rc = ek_pam_tail(c, cid, newd[i], n_members[i], win_lo, win_count,
+                         &c->pam_win_dev->out[i]);
+        if (rc)
+            return rc;
+        ek_launch_pam_decide(c->pam_win_dev, i, (double)c->n, c->dist, c->ndist,
+                             c->assign, c->nassign, c->n, c->med_aos, c->med_G, c->A,
+                             K, cid, c->med_idx, frames[i], n_members[i], c->stream);
+        EK_CHECK_LAUNCH();
+        ++c->pf_hits;
+    }
+    EK_HIP(hipMemcpyAsync(c->pam_win_host, c->pam_win_dev, sizeof(EkPamWin),
+                          hipMemcpyDeviceToHost, c->stream));
+    EK_HIP(ek_wait(c));
+    const EkPamWin &w = *c->pam_win_host;
+    c->pam_cid = -1;
+    c->cnt_cid = -1;
+    c->pf_hits -= count - w.stop;       // the slots past the stop were not served
+    if (w.err)
+        return ek_fail(EK_EARG, "PAM proposal: cluster %d has more members that "
+                                "stay put than the %lld members declared",
+                       cid0 + w.err - 1, (long long)n_members[w.err - 1]);
+    *n_done = w.stop;
+    for (int32_t i = 0; i < count; ++i) {
+        accept[i] = i < w.stop ? w.accept[i] : 0;
+        if (old_cost)
+            old_cost[i] = w.out[i].sum_old / (double)c->n;
+        if (new_cost)
+            new_cost[i] = w.out[i].sum_new / (double)c->n;
+        if (n_ambiguous)
+            n_ambiguous[i] = w.out[i].n_amb;
+    }
     return EK_OK;
 }
 

@@ -253,6 +253,20 @@ struct EkPamOut {
     uint32_t moved;      // bit i: membership of cluster win_lo + i would change
 };
 static_assert(sizeof(EkPamOut) == 32, "EkPamOut layout");
+// a window of proposals decided on the device (ek_pam_window_run)
+struct EkPamWin {
+    int32_t stop;       // slots [0, stop) were decided
+    uint32_t stale;     // clusters of the window whose membership changed
+    int32_t err;        // 1 + slot of a proposal with more ambiguous members than declared
+    int32_t pad;
+    int32_t accept[EK_MAX_CANDS];
+    EkPamOut out[EK_MAX_CANDS];
+};
+void ek_launch_pam_decide(EkPamWin *win, int slot, double n_total, float *dist,
+                          const float *ndist, int32_t *assign,
+                          const int32_t *nassign, int64_t n, float *aos,
+                          double *Gm, int A, int K, int cid, int64_t *med_idx,
+                          int64_t frame, int64_t max_amb, hipStream_t s);
 // active-set proposal prefetch (ek_pam.hip)
 void ek_launch_pam_dtab(const float *aos, const double *Gm, int A, int K, int held,
                         const unsigned char *recs, int count, float *Dtab,

@@ -9,6 +9,7 @@
 //   cost = mean(dist^2) old vs new                    :478, :680-681 -> sumsq
 // The host keeps only the RNG and the accept/reject decision.
 #include "ek_common.h"
+#include <algorithm>
 #include "ek_qcp.h"
 
 // ---- medoid table: centred coordinates of chosen frames, center-major --------
@@ -1081,4 +1082,78 @@ void ek_launch_scatter_vecs(const uint32_t *list, int64_t count,
                        dim3((unsigned)((count + EK_BLOCK - 1) / EK_BLOCK)),
                        dim3(EK_BLOCK), 0, s, list, count, cvecs, cpad, nvec, vecs,
                        n_pad);
+}
+
+// ---------------------------------------------------------------------------
+// a window of proposals decided on the device (ek_pam_window_run)
+// ---------------------------------------------------------------------------
+// After a proposal's trial state (ndist / nassign) and cost sums are in place:
+// accept iff mean(new^2) < mean(old^2), both in float64 (kmedoids.py:478-479,
+// :683) -- the same two divisions and comparison the host made -- and
+//   accepted: the trial state becomes the state (kmedoids.py:684-690), the
+//             cluster's medoid index is the proposed frame, the clusters of the
+//             window whose membership changes are marked stale; the first stale
+//             cluster after this one is where the window stops: its proposal was
+//             drawn from a member list that no longer holds (kmedoids.py:611-614),
+//   rejected (or past the stop): the medoid table gets its row back.
+// A slot past the stop still runs its kernels -- they only write scratch -- but
+// nothing of it is kept.
+__global__ void __launch_bounds__(EK_BLOCK)
+ek_pam_decide_kernel(EkPamWin *__restrict__ win, int slot, double n_total,
+                     float *__restrict__ dist, const float *__restrict__ ndist,
+                     int32_t *__restrict__ assign,
+                     const int32_t *__restrict__ nassign, int64_t n,
+                     float *__restrict__ aos, double *__restrict__ Gm, int A, int K,
+                     int cid, int64_t *__restrict__ med_idx, int64_t frame,
+                     int64_t max_amb)
+{
+    const bool live = slot < win->stop;
+    const EkPamOut o = win->out[slot];
+    const double old_cost = o.sum_old / n_total, new_cost = o.sum_new / n_total;
+    const bool accept = live && new_cost < old_cost;
+    const int64_t f = (int64_t)blockIdx.x * EK_BLOCK + threadIdx.x;
+    if (accept && f < n) {
+        dist[f] = ndist[f];
+        assign[f] = nassign[f];
+    }
+    if (blockIdx.x != 0)
+        return;
+    if (!accept) {              // the proposal's row of the medoid table: undone
+        for (int r = threadIdx.x; r < 3 * A; r += EK_BLOCK)
+            aos[(size_t)cid * 3 * A + r] = aos[(size_t)K * 3 * A + r];
+    }
+    if (threadIdx.x == 0) {
+        if (!accept)
+            Gm[cid] = Gm[K];
+        if (live) {
+            win->accept[slot] = accept ? 1 : 0;
+            if ((int64_t)o.n_amb > max_amb)
+                win->err = 1 + slot;
+            if (accept) {
+                if (med_idx)
+                    med_idx[cid] = frame;
+                const uint32_t stale = win->stale | o.moved;
+                win->stale = stale;
+                const uint32_t later = (slot >= 31) ? 0u : (stale >> (slot + 1));
+                if (later) {
+                    const int first = slot + 1 + (__ffs((int)later) - 1);
+                    if (first < win->stop)
+                        win->stop = first;
+                }
+            }
+        }
+    }
+}
+
+void ek_launch_pam_decide(EkPamWin *win, int slot, double n_total, float *dist,
+                          const float *ndist, int32_t *assign,
+                          const int32_t *nassign, int64_t n, float *aos,
+                          double *Gm, int A, int K, int cid, int64_t *med_idx,
+                          int64_t frame, int64_t max_amb, hipStream_t s)
+{
+    const unsigned blocks = (unsigned)std::max<int64_t>(1, (n + EK_BLOCK - 1) /
+                                                               EK_BLOCK);
+    hipLaunchKernelGGL(ek_pam_decide_kernel, dim3(blocks), dim3(EK_BLOCK), 0, s,
+                       win, slot, n_total, dist, ndist, assign, nassign, n, aos,
+                       Gm, A, K, cid, med_idx, frame, max_amb);
 }

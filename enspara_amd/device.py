@@ -238,6 +238,25 @@ class FrameStore:
             C.byref(mask)))
         return oc.value, nc.value, na.value, mask.value
 
+    def pam_window_run(self, cid0, frames, n_members, win_count):
+        """The proposals frames[i] for clusters cid0 + i (all prefetched),
+        decided and committed on the device in order; stops at the first cluster
+        whose membership an accepted proposal changed.
+        -> (n_done, accept[int], old costs, new costs, ambiguous counts)"""
+        f = np.ascontiguousarray(frames, dtype=np.int64)
+        m = np.ascontiguousarray(n_members, dtype=np.int64)
+        k = len(f)
+        nd = C.c_int32()
+        acc = np.zeros(k, dtype=np.int32)
+        oc = np.zeros(k, dtype=np.float64)
+        nc = np.zeros(k, dtype=np.float64)
+        na = np.zeros(k, dtype=np.int64)
+        _lib.check(self.lib.ek_pam_window_run(
+            self._h, int(cid0), k, _lib.i64p(f), _lib.i64p(m), int(cid0),
+            int(win_count), C.byref(nd), _lib.i32p(acc), _lib.f64p(oc),
+            _lib.f64p(nc), _lib.i64p(na)))
+        return nd.value, acc, oc, nc, na
+
     # -- PAM across shards (device pointers are plain ints) ----------------------
     def centered_frames(self, local_frames, rows, aos_ptr, G_ptr):
         """rows[i] of the device arrays at aos_ptr ([.., 3A] float32) / G_ptr

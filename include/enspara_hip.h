@@ -289,6 +289,25 @@ int ek_pam_propose_ex(ek_ctx *ctx, int32_t cid, int64_t frame_index,
                       double *old_cost, double *new_cost, int64_t *n_ambiguous,
                       uint32_t *moved_mask);
 int ek_pam_prefetch_stats(ek_ctx *ctx, int64_t *hits, int64_t *misses);
+/* A window of proposals without a host round trip each: the loop body of
+ * kmedoids.py:597-699 for clusters cid0 .. cid0 + count - 1 (count <= 8), in
+ * order.  frames[i] is the frame proposed for cluster cid0 + i, drawn by the
+ * caller from that cluster's member list as it stood when the window was
+ * opened, n_members[i] that list's length; every frames[i] must have been
+ * prefetched with ek_pam_prefetch_window(ctx, frames, count, cid0, win_count).
+ * All kernels are enqueued at once.  The device takes each decision --
+ * mean(new^2) < mean(old^2) in float64, kmedoids.py:478-479, :683 --, commits
+ * (:684-690) or undoes the proposal, and STOPS the window at the first cluster
+ * whose member list an accepted proposal changed (its proposal was drawn from a
+ * list that no longer holds, :611-614).  *n_done slots were decided; the caller
+ * handles cluster cid0 + *n_done one proposal at a time and opens a new window
+ * after it.  accept[i] (i < *n_done): 1 if proposal i was accepted; the costs
+ * and ambiguous-member counts are returned for logging. */
+int ek_pam_window_run(ek_ctx *ctx, int32_t cid0, int32_t count,
+                      const int64_t *frames, const int64_t *n_members,
+                      int32_t win_lo, int32_t win_count, int32_t *n_done,
+                      int32_t *accept, double *old_cost, double *new_cost,
+                      int64_t *n_ambiguous);
 
 /* PAM when the frames are sharded over several contexts (one per GPU; the
  * reference's MPI branch of kmedoids.py:575-699 with mpi/ops.py:143-212).  A
