@@ -30,7 +30,7 @@ SYMBOLS = [
     "ek_spec_candidates", "ek_spec_begin", "ek_spec_round", "ek_spec_localmax",
     "ek_spec_apply", "ek_spec_round_end", "ek_spec_progress", "ek_spec_rounds",
     "ek_spec_chain_bytes", "ek_spec_chain_rows", "ek_spec_chain_max",
-    "ek_spec_chain_apply", "ek_run_stats",
+    "ek_spec_chain_apply", "ek_run_stats", "ek_ti_stats",
     "ek_assign_nearest",
     "ek_pam_begin", "ek_pam_count_members", "ek_pam_select_member",
     "ek_pam_propose", "ek_pam_propose_member", "ek_pam_commit",
@@ -118,6 +118,7 @@ def load():
     L.ek_spec_progress.argtypes = [vp, i32p, i32p]
     L.ek_spec_rounds.argtypes = [vp, i32p]
     L.ek_run_stats.argtypes = [vp, i64p, i64p]
+    L.ek_ti_stats.argtypes = [vp, i64p, i64p]
     L.ek_assign_nearest.argtypes = [vp, f32p, i32]
     f64p = C.POINTER(C.c_double)
     L.ek_pam_begin.argtypes = [vp, i64p, i32]

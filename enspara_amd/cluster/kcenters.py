@@ -109,7 +109,8 @@ def kcenters(traj, distance_method, n_clusters=np.inf, dist_cutoff=0,
 
     if util.is_device_rmsd(distance_method):
         return _kcenters_device(traj, n_clusters, dist_cutoff, init_centers,
-                                device)
+                                device,
+                                use_triangle_inequality=use_triangle_inequality)
     return _kcenters_host(traj, distance_method, n_clusters, dist_cutoff,
                           init_centers, use_triangle_inequality)
 
@@ -123,12 +124,18 @@ def _frame_of(traj, i):
 
 
 def _kcenters_device(traj, n_clusters, dist_cutoff, init_centers, device,
-                     store=None):
+                     store=None, use_triangle_inequality=False):
+    """``use_triangle_inequality`` (reference kcenters.py:287-296; like there,
+    reachable from this function only, never set by KCenters.fit): one center
+    per pass, and the tiles of 256 frames none of whose frames can come closer
+    to the new center than to their own are not read.  Same result; pays when
+    neighbouring frames share a cluster (trajectories in time order)."""
     xyz = as_xyz(traj) if store is None else None
     own = store is None
     if own:
         store = FrameStore.from_array(xyz, device=device)
     try:
+        store.set_option(11, 1 if use_triangle_inequality else 0)
         n = store.n
         if n == 0:
             raise ValueError("cannot cluster an empty trajectory")

@@ -146,6 +146,12 @@ struct ek_ctx {
     float *planD = nullptr;          // [64][64] distances between the records on offer
     int pass_form = EK_PASS_FORM_DEFAULT;  // 0: candidates through LDS, 1: as scalar operands
     int fused = 1;               // single-shard rounds in three launches (ek_round.hip)
+    int tri = 0;                 // triangle-inequality tile skip (one-center steps)
+    float *ti_D = nullptr;       // [ti_cap] distances of the existing centers to the new one
+    int32_t ti_cap = 0;
+    uint8_t *ti_skip = nullptr;  // [n_tiles]
+    unsigned long long *ti_stats = nullptr;  // [2] tiles looked at, skipped
+    int64_t ti_tiles = 0, ti_skipped = 0;    // of the last run
     EkPend *pend = nullptr;      // accepted chain not yet applied
     EkChainOrd *ord = nullptr;
     EkChainRow *rows = nullptr;      // [EK_MAX_CANDS] candidate frames' rows
@@ -302,6 +308,9 @@ static int ek_free_all(ek_ctx *c)
     (void)hipFree(c->recsT);
     (void)hipFree(c->ctile);
     (void)hipFree(c->ctrace);
+    (void)hipFree(c->ti_D);
+    (void)hipFree(c->ti_skip);
+    (void)hipFree(c->ti_stats);
     (void)hipFree(c->pend);
     (void)hipFree(c->ord);
     (void)hipFree(c->tick);
@@ -493,6 +502,11 @@ extern "C" int ek_set_option(ek_ctx *c, int32_t key, int32_t value)
         if (value != 0 && value != 1)
             return ek_fail(EK_EARG, "ek_set_option: state-is-exact flag 0 or 1");
         c->state_exact = value != 0;
+        return EK_OK;
+    case 11:
+        if (value != 0 && value != 1)
+            return ek_fail(EK_EARG, "ek_set_option: triangle inequality 0 or 1");
+        c->tri = value;
         return EK_OK;
     case 10:
         if (value != 0 && value != 1)
@@ -845,11 +859,35 @@ static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
         c->st_rounds[m] = c->st_centers[m] = 0;
     const int nb = (int)((c->n + EK_BLOCK - 1) / EK_BLOCK);
     const int wide = Tmax == 8 ? 2 : 1;     // index into st_* of the wide form
+    // Triangle inequality (option key 11; reference `use_triangle_inequality`,
+    // kcenters.py:287-296): one center at a time, tiles that cannot change are
+    // not read.  Needs every frame's distance to be the one to the center its
+    // label names (a fresh run) and distances that behave like a metric.
+    const bool tri = c->tri && c->state_exact && first_label == 0 && c->A >= 3;
+    if (tri) {
+        if (first_label + max_new > c->ti_cap) {
+            EK_HIP(ek_wait(c));
+            (void)hipFree(c->ti_D);
+            c->ti_D = nullptr;
+            c->ti_cap = 0;
+            EK_HIP(hipMalloc((void **)&c->ti_D,
+                             (size_t)(first_label + max_new + 1) * sizeof(float)));
+            c->ti_cap = first_label + max_new + 1;
+        }
+        if (!c->ti_skip) {
+            EK_HIP(hipMalloc((void **)&c->ti_skip,
+                             (size_t)std::max<int64_t>(c->n_tiles, 1)));
+            EK_HIP(hipMalloc((void **)&c->ti_stats, 2 * sizeof(unsigned long long)));
+        }
+        EK_HIP(hipMemsetAsync(c->ti_stats, 0, 2 * sizeof(unsigned long long),
+                              c->stream));
+    }
+    c->ti_tiles = c->ti_skipped = 0;
     // an explicit request (option key 4 = 4 or 8) pins the wide form
-    const bool adaptive = c->cands == -1 && c->adapt;
+    const bool adaptive = c->cands == -1 && c->adapt && !tri;
     const int fpl = ek_pick_fpl(c);
     const int nt = ek_pick_nt(c);
-    bool one = adaptive;        // current form: one-center steps / wide rounds
+    bool one = adaptive || tri; // current form: one-center steps / wide rounds
     int held = -1;              // form the candidate record(s) were picked for
     bool probing = false;
     double rate_home = 0.0;     // centers per ms of the form being run
@@ -933,10 +971,16 @@ static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
         EK_HIP(hipEventRecord(c->evb0, c->stream));
         for (int32_t r = 0; r < batch; ++r) {
             if (one) {
+                const int label = cr.n_done + r;
+                const bool skip = tri && label >= 1;
+                if (skip)
+                    ek_launch_ti(c->aos, c->G, c->A, c->hist, label, c->goff,
+                                 c->recsT, c->ti_D, c->dist, c->assign, c->n,
+                                 c->ctl, c->ti_skip, c->ti_stats, c->stream);
                 ek_launch_step(fpl, 0, nt, c->tiles, c->G, c->dist, c->assign,
-                               c->scratch, c->recsT, 1, c->n, c->A,
-                               cr.n_done + r, dist_cutoff, c->blockmax, c->hist,
-                               c->ctl, c->stream);
+                               c->scratch, c->recsT, 1, c->n, c->A, label,
+                               dist_cutoff, c->blockmax, c->hist, c->ctl, c->stream,
+                               skip ? c->ti_skip : nullptr);
                 ek_launch_pick(c->blockmax, ek_step_blocks(fpl, c->n), c->dist,
                                c->tiles, c->G, c->n, c->A, c->goff, c->recsT,
                                c->ctl, c->stream);
@@ -1046,6 +1090,14 @@ static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
     if (pending) {              // the last round's accepted chain
         ek_launch_round_flush(R, c->stream);
         EK_CHECK_LAUNCH();
+    }
+    if (tri) {
+        unsigned long long st[2] = {0, 0};
+        EK_HIP(hipMemcpyAsync(st, c->ti_stats, sizeof(st), hipMemcpyDeviceToHost,
+                              c->stream));
+        EK_HIP(ek_wait(c));
+        c->ti_tiles = (int64_t)st[0];
+        c->ti_skipped = (int64_t)st[1];
     }
     EK_HIP(hipEventRecord(c->ev1, c->stream));
     EK_HIP(ek_wait(c));
@@ -2313,6 +2365,15 @@ extern "C" int ek_spec_rounds(ek_ctx *c, int32_t *rounds)
                           c->stream));
     EK_HIP(ek_wait(c));
     *rounds = r.n_rounds;
+    return EK_OK;
+}
+
+extern "C" int ek_ti_stats(ek_ctx *c, int64_t *tiles, int64_t *skipped)
+{
+    if (!c || !tiles || !skipped)
+        return ek_fail(EK_EARG, "ek_ti_stats: NULL argument");
+    *tiles = c->ti_tiles;
+    *skipped = c->ti_skipped;
     return EK_OK;
 }
 

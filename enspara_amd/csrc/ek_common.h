@@ -169,7 +169,16 @@ void ek_launch_step(int fpl, int mode, int nt, const float *tiles,
                     float *dist, int32_t *assign, float *out_dist,
                     const unsigned char *recs, int n_recs, int64_t n, int A,
                     int label, double cutoff, EkBlockMax *blockmax,
-                    EkHist *hist, EkCtl *ctl, hipStream_t s);
+                    EkHist *hist, EkCtl *ctl, hipStream_t s,
+                    const uint8_t *tile_skip = nullptr);
+// triangle inequality for the one-center step: distances of the k existing
+// centers (hist[0..k)) to the new one (rec) -> Dnew[k]; tile_skip[t] = 1 for the
+// tiles no frame of which can move; stats[0] += tiles looked at, [1] += skipped
+void ek_launch_ti(const float *aos, const double *G, int A, const EkHist *hist,
+                  int k, int64_t goff, const unsigned char *rec, float *Dnew,
+                  const float *dist, const int32_t *assign, int64_t n,
+                  const EkCtl *ctl, uint8_t *tile_skip, unsigned long long *stats,
+                  hipStream_t s);
 int ek_step_blocks(int fpl, int64_t n);
 
 // reduce block partials (or, if blockmax == nullptr, the dist array itself)

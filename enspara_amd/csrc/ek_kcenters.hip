@@ -67,7 +67,7 @@ ek_step_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
                const unsigned char *__restrict__ recs, int n_recs, int64_t n,
                int A, int label, double cutoff,
                EkBlockMax *__restrict__ blockmax, EkHist *__restrict__ hist,
-               EkCtl *__restrict__ ctl)
+               EkCtl *__restrict__ ctl, const uint8_t *__restrict__ tile_skip)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *ctr = lds;                       // 3A floats, padded to 4 atoms
@@ -125,7 +125,22 @@ ek_step_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
     float bestv = -__builtin_inff();
     uint32_t besti = 0xffffffffu;
 
-    if (fw < n) {
+    // triangle inequality (kcenters.py:287-296, ek_ti_* below): no frame of this
+    // tile can come closer to the new center than it is to its own, so its
+    // coordinates are not read; the farthest point of the slice is still needed
+    if (MODE == 0 && tile_skip && fw < n && tile_skip[fw / EK_TILE]) {
+#pragma unroll
+        for (int q = 0; q < FPL; ++q) {
+            const int64_t f = f0 + q;
+            if (f < n) {
+                const float cur = dist[f];
+                if (ek_better(cur, (uint32_t)f, bestv, besti)) {
+                    bestv = cur;
+                    besti = (uint32_t)f;
+                }
+            }
+        }
+    } else if (fw < n) {
         const int64_t tile = fw / EK_TILE;
         const int in_tile = (int)(fw % EK_TILE) + lane * FPL;
         const float *p = tiles + (size_t)tile * 3 * (size_t)A * EK_TILE + in_tile;
@@ -261,7 +276,7 @@ static void ek_launch_step_t(const float *tiles, const double *G, float *dist,
                              const unsigned char *recs, int n_recs, int64_t n,
                              int A, int label, double cutoff,
                              EkBlockMax *blockmax, EkHist *hist, EkCtl *ctl,
-                             hipStream_t s)
+                             const uint8_t *tile_skip, hipStream_t s)
 {
     const int blocks = ek_step_blocks(FPL, n);
     if (blocks <= 0)
@@ -270,25 +285,26 @@ static void ek_launch_step_t(const float *tiles, const double *G, float *dist,
     hipLaunchKernelGGL((ek_step_kernel<FPL, MODE, NT>), dim3(blocks),
                        dim3(EK_BLOCK), lds, s, tiles, G, dist, assign,
                        out_dist, recs, n_recs, n, A, label, cutoff, blockmax,
-                       hist, ctl);
+                       hist, ctl, tile_skip);
 }
 
 void ek_launch_step(int fpl, int mode, int nt, const float *tiles, const double *G,
                     float *dist, int32_t *assign, float *out_dist,
                     const unsigned char *recs, int n_recs, int64_t n, int A,
                     int label, double cutoff, EkBlockMax *blockmax,
-                    EkHist *hist, EkCtl *ctl, hipStream_t s)
+                    EkHist *hist, EkCtl *ctl, hipStream_t s,
+                    const uint8_t *tile_skip)
 {
 #define EK_GO(F, M)                                                            \
     do {                                                                       \
         if (nt)                                                                \
             ek_launch_step_t<F, M, true>(tiles, G, dist, assign, out_dist,     \
                                          recs, n_recs, n, A, label, cutoff,    \
-                                         blockmax, hist, ctl, s);              \
+                                         blockmax, hist, ctl, tile_skip, s);   \
         else                                                                   \
             ek_launch_step_t<F, M, false>(tiles, G, dist, assign, out_dist,    \
                                           recs, n_recs, n, A, label, cutoff,   \
-                                          blockmax, hist, ctl, s);             \
+                                          blockmax, hist, ctl, tile_skip, s);  \
     } while (0)
     if (mode == 0) {
         if (fpl == 4) EK_GO(4, 0);
@@ -476,4 +492,99 @@ void ek_launch_fill_state(float *dist, int32_t *assign, int64_t n, float d,
     const int64_t blocks = (n + EK_BLOCK - 1) / EK_BLOCK;
     hipLaunchKernelGGL(ek_fill_state_kernel, dim3((unsigned)blocks),
                        dim3(EK_BLOCK), 0, s, dist, assign, n, d, a);
+}
+
+// ---------------------------------------------------------------------------
+// triangle inequality for the one-center step (reference kcenters.py:287-296:
+// `use_triangle_inequality`): a frame whose own center is at least twice its
+// distance away from the new center cannot come closer to the new center than
+// it is to its own, so its distance need not be computed.  On the device the
+// unit that can be left out is a tile of 256 frames (its 3 A KiB of coordinates
+// are then not read): ek_ti_center_kernel gives the distance of every existing
+// center to the new one, ek_ti_tiles_kernel marks the tiles all of whose frames
+// pass the test.  Minimal RMSD is a metric; the computed values carry rounding
+// error, so the test keeps a margin (0.1 % + 1e-3) far above it -- a tile that
+// is not skipped is simply computed, results never depend on the marks.
+// ---------------------------------------------------------------------------
+// one wave per existing center (its summation order is free: the value is only
+// compared, with a margin)
+__global__ void __launch_bounds__(EK_BLOCK)
+ek_ti_center_kernel(const float *__restrict__ aos, const double *__restrict__ G,
+                    int A, const EkHist *__restrict__ hist, int k, int64_t goff,
+                    const unsigned char *__restrict__ rec,
+                    float *__restrict__ Dnew)
+{
+    const int lane = threadIdx.x & (EK_WAVE - 1);
+    const int l = blockIdx.x * (EK_BLOCK / EK_WAVE) + threadIdx.x / EK_WAVE;
+    if (l >= k)
+        return;
+    const int64_t f = hist[l].gidx - goff;
+    const float *x = aos + (size_t)f * 3 * A;
+    const float *y = (const float *)(rec + sizeof(EkRecHdr));
+    float S[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int a = lane; a < A; a += EK_WAVE) {
+        const float x0 = x[3 * a], x1 = x[3 * a + 1], x2 = x[3 * a + 2];
+        const float y0 = y[3 * a], y1 = y[3 * a + 1], y2 = y[3 * a + 2];
+        S[0] += x0 * y0; S[1] += x0 * y1; S[2] += x0 * y2;
+        S[3] += x1 * y0; S[4] += x1 * y1; S[5] += x1 * y2;
+        S[6] += x2 * y0; S[7] += x2 * y1; S[8] += x2 * y2;
+    }
+#pragma unroll
+    for (int q = 0; q < 9; ++q)
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1)
+            S[q] += __shfl_xor(S[q], off, 64);
+    if (lane == 0)
+        Dnew[l] = ek_rmsd_from_S(S, G[f], ((const EkRecHdr *)rec)->trace, A);
+}
+
+// tile t is skipped iff every frame f of it has a center (label >= 0) with
+// Dnew[label] >= 2 dist[f] (1 + 1e-3) + 1e-3;  stats[0] += tiles, [1] += skipped
+__global__ void __launch_bounds__(EK_BLOCK)
+ek_ti_tiles_kernel(const float *__restrict__ dist,
+                   const int32_t *__restrict__ assign, int64_t n, int k,
+                   const float *__restrict__ Dnew,
+                   const EkCtl *__restrict__ ctl, uint8_t *__restrict__ tile_skip,
+                   unsigned long long *__restrict__ stats)
+{
+    __shared__ int any_needed;
+    if (threadIdx.x == 0)
+        any_needed = 0;
+    __syncthreads();
+    const int64_t f = (int64_t)blockIdx.x * EK_BLOCK + threadIdx.x;
+    bool need = false;
+    if (f < n) {
+        const int32_t a = assign[f];
+        need = a < 0 || a >= k ||
+               !(Dnew[a] >= 2.0f * dist[f] * 1.001f + 1e-3f);
+    }
+    if (need)
+        any_needed = 1;         // benign race: everybody writes 1
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const bool live = !ctl->stopped;
+        tile_skip[blockIdx.x] = (live && !any_needed) ? 1 : 0;
+        if (live) {
+            atomicAdd(&stats[0], 1ull);
+            if (!any_needed)
+                atomicAdd(&stats[1], 1ull);
+        }
+    }
+}
+
+void ek_launch_ti(const float *aos, const double *G, int A, const EkHist *hist,
+                  int k, int64_t goff, const unsigned char *rec, float *Dnew,
+                  const float *dist, const int32_t *assign, int64_t n,
+                  const EkCtl *ctl, uint8_t *tile_skip, unsigned long long *stats,
+                  hipStream_t s)
+{
+    if (n <= 0 || k <= 0)
+        return;
+    const int per = EK_BLOCK / EK_WAVE;
+    hipLaunchKernelGGL(ek_ti_center_kernel, dim3((k + per - 1) / per),
+                       dim3(EK_BLOCK), 0, s, aos, G, A, hist, k, goff, rec, Dnew);
+    hipLaunchKernelGGL(ek_ti_tiles_kernel,
+                       dim3((unsigned)((n + EK_BLOCK - 1) / EK_BLOCK)),
+                       dim3(EK_BLOCK), 0, s, dist, assign, n, k, Dnew, ctl,
+                       tile_skip, stats);
 }

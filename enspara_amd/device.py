@@ -377,6 +377,13 @@ class FrameStore:
         return {1: (int(p[0]), int(k[0])), 4: (int(p[1]), int(k[1])),
                 8: (int(p[2]), int(k[2]))}
 
+    def ti_stats(self):
+        """Triangle inequality (set_option(11, 1)): (center, tile) pairs the last
+        kcenters_run looked at, and how many it did not have to read."""
+        t, k = C.c_int64(), C.c_int64()
+        _lib.check(self.lib.ek_ti_stats(self._h, C.byref(t), C.byref(k)))
+        return t.value, k.value
+
     def history(self, first, count):
         idx = np.empty(max(count, 1), dtype=np.int64)
         cd = np.empty(max(count, 1), dtype=np.float32)

@@ -194,6 +194,12 @@ int ek_spec_rounds(ek_ctx *ctx, int32_t *rounds);
  * three forms give identical centers, labels and distances, and the run moves
  * between them by the centers per millisecond each achieves. */
 int ek_run_stats(ek_ctx *ctx, int64_t *passes, int64_t *centers);
+/* Triangle inequality (ek_set_option key 11; the reference's
+ * `use_triangle_inequality`, kcenters.py:287-296 / :351-364): how many
+ * (center, tile of 256 frames) pairs the last ek_kcenters_run looked at and
+ * how many of them it did not have to read because no frame of the tile could
+ * come closer to the new center than it is to its own. */
+int ek_ti_stats(ek_ctx *ctx, int64_t *tiles, int64_t *skipped);
 
 /* history written by ek_kcenters_step: for labels [first, first+count) the
  * global frame index and pre-update distance of each accepted center;
@@ -438,6 +444,12 @@ int ek_set_frames_per_lane(ek_ctx *ctx, int fpl);
  * key 8: with key 4 = -1, let ek_kcenters_run move between 1, 4 and 8
  * candidates per pass by measured centers per millisecond: 1 (default) / 0
  * (always the widest form); identical results either way
+ * key 11: triangle inequality in ek_kcenters_run (0 default / 1): one center
+ * per pass; before each, the distances of the existing centers to the new one
+ * mark the tiles of 256 frames none of whose frames can move (own center at
+ * least twice the frame's distance away, with a margin), and those tiles'
+ * coordinates are not read.  Used only from a fresh state (ek_state_reset) and
+ * for >= 3 atoms; identical results
  * key 10: ek_kcenters_run's rounds in three launches (the single-workgroup
  * steps ride at the end of the launch that produces their input): 1 (default)
  * / 0 (one launch per step); identical results

@@ -261,3 +261,36 @@ def test_tiny_and_exhaustive_runs(ocl, n, A, k):
     assert list(r.center_indices) == [int(i) for i in inds]
     np.testing.assert_array_equal(r.assignments, a)
     np.testing.assert_array_equal(r.distances, d)
+
+
+def test_triangle_inequality_is_invisible(ocl):
+    """reference test_cluster.py:710-770: kcenters(use_triangle_inequality=True)
+    gives what the plain run gives.  Frames in blocks of one template each (a
+    trajectory in time order): most tiles are skipped once the templates have
+    centers; shuffled frames: hardly any -- same centers, labels, distances."""
+    from enspara_amd.cluster.kcenters import kcenters
+    from enspara_amd.device import FrameStore
+    rng = np.random.RandomState(3)
+    A, T, per = 40, 24, 512
+    tmpl = synth.templates(T, A, 9)
+    x = np.concatenate([tmpl[t] + rng.normal(scale=0.05, size=(per, A, 3))
+                        for t in range(T)]).astype(np.float32)
+    for order in (np.arange(len(x)), rng.permutation(len(x))):
+        xx = np.ascontiguousarray(x[order])
+        for kw in (dict(n_clusters=60), dict(n_clusters=np.inf, dist_cutoff=0.35)):
+            plain = kcenters(xx, "rmsd", **kw)
+            ti = kcenters(xx, "rmsd", use_triangle_inequality=True, **kw)
+            want = ocl.kcenters(xx, n_clusters=kw.get("n_clusters"),
+                                dist_cutoff=kw.get("dist_cutoff"))
+            for r in (plain, ti):
+                assert list(r.center_indices) == [int(i) for i in want[0]]
+                np.testing.assert_array_equal(r.assignments, want[1])
+                np.testing.assert_array_equal(r.distances, want[2])
+    # the blocks-of-one-template order really skips tiles
+    with FrameStore.from_array(x) as st:
+        st.set_option(11, 1)
+        st.reset_state()
+        st.kcenters_run(0, 60, 0.0)
+        tiles, skipped = st.ti_stats()
+    assert tiles == 59 * ((len(x) + 255) // 256)
+    assert skipped > 0.5 * tiles
