@@ -21,7 +21,18 @@ class MSM(object):
         self.lag_time = lag_time
         self.trim = trim
         self.max_n_states = max_n_states
-        self.method = method if callable(method) else getattr(builders, method)
+        if callable(method):
+            self.method = method
+        elif hasattr(builders, str(method)):
+            self.method = getattr(builders, method)
+        else:
+            # reference builders: normalize, transpose, mle (Prinz's iteration,
+            # builders.py:24 + libmsm.pyx: a sequential dense sweep that is not
+            # part of this build's path)
+            raise NotImplementedError(
+                "MSM builder '%s' is not available here; supported: "
+                "'normalize', 'transpose', or any callable "
+                "counts -> (counts, probs, eq_probs)" % (method,))
         # the reference ignores its sliding_window argument (msm.py:58)
         self.sliding_window = True
         self.device = device

@@ -42,6 +42,7 @@ def _open_coordinates(filename):
                 return node.read()
             finally:
                 f.close()
+        reader.close = f.close      # for callers that only want the shape
     elif ext == ".npy":
         arr = np.load(filename, mmap_mode="r")
         shape = arr.shape
@@ -56,6 +57,16 @@ def _open_coordinates(filename):
         raise DataInvalid("coordinates in %s have shape %s, expected "
                           "(frames, atoms, 3)" % (filename, (shape,)))
     return shape[0], shape[1], reader
+
+
+def _coordinates_shape(filename):
+    """(n_frames, n_atoms) of a coordinate file; whatever was opened to find
+    out is closed again before returning."""
+    n_frames, n_atoms, reader = _open_coordinates(filename)
+    closer = getattr(reader, "close", None)
+    if closer is not None:
+        closer()
+    return n_frames, n_atoms
 
 
 def _selected_length(n_frames, kw):
@@ -125,10 +136,10 @@ def load_as_concatenated(filenames, lengths=None, processes=None, args=None,
                 "%s lengths were given for %s files"
                 % (len(lengths), len(filenames)))
     else:
-        lengths = [_selected_length(_open_coordinates(f)[0], kw)
+        lengths = [_selected_length(_coordinates_shape(f)[0], kw)
                    for f, kw in zip(filenames, args)]
 
-    n_atoms = _open_coordinates(filenames[0])[1]
+    n_atoms = _coordinates_shape(filenames[0])[1]
     if args[0].get("atom_indices") is not None:
         n_atoms = len(args[0]["atom_indices"])
     xyz = np.empty((sum(lengths), n_atoms, 3), dtype=np.float32)
