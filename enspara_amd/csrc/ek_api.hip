@@ -90,6 +90,7 @@ struct ek_ctx {
     double *sq_part = nullptr;       // leaf sums + chunk sums (ek_pam.hip, numpy's order)
     EkPwShape *pw_shapes = nullptr;  // [2]: a full chunk, the last chunk
     int pw_n_full = 0, pw_leaves = 0, pw_chunks = 0;
+    bool pw_tail_ok = false;         // full chunks are perfect 64-leaf trees
     double *sq_out = nullptr;
     float *med_aos = nullptr;        // [K+1][3A]; row K = saved row
     double *med_G = nullptr;
@@ -1107,8 +1108,9 @@ static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
         ek_launch_blockmax(c->dist, c->n, c->blockmax, c->stream);
         EK_CHECK_LAUNCH();
     }
-    EK_HIP(hipMemcpyAsync(c->rec, c->recsT, ek_rec_bytes(c->A),
-                          hipMemcpyDeviceToDevice, c->stream));
+    if (held >= 0)              // (nothing ran: the slot still describes the state)
+        EK_HIP(hipMemcpyAsync(c->rec, c->recsT, ek_rec_bytes(c->A),
+                              hipMemcpyDeviceToDevice, c->stream));
     EK_HIP(ek_wait(c));
     const int32_t added_t = std::max(0, cr.n_done - first_label);
     const int64_t passes = c->st_rounds[0] + c->st_rounds[1] + c->st_rounds[2];
@@ -1323,6 +1325,25 @@ static int ek_pam_alloc(ek_ctx *c, int32_t K)
             const int last_len = (int)(c->n - n_full * EK_PW_CHUNK);
             ek_pw_build_shape(n_full > 0 ? EK_PW_CHUNK : 0, &hs[0]);
             ek_pw_build_shape(last_len, &hs[1]);
+            // the one-launch cost sums (ek_pw_leaf_kernel<.., true>) add a full
+            // chunk's 64 leaf sums as a perfect in-order binary tree: true for
+            // numpy's pairwise split of 8192 elements, checked here
+            {
+                bool ok = n_full == 0 ||
+                          (hs[0].n_leaves == EK_PW_FULL_LEAVES && hs[0].n_levels == 6);
+                for (int k = 0; ok && n_full > 0 && k < hs[0].n_nodes; ++k) {
+                    // level-ordered nodes: level 1 joins leaves (2j, 2j+1), ..
+                    const int lev_start[7] = {0, 32, 48, 56, 60, 62, 63};
+                    int lev = 0;
+                    while (k >= lev_start[lev + 1])
+                        ++lev;
+                    const int j = k - lev_start[lev];
+                    const int base = lev == 0 ? 0 : hs[0].n_leaves + lev_start[lev - 1];
+                    ok = hs[0].node_l[k] == base + 2 * j &&
+                         hs[0].node_r[k] == base + 2 * j + 1;
+                }
+                c->pw_tail_ok = ok;
+            }
             c->pw_n_full = (int)n_full;
             c->pw_leaves = (int)n_full * EK_PW_FULL_LEAVES + hs[1].n_leaves;
             c->pw_chunks = (int)n_full + (last_len > 0 ? 1 : 0);
@@ -1519,14 +1540,16 @@ extern "C" int ek_pam_select_member(ek_ctx *c, int32_t cid, int64_t j,
 // medoids, both cost sums and the moved-cluster mask, packed into *out (device).
 // No read-back.  max_amb bounds the ambiguous set (a subset of cluster cid's
 // members) and sizes the follow-up launches.
+// fuse != 0 (the window run): ambiguous members stay marked in the trial state
+// until the cost sums resolve them -- no scatter launch
 static int ek_pam_tail(ek_ctx *c, int32_t cid, const float *newd,
                        int64_t max_amb, int32_t win_lo, int32_t win_count,
-                       EkPamOut *out)
+                       EkPamOut *out, int fuse = 0)
 {
     const int K = c->med_K;
     ek_launch_pam_classify(c->dist, c->assign, newd, c->n, cid, c->ndist,
                            c->nassign, c->amb, c->amb_best, c->amb_count,
-                           c->amb_count + 1, c->stream);
+                           c->amb_count + 1, c->stream, fuse);
     // only when dist[f] is known to be the distance to medoid assign[f] (a state
     // this library produced; not one uploaded by the caller) may the search skip
     // medoids out of the members' reach
@@ -1541,12 +1564,14 @@ static int ek_pam_tail(ek_ctx *c, int32_t cid, const float *newd,
                             c->ambt, c->ambG, c->ambt_cap, c->med_aos, c->med_G,
                             K, prune ? c->med_list : nullptr, c->amb_count + 2,
                             newd, cid, c->amb_best, c->stream);
-    ek_launch_pam_scatter(c->amb, c->amb_best, c->amb_count, max_amb, c->ndist,
-                          c->nassign, c->stream);
+    if (!fuse)
+        ek_launch_pam_scatter(c->amb, c->amb_best, c->amb_count, max_amb, c->ndist,
+                              c->nassign, c->stream);
     ek_launch_sumsq_pack(c->dist, c->ndist, c->assign, c->nassign, c->n, win_lo,
                          win_count, c->pw_shapes, c->pw_n_full, c->pw_leaves,
                          c->pw_chunks, c->sq_part, c->amb_count, c->moved, out,
-                         c->stream);
+                         c->stream, fuse ? c->amb_best : nullptr,
+                         (fuse && c->pw_tail_ok) ? c->tick + 3 : nullptr);
     EK_CHECK_LAUNCH();
     return EK_OK;
 }
@@ -1855,7 +1880,7 @@ static int ek_pam_prefetch_vectors(ek_ctx *c, int count, int32_t win_lo,
             }
             EK_HIP(hipMemsetD32Async((hipDeviceptr_t)c->pam_vecs, 0x7f800000,
                                      (size_t)count * c->n_pad, c->stream));
-            ek_launch_gather_tiles(c->tiles, c->G, c->A, c->amb, n_act,
+            ek_launch_gather_tiles(c->aos, c->G, c->A, c->amb, n_act,
                                    c->act_tiles, c->act_G, c->stream);
             ek_launch_pass_dist(count, c->act_tiles, c->act_G, c->act_vecs, n_act,
                                 c->act_cap, c->A, c->pam_recs, c->pam_plan,
@@ -1922,10 +1947,8 @@ static int ek_pam_prefetch_frames(ek_ctx *c, const int64_t *frames, int32_t coun
         if (rc)
             return rc;
     }
-    const size_t rstride = ek_rec_bytes(c->A);
-    for (int32_t j = 0; j < count; ++j)
-        ek_launch_record_from_frame(c->tiles, c->G, c->A, frames[j], nullptr,
-                                    c->goff, c->pam_recs + j * rstride, c->stream);
+    ek_launch_records_from_frames(c->aos, c->G, c->A, frames, count, c->goff,
+                                  c->pam_recs, c->stream);
     {
         int rc = ek_pam_prefetch_vectors(c, count, win_lo, win_count);
         if (rc)
@@ -1994,17 +2017,23 @@ extern "C" int ek_pam_window_run(ek_ctx *c, int32_t cid0, int32_t count,
     const int K = c->med_K;
     for (int32_t i = 0; i < count; ++i) {
         const int32_t cid = cid0 + i;
-        ek_launch_pam_trial(c->tiles, c->G, c->A, c->med_aos, c->med_G, K, cid,
-                            c->pam_restore, frames[i], nullptr, nullptr, nullptr,
-                            c->amb_count, c->moved, c->stream);
+        // the first proposal's trial table; the others' are set up by the
+        // decision kernel of the proposal before
+        if (i == 0)
+            ek_launch_pam_trial(c->tiles, c->G, c->A, c->med_aos, c->med_G, K, cid,
+                                c->pam_restore, frames[i], nullptr, nullptr,
+                                nullptr, c->amb_count, c->moved, c->stream);
         c->pam_restore = -1;
         rc = ek_pam_tail(c, cid, newd[i], n_members[i], win_lo, win_count,
-                         &c->pam_win_dev->out[i]);
+                         &c->pam_win_dev->out[i], 1);
         if (rc)
             return rc;
+        const bool more = i + 1 < count;
         ek_launch_pam_decide(c->pam_win_dev, i, (double)c->n, c->dist, c->ndist,
                              c->assign, c->nassign, c->n, c->med_aos, c->med_G, c->A,
-                             K, cid, c->med_idx, frames[i], n_members[i], c->stream);
+                             K, cid, c->med_idx, frames[i], n_members[i],
+                             more ? cid + 1 : -1, more ? frames[i + 1] : 0, c->aos,
+                             c->G, c->amb_count, c->moved, c->stream);
         EK_CHECK_LAUNCH();
         ++c->pf_hits;
     }

@@ -234,7 +234,7 @@ void ek_launch_pam_classify(const float *dist, const int32_t *assign,
                             float *ndist, int32_t *nassign, uint32_t *amb,
                             unsigned long long *amb_best,
                             unsigned int *amb_count, unsigned int *reach,
-                            hipStream_t s);
+                            hipStream_t s, int mark = 0);
 // medoids within reach of the ambiguous members -> list / n_list
 void ek_launch_pam_prune(const float *aos, const double *Gm, int A, int K, int cid,
                          const unsigned int *reach, int32_t *list,
@@ -275,7 +275,10 @@ void ek_launch_pam_decide(EkPamWin *win, int slot, double n_total, float *dist,
                           const float *ndist, int32_t *assign,
                           const int32_t *nassign, int64_t n, float *aos,
                           double *Gm, int A, int K, int cid, int64_t *med_idx,
-                          int64_t frame, int64_t max_amb, hipStream_t s);
+                          int64_t frame, int64_t max_amb, int next_cid,
+                          int64_t next_frame, const float *frames_aos,
+                          const double *G, unsigned int *amb_count,
+                          unsigned int *moved, hipStream_t s);
 // active-set proposal prefetch (ek_pam.hip)
 void ek_launch_pam_dtab(const float *aos, const double *Gm, int A, int K, int held,
                         const unsigned char *recs, int count, float *Dtab,
@@ -284,9 +287,14 @@ void ek_launch_pam_active(const float *dist, const int32_t *assign, int64_t n,
                           const float *Dtab, int K, int count, int32_t win_lo,
                           int32_t win_count, uint32_t *list, unsigned int *n_list,
                           hipStream_t s);
-void ek_launch_gather_tiles(const float *tiles, const double *G, int A,
+// (aos: the frame-major copy of the shard)
+void ek_launch_gather_tiles(const float *aos, const double *G, int A,
                             const uint32_t *list, int64_t count, float *ctiles,
                             double *cG, hipStream_t s);
+void ek_launch_records_from_frames(const float *aos, const double *G, int A,
+                                   const int64_t *frames, int count,
+                                   int64_t global_offset, unsigned char *recs,
+                                   hipStream_t s);
 void ek_launch_scatter_vecs(const uint32_t *list, int64_t count,
                             const float *cvecs, int64_t cpad, int nvec,
                             float *vecs, int64_t n_pad, hipStream_t s);
@@ -309,12 +317,14 @@ struct EkPwShape {
     int32_t level_start[16];              // nodes of level i: [start[i], start[i+1])
 };
 void ek_pw_build_shape(int len, EkPwShape *sh);      // host
-void ek_launch_sumsq_pack(const float *a, const float *b, const int32_t *assign,
-                          const int32_t *nassign, int64_t n, int32_t win_lo,
+void ek_launch_sumsq_pack(const float *a, float *b, const int32_t *assign,
+                          int32_t *nassign, int64_t n, int32_t win_lo,
                           int32_t win_count, const EkPwShape *shapes, int n_full,
                           int n_leaves_total, int n_chunks, double *part,
                           const unsigned int *n_amb, unsigned int *moved,
-                          EkPamOut *out, hipStream_t s);
+                          EkPamOut *out, hipStream_t s,
+                          const unsigned long long *amb_best = nullptr,
+                          unsigned int *tick = nullptr);
 void ek_launch_gather_rows(const float *tiles, const double *G, int A,
                            const int64_t *idx_dev, const int64_t *rows_dev,
                            int count, float *out_aos, double *outG, hipStream_t s);

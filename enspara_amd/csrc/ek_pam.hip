@@ -9,6 +9,7 @@
 //   cost = mean(dist^2) old vs new                    :478, :680-681 -> sumsq
 // The host keeps only the RNG and the accept/reject decision.
 #include "ek_common.h"
+#include "ek_reduce.h"
 #include <algorithm>
 #include "ek_qcp.h"
 
@@ -310,6 +311,9 @@ void ek_launch_select_member_multi(const int32_t *assign, int64_t n, int32_t cid
 //   dist > newd                      -> (newd, cid)
 //   dist <= newd and assign != cid   -> unchanged
 //   dist <= newd and assign == cid   -> ambiguous: listed, resolved below
+// MARK: an ambiguous member's trial label is -2 - (its position in the list)
+// until the cost-sum kernel resolves it from amb_best (no scatter launch)
+template <bool MARK>
 __global__ void __launch_bounds__(EK_BLOCK)
 ek_pam_classify_kernel(const float *__restrict__ dist,
                        const int32_t *__restrict__ assign,
@@ -335,6 +339,10 @@ ek_pam_classify_kernel(const float *__restrict__ dist,
         const unsigned int pos = atomicAdd(amb_count, 1u);
         amb[pos] = (uint32_t)f;
         amb_best[pos] = ~0ull;
+        if (MARK) {
+            ndist[f] = 0.f;
+            nassign[f] = -2 - (int32_t)pos;
+        }
         // how far a medoid may be from the old one and still matter to this
         // frame (ek_pam_prune_kernel); non-negative floats order like their bits
         atomicMax(reach, __float_as_uint(d + nd));
@@ -346,13 +354,19 @@ void ek_launch_pam_classify(const float *dist, const int32_t *assign,
                             float *ndist, int32_t *nassign, uint32_t *amb,
                             unsigned long long *amb_best,
                             unsigned int *amb_count, unsigned int *reach,
-                            hipStream_t s)
+                            hipStream_t s, int mark)
 {
     const int nblocks = (int)((n + EK_BLOCK - 1) / EK_BLOCK);
-    if (nblocks > 0)
-        hipLaunchKernelGGL(ek_pam_classify_kernel, dim3(nblocks), dim3(EK_BLOCK), 0,
-                       s, dist, assign, newd, n, cid, ndist, nassign, amb,
-                       amb_best, amb_count, reach);
+    if (nblocks <= 0)
+        return;
+    if (mark)
+        hipLaunchKernelGGL(ek_pam_classify_kernel<true>, dim3(nblocks),
+                           dim3(EK_BLOCK), 0, s, dist, assign, newd, n, cid, ndist,
+                           nassign, amb, amb_best, amb_count, reach);
+    else
+        hipLaunchKernelGGL(ek_pam_classify_kernel<false>, dim3(nblocks),
+                           dim3(EK_BLOCK), 0, s, dist, assign, newd, n, cid, ndist,
+                           nassign, amb, amb_best, amb_count, reach);
 }
 
 // ---- which medoids can matter to the ambiguous members --------------------------------
@@ -688,13 +702,71 @@ void ek_launch_pam_trial(const float *tiles, const double *G, int A, float *aos,
 // (ek_pw_build_shape) and shared by every launch.
 
 // one 8-lane group per leaf; moved-cluster mask as a by-product of the same read
+// RESOLVE: trial labels < -1 are ambiguous members still waiting for their
+// result (ek_pam_classify_kernel<true>): it is read from amb_best here -- every
+// frame is visited exactly once -- and written into the trial state
+template <bool RESOLVE>
+__device__ __forceinline__ void ek_pw_fetch(const float *a, float *b,
+                                            const int32_t *assign, int32_t *nassign,
+                                            const unsigned long long *amb_best,
+                                            int64_t f, double &va, double &vb,
+                                            int32_t &oa, int32_t &na)
+{
+    va = a[f];
+    float fb = b[f];
+    oa = assign[f];
+    na = nassign[f];
+    if (RESOLVE && na < -1) {
+        const unsigned long long key = amb_best[-2 - na];
+        fb = __uint_as_float((unsigned int)(key >> 32));
+        na = (int32_t)(key & 0xffffffffu);
+        b[f] = fb;
+        nassign[f] = na;
+    }
+    vb = fb;
+}
+
+// what the last workgroup of the leaf kernel needs to finish the sums itself
+// (TAIL): the chunk trees and the left-to-right total, packed into *out
+struct EkPwTail {
+    unsigned int *tick;
+    int n_chunks;
+    const unsigned int *n_amb;
+    int64_t n;
+    EkPamOut *out;
+};
+
+__device__ __forceinline__ double ek_coh_ld_f64(const double *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// in-order pairwise sum of 16 consecutive leaf sums (a perfect subtree)
+__device__ __forceinline__ double ek_pw_sum16(const double *leafsum, size_t first,
+                                              int which)
+{
+    double v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        v[i] = ek_coh_ld_f64(&leafsum[2 * (first + i) + which]);
+#pragma unroll
+    for (int w = 1; w < 16; w <<= 1)
+#pragma unroll
+        for (int i = 0; i < 16; i += 2 * w)
+            v[i] = v[i] + v[i + w];
+    return v[0];
+}
+
+template <bool RESOLVE, bool TAIL>
 __global__ void __launch_bounds__(EK_BLOCK)
-ek_pw_leaf_kernel(const float *__restrict__ a, const float *__restrict__ b,
+ek_pw_leaf_kernel(const float *__restrict__ a, float *__restrict__ b,
                   const int32_t *__restrict__ assign,
-                  const int32_t *__restrict__ nassign, int64_t n, int32_t win_lo,
+                  int32_t *__restrict__ nassign,
+                  const unsigned long long *__restrict__ amb_best, int64_t n,
+                  int32_t win_lo,
                   int32_t win_count, const EkPwShape *__restrict__ shapes,
                   int n_full, int n_leaves_total, double *__restrict__ leafsum,
-                  unsigned int *__restrict__ mask)
+                  unsigned int *__restrict__ mask, EkPwTail tl)
 {
     __shared__ unsigned int acc;
     if (threadIdx.x == 0)
@@ -718,7 +790,10 @@ ek_pw_leaf_kernel(const float *__restrict__ a, const float *__restrict__ b,
         if (body > 0) {
             for (int i = 0; i < body; i += 8) {
                 const int64_t f = off + i + l8;
-                const double va = a[f], vb = b[f];
+                double va, vb;
+                int32_t oa, na;
+                ek_pw_fetch<RESOLVE>(a, b, assign, nassign, amb_best, f, va, vb, oa,
+                                     na);
                 if (i == 0) {
                     ra = va * va;
                     rb = vb * vb;
@@ -727,7 +802,6 @@ ek_pw_leaf_kernel(const float *__restrict__ a, const float *__restrict__ b,
                     rb = rb + vb * vb;
                 }
                 if (win_count > 0) {
-                    const int32_t oa = assign[f], na = nassign[f];
                     if (oa != na) {
                         const int32_t ia = oa - win_lo, ib = na - win_lo;
                         if (ia >= 0 && ia < win_count)
@@ -746,11 +820,13 @@ ek_pw_leaf_kernel(const float *__restrict__ a, const float *__restrict__ b,
         if (l8 == 0) {
             for (int i = body; i < len; ++i) {          // sequential tail
                 const int64_t f = off + i;
-                const double va = a[f], vb = b[f];
+                double va, vb;
+                int32_t oa, na;
+                ek_pw_fetch<RESOLVE>(a, b, assign, nassign, amb_best, f, va, vb, oa,
+                                     na);
                 ra = ra + va * va;
                 rb = rb + vb * vb;
                 if (win_count > 0) {
-                    const int32_t oa = assign[f], na = nassign[f];
                     if (oa != na) {
                         const int32_t ia = oa - win_lo, ib = na - win_lo;
                         if (ia >= 0 && ia < win_count)
@@ -760,8 +836,15 @@ ek_pw_leaf_kernel(const float *__restrict__ a, const float *__restrict__ b,
                     }
                 }
             }
-            leafsum[2 * (size_t)g + 0] = ra;
-            leafsum[2 * (size_t)g + 1] = rb;
+            if (TAIL) {         // read by the last workgroup: coherent stores
+                __hip_atomic_store(&leafsum[2 * (size_t)g + 0], ra,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&leafsum[2 * (size_t)g + 1], rb,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                leafsum[2 * (size_t)g + 0] = ra;
+                leafsum[2 * (size_t)g + 1] = rb;
+            }
         }
     }
     if (m)
@@ -769,6 +852,67 @@ ek_pw_leaf_kernel(const float *__restrict__ a, const float *__restrict__ b,
     __syncthreads();
     if (threadIdx.x == 0 && acc)
         atomicOr(mask, acc);
+    if (!TAIL)
+        return;
+    // ---- the last workgroup: chunk trees, then the chunks left to right --------
+    // (what ek_pw_chunk_kernel and ek_pw_pack_kernel do in launches of their own)
+    if (!ek_arrive_last(tl.tick))
+        return;
+    __shared__ double ca[EK_BLOCK], cb[EK_BLOCK];
+    __shared__ double la[2 * EK_PW_MAX_LEAVES], lb[2 * EK_PW_MAX_LEAVES];
+    const int t = threadIdx.x;
+    double sa = 0.0, sb = 0.0;
+    for (int c0 = 0; c0 < tl.n_chunks; c0 += EK_BLOCK) {
+        const int c = c0 + t;
+        if (c < n_full) {
+            // a full chunk is a perfect in-order binary tree over its 64 leaves
+            // (checked on the host): four subtrees of 16, then two levels
+            const size_t first = (size_t)c * EK_PW_FULL_LEAVES;
+            double pa[4], pb[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                pa[q] = ek_pw_sum16(leafsum, first + 16 * q, 0);
+                pb[q] = ek_pw_sum16(leafsum, first + 16 * q, 1);
+            }
+            ca[t] = (pa[0] + pa[1]) + (pa[2] + pa[3]);
+            cb[t] = (pb[0] + pb[1]) + (pb[2] + pb[3]);
+        } else if (c == n_full && c < tl.n_chunks) {
+            // the last, shorter chunk: its own tree, node by node
+            const EkPwShape *sh = &shapes[1];
+            const size_t first = (size_t)n_full * EK_PW_FULL_LEAVES;
+            const int nl = sh->n_leaves;
+            for (int i = 0; i < nl; ++i) {
+                la[i] = ek_coh_ld_f64(&leafsum[2 * (first + i) + 0]);
+                lb[i] = ek_coh_ld_f64(&leafsum[2 * (first + i) + 1]);
+            }
+            for (int k = 0; k < sh->n_nodes; ++k) {     // children come first
+                la[nl + k] = la[sh->node_l[k]] + la[sh->node_r[k]];
+                lb[nl + k] = lb[sh->node_l[k]] + lb[sh->node_r[k]];
+            }
+            const int root = (sh->n_nodes > 0) ? nl + sh->n_nodes - 1 : 0;
+            ca[t] = la[root];
+            cb[t] = lb[root];
+        }
+        __syncthreads();
+        if (t == 0) {
+            const int mm = (tl.n_chunks - c0 < EK_BLOCK) ? tl.n_chunks - c0 : EK_BLOCK;
+            for (int k = 0; k < mm; ++k) {
+                sa = sa + ca[k];
+                sb = sb + cb[k];
+            }
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        tl.out->sum_old = sa;
+        tl.out->sum_new = sb;
+        tl.out->n_frames = tl.n;
+        tl.out->n_amb = *tl.n_amb;
+        // every workgroup's bits are in: they were OR-ed before its ticket
+        tl.out->moved = __hip_atomic_load(mask, __ATOMIC_RELAXED,
+                                          __HIP_MEMORY_SCOPE_AGENT);
+        *tl.tick = 0;
+    }
 }
 
 // one workgroup per chunk: the pairwise tree over its leaves, level by level
@@ -842,21 +986,49 @@ ek_pw_pack_kernel(const double *__restrict__ chunksum, int n_chunks,
     out->moved = *moved;
 }
 
-void ek_launch_sumsq_pack(const float *a, const float *b, const int32_t *assign,
-                          const int32_t *nassign, int64_t n, int32_t win_lo,
+// amb_best != nullptr: the trial state still carries marked ambiguous members
+// (ek_launch_pam_classify(.., mark = 1)); they are resolved on the way
+void ek_launch_sumsq_pack(const float *a, float *b, const int32_t *assign,
+                          int32_t *nassign, int64_t n, int32_t win_lo,
                           int32_t win_count, const EkPwShape *shapes, int n_full,
                           int n_leaves_total, int n_chunks, double *part,
                           const unsigned int *n_amb, unsigned int *moved,
-                          EkPamOut *out, hipStream_t s)
+                          EkPamOut *out, hipStream_t s,
+                          const unsigned long long *amb_best, unsigned int *tick)
 {
     double *leafsum = part;
     double *chunksum = part + 2 * (size_t)n_leaves_total;
+    if (n_leaves_total > 0 && amb_best && tick) {
+        // one launch: the last workgroup finishes the sums
+        const int per = EK_BLOCK / 8;
+        EkPwTail tl;
+        tl.tick = tick;
+        tl.n_chunks = n_chunks;
+        tl.n_amb = n_amb;
+        tl.n = n;
+        tl.out = out;
+        hipLaunchKernelGGL((ek_pw_leaf_kernel<true, true>),
+                           dim3((n_leaves_total + per - 1) / per), dim3(EK_BLOCK),
+                           0, s, a, b, assign, nassign, amb_best, n, win_lo,
+                           win_count, shapes, n_full, n_leaves_total, leafsum,
+                           moved, tl);
+        return;
+    }
     if (n_leaves_total > 0) {
         const int per = EK_BLOCK / 8;
-        hipLaunchKernelGGL(ek_pw_leaf_kernel, dim3((n_leaves_total + per - 1) / per),
-                           dim3(EK_BLOCK), 0, s, a, b, assign, nassign, n, win_lo,
+        if (amb_best)
+            hipLaunchKernelGGL((ek_pw_leaf_kernel<true, false>),
+                               dim3((n_leaves_total + per - 1) / per),
+                               dim3(EK_BLOCK), 0, s, a, b, assign, nassign,
+                               amb_best, n, win_lo, win_count, shapes, n_full,
+                               n_leaves_total, leafsum, moved, EkPwTail());
+        else
+        hipLaunchKernelGGL((ek_pw_leaf_kernel<false, false>),
+                           dim3((n_leaves_total + per - 1) / per),
+                           dim3(EK_BLOCK), 0, s, a, b, assign, nassign, amb_best,
+                           n, win_lo,
                            win_count, shapes, n_full, n_leaves_total, leafsum,
-                           moved);
+                           moved, EkPwTail());
         hipLaunchKernelGGL(ek_pw_chunk_kernel, dim3(n_chunks), dim3(128), 0, s,
                            leafsum, shapes, n_full, chunksum);
     }
@@ -1030,32 +1202,72 @@ void ek_launch_pam_active(const float *dist, const int32_t *assign, int64_t n,
 
 // the listed frames, packed into the frame-minor tile layout of the frame store
 // (so that the pass kernel can run over them); one workgroup per frame
+// listed frames -> tile layout.  One workgroup per listed frame (hundreds to a
+// few thousand frames: parallelism matters more than store width here); the
+// frame is read from the frame-major copy, 12 A contiguous bytes.
 __global__ void __launch_bounds__(EK_BLOCK)
-ek_gather_tiles_kernel(const float *__restrict__ tiles,
+ek_gather_tiles_kernel(const float *__restrict__ aos,
                        const double *__restrict__ G, int A,
-                       const uint32_t *__restrict__ list,
+                       const uint32_t *__restrict__ list, int64_t count,
                        float *__restrict__ ctiles, double *__restrict__ cG)
 {
     const unsigned int i = blockIdx.x;
     const uint32_t f = list[i];
-    const float *p = tiles + (size_t)(f / EK_TILE) * 3 * (size_t)A * EK_TILE +
-                     (f % EK_TILE);
+    const float *p = aos + (size_t)f * 3 * A;
     float *o = ctiles + (size_t)(i / EK_TILE) * 3 * (size_t)A * EK_TILE +
                (i % EK_TILE);
     for (int r = threadIdx.x; r < 3 * A; r += EK_BLOCK)
-        o[(size_t)r * EK_TILE] = p[(size_t)r * EK_TILE];
+        o[(size_t)r * EK_TILE] = p[r];
     if (threadIdx.x == 0)
         cG[i] = G[f];
 }
 
-void ek_launch_gather_tiles(const float *tiles, const double *G, int A,
+// the records of up to EK_MAX_CANDS frames in one launch (block j = frame j)
+struct EkFrameList {
+    int64_t f[EK_MAX_CANDS];
+};
+__global__ void __launch_bounds__(EK_BLOCK)
+ek_records_from_frames_kernel(const float *__restrict__ aos,
+                              const double *__restrict__ G, int A, EkFrameList fl,
+                              int64_t global_offset,
+                              unsigned char *__restrict__ recs)
+{
+    const int64_t idx = fl.f[blockIdx.x];
+    EkRecHdr *h = (EkRecHdr *)(recs + (size_t)blockIdx.x * ek_rec_bytes(A));
+    float *coords = (float *)(h + 1);
+    if (threadIdx.x == 0) {
+        h->maxdist = __builtin_inff();
+        h->valid = 1;
+        h->gidx = global_offset + idx;
+        h->trace = G[idx];
+        h->reserved = 0;
+    }
+    for (int r = threadIdx.x; r < 3 * A; r += EK_BLOCK)
+        coords[r] = aos[(size_t)idx * 3 * A + r];
+}
+
+void ek_launch_records_from_frames(const float *aos, const double *G, int A,
+                                   const int64_t *frames, int count,
+                                   int64_t global_offset, unsigned char *recs,
+                                   hipStream_t s)
+{
+    if (count <= 0)
+        return;
+    EkFrameList fl;
+    for (int j = 0; j < EK_MAX_CANDS; ++j)
+        fl.f[j] = j < count ? frames[j] : 0;
+    hipLaunchKernelGGL(ek_records_from_frames_kernel, dim3(count), dim3(EK_BLOCK), 0,
+                       s, aos, G, A, fl, global_offset, recs);
+}
+
+void ek_launch_gather_tiles(const float *aos, const double *G, int A,
                             const uint32_t *list, int64_t count, float *ctiles,
                             double *cG, hipStream_t s)
 {
     if (count <= 0)
         return;
     hipLaunchKernelGGL(ek_gather_tiles_kernel, dim3((unsigned)count),
-                       dim3(EK_BLOCK), 0, s, tiles, G, A, list, ctiles, cG);
+                       dim3(EK_BLOCK), 0, s, aos, G, A, list, count, ctiles, cG);
 }
 
 // vecs[j][list[i]] = cvecs[j][i]
@@ -1105,7 +1317,11 @@ ek_pam_decide_kernel(EkPamWin *__restrict__ win, int slot, double n_total,
                      const int32_t *__restrict__ nassign, int64_t n,
                      float *__restrict__ aos, double *__restrict__ Gm, int A, int K,
                      int cid, int64_t *__restrict__ med_idx, int64_t frame,
-                     int64_t max_amb)
+                     int64_t max_amb, int next_cid, int64_t next_frame,
+                     const float *__restrict__ frames_aos,
+                     const double *__restrict__ G,
+                     unsigned int *__restrict__ amb_count,
+                     unsigned int *__restrict__ moved)
 {
     const bool live = slot < win->stop;
     const EkPamOut o = win->out[slot];
@@ -1118,13 +1334,32 @@ ek_pam_decide_kernel(EkPamWin *__restrict__ win, int slot, double n_total,
     }
     if (blockIdx.x != 0)
         return;
-    if (!accept) {              // the proposal's row of the medoid table: undone
-        for (int r = threadIdx.x; r < 3 * A; r += EK_BLOCK)
+    // the proposal's row of the medoid table is undone if it was not accepted;
+    // then the NEXT proposal's trial table is set up right here (what
+    // ek_pam_trial_kernel does in a launch of its own: old row of its cluster
+    // into row K, the proposed frame -- read from the frame-major copy -- into
+    // the cluster's row, counters cleared).  Thread t owns elements t, t + 256,
+    // .. of every row, so the steps need no barrier.
+    for (int r = threadIdx.x; r < 3 * A; r += EK_BLOCK) {
+        if (!accept)
             aos[(size_t)cid * 3 * A + r] = aos[(size_t)K * 3 * A + r];
+        if (next_cid >= 0) {
+            aos[(size_t)K * 3 * A + r] = aos[(size_t)next_cid * 3 * A + r];
+            aos[(size_t)next_cid * 3 * A + r] =
+                frames_aos[(size_t)next_frame * 3 * A + r];
+        }
     }
     if (threadIdx.x == 0) {
         if (!accept)
             Gm[cid] = Gm[K];
+        if (next_cid >= 0) {
+            Gm[K] = Gm[next_cid];
+            Gm[next_cid] = G[next_frame];
+            amb_count[0] = 0;
+            amb_count[1] = 0;
+            amb_count[2] = 0;
+            *moved = 0;
+        }
         if (live) {
             win->accept[slot] = accept ? 1 : 0;
             if ((int64_t)o.n_amb > max_amb)
@@ -1149,11 +1384,15 @@ void ek_launch_pam_decide(EkPamWin *win, int slot, double n_total, float *dist,
                           const float *ndist, int32_t *assign,
                           const int32_t *nassign, int64_t n, float *aos,
                           double *Gm, int A, int K, int cid, int64_t *med_idx,
-                          int64_t frame, int64_t max_amb, hipStream_t s)
+                          int64_t frame, int64_t max_amb, int next_cid,
+                          int64_t next_frame, const float *frames_aos,
+                          const double *G, unsigned int *amb_count,
+                          unsigned int *moved, hipStream_t s)
 {
     const unsigned blocks = (unsigned)std::max<int64_t>(1, (n + EK_BLOCK - 1) /
                                                                EK_BLOCK);
     hipLaunchKernelGGL(ek_pam_decide_kernel, dim3(blocks), dim3(EK_BLOCK), 0, s,
                        win, slot, n_total, dist, ndist, assign, nassign, n, aos,
-                       Gm, A, K, cid, med_idx, frame, max_amb);
+                       Gm, A, K, cid, med_idx, frame, max_amb, next_cid,
+                       next_frame, frames_aos, G, amb_count, moved);
 }
