@@ -164,6 +164,72 @@ def _check_proposals(proposals, medoid_inds):
 PAM_PREFETCH = 8
 
 
+class _DrawStream:
+    """``random_state.choice(m)`` (kmedoids.py:514 draws a member with
+    ``choice(state_inds)``, which is ``state_inds[choice(len(state_inds))]``)
+    without a Python-level numpy call per draw, and with free look-ahead.
+
+    numpy's legacy ``RandomState.choice(m)`` / ``randint(0, m)`` take 32-bit
+    outputs of the Mersenne Twister, mask them to the bits of ``m - 1`` and
+    reject values above it (``m == 1`` consumes nothing).  This class pulls raw
+    32-bit outputs from the caller's RandomState in blocks and applies the same
+    rule, so every draw is the number ``choice`` would have returned; ``close``
+    puts the RandomState where that many ``choice`` calls would have left it.
+    Proposals drawn *ahead* for a window are simply the same raw numbers looked
+    at early (``peek``): copying a RandomState costs 0.2 ms, more than a whole
+    window of proposals takes on the device."""
+    BLOCK = 4096
+
+    def __init__(self, random_state):
+        self.rs = random_state
+        self.state0 = random_state.get_state()
+        self.raw = np.empty(0, dtype=np.uint32)
+        self.pos = 0            # raw outputs consumed by real draws
+
+    def _need(self, upto):
+        while upto > len(self.raw):
+            more = self.rs.randint(0, 2 ** 32, size=self.BLOCK, dtype=np.uint32)
+            self.raw = np.concatenate([self.raw, more])
+
+    def _draw_at(self, pos, m):
+        if m <= 0:
+            raise ValueError("a must be greater than 0 unless no samples are "
+                             "taken")           # RandomState.choice(0)
+        rng = m - 1
+        if rng == 0:
+            return 0, pos
+        if rng > 0xFFFFFFFE:
+            raise NotImplementedError("member lists of 2**32 frames and more")
+        mask = (1 << rng.bit_length()) - 1
+        while True:
+            self._need(pos + 1)
+            v = int(self.raw[pos]) & mask
+            pos += 1
+            if v <= rng:
+                return v, pos
+
+    def draw(self, m):
+        """the next real draw"""
+        v, self.pos = self._draw_at(self.pos, int(m))
+        return v
+
+    def peek(self, ms):
+        """what the next len(ms) real draws will be if the member counts are
+        ``ms`` (stops before a count <= 0: that draw raises when it is made)"""
+        out, pos = [], self.pos
+        for m in ms:
+            if m <= 0:
+                break
+            v, pos = self._draw_at(pos, int(m))
+            out.append(v)
+        return out
+
+    def close(self):
+        self.rs.set_state(self.state0)
+        if self.pos:
+            self.rs.randint(0, 2 ** 32, size=self.pos, dtype=np.uint32)
+
+
 class _Window:
     """Clusters [lo, hi) of a sweep with their member counts, the proposals
     guessed for them and the bit mask of clusters whose membership has changed
@@ -176,14 +242,9 @@ def _open_window(store, lo, hi, proposals, random_state):
     w.lo, w.hi, w.stale = lo, hi, 0
     w.m = [int(x) for x in store.pam_count_members_batch(lo, hi - lo)]
     if proposals is None:
-        # draw from a copy of the stream: the real draws happen in order below
-        ahead = np.random.RandomState()
-        ahead.set_state(random_state.get_state())
-        w.j = []
-        for m in w.m:
-            if m <= 0:          # the real draw raises when its turn comes
-                break
-            w.j.append(int(ahead.choice(m)))
+        # the draws the real stream will produce if these counts still hold when
+        # each cluster's turn comes (they are made, in order, below)
+        w.j = random_state.peek(w.m)
         w.frame = ([int(f) for f in
                     store.pam_select_members_batch(lo, w.j)] if w.j else [])
     else:
@@ -206,7 +267,7 @@ def _one_proposal(store, cid, proposals, random_state):
         m = store.pam_count_members(cid)                     # :611
         # RandomState.choice(state_inds) == state_inds[choice(len)]
         # (raises ValueError on an empty cluster, like the reference)
-        j = random_state.choice(m)                           # :514
+        j = random_state.draw(m)                             # :514
         prop, old_cost, new_cost, n_amb = store.pam_propose_member(cid, j)
     else:
         prop = int(proposals[cid])
@@ -220,6 +281,15 @@ def _pam_sweep_device(store, medoid_inds, proposals, random_state):
     """One sweep of kmedoids.py:575-699 against device-resident state."""
     random_state = check_random_state(random_state)          # :579
     _check_proposals(proposals, medoid_inds)
+    stream = _DrawStream(random_state)
+    try:
+        return _pam_sweep_device_on(store, medoid_inds, proposals, stream)
+    finally:
+        stream.close()          # the caller's RandomState: as after these draws
+
+
+def _pam_sweep_device_on(store, medoid_inds, proposals, random_state):
+    """(random_state: a _DrawStream over the caller's RandomState)"""
     store.pam_begin(medoid_inds)
     K = len(medoid_inds)
     width = max(1, min(int(PAM_PREFETCH), 8))
@@ -257,7 +327,7 @@ def _pam_sweep_device(store, medoid_inds, proposals, random_state):
                     if proposals is None:
                         # the real draws, in order: the member lists are the ones
                         # the guesses were drawn from, so they are the same draws
-                        j = random_state.choice(win.m[s])    # :514
+                        j = random_state.draw(win.m[s])      # :514
                         if j != win.j[s]:
                             raise RuntimeError("PAM window: draw %d for cluster "
                                                "%d, guessed %d"
@@ -293,7 +363,7 @@ def _pam_sweep_device(store, medoid_inds, proposals, random_state):
             m = store.pam_count_members(cid)             # :611
             counted = True
         if proposals is None:
-            j = random_state.choice(m)                   # :514
+            j = random_state.draw(m)                     # :514
             if exact and slot < len(win.j) and j == win.j[slot]:
                 prop = win.frame[slot]
             else:

@@ -135,3 +135,34 @@ def test_partition():
     np.testing.assert_array_equal(p.distances[1], np.arange(4, 15) / 10.)
     with pytest.raises(DataInvalid):
         res.partition([5, 11])
+
+
+def test_draw_stream_is_randomstate_choice():
+    """kmedoids._DrawStream: every draw is what RandomState.choice(m) returns
+    (masked rejection on 32-bit Mersenne Twister outputs, m == 1 consumes
+    nothing), look-ahead sees the same numbers, and close() leaves the caller's
+    RandomState where that many choice() calls would have (reference
+    kmedoids.py:514 draws proposals with choice(state_inds))."""
+    from enspara_amd.cluster.kmedoids import _DrawStream
+    rng = np.random.default_rng(1)
+    for trial in range(60):
+        seed = int(rng.integers(1 << 30))
+        a, b = np.random.RandomState(seed), np.random.RandomState(seed)
+        b.normal()
+        a.normal()                  # a cached gaussian must survive as well
+        st = _DrawStream(a)
+        ms = [int(x) for x in rng.integers(1, 10 ** int(rng.integers(1, 10)),
+                                           size=int(rng.integers(1, 200)))]
+        if trial % 5 == 0:
+            ms[0] = 1
+        ahead = st.peek(ms[:8])
+        got = [st.draw(m) for m in ms]
+        want = [int(b.choice(m)) for m in ms]
+        assert got == want and ahead == want[:len(ahead)]
+        st.close()
+        assert a.normal() == b.normal()
+        assert int(a.randint(0, 10 ** 9)) == int(b.randint(0, 10 ** 9))
+    st = _DrawStream(np.random.RandomState(0))
+    assert st.peek([5, 0, 7]) == st.peek([5])       # stops before an empty list
+    with pytest.raises(ValueError):
+        st.draw(0)

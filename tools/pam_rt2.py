@@ -11,7 +11,7 @@ def wrapped(*a, **k):
         return orig(*a, **k)
     finally:
         pr.disable()
-        s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(10)
+        s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(22)
         sys.stderr.write(s.getvalue())
 km._pam_sweep_device = wrapped
 bench.main()
