@@ -182,8 +182,17 @@ def _kcenters_host(traj, distance_method, n_clusters, dist_cutoff,
                    init_centers, use_triangle_inequality):
     """The reference's loop for an arbitrary callable metric
     (kcenters.py:195-311)."""
-    if hasattr(distance_method, "bind"):     # device metric: upload traj once
-        distance_method = distance_method.bind(traj)
+    # 'euclidean' / 'manhattan' (/ hamming) on a plain 2-D array: the loop runs
+    # on the device with the state resident there (csrc/ek_features.hip
+    # ek_feat_kcenters: same arithmetic per distance, same strict-< update, same
+    # first-index arg-max) instead of one device metric call plus numpy passes
+    # per center.  The triangle-inequality variant keeps the host loop.
+    mid = getattr(distance_method, "device_metric_id", None)
+    resident = (mid is not None and not use_triangle_inequality
+                and isinstance(traj, np.ndarray) and traj.ndim == 2
+                and len(traj) > 0)
+    if not resident and hasattr(distance_method, "bind"):
+        distance_method = distance_method.bind(traj)   # upload traj once
     if init_centers is None:
         ctr_inds, centers = [], []
         assignments = np.full(len(traj), -1, dtype=int)
@@ -193,6 +202,21 @@ def _kcenters_host(traj, distance_method, n_clusters, dist_cutoff,
         assignments, distances = util.assign_to_nearest_center(
             traj, centers, distance_method)
         ctr_inds = list(util.find_cluster_centers(assignments, distances))
+
+    if resident:
+        from ..geometry import libdist
+        budget = n_clusters - len(ctr_inds)
+        max_new = (0 if budget <= 0 else
+                   (2 * len(traj) + 16 if np.isinf(budget) else int(budget)))
+        new_idx, distances, assignments, _ = libdist.kcenters_resident(
+            traj, mid, len(ctr_inds), max_new, float(dist_cutoff), distances,
+            assignments)
+        for i in new_idx:
+            ctr_inds.append(int(i))
+            centers.append(traj[int(i)])
+        return util.ClusterResult(center_indices=ctr_inds,
+                                  assignments=assignments,
+                                  distances=distances, centers=centers)
 
     maxdist = distances.max()
     while (len(ctr_inds) < n_clusters) and (maxdist > dist_cutoff):

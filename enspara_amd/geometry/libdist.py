@@ -62,6 +62,18 @@ class _Resident:
             self._h, int(metric), yc.ctypes.data_as(C.c_void_p),
             _lib.f64p(out)))
 
+    def kcenters(self, metric, first_label, max_new, cutoff, dist, assign):
+        """ek_feat_kcenters on this matrix; dist (float64) / assign (int32) are
+        updated in place.  -> (center samples int64 [k], distances.max())"""
+        centers = np.empty(max(int(max_new), 1), dtype=np.int64)
+        k = C.c_int32()
+        fmax = C.c_double()
+        _lib.check(self.L.ek_feat_kcenters(
+            self._h, int(metric), int(first_label), int(max_new), float(cutoff),
+            _lib.f64p(dist), _lib.i32p(assign), _lib.i64p(centers), C.byref(k),
+            C.byref(fmax)))
+        return centers[:k.value].copy(), fmax.value
+
     def __del__(self):
         try:
             if self._h:
@@ -132,6 +144,7 @@ def euclidean(X, y, out=None, device=0):
 
 
 euclidean.bind = lambda X, device=0: Bound(0, X, device)
+euclidean.device_metric_id = 0
 
 
 def manhattan(X, y, out=None, device=0):
@@ -141,6 +154,7 @@ def manhattan(X, y, out=None, device=0):
 
 
 manhattan.bind = lambda X, device=0: Bound(1, X, device)
+manhattan.device_metric_id = 1
 
 
 def hamming(X, y, out=None, device=0):
@@ -150,3 +164,22 @@ def hamming(X, y, out=None, device=0):
 
 
 hamming.bind = lambda X, device=0: Bound(2, X, device)
+hamming.device_metric_id = 2
+
+
+def kcenters_resident(X, metric_id, first_label, max_new, cutoff, distances,
+                      assignments, device=0):
+    """The k-centers loop (reference kcenters.py:217-231, :243-311) for one of
+    the metrics above with X, the float64 distances and the labels resident on
+    the device for the whole run: no metric call, numpy pass or arg-max on the
+    host per center.  ``distances`` (float64) and ``assignments`` (any integer
+    dtype) are the state on entry; returns (center sample indices, distances,
+    assignments, distances.max()), the arrays in the dtypes they came in."""
+    Xa = np.asarray(X)
+    dt = _working_dtype(Xa, metric_id == 2)
+    res = _Resident(np.ascontiguousarray(Xa, dtype=dt),
+                    _KIND[np.dtype(dt).name], device)
+    d = np.ascontiguousarray(distances, dtype=np.float64).copy()
+    a = np.ascontiguousarray(assignments, dtype=np.int32).copy()
+    centers, fmax = res.kcenters(metric_id, first_label, max_new, cutoff, d, a)
+    return centers, d, a.astype(np.asarray(assignments).dtype), fmax

@@ -421,6 +421,21 @@ int ek_feat_destroy(ek_feat *k);
 int ek_feat_load(ek_feat *k, const void *X, int64_t first, int64_t count);
 int ek_feat_distance(ek_feat *k, int32_t metric, const void *y,
                      double *out_host);
+/* The k-centers loop itself (kcenters.py:217-231 with the iteration of
+ * :243-311) for a feature metric, resident on the device: per center one
+ * launch computes metric(X, X[argmax]) with the arithmetic of
+ * ek_feat_distance, applies the strict-< update to float64 distances / labels
+ * kept in HBM and leaves arg-max partials; a single-workgroup launch reduces
+ * them (first index of the maximum), applies the stop rule
+ * `distances.max() > dist_cutoff` and fetches the next center's features.
+ * dist_io / assign_io: the state on entry (float64 [n], int32 [n]; a fresh run
+ * passes +inf / -1) and on return; labels first_label, first_label + 1, ..;
+ * at most max_new centers; centers_out[0..*n_added) = the samples chosen;
+ * *final_max = distances.max() after the last update. */
+int ek_feat_kcenters(ek_feat *k, int32_t metric, int32_t first_label,
+                     int32_t max_new, double dist_cutoff, double *dist_io,
+                     int32_t *assign_io, int64_t *centers_out, int32_t *n_added,
+                     double *final_max);
 
 /* ---- tuning knobs (benchmarks only) -------------------------------------- */
 /* frames per lane of the distance kernel: 1, 2 or 4; 0 = choose from the

@@ -94,3 +94,44 @@ def test_feature_metric_many_features():
     y = rng.normal(size=5000).astype(np.float32)
     np.testing.assert_array_equal(libdist.euclidean(X, y), of.euclidean(X, y))
     np.testing.assert_array_equal(libdist.manhattan(X, y), of.manhattan(X, y))
+
+
+@pytest.mark.gpu
+def test_resident_feature_kcenters_equals_the_host_loop():
+    """kcenters(X, 'euclidean' | 'manhattan') on an array runs the whole loop
+    on the device (ek_feat_kcenters); a wrapped callable of the same metric
+    runs the reference-shaped host loop (kcenters.py:217-231, :243-311).  Same
+    centers, labels, distances -- float32, float64 and integer features (exact
+    ties), count and cut-off stop rules, a warm start, more centers than
+    distinct points."""
+    from enspara_amd.cluster.kcenters import kcenters
+    from enspara_amd.geometry import libdist
+    rng = np.random.RandomState(5)
+    cases = [
+        (rng.normal(size=(3001, 17)).astype(np.float32), dict(n_clusters=40)),
+        (rng.normal(size=(2048, 9)), dict(n_clusters=np.inf, dist_cutoff=2.5)),
+        (rng.randint(0, 4, size=(1500, 6)).astype(np.int64), dict(n_clusters=70)),
+        (rng.randint(0, 3, size=(300, 3)).astype(np.float32),
+         dict(n_clusters=60)),                  # 27 distinct points, 60 centers
+        (rng.normal(size=(700, 2100)).astype(np.float32), dict(n_clusters=12)),
+        (rng.normal(size=(5, 4)), dict(n_clusters=3)),
+    ]
+    for X, kw in cases:
+        for name, fn in (("euclidean", libdist.euclidean),
+                         ("manhattan", libdist.manhattan)):
+            got = kcenters(X, name, **kw)
+            want = kcenters(X, lambda A, y, f=fn: f(A, y), **kw)
+            assert list(got.center_indices) == list(want.center_indices), name
+            np.testing.assert_array_equal(got.assignments, want.assignments)
+            np.testing.assert_array_equal(got.distances, want.distances)
+            assert got.distances.dtype == want.distances.dtype
+            assert got.assignments.dtype == want.assignments.dtype
+    # warm start: init centers, then more
+    X = rng.normal(size=(1200, 8)).astype(np.float32)
+    init = [X[3], X[700], X[11]]
+    got = kcenters(X, "euclidean", n_clusters=15, init_centers=init)
+    want = kcenters(X, lambda A, y: libdist.euclidean(A, y), n_clusters=15,
+                    init_centers=init)
+    assert list(got.center_indices) == list(want.center_indices)
+    np.testing.assert_array_equal(got.assignments, want.assignments)
+    np.testing.assert_array_equal(got.distances, want.distances)
