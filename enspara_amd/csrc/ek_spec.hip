@@ -560,6 +560,20 @@ ek_pass2_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
     const int label = plan->label;
     static_assert(EK_BLOCK == EK_TILE, "one workgroup per tile");
     const int64_t f = (int64_t)blockIdx.x * EK_BLOCK + tid;
+#ifdef EK_PASS2_STAGGER
+    // measurement builds: de-phase the workgroups that share a SIMD (the first
+    // wave of workgroups starts together and every tile takes the same time, so
+    // their load-free solve tails coincide): class k starts k * STAGGER * 3.9 us late
+    if (blockIdx.x < 1024) {
+#if EK_PASS2_STAGGER_MODE == 0
+        const int cls = (blockIdx.x >> 8) & 3;
+#else
+        const int cls = (blockIdx.x >> 3) & 3;
+#endif
+        for (int q = 0; q < cls * EK_PASS2_STAGGER; ++q)
+            __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     // FUSE: the last workgroup does a little more at the end (see there), and
     // "last" is decided by arrival tickets.  Only the workgroups that own one of
     // the round's guesses produce something it reads; every other workgroup
