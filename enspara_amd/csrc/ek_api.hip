@@ -157,7 +157,8 @@ struct ek_ctx {
     EkChainOrd *ord = nullptr;
     EkChainRow *rows = nullptr;      // [EK_MAX_CANDS] candidate frames' rows
     uint32_t *vmask = nullptr;       // [n_pad / 64] which vectors a wave stored
-    unsigned int *tick = nullptr;    // [4] arrival counters
+    unsigned int *tick = nullptr;    // [256] arrival counters: [0] pass, [1] chain,
+                                     // [2] + [64..96) next, [128] + [129..161) PAM cost sums
     float *ctile = nullptr;      // the round's candidates, [atom][pair][xyz][2]
     double *ctrace = nullptr;    // their traces
     int chain = 1;               // 1: chained cheap steps, 0: one launch pair per center
@@ -412,7 +413,7 @@ extern "C" int ek_ctx_create(int device, int64_t n_frames, int32_t n_atoms,
     EK_ALLOC(c->hdr, sizeof(EkMaxHdr));
     EK_ALLOC(c->pend, sizeof(EkPend));
     EK_ALLOC(c->ord, sizeof(EkChainOrd));
-    EK_ALLOC(c->tick, 4 * sizeof(unsigned int));
+    EK_ALLOC(c->tick, 256 * sizeof(unsigned int));
     EK_ALLOC(c->rows, EK_MAX_CANDS * sizeof(EkChainRow));
     EK_ALLOC(c->vmask, (nt * EK_TILE / EK_WAVE) * sizeof(uint32_t));
     EK_ALLOC(c->ctile, ek_ctile_bytes(n_atoms));
@@ -438,7 +439,7 @@ extern "C" int ek_ctx_create(int device, int64_t n_frames, int32_t n_atoms,
     if (e == hipSuccess)
         e = hipMemsetAsync(c->ord, 0, sizeof(EkChainOrd), c->stream);
     if (e == hipSuccess)
-        e = hipMemsetAsync(c->tick, 0, 4 * sizeof(unsigned int), c->stream);
+        e = hipMemsetAsync(c->tick, 0, 256 * sizeof(unsigned int), c->stream);
     if (e == hipSuccess)
         e = hipMemsetAsync(c->rows, 0, EK_MAX_CANDS * sizeof(EkChainRow),
                            c->stream);
@@ -1571,7 +1572,7 @@ static int ek_pam_tail(ek_ctx *c, int32_t cid, const float *newd,
                          win_count, c->pw_shapes, c->pw_n_full, c->pw_leaves,
                          c->pw_chunks, c->sq_part, c->amb_count, c->moved, out,
                          c->stream, fuse ? c->amb_best : nullptr,
-                         (fuse && c->pw_tail_ok) ? c->tick + 3 : nullptr);
+                         (fuse && c->pw_tail_ok) ? c->tick + 128 : nullptr);
     EK_CHECK_LAUNCH();
     return EK_OK;
 }

@@ -856,27 +856,25 @@ ek_pw_leaf_kernel(const float *__restrict__ a, float *__restrict__ b,
         return;
     // ---- the last workgroup: chunk trees, then the chunks left to right --------
     // (what ek_pw_chunk_kernel and ek_pw_pack_kernel do in launches of their own)
-    if (!ek_arrive_last(tl.tick))
+    if (!ek_arrive_last_tree(tl.tick, tl.tick + 1))
         return;
-    __shared__ double ca[EK_BLOCK], cb[EK_BLOCK];
+    // four threads per full chunk, one 16-leaf subtree each (one batch of
+    // coherent loads per thread); 64 chunks per trip of the workgroup
+    constexpr int CPT = EK_BLOCK / 4;           // chunks per trip
+    __shared__ double qa[EK_BLOCK], qb[EK_BLOCK];
+    __shared__ double ca[CPT], cb[CPT];
     __shared__ double la[2 * EK_PW_MAX_LEAVES], lb[2 * EK_PW_MAX_LEAVES];
     const int t = threadIdx.x;
     double sa = 0.0, sb = 0.0;
-    for (int c0 = 0; c0 < tl.n_chunks; c0 += EK_BLOCK) {
-        const int c = c0 + t;
+    for (int c0 = 0; c0 < tl.n_chunks; c0 += CPT) {
+        const int c = c0 + t / 4, q = t & 3;
         if (c < n_full) {
             // a full chunk is a perfect in-order binary tree over its 64 leaves
             // (checked on the host): four subtrees of 16, then two levels
-            const size_t first = (size_t)c * EK_PW_FULL_LEAVES;
-            double pa[4], pb[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                pa[q] = ek_pw_sum16(leafsum, first + 16 * q, 0);
-                pb[q] = ek_pw_sum16(leafsum, first + 16 * q, 1);
-            }
-            ca[t] = (pa[0] + pa[1]) + (pa[2] + pa[3]);
-            cb[t] = (pb[0] + pb[1]) + (pb[2] + pb[3]);
-        } else if (c == n_full && c < tl.n_chunks) {
+            const size_t first = (size_t)c * EK_PW_FULL_LEAVES + 16 * q;
+            qa[t] = ek_pw_sum16(leafsum, first, 0);
+            qb[t] = ek_pw_sum16(leafsum, first, 1);
+        } else if (c == n_full && c < tl.n_chunks && q == 0) {
             // the last, shorter chunk: its own tree, node by node
             const EkPwShape *sh = &shapes[1];
             const size_t first = (size_t)n_full * EK_PW_FULL_LEAVES;
@@ -890,12 +888,17 @@ ek_pw_leaf_kernel(const float *__restrict__ a, float *__restrict__ b,
                 lb[nl + k] = lb[sh->node_l[k]] + lb[sh->node_r[k]];
             }
             const int root = (sh->n_nodes > 0) ? nl + sh->n_nodes - 1 : 0;
-            ca[t] = la[root];
-            cb[t] = lb[root];
+            ca[t / 4] = la[root];
+            cb[t / 4] = lb[root];
+        }
+        __syncthreads();
+        if (c < n_full && q == 0) {
+            ca[t / 4] = (qa[t] + qa[t + 1]) + (qa[t + 2] + qa[t + 3]);
+            cb[t / 4] = (qb[t] + qb[t + 1]) + (qb[t + 2] + qb[t + 3]);
         }
         __syncthreads();
         if (t == 0) {
-            const int mm = (tl.n_chunks - c0 < EK_BLOCK) ? tl.n_chunks - c0 : EK_BLOCK;
+            const int mm = (tl.n_chunks - c0 < CPT) ? tl.n_chunks - c0 : CPT;
             for (int k = 0; k < mm; ++k) {
                 sa = sa + ca[k];
                 sb = sb + cb[k];
@@ -911,7 +914,6 @@ ek_pw_leaf_kernel(const float *__restrict__ a, float *__restrict__ b,
         // every workgroup's bits are in: they were OR-ed before its ticket
         tl.out->moved = __hip_atomic_load(mask, __ATOMIC_RELAXED,
                                           __HIP_MEMORY_SCOPE_AGENT);
-        *tl.tick = 0;
     }
 }
 

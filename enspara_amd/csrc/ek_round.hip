@@ -245,7 +245,7 @@ ek_round_next_kernel(EkRound r, int bootstrap)
             }
         }
     }
-    if (!ek_arrive_last(r.tick + 2))
+    if (!ek_arrive_last_tree(r.tick + 2, r.tick + 64))
         return;
     // ---- the next round ----------------------------------------------------------
     __shared__ float sD[EK_TOP_M * EK_TOP_M];
@@ -377,7 +377,6 @@ ek_round_next_kernel(EkRound r, int bootstrap)
             if (!done && ns > 0)
                 r.ctl->stopped = 1;     // maxdist <= cutoff
         }
-        r.tick[2] = 0;
     }
 }
 

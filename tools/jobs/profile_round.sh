@@ -21,3 +21,10 @@ rm -rf $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE
 head -12 $out/kernel_summary.csv | cut -c1-110
 grep -E "pass2|step_kernel" $out/pmc_summary.csv
 cut -c1-400 $out/bench_default.json
+# nearest-center assignment (predict), 10^6 x 5000: a rocprof row for the MFMA kernel
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_assign -- python3 tools/quick_bench2.py 1000000 300 5000 assign > $out/assign.log 2> $out/assign.err
+f=$(find $out/trace_assign -name "*kernel_trace.csv" | head -1)
+python3 tools/summarize_profile.py trace $f $out/kernel_summary_assign.csv
+rm -rf $out/trace_assign
+grep -E "assign" $out/kernel_summary_assign.csv | cut -c1-110
+grep -E "assign n=" $out/assign.log

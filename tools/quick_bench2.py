@@ -20,8 +20,9 @@ if "assign" in what or "pam" in what:
     print("kcenters K=%d: %.2fs  maxdist %.4f" % (K, time.time() - t, mx), flush=True)
 if "assign" in what:
     ctr = x[idx]
-    for variant, kk, abl in [(2, K, 0), (2, K, 1), (2, K, 2), (2, K, 3)]:
-        st.set_option(2, variant); st.set_option(3, abl)
+    # (timing-only ablations of the MFMA kernel need a -DEK_ASSIGN_ABLATE=n build)
+    for variant, kk, abl in [(2, K, 0), (1, K, 0)]:
+        st.set_option(2, variant)
         st.assign_nearest(ctr[:kk]); st.sync()
         t = time.time()
         st.assign_nearest(ctr[:kk]); st.sync()
