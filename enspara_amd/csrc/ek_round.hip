@@ -37,7 +37,7 @@
 #define EK_ROUND_FPT 4              // frames per thread there (16-byte loads)
 
 // ---------------------------------------------------------------------------
-// chain: states after the prefixes, decide, farthest block maxima + gather
+// chain: states after the prefixes, decide, farthest block maxima
 // ---------------------------------------------------------------------------
 // pm[(k - 1) * nb + w] = first-index arg-max over frames [256 w, 256 w + 256) of
 // min(dist, vec[order[0]], .., vec[order[k-1]]), k = 1 .. cn (state 0 is what the

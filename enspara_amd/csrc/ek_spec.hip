@@ -19,9 +19,16 @@
 // its distances come from the same per-pair FMA chain + quartic solve as the
 // one-center kernel, so nothing about the result depends on which candidates
 // were guessed -- only the number of passes does.  All decisions are taken on
-// the device by single-workgroup kernels that are the sole writers of the plan
-// the following kernels read, so no kernel reads state another workgroup of the
-// same launch writes.
+// the device.  In the one-launch-per-step form (this file + ek_chain.hip: what
+// the multi-shard protocol uses, an exchange sitting between the steps) they
+// are taken by single-workgroup kernels that are the sole writers of the plan
+// the following kernels read; a single shard runs the same steps in three
+// launches (ek_round.hip), the single-workgroup parts riding in the last
+// workgroup of the launch that produces their input.
+//
+// Two forms of the pass kernel live here: ek_pass2_kernel (candidates as scalar
+// operands, the default) and ek_pass_kernel (candidates staged in LDS, round 1;
+// ek_set_option key 9).  Same arithmetic, same bits.
 #include "ek_common.h"
 #include "ek_qcp.h"
 #include "ek_reduce.h"
