@@ -1326,12 +1326,14 @@ static int ek_pam_alloc(ek_ctx *c, int32_t K)
             const int last_len = (int)(c->n - n_full * EK_PW_CHUNK);
             ek_pw_build_shape(n_full > 0 ? EK_PW_CHUNK : 0, &hs[0]);
             ek_pw_build_shape(last_len, &hs[1]);
-            // the one-launch cost sums (ek_pw_leaf_kernel<.., true>) add a full
-            // chunk's 64 leaf sums as a perfect in-order binary tree: true for
+            // the one-launch cost sums (ek_pw_window_kernel) add a full chunk's
+            // 64 leaves of 128 as a perfect in-order binary tree: true for
             // numpy's pairwise split of 8192 elements, checked here
             {
                 bool ok = n_full == 0 ||
                           (hs[0].n_leaves == EK_PW_FULL_LEAVES && hs[0].n_levels == 6);
+                for (int i = 0; ok && n_full > 0 && i < EK_PW_FULL_LEAVES; ++i)
+                    ok = hs[0].leaf_off[i] == 128 * i && hs[0].leaf_len[i] == 128;
                 for (int k = 0; ok && n_full > 0 && k < hs[0].n_nodes; ++k) {
                     // level-ordered nodes: level 1 joins leaves (2j, 2j+1), ..
                     const int lev_start[7] = {0, 32, 48, 56, 60, 62, 63};
@@ -1541,16 +1543,26 @@ extern "C" int ek_pam_select_member(ek_ctx *c, int32_t cid, int64_t j,
 // medoids, both cost sums and the moved-cluster mask, packed into *out (device).
 // No read-back.  max_amb bounds the ambiguous set (a subset of cluster cid's
 // members) and sizes the follow-up launches.
-// fuse != 0 (the window run): ambiguous members stay marked in the trial state
-// until the cost sums resolve them -- no scatter launch
+// decide != nullptr (a slot of the window run): three launches -- the
+// classification first takes over the trial state of the slot before if
+// *prev_accept says it was accepted, ambiguous members stay marked in the trial
+// state until the cost-sum launch resolves them, and that launch's last
+// workgroup decides the proposal (EkPamDecide) -- and nothing else to do
 static int ek_pam_tail(ek_ctx *c, int32_t cid, const float *newd,
                        int64_t max_amb, int32_t win_lo, int32_t win_count,
-                       EkPamOut *out, int fuse = 0)
+                       EkPamOut *out, const EkPamDecide *decide = nullptr,
+                       const int32_t *prev_accept = nullptr)
 {
     const int K = c->med_K;
-    ek_launch_pam_classify(c->dist, c->assign, newd, c->n, cid, c->ndist,
-                           c->nassign, c->amb, c->amb_best, c->amb_count,
-                           c->amb_count + 1, c->stream, fuse);
+    const int fuse = decide != nullptr;
+    if (fuse)
+        ek_launch_pam_classify_apply(c->dist, c->assign, newd, c->n, cid, c->ndist,
+                                     c->nassign, c->amb, c->amb_best, c->amb_count,
+                                     c->amb_count + 1, prev_accept, c->stream);
+    else
+        ek_launch_pam_classify(c->dist, c->assign, newd, c->n, cid, c->ndist,
+                               c->nassign, c->amb, c->amb_best, c->amb_count,
+                               c->amb_count + 1, c->stream, 0);
     // only when dist[f] is known to be the distance to medoid assign[f] (a state
     // this library produced; not one uploaded by the caller) may the search skip
     // medoids out of the members' reach
@@ -1572,7 +1584,7 @@ static int ek_pam_tail(ek_ctx *c, int32_t cid, const float *newd,
                          win_count, c->pw_shapes, c->pw_n_full, c->pw_leaves,
                          c->pw_chunks, c->sq_part, c->amb_count, c->moved, out,
                          c->stream, fuse ? c->amb_best : nullptr,
-                         (fuse && c->pw_tail_ok) ? c->tick + 128 : nullptr);
+                         fuse ? c->tick + 128 : nullptr, decide);
     EK_CHECK_LAUNCH();
     return EK_OK;
 }
@@ -1992,6 +2004,9 @@ extern "C" int ek_pam_window_run(ek_ctx *c, int32_t cid0, int32_t count,
         return ek_fail(EK_EARG, "ek_pam_window_run: the stale-mask window "
                                 "[%d,+%d) must start at cid0 = %d and cover the "
                                 "%d slots", win_lo, win_count, cid0, count);
+    if (!c->pw_tail_ok)
+        return ek_fail(EK_ESTATE, "ek_pam_window_run: the pairwise-sum shape of a "
+                                  "full chunk is not the expected perfect tree");
     EK_HIP(hipSetDevice(c->device));
     int64_t max_m = 0;
     const float *newd[EK_MAX_CANDS];
@@ -2025,19 +2040,37 @@ extern "C" int ek_pam_window_run(ek_ctx *c, int32_t cid0, int32_t count,
                                 c->pam_restore, frames[i], nullptr, nullptr,
                                 nullptr, c->amb_count, c->moved, c->stream);
         c->pam_restore = -1;
+        const bool more = i + 1 < count;
+        EkPamDecide dc;
+        dc.win = c->pam_win_dev;
+        dc.slot = i;
+        dc.n_total = (double)c->n;
+        dc.aos = c->med_aos;
+        dc.Gm = c->med_G;
+        dc.A = c->A;
+        dc.K = K;
+        dc.cid = cid;
+        dc.med_idx = c->med_idx;
+        dc.frame = frames[i];
+        dc.max_amb = n_members[i];
+        dc.next_cid = more ? cid + 1 : -1;
+        dc.next_frame = more ? frames[i + 1] : 0;
+        dc.frames_aos = c->aos;
+        dc.G = c->G;
+        dc.amb_count = c->amb_count;
+        dc.moved = c->moved;
         rc = ek_pam_tail(c, cid, newd[i], n_members[i], win_lo, win_count,
-                         &c->pam_win_dev->out[i], 1);
+                         &c->pam_win_dev->out[i], &dc,
+                         i > 0 ? &c->pam_win_dev->accept[i - 1] : &c->pam_win_dev->pad);
         if (rc)
             return rc;
-        const bool more = i + 1 < count;
-        ek_launch_pam_decide(c->pam_win_dev, i, (double)c->n, c->dist, c->ndist,
-                             c->assign, c->nassign, c->n, c->med_aos, c->med_G, c->A,
-                             K, cid, c->med_idx, frames[i], n_members[i],
-                             more ? cid + 1 : -1, more ? frames[i + 1] : 0, c->aos,
-                             c->G, c->amb_count, c->moved, c->stream);
-        EK_CHECK_LAUNCH();
         ++c->pf_hits;
     }
+    // the last slot's trial state, if accepted (the others were taken over by
+    // the classification of the slot after them)
+    ek_launch_pam_apply(&c->pam_win_dev->accept[count - 1], c->dist, c->ndist,
+                        c->assign, c->nassign, c->n, c->stream);
+    EK_CHECK_LAUNCH();
     EK_HIP(hipMemcpyAsync(c->pam_win_host, c->pam_win_dev, sizeof(EkPamWin),
                           hipMemcpyDeviceToHost, c->stream));
     EK_HIP(ek_wait(c));

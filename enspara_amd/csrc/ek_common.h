@@ -235,6 +235,14 @@ void ek_launch_pam_classify(const float *dist, const int32_t *assign,
                             unsigned long long *amb_best,
                             unsigned int *amb_count, unsigned int *reach,
                             hipStream_t s, int mark = 0);
+// the same inside a window: if *prev_accept != 0 the trial state of the slot
+// before (ndist / nassign, about to be overwritten) first becomes the state
+void ek_launch_pam_classify_apply(float *dist, int32_t *assign, const float *newd,
+                                  int64_t n, int32_t cid, float *ndist,
+                                  int32_t *nassign, uint32_t *amb,
+                                  unsigned long long *amb_best,
+                                  unsigned int *amb_count, unsigned int *reach,
+                                  const int32_t *prev_accept, hipStream_t s);
 // medoids within reach of the ambiguous members -> list / n_list
 void ek_launch_pam_prune(const float *aos, const double *Gm, int A, int K, int cid,
                          const unsigned int *reach, int32_t *list,
@@ -271,14 +279,29 @@ struct EkPamWin {
     int32_t accept[EK_MAX_CANDS];
     EkPamOut out[EK_MAX_CANDS];
 };
-void ek_launch_pam_decide(EkPamWin *win, int slot, double n_total, float *dist,
-                          const float *ndist, int32_t *assign,
-                          const int32_t *nassign, int64_t n, float *aos,
-                          double *Gm, int A, int K, int cid, int64_t *med_idx,
-                          int64_t frame, int64_t max_amb, int next_cid,
-                          int64_t next_frame, const float *frames_aos,
-                          const double *G, unsigned int *amb_count,
-                          unsigned int *moved, hipStream_t s);
+// what the last workgroup of a proposal's cost-sum launch needs to decide the
+// proposal and to set up the next one (ek_pam.hip, "a window of proposals")
+struct EkPamDecide {
+    EkPamWin *win;
+    int32_t slot;
+    double n_total;             // frames of all shards: the means' divisor
+    float *aos;                 // trial medoid table [K + 1][3A], row K = saved row
+    double *Gm;
+    int32_t A, K, cid;
+    int64_t *med_idx;           // medoid frame indices (may be nullptr)
+    int64_t frame;              // the frame proposed for cluster cid
+    int64_t max_amb;
+    int32_t next_cid;           // -1: last slot of the window
+    int64_t next_frame;
+    const float *frames_aos;    // frame-major copy of the shard
+    const double *G;
+    unsigned int *amb_count;
+    unsigned int *moved;
+};
+// the state takes over the trial state if *flag != 0 (after a window's last slot)
+void ek_launch_pam_apply(const int32_t *flag, float *dist, const float *ndist,
+                         int32_t *assign, const int32_t *nassign, int64_t n,
+                         hipStream_t s);
 // active-set proposal prefetch (ek_pam.hip)
 void ek_launch_pam_dtab(const float *aos, const double *Gm, int A, int K, int held,
                         const unsigned char *recs, int count, float *Dtab,
@@ -324,7 +347,8 @@ void ek_launch_sumsq_pack(const float *a, float *b, const int32_t *assign,
                           const unsigned int *n_amb, unsigned int *moved,
                           EkPamOut *out, hipStream_t s,
                           const unsigned long long *amb_best = nullptr,
-                          unsigned int *tick = nullptr);
+                          unsigned int *tick = nullptr,
+                          const EkPamDecide *decide = nullptr);
 void ek_launch_gather_rows(const float *tiles, const double *G, int A,
                            const int64_t *idx_dev, const int64_t *rows_dev,
                            int count, float *out_aos, double *outG, hipStream_t s);

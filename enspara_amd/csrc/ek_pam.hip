@@ -11,6 +11,7 @@
 #include "ek_common.h"
 #include "ek_reduce.h"
 #include <algorithm>
+#include <type_traits>
 #include "ek_qcp.h"
 
 // ---- medoid table: centred coordinates of chosen frames, center-major --------
@@ -313,22 +314,44 @@ void ek_launch_select_member_multi(const int32_t *assign, int64_t n, int32_t cid
 //   dist <= newd and assign == cid   -> ambiguous: listed, resolved below
 // MARK: an ambiguous member's trial label is -2 - (its position in the list)
 // until the cost-sum kernel resolves it from amb_best (no scatter launch)
-template <bool MARK>
+// APPLY (inside a window, ek_pam_window_run): the slot before left its trial
+// state in ndist / nassign and its verdict in *prev_accept; an accepted trial
+// state is the state this proposal starts from, and is written back as such
+// (kmedoids.py:684-690) on the way -- no launch of its own for that.
+template <bool MARK, bool APPLY>
 __global__ void __launch_bounds__(EK_BLOCK)
-ek_pam_classify_kernel(const float *__restrict__ dist,
-                       const int32_t *__restrict__ assign,
+ek_pam_classify_kernel(typename std::conditional<APPLY, float, const float>::type
+                           *__restrict__ dist,
+                       typename std::conditional<APPLY, int32_t, const int32_t>::type
+                           *__restrict__ assign,
                        const float *__restrict__ newd, int64_t n, int32_t cid,
                        float *__restrict__ ndist, int32_t *__restrict__ nassign,
                        uint32_t *__restrict__ amb,
                        unsigned long long *__restrict__ amb_best,
                        unsigned int *__restrict__ amb_count,
-                       unsigned int *__restrict__ reach)
+                       unsigned int *__restrict__ reach,
+                       const int32_t *__restrict__ prev_accept)
 {
     const int64_t f = (int64_t)blockIdx.x * EK_BLOCK + threadIdx.x;
     if (f >= n)
         return;
-    const float d = dist[f], nd = newd[f];
-    const int32_t a = assign[f];
+    float d;
+    int32_t a;
+    if constexpr (APPLY) {
+        if (*prev_accept) {
+            d = ndist[f];
+            a = nassign[f];
+            dist[f] = d;
+            assign[f] = a;
+        } else {
+            d = dist[f];
+            a = assign[f];
+        }
+    } else {
+        d = dist[f];
+        a = assign[f];
+    }
+    const float nd = newd[f];
     if (d > nd) {
         ndist[f] = nd;
         nassign[f] = cid;
@@ -360,13 +383,53 @@ void ek_launch_pam_classify(const float *dist, const int32_t *assign,
     if (nblocks <= 0)
         return;
     if (mark)
-        hipLaunchKernelGGL(ek_pam_classify_kernel<true>, dim3(nblocks),
+        hipLaunchKernelGGL((ek_pam_classify_kernel<true, false>), dim3(nblocks),
                            dim3(EK_BLOCK), 0, s, dist, assign, newd, n, cid, ndist,
-                           nassign, amb, amb_best, amb_count, reach);
+                           nassign, amb, amb_best, amb_count, reach, nullptr);
     else
-        hipLaunchKernelGGL(ek_pam_classify_kernel<false>, dim3(nblocks),
+        hipLaunchKernelGGL((ek_pam_classify_kernel<false, false>), dim3(nblocks),
                            dim3(EK_BLOCK), 0, s, dist, assign, newd, n, cid, ndist,
-                           nassign, amb, amb_best, amb_count, reach);
+                           nassign, amb, amb_best, amb_count, reach, nullptr);
+}
+
+void ek_launch_pam_classify_apply(float *dist, int32_t *assign, const float *newd,
+                                  int64_t n, int32_t cid, float *ndist,
+                                  int32_t *nassign, uint32_t *amb,
+                                  unsigned long long *amb_best,
+                                  unsigned int *amb_count, unsigned int *reach,
+                                  const int32_t *prev_accept, hipStream_t s)
+{
+    const int nblocks = (int)((n + EK_BLOCK - 1) / EK_BLOCK);
+    if (nblocks <= 0)
+        return;
+    hipLaunchKernelGGL((ek_pam_classify_kernel<true, true>), dim3(nblocks),
+                       dim3(EK_BLOCK), 0, s, dist, assign, newd, n, cid, ndist,
+                       nassign, amb, amb_best, amb_count, reach, prev_accept);
+}
+
+__global__ void __launch_bounds__(EK_BLOCK)
+ek_pam_apply_kernel(const int32_t *__restrict__ flag, float *__restrict__ dist,
+                    const float *__restrict__ ndist, int32_t *__restrict__ assign,
+                    const int32_t *__restrict__ nassign, int64_t n)
+{
+    if (!*flag)
+        return;
+    const int64_t f = (int64_t)blockIdx.x * EK_BLOCK + threadIdx.x;
+    if (f < n) {
+        dist[f] = ndist[f];
+        assign[f] = nassign[f];
+    }
+}
+
+void ek_launch_pam_apply(const int32_t *flag, float *dist, const float *ndist,
+                         int32_t *assign, const int32_t *nassign, int64_t n,
+                         hipStream_t s)
+{
+    const int nblocks = (int)((n + EK_BLOCK - 1) / EK_BLOCK);
+    if (nblocks <= 0)
+        return;
+    hipLaunchKernelGGL(ek_pam_apply_kernel, dim3(nblocks), dim3(EK_BLOCK), 0, s,
+                       flag, dist, ndist, assign, nassign, n);
 }
 
 // ---- which medoids can matter to the ambiguous members --------------------------------
@@ -726,38 +789,7 @@ __device__ __forceinline__ void ek_pw_fetch(const float *a, float *b,
     vb = fb;
 }
 
-// what the last workgroup of the leaf kernel needs to finish the sums itself
-// (TAIL): the chunk trees and the left-to-right total, packed into *out
-struct EkPwTail {
-    unsigned int *tick;
-    int n_chunks;
-    const unsigned int *n_amb;
-    int64_t n;
-    EkPamOut *out;
-};
-
-__device__ __forceinline__ double ek_coh_ld_f64(const double *p)
-{
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// in-order pairwise sum of 16 consecutive leaf sums (a perfect subtree)
-__device__ __forceinline__ double ek_pw_sum16(const double *leafsum, size_t first,
-                                              int which)
-{
-    double v[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i)
-        v[i] = ek_coh_ld_f64(&leafsum[2 * (first + i) + which]);
-#pragma unroll
-    for (int w = 1; w < 16; w <<= 1)
-#pragma unroll
-        for (int i = 0; i < 16; i += 2 * w)
-            v[i] = v[i] + v[i + w];
-    return v[0];
-}
-
-template <bool RESOLVE, bool TAIL>
+template <bool RESOLVE>
 __global__ void __launch_bounds__(EK_BLOCK)
 ek_pw_leaf_kernel(const float *__restrict__ a, float *__restrict__ b,
                   const int32_t *__restrict__ assign,
@@ -766,7 +798,7 @@ ek_pw_leaf_kernel(const float *__restrict__ a, float *__restrict__ b,
                   int32_t win_lo,
                   int32_t win_count, const EkPwShape *__restrict__ shapes,
                   int n_full, int n_leaves_total, double *__restrict__ leafsum,
-                  unsigned int *__restrict__ mask, EkPwTail tl)
+                  unsigned int *__restrict__ mask)
 {
     __shared__ unsigned int acc;
     if (threadIdx.x == 0)
@@ -836,15 +868,8 @@ ek_pw_leaf_kernel(const float *__restrict__ a, float *__restrict__ b,
                     }
                 }
             }
-            if (TAIL) {         // read by the last workgroup: coherent stores
-                __hip_atomic_store(&leafsum[2 * (size_t)g + 0], ra,
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&leafsum[2 * (size_t)g + 1], rb,
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                leafsum[2 * (size_t)g + 0] = ra;
-                leafsum[2 * (size_t)g + 1] = rb;
-            }
+            leafsum[2 * (size_t)g + 0] = ra;
+            leafsum[2 * (size_t)g + 1] = rb;
         }
     }
     if (m)
@@ -852,69 +877,6 @@ ek_pw_leaf_kernel(const float *__restrict__ a, float *__restrict__ b,
     __syncthreads();
     if (threadIdx.x == 0 && acc)
         atomicOr(mask, acc);
-    if (!TAIL)
-        return;
-    // ---- the last workgroup: chunk trees, then the chunks left to right --------
-    // (what ek_pw_chunk_kernel and ek_pw_pack_kernel do in launches of their own)
-    if (!ek_arrive_last_tree(tl.tick, tl.tick + 1))
-        return;
-    // four threads per full chunk, one 16-leaf subtree each (one batch of
-    // coherent loads per thread); 64 chunks per trip of the workgroup
-    constexpr int CPT = EK_BLOCK / 4;           // chunks per trip
-    __shared__ double qa[EK_BLOCK], qb[EK_BLOCK];
-    __shared__ double ca[CPT], cb[CPT];
-    __shared__ double la[2 * EK_PW_MAX_LEAVES], lb[2 * EK_PW_MAX_LEAVES];
-    const int t = threadIdx.x;
-    double sa = 0.0, sb = 0.0;
-    for (int c0 = 0; c0 < tl.n_chunks; c0 += CPT) {
-        const int c = c0 + t / 4, q = t & 3;
-        if (c < n_full) {
-            // a full chunk is a perfect in-order binary tree over its 64 leaves
-            // (checked on the host): four subtrees of 16, then two levels
-            const size_t first = (size_t)c * EK_PW_FULL_LEAVES + 16 * q;
-            qa[t] = ek_pw_sum16(leafsum, first, 0);
-            qb[t] = ek_pw_sum16(leafsum, first, 1);
-        } else if (c == n_full && c < tl.n_chunks && q == 0) {
-            // the last, shorter chunk: its own tree, node by node
-            const EkPwShape *sh = &shapes[1];
-            const size_t first = (size_t)n_full * EK_PW_FULL_LEAVES;
-            const int nl = sh->n_leaves;
-            for (int i = 0; i < nl; ++i) {
-                la[i] = ek_coh_ld_f64(&leafsum[2 * (first + i) + 0]);
-                lb[i] = ek_coh_ld_f64(&leafsum[2 * (first + i) + 1]);
-            }
-            for (int k = 0; k < sh->n_nodes; ++k) {     // children come first
-                la[nl + k] = la[sh->node_l[k]] + la[sh->node_r[k]];
-                lb[nl + k] = lb[sh->node_l[k]] + lb[sh->node_r[k]];
-            }
-            const int root = (sh->n_nodes > 0) ? nl + sh->n_nodes - 1 : 0;
-            ca[t / 4] = la[root];
-            cb[t / 4] = lb[root];
-        }
-        __syncthreads();
-        if (c < n_full && q == 0) {
-            ca[t / 4] = (qa[t] + qa[t + 1]) + (qa[t + 2] + qa[t + 3]);
-            cb[t / 4] = (qb[t] + qb[t + 1]) + (qb[t + 2] + qb[t + 3]);
-        }
-        __syncthreads();
-        if (t == 0) {
-            const int mm = (tl.n_chunks - c0 < CPT) ? tl.n_chunks - c0 : CPT;
-            for (int k = 0; k < mm; ++k) {
-                sa = sa + ca[k];
-                sb = sb + cb[k];
-            }
-        }
-        __syncthreads();
-    }
-    if (t == 0) {
-        tl.out->sum_old = sa;
-        tl.out->sum_new = sb;
-        tl.out->n_frames = tl.n;
-        tl.out->n_amb = *tl.n_amb;
-        // every workgroup's bits are in: they were OR-ed before its ticket
-        tl.out->moved = __hip_atomic_load(mask, __ATOMIC_RELAXED,
-                                          __HIP_MEMORY_SCOPE_AGENT);
-    }
 }
 
 // one workgroup per chunk: the pairwise tree over its leaves, level by level
@@ -988,6 +950,316 @@ ek_pw_pack_kernel(const double *__restrict__ chunksum, int n_chunks,
     out->moved = *moved;
 }
 
+// ---------------------------------------------------------------------------
+// a window of proposals decided on the device (ek_pam_window_run)
+// ---------------------------------------------------------------------------
+// Inside a window a proposal is three launches: classification (which also
+// takes over the trial state of an accepted predecessor), the ambiguous members
+// against the medoids within reach, and this one: cost sums, verdict, set-up of
+// the next proposal.
+//
+// Cost sums: a workgroup covers 32 leaves = 4096 consecutive frames = half a
+// numpy chunk, a perfect subtree of the pairwise sum, so it adds its leaves up
+// itself (adjacent pairs, level by level: floating-point addition commutes, so
+// a butterfly over lanes gives every lane the in-order result) and hands ONE
+// pair of sums to the last workgroup to finish (arrival counter, coherent
+// stores / loads: ek_reduce.h).  The leaves of the shorter last chunk go through
+// individually and are summed along that chunk's own tree.
+//
+// Verdict, by the last workgroup once the sums are in: accept iff
+// mean(new^2) < mean(old^2), both in float64 (kmedoids.py:478-479, :683) -- the
+// same two divisions and comparison the host made -- and
+//   accepted: the cluster's medoid index is the proposed frame, the clusters of
+//             the window whose membership changes are marked stale; the first
+//             stale cluster after this one is where the window stops: its
+//             proposal was drawn from a member list that no longer holds
+//             (kmedoids.py:611-614).  The trial state becomes the state
+//             (kmedoids.py:684-690) in the next slot's classification launch,
+//             or in ek_pam_apply_kernel after the last slot;
+//   rejected (or past the stop): the medoid table gets its row back.
+// Then the NEXT proposal's trial table is set up (what ek_pam_trial_kernel does
+// in a launch of its own).  A slot past the stop still runs its kernels -- they
+// only write scratch -- but nothing of it is kept.
+struct EkPwTail {
+    unsigned int *tick;         // [0] top, [1 ..] EK_ARRIVE_G leaves
+    int n_chunks;
+    const unsigned int *n_amb;
+    int64_t n;
+};
+
+__device__ __forceinline__ double ek_coh_ld_f64(const double *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void ek_coh_st_f64(double *p, double v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+#define EK_PW_WG_LEAVES (EK_BLOCK / 8)      // 32: half a full chunk
+
+__global__ void __launch_bounds__(EK_BLOCK)
+ek_pw_window_kernel(const float *__restrict__ a, float *__restrict__ b,
+                    const int32_t *__restrict__ assign,
+                    int32_t *__restrict__ nassign,
+                    const unsigned long long *__restrict__ amb_best,
+                    int32_t win_lo, int32_t win_count,
+                    const EkPwShape *__restrict__ shapes, int n_full,
+                    int n_leaves_total, double *__restrict__ part,
+                    unsigned int *__restrict__ mask, EkPwTail tl, EkPamDecide dc)
+{
+    static_assert(EK_PW_FULL_LEAVES == 2 * EK_PW_WG_LEAVES, "half a chunk each");
+    __shared__ unsigned int acc;
+    __shared__ double wsum[2][EK_BLOCK / EK_WAVE];
+    const int t = threadIdx.x;
+    if (t == 0)
+        acc = 0;
+    __syncthreads();
+    const int l8 = t & 7;
+    const int n_half = 2 * n_full;              // workgroups over full chunks
+    // part: [2 * n_half] half-chunk sums, then the last chunk's leaf sums
+    double *ragsum = part + 2 * (size_t)n_half;
+    unsigned int m = 0;
+    if ((int)blockIdx.x < n_half) {
+        const int64_t off = ((int64_t)blockIdx.x * EK_PW_WG_LEAVES + t / 8) * 128;
+        float fa[16], fb[16];
+        int32_t oa[16], na[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int64_t f = off + 8 * i + l8;
+            fa[i] = a[f];
+            fb[i] = b[f];
+            oa[i] = assign[f];
+            na[i] = nassign[f];
+        }
+        double ra = 0.0, rb = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (na[i] < -1) {           // marked ambiguous member: resolved now
+                const int64_t f = off + 8 * i + l8;
+                const unsigned long long key = amb_best[-2 - na[i]];
+                fb[i] = __uint_as_float((unsigned int)(key >> 32));
+                na[i] = (int32_t)(key & 0xffffffffu);
+                b[f] = fb[i];
+                nassign[f] = na[i];
+            }
+            const double va = fa[i], vb = fb[i];
+            if (i == 0) {
+                ra = va * va;
+                rb = vb * vb;
+            } else {
+                ra = ra + va * va;
+                rb = rb + vb * vb;
+            }
+            if (win_count > 0 && oa[i] != na[i]) {
+                const int32_t ia = oa[i] - win_lo, ib = na[i] - win_lo;
+                if (ia >= 0 && ia < win_count)
+                    m |= 1u << ia;
+                if (ib >= 0 && ib < win_count)
+                    m |= 1u << ib;
+            }
+        }
+        // the leaf: (r0+r1)+(r2+r3) ..; then the eight leaves of the wave, the
+        // four waves of the workgroup
+#pragma unroll
+        for (int o = 1; o < EK_WAVE; o <<= 1) {
+            ra = ra + __shfl_xor(ra, o, EK_WAVE);
+            rb = rb + __shfl_xor(rb, o, EK_WAVE);
+        }
+        if ((t & (EK_WAVE - 1)) == 0) {
+            wsum[0][t / EK_WAVE] = ra;
+            wsum[1][t / EK_WAVE] = rb;
+        }
+        __syncthreads();
+        if (t < 2)
+            ek_coh_st_f64(&part[2 * (size_t)blockIdx.x + t],
+                          (wsum[t][0] + wsum[t][1]) + (wsum[t][2] + wsum[t][3]));
+    } else {
+        // leaves of the last, shorter chunk (any shape)
+        const EkPwShape *sh = &shapes[1];
+        const int leaf = ((int)blockIdx.x - n_half) * EK_PW_WG_LEAVES + t / 8;
+        if (leaf < sh->n_leaves) {
+            const int64_t off = (int64_t)n_full * EK_PW_CHUNK + sh->leaf_off[leaf];
+            const int len = sh->leaf_len[leaf];
+            double ra = 0.0, rb = 0.0;
+            const int body = (len < 8) ? 0 : len - (len % 8);
+            for (int i = 0; i < body; i += 8) {
+                double va, vb;
+                int32_t oa, na;
+                ek_pw_fetch<true>(a, b, assign, nassign, amb_best, off + i + l8, va,
+                                  vb, oa, na);
+                if (i == 0) {
+                    ra = va * va;
+                    rb = vb * vb;
+                } else {
+                    ra = ra + va * va;
+                    rb = rb + vb * vb;
+                }
+                if (win_count > 0 && oa != na) {
+                    const int32_t ia = oa - win_lo, ib = na - win_lo;
+                    if (ia >= 0 && ia < win_count)
+                        m |= 1u << ia;
+                    if (ib >= 0 && ib < win_count)
+                        m |= 1u << ib;
+                }
+            }
+            if (body > 0) {
+#pragma unroll
+                for (int o = 1; o < 8; o <<= 1) {
+                    ra = ra + __shfl_xor(ra, o, 8);
+                    rb = rb + __shfl_xor(rb, o, 8);
+                }
+            }
+            if (l8 == 0) {
+                for (int i = body; i < len; ++i) {      // sequential tail
+                    double va, vb;
+                    int32_t oa, na;
+                    ek_pw_fetch<true>(a, b, assign, nassign, amb_best, off + i, va,
+                                      vb, oa, na);
+                    ra = ra + va * va;
+                    rb = rb + vb * vb;
+                    if (win_count > 0 && oa != na) {
+                        const int32_t ia = oa - win_lo, ib = na - win_lo;
+                        if (ia >= 0 && ia < win_count)
+                            m |= 1u << ia;
+                        if (ib >= 0 && ib < win_count)
+                            m |= 1u << ib;
+                    }
+                }
+                ek_coh_st_f64(&ragsum[2 * (size_t)leaf + 0], ra);
+                ek_coh_st_f64(&ragsum[2 * (size_t)leaf + 1], rb);
+            }
+        }
+    }
+    if (m)
+        atomicOr(&acc, m);
+    __syncthreads();
+    if (t == 0 && acc)
+        atomicOr(mask, acc);
+    if (!ek_arrive_last_tree(tl.tick, tl.tick + 1))
+        return;
+
+    // ---- the last workgroup: chunk sums, then the chunks left to right ------------
+    __shared__ double ca[EK_BLOCK], cb[EK_BLOCK];
+    __shared__ double la[2 * EK_PW_MAX_LEAVES], lb[2 * EK_PW_MAX_LEAVES];
+    __shared__ int s_accept;
+    if (tl.n_chunks > n_full) {
+        // the last chunk's own tree, level by level
+        const EkPwShape *sh = &shapes[1];
+        const int nl = sh->n_leaves;
+        for (int i = t; i < nl; i += EK_BLOCK) {
+            la[i] = ek_coh_ld_f64(&ragsum[2 * (size_t)i + 0]);
+            lb[i] = ek_coh_ld_f64(&ragsum[2 * (size_t)i + 1]);
+        }
+        __syncthreads();
+        for (int lev = 0; lev < sh->n_levels; ++lev) {
+            const int k0 = sh->level_start[lev], k1 = sh->level_start[lev + 1];
+            for (int k = k0 + t; k < k1; k += EK_BLOCK) {
+                const int l = sh->node_l[k], r = sh->node_r[k];
+                la[nl + k] = la[l] + la[r];
+                lb[nl + k] = lb[l] + lb[r];
+            }
+            __syncthreads();
+        }
+    }
+    double sa = 0.0, sb = 0.0;
+    for (int c0 = 0; c0 < tl.n_chunks; c0 += EK_BLOCK) {
+        const int c = c0 + t;
+        if (c < n_full) {
+            const double a0 = ek_coh_ld_f64(&part[4 * (size_t)c + 0]),
+                         b0 = ek_coh_ld_f64(&part[4 * (size_t)c + 1]),
+                         a1 = ek_coh_ld_f64(&part[4 * (size_t)c + 2]),
+                         b1 = ek_coh_ld_f64(&part[4 * (size_t)c + 3]);
+            ca[t] = a0 + a1;
+            cb[t] = b0 + b1;
+        } else if (c == n_full && c < tl.n_chunks) {
+            const EkPwShape *sh = &shapes[1];
+            const int root = (sh->n_nodes > 0) ? sh->n_leaves + sh->n_nodes - 1 : 0;
+            ca[t] = la[root];
+            cb[t] = lb[root];
+        }
+        __syncthreads();
+        if (t == 0) {
+            const int mm = (tl.n_chunks - c0 < EK_BLOCK) ? tl.n_chunks - c0 : EK_BLOCK;
+            for (int k0 = 0; k0 < mm; k0 += 16) {
+                // sixteen reads in flight, the additions in order
+                double xa[16], xb[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    xa[j] = ca[(k0 + j) & (EK_BLOCK - 1)];
+                    xb[j] = cb[(k0 + j) & (EK_BLOCK - 1)];
+                }
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    if (k0 + j < mm) {
+                        sa = sa + xa[j];
+                        sb = sb + xb[j];
+                    }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- verdict and the next proposal's trial table ---------------------------------
+    EkPamWin *win = dc.win;
+    EkPamOut o;
+    if (t == 0) {
+        o.sum_old = sa;
+        o.sum_new = sb;
+        o.n_frames = tl.n;
+        o.n_amb = *tl.n_amb;
+        // every workgroup's bits are in: they were OR-ed before its ticket
+        o.moved = __hip_atomic_load(mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        win->out[dc.slot] = o;
+        const bool live = dc.slot < win->stop;
+        const double old_cost = o.sum_old / dc.n_total,
+                     new_cost = o.sum_new / dc.n_total;
+        const bool accept = live && new_cost < old_cost;
+        s_accept = accept ? 1 : 0;
+        if (live) {
+            win->accept[dc.slot] = accept ? 1 : 0;
+            if ((int64_t)o.n_amb > dc.max_amb)
+                win->err = 1 + dc.slot;
+            if (accept) {
+                if (dc.med_idx)
+                    dc.med_idx[dc.cid] = dc.frame;
+                const uint32_t stale = win->stale | o.moved;
+                win->stale = stale;
+                const uint32_t later = (dc.slot >= 31) ? 0u : (stale >> (dc.slot + 1));
+                if (later) {
+                    const int first = dc.slot + 1 + (__ffs((int)later) - 1);
+                    if (first < win->stop)
+                        win->stop = first;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const bool accept = s_accept != 0;
+    const int A = dc.A, K = dc.K;
+    // thread t owns elements t, t + 256, .. of every row: no barrier needed
+    for (int r = t; r < 3 * A; r += EK_BLOCK) {
+        if (!accept)
+            dc.aos[(size_t)dc.cid * 3 * A + r] = dc.aos[(size_t)K * 3 * A + r];
+        if (dc.next_cid >= 0) {
+            dc.aos[(size_t)K * 3 * A + r] = dc.aos[(size_t)dc.next_cid * 3 * A + r];
+            dc.aos[(size_t)dc.next_cid * 3 * A + r] =
+                dc.frames_aos[(size_t)dc.next_frame * 3 * A + r];
+        }
+    }
+    if (t == 0) {
+        if (!accept)
+            dc.Gm[dc.cid] = dc.Gm[K];
+        if (dc.next_cid >= 0) {
+            dc.Gm[K] = dc.Gm[dc.next_cid];
+            dc.Gm[dc.next_cid] = dc.G[dc.next_frame];
+            dc.amb_count[0] = 0;
+            dc.amb_count[1] = 0;
+            dc.amb_count[2] = 0;
+            *dc.moved = 0;
+        }
+    }
+}
+
 // amb_best != nullptr: the trial state still carries marked ambiguous members
 // (ek_launch_pam_classify(.., mark = 1)); they are resolved on the way
 void ek_launch_sumsq_pack(const float *a, float *b, const int32_t *assign,
@@ -996,41 +1268,42 @@ void ek_launch_sumsq_pack(const float *a, float *b, const int32_t *assign,
                           int n_leaves_total, int n_chunks, double *part,
                           const unsigned int *n_amb, unsigned int *moved,
                           EkPamOut *out, hipStream_t s,
-                          const unsigned long long *amb_best, unsigned int *tick)
+                          const unsigned long long *amb_best, unsigned int *tick,
+                          const EkPamDecide *decide)
 {
     double *leafsum = part;
     double *chunksum = part + 2 * (size_t)n_leaves_total;
-    if (n_leaves_total > 0 && amb_best && tick) {
-        // one launch: the last workgroup finishes the sums
-        const int per = EK_BLOCK / 8;
+    if (n_leaves_total > 0 && amb_best && tick && decide) {
+        // inside a window: one launch, the last workgroup finishes the sums and
+        // decides (*out is decide->win->out[decide->slot])
         EkPwTail tl;
         tl.tick = tick;
         tl.n_chunks = n_chunks;
         tl.n_amb = n_amb;
         tl.n = n;
-        tl.out = out;
-        hipLaunchKernelGGL((ek_pw_leaf_kernel<true, true>),
-                           dim3((n_leaves_total + per - 1) / per), dim3(EK_BLOCK),
-                           0, s, a, b, assign, nassign, amb_best, n, win_lo,
-                           win_count, shapes, n_full, n_leaves_total, leafsum,
-                           moved, tl);
+        const int n_rag = n_leaves_total - n_full * EK_PW_FULL_LEAVES;
+        const int blocks = 2 * n_full +
+                           (n_rag + EK_PW_WG_LEAVES - 1) / EK_PW_WG_LEAVES;
+        hipLaunchKernelGGL(ek_pw_window_kernel, dim3(blocks), dim3(EK_BLOCK), 0, s,
+                           a, b, assign, nassign, amb_best, win_lo, win_count,
+                           shapes, n_full, n_leaves_total, part, moved, tl,
+                           *decide);
         return;
     }
     if (n_leaves_total > 0) {
         const int per = EK_BLOCK / 8;
         if (amb_best)
-            hipLaunchKernelGGL((ek_pw_leaf_kernel<true, false>),
+            hipLaunchKernelGGL((ek_pw_leaf_kernel<true>),
                                dim3((n_leaves_total + per - 1) / per),
                                dim3(EK_BLOCK), 0, s, a, b, assign, nassign,
                                amb_best, n, win_lo, win_count, shapes, n_full,
-                               n_leaves_total, leafsum, moved, EkPwTail());
+                               n_leaves_total, leafsum, moved);
         else
-        hipLaunchKernelGGL((ek_pw_leaf_kernel<false, false>),
-                           dim3((n_leaves_total + per - 1) / per),
-                           dim3(EK_BLOCK), 0, s, a, b, assign, nassign, amb_best,
-                           n, win_lo,
-                           win_count, shapes, n_full, n_leaves_total, leafsum,
-                           moved, EkPwTail());
+            hipLaunchKernelGGL((ek_pw_leaf_kernel<false>),
+                               dim3((n_leaves_total + per - 1) / per),
+                               dim3(EK_BLOCK), 0, s, a, b, assign, nassign,
+                               amb_best, n, win_lo, win_count, shapes, n_full,
+                               n_leaves_total, leafsum, moved);
         hipLaunchKernelGGL(ek_pw_chunk_kernel, dim3(n_chunks), dim3(128), 0, s,
                            leafsum, shapes, n_full, chunksum);
     }
@@ -1298,103 +1571,3 @@ void ek_launch_scatter_vecs(const uint32_t *list, int64_t count,
                        n_pad);
 }
 
-// ---------------------------------------------------------------------------
-// a window of proposals decided on the device (ek_pam_window_run)
-// ---------------------------------------------------------------------------
-// After a proposal's trial state (ndist / nassign) and cost sums are in place:
-// accept iff mean(new^2) < mean(old^2), both in float64 (kmedoids.py:478-479,
-// :683) -- the same two divisions and comparison the host made -- and
-//   accepted: the trial state becomes the state (kmedoids.py:684-690), the
-//             cluster's medoid index is the proposed frame, the clusters of the
-//             window whose membership changes are marked stale; the first stale
-//             cluster after this one is where the window stops: its proposal was
-//             drawn from a member list that no longer holds (kmedoids.py:611-614),
-//   rejected (or past the stop): the medoid table gets its row back.
-// A slot past the stop still runs its kernels -- they only write scratch -- but
-// nothing of it is kept.
-__global__ void __launch_bounds__(EK_BLOCK)
-ek_pam_decide_kernel(EkPamWin *__restrict__ win, int slot, double n_total,
-                     float *__restrict__ dist, const float *__restrict__ ndist,
-                     int32_t *__restrict__ assign,
-                     const int32_t *__restrict__ nassign, int64_t n,
-                     float *__restrict__ aos, double *__restrict__ Gm, int A, int K,
-                     int cid, int64_t *__restrict__ med_idx, int64_t frame,
-                     int64_t max_amb, int next_cid, int64_t next_frame,
-                     const float *__restrict__ frames_aos,
-                     const double *__restrict__ G,
-                     unsigned int *__restrict__ amb_count,
-                     unsigned int *__restrict__ moved)
-{
-    const bool live = slot < win->stop;
-    const EkPamOut o = win->out[slot];
-    const double old_cost = o.sum_old / n_total, new_cost = o.sum_new / n_total;
-    const bool accept = live && new_cost < old_cost;
-    const int64_t f = (int64_t)blockIdx.x * EK_BLOCK + threadIdx.x;
-    if (accept && f < n) {
-        dist[f] = ndist[f];
-        assign[f] = nassign[f];
-    }
-    if (blockIdx.x != 0)
-        return;
-    // the proposal's row of the medoid table is undone if it was not accepted;
-    // then the NEXT proposal's trial table is set up right here (what
-    // ek_pam_trial_kernel does in a launch of its own: old row of its cluster
-    // into row K, the proposed frame -- read from the frame-major copy -- into
-    // the cluster's row, counters cleared).  Thread t owns elements t, t + 256,
-    // .. of every row, so the steps need no barrier.
-    for (int r = threadIdx.x; r < 3 * A; r += EK_BLOCK) {
-        if (!accept)
-            aos[(size_t)cid * 3 * A + r] = aos[(size_t)K * 3 * A + r];
-        if (next_cid >= 0) {
-            aos[(size_t)K * 3 * A + r] = aos[(size_t)next_cid * 3 * A + r];
-            aos[(size_t)next_cid * 3 * A + r] =
-                frames_aos[(size_t)next_frame * 3 * A + r];
-        }
-    }
-    if (threadIdx.x == 0) {
-        if (!accept)
-            Gm[cid] = Gm[K];
-        if (next_cid >= 0) {
-            Gm[K] = Gm[next_cid];
-            Gm[next_cid] = G[next_frame];
-            amb_count[0] = 0;
-            amb_count[1] = 0;
-            amb_count[2] = 0;
-            *moved = 0;
-        }
-        if (live) {
-            win->accept[slot] = accept ? 1 : 0;
-            if ((int64_t)o.n_amb > max_amb)
-                win->err = 1 + slot;
-            if (accept) {
-                if (med_idx)
-                    med_idx[cid] = frame;
-                const uint32_t stale = win->stale | o.moved;
-                win->stale = stale;
-                const uint32_t later = (slot >= 31) ? 0u : (stale >> (slot + 1));
-                if (later) {
-                    const int first = slot + 1 + (__ffs((int)later) - 1);
-                    if (first < win->stop)
-                        win->stop = first;
-                }
-            }
-        }
-    }
-}
-
-void ek_launch_pam_decide(EkPamWin *win, int slot, double n_total, float *dist,
-                          const float *ndist, int32_t *assign,
-                          const int32_t *nassign, int64_t n, float *aos,
-                          double *Gm, int A, int K, int cid, int64_t *med_idx,
-                          int64_t frame, int64_t max_amb, int next_cid,
-                          int64_t next_frame, const float *frames_aos,
-                          const double *G, unsigned int *amb_count,
-                          unsigned int *moved, hipStream_t s)
-{
-    const unsigned blocks = (unsigned)std::max<int64_t>(1, (n + EK_BLOCK - 1) /
-                                                               EK_BLOCK);
-    hipLaunchKernelGGL(ek_pam_decide_kernel, dim3(blocks), dim3(EK_BLOCK), 0, s,
-                       win, slot, n_total, dist, ndist, assign, nassign, n, aos,
-                       Gm, A, K, cid, med_idx, frame, max_amb, next_cid,
-                       next_frame, frames_aos, G, amb_count, moved);
-}
