@@ -122,7 +122,9 @@ struct ek_ctx {
     EkPamWin *pam_win_host = nullptr;    // pinned
     int32_t pam_restore = -1;        // row of the trial table a rejected proposal left
     int32_t *med_list = nullptr;     // [med_cap] medoids within reach (ek_pam_prune_kernel)
-    float *dtab = nullptr;           // [EK_MAX_CANDS][med_cap] medoid-to-proposal distances
+    float *dtab = nullptr;           // window tables, three blocks of EK_MAX_CANDS * (med_cap + 1):
+                                     // T medoid-to-proposal, O medoid-to-old-medoid, dmin
+    int32_t tab_lo = -1, tab_n = 0;  // the window (first cluster, slots) the tables were made for
     float *act_tiles = nullptr;      // frames needing exact distances, tile layout
     double *act_G = nullptr;
     float *act_vecs = nullptr;       // [EK_MAX_CANDS][act_cap]
@@ -1399,12 +1401,13 @@ static int ek_pam_alloc(ek_ctx *c, int32_t K)
         EK_HIP(hipMalloc((void **)&c->med_idx, (size_t)(K + 1) * sizeof(int64_t)));
         EK_HIP(hipMalloc((void **)&c->med_list, (size_t)(K + 1) * sizeof(int32_t)));
         EK_HIP(hipMalloc((void **)&c->dtab,
-                         (size_t)EK_MAX_CANDS * (K + 1) * sizeof(float)));
+                         (size_t)3 * EK_MAX_CANDS * (K + 1) * sizeof(float)));
         c->med_cap = K;
     }
     c->med_K = K;
     c->pam_cid = -1;
     c->cnt_cid = -1;
+    c->tab_n = 0;
     return EK_OK;
 }
 
@@ -1555,14 +1558,6 @@ static int ek_pam_tail(ek_ctx *c, int32_t cid, const float *newd,
 {
     const int K = c->med_K;
     const int fuse = decide != nullptr;
-    if (fuse)
-        ek_launch_pam_classify_apply(c->dist, c->assign, newd, c->n, cid, c->ndist,
-                                     c->nassign, c->amb, c->amb_best, c->amb_count,
-                                     c->amb_count + 1, prev_accept, c->stream);
-    else
-        ek_launch_pam_classify(c->dist, c->assign, newd, c->n, cid, c->ndist,
-                               c->nassign, c->amb, c->amb_best, c->amb_count,
-                               c->amb_count + 1, c->stream, 0);
     // only when dist[f] is known to be the distance to medoid assign[f] (a state
     // this library produced; not one uploaded by the caller) may the search skip
     // medoids out of the members' reach
@@ -1570,13 +1565,43 @@ static int ek_pam_tail(ek_ctx *c, int32_t cid, const float *newd,
     // root of the QCP quartic a double root, the computed distances are then too
     // erratic to be treated as a metric)
     const bool prune = c->prune && c->state_exact && c->A >= 3;
-    if (prune)
+    // inside a window whose distance tables are in place the classification's
+    // last workgroup lists the medoids within reach itself
+    const bool tabs = fuse && prune && c->tab_lo == cid - decide->slot &&
+                      decide->slot < c->tab_n;
+    if (fuse) {
+        const size_t tb = (size_t)EK_MAX_CANDS * (c->med_cap + 1);
+        EkPamClsWin w;
+        w.prev_accept = prev_accept;
+        w.frames_aos = c->aos;
+        w.G = c->G;
+        w.A = c->A;
+        w.ambt = c->ambt;
+        w.ambG = c->ambG;
+        w.cap = c->ambt_cap;
+        w.O = tabs ? c->dtab + tb + (size_t)decide->slot * K : nullptr;
+        w.T = c->dtab;
+        w.accepted = decide->win->accept;
+        w.K = K;
+        w.cid0 = cid - decide->slot;
+        w.slot = decide->slot;
+        w.list = c->med_list;
+        w.tick = c->tick + 192;
+        ek_launch_pam_classify_window(c->dist, c->assign, newd, c->n, cid, c->ndist,
+                                      c->nassign, c->amb, c->amb_best,
+                                      c->amb_count, w, c->stream);
+    } else {
+        ek_launch_pam_classify(c->dist, c->assign, newd, c->n, cid, c->ndist,
+                               c->nassign, c->amb, c->amb_best, c->amb_count,
+                               c->amb_count + 1, c->stream, 0);
+    }
+    if (prune && !tabs)
         ek_launch_pam_prune(c->med_aos, c->med_G, c->A, K, cid, c->amb_count + 1,
                             c->med_list, c->amb_count + 2, c->stream);
     ek_launch_subset_assign(c->tiles, c->G, c->A, c->amb, c->amb_count, max_amb,
                             c->ambt, c->ambG, c->ambt_cap, c->med_aos, c->med_G,
                             K, prune ? c->med_list : nullptr, c->amb_count + 2,
-                            newd, cid, c->amb_best, c->stream);
+                            newd, cid, c->amb_best, c->stream, fuse != 0);
     if (!fuse)
         ek_launch_pam_scatter(c->amb, c->amb_best, c->amb_count, max_amb, c->ndist,
                               c->nassign, c->stream);
@@ -1652,6 +1677,7 @@ static int ek_pam_propose_impl(ek_ctx *c, int32_t cid, int64_t frame_index,
         newd = c->scratch;
     }
     // trial medoid table (undoing a rejected proposal's row first), counters
+    c->tab_n = 0;
     ek_launch_pam_trial(c->tiles, c->G, c->A, c->med_aos, c->med_G, K, cid,
                         c->pam_restore, frame_index, idx_dev, nullptr, nullptr,
                         c->amb_count, c->moved, c->stream);
@@ -1852,9 +1878,15 @@ static int ek_pam_vecs_alloc(ek_ctx *c)
 // and the window of clusters being worked through is known, only the frames a
 // proposal can touch get exact distances (ek_pam.hip, "proposal prefetch
 // restricted ..."): the others get +inf.
+// local: the proposals are frames of this shard, proposal j for cluster
+// win_lo + j when win_count == count (the layout ek_pam_window_run expects)
+// prepared: ek_launch_pam_setup made the records (plan, candidate tile and the
+// cleared active-frame counter come with them)
 static int ek_pam_prefetch_vectors(ek_ctx *c, int count, int32_t win_lo,
-                                   int32_t win_count)
+                                   int32_t win_count, bool local,
+                                   bool prepared = false)
 {
+    c->tab_n = 0;
     const int K = c->med_K;
     if (c->pf_backoff > 0)
         --c->pf_backoff;
@@ -1863,15 +1895,34 @@ static int ek_pam_prefetch_vectors(ek_ctx *c, int count, int32_t win_lo,
         if (!c->act_n_host)
             EK_HIP(hipHostMalloc((void **)&c->act_n_host, sizeof(unsigned int),
                                  hipHostMallocDefault));
-        ek_launch_pam_dtab(c->med_aos, c->med_G, c->A, K, c->pam_restore,
-                           c->pam_recs, count, c->dtab, c->stream);
-        ek_launch_pam_active(c->dist, c->assign, c->n, c->dtab, K, count, win_lo,
-                             win_count, c->amb, c->amb_count + 3, c->stream);
+        // O (old medoids of the window's clusters) only where the window's slots
+        // and the proposals coincide: ek_pam_window_run's pruning reads it
+        const bool slots = local && win_count == count;
+        const size_t tb = (size_t)EK_MAX_CANDS * (c->med_cap + 1);
+        ek_launch_pam_tables(c->med_aos, c->med_G, c->A, K, c->pam_restore,
+                             c->pam_recs, count, win_lo, slots ? count : 0, c->dtab,
+                             c->dtab + tb, c->dtab + 2 * tb, c->stream);
+        c->tab_lo = win_lo;
+        c->tab_n = slots ? count : 0;
+        ek_launch_pam_active(c->dist, c->assign, c->n, c->dtab + 2 * tb, K, win_lo,
+                             win_count, c->amb, c->amb_count + 3, c->stream,
+                             prepared);
         EK_CHECK_LAUNCH();
         EK_HIP(hipMemcpyAsync(c->act_n_host, c->amb_count + 3, sizeof(unsigned int),
                               hipMemcpyDeviceToHost, c->stream));
         EK_HIP(ek_wait(c));
         const int64_t n_act = *c->act_n_host;
+        if (n_act * 8 <= c->n && c->aos) {
+            // a short list: straight from the frame-major copy, 64 frames x the
+            // proposals per workgroup, results scattered into the full vectors
+            EK_HIP(hipMemsetD32Async((hipDeviceptr_t)c->pam_vecs, 0x7f800000,
+                                     (size_t)count * c->n_pad, c->stream));
+            ek_launch_pam_list_dist(c->aos, c->G, c->A, c->amb, n_act, c->pam_recs,
+                                    count, c->pam_vecs, c->n_pad, c->stream);
+            EK_CHECK_LAUNCH();
+            ++c->pf_sparse;
+            return EK_OK;
+        }
         if (n_act * 8 <= c->n) {
             const int64_t need = (n_act + EK_TILE - 1) / EK_TILE * EK_TILE;
             if (need > c->act_cap) {
@@ -1897,7 +1948,8 @@ static int ek_pam_prefetch_vectors(ek_ctx *c, int count, int32_t win_lo,
                                    c->act_tiles, c->act_G, c->stream);
             ek_launch_pass_dist(count, c->act_tiles, c->act_G, c->act_vecs, n_act,
                                 c->act_cap, c->A, c->pam_recs, c->pam_plan,
-                                c->pass_form, c->ctile, c->ctrace, c->stream);
+                                c->pass_form, c->ctile, c->ctrace, c->stream,
+                                prepared);
             ek_launch_scatter_vecs(c->amb, n_act, c->act_vecs, c->act_cap, count,
                                    c->pam_vecs, c->n_pad, c->stream);
             EK_CHECK_LAUNCH();
@@ -1910,7 +1962,7 @@ static int ek_pam_prefetch_vectors(ek_ctx *c, int count, int32_t win_lo,
     }
     ek_launch_pass_dist(count, c->tiles, c->G, c->pam_vecs, c->n, c->n_pad, c->A,
                         c->pam_recs, c->pam_plan, c->pass_form, c->ctile,
-                        c->ctrace, c->stream);
+                        c->ctrace, c->stream, prepared);
     EK_CHECK_LAUNCH();
     ++c->pf_full;
     return EK_OK;
@@ -1960,10 +2012,17 @@ static int ek_pam_prefetch_frames(ek_ctx *c, const int64_t *frames, int32_t coun
         if (rc)
             return rc;
     }
-    ek_launch_records_from_frames(c->aos, c->G, c->A, frames, count, c->goff,
-                                  c->pam_recs, c->stream);
+    const bool prepared = c->pass_form == 1 && c->ctile != nullptr;
+    if (prepared)
+        ek_launch_pam_setup(c->aos, c->G, c->A, frames, count, c->goff, c->pam_recs,
+                            c->ctile, c->ctrace, c->pam_plan, c->amb_count + 3,
+                            c->stream);
+    else
+        ek_launch_records_from_frames(c->aos, c->G, c->A, frames, count, c->goff,
+                                      c->pam_recs, c->stream);
     {
-        int rc = ek_pam_prefetch_vectors(c, count, win_lo, win_count);
+        int rc = ek_pam_prefetch_vectors(c, count, win_lo, win_count, true,
+                                         prepared);
         if (rc)
             return rc;
     }
@@ -2025,20 +2084,17 @@ extern "C" int ek_pam_window_run(ek_ctx *c, int32_t cid0, int32_t count,
     rc = ek_pam_amb_room(c, max_m);      // may synchronise: before anything is enqueued
     if (rc)
         return rc;
-    EkPamWin w0;
-    memset(&w0, 0, sizeof(w0));
-    w0.stop = count;
-    EK_HIP(hipMemcpyAsync(c->pam_win_dev, &w0, sizeof(w0), hipMemcpyHostToDevice,
-                          c->stream));
     const int K = c->med_K;
     for (int32_t i = 0; i < count; ++i) {
         const int32_t cid = cid0 + i;
-        // the first proposal's trial table; the others' are set up by the
-        // decision kernel of the proposal before
+        // the first proposal's trial table (and the window record: `count`
+        // slots, nothing decided); the others' are set up by the last workgroup
+        // of the proposal before
         if (i == 0)
             ek_launch_pam_trial(c->tiles, c->G, c->A, c->med_aos, c->med_G, K, cid,
                                 c->pam_restore, frames[i], nullptr, nullptr,
-                                nullptr, c->amb_count, c->moved, c->stream);
+                                nullptr, c->amb_count, c->moved, c->stream,
+                                c->pam_win_dev, count);
         c->pam_restore = -1;
         const bool more = i + 1 < count;
         EkPamDecide dc;
@@ -2075,6 +2131,7 @@ extern "C" int ek_pam_window_run(ek_ctx *c, int32_t cid0, int32_t count,
                           hipMemcpyDeviceToHost, c->stream));
     EK_HIP(ek_wait(c));
     const EkPamWin &w = *c->pam_win_host;
+    c->tab_n = 0;            // the medoid table has moved on
     c->pam_cid = -1;
     c->cnt_cid = -1;
     c->pf_hits -= count - w.stop;       // the slots past the stop were not served
@@ -2166,7 +2223,7 @@ static int ek_pam_prefetch_centers_impl(ek_ctx *c, const float *aos_dev,
     for (int32_t j = 0; j < count; ++j)
         ek_launch_record_from_center(aos_dev + (size_t)j * 3 * c->A, G_dev + j, c->A,
                                      c->pam_recs + j * rstride, c->stream);
-    rc = ek_pam_prefetch_vectors(c, count, win_lo, win_count);
+    rc = ek_pam_prefetch_vectors(c, count, win_lo, win_count, false);
     if (rc)
         return rc;
     for (int32_t j = 0; j < count; ++j)

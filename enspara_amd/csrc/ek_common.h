@@ -235,14 +235,29 @@ void ek_launch_pam_classify(const float *dist, const int32_t *assign,
                             unsigned long long *amb_best,
                             unsigned int *amb_count, unsigned int *reach,
                             hipStream_t s, int mark = 0);
-// the same inside a window: if *prev_accept != 0 the trial state of the slot
-// before (ndist / nassign, about to be overwritten) first becomes the state
-void ek_launch_pam_classify_apply(float *dist, int32_t *assign, const float *newd,
-                                  int64_t n, int32_t cid, float *ndist,
-                                  int32_t *nassign, uint32_t *amb,
-                                  unsigned long long *amb_best,
-                                  unsigned int *amb_count, unsigned int *reach,
-                                  const int32_t *prev_accept, hipStream_t s);
+// the classification of a window's slot (ek_pam.hip, ek_pam_classify_window_kernel)
+struct EkPamClsWin {
+    const int32_t *prev_accept;
+    const float *frames_aos;    // frame-major copy of the shard
+    const double *G;
+    int32_t A;
+    float *ambt;                // [3A][cap]
+    double *ambG;
+    int64_t cap;
+    // pruning from the tables (O == nullptr: ek_pam_prune_kernel follows)
+    const float *O, *T;         // O: this slot's row; T: the whole table [.][K]
+    const int32_t *accepted;    // the window's verdicts so far, [slot]
+    int32_t K, cid0, slot;
+    int32_t *list;
+    unsigned int *tick;         // [0] top, [1 ..] EK_ARRIVE_G leaves
+};
+
+void ek_launch_pam_classify_window(float *dist, int32_t *assign, const float *newd,
+                                   int64_t n, int32_t cid, float *ndist,
+                                   int32_t *nassign, uint32_t *amb,
+                                   unsigned long long *amb_best,
+                                   unsigned int *amb_count, const EkPamClsWin &w,
+                                   hipStream_t s);
 // medoids within reach of the ambiguous members -> list / n_list
 void ek_launch_pam_prune(const float *aos, const double *Gm, int A, int K, int cid,
                          const unsigned int *reach, int32_t *list,
@@ -256,7 +271,7 @@ void ek_launch_subset_assign(const float *tiles, const double *G, int A,
                              const double *Gc, int K, const int32_t *list,
                              const unsigned int *n_list, const float *newd,
                              int cid, unsigned long long *amb_best,
-                             hipStream_t s);
+                             hipStream_t s, bool gathered = false);
 void ek_launch_pam_scatter(const uint32_t *amb,
                            const unsigned long long *amb_best,
                            const unsigned int *n_amb, int64_t max_amb,
@@ -303,13 +318,34 @@ void ek_launch_pam_apply(const int32_t *flag, float *dist, const float *ndist,
                          int32_t *assign, const int32_t *nassign, int64_t n,
                          hipStream_t s);
 // active-set proposal prefetch (ek_pam.hip)
-void ek_launch_pam_dtab(const float *aos, const double *Gm, int A, int K, int held,
-                        const unsigned char *recs, int count, float *Dtab,
-                        hipStream_t s);
-void ek_launch_pam_active(const float *dist, const int32_t *assign, int64_t n,
-                          const float *Dtab, int K, int count, int32_t win_lo,
-                          int32_t win_count, uint32_t *list, unsigned int *n_list,
+// T [n_prop][K]: medoid-to-proposal distances, dmin [K] their minimum per
+// medoid, O [n_old][K]: distances to the medoids of clusters old_lo ..
+void ek_launch_pam_tables(const float *aos, const double *Gm, int A, int K, int held,
+                          const unsigned char *recs, int n_prop, int old_lo,
+                          int n_old, float *T, float *O, float *dmin,
                           hipStream_t s);
+// vecs[j * n_pad + list[i]] = rmsd(frame list[i], record j): the listed frames
+// straight from the frame-major copy, results scattered into the full vectors
+void ek_launch_pam_list_dist(const float *aos, const double *G, int A,
+                             const uint32_t *list, int64_t n_rows,
+                             const unsigned char *recs, int count, float *vecs,
+                             int64_t n_pad, hipStream_t s);
+void ek_launch_pam_active(const float *dist, const int32_t *assign, int64_t n,
+                          const float *dmin, int K, int32_t win_lo,
+                          int32_t win_count, uint32_t *list, unsigned int *n_list,
+                          hipStream_t s, bool cleared = false);
+// records, candidate tile + traces, fixed plan and a cleared counter for a
+// window's proposals (local frames), one launch; the pass launcher is then
+// called with prepared = true
+#define EK_CTILE_PAD 8      // atoms of zeros after a candidate tile's last (read-ahead)
+void ek_launch_pam_setup(const float *aos, const double *G, int A,
+                         const int64_t *frames, int count, int64_t global_offset,
+                         unsigned char *recs, float *ctile, double *ctrace,
+                         EkPlan *plan, unsigned int *counter, hipStream_t s);
+static inline int ek_pass_dist_T(int count)     // the pass width ek_launch_pass_dist picks
+{
+    return (count <= 4) ? 4 : (count <= 8 ? 8 : 16);
+}
 // (aos: the frame-major copy of the shard)
 void ek_launch_gather_tiles(const float *aos, const double *G, int A,
                             const uint32_t *list, int64_t count, float *ctiles,
@@ -326,7 +362,7 @@ void ek_launch_pam_trial(const float *tiles, const double *G, int A, float *aos,
                          int64_t frame_index, const int64_t *idx_dev,
                          const float *ext_aos, const double *ext_G,
                          unsigned int *amb_count, unsigned int *moved,
-                         hipStream_t s);
+                         hipStream_t s, EkPamWin *win = nullptr, int win_slots = 0);
 // numpy's summation order (ek_pam.hip, "cost sums in numpy's order")
 #define EK_PW_CHUNK 8192            // numpy's reduction buffer, in elements
 #define EK_PW_FULL_LEAVES 64        // leaves of a full chunk (128 elements each)
@@ -370,7 +406,7 @@ void ek_launch_pass(int T, const float *tiles, const double *G, float *dist,
 void ek_launch_pass_dist(int count, const float *tiles, const double *G,
                          float *vecs, int64_t n, int64_t n_pad, int A,
                          const unsigned char *recs, EkPlan *plan, int form,
-                         float *ctile, double *ctrace, hipStream_t s);
+                         float *ctile, double *ctrace, hipStream_t s, bool prepared = false);
 // ---- chained rounds (ek_chain.hip) --------------------------------------------------
 // rows_out[EK_MAX_CANDS]: this shard's view of the candidate frames it owns
 void ek_launch_chain_rows(const EkPlan *plan, const float *dist,

@@ -11,7 +11,6 @@
 #include "ek_common.h"
 #include "ek_reduce.h"
 #include <algorithm>
-#include <type_traits>
 #include "ek_qcp.h"
 
 // ---- medoid table: centred coordinates of chosen frames, center-major --------
@@ -314,44 +313,22 @@ void ek_launch_select_member_multi(const int32_t *assign, int64_t n, int32_t cid
 //   dist <= newd and assign == cid   -> ambiguous: listed, resolved below
 // MARK: an ambiguous member's trial label is -2 - (its position in the list)
 // until the cost-sum kernel resolves it from amb_best (no scatter launch)
-// APPLY (inside a window, ek_pam_window_run): the slot before left its trial
-// state in ndist / nassign and its verdict in *prev_accept; an accepted trial
-// state is the state this proposal starts from, and is written back as such
-// (kmedoids.py:684-690) on the way -- no launch of its own for that.
-template <bool MARK, bool APPLY>
+template <bool MARK>
 __global__ void __launch_bounds__(EK_BLOCK)
-ek_pam_classify_kernel(typename std::conditional<APPLY, float, const float>::type
-                           *__restrict__ dist,
-                       typename std::conditional<APPLY, int32_t, const int32_t>::type
-                           *__restrict__ assign,
+ek_pam_classify_kernel(const float *__restrict__ dist,
+                       const int32_t *__restrict__ assign,
                        const float *__restrict__ newd, int64_t n, int32_t cid,
                        float *__restrict__ ndist, int32_t *__restrict__ nassign,
                        uint32_t *__restrict__ amb,
                        unsigned long long *__restrict__ amb_best,
                        unsigned int *__restrict__ amb_count,
-                       unsigned int *__restrict__ reach,
-                       const int32_t *__restrict__ prev_accept)
+                       unsigned int *__restrict__ reach)
 {
     const int64_t f = (int64_t)blockIdx.x * EK_BLOCK + threadIdx.x;
     if (f >= n)
         return;
-    float d;
-    int32_t a;
-    if constexpr (APPLY) {
-        if (*prev_accept) {
-            d = ndist[f];
-            a = nassign[f];
-            dist[f] = d;
-            assign[f] = a;
-        } else {
-            d = dist[f];
-            a = assign[f];
-        }
-    } else {
-        d = dist[f];
-        a = assign[f];
-    }
-    const float nd = newd[f];
+    const float d = dist[f], nd = newd[f];
+    const int32_t a = assign[f];
     if (d > nd) {
         ndist[f] = nd;
         nassign[f] = cid;
@@ -383,28 +360,206 @@ void ek_launch_pam_classify(const float *dist, const int32_t *assign,
     if (nblocks <= 0)
         return;
     if (mark)
-        hipLaunchKernelGGL((ek_pam_classify_kernel<true, false>), dim3(nblocks),
+        hipLaunchKernelGGL(ek_pam_classify_kernel<true>, dim3(nblocks),
                            dim3(EK_BLOCK), 0, s, dist, assign, newd, n, cid, ndist,
-                           nassign, amb, amb_best, amb_count, reach, nullptr);
+                           nassign, amb, amb_best, amb_count, reach);
     else
-        hipLaunchKernelGGL((ek_pam_classify_kernel<false, false>), dim3(nblocks),
+        hipLaunchKernelGGL(ek_pam_classify_kernel<false>, dim3(nblocks),
                            dim3(EK_BLOCK), 0, s, dist, assign, newd, n, cid, ndist,
-                           nassign, amb, amb_best, amb_count, reach, nullptr);
+                           nassign, amb, amb_best, amb_count, reach);
 }
 
-void ek_launch_pam_classify_apply(float *dist, int32_t *assign, const float *newd,
-                                  int64_t n, int32_t cid, float *ndist,
-                                  int32_t *nassign, uint32_t *amb,
-                                  unsigned long long *amb_best,
-                                  unsigned int *amb_count, unsigned int *reach,
-                                  const int32_t *prev_accept, hipStream_t s)
+// The classification inside a window (ek_pam_window_run), one launch for
+//   * taking over an accepted predecessor's trial state (APPLY above),
+//   * the classification itself, 4096 frames per workgroup of 1024 threads,
+//   * the compacted copy of every ambiguous member's coordinates (ambt / ambG,
+//     what ek_gather_amb_kernel does in a launch of its own): the wave that
+//     finds one copies it, the frame-major copy of the shard makes that 12 A
+//     contiguous bytes,
+//   * and, by the last workgroup to finish (arrival counter; `reach` and the
+//     list of ambiguous members travel as atomics / coherent stores,
+//     ek_reduce.h), the list of medoids within reach of those members
+//     (ek_pam_prune_kernel's test) from the window's distance tables: slot
+//     `slot`'s old medoid against medoid c is O[slot][c] -- or, where an earlier
+//     slot i of this window was accepted, T[i][cid]: its proposal sits in row
+//     cid0 + i now and the old medoid of `cid` has not moved since the tables
+//     were made.
+#define EK_CLS_THREADS 1024                 // also the width of the last workgroup's tail
+#define EK_CLS_FPT 4                        // consecutive frames per load
+#define EK_CLS_TRIPS 1
+#define EK_CLS_WG (EK_CLS_THREADS * EK_CLS_FPT * EK_CLS_TRIPS)
+
+__global__ void __launch_bounds__(EK_CLS_THREADS)
+ek_pam_classify_window_kernel(float *dist, int32_t *assign,
+                              const float *__restrict__ newd, int64_t n,
+                              int32_t cid, float *ndist, int32_t *nassign,
+                              uint32_t *__restrict__ amb,
+                              unsigned long long *__restrict__ amb_best,
+                              unsigned int *__restrict__ amb_count, EkPamClsWin w)
 {
-    const int nblocks = (int)((n + EK_BLOCK - 1) / EK_BLOCK);
+    const int t = threadIdx.x;
+    const bool ap = *w.prev_accept != 0;
+    const int64_t base = (int64_t)blockIdx.x * EK_CLS_WG + (int64_t)t * EK_CLS_FPT;
+    float d[EK_CLS_TRIPS][EK_CLS_FPT], nd[EK_CLS_TRIPS][EK_CLS_FPT];
+    int32_t a[EK_CLS_TRIPS][EK_CLS_FPT];
+#pragma unroll
+    for (int q = 0; q < EK_CLS_TRIPS; ++q) {
+        const int64_t f0 = base + (int64_t)q * EK_CLS_THREADS * EK_CLS_FPT;
+        const float *ds = ap ? ndist : dist;
+        const int32_t *as = ap ? nassign : assign;
+        if (f0 + EK_CLS_FPT <= n) {
+            const float4 dv = *(const float4 *)(ds + f0);
+            const int4 av = *(const int4 *)(as + f0);
+            const float4 nv = *(const float4 *)(newd + f0);
+            d[q][0] = dv.x; d[q][1] = dv.y; d[q][2] = dv.z; d[q][3] = dv.w;
+            a[q][0] = av.x; a[q][1] = av.y; a[q][2] = av.z; a[q][3] = av.w;
+            nd[q][0] = nv.x; nd[q][1] = nv.y; nd[q][2] = nv.z; nd[q][3] = nv.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < EK_CLS_FPT; ++k) {
+                const bool in = f0 + k < n;
+                d[q][k] = in ? ds[f0 + k] : 0.f;
+                a[q][k] = in ? as[f0 + k] : -1;
+                nd[q][k] = in ? newd[f0 + k] : 0.f;
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < EK_CLS_TRIPS; ++q) {
+        const int64_t f0 = base + (int64_t)q * EK_CLS_THREADS * EK_CLS_FPT;
+        float od[EK_CLS_FPT];
+        int32_t oa[EK_CLS_FPT];
+        unsigned int ambk = 0;                  // which of the four are ambiguous
+#pragma unroll
+        for (int k = 0; k < EK_CLS_FPT; ++k) {
+            if (d[q][k] > nd[q][k]) {
+                od[k] = nd[q][k];
+                oa[k] = cid;
+            } else {
+                od[k] = d[q][k];
+                oa[k] = a[q][k];
+                if (a[q][k] == cid && f0 + k < n)
+                    ambk |= 1u << k;
+            }
+        }
+        // ambiguous members (rare): listed, marked in the trial state until
+        // the cost-sum launch resolves them, their coordinates compacted
+        while (__ballot(ambk != 0)) {
+            int k = -1;
+            unsigned int pos = 0;
+            if (ambk) {
+                k = __ffs((int)ambk) - 1;
+                ambk &= ambk - 1;
+                pos = atomicAdd(amb_count, 1u);
+                __hip_atomic_store(&amb[pos], (uint32_t)(f0 + k), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+                amb_best[pos] = ~0ull;
+                // how far a medoid may be from the old one and still matter to
+                // this frame; non-negative floats order like their bits
+                float dk = d[q][0], nk = nd[q][0];
+#pragma unroll
+                for (int kk = 1; kk < EK_CLS_FPT; ++kk)
+                    if (k == kk) {
+                        dk = d[q][kk];
+                        nk = nd[q][kk];
+                    }
+                atomicMax(amb_count + 1, __float_as_uint(dk + nk));
+#pragma unroll
+                for (int kk = 0; kk < EK_CLS_FPT; ++kk)
+                    if (k == kk) {
+                        od[kk] = 0.f;
+                        oa[kk] = -2 - (int32_t)pos;
+                    }
+            }
+            unsigned long long todo = __ballot(k >= 0);
+            while (todo) {
+                const int src = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const int64_t f = __shfl(f0 + k, src, EK_WAVE);
+                const unsigned int ps = __shfl(pos, src, EK_WAVE);
+                if ((int64_t)ps < w.cap) {
+                    const float *p = w.frames_aos + (size_t)f * 3 * w.A;
+                    const int lane = t & (EK_WAVE - 1);
+                    for (int r0 = lane; r0 < 3 * w.A; r0 += 8 * EK_WAVE) {
+                        float v[8];             // eight loads in flight
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            v[u] = (r0 + u * EK_WAVE < 3 * w.A) ? p[r0 + u * EK_WAVE]
+                                                                : 0.f;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            if (r0 + u * EK_WAVE < 3 * w.A)
+                                w.ambt[(size_t)(r0 + u * EK_WAVE) * w.cap + ps] = v[u];
+                    }
+                    if (lane == 0)
+                        w.ambG[ps] = w.G[f];
+                }
+            }
+        }
+        if (f0 + EK_CLS_FPT <= n) {
+            if (ap) {
+                *(float4 *)(dist + f0) =
+                    make_float4(d[q][0], d[q][1], d[q][2], d[q][3]);
+                *(int4 *)(assign + f0) = make_int4(a[q][0], a[q][1], a[q][2], a[q][3]);
+            }
+            *(float4 *)(ndist + f0) = make_float4(od[0], od[1], od[2], od[3]);
+            *(int4 *)(nassign + f0) = make_int4(oa[0], oa[1], oa[2], oa[3]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < EK_CLS_FPT; ++k)
+                if (f0 + k < n) {
+                    if (ap) {
+                        dist[f0 + k] = d[q][k];
+                        assign[f0 + k] = a[q][k];
+                    }
+                    ndist[f0 + k] = od[k];
+                    nassign[f0 + k] = oa[k];
+                }
+        }
+    }
+    if (!w.O)
+        return;
+    if (!ek_arrive_last_tree(w.tick, w.tick + 1))
+        return;
+    // ---- the last workgroup: medoids within reach of the ambiguous members --------
+    const float R = __uint_as_float(__hip_atomic_load(amb_count + 1, __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_AGENT));
+    const float lim = R * 1.001f + 1e-3f;
+    for (int c0 = t; c0 < w.K; c0 += 8 * EK_CLS_THREADS) {
+        float D[8];                             // eight table reads in flight
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = c0 + u * EK_CLS_THREADS;
+            D[u] = (c < w.K) ? w.O[c] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = c0 + u * EK_CLS_THREADS;
+            if (c >= w.K)
+                continue;
+            const int i = c - w.cid0;
+            if (i >= 0 && i < w.slot && w.accepted[i])
+                D[u] = w.T[(size_t)i * w.K + cid];
+            if (c == cid || !(D[u] > lim))
+                w.list[atomicAdd(amb_count + 2, 1u)] = c;
+        }
+    }
+}
+
+void ek_launch_pam_classify_window(float *dist, int32_t *assign, const float *newd,
+                                   int64_t n, int32_t cid, float *ndist,
+                                   int32_t *nassign, uint32_t *amb,
+                                   unsigned long long *amb_best,
+                                   unsigned int *amb_count, const EkPamClsWin &w,
+                                   hipStream_t s)
+{
+    const int nblocks = (int)((n + EK_CLS_WG - 1) / EK_CLS_WG);
     if (nblocks <= 0)
         return;
-    hipLaunchKernelGGL((ek_pam_classify_kernel<true, true>), dim3(nblocks),
-                       dim3(EK_BLOCK), 0, s, dist, assign, newd, n, cid, ndist,
-                       nassign, amb, amb_best, amb_count, reach, prev_accept);
+    hipLaunchKernelGGL(ek_pam_classify_window_kernel, dim3(nblocks),
+                       dim3(EK_CLS_THREADS),
+                       0, s, dist, assign, newd, n, cid, ndist, nassign, amb,
+                       amb_best, amb_count, w);
 }
 
 __global__ void __launch_bounds__(EK_BLOCK)
@@ -640,14 +795,15 @@ void ek_launch_subset_assign(const float *tiles, const double *G, int A,
                              const double *Gc, int K, const int32_t *list,
                              const unsigned int *n_list, const float *newd,
                              int cid, unsigned long long *amb_best,
-                             hipStream_t s)
+                             hipStream_t s, bool gathered)
 {
     if (max_amb <= 0 || K <= 0)
         return;
     const unsigned gx = (unsigned)((max_amb + EK_BLOCK - 1) / EK_BLOCK);
-    hipLaunchKernelGGL(ek_gather_amb_kernel, dim3((unsigned)max_amb),
-                       dim3(EK_BLOCK), 0, s, tiles, G, A, amb, n_amb, cap,
-                       list ? n_list : nullptr, ambt, ambG);
+    if (!gathered)      // (the window's classification compacts them itself)
+        hipLaunchKernelGGL(ek_gather_amb_kernel, dim3((unsigned)max_amb),
+                           dim3(EK_BLOCK), 0, s, tiles, G, A, amb, n_amb, cap,
+                           list ? n_list : nullptr, ambt, ambG);
     const dim3 grid(gx, (K + PCT - 1) / PCT);
     const size_t lds = (size_t)3 * A * PCT * sizeof(float);
     if (lds > 48 * 1024)
@@ -709,10 +865,17 @@ ek_pam_trial_kernel(const float *__restrict__ tiles, const double *__restrict__ 
                     const float *__restrict__ ext_aos,
                     const double *__restrict__ ext_G,
                     unsigned int *__restrict__ amb_count,
-                    unsigned int *__restrict__ moved)
+                    unsigned int *__restrict__ moved, EkPamWin *__restrict__ win,
+                    int win_slots)
 {
     // amb_count[0] ambiguous members, [1] reach bits, [2] listed medoids
     const int tid = threadIdx.x;
+    if (win) {          // a window starts here: nothing decided, `win_slots` to go
+        static_assert(sizeof(EkPamWin) % 4 == 0 && sizeof(EkPamWin) / 4 <= 4 * EK_BLOCK,
+                      "EkPamWin is cleared word by word");
+        for (int i = tid; i < (int)(sizeof(EkPamWin) / 4); i += EK_BLOCK)
+            ((uint32_t *)win)[i] = (i == 0) ? (uint32_t)win_slots : 0u;
+    }
     const float *p = nullptr;
     int64_t f = -1;
     if (!ext_aos) {
@@ -742,11 +905,11 @@ void ek_launch_pam_trial(const float *tiles, const double *G, int A, float *aos,
                          int64_t frame_index, const int64_t *idx_dev,
                          const float *ext_aos, const double *ext_G,
                          unsigned int *amb_count, unsigned int *moved,
-                         hipStream_t s)
+                         hipStream_t s, EkPamWin *win, int win_slots)
 {
     hipLaunchKernelGGL(ek_pam_trial_kernel, dim3(1), dim3(EK_BLOCK), 0, s, tiles, G,
                        A, aos, Gm, K, cid, restore_cid, frame_index, idx_dev,
-                       ext_aos, ext_G, amb_count, moved);
+                       ext_aos, ext_G, amb_count, moved, win, win_slots);
 }
 
 // ---- cost sums in numpy's order ------------------------------------------------------------
@@ -1237,13 +1400,30 @@ ek_pw_window_kernel(const float *__restrict__ a, float *__restrict__ b,
     const bool accept = s_accept != 0;
     const int A = dc.A, K = dc.K;
     // thread t owns elements t, t + 256, .. of every row: no barrier needed
-    for (int r = t; r < 3 * A; r += EK_BLOCK) {
-        if (!accept)
-            dc.aos[(size_t)dc.cid * 3 * A + r] = dc.aos[(size_t)K * 3 * A + r];
-        if (dc.next_cid >= 0) {
-            dc.aos[(size_t)K * 3 * A + r] = dc.aos[(size_t)dc.next_cid * 3 * A + r];
-            dc.aos[(size_t)dc.next_cid * 3 * A + r] =
-                dc.frames_aos[(size_t)dc.next_frame * 3 * A + r];
+    for (int r0 = t; r0 < 3 * A; r0 += 4 * EK_BLOCK) {
+        float sv[4], nx[4], pr[4];              // all loads first
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = r0 + u * EK_BLOCK;
+            const bool in = r < 3 * A;
+            sv[u] = in ? dc.aos[(size_t)K * 3 * A + r] : 0.f;
+            nx[u] = (in && dc.next_cid >= 0) ? dc.aos[(size_t)dc.next_cid * 3 * A + r]
+                                             : 0.f;
+            pr[u] = (in && dc.next_cid >= 0)
+                        ? dc.frames_aos[(size_t)dc.next_frame * 3 * A + r]
+                        : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = r0 + u * EK_BLOCK;
+            if (r >= 3 * A)
+                continue;
+            if (!accept)
+                dc.aos[(size_t)dc.cid * 3 * A + r] = sv[u];
+            if (dc.next_cid >= 0) {
+                dc.aos[(size_t)K * 3 * A + r] = nx[u];
+                dc.aos[(size_t)dc.next_cid * 3 * A + r] = pr[u];
+            }
         }
     }
     if (t == 0) {
@@ -1380,99 +1560,283 @@ void ek_pw_build_shape(int len, EkPwShape *sh)
 // carries a margin far above the rounding of a distance; D is only compared, so
 // its summation order is free.
 
-// Dtab[j * K + c] = rmsd(medoid c, proposal j); one wave per medoid, lanes
-// strided over the atoms.  `held` is the row a rejected proposal still occupies
-// (its medoid is in row K), or -1.
-__global__ void __launch_bounds__(EK_BLOCK)
-ek_pam_dtab_kernel(const float *__restrict__ aos, const double *__restrict__ Gm,
-                   int A, int K, int held, const unsigned char *__restrict__ recs,
-                   int count, float *__restrict__ Dtab)
+// Distances of a few thousand rows to a few columns -- too little work to fill
+// the chip with the streaming kernels, whose one wave per 64 frames then runs
+// at memory latency.  Here a workgroup takes 64 rows x EK_MAX_CANDS columns,
+// wave = column, lane = row; the rows (frame-major, 12 A contiguous bytes each)
+// and the columns' coordinates go through LDS in slices of EK_PAIR_CH atoms,
+// read from memory once along the rows with the next slice's loads in flight
+// during the FMAs.  Every (row, column) pair is still one lane's IEEE FMA
+// chains in ascending atom order, S[3 r + c] += row_r * column_c, followed by
+// ek_rmsd_from_S(S, G_row, G_column): bit-identical to the streaming kernels.
+//
+// MODE 0, the distance tables of a window (rows: the medoid table):
+//   T[j * K + c] = rmsd(medoid c, proposal j), j < n_prop
+//   dmin[c]      = min_j T[j * K + c]
+//   O[i * K + c] = rmsd(medoid c, medoid old_lo + i), i < n_old -- what the
+//                  pruning of slot i's ambiguous members asks for
+//                  (ek_pam_prune_kernel / the classification's last workgroup)
+//   `held` is the row a rejected proposal still occupies (its medoid is in row
+//   K), or -1.  grid (ceil(K / 64), 2): y = 0 proposals, y = 1 old medoids.
+// MODE 1, a window's proposals against the frames they can touch (rows: the
+//   listed frames of the frame-major copy):
+//   vecs[j * n_pad + list[i]] = rmsd(frame list[i], proposal j)
+#define EK_PAIR_CH 96
+struct EkPairArgs {
+    const float *aos;           // rows: [.][3A]
+    const double *G;            // their traces
+    int32_t A;
+    const unsigned char *recs;  // columns: records
+    int32_t n_col;
+    // MODE 0
+    int32_t K, held, old_lo, n_old;
+    float *T, *O, *dmin;
+    // MODE 1
+    const uint32_t *list;
+    int64_t n_rows, n_pad;
+    float *vecs;
+};
+
+static inline size_t ek_pair_lds_bytes()
 {
+    return (size_t)(3 * EK_PAIR_CH * (EK_WAVE + 1) + EK_MAX_CANDS * 3 * EK_PAIR_CH) *
+           sizeof(float);
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(EK_MAX_CANDS *EK_WAVE)
+ek_pam_pairs_kernel(EkPairArgs p)
+{
+    constexpr int NT = EK_MAX_CANDS * EK_WAVE;
+    constexpr int LD = EK_WAVE + 1;             // padded: conflict-free both ways
+    constexpr int TPR = NT / EK_WAVE;           // threads per row
+    constexpr int NLD = 3 * EK_PAIR_CH / TPR;   // loads per thread and slice
+    constexpr int NY = (3 * EK_PAIR_CH + EK_WAVE - 1) / EK_WAVE;
+    extern __shared__ __attribute__((aligned(16))) float pair_lds[];
+    float *tile = pair_lds;                                 // [3 CH][LD]
+    float *ytile = pair_lds + 3 * EK_PAIR_CH * LD;          // [columns][3 CH]
+    __shared__ float tmin[EK_MAX_CANDS][EK_WAVE];
+    const int A = p.A;
     const int lane = threadIdx.x & (EK_WAVE - 1);
-    const int c = blockIdx.x * (EK_BLOCK / EK_WAVE) + threadIdx.x / EK_WAVE;
-    if (c >= K)
-        return;
-    const int row = (c == held) ? K : c;
-    const float *x = aos + (size_t)row * 3 * A;
-    const size_t rstride = ek_rec_bytes(A);
-    for (int j = 0; j < count; ++j) {
-        const EkRecHdr *h = (const EkRecHdr *)(recs + (size_t)j * rstride);
-        const float *y = (const float *)(recs + (size_t)j * rstride +
-                                         sizeof(EkRecHdr));
-        float S[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int a = lane; a < A; a += EK_WAVE) {
-            const float x0 = x[3 * a], x1 = x[3 * a + 1], x2 = x[3 * a + 2];
-            const float y0 = y[3 * a], y1 = y[3 * a + 1], y2 = y[3 * a + 2];
-            S[0] += x0 * y0; S[1] += x0 * y1; S[2] += x0 * y2;
-            S[3] += x1 * y0; S[4] += x1 * y1; S[5] += x1 * y2;
-            S[6] += x2 * y0; S[7] += x2 * y1; S[8] += x2 * y2;
+    const int j = __builtin_amdgcn_readfirstlane(threadIdx.x / EK_WAVE);
+    const bool old = MODE == 0 && blockIdx.y != 0;
+    const int ncol = old ? p.n_old : p.n_col;
+    const bool live = j < ncol;
+    // this wave's column
+    const float *y = p.aos;
+    double Gy = 0.0;
+    if (live) {
+        if (old) {
+            const int r = (p.old_lo + j == p.held) ? p.K : p.old_lo + j;
+            y = p.aos + (size_t)r * 3 * A;
+            Gy = p.G[r];
+        } else {
+            const size_t rstride = ek_rec_bytes(A);
+            y = (const float *)(p.recs + (size_t)j * rstride + sizeof(EkRecHdr));
+            Gy = ((const EkRecHdr *)(p.recs + (size_t)j * rstride))->trace;
         }
+    }
+    // row `m` of the workgroup: where it lives, whether it exists
+    auto row_of = [&](int m, bool &ok) -> int64_t {
+        const int64_t i = (int64_t)blockIdx.x * EK_WAVE + m;
+        if (MODE == 0) {
+            ok = i < p.K;
+            return (i == p.held) ? p.K : (ok ? i : 0);
+        }
+        ok = i < p.n_rows;
+        return ok ? (int64_t)p.list[i] : 0;
+    };
+    // loading: TPR threads per row, each every TPR-th element of the slice; a
+    // column's coordinates by its own wave
+    const int lm = threadIdx.x / TPR, le = threadIdx.x % TPR;
+    bool lok;
+    const float *lrow = p.aos + (size_t)row_of(lm, lok) * 3 * A;
+    float S[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float v[NLD], vy[NY];       // the slice after the one being worked on
+#define EK_PAIR_LOAD(A0)                                                       \
+    _Pragma("unroll") for (int k = 0; k < NLD; ++k) {                          \
+        const int e = le + TPR * k;                                            \
+        v[k] = (3 * (A0) + e < 3 * A && lok) ? lrow[3 * (A0) + e] : 0.f;       \
+    }                                                                          \
+    _Pragma("unroll") for (int k = 0; k < NY; ++k) {                           \
+        const int e = lane + EK_WAVE * k;                                      \
+        vy[k] = (live && e < 3 * EK_PAIR_CH && 3 * (A0) + e < 3 * A)           \
+                    ? y[3 * (A0) + e] : 0.f;                                   \
+    }
+    EK_PAIR_LOAD(0)
+    for (int a0 = 0; a0 < A; a0 += EK_PAIR_CH) {
+        const int ch = (A - a0 < EK_PAIR_CH) ? A - a0 : EK_PAIR_CH;
+        __syncthreads();                        // the slice before is done with
 #pragma unroll
-        for (int q = 0; q < 9; ++q)
+        for (int k = 0; k < NLD; ++k)
+            tile[(le + TPR * k) * LD + lm] = v[k];
 #pragma unroll
-            for (int off = 32; off >= 1; off >>= 1)
-                S[q] += __shfl_xor(S[q], off, 64);
-        if (lane == 0)
-            Dtab[(size_t)j * K + c] = ek_rmsd_from_S(S, Gm[row], h->trace, A);
+        for (int k = 0; k < NY; ++k)
+            if (lane + EK_WAVE * k < 3 * EK_PAIR_CH)
+                ytile[j * 3 * EK_PAIR_CH + lane + EK_WAVE * k] = vy[k];
+        __syncthreads();
+        if (a0 + EK_PAIR_CH < A)                // in flight during the FMAs
+            EK_PAIR_LOAD(a0 + EK_PAIR_CH)
+        if (live) {
+            const float *yt = ytile + j * 3 * EK_PAIR_CH;
+#pragma unroll 8
+            for (int a = 0; a < ch; ++a) {
+                const float x0 = tile[(3 * a + 0) * LD + lane],
+                            x1 = tile[(3 * a + 1) * LD + lane],
+                            x2 = tile[(3 * a + 2) * LD + lane];
+                const float y0 = yt[3 * a], y1 = yt[3 * a + 1], y2 = yt[3 * a + 2];
+                S[0] = fmaf(x0, y0, S[0]); S[1] = fmaf(x0, y1, S[1]);
+                S[2] = fmaf(x0, y2, S[2]); S[3] = fmaf(x1, y0, S[3]);
+                S[4] = fmaf(x1, y1, S[4]); S[5] = fmaf(x1, y2, S[5]);
+                S[6] = fmaf(x2, y0, S[6]); S[7] = fmaf(x2, y1, S[7]);
+                S[8] = fmaf(x2, y2, S[8]);
+            }
+        }
+    }
+#undef EK_PAIR_LOAD
+    bool ok;
+    const int64_t row = row_of(lane, ok);
+    float D = __builtin_inff();
+    if (live && ok)
+        D = ek_rmsd_from_S(S, p.G[row], Gy, A);
+    if (MODE == 1) {
+        if (live && ok)
+            p.vecs[(size_t)j * p.n_pad + row] = D;
+        return;
+    }
+    const int c = blockIdx.x * EK_WAVE + lane;
+    if (live && ok)
+        (old ? p.O : p.T)[(size_t)j * p.K + c] = D;
+    if (old)
+        return;
+    tmin[j][lane] = D;
+    __syncthreads();
+    if (j == 0 && ok) {
+        float m = tmin[0][lane];
+#pragma unroll
+        for (int q = 1; q < EK_MAX_CANDS; ++q)
+            m = fminf(m, tmin[q][lane]);
+        p.dmin[c] = m;
     }
 }
 
-void ek_launch_pam_dtab(const float *aos, const double *Gm, int A, int K, int held,
-                        const unsigned char *recs, int count, float *Dtab,
-                        hipStream_t s)
+template <int MODE>
+static void ek_pairs_launch(const EkPairArgs &p, dim3 grid, hipStream_t s)
 {
-    const int per = EK_BLOCK / EK_WAVE;
-    hipLaunchKernelGGL(ek_pam_dtab_kernel, dim3((K + per - 1) / per),
-                       dim3(EK_BLOCK), 0, s, aos, Gm, A, K, held, recs, count,
-                       Dtab);
+    const size_t lds = ek_pair_lds_bytes();     // above the 64 KB a kernel gets unasked
+    (void)hipFuncSetAttribute((const void *)ek_pam_pairs_kernel<MODE>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(ek_pam_pairs_kernel<MODE>, grid, dim3(EK_MAX_CANDS * EK_WAVE),
+                       lds, s, p);
+}
+
+void ek_launch_pam_tables(const float *aos, const double *Gm, int A, int K, int held,
+                          const unsigned char *recs, int n_prop, int old_lo,
+                          int n_old, float *T, float *O, float *dmin,
+                          hipStream_t s)
+{
+    EkPairArgs p = {};
+    p.aos = aos;
+    p.G = Gm;
+    p.A = A;
+    p.recs = recs;
+    p.n_col = n_prop;
+    p.K = K;
+    p.held = held;
+    p.old_lo = old_lo;
+    p.n_old = n_old;
+    p.T = T;
+    p.O = O;
+    p.dmin = dmin;
+    ek_pairs_launch<0>(p, dim3((K + EK_WAVE - 1) / EK_WAVE, n_old > 0 ? 2 : 1), s);
+}
+
+// vecs[j * n_pad + list[i]] = rmsd(frame list[i], record j), i < n_rows, j < count
+void ek_launch_pam_list_dist(const float *aos, const double *G, int A,
+                             const uint32_t *list, int64_t n_rows,
+                             const unsigned char *recs, int count, float *vecs,
+                             int64_t n_pad, hipStream_t s)
+{
+    if (n_rows <= 0 || count <= 0)
+        return;
+    EkPairArgs p = {};
+    p.aos = aos;
+    p.G = G;
+    p.A = A;
+    p.recs = recs;
+    p.n_col = count;
+    p.list = list;
+    p.n_rows = n_rows;
+    p.n_pad = n_pad;
+    p.vecs = vecs;
+    ek_pairs_launch<1>(p, dim3((unsigned)((n_rows + EK_WAVE - 1) / EK_WAVE)), s);
 }
 
 // the frames that need exact distances -> list (any order), *n_list
+// 4096 frames per workgroup, compacted in LDS: one atomic on *n_list each
+#define EK_ACT_PER 16
 __global__ void __launch_bounds__(EK_BLOCK)
 ek_pam_active_kernel(const float *__restrict__ dist,
                      const int32_t *__restrict__ assign, int64_t n,
-                     const float *__restrict__ Dtab, int K, int count,
+                     const float *__restrict__ dmin, int K,
                      int32_t win_lo, int32_t win_count,
                      uint32_t *__restrict__ list, unsigned int *__restrict__ n_list)
 {
-    const int64_t f = (int64_t)blockIdx.x * EK_BLOCK + threadIdx.x;
-    bool act = false;
-    if (f < n) {
-        const int32_t a = assign[f];
-        const float d = dist[f];
-        if (a < 0 || a >= K || (a >= win_lo && a < win_lo + win_count)) {
-            act = true;
-        } else {
-            float dmin = __builtin_inff();
-            for (int j = 0; j < count; ++j)
-                dmin = fminf(dmin, Dtab[(size_t)j * K + a]);
-            act = !(dmin > 2.f * d * 1.001f + 1e-3f);
-        }
+    __shared__ uint32_t found[EK_BLOCK * EK_ACT_PER];
+    __shared__ unsigned int n_found, base_s;
+    const int t = threadIdx.x;
+    if (t == 0)
+        n_found = 0;
+    __syncthreads();
+    const int64_t f0 = (int64_t)blockIdx.x * EK_BLOCK * EK_ACT_PER + t;
+    int32_t a[EK_ACT_PER];
+    float d[EK_ACT_PER], dm[EK_ACT_PER];
+#pragma unroll
+    for (int q = 0; q < EK_ACT_PER; ++q) {
+        const int64_t f = f0 + (int64_t)q * EK_BLOCK;
+        a[q] = (f < n) ? assign[f] : 0;
+        d[q] = (f < n) ? dist[f] : 0.f;
     }
-    const unsigned long long m = __ballot(act);
-    if (m == 0)
+#pragma unroll
+    for (int q = 0; q < EK_ACT_PER; ++q)
+        dm[q] = (a[q] >= 0 && a[q] < K) ? dmin[a[q]] : 0.f;
+#pragma unroll
+    for (int q = 0; q < EK_ACT_PER; ++q) {
+        const int64_t f = f0 + (int64_t)q * EK_BLOCK;
+        if (f >= n)
+            continue;
+        bool act;
+        if (a[q] < 0 || a[q] >= K || (a[q] >= win_lo && a[q] < win_lo + win_count))
+            act = true;
+        else
+            act = !(dm[q] > 2.f * d[q] * 1.001f + 1e-3f);
+        if (act)
+            found[atomicAdd(&n_found, 1u)] = (uint32_t)f;
+    }
+    __syncthreads();
+    const unsigned int cnt = n_found;
+    if (cnt == 0)
         return;
-    const int lane = threadIdx.x & (EK_WAVE - 1);
-    unsigned int base = 0;
-    if (lane == 0)
-        base = atomicAdd(n_list, (unsigned int)__popcll(m));
-    base = __shfl(base, 0, 64);
-    if (act)
-        list[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)f;
+    if (t == 0)
+        base_s = atomicAdd(n_list, cnt);
+    __syncthreads();
+    for (unsigned int i = t; i < cnt; i += EK_BLOCK)
+        list[base_s + i] = found[i];
 }
 
 void ek_launch_pam_active(const float *dist, const int32_t *assign, int64_t n,
-                          const float *Dtab, int K, int count, int32_t win_lo,
+                          const float *dmin, int K, int32_t win_lo,
                           int32_t win_count, uint32_t *list, unsigned int *n_list,
-                          hipStream_t s)
+                          hipStream_t s, bool cleared)
 {
-    (void)hipMemsetAsync(n_list, 0, sizeof(unsigned int), s);
+    if (!cleared)       // (ek_pam_setup_kernel clears it on its way)
+        (void)hipMemsetAsync(n_list, 0, sizeof(unsigned int), s);
     if (n <= 0)
         return;
-    hipLaunchKernelGGL(ek_pam_active_kernel,
-                       dim3((unsigned)((n + EK_BLOCK - 1) / EK_BLOCK)),
-                       dim3(EK_BLOCK), 0, s, dist, assign, n, Dtab, K, count,
-                       win_lo, win_count, list, n_list);
+    const int64_t per = (int64_t)EK_BLOCK * EK_ACT_PER;
+    hipLaunchKernelGGL(ek_pam_active_kernel, dim3((unsigned)((n + per - 1) / per)),
+                       dim3(EK_BLOCK), 0, s, dist, assign, n, dmin, K, win_lo,
+                       win_count, list, n_list);
 }
 
 // the listed frames, packed into the frame-minor tile layout of the frame store
@@ -1533,6 +1897,73 @@ void ek_launch_records_from_frames(const float *aos, const double *G, int A,
         fl.f[j] = j < count ? frames[j] : 0;
     hipLaunchKernelGGL(ek_records_from_frames_kernel, dim3(count), dim3(EK_BLOCK), 0,
                        s, aos, G, A, fl, global_offset, recs);
+}
+
+// Everything a window's prefetch needs of its proposals, in one launch: the
+// records (workgroup j: frame j, as above), the candidate tile / traces the
+// pass kernel reads (ek_spec.hip, ek_ctile_kernel's layout [atom][pair][xyz][2],
+// taken from the frames directly), the fixed plan "distances to these T
+// records", and the active-frame counter cleared.
+__global__ void __launch_bounds__(EK_BLOCK)
+ek_pam_setup_kernel(const float *__restrict__ aos, const double *__restrict__ G,
+                    int A, EkFrameList fl, int count, int T, int64_t global_offset,
+                    unsigned char *__restrict__ recs, float *__restrict__ ctile,
+                    double *__restrict__ ctrace, EkPlan *__restrict__ plan,
+                    unsigned int *__restrict__ counter)
+{
+    if ((int)blockIdx.x < count) {
+        const int64_t idx = fl.f[blockIdx.x];
+        EkRecHdr *h = (EkRecHdr *)(recs + (size_t)blockIdx.x * ek_rec_bytes(A));
+        float *coords = (float *)(h + 1);
+        if (threadIdx.x == 0) {
+            h->maxdist = __builtin_inff();
+            h->valid = 1;
+            h->gidx = global_offset + idx;
+            h->trace = G[idx];
+            h->reserved = 0;
+        }
+        for (int r = threadIdx.x; r < 3 * A; r += EK_BLOCK)
+            coords[r] = aos[(size_t)idx * 3 * A + r];
+    }
+    const int total = (A + EK_CTILE_PAD) * 3 * T;
+    for (int j = blockIdx.x * EK_BLOCK + threadIdx.x; j < total;
+         j += gridDim.x * EK_BLOCK) {
+        const int a = j / (3 * T), w = j % (3 * T);
+        const int c = (w / 6) * 2 + (w & 1), k = (w % 6) / 2;
+        float v = 0.f;
+        if (a < A && c < count)
+            v = aos[(size_t)fl.f[c] * 3 * A + 3 * a + k];
+        ctile[j] = v;
+    }
+    if (blockIdx.x == 0) {
+        if ((int)threadIdx.x < T)
+            ctrace[threadIdx.x] = (int)threadIdx.x < count ? G[fl.f[threadIdx.x]] : 0.0;
+        if (threadIdx.x == 0) {
+            plan->go = 1;
+            plan->teff = count;
+            plan->label = 0;
+            for (int j = 0; j < EK_MAX_CANDS; ++j)
+                plan->src[j] = j;
+            *counter = 0;
+        }
+    }
+}
+
+void ek_launch_pam_setup(const float *aos, const double *G, int A,
+                         const int64_t *frames, int count, int64_t global_offset,
+                         unsigned char *recs, float *ctile, double *ctrace,
+                         EkPlan *plan, unsigned int *counter, hipStream_t s)
+{
+    if (count <= 0)
+        return;
+    EkFrameList fl;
+    for (int j = 0; j < EK_MAX_CANDS; ++j)
+        fl.f[j] = j < count ? frames[j] : 0;
+    const int T = ek_pass_dist_T(count);
+    const int cb = ((A + EK_CTILE_PAD) * 3 * T + EK_BLOCK - 1) / EK_BLOCK;
+    hipLaunchKernelGGL(ek_pam_setup_kernel, dim3(std::max(count, cb)),
+                       dim3(EK_BLOCK), 0, s, aos, G, A, fl, count, T, global_offset,
+                       recs, ctile, ctrace, plan, counter);
 }
 
 void ek_launch_gather_tiles(const float *aos, const double *G, int A,

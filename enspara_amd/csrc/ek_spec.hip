@@ -443,7 +443,6 @@ typedef const float __attribute__((address_space(4))) *ek_cfp;
 #ifndef EK_PASS2_WAVES8
 #define EK_PASS2_WAVES8 4
 #endif
-#define EK_CTILE_PAD 8      // atoms of zeros after the last one (read-ahead)
 // measurement builds only (tools/lab_pass.py): 1 = no quartic solves, 2 = the
 // candidates are read once (no scalar loads in the loop), 4 = no FMAs
 #ifndef EK_PASS2_ABLATE
@@ -566,7 +565,12 @@ ek_pass2_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
     const int teff = plan->teff;
     const int label = plan->label;
     static_assert(EK_BLOCK == EK_TILE, "one workgroup per tile");
-    const int64_t f = (int64_t)blockIdx.x * EK_BLOCK + tid;
+    // distances only (!UPD): nothing is shared between the waves of a
+    // workgroup, so a short frame list may be launched one wave per workgroup
+    // (four workgroups per tile) and spread over four times the CUs
+    const int64_t f0 = UPD ? (int64_t)blockIdx.x * EK_BLOCK
+                           : (int64_t)blockIdx.x * blockDim.x;
+    const int64_t f = f0 + tid;
 #ifdef EK_PASS2_STAGGER
     // measurement builds: de-phase the workgroups that share a SIMD (the first
     // wave of workgroups starts together and every tile takes the same time, so
@@ -632,17 +636,17 @@ ek_pass2_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
         }
     }
 
-    const float *tb = tiles + (size_t)blockIdx.x * 3 * (size_t)A * EK_TILE;
+    const float *tb = tiles + (size_t)(f0 / EK_TILE) * 3 * (size_t)A * EK_TILE;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         (void *)tb, 0, 3 * A * EK_TILE * 4, 0x00020000);
-    const int vo = tid * 4;
+    const int vo = ((int)(f0 % EK_TILE) + tid) * 4;
     // non-temporal: the frame stream is read once per pass
 #ifndef EK_PASS2_LDMODE
 #define EK_PASS2_LDMODE 0   // measurement builds: 1 = no nt hint, 2 = global loads
 #endif
 #if EK_PASS2_LDMODE == 2
 #define EK_LD(SO, K)                                                           \
-    __builtin_nontemporal_load(tb + (size_t)((SO) / 4) + (K) * EK_TILE + tid)
+    __builtin_nontemporal_load(tb + (size_t)((SO) / 4) + (K) * EK_TILE + vo / 4)
 #else
 #define EK_LD(SO, K)                                                           \
     __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(            \
@@ -1002,29 +1006,40 @@ __global__ void ek_plan_fixed_kernel(EkPlan *__restrict__ plan, int count)
 void ek_launch_pass_dist(int count, const float *tiles, const double *G,
                          float *vecs, int64_t n, int64_t n_pad, int A,
                          const unsigned char *recs, EkPlan *plan, int form,
-                         float *ctile, double *ctrace, hipStream_t s)
+                         float *ctile, double *ctrace, hipStream_t s, bool prepared)
 {
     if (n <= 0 || count <= 0)
         return;
-    hipLaunchKernelGGL(ek_plan_fixed_kernel, dim3(1), dim3(EK_WAVE), 0, s, plan,
-                       count);
+    const int T = ek_pass_dist_T(count);
+    // prepared: plan, ctile and ctrace already hold these records
+    // (ek_launch_pam_setup)
+    prepared = prepared && form == 1 && ctile && T <= 8;
+    if (!prepared)
+        hipLaunchKernelGGL(ek_plan_fixed_kernel, dim3(1), dim3(EK_WAVE), 0, s, plan,
+                           count);
     const unsigned blocks = (unsigned)((n + EK_BLOCK - 1) / EK_BLOCK);
-    const int T = (count <= 4) ? 4 : (count <= 8 ? 8 : 16);
     if (form == 1 && ctile && T <= 8) {
         const unsigned cb = (unsigned)(((A + EK_CTILE_PAD) * 3 * T + EK_BLOCK - 1) /
                                        EK_BLOCK);
+        // a list too short to fill the chip (PAM's touched frames): one wave
+        // per workgroup
+        const bool thin = blocks < 1024;
+        const dim3 pg(thin ? (unsigned)((n + EK_WAVE - 1) / EK_WAVE) : blocks);
+        const dim3 pb(thin ? EK_WAVE : EK_BLOCK);
         if (T == 8) {
-            hipLaunchKernelGGL((ek_ctile_kernel<8>), dim3(cb), dim3(EK_BLOCK), 0, s,
-                               recs, plan, A, ctile, ctrace);
-            hipLaunchKernelGGL((ek_pass2_kernel<8, false, false>), dim3(blocks),
-                               dim3(EK_BLOCK), 0, s, tiles, G, nullptr, nullptr,
+            if (!prepared)
+                hipLaunchKernelGGL((ek_ctile_kernel<8>), dim3(cb), dim3(EK_BLOCK), 0,
+                                   s, recs, plan, A, ctile, ctrace);
+            hipLaunchKernelGGL((ek_pass2_kernel<8, false, false>), pg,
+                               pb, 0, s, tiles, G, nullptr, nullptr,
                                vecs, n, n_pad, A, ctile, ctrace, plan, nullptr,
                                EkFuse());
         } else {
-            hipLaunchKernelGGL((ek_ctile_kernel<4>), dim3(cb), dim3(EK_BLOCK), 0, s,
-                               recs, plan, A, ctile, ctrace);
-            hipLaunchKernelGGL((ek_pass2_kernel<4, false, false>), dim3(blocks),
-                               dim3(EK_BLOCK), 0, s, tiles, G, nullptr, nullptr,
+            if (!prepared)
+                hipLaunchKernelGGL((ek_ctile_kernel<4>), dim3(cb), dim3(EK_BLOCK), 0,
+                                   s, recs, plan, A, ctile, ctrace);
+            hipLaunchKernelGGL((ek_pass2_kernel<4, false, false>), pg,
+                               pb, 0, s, tiles, G, nullptr, nullptr,
                                vecs, n, n_pad, A, ctile, ctrace, plan, nullptr,
                                EkFuse());
         }

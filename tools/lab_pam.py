@@ -52,6 +52,7 @@ def child(path, K, reps, sweeps):
         st.reset_state()
         idx, cd, mx = st.kcenters_run(0, K, 0.0)
         med = [int(i) for i in idx]
+        med0 = list(med)
         rs = np.random.RandomState(0)
         spent.clear()
         st.sync()
@@ -67,8 +68,9 @@ def child(path, K, reps, sweeps):
         parts = "  ".join("%s %.3f/%d" % (k.replace("pam_", ""), v[0] / sweeps,
                                           v[1] // sweeps)
                           for k, v in spent.items())
-        print("%-24s sweep %.4f s  %.1f us/proposal  [%s]  sum %s"
-              % (name, dt, dt / K * 1e6, parts, h), flush=True)
+        moved = sum(1 for u, w in zip(med0, med) if u != w)
+        print("%-24s sweep %.4f s  %.1f us/proposal  [%s]  %d of %d medoids moved  sum %s"
+              % (name, dt, dt / K * 1e6, parts, moved, K, h), flush=True)
     print("%-24s checksums agree: %s" % (name, len(sums) == 1), flush=True)
 
 
