@@ -24,6 +24,10 @@ PHASES = ("pam_begin", "pam_count_members_batch", "pam_select_members_batch",
 
 def child(path, K, reps, sweeps):
     import numpy as np
+    if os.environ.get("LAB_TORCH"):         # as in bench.py: torch's runtime alongside
+        import torch
+        torch.cuda.set_device(0)
+        torch.cuda.synchronize()
     from enspara_amd.device import FrameStore
     from enspara_amd.cluster import kmedoids as km
     x = np.load(path, mmap_mode="r")
