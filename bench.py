@@ -300,9 +300,10 @@ def mdtraj_leg(x, centers, seconds):
         return {"available": False, "why": "%s: %s" % (type(e).__name__, e)}
 
 
-def km_width():
+def km_width(sharded_driver):
+    """Proposals drawn ahead and decided per window."""
     from enspara_amd.cluster import kmedoids as km
-    return int(km.PAM_PREFETCH)
+    return 8 if sharded_driver else int(km.PAM_PREFETCH)
 
 
 def kernel_source_hash():
@@ -581,7 +582,7 @@ def main():
             "s_per_sweep": t_pam / args.pam_sweeps,
             "s_per_sweep_runs": runs,
             "ms_per_proposal": t_pam / args.pam_sweeps / len(med) * 1e3,
-            "proposals_per_pass_over_frames": km_width(),
+            "proposals_per_window": km_width(use_dist),
             "prefetched_proposals_used": hits,
             "proposals_with_own_pass": misses,
             "prefetch_passes_over_touched_frames_only": pf_restricted,

@@ -158,10 +158,11 @@ def _check_proposals(proposals, medoid_inds):
                 proposals[0], medoid_inds[0]))
 
 
-# Proposals drawn ahead per pass over the frames (1..8; 1 = one distance pass
-# per proposal).  The results do not depend on it: every guess is checked
-# against the state and the random stream when its turn comes.
-PAM_PREFETCH = 8
+# Proposals drawn ahead and decided as one window (1..16, the library's
+# ek_pam_window_max(); 1 = one distance pass and one read-back per proposal).
+# The results do not depend on it: every guess is checked against the state and
+# the random stream when its turn comes.
+PAM_PREFETCH = 16
 
 
 class _DrawStream:
@@ -292,7 +293,7 @@ def _pam_sweep_device_on(store, medoid_inds, proposals, random_state):
     """(random_state: a _DrawStream over the caller's RandomState)"""
     store.pam_begin(medoid_inds)
     K = len(medoid_inds)
-    width = max(1, min(int(PAM_PREFETCH), 8))
+    width = max(1, min(int(PAM_PREFETCH), store.pam_window_max()))
     acceptances = 0
     old_cost = new_cost = float("nan")
 

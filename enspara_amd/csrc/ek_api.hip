@@ -104,16 +104,16 @@ struct ek_ctx {
     int64_t cnt_m = 0;
     int64_t pam_frame = -1;
     // proposal prefetch: member lists of a window of clusters and the distance
-    // vectors of up to EK_MAX_CANDS proposed frames
-    int32_t *bat_blockcnt = nullptr; // [EK_MAX_CANDS][nb]
-    int64_t *bat_scan = nullptr;     // [EK_MAX_CANDS][nb]
+    // vectors of up to EK_PAM_WIN proposed frames
+    int32_t *bat_blockcnt = nullptr; // [EK_PAM_WIN][nb]
+    int64_t *bat_scan = nullptr;     // [EK_PAM_WIN][nb]
     int64_t *bat_sel = nullptr;      // [0..8) counts, [8..16) selected frames
     int32_t bat_cid0 = -1, bat_count = 0;
-    float *pam_vecs = nullptr;       // [EK_MAX_CANDS][n_pad]
+    float *pam_vecs = nullptr;       // [EK_PAM_WIN][n_pad]
     unsigned char *pam_recs = nullptr;
     EkPlan *pam_plan = nullptr;
     unsigned int *moved = nullptr;
-    int64_t pf_frames[EK_MAX_CANDS];
+    int64_t pf_frames[EK_PAM_WIN];
     int32_t pf_count = 0;
     bool pf_external = false;        // slots hold caller-supplied centers
     EkPamOut *pam_out_dev = nullptr; // result record of a proposal
@@ -122,13 +122,9 @@ struct ek_ctx {
     EkPamWin *pam_win_host = nullptr;    // pinned
     int32_t pam_restore = -1;        // row of the trial table a rejected proposal left
     int32_t *med_list = nullptr;     // [med_cap] medoids within reach (ek_pam_prune_kernel)
-    float *dtab = nullptr;           // window tables, three blocks of EK_MAX_CANDS * (med_cap + 1):
+    float *dtab = nullptr;           // window tables, three blocks of EK_PAM_WIN * (med_cap + 1):
                                      // T medoid-to-proposal, O medoid-to-old-medoid, dmin
     int32_t tab_lo = -1, tab_n = 0;  // the window (first cluster, slots) the tables were made for
-    float *act_tiles = nullptr;      // frames needing exact distances, tile layout
-    double *act_G = nullptr;
-    float *act_vecs = nullptr;       // [EK_MAX_CANDS][act_cap]
-    int64_t act_cap = 0;
     unsigned int *act_n_host = nullptr;  // pinned
     int64_t pf_sparse = 0, pf_full = 0;  // prefetch passes of either kind
     int32_t pf_backoff = 0;          // windows to go before the restricted form is tried again
@@ -299,9 +295,6 @@ static int ek_free_all(ek_ctx *c)
     (void)hipFree(c->pam_out_dev);
     (void)hipFree(c->med_list);
     (void)hipFree(c->dtab);
-    (void)hipFree(c->act_tiles);
-    (void)hipFree(c->act_G);
-    (void)hipFree(c->act_vecs);
     if (c->act_n_host)
         (void)hipHostFree(c->act_n_host);
     if (c->pam_out_host)
@@ -1361,12 +1354,12 @@ static int ek_pam_alloc(ek_ctx *c, int32_t K)
         }
         EK_HIP(hipMalloc((void **)&c->sq_out, 2 * sizeof(double)));
         EK_HIP(hipMalloc((void **)&c->bat_blockcnt,
-                         (size_t)EK_MAX_CANDS * nb * sizeof(int32_t)));
+                         (size_t)EK_PAM_WIN * nb * sizeof(int32_t)));
         EK_HIP(hipMalloc((void **)&c->bat_scan,
-                         (size_t)EK_MAX_CANDS * nb * sizeof(int64_t)));
+                         (size_t)EK_PAM_WIN * nb * sizeof(int64_t)));
         // [0,8) counts, [8,16) selected frames, [16,24) requested member ranks
         EK_HIP(hipMalloc((void **)&c->bat_sel,
-                         3 * EK_MAX_CANDS * sizeof(int64_t)));
+                         3 * EK_PAM_WIN * sizeof(int64_t)));
         EK_HIP(hipMalloc((void **)&c->moved, sizeof(unsigned int)));
         EK_HIP(hipMemsetAsync(c->moved, 0, sizeof(unsigned int), c->stream));
         EK_HIP(hipMalloc((void **)&c->pam_out_dev, sizeof(EkPamOut)));
@@ -1401,7 +1394,7 @@ static int ek_pam_alloc(ek_ctx *c, int32_t K)
         EK_HIP(hipMalloc((void **)&c->med_idx, (size_t)(K + 1) * sizeof(int64_t)));
         EK_HIP(hipMalloc((void **)&c->med_list, (size_t)(K + 1) * sizeof(int32_t)));
         EK_HIP(hipMalloc((void **)&c->dtab,
-                         (size_t)3 * EK_MAX_CANDS * (K + 1) * sizeof(float)));
+                         (size_t)3 * EK_PAM_WIN * (K + 1) * sizeof(float)));
         c->med_cap = K;
     }
     c->med_K = K;
@@ -1570,7 +1563,7 @@ static int ek_pam_tail(ek_ctx *c, int32_t cid, const float *newd,
     const bool tabs = fuse && prune && c->tab_lo == cid - decide->slot &&
                       decide->slot < c->tab_n;
     if (fuse) {
-        const size_t tb = (size_t)EK_MAX_CANDS * (c->med_cap + 1);
+        const size_t tb = (size_t)EK_PAM_WIN * (c->med_cap + 1);
         EkPamClsWin w;
         w.prev_accept = prev_accept;
         w.frames_aos = c->aos;
@@ -1795,6 +1788,11 @@ extern "C" int ek_pam_commit(ek_ctx *c, int accept)
     return EK_OK;
 }
 
+extern "C" int32_t ek_pam_window_max(void)
+{
+    return EK_PAM_WIN;
+}
+
 // ---- PAM proposal prefetch ------------------------------------------------------------
 // A sweep visits clusters 0..K-1 in order and an accepted proposal rarely
 // touches the clusters visited next, so the host draws the next few proposals
@@ -1808,10 +1806,10 @@ extern "C" int ek_pam_count_members_batch(ek_ctx *c, int32_t cid0, int32_t count
     if (!c->ndist || c->med_K < 1)
         return ek_fail(EK_ESTATE, "ek_pam_count_members_batch: call ek_pam_begin "
                                   "first");
-    if (count < 1 || count > EK_MAX_CANDS || cid0 < 0 || cid0 + count > c->med_K)
+    if (count < 1 || count > EK_PAM_WIN || cid0 < 0 || cid0 + count > c->med_K)
         return ek_fail(EK_EARG, "ek_pam_count_members_batch: clusters [%d,+%d) "
                                 "outside [0,%d) or more than %d", cid0, count,
-                       c->med_K, EK_MAX_CANDS);
+                       c->med_K, EK_PAM_WIN);
     EK_HIP(hipSetDevice(c->device));
     const size_t nb = ((size_t)std::max<int64_t>(c->n, 1) + EK_BLOCK - 1) / EK_BLOCK;
     (void)nb;
@@ -1839,14 +1837,14 @@ extern "C" int ek_pam_select_members_batch(ek_ctx *c, int32_t cid0, int32_t coun
     const size_t nb = ((size_t)std::max<int64_t>(c->n, 1) + EK_BLOCK - 1) / EK_BLOCK;
     (void)nb;
     // (a negative rank: that member lives on another shard)
-    EK_HIP(hipMemcpyAsync(c->bat_sel + 2 * EK_MAX_CANDS, js,
+    EK_HIP(hipMemcpyAsync(c->bat_sel + 2 * EK_PAM_WIN, js,
                           (size_t)count * sizeof(int64_t), hipMemcpyHostToDevice,
                           c->stream));
     ek_launch_select_member_multi(c->assign, c->n, cid0, count, c->bat_scan,
-                                  c->bat_sel + 2 * EK_MAX_CANDS,
-                                  c->bat_sel + EK_MAX_CANDS, c->stream);
+                                  c->bat_sel + 2 * EK_PAM_WIN,
+                                  c->bat_sel + EK_PAM_WIN, c->stream);
     EK_CHECK_LAUNCH();
-    EK_HIP(hipMemcpyAsync(frames, c->bat_sel + EK_MAX_CANDS,
+    EK_HIP(hipMemcpyAsync(frames, c->bat_sel + EK_PAM_WIN,
                           (size_t)count * sizeof(int64_t), hipMemcpyDeviceToHost,
                           c->stream));
     EK_HIP(ek_wait(c));
@@ -1864,10 +1862,10 @@ static int ek_pam_vecs_alloc(ek_ctx *c)
 {
     if (!c->pam_vecs) {
         EK_HIP(hipMalloc((void **)&c->pam_vecs,
-                         (size_t)EK_MAX_CANDS * std::max<int64_t>(c->n_pad, 1) *
+                         (size_t)EK_PAM_WIN * std::max<int64_t>(c->n_pad, 1) *
                              sizeof(float)));
         EK_HIP(hipMalloc((void **)&c->pam_recs,
-                         (size_t)EK_MAX_CANDS * ek_rec_bytes(c->A)));
+                         (size_t)EK_PAM_WIN * ek_rec_bytes(c->A)));
         EK_HIP(hipMalloc((void **)&c->pam_plan, sizeof(EkPlan)));
     }
     return EK_OK;
@@ -1898,23 +1896,26 @@ static int ek_pam_prefetch_vectors(ek_ctx *c, int count, int32_t win_lo,
         // O (old medoids of the window's clusters) only where the window's slots
         // and the proposals coincide: ek_pam_window_run's pruning reads it
         const bool slots = local && win_count == count;
-        const size_t tb = (size_t)EK_MAX_CANDS * (c->med_cap + 1);
+        const size_t tb = (size_t)EK_PAM_WIN * (c->med_cap + 1);
+        const int groups = (count + EK_MAX_CANDS - 1) / EK_MAX_CANDS;
         ek_launch_pam_tables(c->med_aos, c->med_G, c->A, K, c->pam_restore,
                              c->pam_recs, count, win_lo, slots ? count : 0, c->dtab,
                              c->dtab + tb, c->dtab + 2 * tb, c->stream);
         c->tab_lo = win_lo;
         c->tab_n = slots ? count : 0;
-        ek_launch_pam_active(c->dist, c->assign, c->n, c->dtab + 2 * tb, K, win_lo,
-                             win_count, c->amb, c->amb_count + 3, c->stream,
+        ek_launch_pam_active(c->dist, c->assign, c->n, c->dtab + 2 * tb, groups, K,
+                             win_lo, win_count, c->amb, c->amb_count + 3, c->stream,
                              prepared);
         EK_CHECK_LAUNCH();
         EK_HIP(hipMemcpyAsync(c->act_n_host, c->amb_count + 3, sizeof(unsigned int),
                               hipMemcpyDeviceToHost, c->stream));
         EK_HIP(ek_wait(c));
         const int64_t n_act = *c->act_n_host;
-        if (n_act * 8 <= c->n && c->aos) {
+        if (n_act * 4 <= c->n) {
             // a short list: straight from the frame-major copy, 64 frames x the
             // proposals per workgroup, results scattered into the full vectors
+            // (a quarter of the frames costs about what the passes over all of
+            // them do)
             EK_HIP(hipMemsetD32Async((hipDeviceptr_t)c->pam_vecs, 0x7f800000,
                                      (size_t)count * c->n_pad, c->stream));
             ek_launch_pam_list_dist(c->aos, c->G, c->A, c->amb, n_act, c->pam_recs,
@@ -1923,46 +1924,18 @@ static int ek_pam_prefetch_vectors(ek_ctx *c, int count, int32_t win_lo,
             ++c->pf_sparse;
             return EK_OK;
         }
-        if (n_act * 8 <= c->n) {
-            const int64_t need = (n_act + EK_TILE - 1) / EK_TILE * EK_TILE;
-            if (need > c->act_cap) {
-                (void)hipFree(c->act_tiles);
-                (void)hipFree(c->act_G);
-                (void)hipFree(c->act_vecs);
-                c->act_tiles = nullptr;
-                c->act_G = nullptr;
-                c->act_vecs = nullptr;
-                c->act_cap = 0;
-                const int64_t cap = std::max<int64_t>(16384, need * 3 / 2 /
-                                                      EK_TILE * EK_TILE + EK_TILE);
-                EK_HIP(hipMalloc((void **)&c->act_tiles,
-                                 (size_t)cap * 3 * c->A * sizeof(float)));
-                EK_HIP(hipMalloc((void **)&c->act_G, (size_t)cap * sizeof(double)));
-                EK_HIP(hipMalloc((void **)&c->act_vecs,
-                                 (size_t)EK_MAX_CANDS * cap * sizeof(float)));
-                c->act_cap = cap;
-            }
-            EK_HIP(hipMemsetD32Async((hipDeviceptr_t)c->pam_vecs, 0x7f800000,
-                                     (size_t)count * c->n_pad, c->stream));
-            ek_launch_gather_tiles(c->aos, c->G, c->A, c->amb, n_act,
-                                   c->act_tiles, c->act_G, c->stream);
-            ek_launch_pass_dist(count, c->act_tiles, c->act_G, c->act_vecs, n_act,
-                                c->act_cap, c->A, c->pam_recs, c->pam_plan,
-                                c->pass_form, c->ctile, c->ctrace, c->stream,
-                                prepared);
-            ek_launch_scatter_vecs(c->amb, n_act, c->act_vecs, c->act_cap, count,
-                                   c->pam_vecs, c->n_pad, c->stream);
-            EK_CHECK_LAUNCH();
-            ++c->pf_sparse;
-            return EK_OK;
-        }
         // too many frames within reach (large clusters): the test cost a table,
         // a scan and a read-back for nothing -- leave it out for a while
         c->pf_backoff = 15;
     }
-    ek_launch_pass_dist(count, c->tiles, c->G, c->pam_vecs, c->n, c->n_pad, c->A,
-                        c->pam_recs, c->pam_plan, c->pass_form, c->ctile,
-                        c->ctrace, c->stream, prepared);
+    // a pass over all frames per group of EK_MAX_CANDS proposals
+    const size_t rstride = ek_rec_bytes(c->A);
+    for (int g0 = 0; g0 < count; g0 += EK_MAX_CANDS)
+        ek_launch_pass_dist(std::min(count - g0, EK_MAX_CANDS), c->tiles, c->G,
+                            c->pam_vecs + (size_t)g0 * c->n_pad, c->n, c->n_pad,
+                            c->A, c->pam_recs + (size_t)g0 * rstride, c->pam_plan,
+                            c->pass_form, c->ctile, c->ctrace, c->stream,
+                            prepared && g0 == 0);
     EK_CHECK_LAUNCH();
     ++c->pf_full;
     return EK_OK;
@@ -1993,9 +1966,9 @@ static int ek_pam_prefetch_frames(ek_ctx *c, const int64_t *frames, int32_t coun
         return ek_fail(EK_EARG, "ek_pam_prefetch: NULL argument");
     if (!c->ndist || c->med_K < 1)
         return ek_fail(EK_ESTATE, "ek_pam_prefetch: call ek_pam_begin first");
-    if (count < 0 || count > EK_MAX_CANDS)
+    if (count < 0 || count > EK_PAM_WIN)
         return ek_fail(EK_EARG, "ek_pam_prefetch: count=%d outside [0,%d]", count,
-                       EK_MAX_CANDS);
+                       EK_PAM_WIN);
     for (int32_t j = 0; j < count; ++j)
         if (frames[j] < 0 || frames[j] >= c->n)
             return ek_fail(EK_EARG, "ek_pam_prefetch: frame %lld out of range",
@@ -2053,7 +2026,7 @@ extern "C" int ek_pam_window_run(ek_ctx *c, int32_t cid0, int32_t count,
     int rc = ek_pam_precheck(c, cid0, "ek_pam_window_run");
     if (rc)
         return rc;
-    if (count < 1 || count > EK_MAX_CANDS || cid0 + count > c->med_K || !frames ||
+    if (count < 1 || count > EK_PAM_WIN || cid0 + count > c->med_K || !frames ||
         !n_members || !n_done || !accept)
         return ek_fail(EK_EARG, "ek_pam_window_run: bad window [%d,+%d)", cid0,
                        count);
@@ -2068,7 +2041,7 @@ extern "C" int ek_pam_window_run(ek_ctx *c, int32_t cid0, int32_t count,
                                   "full chunk is not the expected perfect tree");
     EK_HIP(hipSetDevice(c->device));
     int64_t max_m = 0;
-    const float *newd[EK_MAX_CANDS];
+    const float *newd[EK_PAM_WIN];
     for (int32_t i = 0; i < count; ++i) {
         if (frames[i] < 0 || frames[i] >= c->n || n_members[i] < 0 ||
             n_members[i] > c->n)

@@ -285,14 +285,19 @@ struct EkPamOut {
     uint32_t moved;      // bit i: membership of cluster win_lo + i would change
 };
 static_assert(sizeof(EkPamOut) == 32, "EkPamOut layout");
-// a window of proposals decided on the device (ek_pam_window_run)
+// a window of proposals decided on the device (ek_pam_window_run): up to
+// EK_PAM_WIN consecutive clusters, their proposals drawn, prefetched (in groups
+// of EK_MAX_CANDS columns) and decided without a host round trip in between
+#define EK_PAM_WIN 16
+static_assert(EK_PAM_WIN % EK_MAX_CANDS == 0 && EK_PAM_WIN <= 32,
+              "whole column groups; the stale mask is 32 bits");
 struct EkPamWin {
     int32_t stop;       // slots [0, stop) were decided
     uint32_t stale;     // clusters of the window whose membership changed
     int32_t err;        // 1 + slot of a proposal with more ambiguous members than declared
     int32_t pad;
-    int32_t accept[EK_MAX_CANDS];
-    EkPamOut out[EK_MAX_CANDS];
+    int32_t accept[EK_PAM_WIN];
+    EkPamOut out[EK_PAM_WIN];
 };
 // what the last workgroup of a proposal's cost-sum launch needs to decide the
 // proposal and to set up the next one (ek_pam.hip, "a window of proposals")
@@ -318,8 +323,9 @@ void ek_launch_pam_apply(const int32_t *flag, float *dist, const float *ndist,
                          int32_t *assign, const int32_t *nassign, int64_t n,
                          hipStream_t s);
 // active-set proposal prefetch (ek_pam.hip)
-// T [n_prop][K]: medoid-to-proposal distances, dmin [K] their minimum per
-// medoid, O [n_old][K]: distances to the medoids of clusters old_lo ..
+// T [n_prop][K]: medoid-to-proposal distances, dmin [groups of EK_MAX_CANDS
+// proposals][K] their minimum per medoid and group, O [n_old][K]: distances to
+// the medoids of clusters old_lo ..
 void ek_launch_pam_tables(const float *aos, const double *Gm, int A, int K, int held,
                           const unsigned char *recs, int n_prop, int old_lo,
                           int n_old, float *T, float *O, float *dmin,
@@ -331,7 +337,7 @@ void ek_launch_pam_list_dist(const float *aos, const double *G, int A,
                              const unsigned char *recs, int count, float *vecs,
                              int64_t n_pad, hipStream_t s);
 void ek_launch_pam_active(const float *dist, const int32_t *assign, int64_t n,
-                          const float *dmin, int K, int32_t win_lo,
+                          const float *dmin, int n_groups, int K, int32_t win_lo,
                           int32_t win_count, uint32_t *list, unsigned int *n_list,
                           hipStream_t s, bool cleared = false);
 // records, candidate tile + traces, fixed plan and a cleared counter for a
@@ -347,16 +353,10 @@ static inline int ek_pass_dist_T(int count)     // the pass width ek_launch_pass
     return (count <= 4) ? 4 : (count <= 8 ? 8 : 16);
 }
 // (aos: the frame-major copy of the shard)
-void ek_launch_gather_tiles(const float *aos, const double *G, int A,
-                            const uint32_t *list, int64_t count, float *ctiles,
-                            double *cG, hipStream_t s);
 void ek_launch_records_from_frames(const float *aos, const double *G, int A,
                                    const int64_t *frames, int count,
                                    int64_t global_offset, unsigned char *recs,
                                    hipStream_t s);
-void ek_launch_scatter_vecs(const uint32_t *list, int64_t count,
-                            const float *cvecs, int64_t cpad, int nvec,
-                            float *vecs, int64_t n_pad, hipStream_t s);
 void ek_launch_pam_trial(const float *tiles, const double *G, int A, float *aos,
                          double *Gm, int K, int cid, int restore_cid,
                          int64_t frame_index, const int64_t *idx_dev,

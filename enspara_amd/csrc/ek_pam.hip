@@ -173,8 +173,8 @@ ek_count_members_multi_kernel(const int32_t *__restrict__ assign, int64_t n,
                               int32_t cid0, int count, int nblocks,
                               int32_t *__restrict__ blockcnt)
 {
-    __shared__ int cnt[EK_MAX_CANDS];
-    if (threadIdx.x < EK_MAX_CANDS)
+    __shared__ int cnt[EK_PAM_WIN];
+    if (threadIdx.x < EK_PAM_WIN)
         cnt[threadIdx.x] = 0;
     __syncthreads();
     const int64_t f = (int64_t)blockIdx.x * EK_BLOCK + threadIdx.x;
@@ -1572,12 +1572,12 @@ void ek_pw_build_shape(int len, EkPwShape *sh)
 //
 // MODE 0, the distance tables of a window (rows: the medoid table):
 //   T[j * K + c] = rmsd(medoid c, proposal j), j < n_prop
-//   dmin[c]      = min_j T[j * K + c]
+//   dmin[g * K + c] = min of T[j * K + c] over the columns j of group g
 //   O[i * K + c] = rmsd(medoid c, medoid old_lo + i), i < n_old -- what the
 //                  pruning of slot i's ambiguous members asks for
 //                  (ek_pam_prune_kernel / the classification's last workgroup)
 //   `held` is the row a rejected proposal still occupies (its medoid is in row
-//   K), or -1.  grid (ceil(K / 64), 2): y = 0 proposals, y = 1 old medoids.
+//   K), or -1.  grid (ceil(K / 64), column groups of proposals + of old medoids).
 // MODE 1, a window's proposals against the frames they can touch (rows: the
 //   listed frames of the frame-major copy):
 //   vecs[j * n_pad + list[i]] = rmsd(frame list[i], proposal j)
@@ -1618,8 +1618,13 @@ ek_pam_pairs_kernel(EkPairArgs p)
     __shared__ float tmin[EK_MAX_CANDS][EK_WAVE];
     const int A = p.A;
     const int lane = threadIdx.x & (EK_WAVE - 1);
-    const int j = __builtin_amdgcn_readfirstlane(threadIdx.x / EK_WAVE);
-    const bool old = MODE == 0 && blockIdx.y != 0;
+    // grid.y: the groups of EK_MAX_CANDS columns -- the proposals' first, then
+    // (MODE 0) the old medoids'
+    const int gp = (p.n_col + EK_MAX_CANDS - 1) / EK_MAX_CANDS;
+    const bool old = MODE == 0 && (int)blockIdx.y >= gp;
+    const int grp = old ? (int)blockIdx.y - gp : (int)blockIdx.y;
+    const int jw = __builtin_amdgcn_readfirstlane(threadIdx.x / EK_WAVE);
+    const int j = grp * EK_MAX_CANDS + jw;      // this wave's column
     const int ncol = old ? p.n_old : p.n_col;
     const bool live = j < ncol;
     // this wave's column
@@ -1673,12 +1678,12 @@ ek_pam_pairs_kernel(EkPairArgs p)
 #pragma unroll
         for (int k = 0; k < NY; ++k)
             if (lane + EK_WAVE * k < 3 * EK_PAIR_CH)
-                ytile[j * 3 * EK_PAIR_CH + lane + EK_WAVE * k] = vy[k];
+                ytile[jw * 3 * EK_PAIR_CH + lane + EK_WAVE * k] = vy[k];
         __syncthreads();
         if (a0 + EK_PAIR_CH < A)                // in flight during the FMAs
             EK_PAIR_LOAD(a0 + EK_PAIR_CH)
         if (live) {
-            const float *yt = ytile + j * 3 * EK_PAIR_CH;
+            const float *yt = ytile + jw * 3 * EK_PAIR_CH;
 #pragma unroll 8
             for (int a = 0; a < ch; ++a) {
                 const float x0 = tile[(3 * a + 0) * LD + lane],
@@ -1709,14 +1714,14 @@ ek_pam_pairs_kernel(EkPairArgs p)
         (old ? p.O : p.T)[(size_t)j * p.K + c] = D;
     if (old)
         return;
-    tmin[j][lane] = D;
+    tmin[jw][lane] = D;
     __syncthreads();
-    if (j == 0 && ok) {
+    if (jw == 0 && ok) {
         float m = tmin[0][lane];
 #pragma unroll
         for (int q = 1; q < EK_MAX_CANDS; ++q)
             m = fminf(m, tmin[q][lane]);
-        p.dmin[c] = m;
+        p.dmin[(size_t)grp * p.K + c] = m;
     }
 }
 
@@ -1748,7 +1753,9 @@ void ek_launch_pam_tables(const float *aos, const double *Gm, int A, int K, int 
     p.T = T;
     p.O = O;
     p.dmin = dmin;
-    ek_pairs_launch<0>(p, dim3((K + EK_WAVE - 1) / EK_WAVE, n_old > 0 ? 2 : 1), s);
+    const int groups = (n_prop + EK_MAX_CANDS - 1) / EK_MAX_CANDS +
+                       (n_old + EK_MAX_CANDS - 1) / EK_MAX_CANDS;
+    ek_pairs_launch<0>(p, dim3((K + EK_WAVE - 1) / EK_WAVE, groups), s);
 }
 
 // vecs[j * n_pad + list[i]] = rmsd(frame list[i], record j), i < n_rows, j < count
@@ -1769,7 +1776,8 @@ void ek_launch_pam_list_dist(const float *aos, const double *G, int A,
     p.n_rows = n_rows;
     p.n_pad = n_pad;
     p.vecs = vecs;
-    ek_pairs_launch<1>(p, dim3((unsigned)((n_rows + EK_WAVE - 1) / EK_WAVE)), s);
+    ek_pairs_launch<1>(p, dim3((unsigned)((n_rows + EK_WAVE - 1) / EK_WAVE),
+                               (count + EK_MAX_CANDS - 1) / EK_MAX_CANDS), s);
 }
 
 // the frames that need exact distances -> list (any order), *n_list
@@ -1778,7 +1786,7 @@ void ek_launch_pam_list_dist(const float *aos, const double *G, int A,
 __global__ void __launch_bounds__(EK_BLOCK)
 ek_pam_active_kernel(const float *__restrict__ dist,
                      const int32_t *__restrict__ assign, int64_t n,
-                     const float *__restrict__ dmin, int K,
+                     const float *__restrict__ dmin, int n_groups, int K,
                      int32_t win_lo, int32_t win_count,
                      uint32_t *__restrict__ list, unsigned int *__restrict__ n_list)
 {
@@ -1800,6 +1808,11 @@ ek_pam_active_kernel(const float *__restrict__ dist,
 #pragma unroll
     for (int q = 0; q < EK_ACT_PER; ++q)
         dm[q] = (a[q] >= 0 && a[q] < K) ? dmin[a[q]] : 0.f;
+    for (int g = 1; g < n_groups; ++g)
+#pragma unroll
+        for (int q = 0; q < EK_ACT_PER; ++q)
+            if (a[q] >= 0 && a[q] < K)
+                dm[q] = fminf(dm[q], dmin[(size_t)g * K + a[q]]);
 #pragma unroll
     for (int q = 0; q < EK_ACT_PER; ++q) {
         const int64_t f = f0 + (int64_t)q * EK_BLOCK;
@@ -1825,7 +1838,7 @@ ek_pam_active_kernel(const float *__restrict__ dist,
 }
 
 void ek_launch_pam_active(const float *dist, const int32_t *assign, int64_t n,
-                          const float *dmin, int K, int32_t win_lo,
+                          const float *dmin, int n_groups, int K, int32_t win_lo,
                           int32_t win_count, uint32_t *list, unsigned int *n_list,
                           hipStream_t s, bool cleared)
 {
@@ -1835,35 +1848,13 @@ void ek_launch_pam_active(const float *dist, const int32_t *assign, int64_t n,
         return;
     const int64_t per = (int64_t)EK_BLOCK * EK_ACT_PER;
     hipLaunchKernelGGL(ek_pam_active_kernel, dim3((unsigned)((n + per - 1) / per)),
-                       dim3(EK_BLOCK), 0, s, dist, assign, n, dmin, K, win_lo,
-                       win_count, list, n_list);
+                       dim3(EK_BLOCK), 0, s, dist, assign, n, dmin, n_groups, K,
+                       win_lo, win_count, list, n_list);
 }
 
-// the listed frames, packed into the frame-minor tile layout of the frame store
-// (so that the pass kernel can run over them); one workgroup per frame
-// listed frames -> tile layout.  One workgroup per listed frame (hundreds to a
-// few thousand frames: parallelism matters more than store width here); the
-// frame is read from the frame-major copy, 12 A contiguous bytes.
-__global__ void __launch_bounds__(EK_BLOCK)
-ek_gather_tiles_kernel(const float *__restrict__ aos,
-                       const double *__restrict__ G, int A,
-                       const uint32_t *__restrict__ list, int64_t count,
-                       float *__restrict__ ctiles, double *__restrict__ cG)
-{
-    const unsigned int i = blockIdx.x;
-    const uint32_t f = list[i];
-    const float *p = aos + (size_t)f * 3 * A;
-    float *o = ctiles + (size_t)(i / EK_TILE) * 3 * (size_t)A * EK_TILE +
-               (i % EK_TILE);
-    for (int r = threadIdx.x; r < 3 * A; r += EK_BLOCK)
-        o[(size_t)r * EK_TILE] = p[r];
-    if (threadIdx.x == 0)
-        cG[i] = G[f];
-}
-
-// the records of up to EK_MAX_CANDS frames in one launch (block j = frame j)
+// the records of up to EK_PAM_WIN frames in one launch (block j = frame j)
 struct EkFrameList {
-    int64_t f[EK_MAX_CANDS];
+    int64_t f[EK_PAM_WIN];
 };
 __global__ void __launch_bounds__(EK_BLOCK)
 ek_records_from_frames_kernel(const float *__restrict__ aos,
@@ -1893,7 +1884,7 @@ void ek_launch_records_from_frames(const float *aos, const double *G, int A,
     if (count <= 0)
         return;
     EkFrameList fl;
-    for (int j = 0; j < EK_MAX_CANDS; ++j)
+    for (int j = 0; j < EK_PAM_WIN; ++j)
         fl.f[j] = j < count ? frames[j] : 0;
     hipLaunchKernelGGL(ek_records_from_frames_kernel, dim3(count), dim3(EK_BLOCK), 0,
                        s, aos, G, A, fl, global_offset, recs);
@@ -1902,11 +1893,14 @@ void ek_launch_records_from_frames(const float *aos, const double *G, int A,
 // Everything a window's prefetch needs of its proposals, in one launch: the
 // records (workgroup j: frame j, as above), the candidate tile / traces the
 // pass kernel reads (ek_spec.hip, ek_ctile_kernel's layout [atom][pair][xyz][2],
-// taken from the frames directly), the fixed plan "distances to these T
-// records", and the active-frame counter cleared.
+// taken from the frames directly) and the fixed plan "distances to these
+// records" for the first `cg` <= EK_MAX_CANDS of them (what a pass over all
+// frames starts with when the restriction to touched frames does not apply),
+// and the active-frame counter cleared.
 __global__ void __launch_bounds__(EK_BLOCK)
 ek_pam_setup_kernel(const float *__restrict__ aos, const double *__restrict__ G,
-                    int A, EkFrameList fl, int count, int T, int64_t global_offset,
+                    int A, EkFrameList fl, int count, int cg, int T,
+                    int64_t global_offset,
                     unsigned char *__restrict__ recs, float *__restrict__ ctile,
                     double *__restrict__ ctrace, EkPlan *__restrict__ plan,
                     unsigned int *__restrict__ counter)
@@ -1931,16 +1925,16 @@ ek_pam_setup_kernel(const float *__restrict__ aos, const double *__restrict__ G,
         const int a = j / (3 * T), w = j % (3 * T);
         const int c = (w / 6) * 2 + (w & 1), k = (w % 6) / 2;
         float v = 0.f;
-        if (a < A && c < count)
+        if (a < A && c < cg)
             v = aos[(size_t)fl.f[c] * 3 * A + 3 * a + k];
         ctile[j] = v;
     }
     if (blockIdx.x == 0) {
         if ((int)threadIdx.x < T)
-            ctrace[threadIdx.x] = (int)threadIdx.x < count ? G[fl.f[threadIdx.x]] : 0.0;
+            ctrace[threadIdx.x] = (int)threadIdx.x < cg ? G[fl.f[threadIdx.x]] : 0.0;
         if (threadIdx.x == 0) {
             plan->go = 1;
-            plan->teff = count;
+            plan->teff = cg;
             plan->label = 0;
             for (int j = 0; j < EK_MAX_CANDS; ++j)
                 plan->src[j] = j;
@@ -1957,48 +1951,14 @@ void ek_launch_pam_setup(const float *aos, const double *G, int A,
     if (count <= 0)
         return;
     EkFrameList fl;
-    for (int j = 0; j < EK_MAX_CANDS; ++j)
+    for (int j = 0; j < EK_PAM_WIN; ++j)
         fl.f[j] = j < count ? frames[j] : 0;
-    const int T = ek_pass_dist_T(count);
+    const int cg = std::min(count, EK_MAX_CANDS);
+    const int T = ek_pass_dist_T(cg);
     const int cb = ((A + EK_CTILE_PAD) * 3 * T + EK_BLOCK - 1) / EK_BLOCK;
     hipLaunchKernelGGL(ek_pam_setup_kernel, dim3(std::max(count, cb)),
-                       dim3(EK_BLOCK), 0, s, aos, G, A, fl, count, T, global_offset,
-                       recs, ctile, ctrace, plan, counter);
+                       dim3(EK_BLOCK), 0, s, aos, G, A, fl, count, cg, T,
+                       global_offset, recs, ctile, ctrace, plan, counter);
 }
 
-void ek_launch_gather_tiles(const float *aos, const double *G, int A,
-                            const uint32_t *list, int64_t count, float *ctiles,
-                            double *cG, hipStream_t s)
-{
-    if (count <= 0)
-        return;
-    hipLaunchKernelGGL(ek_gather_tiles_kernel, dim3((unsigned)count),
-                       dim3(EK_BLOCK), 0, s, aos, G, A, list, count, ctiles, cG);
-}
-
-// vecs[j][list[i]] = cvecs[j][i]
-__global__ void __launch_bounds__(EK_BLOCK)
-ek_scatter_vecs_kernel(const uint32_t *__restrict__ list, int64_t count,
-                       const float *__restrict__ cvecs, int64_t cpad, int nvec,
-                       float *__restrict__ vecs, int64_t n_pad)
-{
-    const int64_t i = (int64_t)blockIdx.x * EK_BLOCK + threadIdx.x;
-    if (i >= count)
-        return;
-    const uint32_t f = list[i];
-    for (int j = 0; j < nvec; ++j)
-        vecs[(size_t)j * n_pad + f] = cvecs[(size_t)j * cpad + i];
-}
-
-void ek_launch_scatter_vecs(const uint32_t *list, int64_t count,
-                            const float *cvecs, int64_t cpad, int nvec,
-                            float *vecs, int64_t n_pad, hipStream_t s)
-{
-    if (count <= 0)
-        return;
-    hipLaunchKernelGGL(ek_scatter_vecs_kernel,
-                       dim3((unsigned)((count + EK_BLOCK - 1) / EK_BLOCK)),
-                       dim3(EK_BLOCK), 0, s, list, count, cvecs, cpad, nvec, vecs,
-                       n_pad);
-}
 

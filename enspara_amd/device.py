@@ -238,6 +238,10 @@ class FrameStore:
             C.byref(mask)))
         return oc.value, nc.value, na.value, mask.value
 
+    def pam_window_max(self):
+        """The most proposals a window (pam_prefetch + pam_window_run) holds."""
+        return int(self.lib.ek_pam_window_max())
+
     def pam_window_run(self, cid0, frames, n_members, win_count):
         """The proposals frames[i] for clusters cid0 + i (all prefetched),
         decided and committed on the device in order; stops at the first cluster

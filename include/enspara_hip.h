@@ -252,9 +252,10 @@ int ek_pam_commit(ek_ctx *ctx, int accept);
 
 /* Proposal prefetch.  A sweep (kmedoids.py:575-699) visits clusters 0..K-1 in
  * order, and an accepted proposal rarely changes the clusters visited next, so
- * the host may draw the next `count` (<= 8) proposals ahead of time and have
- * their distance vectors computed by ONE pass over the frames instead of one
- * pass each; every guess is verified when its turn comes, so the sweep's
+ * the host may draw the next `count` (<= ek_pam_window_max(), 16) proposals
+ * ahead of time and have their distance vectors computed together (one pass
+ * over the frames per 8 of them, or -- ek_pam_prefetch_window -- only the
+ * frames they can touch) instead of by one pass each; every guess is verified when its turn comes, so the sweep's
  * results do not change.
  *  ek_pam_count_members_batch: member counts of clusters cid0..cid0+count-1 in
  *    the current state (one read-back);
@@ -296,8 +297,8 @@ int ek_pam_propose_ex(ek_ctx *ctx, int32_t cid, int64_t frame_index,
                       uint32_t *moved_mask);
 int ek_pam_prefetch_stats(ek_ctx *ctx, int64_t *hits, int64_t *misses);
 /* A window of proposals without a host round trip each: the loop body of
- * kmedoids.py:597-699 for clusters cid0 .. cid0 + count - 1 (count <= 8), in
- * order.  frames[i] is the frame proposed for cluster cid0 + i, drawn by the
+ * kmedoids.py:597-699 for clusters cid0 .. cid0 + count - 1 (count <=
+ * ek_pam_window_max()), in order.  frames[i] is the frame proposed for cluster cid0 + i, drawn by the
  * caller from that cluster's member list as it stood when the window was
  * opened, n_members[i] that list's length; every frames[i] must have been
  * prefetched with ek_pam_prefetch_window(ctx, frames, count, cid0, win_count).
@@ -309,6 +310,8 @@ int ek_pam_prefetch_stats(ek_ctx *ctx, int64_t *hits, int64_t *misses);
  * handles cluster cid0 + *n_done one proposal at a time and opens a new window
  * after it.  accept[i] (i < *n_done): 1 if proposal i was accepted; the costs
  * and ambiguous-member counts are returned for logging. */
+/* the most proposals a window / a local-frame prefetch may hold */
+int32_t ek_pam_window_max(void);
 int ek_pam_window_run(ek_ctx *ctx, int32_t cid0, int32_t count,
                       const int64_t *frames, const int64_t *n_members,
                       int32_t win_lo, int32_t win_count, int32_t *n_done,
