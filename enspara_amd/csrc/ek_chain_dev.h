@@ -91,7 +91,7 @@ __device__ __forceinline__ void ek_chain_reduce(const EkBlockMax *blockmax,
     const int tid = threadIdx.x;
     const int wv = tid / EK_WAVE, lane = tid & (EK_WAVE - 1);
     const int w = wv >> 1, part = wv & 1;
-    constexpr int U = 8;
+    constexpr int U = 16;
     if (w < cn) {
         const EkBlockMax *src = (w == 0) ? blockmax : pm + (size_t)(w - 1) * nbp;
         const int cnt = (w == 0) ? nb : nbp;

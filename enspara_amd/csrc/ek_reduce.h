@@ -11,17 +11,51 @@ __device__ __forceinline__ bool ek_better(float v, uint32_t i, float bv,
     return (v > bv) || (v == bv && i < bi);
 }
 
+// Wave-wide arg-max, the winner in every lane.  The order (value descending,
+// index ascending) is total, so any reduction tree gives the same pair: four
+// DPP steps make every row of 16 lanes agree (lane ^ 1, lane ^ 2 inside the
+// quads, then the two mirrors: once the quads agree, mirroring pairs them up
+// as well as an xor would), and the four row results are combined as scalars.
+// Call it with the whole wave active.
+// (A butterfly of ds_bpermute shuffles is six dependent trips through the LDS
+// crossbar per operand: 0.6 us a call, and the round's small kernels make
+// eight or more in a row.)
+template <int CTRL>
+__device__ __forceinline__ void ek_argmax_dpp_step(float &v, uint32_t &i)
+{
+    // (a lane whose partner is switched off sees its own pair: neutral)
+    const int vb = __builtin_bit_cast(int, v);
+    const float ov = __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(vb, vb, CTRL, 0xf, 0xf, false));
+    const uint32_t oi =
+        (uint32_t)__builtin_amdgcn_update_dpp((int)i, (int)i, CTRL, 0xf, 0xf, false);
+    if (ek_better(ov, oi, v, i)) {
+        v = ov;
+        i = oi;
+    }
+}
+
 __device__ __forceinline__ void ek_wave_argmax(float &v, uint32_t &i)
 {
+    ek_argmax_dpp_step<0xB1>(v, i);     // quad_perm [1,0,3,2]
+    ek_argmax_dpp_step<0x4E>(v, i);     // quad_perm [2,3,0,1]
+    ek_argmax_dpp_step<0x141>(v, i);    // row_half_mirror
+    ek_argmax_dpp_step<0x140>(v, i);    // row_mirror
+    float bv = __builtin_bit_cast(
+        float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    uint32_t bi = (uint32_t)__builtin_amdgcn_readlane((int)i, 0);
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const float ov = __shfl_xor(v, off, 64);
-        const uint32_t oi = __shfl_xor(i, off, 64);
-        if (ek_better(ov, oi, v, i)) {
-            v = ov;
-            i = oi;
+    for (int row = 1; row < 4; ++row) {
+        const float rv = __builtin_bit_cast(
+            float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16 * row));
+        const uint32_t ri = (uint32_t)__builtin_amdgcn_readlane((int)i, 16 * row);
+        if (ek_better(rv, ri, bv, bi)) {
+            bv = rv;
+            bi = ri;
         }
     }
+    v = bv;
+    i = bi;
 }
 
 // ---- handing small results from all workgroups of a launch to its last one ------

@@ -33,6 +33,15 @@
 #include "ek_chain_dev.h"
 #include "ek_top_dev.h"
 
+// measurement builds (-DEK_ROUND_STAMPS): the last workgroup of the chain kernel
+// prints where its time went (100 MHz ticks), once, a few hundred rounds in
+#ifdef EK_ROUND_STAMPS
+__device__ unsigned int ek_stamp_count;
+#define EK_STAMP(k) if (threadIdx.x == 0) st[k] = __builtin_amdgcn_s_memrealtime()
+#else
+#define EK_STAMP(k)
+#endif
+
 #define EK_ROUND_THREADS 1024       // chain kernel: also the width of its tail
 #define EK_ROUND_FPT 4              // frames per thread there (16-byte loads)
 
@@ -51,6 +60,10 @@ ek_round_chain_kernel(EkRound r, int bootstrap)
     extern __shared__ uint32_t skip[];      // pick fallback for very large shards
     const int tid = threadIdx.x;
     const int nb = (int)((r.n + EK_BLOCK - 1) / EK_BLOCK);
+#ifdef EK_ROUND_STAMPS
+    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    EK_STAMP(0);
     if (!bootstrap) {
         if (!r.plan->go)
             return;             // the run is over: nothing changes any more
@@ -116,8 +129,10 @@ ek_round_chain_kernel(EkRound r, int bootstrap)
                 }
             }
         }
+        EK_STAMP(1);
         if (!ek_arrive_last(r.tick + 1))
             return;
+        EK_STAMP(2);
         // ---- decide (ek_chain.hip steps 2-3) ------------------------------------
         // states 0 .. cn - 1 are what the walk looks at
         __shared__ long long s_gidx[EK_MAX_CANDS];
@@ -128,6 +143,7 @@ ek_round_chain_kernel(EkRound r, int bootstrap)
         }
         ek_chain_reduce<true>(r.blockmax, r.pm, nb, nb, cn, sv, si);
         __syncthreads();
+        EK_STAMP(3);
         if (tid == 0) {
             // ek_chain_walk on a register copy of the control words: one read,
             // one write-back, no dependent global reads in between
@@ -182,7 +198,16 @@ ek_round_chain_kernel(EkRound r, int bootstrap)
     const int na = s_napply;
     const EkBlockMax *state = na == 0 ? r.blockmax : r.pm + (size_t)(na - 1) * nb;
     EkTop *top = (EkTop *)r.top;
+    EK_STAMP(4);
     ek_pick_top_body<true>(state, nb, top, skip);
+#ifdef EK_ROUND_STAMPS
+    __syncthreads();
+    EK_STAMP(5);
+    if (tid == 0 && !bootstrap && atomicAdd(&ek_stamp_count, 1u) % 200 == 150)
+        printf("chain last wg (x10 ns): body %llu ticket %llu reduce %llu walk %llu "
+               "pick %llu\n", st[1] - st[0], st[2] - st[1], st[3] - st[2],
+               st[4] - st[3], st[5] - st[4]);
+#endif
 }
 
 void ek_launch_round_chain(const EkRound &r, int bootstrap, hipStream_t s)
@@ -266,6 +291,8 @@ ek_round_next_kernel(EkRound r, int bootstrap)
             sval[tid] = top->val[tid];
             sidx[tid] = top->idx[tid];
         }
+        if (tid < EK_MAX_CANDS)
+            sel[tid] = 0;
 #pragma unroll
         for (int u = 0; u < PER; ++u)
             sD[tid + u * EK_BLOCK] = dreg[u];
@@ -335,26 +362,41 @@ ek_round_next_kernel(EkRound r, int bootstrap)
         }
     }
     // ... and, from the same reads, the candidate tile of the next pass:
-    // [atom][pair][xyz][2], zeros for unused slots and the atoms of padding
+    // [atom][pair][xyz][2], zeros for unused slots and the atoms of padding.
+    // All of a trip's loads (T candidates x 4 rows per thread) go out before
+    // the first store: the stores may alias them as far as the compiler knows.
     const int A3 = 3 * r.A;
-    for (int e = tid; e < ns * A3; e += EK_BLOCK) {
-        const int c = e / A3, row = e % A3;
-        const float v = r.aos[(size_t)sidx[sel[c]] * A3 + row];
-        ((float *)(r.recs + (size_t)c * rstride + sizeof(EkRecHdr)))[row] = v;
-        if (go) {
-            const int a = row / 3, k = row % 3;
-            r.ctile[a * (3 * T) + (c / 2) * 6 + k * 2 + (c & 1)] = v;
+    for (int k0 = 0; k0 * EK_BLOCK < A3; k0 += 4) {
+        float v[T][4];
+#pragma unroll
+        for (int c = 0; c < T; ++c) {
+            const float *src = r.aos + (size_t)sidx[sel[c < ns ? c : 0]] * A3;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int row = tid + (k0 + u) * EK_BLOCK;
+                v[c][u] = (c < ns && row < A3) ? src[row] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < T; ++c) {
+            float *rec = (float *)(r.recs + (size_t)c * rstride + sizeof(EkRecHdr));
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int row = tid + (k0 + u) * EK_BLOCK;
+                if (row >= A3)
+                    continue;
+                if (c < ns)
+                    rec[row] = v[c][u];
+                if (go) {       // (zero for a slot without a candidate)
+                    const int a = row / 3, k = row % 3;
+                    r.ctile[a * (3 * T) + (c / 2) * 6 + k * 2 + (c & 1)] = v[c][u];
+                }
+            }
         }
     }
-    if (go) {
-        const int total = (r.A + 8) * 3 * T;
-        for (int j = tid; j < total; j += EK_BLOCK) {
-            const int a = j / (3 * T), w = j % (3 * T);
-            const int c = (w / 6) * 2 + (w & 1);
-            if (a >= r.A || c >= ns)
-                r.ctile[j] = 0.f;
-        }
-    }
+    if (go && tid < EK_CTILE_PAD * 3 * T)       // the atoms of padding
+        r.ctile[r.A * 3 * T + tid] = 0.f;
+    static_assert(EK_CTILE_PAD * 3 * T <= EK_BLOCK, "one store per thread");
     if (tid == 0) {
         EkPlan *plan = r.plan;
         r.ctl->last_max = first_max;

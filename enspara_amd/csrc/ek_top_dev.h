@@ -174,6 +174,7 @@ __device__ __forceinline__ void ek_pick_top_body(const EkBlockMax *blockmax, int
             const uint32_t i = wt_i[tid];
             if (i != 0xffffffffu) {
                 int rank = 0;
+#pragma unroll 16
                 for (int e = 0; e < NWV * LW; ++e) {
                     const uint32_t oi = wt_i[e];
                     if (oi != 0xffffffffu && ek_better(wt_v[e], oi, v, i))
