@@ -60,6 +60,16 @@ def test_counts_edge_cases():
     C = assigns_to_counts([np.array([0, 1]), np.array([2, 2, 2, 2])],
                           lag_time=3).toarray()
     assert C.sum() == 1 and C[2, 2] == 1
+    # more states than the dense count table takes (> 16 384): the sorted-key form
+    C = assigns_to_counts(a, lag_time=1, max_n_states=20000)
+    assert C.shape == (20000, 20000) and C.nnz == 4
+    np.testing.assert_array_equal(C.tocsr()[:3, :3].toarray(),
+                                  [[0, 1, 0], [0, 1, 1], [1, 0, 0]])
+    big = np.array([[19999, 0, 19999, 19999, -1, 17000, 0]])
+    C = assigns_to_counts(big, lag_time=1, max_n_states=20000).tocoo()
+    got = sorted(zip(C.row.tolist(), C.col.tolist(), C.data.tolist()))
+    assert got == [(0, 19999, 1), (17000, 0, 1), (19999, 0, 1), (19999, 17000, 1),
+                   (19999, 19999, 1)]
     with pytest.raises(DataInvalid):
         assigns_to_counts(np.array([0, 1, 2]), lag_time=1)
     with pytest.raises(DataInvalid):

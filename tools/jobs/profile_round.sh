@@ -28,3 +28,12 @@ python3 tools/summarize_profile.py trace $f $out/kernel_summary_assign.csv
 rm -rf $out/trace_assign
 grep -E "assign" $out/kernel_summary_assign.csv | cut -c1-110
 grep -E "assign n=" $out/assign.log
+# one pass per center (BASELINE.md's roofline case) and the torch.distributed driver with one rank
+python3 bench.py --candidates 1 --no-cpu-baseline --pam-sweeps 0 > $out/bench_candidates1.json 2> $out/bench_candidates1.err
+python3 bench.py --sharded --no-cpu-baseline --pam-sweeps 1 > $out/bench_sharded_1rank.json 2> $out/bench_sharded_1rank.err
+# one PAM sweep under the kernel trace (tools/lab_pam.py child): per-kernel table + a window's timeline
+bash tools/jobs/trace_pam.sh $1/pam > /dev/null 2>&1
+python3 tools/lab_pam.py --reps 3 2>&1 | grep -v amdgpu.ids | tail -4 > $out/pam/lab_untraced.log
+head -16 $out/pam/kernel_summary.csv | cut -c1-110; cat $out/pam/lab_untraced.log
+# MSM transition counts at scale
+python3 tools/msm_probe.py 2>&1 | grep -v amdgpu.ids > $out/msm_probe.log; cat $out/msm_probe.log
