@@ -205,8 +205,11 @@ ek_round_chain_kernel(EkRound r, int bootstrap)
     EK_STAMP(5);
     if (tid == 0 && !bootstrap && atomicAdd(&ek_stamp_count, 1u) % 200 == 150)
         printf("chain last wg (x10 ns): body %llu ticket %llu reduce %llu walk %llu "
-               "pick %llu\n", st[1] - st[0], st[2] - st[1], st[3] - st[2],
-               st[4] - st[3], st[5] - st[4]);
+               "pick %llu (setup+issue %llu, looks %llu, rank %llu, rest %llu)\n",
+               st[1] - st[0], st[2] - st[1], st[3] - st[2], st[4] - st[3],
+               st[5] - st[4], ek_pick_st[1] - ek_pick_st[0],
+               ek_pick_st[2] - ek_pick_st[1], ek_pick_st[3] - ek_pick_st[2],
+               st[5] - ek_pick_st[3]);
 #endif
 }
 

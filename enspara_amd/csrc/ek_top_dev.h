@@ -99,10 +99,17 @@ __device__ __forceinline__ float *ek_top_D(unsigned char *scr, int A)
 // the EK_TOP_M largest per-workgroup maxima, ordered (value desc, index asc)
 // (called by all EK_RED_THREADS threads of a workgroup; `skip`: LDS bitmap over
 // the workgroups, (nb + 31) / 32 words, used only when nb > 8 * EK_RED_THREADS)
+#ifdef EK_ROUND_STAMPS
+__device__ unsigned long long ek_pick_st[8];
+#define EK_PSTAMP(k) if (threadIdx.x == 0) ek_pick_st[k] = __builtin_amdgcn_s_memrealtime()
+#else
+#define EK_PSTAMP(k)
+#endif
 template <bool COH = false>
 __device__ __forceinline__ void ek_pick_top_body(const EkBlockMax *blockmax, int nb,
                                                  EkTop *top, uint32_t *skip)
 {
+    EK_PSTAMP(0);
     __shared__ uint32_t top_i[EK_TOP_M];
     __shared__ float top_v[EK_TOP_M];
     __shared__ int n_top;
@@ -133,6 +140,7 @@ __device__ __forceinline__ void ek_pick_top_body(const EkBlockMax *blockmax, int
             }
         }
     }
+    EK_PSTAMP(1);
     constexpr int NWV = EK_RED_THREADS / EK_WAVE;
     constexpr int LW = 8;                // looks per wave
     __shared__ float wt_v[NWV * LW];
@@ -147,21 +155,29 @@ __device__ __forceinline__ void ek_pick_top_body(const EkBlockMax *blockmax, int
         // fall into one wave -- which only costs a slightly worse guess; entry 0
         // is always the overall first-index arg-max.
         const int lane = tid & (EK_WAVE - 1), wv = tid / EK_WAVE;
+        // entries per thread actually in use (uniform: the rest is skipped)
+        const int per = (nb + EK_RED_THREADS - 1) / EK_RED_THREADS;
         for (int look = 0; look < LW; ++look) {
             float v = -__builtin_inff();
             uint32_t i = 0xffffffffu;
 #pragma unroll
-            for (int k = 0; k < PICK_PER; ++k)
+            for (int k = 0; k < PICK_PER; ++k) {
+                if (k >= per)
+                    break;
                 if (ci[k] != 0xffffffffu && ek_better(cv[k], ci[k], v, i)) {
                     v = cv[k];
                     i = ci[k];
                 }
+            }
             ek_wave_argmax(v, i);            // every lane holds the winner
             if (i != 0xffffffffu) {          // its owner retires it (indices are unique)
 #pragma unroll
-                for (int k = 0; k < PICK_PER; ++k)
+                for (int k = 0; k < PICK_PER; ++k) {
+                    if (k >= per)
+                        break;
                     if (ci[k] == i)
                         ci[k] = 0xffffffffu;
+                }
             }
             if (lane == 0) {
                 wt_v[wv * LW + look] = v;
@@ -169,17 +185,36 @@ __device__ __forceinline__ void ek_pick_top_body(const EkBlockMax *blockmax, int
             }
         }
         __syncthreads();
-        if (tid < NWV * LW) {
-            const float v = wt_v[tid];
-            const uint32_t i = wt_i[tid];
+        EK_PSTAMP(2);
+        // every survivor's rank among the NWV * LW of them, the comparisons
+        // spread over the whole workgroup (EK_RED_THREADS / (NWV * LW) threads
+        // per survivor, partial counts added up in LDS)
+        {
+            constexpr int NS = NWV * LW;                // survivors
+            constexpr int SPLIT = EK_RED_THREADS / NS;  // threads per survivor
+            static_assert(EK_RED_THREADS % NS == 0 && NS % SPLIT == 0, "even split");
+            __shared__ int rank_acc[NS];
+            if (tid < NS)
+                rank_acc[tid] = 0;
+            __syncthreads();
+            const int e0 = tid % NS, part = tid / NS;
+            const float v = wt_v[e0];
+            const uint32_t i = wt_i[e0];
             if (i != 0xffffffffu) {
                 int rank = 0;
-#pragma unroll 16
-                for (int e = 0; e < NWV * LW; ++e) {
+#pragma unroll
+                for (int q = 0; q < NS / SPLIT; ++q) {
+                    const int e = part * (NS / SPLIT) + q;
                     const uint32_t oi = wt_i[e];
                     if (oi != 0xffffffffu && ek_better(wt_v[e], oi, v, i))
                         ++rank;
                 }
+                if (rank)
+                    atomicAdd(&rank_acc[e0], rank);
+            }
+            __syncthreads();
+            if (tid < NS && i != 0xffffffffu) {
+                const int rank = rank_acc[tid];
                 if (rank < EK_TOP_M) {
                     top_i[rank] = i;
                     top_v[rank] = v;
@@ -188,6 +223,7 @@ __device__ __forceinline__ void ek_pick_top_body(const EkBlockMax *blockmax, int
             }
         }
         __syncthreads();
+        EK_PSTAMP(3);
         if (tid == 0 && n_top > EK_TOP_M)
             n_top = EK_TOP_M;
     } else {
