@@ -2,6 +2,8 @@
 oracle over many small shapes (ties, tiny inputs, odd sizes, cut-offs, warm
 starts, duplicates).  usage: fuzz_gpu.py [n_cases] [seed]"""
 import os, sys, time
+# (the oracle's OpenMP team: a box shows 256 CPUs and grants 16)
+os.environ.setdefault("OMP_NUM_THREADS", "8")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from enspara_amd import synth

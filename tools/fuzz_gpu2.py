@@ -2,6 +2,8 @@
 assignment (both kernels), the multi-rank drivers on a single DeviceShard, and
 warm-started k-centers.  usage: fuzz_gpu2.py [n_cases] [seed]"""
 import os, sys, time
+# (the oracle's OpenMP team: a box shows 256 CPUs and grants 16)
+os.environ.setdefault("OMP_NUM_THREADS", "8")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch

@@ -1,6 +1,8 @@
 """Scratch: randomized k-hybrid runs large enough for the restricted PAM prefetch
 and the medoid pruning (n >= 16384), against the oracle."""
 import os, sys, time
+# (the oracle's OpenMP team: a box shows 256 CPUs and grants 16)
+os.environ.setdefault("OMP_NUM_THREADS", "8")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from enspara_amd import synth

@@ -1,3 +1,4 @@
-LAB_CONFIGS="1,1,-1,1" python3 tools/lab_pass.py enspara_amd/_variants/stamps.so --centers 3000 2>&1 | grep -v amdgpu.ids | grep chain | tail -3
-LAB_CONFIGS="1,1,-1,1;1,1,-1,0;1,0,1,0" python3 tools/lab_pass.py --centers 5000 2>&1 | grep -v amdgpu.ids | tail -4
-python -m pytest tests -q -m gpu -x 2>&1 | tail -2
+timeout 300 python3 tools/fuzz_gpu.py 3000 21 2>&1 | grep -v amdgpu | tail -1
+timeout 300 python3 tools/fuzz_gpu2.py 800 21 2>&1 | grep -v amdgpu | tail -1
+timeout 400 python3 tools/fuzz_gpu3.py 25 21 2>&1 | grep -v amdgpu | tail -1
+timeout 300 python3 tools/stress_rounds.py 12 2>&1 | grep -v amdgpu | tail -7
