@@ -2398,13 +2398,10 @@ extern "C" int ek_spec_chain_max(ek_ctx *c, const void *rows_all, int32_t n_shar
     if (!c->vecs || !c->pm)
         return ek_fail(EK_ESTATE, "ek_spec_chain_max: call ek_spec_begin first");
     EK_HIP(hipSetDevice(c->device));
-    const int nb = (int)((c->n + EK_BLOCK - 1) / EK_BLOCK);
-    ek_launch_chain_order((const EkChainRow *)rows_all, n_shards, c->plan, c->dist,
-                          c->vecs, c->n, c->n_pad, c->goff, c->stream);
-    ek_launch_chain_max(c->dist, c->vecs, c->n, c->n_pad, c->plan, c->pm, 0,
-                        c->goff, c->stream);
-    ek_launch_chain_localmax(c->blockmax, c->pm, nb, ek_chain_max_blocks(c->n),
-                             c->goff, c->plan, (EkMaxHdr *)hdrs_out, c->stream);
+    // (order, per-prefix maxima and this shard's headers in one launch)
+    ek_launch_chain_max2(c->dist, c->vecs, c->n, c->n_pad, c->plan,
+                         (const EkChainRow *)rows_all, n_shards, c->blockmax, c->pm,
+                         c->goff, (EkMaxHdr *)hdrs_out, c->tick + 3, c->stream);
     EK_CHECK_LAUNCH();
     return EK_OK;
 }

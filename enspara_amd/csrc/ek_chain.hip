@@ -28,6 +28,7 @@
 #include "ek_common.h"
 #include "ek_reduce.h"
 #include "ek_chain_dev.h"
+#include <algorithm>
 
 // ---- 1. order ---------------------------------------------------------------------
 // the rows of the candidate frames this shard owns
@@ -70,53 +71,6 @@ void ek_launch_chain_rows(const EkPlan *plan, const float *dist,
 {
     hipLaunchKernelGGL(ek_chain_rows_kernel, dim3(1), dim3(EK_WAVE), 0, s, plan,
                        dist, vecs, n, n_pad, global_offset, rows_out);
-}
-
-__global__ void __launch_bounds__(EK_WAVE)
-ek_chain_order_kernel(const EkChainRow *__restrict__ rows_all, int n_shards,
-                      EkPlan *__restrict__ plan, const float *__restrict__ dist,
-                      const float *__restrict__ vecs, int64_t n, int64_t n_pad,
-                      int64_t global_offset)
-{
-    __shared__ EkChainRow rows[EK_MAX_CANDS];
-    const int tid = threadIdx.x;
-    if (rows_all) {                     // the owner's row among the shards'
-        if (tid < EK_MAX_CANDS) {
-            rows[tid].valid = 0;
-            for (int sh = 0; sh < n_shards; ++sh) {
-                const EkChainRow *r = &rows_all[(size_t)sh * EK_MAX_CANDS + tid];
-                if (r->valid) {
-                    rows[tid] = *r;
-                    break;
-                }
-            }
-        }
-    } else {
-        ek_chain_rows_local(plan, dist, vecs, n, n_pad, global_offset, rows, tid);
-    }
-    __syncthreads();
-    if (tid != 0)
-        return;
-    plan->chain_n = 0;
-    plan->napply = 0;
-    plan->chain_label0 = 0;
-    if (!plan->go)
-        return;
-    int chain[EK_MAX_CANDS];
-    const int cn = ek_chain_simulate(plan, rows, chain);
-    for (int k = 0; k < cn; ++k)
-        plan->chain[k] = chain[k];
-    plan->chain_n = cn;
-}
-
-void ek_launch_chain_order(const EkChainRow *rows_all, int n_shards,
-                           EkPlan *plan, const float *dist, const float *vecs,
-                           int64_t n, int64_t n_pad, int64_t global_offset,
-                           hipStream_t s)
-{
-    hipLaunchKernelGGL(ek_chain_order_kernel, dim3(1), dim3(EK_WAVE), 0, s,
-                       rows_all, n_shards, plan, dist, vecs, n, n_pad,
-                       global_offset);
 }
 
 // ---- 2. maxima of the states the prefixes would leave --------------------------------
@@ -247,8 +201,7 @@ int ek_chain_max_blocks(int64_t n)
     return (int)((n + per - 1) / per);
 }
 
-// local_order != 0: single shard, the order is worked out here (no
-// ek_launch_chain_order before it)
+// local_order != 0: single shard, the order is worked out here
 void ek_launch_chain_max(const float *dist, const float *vecs, int64_t n,
                          int64_t n_pad, EkPlan *plan, EkBlockMax *pm,
                          int local_order, int64_t global_offset, hipStream_t s)
@@ -260,35 +213,144 @@ void ek_launch_chain_max(const float *dist, const float *vecs, int64_t n,
                        local_order, global_offset);
 }
 
-// ---- 3. decide ----------------------------------------------------------------------
-__global__ void __launch_bounds__(EK_CHAIN_THREADS)
-ek_chain_localmax_kernel(const EkBlockMax *__restrict__ blockmax,
-                         const EkBlockMax *__restrict__ pm, int nb, int nbp,
-                         int64_t global_offset, const EkPlan *__restrict__ plan,
-                         EkMaxHdr *__restrict__ hdrs_out)
+// ---- 1 + 2 + this shard's part of 3, one launch (the multi-shard round) ----------------
+// Steps 1, 2 and the shard-local half of 3: every workgroup works the presumed order out of the gathered
+// rows for itself (64 reads and a few hundred scalar steps; workgroup 0 records
+// it in the plan for the apply step), a wave covers 256 consecutive frames and
+// leaves their first-index arg-max after every prefix of the order in pm (as
+// coherent stores), and the last workgroup to finish (arrival counter,
+// ek_reduce.h) reduces them to this shard's (max distance, global index) per
+// prefix: the 128 bytes that go into the second exchange.
+#define EK_CM2_THREADS 1024
+#define EK_CM2_FPT 4
+
+__global__ void __launch_bounds__(EK_CM2_THREADS)
+ek_chain_max2_kernel(const float *__restrict__ dist, const float *__restrict__ vecs,
+                     int64_t n, int64_t n_pad, EkPlan *plan,
+                     const EkChainRow *__restrict__ rows_all, int n_shards,
+                     const EkBlockMax *__restrict__ blockmax, EkBlockMax *pm,
+                     int64_t global_offset, EkMaxHdr *__restrict__ hdrs_out,
+                     unsigned int *tick)
 {
+    __shared__ EkChainRow rows[EK_MAX_CANDS];
+    __shared__ int s_chain[EK_MAX_CANDS];
+    __shared__ int s_cn;
     __shared__ float sv[EK_MAX_CANDS];
     __shared__ uint32_t si[EK_MAX_CANDS];
-    const int cn = plan->chain_n;
-    ek_chain_reduce(blockmax, pm, nb, nbp, cn, sv, si);
-    __syncthreads();
-    const int k = threadIdx.x;
-    if (k < EK_MAX_CANDS) {
-        const bool ok = k < cn && si[k] != 0xffffffffu;
-        hdrs_out[k].maxdist = ok ? sv[k] : -__builtin_inff();
-        hdrs_out[k].valid = ok ? 1 : 0;
-        hdrs_out[k].gidx = ok ? global_offset + (int64_t)si[k] : -1;
+    const int tid = threadIdx.x;
+    const int nb = (int)((n + EK_BLOCK - 1) / EK_BLOCK);
+    if (tid < EK_MAX_CANDS) {           // the owner's row among the shards'
+        rows[tid].valid = 0;
+        for (int sh = 0; sh < n_shards; ++sh) {
+            const EkChainRow *r = &rows_all[(size_t)sh * EK_MAX_CANDS + tid];
+            if (r->valid) {
+                rows[tid] = *r;
+                break;
+            }
+        }
     }
+    __syncthreads();
+    if (tid == 0) {
+        int chain[EK_MAX_CANDS];
+        const int c = plan->go ? ek_chain_simulate(plan, rows, chain) : 0;
+        for (int k = 0; k < c; ++k)
+            s_chain[k] = chain[k];
+        s_cn = c;
+        if (blockIdx.x == 0) {          // (nobody reads plan->chain* in this launch)
+            for (int k = 0; k < c; ++k)
+                plan->chain[k] = chain[k];
+            plan->chain_n = c;
+            plan->napply = 0;
+            plan->chain_label0 = 0;
+        }
+    }
+    __syncthreads();
+    const int cn = s_cn;
+    if (cn > 1) {
+        const int64_t f0 = ((int64_t)blockIdx.x * EK_CM2_THREADS + tid) * EK_CM2_FPT;
+        const bool whole = f0 + EK_CM2_FPT <= n;
+        float run[EK_CM2_FPT];
+        float dv[EK_MAX_CANDS][EK_CM2_FPT];
+        // all loads first: the running minimum would otherwise serialise them
+#pragma unroll
+        for (int k = 1; k < EK_MAX_CANDS - 1; ++k) {
+#pragma unroll
+            for (int q = 0; q < EK_CM2_FPT; ++q)
+                dv[k][q] = __builtin_inff();
+            if (k < cn) {
+                const float *v = vecs + (size_t)(s_chain[k - 1] - 1) * n_pad + f0;
+                if (whole) {
+                    const float4 t = *(const float4 *)v;
+                    dv[k][0] = t.x; dv[k][1] = t.y; dv[k][2] = t.z; dv[k][3] = t.w;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < EK_CM2_FPT; ++q)
+                        if (f0 + q < n)
+                            dv[k][q] = v[q];
+                }
+            }
+        }
+        if (whole) {
+            const float4 t = *(const float4 *)(dist + f0);
+            run[0] = t.x; run[1] = t.y; run[2] = t.z; run[3] = t.w;
+        } else {
+#pragma unroll
+            for (int q = 0; q < EK_CM2_FPT; ++q)
+                run[q] = (f0 + q < n) ? dist[f0 + q] : 0.f;
+        }
+        const int64_t wg = ((int64_t)blockIdx.x * EK_CM2_THREADS + tid) / EK_WAVE;
+#pragma unroll
+        for (int k = 1; k < EK_MAX_CANDS - 1; ++k) {
+            if (k < cn) {                       // uniform
+                float v = -__builtin_inff();
+                uint32_t i = 0xffffffffu;
+#pragma unroll
+                for (int q = 0; q < EK_CM2_FPT; ++q) {
+                    if (f0 + q < n) {
+                        if (dv[k][q] < run[q])      // kcenters.py:304
+                            run[q] = dv[k][q];
+                        if (ek_better(run[q], (uint32_t)(f0 + q), v, i)) {
+                            v = run[q];
+                            i = (uint32_t)(f0 + q);
+                        }
+                    }
+                }
+                ek_wave_argmax(v, i);
+                if ((tid & (EK_WAVE - 1)) == 0 && wg < nb)
+                    ek_coh_store_bm(&pm[(size_t)(k - 1) * nb + wg], v, i);
+            }
+        }
+    }
+    if (!ek_arrive_last(tick))
+        return;
+    // ---- the last workgroup: this shard's maximum after every prefix ------------------
+    // (state 0 is what the pass left in blockmax: written by the launch before)
+    ek_chain_reduce<true>(blockmax, pm, nb, nb, cn, sv, si);
+    __syncthreads();
+    if (tid < EK_MAX_CANDS) {
+        const bool ok = tid < cn && si[tid] != 0xffffffffu;
+        hdrs_out[tid].maxdist = ok ? sv[tid] : -__builtin_inff();
+        hdrs_out[tid].valid = ok ? 1 : 0;
+        hdrs_out[tid].gidx = ok ? global_offset + (int64_t)si[tid] : -1;
+    }
+    if (tid == 0)
+        *tick = 0;
 }
 
-void ek_launch_chain_localmax(const EkBlockMax *blockmax, const EkBlockMax *pm,
-                              int nb, int nbp, int64_t global_offset,
-                              const EkPlan *plan, EkMaxHdr *hdrs_out, hipStream_t s)
+void ek_launch_chain_max2(const float *dist, const float *vecs, int64_t n,
+                          int64_t n_pad, EkPlan *plan, const EkChainRow *rows_all,
+                          int n_shards, const EkBlockMax *blockmax, EkBlockMax *pm,
+                          int64_t global_offset, EkMaxHdr *hdrs_out,
+                          unsigned int *tick, hipStream_t s)
 {
-    hipLaunchKernelGGL(ek_chain_localmax_kernel, dim3(1), dim3(EK_CHAIN_THREADS),
-                       0, s, blockmax, pm, nb, nbp, global_offset, plan, hdrs_out);
+    const int64_t per = (int64_t)EK_CM2_THREADS * EK_CM2_FPT;
+    const unsigned blocks = (unsigned)std::max<int64_t>(1, (n + per - 1) / per);
+    hipLaunchKernelGGL(ek_chain_max2_kernel, dim3(blocks), dim3(EK_CM2_THREADS), 0, s,
+                       dist, vecs, n, n_pad, plan, rows_all, n_shards, blockmax, pm,
+                       global_offset, hdrs_out, tick);
 }
 
+// ---- 3. decide ----------------------------------------------------------------------
 __global__ void __launch_bounds__(EK_WAVE)
 ek_chain_decide_kernel(const EkMaxHdr *__restrict__ hdrs_all, int n_shards,
                        double cutoff, EkPlan *__restrict__ plan,

@@ -415,19 +415,19 @@ void ek_launch_chain_rows(const EkPlan *plan, const float *dist,
                           hipStream_t s);
 // presumed acceptance order from all shards' rows; rows_all == nullptr: single
 // shard, the rows are computed in place
-void ek_launch_chain_order(const EkChainRow *rows_all, int n_shards,
-                           EkPlan *plan, const float *dist, const float *vecs,
-                           int64_t n, int64_t n_pad, int64_t global_offset,
-                           hipStream_t s);
 // per-workgroup maxima of the states after applying chain[0..k-1], k = 1..
 void ek_launch_chain_max(const float *dist, const float *vecs, int64_t n,
                          int64_t n_pad, EkPlan *plan, EkBlockMax *pm,
                          int local_order, int64_t global_offset, hipStream_t s);
 // this shard's (max, global index) for each of those states -> hdrs_out[8]
 int ek_chain_max_blocks(int64_t n);     // entries per prefix in pm
-void ek_launch_chain_localmax(const EkBlockMax *blockmax, const EkBlockMax *pm,
-                              int nb, int nbp, int64_t global_offset,
-                              const EkPlan *plan, EkMaxHdr *hdrs_out, hipStream_t s);
+// order + per-prefix maxima (one pm entry per 256 frames) + this shard's headers,
+// one launch (the multi-shard round); tick: an arrival counter, left at 0
+void ek_launch_chain_max2(const float *dist, const float *vecs, int64_t n,
+                          int64_t n_pad, EkPlan *plan, const EkChainRow *rows_all,
+                          int n_shards, const EkBlockMax *blockmax, EkBlockMax *pm,
+                          int64_t global_offset, EkMaxHdr *hdrs_out,
+                          unsigned int *tick, hipStream_t s);
 // accept the longest verified prefix of the chain (hdrs_all[shard][8])
 void ek_launch_chain_decide(const EkMaxHdr *hdrs_all, int n_shards, double cutoff,
                             EkPlan *plan, EkHist *hist, EkCtl *ctl, hipStream_t s);

@@ -40,7 +40,8 @@ def child(path, K):
         st.set_option(8, adapt)
         st.set_option(4, cands)
         best = None
-        for rep in range(2):
+        every = []
+        for rep in range(int(os.environ.get("LAB_REPS", "2"))):
             st.reset_state()
             st.sync()
             st.timing_begin(sample_every=1, max_samples=1024)
@@ -48,6 +49,7 @@ def child(path, K):
             idx, cd, mx = st.kcenters_run(0, K, 0.0)
             dt = time.perf_counter() - t
             kms, ns = st.timing_end()
+            every.append("%.4f/%.4f" % (dt, kms))
             if best is None or dt < best[0]:
                 best = (dt, kms, ns)
         d, a = st.download_state()
@@ -55,9 +57,11 @@ def child(path, K):
         sums.add(h)
         stats = st.run_stats() if cands != 1 else {}
         print("%-28s form %d adapt %d cands %2d fused %d: %.4f s  %.4f ms/center  pass %.4f ms "
-              "(%d samples)  %s  sum %s"
+              "(%d samples)  %s  sum %s%s"
               % (name, form, adapt, cands, fused, best[0], best[0] / K * 1e3, best[1], best[2],
-                 {T: pc for T, pc in stats.items() if pc[0]}, h), flush=True)
+                 {T: pc for T, pc in stats.items() if pc[0]}, h,
+                 "  runs (s/pass ms): " + " ".join(every) if len(every) > 2 else ""),
+              flush=True)
     print("%-28s checksums agree: %s" % (name, len(sums) == 1), flush=True)
 
 
