@@ -162,8 +162,24 @@ ek_round_chain_kernel(EkRound r, int bootstrap)
                 }
                 const int j = s_ord[k];
                 const long long g = r.goff + (long long)si[k];
-                if (g != s_gidx[j])
-                    break;                      // the farthest point is not stored
+                if (g != s_gidx[j]) {           // the farthest point is not stored
+#ifdef EK_ROUND_STAMPS
+                    // where was it?  (-1: not among the 64 block maxima the
+                    // guesses were chosen from; else its rank there)
+                    const EkTop *tp = (const EkTop *)r.top;
+                    int pos = -1;
+                    for (int q = 0; q < tp->n; ++q)
+                        if (tp->idx[q] == si[k])
+                            pos = q;
+                    int other = -1;             // another candidate of this round?
+                    for (int q = 1; q < EK_MAX_CANDS; ++q)
+                        if (s_gidx[q] == g)
+                            other = q;
+                    printf("miss at %d of %d: farthest point rank %d in the list, "
+                           "candidate %d\n", k, cn, pos, other);
+#endif
+                    break;
+                }
                 const int label = c.n_done;
                 r.hist[label].gidx = g;
                 r.hist[label].dist = sv[k];
@@ -199,10 +215,20 @@ ek_round_chain_kernel(EkRound r, int bootstrap)
     const EkBlockMax *state = na == 0 ? r.blockmax : r.pm + (size_t)(na - 1) * nb;
     EkTop *top = (EkTop *)r.top;
     EK_STAMP(4);
-    ek_pick_top_body<true>(state, nb, top, skip);
+    ek_pick_top_body<true>(state, nb, top, skip, r.assign);
 #ifdef EK_ROUND_STAMPS
     __syncthreads();
     EK_STAMP(5);
+    if (tid == 0 && !bootstrap) {       // how many different labels hold the list?
+        int distinct = 0;
+        for (int a = 0; a < top->n; ++a) {
+            bool seen = false;
+            for (int b = 0; b < a; ++b)
+                seen = seen || r.assign[top->idx[b]] == r.assign[top->idx[a]];
+            distinct += seen ? 0 : 1;
+        }
+        printf("list: %d entries, %d labels\n", top->n, distinct);
+    }
     if (tid == 0 && !bootstrap && atomicAdd(&ek_stamp_count, 1u) % 200 == 150)
         printf("chain last wg (x10 ns): body %llu ticket %llu reduce %llu walk %llu "
                "pick %llu (setup+issue %llu, looks %llu, rank %llu, rest %llu)\n",

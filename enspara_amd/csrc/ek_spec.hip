@@ -1332,10 +1332,10 @@ size_t ek_top_scratch_bytes(int A)
 
 __global__ void __launch_bounds__(EK_RED_THREADS)
 ek_pick_top_kernel(const EkBlockMax *__restrict__ blockmax, int nb,
-                   EkTop *__restrict__ top)
+                   EkTop *__restrict__ top, const int32_t *__restrict__ assign)
 {
     extern __shared__ uint32_t skip[];       // bitmap over workgroups
-    ek_pick_top_body(blockmax, nb, top, skip);
+    ek_pick_top_body(blockmax, nb, top, skip, assign);
 }
 
 // their centred coordinates and traces; every read is its own cache line, so
@@ -1408,10 +1408,9 @@ void ek_launch_pickT(const EkBlockMax *blockmax, int nb, const float *tiles,
                      int64_t global_offset, unsigned char *recs, EkCtl *ctl,
                      unsigned char *scratch, hipStream_t s)
 {
-    (void)assign;
     const size_t lds = (size_t)((nb + 31) / 32 + 1) * sizeof(uint32_t);
     hipLaunchKernelGGL(ek_pick_top_kernel, dim3(1), dim3(EK_RED_THREADS), lds, s,
-                       blockmax, nb, (EkTop *)scratch);
+                       blockmax, nb, (EkTop *)scratch, assign);
     hipLaunchKernelGGL(ek_top_gather_kernel,
                        dim3((unsigned)((3 * A + EK_BLOCK - 1) / EK_BLOCK),
                             (unsigned)EK_TOP_M),

@@ -105,9 +105,38 @@ __device__ unsigned long long ek_pick_st[8];
 #else
 #define EK_PSTAMP(k)
 #endif
+// The list only steers the round's guesses, but a guess counts only if it is
+// exactly the farthest frame of the state at its turn, so what the list must hold
+// is the top frame of as many different regions as it can.  Taking the 64 largest
+// maxima does not do that: a region far from every center floods the ranking
+// with its own frames (measured on the bench data: the 64 entries carried 24
+// different labels on average, fewer than 10 in one round of nine -- the rounds
+// that ran out of candidates).  Frames of one region share their nearest center
+// (but several regions may share one), so only the EK_PICK_PER_LABEL (4) largest
+// maxima of every current label compete at all: LDS atomic max on a table row per
+// label, one round per place, with the value's leading bits and the entry's
+// number as the key.  Of the survivors a pool of about EK_PICK_POOL is cut off by
+// value (a histogram of their distance below the maximum: no sequential looks)
+// and ranked exactly; the first EK_TOP_M make the list.  (Two per label is too
+// strict -- more passes than without any of this --, four or eight do equally
+// well; giving every label's first a head start changes nothing.)  Entry 0 is
+// always the overall first-index arg-max: it holds slot 0 of the pool by
+// construction.
+#ifndef EK_PICK_POOL
+#define EK_PICK_POOL 128
+#endif
+#ifndef EK_PICK_PER_LABEL
+#define EK_PICK_PER_LABEL 4     // maxima kept per label
+#endif
+#define EK_PICK_BUCKETS 1024
+#ifndef EK_PICK_SLOTS
+#define EK_PICK_SLOTS 2048      // labels modulo this share a table row
+#endif
+
 template <bool COH = false>
 __device__ __forceinline__ void ek_pick_top_body(const EkBlockMax *blockmax, int nb,
-                                                 EkTop *top, uint32_t *skip)
+                                                 EkTop *top, uint32_t *skip,
+                                                 const int32_t *assign = nullptr)
 {
     EK_PSTAMP(0);
     __shared__ uint32_t top_i[EK_TOP_M];
@@ -122,12 +151,24 @@ __device__ __forceinline__ void ek_pick_top_body(const EkBlockMax *blockmax, int
     if (tid == 0)
         n_top = 0;
     __syncthreads();
-    // The per-workgroup maxima are read once: every thread keeps its (up to
-    // PICK_PER) entries in registers across the looks; larger shards fall back
-    // to re-reading them.
-    float cv[PICK_PER];
-    uint32_t ci[PICK_PER];
+    const int max_looks = EK_TOP_M;
     if (cached) {
+        static_assert(EK_RED_THREADS % EK_PICK_POOL == 0 &&
+                          EK_PICK_BUCKETS == EK_RED_THREADS &&
+                          PICK_PER * EK_RED_THREADS <= (1 << 13),
+                      "pool comparisons and buckets are split over the workgroup; "
+                      "13 bits number an entry");
+        __shared__ unsigned int s_maxbits, s_thresh, s_nsel, s_first, s_have;
+        __shared__ unsigned int hist[EK_PICK_BUCKETS];
+        __shared__ unsigned int tab[EK_PICK_PER_LABEL * EK_PICK_SLOTS];
+        __shared__ float sel_v[EK_PICK_POOL];
+        __shared__ uint32_t sel_i[EK_PICK_POOL];
+        __shared__ int sel_rank[EK_PICK_POOL];
+        // The per-workgroup maxima are read once, up to PICK_PER per thread, and
+        // with them the labels of those frames
+        float cv[PICK_PER];
+        uint32_t ci[PICK_PER];
+        int32_t lab[PICK_PER];
 #pragma unroll
         for (int k = 0; k < PICK_PER; ++k) {
             const int bb = tid + k * EK_RED_THREADS;
@@ -139,93 +180,171 @@ __device__ __forceinline__ void ek_pick_top_body(const EkBlockMax *blockmax, int
                 ci[k] = m.idx;
             }
         }
-    }
-    EK_PSTAMP(1);
-    constexpr int NWV = EK_RED_THREADS / EK_WAVE;
-    constexpr int LW = 8;                // looks per wave
-    __shared__ float wt_v[NWV * LW];
-    __shared__ uint32_t wt_i[NWV * LW];
-    const int max_looks = EK_TOP_M;
-    if (cached) {
-        // Level 1: every wave takes the LW best of its own entries with wave-wide
-        // arg-max steps (no workgroup barrier).  Level 2: the NWV * LW survivors
-        // are ranked against one another, one thread each, and the best EK_TOP_M
-        // land in order.  The workgroups' maxima are spread over the waves at
-        // random, so this is the true top list except when more than LW of it
-        // fall into one wave -- which only costs a slightly worse guess; entry 0
-        // is always the overall first-index arg-max.
-        const int lane = tid & (EK_WAVE - 1), wv = tid / EK_WAVE;
-        // entries per thread actually in use (uniform: the rest is skipped)
-        const int per = (nb + EK_RED_THREADS - 1) / EK_RED_THREADS;
-        for (int look = 0; look < LW; ++look) {
-            float v = -__builtin_inff();
-            uint32_t i = 0xffffffffu;
 #pragma unroll
-            for (int k = 0; k < PICK_PER; ++k) {
-                if (k >= per)
-                    break;
-                if (ci[k] != 0xffffffffu && ek_better(cv[k], ci[k], v, i)) {
-                    v = cv[k];
-                    i = ci[k];
-                }
-            }
-            ek_wave_argmax(v, i);            // every lane holds the winner
-            if (i != 0xffffffffu) {          // its owner retires it (indices are unique)
+        for (int k = 0; k < PICK_PER; ++k)
+            lab[k] = (ci[k] != 0xffffffffu && assign) ? assign[ci[k]]
+                                                      : tid + k * EK_RED_THREADS;
+        hist[tid] = 0;
+        for (int q = tid; q < EK_PICK_PER_LABEL * EK_PICK_SLOTS; q += EK_RED_THREADS)
+            tab[q] = 0;
+        if (tid < EK_PICK_POOL)
+            sel_rank[tid] = 0;
+        if (tid == 0) {
+            s_maxbits = 0;
+            s_nsel = 0;
+            s_first = 0xffffffffu;
+            s_have = 0;
+        }
+        __syncthreads();
+        EK_PSTAMP(1);
+        // the EK_PICK_PER_LABEL best of every label, round by round: who is not
+        // the best of a round competes in the next (distances are >= 0: their
+        // bits order like they do; + 1 keeps a key apart from an empty slot)
+        unsigned int key[PICK_PER];
+        int won[PICK_PER];              // the round an entry won, -1: none
+        float mine = 0.f;
 #pragma unroll
-                for (int k = 0; k < PICK_PER; ++k) {
-                    if (k >= per)
-                        break;
-                    if (ci[k] == i)
-                        ci[k] = 0xffffffffu;
-                }
-            }
-            if (lane == 0) {
-                wt_v[wv * LW + look] = v;
-                wt_i[wv * LW + look] = i;
+        for (int k = 0; k < PICK_PER; ++k) {
+            key[k] = 0;
+            won[k] = -1;
+            if (ci[k] != 0xffffffffu) {
+                const unsigned int e = (unsigned int)(tid + k * EK_RED_THREADS);
+                key[k] = (((__float_as_uint(cv[k]) >> 12) + 1u) << 13) | (8191u - e);
+                mine = cv[k] > mine ? cv[k] : mine;
             }
         }
+        if (mine > 0.f)
+            atomicMax(&s_maxbits, __float_as_uint(mine));
+#pragma unroll
+        for (int r = 0; r < EK_PICK_PER_LABEL; ++r) {
+#pragma unroll
+            for (int k = 0; k < PICK_PER; ++k)
+                if (key[k] && won[k] < 0)
+                    atomicMax(&tab[EK_PICK_PER_LABEL *
+                                       ((unsigned int)lab[k] % EK_PICK_SLOTS) + r],
+                              key[k]);
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < PICK_PER; ++k)
+                if (key[k] && won[k] < 0 &&
+                    tab[EK_PICK_PER_LABEL * ((unsigned int)lab[k] % EK_PICK_SLOTS) +
+                        r] == key[k])
+                    won[k] = r;
+        }
+        // the overall first-index arg-max, exactly: the keys round the values,
+        // and entry 0 of the list is a center without further checks
+        const float vmax = __uint_as_float(s_maxbits);
+#pragma unroll
+        for (int k = 0; k < PICK_PER; ++k)
+            if (key[k] && cv[k] == vmax)
+                atomicMin(&s_first, ci[k]);
+        __syncthreads();
+        // the arg-max takes slot 0 of the pool, whatever else happens
+#pragma unroll
+        for (int k = 0; k < PICK_PER; ++k)
+            if (key[k] && cv[k] == vmax && ci[k] == s_first) {
+                won[k] = -1;
+                sel_v[0] = cv[k];
+                sel_i[0] = ci[k];
+                s_have = 1;
+            }
+        // bucket = how far below the maximum, 1024 steps over its top quarter
+        const float scale = vmax > 0.f ? (float)EK_PICK_BUCKETS / (0.25f * vmax) : 0.f;
+        int bk[PICK_PER];
+#pragma unroll
+        for (int k = 0; k < PICK_PER; ++k) {
+            bk[k] = -1;
+            if (won[k] >= 0) {
+                const float below = (vmax - cv[k]) * scale;
+                bk[k] = below >= (float)(EK_PICK_BUCKETS - 1) ? EK_PICK_BUCKETS - 1
+                                                               : (below > 0.f ? (int)below : 0);
+                atomicAdd(&hist[bk[k]], 1u);
+            }
+        }
+        __syncthreads();
+        // the first bucket at which the pool is full (one wave, 16 buckets a lane)
+        if (tid < EK_WAVE) {
+            constexpr int PB = EK_PICK_BUCKETS / EK_WAVE;
+            unsigned int loc[PB], sum = 0;
+#pragma unroll
+            for (int q = 0; q < PB; ++q) {
+                sum += hist[tid * PB + q];
+                loc[q] = sum;
+            }
+            unsigned int incl = sum;
+#pragma unroll
+            for (int o = 1; o < EK_WAVE; o <<= 1) {
+                const unsigned int v = __shfl_up(incl, o, EK_WAVE);
+                if (tid >= o)
+                    incl += v;
+            }
+            const unsigned int excl = incl - sum;
+            int first = EK_PICK_BUCKETS;        // none: everything goes in
+#pragma unroll
+            for (int q = PB - 1; q >= 0; --q)
+                if (excl + loc[q] >= (unsigned int)(EK_PICK_POOL - 1))
+                    first = tid * PB + q;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {     // the lowest over the lanes
+                const int v = __shfl_xor(first, o, EK_WAVE);
+                first = v < first ? v : first;
+            }
+            if (tid == 0)
+                s_thresh = (unsigned int)first;
+        }
+        __syncthreads();
+        // everything above the threshold bucket first (fewer than the pool), then
+        // that bucket's entries while there is room
+        const int thresh = (int)s_thresh;
+#pragma unroll
+        for (int k = 0; k < PICK_PER; ++k)
+            if (bk[k] >= 0 && bk[k] < thresh) {
+                const unsigned int p = 1u + atomicAdd(&s_nsel, 1u);
+                sel_v[p] = cv[k];
+                sel_i[p] = ci[k];
+            }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PICK_PER; ++k)
+            if (bk[k] >= 0 && bk[k] == thresh) {
+                const unsigned int p = 1u + atomicAdd(&s_nsel, 1u);
+                if (p < (unsigned int)EK_PICK_POOL) {
+                    sel_v[p] = cv[k];
+                    sel_i[p] = ci[k];
+                }
+            }
         __syncthreads();
         EK_PSTAMP(2);
-        // every survivor's rank among the NWV * LW of them, the comparisons
-        // spread over the whole workgroup (EK_RED_THREADS / (NWV * LW) threads
-        // per survivor, partial counts added up in LDS)
-        {
-            constexpr int NS = NWV * LW;                // survivors
-            constexpr int SPLIT = EK_RED_THREADS / NS;  // threads per survivor
-            static_assert(EK_RED_THREADS % NS == 0 && NS % SPLIT == 0, "even split");
-            __shared__ int rank_acc[NS];
-            if (tid < NS)
-                rank_acc[tid] = 0;
-            __syncthreads();
-            const int e0 = tid % NS, part = tid / NS;
-            const float v = wt_v[e0];
-            const uint32_t i = wt_i[e0];
-            if (i != 0xffffffffu) {
-                int rank = 0;
+        // exact rank in the pool; the comparisons of an entry are split over
+        // EK_RED_THREADS / POOL threads
+        const int L = !s_have ? 0
+                              : (s_nsel + 1u < (unsigned int)EK_PICK_POOL
+                                     ? (int)s_nsel + 1 : EK_PICK_POOL);
+        constexpr int SPLIT = EK_RED_THREADS / EK_PICK_POOL;
+        constexpr int SHARE = EK_PICK_POOL / SPLIT;
+        const int e = tid % EK_PICK_POOL, part = tid / EK_PICK_POOL;
+        if (e < L) {
+            const float v = sel_v[e];
+            const uint32_t i = sel_i[e];
+            int rank = 0;
 #pragma unroll
-                for (int q = 0; q < NS / SPLIT; ++q) {
-                    const int e = part * (NS / SPLIT) + q;
-                    const uint32_t oi = wt_i[e];
-                    if (oi != 0xffffffffu && ek_better(wt_v[e], oi, v, i))
-                        ++rank;
-                }
-                if (rank)
-                    atomicAdd(&rank_acc[e0], rank);
+            for (int q = 0; q < SHARE; ++q) {
+                const int o = part * SHARE + q;
+                if (o < L && ek_better(sel_v[o], sel_i[o], v, i))
+                    ++rank;
             }
-            __syncthreads();
-            if (tid < NS && i != 0xffffffffu) {
-                const int rank = rank_acc[tid];
-                if (rank < EK_TOP_M) {
-                    top_i[rank] = i;
-                    top_v[rank] = v;
-                }
-                atomicAdd(&n_top, 1);
-            }
+            if (rank)
+                atomicAdd(&sel_rank[e], rank);
         }
         __syncthreads();
+        if (tid < L && sel_rank[tid] < EK_TOP_M) {
+            top_i[sel_rank[tid]] = sel_i[tid];
+            top_v[sel_rank[tid]] = sel_v[tid];
+        }
+        if (tid == 0)
+            n_top = L < EK_TOP_M ? L : EK_TOP_M;
+        __syncthreads();
         EK_PSTAMP(3);
-        if (tid == 0 && n_top > EK_TOP_M)
-            n_top = EK_TOP_M;
     } else {
         for (int look = 0; look < max_looks; ++look) {
             float v;
