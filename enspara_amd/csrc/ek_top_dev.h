@@ -166,6 +166,8 @@ __device__ __forceinline__ void ek_pick_top_body(const EkBlockMax *blockmax, int
         __shared__ int sel_rank[EK_PICK_POOL];
         // The per-workgroup maxima are read once, up to PICK_PER per thread, and
         // with them the labels of those frames
+        // entries per thread actually in use (uniform: the loops skip the rest)
+        const int per = (nb + EK_RED_THREADS - 1) / EK_RED_THREADS;
         float cv[PICK_PER];
         uint32_t ci[PICK_PER];
         int32_t lab[PICK_PER];
@@ -181,7 +183,7 @@ __device__ __forceinline__ void ek_pick_top_body(const EkBlockMax *blockmax, int
             }
         }
 #pragma unroll
-        for (int k = 0; k < PICK_PER; ++k)
+        for (int k = 0; k < PICK_PER && k < per; ++k)
             lab[k] = (ci[k] != 0xffffffffu && assign) ? assign[ci[k]]
                                                       : tid + k * EK_RED_THREADS;
         hist[tid] = 0;
@@ -218,14 +220,14 @@ __device__ __forceinline__ void ek_pick_top_body(const EkBlockMax *blockmax, int
 #pragma unroll
         for (int r = 0; r < EK_PICK_PER_LABEL; ++r) {
 #pragma unroll
-            for (int k = 0; k < PICK_PER; ++k)
+            for (int k = 0; k < PICK_PER && k < per; ++k)
                 if (key[k] && won[k] < 0)
                     atomicMax(&tab[EK_PICK_PER_LABEL *
                                        ((unsigned int)lab[k] % EK_PICK_SLOTS) + r],
                               key[k]);
             __syncthreads();
 #pragma unroll
-            for (int k = 0; k < PICK_PER; ++k)
+            for (int k = 0; k < PICK_PER && k < per; ++k)
                 if (key[k] && won[k] < 0 &&
                     tab[EK_PICK_PER_LABEL * ((unsigned int)lab[k] % EK_PICK_SLOTS) +
                         r] == key[k])
@@ -235,13 +237,13 @@ __device__ __forceinline__ void ek_pick_top_body(const EkBlockMax *blockmax, int
         // and entry 0 of the list is a center without further checks
         const float vmax = __uint_as_float(s_maxbits);
 #pragma unroll
-        for (int k = 0; k < PICK_PER; ++k)
+        for (int k = 0; k < PICK_PER && k < per; ++k)
             if (key[k] && cv[k] == vmax)
                 atomicMin(&s_first, ci[k]);
         __syncthreads();
         // the arg-max takes slot 0 of the pool, whatever else happens
 #pragma unroll
-        for (int k = 0; k < PICK_PER; ++k)
+        for (int k = 0; k < PICK_PER && k < per; ++k)
             if (key[k] && cv[k] == vmax && ci[k] == s_first) {
                 won[k] = -1;
                 sel_v[0] = cv[k];
@@ -297,7 +299,7 @@ __device__ __forceinline__ void ek_pick_top_body(const EkBlockMax *blockmax, int
         // that bucket's entries while there is room
         const int thresh = (int)s_thresh;
 #pragma unroll
-        for (int k = 0; k < PICK_PER; ++k)
+        for (int k = 0; k < PICK_PER && k < per; ++k)
             if (bk[k] >= 0 && bk[k] < thresh) {
                 const unsigned int p = 1u + atomicAdd(&s_nsel, 1u);
                 sel_v[p] = cv[k];
@@ -305,7 +307,7 @@ __device__ __forceinline__ void ek_pick_top_body(const EkBlockMax *blockmax, int
             }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < PICK_PER; ++k)
+        for (int k = 0; k < PICK_PER && k < per; ++k)
             if (bk[k] >= 0 && bk[k] == thresh) {
                 const unsigned int p = 1u + atomicAdd(&s_nsel, 1u);
                 if (p < (unsigned int)EK_PICK_POOL) {
