@@ -175,8 +175,12 @@ ek_round_chain_kernel(EkRound r, int bootstrap)
                     for (int q = 1; q < EK_MAX_CANDS; ++q)
                         if (s_gidx[q] == g)
                             other = q;
+                    // hidden behind a farther frame of its own workgroup of 256?
+                    // (state 0 of this round: after candidate 0 alone)
+                    const bool hidden = r.blockmax[si[k] / EK_BLOCK].idx != si[k];
                     printf("miss at %d of %d: farthest point rank %d in the list, "
-                           "candidate %d\n", k, cn, pos, other);
+                           "candidate %d, hidden %d\n", k, cn, pos, other,
+                           hidden ? 1 : 0);
 #endif
                     break;
                 }
