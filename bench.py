@@ -515,7 +515,10 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": ("ek_pass2_kernel<%d,true>" % dom) if dom > 1
+            # (the name rocprofv3 lists: the third argument is the fused round of
+            # a single shard, ek_round.hip; the multi-shard driver runs without it)
+            "kernel": ("ek_pass2_kernel<%d, true, %s>"
+                       % (dom, "false" if use_dist else "true")) if dom > 1
                       else "ek_step_kernel<FPL,0,NT>",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
