@@ -959,7 +959,8 @@ static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
         const int32_t due = adaptive ? std::max(gap - since, 1) : left;
         int32_t batch;
         if (one)
-            batch = probing ? 4 : std::min(left, std::min(due, 256));
+            // (never past the goal: a step has no limit check of its own)
+            batch = std::min(left, probing ? 4 : std::min(due, 256));
         else if (probing)
             batch = 2;
         else
@@ -1108,7 +1109,7 @@ static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
         EK_HIP(hipMemcpyAsync(c->rec, c->recsT, ek_rec_bytes(c->A),
                               hipMemcpyDeviceToDevice, c->stream));
     EK_HIP(ek_wait(c));
-    const int32_t added_t = std::max(0, cr.n_done - first_label);
+    const int32_t added_t = std::min(max_new, std::max(0, cr.n_done - first_label));
     const int64_t passes = c->st_rounds[0] + c->st_rounds[1] + c->st_rounds[2];
     c->last_launches = (int32_t)passes;
     c->last_passes = (int32_t)passes;

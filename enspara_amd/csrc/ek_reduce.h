@@ -66,6 +66,20 @@ __device__ __forceinline__ void ek_wave_argmax(float &v, uint32_t &i)
 // / L2-coherent accesses, `sc1`), every thread waits for its own stores to be
 // acknowledged before the workgroup takes its arrival ticket, and the workgroup
 // that draws the last ticket therefore finds all of them in place.
+//
+// This is NOT the HIP/LLVM memory model's release/acquire pairing (there the
+// relaxed ticket orders nothing): it leans on three properties of the gfx9
+// memory pipeline -- vmcnt counts stores as well as loads (no separate store
+// counter as on gfx10+), an `sc1` store is written through to the point of
+// agent coherence before it is acknowledged, and a wave issues no speculative
+// loads ahead of the ticket it branches on -- and on every value that crosses
+// workgroups inside a launch going through the ek_coh_* helpers below.  Hence
+// the guard: any other target must get real fences here.  The regression check
+// is the fused-vs-unfused comparison of tests/test_gpu_kcenters.py and
+// tools/stress_rounds.py.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "ek_arrive_last: fence-free hand-over is written for gfx942/gfx950 (see above)"
+#endif
 __device__ __forceinline__ void ek_coh_store(float *p, float v)
 {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

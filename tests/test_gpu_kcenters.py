@@ -294,3 +294,31 @@ def test_triangle_inequality_is_invisible(ocl):
         tiles, skipped = st.ti_stats()
     assert tiles == 59 * ((len(x) + 255) // 256)
     assert skipped > 0.5 * tiles
+
+
+def test_adaptive_run_never_passes_its_goal(ocl):
+    """a probe of the one-center form near the end of a run must not accept
+    centers past first_label + max_new (round-2 advisor finding): iid
+    coordinates are low-yield data (rounds accept ~1 center), so the adaptive
+    loop keeps switching forms; every small max_new returns exactly max_new
+    centers, equal to the oracle's"""
+    from enspara_amd.device import FrameStore
+    rng = np.random.RandomState(11)
+    x = rng.normal(size=(3000, 12, 3)).astype(np.float32)
+    inds, _, _ = ocl.kcenters(x, n_clusters=48)
+    with FrameStore.from_array(x) as st:
+        st.set_option(8, 1)
+        for k in list(range(1, 20)) + [31, 48]:
+            st.reset_state()
+            idx, cd, _ = st.kcenters_run(0, k, 0.0)
+            assert len(idx) == k
+            assert [int(i) for i in idx] == [int(i) for i in inds[:k]]
+        # continuation in small steps from a warm state
+        st.reset_state()
+        got = []
+        while len(got) < 48:
+            step = min(3, 48 - len(got))
+            idx, _, _ = st.kcenters_run(len(got), step, 0.0)
+            assert len(idx) == step
+            got += [int(i) for i in idx]
+        assert got == [int(i) for i in inds]
