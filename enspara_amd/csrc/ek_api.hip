@@ -10,10 +10,6 @@
 #include <new>
 #include <vector>
 
-#ifndef EK_PASS_FORM_DEFAULT
-#define EK_PASS_FORM_DEFAULT 1
-#endif
-
 static thread_local char g_err[512] = "";
 
 // shared with ek_msm.hip
@@ -143,7 +139,6 @@ struct ek_ctx {
     EkBlockMax *pm = nullptr;    // [EK_MAX_CANDS-1][nb] per-prefix maxima (ek_chain.hip)
     unsigned char *top = nullptr;    // scratch of the candidate pick (ek_spec.hip)
     float *planD = nullptr;          // [64][64] distances between the records on offer
-    int pass_form = EK_PASS_FORM_DEFAULT;  // 0: candidates through LDS, 1: as scalar operands
     int fused = 1;               // single-shard rounds in three launches (ek_round.hip)
     int tri = 0;                 // triangle-inequality tile skip (one-center steps)
     float *ti_D = nullptr;       // [ti_cap] distances of the existing centers to the new one
@@ -163,14 +158,16 @@ struct ek_ctx {
     int64_t n_pad = 0;
     int32_t last_passes = 0;
     int adapt = 1;               // choose the candidates per pass from measured rates
-    int64_t st_rounds[3] = {0, 0, 0};   // passes run as 1 / 4 / 8 candidates (last run)
-    int64_t st_centers[3] = {0, 0, 0};  // centers they accepted
+    int64_t st_rounds[4] = {0, 0, 0, 0};    // passes run as 1 / 4 / 8 / 16 candidates (last run)
+    int64_t st_centers[4] = {0, 0, 0, 0};   // centers they accepted
     hipEvent_t evb0 = nullptr, evb1 = nullptr;   // per-batch timing
 
     int fpl = 0;                 // 0 = auto
     int nt = -1;                 // non-temporal frame loads: -1 = auto
     // sampled per-launch timing of the distance kernel (bench only)
     std::vector<hipEvent_t> samp_ev;
+    std::vector<int> samp_form;  // candidates per pass of each sampled launch
+    int samp_dom = 0;            // the form most samples of the last timing had
     int samp_every = 0;
     int samp_used = 0;
     int64_t samp_count = 0;
@@ -217,16 +214,16 @@ static int ek_pick_nt(const ek_ctx *c)
     return bytes > ((size_t)192 << 20) ? 1 : 0;
 }
 
-// candidates per pass: as many as the LDS tile of centers allows (<= 8)
+// the widest form of a round this context may use (candidates per pass):
+// EK_MAX_CANDS unless option key 4 pins it; 1 = one-center passes only
 static int ek_pick_cands(const ek_ctx *c)
 {
-    int t = c->cands;
-    if (t == -1)
-        t = 8;
-    while (t > 1 && ek_pass_lds_bytes(t, c->A) > (size_t)150 * 1024)
-        t /= 2;
-    return (t == 8 || t == 4) ? t : 1;
+    const int t = c->cands == -1 ? EK_MAX_CANDS : c->cands;
+    return (t == 16 || t == 8 || t == 4) ? t : 1;
 }
+
+// slot of a form in the run statistics: passes run as 1 / 4 / 8 / 16 candidates
+static int ek_form_slot(int T) { return T <= 1 ? 0 : (T == 4 ? 1 : (T == 8 ? 2 : 3)); }
 
 static int ek_spec_alloc(ek_ctx *c)
 {
@@ -480,9 +477,9 @@ extern "C" int ek_set_option(ek_ctx *c, int32_t key, int32_t value)
         c->nt = value < 0 ? -1 : (value ? 1 : 0);
         return EK_OK;
     case 4:
-        if (value != -1 && value != 1 && value != 4 && value != 8)
+        if (value != -1 && value != 1 && value != 4 && value != 8 && value != 16)
             return ek_fail(EK_EARG, "ek_set_option: candidates per pass must "
-                                    "be -1 (auto), 1, 4 or 8");
+                                    "be -1 (auto), 1, 4, 8 or 16");
         c->cands = value;
         return EK_OK;
     case 5:
@@ -510,10 +507,9 @@ extern "C" int ek_set_option(ek_ctx *c, int32_t key, int32_t value)
             return ek_fail(EK_EARG, "ek_set_option: fused rounds 0 or 1");
         c->fused = value;
         return EK_OK;
-    case 9:
-        if (value != 0 && value != 1)
-            return ek_fail(EK_EARG, "ek_set_option: pass kernel form 0 or 1");
-        c->pass_form = value;
+    case 9:     // (round 1's LDS form of the pass kernel is retired)
+        if (value != 1)
+            return ek_fail(EK_EARG, "ek_set_option: pass kernel form must be 1");
         return EK_OK;
     case 8:
         if (value != 0 && value != 1)
@@ -774,6 +770,8 @@ extern "C" int ek_kcenters_step(ek_ctx *c, const void *recs_dev, int32_t n_recs,
             c->samp_every > 0 && (c->samp_count++ % c->samp_every) == 0 &&
             2 * (size_t)c->samp_used + 1 < c->samp_ev.size();
         if (sample)
+        c->samp_form[c->samp_used] = 1;
+    if (sample)
             EK_HIP(hipEventRecord(c->samp_ev[2 * c->samp_used], c->stream));
         ek_launch_step(fpl, 0, ek_pick_nt(c), c->tiles, c->G, c->dist, c->assign, c->scratch,
                        recs, n_recs, c->n, c->A, label, dist_cutoff,
@@ -852,10 +850,9 @@ static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
     EK_HIP(hipMemcpyAsync(c->ctl, &ctlw, sizeof(ctlw), hipMemcpyHostToDevice,
                           c->stream));
     EK_HIP(ek_wait(c));
-    for (int m = 0; m < 3; ++m)
+    for (int m = 0; m < 4; ++m)
         c->st_rounds[m] = c->st_centers[m] = 0;
     const int nb = (int)((c->n + EK_BLOCK - 1) / EK_BLOCK);
-    const int wide = Tmax == 8 ? 2 : 1;     // index into st_* of the wide form
     // Triangle inequality (option key 11; reference `use_triangle_inequality`,
     // kcenters.py:287-296): one center at a time, tiles that cannot change are
     // not read.  Needs every frame's distance to be the one to the center its
@@ -880,19 +877,30 @@ static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
                               c->stream));
     }
     c->ti_tiles = c->ti_skipped = 0;
-    // an explicit request (option key 4 = 4 or 8) pins the wide form
+    // an explicit request (option key 4 = 4, 8 or 16) pins the wide form
     const bool adaptive = c->cands == -1 && c->adapt && !tri;
     const int fpl = ek_pick_fpl(c);
     const int nt = ek_pick_nt(c);
-    bool one = adaptive || tri; // current form: one-center steps / wide rounds
+    // the forms the run moves between, by candidates per pass
+    int ladder[3], n_ladder = 0;
+    if (adaptive || tri)
+        ladder[n_ladder++] = 1;
+    if (!tri) {
+        if (adaptive && Tmax == 16)
+            ladder[n_ladder++] = 8;
+        ladder[n_ladder++] = Tmax;
+    }
+    int home = 0;               // ladder index of the form being run
+    int form = ladder[0];       // ... its candidates per pass (the probe's while probing)
     int held = -1;              // form the candidate record(s) were picked for
     bool probing = false;
-    double rate_home = 0.0;     // centers per ms of the form being run
-    int32_t gap = 8;            // centers until the other form is tried again
-    int32_t since = 0;          // centers since it last was
+    int probe_up = 1;           // direction of the next probe (they alternate)
+    double rate_home = 0.0;     // centers per ms of the home form
+    int32_t gap = 8;            // centers until another form is tried again
+    int32_t since = 0;          // centers since one last was
     // three launches per round (ek_round.hip) when the pieces it is built from
     // are the ones selected
-    const bool fused = c->fused && c->pass_form == 1 && c->chain == 1;
+    const bool fused = c->fused && c->chain == 1;
     EkRound R;
     R.dist = c->dist;
     R.assign = c->assign;
@@ -926,13 +934,15 @@ static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
     memset(&cr, 0, sizeof(cr));
     cr.n_done = first_label;
     const int32_t goal = first_label + max_new;
-    double per_round = 0.6 * Tmax;
+    double per_round = 0.6 * form;  // centers per round of the current wide form
     int32_t rounds_before = 0;
     while (cr.n_done < goal) {
         const int32_t left = goal - cr.n_done;
+        const bool one = form == 1;
+        R.T = form;
         // ---- the record(s) this form starts from -------------------------------------
-        if (held != (one ? 1 : Tmax)) {
-            if (pending) {      // leaving the fused form: the state as it stands
+        if (held != form) {
+            if (pending) {      // leaving a fused form: the state as it stands
                 ek_launch_round_flush(R, c->stream);
                 pending = false;
             } else if (held <= 1) {
@@ -947,22 +957,23 @@ static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
                 ek_launch_round_next(R, 1, c->stream);
             } else {
                 ek_launch_pickT(c->blockmax, nb, c->tiles, c->G, c->assign, c->A,
-                                Tmax, c->goff, c->recsT, c->ctl, c->top,
+                                form, c->goff, c->recsT, c->ctl, c->top,
                                 c->stream);
             }
             EK_CHECK_LAUNCH();
-            held = one ? 1 : Tmax;
+            if (held != form && !one)
+                per_round = 0.6 * form;
+            held = form;
         }
         // ---- one batch: steps (one-center form) or rounds ----------------------------
         // long enough to amortise the host's look at the control word, short
-        // enough to come back when the other form is due
+        // enough to come back when another form is due
         const int32_t due = adaptive ? std::max(gap - since, 1) : left;
         int32_t batch;
-        if (one)
-            // (never past the goal: a step has no limit check of its own)
+        if (one)    // (never past the goal: a step has no limit check of its own)
             batch = std::min(left, probing ? 4 : std::min(due, 256));
         else if (probing)
-            batch = 2;
+            batch = 3;
         else
             batch = std::max(2, std::min(256, (int32_t)(std::min(left, due) /
                                                         per_round) + 1));
@@ -989,6 +1000,8 @@ static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
             const bool sample =
                 c->samp_every > 0 && (c->samp_count++ % c->samp_every) == 0 &&
                 2 * (size_t)c->samp_used + 1 < c->samp_ev.size();
+            if (sample)
+                c->samp_form[c->samp_used] = form;
             if (fused) {
                 if (sample)
                     EK_HIP(hipEventRecord(c->samp_ev[2 * c->samp_used],
@@ -1005,13 +1018,13 @@ static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
                 pending = true;
                 continue;
             }
-            ek_launch_plan(c->recsT, Tmax, c->A, Tmax, dist_cutoff, c->planD,
+            ek_launch_plan(c->recsT, form, c->A, form, dist_cutoff, c->planD,
                            c->plan, c->hist, c->ctl, c->stream);
             if (sample)
                 EK_HIP(hipEventRecord(c->samp_ev[2 * c->samp_used], c->stream));
-            ek_launch_pass(Tmax, c->tiles, c->G, c->dist, c->assign, c->vecs, c->n,
+            ek_launch_pass(form, c->tiles, c->G, c->dist, c->assign, c->vecs, c->n,
                            c->n_pad, c->A, c->recsT, c->plan, c->blockmax,
-                           c->pass_form, c->ctile, c->ctrace, c->stream);
+                           c->ctile, c->ctrace, c->stream);
             if (sample) {
                 EK_HIP(hipEventRecord(c->samp_ev[2 * c->samp_used + 1],
                                       c->stream));
@@ -1027,14 +1040,14 @@ static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
                 ek_launch_chain_apply(c->vecs, c->n, c->n_pad, c->dist, c->assign,
                                       c->plan, c->blockmax, c->stream);
             } else {
-                for (int j = 1; j < Tmax; ++j) {
+                for (int j = 1; j < form; ++j) {
                     ek_launch_localmax_check(c->blockmax, nb, c->goff, dist_cutoff,
                                              c->plan, c->hist, c->ctl, c->stream);
                     ek_launch_apply(c->vecs, c->G, c->n, c->n_pad, c->A, c->dist,
                                     c->assign, c->plan, c->blockmax, c->stream);
                 }
             }
-            ek_launch_pickT(c->blockmax, nb, c->tiles, c->G, c->assign, c->A, Tmax,
+            ek_launch_pickT(c->blockmax, nb, c->tiles, c->G, c->assign, c->A, form,
                             c->goff, c->recsT, c->ctl, c->top, c->stream);
             EK_CHECK_LAUNCH();
         }
@@ -1047,8 +1060,8 @@ static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
         // passes that really ran (a step that finds the stop rule met returns at once)
         const int32_t ran = one ? got : cr.n_rounds - rounds_before;
         rounds_before = cr.n_rounds;
-        c->st_rounds[one ? 0 : wide] += ran;
-        c->st_centers[one ? 0 : wide] += got;
+        c->st_rounds[ek_form_slot(form)] += ran;
+        c->st_centers[ek_form_slot(form)] += got;
         if (cr.stopped || cr.n_done >= goal)
             break;
         if (!one)
@@ -1062,11 +1075,14 @@ static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
         if (probing) {
             probing = false;
             since = 0;
-            if (rate > rate_home) {     // the other form wins: it is home now
+            if (rate > rate_home) {     // the probed form wins: it is home now
+                for (int q = 0; q < n_ladder; ++q)
+                    if (ladder[q] == form)
+                        home = q;
                 rate_home = rate;
                 gap = 8;
             } else {                    // back, and wait twice as long
-                one = !one;
+                form = ladder[home];
                 gap = std::min(gap * 2, 1024);
             }
             continue;
@@ -1074,11 +1090,32 @@ static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
         rate_home = rate;
         since += got;
         if (since >= gap) {
-            // one-center steps can only win while rounds accept fewer than ~1.4
-            // centers (the cost ratio of the two forms): no need to try them
-            // while the yield is far above that
-            if (one || per_round < 1.8) {
-                one = !one;
+            // Which neighbour on the ladder is worth a look?  One-center steps
+            // can only win while rounds accept fewer than ~1.4 centers (the cost
+            // ratio of the two forms); a narrower round only while the wider one
+            // accepts fewer than the narrower could at its lower cost (8 / 16:
+            // cost ratio <= 1.35); a wider round only if the chain of the
+            // current one is usually accepted whole -- it breaks where the
+            // farthest point is not a stored candidate, and more candidates
+            // behind that point change nothing.
+            const int T = ladder[home];
+            const bool up_ok = home + 1 < n_ladder &&
+                               (T == 1 || per_round >= 0.8 * T);
+            bool down_ok = home > 0;
+            if (down_ok && ladder[home - 1] == 1)
+                down_ok = per_round < 1.8;
+            else if (down_ok)
+                down_ok = per_round < 1.35 * ladder[home - 1];
+            int target = -1;
+            if (up_ok && down_ok)
+                target = probe_up ? home + 1 : home - 1;
+            else if (up_ok)
+                target = home + 1;
+            else if (down_ok)
+                target = home - 1;
+            if (target >= 0) {
+                probe_up = target > home ? 0 : 1;
+                form = ladder[target];
                 probing = true;
             } else {
                 since = 0;
@@ -1213,6 +1250,7 @@ extern "C" int ek_timing_begin(ek_ctx *c, int32_t sample_every,
         EK_HIP(hipEventCreate(&e));
         c->samp_ev.push_back(e);
     }
+    c->samp_form.assign((size_t)max_samples, 0);
     c->samp_every = sample_every;
     c->samp_used = 0;
     c->samp_count = 0;
@@ -1225,6 +1263,16 @@ extern "C" int ek_timing_end(ek_ctx *c, float *avg_ms, int32_t *n_samples)
         return ek_fail(EK_EARG, "NULL context");
     EK_HIP(hipSetDevice(c->device));
     EK_HIP(ek_wait(c));
+    // the average is over the launches of the form that was sampled most (a run
+    // moves between 1, 8 and 16 candidates per pass; ek_timing_form says which)
+    int cnt[EK_MAX_CANDS + 1] = {0};
+    for (int i = 0; i < c->samp_used; ++i)
+        cnt[std::min(std::max(c->samp_form[i], 0), EK_MAX_CANDS)]++;
+    int dom = 0;
+    for (int f = 1; f <= EK_MAX_CANDS; ++f)
+        if (cnt[f] > cnt[dom])
+            dom = f;
+    c->samp_dom = dom;
     // launches enqueued past the stopping point return immediately (device
     // no-ops): only samples within 4x of the longest count as real launches
     std::vector<float> t((size_t)c->samp_used);
@@ -1232,12 +1280,13 @@ extern "C" int ek_timing_end(ek_ctx *c, float *avg_ms, int32_t *n_samples)
     for (int i = 0; i < c->samp_used; ++i) {
         EK_HIP(hipEventElapsedTime(&t[i], c->samp_ev[2 * i],
                                    c->samp_ev[2 * i + 1]));
-        mx = std::max(mx, t[i]);
+        if (c->samp_form[i] == dom)
+            mx = std::max(mx, t[i]);
     }
     double sum = 0.0;
     int used = 0;
     for (int i = 0; i < c->samp_used; ++i)
-        if (t[i] > 0.25f * mx) {
+        if (c->samp_form[i] == dom && t[i] > 0.25f * mx) {
             sum += t[i];
             ++used;
         }
@@ -1246,6 +1295,14 @@ extern "C" int ek_timing_end(ek_ctx *c, float *avg_ms, int32_t *n_samples)
     if (n_samples)
         *n_samples = used;
     c->samp_every = 0;
+    return EK_OK;
+}
+
+extern "C" int ek_timing_form(ek_ctx *c, int32_t *candidates)
+{
+    if (!c || !candidates)
+        return ek_fail(EK_EARG, "ek_timing_form: NULL argument");
+    *candidates = c->samp_dom;
     return EK_OK;
 }
 
@@ -1898,7 +1955,7 @@ static int ek_pam_prefetch_vectors(ek_ctx *c, int count, int32_t win_lo,
         // and the proposals coincide: ek_pam_window_run's pruning reads it
         const bool slots = local && win_count == count;
         const size_t tb = (size_t)EK_PAM_WIN * (c->med_cap + 1);
-        const int groups = (count + EK_MAX_CANDS - 1) / EK_MAX_CANDS;
+        const int groups = (count + EK_PAM_GROUP - 1) / EK_PAM_GROUP;
         ek_launch_pam_tables(c->med_aos, c->med_G, c->A, K, c->pam_restore,
                              c->pam_recs, count, win_lo, slots ? count : 0, c->dtab,
                              c->dtab + tb, c->dtab + 2 * tb, c->stream);
@@ -1929,14 +1986,13 @@ static int ek_pam_prefetch_vectors(ek_ctx *c, int count, int32_t win_lo,
         // a scan and a read-back for nothing -- leave it out for a while
         c->pf_backoff = 15;
     }
-    // a pass over all frames per group of EK_MAX_CANDS proposals
+    // a pass over all frames per group of EK_PAM_GROUP proposals
     const size_t rstride = ek_rec_bytes(c->A);
-    for (int g0 = 0; g0 < count; g0 += EK_MAX_CANDS)
-        ek_launch_pass_dist(std::min(count - g0, EK_MAX_CANDS), c->tiles, c->G,
+    for (int g0 = 0; g0 < count; g0 += EK_PAM_GROUP)
+        ek_launch_pass_dist(std::min(count - g0, EK_PAM_GROUP), c->tiles, c->G,
                             c->pam_vecs + (size_t)g0 * c->n_pad, c->n, c->n_pad,
                             c->A, c->pam_recs + (size_t)g0 * rstride, c->pam_plan,
-                            c->pass_form, c->ctile, c->ctrace, c->stream,
-                            prepared && g0 == 0);
+                            c->ctile, c->ctrace, c->stream, prepared && g0 == 0);
     EK_CHECK_LAUNCH();
     ++c->pf_full;
     return EK_OK;
@@ -1974,9 +2030,6 @@ static int ek_pam_prefetch_frames(ek_ctx *c, const int64_t *frames, int32_t coun
         if (frames[j] < 0 || frames[j] >= c->n)
             return ek_fail(EK_EARG, "ek_pam_prefetch: frame %lld out of range",
                            (long long)frames[j]);
-    if ((size_t)3 * c->A * EK_MAX_CANDS * sizeof(float) > 150 * 1024)
-        return ek_fail(EK_EARG, "ek_pam_prefetch: %d atoms exceed the LDS center "
-                                "tile (limit 1600)", c->A);
     EK_HIP(hipSetDevice(c->device));
     c->pf_count = 0;
     if (count == 0)
@@ -1986,7 +2039,7 @@ static int ek_pam_prefetch_frames(ek_ctx *c, const int64_t *frames, int32_t coun
         if (rc)
             return rc;
     }
-    const bool prepared = c->pass_form == 1 && c->ctile != nullptr;
+    const bool prepared = c->ctile != nullptr;
     if (prepared)
         ek_launch_pam_setup(c->aos, c->G, c->A, frames, count, c->goff, c->pam_recs,
                             c->ctile, c->ctrace, c->pam_plan, c->amb_count + 3,
@@ -2179,12 +2232,9 @@ static int ek_pam_prefetch_centers_impl(ek_ctx *c, const float *aos_dev,
     if (!c->ndist || c->med_K < 1)
         return ek_fail(EK_ESTATE, "ek_pam_prefetch_centers: call ek_pam_begin[_table] "
                                   "first");
-    if (count < 0 || count > EK_MAX_CANDS)
+    if (count < 0 || count > EK_PAM_GROUP)
         return ek_fail(EK_EARG, "ek_pam_prefetch_centers: count=%d outside [0,%d]",
-                       count, EK_MAX_CANDS);
-    if ((size_t)3 * c->A * EK_MAX_CANDS * sizeof(float) > 150 * 1024)
-        return ek_fail(EK_EARG, "ek_pam_prefetch_centers: %d atoms exceed the LDS "
-                                "center tile (limit 1600)", c->A);
+                       count, EK_PAM_GROUP);
     EK_HIP(hipSetDevice(c->device));
     c->pf_count = 0;
     c->pf_external = true;
@@ -2338,11 +2388,12 @@ extern "C" int ek_spec_round(ek_ctx *c, const void *recs_all, int32_t n_recs,
                         (c->samp_count++ % c->samp_every) == 0 &&
                         2 * (size_t)c->samp_used + 1 < c->samp_ev.size();
     if (sample)
+        c->samp_form[c->samp_used] = T;
+    if (sample)
         EK_HIP(hipEventRecord(c->samp_ev[2 * c->samp_used], c->stream));
     ek_launch_pass(T, c->tiles, c->G, c->dist, c->assign, c->vecs,
                    c->n, c->n_pad, c->A, (const unsigned char *)recs_all,
-                   c->plan, c->blockmax, c->pass_form, c->ctile, c->ctrace,
-                   c->stream);
+                   c->plan, c->blockmax, c->ctile, c->ctrace, c->stream);
     if (sample) {
         EK_HIP(hipEventRecord(c->samp_ev[2 * c->samp_used + 1], c->stream));
         c->samp_used++;
@@ -2472,7 +2523,7 @@ extern "C" int ek_run_stats(ek_ctx *c, int64_t *passes, int64_t *centers)
 {
     if (!c || !passes || !centers)
         return ek_fail(EK_EARG, "ek_run_stats: NULL argument");
-    for (int m = 0; m < 3; ++m) {
+    for (int m = 0; m < 4; ++m) {
         passes[m] = c->st_rounds[m];
         centers[m] = c->st_centers[m];
     }

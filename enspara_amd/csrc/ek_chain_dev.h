@@ -48,7 +48,50 @@ __device__ __forceinline__ int ek_chain_simulate(const EkPlan *plan,
     return cn;
 }
 
-// this shard's rows, one entry per thread (tid < 64), into LDS
+// The same by one wave, lane j = candidate j (all 64 lanes of a wave call it;
+// rows, chain_out, cn_out in LDS): T - 1 steps of a wave arg-max instead of
+// (T - 1)^2 dependent scalar steps.  Same order as the loop above: largest
+// current distance, lowest global index on ties (the candidates' ranks by
+// global index stand in for the 64-bit indices).
+__device__ __forceinline__ void ek_chain_simulate_wave(const EkPlan *plan,
+                                                       const EkChainRow *rows,
+                                                       int *chain_out, int *cn_out)
+{
+    const int lane = threadIdx.x & (EK_WAVE - 1);
+    const int teff = plan->teff;
+    const bool cand = lane >= 1 && lane < teff && lane < EK_MAX_CANDS;
+    bool open = cand && rows[cand ? lane : 0].valid;
+    float cur = open ? rows[lane].cur : 0.f;
+    const long long g = cand ? plan->gidx[lane] : 0;
+    uint32_t rank = 0;
+    for (int j = 1; j < teff && j < EK_MAX_CANDS; ++j)
+        if (plan->gidx[j] < g)
+            ++rank;
+    int cn = 0;
+    for (;;) {
+        float v = open ? cur : -__builtin_inff();
+        uint32_t i = open ? rank : 0xffffffffu;
+        ek_wave_argmax(v, i);
+        if (i == 0xffffffffu)
+            break;
+        const unsigned long long who = __ballot(open && rank == i);
+        const int best = __ffsll((long long)who) - 1;
+        if (lane == best)
+            open = false;
+        if (lane == 0)
+            chain_out[cn] = best;
+        ++cn;
+        if (cand) {                             // kcenters.py:304: strict <
+            const float d = rows[lane].d[best];
+            if (open && d < cur)
+                cur = d;
+        }
+    }
+    if (lane == 0)
+        *cn_out = cn;
+}
+
+// this shard's rows into LDS (all threads of the workgroup call it)
 __device__ __forceinline__ void ek_chain_rows_local(const EkPlan *plan,
                                                     const float *dist,
                                                     const float *vecs, int64_t n,
@@ -56,9 +99,8 @@ __device__ __forceinline__ void ek_chain_rows_local(const EkPlan *plan,
                                                     int64_t global_offset,
                                                     EkChainRow *rows, int tid)
 {
-    if (tid >= EK_MAX_CANDS * EK_MAX_CANDS)
-        return;
-    const int j = tid / EK_MAX_CANDS, u = tid % EK_MAX_CANDS;
+  for (int e = tid; e < EK_MAX_CANDS * EK_MAX_CANDS; e += blockDim.x) {
+    const int j = e / EK_MAX_CANDS, u = e % EK_MAX_CANDS;
     const bool live = plan->go && j >= 1 && j < plan->teff;
     const int64_t local = live ? plan->gidx[j] - global_offset : -1;
     const bool mine = live && local >= 0 && local < n;
@@ -76,10 +118,13 @@ __device__ __forceinline__ void ek_chain_rows_local(const EkPlan *plan,
     } else {
         rows[j].d[u] = val;
     }
+  }
 }
 
-// waves 2w and 2w+1 of the workgroup reduce state w's per-workgroup maxima;
-// the loads of a trip are issued together (the entries are independent)
+// the workgroup's 16 waves reduce the per-workgroup maxima of states 0 .. cn - 1:
+// two waves per state while there are at most 8 states, one each beyond (cn <=
+// EK_MAX_CANDS - 1 = 15); the loads of a trip are issued together (the entries
+// are independent).  Called by 1024 threads.
 template <bool COH = false>
 __device__ __forceinline__ void ek_chain_reduce(const EkBlockMax *blockmax,
                                                 const EkBlockMax *pm, int nb,
@@ -90,18 +135,20 @@ __device__ __forceinline__ void ek_chain_reduce(const EkBlockMax *blockmax,
     __shared__ uint32_t half_i[2 * EK_MAX_CANDS];
     const int tid = threadIdx.x;
     const int wv = tid / EK_WAVE, lane = tid & (EK_WAVE - 1);
-    const int w = wv >> 1, part = wv & 1;
+    static_assert(EK_MAX_CANDS <= EK_CHAIN_THREADS / EK_WAVE, "a wave per state");
+    const int parts = cn <= EK_CHAIN_THREADS / EK_WAVE / 2 ? 2 : 1;
+    const int w = wv / parts, part = wv % parts;
     constexpr int U = 16;
     if (w < cn) {
         const EkBlockMax *src = (w == 0) ? blockmax : pm + (size_t)(w - 1) * nbp;
         const int cnt = (w == 0) ? nb : nbp;
         float v = -__builtin_inff();
         uint32_t i = 0xffffffffu;
-        for (int b0 = part * EK_WAVE + lane; b0 < cnt; b0 += 2 * EK_WAVE * U) {
+        for (int b0 = part * EK_WAVE + lane; b0 < cnt; b0 += parts * EK_WAVE * U) {
             EkBlockMax m[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int b = b0 + u * 2 * EK_WAVE;
+                const int b = b0 + u * parts * EK_WAVE;
                 m[u] = ek_ld_bm<COH>(&src[b < cnt ? b : cnt - 1]);
                 if (b >= cnt)
                     m[u].idx = 0xffffffffu;
@@ -121,11 +168,11 @@ __device__ __forceinline__ void ek_chain_reduce(const EkBlockMax *blockmax,
     }
     __syncthreads();
     if (tid < cn) {
-        float v = half_v[2 * tid];
-        uint32_t i = half_i[2 * tid];
-        const float v2 = half_v[2 * tid + 1];
-        const uint32_t i2 = half_i[2 * tid + 1];
-        if (i == 0xffffffffu || (i2 != 0xffffffffu && ek_better(v2, i2, v, i))) {
+        float v = half_v[parts * tid];
+        uint32_t i = half_i[parts * tid];
+        const float v2 = parts == 2 ? half_v[2 * tid + 1] : 0.f;
+        const uint32_t i2 = parts == 2 ? half_i[2 * tid + 1] : 0xffffffffu;
+        if (i2 != 0xffffffffu && (i == 0xffffffffu || ek_better(v2, i2, v, i))) {
             v = v2;
             i = i2;
         }

@@ -57,9 +57,11 @@ struct EkMaxHdr {
 static_assert(sizeof(EkMaxHdr) == 16, "max header is 16 bytes");
 
 typedef float ek_v2f __attribute__((ext_vector_type(2)));
-#ifndef EK_MAX_CANDS
-#define EK_MAX_CANDS 8      // 16 only in measurement builds (tools/pass16_probe.py)
-#endif
+// candidates per pass of a k-centers round: 4, 8 or 16 (a run-time choice,
+// ek_run_rounds); the structures below are sized for the most
+#define EK_MAX_CANDS 16
+// PAM: proposals per prefetch pass / columns per workgroup of the pairs kernel
+#define EK_PAM_GROUP 8
 // plan of one multi-candidate round (ek_spec.hip); written only by the
 // single-workgroup plan/check kernels, read by the kernels that follow
 struct EkPlan {
@@ -144,7 +146,8 @@ struct EkRound {
     unsigned int *tick;         // [3] arrival counters of the three kernels
     double cutoff;
 };
-void ek_launch_round_pass(const EkRound &r, hipStream_t s);
+// with_order: the pass's last workgroup works out the presumed order (single shard)
+void ek_launch_round_pass(const EkRound &r, hipStream_t s, bool with_order = true);
 // bootstrap != 0: no chain to decide, candidates from blockmax as it is
 void ek_launch_round_chain(const EkRound &r, int bootstrap, hipStream_t s);
 void ek_launch_round_next(const EkRound &r, int bootstrap, hipStream_t s);
@@ -287,9 +290,9 @@ struct EkPamOut {
 static_assert(sizeof(EkPamOut) == 32, "EkPamOut layout");
 // a window of proposals decided on the device (ek_pam_window_run): up to
 // EK_PAM_WIN consecutive clusters, their proposals drawn, prefetched (in groups
-// of EK_MAX_CANDS columns) and decided without a host round trip in between
+// of EK_PAM_GROUP columns) and decided without a host round trip in between
 #define EK_PAM_WIN 16
-static_assert(EK_PAM_WIN % EK_MAX_CANDS == 0 && EK_PAM_WIN <= 32,
+static_assert(EK_PAM_WIN % EK_PAM_GROUP == 0 && EK_PAM_WIN <= 32,
               "whole column groups; the stale mask is 32 bits");
 struct EkPamWin {
     int32_t stop;       // slots [0, stop) were decided
@@ -323,7 +326,7 @@ void ek_launch_pam_apply(const int32_t *flag, float *dist, const float *ndist,
                          int32_t *assign, const int32_t *nassign, int64_t n,
                          hipStream_t s);
 // active-set proposal prefetch (ek_pam.hip)
-// T [n_prop][K]: medoid-to-proposal distances, dmin [groups of EK_MAX_CANDS
+// T [n_prop][K]: medoid-to-proposal distances, dmin [groups of EK_PAM_GROUP
 // proposals][K] their minimum per medoid and group, O [n_old][K]: distances to
 // the medoids of clusters old_lo ..
 void ek_launch_pam_tables(const float *aos, const double *Gm, int A, int K, int held,
@@ -344,13 +347,30 @@ void ek_launch_pam_active(const float *dist, const int32_t *assign, int64_t n,
 // window's proposals (local frames), one launch; the pass launcher is then
 // called with prepared = true
 #define EK_CTILE_PAD 8      // atoms of zeros after a candidate tile's last (read-ahead)
+// Where (atom a, candidate c, coordinate k) of a round's T candidates sits in the
+// candidate tile the pass kernel reads: T <= 8 [atom][pair][xyz][2] (pairs of
+// candidates as scalar operands of v_pk_fma_f32, ek_spec.hip); T = 16
+// [trip of 4 atoms][candidate][xyz][atom of the trip] (a lane of the MFMA
+// kernel reads its candidate's 12 floats of a trip as three 16-byte loads,
+// ek_pass16.hip).  The tile holds A + EK_CTILE_PAD atoms (whole trips), zeros
+// past the last.
+static inline __host__ __device__ size_t ek_ctile_index(int T, int a, int c, int k)
+{
+    if (T == 16)
+        return ((size_t)(a >> 2) * 16 + c) * 12 + k * 4 + (a & 3);
+    return (size_t)a * (3 * T) + (c / 2) * 6 + k * 2 + (c & 1);
+}
+static inline __host__ __device__ int ek_ctile_atoms(int A)  // incl. padding
+{
+    return (A + EK_CTILE_PAD + 3) / 4 * 4;
+}
 void ek_launch_pam_setup(const float *aos, const double *G, int A,
                          const int64_t *frames, int count, int64_t global_offset,
                          unsigned char *recs, float *ctile, double *ctrace,
                          EkPlan *plan, unsigned int *counter, hipStream_t s);
 static inline int ek_pass_dist_T(int count)     // the pass width ek_launch_pass_dist picks
 {
-    return (count <= 4) ? 4 : (count <= 8 ? 8 : 16);
+    return (count <= 4) ? 4 : 8;
 }
 // (aos: the frame-major copy of the shard)
 void ek_launch_records_from_frames(const float *aos, const double *G, int A,
@@ -393,19 +413,23 @@ void ek_launch_gather_rows(const float *tiles, const double *G, int A,
 void ek_launch_plan(const unsigned char *recs, int n_recs, int A, int T,
                     double cutoff, float *D, EkPlan *plan, EkHist *hist,
                     EkCtl *ctl, hipStream_t s);
-size_t ek_pass_lds_bytes(int T, int A);
-// form 0: candidates staged in LDS; form 1: candidates laid out in `ctile`
-// (ek_ctile_bytes) / `ctrace` ([EK_MAX_CANDS] f64) and read as scalar operands
+// the candidates are laid out in `ctile` (ek_ctile_bytes) / `ctrace`
+// ([EK_MAX_CANDS] f64) and read as scalar operands
 size_t ek_ctile_bytes(int A);
 void ek_launch_pass(int T, const float *tiles, const double *G, float *dist,
                     int32_t *assign, float *vecs, int64_t n, int64_t n_pad,
                     int A, const unsigned char *recs, const EkPlan *plan,
-                    EkBlockMax *blockmax, int form, float *ctile, double *ctrace,
+                    EkBlockMax *blockmax, float *ctile, double *ctrace,
                     hipStream_t s);
+// T = 16 through the matrix cores (ek_pass16.hip); fuse: the fused rounds' form
+void ek_launch_pass16(bool fuse, const float *tiles, const double *G, float *dist,
+                      int32_t *assign, float *vecs, int64_t n, int64_t n_pad, int A,
+                      const float *ctile, const double *ctrace, const EkPlan *plan,
+                      EkBlockMax *blockmax, const EkFuse &fz, hipStream_t s);
 // distances only: vecs[j][f] = rmsd(frame f, record j), j < count <= 8
 void ek_launch_pass_dist(int count, const float *tiles, const double *G,
                          float *vecs, int64_t n, int64_t n_pad, int A,
-                         const unsigned char *recs, EkPlan *plan, int form,
+                         const unsigned char *recs, EkPlan *plan,
                          float *ctile, double *ctrace, hipStream_t s, bool prepared = false);
 // ---- chained rounds (ek_chain.hip) --------------------------------------------------
 // rows_out[EK_MAX_CANDS]: this shard's view of the candidate frames it owns

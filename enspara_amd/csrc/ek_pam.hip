@@ -1562,7 +1562,7 @@ void ek_pw_build_shape(int len, EkPwShape *sh)
 
 // Distances of a few thousand rows to a few columns -- too little work to fill
 // the chip with the streaming kernels, whose one wave per 64 frames then runs
-// at memory latency.  Here a workgroup takes 64 rows x EK_MAX_CANDS columns,
+// at memory latency.  Here a workgroup takes 64 rows x EK_PAM_GROUP columns,
 // wave = column, lane = row; the rows (frame-major, 12 A contiguous bytes each)
 // and the columns' coordinates go through LDS in slices of EK_PAIR_CH atoms,
 // read from memory once along the rows with the next slice's loads in flight
@@ -1599,15 +1599,15 @@ struct EkPairArgs {
 
 static inline size_t ek_pair_lds_bytes()
 {
-    return (size_t)(3 * EK_PAIR_CH * (EK_WAVE + 1) + EK_MAX_CANDS * 3 * EK_PAIR_CH) *
+    return (size_t)(3 * EK_PAIR_CH * (EK_WAVE + 1) + EK_PAM_GROUP * 3 * EK_PAIR_CH) *
            sizeof(float);
 }
 
 template <int MODE>
-__global__ void __launch_bounds__(EK_MAX_CANDS *EK_WAVE)
+__global__ void __launch_bounds__(EK_PAM_GROUP *EK_WAVE)
 ek_pam_pairs_kernel(EkPairArgs p)
 {
-    constexpr int NT = EK_MAX_CANDS * EK_WAVE;
+    constexpr int NT = EK_PAM_GROUP * EK_WAVE;
     constexpr int LD = EK_WAVE + 1;             // padded: conflict-free both ways
     constexpr int TPR = NT / EK_WAVE;           // threads per row
     constexpr int NLD = 3 * EK_PAIR_CH / TPR;   // loads per thread and slice
@@ -1615,16 +1615,16 @@ ek_pam_pairs_kernel(EkPairArgs p)
     extern __shared__ __attribute__((aligned(16))) float pair_lds[];
     float *tile = pair_lds;                                 // [3 CH][LD]
     float *ytile = pair_lds + 3 * EK_PAIR_CH * LD;          // [columns][3 CH]
-    __shared__ float tmin[EK_MAX_CANDS][EK_WAVE];
+    __shared__ float tmin[EK_PAM_GROUP][EK_WAVE];
     const int A = p.A;
     const int lane = threadIdx.x & (EK_WAVE - 1);
-    // grid.y: the groups of EK_MAX_CANDS columns -- the proposals' first, then
+    // grid.y: the groups of EK_PAM_GROUP columns -- the proposals' first, then
     // (MODE 0) the old medoids'
-    const int gp = (p.n_col + EK_MAX_CANDS - 1) / EK_MAX_CANDS;
+    const int gp = (p.n_col + EK_PAM_GROUP - 1) / EK_PAM_GROUP;
     const bool old = MODE == 0 && (int)blockIdx.y >= gp;
     const int grp = old ? (int)blockIdx.y - gp : (int)blockIdx.y;
     const int jw = __builtin_amdgcn_readfirstlane(threadIdx.x / EK_WAVE);
-    const int j = grp * EK_MAX_CANDS + jw;      // this wave's column
+    const int j = grp * EK_PAM_GROUP + jw;      // this wave's column
     const int ncol = old ? p.n_old : p.n_col;
     const bool live = j < ncol;
     // this wave's column
@@ -1719,7 +1719,7 @@ ek_pam_pairs_kernel(EkPairArgs p)
     if (jw == 0 && ok) {
         float m = tmin[0][lane];
 #pragma unroll
-        for (int q = 1; q < EK_MAX_CANDS; ++q)
+        for (int q = 1; q < EK_PAM_GROUP; ++q)
             m = fminf(m, tmin[q][lane]);
         p.dmin[(size_t)grp * p.K + c] = m;
     }
@@ -1731,7 +1731,7 @@ static void ek_pairs_launch(const EkPairArgs &p, dim3 grid, hipStream_t s)
     const size_t lds = ek_pair_lds_bytes();     // above the 64 KB a kernel gets unasked
     (void)hipFuncSetAttribute((const void *)ek_pam_pairs_kernel<MODE>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(ek_pam_pairs_kernel<MODE>, grid, dim3(EK_MAX_CANDS * EK_WAVE),
+    hipLaunchKernelGGL(ek_pam_pairs_kernel<MODE>, grid, dim3(EK_PAM_GROUP * EK_WAVE),
                        lds, s, p);
 }
 
@@ -1753,8 +1753,8 @@ void ek_launch_pam_tables(const float *aos, const double *Gm, int A, int K, int 
     p.T = T;
     p.O = O;
     p.dmin = dmin;
-    const int groups = (n_prop + EK_MAX_CANDS - 1) / EK_MAX_CANDS +
-                       (n_old + EK_MAX_CANDS - 1) / EK_MAX_CANDS;
+    const int groups = (n_prop + EK_PAM_GROUP - 1) / EK_PAM_GROUP +
+                       (n_old + EK_PAM_GROUP - 1) / EK_PAM_GROUP;
     ek_pairs_launch<0>(p, dim3((K + EK_WAVE - 1) / EK_WAVE, groups), s);
 }
 
@@ -1777,7 +1777,7 @@ void ek_launch_pam_list_dist(const float *aos, const double *G, int A,
     p.n_pad = n_pad;
     p.vecs = vecs;
     ek_pairs_launch<1>(p, dim3((unsigned)((n_rows + EK_WAVE - 1) / EK_WAVE),
-                               (count + EK_MAX_CANDS - 1) / EK_MAX_CANDS), s);
+                               (count + EK_PAM_GROUP - 1) / EK_PAM_GROUP), s);
 }
 
 // the frames that need exact distances -> list (any order), *n_list
@@ -1894,7 +1894,7 @@ void ek_launch_records_from_frames(const float *aos, const double *G, int A,
 // records (workgroup j: frame j, as above), the candidate tile / traces the
 // pass kernel reads (ek_spec.hip, ek_ctile_kernel's layout [atom][pair][xyz][2],
 // taken from the frames directly) and the fixed plan "distances to these
-// records" for the first `cg` <= EK_MAX_CANDS of them (what a pass over all
+// records" for the first `cg` <= EK_PAM_GROUP of them (what a pass over all
 // frames starts with when the restriction to touched frames does not apply),
 // and the active-frame counter cleared.
 __global__ void __launch_bounds__(EK_BLOCK)
@@ -1919,15 +1919,14 @@ ek_pam_setup_kernel(const float *__restrict__ aos, const double *__restrict__ G,
         for (int r = threadIdx.x; r < 3 * A; r += EK_BLOCK)
             coords[r] = aos[(size_t)idx * 3 * A + r];
     }
-    const int total = (A + EK_CTILE_PAD) * 3 * T;
+    const int total = ek_ctile_atoms(A) * 3 * T;
     for (int j = blockIdx.x * EK_BLOCK + threadIdx.x; j < total;
          j += gridDim.x * EK_BLOCK) {
-        const int a = j / (3 * T), w = j % (3 * T);
-        const int c = (w / 6) * 2 + (w & 1), k = (w % 6) / 2;
+        const int a = j / (3 * T), c = (j % (3 * T)) / 3, k = j % 3;
         float v = 0.f;
         if (a < A && c < cg)
             v = aos[(size_t)fl.f[c] * 3 * A + 3 * a + k];
-        ctile[j] = v;
+        ctile[ek_ctile_index(T, a, c, k)] = v;
     }
     if (blockIdx.x == 0) {
         if ((int)threadIdx.x < T)
@@ -1936,7 +1935,7 @@ ek_pam_setup_kernel(const float *__restrict__ aos, const double *__restrict__ G,
             plan->go = 1;
             plan->teff = cg;
             plan->label = 0;
-            for (int j = 0; j < EK_MAX_CANDS; ++j)
+            for (int j = 0; j < EK_PAM_GROUP; ++j)
                 plan->src[j] = j;
             *counter = 0;
         }
@@ -1953,9 +1952,9 @@ void ek_launch_pam_setup(const float *aos, const double *G, int A,
     EkFrameList fl;
     for (int j = 0; j < EK_PAM_WIN; ++j)
         fl.f[j] = j < count ? frames[j] : 0;
-    const int cg = std::min(count, EK_MAX_CANDS);
+    const int cg = std::min(count, EK_PAM_GROUP);
     const int T = ek_pass_dist_T(cg);
-    const int cb = ((A + EK_CTILE_PAD) * 3 * T + EK_BLOCK - 1) / EK_BLOCK;
+    const int cb = (ek_ctile_atoms(A) * 3 * T + EK_BLOCK - 1) / EK_BLOCK;
     hipLaunchKernelGGL(ek_pam_setup_kernel, dim3(std::max(count, cb)),
                        dim3(EK_BLOCK), 0, s, aos, G, A, fl, count, cg, T,
                        global_offset, recs, ctile, ctrace, plan, counter);

@@ -395,7 +395,7 @@ ek_round_next_kernel(EkRound r, int bootstrap)
         }
     }
     // ... and, from the same reads, the candidate tile of the next pass:
-    // [atom][pair][xyz][2], zeros for unused slots and the atoms of padding.
+    // (ek_ctile_index), zeros for unused slots and the atoms of padding.
     // All of a trip's loads (T candidates x 4 rows per thread) go out before
     // the first store: the stores may alias them as far as the compiler knows.
     const int A3 = 3 * r.A;
@@ -420,16 +420,15 @@ ek_round_next_kernel(EkRound r, int bootstrap)
                     continue;
                 if (c < ns)
                     rec[row] = v[c][u];
-                if (go) {       // (zero for a slot without a candidate)
-                    const int a = row / 3, k = row % 3;
-                    r.ctile[a * (3 * T) + (c / 2) * 6 + k * 2 + (c & 1)] = v[c][u];
-                }
+                if (go)         // (zero for a slot without a candidate)
+                    r.ctile[ek_ctile_index(T, row / 3, c, row % 3)] = v[c][u];
             }
         }
     }
-    if (go && tid < EK_CTILE_PAD * 3 * T)       // the atoms of padding
-        r.ctile[r.A * 3 * T + tid] = 0.f;
-    static_assert(EK_CTILE_PAD * 3 * T <= EK_BLOCK, "one store per thread");
+    if (go)                                     // the atoms of padding
+        for (int k = tid; k < (ek_ctile_atoms(r.A) - r.A) * 3 * T; k += EK_BLOCK)
+            r.ctile[ek_ctile_index(T, r.A + k / (3 * T), (k % (3 * T)) / 3, k % 3)] =
+                0.f;
     if (tid == 0) {
         EkPlan *plan = r.plan;
         r.ctl->last_max = first_max;
@@ -460,7 +459,10 @@ void ek_launch_round_next(const EkRound &r, int bootstrap, hipStream_t s)
     if (r.n <= 0)
         return;
     const unsigned blocks = (unsigned)(EK_TOP_M * EK_TOP_M / (EK_BLOCK / EK_WAVE));
-    if (r.T == 8)
+    if (r.T == 16)
+        hipLaunchKernelGGL((ek_round_next_kernel<16>), dim3(blocks), dim3(EK_BLOCK), 0,
+                           s, r, bootstrap);
+    else if (r.T == 8)
         hipLaunchKernelGGL((ek_round_next_kernel<8>), dim3(blocks), dim3(EK_BLOCK), 0,
                            s, r, bootstrap);
     else

@@ -26,27 +26,11 @@
 // launches (ek_round.hip), the single-workgroup parts riding in the last
 // workgroup of the launch that produces their input.
 //
-// Two forms of the pass kernel live here: ek_pass2_kernel (candidates as scalar
-// operands, the default) and ek_pass_kernel (candidates staged in LDS, round 1;
-// ek_set_option key 9).  Same arithmetic, same bits.
 #include "ek_common.h"
 #include "ek_qcp.h"
 #include "ek_reduce.h"
 #include "ek_top_dev.h"
 #include "ek_chain_dev.h"
-
-// atoms per trip of the pass kernel's main loop, and how many trips ahead of
-// the FMAs the row loads are issued (register ring of DIST + 1 trips)
-#ifndef EK_SPEC_TRIP
-#define EK_SPEC_TRIP 4
-#endif
-#ifndef EK_SPEC_DIST
-#define EK_SPEC_DIST 1
-#endif
-// waves per SIMD asked of the register allocator for the 8-candidate kernel
-#ifndef EK_SPEC_WAVES8
-#define EK_SPEC_WAVES8 3
-#endif
 
 // ---------------------------------------------------------------------------
 // plan: choose the round's candidates among the records on offer
@@ -210,248 +194,33 @@ void ek_launch_plan(const unsigned char *recs, int n_recs, int A, int T,
 }
 
 // ---------------------------------------------------------------------------
-// the pass: every frame against the round's T candidates
-// one lane = one frame; candidates staged in LDS as ctile[atom][cand][xyz]
+// the pass: every frame against the round's T candidates (T = 4, 8, 16)
 // ---------------------------------------------------------------------------
-// waves per SIMD asked of the register allocator: 5 at T = 4, 3 at T = 8
-// UPD = true: a k-centers round (candidate 0 updates the state, the others'
-// distances go to vecs[0..T-2]).  UPD = false: distances only, all T of them to
-// vecs[0..T-1] (PAM proposal prefetch); dist / assign / blockmax are not touched.
-template <int T, bool UPD>
-__global__ void __launch_bounds__(EK_BLOCK,
-                                  (T <= 4) ? 5 : (T <= 8 ? EK_SPEC_WAVES8 : 2))
-ek_pass_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
-               float *__restrict__ dist, int32_t *__restrict__ assign,
-               float *__restrict__ vecs,   // [T-1][n_pad] stored distance vectors
-               int64_t n, int64_t n_pad, int A,
-               const unsigned char *__restrict__ recs,
-               const EkPlan *__restrict__ plan,
-               EkBlockMax *__restrict__ blockmax)
-{
-    extern __shared__ __attribute__((aligned(16))) float ctile[];
-    __shared__ double gtile[T];
-    __shared__ float red_v[EK_BLOCK / EK_WAVE];
-    __shared__ uint32_t red_i[EK_BLOCK / EK_WAVE];
-    if (!plan->go)
-        return;
-    const int tid = threadIdx.x;
-    const int teff = plan->teff;
-    const int label = plan->label;
-    const size_t rstride = ek_rec_bytes(A);
-
-    // stage the candidates: global reads run along each record (coalesced)
-    for (int j = tid; j < 3 * A * T; j += EK_BLOCK) {
-        const int c = j / (3 * A), r = j % (3 * A);
-        float v = 0.f;
-        if (c < teff) {
-            const float *src = (const float *)(recs +
-                (size_t)plan->src[c] * rstride + sizeof(EkRecHdr));
-            v = src[r];
-        }
-        // candidates in pairs: [atom][pair][xyz][2], so that one packed FMA
-        // (v_pk_fma_f32) serves candidates 2p and 2p+1
-        ctile[(r / 3) * (3 * T) + (c / 2) * 6 + (r % 3) * 2 + (c & 1)] = v;
-    }
-    if (tid < T) {
-        double g = 0.0;
-        if (tid < teff)
-            g = ((const EkRecHdr *)(recs + (size_t)plan->src[tid] * rstride))
-                    ->trace;
-        gtile[tid] = g;
-    }
-    __syncthreads();
-
-    const int64_t f = (int64_t)blockIdx.x * EK_BLOCK + tid;
-    // one workgroup = one tile: a wave-uniform base (scalar registers) plus the
-    // lane's 32-bit offset, so the row addresses cost no vector registers
-    static_assert(EK_BLOCK == EK_TILE, "one workgroup per tile");
-    const float *tb = tiles + (size_t)blockIdx.x * 3 * (size_t)A * EK_TILE;
-    // s2[p][j] = (S_j of candidate 2p, S_j of candidate 2p+1): each component is
-    // its own IEEE FMA chain in ascending atom order, exactly as the one-center
-    // kernels compute it; packing only doubles the FMA rate (the T = 8 pass was
-    // bound by the vector ALU, not by HBM, with scalar FMAs).
-    ek_v2f s2[T / 2][9];
-#pragma unroll
-    for (int c = 0; c < T / 2; ++c)
-#pragma unroll
-        for (int j = 0; j < 9; ++j)
-            s2[c][j] = (ek_v2f){0.f, 0.f};
-
-    const float4 *ct4 = (const float4 *)ctile;
-    constexpr int Q = 3 * T / 4;            // float4 per atom (T multiple of 4)
-    // Occupancy is only 3-4 waves per SIMD here (9*T accumulators), and a trip's
-    // FMAs take a fraction of the HBM latency, so the rows of trip t + DIST are
-    // requested before the FMAs of trip t are issued: a ring of DIST + 1
-    // register buffers, unrolled so that every buffer index is a constant.
-    constexpr int TRIP = EK_SPEC_TRIP;      // atoms per trip
-    constexpr int DIST = EK_SPEC_DIST;
-    constexpr int NB = DIST + 1;
-    const int n_trip = (A + TRIP - 1) / TRIP;
-    float bx[NB][TRIP], by[NB][TRIP], bz[NB][TRIP];
-#define EK_ROWS(BUF, TRIP_INDEX)                                               \
-    _Pragma("unroll") for (int u = 0; u < TRIP; ++u) {                         \
-        int au = (TRIP_INDEX) * TRIP + u;                                      \
-        au = (au < A) ? au : A - 1;     /* clamp: in-bounds, masked below */   \
-        const float *row = tb + (size_t)(3 * au) * EK_TILE;                    \
-        bx[BUF][u] = __builtin_nontemporal_load(row + tid);                    \
-        by[BUF][u] = __builtin_nontemporal_load(row + EK_TILE + tid);          \
-        bz[BUF][u] = __builtin_nontemporal_load(row + 2 * EK_TILE + tid);      \
-    }
-#pragma unroll
-    for (int k = 0; k < DIST; ++k)
-        EK_ROWS(k, k)
-    for (int t0 = 0; t0 < n_trip; t0 += NB) {
-#pragma unroll
-        for (int k = 0; k < NB; ++k) {
-            const int t = t0 + k;
-            EK_ROWS((k + DIST) % NB, t + DIST)
-            const int a0 = t * TRIP;
-#pragma unroll
-            for (int u = 0; u < TRIP; ++u) {
-                const int a = a0 + u;
-                if (a < A) {                        // wave-uniform
-                    float cc[3 * T];
-#pragma unroll
-                    for (int q = 0; q < Q; ++q) {
-                        const float4 v = ct4[a * Q + q];
-                        cc[4 * q + 0] = v.x;
-                        cc[4 * q + 1] = v.y;
-                        cc[4 * q + 2] = v.z;
-                        cc[4 * q + 3] = v.w;
-                    }
-                    const ek_v2f x = (ek_v2f){bx[k][u], bx[k][u]},
-                                 y = (ek_v2f){by[k][u], by[k][u]},
-                                 z = (ek_v2f){bz[k][u], bz[k][u]};
-#pragma unroll
-                    for (int c = 0; c < T / 2; ++c) {
-                        const ek_v2f cx = (ek_v2f){cc[6 * c + 0], cc[6 * c + 1]},
-                                     cy = (ek_v2f){cc[6 * c + 2], cc[6 * c + 3]},
-                                     cz = (ek_v2f){cc[6 * c + 4], cc[6 * c + 5]};
-                        s2[c][0] = __builtin_elementwise_fma(x, cx, s2[c][0]);
-                        s2[c][1] = __builtin_elementwise_fma(x, cy, s2[c][1]);
-                        s2[c][2] = __builtin_elementwise_fma(x, cz, s2[c][2]);
-                        s2[c][3] = __builtin_elementwise_fma(y, cx, s2[c][3]);
-                        s2[c][4] = __builtin_elementwise_fma(y, cy, s2[c][4]);
-                        s2[c][5] = __builtin_elementwise_fma(y, cz, s2[c][5]);
-                        s2[c][6] = __builtin_elementwise_fma(z, cx, s2[c][6]);
-                        s2[c][7] = __builtin_elementwise_fma(z, cy, s2[c][7]);
-                        s2[c][8] = __builtin_elementwise_fma(z, cz, s2[c][8]);
-                    }
-                }
-            }
-        }
-    }
-#undef EK_ROWS
-
-    if (!UPD) {
-        if (f < n) {
-            const double Gf = G[f];
-#pragma unroll
-            for (int c = 0; c < T; ++c) {
-                __builtin_amdgcn_sched_barrier(0);
-                if (c < teff) {
-                    float S[9];
-#pragma unroll
-                    for (int j = 0; j < 9; ++j)
-                        S[j] = s2[c / 2][j][c & 1];
-                    vecs[(size_t)c * n_pad + f] =
-                        ek_rmsd_from_S(S, Gf, gtile[c], A);
-                }
-            }
-        }
-        return;
-    }
-    float bestv = -__builtin_inff();
-    uint32_t besti = 0xffffffffu;
-    if (f < n) {
-        const double Gf = G[f];
-        // candidate 0: the new center of this iteration (kcenters.py:298-306)
-        float S0[9];
-#pragma unroll
-        for (int j = 0; j < 9; ++j)
-            S0[j] = s2[0][j][0];
-        float cur = dist[f];
-        // (+inf when d0 >= cur is certain before the quartic has converged)
-        const float d0 = ek_rmsd_from_S_below(S0, Gf, gtile[0], A, cur);
-        if (d0 < cur) {
-            cur = d0;
-            dist[f] = d0;
-            assign[f] = label;
-        }
-        bestv = cur;
-        besti = (uint32_t)f;
-        // the guesses: keep their distances for later (one quartic solve at a
-        // time: interleaving them costs registers)
-#pragma unroll
-        for (int c = 1; c < T; ++c) {
-            __builtin_amdgcn_sched_barrier(0);
-            if (c < teff) {
-                float S[9];
-#pragma unroll
-                for (int j = 0; j < 9; ++j)
-                    S[j] = s2[c / 2][j][c & 1];
-                // every later use of a kept distance is a strict "<" against
-                // this frame's distance, which only shrinks from here on
-                vecs[(size_t)(c - 1) * n_pad + f] =
-                    ek_rmsd_from_S_below(S, Gf, gtile[c], A, cur);
-            }
-        }
-    }
-    ek_wave_argmax(bestv, besti);
-    const int lane = tid & (EK_WAVE - 1), wave = tid / EK_WAVE;
-    if (lane == 0) {
-        red_v[wave] = bestv;
-        red_i[wave] = besti;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        float v = red_v[0];
-        uint32_t i = red_i[0];
-#pragma unroll
-        for (int w = 1; w < EK_BLOCK / EK_WAVE; ++w)
-            if (ek_better(red_v[w], red_i[w], v, i)) {
-                v = red_v[w];
-                i = red_i[w];
-            }
-        blockmax[blockIdx.x].val = v;
-        blockmax[blockIdx.x].idx = i;
-    }
-}
-
-// ---------------------------------------------------------------------------
-// the pass, second form: candidates as SCALAR operands
-// ---------------------------------------------------------------------------
-// The candidates are the same for every lane, so they do not need vector
-// registers or LDS at all: ek_ctile_kernel lays the round's candidates out once
-// in global memory as [atom][pair][xyz][2] and every wave reads an atom's 3T
-// floats with scalar loads (s_load_dwordx8/x16, through the scalar cache) one
-// atom ahead of the FMAs; v_pk_fma_f32 takes the (candidate 2p, candidate 2p+1)
-// pair straight from an SGPR pair.  The frame rows come through buffer loads
-// (SGPR descriptor of the tile + scalar row offset + the lane's constant
-// offset: no address registers; rows past the tile's end read as 0) into the
-// two halves of register pairs, atoms a and a+1 of a coordinate sharing a pair
-// and op_sel picking the half -- the compiler left the odd half of every pair
-// unused.  That is 72 accumulators + 12 row registers per trip in flight and
-// nothing else: 4 waves per SIMD with the rows two trips ahead, where the LDS
-// form had 3 waves and one trip.  Each component is still its own IEEE FMA
-// chain in ascending atom order: same bits as every other kernel here.
+// One lane = one frame.  The candidates are the same for every lane, so they do
+// not need vector registers or LDS at all: the round's candidates are laid out
+// once in global memory as [atom][pair][xyz][2] (ek_ctile_kernel, or the kernel
+// that chose them) and every wave reads them with scalar loads (s_load_dwordx8,
+// through the scalar cache) one CHUNK ahead of the FMAs -- a chunk is one atom
+// of up to 8 candidates, 24 floats in 24 SGPRs; 16 candidates are two chunks
+// per atom, so that two chunk buffers (48 SGPRs) serve every T --;
+// v_pk_fma_f32 takes the (candidate 2p, candidate 2p+1) pair straight from an
+// SGPR pair.  The frame rows come through buffer loads (SGPR descriptor of the
+// tile + scalar row offset + the lane's constant offset: no address registers;
+// rows past the tile's end read as 0) into the two halves of register pairs,
+// atoms a and a+1 of a coordinate sharing a pair and op_sel picking the half.
+// T = 8: 72 accumulators + 36 row registers (rows two trips ahead), 4 waves per
+// SIMD; T = 16: 144 accumulators, 2 waves per SIMD -- that form is bound by the
+// packed-FMA rate, not by HBM, and is chosen when its extra centers per pass
+// pay (ek_run_rounds), i.e. always on shards too small to be bandwidth-bound.
+// Each S component is its own IEEE FMA chain in ascending atom order: the same
+// bits as every other kernel here, whatever T.
 typedef const float __attribute__((address_space(4))) *ek_cfp;
 
-#ifndef EK_PASS2_DIST
-#define EK_PASS2_DIST 2
-#endif
-#ifndef EK_PASS2_WAVES8
-#define EK_PASS2_WAVES8 4
-#endif
-// measurement builds only (tools/lab_pass.py): 1 = no quartic solves, 2 = the
-// candidates are read once (no scalar loads in the loop), 4 = no FMAs
-#ifndef EK_PASS2_ABLATE
-#define EK_PASS2_ABLATE 0
-#endif
+#define EK_PASS2_DIST 2         // trips (of 4 atoms) the row loads run ahead
 
 static inline __host__ __device__ size_t ek_ctile_floats(int A)
 {
-    return (size_t)(A + EK_CTILE_PAD) * 3 * EK_MAX_CANDS;
+    return (size_t)ek_ctile_atoms(A) * 3 * EK_MAX_CANDS;
 }
 
 // acc += x.lo * c  /  x.hi * c  (per component; c = an SGPR pair)
@@ -466,27 +235,26 @@ __device__ __forceinline__ void ek_pkfma_hi(ek_v2f &acc, ek_v2f x, ek_v2f c)
         : "+v"(acc) : "v"(x), "s"(c));
 }
 
-template <int T> struct EkCAtom { float v[3 * T]; };
+// one atom of P candidate pairs: [pair][xyz][2]
+template <int P> struct EkCChunk { float v[6 * P]; };
 
-template <int T>
-__device__ __forceinline__ void ek_ld_catom(EkCAtom<T> &o, ek_cfp p)
+template <int P>
+__device__ __forceinline__ void ek_ld_chunk(EkCChunk<P> &o, ek_cfp p)
 {
-#if EK_PASS2_ABLATE & 2
-    return;
-#endif
 #pragma unroll
-    for (int i = 0; i < 3 * T; ++i)
+    for (int i = 0; i < 6 * P; ++i)
         o.v[i] = p[i];
 }
 
-// FMAs [from, to) of the 9 T / 2 of one atom (order: pair, then S row-major)
-template <int T, bool HI>
-__device__ __forceinline__ void ek_atom_fma(ek_v2f (&s2)[T / 2][9], ek_v2f X,
-                                            ek_v2f Y, ek_v2f Z,
-                                            const EkCAtom<T> &c, int from, int to)
+// FMAs [from, to) of the 9 P of one chunk (order: pair, then S row-major) into
+// the accumulators of pairs p0 .. p0 + P - 1
+template <int NP, int P, bool HI>
+__device__ __forceinline__ void ek_chunk_fma(ek_v2f (&s2)[NP][9], int p0, ek_v2f X,
+                                             ek_v2f Y, ek_v2f Z,
+                                             const EkCChunk<P> &c, int from, int to)
 {
 #pragma unroll
-    for (int p = 0; p < T / 2; ++p) {
+    for (int p = 0; p < P; ++p) {
         const ek_v2f cx = (ek_v2f){c.v[6 * p + 0], c.v[6 * p + 1]};
         const ek_v2f cy = (ek_v2f){c.v[6 * p + 2], c.v[6 * p + 3]};
         const ek_v2f cz = (ek_v2f){c.v[6 * p + 4], c.v[6 * p + 5]};
@@ -497,14 +265,10 @@ __device__ __forceinline__ void ek_atom_fma(ek_v2f (&s2)[T / 2][9], ek_v2f X,
                 continue;
             const ek_v2f r = (j / 3 == 0) ? X : (j / 3 == 1 ? Y : Z);
             const ek_v2f cc = (j % 3 == 0) ? cx : (j % 3 == 1 ? cy : cz);
-#if EK_PASS2_ABLATE & 4
-            if (p != 0 || j % 3 != 0)
-                continue;
-#endif
             if (HI)
-                ek_pkfma_hi(s2[p][j], r, cc);
+                ek_pkfma_hi(s2[p0 + p][j], r, cc);
             else
-                ek_pkfma_lo(s2[p][j], r, cc);
+                ek_pkfma_lo(s2[p0 + p][j], r, cc);
         }
     }
 }
@@ -521,17 +285,16 @@ ek_ctile_kernel(const unsigned char *__restrict__ recs,
         return;
     const int teff = plan->teff;
     const size_t rstride = ek_rec_bytes(A);
-    const int total = (A + EK_CTILE_PAD) * 3 * T;
+    const int total = ek_ctile_atoms(A) * 3 * T;
     for (int j = blockIdx.x * EK_BLOCK + threadIdx.x; j < total;
          j += gridDim.x * EK_BLOCK) {
-        // destination order: [atom][pair][xyz][2]
-        const int a = j / (3 * T), w = j % (3 * T);
-        const int c = (w / 6) * 2 + (w & 1), k = (w % 6) / 2;
+        // source order (atom, candidate, xyz); destination: ek_ctile_index
+        const int a = j / (3 * T), c = (j % (3 * T)) / 3, k = j % 3;
         float v = 0.f;
         if (a < A && c < teff)
             v = ((const float *)(recs + (size_t)plan->src[c] * rstride +
                                  sizeof(EkRecHdr)))[3 * a + k];
-        ctile[j] = v;
+        ctile[ek_ctile_index(T, a, c, k)] = v;
     }
     if (blockIdx.x == 0 && threadIdx.x < T) {
         const int c = threadIdx.x;
@@ -541,13 +304,17 @@ ek_ctile_kernel(const unsigned char *__restrict__ recs,
     }
 }
 
-// FUSE (single-shard rounds, ek_round.hip): the accepted chain of the previous
-// round (`pend`) is applied to the frame's state on the way in instead of by a
-// pass of its own, and the last workgroup to finish works out the presumed
-// acceptance order of this round's candidates (`ord`).
+// UPD = true: a k-centers round (candidate 0 updates the state, the others'
+// distances go to vecs[0..T-2]).  UPD = false: distances only, all T of them to
+// vecs[0..T-1] (PAM proposal prefetch); dist / assign / blockmax are not touched.
+// FUSE (the three- and four-launch rounds, ek_round.hip / ek_mshard.hip): the
+// accepted chain of the previous round (`pend`) is applied to the frame's state
+// on the way in instead of by a pass of its own, a distance vector is stored
+// only where a wave holds a finite value, and -- if fz.ord is given (single
+// shard) -- the last workgroup to finish works out the presumed acceptance
+// order of this round's candidates.
 template <int T, bool UPD, bool FUSE>
-__global__ void __launch_bounds__(EK_BLOCK,
-                                  (T <= 4) ? 5 : EK_PASS2_WAVES8)
+__global__ void __launch_bounds__(EK_BLOCK, (T <= 4) ? 5 : 4)
 ek_pass2_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
                 float *__restrict__ dist, int32_t *__restrict__ assign,
                 float *__restrict__ vecs, int64_t n, int64_t n_pad, int A,
@@ -571,28 +338,16 @@ ek_pass2_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
     const int64_t f0 = UPD ? (int64_t)blockIdx.x * EK_BLOCK
                            : (int64_t)blockIdx.x * blockDim.x;
     const int64_t f = f0 + tid;
-#ifdef EK_PASS2_STAGGER
-    // measurement builds: de-phase the workgroups that share a SIMD (the first
-    // wave of workgroups starts together and every tile takes the same time, so
-    // their load-free solve tails coincide): class k starts k * STAGGER * 3.9 us late
-    if (blockIdx.x < 1024) {
-#if EK_PASS2_STAGGER_MODE == 0
-        const int cls = (blockIdx.x >> 8) & 3;
-#else
-        const int cls = (blockIdx.x >> 3) & 3;
-#endif
-        for (int q = 0; q < cls * EK_PASS2_STAGGER; ++q)
-            __builtin_amdgcn_s_sleep(127);
-    }
-#endif
-    // FUSE: the last workgroup does a little more at the end (see there), and
-    // "last" is decided by arrival tickets.  Only the workgroups that own one of
-    // the round's guesses produce something it reads; every other workgroup
-    // draws its ticket right here, where the atomic's latency costs nothing --
-    // the one that draws the last ticket does so after every owner has finished.
+    // FUSE with an order to work out: the last workgroup does a little more at
+    // the end (see there), and "last" is decided by arrival tickets.  Only the
+    // workgroups that own one of the round's guesses produce something it reads;
+    // every other workgroup draws its ticket right here, where the atomic's
+    // latency costs nothing -- the one that draws the last ticket does so after
+    // every owner has finished.
+    const bool order = UPD && FUSE && fz.ord != nullptr;
     bool owner_blk = false;
     unsigned int ticket = 0;
-    if (UPD && FUSE) {
+    if (order) {
 #pragma unroll
         for (int j = 1; j < T; ++j) {
             const int64_t l = plan->gidx[j] - fz.goff - (int64_t)blockIdx.x * EK_BLOCK;
@@ -606,7 +361,7 @@ ek_pass2_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
     double Gf = 0.0;
     float cur0 = 0.f;
     int32_t lab = -1;           // >= 0: the frame's state changes in this pass
-    int own = 0;                // FUSE: this frame is candidate `own` (>= 1)
+    int own = 0;                // order: this frame is candidate `own` (>= 1)
     if (f < n) {
         Gf = G[f];
         if (UPD)
@@ -614,10 +369,12 @@ ek_pass2_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
         if (UPD && FUSE) {
             // is this frame one of the round's guesses?  (its row of the new
             // distance vectors decides the presumed order, see the end)
+            if (order) {
 #pragma unroll
-            for (int j = 1; j < T; ++j)
-                if (j < teff && plan->gidx[j] - fz.goff == f)
-                    own = j;
+                for (int j = 1; j < T; ++j)
+                    if (j < teff && plan->gidx[j] - fz.goff == f)
+                        own = j;
+            }
             // kcenters.py:304-306 for the pending chain, in order.  A vector is
             // only stored where some frame of the wave got a finite distance
             // (see the end): elsewhere it is +inf and changes nothing.
@@ -640,22 +397,19 @@ ek_pass2_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         (void *)tb, 0, 3 * A * EK_TILE * 4, 0x00020000);
     const int vo = ((int)(f0 % EK_TILE) + tid) * 4;
-    // non-temporal: the frame stream is read once per pass
-#ifndef EK_PASS2_LDMODE
-#define EK_PASS2_LDMODE 0   // measurement builds: 1 = no nt hint, 2 = global loads
-#endif
-#if EK_PASS2_LDMODE == 2
-#define EK_LD(SO, K)                                                           \
-    __builtin_nontemporal_load(tb + (size_t)((SO) / 4) + (K) * EK_TILE + vo / 4)
-#else
+    // non-temporal (aux bit 1): the frame stream is read once per pass
 #define EK_LD(SO, K)                                                           \
     __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(            \
-                                  rs, vo + (K) * (EK_TILE * 4), (SO),          \
-                                  EK_PASS2_LDMODE == 1 ? 0 : 2))
-#endif
-    ek_v2f s2[T / 2][9];
+                                  rs, vo + (K) * (EK_TILE * 4), (SO), 2))
+    constexpr int NP = T / 2;               // candidate pairs
+    constexpr int P = NP < 4 ? NP : 4;      // pairs per chunk
+    constexpr int H = NP / P;               // chunks per atom
+    constexpr int CH = 6 * P;               // floats per chunk
+    constexpr int NF = 9 * P;               // packed FMAs per chunk
+    static_assert(NP % P == 0 && (4 * H) % 2 == 0, "whole chunks, even per trip");
+    ek_v2f s2[NP][9];
 #pragma unroll
-    for (int c = 0; c < T / 2; ++c)
+    for (int c = 0; c < NP; ++c)
 #pragma unroll
         for (int j = 0; j < 9; ++j)
             s2[c][j] = (ek_v2f){0.f, 0.f};
@@ -678,42 +432,36 @@ ek_pass2_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
 #pragma unroll
     for (int k = 0; k < DIST; ++k)
         EK_ROWS2(k, k)
-    EkCAtom<T> c0, c1;
-#if EK_PASS2_ABLATE & 2
-#pragma unroll
-    for (int i = 0; i < 3 * T; ++i)
-        c0.v[i] = c1.v[i] = cp[i];
-#endif
-    ek_ld_catom<T>(c0, cp);
-    constexpr int NF = 9 * T / 2;       // packed FMAs per atom
-    // One trip: request the rows of trip t + DIST, then the 4 * NF FMAs of trip
-    // t.  The first FMA of an atom waits for that atom's scalar loads (they
-    // return out of order, so the wait is for all of them); the next atom's are
-    // issued right after it and have the other NF - 1 FMAs to arrive.
+    EkCChunk<P> cb[2];
+    ek_ld_chunk<P>(cb[0], cp);
+    // One trip: request the rows of trip t + DIST, then the 4 H chunks of trip t.
+    // The first FMA of a chunk waits for that chunk's scalar loads (they return
+    // out of order, so the wait is for all of them); the next chunk's are issued
+    // right after it and have the other NF - 1 FMAs to arrive.  Chunk q of the
+    // trip is atom q / H, candidate pairs (q % H) P ..; chunks alternate between
+    // the two buffers (4 H is even: the parity carries over from trip to trip).
 #define EK_TRIP2(K, TT)                                                        \
     {                                                                          \
         EK_ROWS2(((K) + DIST) % NB, (TT) + DIST)                               \
-        const ek_cfp ca = cp + (size_t)(4 * (TT)) * (3 * T);                   \
-        ek_atom_fma<T, false>(s2, X[K][0], Y[K][0], Z[K][0], c0, 0, 1);        \
-        __builtin_amdgcn_sched_barrier(0);                                     \
-        ek_ld_catom<T>(c1, ca + 1 * 3 * T);                                    \
-        __builtin_amdgcn_sched_barrier(0);                                     \
-        ek_atom_fma<T, false>(s2, X[K][0], Y[K][0], Z[K][0], c0, 1, NF);       \
-        ek_atom_fma<T, true>(s2, X[K][0], Y[K][0], Z[K][0], c1, 0, 1);         \
-        __builtin_amdgcn_sched_barrier(0);                                     \
-        ek_ld_catom<T>(c0, ca + 2 * 3 * T);                                    \
-        __builtin_amdgcn_sched_barrier(0);                                     \
-        ek_atom_fma<T, true>(s2, X[K][0], Y[K][0], Z[K][0], c1, 1, NF);        \
-        ek_atom_fma<T, false>(s2, X[K][1], Y[K][1], Z[K][1], c0, 0, 1);        \
-        __builtin_amdgcn_sched_barrier(0);                                     \
-        ek_ld_catom<T>(c1, ca + 3 * 3 * T);                                    \
-        __builtin_amdgcn_sched_barrier(0);                                     \
-        ek_atom_fma<T, false>(s2, X[K][1], Y[K][1], Z[K][1], c0, 1, NF);       \
-        ek_atom_fma<T, true>(s2, X[K][1], Y[K][1], Z[K][1], c1, 0, 1);         \
-        __builtin_amdgcn_sched_barrier(0);                                     \
-        ek_ld_catom<T>(c0, ca + 4 * 3 * T);   /* next trip's first atom */     \
-        __builtin_amdgcn_sched_barrier(0);                                     \
-        ek_atom_fma<T, true>(s2, X[K][1], Y[K][1], Z[K][1], c1, 1, NF);        \
+        const ek_cfp ca = cp + (size_t)(4 * (TT)) * (H * CH);                  \
+        _Pragma("unroll") for (int q = 0; q < 4 * H; ++q) {                    \
+            const int aa = q / H, p0 = (q % H) * P;                            \
+            if (aa & 1)                                                        \
+                ek_chunk_fma<NP, P, true>(s2, p0, X[K][aa / 2], Y[K][aa / 2],  \
+                                          Z[K][aa / 2], cb[q & 1], 0, 1);      \
+            else                                                               \
+                ek_chunk_fma<NP, P, false>(s2, p0, X[K][aa / 2], Y[K][aa / 2], \
+                                           Z[K][aa / 2], cb[q & 1], 0, 1);     \
+            __builtin_amdgcn_sched_barrier(0);                                 \
+            ek_ld_chunk<P>(cb[(q + 1) & 1], ca + (q + 1) * CH);                \
+            __builtin_amdgcn_sched_barrier(0);                                 \
+            if (aa & 1)                                                        \
+                ek_chunk_fma<NP, P, true>(s2, p0, X[K][aa / 2], Y[K][aa / 2],  \
+                                          Z[K][aa / 2], cb[q & 1], 1, NF);     \
+            else                                                               \
+                ek_chunk_fma<NP, P, false>(s2, p0, X[K][aa / 2], Y[K][aa / 2], \
+                                           Z[K][aa / 2], cb[q & 1], 1, NF);    \
+        }                                                                      \
     }
     // Whole groups of NB trips run without a branch inside, and the first group
     // is peeled: the loop is then entered in the very state it leaves at its
@@ -740,7 +488,7 @@ ek_pass2_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
             EK_TRIP2(k, t0 + k)
     }
 #undef EK_TRIP2
-    // the A % 4 atoms after the last whole trip (c0 holds the first of them)
+    // the A % 4 atoms after the last whole trip
     for (int a = 4 * n_trip; a < A; ++a) {
         const int so = a * (3 * EK_TILE * 4);
         ek_v2f x, y, z;
@@ -750,8 +498,11 @@ ek_pass2_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
         x[1] = 0.f;
         y[1] = 0.f;
         z[1] = 0.f;
-        ek_ld_catom<T>(c0, cp + (size_t)a * (3 * T));
-        ek_atom_fma<T, false>(s2, x, y, z, c0, 0, NF);
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            ek_ld_chunk<P>(cb[0], cp + ((size_t)a * H + h) * CH);
+            ek_chunk_fma<NP, P, false>(s2, h * P, x, y, z, cb[0], 0, NF);
+        }
     }
 #undef EK_ROWS2
 #undef EK_LD
@@ -782,11 +533,7 @@ ek_pass2_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
         for (int j = 0; j < 9; ++j)
             S0[j] = s2[0][j][0];
         float cur = cur0;
-#if EK_PASS2_ABLATE & 1
-        const float d0 = S0[0] + S0[4] + S0[8] + (float)Gf;
-#else
         const float d0 = ek_rmsd_from_S_below(S0, Gf, ctrace[0], A, cur);
-#endif
         if (d0 < cur) {
             cur = d0;
             lab = label;
@@ -797,12 +544,12 @@ ek_pass2_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
         }
         bestv = cur;
         besti = (uint32_t)f;
-        if (FUSE && own) {
+        if (order && own) {
             ek_coh_store(&fz.rows[own].cur, cur);
             ek_coh_store(&fz.rows[own].valid, 1);
         }
         // FUSE: almost every kept distance is +inf (abandoned: it cannot be below
-        // the frame's own), and 4-byte-per-frame stores trickling into seven
+        // the frame's own), and 4-byte-per-frame stores trickling into T - 1
         // arrays cost the pass 12 % (28 MB of writes against 3.6 GB of reads:
         // every small write burst turns the HBM bus around).  So a wave stores a
         // vector only if one of its frames has a finite value, and one word per
@@ -816,13 +563,7 @@ ek_pass2_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
 #pragma unroll
                 for (int j = 0; j < 9; ++j)
                     S[j] = s2[c / 2][j][c & 1];
-#if EK_PASS2_ABLATE & 1
-                const float dc =
-                    S[0] + S[1] + S[2] + S[3] + S[4] + S[5] + S[6] + S[7] + S[8];
-#else
                 const float dc = ek_rmsd_from_S_below(S, Gf, ctrace[c], A, cur);
-#endif
-#if !(EK_PASS2_ABLATE & 8)
                 if (FUSE) {
                     if (__ballot(dc != __builtin_inff())) {     // wave-uniform
                         vecs[(size_t)(c - 1) * n_pad + f] = dc;
@@ -831,11 +572,7 @@ ek_pass2_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
                 } else {
                     vecs[(size_t)(c - 1) * n_pad + f] = dc;
                 }
-#else
-                if (dc == 12345.f)
-                    vecs[(size_t)(c - 1) * n_pad + f] = dc;
-#endif
-                if (FUSE && own)
+                if (order && own)
                     ek_coh_store(&fz.rows[own].d[c], dc);
             }
         }
@@ -861,14 +598,15 @@ ek_pass2_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
         blockmax[blockIdx.x].val = v;
         blockmax[blockIdx.x].idx = i;
     }
-    if (FUSE) {
-        // The last workgroup to get here sees everything the others wrote
-        // (release fence, counter, acquire fence) and works out the order in
-        // which the candidates would be accepted (ek_chain.hip, step 1) from the
-        // candidate frames' own rows of the new distance vectors.
-        // (the rows were written by the workgroups that own the candidate
-        // frames, as coherent stores: ek_reduce.h)
+    if (order) {
+        // The last workgroup to get here works out the order in which the
+        // candidates would be accepted (ek_chain.hip, step 1) from the
+        // candidate frames' own rows of the new distance vectors (written by
+        // the workgroups that own the candidate frames, as coherent stores:
+        // ek_reduce.h)
         __shared__ EkChainRow rows[EK_MAX_CANDS];
+        __shared__ int s_chain[EK_MAX_CANDS];
+        __shared__ int s_cn;
         __shared__ bool early_last;
         bool last;
         if (owner_blk) {            // after its rows are in place
@@ -881,8 +619,8 @@ ek_pass2_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
         }
         if (!last)
             return;
-        if (tid < EK_MAX_CANDS * (EK_MAX_CANDS + 2)) {
-            const int j = tid / (EK_MAX_CANDS + 2), u = tid % (EK_MAX_CANDS + 2);
+        for (int e = tid; e < EK_MAX_CANDS * (EK_MAX_CANDS + 2); e += EK_BLOCK) {
+            const int j = e / (EK_MAX_CANDS + 2), u = e % (EK_MAX_CANDS + 2);
             const bool live = j >= 1 && j < teff;
             if (u == 0)
                 rows[j].cur = live ? ek_coh_load(&fz.rows[j].cur) : 0.f;
@@ -896,12 +634,13 @@ ek_pass2_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
         __syncthreads();
         if (tid < EK_MAX_CANDS)     // the rows are one round's: clear them
             fz.rows[tid].valid = 0;
+        if (tid < EK_WAVE)
+            ek_chain_simulate_wave(plan, rows, s_chain, &s_cn);
+        __syncthreads();
+        if (tid < EK_MAX_CANDS)
+            fz.ord->cand[tid] = tid < s_cn ? s_chain[tid] : 0;
         if (tid == 0) {
-            int chain[EK_MAX_CANDS];
-            const int cn = ek_chain_simulate(plan, rows, chain);
-            for (int k = 0; k < cn; ++k)
-                fz.ord->cand[k] = chain[k];
-            fz.ord->n = cn;
+            fz.ord->n = s_cn;
             // candidate 0 is a center now (kcenters.py:306-309): the count and
             // the history move when its distances are in, not when it was planned
             fz.hist[label].gidx = plan->gidx[0];
@@ -916,78 +655,69 @@ ek_pass2_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
 
 size_t ek_ctile_bytes(int A) { return ek_ctile_floats(A) * sizeof(float); }
 
-void ek_launch_round_pass(const EkRound &r, hipStream_t s)
+#define EK_BY_T(TT, CALL)                                                      \
+    do {                                                                       \
+        if ((TT) == 8) {                                                       \
+            constexpr int T_ = 8;                                              \
+            CALL;                                                              \
+        } else {                                                               \
+            constexpr int T_ = 4;                                              \
+            CALL;                                                              \
+        }                                                                      \
+    } while (0)
+
+// with_order: single shard, the last workgroup works out the presumed order
+void ek_launch_round_pass(const EkRound &r, hipStream_t s, bool with_order)
 {
     if (r.n <= 0)
         return;
     const unsigned blocks = (unsigned)((r.n + EK_BLOCK - 1) / EK_BLOCK);
     EkFuse fz;
     fz.pend = r.pend;
-    fz.ord = r.ord;
+    fz.ord = with_order ? r.ord : nullptr;
     fz.tick = r.tick + 0;
     fz.goff = r.goff;
     fz.hist = r.hist;
     fz.ctl = r.ctl;
     fz.rows = r.rows;
     fz.vmask = r.vmask;
-    if (r.T == 8)
-        hipLaunchKernelGGL((ek_pass2_kernel<8, true, true>), dim3(blocks),
-                           dim3(EK_BLOCK), 0, s, r.tiles, r.G, r.dist, r.assign,
-                           r.vecs, r.n, r.n_pad, r.A, r.ctile, r.ctrace, r.plan,
-                           r.blockmax, fz);
-    else
-        hipLaunchKernelGGL((ek_pass2_kernel<4, true, true>), dim3(blocks),
-                           dim3(EK_BLOCK), 0, s, r.tiles, r.G, r.dist, r.assign,
-                           r.vecs, r.n, r.n_pad, r.A, r.ctile, r.ctrace, r.plan,
-                           r.blockmax, fz);
+    if (r.T == 16) {
+        ek_launch_pass16(true, r.tiles, r.G, r.dist, r.assign, r.vecs, r.n, r.n_pad,
+                         r.A, r.ctile, r.ctrace, r.plan, r.blockmax, fz, s);
+        return;
+    }
+    EK_BY_T(r.T, hipLaunchKernelGGL((ek_pass2_kernel<T_, true, true>), dim3(blocks),
+                                    dim3(EK_BLOCK), 0, s, r.tiles, r.G, r.dist,
+                                    r.assign, r.vecs, r.n, r.n_pad, r.A, r.ctile,
+                                    r.ctrace, r.plan, r.blockmax, fz));
 }
 
-size_t ek_pass_lds_bytes(int T, int A) { return (size_t)3 * A * T * sizeof(float); }
-
+// the one-launch-per-step form: lay the candidates out, then stream the frames
 void ek_launch_pass(int T, const float *tiles, const double *G, float *dist,
                     int32_t *assign, float *vecs, int64_t n, int64_t n_pad,
                     int A, const unsigned char *recs, const EkPlan *plan,
-                    EkBlockMax *blockmax, int form, float *ctile, double *ctrace,
+                    EkBlockMax *blockmax, float *ctile, double *ctrace,
                     hipStream_t s)
 {
     if (n <= 0)
         return;
     const unsigned blocks = (unsigned)((n + EK_BLOCK - 1) / EK_BLOCK);
-    if (form == 1 && ctile) {
-        // scalar-operand form: lay the candidates out, then stream the frames
-        const unsigned cb = (unsigned)(((A + EK_CTILE_PAD) * 3 * T + EK_BLOCK - 1) /
-                                       EK_BLOCK);
-        if (T == 8) {
-            hipLaunchKernelGGL((ek_ctile_kernel<8>), dim3(cb), dim3(EK_BLOCK), 0, s,
-                               recs, plan, A, ctile, ctrace);
-            hipLaunchKernelGGL((ek_pass2_kernel<8, true, false>), dim3(blocks),
-                               dim3(EK_BLOCK), 0, s, tiles, G, dist, assign, vecs,
-                               n, n_pad, A, ctile, ctrace, plan, blockmax, EkFuse());
-        } else {
-            hipLaunchKernelGGL((ek_ctile_kernel<4>), dim3(cb), dim3(EK_BLOCK), 0, s,
-                               recs, plan, A, ctile, ctrace);
-            hipLaunchKernelGGL((ek_pass2_kernel<4, true, false>), dim3(blocks),
-                               dim3(EK_BLOCK), 0, s, tiles, G, dist, assign, vecs,
-                               n, n_pad, A, ctile, ctrace, plan, blockmax, EkFuse());
-        }
+    const unsigned cb = (unsigned)((ek_ctile_atoms(A) * 3 * T + EK_BLOCK - 1) /
+                                   EK_BLOCK);
+    if (T == 16) {
+        hipLaunchKernelGGL((ek_ctile_kernel<16>), dim3(cb), dim3(EK_BLOCK), 0, s,
+                           recs, plan, A, ctile, ctrace);
+        ek_launch_pass16(false, tiles, G, dist, assign, vecs, n, n_pad, A, ctile,
+                         ctrace, plan, blockmax, EkFuse(), s);
         return;
     }
-    const size_t lds = ek_pass_lds_bytes(T, A);
-#define EK_PASS(TT)                                                            \
-    do {                                                                       \
-        if (lds > 48 * 1024)                                                   \
-            (void)hipFuncSetAttribute(                                         \
-                (const void *)ek_pass_kernel<TT, true>,                        \
-                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \
-        hipLaunchKernelGGL((ek_pass_kernel<TT, true>), dim3(blocks),           \
-                           dim3(EK_BLOCK), lds, s, tiles, G, dist, assign,     \
-                           vecs, n, n_pad, A, recs, plan, blockmax);           \
-    } while (0)
-    if (T == 8)
-        EK_PASS(8);
-    else
-        EK_PASS(4);
-#undef EK_PASS
+    EK_BY_T(T, {
+        hipLaunchKernelGGL((ek_ctile_kernel<T_>), dim3(cb), dim3(EK_BLOCK), 0, s,
+                           recs, plan, A, ctile, ctrace);
+        hipLaunchKernelGGL((ek_pass2_kernel<T_, true, false>), dim3(blocks),
+                           dim3(EK_BLOCK), 0, s, tiles, G, dist, assign, vecs, n,
+                           n_pad, A, ctile, ctrace, plan, blockmax, EkFuse());
+    });
 }
 
 // distances of every frame to `count` records (count <= 8), nothing else:
@@ -1005,7 +735,7 @@ __global__ void ek_plan_fixed_kernel(EkPlan *__restrict__ plan, int count)
 
 void ek_launch_pass_dist(int count, const float *tiles, const double *G,
                          float *vecs, int64_t n, int64_t n_pad, int A,
-                         const unsigned char *recs, EkPlan *plan, int form,
+                         const unsigned char *recs, EkPlan *plan,
                          float *ctile, double *ctrace, hipStream_t s, bool prepared)
 {
     if (n <= 0 || count <= 0)
@@ -1013,59 +743,25 @@ void ek_launch_pass_dist(int count, const float *tiles, const double *G,
     const int T = ek_pass_dist_T(count);
     // prepared: plan, ctile and ctrace already hold these records
     // (ek_launch_pam_setup)
-    prepared = prepared && form == 1 && ctile && T <= 8;
     if (!prepared)
         hipLaunchKernelGGL(ek_plan_fixed_kernel, dim3(1), dim3(EK_WAVE), 0, s, plan,
                            count);
     const unsigned blocks = (unsigned)((n + EK_BLOCK - 1) / EK_BLOCK);
-    if (form == 1 && ctile && T <= 8) {
-        const unsigned cb = (unsigned)(((A + EK_CTILE_PAD) * 3 * T + EK_BLOCK - 1) /
-                                       EK_BLOCK);
-        // a list too short to fill the chip (PAM's touched frames): one wave
-        // per workgroup
-        const bool thin = blocks < 1024;
-        const dim3 pg(thin ? (unsigned)((n + EK_WAVE - 1) / EK_WAVE) : blocks);
-        const dim3 pb(thin ? EK_WAVE : EK_BLOCK);
-        if (T == 8) {
-            if (!prepared)
-                hipLaunchKernelGGL((ek_ctile_kernel<8>), dim3(cb), dim3(EK_BLOCK), 0,
-                                   s, recs, plan, A, ctile, ctrace);
-            hipLaunchKernelGGL((ek_pass2_kernel<8, false, false>), pg,
-                               pb, 0, s, tiles, G, nullptr, nullptr,
-                               vecs, n, n_pad, A, ctile, ctrace, plan, nullptr,
-                               EkFuse());
-        } else {
-            if (!prepared)
-                hipLaunchKernelGGL((ek_ctile_kernel<4>), dim3(cb), dim3(EK_BLOCK), 0,
-                                   s, recs, plan, A, ctile, ctrace);
-            hipLaunchKernelGGL((ek_pass2_kernel<4, false, false>), pg,
-                               pb, 0, s, tiles, G, nullptr, nullptr,
-                               vecs, n, n_pad, A, ctile, ctrace, plan, nullptr,
-                               EkFuse());
-        }
-        return;
-    }
-    const size_t lds = ek_pass_lds_bytes(T, A);
-#define EK_PASSD(TT)                                                           \
-    do {                                                                       \
-        if (lds > 48 * 1024)                                                   \
-            (void)hipFuncSetAttribute(                                         \
-                (const void *)ek_pass_kernel<TT, false>,                       \
-                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \
-        hipLaunchKernelGGL((ek_pass_kernel<TT, false>), dim3(blocks),          \
-                           dim3(EK_BLOCK), lds, s, tiles, G, nullptr, nullptr, \
-                           vecs, n, n_pad, A, recs, plan, nullptr);            \
-    } while (0)
-#if EK_MAX_CANDS >= 16
-    if (T == 16)
-        EK_PASSD(16);       // measurement builds only
-    else
-#endif
-    if (T == 8)
-        EK_PASSD(8);
-    else
-        EK_PASSD(4);
-#undef EK_PASSD
+    const unsigned cb = (unsigned)((ek_ctile_atoms(A) * 3 * T + EK_BLOCK - 1) /
+                                   EK_BLOCK);
+    // a list too short to fill the chip (PAM's touched frames): one wave
+    // per workgroup
+    const bool thin = blocks < 1024;
+    const dim3 pg(thin ? (unsigned)((n + EK_WAVE - 1) / EK_WAVE) : blocks);
+    const dim3 pb(thin ? EK_WAVE : EK_BLOCK);
+    EK_BY_T(T, {
+        if (!prepared)
+            hipLaunchKernelGGL((ek_ctile_kernel<T_>), dim3(cb), dim3(EK_BLOCK), 0, s,
+                               recs, plan, A, ctile, ctrace);
+        hipLaunchKernelGGL((ek_pass2_kernel<T_, false, false>), pg, pb, 0, s, tiles,
+                           G, nullptr, nullptr, vecs, n, n_pad, A, ctile, ctrace,
+                           plan, nullptr, EkFuse());
+    });
 }
 
 // ---------------------------------------------------------------------------

@@ -375,11 +375,10 @@ class FrameStore:
     def run_stats(self):
         """How the last kcenters_run spent its passes over the frames:
         -> {candidates per pass: (passes, centers accepted)}"""
-        p = np.zeros(3, dtype=np.int64)
-        k = np.zeros(3, dtype=np.int64)
+        p = np.zeros(4, dtype=np.int64)
+        k = np.zeros(4, dtype=np.int64)
         _lib.check(self.lib.ek_run_stats(self._h, _lib.i64p(p), _lib.i64p(k)))
-        return {1: (int(p[0]), int(k[0])), 4: (int(p[1]), int(k[1])),
-                8: (int(p[2]), int(k[2]))}
+        return {T: (int(p[i]), int(k[i])) for i, T in enumerate((1, 4, 8, 16))}
 
     def ti_stats(self):
         """Triangle inequality (set_option(11, 1)): (center, tile) pairs the last
@@ -424,3 +423,9 @@ class FrameStore:
         k = C.c_int32()
         _lib.check(self.lib.ek_timing_end(self._h, C.byref(ms), C.byref(k)))
         return ms.value, k.value
+
+    def timing_form(self):
+        """candidates per pass of the launches timing_end averaged over"""
+        t = C.c_int32()
+        _lib.check(self.lib.ek_timing_form(self._h, C.byref(t)))
+        return t.value

@@ -188,10 +188,10 @@ int ek_spec_chain_apply(ek_ctx *ctx, const void *hdrs_all, int32_t n_shards,
  * ek_kcenters_run started */
 int ek_spec_rounds(ek_ctx *ctx, int32_t *rounds);
 /* How the last ek_kcenters_run spent its passes over the frames:
- * passes[i] / centers[i] = passes run with 1, 4, 8 candidate centers
- * (i = 0, 1, 2) and the centers those passes accepted.  The loop of
+ * passes[i] / centers[i] = passes run with 1, 4, 8, 16 candidate centers
+ * (i = 0 .. 3) and the centers those passes accepted.  The loop of
  * kcenters.py:217-231 has no such notion (one metric call per center); the
- * three forms give identical centers, labels and distances, and the run moves
+ * forms give identical centers, labels and distances, and the run moves
  * between them by the centers per millisecond each achieves. */
 int ek_run_stats(ek_ctx *ctx, int64_t *passes, int64_t *centers);
 /* Triangle inequality (ek_set_option key 11; the reference's
@@ -447,7 +447,7 @@ int ek_set_frames_per_lane(ek_ctx *ctx, int fpl);
 /* key 1: non-temporal loads of the frame stream (0/1; -1 = automatic:
  * on when the shard is larger than the Infinity Cache)
  * key 4: candidate centers per pass of ek_kcenters_run / ek_spec_*: -1
- * automatic (8, fewer for very large atom counts), 1 = one-center passes, 4, 8
+ * automatic (up to 16, see key 8), 1 = one-center passes, 4, 8, 16
  * key 2: nearest-center kernel: 0 automatic, 1 vector FMA, 2 MFMA (identical
  * results)
  * key 5: cheap steps of a round in ek_kcenters_run: 1 chained (default), 0 one
@@ -459,7 +459,7 @@ int ek_set_frames_per_lane(ek_ctx *ctx, int fpl);
  * ek_state_reset + k-centers, false after ek_state_upload / ek_assign_nearest
  * key 7: assert (1) or withdraw (0) that property, e.g. after
  * ek_assign_nearest with the medoid frames themselves as centers
- * key 8: with key 4 = -1, let ek_kcenters_run move between 1, 4 and 8
+ * key 8: with key 4 = -1, let ek_kcenters_run move between 1, 8 and 16
  * candidates per pass by measured centers per millisecond: 1 (default) / 0
  * (always the widest form); identical results either way
  * key 11: triangle inequality in ek_kcenters_run (0 default / 1): one center
@@ -471,9 +471,8 @@ int ek_set_frames_per_lane(ek_ctx *ctx, int fpl);
  * key 10: ek_kcenters_run's rounds in three launches (the single-workgroup
  * steps ride at the end of the launch that produces their input): 1 (default)
  * / 0 (one launch per step); identical results
- * key 9: multi-candidate pass kernel: 1 (default) candidates as scalar
- * operands read through the scalar cache, 0 candidates staged in LDS;
- * identical results */
+ * key 9: retired (round 1's pass kernel with the candidates staged in LDS);
+ * only the value 1 is accepted */
 int ek_set_option(ek_ctx *ctx, int32_t key, int32_t value);
 /* time of the last ek_kcenters_run loop measured with HIP events on the
  * context's stream, milliseconds, and the number of distance-kernel launches
@@ -484,9 +483,12 @@ int ek_last_run_timing(ek_ctx *ctx, float *ms, int32_t *launches);
  * `sample_every`-th ek_kcenters_step brackets its distance-kernel launch with
  * a HIP event pair on the context's stream (at most max_samples pairs).
  * ek_timing_end synchronises and returns the mean elapsed time per sampled
- * launch in milliseconds. */
+ * launch in milliseconds -- of the launches with the number of candidates per
+ * pass that was sampled most, which ek_timing_form then reports (a run moves
+ * between 1, 8 and 16 candidates per pass). */
 int ek_timing_begin(ek_ctx *ctx, int32_t sample_every, int32_t max_samples);
 int ek_timing_end(ek_ctx *ctx, float *avg_ms, int32_t *n_samples);
+int ek_timing_form(ek_ctx *ctx, int32_t *candidates);
 
 #ifdef __cplusplus
 }

@@ -202,7 +202,7 @@ def test_assign_variants_bit_identical(qcp, n, A, K):
             assert not np.isin(a, [3, 4, 5]).any()
 
 
-@pytest.mark.parametrize("cands", [1, 4, 8])
+@pytest.mark.parametrize("cands", [1, 4, 8, 16])
 @pytest.mark.parametrize("chain", [1, 0])
 def test_candidates_per_pass_do_not_change_results(ocl, cands, chain):
     """multi-candidate rounds are the same algorithm: identical centers,

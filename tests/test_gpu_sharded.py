@@ -152,14 +152,14 @@ def ar(t, op=dist.ReduceOp.SUM, group=None):
 dist.all_gather_into_tensor, dist.all_reduce = agit, ar
 from enspara_amd import sharded, synth
 from enspara_amd.device import FrameStore
-n, A, K, tmpl, iters, form = [int(v) for v in sys.argv[6:12]]
+n, A, K, tmpl, iters, cands = [int(v) for v in sys.argv[6:12]]
 x = synth.synth(n, A, tmpl, seed=21)
 lo, cnt = sharded.shard_bounds(n, world, rank)
 torch.cuda.set_device(0)
 ts = torch.cuda.Stream(device=0)
 with FrameStore(cnt, A, device=0, global_offset=lo, stream=ts.cuda_stream) as st:
     st.load(x[lo:lo + cnt])
-    st.set_option(9, form)
+    st.set_option(4, cands)
     st.reset_state()
     sh = sharded.DeviceShard(st)
     with torch.cuda.stream(ts):
@@ -171,15 +171,14 @@ dist.destroy_process_group()
 """
 
 
-@pytest.mark.parametrize("n,A,K,tmpl,iters,form", [
-    (6000, 14, 45, 9, 2, 1),
-    # the shape of BASELINE.json configs[3] as far as one GPU allows: 500 atoms
-    # (the LDS form's candidate tile is 8 x 6000 B = 48 000 B, right at the
-    # 48 KiB boundary), two shards, ~200 centers -- both pass-kernel forms
-    (40000, 500, 200, 300, 0, 1),
-    (40000, 500, 200, 300, 0, 0),
+@pytest.mark.parametrize("n,A,K,tmpl,iters,cands", [
+    (6000, 14, 45, 9, 2, 8),
+    # the shape of BASELINE.json configs[3] as far as one GPU allows: 500 atoms,
+    # two shards, ~200 centers -- rounds of 16 and of 8 candidates
+    (40000, 500, 200, 300, 0, 16),
+    (40000, 500, 200, 300, 0, 8),
 ])
-def test_two_device_shards_on_one_gpu(tmp_path, n, A, K, tmpl, iters, form):
+def test_two_device_shards_on_one_gpu(tmp_path, n, A, K, tmpl, iters, cands):
     import socket
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -188,7 +187,7 @@ def test_two_device_shards_on_one_gpu(tmp_path, n, A, K, tmpl, iters, form):
     out = str(tmp_path / "r")
     procs = [subprocess.Popen([sys.executable, "-c", _CHILD2, ROOT, str(r), "2",
                                port, out, str(n), str(A), str(K), str(tmpl),
-                               str(iters), str(form)], stdout=subprocess.PIPE,
+                               str(iters), str(cands)], stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT, text=True)
              for r in range(2)]
     logs = [p.communicate(timeout=900)[0] for p in procs]

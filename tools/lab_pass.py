@@ -4,8 +4,8 @@
 
 For every library given (default: the in-tree build) a child process loads the
 same frames and times a k-centers run of K centers for each combination of
-  form   0 = candidates through LDS, 1 = candidates as scalar operands
-  adapt  0 = always 8 candidates per pass, 1 = 1/4/8 by measured rate
+  form   (ignored: round 1's LDS form of the pass kernel is retired)
+  adapt  0 = always the pinned / widest form, 1 = 1/8/16 by measured rate
 (LAB_CONFIGS="form,adapt,cands[,fused];..." picks the combinations) printing seconds per run, the mean pass-kernel time (HIP events), the passes
 by candidates per pass, and a checksum of centers + final state (all
 combinations must agree: the forms are bit-identical by construction).
@@ -30,13 +30,12 @@ def child(path, K):
     sums = set()
     configs = os.environ.get("LAB_CONFIGS")
     configs = ([tuple(int(v) for v in c.split(",")) for c in configs.split(";")]
-               if configs else [(0, 0, -1), (1, 0, -1), (1, 1, -1), (0, 1, -1),
-                                (1, 0, 4), (0, 0, 4), (1, 0, 1)])
+               if configs else [(1, 0, 8), (1, 0, 16), (1, 1, -1), (1, 0, 4),
+                                (1, 0, 1)])
     for cfg in configs:
         form, adapt, cands = cfg[:3]
         fused = cfg[3] if len(cfg) > 3 else 1
         st.set_option(10, fused)
-        st.set_option(9, form)
         st.set_option(8, adapt)
         st.set_option(4, cands)
         best = None
