@@ -31,6 +31,8 @@ SYMBOLS = [
     "ek_spec_apply", "ek_spec_round_end", "ek_spec_progress", "ek_spec_rounds",
     "ek_spec_chain_bytes", "ek_spec_chain_rows", "ek_spec_chain_max",
     "ek_spec_chain_apply", "ek_run_stats", "ek_ti_stats",
+    "ek_ms_setup", "ek_ms_mailbox", "ek_ms_connect", "ek_ms_begin", "ek_ms_local",
+    "ek_ms_global", "ek_ms_end", "ek_ms_run", "ek_ms_state",
     "ek_assign_nearest",
     "ek_pam_begin", "ek_pam_count_members", "ek_pam_select_member",
     "ek_pam_propose", "ek_pam_propose_member", "ek_pam_commit",
@@ -120,6 +122,15 @@ def load():
     L.ek_spec_progress.argtypes = [vp, i32p, i32p]
     L.ek_spec_rounds.argtypes = [vp, i32p]
     L.ek_run_stats.argtypes = [vp, i64p, i64p]
+    L.ek_ms_setup.argtypes = [vp, i32, i32, C.POINTER(C.c_size_t)]
+    L.ek_ms_mailbox.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), vp, vp]
+    L.ek_ms_connect.argtypes = [vp, i32, vp, vp, vp, vp]
+    L.ek_ms_begin.argtypes = [vp, i32, i32]
+    L.ek_ms_local.argtypes = [vp, C.c_double, vp]
+    L.ek_ms_global.argtypes = [vp, C.c_double, vp]
+    L.ek_ms_end.argtypes = [vp]
+    L.ek_ms_state.argtypes = [vp, i32p, i32p, i32p]
+    L.ek_ms_run.argtypes = [vp, i32, i32, C.c_double, i32p, i64p, f32p, f32p]
     L.ek_ti_stats.argtypes = [vp, i64p, i64p]
     L.ek_assign_nearest.argtypes = [vp, f32p, i32]
     f64p = C.POINTER(C.c_double)

@@ -154,6 +154,51 @@ void ek_launch_round_next(const EkRound &r, int bootstrap, hipStream_t s);
 // apply what is pending (end of a run, or before leaving the fused form)
 void ek_launch_round_flush(const EkRound &r, hipStream_t s);
 
+// ---- rounds across shards (ek_mshard.hip) ------------------------------------------
+// One exchange per round: every shard's MESSAGE = the (max distance, global
+// index) of its frames in the state every prefix of the round's chain would
+// leave + its `offer` farthest frames of the state the whole chain would leave
+// (records).  EkMsMsg | EkMaxHdr[EK_MAX_CANDS] | offer records.
+#define EK_MS_MAX_WORLD 64
+struct EkMsMsg {
+    int32_t n_recs;         // valid records offered
+    int32_t cn;             // states with a header
+    int32_t pad[2];
+};
+static inline __host__ __device__ size_t ek_ms_msg_bytes(int A, int offer)
+{
+    return sizeof(EkMsMsg) + EK_MAX_CANDS * sizeof(EkMaxHdr) +
+           (size_t)offer * ek_rec_bytes(A);
+}
+// device-side state of the rounds (one per context)
+struct EkMsState {
+    int32_t mode;           // 0 the run is over, 1 the pass runs, 2 no pass: offer
+                            // records of state `pick_state` (the chain broke there)
+    int32_t pick_state;
+    uint32_t seq;           // exchanges completed (mailbox sequence number)
+    int32_t err;            // a peer's message did not arrive
+    uint32_t err_seq;       // ... in this exchange
+};
+// where a round's messages go and come from
+struct EkMsXchg {
+    int32_t world = 1, rank = 0, offer = 0;
+    int32_t sys = 0;        // 1: peer mailboxes (system-scope stores / loads, flags);
+                            // 0: dst[0] is a local buffer, src the gathered messages
+    size_t msg_bytes = 0;
+    unsigned char *dst[EK_MS_MAX_WORLD] = {};   // peer p's mailbox area [2][world][msg]
+    uint32_t *dflag[EK_MS_MAX_WORLD] = {};      // peer p's flags [2][world][16]
+    const unsigned char *src = nullptr;         // own mailbox area / gathered messages
+    const uint32_t *sflag = nullptr;            // own flags
+};
+// chain: per-prefix maxima (presumed order = pick order), this shard's headers,
+// its farthest frames of the speculated state, the message out
+void ek_launch_ms_chain(const EkRound &r, EkMsState *ms, const EkMsXchg &x,
+                        hipStream_t s);
+// plan: all shards' messages in -> decide the chain, choose the next round's
+// candidates (or ask for the records of the state the chain broke at)
+void ek_launch_ms_plan(const EkRound &r, EkMsState *ms, const EkMsXchg &x, float *D,
+                       hipStream_t s);
+
 // ---- kernel launchers (defined in the .hip files) ---------------------------
 // centring + trace + frame-minor transposition of `count` AoS frames
 // aos_copy (optional): the centred coordinates once more, frame-major [n][3A]

@@ -1,0 +1,748 @@
+// ek_mshard.hip -- a k-centers round ACROSS SHARDS in three launches and one
+// exchange.
+//
+// The reference's MPI iteration (enspara/cluster/kcenters.py:314-378) moves, per
+// center, two pickled allgathers (:332-335), the owner's frame (mpi/ops.py:
+// 169-212) and an allreduce for the stop test (mpi/ops.py:128-140).  Here a ROUND
+// of up to 16 candidates (ek_spec.hip, ek_pass16.hip) accepts ~15 centers and
+// moves one message per shard:
+//
+//   pass    every shard streams its frames against the round's candidates
+//           (the same candidates on every shard: the plan below is computed
+//           from the same messages by the same code), applies the chain the
+//           previous round accepted on the way in, candidate 0, and keeps the
+//           guesses' distances (ek_pass2_kernel / ek_pass16_kernel, FUSE).
+//   chain   per-256-frame maxima of the states every prefix of the presumed
+//           order would leave; last workgroup: this shard's (max distance,
+//           global index) per prefix -- what the decision needs (kcenters.py:337:
+//           the largest, lowest rank = lowest global index on ties) -- and,
+//           SPECULATING that the whole chain will be accepted, its farthest
+//           frames of the state that leaves (ek_pick_top_body: label-diverse),
+//           as records.  That is the message; it goes out from here.
+//   plan    all messages in.  Every workgroup: pairwise distances of the
+//           records on offer (they steer the choice of guesses only).  Last
+//           workgroup: the decision (ek_chain_walk on the global maxima: the
+//           k-th candidate is accepted iff the farthest point of the state
+//           before it is its frame), then -- if the whole chain was accepted --
+//           the next round's candidates (greedy, as ek_round_next_kernel),
+//           their tile, the plan.  If the chain broke at prefix k < n the
+//           offers describe a state that never came to be: the next round runs
+//           no pass, the chain kernel offers the records of state k instead
+//           (the per-prefix maxima are still there), and the plan after that
+//           is made from those.  ~5 % of the rounds.
+//
+// The presumed order is the order in which the greedy choice took the
+// candidates (it IS the simulation ek_chain_simulate runs, on the offered
+// distances); being a guess, it needs no exchange of its own: a wrong guess
+// costs acceptance, never correctness.
+//
+// Transport.  `sys = 0`: the chain kernel leaves the message in a local buffer,
+// the caller all-gathers (torch.distributed: RCCL, or gloo in the CPU tests of
+// the host restatement), the plan kernel reads the gathered buffer.  `sys = 1`:
+// per-peer mailboxes -- the chain kernel's last workgroup writes the message
+// straight into every peer's memory (system-scope write-through stores over
+// xGMI; hipIpc mappings, or plain pointers between contexts of one process),
+// waits for its stores, and raises a sequence flag per peer; the plan kernel
+// polls its own flags.  No host, no collective launch in a round: SURVEY.md
+// section 8(e) "Fabric note".  Two mailbox sets alternate by round parity: a
+// shard can only be one exchange ahead of a peer (it needs that peer's next
+// message to go on).
+#include "ek_common.h"
+#include "ek_qcp.h"
+#include "ek_reduce.h"
+#include "ek_chain_dev.h"
+#include "ek_top_dev.h"
+
+#define EK_MS_THREADS 1024
+#define EK_MS_FPT 4
+// polls of a flag (with s_sleep between) before a shard gives up on a peer:
+// ~0.25 s; a missing peer then shows as EkMsState::err (and ends the run: every
+// later launch is a no-op) instead of a hung GPU
+#ifndef EK_MS_SPIN_LIMIT
+#define EK_MS_SPIN_LIMIT (1 << 20)
+#endif
+
+// ---- system-scope accesses (mailbox transport) ---------------------------------
+__device__ __forceinline__ void ek_sys_store(uint32_t *p, uint32_t v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ uint32_t ek_sys_load(const uint32_t *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+typedef float ek_f4 __attribute__((ext_vector_type(4)));
+// 16 bytes at system scope (write-through / past the caches); the loads of a
+// batch are issued together and waited for once
+__device__ __forceinline__ void ek_sys_store4(void *p, ek_f4 v)
+{
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+template <bool SYS, int N>
+__device__ __forceinline__ void ek_msg_load4(const void *const (&p)[N], ek_f4 (&v)[N])
+{
+    if (SYS) {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1"
+                         : "=v"(v[i]) : "v"(p[i]) : "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < N; ++i)     // (the values are there only after the wait)
+            asm volatile("" : "+v"(v[i]));
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            v[i] = *(const ek_f4 *)p[i];
+    }
+}
+template <bool SYS>
+__device__ __forceinline__ uint32_t ek_msg_load(const uint32_t *p)
+{
+    return SYS ? ek_sys_load(p) : *p;
+}
+template <bool SYS>
+__device__ __forceinline__ float ek_msg_loadf(const float *p)
+{
+    return __uint_as_float(ek_msg_load<SYS>((const uint32_t *)p));
+}
+
+// shard `rk`'s message of the exchange with sequence number `seq`
+__device__ __forceinline__ const unsigned char *ek_ms_src(const EkMsXchg &x, int rk,
+                                                          uint32_t seq)
+{
+    const size_t slot = x.sys ? (size_t)(seq & 1u) * x.world + rk : (size_t)rk;
+    return x.src + slot * x.msg_bytes;
+}
+
+// ---------------------------------------------------------------------------
+// chain: per-prefix maxima, this shard's headers and offers, the message out
+// ---------------------------------------------------------------------------
+// Helper workgroups: writing up to 64 records of 12 A bytes to up to 8 peers is
+// 230 KB of stores -- 45 us from the one workgroup that knows which frames they
+// are.  EK_MS_HELPERS extra workgroups at the END of the grid wait for that
+// workgroup's list and share the records.  (They are dispatched after the
+// workgroups they wait for, which in turn wait for nobody: no residency
+// assumption.)
+#define EK_MS_HELPERS 16
+struct EkMsPub {            // the list, published for the helpers (in r.top + 1024)
+    int32_t n_off;
+    int32_t pad[3];
+    uint32_t idx[EK_TOP_M];
+    float val[EK_TOP_M];
+};
+
+__global__ void __launch_bounds__(EK_MS_THREADS)
+ek_ms_chain_kernel(EkRound r, EkMsState *ms, EkMsXchg x, int nblk)
+{
+    __shared__ float sv[EK_MAX_CANDS];
+    __shared__ uint32_t si[EK_MAX_CANDS];
+    __shared__ uint32_t t_idx[EK_TOP_M];
+    __shared__ float t_val[EK_TOP_M];
+    __shared__ int t_n;
+    extern __shared__ uint32_t skip[];      // pick fallback for very large shards
+    const int mode = ms->mode;              // (written by the launch before)
+    if (mode == 0)
+        return;                             // the run is over
+    const int tid = threadIdx.x;
+    const uint32_t seq = ms->seq;
+    const int n_dst = x.sys ? x.world : 1;
+    const size_t slot = x.sys ? (size_t)(seq & 1u) * x.world + x.rank : 0;
+    const size_t head_bytes = sizeof(EkMsMsg) + EK_MAX_CANDS * sizeof(EkMaxHdr);
+    EkMsPub *pub = (EkMsPub *)(r.top + 1024);
+    if ((int)blockIdx.x >= nblk) {
+        // ---- a helper: records h, h + H, .. of the list, to every destination ----------
+        const int h = (int)blockIdx.x - nblk;
+        __shared__ int s_ok;
+        if (tid == 0) {
+            int spins = 0;
+            s_ok = 1;
+            while (__hip_atomic_load(r.tick + 5, __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT) != seq + 1u) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > EK_MS_SPIN_LIMIT) {
+                    s_ok = 0;
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < EK_TOP_M) {
+            t_idx[tid] = (uint32_t)ek_coh_load((const int32_t *)&pub->idx[tid]);
+            t_val[tid] = ek_coh_load(&pub->val[tid]);
+        }
+        if (tid == 0)
+            t_n = s_ok ? ek_coh_load(&pub->n_off) : 0;
+        __syncthreads();
+        const int n_off = t_n;
+        const int A3 = 3 * r.A;
+        const int cpr = (int)(ek_rec_bytes(r.A) / 16);      // 16-byte chunks per record
+        for (int j = h; j < n_off; j += EK_MS_HELPERS) {
+            const uint32_t fi = t_idx[j];
+            const float *src = r.aos + (size_t)fi * A3;
+            for (int item = tid; item < n_dst * cpr; item += EK_MS_THREADS) {
+                const int p = item / cpr, q = item % cpr;
+                ek_f4 v;
+                if (q == 0) {
+                    const long long g = r.goff + (long long)fi;
+                    v[0] = t_val[j];
+                    v[1] = __uint_as_float(1u);
+                    v[2] = __uint_as_float((uint32_t)((unsigned long long)g & 0xffffffffu));
+                    v[3] = __uint_as_float((uint32_t)((unsigned long long)g >> 32));
+                } else if (q == 1) {
+                    const unsigned long long tr = __double_as_longlong(r.G[fi]);
+                    v[0] = __uint_as_float((uint32_t)(tr & 0xffffffffu));
+                    v[1] = __uint_as_float((uint32_t)(tr >> 32));
+                    v[2] = 0.f;
+                    v[3] = 0.f;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int w = 4 * (q - 2) + e;
+                        v[e] = w < A3 ? src[w] : 0.f;
+                    }
+                }
+                unsigned char *d = x.dst[p] + slot * x.msg_bytes + head_bytes +
+                                   (size_t)j * ek_rec_bytes(r.A) + (size_t)q * 16;
+                if (x.sys)
+                    ek_sys_store4(d, v);
+                else
+                    *(ek_f4 *)d = v;
+            }
+        }
+        // this helper's stores acknowledged; the one that finishes last tells the peers
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        __shared__ int s_last;
+        if (tid == 0) {
+            s_last = __hip_atomic_fetch_add(r.tick + 6, 1u, __ATOMIC_RELAXED,
+                                            __HIP_MEMORY_SCOPE_AGENT) ==
+                     EK_MS_HELPERS - 1;
+            if (s_last)
+                r.tick[6] = 0;
+            if (!s_ok && !ms->err) {        // the list of this shard's own records
+                ms->err = 2;
+                ms->err_seq = seq;
+            }
+        }
+        __syncthreads();
+        if (s_last && x.sys && tid < x.world) {
+            ek_sys_store(x.dflag[tid] + (slot * 16), seq + 1u);
+            // ... and this launch ends when every peer's message of this exchange
+            // is in: ONE workgroup waits, not the thousand of the plan kernel
+            // that needs them -- a kernel that fills the chip while it polls
+            // starves whatever else shares the GPU (another shard's launches, in
+            // the tests: that is a deadlock until the time-out)
+            const uint32_t *f = x.sflag + ((size_t)(seq & 1u) * x.world + tid) * 16;
+            int spins = 0;
+            while (ek_sys_load(f) != seq + 1u) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > EK_MS_SPIN_LIMIT) {
+                    if (!ms->err) {         // peer `tid`'s message did not arrive
+                        ms->err = 0x100 + tid;
+                        ms->err_seq = seq;
+                    }
+                    break;
+                }
+            }
+        }
+        return;
+    }
+    const int nb = (int)((r.n + EK_BLOCK - 1) / EK_BLOCK);
+    const int cn = mode == 1 ? r.ord->n : 0;
+    if (cn > 0) {
+        // pm[(k - 1) * nb + w] = first-index arg-max over frames [256 w, 256 w + 256)
+        // of min(dist, vec[order[0]], .., vec[order[k-1]]), k = 1 .. cn (state 0
+        // is what the pass left in blockmax): as ek_round_chain_kernel
+        const int64_t f0 = ((int64_t)blockIdx.x * EK_MS_THREADS + tid) * EK_MS_FPT;
+        const bool whole = f0 + EK_MS_FPT <= r.n;
+        float run[EK_MS_FPT];
+        float dv[EK_MAX_CANDS][EK_MS_FPT];
+        const uint32_t vm = f0 < r.n ? r.vmask[f0 >> 6] : 0u;
+#pragma unroll
+        for (int k = 1; k < EK_MAX_CANDS; ++k) {
+#pragma unroll
+            for (int q = 0; q < EK_MS_FPT; ++q)
+                dv[k][q] = __builtin_inff();
+            if (k <= cn && ((vm >> r.ord->cand[k - 1]) & 1u)) {
+                const float *v = r.vecs + (size_t)(r.ord->cand[k - 1] - 1) * r.n_pad + f0;
+                if (whole) {
+                    const float4 t = *(const float4 *)v;
+                    dv[k][0] = t.x; dv[k][1] = t.y; dv[k][2] = t.z; dv[k][3] = t.w;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < EK_MS_FPT; ++q)
+                        if (f0 + q < r.n)
+                            dv[k][q] = v[q];
+                }
+            }
+        }
+        if (whole) {
+            const float4 t = *(const float4 *)(r.dist + f0);
+            run[0] = t.x; run[1] = t.y; run[2] = t.z; run[3] = t.w;
+        } else {
+#pragma unroll
+            for (int q = 0; q < EK_MS_FPT; ++q)
+                run[q] = (f0 + q < r.n) ? r.dist[f0 + q] : 0.f;
+        }
+        const int64_t wg = ((int64_t)blockIdx.x * EK_MS_THREADS + tid) / EK_WAVE;
+#pragma unroll
+        for (int k = 1; k < EK_MAX_CANDS; ++k) {
+            if (k <= cn) {                  // uniform
+                float v = -__builtin_inff();
+                uint32_t i = 0xffffffffu;
+#pragma unroll
+                for (int q = 0; q < EK_MS_FPT; ++q) {
+                    if (f0 + q < r.n) {
+                        if (dv[k][q] < run[q])      // kcenters.py:304
+                            run[q] = dv[k][q];
+                        if (ek_better(run[q], (uint32_t)(f0 + q), v, i)) {
+                            v = run[q];
+                            i = (uint32_t)(f0 + q);
+                        }
+                    }
+                }
+                ek_wave_argmax(v, i);
+                if ((tid & (EK_WAVE - 1)) == 0 && wg < nb)
+                    ek_coh_store_bm(&r.pm[(size_t)(k - 1) * nb + wg], v, i);
+            }
+        }
+    }
+    if (!ek_arrive_last(r.tick + 1, (unsigned int)nblk))
+        return;
+    // ---- the last workgroup ---------------------------------------------------------
+    // this shard's maximum of states 0 .. cn - 1 (what the decision looks at)
+    if (cn > 0)
+        ek_chain_reduce<true>(r.blockmax, r.pm, nb, nb, cn, sv, si);
+    __syncthreads();
+    // its farthest frames of the state the offers are for: the one the whole
+    // chain would leave, or (the chain broke) the one it did leave
+    const int ps = mode == 1 ? cn : ms->pick_state;
+    const EkBlockMax *state = ps == 0 ? r.blockmax : r.pm + (size_t)(ps - 1) * nb;
+    EkTop *top = (EkTop *)r.top;
+    ek_pick_top_body<true>(state, nb, top, skip, r.assign);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // the list for the helpers, and the head of the message: this workgroup's part
+    if (tid < EK_TOP_M) {
+        ek_coh_store((int32_t *)&pub->idx[tid], (int32_t)top->idx[tid]);
+        ek_coh_store(&pub->val[tid], top->val[tid]);
+    }
+    const int n_off = top->n < x.offer ? top->n : x.offer;
+    if (tid == 0)
+        ek_coh_store(&pub->n_off, (int32_t)n_off);
+    const int head_words = (int)(head_bytes / 4);
+    for (int item = tid; item < n_dst * head_words; item += EK_MS_THREADS) {
+        const int p = item / head_words, w = item % head_words;
+        uint32_t val = 0;
+        if (w < (int)(sizeof(EkMsMsg) / 4)) {
+            val = w == 0 ? (uint32_t)n_off : (w == 1 ? (uint32_t)cn : 0u);
+        } else {
+            const int k = (w - (int)(sizeof(EkMsMsg) / 4)) / 4;
+            const int u = (w - (int)(sizeof(EkMsMsg) / 4)) % 4;
+            const bool ok = k < cn && si[k] != 0xffffffffu;
+            const long long g = ok ? r.goff + (long long)si[k] : -1;
+            val = u == 0 ? __float_as_uint(ok ? sv[k] : -__builtin_inff())
+                : u == 1 ? (ok ? 1u : 0u)
+                : u == 2 ? (uint32_t)((unsigned long long)g & 0xffffffffu)
+                         : (uint32_t)((unsigned long long)g >> 32);
+        }
+        uint32_t *d = (uint32_t *)(x.dst[p] + slot * x.msg_bytes) + w;
+        if (x.sys)
+            ek_sys_store(d, val);
+        else
+            *d = val;
+    }
+    // all of that in place, then the helpers may go
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        r.tick[1] = 0;
+        __hip_atomic_store(r.tick + 5, seq + 1u, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+void ek_launch_ms_chain(const EkRound &r, EkMsState *ms, const EkMsXchg &x,
+                        hipStream_t s)
+{
+    const int64_t per = (int64_t)EK_MS_THREADS * EK_MS_FPT;
+    const unsigned blocks = (unsigned)std::max<int64_t>(1, (r.n + per - 1) / per);
+    const int nb = (int)((r.n + EK_BLOCK - 1) / EK_BLOCK);
+    const size_t lds = (size_t)((nb + 31) / 32 + 1) * sizeof(uint32_t);
+    hipLaunchKernelGGL(ek_ms_chain_kernel, dim3(blocks + EK_MS_HELPERS),
+                       dim3(EK_MS_THREADS), lds, s, r, ms, x, (int)blocks);
+}
+
+// ---------------------------------------------------------------------------
+// plan: all shards' messages -> the decision, the next round's candidates
+// ---------------------------------------------------------------------------
+// record slot s = shard s / offer, its (s % offer)-th offer
+template <bool SYS>
+__device__ __forceinline__ const uint32_t *ek_ms_rec(const EkMsXchg &x, int slot,
+                                                     uint32_t seq, int A)
+{
+    const unsigned char *m = ek_ms_src(x, slot / x.offer, seq);
+    return (const uint32_t *)(m + sizeof(EkMsMsg) + EK_MAX_CANDS * sizeof(EkMaxHdr) +
+                              (size_t)(slot % x.offer) * ek_rec_bytes(A));
+}
+
+template <int T, bool SYS>
+__global__ void __launch_bounds__(EK_BLOCK)
+ek_ms_plan_kernel(EkRound r, EkMsState *ms, EkMsXchg x, float *D)
+{
+    const int mode = ms->mode;
+    if (mode == 0)
+        return;
+    const int tid = threadIdx.x;
+    const uint32_t seq = ms->seq;
+    const int A = r.A;
+    __shared__ int s_nrec[EK_MS_MAX_WORLD];
+    // (mailbox transport: the chain kernel did not end before every peer's
+    // message of this exchange was in)
+    if (tid < x.world)
+        s_nrec[tid] = 0;
+    __syncthreads();
+    if (tid < x.world)
+        s_nrec[tid] = (int)ek_msg_load<SYS>((const uint32_t *)ek_ms_src(x, tid, seq));
+    __syncthreads();
+    const int n_slots = x.world * x.offer;      // <= 64
+    {
+        // one wave per pair of records on offer; the values only steer the guesses,
+        // so the lanes may stride over the atoms (but every shard computes the
+        // same values from the same messages, and so the same plan)
+        const int lane = tid & (EK_WAVE - 1);
+        const int w = blockIdx.x * (EK_BLOCK / EK_WAVE) + tid / EK_WAVE;
+        const int i = w / 64, j = w % 64;
+        if (i < j && j < n_slots && i % x.offer < s_nrec[i / x.offer] &&
+            j % x.offer < s_nrec[j / x.offer]) {
+            const uint32_t *ri = ek_ms_rec<SYS>(x, i, seq, A);
+            const uint32_t *rj = ek_ms_rec<SYS>(x, j, seq, A);
+            const unsigned char *bi = (const unsigned char *)(ri + 8);
+            const unsigned char *bj = (const unsigned char *)(rj + 8);
+            const int cpr_c = (3 * A + 3) / 4;      // 16-byte chunks of coordinates
+            float S[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            // a lane takes 4 atoms = three chunks of either record at a time
+            for (int a0 = 4 * lane; a0 < A; a0 += 4 * EK_WAVE) {
+                const void *p[6];
+                ek_f4 v[6];
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const int c = min(3 * (a0 / 4) + u, cpr_c - 1);
+                    p[u] = bi + 16 * c;
+                    p[3 + u] = bj + 16 * c;
+                }
+                ek_msg_load4<SYS, 6>(p, v);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (a0 + e < A) {
+                        const float x0 = v[(3 * e) / 4][(3 * e) % 4],
+                                    x1 = v[(3 * e + 1) / 4][(3 * e + 1) % 4],
+                                    x2 = v[(3 * e + 2) / 4][(3 * e + 2) % 4];
+                        const float y0 = v[3 + (3 * e) / 4][(3 * e) % 4],
+                                    y1 = v[3 + (3 * e + 1) / 4][(3 * e + 1) % 4],
+                                    y2 = v[3 + (3 * e + 2) / 4][(3 * e + 2) % 4];
+                        S[0] += x0 * y0; S[1] += x0 * y1; S[2] += x0 * y2;
+                        S[3] += x1 * y0; S[4] += x1 * y1; S[5] += x1 * y2;
+                        S[6] += x2 * y0; S[7] += x2 * y1; S[8] += x2 * y2;
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 9; ++q)
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1)
+                    S[q] += __shfl_xor(S[q], off, 64);
+            if (lane == 0) {
+                const unsigned long long ti =
+                    (unsigned long long)ek_msg_load<SYS>(ri + 4) |
+                    ((unsigned long long)ek_msg_load<SYS>(ri + 5) << 32);
+                const unsigned long long tj =
+                    (unsigned long long)ek_msg_load<SYS>(rj + 4) |
+                    ((unsigned long long)ek_msg_load<SYS>(rj + 5) << 32);
+                const float d = ek_rmsd_from_S(S, __longlong_as_double((long long)ti),
+                                               __longlong_as_double((long long)tj), A);
+                ek_coh_store(&D[i * 64 + j], d);
+                ek_coh_store(&D[j * 64 + i], d);
+            }
+        }
+    }
+    if (!ek_arrive_last_tree(r.tick + 2, r.tick + 64))
+        return;
+    // ---- the last workgroup ---------------------------------------------------------
+    __shared__ float sD[64 * 64];
+    __shared__ float sval[64];
+    __shared__ long long sgidx[64];
+    __shared__ int sel[EK_MAX_CANDS];
+    __shared__ int n_sel;
+    __shared__ float gv[EK_MAX_CANDS];          // global maximum of state k
+    __shared__ long long gg[EK_MAX_CANDS];
+    __shared__ int gok[EK_MAX_CANDS];
+    __shared__ int s_over, s_repick, s_short;
+    {
+        constexpr int PER = 64 * 64 / EK_BLOCK;
+        float dreg[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u)
+            dreg[u] = ek_coh_load(&D[tid + u * EK_BLOCK]);
+#pragma unroll
+        for (int u = 0; u < PER; ++u)
+            sD[tid + u * EK_BLOCK] = dreg[u];
+    }
+    if (tid < 64) {
+        float v = -__builtin_inff();
+        long long g = -1;
+        if (tid < n_slots && tid % x.offer < s_nrec[tid / x.offer]) {
+            const uint32_t *rr = ek_ms_rec<SYS>(x, tid, seq, A);
+            v = __uint_as_float(ek_msg_load<SYS>(rr));
+            g = (long long)((unsigned long long)ek_msg_load<SYS>(rr + 2) |
+                            ((unsigned long long)ek_msg_load<SYS>(rr + 3) << 32));
+        }
+        sval[tid] = v;
+        sgidx[tid] = g;
+    }
+    const int cn = mode == 1 ? r.ord->n : 0;
+    if (tid < EK_MAX_CANDS) {
+        // state k's maximum over the shards: the largest, the lowest global
+        // index on ties (kcenters.py:337)
+        sel[tid] = 0;
+        bool ok = false;
+        float v = 0.f;
+        long long g = 0;
+        if (tid < cn) {
+            for (int rk = 0; rk < x.world; ++rk) {
+                const uint32_t *h = (const uint32_t *)(ek_ms_src(x, rk, seq) +
+                                                       sizeof(EkMsMsg)) + 4 * tid;
+                if (!ek_msg_load<SYS>(h + 1))
+                    continue;
+                const float hv = __uint_as_float(ek_msg_load<SYS>(h));
+                const long long hg =
+                    (long long)((unsigned long long)ek_msg_load<SYS>(h + 2) |
+                                ((unsigned long long)ek_msg_load<SYS>(h + 3) << 32));
+                if (!ok || hv > v || (hv == v && hg < g)) {
+                    ok = true;
+                    v = hv;
+                    g = hg;
+                }
+            }
+        }
+        gv[tid] = v;
+        gg[tid] = g;
+        gok[tid] = ok ? 1 : 0;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        // the decision: ek_chain_walk / ek_round_chain_kernel on the global maxima
+        EkCtl c = *r.ctl;
+        if (mode == 1) {
+            // candidate 0 of the pass that has just run is a center now
+            // (kcenters.py:306-309): the count and the history move when its
+            // distances are in, not when it was planned -- the host stops
+            // enqueuing rounds when the count reaches its goal
+            const int l0 = r.plan->label;
+            r.hist[l0].gidx = r.plan->gidx[0];
+            r.hist[l0].dist = r.plan->maxdist[0];
+            r.hist[l0].set = 1;
+            c.n_done = l0 + 1;
+            c.n_rounds = c.n_rounds + 1;
+        }
+        const int label0 = c.n_done;
+        uint32_t used = r.plan->used;
+        int na = 0;
+        for (int k = 0; k < cn; ++k) {
+            if (c.stopped || c.n_done >= c.limit || !gok[k])
+                break;
+            c.last_max = gv[k];
+            if (!((double)gv[k] > r.cutoff)) {      // kcenters.py:217
+                c.stopped = 1;
+                break;
+            }
+            const int j = r.ord->cand[k];
+            if (gg[k] != r.plan->gidx[j])           // the farthest point is not stored
+                break;
+            const int label = c.n_done;
+            r.hist[label].gidx = gg[k];
+            r.hist[label].dist = gv[k];
+            r.hist[label].set = 1;
+            c.n_done = label + 1;
+            used |= 1u << j;
+            r.pend->slot[na] = j - 1;
+            ++na;
+        }
+        // distances.max() after the last update (kcenters.py:226), if the chain
+        // ended early: the maximum of the state it left
+        if (na < cn && gok[na])
+            c.last_max = gv[na];
+        s_short = na < cn ? 1 : 0;
+        if (mode == 1) {
+            r.plan->used = used;
+            r.plan->napply = na;
+            r.plan->chain_label0 = label0;
+            r.pend->n = na;
+            r.pend->label0 = label0;
+        }
+        r.ctl->n_done = c.n_done;
+        r.ctl->n_rounds = c.n_rounds;
+        r.ctl->stopped = c.stopped;
+        r.ctl->last_max = c.last_max;
+        // (a message that never came: the run ends here, on every later launch too)
+        s_over = (c.stopped || c.n_done >= c.limit || ms->err) ? 1 : 0;
+        s_repick = (!s_over && mode == 1 && na < cn) ? 1 : 0;
+        if (s_repick)
+            ms->pick_state = na;
+    }
+    __syncthreads();
+    const bool over = s_over != 0, repick = s_repick != 0;
+    // ---- the next round's candidates among the records on offer ----------------------
+    // (greedy, as ek_round_next_kernel: the record with the largest remaining
+    // distance, then every other one's is lowered by its distance to it; slot order
+    // = (shard, local rank) breaks ties like the lowest global index does)
+    if (tid < EK_WAVE) {
+        const int lane = tid;
+        bool open = !repick && sgidx[lane] >= 0;
+        float cur = open ? sval[lane] : 0.f;
+        int ns = 0;
+        while (ns < T) {
+            float v = open ? cur : -__builtin_inff();
+            uint32_t i = open ? (uint32_t)lane : 0xffffffffu;
+            ek_wave_argmax(v, i);
+            if (i == 0xffffffffu)
+                break;
+            const int best = (int)i;
+            if (lane == best)
+                open = false;
+            if (lane == 0)
+                sel[ns] = best;
+            ++ns;
+            const float d = sD[best * 64 + lane];
+            if (open && d < cur)
+                cur = d;
+        }
+        if (lane == 0)
+            n_sel = ns;
+    }
+    __syncthreads();
+    const int ns = n_sel;
+    const float first_max = ns > 0 ? sval[sel[0]] : -__builtin_inff();
+    const bool go = !over && !repick && ns > 0 && (double)first_max > r.cutoff;
+    const size_t rstride = ek_rec_bytes(A);
+    // the chosen records (kept for the other entry points: [0] = the farthest
+    // point of the state) and the candidate tile of the next pass
+    if (!repick) {
+        const int A3 = 3 * A;
+        for (int e = tid; e < T * 8; e += EK_BLOCK) {
+            const int c = e / 8, u = e % 8;
+            uint32_t *h = (uint32_t *)(r.recs + (size_t)c * rstride);
+            if (c < ns)
+                h[u] = ek_msg_load<SYS>(ek_ms_rec<SYS>(x, sel[c], seq, A) + u);
+            else
+                h[u] = u == 0 ? __float_as_uint(-__builtin_inff())
+                              : ((u == 2 || u == 3) ? 0xffffffffu : 0u);
+        }
+        const int cpr_c = (A3 + 3) / 4;         // 16-byte chunks of coordinates
+        for (int e0 = tid; e0 < T * cpr_c; e0 += 4 * EK_BLOCK) {
+            const void *p[4];
+            ek_f4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = min(e0 + u * EK_BLOCK, T * cpr_c - 1);
+                const int c = e / cpr_c, q = e % cpr_c;
+                p[u] = (const unsigned char *)(ek_ms_rec<SYS>(x, sel[c < ns ? c : 0],
+                                                              seq, A) + 8) + 16 * q;
+            }
+            ek_msg_load4<SYS, 4>(p, v);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + u * EK_BLOCK;
+                if (e >= T * cpr_c)
+                    continue;
+                const int c = e / cpr_c, q = e % cpr_c;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int row = 4 * q + k;
+                    if (row >= A3)
+                        continue;
+                    const float val = c < ns ? v[u][k] : 0.f;
+                    if (c < ns)
+                        ((float *)(r.recs + (size_t)c * rstride + sizeof(EkRecHdr)))[row] =
+                            val;
+                    if (go)     // (zero for a slot without a candidate)
+                        r.ctile[ek_ctile_index(T, row / 3, c, row % 3)] = val;
+                }
+            }
+        }
+        if (go)                                     // the atoms of padding
+            for (int k = tid; k < (ek_ctile_atoms(A) - A) * 3 * T; k += EK_BLOCK)
+                r.ctile[ek_ctile_index(T, A + k / (3 * T), (k % (3 * T)) / 3, k % 3)] =
+                    0.f;
+        if (tid < T) {
+            EkPlan *plan = r.plan;
+            double tr = 0.0;
+            if (tid < ns) {
+                const uint32_t *rr = ek_ms_rec<SYS>(x, sel[tid], seq, A);
+                tr = __longlong_as_double(
+                    (long long)((unsigned long long)ek_msg_load<SYS>(rr + 4) |
+                                ((unsigned long long)ek_msg_load<SYS>(rr + 5) << 32)));
+                plan->src[tid] = tid;
+                plan->gidx[tid] = sgidx[sel[tid]];
+                plan->maxdist[tid] = sval[sel[tid]];
+                plan->trace[tid] = tr;
+            }
+            r.ctrace[tid] = tr;
+        }
+        if (tid >= 1 && tid < EK_MAX_CANDS)     // the presumed order: as chosen
+            r.ord->cand[tid - 1] = tid;
+    }
+    if (tid == 0) {
+        EkPlan *plan = r.plan;
+        plan->apply = -1;
+        plan->chain_n = 0;
+        if (!repick && !s_short && ns > 0)  // (the offers describe the state as it is)
+            r.ctl->last_max = first_max;
+        if (go) {
+            // (candidate 0 is counted by the plan kernel that follows its pass)
+            plan->go = 1;
+            plan->teff = ns;
+            plan->label = r.ctl->n_done;
+            plan->used = 1;
+            plan->miss = 0;
+            r.ord->n = ns - 1;
+            ms->mode = 1;
+        } else {
+            plan->go = 0;
+            plan->teff = 0;
+            plan->miss = 1;
+            if (repick) {
+                ms->mode = 2;
+            } else {
+                if (!over && ns > 0)
+                    r.ctl->stopped = 1;     // maxdist <= cutoff
+                plan->used = 0;
+                ms->mode = 0;
+            }
+        }
+        ms->seq = seq + 1u;
+    }
+}
+
+void ek_launch_ms_plan(const EkRound &r, EkMsState *ms, const EkMsXchg &x, float *D,
+                       hipStream_t s)
+{
+    const unsigned blocks = (unsigned)(64 * 64 / (EK_BLOCK / EK_WAVE));
+#define EK_MS_PLAN(TT)                                                         \
+    do {                                                                       \
+        if (x.sys)                                                             \
+            hipLaunchKernelGGL((ek_ms_plan_kernel<TT, true>), dim3(blocks),    \
+                               dim3(EK_BLOCK), 0, s, r, ms, x, D);             \
+        else                                                                   \
+            hipLaunchKernelGGL((ek_ms_plan_kernel<TT, false>), dim3(blocks),   \
+                               dim3(EK_BLOCK), 0, s, r, ms, x, D);             \
+    } while (0)
+    if (r.T == 16)
+        EK_MS_PLAN(16);
+    else if (r.T == 8)
+        EK_MS_PLAN(8);
+    else
+        EK_MS_PLAN(4);
+#undef EK_MS_PLAN
+}

@@ -121,7 +121,9 @@ __device__ __forceinline__ void ek_coh_store_bm(BM *p, float v, uint32_t i)
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // arrival of this workgroup at `tick`; true in all threads of the last one
-__device__ __forceinline__ bool ek_arrive_last(unsigned int *tick)
+// (`expected`: the workgroups that arrive, if not the whole grid)
+__device__ __forceinline__ bool ek_arrive_last(unsigned int *tick,
+                                               unsigned int expected = 0)
 {
     __shared__ bool ek_last_flag;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this thread's stores
@@ -129,7 +131,7 @@ __device__ __forceinline__ bool ek_arrive_last(unsigned int *tick)
     if (threadIdx.x == 0)
         ek_last_flag = __hip_atomic_fetch_add(tick, 1u, __ATOMIC_RELAXED,
                                               __HIP_MEMORY_SCOPE_AGENT) ==
-                       gridDim.x - 1;
+                       (expected ? expected : gridDim.x) - 1;
     __syncthreads();
     return ek_last_flag;
 }

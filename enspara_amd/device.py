@@ -372,6 +372,75 @@ class FrameStore:
         _lib.check(self.lib.ek_spec_rounds(self._h, C.byref(r)))
         return r.value
 
+    # -- rounds across shards, one exchange per round (csrc/ek_mshard.hip) ------
+    def ms_setup(self, world, rank):
+        """-> bytes of a shard's round message"""
+        b = C.c_size_t()
+        _lib.check(self.lib.ek_ms_setup(self._h, int(world), int(rank),
+                                        C.byref(b)))
+        return b.value
+
+    def ms_mailbox(self, ipc=False):
+        """This shard's mailbox: (address, flags address), or with ipc=True the
+        two 64-byte hipIpc handles another process opens (bytes, bytes)."""
+        if ipc:
+            hm = C.create_string_buffer(64)
+            hf = C.create_string_buffer(64)
+            _lib.check(self.lib.ek_ms_mailbox(self._h, None, None, hm, hf))
+            return hm.raw, hf.raw
+        m, f = C.c_void_p(), C.c_void_p()
+        _lib.check(self.lib.ek_ms_mailbox(self._h, C.byref(m), C.byref(f), None,
+                                          None))
+        return m.value, f.value
+
+    def ms_connect(self, peer, mbox=None, flags=None, ipc=None):
+        """Where peer's mailbox is: addresses (contexts of one process) or
+        ipc=(handle, handle) from that process's ms_mailbox(ipc=True)."""
+        if ipc is not None:
+            hm = C.create_string_buffer(bytes(ipc[0]), 64)
+            hf = C.create_string_buffer(bytes(ipc[1]), 64)
+            _lib.check(self.lib.ek_ms_connect(self._h, int(peer), None, None,
+                                              hm, hf))
+        else:
+            _lib.check(self.lib.ek_ms_connect(
+                self._h, int(peer), C.c_void_p(mbox), C.c_void_p(flags), None,
+                None))
+
+    def ms_begin(self, first_label, limit):
+        _lib.check(self.lib.ek_ms_begin(self._h, int(first_label), int(limit)))
+
+    def ms_local(self, dist_cutoff, message_out_ptr):
+        _lib.check(self.lib.ek_ms_local(self._h, float(dist_cutoff),
+                                        C.c_void_p(int(message_out_ptr))))
+
+    def ms_global(self, dist_cutoff, messages_all_ptr):
+        _lib.check(self.lib.ek_ms_global(self._h, float(dist_cutoff),
+                                         C.c_void_p(int(messages_all_ptr))))
+
+    def ms_end(self):
+        _lib.check(self.lib.ek_ms_end(self._h))
+
+    def ms_state(self):
+        """-> (mode, exchanges completed since ms_setup, error code)"""
+        m, e, r = C.c_int32(), C.c_int32(), C.c_int32()
+        _lib.check(self.lib.ek_ms_state(self._h, C.byref(m), C.byref(e),
+                                        C.byref(r)))
+        return m.value, e.value, r.value
+
+    def ms_run(self, first_label, max_new, dist_cutoff):
+        """k-centers over all connected shards, exchange on the device; every
+        shard calls it at the same time.  -> as kcenters_run"""
+        max_new = int(max_new)
+        idx = np.empty(max(max_new, 1), dtype=np.int64)
+        cd = np.empty(max(max_new, 1), dtype=np.float32)
+        n_added = C.c_int32()
+        fmax = C.c_float()
+        _lib.check(self.lib.ek_ms_run(
+            self._h, int(first_label), max_new, float(dist_cutoff),
+            C.byref(n_added), _lib.i64p(idx), _lib.f32p(cd), C.byref(fmax)))
+        k = n_added.value
+        return idx[:k].copy(), cd[:k].copy(), fmax.value
+
     def run_stats(self):
         """How the last kcenters_run spent its passes over the frames:
         -> {candidates per pass: (passes, centers accepted)}"""

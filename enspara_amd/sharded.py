@@ -98,6 +98,28 @@ class DeviceShard:
     def spec_progress(self):
         return self.store.spec_progress()
 
+    # rounds with one exchange each (csrc/ek_mshard.hip)
+    def ms_setup(self, world, rank):
+        return self.store.ms_setup(world, rank)
+
+    def ms_begin(self, first_label, limit):
+        self.store.ms_begin(first_label, limit)
+
+    def ms_local(self, cutoff, msg):
+        self.store.ms_local(cutoff, msg.data_ptr())
+
+    def ms_global(self, cutoff, msgs_all):
+        self.store.ms_global(cutoff, msgs_all.data_ptr())
+
+    def ms_end(self):
+        self.store.ms_end()
+
+    ms_connected = 0        # shards whose mailboxes are connected (connect_mailboxes)
+
+    def ms_run(self, first_label, max_new, cutoff):
+        idx, cd, _ = self.store.ms_run(first_label, max_new, cutoff)
+        return idx, cd
+
     def history(self, first, count):
         idx, cd, n_done = self.store.history(first, count)
         return idx, cd, n_done
@@ -207,6 +229,9 @@ def kcenters_sharded(shard, first_label, max_new, dist_cutoff=0.0, group=None,
     world, _ = _world(group)
     collective = dist.is_available() and dist.is_initialized()
     T = getattr(shard, "candidates", 1)
+    if T > 1 and world <= MAX_ROUND_RECORDS and hasattr(shard, "ms_local"):
+        return _kcenters_sharded_ms(shard, first_label, max_new, dist_cutoff,
+                                    group, fresh, world, T, collective)
     if T > 1 and world <= MAX_ROUND_RECORDS:
         return _kcenters_sharded_rounds(shard, first_label, max_new,
                                         dist_cutoff, group, fresh, world, T,
@@ -247,6 +272,79 @@ def kcenters_sharded(shard, first_label, max_new, dist_cutoff=0.0, group=None,
 # records a round's plan can choose its candidates from (the device keeps a
 # 64 x 64 table of their pairwise distances, csrc/ek_spec.hip)
 MAX_ROUND_RECORDS = 64
+
+
+def _kcenters_sharded_ms(shard, first_label, max_new, dist_cutoff, group, fresh,
+                         world, T, collective):
+    """Rounds of up to T candidates with ONE exchange each (csrc/
+    ek_mshard.hip): per round every rank all-gathers one message -- its (max
+    distance, global index) in the state every prefix of the round's chain
+    would leave, and its farthest frames of the state the whole chain would
+    leave -- where the reference moves two allgathers, a frame broadcast and
+    an allreduce per CENTER (kcenters.py:332-348).  Every rank takes the same
+    decisions from the same messages.  If the shards are connected by peer
+    mailboxes (`shard.ms_connected`), the exchange happens on the device and
+    the whole loop inside the library (`ms_run`): nothing here per round."""
+    import torch.distributed as dist
+    rank = dist.get_rank(group) if collective else 0
+    if fresh:
+        shard.reset_history()
+    if getattr(shard, "ms_connected", 0) == world:
+        idx, cd = shard.ms_run(first_label, max_new, float(dist_cutoff))
+        return (np.array(idx, dtype=np.int64), np.array(cd, dtype=np.float32))
+    key = (world, rank)
+    if getattr(shard, "_ms_key", None) != key:
+        shard._ms_bytes = shard.ms_setup(world, rank)
+        shard._ms_key = key
+    mb = shard._ms_bytes
+    mine = shard.new_buffer(mb)
+    everyone = shard.new_buffer(mb * world) if collective else mine
+    limit = first_label + max_new
+    shard.ms_begin(first_label, limit)
+    n_done = first_label
+    per_round = 0.6 * T
+    while max_new > 0:
+        # (the same count on every rank: n_done is)
+        rounds = max(2, min(256, int((limit - n_done) / per_round) + 2))
+        before = n_done
+        for _ in range(rounds):
+            shard.ms_local(float(dist_cutoff), mine)
+            if collective:
+                dist.all_gather_into_tensor(everyone, mine, group=group)
+            shard.ms_global(float(dist_cutoff), everyone)
+        n_done, stopped = shard.spec_progress()
+        if stopped or n_done >= limit:
+            break
+        per_round = max(1.0, (n_done - before) / rounds)
+    shard.ms_end()
+    idx, cd, n_done = shard.history(first_label, max_new)
+    k = max(0, min(max_new, n_done - first_label))
+    return np.array(idx[:k], dtype=np.int64), np.array(cd[:k],
+                                                      dtype=np.float32)
+
+
+def connect_mailboxes(shard, group=None):
+    """Peer mailboxes for the shards of a torch.distributed group of processes
+    on one node (one GPU each): every rank publishes the hipIpc handles of its
+    mailbox, opens the others', and from then on `kcenters_sharded` runs its
+    rounds with the exchange on the device (DeviceShard.ms_run).  Collective:
+    every rank calls it."""
+    import torch.distributed as dist
+    world, rank = _world(group)
+    st = shard.store
+    st.ms_setup(world, rank)
+    mine = st.ms_mailbox(ipc=True) if world > 1 else None
+    handles = [None] * world
+    if world > 1:
+        dist.all_gather_object(handles, mine, group=group)
+    for p in range(world):
+        if p == rank:
+            st.ms_connect(p)
+        else:
+            st.ms_connect(p, ipc=handles[p])
+    if world > 1:
+        dist.barrier(group=group)
+    shard.ms_connected = world
 
 
 def _kcenters_sharded_rounds(shard, first_label, max_new, dist_cutoff, group,

@@ -184,6 +184,47 @@ int ek_spec_chain_max(ek_ctx *ctx, const void *rows_all, int32_t n_shards,
                       void *hdrs_out);
 int ek_spec_chain_apply(ek_ctx *ctx, const void *hdrs_all, int32_t n_shards,
                         double dist_cutoff);
+/* ---- rounds across shards with ONE exchange per round (csrc/ek_mshard.hip) -------
+ * Replaces, per ROUND of up to 16 candidates (~15 accepted centers), what the
+ * reference's MPI iteration moves per CENTER: two pickled allgathers
+ * (kcenters.py:332-335), the owner's frame (mpi/ops.py:169-212) and the
+ * allreduce of the stop test (mpi/ops.py:128-140).  A shard's message holds its
+ * (max distance, global index) in the state every prefix of the round's chain
+ * would leave and its farthest frames of the state the whole chain would leave
+ * (16 + 16 * 16 + offer * ek_record_bytes bytes, offer = 64 / world).  Results are
+ * those of the single-shard run bit for bit: every accepted center is the
+ * global first-index arg-max of the state before it (lowest rank on ties,
+ * kcenters.py:337).
+ *
+ *   ek_ms_setup(ctx, world, rank, &message_bytes)      once per group
+ * Exchange by the caller (any all-gather: RCCL, gloo):
+ *   ek_ms_begin(ctx, first_label, limit)
+ *   repeat:  ek_ms_local(ctx, cutoff, my_message)       pass + chain -> message
+ *            all-gather my_message -> all_messages      (message_bytes per shard)
+ *            ek_ms_global(ctx, cutoff, all_messages)    decision + next plan
+ *            (ek_spec_progress now and then; calls past the end are no-ops)
+ *   ek_ms_end(ctx)                                      pending chain applied
+ * Exchange on the device (peer mailboxes, no host and no collective in a
+ * round): every shard publishes its mailbox (ek_ms_mailbox: addresses for
+ * contexts of one process, hipIpc handles of 64 bytes each across processes),
+ * connects every shard's including its own (ek_ms_connect), then
+ *   ek_ms_run(ctx, first_label, max_new, cutoff, ...)   as ek_kcenters_run
+ * on every shard at the same time.  A message that does not arrive within ~1 s
+ * is reported as an error (a peer died), not waited for. */
+int ek_ms_setup(ek_ctx *ctx, int32_t world, int32_t rank, size_t *message_bytes);
+int ek_ms_mailbox(ek_ctx *ctx, void **mbox, void **flags, void *ipc_mbox,
+                  void *ipc_flags);
+int ek_ms_connect(ek_ctx *ctx, int32_t peer, void *mbox, void *flags,
+                  const void *ipc_mbox, const void *ipc_flags);
+int ek_ms_begin(ek_ctx *ctx, int32_t first_label, int32_t limit);
+int ek_ms_local(ek_ctx *ctx, double dist_cutoff, void *message_out);
+int ek_ms_global(ek_ctx *ctx, double dist_cutoff, const void *messages_all);
+int ek_ms_end(ek_ctx *ctx);
+/* mode (0: the run is over), exchanges completed since ek_ms_setup, error */
+int ek_ms_state(ek_ctx *ctx, int32_t *mode, int32_t *exchanges, int32_t *err);
+int ek_ms_run(ek_ctx *ctx, int32_t first_label, int32_t max_new,
+              double dist_cutoff, int32_t *n_added, int64_t *center_index_out,
+              float *center_dist_out, float *final_maxdist);
 /* rounds (passes over the frames) that really ran since ek_spec_begin /
  * ek_kcenters_run started */
 int ek_spec_rounds(ek_ctx *ctx, int32_t *rounds);

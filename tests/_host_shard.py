@@ -411,3 +411,187 @@ class HostShardChain(HostShardRounds):
             if int(w["gidx"]) != cands[j]["gidx"]:
                 break
             self._accept(cands[j], float(w["maxdist"]))
+
+
+MS_MSG = np.dtype([("n_recs", "<i4"), ("cn", "<i4"), ("pad", "<i4", (2,))])
+MAX_CANDS = 16
+
+
+class HostShardMs(HostShard):
+    """The shard speaking the one-exchange-per-round protocol of
+    csrc/ek_mshard.hip (ek_ms_setup / _begin / _local / _global / _end), with
+    the device's message layout: EkMsMsg | 16 x EkMaxHdr | `offer` records.
+    Restated on the CPU with the checker's distances so that the product's
+    driver loop (enspara_amd/sharded.py, gather transport) and the protocol's
+    decisions -- per-prefix global maxima, lowest global index on ties, the
+    chain that breaks and is re-offered -- run under gloo without a GPU.  The
+    guesses are simpler than the device's (largest distances, no pairwise
+    table); correctness never depends on them."""
+
+    far_as_inf = True
+
+    def __init__(self, xyz, global_offset, candidates=8):
+        super().__init__(xyz, global_offset)
+        self.candidates = candidates
+        self.mode = 0
+        self.exchanges = 0
+        self.repicks = 0
+
+    # -- layout ---------------------------------------------------------------
+    def ms_setup(self, world, rank):
+        self.world, self.rank = world, rank
+        self.offer = max(1, 64 // world)
+        self.msg_bytes = 16 + 16 * MAX_CANDS + self.offer * self.record_bytes
+        return self.msg_bytes
+
+    def ms_begin(self, first_label, limit):
+        self.n_done = first_label
+        self.limit = limit
+        self.stopped = False
+        self.mode = 2               # offer the records of the state as it stands
+        self.pick_state = 0
+        self.cands = []             # the round's candidates (dicts), [0] applied
+        self.order = []             # presumed order of candidates 1..
+        self.states = [self.dist]   # state k: after the first k of the order
+        self.pending = 0
+        self.rounds = 0
+
+    def _state(self, k):
+        return self.states[k]
+
+    # -- pass + chain -> message ----------------------------------------------
+    def ms_local(self, cutoff, msg):
+        if self.mode == 0:
+            return
+        buf = msg.numpy()
+        buf[:self.msg_bytes] = 0
+        if self.mode == 1:
+            # the pass: the pending chain of the round before is the state
+            # already (applied when it was accepted, below); candidate 0 ...
+            c0 = self.cands[0]
+            for c in self.cands:
+                c["vec"] = (qcp.rmsd_centered(self.P.c, self.P.G, c["coords"],
+                                              c["trace"])
+                            if self.n else np.zeros(0, np.float32))
+            upd = c0["vec"] < self.dist
+            self.dist[upd] = c0["vec"][upd]
+            self.assign[upd] = c0["label"]
+            # ... and the states every prefix of the presumed order would leave
+            self.states = [self.dist.copy()]
+            for j in self.order:
+                v = self.cands[j]["vec"]
+                if self.far_as_inf:     # what the device keeps of a far distance
+                    v = np.where(v < self.states[0], v, np.float32(np.inf))
+                self.states.append(np.minimum(self.states[-1], v))
+        cn = len(self.order) if self.mode == 1 else 0
+        hdrs = np.zeros(MAX_CANDS, dtype=MAXHDR)
+        hdrs["maxdist"], hdrs["gidx"] = -np.inf, -1
+        for k in range(cn):             # states 0 .. cn - 1
+            if self.n:
+                s = self.states[k]
+                i = int(np.argmax(s))
+                hdrs[k] = (s[i], 1, self.offset + i)
+        ps = cn if self.mode == 1 else self.pick_state
+        s = self.states[ps] if self.n else np.zeros(0, np.float32)
+        order = []
+        if self.n:
+            first = int(np.argmax(s))
+            rest = [int(i) for i in np.argsort(-s, kind="stable")
+                    if int(i) != first]
+            order = [first] + rest[:self.offer - 1]
+        head = np.zeros(1, dtype=MS_MSG)
+        head["n_recs"], head["cn"] = len(order), cn
+        buf[:16] = head.view(np.uint8)
+        buf[16:16 + hdrs.nbytes] = hdrs.view(np.uint8)
+        rb = self.record_bytes
+        base = 16 + 16 * MAX_CANDS
+        for j, i in enumerate(order):
+            sub = msg[base + j * rb:base + (j + 1) * rb]
+            self._write(sub, s[i], 1, self.offset + i, self.P.G[i], self.P.c[i])
+
+    # -- all messages -> decision, next plan -----------------------------------
+    def ms_global(self, cutoff, msgs):
+        if self.mode == 0:
+            return
+        buf = msgs.numpy()
+        mb, rb = self.msg_bytes, self.record_bytes
+        base = 16 + 16 * MAX_CANDS
+        heads = [buf[r * mb:r * mb + 16].view(MS_MSG)[0]
+                 for r in range(self.world)]
+        cn = len(self.order) if self.mode == 1 else 0
+        na = 0
+        short = False
+        if self.mode == 1:
+            # candidate 0 of the pass that has just run is a center now
+            c0 = self.cands[0]
+            self.hist[c0["label"]] = (c0["gidx"], c0["maxdist"])
+            self.n_done = c0["label"] + 1
+            self.rounds += 1
+            label0 = self.n_done
+            for k in range(cn):
+                hs = [buf[r * mb + 16:r * mb + 16 + 16 * MAX_CANDS].view(MAXHDR)[k]
+                      for r in range(self.world)]
+                hs = [h for h in hs if h["valid"]]
+                if self.stopped or self.n_done >= self.limit or not hs:
+                    break
+                hs.sort(key=lambda h: (-float(h["maxdist"]), int(h["gidx"])))
+                w = hs[0]
+                if not (float(w["maxdist"]) > cutoff):      # kcenters.py:217
+                    self.stopped = True
+                    break
+                cand = self.cands[self.order[k]]
+                if int(w["gidx"]) != cand["gidx"]:
+                    break
+                self.hist[self.n_done] = (cand["gidx"], float(w["maxdist"]))
+                self.n_done += 1
+                na += 1
+            short = na < cn
+            # the accepted prefix becomes the state (labels in order)
+            for k in range(na):
+                v = self.cands[self.order[k]]["vec"]
+                upd = v < self.dist
+                self.dist[upd] = v[upd]
+                self.assign[upd] = label0 + k
+        self.exchanges += 1
+        over = self.stopped or self.n_done >= self.limit
+        if over:
+            self.mode = 0
+            return
+        if self.mode == 1 and short:
+            self.mode, self.pick_state = 2, na
+            self.repicks += 1
+            return
+        # the next round's candidates: the largest offered distances, lowest
+        # global index on ties
+        offers = []
+        for r in range(self.world):
+            for j in range(int(heads[r]["n_recs"])):
+                o = r * mb + base + j * rb
+                h = buf[o:o + 32].view(HDR)[0]
+                offers.append((-float(h["maxdist"]), int(h["gidx"]), o))
+        offers.sort()
+        offers = offers[:self.candidates]
+        if not offers:
+            self.mode = 0
+            return
+        if not (-offers[0][0] > cutoff):
+            self.stopped = True
+            self.mode = 0
+            return
+        self.cands = []
+        for nd, g, o in offers:
+            h = buf[o:o + 32].view(HDR)[0]
+            self.cands.append(dict(
+                gidx=g, trace=float(h["trace"]),
+                coords=buf[o + 32:o + 32 + 12 * self.A].view(np.float32)
+                .reshape(self.A, 3).copy()))
+        self.cands[0]["label"] = self.n_done     # (counted once its pass has run)
+        self.cands[0]["maxdist"] = -offers[0][0]
+        self.order = list(range(1, len(self.cands)))
+        self.mode = 1
+
+    def ms_end(self):
+        self.mode = 0
+
+    def spec_progress(self):
+        return self.n_done, self.stopped

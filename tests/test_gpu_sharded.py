@@ -153,6 +153,7 @@ dist.all_gather_into_tensor, dist.all_reduce = agit, ar
 from enspara_amd import sharded, synth
 from enspara_amd.device import FrameStore
 n, A, K, tmpl, iters, cands = [int(v) for v in sys.argv[6:12]]
+mailboxes = len(sys.argv) > 12 and sys.argv[12] == "ipc"
 x = synth.synth(n, A, tmpl, seed=21)
 lo, cnt = sharded.shard_bounds(n, world, rank)
 torch.cuda.set_device(0)
@@ -162,6 +163,8 @@ with FrameStore(cnt, A, device=0, global_offset=lo, stream=ts.cuda_stream) as st
     st.set_option(4, cands)
     st.reset_state()
     sh = sharded.DeviceShard(st)
+    if mailboxes:       # the k-centers rounds exchange on the device (hipIpc)
+        sharded.connect_mailboxes(sh)
     with torch.cuda.stream(ts):
         med = sharded.khybrid_sharded(sh, K, 0.0, iters, random_state=5)
     d, a = st.download_state()
@@ -171,14 +174,19 @@ dist.destroy_process_group()
 """
 
 
-@pytest.mark.parametrize("n,A,K,tmpl,iters,cands", [
-    (6000, 14, 45, 9, 2, 8),
+@pytest.mark.parametrize("n,A,K,tmpl,iters,cands,transport", [
+    (6000, 14, 45, 9, 2, 8, "gather"),
     # the shape of BASELINE.json configs[3] as far as one GPU allows: 500 atoms,
     # two shards, ~200 centers -- rounds of 16 and of 8 candidates
-    (40000, 500, 200, 300, 0, 16),
-    (40000, 500, 200, 300, 0, 8),
+    (40000, 500, 200, 300, 0, 16, "gather"),
+    (40000, 500, 200, 300, 0, 8, "gather"),
+    # the same two processes with their mailboxes mapped into each other
+    # (hipIpc): the exchange of a round happens on the device
+    (6000, 14, 45, 9, 2, 16, "ipc"),
+    (40000, 500, 200, 300, 0, 16, "ipc"),
 ])
-def test_two_device_shards_on_one_gpu(tmp_path, n, A, K, tmpl, iters, cands):
+def test_two_device_shards_on_one_gpu(tmp_path, n, A, K, tmpl, iters, cands,
+                                      transport):
     import socket
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -187,7 +195,8 @@ def test_two_device_shards_on_one_gpu(tmp_path, n, A, K, tmpl, iters, cands):
     out = str(tmp_path / "r")
     procs = [subprocess.Popen([sys.executable, "-c", _CHILD2, ROOT, str(r), "2",
                                port, out, str(n), str(A), str(K), str(tmpl),
-                               str(iters), str(cands)], stdout=subprocess.PIPE,
+                               str(iters), str(cands), transport],
+                              stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT, text=True)
              for r in range(2)]
     logs = [p.communicate(timeout=900)[0] for p in procs]
@@ -201,6 +210,74 @@ def test_two_device_shards_on_one_gpu(tmp_path, n, A, K, tmpl, iters, cands):
     np.testing.assert_array_equal(np.concatenate([p["a"] for p in parts]), wa)
     np.testing.assert_array_equal(
         np.concatenate([p["d"] for p in parts]).astype(np.float64), wd)
+
+
+_CHILD_MBOX = r"""
+import sys, threading
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+from enspara_amd import sharded, synth
+from enspara_amd.device import FrameStore
+from oracle import cluster as oc
+shards, n, A, K, cands = [int(v) for v in sys.argv[2:7]]
+cutoff = float(sys.argv[7])
+x = synth.synth(n, A, 11, seed=n + shards)
+inds, wa, wd = oc.kcenters(x, n_clusters=K or None, dist_cutoff=cutoff or None)
+stores = []
+for r in range(shards):
+    lo, cnt = sharded.shard_bounds(n, shards, r)
+    st = FrameStore(cnt, A, device=0, global_offset=lo)
+    st.load(x[lo:lo + cnt])
+    st.set_option(4, cands)
+    st.ms_setup(shards, r)
+    stores.append(st)
+boxes = [st.ms_mailbox() for st in stores]
+for st in stores:
+    for p in range(shards):
+        st.ms_connect(p, boxes[p][0], boxes[p][1])
+out = [None] * shards
+def work(r):
+    out[r] = stores[r].ms_run(0, K if K else n, cutoff)
+for rep in range(2):
+    for st in stores:
+        st.reset_state()
+        st.sync()
+    th = [threading.Thread(target=work, args=(r,)) for r in range(shards)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for o in out:
+        np.testing.assert_array_equal(o[0], np.array(inds))
+    parts = [st.download_state() for st in stores]
+    np.testing.assert_array_equal(np.concatenate([p[1] for p in parts]), wa)
+    np.testing.assert_array_equal(
+        np.concatenate([p[0] for p in parts]).astype(np.float64), wd)
+    # distances.max() after the last update (kcenters.py:226)
+    assert out[0][2] == np.float32(wd.max()), (out[0][2], wd.max())
+print("ok", len(inds), stores[0].ms_state())
+"""
+
+
+@pytest.mark.parametrize("shards,n,A,K,cutoff,cands", [
+    (2, 9000, 21, 70, 0.0, 16), (3, 7000, 10, 0, 0.3, 8),
+    (3, 600, 5, 40, 0.0, 16),           # the third shard is empty
+    (2, 30000, 33, 300, 0.0, 16), (8, 40000, 20, 400, 0.0, 16)])
+def test_mailbox_rounds_between_contexts(shards, n, A, K, cutoff, cands):
+    """the rounds of csrc/ek_mshard.hip with the exchange on the device: the
+    shards are contexts of ONE process on the one GPU, their mailboxes plain
+    addresses, every shard's loop runs in its own host thread (ek_ms_run) --
+    twice from the untouched state: the second start is simultaneous.  (In a
+    child process with one hardware queue per stream: shards that wait for one
+    another on the device must not share a queue, which one shard per GPU never
+    does.)"""
+    env = dict(os.environ)
+    env["GPU_MAX_HW_QUEUES"] = "16"
+    p = subprocess.run([sys.executable, "-c", _CHILD_MBOX, ROOT, str(shards),
+                        str(n), str(A), str(K), str(cands), str(cutoff)],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    assert p.stdout.strip().splitlines()[-1].startswith("ok")
 
 
 # ---- the estimators' mpi_mode=True (every rank passes its own frames) ------------

@@ -31,13 +31,15 @@ def _worker(rank, world, port, n, A, seed, n_clusters, cutoff, outdir,
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["OMP_NUM_THREADS"] = "2" if world <= 3 else "1"
     from enspara_amd import sharded, synth
-    from _host_shard import HostShard, HostShardRounds, HostShardChain
+    from _host_shard import (HostShard, HostShardRounds, HostShardChain,
+                             HostShardMs)
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port,
                             rank=rank, world_size=world)
     x = synth.synth(n, A, 9, seed=seed)
     lo, cnt = sharded.shard_bounds(n, world, rank)
     shard = (HostShard(x[lo:lo + cnt], lo) if cands == 1 else
-             (HostShardChain if chain else HostShardRounds)(
+             (HostShardMs if chain == "ms" else
+              HostShardChain if chain else HostShardRounds)(
                  x[lo:lo + cnt], lo, cands))
     max_new = n_clusters if n_clusters else n
     idx, cd = sharded.kcenters_sharded(shard, 0, max_new, cutoff,
@@ -127,6 +129,20 @@ def test_larger_groups_chained_rounds(world, n, K):
     assert len(inds) == K
 
 
+@pytest.mark.parametrize("world,n,K,cutoff,cands", [
+    (2, 1500, 40, 0.0, 8), (2, 1200, None, 0.45, 8), (3, 300, 12, 0.0, 16),
+    (8, 2600, 50, 0.0, 16)])
+def test_one_exchange_per_round(world, n, K, cutoff, cands):
+    """the round protocol of csrc/ek_mshard.hip (one message per shard and
+    round: per-prefix maxima + speculative offers, a broken chain re-offered)
+    through the product's driver loop, gather transport over gloo; world 3:
+    one shard is empty"""
+    inds = _run(world, n, 20 if world < 8 else 10, 5, K, cutoff, cands=cands,
+                chain="ms")
+    if K:
+        assert len(inds) == K
+
+
 def test_shard_bounds():
     from enspara_amd.sharded import shard_bounds
     for n, w in [(1000, 2), (1_000_000, 8), (255, 4), (256 * 7 + 3, 3)]:
@@ -140,7 +156,8 @@ def test_shard_bounds():
 
 def test_single_process_without_process_group():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from _host_shard import HostShard, HostShardRounds, HostShardChain
+    from _host_shard import (HostShard, HostShardRounds, HostShardChain,
+                             HostShardMs)
     from enspara_amd import sharded, synth
     from oracle import cluster as oc
     x = synth.synth(700, 12, 5, seed=2)

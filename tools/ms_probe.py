@@ -1,0 +1,87 @@
+"""Rounds across shards with one exchange each (csrc/ek_mshard.hip) on ONE GPU:
+  ms_probe.py <n> <atoms> <centers> [shards=1] [cands=16] [reps=2]
+`shards` contexts of one process share the GPU (own stream each), connected by
+peer mailboxes (plain addresses); each runs ek_ms_run from its own host thread.
+Prints seconds per run, rounds, microseconds per accepted center, and compares
+centers / labels / distances with the single-shard ek_kcenters_run of the same
+data (which the GPU tests compare with the oracle)."""
+import os
+import sys
+import threading
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from enspara_amd import sharded, synth
+from enspara_amd.device import FrameStore
+
+n, A, K = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+S = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+T = int(sys.argv[5]) if len(sys.argv) > 5 else 16
+reps = int(sys.argv[6]) if len(sys.argv) > 6 else 2
+tm = synth.templates(int(os.environ.get("MS_TEMPLATES", "5000")), A, 1)
+x = np.concatenate([synth.synth_chunk(c, min(synth.CHUNK, n - c * synth.CHUNK), tm, 1)
+                    for c in range((n + synth.CHUNK - 1) // synth.CHUNK)])
+
+ref = FrameStore.from_array(x)
+ref.set_option(4, T)
+ref.set_option(8, 0)
+ref.reset_state()
+t0 = time.perf_counter()
+ridx, rcd, rmx = ref.kcenters_run(0, K, 0.0)
+t_ref = time.perf_counter() - t0
+ref.reset_state()
+t0 = time.perf_counter()
+ridx, rcd, rmx = ref.kcenters_run(0, K, 0.0)
+t_ref = time.perf_counter() - t0
+rd, ra = ref.download_state()
+rstats = {k: v for k, v in ref.run_stats().items() if v[0]}
+ref.close()
+print("single shard, %d candidates: %.4f s  %.2f us/center  %s" % (T, t_ref, t_ref / K * 1e6, rstats), flush=True)
+
+stores = []
+for r in range(S):
+    lo, cnt = sharded.shard_bounds(n, S, r)
+    st = FrameStore(cnt, A, device=0, global_offset=lo)
+    st.load(x[lo:lo + cnt])
+    st.set_option(4, T)
+    st.ms_setup(S, r)
+    stores.append(st)
+boxes = [st.ms_mailbox() for st in stores]
+for st in stores:
+    for p in range(S):
+        st.ms_connect(p, boxes[p][0], boxes[p][1])
+out = [None] * S
+
+
+def work(r):
+    try:
+        out[r] = stores[r].ms_run(0, K, 0.0)
+    except Exception as e:
+        print("shard %d: %s" % (r, e), flush=True)
+        out[r] = (np.zeros(0, np.int64), np.zeros(0, np.float32), 0.0)
+
+
+for rep in range(reps):
+    for st in stores:
+        st.reset_state()
+        st.reset_history()
+        st.sync()
+    th = [threading.Thread(target=work, args=(r,)) for r in range(S)]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = time.perf_counter() - t0
+    rounds = stores[0].spec_rounds()
+    print("   exchanges per shard:", [st.ms_state() for st in stores], flush=True)
+    print("%d shard(s) of %d frames, mailboxes: %.4f s  %d passes  %.2f centers/pass  %.2f us/center  %.1f us/round"
+          % (S, stores[0].n, dt, rounds, K / max(rounds, 1), dt / K * 1e6, dt / max(rounds, 1) * 1e6), flush=True)
+ok = all(np.array_equal(o[0], ridx) and np.array_equal(o[1], rcd) for o in out)
+d = np.concatenate([st.download_state()[0] for st in stores])
+a = np.concatenate([st.download_state()[1] for st in stores])
+print("centers equal: %s  distances equal: %s  labels equal: %s  final max %r / %r"
+      % (ok, np.array_equal(d, rd), np.array_equal(a, ra), out[0][2], rmx), flush=True)
+for st in stores:
+    st.close()
