@@ -43,7 +43,7 @@ SYMBOLS = [
     "ek_pam_prefetch_centers_window",
     "ek_centered_frames", "ek_pam_begin_table", "ek_pam_prefetch_centers",
     "ek_pam_propose_center",
-    "ek_msm_counts", "ek_msm_row_normalize",
+    "ek_msm_counts", "ek_msm_counts_ctx", "ek_msm_row_normalize",
     "ek_krylov_create", "ek_krylov_destroy", "ek_krylov_set_vector",
     "ek_krylov_get_vector", "ek_krylov_step", "ek_krylov_rotate",
     "ek_krylov_combine", "ek_krylov_expand",
@@ -159,6 +159,8 @@ def load():
     L.ek_pam_propose_center.argtypes = [vp, i32, i32, vp, vp, i64, i32, i32, vp]
     L.ek_msm_counts.argtypes = [C.c_int, i32p, i64p, i64, i32, i32, i32, i64,
                                 i32p, i32p, i64p, i64p]
+    L.ek_msm_counts_ctx.argtypes = [vp, i64p, i64, i32, i32, i32, i64, i32p, i32p,
+                                    i64p, i64p]
     L.ek_msm_row_normalize.argtypes = [C.c_int, i64p, f64p, i64, f64p, f64p]
     L.ek_krylov_create.argtypes = [C.c_int, i64, i64p, i32p, f64p, i32,
                                    C.POINTER(vp)]

@@ -10,6 +10,8 @@
 #include <new>
 #include <vector>
 
+void ek_msm_scratch_free(void *w);      // ek_msm.hip
+
 static thread_local char g_err[512] = "";
 
 // shared with ek_msm.hip
@@ -172,6 +174,8 @@ struct ek_ctx {
     std::vector<void *> ms_ipc;      // mappings opened with hipIpcOpenMemHandle
     int ms_T = 0;                    // candidates per pass of the run in progress
 
+    void *msm_scratch = nullptr;     // ek_msm.hip: buffers of ek_msm_counts_ctx
+
     int fpl = 0;                 // 0 = auto
     int nt = -1;                 // non-temporal frame loads: -1 = auto
     // sampled per-launch timing of the distance kernel (bench only)
@@ -185,6 +189,16 @@ struct ek_ctx {
     float last_ms = 0.f;
     int32_t last_launches = 0;
 };
+
+void ek_ctx_msm_view(ek_ctx *c, int *device, int64_t *n, const int32_t **assign,
+                     hipStream_t *stream, void ***scratch_slot)
+{
+    *device = c->device;
+    *n = c->loaded ? c->n : -1;
+    *assign = c->assign;
+    *stream = c->stream;
+    *scratch_slot = &c->msm_scratch;
+}
 
 // Wait for the stream by polling.  The loops that read a few bytes back per
 // step (PAM proposals, the k-centers progress checks) use this:
@@ -309,6 +323,7 @@ static int ek_free_all(ek_ctx *c)
     (void)hipFree(c->pam_win_dev);
     if (c->pam_win_host)
         (void)hipHostFree(c->pam_win_host);
+    ek_msm_scratch_free(c->msm_scratch);
     for (void *m : c->ms_ipc)
         (void)hipIpcCloseMemHandle(m);
     (void)hipFree(c->ms);

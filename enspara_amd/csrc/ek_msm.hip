@@ -9,25 +9,29 @@
 //   _row_normalize        enspara/msm/builders.py:171-204 (sparse branch
 //     :188-196): T = diag(1/rowsum) * C with empty rows left at zero.
 //
-// Integer work.  While the dense n_states x n_states table fits (<= 2^28 cells:
-// 16 384 states, 1 GiB of int32) the counts are a histogram: the -1 frames are
-// squeezed out by a two-level prefix sum (per-workgroup counts, one workgroup
-// scans them, every workgroup places its survivors), every transition is one
-// atomic add on its cell, and the cells that are not zero leave the table in
-// index order -- the same two-level compaction -- which is COO sorted by
-// (row, col) = CSR order.  Beyond that size: one 64-bit key
-// (row * n_states + col) per transition, radix sort + run-length encode
-// (rocPRIM through hipCUB).
+// Integer work, all of it hand-written here (no library sort / scan): the counts
+// are a histogram over the dense n_states x n_states int32 table -- 100 MB at
+// the 5 000 states of BASELINE.json configs[4], 1.6 GB at the 20 000 of
+// configs[3], of 288 GB --: the -1 frames are squeezed out by a two-level prefix
+// sum (per-workgroup counts, one workgroup scans them, every workgroup places
+// its survivors), every transition is one atomic add on its cell, and the cells
+// that are not zero leave the table in index order -- the same two-level
+// compaction -- which is COO sorted by (row, col) = CSR order.  The labels may
+// come from the host (ek_msm_counts) or be the ones a fit left in HBM
+// (ek_msm_counts_ctx: the reference pipes result.assignments straight into
+// assigns_to_counts; here they need not leave the device in between).
 #include "ek_common.h"
-
-#include <hipcub/hipcub.hpp>
 
 #include <stdarg.h>
 #include <stdio.h>
 
 #include <algorithm>
+#include <new>
 
 extern int ek_set_error(int code, const char *fmt, ...);
+// (ek_api.hip) what a count over a context's resident labels needs of it
+void ek_ctx_msm_view(ek_ctx *c, int *device, int64_t *n, const int32_t **assign,
+                     hipStream_t *stream, void ***scratch_slot);
 
 #define MSM_HIP(call)                                                          \
     do {                                                                       \
@@ -38,88 +42,6 @@ extern int ek_set_error(int code, const char *fmt, ...);
             goto done;                                                         \
         }                                                                      \
     } while (0)
-
-__global__ void __launch_bounds__(EK_BLOCK)
-msm_valid_kernel(const int32_t *__restrict__ a, int64_t n,
-                 int32_t *__restrict__ valid)
-{
-    const int64_t i = (int64_t)blockIdx.x * EK_BLOCK + threadIdx.x;
-    if (i < n)
-        valid[i] = (a[i] != -1) ? 1 : 0;
-}
-
-__global__ void __launch_bounds__(EK_BLOCK)
-msm_compact_kernel(const int32_t *__restrict__ a,
-                   const int64_t *__restrict__ pos, int64_t n,
-                   int32_t *__restrict__ c)
-{
-    const int64_t i = (int64_t)blockIdx.x * EK_BLOCK + threadIdx.x;
-    if (i < n && a[i] != -1)
-        c[pos[i]] = a[i];
-}
-
-// compacted start of every trajectory: cstart[t] = pos[start[t]]
-__global__ void __launch_bounds__(EK_BLOCK)
-msm_cstart_kernel(const int64_t *__restrict__ start,
-                  const int64_t *__restrict__ pos, int64_t n_trj, int64_t n,
-                  int64_t total_valid, int64_t *__restrict__ cstart)
-{
-    const int64_t t = (int64_t)blockIdx.x * EK_BLOCK + threadIdx.x;
-    if (t < n_trj)
-        cstart[t] = (start[t] < n) ? pos[start[t]] : total_valid;
-    if (t == n_trj)
-        cstart[t] = total_valid;
-}
-
-__global__ void __launch_bounds__(EK_BLOCK)
-msm_keys_kernel(const int32_t *__restrict__ c,
-                const int64_t *__restrict__ cstart, int64_t n_trj,
-                int64_t m, int32_t lag, int sliding, int64_t n_states,
-                unsigned long long *__restrict__ keys)
-{
-    const int64_t p = (int64_t)blockIdx.x * EK_BLOCK + threadIdx.x;
-    if (p >= m)
-        return;
-    // trajectory of compacted position p: last t with cstart[t] <= p
-    int64_t lo = 0, hi = n_trj - 1;
-    while (lo < hi) {
-        const int64_t mid = (lo + hi + 1) >> 1;
-        if (cstart[mid] <= p)
-            lo = mid;
-        else
-            hi = mid - 1;
-    }
-    const int64_t end = cstart[lo + 1];
-    const int64_t local = p - cstart[lo];
-    bool ok = (p + lag < end);
-    if (ok && !sliding)
-        ok = (local % lag) == 0;
-    keys[p] = ok ? (unsigned long long)c[p] * (unsigned long long)n_states +
-                       (unsigned long long)c[p + lag]
-                 : ~0ull;
-}
-
-__global__ void __launch_bounds__(EK_BLOCK)
-msm_split_kernel(const unsigned long long *__restrict__ ukeys,
-                 const int64_t *__restrict__ ucnt, int64_t runs,
-                 int64_t n_states, int32_t *__restrict__ rows,
-                 int32_t *__restrict__ cols, int64_t *__restrict__ vals)
-{
-    const int64_t i = (int64_t)blockIdx.x * EK_BLOCK + threadIdx.x;
-    if (i >= runs)
-        return;
-    const unsigned long long k = ukeys[i];
-    if (k == ~0ull) {
-        rows[i] = -1;
-        cols[i] = -1;
-        vals[i] = 0;
-        return;
-    }
-    rows[i] = (int32_t)(k / (unsigned long long)n_states);
-    cols[i] = (int32_t)(k % (unsigned long long)n_states);
-    vals[i] = ucnt[i];
-}
-
 
 static inline unsigned msm_blocks(int64_t n)
 {
@@ -296,113 +218,177 @@ msm_cells_kernel(const int32_t *__restrict__ table, int64_t n_cells,
     }
 }
 
-#define MSM_DENSE_CELLS ((int64_t)1 << 28)
+// scratch of a count, kept between calls by a context (hipMalloc costs more than
+// the kernels)
+struct EkMsmScratch {
+    int32_t *c = nullptr;       // squeezed labels [n + lag]
+    int32_t *cnt = nullptr;     // per-workgroup counts
+    int64_t *off = nullptr;     // their prefix sums
+    int64_t *start = nullptr, *cstart = nullptr;    // [n_trj + 1]
+    int32_t *table = nullptr;   // [n_states^2]
+    int32_t *bad = nullptr;
+    int32_t *rows = nullptr, *cols = nullptr;
+    int64_t *vals = nullptr;
+    int64_t cap_c = 0, cap_blocks = 0, cap_trj = 0, cap_cells = 0, cap_out = 0;
+};
 
-static int msm_counts_dense(int device, const int32_t *assigns,
-                            const int64_t *h_start, int64_t n, int64_t n_trj,
-                            int32_t lag_time, int32_t sliding_window,
-                            int32_t n_states, int64_t capacity, int32_t *rows_out,
-                            int32_t *cols_out, int64_t *counts_out,
-                            int64_t *nnz_out)
+static void msm_scratch_release(EkMsmScratch *w)
+{
+    if (!w)
+        return;
+    (void)hipFree(w->c);
+    (void)hipFree(w->cnt);
+    (void)hipFree(w->off);
+    (void)hipFree(w->start);
+    (void)hipFree(w->cstart);
+    (void)hipFree(w->table);
+    (void)hipFree(w->bad);
+    (void)hipFree(w->rows);
+    (void)hipFree(w->cols);
+    (void)hipFree(w->vals);
+    *w = EkMsmScratch();
+}
+
+void ek_msm_scratch_free(void *w)
+{
+    if (w) {
+        msm_scratch_release((EkMsmScratch *)w);
+        delete (EkMsmScratch *)w;
+    }
+}
+
+template <typename P>
+static hipError_t msm_grow(P *&ptr, int64_t &cap, int64_t need)
+{
+    if (need <= cap)
+        return hipSuccess;
+    (void)hipFree(ptr);
+    ptr = nullptr;
+    cap = 0;
+    const hipError_t e = hipMalloc((void **)&ptr, (size_t)need * sizeof(*ptr));
+    if (e == hipSuccess)
+        cap = need;
+    return e;
+}
+
+// d_a: the labels on the device, one per frame; h_start[t]: first frame of
+// trajectory t (h_start[n_trj] = n)
+static int msm_counts_device(hipStream_t s, EkMsmScratch &w, const int32_t *d_a,
+                             const int64_t *h_start, int64_t n, int64_t n_trj,
+                             int32_t lag_time, int32_t sliding_window,
+                             int32_t n_states, int64_t capacity, int32_t *rows_out,
+                             int32_t *cols_out, int64_t *counts_out,
+                             int64_t *nnz_out)
 {
     int rc = EK_OK;
     const int64_t n_cells = (int64_t)n_states * n_states;
     const int64_t nb = (n + MSM_WG - 1) / MSM_WG;
     const int64_t ncb = (n_cells + MSM_WG - 1) / MSM_WG;
-    const int64_t cap = std::min<int64_t>(capacity, std::min<int64_t>(n, n_cells));
-    int32_t *d_a = nullptr, *d_c = nullptr, *d_cnt = nullptr, *d_table = nullptr;
-    int32_t *d_rows = nullptr, *d_cols = nullptr, *d_bad = nullptr;
-    int64_t *d_off = nullptr, *d_start = nullptr, *d_cstart = nullptr,
-            *d_vals = nullptr;
-    hipStream_t s = nullptr;
+    const int64_t cap = std::max<int64_t>(
+        1, std::min<int64_t>(capacity, std::min<int64_t>(n, n_cells)));
     int32_t bad = 0;
     int64_t nnz = 0;
-    MSM_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-    MSM_HIP(hipMalloc((void **)&d_a, (size_t)n * sizeof(int32_t)));
-    MSM_HIP(hipMalloc((void **)&d_c, (size_t)(n + lag_time) * sizeof(int32_t)));
-    MSM_HIP(hipMalloc((void **)&d_cnt,
-                      (size_t)std::max(nb, ncb) * sizeof(int32_t)));
-    MSM_HIP(hipMalloc((void **)&d_off,
-                      (size_t)(std::max(nb, ncb) + 1) * sizeof(int64_t)));
-    MSM_HIP(hipMalloc((void **)&d_start, (size_t)(n_trj + 1) * sizeof(int64_t)));
-    MSM_HIP(hipMalloc((void **)&d_cstart, (size_t)(n_trj + 1) * sizeof(int64_t)));
-    MSM_HIP(hipMalloc((void **)&d_table, (size_t)n_cells * sizeof(int32_t)));
-    MSM_HIP(hipMalloc((void **)&d_bad, sizeof(int32_t)));
-    MSM_HIP(hipMalloc((void **)&d_rows, (size_t)std::max<int64_t>(cap, 1) * sizeof(int32_t)));
-    MSM_HIP(hipMalloc((void **)&d_cols, (size_t)std::max<int64_t>(cap, 1) * sizeof(int32_t)));
-    MSM_HIP(hipMalloc((void **)&d_vals, (size_t)std::max<int64_t>(cap, 1) * sizeof(int64_t)));
-    MSM_HIP(hipMemcpyAsync(d_a, assigns, (size_t)n * sizeof(int32_t),
+    {
+        int64_t cap_rows = w.cap_out, cap_cols = w.cap_out, cap_vals = w.cap_out;
+        int64_t cap_cnt = w.cap_blocks, cap_off = w.cap_blocks ? w.cap_blocks + 1 : 0;
+        int64_t cap_start = w.cap_trj, cap_cstart = w.cap_trj, cap_bad = w.bad ? 1 : 0;
+        hipError_t e = msm_grow(w.c, w.cap_c, n + lag_time);
+        if (e == hipSuccess)
+            e = msm_grow(w.cnt, cap_cnt, std::max(nb, ncb));
+        if (e == hipSuccess)
+            e = msm_grow(w.off, cap_off, std::max(nb, ncb) + 1);
+        if (e == hipSuccess)
+            e = msm_grow(w.start, cap_start, n_trj + 1);
+        if (e == hipSuccess)
+            e = msm_grow(w.cstart, cap_cstart, n_trj + 1);
+        if (e == hipSuccess)
+            e = msm_grow(w.table, w.cap_cells, n_cells);
+        if (e == hipSuccess)
+            e = msm_grow(w.bad, cap_bad, 1);
+        if (e == hipSuccess)
+            e = msm_grow(w.rows, cap_rows, cap);
+        if (e == hipSuccess)
+            e = msm_grow(w.cols, cap_cols, cap);
+        if (e == hipSuccess)
+            e = msm_grow(w.vals, cap_vals, cap);
+        w.cap_blocks = std::min(cap_cnt, cap_off ? cap_off - 1 : 0);
+        w.cap_trj = std::min(cap_start, cap_cstart);
+        w.cap_out = std::min(cap_rows, std::min(cap_cols, cap_vals));
+        if (e != hipSuccess)
+            return ek_set_error(e == hipErrorOutOfMemory ? EK_ENOMEM : EK_EHIP,
+                                "ek_msm_counts: %s (the count table of %d states "
+                                "is %.1f GB)", hipGetErrorString(e), n_states,
+                                (double)n_cells * 4e-9);
+    }
+    MSM_HIP(hipMemcpyAsync(w.start, h_start, (size_t)(n_trj + 1) * sizeof(int64_t),
                            hipMemcpyHostToDevice, s));
-    MSM_HIP(hipMemcpyAsync(d_start, h_start, (size_t)(n_trj + 1) * sizeof(int64_t),
-                           hipMemcpyHostToDevice, s));
-    MSM_HIP(hipMemsetAsync(d_table, 0, (size_t)n_cells * sizeof(int32_t), s));
-    MSM_HIP(hipMemsetAsync(d_bad, 0, sizeof(int32_t), s));
+    MSM_HIP(hipMemsetAsync(w.table, 0, (size_t)n_cells * sizeof(int32_t), s));
+    MSM_HIP(hipMemsetAsync(w.bad, 0, sizeof(int32_t), s));
     // 1. drop the -1 frames
     hipLaunchKernelGGL(msm_count_kernel<0>, dim3((unsigned)nb), dim3(MSM_WG), 0, s,
-                       d_a, n, d_cnt);
-    hipLaunchKernelGGL(msm_scan_kernel, dim3(1), dim3(MSM_WG), 0, s, d_cnt, nb,
-                       d_off);
+                       d_a, n, w.cnt);
+    hipLaunchKernelGGL(msm_scan_kernel, dim3(1), dim3(MSM_WG), 0, s, w.cnt, nb,
+                       w.off);
     hipLaunchKernelGGL(msm_squeeze_kernel, dim3((unsigned)nb), dim3(MSM_WG), 0, s,
-                       d_a, n, d_off, d_c);
+                       d_a, n, w.off, w.c);
     hipLaunchKernelGGL(msm_cstart2_kernel,
                        dim3(msm_blocks((n_trj + 1) * EK_WAVE)), dim3(EK_BLOCK), 0,
-                       s, d_a, n, d_start, d_off, nb, n_trj, d_cstart);
+                       s, d_a, n, w.start, w.off, nb, n_trj, w.cstart);
     // 2. the histogram (a launch over all frames; the survivors' count stays on
     //    the device)
     hipLaunchKernelGGL(msm_hist_kernel, dim3(msm_blocks(n)), dim3(EK_BLOCK), 0, s,
-                       d_c, d_cstart, n_trj, lag_time, sliding_window, n_states,
-                       d_table, d_bad);
+                       w.c, w.cstart, n_trj, lag_time, sliding_window, n_states,
+                       w.table, w.bad);
     // 3. the cells that are not zero, in (row, col) order
     hipLaunchKernelGGL(msm_count_kernel<1>, dim3((unsigned)ncb), dim3(MSM_WG), 0, s,
-                       d_table, n_cells, d_cnt);
-    hipLaunchKernelGGL(msm_scan_kernel, dim3(1), dim3(MSM_WG), 0, s, d_cnt, ncb,
-                       d_off);
+                       w.table, n_cells, w.cnt);
+    hipLaunchKernelGGL(msm_scan_kernel, dim3(1), dim3(MSM_WG), 0, s, w.cnt, ncb,
+                       w.off);
     hipLaunchKernelGGL(msm_cells_kernel, dim3((unsigned)ncb), dim3(MSM_WG), 0, s,
-                       d_table, n_cells, n_states, d_off, cap, d_rows, d_cols,
-                       d_vals);
+                       w.table, n_cells, n_states, w.off, cap, w.rows, w.cols,
+                       w.vals);
     MSM_HIP(hipGetLastError());
-    MSM_HIP(hipMemcpyAsync(&nnz, d_off + ncb, sizeof(int64_t), hipMemcpyDeviceToHost,
+    MSM_HIP(hipMemcpyAsync(&nnz, w.off + ncb, sizeof(int64_t), hipMemcpyDeviceToHost,
                            s));
-    MSM_HIP(hipMemcpyAsync(&bad, d_bad, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    MSM_HIP(hipMemcpyAsync(&bad, w.bad, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     MSM_HIP(hipStreamSynchronize(s));
-    if (bad) {
-        rc = ek_set_error(EK_EARG, "ek_msm_counts: a state lies outside [0, %d)",
-                          n_states);
-        goto done;
-    }
-    if (nnz > capacity) {
-        rc = ek_set_error(EK_EARG, "ek_msm_counts: %lld entries exceed the "
-                                   "capacity %lld", (long long)nnz,
-                          (long long)capacity);
-        goto done;
-    }
+    if (bad)
+        return ek_set_error(EK_EARG, "ek_msm_counts: a state lies outside [0, %d)",
+                            n_states);
+    if (nnz > capacity)
+        return ek_set_error(EK_EARG, "ek_msm_counts: %lld entries exceed the "
+                                     "capacity %lld", (long long)nnz,
+                            (long long)capacity);
     if (nnz > 0) {
-        MSM_HIP(hipMemcpyAsync(rows_out, d_rows, (size_t)nnz * sizeof(int32_t),
+        MSM_HIP(hipMemcpyAsync(rows_out, w.rows, (size_t)nnz * sizeof(int32_t),
                                hipMemcpyDeviceToHost, s));
-        MSM_HIP(hipMemcpyAsync(cols_out, d_cols, (size_t)nnz * sizeof(int32_t),
+        MSM_HIP(hipMemcpyAsync(cols_out, w.cols, (size_t)nnz * sizeof(int32_t),
                                hipMemcpyDeviceToHost, s));
-        MSM_HIP(hipMemcpyAsync(counts_out, d_vals, (size_t)nnz * sizeof(int64_t),
+        MSM_HIP(hipMemcpyAsync(counts_out, w.vals, (size_t)nnz * sizeof(int64_t),
                                hipMemcpyDeviceToHost, s));
         MSM_HIP(hipStreamSynchronize(s));
     }
     *nnz_out = nnz;
 done:
-    if (s)
-        (void)hipStreamSynchronize(s);
-    (void)hipFree(d_a);
-    (void)hipFree(d_c);
-    (void)hipFree(d_cnt);
-    (void)hipFree(d_off);
-    (void)hipFree(d_start);
-    (void)hipFree(d_cstart);
-    (void)hipFree(d_table);
-    (void)hipFree(d_bad);
-    (void)hipFree(d_rows);
-    (void)hipFree(d_cols);
-    (void)hipFree(d_vals);
-    if (s)
-        (void)hipStreamDestroy(s);
     return rc;
+}
+
+// -> starts[n_trj + 1] (malloc'd), *n_out = frames in all; nullptr on a bad length
+static int64_t *msm_starts(const int64_t *lengths, int64_t n_trj, int64_t *n_out)
+{
+    int64_t *starts = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n_trj + 1));
+    if (!starts)
+        return nullptr;
+    starts[0] = 0;
+    for (int64_t t = 0; t < n_trj; ++t) {
+        if (lengths[t] < 0) {
+            free(starts);
+            return nullptr;
+        }
+        starts[t + 1] = starts[t] + lengths[t];
+    }
+    *n_out = starts[n_trj];
+    return starts;
 }
 
 extern "C" int ek_msm_counts(int device, const int32_t *assigns,
@@ -416,188 +402,91 @@ extern "C" int ek_msm_counts(int device, const int32_t *assigns,
     if (!lengths || !nnz_out || n_trj < 0 || lag_time < 1 || n_states < 1)
         return ek_set_error(EK_EARG, "ek_msm_counts: bad argument");
     int64_t n = 0;
-    for (int64_t t = 0; t < n_trj; ++t) {
-        if (lengths[t] < 0)
-            return ek_set_error(EK_EARG, "ek_msm_counts: negative length");
-        n += lengths[t];
-    }
+    int64_t *starts = msm_starts(lengths, n_trj, &n);
+    if (!starts)
+        return ek_set_error(EK_EARG, "ek_msm_counts: negative length (or out of "
+                                     "host memory)");
     *nnz_out = 0;
-    if (n == 0 || n_trj == 0)
-        return EK_OK;
-    if (!assigns)
-        return ek_set_error(EK_EARG, "ek_msm_counts: assigns is NULL");
-    if ((int64_t)n_states * n_states <= MSM_DENSE_CELLS && n < ((int64_t)1 << 31)) {
-        // the histogram form (int32 cells: a count cannot exceed the frames)
-        hipError_t e0 = hipSetDevice(device);
-        if (e0 != hipSuccess)
-            return ek_set_error(EK_EHIP, "hipSetDevice(%d): %s", device,
-                                hipGetErrorString(e0));
-        int64_t *starts = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n_trj + 1));
-        if (!starts)
-            return ek_set_error(EK_ENOMEM, "ek_msm_counts: out of host memory");
-        starts[0] = 0;
-        for (int64_t t = 0; t < n_trj; ++t)
-            starts[t + 1] = starts[t] + lengths[t];
-        rc = msm_counts_dense(device, assigns, starts, n, n_trj, lag_time,
-                              sliding_window, n_states, capacity, rows_out,
-                              cols_out, counts_out, nnz_out);
+    if (n == 0 || n_trj == 0) {
         free(starts);
-        return rc;
+        return EK_OK;
     }
-
-    int32_t *d_a = nullptr, *d_valid = nullptr, *d_c = nullptr;
-    int64_t *d_pos = nullptr, *d_start = nullptr, *d_cstart = nullptr;
-    unsigned long long *d_keys = nullptr, *d_keys2 = nullptr, *d_ukeys = nullptr;
-    int64_t *d_ucnt = nullptr, *d_runs = nullptr, *d_vals = nullptr;
-    int32_t *d_rows = nullptr, *d_cols = nullptr;
-    void *d_tmp = nullptr;
-    size_t tmp_bytes = 0, need = 0;
-    int64_t *h_start = nullptr;
+    EkMsmScratch w;
+    int32_t *d_a = nullptr;
     hipStream_t s = nullptr;
-    int64_t m = 0, runs = 0;
-    int32_t last_valid = 0;
-    int64_t last_pos = 0;
-    int end_bit = 64;
-
-    {
-        hipError_t e0 = hipSetDevice(device);
-        if (e0 != hipSuccess)
-            return ek_set_error(EK_EHIP, "hipSetDevice(%d): %s", device,
-                                hipGetErrorString(e0));
-    }
-    MSM_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-    h_start = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n_trj + 1));
-    if (!h_start) {
-        rc = ek_set_error(EK_ENOMEM, "ek_msm_counts: out of host memory");
+    if (!assigns) {
+        rc = ek_set_error(EK_EARG, "ek_msm_counts: assigns is NULL");
         goto done;
     }
-    h_start[0] = 0;
-    for (int64_t t = 0; t < n_trj; ++t)
-        h_start[t + 1] = h_start[t] + lengths[t];
-
+    if (n >= ((int64_t)1 << 31)) {
+        rc = ek_set_error(EK_EARG, "ek_msm_counts: %lld frames: a cell of the int32 "
+                                   "table could overflow", (long long)n);
+        goto done;
+    }
+    MSM_HIP(hipSetDevice(device));
+    MSM_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     MSM_HIP(hipMalloc((void **)&d_a, (size_t)n * sizeof(int32_t)));
-    MSM_HIP(hipMalloc((void **)&d_valid, (size_t)n * sizeof(int32_t)));
-    MSM_HIP(hipMalloc((void **)&d_pos, (size_t)n * sizeof(int64_t)));
-    MSM_HIP(hipMalloc((void **)&d_c, (size_t)(n + lag_time) * sizeof(int32_t)));
-    MSM_HIP(hipMalloc((void **)&d_start, (size_t)(n_trj + 1) * sizeof(int64_t)));
-    MSM_HIP(hipMalloc((void **)&d_cstart, (size_t)(n_trj + 1) * sizeof(int64_t)));
     MSM_HIP(hipMemcpyAsync(d_a, assigns, (size_t)n * sizeof(int32_t),
                            hipMemcpyHostToDevice, s));
-    MSM_HIP(hipMemcpyAsync(d_start, h_start,
-                           (size_t)(n_trj + 1) * sizeof(int64_t),
-                           hipMemcpyHostToDevice, s));
-
-    // 1. drop the -1 frames (transition_matrices.py:156): flags -> scan -> scatter
-    hipLaunchKernelGGL(msm_valid_kernel, dim3(msm_blocks(n)), dim3(EK_BLOCK), 0,
-                       s, d_a, n, d_valid);
-    MSM_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, need, d_valid, d_pos, n, s));
-    tmp_bytes = need;
-    MSM_HIP(hipMalloc(&d_tmp, tmp_bytes));
-    MSM_HIP(hipcub::DeviceScan::ExclusiveSum(d_tmp, need, d_valid, d_pos, n, s));
-    MSM_HIP(hipMemcpyAsync(&last_valid, d_valid + (n - 1), sizeof(int32_t),
-                           hipMemcpyDeviceToHost, s));
-    MSM_HIP(hipMemcpyAsync(&last_pos, d_pos + (n - 1), sizeof(int64_t),
-                           hipMemcpyDeviceToHost, s));
-    MSM_HIP(hipStreamSynchronize(s));
-    m = last_pos + last_valid;                       // frames that survive
-    if (m <= lag_time)
-        goto done;
-    hipLaunchKernelGGL(msm_compact_kernel, dim3(msm_blocks(n)), dim3(EK_BLOCK),
-                       0, s, d_a, d_pos, n, d_c);
-    hipLaunchKernelGGL(msm_cstart_kernel, dim3(msm_blocks(n_trj + 1)),
-                       dim3(EK_BLOCK), 0, s, d_start, d_pos, n_trj, n, m,
-                       d_cstart);
-
-    // 2. one key per (start, end) pair (:310-321), sentinel where none
-    MSM_HIP(hipMalloc((void **)&d_keys, (size_t)m * sizeof(unsigned long long)));
-    MSM_HIP(hipMalloc((void **)&d_keys2, (size_t)m * sizeof(unsigned long long)));
-    hipLaunchKernelGGL(msm_keys_kernel, dim3(msm_blocks(m)), dim3(EK_BLOCK), 0,
-                       s, d_c, d_cstart, n_trj, m, lag_time, sliding_window,
-                       (int64_t)n_states, d_keys);
-
-    // 3. sort + run-length encode = the duplicate-summing of the COO->CSR
-    //    conversion (:167-169)
-    need = 0;
-    MSM_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, need, d_keys, d_keys2, m,
-                                              0, end_bit, s));
-    if (need > tmp_bytes) {
-        MSM_HIP(hipFree(d_tmp));
-        d_tmp = nullptr;
-        tmp_bytes = need;
-        MSM_HIP(hipMalloc(&d_tmp, tmp_bytes));
-    }
-    MSM_HIP(hipcub::DeviceRadixSort::SortKeys(d_tmp, need, d_keys, d_keys2, m, 0,
-                                              end_bit, s));
-    MSM_HIP(hipMalloc((void **)&d_ukeys, (size_t)m * sizeof(unsigned long long)));
-    MSM_HIP(hipMalloc((void **)&d_ucnt, (size_t)m * sizeof(int64_t)));
-    MSM_HIP(hipMalloc((void **)&d_runs, sizeof(int64_t)));
-    need = 0;
-    MSM_HIP(hipcub::DeviceRunLengthEncode::Encode(nullptr, need, d_keys2, d_ukeys,
-                                                  d_ucnt, d_runs, m, s));
-    if (need > tmp_bytes) {
-        MSM_HIP(hipFree(d_tmp));
-        d_tmp = nullptr;
-        tmp_bytes = need;
-        MSM_HIP(hipMalloc(&d_tmp, tmp_bytes));
-    }
-    MSM_HIP(hipcub::DeviceRunLengthEncode::Encode(d_tmp, need, d_keys2, d_ukeys,
-                                                  d_ucnt, d_runs, m, s));
-    MSM_HIP(hipMemcpyAsync(&runs, d_runs, sizeof(int64_t), hipMemcpyDeviceToHost,
-                           s));
-    MSM_HIP(hipStreamSynchronize(s));
-    if (runs > 0) {
-        MSM_HIP(hipMalloc((void **)&d_rows, (size_t)runs * sizeof(int32_t)));
-        MSM_HIP(hipMalloc((void **)&d_cols, (size_t)runs * sizeof(int32_t)));
-        MSM_HIP(hipMalloc((void **)&d_vals, (size_t)runs * sizeof(int64_t)));
-        hipLaunchKernelGGL(msm_split_kernel, dim3(msm_blocks(runs)),
-                           dim3(EK_BLOCK), 0, s, d_ukeys, d_ucnt, runs,
-                           (int64_t)n_states, d_rows, d_cols, d_vals);
-        // the sentinel run, if any, sorts last
-        unsigned long long lastkey = 0;
-        MSM_HIP(hipMemcpyAsync(&lastkey, d_ukeys + (runs - 1), sizeof(lastkey),
-                               hipMemcpyDeviceToHost, s));
-        MSM_HIP(hipStreamSynchronize(s));
-        const int64_t nnz = (lastkey == ~0ull) ? runs - 1 : runs;
-        if (nnz > capacity) {
-            rc = ek_set_error(EK_EARG, "ek_msm_counts: %lld entries exceed the "
-                                       "capacity %lld", (long long)nnz,
-                              (long long)capacity);
-            goto done;
-        }
-        if (nnz > 0) {
-            MSM_HIP(hipMemcpyAsync(rows_out, d_rows, (size_t)nnz * sizeof(int32_t),
-                                   hipMemcpyDeviceToHost, s));
-            MSM_HIP(hipMemcpyAsync(cols_out, d_cols, (size_t)nnz * sizeof(int32_t),
-                                   hipMemcpyDeviceToHost, s));
-            MSM_HIP(hipMemcpyAsync(counts_out, d_vals,
-                                   (size_t)nnz * sizeof(int64_t),
-                                   hipMemcpyDeviceToHost, s));
-            MSM_HIP(hipStreamSynchronize(s));
-        }
-        *nnz_out = nnz;
-    }
-
+    rc = msm_counts_device(s, w, d_a, starts, n, n_trj, lag_time, sliding_window,
+                           n_states, capacity, rows_out, cols_out, counts_out,
+                           nnz_out);
 done:
     if (s)
         (void)hipStreamSynchronize(s);
     (void)hipFree(d_a);
-    (void)hipFree(d_valid);
-    (void)hipFree(d_pos);
-    (void)hipFree(d_c);
-    (void)hipFree(d_start);
-    (void)hipFree(d_cstart);
-    (void)hipFree(d_keys);
-    (void)hipFree(d_keys2);
-    (void)hipFree(d_ukeys);
-    (void)hipFree(d_ucnt);
-    (void)hipFree(d_runs);
-    (void)hipFree(d_rows);
-    (void)hipFree(d_cols);
-    (void)hipFree(d_vals);
-    (void)hipFree(d_tmp);
-    free(h_start);
+    msm_scratch_release(&w);
+    free(starts);
     if (s)
         (void)hipStreamDestroy(s);
+    return rc;
+}
+
+// the labels a fit left in the context's HBM (dist / assign of its n frames, in
+// frame order), `lengths` saying how the frames split into trajectories
+extern "C" int ek_msm_counts_ctx(ek_ctx *ctx, const int64_t *lengths, int64_t n_trj,
+                                 int32_t lag_time, int32_t sliding_window,
+                                 int32_t n_states, int64_t capacity,
+                                 int32_t *rows_out, int32_t *cols_out,
+                                 int64_t *counts_out, int64_t *nnz_out)
+{
+    if (!ctx || !lengths || !nnz_out || n_trj < 0 || lag_time < 1 || n_states < 1)
+        return ek_set_error(EK_EARG, "ek_msm_counts_ctx: bad argument");
+    int device = 0;
+    int64_t n_ctx = 0;
+    const int32_t *d_a = nullptr;
+    hipStream_t s = nullptr;
+    void **slot = nullptr;
+    ek_ctx_msm_view(ctx, &device, &n_ctx, &d_a, &s, &slot);
+    int64_t n = 0;
+    int64_t *starts = msm_starts(lengths, n_trj, &n);
+    if (!starts)
+        return ek_set_error(EK_EARG, "ek_msm_counts_ctx: negative length (or out of "
+                                     "host memory)");
+    int rc = EK_OK;
+    *nnz_out = 0;
+    if (n != n_ctx) {
+        rc = ek_set_error(EK_EARG, "ek_msm_counts_ctx: the lengths add up to %lld "
+                                   "frames, the context holds %lld", (long long)n,
+                          (long long)n_ctx);
+    } else if (n > 0 && n_trj > 0) {
+        hipError_t e = hipSetDevice(device);
+        if (e != hipSuccess) {
+            rc = ek_set_error(EK_EHIP, "hipSetDevice(%d): %s", device,
+                              hipGetErrorString(e));
+        } else {
+            if (!*slot)
+                *slot = new (std::nothrow) EkMsmScratch();
+            if (!*slot)
+                rc = ek_set_error(EK_ENOMEM, "ek_msm_counts_ctx: out of host memory");
+            else
+                rc = msm_counts_device(s, *(EkMsmScratch *)*slot, d_a, starts, n,
+                                       n_trj, lag_time, sliding_window, n_states,
+                                       capacity, rows_out, cols_out, counts_out,
+                                       nnz_out);
+        }
+    }
+    free(starts);
     return rc;
 }
 

@@ -372,6 +372,26 @@ class FrameStore:
         _lib.check(self.lib.ek_spec_rounds(self._h, C.byref(r)))
         return r.value
 
+    # -- MSM counts over the resident labels (csrc/ek_msm.hip) ------------------
+    def msm_counts(self, lengths, lag_time, n_states, sliding_window=True):
+        """Transition counts of the labels this store holds (after a fit or
+        assign_nearest), split into trajectories of `lengths` frames: COO
+        (rows int32, cols int32, counts int64) sorted by (row, col).  The labels
+        do not leave the device (reference flow: cluster -> assigns_to_counts,
+        enspara/msm/transition_matrices.py:113-170)."""
+        lengths = np.ascontiguousarray(lengths, dtype=np.int64)
+        cap = max(1, min(int(self.n), int(n_states) * int(n_states)))
+        rows = np.empty(cap, dtype=np.int32)
+        cols = np.empty(cap, dtype=np.int32)
+        vals = np.empty(cap, dtype=np.int64)
+        nnz = C.c_int64()
+        _lib.check(self.lib.ek_msm_counts_ctx(
+            self._h, _lib.i64p(lengths), len(lengths), int(lag_time),
+            1 if sliding_window else 0, int(n_states), cap, _lib.i32p(rows),
+            _lib.i32p(cols), _lib.i64p(vals), C.byref(nnz)))
+        k = nnz.value
+        return rows[:k], cols[:k], vals[:k]
+
     # -- rounds across shards, one exchange per round (csrc/ek_mshard.hip) ------
     def ms_setup(self, world, rank):
         """-> bytes of a shard's round message"""

@@ -41,7 +41,7 @@ def _rows_of(assigns):
 
 
 def assigns_to_counts(assigns, lag_time, max_n_states=None,
-                      sliding_window=True, device=0):
+                      sliding_window=True, device=0, lengths=None):
     """Count transitions (reference transition_matrices.py:113-170).
 
     Returns a scipy.sparse.coo_matrix of int counts, shape
@@ -49,6 +49,12 @@ def assigns_to_counts(assigns, lag_time, max_n_states=None,
     per observed transition, summed only on conversion) duplicates are already
     summed and entries are sorted by (row, col); every derived quantity
     (todense, tocsr, arithmetic) is identical.
+
+    ``assigns`` may also be a :class:`enspara_amd.device.FrameStore` whose
+    labels are resident on the GPU after a fit -- the reference pipes
+    ``result.assignments`` straight into this function; here they need not
+    leave the device in between.  Then ``lengths`` (frames per trajectory, in
+    the store's frame order) and ``max_n_states`` are required.
     """
     if not isinstance(lag_time, numbers.Integral):
         raise DataInvalid("The lag time must be an integer. Got %s type %s."
@@ -56,6 +62,21 @@ def assigns_to_counts(assigns, lag_time, max_n_states=None,
     if lag_time < 1:
         raise DataInvalid("Lag times must be be strictly greater than 0. "
                           "Got '%s'." % lag_time)
+    if hasattr(assigns, "msm_counts"):
+        if lengths is None or max_n_states is None:
+            raise DataInvalid("counting over a FrameStore's resident labels "
+                              "needs lengths= and max_n_states=")
+        if sum(int(v) for v in lengths) != assigns.n:
+            raise DataInvalid("lengths add up to %d frames, the store holds %d"
+                              % (sum(int(v) for v in lengths), assigns.n))
+        max_n_states = int(max_n_states)
+        if max_n_states == 0 or assigns.n == 0:
+            return scipy.sparse.coo_matrix((max_n_states, max_n_states),
+                                           dtype=int)
+        r, c, v = assigns.msm_counts(lengths, lag_time, max_n_states,
+                                     sliding_window)
+        return scipy.sparse.coo_matrix((v.astype(int), (r, c)),
+                                       shape=(max_n_states, max_n_states))
     flat, lengths = _rows_of(assigns)
     if max_n_states is None:
         kept = flat[flat != -1]

@@ -410,6 +410,15 @@ int ek_msm_counts(int device, const int32_t *assigns, const int64_t *lengths,
                   int64_t n_trj, int32_t lag_time, int32_t sliding_window,
                   int32_t n_states, int64_t capacity, int32_t *rows_out,
                   int32_t *cols_out, int64_t *counts_out, int64_t *nnz_out);
+/* The same count over the labels a fit left in the context's HBM (the
+ * reference pipes result.assignments into assigns_to_counts,
+ * transition_matrices.py:113: here they need not leave the device in between).
+ * lengths[n_trj]: how the context's frames, in order, split into trajectories
+ * (they must add up to its frame count). */
+int ek_msm_counts_ctx(ek_ctx *ctx, const int64_t *lengths, int64_t n_trj,
+                      int32_t lag_time, int32_t sliding_window, int32_t n_states,
+                      int64_t capacity, int32_t *rows_out, int32_t *cols_out,
+                      int64_t *counts_out, int64_t *nnz_out);
 /* ek_msm_row_normalize replaces _row_normalize's sparse branch
  * (enspara/msm/builders.py:188-196) on a CSR matrix (host arrays):
  * probs = diag(1/rowsum) * data, empty rows stay zero.  rowsum_out may be

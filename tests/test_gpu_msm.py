@@ -60,7 +60,7 @@ def test_counts_edge_cases():
     C = assigns_to_counts([np.array([0, 1]), np.array([2, 2, 2, 2])],
                           lag_time=3).toarray()
     assert C.sum() == 1 and C[2, 2] == 1
-    # more states than the dense count table takes (> 16 384): the sorted-key form
+    # 20 000 states (BASELINE.json configs[3]'s center count): a 1.6 GB count table
     C = assigns_to_counts(a, lag_time=1, max_n_states=20000)
     assert C.shape == (20000, 20000) and C.nnz == 4
     np.testing.assert_array_equal(C.tocsr()[:3, :3].toarray(),
@@ -138,6 +138,81 @@ def test_msm_build_at_scale():
     np.testing.assert_allclose(vals, want.real, atol=1e-8)
     np.testing.assert_allclose(m.eq_probs_, vecs[:, 0], atol=1e-9)
     assert abs(m.eq_probs_.sum() - 1) < 1e-12
+
+
+def _scipy_counts(A, lag, K):
+    rows, cols = [], []
+    for a in A:
+        a = a[a != -1]
+        rows.append(a[:-lag])
+        cols.append(a[lag:])
+    return scipy.sparse.coo_matrix(
+        (np.ones(sum(len(r) for r in rows), dtype=np.int64),
+         (np.concatenate(rows), np.concatenate(cols))), shape=(K, K)).tocsr()
+
+
+def test_msm_build_at_full_size():
+    """BASELINE.json configs[4] at its own size: 10^7 frames of assignments
+    (1000 trajectories of 10^4, ~0.1 % of them -1) over 5000 states -> counts
+    (exact against a scipy construction), row-normalised probabilities, top-20
+    eigenvalues (against ARPACK on the same matrix, 1e-8)"""
+    import scipy.sparse.linalg
+    from enspara_amd.msm import MSM, eigenspectrum
+    rng = np.random.RandomState(11)
+    K, n_trj, L, lag = 5000, 1000, 10000, 1
+    # 50 metastable blocks of 100 states, rare hops between blocks (a spectrum
+    # with gaps: see test_msm_build_at_scale)
+    steps = rng.choice(np.array([-3, -2, -1, 0, 0, 1, 2, 3], dtype=np.int8),
+                       size=(n_trj, L))
+    inblock = (rng.randint(100, size=(n_trj, 1)) +
+               np.cumsum(steps, axis=1, dtype=np.int32)) % 100
+    hops = np.cumsum(rng.rand(n_trj, L) < 0.002, axis=1, dtype=np.int32)
+    block = (rng.randint(50, size=(n_trj, 1)) + hops * 7) % 50
+    A = (block * 100 + inblock).astype(np.int32)
+    A[rng.rand(n_trj, L) < 0.001] = -1
+    del steps, inblock, hops, block
+    m = MSM(lag_time=lag, method="normalize", max_n_states=K)
+    m.fit(A)
+    ref = _scipy_counts(A, lag, K)
+    assert (m.tcounts_.tocsr() != ref).nnz == 0
+    Tref = scipy.sparse.diags(1.0 / np.asarray(ref.sum(axis=1)).ravel()) @ ref
+    assert abs(m.tprobs_.tocsr() - Tref).max() < 1e-15
+    vals, vecs = eigenspectrum(m.tprobs_, n_eigs=20)
+    want = scipy.sparse.linalg.eigs(Tref.T.tocsr(), k=20, which="LR", tol=1e-12,
+                                    return_eigenvectors=False)
+    want = np.sort(want.real)[::-1]
+    np.testing.assert_allclose(vals, want, atol=1e-8)
+    assert abs(vecs[:, 0].sum() - 1) < 1e-12
+
+
+def test_counts_over_resident_labels():
+    """cluster -> assigns_to_counts without the labels leaving the device
+    (reference flow, transition_matrices.py:113-170): the same COO as counting
+    the downloaded labels, for equal and ragged trajectory lengths, both window
+    forms; the scratch of the first call is reused by the next"""
+    from enspara_amd import synth
+    from enspara_amd.device import FrameStore
+    from enspara_amd.exception import DataInvalid
+    from enspara_amd.msm import assigns_to_counts
+    n, A, K = 30000, 12, 150
+    x = synth.synth(n, A, 40, seed=8)
+    with FrameStore.from_array(x) as st:
+        st.reset_state()
+        st.kcenters_run(0, K, 0.0)
+        _, labels = st.download_state()
+        for lengths in ([n // 10] * 10, [1, 7000, 0, 12999, 10000]):
+            for lag, sliding in ((1, True), (7, True), (5, False)):
+                got = assigns_to_counts(st, lag, max_n_states=K, lengths=lengths,
+                                        sliding_window=sliding)
+                rows = np.split(labels, np.cumsum(lengths)[:-1])
+                want = assigns_to_counts(rows, lag, max_n_states=K,
+                                         sliding_window=sliding)
+                assert (got.tocsr() != want.tocsr()).nnz == 0
+                assert got.sum() == want.sum() > 0
+        with pytest.raises(DataInvalid):
+            assigns_to_counts(st, 1, max_n_states=K, lengths=[n - 1])
+        with pytest.raises(DataInvalid):
+            assigns_to_counts(st, 1, lengths=[n])
 
 
 def test_implied_timescales_match_reference(M):
