@@ -19,14 +19,21 @@ it started are used as they are.  Default there is STRONG scaling -- the same
 1,000,000 frames split into N contiguous blocks --
 `--scaling weak` holds 1,000,000 frames per GPU instead.
 
-The frames are streamed once per ROUND against up to 8 candidate centers and
+The frames are streamed once per ROUND against up to 16 candidate centers and
 further centers are accepted from the stored distances while the farthest
-point is one of them (csrc/ek_spec.hip): the same sequential
-algorithm and bit-identical results with fewer passes over HBM.  The fit moves
-between 1, 4 and 8 candidates per pass by the centers per millisecond each
-achieves (`--candidates 1|4|8` pins one form; 1 is the HBM roofline case of
-BASELINE.md).  Every reported pair is a distance the result depends on;
-guesses that were never used are not counted ("pairs_computed" has the total).
+point is one of them (csrc/ek_spec.hip, ek_pass16.hip): the same
+sequential algorithm and bit-identical results with fewer passes over HBM.
+The fit moves between 1, 8 and 16 candidates per pass by the centers per
+millisecond each achieves (`--candidates 1|4|8|16` pins one form; 1 is the HBM
+roofline case of BASELINE.md).  Every reported pair is a distance the result
+depends on; guesses that were never used are not counted ("pairs_computed" has
+the total).  `roofline` describes the kernel most passes ran: the 16-candidate
+pass is a dense contraction on the matrix cores (bound "mfma", its HBM figures
+beside it), the 8-candidate and one-center passes are HBM-bound.
+
+N > 1: the rounds exchange one message per shard and round through peer
+mailboxes written on the device (csrc/ek_mshard.hip; `--transport gather` uses
+one RCCL all-gather per round instead).
 
 Inputs are resident in HBM (already centred and laid out frame-minor) when the
 timed region starts; generation, upload and layout are reported separately in
@@ -48,7 +55,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E nominal (MI355X_MICROARCH.md)
-HBM_COPY_CEILING_GBS = 6290.0  # measured float4 copy on MI355X (same guide)
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X dense f32 matrix peak (same guide)
 
 
 def bytes_per_pair(n_atoms):
@@ -78,12 +85,22 @@ def parse():
                         "target of BASELINE.md) or hold --frames on each")
     p.add_argument("--atoms", type=int, default=300)
     p.add_argument("--templates", type=int, default=5000)
+    p.add_argument("--data", choices=["templates", "walk"], default="templates",
+                   help="templates: noisy copies of --templates chains in random "
+                        "order (BASELINE's synthetic set); walk: one time-ordered "
+                        "trajectory on a continuous landscape (one GPU only)")
     p.add_argument("--seed", type=int, default=1)
     p.add_argument("--fpl", type=int, default=0,
                    help="frames per lane of the one-center kernel (0 = auto)")
     p.add_argument("--candidates", type=int, default=-1,
                    help="candidate centers per pass: -1 by measured rate "
-                        "(1, 4, 8), or pin 1, 4 or 8")
+                        "(1, 8, 16), or pin 1, 4, 8 or 16")
+    p.add_argument("--transport", choices=["mailbox", "gather"], default="mailbox",
+                   help="N > 1 / --sharded: a round's exchange through peer "
+                        "mailboxes on the device, or one all-gather per round")
+    p.add_argument("--no-msm", action="store_true",
+                   help="skip the MSM block (BASELINE.json configs[4])")
+    p.add_argument("--msm-frames", type=int, default=10_000_000)
     p.add_argument("--cpu-seconds", type=float, default=15.0,
                    help="time budget of the CPU baseline leg (rank 0, N=1)")
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -124,11 +141,31 @@ def spawn_ranks(args):
         procs.append(subprocess.Popen(
             [sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
             env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
+    # rank 0's line is read by a thread; all children are watched: the first one
+    # to fail takes the others down instead of leaving them in a collective
+    import threading
+    out = []
+    t = threading.Thread(target=lambda: out.append(procs[0].stdout.read()))
+    t.start()
+    bad = []
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c]
+        if bad or all(c is not None for c in codes):
+            break
+        time.sleep(0.2)
+    if bad:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    t.join(timeout=10)
+    sys.stdout.write(b"".join(out).decode())
     sys.stdout.flush()
-    bad = [(r, c) for r, c in enumerate(codes) if c]
     if bad:
         raise SystemExit("ranks failed (rank, exit code): %s" % bad)
 
@@ -300,6 +337,148 @@ def mdtraj_leg(x, centers, seconds):
         return {"available": False, "why": "%s: %s" % (type(e).__name__, e)}
 
 
+def copy_ceiling(nbytes, device):
+    """The device-to-device copy rate of this GPU, in this process: a
+    16-byte-per-lane non-temporal copy of `nbytes` (read + write = 2 x nbytes of
+    HBM traffic), best of four (csrc/ek_api.hip ek_hbm_copy_rate).  The ceiling
+    a streaming kernel can be compared with besides the nominal peak."""
+    import ctypes as C
+    from enspara_amd import _lib
+    g = C.c_double()
+    _lib.check(_lib.load().ek_hbm_copy_rate(int(device), int(nbytes), C.byref(g)))
+    return g.value
+
+
+def msm_block(args):
+    """BASELINE.json configs[4]: 10^7 frames of assignments -> sparse transition
+    counts -> row-normalise -> top-20 eigenpairs, on the device, with a scipy
+    construction of the same matrix (and ARPACK on it) as the CPU figure.  The
+    assignments are a seeded banded walk inside metastable blocks with rare hops
+    (SURVEY.md 8d), ~0.1 % of the frames -1."""
+    import scipy.sparse
+    import scipy.sparse.linalg
+    from enspara_amd.device import FrameStore
+    from enspara_amd.msm import assigns_to_counts, builders, eigenspectrum
+    K, L, lag = 5000, 10000, 1
+    n_trj = max(1, args.msm_frames // L)
+    rng = np.random.RandomState(11)
+    steps = rng.choice(np.array([-3, -2, -1, 0, 0, 1, 2, 3], dtype=np.int8),
+                       size=(n_trj, L))
+    inblock = (rng.randint(100, size=(n_trj, 1)) +
+               np.cumsum(steps, axis=1, dtype=np.int32)) % 100
+    hops = np.cumsum(rng.rand(n_trj, L) < 0.002, axis=1, dtype=np.int32)
+    block = (rng.randint(K // 100, size=(n_trj, 1)) + hops * 7) % (K // 100)
+    A = (block * 100 + inblock).astype(np.int32)
+    A[rng.rand(n_trj, L) < 0.001] = -1
+    del steps, inblock, hops, block
+    n = A.size
+
+    def best_of(f, reps=3):
+        out, best = None, None
+        for _ in range(reps):
+            t = time.perf_counter()
+            out = f()
+            dt = time.perf_counter() - t
+            best = dt if best is None else min(best, dt)
+        return out, best
+    C, t_host = best_of(lambda: assigns_to_counts(A, lag, max_n_states=K))
+    # the same labels resident on the device, as a fit leaves them
+    st = FrameStore(n, 1, device=0)
+    st.load(np.zeros((n, 1, 3), dtype=np.float32))
+    st.upload_state(np.zeros(n, dtype=np.float32), A.reshape(-1))
+    st.msm_counts([L] * n_trj, lag, K)          # (buffers allocated)
+    st.sync()
+    res, t_res = best_of(lambda: st.msm_counts([L] * n_trj, lag, K))
+    st.close()
+    Cr = scipy.sparse.coo_matrix((res[2], (res[0], res[1])), shape=(K, K)).tocsr()
+    (Cn, T, _), t_norm = best_of(
+        lambda: builders.normalize(C, calculate_eq_probs=False), reps=2)
+    (vals, vecs), t_eig = best_of(lambda: eigenspectrum(T, n_eigs=20), reps=1)
+    # CPU: the reference's own construction (a COO of ones, summed on conversion)
+    t0 = time.perf_counter()
+    rows, cols = [], []
+    for a in A:
+        a = a[a != -1]
+        rows.append(a[:-lag])
+        cols.append(a[lag:])
+    ref = scipy.sparse.coo_matrix(
+        (np.ones(sum(len(r) for r in rows), dtype=np.int64),
+         (np.concatenate(rows), np.concatenate(cols))), shape=(K, K)).tocsr()
+    t_cpu_counts = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    Tref = scipy.sparse.diags(1.0 / np.asarray(ref.sum(axis=1)).ravel()) @ ref
+    t_cpu_norm = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    want = scipy.sparse.linalg.eigs(Tref.T.tocsr(), k=20, which="LR", tol=1e-12,
+                                    return_eigenvectors=False)
+    t_cpu_eig = time.perf_counter() - t0
+    want = np.sort(want.real)[::-1]
+    return {
+        "workload": "MSM build, %d frames of assignments in %d trajectories, %d "
+                    "states, lag %d, top-20 eigenpairs (BASELINE.json configs[4])"
+                    % (n, n_trj, K, lag),
+        "counts_s_labels_resident_on_device": t_res,
+        "counts_s_labels_from_host_arrays": t_host,
+        "transitions_per_s_resident": n / t_res,
+        "GBps_vs_8_bytes_per_transition_resident": 8.0 * n / t_res / 1e9,
+        "nonzero_cells": int(C.nnz),
+        "normalize_s": t_norm,
+        "top20_eigenpairs_s": t_eig,
+        "counts_equal_scipy": bool((C.tocsr() != ref).nnz == 0 and
+                                   (Cr != ref).nnz == 0),
+        "probabilities_max_abs_diff_vs_scipy": float(abs(T.tocsr() - Tref).max()),
+        "eigenvalues_max_abs_diff_vs_arpack": float(np.abs(vals - want).max()),
+        "cpu_scipy": {"counts_s": t_cpu_counts, "normalize_s": t_cpu_norm,
+                      "top20_arpack_s": t_cpu_eig,
+                      "what": "scipy.sparse COO of ones -> CSR (the reference's "
+                              "assigns_to_counts), diags @ CSR, scipy.sparse."
+                              "linalg.eigs(k=20, which='LR', tol=1e-12)"},
+    }
+
+
+def khybrid_check(x, store, start_medoids, gpu_medoids, seed, seconds):
+    """Full-size parity of the k-hybrid leg (BASELINE.json configs[2]): the
+    first proposals of the sweep replayed by the oracle's PAM
+    (oracle/cluster.py pam_update = enspara/cluster/kmedoids.py:575-699) on the
+    same frames from the same k-centers state and the same random stream, as
+    many as fit the time budget -- the medoids must be the GPU's --, and after
+    the GPU's whole sweep a sample of frames: every one's distance must be, bit
+    for bit, its RMSD to the medoid its label names."""
+    from oracle import cluster as oc
+    from oracle import qcp
+    usable, _, _ = host_threads()
+    qcp.set_num_threads(usable)
+    P = qcp.Prepared(x)
+    d0, a0 = start_medoids["dist"], start_medoids["assign"]
+    done = []
+    t0 = time.perf_counter()
+    med, _, _ = oc.pam_update(P, list(start_medoids["medoids"]),
+                              a0.astype(np.int64), d0.astype(np.float64),
+                              random_state=np.random.RandomState(seed),
+                              budget_s=seconds, done=done)
+    wall = time.perf_counter() - t0
+    k = done[0] if done else 0
+    same = [int(m) for m in med[:k]] == [int(m) for m in gpu_medoids[:k]]
+    moved = sum(1 for i in range(k)
+                if int(med[i]) != int(start_medoids["medoids"][i]))
+    # sampled state check after the whole sweep
+    d, a = store.download_state()
+    rng = np.random.RandomState(7)
+    sample = rng.choice(len(x), size=min(4000, len(x)), replace=False)
+    ok = True
+    for lab in np.unique(a[sample]):
+        fr = sample[a[sample] == lab]
+        want = qcp.rmsd_centered(np.ascontiguousarray(P.c[fr]),
+                                 np.ascontiguousarray(P.G[fr]),
+                                 P.c[int(gpu_medoids[lab])],
+                                 float(P.G[int(gpu_medoids[lab])]))
+        ok = ok and bool(np.array_equal(want, d[fr]))
+    return {"proposals_replayed_by_oracle": k, "medoids_match_gpu": bool(same),
+            "of_them_accepted": moved, "oracle_s": wall,
+            "sampled_frames": int(len(sample)),
+            "sampled_state_is_rmsd_to_own_medoid_bit_exact": bool(ok)}
+
+
 def km_width(sharded_driver):
     """Proposals drawn ahead and decided per window."""
     from enspara_amd.cluster import kmedoids as km
@@ -310,8 +489,9 @@ def kernel_source_hash():
     """Identifies the code the distance kernels were built from: the traffic
     figure below is only quoted for the sources it was measured on."""
     h = hashlib.sha256()
-    for f in ("ek_spec.hip", "ek_round.hip", "ek_kcenters.hip", "ek_qcp.h",
-              "ek_common.h", "ek_reduce.h", "ek_chain_dev.h", "ek_top_dev.h"):
+    for f in ("ek_spec.hip", "ek_pass16.hip", "ek_round.hip", "ek_kcenters.hip",
+              "ek_qcp.h", "ek_common.h", "ek_reduce.h", "ek_chain_dev.h",
+              "ek_top_dev.h"):
         with open(os.path.join(ROOT, "enspara_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -362,6 +542,9 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.steps < 1 or args.warmup < 0:
         raise SystemExit("--steps >= 1 and --warmup >= 0")
+    if args.steps > args.centers:
+        raise SystemExit("--steps %d > --centers %d: a step is at least one "
+                         "center" % (args.steps, args.centers))
 
     import torch
     import torch.distributed as dist
@@ -393,7 +576,13 @@ def main():
 
     # ---- setup: synthetic frames -> HBM (centred, frame-minor) ------------
     t0 = time.perf_counter()
-    x = make_shard(args, data_lo, n_local, n_stream)
+    if args.data == "walk":
+        if world > 1:
+            raise SystemExit("--data walk is a one-GPU probe")
+        from enspara_amd import synth
+        x = synth.walk(n_local, args.atoms, args.seed)
+    else:
+        x = make_shard(args, data_lo, n_local, n_stream)
     t_gen = time.perf_counter() - t0
     tstream = torch.cuda.Stream(device=local_rank) if use_dist else None
     stream = tstream.cuda_stream if use_dist else None
@@ -408,6 +597,21 @@ def main():
     cands = store.candidates
 
     shard = sharded.DeviceShard(store) if use_dist else None
+    transport = None
+    if use_dist:
+        transport = "gather"
+        if args.transport == "mailbox" and cands > 1:
+            try:        # every rank's mailbox mapped into every other (hipIpc)
+                sharded.connect_mailboxes(shard)
+                transport = "mailbox"
+            except Exception as e:      # no peer access: one all-gather per round
+                print("mailboxes unavailable (%s): gather transport" % e,
+                      file=sys.stderr)
+                shard.ms_connected = 0
+        flag = torch.tensor([1 if transport == "mailbox" else 0], device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0 and transport == "mailbox":
+            transport, shard.ms_connected = "gather", 0
 
     def run(count):
         """`count` centers from the untouched state"""
@@ -453,6 +657,7 @@ def main():
     if len(idx) != centers_total:
         raise SystemExit("only %d of %d centers" % (len(idx), centers_total))
     kern_ms, n_samp = store.timing_end()
+    timed_form = store.timing_form()
     if use_dist:
         rounds = store.spec_rounds() if cands > 1 else centers_total
         mix = {cands: (rounds, centers_total)}
@@ -469,12 +674,50 @@ def main():
     pairs = float(n_total) * centers_total
     value = pairs / elapsed
     bpp = bytes_per_pair(args.atoms)
-    # the dominant kernel: the widest pass the run used
-    dom = cands if (use_dist or cands == 1) else max(mix)
+    # the dominant kernel: the form most of the sampled passes ran
+    dom = timed_form if timed_form >= 1 else (cands if cands > 1 else 1)
     launch_bytes = n_local * (bytes_per_frame_pass(args.atoms, dom)
                               if dom > 1 else bpp)
     achieved = (launch_bytes / (kern_ms * 1e-3)) / 1e9 if kern_ms > 0 else None
+    # 16 candidates: a dense contraction, 18 A flop per frame x candidate pair
+    launch_flops = float(n_local) * dom * 18 * args.atoms
+    tflops = (launch_flops / (kern_ms * 1e-3)) / 1e12 if kern_ms > 0 else None
     traffic, traffic_src = load_traffic(args, n_local, dom)
+    ceiling = copy_ceiling(min(x.nbytes, 4 << 30), local_rank)
+    if dom == 16:
+        kernel_name = "ek_pass16_kernel<true>"
+    elif dom > 1:
+        kernel_name = "ek_pass2_kernel<%d, true, true>" % dom
+    else:
+        kernel_name = "ek_step_kernel<FPL,0,NT>"
+    hbm = {
+        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+        "measured_copy_ceiling_GBps": ceiling,
+        "frac_of_measured_copy_ceiling": (achieved / ceiling) if achieved else None,
+        "algorithmic_bytes_per_launch": launch_bytes,
+    }
+    if dom == 16:
+        roof = {"bound": "mfma", "kernel": kernel_name, "achieved": tflops,
+                "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": (tflops / MFMA_F32_PEAK_TFLOPS) if tflops else None,
+                "algorithmic_flops_per_launch": launch_flops,
+                "why": "16 candidates per frame read: 24 flop per byte, the f32 "
+                       "matrix pipe (86 GFLOP per pass) and HBM (3.7 GB) are "
+                       "both ~60-70 % busy; the quartic solves do not overlap "
+                       "with matrix instructions (DESIGN.md 4a)",
+                "hbm": hbm}
+    else:
+        roof = dict(hbm)
+        roof.update({"bound": "hbm", "kernel": kernel_name})
+    roof.update({
+        "bytes_per_pair_one_center_pass": bpp,
+        "pairs_per_launch": n_local * dom,
+        "avg_launch_ms": kern_ms,
+        "launches_sampled": n_samp,
+        "traffic": traffic,
+        "traffic_source": traffic_src,
+    })
 
     out = {
         "metric": "frame x center RMSD pairs/sec in k-centers assign",
@@ -503,37 +746,19 @@ def main():
             "passes_by_candidates": {str(T): {"passes": p, "centers": k}
                                      for T, (p, k) in sorted(mix.items())},
             "algorithm": "k-centers, up to %d candidate centers per pass over "
-                         "the frames (1, 4 or 8 by measured centers/ms), "
+                         "the frames (1, 8 or 16 by measured centers/ms), "
                          "results identical to one pass per center" % cands
                          if cands > 1 else
                          "k-centers, one pass over the frames per center",
-            "templates": args.templates, "seed": args.seed,
+            "templates": args.templates if args.data == "templates" else None,
+            "data": args.data, "seed": args.seed,
             "world_size": (dist.get_world_size() if use_dist else 1),
-            "sharding": ("contiguous frame blocks; per round of ~7 centers: "
-                         "all-gather of 8 candidate records + 320 B + 128 B "
-                         "per rank") if use_dist else "single shard",
+            "sharding": ("contiguous frame blocks; per round of ~15 centers ONE "
+                         "message per rank (per-prefix maxima + its farthest "
+                         "frames as records), transport: %s" % transport)
+                        if use_dist else "single shard",
         },
-        "roofline": {
-            "bound": "hbm",
-            # (the name rocprofv3 lists: the third argument is the fused round of
-            # a single shard, ek_round.hip; the multi-shard driver runs without it)
-            "kernel": ("ek_pass2_kernel<%d, true, %s>"
-                       % (dom, "false" if use_dist else "true")) if dom > 1
-                      else "ek_step_kernel<FPL,0,NT>",
-            "achieved": achieved,
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-            "frac_of_measured_copy_ceiling":
-                (achieved / HBM_COPY_CEILING_GBS) if achieved else None,
-            "algorithmic_bytes_per_launch": launch_bytes,
-            "bytes_per_pair_one_center_pass": bpp,
-            "pairs_per_launch": n_local * dom,
-            "avg_launch_ms": kern_ms,
-            "launches_sampled": n_samp,
-            "traffic": traffic,
-            "traffic_source": traffic_src,
-        },
+        "roofline": roof,
         "passes_over_frames": rounds,
         "centers_per_pass": centers_total / rounds if rounds else None,
         "pairs_computed": float(n_total) * sum(T * p for T, (p, _) in
@@ -553,8 +778,12 @@ def main():
         # Every run starts from the same state and makes the same proposals.
         runs = []
         from enspara_amd.cluster import kmedoids as km     # (not inside the timing)
+        start = None
         for _ in range(max(1, args.pam_runs)):
             med = [int(i) for i in run(centers_total)]
+            if start is None and world == 1:
+                d0, a0 = store.download_state()
+                start = {"medoids": list(med), "dist": d0, "assign": a0}
             rs = np.random.RandomState(args.seed)
             base = store.pam_prefetch_stats() + store.pam_prefetch_passes()
             torch.cuda.synchronize()
@@ -591,6 +820,12 @@ def main():
             "prefetch_passes_over_touched_frames_only": pf_restricted,
             "prefetch_passes_over_all_frames": pf_full,
         }
+        if start is not None and args.pam_sweeps == 1 and not args.no_cpu_baseline:
+            out["khybrid"]["parity"] = khybrid_check(x, store, start, med, args.seed,
+                                                     min(40.0, 3 * args.cpu_seconds))
+
+    if rank == 0 and world == 1 and not args.no_msm:
+        out["msm"] = msm_block(args)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(x, idx, args.cpu_seconds)

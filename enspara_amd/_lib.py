@@ -50,7 +50,7 @@ SYMBOLS = [
     "ek_feat_create", "ek_feat_destroy", "ek_feat_load", "ek_feat_distance",
     "ek_feat_kcenters",
     "ek_set_frames_per_lane", "ek_set_option", "ek_last_run_timing",
-    "ek_timing_begin", "ek_timing_end", "ek_timing_form",
+    "ek_timing_begin", "ek_timing_end", "ek_timing_form", "ek_hbm_copy_rate",
 ]
 
 
@@ -183,6 +183,7 @@ def load():
     L.ek_timing_begin.argtypes = [vp, i32, i32]
     L.ek_timing_end.argtypes = [vp, f32p, i32p]
     L.ek_timing_form.argtypes = [vp, i32p]
+    L.ek_hbm_copy_rate.argtypes = [C.c_int, C.c_size_t, f64p]
     for name in SYMBOLS:
         getattr(L, name)
     _lib = L

@@ -2944,3 +2944,67 @@ extern "C" int ek_ms_run(ek_ctx *c, int32_t first_label, int32_t max_new,
     }
     return EK_OK;
 }
+
+// ---- the copy rate of this GPU (bench.py: the ceiling beside the nominal peak) -----------
+typedef float ek_probe_f4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(EK_BLOCK)
+ek_copy_probe_kernel(const ek_probe_f4 *__restrict__ src,
+                     ek_probe_f4 *__restrict__ dst, size_t n)
+{
+    // eight 16-byte elements per thread, a workgroup's loads contiguous
+    const size_t base = (size_t)blockIdx.x * (EK_BLOCK * 8) + threadIdx.x;
+    ek_probe_f4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+        if (base + (size_t)u * EK_BLOCK < n)
+            v[u] = __builtin_nontemporal_load(&src[base + (size_t)u * EK_BLOCK]);
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+        if (base + (size_t)u * EK_BLOCK < n)
+            __builtin_nontemporal_store(v[u], &dst[base + (size_t)u * EK_BLOCK]);
+}
+
+extern "C" int ek_hbm_copy_rate(int device, size_t bytes, double *gbytes_per_s)
+{
+    if (!gbytes_per_s || bytes < 16)
+        return ek_fail(EK_EARG, "ek_hbm_copy_rate: bad argument");
+    EK_HIP(hipSetDevice(device));
+    const size_t n = bytes / 16;
+    ek_probe_f4 *src = nullptr, *dst = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipMalloc((void **)&src, n * 16);
+    if (e == hipSuccess)
+        e = hipMalloc((void **)&dst, n * 16);
+    if (e == hipSuccess)
+        e = hipMemset(src, 0, n * 16);
+    if (e == hipSuccess)
+        e = hipEventCreate(&e0);
+    if (e == hipSuccess)
+        e = hipEventCreate(&e1);
+    float best = 0.f;
+    if (e == hipSuccess) {
+        const unsigned blocks = (unsigned)((n + EK_BLOCK * 8 - 1) / (EK_BLOCK * 8));
+        for (int rep = 0; rep < 5 && e == hipSuccess; ++rep) {
+            (void)hipEventRecord(e0, nullptr);
+            hipLaunchKernelGGL(ek_copy_probe_kernel, dim3(blocks), dim3(EK_BLOCK), 0,
+                               nullptr, src, dst, n);
+            (void)hipEventRecord(e1, nullptr);
+            e = hipEventSynchronize(e1);
+            float ms = 0.f;
+            if (e == hipSuccess)
+                e = hipEventElapsedTime(&ms, e0, e1);
+            if (rep > 0 && (best == 0.f || ms < best))
+                best = ms;
+        }
+    }
+    (void)hipFree(src);
+    (void)hipFree(dst);
+    if (e0)
+        (void)hipEventDestroy(e0);
+    if (e1)
+        (void)hipEventDestroy(e1);
+    if (e != hipSuccess)
+        return ek_fail(EK_EHIP, "ek_hbm_copy_rate: %s", hipGetErrorString(e));
+    *gbytes_per_s = best > 0.f ? 2.0 * (double)(n * 16) / (best * 1e-3) / 1e9 : 0.0;
+    return EK_OK;
+}

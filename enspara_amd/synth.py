@@ -67,3 +67,32 @@ def synth(n_frames, n_atoms, n_templates, seed, first_frame=0):
         done += cnt
         c += 1
     return out
+
+
+def walk(n_frames, n_atoms, seed, kappa=1e-3, sigma=0.03):
+    """float32 [n_frames, n_atoms, 3]: ONE time-ordered trajectory on a
+    continuous landscape -- every coordinate an Ornstein-Uhlenbeck process around
+    a random-walk chain (x[t+1] = x[t] + kappa (x0 - x[t]) + N(0, sigma)),
+    stationary spread sigma / sqrt(2 kappa) = 0.67 nm, neighbouring frames
+    ~0.05 nm apart, frames 10^4 steps apart unrelated -- then a random rigid
+    motion per frame.  No templates, no discrete clusters: the unfriendly case
+    for guessing several farthest points ahead (bench.py --data walk)."""
+    from scipy.signal import lfilter
+    x0 = templates(1, n_atoms, seed)[0]
+    rng = np.random.Generator(np.random.PCG64([seed, 0x0a1c]))
+    out = np.empty((n_frames, n_atoms, 3), dtype=np.float32)
+    zi = np.zeros((1, n_atoms * 3))
+    a = np.array([1.0, -(1.0 - kappa)])
+    done = 0
+    while done < n_frames:
+        cnt = min(CHUNK, n_frames - done)
+        noise = rng.normal(scale=sigma, size=(cnt, n_atoms * 3))
+        dev, zi = lfilter([1.0], a, noise, axis=0, zi=zi)
+        xyz = x0[None] + dev.reshape(cnt, n_atoms, 3)
+        q = rng.normal(size=(cnt, 4))
+        q /= np.linalg.norm(q, axis=1, keepdims=True)
+        xyz = np.einsum("nij,naj->nai", _quat_to_rot(q), xyz)
+        xyz += rng.uniform(-5.0, 5.0, size=(cnt, 1, 3))
+        out[done:done + cnt] = xyz.astype(np.float32)
+        done += cnt
+    return out

@@ -87,14 +87,24 @@ def msq(d):
 
 
 def pam_update(X, medoid_inds, assignments, distances, proposals=None,
-               random_state=None):
-    """One PAM sweep, kmedoids.py:575-699 (non-MPI branch)."""
+               random_state=None, stop_after=None, budget_s=None, done=None):
+    """One PAM sweep, kmedoids.py:575-699 (non-MPI branch).  ``stop_after`` /
+    ``budget_s`` (checker only): only the first that many clusters' proposals,
+    or as many as fit the seconds -- what a full-size cross-check can afford;
+    ``done`` (a list) receives the number of proposals made."""
+    import time
+    t_start = time.perf_counter()
     P = X if isinstance(X, qcp.Prepared) else qcp.Prepared(X)
     m = _metric_on(P)
     random_state = check_random_state(random_state)          # :579
     medoid_inds = list(medoid_inds)
     medoid_xyz = [P.xyz[i] for i in medoid_inds]             # :607
-    for cid in range(len(medoid_inds)):
+    for cid in range(len(medoid_inds) if stop_after is None
+                     else min(stop_after, len(medoid_inds))):
+        if budget_s is not None and time.perf_counter() - t_start > budget_s:
+            break
+        if done is not None:
+            done[:] = [cid + 1]
         members = np.flatnonzero(assignments == cid)         # :611
         if proposals is None:
             # the state was wrapped once per sweep (:579), so an int seed

@@ -13,7 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench
 
-KERNELS = {"cands8": "ek_pass2_kernel<8, true, true>",
+KERNELS = {"cands16": "ek_pass16_kernel<true>",
+           "cands8": "ek_pass2_kernel<8, true, true>",
            "cands1": "ek_step_kernel<2, 0, true>"}
 
 
