@@ -338,15 +338,16 @@ def mdtraj_leg(x, centers, seconds):
 
 
 def copy_ceiling(nbytes, device):
-    """The device-to-device copy rate of this GPU, in this process: a
+    """-> (copy GB/s, read-only GB/s) of this GPU, in this process: a
     16-byte-per-lane non-temporal copy of `nbytes` (read + write = 2 x nbytes of
-    HBM traffic), best of four (csrc/ek_api.hip ek_hbm_copy_rate).  The ceiling
-    a streaming kernel can be compared with besides the nominal peak."""
+    HBM traffic) and the same stream only read (what the distance kernels do),
+    best of four each (csrc/ek_api.hip ek_hbm_copy_rate).  The ceilings a
+    streaming kernel can be compared with besides the nominal peak."""
     import ctypes as C
     from enspara_amd import _lib
-    g = C.c_double()
-    _lib.check(_lib.load().ek_hbm_copy_rate(int(device), int(nbytes), C.byref(g)))
-    return g.value
+    g = (C.c_double * 2)()
+    _lib.check(_lib.load().ek_hbm_copy_rate(int(device), int(nbytes), g))
+    return g[0], g[1]
 
 
 def msm_block(args):
@@ -693,8 +694,10 @@ def main():
     hbm = {
         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-        "measured_copy_ceiling_GBps": ceiling,
-        "frac_of_measured_copy_ceiling": (achieved / ceiling) if achieved else None,
+        "measured_copy_GBps": ceiling[0],
+        "measured_read_stream_GBps": ceiling[1],
+        "frac_of_measured_read_stream": (achieved / ceiling[1])
+                                        if achieved and ceiling[1] else None,
         "algorithmic_bytes_per_launch": launch_bytes,
     }
     if dom == 16:

@@ -539,9 +539,10 @@ int ek_last_run_timing(ek_ctx *ctx, float *ms, int32_t *launches);
 int ek_timing_begin(ek_ctx *ctx, int32_t sample_every, int32_t max_samples);
 int ek_timing_end(ek_ctx *ctx, float *avg_ms, int32_t *n_samples);
 int ek_timing_form(ek_ctx *ctx, int32_t *candidates);
-/* read + write rate (GB/s) of a 16-byte-per-lane copy of `bytes` bytes on this
- * GPU, best of four: the measured ceiling bench.py quotes beside the nominal
- * HBM peak */
+/* gbytes_per_s[0]: read + write rate (GB/s) of a 16-byte-per-lane non-temporal
+ * copy of `bytes` bytes on this GPU; [1]: the rate of only reading them (what the
+ * distance kernels do); best of four each: the measured ceilings bench.py quotes
+ * beside the nominal HBM peak */
 int ek_hbm_copy_rate(int device, size_t bytes, double *gbytes_per_s);
 
 #ifdef __cplusplus
