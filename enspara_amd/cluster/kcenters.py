@@ -188,9 +188,17 @@ def _kcenters_host(traj, distance_method, n_clusters, dist_cutoff,
     # first-index arg-max) instead of one device metric call plus numpy passes
     # per center.  The triangle-inequality variant keeps the host loop.
     mid = getattr(distance_method, "device_metric_id", None)
+    # (real floating or integer data without NaN only: np.argmax / .max() treat a
+    # NaN distance as the maximum and the reference's loop stops on it, which the
+    # device arg-max does not reproduce; anything else keeps the host loop)
     resident = (mid is not None and not use_triangle_inequality
                 and isinstance(traj, np.ndarray) and traj.ndim == 2
-                and len(traj) > 0)
+                and len(traj) > 0
+                and (np.issubdtype(traj.dtype, np.floating)
+                     or np.issubdtype(traj.dtype, np.integer))
+                and traj.dtype != np.float16
+                and not (np.issubdtype(traj.dtype, np.floating)
+                         and np.isnan(traj).any()))
     if not resident and hasattr(distance_method, "bind"):
         distance_method = distance_method.bind(traj)   # upload traj once
     if init_centers is None:
@@ -203,6 +211,10 @@ def _kcenters_host(traj, distance_method, n_clusters, dist_cutoff,
             traj, centers, distance_method)
         ctr_inds = list(util.find_cluster_centers(assignments, distances))
 
+    if resident and np.isnan(distances).any():     # (a warm start's distances)
+        resident = False
+        if hasattr(distance_method, "bind"):
+            distance_method = distance_method.bind(traj)
     if resident:
         from ..geometry import libdist
         budget = n_clusters - len(ctr_inds)

@@ -135,3 +135,21 @@ def test_resident_feature_kcenters_equals_the_host_loop():
     assert list(got.center_indices) == list(want.center_indices)
     np.testing.assert_array_equal(got.assignments, want.assignments)
     np.testing.assert_array_equal(got.distances, want.distances)
+
+
+def test_nan_features_keep_the_reference_loop():
+    """np.argmax / .max() treat a NaN distance as the maximum and the
+    reference's loop (kcenters.py:217, :282) stops on it; the device arg-max
+    does not reproduce that, so data with NaN (and dtypes the device does not
+    compute in) stays on the reference-shaped host loop (round-2 advisor
+    finding): same result as the wrapped callable."""
+    from enspara_amd.cluster.kcenters import kcenters
+    from enspara_amd.geometry import libdist
+    rng = np.random.RandomState(2)
+    X = rng.normal(size=(400, 6))
+    X[37, 2] = np.nan
+    got = kcenters(X, "euclidean", n_clusters=9)
+    want = kcenters(X, lambda A, y: libdist.euclidean(A, y), n_clusters=9)
+    assert list(got.center_indices) == list(want.center_indices)
+    np.testing.assert_array_equal(got.assignments, want.assignments)
+    np.testing.assert_array_equal(got.distances, want.distances)
