@@ -158,11 +158,11 @@ def _check_proposals(proposals, medoid_inds):
                 proposals[0], medoid_inds[0]))
 
 
-# Proposals drawn ahead and decided as one window (1..16, the library's
+# Proposals drawn ahead and decided as one window (1..32, the library's
 # ek_pam_window_max(); 1 = one distance pass and one read-back per proposal).
 # The results do not depend on it: every guess is checked against the state and
 # the random stream when its turn comes.
-PAM_PREFETCH = 16
+PAM_PREFETCH = 32
 
 
 class _DrawStream:

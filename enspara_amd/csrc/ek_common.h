@@ -336,7 +336,9 @@ static_assert(sizeof(EkPamOut) == 32, "EkPamOut layout");
 // a window of proposals decided on the device (ek_pam_window_run): up to
 // EK_PAM_WIN consecutive clusters, their proposals drawn, prefetched (in groups
 // of EK_PAM_GROUP columns) and decided without a host round trip in between
-#define EK_PAM_WIN 16
+#ifndef EK_PAM_WIN
+#define EK_PAM_WIN 32     // (16 in round 2: the set-up of a window is ~240 us whatever its width)
+#endif
 static_assert(EK_PAM_WIN % EK_PAM_GROUP == 0 && EK_PAM_WIN <= 32,
               "whole column groups; the stale mask is 32 bits");
 struct EkPamWin {

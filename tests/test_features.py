@@ -137,6 +137,7 @@ def test_resident_feature_kcenters_equals_the_host_loop():
     np.testing.assert_array_equal(got.distances, want.distances)
 
 
+@pytest.mark.gpu
 def test_nan_features_keep_the_reference_loop():
     """np.argmax / .max() treat a NaN distance as the maximum and the
     reference's loop (kcenters.py:217, :282) stops on it; the device arg-max
