@@ -56,10 +56,11 @@
 #define EK_MS_THREADS 1024
 #define EK_MS_FPT 4
 // polls of a flag (with s_sleep between) before a shard gives up on a peer:
-// ~0.25 s; a missing peer then shows as EkMsState::err (and ends the run: every
-// later launch is a no-op) instead of a hung GPU
+// ~10 s -- ranks enter a fit seconds apart when one is still loading frames --;
+// a missing peer then shows as EkMsState::err (and ends the run: every later
+// launch is a no-op) instead of a hung GPU
 #ifndef EK_MS_SPIN_LIMIT
-#define EK_MS_SPIN_LIMIT (1 << 20)
+#define EK_MS_SPIN_LIMIT (1 << 25)
 #endif
 
 // ---- system-scope accesses (mailbox transport) ---------------------------------

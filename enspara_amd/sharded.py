@@ -290,6 +290,8 @@ def _kcenters_sharded_ms(shard, first_label, max_new, dist_cutoff, group, fresh,
     if fresh:
         shard.reset_history()
     if getattr(shard, "ms_connected", 0) == world:
+        if collective:      # (the shards wait for one another on the device from here on)
+            dist.barrier(group=group)
         idx, cd = shard.ms_run(first_label, max_new, float(dist_cutoff))
         return (np.array(idx, dtype=np.int64), np.array(cd, dtype=np.float32))
     key = (world, rank)

@@ -209,7 +209,7 @@ int ek_spec_chain_apply(ek_ctx *ctx, const void *hdrs_all, int32_t n_shards,
  * contexts of one process, hipIpc handles of 64 bytes each across processes),
  * connects every shard's including its own (ek_ms_connect), then
  *   ek_ms_run(ctx, first_label, max_new, cutoff, ...)   as ek_kcenters_run
- * on every shard at the same time.  A message that does not arrive within ~1 s
+ * on every shard at the same time.  A message that does not arrive within ~10 s
  * is reported as an error (a peer died), not waited for. */
 int ek_ms_setup(ek_ctx *ctx, int32_t world, int32_t rank, size_t *message_bytes);
 int ek_ms_mailbox(ek_ctx *ctx, void **mbox, void **flags, void *ipc_mbox,

@@ -255,6 +255,26 @@ for rep in range(2):
         np.concatenate([p[0] for p in parts]).astype(np.float64), wd)
     # distances.max() after the last update (kcenters.py:226)
     assert out[0][2] == np.float32(wd.max()), (out[0][2], wd.max())
+if K > 4:
+    # the same fit in two calls: the second continues from the first's labels
+    k1 = K // 3
+    for st in stores:
+        st.reset_state()
+        st.sync()
+    def part(r, first, count):
+        out[r] = stores[r].ms_run(first, count, cutoff)
+    got = []
+    for first, count in ((0, k1), (k1, K - k1)):
+        th = [threading.Thread(target=part, args=(r, first, count))
+              for r in range(shards)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        got += [int(i) for i in out[0][0]]
+    assert got == [int(i) for i in inds], (got, inds)
+    parts = [st.download_state() for st in stores]
+    np.testing.assert_array_equal(np.concatenate([p[1] for p in parts]), wa)
 print("ok", len(inds), stores[0].ms_state())
 """
 
