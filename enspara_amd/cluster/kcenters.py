@@ -105,7 +105,8 @@ def kcenters(traj, distance_method, n_clusters=np.inf, dist_cutoff=0,
                 "(one process per GPU over torch.distributed)")
         from .. import sharded
         return sharded.fit_sharded(
-            traj, n_clusters=n_clusters, dist_cutoff=dist_cutoff, n_iters=0)
+            traj, n_clusters=n_clusters, dist_cutoff=dist_cutoff, n_iters=0,
+            use_triangle_inequality=use_triangle_inequality)
 
     if util.is_device_rmsd(distance_method):
         return _kcenters_device(traj, n_clusters, dist_cutoff, init_centers,

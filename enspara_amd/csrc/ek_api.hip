@@ -148,6 +148,10 @@ struct ek_ctx {
     uint8_t *ti_skip = nullptr;  // [n_tiles]
     unsigned long long *ti_stats = nullptr;  // [2] tiles looked at, skipped
     int64_t ti_tiles = 0, ti_skipped = 0;    // of the last run
+    float *ti_tab = nullptr;     // sharded steps: the accepted centers, [ti_tab_cap][3A]
+    double *ti_tabG = nullptr;
+    int32_t ti_tab_cap = 0;
+    int32_t ti_tab_n = 0;        // rows 0 .. ti_tab_n - 1 are the centers of labels 0 ..
     EkPend *pend = nullptr;      // accepted chain not yet applied
     EkChainOrd *ord = nullptr;
     EkChainRow *rows = nullptr;      // [EK_MAX_CANDS] candidate frames' rows
@@ -333,6 +337,8 @@ static int ek_free_all(ek_ctx *c)
     (void)hipFree(c->ctile);
     (void)hipFree(c->ctrace);
     (void)hipFree(c->ti_D);
+    (void)hipFree(c->ti_tab);
+    (void)hipFree(c->ti_tabG);
     (void)hipFree(c->ti_skip);
     (void)hipFree(c->ti_stats);
     (void)hipFree(c->pend);
@@ -795,6 +801,57 @@ extern "C" int ek_kcenters_step(ek_ctx *c, const void *recs_dev, int32_t n_recs,
         return ek_fail(EK_EARG, "ek_kcenters_step: n_recs < 1");
     unsigned char *own = own_rec_out ? (unsigned char *)own_rec_out : c->rec;
     const int fpl = ek_pick_fpl(c);
+    // Triangle inequality in the sharded iteration (option key 11; reference
+    // kcenters.py:351-364): every shard keeps the accepted centers in a table
+    // (they are other shards' frames as often as its own) and skips the tiles
+    // none of whose frames can move.  From label 0 of a fresh state only.
+    bool tri = false;
+    if (c->tri && recs_dev && c->state_exact && c->A >= 3) {
+        if (label == 0)
+            c->ti_tab_n = 0;
+        if (c->ti_tab_n == label) {
+            if (label + 1 > c->ti_tab_cap) {
+                const int32_t cap = std::max(2 * c->ti_tab_cap, std::max(label + 1, 256));
+                float *t2 = nullptr, *d2 = nullptr;
+                double *g2 = nullptr;
+                EK_HIP(ek_wait(c));
+                EK_HIP(hipMalloc((void **)&t2, (size_t)cap * 3 * c->A * sizeof(float)));
+                EK_HIP(hipMalloc((void **)&g2, (size_t)cap * sizeof(double)));
+                EK_HIP(hipMalloc((void **)&d2, (size_t)cap * sizeof(float)));
+                if (c->ti_tab_n > 0) {
+                    EK_HIP(hipMemcpy(t2, c->ti_tab, (size_t)c->ti_tab_n * 3 * c->A *
+                                                        sizeof(float),
+                                     hipMemcpyDeviceToDevice));
+                    EK_HIP(hipMemcpy(g2, c->ti_tabG, (size_t)c->ti_tab_n * sizeof(double),
+                                     hipMemcpyDeviceToDevice));
+                }
+                (void)hipFree(c->ti_tab);
+                (void)hipFree(c->ti_tabG);
+                (void)hipFree(c->ti_D);
+                c->ti_tab = t2;
+                c->ti_tabG = g2;
+                c->ti_D = d2;
+                c->ti_tab_cap = cap;
+                c->ti_cap = cap;
+            }
+            if (!c->ti_skip) {
+                EK_HIP(hipMalloc((void **)&c->ti_skip,
+                                 (size_t)std::max<int64_t>(c->n_tiles, 1)));
+                EK_HIP(hipMalloc((void **)&c->ti_stats, 2 * sizeof(unsigned long long)));
+                EK_HIP(hipMemsetAsync(c->ti_stats, 0, 2 * sizeof(unsigned long long),
+                                      c->stream));
+            }
+            if (label == 0)
+                EK_HIP(hipMemsetAsync(c->ti_stats, 0, 2 * sizeof(unsigned long long),
+                                      c->stream));
+            ek_launch_ti_tab(c->ti_tab, c->ti_tabG, c->A, label, recs, n_recs, c->ti_D,
+                             c->dist, c->assign, c->n, c->ctl, c->ti_skip, c->ti_stats,
+                             c->stream);
+            EK_CHECK_LAUNCH();
+            c->ti_tab_n = label + 1;
+            tri = label >= 1 && c->n > 0;
+        }
+    }
     if (c->n > 0) {
         const bool sample =
             c->samp_every > 0 && (c->samp_count++ % c->samp_every) == 0 &&
@@ -805,7 +862,8 @@ extern "C" int ek_kcenters_step(ek_ctx *c, const void *recs_dev, int32_t n_recs,
             EK_HIP(hipEventRecord(c->samp_ev[2 * c->samp_used], c->stream));
         ek_launch_step(fpl, 0, ek_pick_nt(c), c->tiles, c->G, c->dist, c->assign, c->scratch,
                        recs, n_recs, c->n, c->A, label, dist_cutoff,
-                       c->blockmax, c->hist, c->ctl, c->stream);
+                       c->blockmax, c->hist, c->ctl, c->stream,
+                       tri ? c->ti_skip : nullptr);
         EK_CHECK_LAUNCH();
         if (sample) {
             EK_HIP(hipEventRecord(c->samp_ev[2 * c->samp_used + 1], c->stream));
@@ -2544,6 +2602,15 @@ extern "C" int ek_ti_stats(ek_ctx *c, int64_t *tiles, int64_t *skipped)
 {
     if (!c || !tiles || !skipped)
         return ek_fail(EK_EARG, "ek_ti_stats: NULL argument");
+    if (c->ti_tab_n > 0 && c->ti_stats) {       // sharded steps: counted on the device
+        unsigned long long st[2] = {0, 0};
+        EK_HIP(hipSetDevice(c->device));
+        EK_HIP(hipMemcpyAsync(st, c->ti_stats, sizeof(st), hipMemcpyDeviceToHost,
+                              c->stream));
+        EK_HIP(ek_wait(c));
+        c->ti_tiles = (int64_t)st[0];
+        c->ti_skipped = (int64_t)st[1];
+    }
     *tiles = c->ti_tiles;
     *skipped = c->ti_skipped;
     return EK_OK;

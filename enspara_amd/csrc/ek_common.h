@@ -227,6 +227,13 @@ void ek_launch_ti(const float *aos, const double *G, int A, const EkHist *hist,
                   const float *dist, const int32_t *assign, int64_t n,
                   const EkCtl *ctl, uint8_t *tile_skip, unsigned long long *stats,
                   hipStream_t s);
+// the sharded form: centers from the table of accepted centers (row k is filled
+// with the winner of `recs` here), tile marks as above
+void ek_launch_ti_tab(float *tab, double *tabG, int A, int k,
+                      const unsigned char *recs, int n_recs, float *Dnew,
+                      const float *dist, const int32_t *assign, int64_t n,
+                      const EkCtl *ctl, uint8_t *tile_skip, unsigned long long *stats,
+                      hipStream_t s);
 int ek_step_blocks(int fpl, int64_t n);
 
 // reduce block partials (or, if blockmax == nullptr, the dist array itself)

@@ -572,6 +572,76 @@ ek_ti_tiles_kernel(const float *__restrict__ dist,
     }
 }
 
+// The same for a SHARDED iteration (reference kcenters.py:351-364): the existing
+// centers are other shards' frames as often as this one's, so they come from a
+// table of the centers accepted so far (centred coordinates + trace, a row per
+// label, filled here as they are accepted), and the new center is the winner
+// among the gathered records (largest distance, lowest rank on ties: the rule
+// ek_step_kernel applies).  Wave l < k: Dnew[l]; wave k: the winner's row -> table.
+__global__ void __launch_bounds__(EK_BLOCK)
+ek_ti_center_tab_kernel(float *__restrict__ tab, double *__restrict__ tabG, int A,
+                        int k, const unsigned char *__restrict__ recs, int n_recs,
+                        float *__restrict__ Dnew)
+{
+    const int lane = threadIdx.x & (EK_WAVE - 1);
+    const int l = blockIdx.x * (EK_BLOCK / EK_WAVE) + threadIdx.x / EK_WAVE;
+    if (l > k)
+        return;
+    const size_t rstride = ek_rec_bytes(A);
+    int win = 0;
+    float wmax = ((const EkRecHdr *)recs)->valid ? ((const EkRecHdr *)recs)->maxdist
+                                                  : -__builtin_inff();
+    for (int r = 1; r < n_recs; ++r) {
+        const EkRecHdr *h = (const EkRecHdr *)(recs + (size_t)r * rstride);
+        const float m = h->valid ? h->maxdist : -__builtin_inff();
+        if (m > wmax) {
+            wmax = m;
+            win = r;
+        }
+    }
+    const EkRecHdr *wh = (const EkRecHdr *)(recs + (size_t)win * rstride);
+    const float *y = (const float *)(wh + 1);
+    if (l == k) {               // the new center's own row
+        for (int q = lane; q < 3 * A; q += EK_WAVE)
+            tab[(size_t)k * 3 * A + q] = y[q];
+        if (lane == 0)
+            tabG[k] = wh->trace;
+        return;
+    }
+    const float *x = tab + (size_t)l * 3 * A;
+    float S[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int a = lane; a < A; a += EK_WAVE) {
+        const float x0 = x[3 * a], x1 = x[3 * a + 1], x2 = x[3 * a + 2];
+        const float y0 = y[3 * a], y1 = y[3 * a + 1], y2 = y[3 * a + 2];
+        S[0] += x0 * y0; S[1] += x0 * y1; S[2] += x0 * y2;
+        S[3] += x1 * y0; S[4] += x1 * y1; S[5] += x1 * y2;
+        S[6] += x2 * y0; S[7] += x2 * y1; S[8] += x2 * y2;
+    }
+#pragma unroll
+    for (int q = 0; q < 9; ++q)
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1)
+            S[q] += __shfl_xor(S[q], off, 64);
+    if (lane == 0)
+        Dnew[l] = ek_rmsd_from_S(S, tabG[l], wh->trace, A);
+}
+
+void ek_launch_ti_tab(float *tab, double *tabG, int A, int k,
+                      const unsigned char *recs, int n_recs, float *Dnew,
+                      const float *dist, const int32_t *assign, int64_t n,
+                      const EkCtl *ctl, uint8_t *tile_skip, unsigned long long *stats,
+                      hipStream_t s)
+{
+    const int per = EK_BLOCK / EK_WAVE;
+    hipLaunchKernelGGL(ek_ti_center_tab_kernel, dim3((k + 1 + per - 1) / per),
+                       dim3(EK_BLOCK), 0, s, tab, tabG, A, k, recs, n_recs, Dnew);
+    if (n > 0 && k > 0)
+        hipLaunchKernelGGL(ek_ti_tiles_kernel,
+                           dim3((unsigned)((n + EK_BLOCK - 1) / EK_BLOCK)),
+                           dim3(EK_BLOCK), 0, s, dist, assign, n, k, Dnew, ctl,
+                           tile_skip, stats);
+}
+
 void ek_launch_ti(const float *aos, const double *G, int A, const EkHist *hist,
                   int k, int64_t goff, const unsigned char *rec, float *Dnew,
                   const float *dist, const int32_t *assign, int64_t n,

@@ -56,6 +56,9 @@ class DeviceShard:
         self.store.kcenters_step(all_recs.data_ptr(), n_recs, label, cutoff,
                                  own_rec.data_ptr())
 
+    def set_triangle_inequality(self, on):
+        self.store.set_option(11, 1 if on else 0)
+
     def progress(self):
         """-> number of centers so far; synchronises"""
         _, _, n_done = self.store.history(0, 0)
@@ -216,7 +219,7 @@ def _world(group):
 
 
 def kcenters_sharded(shard, first_label, max_new, dist_cutoff=0.0, group=None,
-                     check_every=16, fresh=True):
+                     check_every=16, fresh=True, use_triangle_inequality=False):
     """Run up to ``max_new`` k-centers iterations over all ranks' shards.
 
     Every rank calls this with its own shard.  Returns
@@ -224,11 +227,20 @@ def kcenters_sharded(shard, first_label, max_new, dist_cutoff=0.0, group=None,
     identical on every rank.  The per-frame state stays on each shard.
     ``fresh=False`` continues a previous call (keeps the accepted-center
     history and the candidate record already held by the shard).
+    ``use_triangle_inequality`` (reference kcenters.py:351-364): one center per
+    pass, every shard keeps the accepted centers and does not read the tiles of
+    256 frames none of which can come closer to the new center than to its own
+    (csrc/ek_kcenters.hip ek_ti_center_tab_kernel); same results, fewer bytes
+    on time-ordered data.
     """
     import torch.distributed as dist
     world, _ = _world(group)
     collective = dist.is_available() and dist.is_initialized()
     T = getattr(shard, "candidates", 1)
+    if hasattr(shard, "set_triangle_inequality"):
+        shard.set_triangle_inequality(bool(use_triangle_inequality))
+    if use_triangle_inequality:
+        T = 1               # (the test is per center: one-center passes)
     if T > 1 and world <= MAX_ROUND_RECORDS and hasattr(shard, "ms_local"):
         return _kcenters_sharded_ms(shard, first_label, max_new, dist_cutoff,
                                     group, fresh, world, T, collective)
@@ -656,7 +668,7 @@ def khybrid_sharded(shard, n_clusters, dist_cutoff=0.0, n_iters=5,
 # estimator-level entry: the reference's mpi_mode
 # ---------------------------------------------------------------------------
 def fit_sharded(traj, n_clusters=None, dist_cutoff=0.0, n_iters=0,
-                random_state=None, group=None):
+                random_state=None, group=None, use_triangle_inequality=False):
     """k-centers (+ ``n_iters`` PAM sweeps) where every rank of the initialised
     ``torch.distributed`` group passes ITS OWN frames -- what ``mpi_mode=True``
     means in the reference (kcenters.py:314-378, kmedoids.py MPI branch): rank
@@ -707,8 +719,9 @@ def fit_sharded(traj, n_clusters=None, dist_cutoff=0.0, n_iters=0,
         store.reset_state()
         shard = DeviceShard(store)
         with torch.cuda.stream(tstream):
-            idx, _ = kcenters_sharded(shard, 0, max_new,
-                                      float(dist_cutoff or 0.0), group=group)
+            idx, _ = kcenters_sharded(
+                shard, 0, max_new, float(dist_cutoff or 0.0), group=group,
+                use_triangle_inequality=use_triangle_inequality)
             med = [int(g) for g in idx]
             for _ in range(int(n_iters)):
                 med = pam_sweep_sharded(shard, med, random_state=rs,

@@ -517,7 +517,10 @@ int ek_set_frames_per_lane(ek_ctx *ctx, int fpl);
  * mark the tiles of 256 frames none of whose frames can move (own center at
  * least twice the frame's distance away, with a margin), and those tiles'
  * coordinates are not read.  Used only from a fresh state (ek_state_reset) and
- * for >= 3 atoms; identical results
+ * for >= 3 atoms; identical results.  Also in the sharded one-center iteration
+ * (ek_kcenters_step with gathered records; reference kcenters.py:351-364):
+ * every shard keeps a table of the accepted centers -- other shards' frames as
+ * often as its own -- filled from the winning records
  * key 10: ek_kcenters_run's rounds in three launches (the single-workgroup
  * steps ride at the end of the launch that produces their input): 1 (default)
  * / 0 (one launch per step); identical results

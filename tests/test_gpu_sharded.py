@@ -300,6 +300,83 @@ def test_mailbox_rounds_between_contexts(shards, n, A, K, cutoff, cands):
     assert p.stdout.strip().splitlines()[-1].startswith("ok")
 
 
+_CHILD_TI = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+import torch
+import torch.distributed as dist
+rank, world, port, out = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + port,
+                        rank=rank, world_size=world)
+_agit = dist.all_gather_into_tensor
+def agit(out_t, in_t, group=None):
+    torch.cuda.current_stream().synchronize()
+    o = torch.empty(out_t.shape, dtype=out_t.dtype)
+    _agit(o, in_t.cpu(), group=group)
+    out_t.copy_(o)
+dist.all_gather_into_tensor = agit
+from enspara_amd import sharded, synth
+from enspara_amd.device import FrameStore
+rng = np.random.RandomState(3)
+A, T, per, K = 40, 24, 512, 60
+tmpl = synth.templates(T, A, 9)
+x = np.concatenate([tmpl[t] + rng.normal(scale=0.05, size=(per, A, 3))
+                    for t in range(T)]).astype(np.float32)      # time-ordered blocks
+n = len(x)
+lo, cnt = sharded.shard_bounds(n, world, rank)
+torch.cuda.set_device(0)
+ts = torch.cuda.Stream(device=0)
+with FrameStore(cnt, A, device=0, global_offset=lo, stream=ts.cuda_stream) as st:
+    st.load(x[lo:lo + cnt])
+    st.reset_state()
+    sh = sharded.DeviceShard(st)
+    with torch.cuda.stream(ts):
+        idx, cd = sharded.kcenters_sharded(sh, 0, K, 0.0, use_triangle_inequality=True)
+    d, a = st.download_state()
+    tiles, skipped = st.ti_stats()
+np.savez(out + ".%d.npz" % rank, idx=idx, d=d, a=a, tiles=tiles, skipped=skipped)
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_triangle_inequality_in_the_sharded_iteration(tmp_path):
+    """reference kcenters.py:351-364 (`use_triangle_inequality` in
+    _kcenters_iteration_mpi): two shards on the one GPU (collectives staged
+    through gloo), frames in blocks of one template each: same centers, labels
+    and distances as the oracle's plain run, and most tiles are never read once
+    the templates have centers"""
+    import socket
+    from oracle import cluster as oc
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = str(s.getsockname()[1])
+    s.close()
+    out = str(tmp_path / "ti")
+    procs = [subprocess.Popen([sys.executable, "-c", _CHILD_TI, ROOT, str(r), "2",
+                               port, out], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True)
+             for r in range(2)]
+    logs = [p.communicate(timeout=600)[0] for p in procs]
+    for p, log in zip(procs, logs):
+        assert p.returncode == 0, log[-4000:]
+    parts = [np.load(out + ".%d.npz" % r) for r in range(2)]
+    rng = np.random.RandomState(3)
+    A, T, per, K = 40, 24, 512, 60
+    tmpl = synth.templates(T, A, 9)
+    x = np.concatenate([tmpl[t] + rng.normal(scale=0.05, size=(per, A, 3))
+                        for t in range(T)]).astype(np.float32)
+    inds, wa, wd = oc.kcenters(x, n_clusters=K)
+    for p in parts:
+        np.testing.assert_array_equal(p["idx"], np.array(inds))
+        assert int(p["tiles"]) == (K - 1) * ((len(x) // 2 + 255) // 256)
+        assert int(p["skipped"]) > 0.5 * int(p["tiles"])
+    np.testing.assert_array_equal(np.concatenate([p["a"] for p in parts]), wa)
+    np.testing.assert_array_equal(
+        np.concatenate([p["d"] for p in parts]).astype(np.float64), wd)
+
+
 # ---- the estimators' mpi_mode=True (every rank passes its own frames) ------------
 _CHILD3 = r"""
 import os, sys
