@@ -613,6 +613,24 @@ def main():
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0 and transport == "mailbox":
             transport, shard.ms_connected = "gather", 0
+        if transport == "mailbox" and world > 1:
+            # a short fit through the mailboxes before anything is timed: if the
+            # peers' stores do not arrive on this node (no peer access after
+            # all), every rank falls back to the all-gather transport together
+            ok = 1
+            try:
+                store.reset_state()
+                with torch.cuda.stream(tstream):
+                    sharded.kcenters_sharded(shard, 0, min(64, args.centers), 0.0,
+                                             fresh=True)
+            except Exception as e:
+                print("mailbox transport failed (%s): gather transport" % e,
+                      file=sys.stderr)
+                ok = 0
+            flag = torch.tensor([ok], device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                transport, shard.ms_connected = "gather", 0
 
     def run(count):
         """`count` centers from the untouched state"""
