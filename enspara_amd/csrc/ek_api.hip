@@ -1,5 +1,6 @@
 // ek_api.hip -- the C ABI of include/enspara_hip.h (host side).
 #include "ek_common.h"
+#include "ek_pam_sparse.h"
 
 #include <stdarg.h>
 #include <stdio.h>
@@ -131,6 +132,17 @@ struct ek_ctx {
     int64_t *tmp_idx = nullptr;      // scratch for index lists
     int64_t tmp_idx_cap = 0;
     int64_t pf_hits = 0, pf_misses = 0;
+    // windows worked through by one workgroup (ek_pam_sparse.hip)
+    int pam_sparse = 1;              // use them where they apply (option key 12)
+    int64_t sp_max_pairs = EK_SP_MAX_PAIRS;  // (option key 13)
+    bool sp_ready = false;           // act_list holds the list of the window just prefetched
+    uint32_t *act_list = nullptr;    // [n] the frames a window's proposals can touch
+    int64_t vecs_rows = -1;          // >= 0: pam_vecs is +inf except at act_list[0 .. vecs_rows)
+    int32_t vecs_cols = 0;           //   of its first vecs_cols vectors
+    int64_t sp_nact = 0;
+    unsigned char *sp_buf = nullptr; // the slots' buckets and their lengths
+    int64_t sp_windows = 0, sp_bailed = 0;
+    int32_t sp_backoff = 0, sp_backoff_next = 8;    // windows to go the three-launch way after one ended early
 
     // multi-candidate rounds (ek_spec.hip)
     int cands = -1;              // candidates per pass: -1 auto, 1 = one-center passes
@@ -325,6 +337,8 @@ static int ek_free_all(ek_ctx *c)
     if (c->pam_out_host)
         (void)hipHostFree(c->pam_out_host);
     (void)hipFree(c->pam_win_dev);
+    (void)hipFree(c->sp_buf);
+    (void)hipFree(c->act_list);
     if (c->pam_win_host)
         (void)hipHostFree(c->pam_win_host);
     ek_msm_scratch_free(c->msm_scratch);
@@ -552,6 +566,16 @@ extern "C" int ek_set_option(ek_ctx *c, int32_t key, int32_t value)
             return ek_fail(EK_EARG, "ek_set_option: adaptive candidates 0 or 1");
         c->adapt = value;
         return EK_OK;
+    case 12:
+        if (value != 0 && value != 1)
+            return ek_fail(EK_EARG, "ek_set_option: one-workgroup PAM windows 0 or 1");
+        c->pam_sparse = value;
+        return EK_OK;
+    case 13:
+        if (value < 0)
+            return ek_fail(EK_EARG, "ek_set_option: pairs one workgroup searches >= 0");
+        c->sp_max_pairs = value;
+        return EK_OK;
     case 2:
         if (value < 0 || value > 2)
             return ek_fail(EK_EARG, "ek_set_option: assign variant 0..2");
@@ -693,6 +717,15 @@ extern "C" int ek_history_reset(ek_ctx *c)
     return EK_OK;
 }
 
+// the state is about to be replaced: what a PAM prefetch derived from it (the
+// frames a window's proposals can touch, +inf for the rest) no longer holds
+static void ek_pam_forget(ek_ctx *c)
+{
+    c->pf_count = 0;
+    c->tab_n = 0;
+    c->sp_ready = false;
+}
+
 extern "C" int ek_state_reset(ek_ctx *c)
 {
     if (!c)
@@ -704,6 +737,7 @@ extern "C" int ek_state_reset(ek_ctx *c)
                          c->stream);
     EK_CHECK_LAUNCH();
     c->state_exact = true;      // k-centers labels name frames, at their distance
+    ek_pam_forget(c);
     int rc = ek_history_reset(c);
     if (rc)
         return rc;
@@ -742,6 +776,7 @@ extern "C" int ek_state_upload(ek_ctx *c, const float *dist_host,
     }
     EK_HIP(hipStreamSynchronize(c->stream));
     c->state_exact = false;     // the caller's numbers: taken as they are
+    ek_pam_forget(c);
     return ek_local_candidate(c, nullptr);
 }
 
@@ -1409,6 +1444,7 @@ extern "C" int ek_assign_nearest(ek_ctx *c, const float *centers_xyz,
                                 "center tile (limit 1600)", c->A);
     EK_HIP(hipSetDevice(c->device));
     c->state_exact = false;     // labels name the caller's centers, not frames
+    ek_pam_forget(c);
     if (n_centers > 0) {
         int rc = ek_upload_centers(c, centers_xyz, n_centers);
         if (rc)
@@ -1517,6 +1553,9 @@ static int ek_pam_alloc(ek_ctx *c, int32_t K)
     }
     c->pam_restore = -1;
     c->pf_backoff = 0;
+    c->sp_ready = false;
+    c->sp_backoff = 0;
+    c->sp_backoff_next = 8;
     c->bat_cid0 = -1;
     c->bat_count = 0;
     c->pf_count = 0;
@@ -1697,6 +1736,7 @@ static int ek_pam_tail(ek_ctx *c, int32_t cid, const float *newd,
 {
     const int K = c->med_K;
     const int fuse = decide != nullptr;
+    c->sp_ready = false;        // c->amb is the ambiguous members' list from here on
     // only when dist[f] is known to be the distance to medoid assign[f] (a state
     // this library produced; not one uploaded by the caller) may the search skip
     // medoids out of the members' reach
@@ -2031,6 +2071,7 @@ static int ek_pam_prefetch_vectors(ek_ctx *c, int count, int32_t win_lo,
                                    bool prepared = false)
 {
     c->tab_n = 0;
+    c->sp_ready = false;
     const int K = c->med_K;
     if (c->pf_backoff > 0)
         --c->pf_backoff;
@@ -2049,9 +2090,19 @@ static int ek_pam_prefetch_vectors(ek_ctx *c, int count, int32_t win_lo,
                              c->dtab + tb, c->dtab + 2 * tb, c->stream);
         c->tab_lo = win_lo;
         c->tab_n = slots ? count : 0;
+        if (!c->act_list)
+            EK_HIP(hipMalloc((void **)&c->act_list,
+                             (size_t)std::max<int64_t>(c->n, 1) * sizeof(uint32_t)));
+        // the vectors go back to +inf: the entries the window before wrote, if
+        // that is all there is (before the list is overwritten)
+        const bool sparse_reset = c->vecs_rows >= 0 && c->vecs_cols >= count;
+        if (sparse_reset)
+            ek_launch_pam_vecs_reset(c->act_list, c->vecs_rows, c->vecs_cols, c->n_pad,
+                                     c->pam_vecs, c->stream);
+        c->vecs_rows = -1;
         ek_launch_pam_active(c->dist, c->assign, c->n, c->dtab + 2 * tb, groups, K,
-                             win_lo, win_count, c->amb, c->amb_count + 3, c->stream,
-                             prepared);
+                             win_lo, win_count, c->act_list, c->amb_count + 3,
+                             c->stream, prepared);
         EK_CHECK_LAUNCH();
         EK_HIP(hipMemcpyAsync(c->act_n_host, c->amb_count + 3, sizeof(unsigned int),
                               hipMemcpyDeviceToHost, c->stream));
@@ -2062,12 +2113,19 @@ static int ek_pam_prefetch_vectors(ek_ctx *c, int count, int32_t win_lo,
             // proposals per workgroup, results scattered into the full vectors
             // (a quarter of the frames costs about what the passes over all of
             // them do)
-            EK_HIP(hipMemsetD32Async((hipDeviceptr_t)c->pam_vecs, 0x7f800000,
-                                     (size_t)count * c->n_pad, c->stream));
-            ek_launch_pam_list_dist(c->aos, c->G, c->A, c->amb, n_act, c->pam_recs,
+            if (!sparse_reset)
+                EK_HIP(hipMemsetD32Async((hipDeviceptr_t)c->pam_vecs, 0x7f800000,
+                                         (size_t)count * c->n_pad, c->stream));
+            ek_launch_pam_list_dist(c->aos, c->G, c->A, c->act_list, n_act, c->pam_recs,
                                     count, c->pam_vecs, c->n_pad, c->stream);
             EK_CHECK_LAUNCH();
+            c->vecs_rows = n_act;
+            c->vecs_cols = sparse_reset ? c->vecs_cols : count;
             ++c->pf_sparse;
+            // the list stays in c->amb until something else uses it: a window run
+            // right away may work from it (ek_pam_sparse.hip)
+            c->sp_ready = slots && n_act <= EK_SP_CAP;
+            c->sp_nact = n_act;
             return EK_OK;
         }
         // too many frames within reach (large clusters): the test cost a table,
@@ -2075,6 +2133,7 @@ static int ek_pam_prefetch_vectors(ek_ctx *c, int count, int32_t win_lo,
         c->pf_backoff = 15;
     }
     // a pass over all frames per group of EK_PAM_GROUP proposals
+    c->vecs_rows = -1;          // (whole vectors are written)
     const size_t rstride = ek_rec_bytes(c->A);
     for (int g0 = 0; g0 < count; g0 += EK_PAM_GROUP)
         ek_launch_pass_dist(std::min(count - g0, EK_PAM_GROUP), c->tiles, c->G,
@@ -2148,6 +2207,90 @@ static int ek_pam_prefetch_frames(ek_ctx *c, const int64_t *frames, int32_t coun
     return EK_OK;
 }
 
+// The same window worked through by one workgroup (ek_pam_sparse.hip): possible
+// when the prefetch just made was restricted to a list of frames (still in
+// c->amb) and the window's tables are in place.  Enqueues; the caller reads the
+// window record back.
+static int ek_pam_window_sparse(ek_ctx *c, int32_t cid0, int32_t count,
+                                const int64_t *frames, const int64_t *n_members,
+                                int32_t win_count)
+{
+    const size_t cap = EK_SP_CAP;
+    const size_t o_bucket = 0;
+    const size_t o_bcnt = o_bucket + (size_t)EK_PAM_WIN * cap * sizeof(uint2);
+    if (!c->sp_buf)
+        EK_HIP(hipMalloc((void **)&c->sp_buf, o_bcnt + 256));
+    const int K = c->med_K;
+    const size_t tb = (size_t)EK_PAM_WIN * (c->med_cap + 1);
+    // the state's cost tree, the slots' frames
+    ek_launch_pw_tree(c->dist, c->assign, c->n, c->pw_shapes, c->pw_n_full,
+                      c->pw_leaves, c->pw_chunks, c->sq_part, c->moved, c->stream);
+    ek_launch_sp_bucket(c->act_list, c->sp_nact, c->dist, c->assign, c->pam_vecs, c->n_pad,
+                        cid0, count, (uint2 *)(c->sp_buf + o_bucket),
+                        (unsigned int *)(c->sp_buf + o_bcnt), (int64_t)cap, c->stream);
+    EkSpArgs a = {};
+    a.dist = c->dist;
+    a.assign = c->assign;
+    a.n = c->n;
+    a.n_total = (double)c->n;
+    a.A = c->A;
+    a.K = K;
+    a.cid0 = cid0;
+    a.count = count;
+    a.win_count = win_count;
+    a.vecs = c->pam_vecs;
+    a.n_pad = c->n_pad;
+    a.bucket = (const uint2 *)(c->sp_buf + o_bucket);
+    a.bcnt = (const unsigned int *)(c->sp_buf + o_bcnt);
+    a.bcap = (int64_t)cap;
+    for (int32_t i = 0; i < EK_PAM_WIN; ++i) {
+        a.frames[i] = i < count ? frames[i] : 0;
+        a.max_amb[i] = i < count ? n_members[i] : 0;
+    }
+    a.O = c->dtab + tb;
+    a.T = c->dtab;
+    a.med_aos = c->med_aos;
+    a.med_G = c->med_G;
+    a.med_idx = c->med_idx;
+    a.restore = c->pam_restore;
+    a.frames_aos = c->aos;
+    a.G = c->G;
+    a.leaf = c->sq_part;
+    a.chunk = c->sq_part + 2 * (size_t)c->pw_leaves;
+    a.shapes = c->pw_shapes;
+    a.n_full = c->pw_n_full;
+    a.n_leaves = c->pw_leaves;
+    a.n_chunks = c->pw_chunks;
+    a.max_pairs = c->sp_max_pairs;
+    a.win = c->pam_win_dev;
+#ifdef EK_SP_PROF
+    static unsigned long long *prof_dev = nullptr;
+    static unsigned long long prof_tot[16];
+    static int prof_n = 0;
+    if (!prof_dev) {
+        EK_HIP(hipMalloc((void **)&prof_dev, 16 * sizeof(unsigned long long)));
+        EK_HIP(hipMemset(prof_dev, 0, 16 * sizeof(unsigned long long)));
+    }
+    a.prof = prof_dev;
+    if (++prof_n % 100 == 0) {
+        EK_HIP(ek_wait(c));
+        EK_HIP(hipMemcpy(prof_tot, prof_dev, sizeof(prof_tot), hipMemcpyDeviceToHost));
+        fprintf(stderr, "sp prof after %d windows (ms): classify %.2f search %.2f apply %.2f "
+                        "leaves %.2f chunks %.2f total %.2f verdict %.2f keep/undo %.2f [issue %.2f loop %.2f]\n",
+                prof_n, prof_tot[0] * 1e-5, prof_tot[1] * 1e-5, prof_tot[2] * 1e-5,
+                prof_tot[3] * 1e-5, prof_tot[4] * 1e-5, prof_tot[5] * 1e-5,
+                prof_tot[6] * 1e-5, prof_tot[7] * 1e-5, prof_tot[8] * 1e-5, prof_tot[9] * 1e-5);
+    }
+#endif
+    ek_launch_sp_window(a, c->stream);
+    EK_CHECK_LAUNCH();
+    c->pam_restore = -1;
+    c->sp_ready = false;
+    c->pf_hits += count;
+    ++c->sp_windows;
+    return EK_OK;
+}
+
 // A window of proposals without a host round trip each (reference
 // kmedoids.py:575-699 for clusters cid0 .. cid0 + count - 1, in order).  frames[i]
 // is the frame proposed for cluster cid0 + i -- the caller drew it from the
@@ -2196,11 +2339,29 @@ extern "C" int ek_pam_window_run(ek_ctx *c, int32_t cid0, int32_t count,
                                       "prefetched", (long long)frames[i]);
         max_m = std::max(max_m, n_members[i]);
     }
-    rc = ek_pam_amb_room(c, max_m);      // may synchronise: before anything is enqueued
-    if (rc)
-        return rc;
+    // (a window that had to hand a proposal back -- more ambiguous members x
+    // medoids within reach than one workgroup should search -- cost a window's
+    // set-up for one slot: the next few go the three-launch way, twice as many
+    // each time it happens again)
+    if (c->sp_backoff > 0)
+        --c->sp_backoff;
+    bool sparse = c->pam_sparse && c->sp_ready && c->tab_lo == cid0 &&
+                  count <= c->tab_n && c->prune && c->state_exact && c->A >= 3 &&
+                  c->aos != nullptr && c->pw_chunks <= EK_SP_MAX_CHUNKS &&
+                  (c->sp_backoff == 0 || c->sp_max_pairs == 0);
+    for (int32_t i = 0; sparse && i < count; ++i)
+        sparse = newd[i] == c->pam_vecs + (size_t)i * c->n_pad;
+    if (sparse) {
+        rc = ek_pam_window_sparse(c, cid0, count, frames, n_members, win_count);
+        if (rc)
+            return rc;
+    } else {
+        rc = ek_pam_amb_room(c, max_m);  // may synchronise: before anything is enqueued
+        if (rc)
+            return rc;
+    }
     const int K = c->med_K;
-    for (int32_t i = 0; i < count; ++i) {
+    for (int32_t i = 0; !sparse && i < count; ++i) {
         const int32_t cid = cid0 + i;
         // the first proposal's trial table (and the window record: `count`
         // slots, nothing decided); the others' are set up by the last workgroup
@@ -2239,8 +2400,9 @@ extern "C" int ek_pam_window_run(ek_ctx *c, int32_t cid0, int32_t count,
     }
     // the last slot's trial state, if accepted (the others were taken over by
     // the classification of the slot after them)
-    ek_launch_pam_apply(&c->pam_win_dev->accept[count - 1], c->dist, c->ndist,
-                        c->assign, c->nassign, c->n, c->stream);
+    if (!sparse)
+        ek_launch_pam_apply(&c->pam_win_dev->accept[count - 1], c->dist, c->ndist,
+                            c->assign, c->nassign, c->n, c->stream);
     EK_CHECK_LAUNCH();
     EK_HIP(hipMemcpyAsync(c->pam_win_host, c->pam_win_dev, sizeof(EkPamWin),
                           hipMemcpyDeviceToHost, c->stream));
@@ -2250,6 +2412,15 @@ extern "C" int ek_pam_window_run(ek_ctx *c, int32_t cid0, int32_t count,
     c->pam_cid = -1;
     c->cnt_cid = -1;
     c->pf_hits -= count - w.stop;       // the slots past the stop were not served
+    if (sparse) {
+        if (w.pad) {
+            ++c->sp_bailed;
+            c->sp_backoff = c->sp_backoff_next;
+            c->sp_backoff_next = std::min(256, 2 * c->sp_backoff_next);
+        } else {
+            c->sp_backoff_next = 8;
+        }
+    }
     if (w.err)
         return ek_fail(EK_EARG, "PAM proposal: cluster %d has more members that "
                                 "stay put than the %lld members declared",
@@ -2405,6 +2576,17 @@ extern "C" int ek_pam_prefetch_passes(ek_ctx *c, int64_t *restricted,
         *restricted = c->pf_sparse;
     if (full)
         *full = c->pf_full;
+    return EK_OK;
+}
+
+extern "C" int ek_pam_sparse_stats(ek_ctx *c, int64_t *windows, int64_t *ended_early)
+{
+    if (!c)
+        return ek_fail(EK_EARG, "NULL context");
+    if (windows)
+        *windows = c->sp_windows;
+    if (ended_early)
+        *ended_early = c->sp_bailed;
     return EK_OK;
 }
 

@@ -459,6 +459,12 @@ void ek_launch_sumsq_pack(const float *a, float *b, const int32_t *assign,
                           const unsigned long long *amb_best = nullptr,
                           unsigned int *tick = nullptr,
                           const EkPamDecide *decide = nullptr);
+void ek_launch_pam_vecs_reset(const uint32_t *list, int64_t n_rows, int cols,
+                              int64_t n_pad, float *vecs, hipStream_t s);
+void ek_launch_pw_tree(const float *dist, const int32_t *assign, int64_t n,
+                       const EkPwShape *shapes, int n_full, int n_leaves_total,
+                       int n_chunks, double *part, unsigned int *mask_scratch,
+                       hipStream_t s);
 void ek_launch_gather_rows(const float *tiles, const double *G, int A,
                            const int64_t *idx_dev, const int64_t *rows_dev,
                            int count, float *out_aos, double *outG, hipStream_t s);

@@ -1491,6 +1491,25 @@ void ek_launch_sumsq_pack(const float *a, float *b, const int32_t *assign,
                        n_chunks, n_amb, moved, n, out);
 }
 
+// leaf sums and chunk sums of one array alone (the tree ek_pam_sparse.hip keeps
+// up to date): part[2 g] / part[2 (n_leaves + c)], the odd entries are scratch
+void ek_launch_pw_tree(const float *dist, const int32_t *assign, int64_t n,
+                       const EkPwShape *shapes, int n_full, int n_leaves_total,
+                       int n_chunks, double *part, unsigned int *mask_scratch,
+                       hipStream_t s)
+{
+    if (n_leaves_total <= 0)
+        return;
+    const int per = EK_BLOCK / 8;
+    hipLaunchKernelGGL((ek_pw_leaf_kernel<false>),
+                       dim3((n_leaves_total + per - 1) / per), dim3(EK_BLOCK), 0, s,
+                       dist, const_cast<float *>(dist), assign,
+                       const_cast<int32_t *>(assign), nullptr, n, 0, 0, shapes, n_full,
+                       n_leaves_total, part, mask_scratch);
+    hipLaunchKernelGGL(ek_pw_chunk_kernel, dim3(n_chunks), dim3(128), 0, s, part,
+                       shapes, n_full, part + 2 * (size_t)n_leaves_total);
+}
+
 // host: the pairwise tree of a chunk of `len` elements (len <= EK_PW_CHUNK)
 static int ek_pw_rec(int off, int len, EkPwShape *sh, int *node_level,
                      int *tmp_l, int *tmp_r, int *n_tmp)
@@ -1850,6 +1869,27 @@ void ek_launch_pam_active(const float *dist, const int32_t *assign, int64_t n,
     hipLaunchKernelGGL(ek_pam_active_kernel, dim3((unsigned)((n + per - 1) / per)),
                        dim3(EK_BLOCK), 0, s, dist, assign, n, dmin, n_groups, K,
                        win_lo, win_count, list, n_list);
+}
+
+// The distance vectors are +inf except at the frames of the window before: those
+// entries alone go back to +inf (instead of filling `cols` whole vectors).
+__global__ void __launch_bounds__(EK_BLOCK)
+ek_pam_vecs_reset_kernel(const uint32_t *__restrict__ list, int64_t n_rows, int64_t n_pad,
+                         float *__restrict__ vecs)
+{
+    const int64_t i = (int64_t)blockIdx.x * EK_BLOCK + threadIdx.x;
+    if (i < n_rows)
+        vecs[(size_t)blockIdx.y * n_pad + list[i]] = __builtin_inff();
+}
+
+void ek_launch_pam_vecs_reset(const uint32_t *list, int64_t n_rows, int cols,
+                              int64_t n_pad, float *vecs, hipStream_t s)
+{
+    if (n_rows <= 0 || cols <= 0)
+        return;
+    hipLaunchKernelGGL(ek_pam_vecs_reset_kernel,
+                       dim3((unsigned)((n_rows + EK_BLOCK - 1) / EK_BLOCK), cols),
+                       dim3(EK_BLOCK), 0, s, list, n_rows, n_pad, vecs);
 }
 
 // the records of up to EK_PAM_WIN frames in one launch (block j = frame j)

@@ -1,0 +1,50 @@
+// ek_pam_sparse.h -- a window of PAM proposals in one workgroup (ek_pam_sparse.hip)
+#pragma once
+#include "ek_common.h"
+
+#define EK_SP_THREADS 512
+// frames on a window's list (ek_pam_active_kernel) up to which the one-workgroup
+// form is used; above it the three launches per proposal of ek_pam.hip are
+#define EK_SP_CAP 65536
+// (ambiguous member, medoid within reach) pairs one workgroup searches itself;
+// a proposal with more ends the window and goes through the launches
+#define EK_SP_MAX_PAIRS 16384
+// chunks of 8192 frames whose sums the workgroup keeps in LDS (shards of up to
+// 8.4 million frames)
+#define EK_SP_MAX_CHUNKS 1024
+
+struct EkSpArgs {
+    float *dist;                // the state; trial values are written into it and
+    int32_t *assign;            //   taken back if the proposal is rejected
+    int64_t n;
+    double n_total;             // the means' divisor
+    int32_t A, K, cid0, count, win_count;
+    const float *vecs;          // [slot][n_pad] distances to the proposals (by frame)
+    int64_t n_pad;
+    const uint2 *bucket;        // [slot][bcap] the frames a slot looks at, with their
+                                //   distance to the slot's proposal
+    const unsigned int *bcnt;
+    int64_t bcap;
+    int64_t frames[EK_PAM_WIN]; // the proposed frames
+    int64_t max_amb[EK_PAM_WIN];// members declared for the slots' clusters
+    const float *O, *T;         // the window's tables (ek_pam_pairs_kernel<0>)
+    float *med_aos;             // medoid table [K + 1][3A]
+    double *med_G;
+    int64_t *med_idx;
+    int32_t restore;            // row a rejected proposal still occupies, or -1
+    const float *frames_aos;    // frame-major copy of the shard
+    const double *G;
+    double *leaf;               // [2 g] leaf sum of the state, [2 g + 1] the value before
+    double *chunk;              // same per chunk
+    const EkPwShape *shapes;
+    int32_t n_full, n_leaves, n_chunks;
+    int64_t max_pairs;
+    EkPamWin *win;
+    unsigned long long *prof;   // measurement builds (EK_SP_PROF): 10 ns ticks per step
+};
+
+void ek_launch_sp_bucket(const uint32_t *list, int64_t n_act, const float *dist,
+                         const int32_t *assign, const float *vecs, int64_t n_pad,
+                         int32_t cid0, int count, uint2 *bucket,
+                         unsigned int *bcnt, int64_t bcap, hipStream_t s);
+void ek_launch_sp_window(const EkSpArgs &p, hipStream_t s);

@@ -1,0 +1,754 @@
+// ek_pam_sparse.hip -- a window of PAM proposals worked through by ONE workgroup.
+//
+// Same arithmetic and same outcome as the three launches per proposal of
+// ek_pam.hip ("a window of proposals decided on the device"; reference
+// enspara/cluster/kmedoids.py:610-690), for windows whose prefetch was
+// restricted to the frames a proposal can touch (ek_pam.hip, "proposal prefetch
+// restricted ..."): every frame outside that list keeps its label and distance
+// whatever the window does, so a proposal is
+//   * the classification (kmedoids.py:644-658) of ITS frames only -- the members
+//     of its cluster and the listed frames closer to it than to their medoid at
+//     the time the window was opened (ek_sp_bucket_kernel; a distance only grows
+//     for the members an accepted earlier slot's proposal is farther from, and
+//     the list allows for that);
+//   * the search of kmedoids.py:666 for the members the proposal is farther
+//     from, over the medoids within their reach (the window's tables, as in
+//     ek_pam_classify_window_kernel's last workgroup): 64 members x 16 medoids
+//     per step through LDS, every pair one lane's IEEE FMA chains in ascending
+//     atom order and ek_rmsd_from_S, as everywhere else;
+//   * the two cost sums in numpy's order (ek_pam.hip, "cost sums in numpy's
+//     order") -- kept as a tree: leaf sums and chunk sums of the current state
+//     sit in memory, a proposal writes its changes into the state, re-adds the
+//     leaves and chunks it touched, adds the chunks up left to right, decides
+//     (mean of squares, float64, strict <: kmedoids.py:478-479, :683) and either
+//     keeps all that or puts the old values back.
+// No launch, no arrival counter and no other workgroup between two proposals:
+// the steps are separated by workgroup barriers.  A dependent launch costs
+// ~4.5 us on this GPU and the three-launch form spends ~29 us per proposal at
+// 10^6 frames, two thirds of it launch gaps and single-workgroup tails.
+#include "ek_common.h"
+#include "ek_qcp.h"
+#include "ek_pam_sparse.h"
+#include "ek_lanes.h"
+#include <algorithm>
+
+#define SP_NT EK_SP_THREADS
+#ifdef EK_SP_PROF
+#define SP_T(k)                                                                \
+    do {                                                                       \
+        if (t == 0 && p.prof) {                                                \
+            const unsigned long long now = wall_clock64();                     \
+            p.prof[k] += now - sp_t0;                                          \
+            sp_t0 = now;                                                       \
+        }                                                                      \
+    } while (0)
+#else
+#define SP_T(k)
+#endif
+#define SP_WAVES (SP_NT / EK_WAVE)
+#define SP_CH 64                            // atoms per LDS slice of the search
+#define SP_LD (EK_WAVE + 1)
+
+// ---- per slot: the frames it has to look at --------------------------------------------
+// list position p, slot j: frame f = list[p] goes into bucket j if it is a member
+// of cluster cid0 + j or closer to proposal j than to its medoid (the test of
+// kmedoids.py:644) -- on the state the window opens with, which is enough: until
+// slot j's turn a frame's distance only shrinks, except for the members an
+// accepted proposal i < j is farther from (see `grown` below)
+__global__ void __launch_bounds__(EK_BLOCK)
+ek_sp_bucket_kernel(const uint32_t *__restrict__ list, int64_t n_act,
+                    const float *__restrict__ dist,
+                    const int32_t *__restrict__ assign,
+                    const float *__restrict__ vecs, int64_t n_pad, int32_t cid0,
+                    int count, uint2 *__restrict__ bucket,
+                    unsigned int *__restrict__ bcnt, int64_t bcap)
+{
+    static_assert(EK_PAM_WIN <= 32, "one lane per slot adds up a wave's entries");
+    const int lane = threadIdx.x & (EK_WAVE - 1);
+    const int64_t p = (int64_t)blockIdx.x * EK_BLOCK + threadIdx.x;
+    const bool ok = p < n_act;
+    const uint32_t f = ok ? list[p] : 0u;
+    const float d = ok ? dist[f] : 0.f;
+    const int32_t a = ok ? assign[f] : -1;
+    float nd[EK_PAM_WIN];                       // all gathers in flight at once
+#pragma unroll
+    for (int j = 0; j < EK_PAM_WIN; ++j)
+        nd[j] = (ok && j < count) ? vecs[(size_t)j * n_pad + f] : __builtin_inff();
+    // A member of the window's cluster i may be left farther from its medoid than
+    // it is now when proposal i is accepted -- but not farther than from proposal
+    // i itself, which is a medoid then: for the slots after i that distance is
+    // the bound the test is made with.
+    const int i = a - cid0;
+    float grown = d;
+#pragma unroll
+    for (int j = 0; j < EK_PAM_WIN; ++j)
+        if (j == i)
+            grown = fmaxf(d, nd[j]);
+    uint32_t hit = 0;
+#pragma unroll
+    for (int j = 0; j < EK_PAM_WIN; ++j)
+        if (ok && j < count && (a == cid0 + j || (j > i ? grown : d) > nd[j]))
+            hit |= 1u << j;
+    // lane j asks for the room of the wave's entries in bucket j
+    unsigned int mine = 0;
+#pragma unroll
+    for (int j = 0; j < EK_PAM_WIN; ++j) {
+        const unsigned long long m = __ballot((hit >> j) & 1u);
+        if (lane == j)
+            mine = (unsigned int)__popcll(m);
+    }
+    const unsigned int base = mine ? atomicAdd(&bcnt[lane], mine) : 0u;
+#pragma unroll
+    for (int j = 0; j < EK_PAM_WIN; ++j) {
+        const bool h = (hit >> j) & 1u;
+        const unsigned long long m = __ballot(h);
+        const unsigned int b = __shfl(base, j, EK_WAVE);
+        if (h) {
+            const unsigned int pos = b + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
+            // with its distance to the proposal: the window's workgroup would
+            // wait a cold gather for it
+            if ((int64_t)pos < bcap)
+                bucket[(size_t)j * bcap + pos] = make_uint2(f, __float_as_uint(nd[j]));
+        }
+    }
+}
+
+void ek_launch_sp_bucket(const uint32_t *list, int64_t n_act, const float *dist,
+                         const int32_t *assign, const float *vecs, int64_t n_pad,
+                         int32_t cid0, int count, uint2 *bucket,
+                         unsigned int *bcnt, int64_t bcap, hipStream_t s)
+{
+    (void)hipMemsetAsync(bcnt, 0, EK_PAM_WIN * sizeof(unsigned int), s);
+    if (n_act <= 0)
+        return;
+    hipLaunchKernelGGL(ek_sp_bucket_kernel,
+                       dim3((unsigned)((n_act + EK_BLOCK - 1) / EK_BLOCK)),
+                       dim3(EK_BLOCK), 0, s, list, n_act, dist, assign, vecs, n_pad,
+                       cid0, count, bucket, bcnt, bcap);
+}
+
+// ---- numpy's leaf: eight interleaved running sums, combined pairwise, then the tail ------
+// called by eight consecutive lanes (l8 = lane & 7); the sum is lane l8 == 0's
+__device__ __forceinline__ double ek_sp_leaf(const float *__restrict__ d, int64_t off,
+                                             int len, int l8)
+{
+    double r = 0.0;
+    const int body = (len < 8) ? 0 : len - (len % 8);
+    if (len == 128) {
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            v[i] = d[off + 8 * i + l8];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const double x = v[i];
+            r = (i == 0) ? x * x : r + x * x;
+        }
+    } else {
+        for (int i = 0; i < body; i += 8) {
+            const double x = d[off + i + l8];
+            r = (i == 0) ? x * x : r + x * x;
+        }
+    }
+    if (body > 0) {
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1)
+            r = r + __shfl_xor(r, o, 8);
+    }
+    if (l8 == 0)
+        for (int i = body; i < len; ++i) {
+            const double x = d[off + i];
+            r = r + x * x;
+        }
+    return r;
+}
+
+// the leaf a frame belongs to
+__device__ __forceinline__ int ek_sp_leaf_of(int64_t f, const EkSpArgs &p)
+{
+    const int64_t full = (int64_t)p.n_full * EK_PW_CHUNK;
+    if (f < full)
+        return (int)(f / 128);
+    const EkPwShape *sh = &p.shapes[1];
+    const int rel = (int)(f - full);
+    int lo = 0, hi = sh->n_leaves - 1;          // last leaf starting at or before rel
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) / 2;
+        if (sh->leaf_off[mid] <= rel)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    return p.n_full * EK_PW_FULL_LEAVES + lo;
+}
+
+// A workgroup barrier for steps that hand over LDS contents only.  __syncthreads()
+// also waits for every global load still in flight (its release fence is
+// s_waitcnt vmcnt(0)), which would make each barrier wait for the loads asked for
+// ahead of time -- the next slot's frames, the tables -- at memory latency.
+__device__ __forceinline__ void ek_lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+__device__ __forceinline__ unsigned long long ek_sp_key(float d, int32_t c)
+{
+    return ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)c;
+}
+
+// the chunks left to right (numpy adds its buffer's partial sums in order).  The
+// chunk sums of the state live in LDS for the whole window (padded with +0.0 to a
+// multiple of 16: the sum of squares is >= +0 and stays what it is); every wave
+// adds them up for itself, all lanes alike -- broadcast reads, sixteen in flight,
+// the chain of additions is the only thing that takes time -- so nothing has to
+// be handed from one wave to the others.
+__device__ __forceinline__ double ek_sp_total(const double *s_chunk, int n_chunks)
+{
+    double sum = 0.0;
+    for (int c0 = 0; c0 < n_chunks; c0 += 16) {
+        double x[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            x[j] = s_chunk[c0 + j];
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            sum = sum + x[j];
+    }
+    return sum;
+}
+
+// the last, shorter chunk's own tree over its leaves (whole workgroup) -> *out
+__device__ void ek_sp_ragged(const EkSpArgs &p, double *la, double *out)
+{
+    const EkPwShape *sh = &p.shapes[1];
+    const int t = threadIdx.x, nl = sh->n_leaves;
+    const size_t g0 = (size_t)p.n_full * EK_PW_FULL_LEAVES;
+    for (int i = t; i < nl; i += SP_NT)
+        la[i] = p.leaf[2 * (g0 + i)];
+    __syncthreads();
+    for (int lev = 0; lev < sh->n_levels; ++lev) {
+        const int k0 = sh->level_start[lev], k1 = sh->level_start[lev + 1];
+        for (int k = k0 + t; k < k1; k += SP_NT)
+            la[nl + k] = la[sh->node_l[k]] + la[sh->node_r[k]];
+        __syncthreads();
+    }
+    if (t == 0)
+        *out = la[(sh->n_nodes > 0) ? nl + sh->n_nodes - 1 : 0];
+    __syncthreads();
+}
+
+// the lists of a proposal are kept in LDS: a dependent trip to memory costs about
+// a microsecond, and that -- not arithmetic -- is what a proposal's time is made of
+#define SP_KU 10        // table entries a thread asks for ahead of the search
+#define SP_LB 6         // leaves a group of eight lanes re-adds with its loads in flight
+#define SP_CB 8         // pairs of chunks a wave does with its loads in flight
+#define SP_CAP_CHG 2048 // frames a proposal may change
+#define SP_CAP_AMB 1024 // members it may leave behind
+#define SP_CAP_COLS 256 // medoids within their reach
+
+struct EkSpLds {        // byte offsets into the dynamic LDS block
+    static constexpr size_t tile = 0;
+    static constexpr size_t ytile = tile + (size_t)3 * SP_CH * SP_LD * 4;
+    static constexpr size_t chunk = ytile + (size_t)SP_WAVES * 3 * SP_CH * 4;
+    static constexpr size_t chunk_old = chunk + (size_t)EK_SP_MAX_CHUNKS * 8;
+    static constexpr size_t amb_key = chunk_old + (size_t)EK_SP_MAX_CHUNKS * 8;
+    static constexpr size_t lbits = amb_key + (size_t)SP_CAP_AMB * 8;
+    static constexpr size_t chg_f = lbits + (size_t)EK_SP_MAX_CHUNKS * EK_PW_FULL_LEAVES / 8;
+    static constexpr size_t chg_od = chg_f + (size_t)SP_CAP_CHG * 4;
+    static constexpr size_t chg_nd = chg_od + (size_t)SP_CAP_CHG * 4;
+    static constexpr size_t chg_oa = chg_nd + (size_t)SP_CAP_CHG * 4;
+    static constexpr size_t chg_na = chg_oa + (size_t)SP_CAP_CHG * 4;
+    static constexpr size_t amb_f = chg_na + (size_t)SP_CAP_CHG * 4;
+    static constexpr size_t amb_d = amb_f + (size_t)SP_CAP_AMB * 4;
+    static constexpr size_t tleaf = amb_d + (size_t)SP_CAP_AMB * 4;
+    static constexpr size_t cols = tleaf + (size_t)SP_CAP_CHG * 4;
+    static constexpr size_t end = cols + (size_t)SP_CAP_COLS * 4;
+};
+static_assert(EkSpLds::chunk % 8 == 0 && EkSpLds::amb_key % 8 == 0, "doubles");
+static_assert(EkSpLds::end + 2048 <= 160 * 1024, "one workgroup's LDS");
+static_assert((size_t)3 * SP_CH * SP_LD * 4 >= 2 * EK_PW_MAX_LEAVES * 8,
+              "the last chunk's tree shares the search's tile");
+
+__global__ void __launch_bounds__(SP_NT)
+ek_sp_window_kernel(EkSpArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char sp_lds[];
+    float *tile = (float *)(sp_lds + EkSpLds::tile);            // [3 CH][LD]
+    float *ytile = (float *)(sp_lds + EkSpLds::ytile);          // [waves][3 CH]
+    double *la = (double *)(sp_lds + EkSpLds::tile);            // (outside the search)
+    double *s_chunk = (double *)(sp_lds + EkSpLds::chunk);
+    double *s_chunk_old = (double *)(sp_lds + EkSpLds::chunk_old);
+    unsigned long long *amb_key = (unsigned long long *)(sp_lds + EkSpLds::amb_key);
+    uint32_t *s_lbits = (uint32_t *)(sp_lds + EkSpLds::lbits);
+    uint32_t *chg_f = (uint32_t *)(sp_lds + EkSpLds::chg_f);
+    float *chg_od = (float *)(sp_lds + EkSpLds::chg_od);
+    float *chg_nd = (float *)(sp_lds + EkSpLds::chg_nd);
+    int32_t *chg_oa = (int32_t *)(sp_lds + EkSpLds::chg_oa);
+    int32_t *chg_na = (int32_t *)(sp_lds + EkSpLds::chg_na);
+    uint32_t *amb_f = (uint32_t *)(sp_lds + EkSpLds::amb_f);
+    float *amb_d = (float *)(sp_lds + EkSpLds::amb_d);
+    int32_t *tleaf = (int32_t *)(sp_lds + EkSpLds::tleaf);
+    int32_t *cols = (int32_t *)(sp_lds + EkSpLds::cols);
+    __shared__ unsigned long long s_best[EK_WAVE];
+    __shared__ uint32_t s_rowf[EK_WAVE];
+    __shared__ uint32_t s_cbits[EK_SP_MAX_CHUNKS / 32];
+    __shared__ unsigned int s_n_chg, s_n_amb, s_reach, s_n_col, s_mask, s_n_leaf;
+    __shared__ float s_T[EK_PAM_WIN];
+    __shared__ unsigned int s_bcnt[EK_PAM_WIN + 1];
+    __shared__ int s_stop, s_acc[EK_PAM_WIN];
+    __shared__ uint32_t s_stale;
+    __shared__ EkPamWin s_win;
+    const int t = threadIdx.x, lane = t & (EK_WAVE - 1),
+              wv = __builtin_amdgcn_readfirstlane(t / EK_WAVE);
+    const int A = p.A, K = p.K;
+
+    // ---- the window record; a row a rejected proposal still sits in --------------------
+    for (int i = t; i < (int)(sizeof(EkPamWin) / 4); i += SP_NT)
+        ((uint32_t *)&s_win)[i] = (i == 0) ? (uint32_t)p.count : 0u;
+    if (p.restore >= 0) {
+        for (int r = t; r < 3 * A; r += SP_NT)
+            p.med_aos[(size_t)p.restore * 3 * A + r] = p.med_aos[(size_t)K * 3 * A + r];
+        if (t == 0)
+            p.med_G[p.restore] = p.med_G[K];
+    }
+    for (int c = t; c < EK_SP_MAX_CHUNKS; c += SP_NT)
+        s_chunk[c] = (c < p.n_chunks) ? p.chunk[2 * (size_t)c] : 0.0;
+    for (int i = t; i < EK_SP_MAX_CHUNKS * EK_PW_FULL_LEAVES / 32; i += SP_NT)
+        s_lbits[i] = 0;
+    if (t < EK_SP_MAX_CHUNKS / 32)
+        s_cbits[t] = 0;
+    if (t < EK_PAM_WIN)
+        s_acc[t] = 0;
+    if (t <= EK_PAM_WIN)
+        s_bcnt[t] = (t < p.count) ? min(p.bcnt[t], (unsigned int)p.bcap) : 0u;
+    if (t == 0) {
+        s_stop = p.count;
+        s_stale = 0;
+        s_n_chg = 0;
+        s_n_amb = 0;
+        s_reach = 0;
+        s_n_col = 0;
+        s_mask = 0;
+        s_n_leaf = 0;
+    }
+    // the first slot's frames; every slot fetches the next one's while it works
+    uint2 f_pre = make_uint2(0u, 0u);
+    if ((unsigned int)t < min(p.bcnt[0], (unsigned int)p.bcap))
+        f_pre = p.bucket[t];
+    __syncthreads();
+    double total = ek_sp_total(s_chunk, p.n_chunks);      // the state's sum of squares
+#ifdef EK_SP_PROF
+    unsigned long long sp_t0 = wall_clock64();
+#endif
+
+    int slot = 0;
+    for (; slot < p.count; ++slot) {
+        const int32_t cid = p.cid0 + slot;
+        if (slot >= s_stop)
+            break;
+        // ---- classification (kmedoids.py:644-658) of this slot's frames ------------------
+        const unsigned int nb = s_bcnt[slot];
+        const uint2 f_first = f_pre;
+        // (what the search may need of the tables, see below: asked for now, there
+        // when the classification is through)
+        // (loads come back in the order they were asked for: the state of this
+        // thread's first frame goes before the tables and the next slot's frames)
+        float d_first = 0.f;
+        int32_t a_first = 0;
+        if ((unsigned int)t < nb) {
+            d_first = p.dist[f_first.x];
+            a_first = p.assign[f_first.x];
+        }
+        if (t < slot && s_acc[t])
+            s_T[t] = p.T[(size_t)t * K + cid];
+        float Dtab[SP_KU];
+        {
+            const float *O = p.O + (size_t)slot * K;
+#pragma unroll
+            for (int u = 0; u < SP_KU; ++u) {
+                const int c = t + u * SP_NT;
+                Dtab[u] = (c < K) ? O[c] : 0.f;
+            }
+        }
+        if ((unsigned int)t < s_bcnt[slot + 1])
+            f_pre = p.bucket[(size_t)(slot + 1) * p.bcap + t];
+        SP_T(8);
+        for (unsigned int e = t; e < nb; e += SP_NT) {
+            const uint2 fe = (e < SP_NT) ? f_first : p.bucket[(size_t)slot * p.bcap + e];
+            const uint32_t f = fe.x;
+            const float nd = __uint_as_float(fe.y);
+            const float d = (e < SP_NT) ? d_first : p.dist[f];
+            const int32_t a = (e < SP_NT) ? a_first : p.assign[f];
+            if (d > nd) {
+                const unsigned int q = atomicAdd(&s_n_chg, 1u);
+                if (q < SP_CAP_CHG) {
+                    chg_f[q] = f;
+                    chg_od[q] = d;
+                    chg_oa[q] = a;
+                    chg_nd[q] = nd;
+                    chg_na[q] = cid;
+                }
+            } else if (a == cid) {
+                const unsigned int q = atomicAdd(&s_n_amb, 1u);
+                if (q < SP_CAP_AMB) {
+                    amb_f[q] = f;
+                    amb_d[q] = d;
+                    amb_key[q] = ek_sp_key(nd, cid);
+                }
+                // how far a medoid may be from the old one and still matter to
+                // this frame; non-negative floats order like their bits
+                atomicMax(&s_reach, __float_as_uint(d + nd));
+            }
+        }
+        SP_T(9);
+        ek_lds_barrier();
+        SP_T(0);
+        const unsigned int n_amb = s_n_amb;
+        const bool too_many = (int64_t)n_amb > p.max_amb[slot];
+        bool bail = n_amb > SP_CAP_AMB;
+        if (n_amb > 0 && !too_many && !bail) {
+            // ---- the medoids within reach of those members (ek_pam_prune_kernel's
+            // test, from the window's tables) -------------------------------------------
+            const float lim = __uint_as_float(s_reach) * 1.001f + 1e-3f;
+            const float *O = p.O + (size_t)slot * K;
+            for (int c0 = t; c0 < K; c0 += SP_KU * SP_NT) {
+                float D[SP_KU];                 // the table reads in flight
+#pragma unroll
+                for (int u = 0; u < SP_KU; ++u) {
+                    const int c = c0 + u * SP_NT;
+                    D[u] = (c0 == t) ? Dtab[u] : ((c < K) ? O[c] : 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < SP_KU; ++u) {
+                    const int c = c0 + u * SP_NT;
+                    if (c >= K)
+                        continue;
+                    const int i = c - p.cid0;
+                    if (i >= 0 && i < slot && s_acc[i])
+                        D[u] = s_T[i];  // its proposal sits there now: T[i][cid]
+                    if (c != cid && !(D[u] > lim)) {
+                        const unsigned int q = atomicAdd(&s_n_col, 1u);
+                        if (q < SP_CAP_COLS)
+                            cols[q] = c;
+                    }
+                }
+            }
+            ek_lds_barrier();
+            const unsigned int n_col = s_n_col;
+            bail = n_col > SP_CAP_COLS || (uint64_t)n_amb * n_col > (uint64_t)p.max_pairs;
+            // ---- kmedoids.py:666 over them: rows = members, columns = medoids ------------
+            for (unsigned int r0 = 0; !bail && n_col > 0 && r0 < n_amb; r0 += EK_WAVE) {
+                if (t < EK_WAVE) {
+                    const bool ok = r0 + t < n_amb;
+                    s_rowf[t] = ok ? amb_f[r0 + t] : 0u;
+                    s_best[t] = ok ? amb_key[r0 + t] : ~0ull;
+                }
+                __syncthreads();
+                const bool rok = r0 + lane < n_amb;
+                constexpr int TPR = SP_NT / EK_WAVE;            // threads per row
+                constexpr int NLD = 3 * SP_CH / TPR;
+                const int lm = t / TPR, le = t % TPR;
+                const bool lok = r0 + lm < n_amb;
+                const float *lrow = p.frames_aos + (size_t)s_rowf[lm] * 3 * A;
+                for (unsigned int k0 = 0; k0 < n_col; k0 += SP_WAVES) {
+                    const bool live = k0 + wv < n_col;
+                    const int32_t col = live ? cols[k0 + wv] : 0;
+                    // (a medoid accepted in this window: its row of the table is
+                    // written when the window is over)
+                    const int ci = col - p.cid0;
+                    const bool moved_in = live && ci >= 0 && ci < slot && s_acc[ci];
+                    const float *y = moved_in
+                                         ? p.frames_aos + (size_t)p.frames[ci] * 3 * A
+                                         : p.med_aos + (size_t)col * 3 * A;
+                    float S[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    for (int a0 = 0; a0 < A; a0 += SP_CH) {
+                        const int ch = (A - a0 < SP_CH) ? A - a0 : SP_CH;
+                        float v[NLD], vy[3];
+#pragma unroll
+                        for (int k = 0; k < NLD; ++k) {
+                            const int e = le + TPR * k;
+                            v[k] = (3 * a0 + e < 3 * A && lok) ? lrow[3 * a0 + e] : 0.f;
+                        }
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            const int e = lane + EK_WAVE * k;
+                            vy[k] = (live && 3 * a0 + e < 3 * A) ? y[3 * a0 + e] : 0.f;
+                        }
+                        __syncthreads();                // the slice before is done with
+#pragma unroll
+                        for (int k = 0; k < NLD; ++k)
+                            tile[(le + TPR * k) * SP_LD + lm] = v[k];
+#pragma unroll
+                        for (int k = 0; k < 3; ++k)
+                            ytile[wv * 3 * SP_CH + lane + EK_WAVE * k] = vy[k];
+                        __syncthreads();
+                        if (live) {
+                            const float *yt = ytile + wv * 3 * SP_CH;
+#pragma unroll 8
+                            for (int a = 0; a < ch; ++a) {
+                                const float x0 = tile[(3 * a + 0) * SP_LD + lane],
+                                            x1 = tile[(3 * a + 1) * SP_LD + lane],
+                                            x2 = tile[(3 * a + 2) * SP_LD + lane];
+                                const float y0 = yt[3 * a], y1 = yt[3 * a + 1],
+                                            y2 = yt[3 * a + 2];
+                                S[0] = fmaf(x0, y0, S[0]); S[1] = fmaf(x0, y1, S[1]);
+                                S[2] = fmaf(x0, y2, S[2]); S[3] = fmaf(x1, y0, S[3]);
+                                S[4] = fmaf(x1, y1, S[4]); S[5] = fmaf(x1, y2, S[5]);
+                                S[6] = fmaf(x2, y0, S[6]); S[7] = fmaf(x2, y1, S[7]);
+                                S[8] = fmaf(x2, y2, S[8]);
+                            }
+                        }
+                    }
+                    if (live && rok) {
+                        const double Gy = moved_in ? p.G[p.frames[ci]] : p.med_G[col];
+                        const float D = ek_rmsd_from_S(S, p.G[s_rowf[lane]], Gy, A);
+                        // equal distances: the lowest medoid index, util.py:199-203's
+                        // strict-< scan in ascending order
+                        atomicMin(&s_best[lane], ek_sp_key(D, col));
+                    }
+                }
+                __syncthreads();
+                if (t < EK_WAVE && r0 + t < n_amb)
+                    amb_key[r0 + t] = s_best[t];
+                __syncthreads();
+            }
+            // the members' new labels and distances
+            for (unsigned int r = t; !bail && r < n_amb; r += SP_NT) {
+                const unsigned long long key = amb_key[r];
+                const float d = amb_d[r];
+                const float ndv = __uint_as_float((unsigned int)(key >> 32));
+                const int32_t na = (int32_t)(key & 0xffffffffu);
+                if (na != cid || __float_as_uint(ndv) != __float_as_uint(d)) {
+                    const unsigned int q = atomicAdd(&s_n_chg, 1u);
+                    if (q < SP_CAP_CHG) {
+                        chg_f[q] = amb_f[r];
+                        chg_od[q] = d;
+                        chg_oa[q] = cid;
+                        chg_nd[q] = ndv;
+                        chg_na[q] = na;
+                    }
+                }
+            }
+        }
+        ek_lds_barrier();
+        const unsigned int n_chg = s_n_chg;
+        if (bail || too_many || n_chg > SP_CAP_CHG) {
+            // more than one workgroup should take on (or more members than
+            // declared): the window ends before this slot, nothing of it is kept
+            if (t == 0) {
+                if (too_many)
+                    s_win.err = 1 + slot;
+                else
+                    s_win.pad = 1 + slot;
+                s_win.stop = slot;
+            }
+            break;
+        }
+        SP_T(1);
+        // ---- the trial state, written into the state; old values kept -------------------
+        unsigned int m = 0;
+        for (unsigned int q = t; q < n_chg; q += SP_NT) {
+            const uint32_t f = chg_f[q];
+            const int32_t oa = chg_oa[q], na = chg_na[q];
+            p.dist[f] = chg_nd[q];
+            p.assign[f] = na;
+            if (oa != na) {
+                const int32_t ia = oa - p.cid0, ib = na - p.cid0;
+                if (ia >= 0 && ia < p.win_count)
+                    m |= 1u << ia;
+                if (ib >= 0 && ib < p.win_count)
+                    m |= 1u << ib;
+            }
+            const int g = ek_sp_leaf_of(f, p);
+            const uint32_t bit = 1u << (g & 31);
+            if (!(atomicOr(&s_lbits[g >> 5], bit) & bit))
+                tleaf[atomicAdd(&s_n_leaf, 1u)] = g;
+        }
+        if (m)
+            atomicOr(&s_mask, m);
+        __syncthreads();
+        SP_T(2);
+        // ---- the leaves and chunks that changed, re-added ---------------------------------
+        const unsigned int n_leaf = s_n_leaf;
+        const int full_leaves = p.n_full * EK_PW_FULL_LEAVES;
+        for (unsigned int q0 = 0; q0 < n_leaf; q0 += SP_LB * (SP_NT / 8)) {
+            int g[SP_LB];
+            double old[SP_LB];
+            float v[SP_LB][16];
+#pragma unroll
+            for (int b = 0; b < SP_LB; ++b) {
+                const unsigned int q = q0 + b * (SP_NT / 8) + t / 8;
+                g[b] = (q < n_leaf) ? tleaf[q] : -1;    // (uniform over a group of 8 lanes)
+            }
+#pragma unroll
+            for (int b = 0; b < SP_LB; ++b) {
+                old[b] = (g[b] >= 0) ? p.leaf[2 * (size_t)g[b]] : 0.0;
+                if (g[b] >= 0 && g[b] < full_leaves) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        v[b][i] = p.dist[(int64_t)g[b] * 128 + 8 * i + (t & 7)];
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < SP_LB; ++b) {
+                if (g[b] < 0)
+                    continue;
+                double r;
+                int chunk;
+                if (g[b] < full_leaves) {
+                    r = 0.0;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const double x = v[b][i];
+                        r = (i == 0) ? x * x : r + x * x;
+                    }
+                    r = ek_tree_sum8(r);
+                    chunk = g[b] / EK_PW_FULL_LEAVES;
+                } else {
+                    const EkPwShape *sh = &p.shapes[1];
+                    const int l = g[b] - full_leaves;
+                    r = ek_sp_leaf(p.dist, (int64_t)p.n_full * EK_PW_CHUNK + sh->leaf_off[l],
+                                   sh->leaf_len[l], t & 7);
+                    chunk = p.n_full;
+                }
+                if ((t & 7) == 0) {
+                    p.leaf[2 * (size_t)g[b] + 1] = old[b];
+                    p.leaf[2 * (size_t)g[b]] = r;
+                    atomicOr(&s_cbits[chunk >> 5], 1u << (chunk & 31));
+                }
+            }
+        }
+        __syncthreads();
+        SP_T(3);
+        // a full chunk: 64 leaves, a perfect in-order tree (checked by
+        // ek_pam_alloc).  Half a wave per chunk: a lane adds leaves 2l and 2l + 1
+        // itself, ek_tree_sum32 does the five levels above.
+        for (int c0 = 0; c0 < p.n_full; c0 += 2 * SP_CB * SP_WAVES) {
+            double r[SP_CB];
+            bool on[SP_CB];
+            const int half = lane >> 5, l32 = lane & 31;
+#pragma unroll
+            for (int k = 0; k < SP_CB; ++k) {
+                const int c = c0 + 2 * (k * SP_WAVES + wv) + half;
+                on[k] = c < p.n_full && ((s_cbits[c >> 5] >> (c & 31)) & 1u);
+                const size_t g = (size_t)c * EK_PW_FULL_LEAVES + 2 * l32;
+                const double a0 = on[k] ? p.leaf[2 * g] : 0.0;
+                const double a1 = on[k] ? p.leaf[2 * g + 2] : 0.0;
+                r[k] = a0 + a1;
+            }
+#pragma unroll
+            for (int k = 0; k < SP_CB; ++k)
+                r[k] = ek_tree_sum32(r[k]);
+#pragma unroll
+            for (int k = 0; k < SP_CB; ++k) {
+                const int c = c0 + 2 * (k * SP_WAVES + wv) + half;
+                if (on[k] && l32 == 0) {
+                    s_chunk_old[c] = s_chunk[c];
+                    s_chunk[c] = r[k];
+                }
+            }
+        }
+        const bool ragged = p.n_chunks > p.n_full &&
+                            ((s_cbits[p.n_full >> 5] >> (p.n_full & 31)) & 1u);
+        if (ragged) {
+            if (t == 0)
+                s_chunk_old[p.n_full] = s_chunk[p.n_full];
+            ek_sp_ragged(p, la, &s_chunk[p.n_full]);
+        }
+        ek_lds_barrier();
+        SP_T(4);
+        const double total_new = ek_sp_total(s_chunk, p.n_chunks);
+        SP_T(5);
+        // ---- verdict (ek_pw_window_kernel's), taken by every thread alike ------------------
+        const bool accept = total_new / p.n_total < total / p.n_total;
+        if (t == 0) {
+            EkPamOut o;
+            o.sum_old = total;
+            o.sum_new = total_new;
+            o.n_frames = p.n;
+            o.n_amb = n_amb;
+            o.moved = s_mask;
+            s_win.out[slot] = o;
+            s_acc[slot] = accept ? 1 : 0;
+            s_win.accept[slot] = accept ? 1 : 0;
+            if (accept) {
+                const uint32_t stale = s_stale | o.moved;
+                s_stale = stale;
+                s_win.stale = stale;
+                const uint32_t later = (slot >= 31) ? 0u : (stale >> (slot + 1));
+                if (later) {
+                    const int first = slot + 1 + (__ffs((int)later) - 1);
+                    if (first < s_stop) {
+                        s_stop = first;
+                        s_win.stop = first;
+                    }
+                }
+            }
+        }
+        SP_T(6);
+        if (accept) {
+            total = total_new;
+        } else {
+            for (unsigned int q = t; q < n_chg; q += SP_NT) {
+                const uint32_t f = chg_f[q];
+                p.dist[f] = chg_od[q];
+                p.assign[f] = chg_oa[q];
+            }
+            for (unsigned int q = t; q < n_leaf; q += SP_NT) {
+                const int g = tleaf[q];
+                p.leaf[2 * (size_t)g] = p.leaf[2 * (size_t)g + 1];
+            }
+            for (int c = t; c < p.n_chunks; c += SP_NT)
+                if ((s_cbits[c >> 5] >> (c & 31)) & 1u)
+                    s_chunk[c] = s_chunk_old[c];
+        }
+        for (unsigned int q = t; q < n_leaf; q += SP_NT)
+            s_lbits[tleaf[q] >> 5] = 0;
+        if (accept)
+            ek_lds_barrier();
+        else
+            __syncthreads();    // the state was put back: the stores have to be through
+        if (t < EK_SP_MAX_CHUNKS / 32)
+            s_cbits[t] = 0;
+        if (t == 0) {
+            s_n_chg = 0;
+            s_n_amb = 0;
+            s_reach = 0;
+            s_n_col = 0;
+            s_mask = 0;
+            s_n_leaf = 0;
+        }
+        ek_lds_barrier();
+        SP_T(7);
+    }
+    // ---- the accepted proposals are their clusters' medoids (kmedoids.py:684-690) ---------
+    __syncthreads();
+    for (int i = 0; i < p.count; ++i) {
+        if (!s_acc[i])
+            continue;
+        const int32_t cid = p.cid0 + i;
+        const float *src = p.frames_aos + (size_t)p.frames[i] * 3 * A;
+        for (int r = t; r < 3 * A; r += SP_NT)
+            p.med_aos[(size_t)cid * 3 * A + r] = src[r];
+        if (t == 0) {
+            p.med_G[cid] = p.G[p.frames[i]];
+            if (p.med_idx)
+                p.med_idx[cid] = p.frames[i];
+        }
+    }
+    for (int i = t; i < (int)(sizeof(EkPamWin) / 4); i += SP_NT)
+        ((uint32_t *)p.win)[i] = ((const uint32_t *)&s_win)[i];
+}
+
+size_t ek_sp_lds_bytes()
+{
+    return EkSpLds::end;
+}
+
+void ek_launch_sp_window(const EkSpArgs &p, hipStream_t s)
+{
+    const size_t lds = ek_sp_lds_bytes();
+    (void)hipFuncSetAttribute((const void *)ek_sp_window_kernel,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(ek_sp_window_kernel, dim3(1), dim3(SP_NT), lds, s, p);
+}

@@ -226,6 +226,12 @@ class FrameStore:
                                                    C.byref(b)))
         return a.value, b.value
 
+    def pam_sparse_stats(self):
+        """-> (windows worked through in one workgroup, of them ended early)"""
+        a, b = C.c_int64(), C.c_int64()
+        _lib.check(self.lib.ek_pam_sparse_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def pam_propose_ex(self, cid, frame_index, n_members, win_lo=0,
                        win_count=0):
         """-> (old cost, new cost, number of ambiguous frames, moved mask)"""

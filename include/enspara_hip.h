@@ -351,6 +351,10 @@ int ek_pam_prefetch_stats(ek_ctx *ctx, int64_t *hits, int64_t *misses);
  * handles cluster cid0 + *n_done one proposal at a time and opens a new window
  * after it.  accept[i] (i < *n_done): 1 if proposal i was accepted; the costs
  * and ambiguous-member counts are returned for logging. */
+/* windows ek_pam_window_run worked through in one workgroup (ek_set_option key
+ * 12), and how many of them ended early because a proposal's ambiguous members
+ * had more medoids within reach than one workgroup should search */
+int ek_pam_sparse_stats(ek_ctx *ctx, int64_t *windows, int64_t *ended_early);
 /* the most proposals a window / a local-frame prefetch may hold */
 int32_t ek_pam_window_max(void);
 int ek_pam_window_run(ek_ctx *ctx, int32_t cid0, int32_t count,
@@ -525,7 +529,15 @@ int ek_set_frames_per_lane(ek_ctx *ctx, int fpl);
  * steps ride at the end of the launch that produces their input): 1 (default)
  * / 0 (one launch per step); identical results
  * key 9: retired (round 1's pass kernel with the candidates staged in LDS);
- * only the value 1 is accepted */
+ * only the value 1 is accepted
+ * key 12: ek_pam_window_run works through a window whose prefetch was
+ * restricted to a list of frames in ONE workgroup, no launch between two
+ * proposals (1, default) or with three launches per proposal (0); identical
+ * results
+ * key 13: the (ambiguous member, medoid within reach) pairs such a workgroup
+ * searches itself (default 16384); a proposal with more ends the window and goes
+ * through the launches.  0 makes every proposal whose members have another
+ * medoid within reach do so (tests) */
 int ek_set_option(ek_ctx *ctx, int32_t key, int32_t value);
 /* time of the last ek_kcenters_run loop measured with HIP events on the
  * context's stream, milliseconds, and the number of distance-kernel launches

@@ -11,7 +11,7 @@ from enspara_amd.device import FrameStore
 from oracle import cluster as oc
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 base = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-bad = 0; t0 = time.time(); tot_r = tot_f = 0
+bad = 0; t0 = time.time(); tot_r = tot_f = tot_sw = tot_se = 0
 for case in range(cases):
     if case and case % 5 == 0:
         print("... %d cases, %d mismatches, %.0f s" % (case, bad, time.time() - t0), flush=True)
@@ -20,6 +20,8 @@ for case in range(cases):
     nt = int(rng.choice([2, 10, 100, 400])); K = int(rng.choice([150, 300, 600, 900]))
     sweeps = int(rng.choice([1, 2]))
     x = synth.synth(n, A, nt, seed=int(rng.randint(1 << 30)))
+    if rng.rand() < 0.25:       # a time-ordered walk: neighbouring medoids within reach
+        x = synth.walk(n, A, seed=int(rng.randint(1 << 30)))
     if rng.rand() < 0.2:
         x = np.concatenate([x[: n // 2], x[: n - n // 2]])
     inds, a, d = oc.kcenters(x, n_clusters=K)
@@ -44,6 +46,7 @@ for case in range(cases):
         except ValueError as e:
             gerr = e
         rr, ff = st.pam_prefetch_passes(); tot_r += rr; tot_f += ff
+        sw, se = st.pam_sparse_stats(); tot_sw += sw; tot_se += se
     if err is None and gerr is None:
         ok = (list(r.center_indices) == [int(i) for i in wi] and np.array_equal(r.assignments, wa)
               and np.array_equal(r.distances, wd))
@@ -52,4 +55,6 @@ for case in range(cases):
     if not ok:
         bad += 1
         print("MISMATCH: case %d n=%d A=%d nt=%d K=%d sweeps=%d props=%s" % (case, n, A, nt, K, sweeps, props is not None), flush=True)
-print("fuzz3: %d cases, %d mismatches, %.0f s; prefetch passes restricted %d full %d" % (cases, bad, time.time() - t0, tot_r, tot_f))
+print("fuzz3: %d cases, %d mismatches, %.0f s; prefetch passes restricted %d full %d; "
+      "windows in one workgroup %d, of them ended early %d"
+      % (cases, bad, time.time() - t0, tot_r, tot_f, tot_sw, tot_se))
