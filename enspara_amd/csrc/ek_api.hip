@@ -2348,6 +2348,7 @@ extern "C" int ek_pam_window_run(ek_ctx *c, int32_t cid0, int32_t count,
     bool sparse = c->pam_sparse && c->sp_ready && c->tab_lo == cid0 &&
                   count <= c->tab_n && c->prune && c->state_exact && c->A >= 3 &&
                   c->aos != nullptr && c->pw_chunks <= EK_SP_MAX_CHUNKS &&
+                  c->pw_leaves <= EK_SP_MAX_CHUNKS * EK_PW_FULL_LEAVES &&
                   (c->sp_backoff == 0 || c->sp_max_pairs == 0);
     for (int32_t i = 0; sparse && i < count; ++i)
         sparse = newd[i] == c->pam_vecs + (size_t)i * c->n_pad;
