@@ -1600,7 +1600,7 @@ void ek_pw_build_shape(int len, EkPwShape *sh)
 // MODE 1, a window's proposals against the frames they can touch (rows: the
 //   listed frames of the frame-major copy):
 //   vecs[j * n_pad + list[i]] = rmsd(frame list[i], proposal j)
-#define EK_PAIR_CH 64
+#define EK_PAIR_CH 48
 struct EkPairArgs {
     const float *aos;           // rows: [.][3A]
     const double *G;            // their traces

@@ -55,7 +55,12 @@
 // kmedoids.py:644) -- on the state the window opens with, which is enough: until
 // slot j's turn a frame's distance only shrinks, except for the members an
 // accepted proposal i < j is farther from (see `grown` below)
-__global__ void __launch_bounds__(EK_BLOCK)
+// One wave per 64 listed frames and group of SP_BK_G slots: the gathers out of the
+// distance vectors (a hundred-odd megabytes apart) are what this kernel waits for,
+// and the more waves on the more compute units share them the better (1024-thread
+// workgroups: 72 us; 256: 25 us; this: 8 us per window at 10^6 frames).
+#define SP_BK_G 8
+__global__ void __launch_bounds__(EK_WAVE)
 ek_sp_bucket_kernel(const uint32_t *__restrict__ list, int64_t n_act,
                     const float *__restrict__ dist,
                     const int32_t *__restrict__ assign,
@@ -63,52 +68,53 @@ ek_sp_bucket_kernel(const uint32_t *__restrict__ list, int64_t n_act,
                     int count, uint2 *__restrict__ bucket,
                     unsigned int *__restrict__ bcnt, int64_t bcap)
 {
-    static_assert(EK_PAM_WIN <= 32, "one lane per slot adds up a wave's entries");
-    const int lane = threadIdx.x & (EK_WAVE - 1);
-    const int64_t p = (int64_t)blockIdx.x * EK_BLOCK + threadIdx.x;
+    const int lane = threadIdx.x;
+    const int j0 = blockIdx.y * SP_BK_G;
+    const int64_t p = (int64_t)blockIdx.x * EK_WAVE + lane;
     const bool ok = p < n_act;
     const uint32_t f = ok ? list[p] : 0u;
     const float d = ok ? dist[f] : 0.f;
     const int32_t a = ok ? assign[f] : -1;
-    float nd[EK_PAM_WIN];                       // all gathers in flight at once
+    float nd[SP_BK_G];                          // all gathers in flight at once
 #pragma unroll
-    for (int j = 0; j < EK_PAM_WIN; ++j)
-        nd[j] = (ok && j < count) ? vecs[(size_t)j * n_pad + f] : __builtin_inff();
+    for (int u = 0; u < SP_BK_G; ++u)
+        nd[u] = (ok && j0 + u < count) ? vecs[(size_t)(j0 + u) * n_pad + f]
+                                       : __builtin_inff();
     // A member of the window's cluster i may be left farther from its medoid than
     // it is now when proposal i is accepted -- but not farther than from proposal
     // i itself, which is a medoid then: for the slots after i that distance is
     // the bound the test is made with.
     const int i = a - cid0;
     float grown = d;
-#pragma unroll
-    for (int j = 0; j < EK_PAM_WIN; ++j)
-        if (j == i)
-            grown = fmaxf(d, nd[j]);
+    if (ok && i >= 0 && i < count && i < j0 + SP_BK_G - 1)
+        grown = fmaxf(d, vecs[(size_t)i * n_pad + f]);
     uint32_t hit = 0;
 #pragma unroll
-    for (int j = 0; j < EK_PAM_WIN; ++j)
-        if (ok && j < count && (a == cid0 + j || (j > i ? grown : d) > nd[j]))
-            hit |= 1u << j;
-    // lane j asks for the room of the wave's entries in bucket j
+    for (int u = 0; u < SP_BK_G; ++u) {
+        const int j = j0 + u;
+        if (ok && j < count && (a == cid0 + j || (j > i ? grown : d) > nd[u]))
+            hit |= 1u << u;
+    }
+    // lane u asks for the room of the wave's entries in bucket j0 + u
     unsigned int mine = 0;
 #pragma unroll
-    for (int j = 0; j < EK_PAM_WIN; ++j) {
-        const unsigned long long m = __ballot((hit >> j) & 1u);
-        if (lane == j)
+    for (int u = 0; u < SP_BK_G; ++u) {
+        const unsigned long long m = __ballot((hit >> u) & 1u);
+        if (lane == u)
             mine = (unsigned int)__popcll(m);
     }
-    const unsigned int base = mine ? atomicAdd(&bcnt[lane], mine) : 0u;
+    const unsigned int base = mine ? atomicAdd(&bcnt[j0 + lane], mine) : 0u;
 #pragma unroll
-    for (int j = 0; j < EK_PAM_WIN; ++j) {
-        const bool h = (hit >> j) & 1u;
+    for (int u = 0; u < SP_BK_G; ++u) {
+        const bool h = (hit >> u) & 1u;
         const unsigned long long m = __ballot(h);
-        const unsigned int b = __shfl(base, j, EK_WAVE);
+        const unsigned int b = __shfl(base, u, EK_WAVE);
         if (h) {
             const unsigned int pos = b + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
             // with its distance to the proposal: the window's workgroup would
             // wait a cold gather for it
             if ((int64_t)pos < bcap)
-                bucket[(size_t)j * bcap + pos] = make_uint2(f, __float_as_uint(nd[j]));
+                bucket[(size_t)(j0 + u) * bcap + pos] = make_uint2(f, __float_as_uint(nd[u]));
         }
     }
 }
@@ -122,8 +128,9 @@ void ek_launch_sp_bucket(const uint32_t *list, int64_t n_act, const float *dist,
     if (n_act <= 0)
         return;
     hipLaunchKernelGGL(ek_sp_bucket_kernel,
-                       dim3((unsigned)((n_act + EK_BLOCK - 1) / EK_BLOCK)),
-                       dim3(EK_BLOCK), 0, s, list, n_act, dist, assign, vecs, n_pad,
+                       dim3((unsigned)((n_act + EK_WAVE - 1) / EK_WAVE),
+                            (count + SP_BK_G - 1) / SP_BK_G),
+                       dim3(EK_WAVE), 0, s, list, n_act, dist, assign, vecs, n_pad,
                        cid0, count, bucket, bcnt, bcap);
 }
 
