@@ -260,6 +260,12 @@ def _open_window(store, lo, hi, proposals, random_state):
 # proposal.  Same results.
 PAM_DEVICE_DECISIONS = 1
 
+# 1: with PAM_DEVICE_DECISIONS, the loop over the windows of a sweep runs inside
+# the library too (ek_pam_sweep: the same calls in the same order, without the
+# interpreter between them -- four read-backs per window, and the host came back
+# from each 25-60 us later than it had to); 0: the loop below.  Same results.
+PAM_NATIVE_SWEEP = 1
+
 
 def _one_proposal(store, cid, proposals, random_state):
     """kmedoids.py:597-699 for one cluster, counted and drawn right now.
@@ -302,6 +308,8 @@ def _pam_sweep_device_on(store, medoid_inds, proposals, random_state):
                      "(%d ambiguous).", "Accepted" if accept else "Rejected",
                      cid, oc, nc, n_amb)
 
+    if width > 1 and PAM_DEVICE_DECISIONS and PAM_NATIVE_SWEEP:
+        return _pam_sweep_native(store, medoid_inds, proposals, random_state, width)
     cid = 0
     win = None
     while cid < K:
@@ -386,6 +394,42 @@ def _pam_sweep_device_on(store, medoid_inds, proposals, random_state):
     logger.info("Kmedoid sweep reduced cost to %.7f (%.2f%% acceptance)",
                 min(old_cost, new_cost),
                 acceptances / len(medoid_inds) * 100)
+    return medoid_inds
+
+
+def _pam_sweep_native(store, medoid_inds, proposals, random_state, width):
+    """_pam_sweep_device_on's loop over windows, inside the library
+    (FrameStore.pam_sweep_run); random_state: the sweep's _DrawStream."""
+    K = len(medoid_inds)
+    med = np.ascontiguousarray(medoid_inds, dtype=np.int64)
+    accept = np.zeros(K, dtype=np.int32)
+    oc = np.zeros(K, dtype=np.float64)
+    nc = np.zeros(K, dtype=np.float64)
+    na = np.zeros(K, dtype=np.int64)
+    cid = 0
+    while True:
+        if proposals is None:
+            # a draw takes two raw outputs on average at worst (rejection above
+            # the mask): enough for the rest of the sweep in all likelihood
+            random_state._need(random_state.pos + 4 * (K - cid) + 64)
+        status, cid, random_state.pos = store.pam_sweep_run(
+            width, random_state.raw, random_state.pos, proposals, cid, med, accept,
+            oc, nc, na)
+        if status == 0:
+            break
+        if status == 2:
+            random_state.draw(0)        # raises what RandomState.choice(0) raises
+        random_state._need(len(random_state.raw) + random_state.BLOCK)
+    for c in range(K):
+        if accept[c]:
+            medoid_inds[c] = int(med[c])
+    if logger.isEnabledFor(logging.DEBUG):
+        for c in range(K):
+            logger.debug("%s proposed center for k=%s: cost %.5f -> %.5f "
+                         "(%d ambiguous).", "Accepted" if accept[c] else "Rejected",
+                         c, oc[c], nc[c], na[c])
+    logger.info("Kmedoid sweep reduced cost to %.7f (%.2f%% acceptance)",
+                min(oc[K - 1], nc[K - 1]), int(accept.sum()) / K * 100)
     return medoid_inds
 
 

@@ -2439,6 +2439,173 @@ extern "C" int ek_pam_window_run(ek_ctx *c, int32_t cid0, int32_t count,
     return EK_OK;
 }
 
+// ---- a whole sweep's window loop on the host side of the library ------------------------
+// numpy's legacy RandomState.choice(m) / randint(0, m): 32-bit outputs of the
+// Mersenne Twister masked to the bits of m - 1, values above it rejected; m == 1
+// consumes nothing.  `raw` are such outputs, *pos the next unused one.
+// -> 0: drawn, 1: the outputs ran out (nothing consumed)
+static int ek_draw_at(const uint32_t *raw, int64_t n_raw, int64_t *pos, int64_t m,
+                      int64_t *out)
+{
+    const uint64_t rng = (uint64_t)(m - 1);
+    if (rng == 0) {
+        *out = 0;
+        return 0;
+    }
+    uint64_t mask = rng;
+    mask |= mask >> 1;
+    mask |= mask >> 2;
+    mask |= mask >> 4;
+    mask |= mask >> 8;
+    mask |= mask >> 16;
+    int64_t p = *pos;
+    for (;;) {
+        if (p >= n_raw)
+            return 1;
+        const uint64_t v = raw[p++] & mask;
+        if (v <= rng) {
+            *out = (int64_t)v;
+            *pos = p;
+            return 0;
+        }
+    }
+}
+
+// The loop of kmedoids.py:575-699 over clusters *cid .. K - 1 in windows of up to
+// `width` proposals decided on the device (ek_pam_window_run), the cluster a
+// window stops at one proposal at a time -- what enspara_amd/cluster/kmedoids.py's
+// _pam_sweep_device_on does call by call, without the interpreter between the
+// calls (four read-backs per window, and as many waits for the host to come
+// back).  The draws are numpy's: `raw` holds the next outputs of the caller's
+// RandomState (RandomState.randint(0, 2**32, dtype=uint32)), *pos how many of
+// them the draws made so far have consumed.
+// *status: 0 the sweep is through (*cid == K); 1 more random outputs are needed
+// (call again with a longer `raw`: *cid, *pos and the outputs so far stand);
+// 2 cluster *cid has no member to draw (RandomState.choice raises there).
+extern "C" int ek_pam_sweep(ek_ctx *c, int32_t K, int32_t width, const uint32_t *raw,
+                            int64_t n_raw, int64_t *pos, const int64_t *proposals,
+                            int32_t *cid_io, int64_t *medoids, int32_t *accept,
+                            double *old_cost, double *new_cost, int64_t *n_amb,
+                            int32_t *status)
+{
+    if (!c || !pos || !cid_io || !medoids || !accept || !old_cost || !new_cost ||
+        !n_amb || !status || (!raw && n_raw > 0))
+        return ek_fail(EK_EARG, "ek_pam_sweep: NULL argument");
+    if (!c->ndist || c->med_K != K)
+        return ek_fail(EK_ESTATE, "ek_pam_sweep: call ek_pam_begin with these %d "
+                                  "medoids first", K);
+    if (width < 2 || width > EK_PAM_WIN)
+        return ek_fail(EK_EARG, "ek_pam_sweep: windows of 2..%d proposals", EK_PAM_WIN);
+    if (*cid_io < 0 || *cid_io > K || *pos < 0)
+        return ek_fail(EK_EARG, "ek_pam_sweep: cluster %d, position %lld", *cid_io,
+                       (long long)*pos);
+    if (n_raw > 0 && (uint64_t)c->n > 0xffffffffull)
+        return ek_fail(EK_EARG, "ek_pam_sweep: member lists of 2**32 frames and more");
+    int32_t cid = *cid_io;
+    *status = 0;
+    int64_t counts[EK_PAM_WIN], js[EK_PAM_WIN], frames[EK_PAM_WIN], na[EK_PAM_WIN];
+    int32_t acc[EK_PAM_WIN];
+    double oc[EK_PAM_WIN], nc[EK_PAM_WIN];
+    while (cid < K) {
+        const int32_t hi = std::min(K, cid + width), cnt = hi - cid;
+        int rc = ek_pam_count_members_batch(c, cid, cnt, counts);
+        if (rc)
+            return rc;
+        int32_t n_slots = 0;
+        if (!proposals) {
+            // the draws the real stream will produce if these counts still hold
+            // when each cluster's turn comes
+            int64_t p = *pos;
+            for (; n_slots < cnt && counts[n_slots] > 0; ++n_slots)
+                if (ek_draw_at(raw, n_raw, &p, counts[n_slots], &js[n_slots])) {
+                    *cid_io = cid;
+                    *status = 1;
+                    return EK_OK;
+                }
+            if (n_slots > 0) {
+                rc = ek_pam_select_members_batch(c, cid, n_slots, js, frames);
+                if (rc)
+                    return rc;
+            }
+        } else {
+            n_slots = cnt;
+            for (int32_t s = 0; s < cnt; ++s)
+                frames[s] = proposals[cid + s];
+        }
+        rc = ek_pam_prefetch_window(c, frames, n_slots, cid, cnt);
+        if (rc)
+            return rc;
+        int32_t n_done = 0;
+        if (n_slots > 0) {
+            rc = ek_pam_window_run(c, cid, n_slots, frames, counts, cid, cnt, &n_done,
+                                   acc, oc, nc, na);
+            if (rc)
+                return rc;
+        }
+        for (int32_t s = 0; s < n_done; ++s) {
+            if (!proposals) {
+                // the real draws, in order: the member lists are the ones the
+                // guesses were drawn from, so they are the same draws
+                int64_t j = -1;
+                if (ek_draw_at(raw, n_raw, pos, counts[s], &j) || j != js[s])
+                    return ek_fail(EK_ESTATE, "ek_pam_sweep: draw %lld for cluster %d, "
+                                              "guessed %lld", (long long)j, cid + s,
+                                   (long long)js[s]);
+            }
+            accept[cid + s] = acc[s];
+            old_cost[cid + s] = oc[s];
+            new_cost[cid + s] = nc[s];
+            n_amb[cid + s] = na[s];
+            if (acc[s])
+                medoids[cid + s] = frames[s];
+        }
+        cid += n_done;
+        if (cid < hi) {
+            // the window stopped here: this cluster's members changed under an
+            // accepted proposal (or it is empty) -- counted and drawn now
+            int64_t prop = -1;
+            double o = 0.0, nw = 0.0;
+            int64_t amb = 0;
+            if (!proposals) {
+                int64_t m = 0;
+                rc = ek_pam_count_members(c, cid, &m);
+                if (rc)
+                    return rc;
+                if (m <= 0) {
+                    *cid_io = cid;
+                    *status = 2;
+                    return EK_OK;
+                }
+                int64_t j = 0;
+                if (ek_draw_at(raw, n_raw, pos, m, &j)) {
+                    *cid_io = cid;
+                    *status = 1;
+                    return EK_OK;
+                }
+                rc = ek_pam_propose_member(c, cid, j, &prop, &o, &nw, &amb);
+            } else {
+                prop = proposals[cid];
+                rc = ek_pam_propose(c, cid, prop, &o, &nw, &amb);
+            }
+            if (rc)
+                return rc;
+            const int a = nw < o;                               // kmedoids.py:683
+            rc = ek_pam_commit(c, a);
+            if (rc)
+                return rc;
+            accept[cid] = a;
+            old_cost[cid] = o;
+            new_cost[cid] = nw;
+            n_amb[cid] = amb;
+            if (a)
+                medoids[cid] = prop;
+            ++cid;
+        }
+    }
+    *cid_io = cid;
+    return EK_OK;
+}
+
 extern "C" int ek_pam_propose_ex(ek_ctx *c, int32_t cid, int64_t frame_index,
                                  int64_t n_members, int32_t win_lo,
                                  int32_t win_count, double *old_cost,

@@ -267,6 +267,29 @@ class FrameStore:
             _lib.f64p(nc), _lib.i64p(na)))
         return nd.value, acc, oc, nc, na
 
+    def pam_sweep_run(self, width, raw, pos, proposals, cid, medoids, accept,
+                      old_cost, new_cost, n_amb):
+        """The window loop of a sweep inside the library (ek_pam_sweep): from
+        cluster `cid` on, draws taken from the raw 32-bit outputs `raw` (uint32,
+        `pos` of them consumed so far).  medoids / accept / old_cost / new_cost /
+        n_amb (arrays of len(medoids)) are updated in place.
+        -> (status, cid, pos): status 0 done, 1 more raw outputs needed, 2 cluster
+        `cid` is empty"""
+        K = len(medoids)
+        p = C.c_int64(int(pos))
+        c = C.c_int32(int(cid))
+        st = C.c_int32(0)
+        props = None
+        if proposals is not None:
+            props = np.ascontiguousarray(proposals, dtype=np.int64)
+        _lib.check(self.lib.ek_pam_sweep(
+            self._h, K, int(width),
+            raw.ctypes.data_as(C.POINTER(C.c_uint32)), len(raw), C.byref(p),
+            _lib.i64p(props) if props is not None else None, C.byref(c),
+            _lib.i64p(medoids), _lib.i32p(accept), _lib.f64p(old_cost),
+            _lib.f64p(new_cost), _lib.i64p(n_amb), C.byref(st)))
+        return st.value, c.value, p.value
+
     # -- PAM across shards (device pointers are plain ints) ----------------------
     def centered_frames(self, local_frames, rows, aos_ptr, G_ptr):
         """rows[i] of the device arrays at aos_ptr ([.., 3A] float32) / G_ptr

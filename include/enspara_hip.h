@@ -363,6 +363,23 @@ int ek_pam_window_run(ek_ctx *ctx, int32_t cid0, int32_t count,
                       int32_t *accept, double *old_cost, double *new_cost,
                       int64_t *n_ambiguous);
 
+/* The window loop of a whole sweep (kmedoids.py:575-699 for clusters *cid ..
+ * n_medoids - 1, after ek_pam_begin): windows of up to `width` (2 ..
+ * ek_pam_window_max()) proposals -- counted, drawn, selected, prefetched, decided
+ * by ek_pam_window_run --, the cluster a window stops at one proposal at a time.
+ * What the Python driver does call by call, without the interpreter between the
+ * calls.  proposals == NULL: the draws are numpy's RandomState.choice(m) made on
+ * `raw`, the next 32-bit outputs of the caller's RandomState
+ * (randint(0, 2**32, dtype=uint32)); *pos counts the outputs consumed.
+ * medoids[i] is replaced where proposal i was accepted; accept / old_cost /
+ * new_cost / n_ambiguous [n_medoids] report every proposal.
+ * *status: 0 done (*cid == n_medoids); 1 `raw` ran out -- call again with more
+ * (everything returned so far stands); 2 cluster *cid is empty (choice raises). */
+int ek_pam_sweep(ek_ctx *ctx, int32_t n_medoids, int32_t width, const uint32_t *raw,
+                 int64_t n_raw, int64_t *pos, const int64_t *proposals, int32_t *cid,
+                 int64_t *medoids, int32_t *accept, double *old_cost,
+                 double *new_cost, int64_t *n_ambiguous, int32_t *status);
+
 /* PAM when the frames are sharded over several contexts (one per GPU; the
  * reference's MPI branch of kmedoids.py:575-699 with mpi/ops.py:143-212).  A
  * medoid or a proposal may then be a frame of another shard, so centers are
