@@ -57,3 +57,13 @@ __device__ __forceinline__ double ek_tree_sum64(double r)
     }
     return r;
 }
+
+// A workgroup barrier for steps that hand over LDS contents only.  __syncthreads()
+// also waits for every global load still in flight (its release fence is
+// s_waitcnt vmcnt(0)), which would make each barrier wait for the loads asked for
+// ahead of time -- the next slot's frames, the tables -- at memory latency.
+__device__ __forceinline__ void ek_lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+

@@ -189,15 +189,6 @@ __device__ __forceinline__ int ek_sp_leaf_of(int64_t f, const EkSpArgs &p)
     return p.n_full * EK_PW_FULL_LEAVES + lo;
 }
 
-// A workgroup barrier for steps that hand over LDS contents only.  __syncthreads()
-// also waits for every global load still in flight (its release fence is
-// s_waitcnt vmcnt(0)), which would make each barrier wait for the loads asked for
-// ahead of time -- the next slot's frames, the tables -- at memory latency.
-__device__ __forceinline__ void ek_lds_barrier()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
 __device__ __forceinline__ unsigned long long ek_sp_key(float d, int32_t c)
 {
     return ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)c;
