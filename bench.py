@@ -554,15 +554,25 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: there is no CPU path")
+    # EK_BENCH_ONE_DEVICE=1 (a check of the N > 1 code path on a one-GPU box, not a
+    # measurement): every rank on device 0, rendezvous and control tensors over
+    # gloo -- RCCL refuses two ranks on one device; the mailboxes do not care
+    one_device = os.environ.get("EK_BENCH_ONE_DEVICE") == "1" and world > 1
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.sharded
+    ctl = "cpu" if one_device else "cuda"
     if use_dist:
         if "MASTER_ADDR" not in os.environ:
             os.environ["MASTER_ADDR"] = "127.0.0.1"
             os.environ.setdefault("MASTER_PORT", "29541")
-        dist.init_process_group(
-            "nccl", rank=rank, world_size=world,
-            device_id=torch.device("cuda", local_rank))
+        if one_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(
+                "nccl", rank=rank, world_size=world,
+                device_id=torch.device("cuda", local_rank))
 
     # a step = cps consecutive centers of the one fit
     cps = max(1, args.centers // args.steps)
@@ -609,7 +619,7 @@ def main():
                 print("mailboxes unavailable (%s): gather transport" % e,
                       file=sys.stderr)
                 shard.ms_connected = 0
-        flag = torch.tensor([1 if transport == "mailbox" else 0], device="cuda")
+        flag = torch.tensor([1 if transport == "mailbox" else 0], device=ctl)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0 and transport == "mailbox":
             transport, shard.ms_connected = "gather", 0
@@ -627,7 +637,7 @@ def main():
                 print("mailbox transport failed (%s): gather transport" % e,
                       file=sys.stderr)
                 ok = 0
-            flag = torch.tensor([ok], device="cuda")
+            flag = torch.tensor([ok], device=ctl)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) == 0:
                 transport, shard.ms_connected = "gather", 0
@@ -686,7 +696,7 @@ def main():
         rounds = sum(p for p, _ in mix.values())
 
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=ctl)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -774,6 +784,9 @@ def main():
             "templates": args.templates if args.data == "templates" else None,
             "data": args.data, "seed": args.seed,
             "world_size": (dist.get_world_size() if use_dist else 1),
+            **({"one_device_check": "EK_BENCH_ONE_DEVICE=1: every rank on device 0, gloo "
+                                    "rendezvous -- the N > 1 code path exercised on a "
+                                    "one-GPU box, not a measurement"} if one_device else {}),
             "sharding": ("contiguous frame blocks; per round of ~15 centers ONE "
                          "message per rank (per-prefix maxima + its farthest "
                          "frames as records), transport: %s" % transport)
