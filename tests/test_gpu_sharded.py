@@ -466,3 +466,31 @@ def test_estimators_in_mpi_mode(tmp_path, world, backend, n, K):
             np.concatenate([p[key + "_a"] for p in parts]), want_a)
         np.testing.assert_array_equal(
             np.concatenate([p[key + "_d"] for p in parts]), want_d)
+
+
+def test_bench_two_ranks_on_one_device():
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one
+    process per rank), with EK_BENCH_ONE_DEVICE=1: both ranks on device 0 and a
+    gloo rendezvous -- the N > 1 code path of the bench (mailboxes over hipIpc,
+    the validation fit, barriers, the max-over-ranks time, rank 0's one JSON
+    line), exercised where there is one GPU.  The fit's centers are checked by
+    the sharded tests above; here the line has to come out whole."""
+    import json
+    env = dict(os.environ)
+    env.update({"EK_BENCH_ONE_DEVICE": "1", "GPU_MAX_HW_QUEUES": "16",
+                "PYTHONPATH": ROOT + os.pathsep + env.get("PYTHONPATH", "")})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+           "29547", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6",
+           "--warmup", "1", "--frames", "120000", "--atoms", "60", "--centers", "600",
+           "--templates", "600", "--pam-sweeps", "0", "--no-msm", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 1
+    assert d["config"]["world_size"] == 2 and d["value"] > 0
+    assert "mailbox" in d["config"]["sharding"]
+    assert d["roofline"]["frac"] > 0 and d["config"]["frames_total"] == 120000
