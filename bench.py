@@ -853,6 +853,10 @@ def main():
             "proposals_with_own_pass": misses,
             "prefetch_passes_over_touched_frames_only": pf_restricted,
             "prefetch_passes_over_all_frames": pf_full,
+            # (windows worked through by one workgroup, no launch
+            # between two proposals; the rest take three launches per proposal)
+            "windows_in_one_workgroup": store.pam_sparse_stats()[0] if world == 1 else None,
+            "of_them_ended_early": store.pam_sparse_stats()[1] if world == 1 else None,
         }
         if start is not None and args.pam_sweeps == 1 and not args.no_cpu_baseline:
             out["khybrid"]["parity"] = khybrid_check(x, store, start, med, args.seed,
