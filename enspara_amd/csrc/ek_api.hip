@@ -135,6 +135,7 @@ struct ek_ctx {
     // windows worked through by one workgroup (ek_pam_sparse.hip)
     int pam_sparse = 1;              // use them where they apply (option key 12)
     int64_t sp_max_pairs = EK_SP_MAX_PAIRS;  // (option key 13)
+    int sp_exact = 0;                // (option key 14)
     bool sp_ready = false;           // act_list holds the list of the window just prefetched
     uint32_t *act_list = nullptr;    // [n] the frames a window's proposals can touch
     int64_t vecs_rows = -1;          // >= 0: pam_vecs is +inf except at act_list[0 .. vecs_rows)
@@ -570,6 +571,11 @@ extern "C" int ek_set_option(ek_ctx *c, int32_t key, int32_t value)
         if (value != 0 && value != 1)
             return ek_fail(EK_EARG, "ek_set_option: one-workgroup PAM windows 0 or 1");
         c->pam_sparse = value;
+        return EK_OK;
+    case 14:
+        if (value != 0 && value != 1)
+            return ek_fail(EK_EARG, "ek_set_option: both cost sums for every proposal 0 or 1");
+        c->sp_exact = value;
         return EK_OK;
     case 13:
         if (value < 0)
@@ -2262,6 +2268,7 @@ static int ek_pam_window_sparse(ek_ctx *c, int32_t cid0, int32_t count,
     a.n_leaves = c->pw_leaves;
     a.n_chunks = c->pw_chunks;
     a.max_pairs = c->sp_max_pairs;
+    a.exact_always = c->sp_exact;
     a.win = c->pam_win_dev;
 #ifdef EK_SP_PROF
     static unsigned long long *prof_dev = nullptr;

@@ -39,6 +39,7 @@ struct EkSpArgs {
     const EkPwShape *shapes;
     int32_t n_full, n_leaves, n_chunks;
     int64_t max_pairs;
+    int32_t exact_always;       // take both cost sums for every proposal (ek_set_option key 14)
     EkPamWin *win;
     unsigned long long *prof;   // measurement builds (EK_SP_PROF): 10 ns ticks per step
 };

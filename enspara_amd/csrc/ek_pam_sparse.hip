@@ -21,7 +21,10 @@
 //     sit in memory, a proposal writes its changes into the state, re-adds the
 //     leaves and chunks it touched, adds the chunks up left to right, decides
 //     (mean of squares, float64, strict <: kmedoids.py:478-479, :683) and either
-//     keeps all that or puts the old values back.
+//     keeps all that or puts the old values back.  That is: where the sums decide.
+//     Where the sum of new^2 - old^2 over the frames the proposal changes is far
+//     beyond what the rounding of the two big sums can amount to, its sign is the
+//     outcome and the sums are not taken (see "what the proposal would change").
 // No launch, no arrival counter and no other workgroup between two proposals:
 // the steps are separated by workgroup barriers.  A dependent launch costs
 // ~4.5 us on this GPU and the three-launch form spends ~29 us per proposal at
@@ -235,11 +238,113 @@ __device__ void ek_sp_ragged(const EkSpArgs &p, double *la, double *out)
     __syncthreads();
 }
 
+#define SP_LB 6         // leaves a group of eight lanes re-adds with its loads in flight
+#define SP_CB 8         // pairs of chunks a wave does with its loads in flight
+
+// the listed leaves' sums, re-added from the state (numpy's leaf: eight
+// interleaved running sums, combined pairwise, then the tail); the value before
+// goes to p.leaf[2 g + 1], the leaf's chunk is marked in `cbits`
+__device__ __forceinline__ void ek_sp_readd_leaves(const EkSpArgs &p, const int32_t *tleaf,
+                                                   unsigned int n_leaf, uint32_t *cbits)
+{
+    const int t = threadIdx.x;
+    const int full_leaves = p.n_full * EK_PW_FULL_LEAVES;
+    for (unsigned int q0 = 0; q0 < n_leaf; q0 += SP_LB * (SP_NT / 8)) {
+        int g[SP_LB];
+        double old[SP_LB];
+        float v[SP_LB][16];
+#pragma unroll
+        for (int b = 0; b < SP_LB; ++b) {
+            const unsigned int q = q0 + b * (SP_NT / 8) + t / 8;
+            g[b] = (q < n_leaf) ? tleaf[q] : -1;        // (uniform over a group of 8 lanes)
+        }
+#pragma unroll
+        for (int b = 0; b < SP_LB; ++b) {
+            old[b] = (g[b] >= 0) ? p.leaf[2 * (size_t)g[b]] : 0.0;
+            if (g[b] >= 0 && g[b] < full_leaves) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    v[b][i] = p.dist[(int64_t)g[b] * 128 + 8 * i + (t & 7)];
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < SP_LB; ++b) {
+            if (g[b] < 0)
+                continue;
+            double r;
+            int chunk;
+            if (g[b] < full_leaves) {
+                r = 0.0;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const double x = v[b][i];
+                    r = (i == 0) ? x * x : r + x * x;
+                }
+                r = ek_tree_sum8(r);
+                chunk = g[b] / EK_PW_FULL_LEAVES;
+            } else {
+                const EkPwShape *sh = &p.shapes[1];
+                const int l = g[b] - full_leaves;
+                r = ek_sp_leaf(p.dist, (int64_t)p.n_full * EK_PW_CHUNK + sh->leaf_off[l],
+                               sh->leaf_len[l], t & 7);
+                chunk = p.n_full;
+            }
+            if ((t & 7) == 0) {
+                p.leaf[2 * (size_t)g[b] + 1] = old[b];
+                p.leaf[2 * (size_t)g[b]] = r;
+                atomicOr(&cbits[chunk >> 5], 1u << (chunk & 31));
+            }
+        }
+    }
+}
+
+// the marked chunks' sums, re-added from their leaf sums (after a barrier that
+// waits for the stores above); the value before goes to s_chunk_old.  A full
+// chunk: 64 leaves, a perfect in-order tree (checked by ek_pam_alloc) -- half a
+// wave per chunk: a lane adds leaves 2l and 2l + 1 itself, ek_tree_sum32 does the
+// five levels above.  -> whether the last, shorter chunk was among them
+__device__ __forceinline__ bool ek_sp_readd_chunks(const EkSpArgs &p, const uint32_t *cbits,
+                                                   double *s_chunk, double *s_chunk_old,
+                                                   double *la, int lane, int wv)
+{
+    for (int c0 = 0; c0 < p.n_full; c0 += 2 * SP_CB * SP_WAVES) {
+        double r[SP_CB];
+        bool on[SP_CB];
+        const int half = lane >> 5, l32 = lane & 31;
+#pragma unroll
+        for (int k = 0; k < SP_CB; ++k) {
+            const int c = c0 + 2 * (k * SP_WAVES + wv) + half;
+            on[k] = c < p.n_full && ((cbits[c >> 5] >> (c & 31)) & 1u);
+            const size_t g = (size_t)c * EK_PW_FULL_LEAVES + 2 * l32;
+            const double a0 = on[k] ? p.leaf[2 * g] : 0.0;
+            const double a1 = on[k] ? p.leaf[2 * g + 2] : 0.0;
+            r[k] = a0 + a1;
+        }
+#pragma unroll
+        for (int k = 0; k < SP_CB; ++k)
+            r[k] = ek_tree_sum32(r[k]);
+#pragma unroll
+        for (int k = 0; k < SP_CB; ++k) {
+            const int c = c0 + 2 * (k * SP_WAVES + wv) + half;
+            if (on[k] && l32 == 0) {
+                s_chunk_old[c] = s_chunk[c];
+                s_chunk[c] = r[k];
+            }
+        }
+    }
+    const bool ragged = p.n_chunks > p.n_full &&
+                        ((cbits[p.n_full >> 5] >> (p.n_full & 31)) & 1u);
+    if (ragged) {
+        if (threadIdx.x == 0)
+            s_chunk_old[p.n_full] = s_chunk[p.n_full];
+        ek_sp_ragged(p, la, &s_chunk[p.n_full]);
+    }
+    return ragged;
+}
+
 // the lists of a proposal are kept in LDS: a dependent trip to memory costs about
 // a microsecond, and that -- not arithmetic -- is what a proposal's time is made of
 #define SP_KU 10        // table entries a thread asks for ahead of the search
-#define SP_LB 6         // leaves a group of eight lanes re-adds with its loads in flight
-#define SP_CB 8         // pairs of chunks a wave does with its loads in flight
 #define SP_CAP_CHG 2048 // frames a proposal may change
 #define SP_CAP_AMB 1024 // members it may leave behind
 #define SP_CAP_COLS 256 // medoids within their reach
@@ -251,7 +356,8 @@ struct EkSpLds {        // byte offsets into the dynamic LDS block
     static constexpr size_t chunk_old = chunk + (size_t)EK_SP_MAX_CHUNKS * 8;
     static constexpr size_t amb_key = chunk_old + (size_t)EK_SP_MAX_CHUNKS * 8;
     static constexpr size_t lbits = amb_key + (size_t)SP_CAP_AMB * 8;
-    static constexpr size_t chg_f = lbits + (size_t)EK_SP_MAX_CHUNKS * EK_PW_FULL_LEAVES / 8;
+    static constexpr size_t dirty = lbits + (size_t)EK_SP_MAX_CHUNKS * EK_PW_FULL_LEAVES / 8;
+    static constexpr size_t chg_f = dirty + (size_t)EK_SP_MAX_CHUNKS * EK_PW_FULL_LEAVES / 8;
     static constexpr size_t chg_od = chg_f + (size_t)SP_CAP_CHG * 4;
     static constexpr size_t chg_nd = chg_od + (size_t)SP_CAP_CHG * 4;
     static constexpr size_t chg_oa = chg_nd + (size_t)SP_CAP_CHG * 4;
@@ -278,6 +384,7 @@ ek_sp_window_kernel(EkSpArgs p)
     double *s_chunk_old = (double *)(sp_lds + EkSpLds::chunk_old);
     unsigned long long *amb_key = (unsigned long long *)(sp_lds + EkSpLds::amb_key);
     uint32_t *s_lbits = (uint32_t *)(sp_lds + EkSpLds::lbits);
+    uint32_t *s_dirty = (uint32_t *)(sp_lds + EkSpLds::dirty);  // leaves whose sum is out of date
     uint32_t *chg_f = (uint32_t *)(sp_lds + EkSpLds::chg_f);
     float *chg_od = (float *)(sp_lds + EkSpLds::chg_od);
     float *chg_nd = (float *)(sp_lds + EkSpLds::chg_nd);
@@ -292,6 +399,7 @@ ek_sp_window_kernel(EkSpArgs p)
     __shared__ uint32_t s_cbits[EK_SP_MAX_CHUNKS / 32];
     __shared__ unsigned int s_n_chg, s_n_amb, s_reach, s_n_col, s_mask, s_n_leaf;
     __shared__ float s_T[EK_PAM_WIN];
+    __shared__ double s_part[2 * SP_WAVES];
     __shared__ unsigned int s_bcnt[EK_PAM_WIN + 1];
     __shared__ int s_stop, s_acc[EK_PAM_WIN];
     __shared__ uint32_t s_stale;
@@ -311,8 +419,11 @@ ek_sp_window_kernel(EkSpArgs p)
     }
     for (int c = t; c < EK_SP_MAX_CHUNKS; c += SP_NT)
         s_chunk[c] = (c < p.n_chunks) ? p.chunk[2 * (size_t)c] : 0.0;
-    for (int i = t; i < EK_SP_MAX_CHUNKS * EK_PW_FULL_LEAVES / 32; i += SP_NT)
+    for (int i = t; i < EK_SP_MAX_CHUNKS * EK_PW_FULL_LEAVES / 32; i += SP_NT) {
         s_lbits[i] = 0;
+        s_dirty[i] = 0;
+    }
+    bool tree_fresh = true;     // leaf and chunk sums are those of the state
     if (t < EK_SP_MAX_CHUNKS / 32)
         s_cbits[t] = 0;
     if (t < EK_PAM_WIN)
@@ -543,122 +654,147 @@ ek_sp_window_kernel(EkSpArgs p)
             break;
         }
         SP_T(1);
-        // ---- the trial state, written into the state; old values kept -------------------
-        unsigned int m = 0;
+        // ---- what the proposal would change in the sum of squares -------------------------
+        // Both sums are numpy's pairwise sums of ~n terms: each within (chunks + 30)
+        // eps of the exact value, eps = 1.1e-16 -- 1.2e-13 relative at the 1024 chunks
+        // a window may have.  The sum of (new^2 - old^2) over the frames the proposal
+        // changes is exact to 2048 eps of the sum of its terms' magnitudes at worst
+        // (each square of a float32 is exact in float64).  If it is four orders of
+        // magnitude beyond what the rounding of the two big sums can amount to, its
+        // sign IS the outcome of kmedoids.py:683's comparison and neither sum has to
+        // be taken; otherwise (a two-member cluster swapping its medoid changes
+        // nothing in exact arithmetic) both are, in numpy's order, below.
+        double dsum = 0.0, dabs = 0.0;
         for (unsigned int q = t; q < n_chg; q += SP_NT) {
-            const uint32_t f = chg_f[q];
-            const int32_t oa = chg_oa[q], na = chg_na[q];
-            p.dist[f] = chg_nd[q];
-            p.assign[f] = na;
-            if (oa != na) {
-                const int32_t ia = oa - p.cid0, ib = na - p.cid0;
-                if (ia >= 0 && ia < p.win_count)
-                    m |= 1u << ia;
-                if (ib >= 0 && ib < p.win_count)
-                    m |= 1u << ib;
-            }
-            const int g = ek_sp_leaf_of(f, p);
-            const uint32_t bit = 1u << (g & 31);
-            if (!(atomicOr(&s_lbits[g >> 5], bit) & bit))
-                tleaf[atomicAdd(&s_n_leaf, 1u)] = g;
+            const double od = chg_od[q], nd = chg_nd[q];
+            const double term = nd * nd - od * od;
+            dsum += term;
+            dabs += fabs(term);
         }
-        if (m)
-            atomicOr(&s_mask, m);
-        __syncthreads();
-        SP_T(2);
-        // ---- the leaves and chunks that changed, re-added ---------------------------------
-        const unsigned int n_leaf = s_n_leaf;
-        const int full_leaves = p.n_full * EK_PW_FULL_LEAVES;
-        for (unsigned int q0 = 0; q0 < n_leaf; q0 += SP_LB * (SP_NT / 8)) {
-            int g[SP_LB];
-            double old[SP_LB];
-            float v[SP_LB][16];
 #pragma unroll
-            for (int b = 0; b < SP_LB; ++b) {
-                const unsigned int q = q0 + b * (SP_NT / 8) + t / 8;
-                g[b] = (q < n_leaf) ? tleaf[q] : -1;    // (uniform over a group of 8 lanes)
-            }
-#pragma unroll
-            for (int b = 0; b < SP_LB; ++b) {
-                old[b] = (g[b] >= 0) ? p.leaf[2 * (size_t)g[b]] : 0.0;
-                if (g[b] >= 0 && g[b] < full_leaves) {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i)
-                        v[b][i] = p.dist[(int64_t)g[b] * 128 + 8 * i + (t & 7)];
-                }
-            }
-#pragma unroll
-            for (int b = 0; b < SP_LB; ++b) {
-                if (g[b] < 0)
-                    continue;
-                double r;
-                int chunk;
-                if (g[b] < full_leaves) {
-                    r = 0.0;
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const double x = v[b][i];
-                        r = (i == 0) ? x * x : r + x * x;
-                    }
-                    r = ek_tree_sum8(r);
-                    chunk = g[b] / EK_PW_FULL_LEAVES;
-                } else {
-                    const EkPwShape *sh = &p.shapes[1];
-                    const int l = g[b] - full_leaves;
-                    r = ek_sp_leaf(p.dist, (int64_t)p.n_full * EK_PW_CHUNK + sh->leaf_off[l],
-                                   sh->leaf_len[l], t & 7);
-                    chunk = p.n_full;
-                }
-                if ((t & 7) == 0) {
-                    p.leaf[2 * (size_t)g[b] + 1] = old[b];
-                    p.leaf[2 * (size_t)g[b]] = r;
-                    atomicOr(&s_cbits[chunk >> 5], 1u << (chunk & 31));
-                }
-            }
+        for (int o = 1; o < EK_WAVE; o <<= 1) {
+            dsum += __shfl_xor(dsum, o, EK_WAVE);
+            dabs += __shfl_xor(dabs, o, EK_WAVE);
         }
-        __syncthreads();
-        SP_T(3);
-        // a full chunk: 64 leaves, a perfect in-order tree (checked by
-        // ek_pam_alloc).  Half a wave per chunk: a lane adds leaves 2l and 2l + 1
-        // itself, ek_tree_sum32 does the five levels above.
-        for (int c0 = 0; c0 < p.n_full; c0 += 2 * SP_CB * SP_WAVES) {
-            double r[SP_CB];
-            bool on[SP_CB];
-            const int half = lane >> 5, l32 = lane & 31;
-#pragma unroll
-            for (int k = 0; k < SP_CB; ++k) {
-                const int c = c0 + 2 * (k * SP_WAVES + wv) + half;
-                on[k] = c < p.n_full && ((s_cbits[c >> 5] >> (c & 31)) & 1u);
-                const size_t g = (size_t)c * EK_PW_FULL_LEAVES + 2 * l32;
-                const double a0 = on[k] ? p.leaf[2 * g] : 0.0;
-                const double a1 = on[k] ? p.leaf[2 * g + 2] : 0.0;
-                r[k] = a0 + a1;
-            }
-#pragma unroll
-            for (int k = 0; k < SP_CB; ++k)
-                r[k] = ek_tree_sum32(r[k]);
-#pragma unroll
-            for (int k = 0; k < SP_CB; ++k) {
-                const int c = c0 + 2 * (k * SP_WAVES + wv) + half;
-                if (on[k] && l32 == 0) {
-                    s_chunk_old[c] = s_chunk[c];
-                    s_chunk[c] = r[k];
-                }
-            }
-        }
-        const bool ragged = p.n_chunks > p.n_full &&
-                            ((s_cbits[p.n_full >> 5] >> (p.n_full & 31)) & 1u);
-        if (ragged) {
-            if (t == 0)
-                s_chunk_old[p.n_full] = s_chunk[p.n_full];
-            ek_sp_ragged(p, la, &s_chunk[p.n_full]);
+        if (lane == 0) {
+            s_part[wv] = dsum;
+            s_part[SP_WAVES + wv] = dabs;
         }
         ek_lds_barrier();
-        SP_T(4);
-        const double total_new = ek_sp_total(s_chunk, p.n_chunks);
-        SP_T(5);
-        // ---- verdict (ek_pw_window_kernel's), taken by every thread alike ------------------
-        const bool accept = total_new / p.n_total < total / p.n_total;
+        double delta = 0.0, dab = 0.0;
+#pragma unroll
+        for (int w = 0; w < SP_WAVES; ++w) {    // the same order in every thread
+            delta += s_part[w];
+            dab += s_part[SP_WAVES + w];
+        }
+        const bool obvious = !p.exact_always && fabs(delta) > 1e-9 * total + 1e-11 * dab;
+        bool accept, wrote = false;
+        double total_new;
+        unsigned int n_leaf = 0;
+        if (obvious) {
+            accept = delta < 0.0;
+            total_new = total + delta;
+            if (accept) {
+                // the trial state becomes the state; its leaves' sums are out of date
+                unsigned int m = 0;
+                for (unsigned int q = t; q < n_chg; q += SP_NT) {
+                    const uint32_t f = chg_f[q];
+                    const int32_t oa = chg_oa[q], na = chg_na[q];
+                    p.dist[f] = chg_nd[q];
+                    p.assign[f] = na;
+                    if (oa != na) {
+                        const int32_t ia = oa - p.cid0, ib = na - p.cid0;
+                        if (ia >= 0 && ia < p.win_count)
+                            m |= 1u << ia;
+                        if (ib >= 0 && ib < p.win_count)
+                            m |= 1u << ib;
+                    }
+                    const int g = ek_sp_leaf_of(f, p);
+                    atomicOr(&s_dirty[g >> 5], 1u << (g & 31));
+                }
+                if (m)
+                    atomicOr(&s_mask, m);
+                tree_fresh = false;
+                wrote = true;
+            }
+            ek_lds_barrier();
+            SP_T(2);
+        } else {
+            if (!tree_fresh) {
+                // ---- the leaves changed since the tree was last brought up to date -------
+                for (;;) {
+                    if (t == 0)
+                        s_n_leaf = 0;
+                    ek_lds_barrier();
+                    const int n_words = (p.n_leaves + 31) / 32;
+                    for (int w = t; w < n_words; w += SP_NT) {
+                        uint32_t bits = s_dirty[w];
+                        while (bits) {
+                            const int b = __ffs((int)bits) - 1;
+                            const unsigned int q = atomicAdd(&s_n_leaf, 1u);
+                            if (q >= SP_CAP_CHG)
+                                break;          // the next round takes the rest
+                            tleaf[q] = w * 32 + b;
+                            bits &= bits - 1;
+                        }
+                        s_dirty[w] = bits;
+                    }
+                    ek_lds_barrier();
+                    const unsigned int listed = s_n_leaf;
+                    if (listed == 0)
+                        break;
+                    ek_sp_readd_leaves(p, tleaf, min(listed, (unsigned int)SP_CAP_CHG),
+                                       s_cbits);
+                    __syncthreads();
+                }
+                ek_sp_readd_chunks(p, s_cbits, s_chunk, s_chunk_old, la, lane, wv);
+                ek_lds_barrier();
+                if (t < EK_SP_MAX_CHUNKS / 32)
+                    s_cbits[t] = 0;
+                if (t == 0)
+                    s_n_leaf = 0;
+                total = ek_sp_total(s_chunk, p.n_chunks);
+                tree_fresh = true;
+                ek_lds_barrier();
+            }
+            // ---- the trial state, written into the state; old values kept ---------------
+            unsigned int m = 0;
+            for (unsigned int q = t; q < n_chg; q += SP_NT) {
+                const uint32_t f = chg_f[q];
+                const int32_t oa = chg_oa[q], na = chg_na[q];
+                p.dist[f] = chg_nd[q];
+                p.assign[f] = na;
+                if (oa != na) {
+                    const int32_t ia = oa - p.cid0, ib = na - p.cid0;
+                    if (ia >= 0 && ia < p.win_count)
+                        m |= 1u << ia;
+                    if (ib >= 0 && ib < p.win_count)
+                        m |= 1u << ib;
+                }
+                const int g = ek_sp_leaf_of(f, p);
+                const uint32_t bit = 1u << (g & 31);
+                if (!(atomicOr(&s_lbits[g >> 5], bit) & bit))
+                    tleaf[atomicAdd(&s_n_leaf, 1u)] = g;
+            }
+            if (m)
+                atomicOr(&s_mask, m);
+            __syncthreads();
+            SP_T(2);
+            // ---- the leaves and chunks that changed, re-added ------------------------------
+            n_leaf = s_n_leaf;
+            ek_sp_readd_leaves(p, tleaf, n_leaf, s_cbits);
+            __syncthreads();
+            SP_T(3);
+            ek_sp_readd_chunks(p, s_cbits, s_chunk, s_chunk_old, la, lane, wv);
+            ek_lds_barrier();
+            SP_T(4);
+            total_new = ek_sp_total(s_chunk, p.n_chunks);
+            SP_T(5);
+            // kmedoids.py:478-479, :683 (ek_pw_window_kernel's verdict)
+            accept = total_new / p.n_total < total / p.n_total;
+            wrote = true;
+        }
+        // ---- verdict, taken by every thread alike --------------------------------------------
         if (t == 0) {
             EkPamOut o;
             o.sum_old = total;
@@ -686,7 +822,7 @@ ek_sp_window_kernel(EkSpArgs p)
         SP_T(6);
         if (accept) {
             total = total_new;
-        } else {
+        } else if (!obvious) {
             for (unsigned int q = t; q < n_chg; q += SP_NT) {
                 const uint32_t f = chg_f[q];
                 p.dist[f] = chg_od[q];
@@ -702,11 +838,11 @@ ek_sp_window_kernel(EkSpArgs p)
         }
         for (unsigned int q = t; q < n_leaf; q += SP_NT)
             s_lbits[tleaf[q] >> 5] = 0;
-        if (accept)
-            ek_lds_barrier();
+        if (wrote)
+            __syncthreads();    // the state was written: the stores have to be through
         else
-            __syncthreads();    // the state was put back: the stores have to be through
-        if (t < EK_SP_MAX_CHUNKS / 32)
+            ek_lds_barrier();
+        if (!obvious && t < EK_SP_MAX_CHUNKS / 32)
             s_cbits[t] = 0;
         if (t == 0) {
             s_n_chg = 0;

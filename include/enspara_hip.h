@@ -554,7 +554,12 @@ int ek_set_frames_per_lane(ek_ctx *ctx, int fpl);
  * key 13: the (ambiguous member, medoid within reach) pairs such a workgroup
  * searches itself (default 16384); a proposal with more ends the window and goes
  * through the launches.  0 makes every proposal whose members have another
- * medoid within reach do so (tests) */
+ * medoid within reach do so (tests)
+ * key 14: such a workgroup takes both cost sums (numpy's order) for every
+ * proposal (1) or only where the sum of the changes, new^2 - old^2 over the
+ * frames the proposal moves, does not decide kmedoids.py:683's comparison by
+ * four orders of magnitude more than the rounding of the sums can amount to
+ * (0, default); identical decisions */
 int ek_set_option(ek_ctx *ctx, int32_t key, int32_t value);
 /* time of the last ek_kcenters_run loop measured with HIP events on the
  * context's stream, milliseconds, and the number of distance-kernel launches
