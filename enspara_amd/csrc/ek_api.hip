@@ -2308,12 +2308,17 @@ static int ek_pam_window_sparse(ek_ctx *c, int32_t cid0, int32_t count,
 // window at the first cluster whose membership an accepted proposal changed:
 // *n_done slots were decided, the caller handles slot *n_done one at a time
 // (its member list has to be counted again) and opens a new window after it.
-extern "C" int ek_pam_window_run(ek_ctx *c, int32_t cid0, int32_t count,
-                                 const int64_t *frames, const int64_t *n_members,
-                                 int32_t win_lo, int32_t win_count,
-                                 int32_t *n_done, int32_t *accept,
-                                 double *old_cost, double *new_cost,
-                                 int64_t *n_ambiguous)
+// next_count > 0: the member counts of clusters next_cid0 .. +next_count (what the
+// window after this one starts with) are taken on the state this window leaves,
+// right behind its kernels, and come back with its record -- one wait less per
+// window; they stand if the window runs to its end (the caller checks)
+static int ek_pam_window_run_impl(ek_ctx *c, int32_t cid0, int32_t count,
+                                  const int64_t *frames, const int64_t *n_members,
+                                  int32_t win_lo, int32_t win_count,
+                                  int32_t *n_done, int32_t *accept,
+                                  double *old_cost, double *new_cost,
+                                  int64_t *n_ambiguous, int32_t next_cid0,
+                                  int32_t next_count, int64_t *next_counts)
 {
     int rc = ek_pam_precheck(c, cid0, "ek_pam_window_run");
     if (rc)
@@ -2414,7 +2419,16 @@ extern "C" int ek_pam_window_run(ek_ctx *c, int32_t cid0, int32_t count,
     EK_CHECK_LAUNCH();
     EK_HIP(hipMemcpyAsync(c->pam_win_host, c->pam_win_dev, sizeof(EkPamWin),
                           hipMemcpyDeviceToHost, c->stream));
+    if (next_count > 0) {
+        ek_launch_count_members_multi(c->assign, c->n, next_cid0, next_count,
+                                      c->bat_blockcnt, c->bat_scan, c->bat_sel, c->stream);
+        EK_CHECK_LAUNCH();
+        EK_HIP(hipMemcpyAsync(next_counts, c->bat_sel, (size_t)next_count * sizeof(int64_t),
+                              hipMemcpyDeviceToHost, c->stream));
+    }
     EK_HIP(ek_wait(c));
+    c->bat_cid0 = -1;
+    c->bat_count = 0;
     const EkPamWin &w = *c->pam_win_host;
     c->tab_n = 0;            // the medoid table has moved on
     c->pam_cid = -1;
@@ -2443,7 +2457,24 @@ extern "C" int ek_pam_window_run(ek_ctx *c, int32_t cid0, int32_t count,
         if (n_ambiguous)
             n_ambiguous[i] = w.out[i].n_amb;
     }
+    if (next_count > 0 && w.stop == count) {
+        // the state the counts were taken on is the one the next window opens with
+        c->bat_cid0 = next_cid0;
+        c->bat_count = next_count;
+    }
     return EK_OK;
+}
+
+extern "C" int ek_pam_window_run(ek_ctx *c, int32_t cid0, int32_t count,
+                                 const int64_t *frames, const int64_t *n_members,
+                                 int32_t win_lo, int32_t win_count,
+                                 int32_t *n_done, int32_t *accept,
+                                 double *old_cost, double *new_cost,
+                                 int64_t *n_ambiguous)
+{
+    return ek_pam_window_run_impl(c, cid0, count, frames, n_members, win_lo, win_count,
+                                  n_done, accept, old_cost, new_cost, n_ambiguous, 0, 0,
+                                  nullptr);
 }
 
 // ---- a whole sweep's window loop on the host side of the library ------------------------
@@ -2513,9 +2544,18 @@ extern "C" int ek_pam_sweep(ek_ctx *c, int32_t K, int32_t width, const uint32_t 
     int64_t counts[EK_PAM_WIN], js[EK_PAM_WIN], frames[EK_PAM_WIN], na[EK_PAM_WIN];
     int32_t acc[EK_PAM_WIN];
     double oc[EK_PAM_WIN], nc[EK_PAM_WIN];
+    int64_t ahead[EK_PAM_WIN];
+    bool have_counts = false;       // `ahead` holds the counts of the window at `cid`
     while (cid < K) {
         const int32_t hi = std::min(K, cid + width), cnt = hi - cid;
-        int rc = ek_pam_count_members_batch(c, cid, cnt, counts);
+        int rc = EK_OK;
+        if (have_counts && c->bat_cid0 == cid && c->bat_count == cnt) {
+            for (int32_t s = 0; s < cnt; ++s)
+                counts[s] = ahead[s];
+        } else {
+            rc = ek_pam_count_members_batch(c, cid, cnt, counts);
+        }
+        have_counts = false;
         if (rc)
             return rc;
         int32_t n_slots = 0;
@@ -2544,10 +2584,14 @@ extern "C" int ek_pam_sweep(ek_ctx *c, int32_t K, int32_t width, const uint32_t 
             return rc;
         int32_t n_done = 0;
         if (n_slots > 0) {
-            rc = ek_pam_window_run(c, cid, n_slots, frames, counts, cid, cnt, &n_done,
-                                   acc, oc, nc, na);
+            // (the counts the next window starts with ride along when this one
+            // covers its clusters: they stand if it runs to its end)
+            const int32_t ncnt = (n_slots == cnt) ? std::min(K, hi + width) - hi : 0;
+            rc = ek_pam_window_run_impl(c, cid, n_slots, frames, counts, cid, cnt, &n_done,
+                                        acc, oc, nc, na, hi, ncnt, ahead);
             if (rc)
                 return rc;
+            have_counts = ncnt > 0 && n_done == n_slots;
         }
         for (int32_t s = 0; s < n_done; ++s) {
             if (!proposals) {
