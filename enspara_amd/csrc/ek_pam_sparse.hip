@@ -37,13 +37,13 @@
 
 #define SP_NT EK_SP_THREADS
 #ifdef EK_SP_PROF
+// (kept in registers and written once at the end: a read-modify-write of memory
+// per mark cost more than most steps)
 #define SP_T(k)                                                                \
     do {                                                                       \
-        if (t == 0 && p.prof) {                                                \
-            const unsigned long long now = wall_clock64();                     \
-            p.prof[k] += now - sp_t0;                                          \
-            sp_t0 = now;                                                       \
-        }                                                                      \
+        const unsigned long long now = wall_clock64();                         \
+        sp_acc[k] += now - sp_t0;                                              \
+        sp_t0 = now;                                                           \
     } while (0)
 #else
 #define SP_T(k)
@@ -190,6 +190,22 @@ __device__ __forceinline__ int ek_sp_leaf_of(int64_t f, const EkSpArgs &p)
             hi = mid - 1;
     }
     return p.n_full * EK_PW_FULL_LEAVES + lo;
+}
+
+// room in a list for the lanes of a wave that want to append (all lanes of the wave
+// call this): one LDS atomic per wave instead of one per lane -- same-address
+// atomics are served one after the other.  -> this lane's position (if `want`)
+__device__ __forceinline__ unsigned int ek_sp_append(unsigned int *counter, bool want, int lane)
+{
+    const unsigned long long m = __ballot(want);
+    if (m == 0)
+        return 0u;
+    const int leader = __ffsll((long long)m) - 1;
+    unsigned int base = 0;
+    if (lane == leader)
+        base = atomicAdd(counter, (unsigned int)__popcll(m));
+    base = __shfl(base, leader, EK_WAVE);
+    return base + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
 }
 
 __device__ __forceinline__ unsigned long long ek_sp_key(float d, int32_t c)
@@ -447,6 +463,7 @@ ek_sp_window_kernel(EkSpArgs p)
     __syncthreads();
     double total = ek_sp_total(s_chunk, p.n_chunks);      // the state's sum of squares
 #ifdef EK_SP_PROF
+    unsigned long long sp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long sp_t0 = wall_clock64();
 #endif
 
@@ -468,8 +485,9 @@ ek_sp_window_kernel(EkSpArgs p)
             d_first = p.dist[f_first.x];
             a_first = p.assign[f_first.x];
         }
+        float t_reg = 0.f;      // (into LDS after the classification: no wait for it here)
         if (t < slot && s_acc[t])
-            s_T[t] = p.T[(size_t)t * K + cid];
+            t_reg = p.T[(size_t)t * K + cid];
         float Dtab[SP_KU];
         {
             const float *O = p.O + (size_t)slot * K;
@@ -482,33 +500,40 @@ ek_sp_window_kernel(EkSpArgs p)
         if ((unsigned int)t < s_bcnt[slot + 1])
             f_pre = p.bucket[(size_t)(slot + 1) * p.bcap + t];
         SP_T(8);
-        for (unsigned int e = t; e < nb; e += SP_NT) {
-            const uint2 fe = (e < SP_NT) ? f_first : p.bucket[(size_t)slot * p.bcap + e];
+        for (unsigned int e0 = 0; e0 < nb; e0 += SP_NT) {      // (uniform over the wave)
+            const unsigned int e = e0 + t;
+            const bool in = e < nb;
+            uint2 fe = f_first;
+            if (in && e0 > 0)
+                fe = p.bucket[(size_t)slot * p.bcap + e];
             const uint32_t f = fe.x;
             const float nd = __uint_as_float(fe.y);
-            const float d = (e < SP_NT) ? d_first : p.dist[f];
-            const int32_t a = (e < SP_NT) ? a_first : p.assign[f];
-            if (d > nd) {
-                const unsigned int q = atomicAdd(&s_n_chg, 1u);
-                if (q < SP_CAP_CHG) {
-                    chg_f[q] = f;
-                    chg_od[q] = d;
-                    chg_oa[q] = a;
-                    chg_nd[q] = nd;
-                    chg_na[q] = cid;
-                }
-            } else if (a == cid) {
-                const unsigned int q = atomicAdd(&s_n_amb, 1u);
-                if (q < SP_CAP_AMB) {
-                    amb_f[q] = f;
-                    amb_d[q] = d;
-                    amb_key[q] = ek_sp_key(nd, cid);
+            const float d = (e0 == 0) ? d_first : (in ? p.dist[f] : 0.f);
+            const int32_t a = (e0 == 0) ? a_first : (in ? p.assign[f] : 0);
+            const bool closer = in && d > nd;
+            const bool member = in && !closer && a == cid;
+            const unsigned int q1 = ek_sp_append(&s_n_chg, closer, lane);
+            if (closer && q1 < SP_CAP_CHG) {
+                chg_f[q1] = f;
+                chg_od[q1] = d;
+                chg_oa[q1] = a;
+                chg_nd[q1] = nd;
+                chg_na[q1] = cid;
+            }
+            const unsigned int q2 = ek_sp_append(&s_n_amb, member, lane);
+            if (member) {
+                if (q2 < SP_CAP_AMB) {
+                    amb_f[q2] = f;
+                    amb_d[q2] = d;
+                    amb_key[q2] = ek_sp_key(nd, cid);
                 }
                 // how far a medoid may be from the old one and still matter to
                 // this frame; non-negative floats order like their bits
                 atomicMax(&s_reach, __float_as_uint(d + nd));
             }
         }
+        if (t < slot && s_acc[t])
+            s_T[t] = t_reg;
         SP_T(9);
         ek_lds_barrier();
         SP_T(0);
@@ -622,20 +647,22 @@ ek_sp_window_kernel(EkSpArgs p)
                 __syncthreads();
             }
             // the members' new labels and distances
-            for (unsigned int r = t; !bail && r < n_amb; r += SP_NT) {
-                const unsigned long long key = amb_key[r];
-                const float d = amb_d[r];
+            for (unsigned int r0 = 0; !bail && r0 < n_amb; r0 += SP_NT) {
+                const unsigned int r = r0 + t;
+                const bool in = r < n_amb;
+                const unsigned long long key = in ? amb_key[r] : 0ull;
+                const float d = in ? amb_d[r] : 0.f;
                 const float ndv = __uint_as_float((unsigned int)(key >> 32));
                 const int32_t na = (int32_t)(key & 0xffffffffu);
-                if (na != cid || __float_as_uint(ndv) != __float_as_uint(d)) {
-                    const unsigned int q = atomicAdd(&s_n_chg, 1u);
-                    if (q < SP_CAP_CHG) {
-                        chg_f[q] = amb_f[r];
-                        chg_od[q] = d;
-                        chg_oa[q] = cid;
-                        chg_nd[q] = ndv;
-                        chg_na[q] = na;
-                    }
+                const bool moved = in && (na != cid ||
+                                          __float_as_uint(ndv) != __float_as_uint(d));
+                const unsigned int q = ek_sp_append(&s_n_chg, moved, lane);
+                if (moved && q < SP_CAP_CHG) {
+                    chg_f[q] = amb_f[r];
+                    chg_od[q] = d;
+                    chg_oa[q] = cid;
+                    chg_nd[q] = ndv;
+                    chg_na[q] = na;
                 }
             }
         }
@@ -671,11 +698,8 @@ ek_sp_window_kernel(EkSpArgs p)
             dsum += term;
             dabs += fabs(term);
         }
-#pragma unroll
-        for (int o = 1; o < EK_WAVE; o <<= 1) {
-            dsum += __shfl_xor(dsum, o, EK_WAVE);
-            dabs += __shfl_xor(dabs, o, EK_WAVE);
-        }
+        dsum = ek_tree_sum64(dsum);             // (any fixed order will do)
+        dabs = ek_tree_sum64(dabs);
         if (lane == 0) {
             s_part[wv] = dsum;
             s_part[SP_WAVES + wv] = dabs;
@@ -872,6 +896,11 @@ ek_sp_window_kernel(EkSpArgs p)
     }
     for (int i = t; i < (int)(sizeof(EkPamWin) / 4); i += SP_NT)
         ((uint32_t *)p.win)[i] = ((const uint32_t *)&s_win)[i];
+#ifdef EK_SP_PROF
+    if (t == 0 && p.prof)
+        for (int k = 0; k < 10; ++k)
+            p.prof[k] += sp_acc[k];
+#endif
 }
 
 size_t ek_sp_lds_bytes()
