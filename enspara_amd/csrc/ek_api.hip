@@ -2244,8 +2244,6 @@ static int ek_pam_window_sparse(ek_ctx *c, int32_t cid0, int32_t count,
     a.cid0 = cid0;
     a.count = count;
     a.win_count = win_count;
-    a.vecs = c->pam_vecs;
-    a.n_pad = c->n_pad;
     a.bucket = (const uint2 *)(c->sp_buf + o_bucket);
     a.bcnt = (const unsigned int *)(c->sp_buf + o_bcnt);
     a.bcap = (int64_t)cap;

@@ -19,8 +19,6 @@ struct EkSpArgs {
     int64_t n;
     double n_total;             // the means' divisor
     int32_t A, K, cid0, count, win_count;
-    const float *vecs;          // [slot][n_pad] distances to the proposals (by frame)
-    int64_t n_pad;
     const uint2 *bucket;        // [slot][bcap] the frames a slot looks at, with their
                                 //   distance to the slot's proposal
     const unsigned int *bcnt;
