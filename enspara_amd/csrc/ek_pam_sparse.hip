@@ -13,7 +13,7 @@
 //     the list allows for that);
 //   * the search of kmedoids.py:666 for the members the proposal is farther
 //     from, over the medoids within their reach (the window's tables, as in
-//     ek_pam_classify_window_kernel's last workgroup): 64 members x 16 medoids
+//     ek_pam_classify_window_kernel's last workgroup): 64 members x 8 medoids
 //     per step through LDS, every pair one lane's IEEE FMA chains in ascending
 //     atom order and ek_rmsd_from_S, as everywhere else;
 //   * the two cost sums in numpy's order (ek_pam.hip, "cost sums in numpy's
