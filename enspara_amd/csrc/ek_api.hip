@@ -2507,6 +2507,24 @@ static int ek_draw_at(const uint32_t *raw, int64_t n_raw, int64_t *pos, int64_t 
     }
 }
 
+// The draws above, exposed for tests that hold them against numpy itself (no
+// device involved): out[i] = RandomState.choice(m[i]) taken from `raw` at *pos on.
+// -> how many were made (fewer than count: the outputs ran out, or m[i] < 1)
+extern "C" int64_t ek_np_choice_draws(const uint32_t *raw, int64_t n_raw, int64_t *pos,
+                                      const int64_t *m, int64_t count, int64_t *out)
+{
+    if (!raw || !pos || !m || !out || *pos < 0)
+        return -1;
+    int64_t i = 0;
+    for (; i < count; ++i) {
+        if (m[i] < 1 || (uint64_t)m[i] > 0x100000000ull)
+            break;
+        if (ek_draw_at(raw, n_raw, pos, m[i], &out[i]))
+            break;
+    }
+    return i;
+}
+
 // The loop of kmedoids.py:575-699 over clusters *cid .. K - 1 in windows of up to
 // `width` proposals decided on the device (ek_pam_window_run), the cluster a
 // window stops at one proposal at a time -- what enspara_amd/cluster/kmedoids.py's

@@ -375,6 +375,13 @@ int ek_pam_window_run(ek_ctx *ctx, int32_t cid0, int32_t count,
  * new_cost / n_ambiguous [n_medoids] report every proposal.
  * *status: 0 done (*cid == n_medoids); 1 `raw` ran out -- call again with more
  * (everything returned so far stands); 2 cluster *cid is empty (choice raises). */
+/* ek_pam_sweep's draws alone (host only, for tests): out[i] =
+ * RandomState.choice(m[i]) -- 32-bit outputs masked to the bits of m - 1, values
+ * above it rejected, m == 1 consumes nothing -- taken from `raw` from *pos on.
+ * Returns how many draws were made: fewer than `count` if the outputs ran out or
+ * an m[i] is < 1; -1 on a NULL argument. */
+int64_t ek_np_choice_draws(const uint32_t *raw, int64_t n_raw, int64_t *pos,
+                           const int64_t *m, int64_t count, int64_t *out);
 int ek_pam_sweep(ek_ctx *ctx, int32_t n_medoids, int32_t width, const uint32_t *raw,
                  int64_t n_raw, int64_t *pos, const int64_t *proposals, int32_t *cid,
                  int64_t *medoids, int32_t *accept, double *old_cost,

@@ -166,3 +166,52 @@ def test_draw_stream_is_randomstate_choice():
     assert st.peek([5, 0, 7]) == st.peek([5])       # stops before an empty list
     with pytest.raises(ValueError):
         st.draw(0)
+
+
+def test_library_draws_are_randomstate_choice():
+    """The draws ek_pam_sweep makes inside the library (ek_np_choice_draws: the
+    same routine, host only) against numpy itself: RandomState.choice(m) for
+    list lengths from 1 to 2**32, the number of raw outputs consumed, a stream
+    that runs out in the middle of a rejection loop, an empty list."""
+    import ctypes as C
+    from enspara_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(7)
+    for trial in range(40):
+        seed = int(rng.integers(1 << 30))
+        ref = np.random.RandomState(seed)
+        raw = np.random.RandomState(seed).randint(0, 2 ** 32, size=4096, dtype=np.uint32)
+        ms = rng.integers(1, 10 ** int(rng.integers(1, 10)), size=int(rng.integers(1, 300)))
+        ms = np.ascontiguousarray(ms, dtype=np.int64)
+        if trial % 4 == 0:
+            ms[::7] = 1                         # consumes nothing
+        if trial % 9 == 0:
+            ms[-1] = 2 ** 32                    # the widest mask
+        out = np.zeros(len(ms), dtype=np.int64)
+        pos = C.c_int64(0)
+        made = lib.ek_np_choice_draws(raw.ctypes.data_as(C.POINTER(C.c_uint32)), len(raw),
+                                      C.byref(pos), _lib.i64p(ms), len(ms), _lib.i64p(out))
+        assert made == len(ms)
+        want = [int(ref.choice(int(m))) for m in ms]
+        assert [int(v) for v in out] == want
+        # the RandomState is where `pos` raw outputs would have left it
+        check = np.random.RandomState(seed)
+        if pos.value:
+            check.randint(0, 2 ** 32, size=pos.value, dtype=np.uint32)
+        assert int(check.randint(0, 10 ** 9)) == int(ref.randint(0, 10 ** 9))
+    # the outputs run out: nothing of the unfinished draw is consumed
+    raw = np.random.RandomState(3).randint(0, 2 ** 32, size=5, dtype=np.uint32)
+    ms = np.full(50, 3 * 10 ** 8, dtype=np.int64)
+    out = np.zeros(50, dtype=np.int64)
+    pos = C.c_int64(0)
+    made = lib.ek_np_choice_draws(raw.ctypes.data_as(C.POINTER(C.c_uint32)), len(raw),
+                                  C.byref(pos), _lib.i64p(ms), 50, _lib.i64p(out))
+    ref = np.random.RandomState(3)
+    assert 0 < made < 50 and pos.value <= 5
+    assert [int(v) for v in out[:made]] == [int(ref.choice(3 * 10 ** 8)) for _ in range(made)]
+    # an empty list ends the draws (RandomState.choice(0) raises)
+    ms = np.array([4, 0, 4], dtype=np.int64)
+    pos = C.c_int64(0)
+    raw = np.random.RandomState(1).randint(0, 2 ** 32, size=64, dtype=np.uint32)
+    assert lib.ek_np_choice_draws(raw.ctypes.data_as(C.POINTER(C.c_uint32)), 64, C.byref(pos),
+                                  _lib.i64p(ms), 3, _lib.i64p(out)) == 1
