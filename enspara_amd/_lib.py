@@ -48,7 +48,7 @@ SYMBOLS = [
     "ek_krylov_get_vector", "ek_krylov_step", "ek_krylov_rotate",
     "ek_krylov_combine", "ek_krylov_expand",
     "ek_feat_create", "ek_feat_destroy", "ek_feat_load", "ek_feat_distance",
-    "ek_feat_kcenters",
+    "ek_feat_kcenters", "ek_feat_pam_sweep", "ek_feat_pam_release",
     "ek_set_frames_per_lane", "ek_set_option", "ek_last_run_timing",
     "ek_timing_begin", "ek_timing_end", "ek_timing_form", "ek_hbm_copy_rate",
 ]
@@ -180,6 +180,10 @@ def load():
     L.ek_feat_destroy.argtypes = [vp]
     L.ek_feat_load.argtypes = [vp, vp, i64, i64]
     L.ek_feat_distance.argtypes = [vp, i32, vp, f64p]
+    L.ek_feat_pam_sweep.argtypes = [vp, i32, i32, i64p, i64p, C.POINTER(C.c_uint32), i64,
+                                    i64p, f64p, i32p, i32p, i32p, i32p]
+    L.ek_feat_pam_release.argtypes = [vp]
+    L.ek_feat_pam_release.restype = None
     L.ek_feat_kcenters.argtypes = [vp, i32, i32, i32, C.c_double, f64p, i32p, i64p,
                                    i32p, f64p]
     L.ek_set_frames_per_lane.argtypes = [vp, C.c_int]

@@ -452,6 +452,61 @@ def _msq(x):
     return np.square(x).mean()
 
 
+# 1: a sweep over 'euclidean' / 'manhattan' features runs with the distances, the
+# labels and the medoids resident on the device (ek_feat_pam_sweep); 0: the
+# reference-shaped loop below around a device metric.  Same results.
+PAM_FEATURE_DEVICE = 1
+
+
+def _feature_sweep_applies(X, metric, distances, proposals):
+    """A floating-point (or integer) sample matrix without NaN, a finite state,
+    one of the two resident metrics, the default cost."""
+    if getattr(metric, "device_metric_id", None) not in (0, 1):
+        return False
+    if not isinstance(X, np.ndarray) or X.ndim != 2 or X.shape[0] < 1:
+        return False
+    if not (np.issubdtype(X.dtype, np.floating) or np.issubdtype(X.dtype, np.integer)):
+        return False
+    if X.dtype.itemsize > 8 or not np.all(np.isfinite(distances)):
+        return False
+    if np.issubdtype(X.dtype, np.floating) and not np.all(np.isfinite(X)):
+        return False
+    return True
+
+
+def _feature_sweep_device(X, metric, medoid_inds, assignments, distances, proposals,
+                          random_state):
+    """reference kmedoids.py:575-699 (serial branch) on the device; the random
+    stream is the caller's: numpy's choice() restated on its raw outputs."""
+    from ..geometry import libdist
+    bound = metric.bind(X)
+    K = len(medoid_inds)
+    med = np.ascontiguousarray(medoid_inds, dtype=np.int64).copy()
+    d = np.ascontiguousarray(distances, dtype=np.float64).copy()
+    a = np.ascontiguousarray(assignments, dtype=np.int32).copy()
+    accept = np.zeros(K, dtype=np.int32)
+    stream = _DrawStream(random_state)
+    try:
+        cid = 0
+        while True:
+            if proposals is None:
+                stream._need(stream.pos + 4 * (K - cid) + 64)
+            status, cid, stream.pos = bound.res.pam_sweep(
+                bound.metric, med, proposals, stream.raw, stream.pos, d, a, accept, cid)
+            if status == 0:
+                break
+            if status == 2:
+                stream.draw(0)          # raises what RandomState.choice([]) raises
+            stream._need(len(stream.raw) + stream.BLOCK)
+    finally:
+        stream.close()
+    for c in range(K):
+        if accept[c]:
+            medoid_inds[c] = int(med[c])        # (in place, like the loop below)
+    return (medoid_inds, d.astype(np.asarray(distances).dtype),
+            a.astype(np.asarray(assignments).dtype), [X[i] for i in medoid_inds])
+
+
 def _kmedoids_pam_update(X, metric, medoid_inds, assignments, distances,
                          proposals=None, cost=_msq, random_state=None):
     """One PAM sweep for a callable metric (reference kmedoids.py:520-699,
@@ -471,6 +526,10 @@ def _kmedoids_pam_update(X, metric, medoid_inds, assignments, distances,
 
     random_state = check_random_state(random_state)
     _check_proposals(proposals, medoid_inds)
+    if (PAM_FEATURE_DEVICE and cost is _msq and
+            _feature_sweep_applies(X, metric, distances, proposals)):
+        return _feature_sweep_device(X, metric, medoid_inds, assignments, distances,
+                                     proposals, random_state)
     if hasattr(metric, "bind"):              # device metric: upload X once
         metric = metric.bind(X)
     medoid_coords = [X[i] for i in medoid_inds]

@@ -174,10 +174,13 @@ feat_distance_kernel(const T *__restrict__ tiles, const T *__restrict__ y,
 }
 
 // ---- C ABI ----------------------------------------------------------------------
+extern "C" void ek_feat_pam_release(ek_feat *k);
+
 extern "C" int ek_feat_destroy(ek_feat *k)
 {
     if (!k)
         return EK_OK;
+    ek_feat_pam_release(k);
     (void)hipSetDevice(k->device);
     if (k->s)
         (void)hipStreamSynchronize(k->s);
@@ -605,5 +608,468 @@ extern "C" int ek_feat_kcenters(ek_feat *k, int32_t metric, int32_t first_label,
                               hipMemcpyDeviceToHost, k->s));
         FE_HIP(hipStreamSynchronize(k->s));
     }
+    return EK_OK;
+}
+
+// ===========================================================================
+// PAM (k-medoids) sweep in feature space, resident on the device
+// ===========================================================================
+// Reference: enspara/cluster/kmedoids.py:575-699 (_kmedoids_pam_update, serial
+// branch) for metrics 'euclidean' / 'manhattan' (libdist.pyx): per cluster
+//   state_inds = where(assignments == cid); prop = choice(state_inds)      :611, :514
+//   nd = metric(X, X[prop])                                                :637
+//   distances > nd            -> (nd, cid)                                 :644
+//   else assignments != cid   -> unchanged                                 :651
+//   else                      -> assign_to_nearest_center(X[those], medoids
+//                                with the proposal in place of medoid cid)  :658-666
+//   accept iff mean(new**2) < mean(old**2), float64, numpy's summation     :478, :683
+// -- a metric call, the read-back of n float64 and a dozen numpy passes over n
+// per proposal when only the metric runs on the device.  Here the float64
+// distances, the labels and the medoids' features stay in HBM; the host keeps
+// the random stream (numpy's draws on raw outputs, ek_np_choice_draws) and the
+// accept / reject decision: two waits per proposal.  Distances are computed with
+// the arithmetic of feat_distance_kernel (FeatAcc, features in order) whatever
+// the pairing of sample and medoid, so every number is the one the reference's
+// loop -- metric(X[subset], center) per center, strict < in ascending center
+// order (util.py:199-203) -- produces.
+#include "ek_pw.h"
+
+extern "C" int64_t ek_np_choice_draws(const uint32_t *raw, int64_t n_raw, int64_t *pos,
+                                      const int64_t *m, int64_t count, int64_t *out);
+
+struct FeatPam {
+    int32_t K = 0, Kcap = 0;
+    void *MT = nullptr;         // medoids' features, transposed: [F][Kcap] elements
+    void *col = nullptr;        // [F] the column a proposal displaced
+    int64_t *med = nullptr;     // [Kcap] the medoids' samples (for the table)
+    int64_t *idx = nullptr;     // [1] the proposed sample (device)
+    double *ndist = nullptr;    // trial state
+    int32_t *nassign = nullptr;
+    uint32_t *amb = nullptr;    // ambiguous members
+    double *best_d = nullptr;
+    int32_t *best_c = nullptr;
+    unsigned int *counters = nullptr;   // [0] ambiguous members
+    int32_t *blockcnt = nullptr;
+    int64_t *scan = nullptr, *total = nullptr;
+    double *part = nullptr;     // leaf sums + chunk sums (both columns)
+    double *out2 = nullptr;
+    EkPwShape *shapes = nullptr;
+    int n_full = 0, n_leaves = 0, n_chunks = 0;
+};
+
+// one FeatPam per ek_feat, kept in a side table (ek_feat itself stays as it is)
+#include <map>
+static std::map<ek_feat *, FeatPam> g_feat_pam;
+
+extern "C" void ek_feat_pam_release(ek_feat *k)
+{
+    auto it = g_feat_pam.find(k);
+    if (it == g_feat_pam.end())
+        return;
+    FeatPam &p = it->second;
+    (void)hipFree(p.MT);
+    (void)hipFree(p.col);
+    (void)hipFree(p.med);
+    (void)hipFree(p.idx);
+    (void)hipFree(p.ndist);
+    (void)hipFree(p.nassign);
+    (void)hipFree(p.amb);
+    (void)hipFree(p.best_d);
+    (void)hipFree(p.best_c);
+    (void)hipFree(p.counters);
+    (void)hipFree(p.blockcnt);
+    (void)hipFree(p.scan);
+    (void)hipFree(p.total);
+    (void)hipFree(p.part);
+    (void)hipFree(p.out2);
+    (void)hipFree(p.shapes);
+    g_feat_pam.erase(it);
+}
+
+// MT[j][c] = feature j of sample med[c]
+template <typename T>
+__global__ void __launch_bounds__(EK_BLOCK)
+feat_medoid_table_kernel(const T *__restrict__ tiles, int F,
+                         const int64_t *__restrict__ med, int K, int Kcap,
+                         T *__restrict__ MT)
+{
+    const int c = blockIdx.x;
+    const int64_t f = med[c];
+    const T *p = tiles + (size_t)(f / EK_TILE) * (size_t)F * EK_TILE + (f % EK_TILE);
+    for (int j = threadIdx.x; j < F; j += EK_BLOCK)
+        MT[(size_t)j * Kcap + c] = p[(size_t)j * EK_TILE];
+}
+
+// y = features of sample *idx; column cid of MT is saved in `col` and replaced by y
+template <typename T>
+__global__ void __launch_bounds__(EK_BLOCK)
+feat_propose_kernel(const T *__restrict__ tiles, int F, const int64_t *__restrict__ idx,
+                    int cid, int Kcap, T *__restrict__ MT, T *__restrict__ col,
+                    T *__restrict__ y, unsigned int *__restrict__ counters)
+{
+    const int64_t f = idx[0];
+    const T *p = tiles + (size_t)(f / EK_TILE) * (size_t)F * EK_TILE + (f % EK_TILE);
+    for (int j = threadIdx.x; j < F; j += EK_BLOCK) {
+        const T v = p[(size_t)j * EK_TILE];
+        col[j] = MT[(size_t)j * Kcap + cid];
+        MT[(size_t)j * Kcap + cid] = v;
+        y[j] = v;
+    }
+    if (threadIdx.x == 0)
+        counters[0] = 0;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(EK_BLOCK)
+feat_restore_kernel(int F, int cid, int Kcap, T *__restrict__ MT,
+                    const T *__restrict__ col)
+{
+    for (int j = threadIdx.x; j < F; j += EK_BLOCK)
+        MT[(size_t)j * Kcap + cid] = col[j];
+}
+
+// kmedoids.py:644-658 on float64 distances
+__global__ void __launch_bounds__(EK_BLOCK)
+feat_pam_classify_kernel(const double *__restrict__ dist,
+                         const int32_t *__restrict__ assign,
+                         const double *__restrict__ nd, int64_t n, int32_t cid,
+                         double *__restrict__ ndist, int32_t *__restrict__ nassign,
+                         uint32_t *__restrict__ amb, unsigned int *__restrict__ counters)
+{
+    const int64_t f = (int64_t)blockIdx.x * EK_BLOCK + threadIdx.x;
+    if (f >= n)
+        return;
+    const double d = dist[f], x = nd[f];
+    const int32_t a = assign[f];
+    if (d > x) {
+        ndist[f] = x;
+        nassign[f] = cid;
+    } else if (a != cid) {
+        ndist[f] = d;
+        nassign[f] = a;
+    } else {
+        amb[atomicAdd(&counters[0], 1u)] = (uint32_t)f;
+    }
+}
+
+// One workgroup per ambiguous member: threads stride the medoids in ascending
+// order, every (member, medoid) distance is one thread's FeatAcc chain over the
+// features in order; the workgroup keeps the smallest distance, the lowest medoid
+// index among equal ones -- util.py:199-203's strict-< scan from +inf.
+template <typename T, int METRIC>
+__global__ void __launch_bounds__(EK_BLOCK)
+feat_pam_nearest_kernel(const T *__restrict__ tiles, int F,
+                        const uint32_t *__restrict__ amb,
+                        const unsigned int *__restrict__ counters,
+                        const T *__restrict__ MT, int K, int Kcap,
+                        double *__restrict__ ndist, int32_t *__restrict__ nassign)
+{
+    __shared__ T xs[FY_CHUNK];
+    __shared__ double rv[EK_BLOCK / EK_WAVE];
+    __shared__ int32_t rc[EK_BLOCK / EK_WAVE];
+    if (blockIdx.x >= counters[0])
+        return;
+    const uint32_t f = amb[blockIdx.x];
+    const T *p = tiles + (size_t)(f / EK_TILE) * (size_t)F * EK_TILE + (f % EK_TILE);
+    double best = __builtin_inf();
+    int32_t bc = 0x7fffffff;
+    for (int c0 = 0; c0 < K; c0 += EK_BLOCK) {
+        const int c = c0 + threadIdx.x;
+        double acc = 0.0;
+        for (int j0 = 0; j0 < F; j0 += FY_CHUNK) {
+            const int w = (F - j0 < FY_CHUNK) ? (F - j0) : FY_CHUNK;
+            __syncthreads();
+            for (int j = threadIdx.x; j < w; j += EK_BLOCK)
+                xs[j] = p[(size_t)(j0 + j) * EK_TILE];
+            __syncthreads();
+            if (c < K)
+                for (int j = 0; j < w; ++j)
+                    FeatAcc<T, METRIC>::add(acc, xs[j], MT[(size_t)(j0 + j) * Kcap + c]);
+        }
+        if (c < K) {
+            if (METRIC == 0)
+                acc = __builtin_sqrt(acc);
+            if (acc < best) {               // ascending c per thread: strict <
+                best = acc;
+                bc = c;
+            }
+        }
+    }
+    // the smallest distance, the lowest index among equal ones
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double ov = __shfl_xor(best, off, 64);
+        const int32_t oc = __shfl_xor(bc, off, 64);
+        if (ov < best || (ov == best && oc < bc)) {
+            best = ov;
+            bc = oc;
+        }
+    }
+    if ((threadIdx.x & (EK_WAVE - 1)) == 0) {
+        rv[threadIdx.x / EK_WAVE] = best;
+        rc[threadIdx.x / EK_WAVE] = bc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < EK_BLOCK / EK_WAVE; ++w)
+            if (rv[w] < best || (rv[w] == best && rc[w] < bc)) {
+                best = rv[w];
+                bc = rc[w];
+            }
+        ndist[f] = best;
+        nassign[f] = bc;
+    }
+}
+
+// numpy's leaf (ek_pam.hip, "cost sums in numpy's order") over the squares of
+// float64 values: np.square(x) rounds each square, then the pairwise sum
+__global__ void __launch_bounds__(EK_BLOCK)
+feat_pw_leaf_kernel(const double *__restrict__ a, const double *__restrict__ b,
+                    const EkPwShape *__restrict__ shapes, int n_full,
+                    int n_leaves_total, double *__restrict__ leafsum)
+{
+    const int g = blockIdx.x * (EK_BLOCK / 8) + threadIdx.x / 8;
+    const int l8 = threadIdx.x & 7;
+    if (g >= n_leaves_total)
+        return;                     // (whole groups of eight lanes)
+    const EkPwShape *sh = &shapes[0];
+    int chunk = g / EK_PW_FULL_LEAVES, leaf = g % EK_PW_FULL_LEAVES;
+    if (chunk >= n_full) {
+        chunk = n_full;
+        leaf = g - n_full * EK_PW_FULL_LEAVES;
+        sh = &shapes[1];
+    }
+    const int64_t off = (int64_t)chunk * EK_PW_CHUNK + sh->leaf_off[leaf];
+    const int len = sh->leaf_len[leaf];
+    double ra = 0.0, rb = 0.0;
+    const int body = (len < 8) ? 0 : len - (len % 8);
+    for (int i = 0; i < body; i += 8) {
+        const double va = a[off + i + l8], vb = b[off + i + l8];
+        if (i == 0) {
+            ra = va * va;
+            rb = vb * vb;
+        } else {
+            ra = ra + va * va;
+            rb = rb + vb * vb;
+        }
+    }
+    if (body > 0) {
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {       // (r0+r1)+(r2+r3) ...
+            ra = ra + __shfl_xor(ra, o, 8);
+            rb = rb + __shfl_xor(rb, o, 8);
+        }
+    }
+    if (l8 == 0) {
+        for (int i = body; i < len; ++i) {      // sequential tail
+            const double va = a[off + i], vb = b[off + i];
+            ra = ra + va * va;
+            rb = rb + vb * vb;
+        }
+        leafsum[2 * (size_t)g + 0] = ra;
+        leafsum[2 * (size_t)g + 1] = rb;
+    }
+}
+
+static int feat_pam_alloc(ek_feat *k, FeatPam &p, int32_t K)
+{
+    const size_t n = (size_t)std::max<int64_t>(k->n, 1);
+    const size_t nb = (n + EK_BLOCK - 1) / EK_BLOCK;
+    if (!p.ndist) {
+        FE_HIP(hipMalloc((void **)&p.ndist, n * sizeof(double)));
+        FE_HIP(hipMalloc((void **)&p.nassign, n * sizeof(int32_t)));
+        FE_HIP(hipMalloc((void **)&p.amb, n * sizeof(uint32_t)));
+        FE_HIP(hipMalloc((void **)&p.counters, 4 * sizeof(unsigned int)));
+        FE_HIP(hipMalloc((void **)&p.blockcnt, nb * sizeof(int32_t)));
+        FE_HIP(hipMalloc((void **)&p.scan, nb * sizeof(int64_t)));
+        FE_HIP(hipMalloc((void **)&p.total, sizeof(int64_t)));
+        FE_HIP(hipMalloc((void **)&p.idx, sizeof(int64_t)));
+        FE_HIP(hipMalloc((void **)&p.col, (size_t)k->F * k->esize));
+        FE_HIP(hipMalloc((void **)&p.out2, 2 * sizeof(double)));
+        EkPwShape hs[2];
+        const int64_t n_full = k->n / EK_PW_CHUNK;
+        const int last_len = (int)(k->n - n_full * EK_PW_CHUNK);
+        ek_pw_build_shape(n_full > 0 ? EK_PW_CHUNK : 0, &hs[0]);
+        ek_pw_build_shape(last_len, &hs[1]);
+        p.n_full = (int)n_full;
+        p.n_leaves = (int)n_full * EK_PW_FULL_LEAVES + hs[1].n_leaves;
+        p.n_chunks = (int)n_full + (last_len > 0 ? 1 : 0);
+        if (n_full > 0 && hs[0].n_leaves != EK_PW_FULL_LEAVES)
+            return ek_set_error(EK_ESTATE, "ek_feat_pam_sweep: unexpected shape of a "
+                                           "full chunk's pairwise sum");
+        FE_HIP(hipMalloc((void **)&p.shapes, sizeof(hs)));
+        FE_HIP(hipMemcpy(p.shapes, hs, sizeof(hs), hipMemcpyHostToDevice));
+        FE_HIP(hipMalloc((void **)&p.part, (2 * (size_t)std::max(p.n_leaves, 1) +
+                                            2 * (size_t)std::max(p.n_chunks, 1)) *
+                                               sizeof(double)));
+    }
+    if (K > p.Kcap) {
+        FE_HIP(hipStreamSynchronize(k->s));
+        (void)hipFree(p.MT);
+        (void)hipFree(p.med);
+        p.MT = nullptr;
+        p.med = nullptr;
+        p.Kcap = 0;
+        FE_HIP(hipMalloc((void **)&p.MT, (size_t)k->F * K * k->esize));
+        FE_HIP(hipMalloc((void **)&p.med, (size_t)K * sizeof(int64_t)));
+        p.Kcap = K;
+    }
+    p.K = K;
+    return EK_OK;
+}
+
+// One sweep over clusters *cid .. n_medoids - 1 (kmedoids.py:575-699) from the
+// state (dist_io float64, assign_io int32) -- uploaded when *cid == 0, written
+// back when the sweep is through.  proposals == NULL: numpy's draws on `raw`
+// (ek_np_choice_draws), *pos outputs consumed.  medoids[c] is replaced and
+// accept[c] set where proposal c was accepted.
+// *status: 0 done; 1 `raw` ran out at cluster *cid (call again with more: the
+// state stays on the device); 2 cluster *cid has no member (choice raises).
+extern "C" int ek_feat_pam_sweep(ek_feat *k, int32_t metric, int32_t n_medoids,
+                                 int64_t *medoids, const int64_t *proposals,
+                                 const uint32_t *raw, int64_t n_raw, int64_t *pos,
+                                 double *dist_io, int32_t *assign_io,
+                                 int32_t *accept, int32_t *cid_io, int32_t *status)
+{
+    if (!k || !medoids || !dist_io || !assign_io || !accept || !cid_io || !status ||
+        !pos || n_medoids < 1 || metric < 0 || metric > 1)
+        return ek_set_error(EK_EARG, "ek_feat_pam_sweep: bad argument (metrics: "
+                                     "euclidean 0, manhattan 1)");
+    if (!k->loaded || k->kind == 2)
+        return ek_set_error(EK_ESTATE, "ek_feat_pam_sweep: floating-point samples "
+                                       "have to be loaded");
+    if (k->n < 1 || k->n > 0xffffffffLL)
+        return ek_set_error(EK_EARG, "ek_feat_pam_sweep: %lld samples",
+                            (long long)k->n);
+    const int32_t K = n_medoids;
+    for (int32_t c = 0; c < K; ++c)
+        if (medoids[c] < 0 || medoids[c] >= k->n ||
+            (proposals && (proposals[c] < 0 || proposals[c] >= k->n)))
+            return ek_set_error(EK_EARG, "ek_feat_pam_sweep: medoid or proposal %d "
+                                         "out of range", c);
+    FE_HIP(hipSetDevice(k->device));
+    FeatPam &p = g_feat_pam[k];
+    int rc = feat_pam_alloc(k, p, K);
+    if (rc)
+        return rc;
+    const int nb = (int)((k->n + EK_BLOCK - 1) / EK_BLOCK);
+    if (!k->kdist) {
+        FE_HIP(hipMalloc((void **)&k->kdist, (size_t)k->n * sizeof(double)));
+        FE_HIP(hipMalloc((void **)&k->kassign, (size_t)k->n * sizeof(int32_t)));
+        FE_HIP(hipMalloc((void **)&k->bm, (size_t)nb * sizeof(FeatBlockMax)));
+        FE_HIP(hipMalloc((void **)&k->ctl, sizeof(FeatCtl)));
+    }
+    *status = 0;
+    int32_t cid = *cid_io;
+    if (cid == 0) {
+        FE_HIP(hipMemcpyAsync(k->kdist, dist_io, (size_t)k->n * sizeof(double),
+                              hipMemcpyHostToDevice, k->s));
+        FE_HIP(hipMemcpyAsync(k->kassign, assign_io, (size_t)k->n * sizeof(int32_t),
+                              hipMemcpyHostToDevice, k->s));
+        // the medoids' features
+        FE_HIP(hipMemcpyAsync(p.med, medoids, (size_t)K * sizeof(int64_t),
+                              hipMemcpyHostToDevice, k->s));
+        if (k->kind == 0)
+            hipLaunchKernelGGL(feat_medoid_table_kernel<float>, dim3(K), dim3(EK_BLOCK),
+                               0, k->s, (const float *)k->tiles, k->F, p.med, K,
+                               p.Kcap, (float *)p.MT);
+        else
+            hipLaunchKernelGGL(feat_medoid_table_kernel<double>, dim3(K),
+                               dim3(EK_BLOCK), 0, k->s, (const double *)k->tiles, k->F,
+                               p.med, K, p.Kcap, (double *)p.MT);
+        FE_HIP(hipGetLastError());
+        FE_HIP(hipStreamSynchronize(k->s));
+    }
+    const unsigned blocks = (unsigned)nb;
+    for (; cid < K; ++cid) {
+        // ---- the proposal: a member drawn like choice(state_inds), or given ----------
+        ek_launch_count_members(k->kassign, k->n, cid, p.blockcnt, p.scan, p.total, k->s);
+        int64_t m = 0;
+        FE_HIP(hipMemcpyAsync(&m, p.total, sizeof(int64_t), hipMemcpyDeviceToHost, k->s));
+        FE_HIP(hipStreamSynchronize(k->s));
+        if (!proposals) {
+            if (m <= 0) {
+                *cid_io = cid;
+                *status = 2;
+                return EK_OK;
+            }
+            int64_t j = 0;
+            if (ek_np_choice_draws(raw, n_raw, pos, &m, 1, &j) != 1) {
+                *cid_io = cid;
+                *status = 1;
+                return EK_OK;
+            }
+            ek_launch_select_member(k->kassign, k->n, cid, p.scan, j, p.idx, k->s);
+        } else {
+            FE_HIP(hipMemcpyAsync(p.idx, &proposals[cid], sizeof(int64_t),
+                                  hipMemcpyHostToDevice, k->s));
+        }
+#define FP_T(T, M)                                                             \
+    do {                                                                       \
+        hipLaunchKernelGGL((feat_propose_kernel<T>), dim3(1), dim3(EK_BLOCK), 0, k->s, \
+                           (const T *)k->tiles, k->F, p.idx, cid, p.Kcap,      \
+                           (T *)p.MT, (T *)p.col, (T *)k->y, p.counters);      \
+        hipLaunchKernelGGL((feat_distance_kernel<T, M>), dim3(blocks),         \
+                           dim3(EK_BLOCK), 0, k->s, (const T *)k->tiles,       \
+                           (const T *)k->y, k->n, k->F, k->out);               \
+        hipLaunchKernelGGL(feat_pam_classify_kernel, dim3(blocks), dim3(EK_BLOCK), 0, \
+                           k->s, k->kdist, k->kassign, k->out, k->n, cid, p.ndist, \
+                           p.nassign, p.amb, p.counters);                      \
+        if (m > 0)                                                             \
+            hipLaunchKernelGGL((feat_pam_nearest_kernel<T, M>), dim3((unsigned)m), \
+                               dim3(EK_BLOCK), 0, k->s, (const T *)k->tiles, k->F, \
+                               p.amb, p.counters, (const T *)p.MT, K, p.Kcap,  \
+                               p.ndist, p.nassign);                            \
+    } while (0)
+        if (k->kind == 0) {
+            if (metric == 0)
+                FP_T(float, 0);
+            else
+                FP_T(float, 1);
+        } else {
+            if (metric == 0)
+                FP_T(double, 0);
+            else
+                FP_T(double, 1);
+        }
+#undef FP_T
+        // ---- cost of the state and of the trial state, numpy's order ------------------
+        const int per = EK_BLOCK / 8;
+        hipLaunchKernelGGL(feat_pw_leaf_kernel, dim3((p.n_leaves + per - 1) / per),
+                           dim3(EK_BLOCK), 0, k->s, k->kdist, p.ndist, p.shapes, p.n_full,
+                           p.n_leaves, p.part);
+        ek_launch_pw_chunks_total(p.part, p.shapes, p.n_full, p.n_leaves, p.n_chunks,
+                                  p.out2, k->s);
+        FE_HIP(hipGetLastError());
+        double sums[2] = {0.0, 0.0};
+        int64_t prop = -1;
+        FE_HIP(hipMemcpyAsync(sums, p.out2, sizeof(sums), hipMemcpyDeviceToHost, k->s));
+        FE_HIP(hipMemcpyAsync(&prop, p.idx, sizeof(int64_t), hipMemcpyDeviceToHost, k->s));
+        FE_HIP(hipStreamSynchronize(k->s));
+        // np.square(x).mean(): the pairwise sum divided by n (kmedoids.py:478-479)
+        const double old_cost = sums[0] / (double)k->n, new_cost = sums[1] / (double)k->n;
+        const bool acc = new_cost < old_cost;               // :683
+        accept[cid] = acc ? 1 : 0;
+        if (acc) {
+            std::swap(k->kdist, p.ndist);
+            std::swap(k->kassign, p.nassign);
+            medoids[cid] = prop;
+        } else {
+            if (k->kind == 0)
+                hipLaunchKernelGGL(feat_restore_kernel<float>, dim3(1), dim3(EK_BLOCK), 0,
+                                   k->s, k->F, cid, p.Kcap, (float *)p.MT,
+                                   (const float *)p.col);
+            else
+                hipLaunchKernelGGL(feat_restore_kernel<double>, dim3(1), dim3(EK_BLOCK),
+                                   0, k->s, k->F, cid, p.Kcap, (double *)p.MT,
+                                   (const double *)p.col);
+        }
+    }
+    FE_HIP(hipMemcpyAsync(dist_io, k->kdist, (size_t)k->n * sizeof(double),
+                          hipMemcpyDeviceToHost, k->s));
+    FE_HIP(hipMemcpyAsync(assign_io, k->kassign, (size_t)k->n * sizeof(int32_t),
+                          hipMemcpyDeviceToHost, k->s));
+    FE_HIP(hipStreamSynchronize(k->s));
+    *cid_io = K;
     return EK_OK;
 }

@@ -1510,6 +1510,33 @@ void ek_launch_pw_tree(const float *dist, const int32_t *assign, int64_t n,
                        shapes, n_full, part + 2 * (size_t)n_leaves_total);
 }
 
+// chunk sums of both columns of `part` ([2 g + 0 / 1] leaf sums) and the totals,
+// chunks added left to right -> out2[0], out2[1]  (ek_features.hip: PAM over
+// float64 distances brings its own leaf kernel)
+__global__ void __launch_bounds__(EK_WAVE)
+ek_pw_total_kernel(const double *__restrict__ chunksum, int n_chunks,
+                   double *__restrict__ out2)
+{
+    if (threadIdx.x >= 2)
+        return;
+    double s = 0.0;
+    for (int c = 0; c < n_chunks; ++c)
+        s = s + chunksum[2 * (size_t)c + threadIdx.x];
+    out2[threadIdx.x] = s;
+}
+
+void ek_launch_pw_chunks_total(double *part, const EkPwShape *shapes, int n_full,
+                               int n_leaves_total, int n_chunks, double *out2,
+                               hipStream_t s)
+{
+    double *chunksum = part + 2 * (size_t)n_leaves_total;
+    if (n_leaves_total > 0)
+        hipLaunchKernelGGL(ek_pw_chunk_kernel, dim3(n_chunks), dim3(128), 0, s, part,
+                           shapes, n_full, chunksum);
+    hipLaunchKernelGGL(ek_pw_total_kernel, dim3(1), dim3(EK_WAVE), 0, s, chunksum,
+                       n_chunks, out2);
+}
+
 // host: the pairwise tree of a chunk of `len` elements (len <= EK_PW_CHUNK)
 static int ek_pw_rec(int off, int len, EkPwShape *sh, int *node_level,
                      int *tmp_l, int *tmp_r, int *n_tmp)

@@ -74,6 +74,25 @@ class _Resident:
             C.byref(fmax)))
         return centers[:k.value].copy(), fmax.value
 
+    def pam_sweep(self, metric, medoids, proposals, raw, pos, dist, assign, accept,
+                  cid):
+        """ek_feat_pam_sweep on this matrix from cluster `cid` on; medoids
+        (int64), dist (float64), assign (int32) and accept (int32) are updated
+        in place.  -> (status, cid, pos)"""
+        p = C.c_int64(int(pos))
+        c = C.c_int32(int(cid))
+        st = C.c_int32(0)
+        props = None
+        if proposals is not None:
+            props = np.ascontiguousarray(proposals, dtype=np.int64)
+        _lib.check(self.L.ek_feat_pam_sweep(
+            self._h, int(metric), len(medoids), _lib.i64p(medoids),
+            _lib.i64p(props) if props is not None else None,
+            raw.ctypes.data_as(C.POINTER(C.c_uint32)), len(raw), C.byref(p),
+            _lib.f64p(dist), _lib.i32p(assign), _lib.i32p(accept), C.byref(c),
+            C.byref(st)))
+        return st.value, c.value, p.value
+
     def __del__(self):
         try:
             if self._h:

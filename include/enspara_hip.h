@@ -517,6 +517,26 @@ int ek_feat_kcenters(ek_feat *k, int32_t metric, int32_t first_label,
                      int32_t max_new, double dist_cutoff, double *dist_io,
                      int32_t *assign_io, int64_t *centers_out, int32_t *n_added,
                      double *final_max);
+/* One PAM sweep (reference kmedoids.py:575-699, serial branch) over clusters
+ * *cid .. n_medoids - 1 for metric 0 (euclidean) / 1 (manhattan), with the
+ * float64 distances, the labels and the medoids' features resident on the device:
+ * per proposal the member count, the draw, the distance of every sample to the
+ * proposal, the three masks (:644-658), the ambiguous members against all
+ * medoids (strict <, ascending medoid index: util.py:199-203), and both costs
+ * mean(d**2) in float64 with numpy's pairwise summation (:478-479); the host
+ * compares them (:683).  dist_io (float64) / assign_io (int32) are the state:
+ * uploaded when *cid == 0, written back when the sweep is through.  proposals ==
+ * NULL: proposals are drawn like RandomState.choice(state_inds) from `raw`, the
+ * next 32-bit outputs of the caller's RandomState (*pos: outputs consumed).
+ * medoids[c] is replaced and accept[c] = 1 where proposal c was accepted.
+ * *status: 0 done; 1 `raw` ran out at cluster *cid (call again with more; the
+ * state stays on the device); 2 cluster *cid has no member (choice raises). */
+int ek_feat_pam_sweep(ek_feat *k, int32_t metric, int32_t n_medoids, int64_t *medoids,
+                      const int64_t *proposals, const uint32_t *raw, int64_t n_raw,
+                      int64_t *pos, double *dist_io, int32_t *assign_io,
+                      int32_t *accept, int32_t *cid, int32_t *status);
+/* frees what ek_feat_pam_sweep keeps between calls (ek_feat_destroy does it too) */
+void ek_feat_pam_release(ek_feat *k);
 
 /* ---- tuning knobs (benchmarks only) -------------------------------------- */
 /* frames per lane of the distance kernel: 1, 2 or 4; 0 = choose from the

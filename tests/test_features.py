@@ -138,6 +138,76 @@ def test_resident_feature_kcenters_equals_the_host_loop():
 
 
 @pytest.mark.gpu
+def test_resident_feature_pam_equals_the_host_loop():
+    """A PAM sweep over 'euclidean' / 'manhattan' features runs with distances,
+    labels and medoids resident on the device (ek_feat_pam_sweep,
+    kmedoids.PAM_FEATURE_DEVICE); with the switch off, the reference-shaped loop
+    (kmedoids.py:575-699) around the device metric.  Same medoids, labels and
+    float64 distances, and the caller's RandomState left in the same place --
+    float32, float64 and integer features (exact ties in distances and in
+    costs), random and explicit proposals, two sweeps, a last chunk of its own
+    shape in the cost sums, more features than one LDS chunk."""
+    from enspara_amd.cluster import kmedoids as km
+    from enspara_amd.cluster.kcenters import kcenters
+    rng = np.random.RandomState(11)
+    cases = [
+        (rng.normal(size=(3001, 17)).astype(np.float32), 40),
+        (rng.normal(size=(4000, 9)), 25),
+        (rng.randint(0, 4, size=(1500, 6)).astype(np.int64), 70),
+        (rng.randint(0, 3, size=(400, 3)).astype(np.float32), 20),
+        (rng.normal(size=(700, 2100)).astype(np.float32), 12),
+        (rng.normal(size=(8200, 5)).astype(np.float32), 60),
+    ]
+    moved = 0
+    for X, K in cases:
+        for name in ("euclidean", "manhattan"):
+            r = kcenters(X, name, n_clusters=K)
+            for explicit in (False, True):
+                props = None
+                if explicit:
+                    props = [int(v) for v in rng.randint(0, len(X), size=K)]
+                out = {}
+                old = km.PAM_FEATURE_DEVICE
+                try:
+                    for dev in (1, 0):
+                        km.PAM_FEATURE_DEVICE = dev
+                        rs = np.random.RandomState(4)
+                        inds = [int(i) for i in r.center_indices]
+                        d, a = r.distances.copy(), r.assignments.copy()
+                        for _ in range(2):
+                            inds, d, a, ctrs = km._kmedoids_pam_update(
+                                X, name, inds, a, d, proposals=props, random_state=rs)
+                        out[dev] = (list(inds), d, a, ctrs, rs.randint(1 << 30, size=3))
+                finally:
+                    km.PAM_FEATURE_DEVICE = old
+                assert out[1][0] == out[0][0], (name, X.shape, explicit)
+                np.testing.assert_array_equal(out[1][1], out[0][1])
+                np.testing.assert_array_equal(out[1][2], out[0][2])
+                assert out[1][1].dtype == out[0][1].dtype
+                assert out[1][2].dtype == out[0][2].dtype
+                for x, y in zip(out[1][3], out[0][3]):
+                    np.testing.assert_array_equal(x, y)
+                np.testing.assert_array_equal(out[1][4], out[0][4])
+                moved += out[1][0] != [int(i) for i in r.center_indices]
+    assert moved >= 12          # (most sweeps accept proposals)
+    # an empty cluster: choice([]) raises in both
+    X = rng.normal(size=(500, 4)).astype(np.float32)
+    r = kcenters(X, "euclidean", n_clusters=10)
+    a = r.assignments.copy()
+    a[a == 0] = 3
+    for dev in (1, 0):
+        old = km.PAM_FEATURE_DEVICE
+        km.PAM_FEATURE_DEVICE = dev
+        try:
+            with pytest.raises(ValueError):
+                km._kmedoids_pam_update(X, "euclidean", [int(i) for i in r.center_indices],
+                                        a.copy(), r.distances.copy(),
+                                        random_state=np.random.RandomState(1))
+        finally:
+            km.PAM_FEATURE_DEVICE = old
+
+
+@pytest.mark.gpu
 def test_nan_features_keep_the_reference_loop():
     """np.argmax / .max() treat a NaN distance as the maximum and the
     reference's loop (kcenters.py:217, :282) stops on it; the device arg-max

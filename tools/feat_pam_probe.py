@@ -1,0 +1,34 @@
+"""A PAM sweep in feature space: resident on the device (ek_feat_pam_sweep) against
+the reference-shaped host loop around the device metric (measurement only).
+
+  feat_pam_probe.py [n] [features] [medoids]
+"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+from enspara_amd.cluster import kmedoids as km
+from enspara_amd.cluster.kcenters import kcenters
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
+F = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+K = int(sys.argv[3]) if len(sys.argv) > 3 else 400
+X = np.random.RandomState(0).normal(size=(n, F)).astype(np.float32)
+r = kcenters(X, "euclidean", n_clusters=K)
+out = {}
+for dev in (1, 0):
+    km.PAM_FEATURE_DEVICE = dev
+    inds = [int(i) for i in r.center_indices]
+    t = time.perf_counter()
+    inds, d, a, _ = km._kmedoids_pam_update(X, "euclidean", inds, r.assignments.copy(),
+                                            r.distances.copy(),
+                                            random_state=np.random.RandomState(1))
+    out[dev] = (time.perf_counter() - t, list(inds), d, a)
+same = (out[1][1] == out[0][1] and np.array_equal(out[1][2], out[0][2]) and
+        np.array_equal(out[1][3], out[0][3]))
+print("%d x %d, %d medoids, euclidean: device-resident sweep %.3f s (%.1f us per proposal), "
+      "host loop around the device metric %.3f s (%.1f us); same results: %s"
+      % (n, F, K, out[1][0], out[1][0] / K * 1e6, out[0][0], out[0][0] / K * 1e6, same))
