@@ -215,3 +215,28 @@ def test_library_draws_are_randomstate_choice():
     raw = np.random.RandomState(1).randint(0, 2 ** 32, size=64, dtype=np.uint32)
     assert lib.ek_np_choice_draws(raw.ctypes.data_as(C.POINTER(C.c_uint32)), 64, C.byref(pos),
                                   _lib.i64p(ms), 3, _lib.i64p(out)) == 1
+
+
+def test_feature_sweep_on_the_device_only_where_it_is_the_same_computation():
+    """kmedoids._feature_sweep_applies: the resident PAM sweep takes 'euclidean' /
+    'manhattan' over a real matrix without NaN and a finite state; everything
+    else (other metrics, callables, NaN or infinite data, objects that are not
+    arrays) keeps the reference-shaped loop."""
+    from enspara_amd.cluster import kmedoids as km
+    from enspara_amd.geometry import libdist
+    X = np.random.RandomState(0).normal(size=(50, 3)).astype(np.float32)
+    d = np.ones(50)
+    assert km._feature_sweep_applies(X, libdist.euclidean, d, None)
+    assert km._feature_sweep_applies(X.astype(np.float64), libdist.manhattan, d, None)
+    assert km._feature_sweep_applies((X * 10).astype(np.int64), libdist.euclidean, d, None)
+    assert not km._feature_sweep_applies(X, libdist.hamming, d, None)
+    assert not km._feature_sweep_applies(X, lambda A, y: libdist.euclidean(A, y), d, None)
+    assert not km._feature_sweep_applies(X.tolist(), libdist.euclidean, d, None)
+    assert not km._feature_sweep_applies(X[0], libdist.euclidean, d, None)
+    bad = X.copy()
+    bad[3, 1] = np.nan
+    assert not km._feature_sweep_applies(bad, libdist.euclidean, d, None)
+    dinf = d.copy()
+    dinf[7] = np.inf
+    assert not km._feature_sweep_applies(X, libdist.euclidean, dinf, None)
+    assert not km._feature_sweep_applies(X.astype(np.complex64), libdist.euclidean, d, None)
