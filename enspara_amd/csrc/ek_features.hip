@@ -31,6 +31,8 @@ extern int ek_set_error(int code, const char *fmt, ...);
 #define FT_CHUNK 32           // features per staged transposition chunk
 #define FY_CHUNK 2048         // target-point features staged in LDS at a time
 
+struct FeatPam;           // working set of ek_feat_pam_sweep (below)
+
 struct ek_feat {
     int device = 0;
     int64_t n = 0;
@@ -52,6 +54,7 @@ struct ek_feat {
     struct FeatCtl *ctl = nullptr;
     int64_t *hist = nullptr;
     int32_t hist_cap = 0;
+    FeatPam *pam = nullptr;
 };
 
 // per-workgroup partial of the arg-max over float64 distances
@@ -657,16 +660,11 @@ struct FeatPam {
     int n_full = 0, n_leaves = 0, n_chunks = 0;
 };
 
-// one FeatPam per ek_feat, kept in a side table (ek_feat itself stays as it is)
-#include <map>
-static std::map<ek_feat *, FeatPam> g_feat_pam;
-
 extern "C" void ek_feat_pam_release(ek_feat *k)
 {
-    auto it = g_feat_pam.find(k);
-    if (it == g_feat_pam.end())
+    if (!k || !k->pam)
         return;
-    FeatPam &p = it->second;
+    FeatPam &p = *k->pam;
     (void)hipFree(p.MT);
     (void)hipFree(p.col);
     (void)hipFree(p.med);
@@ -683,7 +681,8 @@ extern "C" void ek_feat_pam_release(ek_feat *k)
     (void)hipFree(p.part);
     (void)hipFree(p.out2);
     (void)hipFree(p.shapes);
-    g_feat_pam.erase(it);
+    delete k->pam;
+    k->pam = nullptr;
 }
 
 // MT[j][c] = feature j of sample med[c]
@@ -948,7 +947,12 @@ extern "C" int ek_feat_pam_sweep(ek_feat *k, int32_t metric, int32_t n_medoids,
             return ek_set_error(EK_EARG, "ek_feat_pam_sweep: medoid or proposal %d "
                                          "out of range", c);
     FE_HIP(hipSetDevice(k->device));
-    FeatPam &p = g_feat_pam[k];
+    if (!k->pam) {
+        k->pam = new (std::nothrow) FeatPam();
+        if (!k->pam)
+            return ek_set_error(EK_ENOMEM, "ek_feat_pam_sweep: out of host memory");
+    }
+    FeatPam &p = *k->pam;
     int rc = feat_pam_alloc(k, p, K);
     if (rc)
         return rc;
