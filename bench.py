@@ -102,7 +102,10 @@ def parse():
                    help="skip the MSM block (BASELINE.json configs[4])")
     p.add_argument("--msm-frames", type=int, default=10_000_000)
     p.add_argument("--cpu-seconds", type=float, default=15.0,
-                   help="time budget of the CPU baseline leg (rank 0, N=1)")
+                   help="time budget of the CPU baseline leg (rank 0, N=1); 0 = "
+                        "no budget: the oracle replays ALL centers of the fit "
+                        "(labels and distances compared too) and the complete "
+                        "PAM sweep -- minutes of CPU work")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--pam-runs", type=int, default=2,
                    help="repetitions of the PAM measurement, each from the same "
@@ -233,12 +236,15 @@ def host_threads():
     return n, len(os.sched_getaffinity(0)), quota
 
 
-def cpu_baseline(x, gpu_centers, seconds):
+def cpu_baseline(x, gpu_centers, seconds, gpu_state=None):
     """Time the CPU oracle (oracle/qcp_oracle.c: OpenMP, frames centred once,
     frame-minor tiles, AVX2 FMA across frames) on the same frames for as many
     leading k-centers iterations as fit the time budget, and check the GPU's
-    centers for those iterations against it.  The oracle is the checker and
-    the reported baseline, never the product path."""
+    centers for those iterations against it.  ``seconds <= 0`` (--cpu-seconds
+    0): no budget -- every center of the fit, and with ``gpu_state`` (the
+    distances and labels the same fit left on the device) every frame's label
+    and float32 distance too.  The oracle is the checker and the reported
+    baseline, never the product path."""
     from oracle import qcp
     usable, affinity, quota = host_threads()
     qcp.set_num_threads(usable)
@@ -256,11 +262,18 @@ def cpu_baseline(x, gpu_centers, seconds):
         centers.append(nxt)
         mx, nxt = P.kcenters_step(P.c[nxt], P.G[nxt], len(centers) - 1, dist,
                                   assign)
-        if time.perf_counter() - t0 > seconds:
+        if seconds > 0 and time.perf_counter() - t0 > seconds:
             break
     wall = time.perf_counter() - t0
     k = len(centers)
     ok = [int(c) for c in gpu_centers[:k]] == centers
+    state_ok = None
+    if k == len(gpu_centers) and gpu_state is not None:
+        state_ok = {"labels_equal": bool(np.array_equal(gpu_state["assign"], assign)),
+                    "distances_equal_f32": bool(np.array_equal(
+                        np.asarray(gpu_state["dist"], dtype=np.float32), dist))}
+    if seconds <= 0:
+        seconds = 15.0          # the one-thread figure keeps its small budget
     cores = qcp.num_threads()
     # the same loop on one thread, for a fifth of the budget
     one = None
@@ -289,7 +302,9 @@ def cpu_baseline(x, gpu_centers, seconds):
         "sample": "all %d frames x first %d k-centers iterations "
                   "(%.1f s; centring+layout %.1f s not included)"
                   % (n, k, wall, prep),
+        "centers_checked": k,
         "centers_match_gpu": bool(ok),
+        "whole_fit_state_vs_gpu": state_ok,
         "host": {"logical_cpus": os.cpu_count(), "affinity_cpus": affinity,
                  "cgroup_cpu_quota": quota,
                  "threads_policy": "OpenMP static schedule over tiles; the "
@@ -453,10 +468,11 @@ def khybrid_check(x, store, start_medoids, gpu_medoids, seed, seconds):
     d0, a0 = start_medoids["dist"], start_medoids["assign"]
     done = []
     t0 = time.perf_counter()
-    med, _, _ = oc.pam_update(P, list(start_medoids["medoids"]),
-                              a0.astype(np.int64), d0.astype(np.float64),
-                              random_state=np.random.RandomState(seed),
-                              budget_s=seconds, done=done)
+    med, od, oa = oc.pam_update(P, list(start_medoids["medoids"]),
+                                a0.astype(np.int64), d0.astype(np.float64),
+                                random_state=np.random.RandomState(seed),
+                                budget_s=seconds if seconds > 0 else None,
+                                done=done)
     wall = time.perf_counter() - t0
     k = done[0] if done else 0
     same = [int(m) for m in med[:k]] == [int(m) for m in gpu_medoids[:k]]
@@ -474,7 +490,13 @@ def khybrid_check(x, store, start_medoids, gpu_medoids, seed, seconds):
                                  P.c[int(gpu_medoids[lab])],
                                  float(P.G[int(gpu_medoids[lab])]))
         ok = ok and bool(np.array_equal(want, d[fr]))
+    whole = None
+    if k == len(gpu_medoids):   # a complete sweep: the states must be equal
+        whole = {"labels_equal": bool(np.array_equal(a, oa)),
+                 "distances_equal": bool(np.array_equal(
+                     np.asarray(d, dtype=np.float64), od))}
     return {"proposals_replayed_by_oracle": k, "medoids_match_gpu": bool(same),
+            "whole_sweep_state_vs_oracle": whole,
             "of_them_accepted": moved, "oracle_s": wall,
             "sampled_frames": int(len(sample)),
             "sampled_state_is_rmsd_to_own_medoid_bit_exact": bool(ok)}
@@ -612,17 +634,14 @@ def main():
     if use_dist:
         transport = "gather"
         if args.transport == "mailbox" and cands > 1:
-            try:        # every rank's mailbox mapped into every other (hipIpc)
-                sharded.connect_mailboxes(shard)
+            # every rank's mailbox mapped into every other (hipIpc); collective,
+            # the same verdict on every rank (no peer access anywhere: one
+            # all-gather per round instead)
+            if sharded.connect_mailboxes(shard):
                 transport = "mailbox"
-            except Exception as e:      # no peer access: one all-gather per round
-                print("mailboxes unavailable (%s): gather transport" % e,
-                      file=sys.stderr)
-                shard.ms_connected = 0
-        flag = torch.tensor([1 if transport == "mailbox" else 0], device=ctl)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0 and transport == "mailbox":
-            transport, shard.ms_connected = "gather", 0
+            else:
+                print("mailboxes unavailable (%s): gather transport"
+                      % shard.ms_connect_error, file=sys.stderr)
         if transport == "mailbox" and world > 1:
             # a short fit through the mailboxes before anything is timed: if the
             # peers' stores do not arrive on this node (no peer access after
@@ -861,12 +880,18 @@ def main():
         if start is not None and args.pam_sweeps == 1 and not args.no_cpu_baseline:
             out["khybrid"]["parity"] = khybrid_check(x, store, start, med, args.seed,
                                                      min(40.0, 3 * args.cpu_seconds))
+    gpu_state = start if (args.pam_sweeps > 0 and world == 1) else None
+    if gpu_state is None and world == 1 and args.cpu_seconds <= 0 \
+            and not args.no_cpu_baseline:
+        run(centers_total)
+        d0, a0 = store.download_state()
+        gpu_state = {"dist": d0, "assign": a0}
 
     if rank == 0 and world == 1 and not args.no_msm:
         out["msm"] = msm_block(args)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(x, idx, args.cpu_seconds)
+        out["cpu_baseline"] = cpu_baseline(x, idx, args.cpu_seconds, gpu_state)
     elif rank == 0:
         out["cpu_baseline"] = None
 

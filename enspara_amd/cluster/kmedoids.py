@@ -131,6 +131,8 @@ def _kmedoids_iterations(X, distance_method, n_iters, cluster_center_inds,
         finally:
             if own:
                 store.close()
+    if hasattr(distance_method, "bind"):     # device metric: X resident for
+        distance_method = distance_method.bind(X)   # all sweeps, not per sweep
     result = None
     for i in range(n_iters):
         cluster_center_inds, distances, assignments, centers = \
@@ -458,10 +460,19 @@ def _msq(x):
 PAM_FEATURE_DEVICE = 1
 
 
-def _feature_sweep_applies(X, metric, distances, proposals):
-    """A floating-point (or integer) sample matrix without NaN, a finite state,
-    one of the two resident metrics, the default cost."""
+def _feature_sweep_applies(X, metric, distances, proposals, assignments=None):
+    """A floating-point (or integer) sample matrix without NaN, a finite
+    float64 state with integer labels, one of the two resident metrics, the
+    default cost.  (The reference builds ``new_dist = zeros_like(distances)``,
+    kmedoids.py:639: with float32 distances every accepted proposal rounds the
+    new values to float32 before the next comparison -- the resident sweep
+    works in float64 throughout, so it only takes float64 states.)"""
     if getattr(metric, "device_metric_id", None) not in (0, 1):
+        return False
+    if np.asarray(distances).dtype != np.float64:
+        return False
+    if assignments is not None and not np.issubdtype(
+            np.asarray(assignments).dtype, np.integer):
         return False
     if not isinstance(X, np.ndarray) or X.ndim != 2 or X.shape[0] < 1:
         return False
@@ -527,7 +538,7 @@ def _kmedoids_pam_update(X, metric, medoid_inds, assignments, distances,
     random_state = check_random_state(random_state)
     _check_proposals(proposals, medoid_inds)
     if (PAM_FEATURE_DEVICE and cost is _msq and
-            _feature_sweep_applies(X, metric, distances, proposals)):
+            _feature_sweep_applies(X, metric, distances, proposals, assignments)):
         return _feature_sweep_device(X, metric, medoid_inds, assignments, distances,
                                      proposals, random_state)
     if hasattr(metric, "bind"):              # device metric: upload X once

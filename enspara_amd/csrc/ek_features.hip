@@ -770,8 +770,10 @@ feat_pam_nearest_kernel(const T *__restrict__ tiles, int F,
         return;
     const uint32_t f = amb[blockIdx.x];
     const T *p = tiles + (size_t)(f / EK_TILE) * (size_t)F * EK_TILE + (f % EK_TILE);
+    // (label 0 where no distance is below +inf -- overflowed squares --: what
+    // util.py:186-203's zeros + strict < leave)
     double best = __builtin_inf();
-    int32_t bc = 0x7fffffff;
+    int32_t bc = 0;
     for (int c0 = 0; c0 < K; c0 += EK_BLOCK) {
         const int c = c0 + threadIdx.x;
         double acc = 0.0;

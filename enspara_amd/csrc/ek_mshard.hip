@@ -55,12 +55,14 @@
 
 #define EK_MS_THREADS 1024
 #define EK_MS_FPT 4
-// polls of a flag (with s_sleep between) before a shard gives up on a peer:
-// ~10 s -- ranks enter a fit seconds apart when one is still loading frames --;
-// a missing peer then shows as EkMsState::err (and ends the run: every later
-// launch is a no-op) instead of a hung GPU
-#ifndef EK_MS_SPIN_LIMIT
-#define EK_MS_SPIN_LIMIT (1 << 25)
+// how long a shard polls a flag (s_sleep between polls) before it gives up on a
+// peer: 10 s of the 100 MHz constant clock (wall_clock64: a time, whatever the
+// shader clock and whether the flag is local or across xGMI) -- ranks enter a
+// fit seconds apart when one is still loading frames --; a missing peer then
+// shows as EkMsState::err (and ends the run: every later launch is a no-op)
+// instead of a hung GPU.  Both waits of an exchange use the same bound.
+#ifndef EK_MS_WAIT_TICKS
+#define EK_MS_WAIT_TICKS (10ull * 100000000ull)
 #endif
 
 // ---- system-scope accesses (mailbox transport) ---------------------------------
@@ -156,12 +158,12 @@ ek_ms_chain_kernel(EkRound r, EkMsState *ms, EkMsXchg x, int nblk)
         const int h = (int)blockIdx.x - nblk;
         __shared__ int s_ok;
         if (tid == 0) {
-            int spins = 0;
+            const uint64_t t_start = wall_clock64();
             s_ok = 1;
             while (__hip_atomic_load(r.tick + 5, __ATOMIC_RELAXED,
                                      __HIP_MEMORY_SCOPE_AGENT) != seq + 1u) {
                 __builtin_amdgcn_s_sleep(2);
-                if (++spins > EK_MS_SPIN_LIMIT) {
+                if (wall_clock64() - t_start > EK_MS_WAIT_TICKS) {
                     s_ok = 0;
                     break;
                 }
@@ -235,10 +237,10 @@ ek_ms_chain_kernel(EkRound r, EkMsState *ms, EkMsXchg x, int nblk)
             // starves whatever else shares the GPU (another shard's launches, in
             // the tests: that is a deadlock until the time-out)
             const uint32_t *f = x.sflag + ((size_t)(seq & 1u) * x.world + tid) * 16;
-            int spins = 0;
+            const uint64_t t_start = wall_clock64();
             while (ek_sys_load(f) != seq + 1u) {
                 __builtin_amdgcn_s_sleep(8);
-                if (++spins > EK_MS_SPIN_LIMIT) {
+                if (wall_clock64() - t_start > EK_MS_WAIT_TICKS) {
                     if (!ms->err) {         // peer `tid`'s message did not arrive
                         ms->err = 0x100 + tid;
                         ms->err_seq = seq;

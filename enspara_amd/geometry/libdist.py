@@ -124,6 +124,7 @@ class Bound:
 
     def __init__(self, metric, X, device=0):
         self.metric = metric
+        self.device_metric_id = metric      # (what the unbound callables carry)
         self.X = X
         self.device = device
         Xa = np.asarray(X)
@@ -132,6 +133,13 @@ class Bound:
         if Xa.ndim == 2 and Xa.shape[0] > 0:
             self.res = _Resident(np.ascontiguousarray(Xa, dtype=self.dt),
                                  _KIND[np.dtype(self.dt).name], device)
+
+    def bind(self, X, device=None):
+        """The loops bind on entry; a metric already bound to this very array
+        is handed on as it is (one upload per fit, not one per sweep)."""
+        if X is self.X and (device is None or device == self.device):
+            return self
+        return Bound(self.metric, X, self.device if device is None else device)
 
     def __call__(self, X, y, out=None):
         if X is not self.X or self.res is None:

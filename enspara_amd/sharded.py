@@ -342,23 +342,52 @@ def connect_mailboxes(shard, group=None):
     on one node (one GPU each): every rank publishes the hipIpc handles of its
     mailbox, opens the others', and from then on `kcenters_sharded` runs its
     rounds with the exchange on the device (DeviceShard.ms_run).  Collective:
-    every rank calls it."""
+    every rank calls it, and every rank makes the SAME sequence of collectives
+    whatever fails where (a rank that cannot export or open a handle -- no
+    peer access to one GPU -- still takes part in both gathers).  Returns True
+    with ``shard.ms_connected = world`` only if every rank connected every
+    peer; otherwise every rank closes what it opened, ``ms_connected`` is 0,
+    ``shard.ms_connect_error`` holds this rank's exception (if it had one) and
+    the caller stays on the all-gather transport."""
     import torch.distributed as dist
     world, rank = _world(group)
     st = shard.store
-    st.ms_setup(world, rank)
-    mine = st.ms_mailbox(ipc=True) if world > 1 else None
+    why, mine = None, None
+    try:
+        st.ms_setup(world, rank)
+        mine = st.ms_mailbox(ipc=True) if world > 1 else None
+    except Exception as e:          # reported below, after the collectives
+        why = e
     handles = [None] * world
     if world > 1:
         dist.all_gather_object(handles, mine, group=group)
-    for p in range(world):
-        if p == rank:
-            st.ms_connect(p)
-        else:
-            st.ms_connect(p, ipc=handles[p])
+    if why is None:
+        try:
+            for p in range(world):
+                if p == rank:
+                    st.ms_connect(p)
+                elif handles[p] is None:
+                    raise RuntimeError("rank %d published no mailbox" % p)
+                else:
+                    st.ms_connect(p, ipc=handles[p])
+        except Exception as e:
+            why = e
+    # one more gather: the verdict, and the point no rank passes before every
+    # rank has mapped every mailbox
+    verdicts = [why is None]
     if world > 1:
-        dist.barrier(group=group)
+        verdicts = [None] * world
+        dist.all_gather_object(verdicts, why is None, group=group)
+    shard.ms_connect_error = why
+    if not all(verdicts):
+        try:                        # closes the mappings, ms_peers = 0
+            st.ms_setup(world, rank)
+        except Exception:
+            pass
+        shard.ms_connected = 0
+        return False
     shard.ms_connected = world
+    return True
 
 
 def _kcenters_sharded_rounds(shard, first_label, max_new, dist_cutoff, group,

@@ -88,6 +88,55 @@ def msq(d):
 
 def pam_update(X, medoid_inds, assignments, distances, proposals=None,
                random_state=None, stop_after=None, budget_s=None, done=None):
+    """One PAM sweep, kmedoids.py:575-699 (non-MPI branch), with the trial
+    state of every proposal (:637-678: the proposal's distances, the three
+    masks, the ambiguous members against all medoids) built by
+    ``qcp_oracle.c:eko_pam_trial`` -- the loop ``pam_update_numpy`` below
+    spells out in numpy, at a cost a complete 5000-proposal sweep over 10^6
+    frames can afford (tests/test_oracle.py holds the two equal).  The draw
+    (:514) and the cost comparison (:478-479, :680-683) are numpy's own.
+    ``stop_after`` / ``budget_s`` / ``done`` as in ``pam_update_numpy``."""
+    import time
+    t_start = time.perf_counter()
+    P = X if isinstance(X, qcp.Prepared) else qcp.Prepared(X)
+    random_state = check_random_state(random_state)          # :579
+    medoid_inds = list(medoid_inds)
+    K = len(medoid_inds)
+    med_c = np.ascontiguousarray(P.c[np.asarray(medoid_inds, dtype=np.int64)])
+    med_G = np.ascontiguousarray(P.G[np.asarray(medoid_inds, dtype=np.int64)])
+    # (copies: the two pairs of buffers swap roles when a proposal is accepted)
+    distances = np.array(distances, dtype=np.float64)
+    assignments = np.array(assignments, dtype=np.int64)
+    new_dist = np.empty_like(distances)
+    new_assig = np.empty_like(assignments)
+    scratch = np.empty(P.n, dtype=np.float32)
+    cost = msq(distances)       # the same call on the same array every time
+    for cid in range(K if stop_after is None else min(stop_after, K)):
+        if budget_s is not None and time.perf_counter() - t_start > budget_s:
+            break
+        if done is not None:
+            done[:] = [cid + 1]
+        if proposals is None:
+            members = np.flatnonzero(assignments == cid)     # :611
+            prop = random_state.choice(members)              # :514
+        else:
+            prop = proposals[cid]
+        qcp.pam_trial(P, med_c, med_G, cid, P.c[prop], P.G[prop], distances,
+                      assignments, new_dist, new_assig, scratch)
+        new_cost = msq(new_dist)
+        if new_cost < cost:                                  # :680-683
+            cost = new_cost
+            distances, new_dist = new_dist, distances
+            assignments, new_assig = new_assig, assignments
+            med_c[cid] = P.c[prop]
+            med_G[cid] = P.G[prop]
+            medoid_inds[cid] = prop
+    return medoid_inds, distances, assignments
+
+
+def pam_update_numpy(X, medoid_inds, assignments, distances, proposals=None,
+                     random_state=None, stop_after=None, budget_s=None,
+                     done=None):
     """One PAM sweep, kmedoids.py:575-699 (non-MPI branch).  ``stop_after`` /
     ``budget_s`` (checker only): only the first that many clusters' proposals,
     or as many as fit the seconds -- what a full-size cross-check can afford;

@@ -47,6 +47,10 @@ def lib():
         L.eko_argmax_first.argtypes = [f32p, C.c_int64]
         L.eko_assign_nearest.argtypes = [f32p, f64p, C.c_int64, C.c_int,
                                          f32p, f64p, C.c_int32, i32p, f32p]
+        L.eko_pam_trial.argtypes = [
+            f32p, f32p, f64p, C.c_int64, C.c_int, f32p, f64p, C.c_int32,
+            C.c_int32, f32p, C.c_double, f64p, i64p, f64p, i64p, f32p]
+        L.eko_pam_trial.restype = None
         _lib = L
     return _lib
 
@@ -170,6 +174,23 @@ class Prepared:
             float(Gc), int(label), _f32(dist), _i32(assign),
             C.byref(mx), C.byref(am))
         return mx.value, am.value
+
+
+def pam_trial(P, med_c, med_G, cid, prop_c, prop_G, dist, assign, new_dist,
+              new_assig, scratch):
+    """The trial state of one PAM proposal (kmedoids.py:637-678) into
+    ``new_dist`` / ``new_assig`` (float64 / int64 [n], overwritten)."""
+    i64p = C.POINTER(C.c_int64)
+    prop_c = np.ascontiguousarray(prop_c, dtype=np.float32)
+    assert med_c.dtype == np.float32 and med_c.flags.c_contiguous
+    assert med_G.dtype == np.float64 and dist.dtype == np.float64
+    assert assign.dtype == np.int64 and new_assig.dtype == np.int64
+    assert new_dist.dtype == np.float64 and scratch.dtype == np.float32
+    lib().eko_pam_trial(
+        _f32(P.tiled), _f32(P.c), _f64(P.G), P.n, P.A, _f32(med_c),
+        _f64(med_G), int(med_c.shape[0]), int(cid), _f32(prop_c),
+        float(prop_G), _f64(dist), assign.ctypes.data_as(i64p),
+        _f64(new_dist), new_assig.ctypes.data_as(i64p), _f32(scratch))
 
 
 def assign_nearest(cframes, G, ccenters, Gc):

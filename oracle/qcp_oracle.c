@@ -454,3 +454,68 @@ void eko_assign_nearest(const float *frames, const double *G, int64_t n, int A,
         dist[f] = best;
     }
 }
+
+/* ---- one PAM proposal (kmedoids.py:637-678, non-MPI branch) ---------------- */
+/* The trial state a proposal would leave, before the cost comparison of
+ * :680-683 (which stays numpy's np.square(d).mean() in oracle/cluster.py).
+ *   tiled / frames / G : the centred frames in both layouts and their traces
+ *   medoids / Gm       : the K current medoids, centred [K][A][3], traces [K]
+ *   prop / Gp          : the proposed medoid of cluster `cid`, centred
+ *   dist / assign      : the state (float64 holding float32 values, int64)
+ *   new_dist/new_assig : the trial state (written everywhere)
+ *   nd_scratch         : float32 [n]
+ * :637  nd = metric(X, proposal)
+ * :644  down      = dist > nd                      -> (cid, nd)
+ * :651  up_other  = dist <= nd and assign != cid   -> unchanged
+ * :658  up_this   = dist <= nd and assign == cid   -> :666 assign_to_nearest_
+ *       center over the trial medoid list (util.py:199-203: centers in order,
+ *       strict <, labels start at 0, distances at +inf)
+ * A NaN distance fails both comparisons and keeps the -1 / -1 the reference's
+ * zeros_like(...) - 1 initialisation leaves. */
+void eko_pam_trial(const float *tiled, const float *frames, const double *G,
+                   int64_t n, int A, const float *medoids, const double *Gm,
+                   int32_t K, int32_t cid, const float *prop, double Gp,
+                   const double *dist, const int64_t *assign, double *new_dist,
+                   int64_t *new_assig, float *nd_scratch)
+{
+    eko_rmsd_one_to_many_tiled(tiled, G, n, A, prop, Gp, nd_scratch);
+#pragma omp parallel for schedule(dynamic, 1024)
+    for (int64_t f = 0; f < n; ++f) {
+        const double d = dist[f];
+        const double nd = (double)nd_scratch[f];
+        double od = -1.0;
+        int64_t oa = -1;
+        if (d > nd) {
+            oa = cid;
+            od = nd;
+        } else if (d <= nd) {
+            if (assign[f] != cid) {
+                oa = assign[f];
+                od = d;
+            } else {
+                const float *x = frames + (size_t)f * A * 3;
+                float best = INFINITY;
+                int64_t bi = 0;
+                for (int32_t c = 0; c < K; ++c) {
+                    float S[9];
+                    float dc;
+                    if (c == cid) {
+                        eko_accum_S(x, prop, A, S);
+                        dc = eko_rmsd_from_S(S, G[f], Gp, A);
+                    } else {
+                        eko_accum_S(x, medoids + (size_t)c * A * 3, A, S);
+                        dc = eko_rmsd_from_S(S, G[f], Gm[c], A);
+                    }
+                    if (dc < best) {
+                        best = dc;
+                        bi = c;
+                    }
+                }
+                oa = bi;
+                od = (double)best;
+            }
+        }
+        new_dist[f] = od;
+        new_assig[f] = oa;
+    }
+}

@@ -1,0 +1,93 @@
+"""BASELINE.json configs[1] and configs[2] at their own size, checked COMPLETELY
+against the oracle: every one of the 5000 center indices, every frame's label
+and float32 distance after the k-centers fit (default ladder of 1 / 8 / 16
+candidates per pass), then one complete PAM sweep of 5000 proposals -- medoids,
+labels, distances.  The oracle's loops are qcp_oracle.c's (OpenMP): about two
+minutes for the fit and three for the sweep on the GPU box's 16 host threads."""
+import os
+
+import numpy as np
+import pytest
+
+from enspara_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+N, A, K = 1_000_000, 300, 5000
+
+
+def _threads():
+    n = len(os.sched_getaffinity(0))
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            q, per = fh.read().split()
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(per) + 0.5)))
+    except Exception:
+        pass
+    return n
+
+
+@pytest.fixture(scope="module")
+def world():
+    from oracle import qcp
+    qcp.set_num_threads(_threads())
+    x = synth.synth(N, A, 5000, seed=1)         # the bench's data
+    P = qcp.Prepared(x)
+    _ = P.tiled
+    # the oracle's own fit: kcenters.py:217-231 / :282-306, fused per iteration
+    dist = np.full(N, np.inf, dtype=np.float32)
+    assign = np.full(N, -1, dtype=np.int32)
+    centers, nxt = [], 0
+    for k in range(K):
+        centers.append(nxt)
+        _, nxt = P.kcenters_step(P.c[nxt], P.G[nxt], k, dist, assign)
+    yield {"x": x, "P": P, "centers": centers, "dist": dist, "assign": assign}
+    qcp.set_num_threads(int(os.environ.get("OMP_NUM_THREADS", "8")))
+
+
+def test_whole_fit_at_the_bench_shape(world):
+    """all 5000 centers, all 10^6 labels and distances (configs[1])"""
+    from enspara_amd.cluster.kcenters import kcenters
+    from enspara_amd.device import FrameStore
+    r = kcenters(world["x"], "rmsd", n_clusters=K)
+    assert [int(i) for i in r.center_indices] == world["centers"]
+    np.testing.assert_array_equal(r.assignments, world["assign"])
+    np.testing.assert_array_equal(r.distances.astype(np.float32), world["dist"])
+    assert r.distances.dtype == np.float64 and r.assignments.dtype == np.int64
+    # and the forms the ladder did not spend most of its time in
+    with FrameStore.from_array(world["x"]) as st:
+        st.set_option(4, 8)
+        st.reset_state()
+        idx, _, _ = st.kcenters_run(0, 600, 0.0)
+        assert [int(i) for i in idx] == world["centers"][:600]
+
+
+def test_whole_pam_sweep_at_the_bench_shape(world):
+    """one complete sweep of 5000 proposals (configs[2]): medoid for medoid,
+    then every label and distance of the state it leaves"""
+    from enspara_amd.cluster import kmedoids as km
+    from enspara_amd.device import FrameStore
+    from oracle import cluster as oc
+    with FrameStore.from_array(world["x"]) as st:
+        st.reset_state()
+        idx, _, _ = st.kcenters_run(0, K, 0.0)
+        assert [int(i) for i in idx] == world["centers"]
+        med = km._pam_sweep_device(st, [int(i) for i in idx], None,
+                                   np.random.RandomState(1))
+        restricted, full = st.pam_prefetch_passes()
+        hits, misses = st.pam_prefetch_stats()
+        d1, a1 = st.download_state()
+    # (the restricted prefetch -- exact distances only for the frames a
+    # proposal can touch -- is what served every proposal)
+    assert restricted > 0 and full == 0 and hits == K and misses == 0
+    done = []
+    want, wd, wa = oc.pam_update(world["P"], world["centers"],
+                                 world["assign"].astype(np.int64),
+                                 world["dist"].astype(np.float64),
+                                 random_state=np.random.RandomState(1), done=done)
+    assert done == [K]
+    assert [int(m) for m in med] == [int(m) for m in want]
+    assert sum(int(a) != int(b) for a, b in zip(med, world["centers"])) > K // 4
+    np.testing.assert_array_equal(a1, wa)
+    np.testing.assert_array_equal(np.asarray(d1, dtype=np.float64), wd)

@@ -150,32 +150,6 @@ def test_sampled_parity_at_scale(qcp):
         assert r.assignments[i] == k
 
 
-def test_first_centers_at_the_bench_shape(qcp):
-    """BASELINE.json configs[1]'s own shape -- 10^6 frames x 300 atoms, the
-    bench's data -- for the first 64 centers: every center index against the
-    checker's k-centers on the same frames, and a sample of frames (label =
-    first arg-min over the centers, distance bit-equal)."""
-    from enspara_amd.cluster.kcenters import kcenters
-    n, A, K = 1_000_000, 300, 64
-    x = synth.synth(n, A, 5000, seed=1)
-    r = kcenters(x, "rmsd", n_clusters=K)
-    # the checker's own run of the same iterations (tiled AVX2 form)
-    P = qcp.Prepared(x)
-    dist = np.full(n, np.inf, dtype=np.float32)
-    assign = np.full(n, -1, dtype=np.int32)
-    centers, nxt = [], 0
-    for k in range(K):
-        centers.append(nxt)
-        _, nxt = P.kcenters_step(P.c[nxt], P.G[nxt], k, dist, assign)
-    assert [int(i) for i in r.center_indices] == centers
-    rng = np.random.RandomState(1)
-    sample = np.unique(np.concatenate([rng.randint(0, n, 20000),
-                                       np.array(centers)]))
-    np.testing.assert_array_equal(r.assignments[sample], assign[sample])
-    np.testing.assert_array_equal(r.distances[sample].astype(np.float32),
-                                  dist[sample])
-
-
 @pytest.mark.parametrize("n,A,K", [(1000, 35, 21), (64, 22, 32), (777, 301, 97),
                                    (2500, 100, 64), (130, 7, 300), (5, 3, 2)])
 def test_assign_variants_bit_identical(qcp, n, A, K):

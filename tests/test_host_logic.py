@@ -240,3 +240,24 @@ def test_feature_sweep_on_the_device_only_where_it_is_the_same_computation():
     dinf[7] = np.inf
     assert not km._feature_sweep_applies(X, libdist.euclidean, dinf, None)
     assert not km._feature_sweep_applies(X.astype(np.complex64), libdist.euclidean, d, None)
+    # a float32 state: the reference rounds every accepted proposal's distances
+    # to float32 (zeros_like(distances), kmedoids.py:639) -- not the resident
+    # sweep's float64 arithmetic; labels that are not integers neither
+    a = np.zeros(50, dtype=np.int64)
+    assert km._feature_sweep_applies(X, libdist.euclidean, d, None, a)
+    assert not km._feature_sweep_applies(X, libdist.euclidean,
+                                         d.astype(np.float32), None, a)
+    assert not km._feature_sweep_applies(X, libdist.euclidean, d, None,
+                                         a.astype(np.float64))
+
+
+def test_a_bound_metric_is_bound_once():
+    """libdist.Bound.bind: the loops bind on entry (kmedoids.py once per sweep,
+    kcenters.py once per fit); a metric already bound to the same array is
+    handed on, not uploaded again -- checked here without a device"""
+    from enspara_amd.geometry import libdist
+    X = np.zeros((0, 3), dtype=np.float32)      # (no rows: nothing is uploaded)
+    b = libdist.euclidean.bind(X)
+    assert b.device_metric_id == 0 and b.bind(X) is b
+    Y = np.zeros((0, 3), dtype=np.float32)
+    assert b.bind(Y) is not b and b.bind(Y).X is Y

@@ -202,3 +202,70 @@ def test_pam_with_proposals_matches_reference(G):
     np.testing.assert_array_equal(mi, G["pam_idx"])
     np.testing.assert_array_equal(aa, G["pam_assign"])
     np.testing.assert_array_equal(dd, G["pam_dist"])
+
+
+# --- two more mdtraj-produced known answers the reference's tests hold ----------
+# (integer-exact: medoid indices after one PAM sweep on test/data/frame0.h5,
+# decoded here by enspara_amd.h5lite through util.load)
+
+def _frame0_h5(golden_dir):
+    from enspara_amd.util.load import load_as_concatenated
+    lengths, x = load_as_concatenated([os.path.join(golden_dir, "frame0.h5")])
+    assert list(lengths) == [501] and x.shape == (501, 22, 3)
+    return x
+
+
+def test_reference_known_answer_pam_k3(golden_dir):
+    """enspara/test/test_cluster.py:533-554: k-centers with 3 clusters, one PAM
+    sweep with random_state=0 -> medoids [298, 44, 341]; the state it leaves is
+    the nearest-medoid assignment."""
+    x = _frame0_h5(golden_dir)
+    inds, a, d = oc.kcenters(x, n_clusters=3)
+    mi, dd, aa = oc.pam_update(x, inds, a, d, random_state=0)
+    assert [int(i) for i in mi] == [298, 44, 341]
+    ea, ed = oc.assign_to_nearest_center(x, [x[i] for i in mi])
+    np.testing.assert_array_equal(np.unique(aa), np.arange(3))
+    np.testing.assert_array_equal(aa, ea)
+    np.testing.assert_allclose(dd, ed, atol=1e-6)
+
+
+def test_reference_known_answer_pam_k10_first_members(golden_dir):
+    """enspara/test/test_cluster.py:379-412 at MPI size 1: 10 clusters, every
+    cluster proposes its first member -> medoids
+    [0, 37, 400, 105, 12, 327, 242, 346, 42, 3]."""
+    x = _frame0_h5(golden_dir)
+    inds, a, d = oc.kcenters(x, n_clusters=10)
+    props = [int(np.where(a == c)[0][0]) for c in range(10)]
+    mi, dd, aa = oc.pam_update(x, inds, a, d, proposals=props, random_state=0)
+    assert [int(i) for i in mi] == [0, 37, 400, 105, 12, 327, 242, 346, 42, 3]
+
+
+@pytest.mark.parametrize("n,A,K,T,seed", [(3000, 25, 40, 30, 1),
+                                          (5000, 10, 200, 50, 2),
+                                          (2000, 3, 30, 5, 3),
+                                          (700, 22, 400, 10, 4)])
+def test_pam_trial_in_c_equals_the_numpy_loop(n, A, K, T, seed):
+    """oracle.cluster.pam_update builds every proposal's trial state in
+    qcp_oracle.c (eko_pam_trial); pam_update_numpy is the line-by-line numpy
+    form of kmedoids.py:637-683 that the goldens of the real reference were
+    first pinned with.  Same medoids, labels, distances -- random and explicit
+    proposals, a RandomState carried over two sweeps and an int seed."""
+    x = synth.synth(n, A, T, seed=seed)
+    P = qcp.Prepared(x)
+    inds, a, d = oc.kcenters(P, n_clusters=K)
+    for rs in (np.random.RandomState(seed), 7):
+        rs2 = np.random.RandomState(seed) if not isinstance(rs, int) else rs
+        r1 = oc.pam_update(P, inds, a.copy(), d.copy(), random_state=rs)
+        r2 = oc.pam_update_numpy(P, inds, a.copy(), d.copy(), random_state=rs2)
+        for _ in range(2):
+            assert [int(i) for i in r1[0]] == [int(i) for i in r2[0]]
+            np.testing.assert_array_equal(r1[1], r2[1])
+            np.testing.assert_array_equal(r1[2], r2[2])
+            r1 = oc.pam_update(P, r1[0], r1[2], r1[1], random_state=rs)
+            r2 = oc.pam_update_numpy(P, r2[0], r2[2], r2[1], random_state=rs2)
+    props = [int(np.flatnonzero(a == c)[-1]) for c in range(K)]
+    r1 = oc.pam_update(P, inds, a, d, proposals=props)
+    r2 = oc.pam_update_numpy(P, inds, a, d, proposals=props)
+    assert [int(i) for i in r1[0]] == [int(i) for i in r2[0]]
+    np.testing.assert_array_equal(r1[1], r2[1])
+    np.testing.assert_array_equal(r1[2], r2[2])
