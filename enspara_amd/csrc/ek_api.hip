@@ -55,6 +55,9 @@ struct ek_ctx {
     bool loaded = false;
 
     float *tiles = nullptr;      // [n_tiles][3A][EK_TILE]
+    float *qtiles = nullptr;     // quad copy [n_tiles][ceil(A/4)][3][EK_TILE][4]: what the
+                                 // 16-candidate pass streams; made when one first runs
+    bool qt_valid = false;       //   (ek_ensure_qtiles), again after frames are loaded
     float *aos = nullptr;        // [n][3A] the same centred frames, frame-major
     double *G = nullptr;         // [n]
     float *dist = nullptr;       // [n]
@@ -263,6 +266,23 @@ static int ek_pick_cands(const ek_ctx *c)
     return (t == 16 || t == 8 || t == 4) ? t : 1;
 }
 
+// The quad copy of the frames (ek_pass16.hip) is made when a 16-candidate pass
+// first needs it and again after frames were loaded: a third copy of the
+// coordinates (12 A bytes per frame, 3.6 GB at 10^6 x 300 of the 288 GB), one
+// read and one write of the shard.
+static int ek_ensure_qtiles(ek_ctx *c)
+{
+    if (c->qt_valid)
+        return EK_OK;
+    if (!c->qtiles)
+        EK_HIP(hipMalloc((void **)&c->qtiles,
+                         ek_quad_tiles_bytes(std::max<int64_t>(c->n_tiles, 1), c->A)));
+    ek_launch_quad_tiles(c->tiles, c->n_tiles, c->A, c->qtiles, c->stream);
+    EK_CHECK_LAUNCH();
+    c->qt_valid = true;
+    return EK_OK;
+}
+
 // slot of a form in the run statistics: passes run as 1 / 4 / 8 / 16 candidates
 static int ek_form_slot(int T) { return T <= 1 ? 0 : (T == 4 ? 1 : (T == 8 ? 2 : 3)); }
 
@@ -308,6 +328,7 @@ static int ek_free_all(ek_ctx *c)
     if (c->stream)
         (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->tiles);
+    (void)hipFree(c->qtiles);
     (void)hipFree(c->aos);
     (void)hipFree(c->G);
     (void)hipFree(c->dist);
@@ -648,6 +669,7 @@ extern "C" int ek_load_frames(ek_ctx *c, const float *xyz, int64_t first,
         }
     }
     c->loaded = true;
+    c->qt_valid = false;
     return EK_OK;
 }
 
@@ -1006,6 +1028,11 @@ static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
                               c->stream));
     }
     c->ti_tiles = c->ti_skipped = 0;
+    if (Tmax == 16 && !tri) {
+        const int eq = ek_ensure_qtiles(c);
+        if (eq != EK_OK)
+            return eq;
+    }
     // an explicit request (option key 4 = 4, 8 or 16) pins the wide form
     const bool adaptive = c->cands == -1 && c->adapt && !tri;
     const int fpl = ek_pick_fpl(c);
@@ -1040,6 +1067,7 @@ static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
     R.A = c->A;
     R.T = Tmax;
     R.tiles = c->tiles;
+    R.qtiles = c->qtiles;
     R.aos = c->aos;
     R.G = c->G;
     R.recs = c->recsT;
@@ -1151,9 +1179,9 @@ static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
                            c->plan, c->hist, c->ctl, c->stream);
             if (sample)
                 EK_HIP(hipEventRecord(c->samp_ev[2 * c->samp_used], c->stream));
-            ek_launch_pass(form, c->tiles, c->G, c->dist, c->assign, c->vecs, c->n,
-                           c->n_pad, c->A, c->recsT, c->plan, c->blockmax,
-                           c->ctile, c->ctrace, c->stream);
+            ek_launch_pass(form, c->tiles, c->qtiles, c->G, c->dist, c->assign,
+                           c->vecs, c->n, c->n_pad, c->A, c->recsT, c->plan,
+                           c->blockmax, c->ctile, c->ctrace, c->stream);
             if (sample) {
                 EK_HIP(hipEventRecord(c->samp_ev[2 * c->samp_used + 1],
                                       c->stream));
@@ -2896,7 +2924,12 @@ extern "C" int ek_spec_round(ek_ctx *c, const void *recs_all, int32_t n_recs,
         c->samp_form[c->samp_used] = T;
     if (sample)
         EK_HIP(hipEventRecord(c->samp_ev[2 * c->samp_used], c->stream));
-    ek_launch_pass(T, c->tiles, c->G, c->dist, c->assign, c->vecs,
+    if (T == 16) {
+        const int eq = ek_ensure_qtiles(c);
+        if (eq != EK_OK)
+            return eq;
+    }
+    ek_launch_pass(T, c->tiles, c->qtiles, c->G, c->dist, c->assign, c->vecs,
                    c->n, c->n_pad, c->A, (const unsigned char *)recs_all,
                    c->plan, c->blockmax, c->ctile, c->ctrace, c->stream);
     if (sample) {
@@ -3074,6 +3107,7 @@ static void ek_round_of(ek_ctx *c, int T, double cutoff, EkRound &R)
     R.A = c->A;
     R.T = T;
     R.tiles = c->tiles;
+    R.qtiles = c->qtiles;
     R.aos = c->aos;
     R.G = c->G;
     R.recs = c->recsT;
@@ -3219,6 +3253,11 @@ extern "C" int ek_ms_begin(ek_ctx *c, int32_t first_label, int32_t limit)
     if (rc)
         return rc;
     c->ms_T = T;
+    if (T == 16) {
+        const int eq = ek_ensure_qtiles(c);
+        if (eq != EK_OK)
+            return eq;
+    }
     EkCtl w;
     memset(&w, 0, sizeof(w));
     w.n_done = first_label;

@@ -128,6 +128,7 @@ struct EkRound {
     int64_t n, n_pad, goff;
     int A, T;
     const float *tiles;
+    const float *qtiles;        // quad copy (16-candidate pass; null until one runs)
     const float *aos;           // the centred frames, frame-major [n][3A]
     const double *G;
     unsigned char *recs;        // T records (kept for the other entry points)
@@ -404,19 +405,24 @@ void ek_launch_pam_active(const float *dist, const int32_t *assign, int64_t n,
 // Where (atom a, candidate c, coordinate k) of a round's T candidates sits in the
 // candidate tile the pass kernel reads: T <= 8 [atom][pair][xyz][2] (pairs of
 // candidates as scalar operands of v_pk_fma_f32, ek_spec.hip); T = 16
-// [trip of 4 atoms][candidate][xyz][atom of the trip] (a lane of the MFMA
-// kernel reads its candidate's 12 floats of a trip as three 16-byte loads,
-// ek_pass16.hip).  The tile holds A + EK_CTILE_PAD atoms (whole trips), zeros
-// past the last.
+// [16 atoms][load 0..2][lane group 0..3][candidate][atom % 4]: the twelve
+// (trip of 4 atoms, xyz) slices of 16 atoms are numbered quad = 3 * trip + k;
+// slice `quad` is load quad / 4, lane group quad % 4, so that one 16-byte load
+// per lane fetches four slices of the 16 candidates and the matrix instruction
+// picks its slice with B's lane-group broadcast (ek_pass16.hip).  The tile
+// holds A + EK_CTILE_PAD atoms rounded up to whole groups of 16, zeros past the
+// last.
 static inline __host__ __device__ size_t ek_ctile_index(int T, int a, int c, int k)
 {
-    if (T == 16)
-        return ((size_t)(a >> 2) * 16 + c) * 12 + k * 4 + (a & 3);
+    if (T == 16) {
+        const int quad = ((a >> 2) & 3) * 3 + k;
+        return ((((size_t)(a >> 4) * 3 + quad / 4) * 4 + quad % 4) * 16 + c) * 4 + (a & 3);
+    }
     return (size_t)a * (3 * T) + (c / 2) * 6 + k * 2 + (c & 1);
 }
 static inline __host__ __device__ int ek_ctile_atoms(int A)  // incl. padding
 {
-    return (A + EK_CTILE_PAD + 3) / 4 * 4;
+    return (A + EK_CTILE_PAD + 15) / 16 * 16;
 }
 void ek_launch_pam_setup(const float *aos, const double *G, int A,
                          const int64_t *frames, int count, int64_t global_offset,
@@ -476,13 +482,18 @@ void ek_launch_plan(const unsigned char *recs, int n_recs, int A, int T,
 // the candidates are laid out in `ctile` (ek_ctile_bytes) / `ctrace`
 // ([EK_MAX_CANDS] f64) and read as scalar operands
 size_t ek_ctile_bytes(int A);
-void ek_launch_pass(int T, const float *tiles, const double *G, float *dist,
-                    int32_t *assign, float *vecs, int64_t n, int64_t n_pad,
-                    int A, const unsigned char *recs, const EkPlan *plan,
-                    EkBlockMax *blockmax, float *ctile, double *ctrace,
-                    hipStream_t s);
+// (qtiles: read instead of tiles when T == 16)
+void ek_launch_pass(int T, const float *tiles, const float *qtiles, const double *G,
+                    float *dist, int32_t *assign, float *vecs, int64_t n,
+                    int64_t n_pad, int A, const unsigned char *recs,
+                    const EkPlan *plan, EkBlockMax *blockmax, float *ctile,
+                    double *ctrace, hipStream_t s);
 // T = 16 through the matrix cores (ek_pass16.hip); fuse: the fused rounds' form
-void ek_launch_pass16(bool fuse, const float *tiles, const double *G, float *dist,
+// (qtiles: the quad copy of the frames, ek_launch_quad_tiles)
+size_t ek_quad_tiles_bytes(int64_t n_tiles, int A);
+void ek_launch_quad_tiles(const float *tiles, int64_t n_tiles, int A, float *qtiles,
+                          hipStream_t s);
+void ek_launch_pass16(bool fuse, const float *qtiles, const double *G, float *dist,
                       int32_t *assign, float *vecs, int64_t n, int64_t n_pad, int A,
                       const float *ctile, const double *ctrace, const EkPlan *plan,
                       EkBlockMax *blockmax, const EkFuse &fz, hipStream_t s);

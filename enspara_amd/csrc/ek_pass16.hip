@@ -4,23 +4,30 @@
 // One frame against ONE center is a matrix-vector product (1.5 flop per byte:
 // HBM-bound, ek_kcenters.hip).  Every frame against SIXTEEN candidates is a
 // dense contraction -- S[frame][cand][i][j] = sum_a x[frame][a][i] y[cand][a][j],
-// M = frames x 3, N = candidates x 3, K = atoms -- with 24 flop per byte: its
-// vector-FMA form (ek_pass2_kernel, 8 candidates as scalar operands) already
-// runs at the packed-FMA rate's edge at 16, starved by its scalar loads (two
-// waves per SIMD cannot hide a scalar-cache miss every 36 FMAs: 1.08 ms per
-// 10^6 x 300 pass measured, against 0.64 ms for 8 candidates).  Here the same
-// sums run on v_mfma_f32_16x16x1_f32:
+// M = frames x 3, N = candidates x 3, K = atoms -- with 24 flop per byte.  Here
+// the sums run on v_mfma_f32_16x16x1_4b_f32:
 //
 //   * 4 blocks of 16 x 16 per instruction, ONE k per instruction: the A
-//     operand is a frame row exactly as the tile layout delivers it (lane =
-//     frame, 64 frames = 4 blocks of 16), the B operand 16 candidates'
-//     coordinate j of the same atom (replicated over the blocks); nine
-//     instructions per atom (i, j = x, y, z), 144 accumulators per lane.
+//     operand is a frame row (lane = frame, 64 frames = 4 blocks of 16), the B
+//     operand 16 candidates' coordinate j of the same atom; nine instructions
+//     per atom (i, j = x, y, z), 144 accumulators per lane.
 //   * every accumulator is the IEEE FMA chain over the atoms in ascending
 //     order -- one k per instruction, a fused multiply-add per element
 //     (tools/probes/mfma16_probe.hip: bit-identical to fmaf in k order) -- so
 //     the distances are the bits the one-center kernel and the CPU checker
 //     produce.
+//   * rows (round 4): the frames' QUAD copy, [tile][atom / 4][xyz][frame %
+//     256][atom % 4] -- one 16-byte load per lane is atoms a .. a + 3 of one
+//     axis of the lane's frame = the A operands of four consecutive atoms;
+//     three loads of 1 KB per wave and trip of 4 atoms where the frame-minor
+//     tiles took twelve of 256 B.  The per-wave queue of outstanding loads was
+//     what bounded the bytes in flight (profiles/r03/README.md).
+//   * candidates (round 4): B's lane-group broadcast (blgp 4 + g: lanes
+//     16 g .. 16 g + 15 feed all four blocks; tools/probes/mfma_bcast_probe.hip)
+//     lets ONE 16-byte load per lane carry four different (trip, axis) slices
+//     of the 16 candidates -- three loads per 16 atoms, every byte of them
+//     used, where every lane of all four groups used to fetch the same 16
+//     values: three loads per 4 atoms.
 //   * a lane ends up with 16 (frame, candidate) pairs, all of ONE candidate
 //     (l % 16) and 16 frames: it solves their quartics (early stop against the
 //     frame's distance BEFORE this pass), the results cross an LDS transposition
@@ -28,14 +35,7 @@
 //     ek_pass2_kernel's: candidate 0 updates the state (kcenters.py:298-306),
 //     the others' distances are kept (where a wave holds a finite one), the
 //     per-workgroup arg-max, and -- single shard -- the presumed order.
-//
-// What bounds it (10^6 x 300, builds without one part each): the matrix
-// instructions alone 0.64 ms -- 86 GFLOP at the 135-145 TFLOP/s the f32 matrix
-// pipe sustains --, streaming the rows beside them +0.18 ms (3.7 GB: both HBM
-// and the matrix pipe would have to run at ~90 % at once), the 16 quartic
-// solves per frame +0.14 ms (they do not overlap with another wave's matrix
-// instructions, see the stagger below): 0.95 ms per pass, 59 us per candidate
-// against 80 us for the 8-candidate vector form.
+#include <algorithm>
 #include "ek_common.h"
 #include "ek_qcp.h"
 #include "ek_reduce.h"
@@ -43,10 +43,6 @@
 
 typedef float ek_v16f __attribute__((ext_vector_type(16)));
 typedef float ek_v4f __attribute__((ext_vector_type(4)));
-
-#ifndef EK_P16_DIST
-#define EK_P16_DIST 2           // trips (of 4 atoms) the row loads run ahead
-#endif
 
 // LDS per wave: the frames' traces and current distances, then the 16 x 64
 // table of new distances (row stride 65: the writers of a register are 4
@@ -62,7 +58,7 @@ typedef float ek_v4f __attribute__((ext_vector_type(4)));
 
 template <bool FUSE>
 __global__ void __launch_bounds__(EK_BLOCK, 2)
-ek_pass16_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
+ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
                  float *__restrict__ dist, int32_t *__restrict__ assign,
                  float *__restrict__ vecs, int64_t n, int64_t n_pad, int A,
                  const float *__restrict__ ctile,
@@ -153,121 +149,138 @@ ek_pass16_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
         s_cur[tid] = cur0;      // read back after the loop, by this wave only
     }
 
-    const float *tb = tiles + (size_t)(f0 / EK_TILE) * 3 * (size_t)A * EK_TILE;
+    // ---- the contraction ------------------------------------------------------------
+    // rows: this tile of the quad copy; a trip of 4 atoms = 3 loads (x, y, z),
+    // 16 bytes per lane; candidates: [16 atoms][3 loads][lane group][candidate][4]
+    const int n_trip = A / 4;           // whole trips; A % 4 atoms follow
+    const int NQ = (A + 3) / 4;
+    const float *tb = qtiles + (size_t)(f0 / EK_TILE) * (size_t)NQ * (3 * EK_TILE * 4);
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)tb, 0, 3 * A * EK_TILE * 4, 0x00020000);
-    const int vo = tid * 4;
-    // non-temporal (aux bit 1): the frame stream is read once per pass
-#define EK_LD(SO, K)                                                           \
-    __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(            \
-                                  rs, vo + (K) * (EK_TILE * 4), (SO), 2))
+        (void *)tb, 0, NQ * (3 * EK_TILE * 16), 0x00020000);
+    const __amdgpu_buffer_rsrc_t cs = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)ctile, 0, ek_ctile_atoms(A) * (3 * 16 * 4), 0x00020000);
+    const int vo = tid * 16, co = lane * 16;
+    // (aux 2: non-temporal, the frame stream is read once per pass; loads past
+    // the end of either buffer return zeros and are never multiplied)
+    // (-DEK_P16_ABLATE=bits, measurement builds only: 1 no quartic solves, 2 no
+    // row loads, 4 no candidate loads; results are then meaningless)
+#ifndef EK_P16_ABLATE
+#define EK_P16_ABLATE 0
+#endif
+    const ek_v4f ablate_v = {1.0f + (float)tid, 0.5f, -0.25f, 2.0f};
+#define EK_LDR(TR, K)                                                          \
+    ((EK_P16_ABLATE & 2) ? ablate_v :                                          \
+    __builtin_bit_cast(ek_v4f, __builtin_amdgcn_raw_buffer_load_b128(          \
+                                   rs, vo, ((TR) * 3 + (K)) * (EK_TILE * 16), 2)))
+#define EK_LDC(SS, I)                                                          \
+    ((EK_P16_ABLATE & 4) ? ablate_v :                                          \
+    __builtin_bit_cast(ek_v4f, __builtin_amdgcn_raw_buffer_load_b128(          \
+                                   cs, co, ((SS) * 3 + (I)) * (EK_WAVE * 16), 0)))
     ek_v16f acc[9];
 #pragma unroll
     for (int q = 0; q < 9; ++q)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
             acc[q][r] = 0.f;
-
-    // rows (the HBM stream) run DR trips of 4 atoms ahead of the matrix
-    // instructions, the candidates (a few cache lines out of L2) DC = DR - 1
-    constexpr int DR = EK_P16_DIST, DC = DR - 1;
-    constexpr int NR = DR + 1, NC = DC + 1;
-    constexpr int GRP = NR * NC;            // buffers are back in phase (NR, NC coprime)
-    float X[NR][4], Y[NR][4], Z[NR][4];     // the rows of a trip of 4 atoms
-    ek_v4f Cq[NC][3];                       // its candidates: [xyz] -> 4 atoms
-    // candidate tile: [trip][candidate][xyz][atom of the trip] (ek_ctile_index)
-    const ek_v4f *cp = (const ek_v4f *)ctile + (size_t)(lane & 15) * 3;
-#define EK_ROWS16(B, TR)                                                       \
-    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                            \
-        const int so = ((TR) * 4 + e) * (3 * EK_TILE * 4);                     \
-        X[B][e] = EK_LD(so, 0);                                                \
-        Y[B][e] = EK_LD(so, 1);                                                \
-        Z[B][e] = EK_LD(so, 2);                                                \
-    }
-#define EK_CAND16(B, TR)                                                       \
-    _Pragma("unroll") for (int j = 0; j < 3; ++j)                              \
-        Cq[B][j] = cp[(size_t)(TR) * (16 * 3) + j];
-    // three of the nine matrix instructions of one atom: S_ij += x_i * y_j, j fixed
-#define EK_MFMA3(J, XX, YY, ZZ, CC)                                            \
+    constexpr int DR = 3;               // trips the row loads run ahead; DR + 1 buffers
+    ek_v4f R[DR + 1][3];                // [trip % 4][xyz] -> 4 atoms
+    ek_v4f Cq[2][3];                    // [super-trip % 2][load] -> 4 atoms
+    // three of the nine matrix instructions of one atom: S_ij += x_i * y_j, j
+    // fixed; the candidates come from lane group G of the register
+#define EK_MFMA3(J, XX, YY, ZZ, CC, G)                                         \
     {                                                                          \
-        acc[0 + J] = __builtin_amdgcn_mfma_f32_16x16x1f32(XX, CC, acc[0 + J], 0, 0, 0); \
-        acc[3 + J] = __builtin_amdgcn_mfma_f32_16x16x1f32(YY, CC, acc[3 + J], 0, 0, 0); \
-        acc[6 + J] = __builtin_amdgcn_mfma_f32_16x16x1f32(ZZ, CC, acc[6 + J], 0, 0, 0); \
+        acc[0 + J] = __builtin_amdgcn_mfma_f32_16x16x1f32(XX, CC, acc[0 + J], 0, 0, 4 + (G)); \
+        acc[3 + J] = __builtin_amdgcn_mfma_f32_16x16x1f32(YY, CC, acc[3 + J], 0, 0, 4 + (G)); \
+        acc[6 + J] = __builtin_amdgcn_mfma_f32_16x16x1f32(ZZ, CC, acc[6 + J], 0, 0, 4 + (G)); \
     }
-    const int n_trip = A / 4;           // whole trips; A % 4 atoms follow
-    // (trip t is in row buffer t % NR and candidate buffer t % NC)
-#pragma unroll
-    for (int k = 0; k < DR; ++k) {
-        if (k < DC)
-            EK_CAND16(k, k)
-        __builtin_amdgcn_sched_barrier(0);
-        EK_ROWS16(k, k)
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    // One trip: the 36 matrix instructions of trip t with the requests for the
-    // candidates of trip t + DC (first) and the rows of trip t + DR spread
-    // among them, one load behind every three matrix instructions: a wave
-    // issues in order, so a burst of fifteen loads that meets a full memory
-    // queue holds the matrix instructions behind it back; spread out, a load
-    // that has to wait costs the matrix pipe at most the slack of one
-    // instruction.  The order of the requests matters too: vector loads are
-    // counted in order, so waiting for a trip's candidates (a few cache lines
-    // out of L2) also waits for every load issued before them.  Asked for first
-    // and one trip later than the rows of the same trip, they are only behind
-    // rows that are needed before they are.
+    // slice (trip-in-super-trip TT, axis J) of the candidates is quad TT * 3 + J
+    // of its 16 atoms: load (quad / 4), lane group (quad % 4)
+    // One trip K (0 .. 7 of the unrolled pair of super-trips) at trip index TT:
+    // the 36 matrix instructions of its 4 atoms with the requests for the
+    // candidates of the NEXT 16 atoms (first trip of a super-trip, asked for
+    // before the rows of the same trip: vector loads are counted in order) and
+    // for the rows of trip TT + DR spread among them.
 #define EK_TRIP16(K, TT)                                                       \
     {                                                                          \
+        constexpr int SB = ((K) / 4) % 2;                                      \
         _Pragma("unroll") for (int e = 0; e < 4; ++e) {                        \
-            const int so = (((TT) + DR) * 4 + e) * (3 * EK_TILE * 4);          \
-            EK_MFMA3(0, X[(K) % NR][e], Y[(K) % NR][e], Z[(K) % NR][e],        \
-                     Cq[(K) % NC][0][e])                                       \
+            EK_MFMA3(0, R[(K) % 4][0][e], R[(K) % 4][1][e], R[(K) % 4][2][e],  \
+                     Cq[SB][(((K) % 4) * 3 + 0) / 4][e], (((K) % 4) * 3 + 0) % 4) \
             __builtin_amdgcn_sched_barrier(0);                                 \
-            if (e == 0) {                                                      \
-                EK_CAND16(((K) + DC) % NC, (TT) + DC)                          \
+            if ((K) % 4 == 0 && e < 3) {                                       \
+                Cq[1 - SB][e] = EK_LDC((TT) / 4 + 1, e);                       \
+                __builtin_amdgcn_sched_barrier(0);                             \
             }                                                                  \
-            X[((K) + DR) % NR][e] = EK_LD(so, 0);                              \
+            EK_MFMA3(1, R[(K) % 4][0][e], R[(K) % 4][1][e], R[(K) % 4][2][e],  \
+                     Cq[SB][(((K) % 4) * 3 + 1) / 4][e], (((K) % 4) * 3 + 1) % 4) \
             __builtin_amdgcn_sched_barrier(0);                                 \
-            EK_MFMA3(1, X[(K) % NR][e], Y[(K) % NR][e], Z[(K) % NR][e],        \
-                     Cq[(K) % NC][1][e])                                       \
-            __builtin_amdgcn_sched_barrier(0);                                 \
-            Y[((K) + DR) % NR][e] = EK_LD(so, 1);                              \
-            __builtin_amdgcn_sched_barrier(0);                                 \
-            EK_MFMA3(2, X[(K) % NR][e], Y[(K) % NR][e], Z[(K) % NR][e],        \
-                     Cq[(K) % NC][2][e])                                       \
-            __builtin_amdgcn_sched_barrier(0);                                 \
-            Z[((K) + DR) % NR][e] = EK_LD(so, 2);                              \
+            if (e < 3) {                                                       \
+                R[((K) + DR) % 4][e] = EK_LDR((TT) + DR, e);                   \
+                __builtin_amdgcn_sched_barrier(0);                             \
+            }                                                                  \
+            EK_MFMA3(2, R[(K) % 4][0][e], R[(K) % 4][1][e], R[(K) % 4][2][e],  \
+                     Cq[SB][(((K) % 4) * 3 + 2) / 4][e], (((K) % 4) * 3 + 2) % 4) \
             __builtin_amdgcn_sched_barrier(0);                                 \
         }                                                                      \
     }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        Cq[0][i] = EK_LDC(0, i);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < DR; ++k) {
+#pragma unroll
+        for (int x = 0; x < 3; ++x)
+            R[k][x] = EK_LDR(k, x);
+    }
+    __builtin_amdgcn_sched_barrier(0);
     int t0 = 0;
-    for (; t0 + GRP <= n_trip; t0 += GRP) {
-#pragma unroll
-        for (int k = 0; k < GRP; ++k)
-            EK_TRIP16(k, t0 + k)
+    for (; t0 + 8 <= n_trip; t0 += 8) {
+        EK_TRIP16(0, t0 + 0)
+        EK_TRIP16(1, t0 + 1)
+        EK_TRIP16(2, t0 + 2)
+        EK_TRIP16(3, t0 + 3)
+        EK_TRIP16(4, t0 + 4)
+        EK_TRIP16(5, t0 + 5)
+        EK_TRIP16(6, t0 + 6)
+        EK_TRIP16(7, t0 + 7)
     }
-#pragma unroll
-    for (int k = 0; k < GRP - 1; ++k) {
-        if (t0 + k < n_trip)            // wave-uniform
-            EK_TRIP16(k, t0 + k)
-    }
+    // up to seven whole trips more (wave-uniform branches)
+#define EK_REST16(K)                                                           \
+    if (t0 + (K) < n_trip)                                                     \
+        EK_TRIP16(K, t0 + (K))
+    EK_REST16(0)
+    EK_REST16(1)
+    EK_REST16(2)
+    EK_REST16(3)
+    EK_REST16(4)
+    EK_REST16(5)
+    EK_REST16(6)
     // the A % 4 atoms after the last whole trip, one at a time (their rows and
-    // candidates fetched for themselves: a product with the zeros past the end
-    // is never issued, the chain of an accumulator is exactly the A atoms)
+    // candidates fetched for themselves, every lane its own candidate's: a
+    // product with the zeros of the padding is never issued, the chain of an
+    // accumulator is exactly the A atoms)
     for (int a = 4 * n_trip; a < A; ++a) {
-        const int so = a * (3 * EK_TILE * 4);
-        const float x = EK_LD(so, 0), y = EK_LD(so, 1), z = EK_LD(so, 2);
+        const float *rq = tb + (size_t)n_trip * (3 * EK_TILE * 4) + tid * 4 + (a & 3);
+        const float x = rq[0], y = rq[EK_TILE * 4], z = rq[2 * EK_TILE * 4];
         const float c0 = ctile[ek_ctile_index(16, a, lane & 15, 0)];
         const float c1 = ctile[ek_ctile_index(16, a, lane & 15, 1)];
         const float c2 = ctile[ek_ctile_index(16, a, lane & 15, 2)];
-        EK_MFMA3(0, x, y, z, c0)
-        EK_MFMA3(1, x, y, z, c1)
-        EK_MFMA3(2, x, y, z, c2)
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x1f32(x, c0, acc[0], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_16x16x1f32(y, c0, acc[3], 0, 0, 0);
+        acc[6] = __builtin_amdgcn_mfma_f32_16x16x1f32(z, c0, acc[6], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x1f32(x, c1, acc[1], 0, 0, 0);
+        acc[4] = __builtin_amdgcn_mfma_f32_16x16x1f32(y, c1, acc[4], 0, 0, 0);
+        acc[7] = __builtin_amdgcn_mfma_f32_16x16x1f32(z, c1, acc[7], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_16x16x1f32(x, c2, acc[2], 0, 0, 0);
+        acc[5] = __builtin_amdgcn_mfma_f32_16x16x1f32(y, c2, acc[5], 0, 0, 0);
+        acc[8] = __builtin_amdgcn_mfma_f32_16x16x1f32(z, c2, acc[8], 0, 0, 0);
     }
+#undef EK_REST16
 #undef EK_TRIP16
 #undef EK_MFMA3
-#undef EK_CAND16
-#undef EK_ROWS16
-#undef EK_LD
+#undef EK_LDC
+#undef EK_LDR
 
     // ---- the lane's 16 pairs: candidate lane % 16, frames 16 b + 4 (lane / 16) + r ----
     {
@@ -287,7 +300,14 @@ ek_pass16_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
             float d = __builtin_inff();
             // (a frame of the last tile's padding has S = 0: a quadruple root,
             // fifty Newton steps for nothing)
-            if (cand < teff && f0 + wave * EK_WAVE + fr < n)
+            if (EK_P16_ABLATE & 1) {    // (keeps the accumulators alive, costs ~10 adds)
+                float t = S[0];
+#pragma unroll
+                for (int q = 1; q < 9; ++q)
+                    t += S[q];
+                if (t > 3e38f)
+                    d = 0.f;
+            } else if (cand < teff && f0 + wave * EK_WAVE + fr < n)
                 d = ek_rmsd_from_S_below(S, s_G[wave * EK_WAVE + fr], Gc, A,
                                          s_cur[wave * EK_WAVE + fr]);
             Dw[cand * EK_P16_DSTRIDE + fr] = d;
@@ -410,7 +430,7 @@ ek_pass16_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
     }
 }
 
-void ek_launch_pass16(bool fuse, const float *tiles, const double *G, float *dist,
+void ek_launch_pass16(bool fuse, const float *qtiles, const double *G, float *dist,
                       int32_t *assign, float *vecs, int64_t n, int64_t n_pad, int A,
                       const float *ctile, const double *ctrace, const EkPlan *plan,
                       EkBlockMax *blockmax, const EkFuse &fz, hipStream_t s)
@@ -420,10 +440,62 @@ void ek_launch_pass16(bool fuse, const float *tiles, const double *G, float *dis
     const unsigned blocks = (unsigned)((n + EK_BLOCK - 1) / EK_BLOCK);
     if (fuse)
         hipLaunchKernelGGL((ek_pass16_kernel<true>), dim3(blocks), dim3(EK_BLOCK), 0,
-                           s, tiles, G, dist, assign, vecs, n, n_pad, A, ctile,
+                           s, qtiles, G, dist, assign, vecs, n, n_pad, A, ctile,
                            ctrace, plan, blockmax, fz);
     else
         hipLaunchKernelGGL((ek_pass16_kernel<false>), dim3(blocks), dim3(EK_BLOCK), 0,
-                           s, tiles, G, dist, assign, vecs, n, n_pad, A, ctile,
+                           s, qtiles, G, dist, assign, vecs, n, n_pad, A, ctile,
                            ctrace, plan, blockmax, fz);
+}
+
+
+// ---- the quad copy of the frames ----------------------------------------------------
+// qtiles[((tile * NQ + a / 4) * 3 + k) * 256 + f % 256][a % 4], NQ = ceil(A / 4),
+// zeros for the atoms past the last: made once per loaded shard from the
+// frame-minor tiles (reads of 1 KB rows, 16-byte-per-lane writes).
+__global__ void __launch_bounds__(EK_BLOCK)
+ek_quad_tiles_kernel(const float *__restrict__ tiles, int A, int NQ,
+                     float *__restrict__ qtiles)
+{
+    const int l = threadIdx.x;
+    const size_t tile = blockIdx.x;
+    const float *src = tiles + tile * 3 * (size_t)A * EK_TILE + l;
+    ek_v4f *dst = (ek_v4f *)qtiles + tile * (size_t)NQ * 3 * EK_TILE + l;
+    for (int q = blockIdx.y; q < NQ; q += gridDim.y) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            ek_v4f v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int a = 4 * q + e;
+                v[e] = a < A ? src[(size_t)(3 * a + k) * EK_TILE] : 0.f;
+            }
+            dst[(size_t)(q * 3 + k) * EK_TILE] = v;
+        }
+    }
+}
+
+size_t ek_quad_tiles_bytes(int64_t n_tiles, int A)
+{
+    return (size_t)n_tiles * (size_t)((A + 3) / 4) * 3 * EK_TILE * 16;
+}
+
+void ek_launch_quad_tiles(const float *tiles, int64_t n_tiles, int A, float *qtiles,
+                          hipStream_t s)
+{
+    if (n_tiles <= 0)
+        return;
+    const int NQ = (A + 3) / 4;
+    // (grid.y: a few workgroups per tile while the shard is small)
+    const unsigned gy = (unsigned)std::max<int64_t>(
+        1, std::min<int64_t>(NQ, 2048 / std::max<int64_t>(n_tiles, 1)));
+    int64_t done = 0;
+    while (done < n_tiles) {            // grid.x is limited to 2^31 - 1
+        const int64_t cnt = std::min<int64_t>(n_tiles - done, 1 << 30);
+        hipLaunchKernelGGL(ek_quad_tiles_kernel, dim3((unsigned)cnt, gy),
+                           dim3(EK_BLOCK), 0, s,
+                           tiles + (size_t)done * 3 * (size_t)A * EK_TILE, A, NQ,
+                           qtiles + (size_t)done * (size_t)NQ * 3 * EK_TILE * 4);
+        done += cnt;
+    }
 }

@@ -682,7 +682,7 @@ void ek_launch_round_pass(const EkRound &r, hipStream_t s, bool with_order)
     fz.rows = r.rows;
     fz.vmask = r.vmask;
     if (r.T == 16) {
-        ek_launch_pass16(true, r.tiles, r.G, r.dist, r.assign, r.vecs, r.n, r.n_pad,
+        ek_launch_pass16(true, r.qtiles, r.G, r.dist, r.assign, r.vecs, r.n, r.n_pad,
                          r.A, r.ctile, r.ctrace, r.plan, r.blockmax, fz, s);
         return;
     }
@@ -693,11 +693,11 @@ void ek_launch_round_pass(const EkRound &r, hipStream_t s, bool with_order)
 }
 
 // the one-launch-per-step form: lay the candidates out, then stream the frames
-void ek_launch_pass(int T, const float *tiles, const double *G, float *dist,
-                    int32_t *assign, float *vecs, int64_t n, int64_t n_pad,
-                    int A, const unsigned char *recs, const EkPlan *plan,
-                    EkBlockMax *blockmax, float *ctile, double *ctrace,
-                    hipStream_t s)
+void ek_launch_pass(int T, const float *tiles, const float *qtiles, const double *G,
+                    float *dist, int32_t *assign, float *vecs, int64_t n,
+                    int64_t n_pad, int A, const unsigned char *recs,
+                    const EkPlan *plan, EkBlockMax *blockmax, float *ctile,
+                    double *ctrace, hipStream_t s)
 {
     if (n <= 0)
         return;
@@ -707,7 +707,7 @@ void ek_launch_pass(int T, const float *tiles, const double *G, float *dist,
     if (T == 16) {
         hipLaunchKernelGGL((ek_ctile_kernel<16>), dim3(cb), dim3(EK_BLOCK), 0, s,
                            recs, plan, A, ctile, ctrace);
-        ek_launch_pass16(false, tiles, G, dist, assign, vecs, n, n_pad, A, ctile,
+        ek_launch_pass16(false, qtiles, G, dist, assign, vecs, n, n_pad, A, ctile,
                          ctrace, plan, blockmax, EkFuse(), s);
         return;
     }

@@ -40,6 +40,16 @@ extern "C" void h_batch(const float *S, const double *Gx, const double *Gy,
         below[i] = ek_rmsd_from_S_below(s, Gx[i], Gy[i], n_atoms, cur[i]);
     }
 }
+extern "C" void h_cert(const float *S, const double *Gsum, int n_atoms,
+                       const float *cur, int64_t m, unsigned char *out)
+{
+    for (int64_t i = 0; i < m; ++i) {
+        float s[9];
+        for (int j = 0; j < 9; ++j)
+            s[j] = S[9 * i + j];
+        out[i] = ek_far_certified_f32(s, (float)Gsum[i], n_atoms, cur[i]) ? 1 : 0;
+    }
+}
 '''
 
 
@@ -57,6 +67,7 @@ def host(tmp_path_factory):
                            "-o", so])
     lib = C.CDLL(so)
     lib.h_batch.restype = None
+    lib.h_cert.restype = None
     return lib
 
 
@@ -175,3 +186,80 @@ def test_coincident_largest_roots(host, eps):
         assert stops == 0          # never trusted
     if eps >= 1e-1:
         assert stops > m           # separated again: most far solves stop early
+
+
+@pytest.mark.parametrize("family", ["generic", "s1~s2", "s2~-s3", "s2~s3", "rank1",
+                                    "rank2", "isotropic", "tiny", "huge"])
+def test_float32_far_certificate_is_sound(host, family):
+    """ek_far_certified_f32: S = U diag(s1, s2, s3) V^T with the spectrum drawn
+    from the family named -- generic, and every way two roots of the quartic
+    can come close -- and `cur` placed around the true distance.  Where the
+    certificate says "far": the full reference iteration ends at or above
+    `cur`; the largest root really is separated ((s2 + s3)^2 >= 1e-4 q, from a
+    float64 SVD); and on generic spectra it certifies most far pairs."""
+    rng = np.random.default_rng(abs(hash(family)) % 10**6)
+    m, A = 300000, 30
+    s1 = A * 10.0 ** rng.uniform(-1, 1, m)
+    u, v = rng.random(m), rng.random(m)
+    tiny = 10.0 ** rng.uniform(-9, -1, m)
+    sign = np.where(rng.random(m) < 0.5, -1.0, 1.0)
+    if family == "generic":
+        s2, s3 = s1 * u, s1 * u * v * sign
+    elif family == "s1~s2":
+        s2, s3 = s1 * (1 - tiny), s1 * u * sign
+    elif family == "s2~-s3":
+        s2 = s1 * u
+        s3 = -s2 * (1 - tiny)
+    elif family == "s2~s3":
+        s2 = s1 * u
+        s3 = s2 * (1 - tiny)
+    elif family == "rank1":
+        s2, s3 = s1 * tiny, s1 * tiny * v * sign
+    elif family == "rank2":
+        s2, s3 = s1 * u, s1 * tiny * u * sign
+    elif family == "isotropic":
+        s2, s3 = s1 * (1 - tiny), s1 * (1 - tiny * (1 + v)) * sign
+    elif family == "tiny":
+        s1 = s1 * 1e-15
+        s2, s3 = s1 * u, s1 * u * v * sign
+    else:
+        s1 = s1 * 1e9
+        s2, s3 = s1 * u, s1 * u * v * sign
+    sig = np.stack([s1, s2, s3], axis=1)
+    S = np.einsum("mik,mk,mjk->mij", _rotations(rng, m), sig, _rotations(rng, m))
+    S = np.ascontiguousarray(S.reshape(m, 9), dtype=np.float32)
+    # the spectrum of the float32 matrix the kernels would hold
+    M = S.astype(np.float64).reshape(m, 3, 3)
+    sv = np.linalg.svd(M, compute_uv=False)
+    t3 = np.where(np.linalg.det(M) < 0, -sv[:, 2], sv[:, 2])
+    lam = sv[:, 0] + sv[:, 1] + t3
+    q = (sv ** 2).sum(1)
+    Gsum = 2 * lam + A * lam.clip(1e-300) / A * 10.0 ** rng.uniform(-7, 1, m)
+    Gx = np.ascontiguousarray(Gsum / 2)
+    full = np.empty(m, dtype=np.float32)
+    below = np.empty(m, dtype=np.float32)
+    inf = np.full(m, np.inf, dtype=np.float32)
+    host.h_batch(S.ctypes.data_as(C.c_void_p), Gx.ctypes.data_as(C.c_void_p),
+                 Gx.ctypes.data_as(C.c_void_p), A, inf.ctypes.data_as(C.c_void_p),
+                 C.c_int64(m), full.ctypes.data_as(C.c_void_p),
+                 below.ctypes.data_as(C.c_void_p))
+    cert = np.empty(m, dtype=np.uint8)
+    total = 0
+    for factor in (0.3, 0.8, 0.97, 0.9999, 1.0, 1.0002, 1.3):
+        cur = (full * np.float32(factor)).astype(np.float32)
+        host.h_cert(S.ctypes.data_as(C.c_void_p), Gsum.ctypes.data_as(C.c_void_p), A,
+                    cur.ctypes.data_as(C.c_void_p), C.c_int64(m),
+                    cert.ctypes.data_as(C.c_void_p))
+        yes = cert.astype(bool)
+        assert not np.any(full[yes] < cur[yes])
+        assert np.all((sv[yes, 1] + t3[yes]) ** 2 >= 1e-4 * q[yes])
+        if factor >= 1.0:
+            assert not np.any(yes & (full > 0))
+        if factor == 0.8 and family in ("generic", "tiny", "huge"):
+            # (pairs whose mean square distance is not small beside lambda / A:
+            # the bracket of s1^2 is 1e-3 wide)
+            roomy = (Gsum - 2 * lam) > 0.05 * lam
+            assert yes[roomy].mean() > 0.9
+        total += int(yes.sum())
+    if family in ("s2~-s3", "rank1"):
+        assert total < 0.12 * 7 * m     # (only where `tiny` is not tiny)
