@@ -85,13 +85,10 @@ def hybrid(X, distance_method, n_iters=5, n_clusters=np.inf, dist_cutoff=0,
             "We haven't implemented kcenters 'random_first_center' yet.")
     if mpi_mode:
         # hybrid.py:112-162 in MPI mode: every rank passes its own frames
-        if init_centers is not None:
-            raise ImproperlyConfigured(
-                "mpi_mode does not take init_centers in this build")
         from .. import sharded
         return sharded.fit_sharded(
             X, n_clusters=n_clusters, dist_cutoff=dist_cutoff, n_iters=n_iters,
-            random_state=random_state)
+            random_state=random_state, init_centers=init_centers)
 
     with FrameStore.from_array(as_xyz(X), device=device) as store:
         result = _kc._kcenters_device(X, n_clusters, dist_cutoff, init_centers,

@@ -98,15 +98,16 @@ def kcenters(traj, distance_method, n_clusters=np.inf, dist_cutoff=0,
             "We haven't implemented kcenters 'random_first_center' yet.")
     if mpi_mode:
         # every rank of the torch.distributed group passes its own frames
-        # (kcenters.py:314-378); RMSD only, no warm start
-        if not util.is_device_rmsd(distance_method) or init_centers is not None:
+        # (kcenters.py:314-378); RMSD only
+        if not util.is_device_rmsd(distance_method):
             raise ImproperlyConfigured(
-                "mpi_mode is available for metric 'rmsd' without init_centers "
+                "mpi_mode is available for metric 'rmsd' "
                 "(one process per GPU over torch.distributed)")
         from .. import sharded
         return sharded.fit_sharded(
             traj, n_clusters=n_clusters, dist_cutoff=dist_cutoff, n_iters=0,
-            use_triangle_inequality=use_triangle_inequality)
+            use_triangle_inequality=use_triangle_inequality,
+            init_centers=init_centers)
 
     if util.is_device_rmsd(distance_method):
         return _kcenters_device(traj, n_clusters, dist_cutoff, init_centers,

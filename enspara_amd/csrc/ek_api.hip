@@ -8,7 +8,10 @@
 #include <string.h>
 
 #include <algorithm>
+#include <condition_variable>
+#include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 
 void ek_msm_scratch_free(void *w);      // ek_msm.hip
@@ -44,6 +47,69 @@ int ek_set_error(int code, const char *fmt, ...)
                            __LINE__);                                          \
     } while (0)
 
+// A few host threads that copy slices of a chunk into pinned memory
+// (ek_load_frames); they live as long as the context that first needed them.
+struct EkCopyPool {
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv, done_cv;
+    const char *src = nullptr;
+    char *dst = nullptr;
+    size_t bytes = 0, per = 0;
+    int next = 0, n_parts = 0, left = 0;
+    bool quit = false;
+    void worker()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv.wait(lk, [&] { return quit || next < n_parts; });
+            if (quit)
+                return;
+            const int part = next++;
+            const size_t lo = std::min(bytes, (size_t)part * per);
+            const size_t hi = std::min(bytes, lo + per);
+            const char *s_ = src;
+            char *d_ = dst;
+            lk.unlock();
+            if (hi > lo)
+                memcpy(d_ + lo, s_ + lo, hi - lo);
+            lk.lock();
+            if (--left == 0)
+                done_cv.notify_all();
+        }
+    }
+    void start(int n)
+    {
+        for (int i = (int)th.size(); i < n; ++i)
+            th.emplace_back([this] { worker(); });
+    }
+    // copy `n` bytes in slices of 2 MiB-aligned size, all threads; returns when done
+    void copy(char *d, const char *s, size_t n)
+    {
+        const int parts = (int)th.size();
+        std::unique_lock<std::mutex> lk(mu);
+        src = s;
+        dst = d;
+        bytes = n;
+        per = (n / parts + ((size_t)2 << 20) - 1) / ((size_t)2 << 20) * ((size_t)2 << 20);
+        next = 0;
+        n_parts = left = parts;
+        cv.notify_all();
+        done_cv.wait(lk, [&] { return left == 0; });
+        n_parts = 0;
+    }
+    ~EkCopyPool()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            quit = true;
+        }
+        cv.notify_all();
+        for (auto &t : th)
+            t.join();
+    }
+};
+
 struct ek_ctx {
     int device = 0;
     int64_t n = 0;
@@ -71,7 +137,13 @@ struct ek_ctx {
     int32_t hist_cap = 0;
     EkCtl *ctl = nullptr;
 
-    float *stage = nullptr;      // AoS staging for host uploads
+    // host uploads (ek_load_frames): two pinned host buffers filled by a few
+    // threads, two device staging buffers, an event per pair
+    float *stage[2] = {nullptr, nullptr};    // AoS staging on the device
+    float *pin[2] = {nullptr, nullptr};      // pinned host memory
+    hipEvent_t up_ev[2] = {nullptr, nullptr};
+    bool up_busy[2] = {false, false};        // the event of the pair was recorded
+    EkCopyPool *pool = nullptr;
     int64_t stage_frames = 0;
     float *cen_aos = nullptr;    // centred center-major centers
     double *cen_G = nullptr;
@@ -339,7 +411,13 @@ static int ek_free_all(ek_ctx *c)
     (void)hipFree(c->blockmax);
     (void)hipFree(c->hist);
     (void)hipFree(c->ctl);
-    (void)hipFree(c->stage);
+    for (int b = 0; b < 2; ++b) {
+        (void)hipFree(c->stage[b]);
+        (void)hipHostFree(c->pin[b]);
+        if (c->up_ev[b])
+            (void)hipEventDestroy(c->up_ev[b]);
+    }
+    delete c->pool;
     (void)hipFree(c->cen_aos);
     (void)hipFree(c->cen_G);
     (void)hipFree(c->cen_tiles);
@@ -643,29 +721,69 @@ extern "C" int ek_load_frames(ek_ctx *c, const float *xyz, int64_t first,
                                 c->aos, c->stream);
         EK_CHECK_LAUNCH();
     } else {
-        // stage through a device buffer in tile-aligned chunks (<= 256 MiB)
-        int64_t chunk = (int64_t)((256u << 20) / (frame_floats * sizeof(float)));
+        // Pageable host memory reaches the device through the driver's own bounce
+        // buffer at ~16 GB/s (3.6 GB: 0.23 s next to a 0.35 s fit).  Here: chunks
+        // of <= 128 MiB (whole tiles; EK_UPLOAD_CHUNK_MB: every chunk costs ~0.75 ms
+        // beside its bytes at ~53 GB/s, measured) copied by a few host threads
+        // (EK_UPLOAD_THREADS, default 8) into one of two
+        // PINNED buffers, a DMA from there into one of two device staging buffers
+        // and the layout kernel behind it on the context's stream -- while the
+        // threads fill the other buffer.  The caller's array has been read
+        // completely when this returns; the stream may still be working.
+        size_t chunk_mb = 128;
+        if (const char *e = getenv("EK_UPLOAD_CHUNK_MB"))
+            chunk_mb = (size_t)std::max(1, std::min(atoi(e), 1024));
+        int64_t chunk = (int64_t)((chunk_mb << 20) / (frame_floats * sizeof(float)));
         chunk = std::max<int64_t>(EK_TILE, chunk / EK_TILE * EK_TILE);
         chunk = std::min<int64_t>(chunk, (count + EK_TILE - 1) / EK_TILE * EK_TILE);
-        if (chunk > c->stage_frames) {
+        if (chunk != c->stage_frames) {
             EK_HIP(hipStreamSynchronize(c->stream));
-            (void)hipFree(c->stage);
-            c->stage = nullptr;
+            for (int b = 0; b < 2; ++b) {
+                (void)hipFree(c->stage[b]);
+                (void)hipHostFree(c->pin[b]);
+                c->stage[b] = c->pin[b] = nullptr;
+                c->up_busy[b] = false;
+            }
             c->stage_frames = 0;
-            EK_HIP(hipMalloc((void **)&c->stage,
-                             (size_t)chunk * frame_floats * sizeof(float)));
+            const size_t bytes = (size_t)chunk * frame_floats * sizeof(float);
+            for (int b = 0; b < 2; ++b) {
+                EK_HIP(hipMalloc((void **)&c->stage[b], bytes));
+                EK_HIP(hipHostMalloc((void **)&c->pin[b], bytes, hipHostMallocDefault));
+                if (!c->up_ev[b])
+                    EK_HIP(hipEventCreateWithFlags(&c->up_ev[b], hipEventDisableTiming));
+            }
             c->stage_frames = chunk;
         }
-        for (int64_t done = 0; done < count; done += chunk) {
+        int n_thr = 8;
+        if (const char *e = getenv("EK_UPLOAD_THREADS"))
+            n_thr = atoi(e);
+        n_thr = std::max(1, std::min(n_thr, 64));
+        int k = 0;
+        for (int64_t done = 0; done < count; done += chunk, ++k) {
+            const int b = k & 1;
             const int64_t cnt = std::min(chunk, count - done);
-            EK_HIP(hipMemcpyAsync(c->stage, xyz + (size_t)done * frame_floats,
-                                  (size_t)cnt * frame_floats * sizeof(float),
-                                  hipMemcpyHostToDevice, c->stream));
-            ek_launch_prepare_tiles(c->stage, cnt, c->A, c->tiles, c->G,
+            const size_t bytes = (size_t)cnt * frame_floats * sizeof(float);
+            if (c->up_busy[b])      // the DMA and the kernel that read this pair
+                EK_HIP(hipEventSynchronize(c->up_ev[b]));
+            const char *src = (const char *)(xyz + (size_t)done * frame_floats);
+            char *dst = (char *)c->pin[b];
+            if (bytes < ((size_t)4 << 20) || n_thr == 1) {
+                memcpy(dst, src, bytes);
+            } else {
+                if (!c->pool)
+                    c->pool = new (std::nothrow) EkCopyPool();
+                if (!c->pool)
+                    return ek_fail(EK_EARG, "ek_load_frames: out of host memory");
+                c->pool->start(n_thr);
+                c->pool->copy(dst, src, bytes);
+            }
+            EK_HIP(hipMemcpyAsync(c->stage[b], c->pin[b], bytes, hipMemcpyHostToDevice,
+                                  c->stream));
+            ek_launch_prepare_tiles(c->stage[b], cnt, c->A, c->tiles, c->G,
                                     first + done, c->n, c->aos, c->stream);
             EK_CHECK_LAUNCH();
-            // the staging buffer is reused by the next chunk
-            EK_HIP(hipStreamSynchronize(c->stream));
+            EK_HIP(hipEventRecord(c->up_ev[b], c->stream));
+            c->up_busy[b] = true;
         }
     }
     c->loaded = true;
@@ -3234,6 +3352,8 @@ static int ek_ms_check(ek_ctx *c, const char *who)
     return EK_OK;
 }
 
+static int ek_ms_begin_T(ek_ctx *c, int32_t first_label, int32_t limit, int T);
+
 extern "C" int ek_ms_begin(ek_ctx *c, int32_t first_label, int32_t limit)
 {
     int rc = ek_ms_check(c, "ek_ms_begin");
@@ -3245,6 +3365,14 @@ extern "C" int ek_ms_begin(ek_ctx *c, int32_t first_label, int32_t limit)
     if (T < 4)
         return ek_fail(EK_ESTATE, "ek_ms_begin: multi-candidate rounds are off "
                                   "(option key 4 = 1: use ek_kcenters_step)");
+    return ek_ms_begin_T(c, first_label, limit, T);
+}
+
+// rounds of T candidates from the state as it stands (also where a run changes
+// its form: ek_ms_run)
+static int ek_ms_begin_T(ek_ctx *c, int32_t first_label, int32_t limit, int T)
+{
+    int rc;
     EK_HIP(hipSetDevice(c->device));
     rc = ek_ensure_hist(c, limit);
     if (rc)
@@ -3404,11 +3532,27 @@ extern "C" int ek_ms_run(ek_ctx *c, int32_t first_label, int32_t max_new,
                        c->ms_peers, c->ms_x.world);
     if (first_label < 0 || max_new < 0)
         return ek_fail(EK_EARG, "ek_ms_run: negative argument");
-    rc = ek_ms_begin(c, first_label, first_label + max_new);
+    // Rounds of 8 or of 16 candidates: early in a fit every new center reshapes
+    // most frames' distances and a round accepts one to three of its guesses --
+    // eight of them then cost less than sixteen.  ek_run_rounds moves between
+    // the forms by measured centers per ms; here every shard has to take the
+    // SAME decision at the same round, so it is taken from what they all see
+    // alike: the centers the rounds of a batch accepted.  Rounds of 8 while they
+    // accept fewer than 6.5; a batch of 16 that accepts fewer than 8.5 per round
+    // goes back to 8 and the next try waits twice as many batches.  A change of
+    // form costs one exchange without a pass (the state's farthest frames are
+    // offered again).  Results do not depend on the form.
+    const int Tmax = ek_pick_cands(c);
+    if (Tmax < 4)
+        return ek_fail(EK_ESTATE, "ek_ms_run: multi-candidate rounds are off "
+                                  "(option key 4 = 1: use ek_kcenters_step)");
+    const bool ladder = Tmax == 16 && c->cands == -1 && c->adapt;
+    int T = ladder ? 8 : Tmax;
+    rc = ek_ms_begin_T(c, first_label, first_label + max_new, T);
     if (rc)
         return rc;
     EkRound R;
-    ek_round_of(c, c->ms_T, dist_cutoff, R);
+    ek_round_of(c, T, dist_cutoff, R);
     EkMsXchg x = c->ms_x;
     x.sys = 1;
     x.src = c->ms_mbox;
@@ -3420,11 +3564,16 @@ extern "C" int ek_ms_run(ek_ctx *c, int32_t first_label, int32_t max_new,
     cr.n_done = first_label;
     EkMsState st;
     memset(&st, 0, sizeof(st));
-    double per_round = 0.6 * c->ms_T;
+    double per_round = 0.6 * T;
     int32_t rounds_before = 0, passes = 0;
+    int wait16 = 0, next_wait = 1;
+    for (int k = 0; k < 4; ++k)
+        c->st_rounds[k] = c->st_centers[k] = 0;
     while (max_new > 0) {
         const int32_t left = goal - cr.n_done;
-        const int32_t batch = std::max(2, std::min(256, (int32_t)(left / per_round) + 2));
+        int32_t batch = std::max(2, std::min(256, (int32_t)(left / per_round) + 2));
+        if (ladder)
+            batch = std::min(batch, T == 8 ? 24 : 64);
         for (int32_t r = 0; r < batch; ++r) {
             rc = ek_ms_enqueue_local(c, R, x);
             if (rc)
@@ -3441,9 +3590,37 @@ extern "C" int ek_ms_run(ek_ctx *c, int32_t first_label, int32_t max_new,
         const int32_t ran = cr.n_rounds - rounds_before;
         rounds_before = cr.n_rounds;
         passes += ran;
+        c->st_rounds[ek_form_slot(T)] += ran;
+        c->st_centers[ek_form_slot(T)] += cr.n_done - before;
         if (st.err || st.mode == 0 || cr.stopped || cr.n_done >= goal)
             break;
         per_round = std::max(1.0, (double)(cr.n_done - before) / std::max(ran, 1));
+        if (ladder && ran > 0) {
+            int want = T;
+            if (T == 8) {
+                if (wait16 > 0)
+                    --wait16;
+                else if (per_round >= 6.5)
+                    want = 16;
+            } else if (per_round < 8.5) {
+                want = 8;
+                wait16 = next_wait;
+                next_wait = std::min(2 * next_wait, 64);
+            } else {
+                next_wait = 1;
+            }
+            if (want != T) {
+                ek_launch_round_flush(R, c->stream);    // the chain still pending
+                EK_CHECK_LAUNCH();
+                rc = ek_ms_begin_T(c, cr.n_done, goal, want);
+                if (rc)
+                    return rc;
+                T = want;
+                ek_round_of(c, T, dist_cutoff, R);
+                rounds_before = 0;
+                per_round = std::max(per_round, 0.6 * T);
+            }
+        }
     }
     EK_HIP(hipEventRecord(c->ev1, c->stream));
     rc = ek_ms_end(c);

@@ -59,6 +59,15 @@ class DeviceShard:
     def set_triangle_inequality(self, on):
         self.store.set_option(11, 1 if on else 0)
 
+    def assign_nearest(self, centers_xyz):
+        """every local frame against the given centers (float32 [K, A, 3]):
+        the state becomes (nearest center, distance), util.py:199-203"""
+        self.store.assign_nearest(centers_xyz)
+
+    def state(self):
+        """-> (distances float32 [n_local], labels int32 [n_local]) on the host"""
+        return self.store.download_state()
+
     def progress(self):
         """-> number of centers so far; synchronises"""
         _, _, n_done = self.store.history(0, 0)
@@ -460,6 +469,54 @@ def _kcenters_sharded_rounds(shard, first_label, max_new, dist_cutoff, group,
                                                       dtype=np.float32)
 
 
+def warm_start_sharded(shard, init_centers, group=None):
+    """The warm start of the reference's k-centers (kcenters.py:200-206) over
+    all ranks' shards: every frame goes to its nearest initial center
+    (util.assign_to_nearest_center: strict <, the lower index wins ties) and
+    every OCCUPIED label is represented by its member closest to that center
+    (util.find_cluster_centers: the first such member) -- first in the GLOBAL
+    order, rank r's frames following rank r-1's, so that the result is the
+    single-process one.  (The reference's MPI mode runs find_cluster_centers on
+    each rank's local arrays, kcenters.py:205: indices that mean different
+    frames on different ranks.  Not reproduced.)
+
+    Every rank passes the same ``init_centers``.  Returns the list of global
+    frame indices, one per occupied label in label order: the k-centers loop
+    continues from ``first_label = len(result)`` (kcenters.py:306)."""
+    import torch.distributed as dist
+    world, rank = _world(group)
+    collective = dist.is_available() and dist.is_initialized()
+    from .cluster.util import _stack_centers
+    centers = _stack_centers([c for c in init_centers])
+    K0 = int(centers.shape[0])
+    shard.assign_nearest(centers)
+    d, a = shard.state()
+    d = np.asarray(d, dtype=np.float64)
+    a = np.asarray(a, dtype=np.int64)
+    best_d = np.full(K0, np.inf, dtype=np.float64)
+    best_g = np.full(K0, -1, dtype=np.int64)
+    if len(a):
+        # per label: smallest distance, then smallest index
+        order = np.lexsort((np.arange(len(a)), d, a))
+        lab = a[order]
+        first = np.flatnonzero(np.r_[True, lab[1:] != lab[:-1]])
+        best_d[lab[first]] = d[order[first]]
+        best_g[lab[first]] = shard.offset + order[first]
+    tables = [(best_d, best_g)]
+    if collective and world > 1:
+        tables = [None] * world
+        dist.all_gather_object(tables, (best_d, best_g), group=group)
+    ctr = []
+    for lab in range(K0):
+        win_d, win_g = np.inf, -1
+        for bd, bg in tables:               # rank order = global frame order
+            if bg[lab] >= 0 and (win_g < 0 or bd[lab] < win_d):
+                win_d, win_g = bd[lab], int(bg[lab])
+        if win_g >= 0:
+            ctr.append(win_g)
+    return ctr
+
+
 def shard_bounds(n_total, world, rank, align=256):
     """Contiguous, tile-aligned split of n_total frames over ``world`` ranks.
     -> (offset, count)"""
@@ -697,7 +754,8 @@ def khybrid_sharded(shard, n_clusters, dist_cutoff=0.0, n_iters=5,
 # estimator-level entry: the reference's mpi_mode
 # ---------------------------------------------------------------------------
 def fit_sharded(traj, n_clusters=None, dist_cutoff=0.0, n_iters=0,
-                random_state=None, group=None, use_triangle_inequality=False):
+                random_state=None, group=None, use_triangle_inequality=False,
+                init_centers=None):
     """k-centers (+ ``n_iters`` PAM sweeps) where every rank of the initialised
     ``torch.distributed`` group passes ITS OWN frames -- what ``mpi_mode=True``
     means in the reference (kcenters.py:314-378, kmedoids.py MPI branch): rank
@@ -708,7 +766,8 @@ def fit_sharded(traj, n_clusters=None, dist_cutoff=0.0, n_iters=0,
     as (rank, local frame index) pairs (kcenters.py:375-376), ``assignments`` /
     ``distances`` for this rank's frames, ``centers`` = the centers'
     coordinates (float32 [A, 3] each), the same list on every rank.
-    ``random_state`` must be the same on every rank."""
+    ``random_state`` and ``init_centers`` (a warm start, kcenters.py:200-206:
+    see ``warm_start_sharded``) must be the same on every rank."""
     import torch
     import torch.distributed as dist
     from .cluster import util
@@ -748,10 +807,17 @@ def fit_sharded(traj, n_clusters=None, dist_cutoff=0.0, n_iters=0,
         store.reset_state()
         shard = DeviceShard(store)
         with torch.cuda.stream(tstream):
+            med = []
+            if init_centers is not None:
+                med = warm_start_sharded(shard, init_centers, group=group)
+                # (the shards' tables of accepted centers would lack these: the
+                # tile skip is an optimisation only, results do not change)
+                use_triangle_inequality = False
             idx, _ = kcenters_sharded(
-                shard, 0, max_new, float(dist_cutoff or 0.0), group=group,
+                shard, len(med), max(0, max_new - len(med)),
+                float(dist_cutoff or 0.0), group=group,
                 use_triangle_inequality=use_triangle_inequality)
-            med = [int(g) for g in idx]
+            med = med + [int(g) for g in idx]
             for _ in range(int(n_iters)):
                 med = pam_sweep_sharded(shard, med, random_state=rs,
                                         group=group)

@@ -200,6 +200,18 @@ class HostShard(_PamMixin):
     def progress(self):
         return self.n_done
 
+    # -- warm start (sharded.warm_start_sharded) ---------------------------------
+    def assign_nearest(self, centers_xyz):
+        if self.n == 0:
+            return
+        cc, Gc = qcp.center_and_trace(centers_xyz)
+        a, d = qcp.assign_nearest(self.P.c, self.P.G, cc, Gc)
+        self.dist[:] = d
+        self.assign[:] = a
+
+    def state(self):
+        return self.dist, self.assign
+
     def history(self, first, count):
         idx = np.full(max(count, 1), -1, dtype=np.int64)
         cd = np.zeros(max(count, 1), dtype=np.float32)

@@ -212,6 +212,43 @@ def test_two_device_shards_on_one_gpu(tmp_path, n, A, K, tmpl, iters, cands,
         np.concatenate([p["d"] for p in parts]).astype(np.float64), wd)
 
 
+@pytest.mark.parametrize("world,n,A,K,tmpl,iters,cands", [
+    (8, 60000, 30, 260, 400, 1, -1),    # the ladder of 8 / 16 candidates per round
+    (8, 3000, 12, 40, 9, 0, 16),        # shards of one or two tiles, some empty
+])
+def test_eight_processes_on_one_gpu(tmp_path, world, n, A, K, tmpl, iters, cands):
+    """BASELINE.json configs[3]'s process layout -- EIGHT ranks, one process
+    each, every rank's mailbox mapped into every other by hipIpc, the exchange
+    of a round written and polled on the device (ek_ms_run) -- as far as one
+    GPU allows: all eight contexts share it.  k-hybrid (the PAM exchanges go
+    through gloo) against the single-process oracle."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = str(s.getsockname()[1])
+    s.close()
+    out = str(tmp_path / "r")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = [subprocess.Popen([sys.executable, "-c", _CHILD2, ROOT, str(r), str(world),
+                               port, out, str(n), str(A), str(K), str(tmpl),
+                               str(iters), str(cands), "ipc"],
+                              env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True)
+             for r in range(world)]
+    logs = [p.communicate(timeout=1200)[0] for p in procs]
+    for p, log in zip(procs, logs):
+        assert p.returncode == 0, log[-4000:]
+    parts = [np.load(out + ".%d.npz" % r) for r in range(world)]
+    x = synth.synth(n, A, tmpl, seed=21)
+    inds, wa, wd = _expected(x, K, iters, 5)
+    for p in parts:
+        np.testing.assert_array_equal(p["med"], inds)
+    np.testing.assert_array_equal(np.concatenate([p["a"] for p in parts]), wa)
+    np.testing.assert_array_equal(
+        np.concatenate([p["d"] for p in parts]).astype(np.float64), wd)
+
+
 _CHILD_MBOX = r"""
 import sys, threading
 sys.path.insert(0, sys.argv[1])
@@ -415,9 +452,18 @@ mine = x[lo:lo + cnt]
 kc = KCenters("rmsd", n_clusters=K, mpi_mode=True).fit(mine)
 hy = KHybrid("rmsd", n_clusters=K, kmedoids_updates=2, random_state=3,
              mpi_mode=True).fit(mine)
+# a warm start (kcenters.py:200-213): the same initial centers on every rank
+init = [x[5], x[n // 2], x[7], x[5]]
+ws = KCenters("rmsd", n_clusters=K, mpi_mode=True).fit(mine, init_centers=init)
+wh = KHybrid("rmsd", n_clusters=K, kmedoids_updates=1, random_state=5,
+             mpi_mode=True).fit(mine, init_centers=init)
 np.savez(out + ".%d.npz" % rank, lo=lo,
          kc_ci=np.array(kc.center_indices_), kc_a=kc.labels_, kc_d=kc.distances_,
          kc_c=np.array(kc.centers_),
+         ws_ci=np.array(ws.center_indices_), ws_a=ws.labels_, ws_d=ws.distances_,
+         ws_c=np.array(ws.centers_),
+         wh_ci=np.array(wh.center_indices_), wh_a=wh.labels_, wh_d=wh.distances_,
+         wh_c=np.array(wh.centers_),
          hy_ci=np.array(hy.center_indices_), hy_a=hy.labels_, hy_d=hy.distances_,
          hy_c=np.array(hy.centers_))
 dist.barrier()
@@ -456,7 +502,14 @@ def test_estimators_in_mpi_mode(tmp_path, world, backend, n, K):
     wi, wd, wa = list(inds), d.copy(), a.copy()
     for _ in range(2):
         wi, wd, wa = oc.pam_update(x, wi, wa, wd, random_state=rs)
-    for key, want_i, want_a, want_d in (("kc", inds, a, d), ("hy", wi, wa, wd)):
+    # the warm starts: the single-process oracle from the same initial centers
+    init = [x[5], x[n // 2], x[7], x[5]]
+    si, sa, sd = oc.kcenters(x, n_clusters=K, init_centers=init)
+    assert len(si) == K
+    hi, hd, ha = oc.pam_update(x, list(si), sa.copy(), sd.copy(),
+                               random_state=np.random.RandomState(5))
+    for key, want_i, want_a, want_d in (("kc", inds, a, d), ("hy", wi, wa, wd),
+                                        ("ws", si, sa, sd), ("wh", hi, ha, hd)):
         for p in parts:             # (rank, local index) pairs, kcenters.py:375-376
             got = [starts[int(r)] + int(i) for r, i in p[key + "_ci"]]
             assert got == [int(i) for i in want_i]

@@ -276,3 +276,60 @@ def test_pam_sweep_without_process_group():
         np.testing.assert_array_equal(med, wi)
         np.testing.assert_array_equal(sh.assign, wa)
         np.testing.assert_array_equal(sh.dist.astype(np.float64), wd)
+
+
+# ---- warm start across ranks (reference kcenters.py:200-213 in MPI mode) --------------
+def _warm_worker(rank, world, port, n, A, seed, n_clusters, init_frames, outdir,
+                 cands, chain):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["OMP_NUM_THREADS"] = "2"
+    from enspara_amd import sharded, synth
+    from _host_shard import HostShard, HostShardMs
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port,
+                            rank=rank, world_size=world)
+    x = synth.synth(n, A, 9, seed=seed)
+    init = _init_centers(x, init_frames)
+    lo, cnt = sharded.shard_bounds(n, world, rank)
+    shard = (HostShard(x[lo:lo + cnt], lo) if cands == 1 else
+             HostShardMs(x[lo:lo + cnt], lo, cands))
+    ctr = sharded.warm_start_sharded(shard, init)
+    idx, cd = sharded.kcenters_sharded(shard, len(ctr), n_clusters - len(ctr), 0.0,
+                                       check_every=4)
+    np.savez(os.path.join(outdir, "r%d.npz" % rank),
+             idx=np.array(ctr + [int(i) for i in idx]), lo=lo, dist=shard.dist,
+             assign=shard.assign)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _init_centers(x, init_frames):
+    """frames of the data, one of them twice (the second copy attracts nothing:
+    a label without members, kcenters.py:233), and a structure far from all"""
+    init = [x[j] for j in init_frames] + [x[init_frames[0]]]
+    init.append((x[0] * 7.0 + 3.0).astype(np.float32))
+    return init
+
+
+@pytest.mark.parametrize("world,cands", [(2, 1), (2, 8), (3, 16)])
+def test_warm_start_across_ranks(world, cands):
+    """every rank assigns its frames to the initial centers, the occupied
+    labels' closest members are found over all ranks (first in the global
+    order), the sharded loop continues from there: equal to the single-process
+    oracle, including a label that attracts no frame"""
+    from oracle import cluster as oc
+    from enspara_amd import synth
+    n, A, seed, K = 1800, 25, 21, 12
+    init_frames = [5, 1000, 700]
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_warm_worker, args=(world, _free_port(), n, A, seed, K, init_frames,
+                                     d, cands, "ms"), nprocs=world, join=True)
+        parts = [np.load(os.path.join(d, "r%d.npz" % r)) for r in range(world)]
+    x = synth.synth(n, A, 9, seed=seed)
+    inds, a, dd = oc.kcenters(x, n_clusters=K, init_centers=_init_centers(x, init_frames))
+    assert len(inds) == K
+    for p in parts:
+        np.testing.assert_array_equal(p["idx"], np.array(inds))
+    np.testing.assert_array_equal(np.concatenate([p["assign"] for p in parts]), a)
+    np.testing.assert_array_equal(
+        np.concatenate([p["dist"] for p in parts]).astype(np.float64), dd)
