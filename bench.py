@@ -717,8 +717,14 @@ def main():
     kern_ms, n_samp = store.timing_end()
     timed_form = store.timing_form()
     if use_dist:
-        rounds = store.spec_rounds() if cands > 1 else centers_total
-        mix = {cands: (rounds, centers_total)}
+        # (the mailbox loop moves between rounds of 8 and of 16 and counts both;
+        # the gather loop runs one form)
+        mix = {T: pc for T, pc in store.run_stats().items() if pc[0]} \
+            if (transport == "mailbox" and cands > 1) else {}
+        if not mix:
+            rounds = store.spec_rounds() if cands > 1 else centers_total
+            mix = {cands: (rounds, centers_total)}
+        rounds = sum(p for p, _ in mix.values())
     else:
         mix = {T: pc for T, pc in store.run_stats().items() if pc[0]} \
             if cands > 1 else {1: (centers_total, centers_total)}

@@ -48,6 +48,13 @@ typedef float ek_v4f __attribute__((ext_vector_type(4)));
 // table of new distances (row stride 65: the writers of a register are 4
 // frames apart)
 #define EK_P16_DSTRIDE 65
+// the queue of pairs the float32 certificate does not settle: entries of nine
+// floats + (candidate, frame) per wave; beyond the capacity a wave solves all
+// its pairs the old way
+#ifndef EK_P16_QUEUE
+#define EK_P16_QUEUE 1
+#endif
+#define EK_P16_QCAP 256
 // the workgroups resident at the start of a launch (256 CUs x 2), and how long
 // the second of a CU waits before it starts: ~20 us in s_sleep(127) units of
 // 64 x 127 cycles
@@ -73,6 +80,9 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
     __shared__ double s_G[EK_BLOCK];
     __shared__ float s_cur[EK_BLOCK];
     __shared__ float s_D[EK_BLOCK / EK_WAVE][T * EK_P16_DSTRIDE];
+#if EK_P16_QUEUE
+    __shared__ uint32_t s_Q[EK_BLOCK / EK_WAVE][EK_P16_QCAP * 10];
+#endif
     if (!plan->go)
         return;
     // Two workgroups share a CU (two waves per SIMD).  Launched together and
@@ -283,10 +293,93 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
 #undef EK_LDR
 
     // ---- the lane's 16 pairs: candidate lane % 16, frames 16 b + 4 (lane / 16) + r ----
+    // Most of these distances are never used -- the pair is far, all a strict "<"
+    // asks -- and the float64 solve costs a wave whatever its SLOWEST lane needs.
+    // So (round 4, EK_P16_QUEUE): every pair first takes the float32 certificate
+    // (ek_far_certified_f32: sound, ~99 % of the far pairs, no float64), straight
+    // line, no lane waits for another; the pairs it does not certify go into a
+    // queue in LDS and are solved afterwards DENSELY, one per lane: the float64
+    // path then runs once or twice per wave instead of sixteen times.  A wave
+    // whose queue overflows (the first passes of a fit, where little is far yet)
+    // takes the old path for all its pairs.  Same results either way: a
+    // certified pair is +inf for every consumer, the others are solved as before.
     {
         const int cand = lane & 15;
         const double Gc = ctrace[cand];
         float *Dw = s_D[wave];
+#if EK_P16_QUEUE
+        uint32_t *Q = s_Q[wave];
+        int qn = 0;                     // wave-uniform
+        // (two pairs at a time, their certificates in one basic block: the
+        // chains are long and dependent, two of them interleave)
+#pragma unroll
+        for (int r0 = 0; r0 < 16; r0 += 2) {
+            float S[2][9];
+            int fr[2];
+            bool need[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int r = r0 + u;
+                fr[u] = 16 * (r >> 2) + 4 * (lane >> 4) + (r & 3);
+#pragma unroll
+                for (int q = 0; q < 9; ++q)
+                    S[u][q] = acc[q][r];
+            }
+            {
+                float gs[2], cu[2];
+                bool far[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    gs[u] = (float)(s_G[wave * EK_WAVE + fr[u]] + Gc);
+                    cu[u] = s_cur[wave * EK_WAVE + fr[u]];
+                }
+                ek_far_certified_f32_w<2>(S, gs, A, cu, far);
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    need[u] = cand < teff && f0 + wave * EK_WAVE + fr[u] < n && !far[u];
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                Dw[cand * EK_P16_DSTRIDE + fr[u]] = __builtin_inff();
+                const unsigned long long m = __ballot(need[u]);
+                const int pos = qn + __popcll(m & ((1ull << lane) - 1ull));
+                if (need[u] && pos < EK_P16_QCAP) {
+                    uint32_t *e = Q + pos * 10;
+#pragma unroll
+                    for (int q = 0; q < 9; ++q)
+                        e[q] = __float_as_uint(S[u][q]);
+                    e[9] = (uint32_t)(cand << 8 | fr[u]);
+                }
+                qn += __popcll(m);
+            }
+        }
+#ifdef EK_P16_STATS     // (measurement build: waves, overflowing waves, queued pairs)
+        if (FUSE && lane == 0) {
+            atomicAdd(fz.tick + 240, 1u);
+            atomicAdd(fz.tick + 241, qn > EK_P16_QCAP ? 1u : 0u);
+            atomicAdd(fz.tick + 242, (unsigned)qn);
+            atomicAdd(fz.tick + 243, (unsigned)((qn + 63) / 64));
+        }
+#endif
+        if (qn <= EK_P16_QCAP) {
+            // (one wave: its LDS accesses are in order, no barrier)
+            for (int base = 0; base < qn; base += EK_WAVE) {
+                const int e = base + lane;
+                if (e < qn) {
+                    const uint32_t *ent = Q + e * 10;
+                    float S[9];
+#pragma unroll
+                    for (int q = 0; q < 9; ++q)
+                        S[q] = __uint_as_float(ent[q]);
+                    const int c2 = (int)(ent[9] >> 8), fr = (int)(ent[9] & 255u);
+                    Dw[c2 * EK_P16_DSTRIDE + fr] =
+                        ek_rmsd_from_S_below(S, s_G[wave * EK_WAVE + fr], ctrace[c2], A,
+                                             s_cur[wave * EK_WAVE + fr]);
+                }
+            }
+        } else
+#endif
+        {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             __builtin_amdgcn_sched_barrier(0);
@@ -311,6 +404,7 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
                 d = ek_rmsd_from_S_below(S, s_G[wave * EK_WAVE + fr], Gc, A,
                                          s_cur[wave * EK_WAVE + fr]);
             Dw[cand * EK_P16_DSTRIDE + fr] = d;
+        }
         }
     }
     __syncthreads();
@@ -426,6 +520,13 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
             fz.ctl->n_done = label + 1;
             fz.ctl->n_rounds = fz.ctl->n_rounds + 1;
             *fz.tick = 0;
+#ifdef EK_P16_STATS
+            if ((fz.ctl->n_rounds & 15) == 0)
+                printf("pass16 round %d label %d: waves %u overflow %u queued %u drains %u\n",
+                       fz.ctl->n_rounds, label, fz.tick[240], fz.tick[241], fz.tick[242],
+                       fz.tick[243]);
+            fz.tick[240] = fz.tick[241] = fz.tick[242] = fz.tick[243] = 0;
+#endif
         }
     }
 }

@@ -167,91 +167,201 @@ __device__ __forceinline__ float ek_rmsd_from_S(const float (&S)[9], double Gx,
 #define EK_FAR_F32 0
 #endif
 
-__device__ __forceinline__ bool ek_far_certified_f32(const float (&S)[9], float Gsum,
-                                                     int n_atoms, float cur)
+// W pairs at once, statement by statement: the chains below are long and
+// dependent (each step waits out the latency of the one before), W = 2 of them
+// interleaved in program order fill the gaps.  Straight-line code, no early
+// exit: a wave does not branch on its slowest lane.
+#define EK_W_ for (int u = 0; u < W; ++u)
+// (after every statement its W results pass through one empty asm statement:
+// both are computed by then, and the next statement starts from both -- the
+// compiler otherwise sinks each pair's chain to where its result is used, one
+// chain after the other)
+#if defined(__HIP_DEVICE_COMPILE__)
+template <int W> __device__ __forceinline__ void ek_tie(float (&v)[W])
 {
-    float q = S[0] * S[0];
+    if constexpr (W == 2)
+        asm volatile("" : "+v"(v[0]), "+v"(v[1]));
+    else
+        asm volatile("" : "+v"(v[0]));
+}
+#define EK_TIE_(V) ek_tie<W>(V);
+#else
+#define EK_TIE_(V)
+#endif
+template <int W>
+__device__ __forceinline__ void ek_far_certified_f32_w(const float (&S)[W][9],
+                                                       const float (&Gsum)[W], int n_atoms,
+                                                       const float (&cur)[W], bool (&far)[W])
+{
+    float q[W], rs[W], N[W][9], bn[W], dn[W], dn2[W];
+    bool ok[W];
+#pragma unroll
+    EK_W_ q[u] = S[u][0] * S[u][0];
+    EK_TIE_(q)
 #pragma unroll
     for (int j = 1; j < 9; ++j)
-        q = __builtin_fmaf(S[j], S[j], q);
-    if (!(q > 1e-30f && q < 1e30f))     // (also NaN)
-        return false;
+#pragma unroll
+        EK_W_ q[u] = __builtin_fmaf(S[u][j], S[u][j], q[u]);
+    EK_TIE_(q)
+#pragma unroll
+    EK_W_ ok[u] = q[u] > 1e-30f && q[u] < 1e30f;    // (false for NaN too)
     // N = S / sqrt(q): |N|_F^2 = 1 within 1.5e-6, nothing below under- or overflows
-    const float rs = EK_SQRTF(EK_RCPF(q));
-    float N[9];
+#pragma unroll
+    EK_W_ rs[u] = EK_SQRTF(EK_RCPF(q[u]));
+    EK_TIE_(rs)
 #pragma unroll
     for (int j = 0; j < 9; ++j)
-        N[j] = S[j] * rs;
+#pragma unroll
+        EK_W_ N[u][j] = S[u][j] * rs[u];
     // cofactors, b = |cof N|_F^2 <= 1/3, d = det N; absolute errors below 1e-6
-    const float c00 = __builtin_fmaf(N[4], N[8], -(N[5] * N[7]));
-    const float c01 = __builtin_fmaf(N[5], N[6], -(N[3] * N[8]));
-    const float c02 = __builtin_fmaf(N[3], N[7], -(N[4] * N[6]));
-    const float c10 = __builtin_fmaf(N[2], N[7], -(N[1] * N[8]));
-    const float c11 = __builtin_fmaf(N[0], N[8], -(N[2] * N[6]));
-    const float c12 = __builtin_fmaf(N[1], N[6], -(N[0] * N[7]));
-    const float c20 = __builtin_fmaf(N[1], N[5], -(N[2] * N[4]));
-    const float c21 = __builtin_fmaf(N[2], N[3], -(N[0] * N[5]));
-    const float c22 = __builtin_fmaf(N[0], N[4], -(N[1] * N[3]));
-    float bn = c00 * c00;
-    bn = __builtin_fmaf(c01, c01, bn);
-    bn = __builtin_fmaf(c02, c02, bn);
-    bn = __builtin_fmaf(c10, c10, bn);
-    bn = __builtin_fmaf(c11, c11, bn);
-    bn = __builtin_fmaf(c12, c12, bn);
-    bn = __builtin_fmaf(c20, c20, bn);
-    bn = __builtin_fmaf(c21, c21, bn);
-    bn = __builtin_fmaf(c22, c22, bn);
-    float dn = N[0] * c00;
-    dn = __builtin_fmaf(N[1], c01, dn);
-    dn = __builtin_fmaf(N[2], c02, dn);
-    const float dn2 = dn * dn;
+    float c[W][9];
+#define EK_COF_(K, A0, A1, B0, B1)                                             \
+    _Pragma("unroll") EK_W_ c[u][K] =                                         \
+        __builtin_fmaf(N[u][A0], N[u][A1], -(N[u][B0] * N[u][B1]));
+    EK_COF_(0, 4, 8, 5, 7)
+    EK_COF_(1, 5, 6, 3, 8)
+    EK_COF_(2, 3, 7, 4, 6)
+    EK_COF_(3, 2, 7, 1, 8)
+    EK_COF_(4, 0, 8, 2, 6)
+    EK_COF_(5, 1, 6, 0, 7)
+    EK_COF_(6, 1, 5, 2, 4)
+    EK_COF_(7, 2, 3, 0, 5)
+    EK_COF_(8, 0, 4, 1, 3)
+#undef EK_COF_
+#pragma unroll
+    EK_W_ bn[u] = c[u][0] * c[u][0];
+    EK_TIE_(bn)
+#pragma unroll
+    for (int j = 1; j < 9; ++j)
+#pragma unroll
+        EK_W_ bn[u] = __builtin_fmaf(c[u][j], c[u][j], bn[u]);
+    EK_TIE_(bn)
+#pragma unroll
+    EK_W_ dn[u] = N[u][0] * c[u][0];
+    EK_TIE_(dn)
+#pragma unroll
+    EK_W_ dn[u] = __builtin_fmaf(N[u][1], c[u][1], dn[u]);
+    EK_TIE_(dn)
+#pragma unroll
+    EK_W_ dn[u] = __builtin_fmaf(N[u][2], c[u][2], dn[u]);
+    EK_TIE_(dn)
+#pragma unroll
+    EK_W_ dn2[u] = dn[u] * dn[u];
+    EK_TIE_(dn2)
     // c(x) = x^3 - x^2 + bn x - dn^2, x = s1^2 / q in [1/3, 1]; evaluated with an
     // absolute error below 8e-6 (the unit coefficient stands for 1 +- 1.5e-6)
     // x+ from above (guard) and from below (a lower bound of x that needs no check)
-    const float disc = __builtin_fmaf(-3.0f, bn, 1.0f);
-    const float xg = (1.0f + EK_SQRTF(__builtin_fmaxf(disc + 1e-5f, 0.0f))) *
-                     (0.33333334f * 1.000003f);
-    const float xpl = (1.0f + EK_SQRTF(__builtin_fmaxf(disc - 1e-5f, 0.0f))) *
-                      (0.33333331f * 0.999997f);
-    float x = 1.0f - bn;
+    float disc[W], xg[W], xpl[W], x[W];
+#pragma unroll
+    EK_W_ disc[u] = __builtin_fmaf(-3.0f, bn[u], 1.0f);
+    EK_TIE_(disc)
+#pragma unroll
+    EK_W_ xg[u] = (1.0f + EK_SQRTF(__builtin_fmaxf(disc[u] + 1e-5f, 0.0f))) *
+                  (0.33333334f * 1.000003f);
+    EK_TIE_(xg)
+#pragma unroll
+    EK_W_ xpl[u] = (1.0f + EK_SQRTF(__builtin_fmaxf(disc[u] - 1e-5f, 0.0f))) *
+                   (0.33333331f * 0.999997f);
+    EK_TIE_(xpl)
+#pragma unroll
+    EK_W_ x[u] = 1.0f - bn[u];
+    EK_TIE_(x)
 #pragma unroll
     for (int it = 0; it < 5; ++it) {
-        const float cv = __builtin_fmaf(__builtin_fmaf(x - 1.0f, x, bn), x, -dn2);
-        const float cp = __builtin_fmaf(__builtin_fmaf(3.0f, x, -2.0f), x, bn);
-        x = __builtin_fmaf(-cv, EK_RCPF(cp), x);
+        float cv[W], cp[W];
+#pragma unroll
+        EK_W_ cv[u] = __builtin_fmaf(__builtin_fmaf(x[u] - 1.0f, x[u], bn[u]), x[u], -dn2[u]);
+    EK_TIE_(cv)
+#pragma unroll
+        EK_W_ cp[u] = __builtin_fmaf(__builtin_fmaf(3.0f, x[u], -2.0f), x[u], bn[u]);
+    EK_TIE_(cp)
+#pragma unroll
+        EK_W_ x[u] = __builtin_fmaf(-cv[u], EK_RCPF(cp[u]), x[u]);
+    EK_TIE_(x)
     }
-    const float x_up = __builtin_fmaxf(x * 1.001f, xg);
-    const float c_up = __builtin_fmaf(__builtin_fmaf(x_up - 1.0f, x_up, bn), x_up, -dn2);
-    if (!(c_up > 8e-6f))            // (also NaN)
-        return false;
-    const float x_try = x * 0.999f;
-    const float c_lo = __builtin_fmaf(__builtin_fmaf(x_try - 1.0f, x_try, bn), x_try, -dn2);
-    const float x_lo = (x_try > xg && c_lo < -8e-6f) ? x_try : xpl;
+    float x_up[W], c_up[W], x_try[W], c_lo[W], x_lo[W];
+#pragma unroll
+    EK_W_ x_up[u] = __builtin_fmaxf(x[u] * 1.001f, xg[u]);
+    EK_TIE_(x_up)
+#pragma unroll
+    EK_W_ c_up[u] = __builtin_fmaf(__builtin_fmaf(x_up[u] - 1.0f, x_up[u], bn[u]), x_up[u],
+                                   -dn2[u]);
+    EK_TIE_(c_up)
+#pragma unroll
+    EK_W_ ok[u] = ok[u] && c_up[u] > 8e-6f;         // (false for NaN too)
+#pragma unroll
+    EK_W_ x_try[u] = x[u] * 0.999f;
+    EK_TIE_(x_try)
+#pragma unroll
+    EK_W_ c_lo[u] = __builtin_fmaf(__builtin_fmaf(x_try[u] - 1.0f, x_try[u], bn[u]),
+                                   x_try[u], -dn2[u]);
+    EK_TIE_(c_lo)
+#pragma unroll
+    EK_W_ x_lo[u] = (x_try[u] > xg[u] && c_lo[u] < -8e-6f) ? x_try[u] : xpl[u];
+    EK_TIE_(x_lo)
     // bounds of (s2^2 + s3^2) / q and of 2 |d| / (s1 q)
-    const float bl = bn - 1e-6f, bu = bn + 1e-6f;
-    const float da = __builtin_fabsf(dn);
-    const float dl = __builtin_fmaxf(da - 1e-6f, 0.0f), du = da + 1e-6f;
-    const float rx_lo = EK_RCPF(x_lo) * 1.000001f;     // >= 1 / x_lo
-    const float rx_up = EK_RCPF(x_up) * 0.999999f;     // <= 1 / x_up
-    const float y_lo = (bl - du * du * rx_lo) * rx_up;
-    const float y_up = (bu - dl * dl * rx_up) * rx_lo;
-    const float rs_lo = EK_SQRTF(rx_lo) * 1.000001f;   // >= sqrt(q) / s1
-    const float rs_up = EK_SQRTF(rx_up) * 0.999999f;   // <= sqrt(q) / s1
-    float g_lo, g_up;
-    if (dn > 0.0f) {
-        g_lo = __builtin_fmaf(2.0f * dl, rs_up, y_lo);
-        g_up = __builtin_fmaf(2.0f * du, rs_lo, y_up);
-    } else {
-        g_lo = __builtin_fmaf(-2.0f * du, rs_lo, y_lo);
-        g_up = __builtin_fmaf(-2.0f * dl, rs_up, y_up);
-    }
-    if (!(g_lo >= 2e-4f))           // the largest root is not certainly separated
-        return false;
+    float dl[W], du[W], rx_lo[W], rx_up[W], y_lo[W], y_up[W], rs_lo[W], rs_up[W];
+    float g_lo[W], g_up[W];
+#pragma unroll
+    EK_W_ dl[u] = __builtin_fmaxf(__builtin_fabsf(dn[u]) - 1e-6f, 0.0f);
+    EK_TIE_(dl)
+#pragma unroll
+    EK_W_ du[u] = __builtin_fabsf(dn[u]) + 1e-6f;
+    EK_TIE_(du)
+#pragma unroll
+    EK_W_ rx_lo[u] = EK_RCPF(x_lo[u]) * 1.000001f;      // >= 1 / x_lo
+    EK_TIE_(rx_lo)
+#pragma unroll
+    EK_W_ rx_up[u] = EK_RCPF(x_up[u]) * 0.999999f;      // <= 1 / x_up
+    EK_TIE_(rx_up)
+#pragma unroll
+    EK_W_ y_lo[u] = ((bn[u] - 1e-6f) - du[u] * du[u] * rx_lo[u]) * rx_up[u];
+    EK_TIE_(y_lo)
+#pragma unroll
+    EK_W_ y_up[u] = ((bn[u] + 1e-6f) - dl[u] * dl[u] * rx_up[u]) * rx_lo[u];
+    EK_TIE_(y_up)
+#pragma unroll
+    EK_W_ rs_lo[u] = EK_SQRTF(rx_lo[u]) * 1.000001f;    // >= sqrt(q) / s1
+    EK_TIE_(rs_lo)
+#pragma unroll
+    EK_W_ rs_up[u] = EK_SQRTF(rx_up[u]) * 0.999999f;    // <= sqrt(q) / s1
+    EK_TIE_(rs_up)
+#pragma unroll
+    EK_W_ g_lo[u] = dn[u] > 0.0f ? __builtin_fmaf(2.0f * dl[u], rs_up[u], y_lo[u])
+                                 : __builtin_fmaf(-2.0f * du[u], rs_lo[u], y_lo[u]);
+    EK_TIE_(g_lo)
+#pragma unroll
+    EK_W_ g_up[u] = dn[u] > 0.0f ? __builtin_fmaf(2.0f * du[u], rs_lo[u], y_up[u])
+                                 : __builtin_fmaf(-2.0f * dl[u], rs_up[u], y_up[u]);
+    EK_TIE_(g_up)
+#pragma unroll
+    EK_W_ ok[u] = ok[u] && g_lo[u] >= 2e-4f;    // else: the largest root is not certainly separated
     // lambda_max <= sqrt(q) (s1_up + sqrt(G2_up)) / sqrt(q_n)
-    const float u = (EK_SQRTF(x_up) + EK_SQRTF(__builtin_fmaxf(g_up, 0.0f))) * 1.000003f;
-    const float U = u * EK_SQRTF(q) * 1.000002f;
-    const float thr = __builtin_fmaf((float)n_atoms * (cur * cur), 1.0001f, 5e-6f * Gsum);
-    return __builtin_fmaf(-2.0f, U, Gsum) > thr;
+    float U[W];
+#pragma unroll
+    EK_W_ U[u] = (EK_SQRTF(x_up[u]) + EK_SQRTF(__builtin_fmaxf(g_up[u], 0.0f))) * 1.000003f;
+    EK_TIE_(U)
+#pragma unroll
+    EK_W_ U[u] = U[u] * EK_SQRTF(q[u]) * 1.000002f;
+    EK_TIE_(U)
+#pragma unroll
+    EK_W_ far[u] = ok[u] && __builtin_fmaf(-2.0f, U[u], Gsum[u]) >
+                                __builtin_fmaf((float)n_atoms * (cur[u] * cur[u]), 1.0001f,
+                                               5e-6f * Gsum[u]);
+}
+#undef EK_W_
+#undef EK_TIE_
+
+__device__ __forceinline__ bool ek_far_certified_f32(const float (&S)[9], float Gsum,
+                                                     int n_atoms, float cur)
+{
+    float S1[1][9], G1[1] = {Gsum}, c1[1] = {cur};
+    bool f1[1];
+#pragma unroll
+    for (int j = 0; j < 9; ++j)
+        S1[0][j] = S[j];
+    ek_far_certified_f32_w<1>(S1, G1, n_atoms, c1, f1);
+    return f1[0];
 }
 
 // The same solve, abandoned as soon as its result is known to be >= `cur`.

@@ -74,7 +74,9 @@ for rep in range(reps):
     for t in th:
         t.join()
     dt = time.perf_counter() - t0
-    rounds = stores[0].spec_rounds()
+    mix = {k: v for k, v in stores[0].run_stats().items() if v[0]}
+    rounds = sum(v[0] for v in mix.values())
+    print("   passes by candidates:", mix, flush=True)
     print("   exchanges per shard:", [st.ms_state() for st in stores], flush=True)
     print("%d shard(s) of %d frames, mailboxes: %.4f s  %d passes  %.2f centers/pass  %.2f us/center  %.1f us/round"
           % (S, stores[0].n, dt, rounds, K / max(rounds, 1), dt / K * 1e6, dt / max(rounds, 1) * 1e6), flush=True)
