@@ -16,8 +16,9 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_build")
 OUT = os.path.join(HERE, "libenspara_hip.so")
 SOURCES = ["ek_prepare.hip", "ek_kcenters.hip", "ek_spec.hip", "ek_pass16.hip", "ek_chain.hip", "ek_round.hip", "ek_mshard.hip", "ek_assign.hip", "ek_pam.hip", "ek_pam_sparse.hip",
-           "ek_msm.hip", "ek_krylov.hip", "ek_features.hip", "ek_api.hip"]
-HEADERS = ["ek_common.h", "ek_qcp.h", "ek_reduce.h", "ek_chain_dev.h", "ek_top_dev.h", "ek_pam_sparse.h", "ek_lanes.h", os.path.join("..", "..", "include",
+           "ek_msm.hip", "ek_krylov.hip", "ek_features.hip", "ek_api.hip", "ek_api_pam.hip",
+           "ek_api_ms.hip"]
+HEADERS = ["ek_common.h", "ek_ctx.h", "ek_qcp.h", "ek_reduce.h", "ek_chain_dev.h", "ek_top_dev.h", "ek_pam_sparse.h", "ek_lanes.h", os.path.join("..", "..", "include",
                                                    "enspara_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: FMAs are explicit in the sources (numerical contract,

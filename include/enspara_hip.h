@@ -71,7 +71,13 @@ void *ek_ctx_stream(ek_ctx *ctx);
  * enspara/util/load.py:211-216), host or device memory.  Frames
  * [first, first+count) of the shard are centred (float64 mean), their traces
  * computed, and stored frame-minor.  `first` must be a multiple of EK_TILE
- * unless it is 0. */
+ * unless it is 0.
+ * Host memory (any: pageable numpy arrays) goes through two pinned buffers of
+ * <= 128 MiB filled by a few host threads and a DMA behind each (16 -> 42 GB/s
+ * measured; EK_UPLOAD_THREADS, EK_UPLOAD_CHUNK_MB).  On return the caller's
+ * array has been read completely; the centring / layout kernels may still be
+ * running on the context's stream, where everything that follows is ordered
+ * behind them (ek_ctx_sync to wait). */
 int ek_load_frames(ek_ctx *ctx, const float *xyz, int64_t first,
                    int64_t count, int src_is_device);
 
@@ -209,8 +215,12 @@ int ek_spec_chain_apply(ek_ctx *ctx, const void *hdrs_all, int32_t n_shards,
  * contexts of one process, hipIpc handles of 64 bytes each across processes),
  * connects every shard's including its own (ek_ms_connect), then
  *   ek_ms_run(ctx, first_label, max_new, cutoff, ...)   as ek_kcenters_run
- * on every shard at the same time.  A message that does not arrive within ~10 s
- * is reported as an error (a peer died), not waited for. */
+ * on every shard at the same time.  A message that does not arrive within 10 s
+ * (of the device's constant 100 MHz clock) is reported as an error (a peer
+ * died), not waited for.  With the default option key 4 = -1 the run moves
+ * between rounds of 8 and of 16 candidates by the centers the rounds of a batch
+ * accepted -- numbers every shard sees alike, so every shard takes the same
+ * decision at the same round; ek_run_stats reports the mix. */
 int ek_ms_setup(ek_ctx *ctx, int32_t world, int32_t rank, size_t *message_bytes);
 int ek_ms_mailbox(ek_ctx *ctx, void **mbox, void **flags, void *ipc_mbox,
                   void *ipc_flags);
