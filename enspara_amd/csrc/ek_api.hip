@@ -61,7 +61,9 @@ int ek_pick_nt(const ek_ctx *c)
 // EK_MAX_CANDS unless option key 4 pins it; 1 = one-center passes only
 int ek_pick_cands(const ek_ctx *c)
 {
-    const int t = c->cands == -1 ? EK_MAX_CANDS : c->cands;
+    int t = c->cands == -1 ? EK_MAX_CANDS : c->cands;
+    if (t == 16 && c->no_qtiles)    // (ek_ensure_qtiles found no room)
+        t = 8;
     return (t == 16 || t == 8 || t == 4) ? t : 1;
 }
 
@@ -73,9 +75,20 @@ int ek_ensure_qtiles(ek_ctx *c)
 {
     if (c->qt_valid)
         return EK_OK;
-    if (!c->qtiles)
-        EK_HIP(hipMalloc((void **)&c->qtiles,
-                         ek_quad_tiles_bytes(std::max<int64_t>(c->n_tiles, 1), c->A)));
+    if (!c->qtiles) {
+        const hipError_t e = hipMalloc(
+            (void **)&c->qtiles, ek_quad_tiles_bytes(std::max<int64_t>(c->n_tiles, 1), c->A));
+        if (e == hipErrorOutOfMemory) {
+            // no room for a third copy of the coordinates: a single shard then
+            // runs rounds of 8 (ek_pick_cands), which stream the frame-minor tiles
+            (void)hipGetLastError();
+            c->qtiles = nullptr;
+            c->no_qtiles = true;
+            return ek_fail(EK_ENOMEM, "no memory for the quad copy of the frames "
+                                      "(16-candidate rounds)");
+        }
+        EK_HIP(e);
+    }
     ek_launch_quad_tiles(c->tiles, c->n_tiles, c->A, c->qtiles, c->stream);
     EK_CHECK_LAUNCH();
     c->qt_valid = true;
@@ -875,7 +888,9 @@ static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
     c->ti_tiles = c->ti_skipped = 0;
     if (Tmax == 16 && !tri) {
         const int eq = ek_ensure_qtiles(c);
-        if (eq != EK_OK)
+        if (eq == EK_ENOMEM)
+            Tmax = 8;
+        else if (eq != EK_OK)
             return eq;
     }
     // an explicit request (option key 4 = 4, 8 or 16) pins the wide form

@@ -118,6 +118,7 @@ struct ek_ctx {
     float *qtiles = nullptr;     // quad copy [n_tiles][ceil(A/4)][3][EK_TILE][4]: what the
                                  // 16-candidate pass streams; made when one first runs
     bool qt_valid = false;       //   (ek_ensure_qtiles), again after frames are loaded
+    bool no_qtiles = false;      // there was no memory for it: rounds of 8 at most
     float *aos = nullptr;        // [n][3A] the same centred frames, frame-major
     double *G = nullptr;         // [n]
     float *dist = nullptr;       // [n]

@@ -333,3 +333,74 @@ def test_warm_start_across_ranks(world, cands):
     np.testing.assert_array_equal(np.concatenate([p["assign"] for p in parts]), a)
     np.testing.assert_array_equal(
         np.concatenate([p["dist"] for p in parts]).astype(np.float64), dd)
+
+
+# ---- connect_mailboxes is a collective every rank completes, whatever fails where -------
+class _FakeStore:
+    """stands for a FrameStore in connect_mailboxes: exports a handle, opens the
+    peers' -- and fails where told to"""
+
+    def __init__(self, rank, fail_export_on, fail_open_on):
+        self.rank, self.fe, self.fo = rank, fail_export_on, fail_open_on
+        self.setups, self.connected = 0, []
+
+    def ms_setup(self, world, rank):
+        self.setups += 1
+        self.connected = []
+
+    def ms_mailbox(self, ipc=False):
+        if self.rank == self.fe:
+            raise RuntimeError("no IPC handle on rank %d" % self.rank)
+        return ("handle", self.rank)
+
+    def ms_connect(self, p, ipc=None):
+        if self.rank == self.fo and p != self.rank:
+            raise RuntimeError("no peer access from rank %d to %d" % (self.rank, p))
+        self.connected.append(p)
+
+
+class _FakeShard:
+    def __init__(self, store):
+        self.store = store
+        self.ms_connected = -1
+
+
+def _connect_worker(rank, world, port, fail_export_on, fail_open_on, outdir):
+    sys.path.insert(0, ROOT)
+    from enspara_amd import sharded
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port,
+                            rank=rank, world_size=world)
+    sh = _FakeShard(_FakeStore(rank, fail_export_on, fail_open_on))
+    ok = sharded.connect_mailboxes(sh)
+    # the next collective every rank makes must still line up
+    t = torch.tensor([rank])
+    dist.all_reduce(t)
+    np.savez(os.path.join(outdir, "c%d.npz" % rank), ok=ok, connected=sh.ms_connected,
+             setups=sh.store.setups, n_conn=len(sh.store.connected),
+             had_error=sh.ms_connect_error is not None, total=int(t.item()))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail_export_on,fail_open_on", [(-1, -1), (1, -1), (-1, 2), (0, 1)])
+def test_connect_mailboxes_is_collective_whatever_fails(fail_export_on, fail_open_on):
+    """round-3 advisor: a rank whose hipIpc export / open failed skipped the
+    trailing barrier and left the healthy ranks in it.  Now every rank makes the
+    same two gathers, all ranks get the same verdict, a failed group has closed
+    what it opened (ms_setup again) and stays on the all-gather transport."""
+    world = 3
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_connect_worker, args=(world, _free_port(), fail_export_on,
+                                        fail_open_on, d), nprocs=world, join=True)
+        parts = [np.load(os.path.join(d, "c%d.npz" % r)) for r in range(world)]
+    healthy = fail_export_on < 0 and fail_open_on < 0
+    for r, p in enumerate(parts):
+        assert bool(p["ok"]) == healthy
+        assert int(p["connected"]) == (world if healthy else 0)
+        assert int(p["total"]) == 0 + 1 + 2
+        if healthy:
+            assert int(p["n_conn"]) == world and int(p["setups"]) == 1
+        else:
+            assert int(p["setups"]) >= 1 and int(p["n_conn"]) == 0
+    if not healthy:
+        bad = {fail_export_on, fail_open_on} - {-1}
+        assert all(bool(parts[r]["had_error"]) for r in bad)
