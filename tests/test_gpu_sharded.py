@@ -215,6 +215,7 @@ def test_two_device_shards_on_one_gpu(tmp_path, n, A, K, tmpl, iters, cands,
 @pytest.mark.parametrize("world,n,A,K,tmpl,iters,cands", [
     (8, 60000, 30, 260, 400, 1, -1),    # the ladder of 8 / 16 candidates per round
     (8, 3000, 12, 40, 9, 0, 16),        # shards of one or two tiles, some empty
+    (8, 3000, 12, 60, 9, 1, -1),        # ... and the ladder's decisions with empty shards
 ])
 def test_eight_processes_on_one_gpu(tmp_path, world, n, A, K, tmpl, iters, cands):
     """BASELINE.json configs[3]'s process layout -- EIGHT ranks, one process
