@@ -838,7 +838,7 @@ def main():
                   "device_wake_fit_s": t_wake,
                   "host_to_hbm_GBps": x.nbytes / t_load / 1e9,
                   "host_to_hbm_first_GBps": x.nbytes / t_load_first / 1e9,
-                  "how": "pageable numpy array -> two pinned 128 MiB buffers "
+                  "how": "pageable numpy array -> two pinned 256 MiB buffers "
                          "(8 host threads) -> DMA -> centring + three layouts "
                          "on the device, double-buffered (csrc/ek_api.hip "
                          "ek_load_frames); PCIe-inclusive, never part of value"},

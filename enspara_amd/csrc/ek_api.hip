@@ -463,14 +463,15 @@ extern "C" int ek_load_frames(ek_ctx *c, const float *xyz, int64_t first,
     } else {
         // Pageable host memory reaches the device through the driver's own bounce
         // buffer at ~16 GB/s (3.6 GB: 0.23 s next to a 0.35 s fit).  Here: chunks
-        // of <= 128 MiB (whole tiles; EK_UPLOAD_CHUNK_MB: every chunk costs ~0.75 ms
-        // beside its bytes at ~53 GB/s, measured) copied by a few host threads
+        // of <= 256 MiB (whole tiles; EK_UPLOAD_CHUNK_MB: every chunk costs ~0.75 ms
+        // beside its bytes at ~53 GB/s, measured: 64 MiB chunks 34 GB/s, 128 MiB 42,
+        // 256 MiB 45) copied by a few host threads
         // (EK_UPLOAD_THREADS, default 8) into one of two
         // PINNED buffers, a DMA from there into one of two device staging buffers
         // and the layout kernel behind it on the context's stream -- while the
         // threads fill the other buffer.  The caller's array has been read
         // completely when this returns; the stream may still be working.
-        size_t chunk_mb = 128;
+        size_t chunk_mb = 256;
         if (const char *e = getenv("EK_UPLOAD_CHUNK_MB"))
             chunk_mb = (size_t)std::max(1, std::min(atoi(e), 1024));
         int64_t chunk = (int64_t)((chunk_mb << 20) / (frame_floats * sizeof(float)));

@@ -28,6 +28,8 @@ struct ek_krylov {
     double *data = nullptr;
     double *V = nullptr;      // [m_max + 1][n]
     double *w = nullptr;      // [n]
+    double *w2 = nullptr;     // [n] the other half of the ping-pong in ek_krylov_expand
+    double *part = nullptr;   // [blocks(n)] per-block sums of w^2 (its norm, in block order)
     double *tmp = nullptr;    // [m_max + 1][n] scratch for basis rotations
     double *h = nullptr;      // [m_max + 2] coefficients of one pass
     double *q = nullptr;      // [(m_max+1) * (m_max+1)] rotation matrix
@@ -140,6 +142,8 @@ extern "C" int ek_krylov_destroy(ek_krylov *k)
     (void)hipFree(k->data);
     (void)hipFree(k->V);
     (void)hipFree(k->w);
+    (void)hipFree(k->w2);
+    (void)hipFree(k->part);
     (void)hipFree(k->tmp);
     (void)hipFree(k->h);
     (void)hipFree(k->q);
@@ -176,6 +180,8 @@ extern "C" int ek_krylov_create(int device, int64_t n, const int64_t *indptr,
     KA(k->V, (size_t)(m_max + 1) * n * sizeof(double));
     KA(k->tmp, (size_t)(m_max + 1) * n * sizeof(double));
     KA(k->w, (size_t)n * sizeof(double));
+    KA(k->w2, (size_t)n * sizeof(double));
+    KA(k->part, (size_t)((n + EK_BLOCK - 1) / EK_BLOCK) * sizeof(double));
     KA(k->h, (size_t)(m_max + 2) * sizeof(double));
     KA(k->q, (size_t)(m_max + 1) * (m_max + 1) * sizeof(double));
     KA(k->hcols, (size_t)m_max * (m_max + 2) * sizeof(double));
@@ -334,32 +340,109 @@ extern "C" int ek_krylov_combine(ek_krylov *k, int32_t m, int32_t kk,
 }
 
 // ---- a whole run of Arnoldi steps without host round trips ---------------------
-__global__ void kr_hsum_kernel(const double *__restrict__ h, int cnt, int first,
-                               double *__restrict__ col)
+// ---- fused forms for ek_krylov_expand: five launches per step instead of nine ------
+// ||w||^2 from the per-block partial sums, in a fixed order: every wave adds the
+// partials lane-strided and reduces over the lanes (all lanes get the total)
+__device__ __forceinline__ double kr_total(const double *__restrict__ part, int nb)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < cnt)
-        col[i] = first ? h[i] : col[i] + h[i];
+    const int lane = threadIdx.x & (EK_WAVE - 1);
+    double t = 0.0;
+    for (int i = lane; i < nb; i += EK_WAVE)
+        t = t + part[i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+        t = t + __shfl_xor(t, off, 64);
+    return t;
 }
 
-// V[j+1] = w / sqrt(nn[0]); col[cnt] = sqrt(nn[0])
+// w_out = A (w_prev / ||w_prev||), and on the way V_out = w_prev / ||w_prev||,
+// *col_last = ||w_prev||: the normalisation of the step before folded into the
+// sparse product of this one (the product reads w_prev / nrm, the very values
+// V_out receives).  One wave per row.
 __global__ void __launch_bounds__(EK_BLOCK)
-kr_normalize_kernel(const double *__restrict__ w, const double *__restrict__ nn,
-                    int64_t n, double *__restrict__ out,
+kr_spmv_norm_kernel(const int64_t *__restrict__ indptr,
+                    const int32_t *__restrict__ indices,
+                    const double *__restrict__ data, const double *__restrict__ w_prev,
+                    const double *__restrict__ part, int nb, int64_t n,
+                    double *__restrict__ w_out, double *__restrict__ V_out,
                     double *__restrict__ col_last)
 {
+    const int64_t row = (int64_t)blockIdx.x * (EK_BLOCK / EK_WAVE) +
+                        threadIdx.x / EK_WAVE;
+    const int lane = threadIdx.x & (EK_WAVE - 1);
+    if (row >= n)
+        return;
+    const double nrm = sqrt(kr_total(part, nb));
+    if (lane == 0) {
+        V_out[row] = (nrm > 0.0) ? w_prev[row] / nrm : 0.0;
+        if (row == 0)
+            *col_last = nrm;
+    }
+    double acc = 0.0;
+    for (int64_t j = indptr[row] + lane; j < indptr[row + 1]; j += EK_WAVE) {
+        const double v = (nrm > 0.0) ? w_prev[indices[j]] / nrm : 0.0;
+        acc = __builtin_fma(data[j], v, acc);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+        acc = acc + __shfl_xor(acc, off, 64);
+    if (lane == 0)
+        w_out[row] = acc;
+}
+
+// w -= sum_{i < cnt} h[i] V[i]; the column of coefficients (= on the first pass,
+// += on the second) by workgroup 0; and, where asked, the workgroup's share of
+// ||w||^2 (a fixed tree over its 256 elements)
+__global__ void __launch_bounds__(EK_BLOCK)
+kr_axpy_hsum_kernel(const double *__restrict__ V, const double *__restrict__ h,
+                    int cnt, int64_t n, double *__restrict__ w,
+                    double *__restrict__ col, int first, double *__restrict__ part)
+{
+    __shared__ double sh[EK_BLOCK];
     const int64_t e = (int64_t)blockIdx.x * EK_BLOCK + threadIdx.x;
-    const double nrm = sqrt(nn[0]);
+    double x = 0.0;
+    if (e < n) {
+        x = w[e];
+        for (int i = 0; i < cnt; ++i)
+            x = __builtin_fma(-h[i], V[(size_t)i * n + e], x);
+        w[e] = x;
+    }
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < cnt; i += EK_BLOCK)
+            col[i] = first ? h[i] : col[i] + h[i];
+    if (part) {
+        sh[threadIdx.x] = x * x;
+        __syncthreads();
+        for (int s = EK_BLOCK / 2; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s)
+                sh[threadIdx.x] = sh[threadIdx.x] + sh[threadIdx.x + s];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0)
+            part[blockIdx.x] = sh[0];
+    }
+}
+
+// the last step's normalisation: V_out = w / ||w||, *col_last = ||w||
+__global__ void __launch_bounds__(EK_BLOCK)
+kr_finish_kernel(const double *__restrict__ w, const double *__restrict__ part, int nb,
+                 int64_t n, double *__restrict__ V_out, double *__restrict__ col_last)
+{
+    const int64_t e = (int64_t)blockIdx.x * EK_BLOCK + threadIdx.x;
+    const double nrm = sqrt(kr_total(part, nb));
     if (e == 0)
         *col_last = nrm;
     if (e < n)
-        out[e] = (nrm > 0.0) ? w[e] / nrm : 0.0;
+        V_out[e] = (nrm > 0.0) ? w[e] / nrm : 0.0;
 }
 
 // Steps j0 .. m-1 back to back.  H_out is column-major with leading dimension
 // ldh >= m + 1: column j receives h[0..j+1].  A (near-)zero sub-diagonal entry
 // signals a breakdown at that step; the caller then redoes the tail with
 // ek_krylov_step, which can insert a fresh direction.
+// Five launches per step (round 4; nine before): the sparse product with the
+// normalisation of the step before folded in, and twice [coefficients, update +
+// their column sum (+ the norm's partial sums on the second pass)].
 extern "C" int ek_krylov_expand(ek_krylov *k, int32_t j0, int32_t m,
                                 double *H_out, int32_t ldh)
 {
@@ -368,27 +451,34 @@ extern "C" int ek_krylov_expand(ek_krylov *k, int32_t j0, int32_t m,
     KR_HIP(hipSetDevice(k->device));
     const int64_t n = k->n;
     const int ld = k->m_max + 2;
+    const int nb = (int)kr_blocks(n);
+    double *w = k->w, *w_prev = k->w2;
     for (int j = j0; j < m; ++j) {
         const int cnt = j + 1;
         double *col = k->hcols + (size_t)j * ld;
-        hipLaunchKernelGGL(kr_spmv_kernel, dim3((unsigned)((n + 3) / 4)),
-                           dim3(EK_BLOCK), 0, k->s, k->indptr, k->indices,
-                           k->data, k->V + (size_t)j * n, n, k->w);
+        if (j == j0)
+            hipLaunchKernelGGL(kr_spmv_kernel, dim3((unsigned)((n + 3) / 4)),
+                               dim3(EK_BLOCK), 0, k->s, k->indptr, k->indices,
+                               k->data, k->V + (size_t)j * n, n, w);
+        else        // (w_prev: what step j - 1 left; its column's last entry)
+            hipLaunchKernelGGL(kr_spmv_norm_kernel, dim3((unsigned)((n + 3) / 4)),
+                               dim3(EK_BLOCK), 0, k->s, k->indptr, k->indices,
+                               k->data, w_prev, k->part, nb, n, w,
+                               k->V + (size_t)j * n,
+                               k->hcols + (size_t)(j - 1) * ld + j);
         for (int pass = 0; pass < 2; ++pass) {
             hipLaunchKernelGGL(kr_dots_kernel, dim3(cnt), dim3(EK_BLOCK), 0,
-                               k->s, k->V, k->w, n, k->h);
-            hipLaunchKernelGGL(kr_axpy_kernel, dim3(kr_blocks(n)),
-                               dim3(EK_BLOCK), 0, k->s, k->V, k->h, cnt, n,
-                               k->w);
-            hipLaunchKernelGGL(kr_hsum_kernel, dim3((cnt + 255) / 256),
-                               dim3(256), 0, k->s, k->h, cnt, pass == 0, col);
+                               k->s, k->V, w, n, k->h);
+            hipLaunchKernelGGL(kr_axpy_hsum_kernel, dim3(kr_blocks(n)),
+                               dim3(EK_BLOCK), 0, k->s, k->V, k->h, cnt, n, w, col,
+                               pass == 0, pass == 1 ? k->part : (double *)nullptr);
         }
-        hipLaunchKernelGGL(kr_dots_kernel, dim3(1), dim3(EK_BLOCK), 0, k->s,
-                           k->w, k->w, n, k->h);
-        hipLaunchKernelGGL(kr_normalize_kernel, dim3(kr_blocks(n)),
-                           dim3(EK_BLOCK), 0, k->s, k->w, k->h, n,
-                           k->V + (size_t)(j + 1) * n, col + cnt);
+        std::swap(w, w_prev);
     }
+    if (m > j0)     // the last step's vector and sub-diagonal entry
+        hipLaunchKernelGGL(kr_finish_kernel, dim3(kr_blocks(n)), dim3(EK_BLOCK), 0,
+                           k->s, w_prev, k->part, nb, n, k->V + (size_t)m * n,
+                           k->hcols + (size_t)(m - 1) * ld + m);
     KR_HIP(hipGetLastError());
     for (int j = j0; j < m; ++j)
         KR_HIP(hipMemcpyAsync(H_out + (size_t)j * ldh,

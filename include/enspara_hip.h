@@ -73,7 +73,7 @@ void *ek_ctx_stream(ek_ctx *ctx);
  * computed, and stored frame-minor.  `first` must be a multiple of EK_TILE
  * unless it is 0.
  * Host memory (any: pageable numpy arrays) goes through two pinned buffers of
- * <= 128 MiB filled by a few host threads and a DMA behind each (16 -> 42 GB/s
+ * <= 256 MiB filled by a few host threads and a DMA behind each (16 -> 45 GB/s
  * measured; EK_UPLOAD_THREADS, EK_UPLOAD_CHUNK_MB).  On return the caller's
  * array has been read completely; the centring / layout kernels may still be
  * running on the context's stream, where everything that follows is ordered

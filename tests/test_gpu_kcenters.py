@@ -296,3 +296,39 @@ def test_adaptive_run_never_passes_its_goal(ocl):
             assert len(idx) == step
             got += [int(i) for i in idx]
         assert got == [int(i) for i in inds]
+
+
+def test_upload_paths_give_the_same_frames(ocl, monkeypatch):
+    """ek_load_frames from host memory: many small chunks through both pinned
+    buffers (EK_UPLOAD_CHUNK_MB=1, three copy threads), a load in two pieces at
+    tile-aligned offsets, and a RE-load of other data into the same context --
+    the quad copy of the 16-candidate pass has to follow it."""
+    from enspara_amd.cluster import kcenters as kc
+    from enspara_amd.device import FrameStore
+    n, A = 30000, 41
+    x = synth.synth(n, A, 60, seed=5)
+    y = synth.synth(n, A, 60, seed=6)
+    with FrameStore.from_array(x) as st:
+        want = st.rmsd_to_frame(123)
+    monkeypatch.setenv("EK_UPLOAD_CHUNK_MB", "1")
+    monkeypatch.setenv("EK_UPLOAD_THREADS", "3")
+    with FrameStore(n, A) as st:
+        st.load(x)
+        np.testing.assert_array_equal(st.rmsd_to_frame(123), want)
+        # two pieces, the second from a tile-aligned offset
+        cut = 256 * 37
+        st.load(y[:cut])
+        st.load(y[cut:], first=cut)
+        inds, a, d = ocl.kcenters(y, n_clusters=70)
+        st.set_option(4, 16)
+        r = kc._kcenters_device(y, 70, 0, None, 0, store=st)
+        assert list(r.center_indices) == [int(i) for i in inds]
+        np.testing.assert_array_equal(r.assignments, a)
+        np.testing.assert_array_equal(r.distances, d)
+        # ... and back to the first data: the quad copy is made again
+        st.load(x)
+        inds, a, d = ocl.kcenters(x, n_clusters=70)
+        r = kc._kcenters_device(x, 70, 0, None, 0, store=st)
+        assert list(r.center_indices) == [int(i) for i in inds]
+        np.testing.assert_array_equal(r.assignments, a)
+        np.testing.assert_array_equal(r.distances, d)
