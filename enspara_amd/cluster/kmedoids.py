@@ -458,6 +458,10 @@ def _msq(x):
 # labels and the medoids resident on the device (ek_feat_pam_sweep); 0: the
 # reference-shaped loop below around a device metric.  Same results.
 PAM_FEATURE_DEVICE = 1
+# raw random outputs handed to a resident sweep beyond its position (None: four
+# per cluster still to go + 64, which practically never run out; tests set a
+# handful to walk the "ran out, call again" path)
+FEATURE_RAW_AHEAD = None
 
 
 def _feature_sweep_applies(X, metric, distances, proposals, assignments=None):
@@ -501,7 +505,9 @@ def _feature_sweep_device(X, metric, medoid_inds, assignments, distances, propos
         cid = 0
         while True:
             if proposals is None:
-                stream._need(stream.pos + 4 * (K - cid) + 64)
+                ahead = (4 * (K - cid) + 64 if FEATURE_RAW_AHEAD is None
+                         else FEATURE_RAW_AHEAD)
+                stream._need(stream.pos + ahead)
             status, cid, stream.pos = bound.res.pam_sweep(
                 bound.metric, med, proposals, stream.raw, stream.pos, d, a, accept, cid)
             if status == 0:

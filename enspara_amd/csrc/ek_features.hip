@@ -23,7 +23,9 @@
 
 #include <stdlib.h>
 
+#include <string.h>
 #include <algorithm>
+#include <vector>
 #include <new>
 
 extern int ek_set_error(int code, const char *fmt, ...);
@@ -658,6 +660,23 @@ struct FeatPam {
     double *out2 = nullptr;
     EkPwShape *shapes = nullptr;
     int n_full = 0, n_leaves = 0, n_chunks = 0;
+    // the sweep without a host round trip per proposal (round 4)
+    struct FeatPamCtl *ctl = nullptr;   // device: stream position, status, last verdict
+    uint32_t *raw_dev = nullptr;        // the caller's raw random outputs
+    int64_t raw_cap = 0;
+    int64_t *jdev = nullptr;            // [1] the member drawn
+    int64_t *props_dev = nullptr;       // [Kcap] explicit proposals
+    int32_t *accept_dev = nullptr;      // [Kcap]
+    int32_t Kcap_async = 0;
+};
+
+// device-side state of an asynchronous sweep
+struct FeatPamCtl {
+    long long pos;      // next raw output to use
+    int32_t status;     // 0 ok; 1 the raw outputs ran out; 2 an empty cluster
+    int32_t fail_cid;   // the cluster at which status was set
+    int32_t acc;        // the last proposal was accepted
+    int32_t pad;
 };
 
 extern "C" void ek_feat_pam_release(ek_feat *k)
@@ -681,6 +700,11 @@ extern "C" void ek_feat_pam_release(ek_feat *k)
     (void)hipFree(p.part);
     (void)hipFree(p.out2);
     (void)hipFree(p.shapes);
+    (void)hipFree(p.ctl);
+    (void)hipFree(p.raw_dev);
+    (void)hipFree(p.jdev);
+    (void)hipFree(p.props_dev);
+    (void)hipFree(p.accept_dev);
     delete k->pam;
     k->pam = nullptr;
 }
@@ -766,9 +790,10 @@ feat_pam_nearest_kernel(const T *__restrict__ tiles, int F,
     __shared__ T xs[FY_CHUNK];
     __shared__ double rv[EK_BLOCK / EK_WAVE];
     __shared__ int32_t rc[EK_BLOCK / EK_WAVE];
-    if (blockIdx.x >= counters[0])
-        return;
-    const uint32_t f = amb[blockIdx.x];
+    // (any grid: workgroup b takes members b, b + gridDim.x, ..)
+    for (unsigned int mem = blockIdx.x; mem < counters[0]; mem += gridDim.x) {
+    __syncthreads();        // (rv / rc of the member before are read by then)
+    const uint32_t f = amb[mem];
     const T *p = tiles + (size_t)(f / EK_TILE) * (size_t)F * EK_TILE + (f % EK_TILE);
     // (label 0 where no distance is below +inf -- overflowed squares --: what
     // util.py:186-203's zeros + strict < leave)
@@ -820,6 +845,127 @@ feat_pam_nearest_kernel(const T *__restrict__ tiles, int F,
         ndist[f] = best;
         nassign[f] = bc;
     }
+    }
+}
+
+// ---- the sweep without a host round trip per proposal (round 4) -------------------
+// numpy's RandomState.choice(m) on the raw 32-bit outputs (kmedoids.py:514; the
+// host form is ek_np_choice_draws): mask to the bits of m - 1, reject above it;
+// m == 1 consumes nothing.  One thread.  An empty cluster or a stream that runs
+// out stops the sweep: every later kernel of it returns at once.
+__global__ void feat_draw_kernel(FeatPamCtl *__restrict__ ctl, int cid,
+                                 const int64_t *__restrict__ total,
+                                 const uint32_t *__restrict__ raw, long long n_raw,
+                                 const int64_t *__restrict__ props,
+                                 int64_t *__restrict__ jdev, int64_t *__restrict__ idx,
+                                 unsigned int *__restrict__ counters)
+{
+    // (a stopped sweep: the kernels that follow find no ambiguous member to look at)
+    if (ctl->status) {
+        counters[0] = 0;
+        return;
+    }
+    if (props) {
+        idx[0] = props[cid];
+        return;
+    }
+    const long long m = total[0];
+    if (m <= 0) {
+        ctl->status = 2;
+        ctl->fail_cid = cid;
+        counters[0] = 0;
+        return;
+    }
+    const unsigned long long rng = (unsigned long long)(m - 1);
+    if (rng == 0) {
+        jdev[0] = 0;
+        return;
+    }
+    unsigned long long mask = rng;
+    mask |= mask >> 1;
+    mask |= mask >> 2;
+    mask |= mask >> 4;
+    mask |= mask >> 8;
+    mask |= mask >> 16;
+    long long p = ctl->pos;
+    for (;;) {
+        if (p >= n_raw) {
+            ctl->status = 1;
+            ctl->fail_cid = cid;
+            counters[0] = 0;
+            return;
+        }
+        const unsigned long long v = raw[p++] & mask;
+        if (v <= rng) {
+            jdev[0] = (long long)v;
+            ctl->pos = p;
+            return;
+        }
+    }
+}
+
+// the verdict (kmedoids.py:478-479, :683: np.square(x).mean() of either state,
+// strictly lower wins), the medoid's sample if accepted, the table's column back
+// if not
+template <typename T>
+__global__ void __launch_bounds__(EK_BLOCK)
+feat_decide_kernel(FeatPamCtl *__restrict__ ctl, const double *__restrict__ sums,
+                   long long n, int cid, const int64_t *__restrict__ idx,
+                   int32_t *__restrict__ accept, int64_t *__restrict__ med, int F,
+                   int Kcap, T *__restrict__ MT, const T *__restrict__ col)
+{
+    if (ctl->status)
+        return;
+    const double old_cost = sums[0] / (double)n, new_cost = sums[1] / (double)n;
+    const bool acc = new_cost < old_cost;
+    if (!acc)
+        for (int j = threadIdx.x; j < F; j += EK_BLOCK)
+            MT[(size_t)j * Kcap + cid] = col[j];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ctl->acc = acc ? 1 : 0;
+        accept[cid] = acc ? 1 : 0;
+        if (acc)
+            med[cid] = idx[0];
+    }
+}
+
+// an accepted trial state becomes the state (kmedoids.py:684-690)
+__global__ void __launch_bounds__(EK_BLOCK)
+feat_commit_kernel(const FeatPamCtl *__restrict__ ctl, long long n,
+                   const double *__restrict__ ndist, const int32_t *__restrict__ nassign,
+                   double *__restrict__ dist, int32_t *__restrict__ assign)
+{
+    if (ctl->status || !ctl->acc)
+        return;
+    const long long f = (long long)blockIdx.x * EK_BLOCK + threadIdx.x;
+    if (f < n) {
+        dist[f] = ndist[f];
+        assign[f] = nassign[f];
+    }
+}
+
+// (the proposal's kernel, with the sweep's stop flag in front)
+template <typename T>
+__global__ void __launch_bounds__(EK_BLOCK)
+feat_propose_async_kernel(const FeatPamCtl *__restrict__ ctl,
+                          const T *__restrict__ tiles, int F,
+                          const int64_t *__restrict__ idx, int cid, int Kcap,
+                          T *__restrict__ MT, T *__restrict__ col, T *__restrict__ y,
+                          unsigned int *__restrict__ counters)
+{
+    if (ctl->status)
+        return;
+    const int64_t f = idx[0];
+    const T *p = tiles + (size_t)(f / EK_TILE) * (size_t)F * EK_TILE + (f % EK_TILE);
+    for (int j = threadIdx.x; j < F; j += EK_BLOCK) {
+        const T v = p[(size_t)j * EK_TILE];
+        col[j] = MT[(size_t)j * Kcap + cid];
+        MT[(size_t)j * Kcap + cid] = v;
+        y[j] = v;
+    }
+    if (threadIdx.x == 0)
+        counters[0] = 0;
 }
 
 // numpy's leaf (ek_pam.hip, "cost sums in numpy's order") over the squares of
@@ -987,6 +1133,136 @@ extern "C" int ek_feat_pam_sweep(ek_feat *k, int32_t metric, int32_t n_medoids,
         FE_HIP(hipStreamSynchronize(k->s));
     }
     const unsigned blocks = (unsigned)nb;
+    // ---- round 4: the whole sweep enqueued, no host round trip per proposal ----------
+    // The draw (numpy's choice on the raw outputs), the choice of the member, the
+    // verdict and the commit are kernels; the host reads the control block every
+    // 128 proposals.  Same kernels for the arithmetic, same results; the loop below
+    // (EK_FEAT_PAM_SYNC=1) is the form with two waits per proposal.
+    if (!getenv("EK_FEAT_PAM_SYNC")) {
+        if (!p.ctl) {
+            FE_HIP(hipMalloc((void **)&p.ctl, sizeof(FeatPamCtl)));
+            FE_HIP(hipMalloc((void **)&p.jdev, sizeof(int64_t)));
+            FE_HIP(hipMemsetAsync(p.jdev, 0, sizeof(int64_t), k->s));
+        }
+        if (!p.accept_dev || K > p.Kcap_async) {
+            FE_HIP(hipStreamSynchronize(k->s));
+            (void)hipFree(p.accept_dev);
+            (void)hipFree(p.props_dev);
+            p.accept_dev = nullptr;
+            p.props_dev = nullptr;
+            FE_HIP(hipMalloc((void **)&p.accept_dev, (size_t)K * sizeof(int32_t)));
+            FE_HIP(hipMalloc((void **)&p.props_dev, (size_t)K * sizeof(int64_t)));
+            p.Kcap_async = K;
+        }
+        const int64_t raw_left = proposals ? 0 : std::max<int64_t>(n_raw - *pos, 0);
+        if (raw_left > p.raw_cap) {
+            FE_HIP(hipStreamSynchronize(k->s));
+            (void)hipFree(p.raw_dev);
+            p.raw_dev = nullptr;
+            p.raw_cap = 0;
+            FE_HIP(hipMalloc((void **)&p.raw_dev, (size_t)raw_left * sizeof(uint32_t)));
+            p.raw_cap = raw_left;
+        }
+        if (raw_left > 0)       // (positions on the device count from *pos)
+            FE_HIP(hipMemcpyAsync(p.raw_dev, raw + *pos, (size_t)raw_left * sizeof(uint32_t),
+                                  hipMemcpyHostToDevice, k->s));
+        if (proposals)
+            FE_HIP(hipMemcpyAsync(p.props_dev, proposals, (size_t)K * sizeof(int64_t),
+                                  hipMemcpyHostToDevice, k->s));
+        FeatPamCtl hc;
+        memset(&hc, 0, sizeof(hc));
+        FE_HIP(hipMemcpyAsync(p.ctl, &hc, sizeof(hc), hipMemcpyHostToDevice, k->s));
+        FE_HIP(hipMemsetAsync(p.accept_dev, 0, (size_t)K * sizeof(int32_t), k->s));
+        const int32_t cid_start = cid;
+        const unsigned near_blocks = (unsigned)std::min<int64_t>(k->n, 1024);
+        const int per = EK_BLOCK / 8;
+        while (cid < K) {
+            const int32_t stop = std::min(K, cid + 128);
+            for (; cid < stop; ++cid) {
+                if (!proposals)
+                    ek_launch_count_members_multi(k->kassign, k->n, cid, 1, p.blockcnt,
+                                                  p.scan, p.total, k->s);
+                hipLaunchKernelGGL(feat_draw_kernel, dim3(1), dim3(1), 0, k->s, p.ctl, cid,
+                                   p.total, p.raw_dev, (long long)raw_left,
+                                   proposals ? p.props_dev : (const int64_t *)nullptr,
+                                   p.jdev, p.idx, p.counters);
+                if (!proposals)
+                    ek_launch_select_member_multi(k->kassign, k->n, cid, 1, p.scan, p.jdev,
+                                                  p.idx, k->s);
+#define FA_T(T, M)                                                             \
+    do {                                                                       \
+        hipLaunchKernelGGL((feat_propose_async_kernel<T>), dim3(1), dim3(EK_BLOCK), 0, \
+                           k->s, p.ctl, (const T *)k->tiles, k->F, p.idx, cid, p.Kcap, \
+                           (T *)p.MT, (T *)p.col, (T *)k->y, p.counters);      \
+        hipLaunchKernelGGL((feat_distance_kernel<T, M>), dim3(blocks),         \
+                           dim3(EK_BLOCK), 0, k->s, (const T *)k->tiles,       \
+                           (const T *)k->y, k->n, k->F, k->out);               \
+        hipLaunchKernelGGL(feat_pam_classify_kernel, dim3(blocks), dim3(EK_BLOCK), 0, \
+                           k->s, k->kdist, k->kassign, k->out, k->n, cid, p.ndist, \
+                           p.nassign, p.amb, p.counters);                      \
+        hipLaunchKernelGGL((feat_pam_nearest_kernel<T, M>), dim3(near_blocks), \
+                           dim3(EK_BLOCK), 0, k->s, (const T *)k->tiles, k->F, \
+                           p.amb, p.counters, (const T *)p.MT, K, p.Kcap,      \
+                           p.ndist, p.nassign);                                \
+        hipLaunchKernelGGL(feat_pw_leaf_kernel, dim3((p.n_leaves + per - 1) / per), \
+                           dim3(EK_BLOCK), 0, k->s, k->kdist, p.ndist, p.shapes, \
+                           p.n_full, p.n_leaves, p.part);                      \
+        ek_launch_pw_chunks_total(p.part, p.shapes, p.n_full, p.n_leaves, p.n_chunks, \
+                                  p.out2, k->s);                               \
+        hipLaunchKernelGGL((feat_decide_kernel<T>), dim3(1), dim3(EK_BLOCK), 0, k->s, \
+                           p.ctl, p.out2, (long long)k->n, cid, p.idx, p.accept_dev, \
+                           p.med, k->F, p.Kcap, (T *)p.MT, (const T *)p.col);  \
+        hipLaunchKernelGGL(feat_commit_kernel, dim3(blocks), dim3(EK_BLOCK), 0, k->s, \
+                           p.ctl, (long long)k->n, p.ndist, p.nassign, k->kdist, \
+                           k->kassign);                                        \
+    } while (0)
+                if (k->kind == 0) {
+                    if (metric == 0)
+                        FA_T(float, 0);
+                    else
+                        FA_T(float, 1);
+                } else {
+                    if (metric == 0)
+                        FA_T(double, 0);
+                    else
+                        FA_T(double, 1);
+                }
+#undef FA_T
+            }
+            FE_HIP(hipGetLastError());
+            FE_HIP(hipMemcpyAsync(&hc, p.ctl, sizeof(hc), hipMemcpyDeviceToHost, k->s));
+            FE_HIP(hipStreamSynchronize(k->s));
+            if (hc.status)
+                break;
+        }
+        // what was decided: clusters cid_start .. (the stop)
+        const int32_t cid_end = hc.status ? hc.fail_cid : K;
+        if (cid_end > cid_start) {
+            std::vector<int64_t> hm((size_t)K);
+            FE_HIP(hipMemcpyAsync(accept + cid_start, p.accept_dev + cid_start,
+                                  (size_t)(cid_end - cid_start) * sizeof(int32_t),
+                                  hipMemcpyDeviceToHost, k->s));
+            FE_HIP(hipMemcpyAsync(hm.data(), p.med, (size_t)K * sizeof(int64_t),
+                                  hipMemcpyDeviceToHost, k->s));
+            FE_HIP(hipStreamSynchronize(k->s));
+            for (int32_t c = cid_start; c < cid_end; ++c)
+                if (accept[c])
+                    medoids[c] = hm[(size_t)c];
+        }
+        *pos += hc.pos;
+        if (hc.status) {
+            *cid_io = hc.fail_cid;
+            *status = hc.status;
+            return EK_OK;
+        }
+        FE_HIP(hipMemcpyAsync(dist_io, k->kdist, (size_t)k->n * sizeof(double),
+                              hipMemcpyDeviceToHost, k->s));
+        FE_HIP(hipMemcpyAsync(assign_io, k->kassign, (size_t)k->n * sizeof(int32_t),
+                              hipMemcpyDeviceToHost, k->s));
+        FE_HIP(hipStreamSynchronize(k->s));
+        *cid_io = K;
+        return EK_OK;
+    }
     for (; cid < K; ++cid) {
         // ---- the proposal: a member drawn like choice(state_inds), or given ----------
         ek_launch_count_members(k->kassign, k->n, cid, p.blockcnt, p.scan, p.total, k->s);

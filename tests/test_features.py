@@ -190,6 +190,29 @@ def test_resident_feature_pam_equals_the_host_loop():
                 np.testing.assert_array_equal(out[1][4], out[0][4])
                 moved += out[1][0] != [int(i) for i in r.center_indices]
     assert moved >= 12          # (most sweeps accept proposals)
+    # the raw random outputs run out again and again: the sweep stops at that
+    # cluster, gets more, goes on from there -- same medoids, state and stream
+    X, K = cases[0]
+    r = kcenters(X, "euclidean", n_clusters=K)
+    out = {}
+    for ahead in (None, 2):
+        monkey = km.FEATURE_RAW_AHEAD
+        km.FEATURE_RAW_AHEAD = ahead
+        block = km._DrawStream.BLOCK
+        km._DrawStream.BLOCK = 4096 if ahead is None else 3
+        try:
+            rs = np.random.RandomState(9)
+            inds, d, a, _ = km._kmedoids_pam_update(
+                X, "euclidean", [int(i) for i in r.center_indices],
+                r.assignments.copy(), r.distances.copy(), random_state=rs)
+            out[ahead] = (list(inds), d, a, rs.randint(1 << 30, size=3))
+        finally:
+            km.FEATURE_RAW_AHEAD = monkey
+            km._DrawStream.BLOCK = block
+    assert out[None][0] == out[2][0]
+    np.testing.assert_array_equal(out[None][1], out[2][1])
+    np.testing.assert_array_equal(out[None][2], out[2][2])
+    np.testing.assert_array_equal(out[None][3], out[2][3])
     # an empty cluster: choice([]) raises in both
     X = rng.normal(size=(500, 4)).astype(np.float32)
     r = kcenters(X, "euclidean", n_clusters=10)
