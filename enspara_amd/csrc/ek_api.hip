@@ -477,7 +477,7 @@ extern "C" int ek_load_frames(ek_ctx *c, const float *xyz, int64_t first,
         int64_t chunk = (int64_t)((chunk_mb << 20) / (frame_floats * sizeof(float)));
         chunk = std::max<int64_t>(EK_TILE, chunk / EK_TILE * EK_TILE);
         chunk = std::min<int64_t>(chunk, (count + EK_TILE - 1) / EK_TILE * EK_TILE);
-        if (chunk != c->stage_frames) {
+        if (chunk > c->stage_frames) {      // (the buffers only grow)
             EK_HIP(hipStreamSynchronize(c->stream));
             for (int b = 0; b < 2; ++b) {
                 (void)hipFree(c->stage[b]);
