@@ -641,6 +641,12 @@ extern "C" int ek_feat_kcenters(ek_feat *k, int32_t metric, int32_t first_label,
 
 extern "C" int64_t ek_np_choice_draws(const uint32_t *raw, int64_t n_raw, int64_t *pos,
                                       const int64_t *m, int64_t count, int64_t *out);
+// (ek_pam.hip: the scan of per-workgroup member counts and the chunk sums of the
+// pairwise cost tree, each without the step that follows it there)
+void ek_launch_scan_counts(const int32_t *blockcnt, int64_t n, int64_t *scan,
+                           int64_t *total, hipStream_t s);
+void ek_launch_pw_chunks(double *part, const EkPwShape *shapes, int n_full,
+                         int n_leaves_total, int n_chunks, hipStream_t s);
 
 struct FeatPam {
     int32_t K = 0, Kcap = 0;
@@ -849,73 +855,213 @@ feat_pam_nearest_kernel(const T *__restrict__ tiles, int F,
 }
 
 // ---- the sweep without a host round trip per proposal (round 4) -------------------
-// numpy's RandomState.choice(m) on the raw 32-bit outputs (kmedoids.py:514; the
-// host form is ek_np_choice_draws): mask to the bits of m - 1, reject above it;
-// m == 1 consumes nothing.  One thread.  An empty cluster or a stream that runs
-// out stops the sweep: every later kernel of it returns at once.
-__global__ void feat_draw_kernel(FeatPamCtl *__restrict__ ctl, int cid,
-                                 const int64_t *__restrict__ total,
-                                 const uint32_t *__restrict__ raw, long long n_raw,
-                                 const int64_t *__restrict__ props,
-                                 int64_t *__restrict__ jdev, int64_t *__restrict__ idx,
-                                 unsigned int *__restrict__ counters)
+// The draw is numpy's RandomState.choice(m) on the raw 32-bit outputs
+// (kmedoids.py:514; the host form is ek_np_choice_draws): mask to the bits of
+// m - 1, reject above it; m == 1 consumes nothing.  An empty cluster or a stream
+// that runs out stops the sweep: every later kernel of it returns at once.
+// an accepted trial state becomes the state (kmedoids.py:684-690) and, in the same
+// sweep over the labels, the members of cluster `cid` are counted per workgroup
+// (cid < 0: the commit alone, after the last proposal)
+__global__ void __launch_bounds__(EK_BLOCK)
+feat_commit_count_kernel(const FeatPamCtl *__restrict__ ctl, long long n,
+                         const double *__restrict__ ndist,
+                         const int32_t *__restrict__ nassign, double *__restrict__ dist,
+                         int32_t *__restrict__ assign, int do_commit, int cid,
+                         int32_t *__restrict__ blockcnt)
 {
-    // (a stopped sweep: the kernels that follow find no ambiguous member to look at)
-    if (ctl->status) {
-        counters[0] = 0;
-        return;
-    }
-    if (props) {
-        idx[0] = props[cid];
-        return;
-    }
-    const long long m = total[0];
-    if (m <= 0) {
-        ctl->status = 2;
-        ctl->fail_cid = cid;
-        counters[0] = 0;
-        return;
-    }
-    const unsigned long long rng = (unsigned long long)(m - 1);
-    if (rng == 0) {
-        jdev[0] = 0;
-        return;
-    }
-    unsigned long long mask = rng;
-    mask |= mask >> 1;
-    mask |= mask >> 2;
-    mask |= mask >> 4;
-    mask |= mask >> 8;
-    mask |= mask >> 16;
-    long long p = ctl->pos;
-    for (;;) {
-        if (p >= n_raw) {
-            ctl->status = 1;
-            ctl->fail_cid = cid;
-            counters[0] = 0;
-            return;
+    __shared__ int cnt;
+    if (threadIdx.x == 0)
+        cnt = 0;
+    __syncthreads();
+    const long long f = (long long)blockIdx.x * EK_BLOCK + threadIdx.x;
+    if (f < n) {
+        int32_t a;
+        if (do_commit && !ctl->status && ctl->acc) {
+            dist[f] = ndist[f];
+            a = nassign[f];
+            assign[f] = a;
+        } else {
+            a = assign[f];
         }
-        const unsigned long long v = raw[p++] & mask;
-        if (v <= rng) {
-            jdev[0] = (long long)v;
-            ctl->pos = p;
-            return;
+        if (cid >= 0 && a == cid)
+            atomicAdd(&cnt, 1);
+    }
+    __syncthreads();
+    if (cid >= 0 && threadIdx.x == 0)
+        blockcnt[blockIdx.x] = cnt;
+}
+
+// one workgroup: the draw, the member it names
+// (ek_select_member_multi_kernel's search) and the proposal's features into y and
+// into the medoid table (feat_propose_kernel)
+template <typename T>
+__global__ void __launch_bounds__(EK_BLOCK)
+feat_pick_kernel(FeatPamCtl *__restrict__ ctl, int cid, const int64_t *__restrict__ total,
+                 const uint32_t *__restrict__ raw, long long n_raw,
+                 const int64_t *__restrict__ props, const int32_t *__restrict__ assign,
+                 long long n, const int64_t *__restrict__ scan, int nblocks,
+                 const T *__restrict__ tiles, int F, int Kcap, T *__restrict__ MT,
+                 T *__restrict__ col, T *__restrict__ y, int64_t *__restrict__ idx,
+                 unsigned int *__restrict__ counters)
+{
+    __shared__ long long s_want, s_f;
+    __shared__ int s_go, s_lo;
+    __shared__ int wcnt[EK_BLOCK / EK_WAVE];
+    if (threadIdx.x == 0) {
+        s_go = 0;
+        s_want = -1;
+        s_f = -1;
+        counters[0] = 0;
+        if (!ctl->status) {
+            if (props) {
+                s_f = props[cid];
+                s_go = 1;
+            } else {
+                const long long m = total[0];
+                if (m <= 0) {
+                    ctl->status = 2;
+                    ctl->fail_cid = cid;
+                } else {
+                    const unsigned long long rng = (unsigned long long)(m - 1);
+                    if (rng == 0) {
+                        s_want = 0;
+                        s_go = 1;
+                    } else {
+                        unsigned long long mask = rng;
+                        mask |= mask >> 1;
+                        mask |= mask >> 2;
+                        mask |= mask >> 4;
+                        mask |= mask >> 8;
+                        mask |= mask >> 16;
+                        long long p = ctl->pos;
+                        for (;;) {
+                            if (p >= n_raw) {
+                                ctl->status = 1;
+                                ctl->fail_cid = cid;
+                                break;
+                            }
+                            const unsigned long long v = raw[p++] & mask;
+                            if (v <= rng) {
+                                s_want = (long long)v;
+                                ctl->pos = p;
+                                s_go = 1;
+                                break;
+                            }
+                        }
+                    }
+                }
+            }
         }
+        if (s_go && s_want >= 0) {      // last workgroup whose scan <= want
+            int lo = 0, hi = nblocks - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) / 2;
+                if (scan[mid] <= s_want)
+                    lo = mid;
+                else
+                    hi = mid - 1;
+            }
+            s_lo = lo;
+        }
+    }
+    __syncthreads();
+    if (!s_go)
+        return;
+    if (s_want >= 0) {
+        const int lo = s_lo;
+        const long long rank = s_want - scan[lo];
+        const long long f = (long long)lo * EK_BLOCK + threadIdx.x;
+        const bool hit = f < n && assign[f] == cid;
+        const unsigned long long m = __ballot(hit);
+        const int lane = threadIdx.x & (EK_WAVE - 1), wv = threadIdx.x / EK_WAVE;
+        if (lane == 0)
+            wcnt[wv] = __popcll(m);
+        __syncthreads();
+        int before = 0;
+        for (int w = 0; w < wv; ++w)
+            before += wcnt[w];
+        if (hit && before + __popcll(m & ((1ull << lane) - 1ull)) == rank)
+            s_f = f;
+        __syncthreads();
+    }
+    const long long f = s_f;
+    if (f < 0)
+        return;             // (cannot happen: the count said the member exists)
+    if (threadIdx.x == 0)
+        idx[0] = f;
+    const T *p = tiles + (size_t)(f / EK_TILE) * (size_t)F * EK_TILE + (f % EK_TILE);
+    for (int j = threadIdx.x; j < F; j += EK_BLOCK) {
+        const T v = p[(size_t)j * EK_TILE];
+        col[j] = MT[(size_t)j * Kcap + cid];
+        MT[(size_t)j * Kcap + cid] = v;
+        y[j] = v;
     }
 }
 
-// the verdict (kmedoids.py:478-479, :683: np.square(x).mean() of either state,
-// strictly lower wins), the medoid's sample if accepted, the table's column back
-// if not
+// distance of every sample to the proposal (feat_distance_kernel's chain) and its
+// classification (kmedoids.py:644-658) in one sweep
+template <typename T, int METRIC>
+__global__ void __launch_bounds__(EK_BLOCK)
+feat_dist_classify_kernel(const T *__restrict__ tiles, const T *__restrict__ y,
+                          int64_t n, int F, const double *__restrict__ dist,
+                          const int32_t *__restrict__ assign, int32_t cid,
+                          double *__restrict__ ndist, int32_t *__restrict__ nassign,
+                          uint32_t *__restrict__ amb, unsigned int *__restrict__ counters)
+{
+    __shared__ T ys[FY_CHUNK];
+    const int64_t f = (int64_t)blockIdx.x * EK_BLOCK + threadIdx.x;
+    const T *p = tiles + (size_t)(f / EK_TILE) * (size_t)F * EK_TILE + (f % EK_TILE);
+    double acc = 0.0;
+    for (int j0 = 0; j0 < F; j0 += FY_CHUNK) {
+        const int w = (F - j0 < FY_CHUNK) ? (F - j0) : FY_CHUNK;
+        __syncthreads();
+        for (int j = threadIdx.x; j < w; j += EK_BLOCK)
+            ys[j] = y[j0 + j];
+        __syncthreads();
+#pragma unroll 8
+        for (int j = 0; j < w; ++j)
+            FeatAcc<T, METRIC>::add(acc, __builtin_nontemporal_load(
+                                             p + (size_t)(j0 + j) * EK_TILE),
+                                    ys[j]);
+    }
+    if (f >= n)
+        return;
+    if (METRIC == 0)
+        acc = __builtin_sqrt(acc);
+    const double d = dist[f], x = acc;
+    const int32_t a = assign[f];
+    if (d > x) {
+        ndist[f] = x;
+        nassign[f] = cid;
+    } else if (a != cid) {
+        ndist[f] = d;
+        nassign[f] = a;
+    } else {
+        amb[atomicAdd(&counters[0], 1u)] = (uint32_t)f;
+    }
+}
+
+// the two cost sums (the chunk sums added left to right: ek_pw_total_kernel) and the
+// verdict (kmedoids.py:478-479, :683: np.square(x).mean() of either state, strictly
+// lower wins; the table's column back if not)
 template <typename T>
 __global__ void __launch_bounds__(EK_BLOCK)
-feat_decide_kernel(FeatPamCtl *__restrict__ ctl, const double *__restrict__ sums,
-                   long long n, int cid, const int64_t *__restrict__ idx,
-                   int32_t *__restrict__ accept, int64_t *__restrict__ med, int F,
-                   int Kcap, T *__restrict__ MT, const T *__restrict__ col)
+feat_total_decide_kernel(FeatPamCtl *__restrict__ ctl, const double *__restrict__ chunksum,
+                         int n_chunks, long long n, int cid,
+                         const int64_t *__restrict__ idx, int32_t *__restrict__ accept,
+                         int64_t *__restrict__ med, int F, int Kcap, T *__restrict__ MT,
+                         const T *__restrict__ col)
 {
+    __shared__ double sums[2];
     if (ctl->status)
         return;
+    if (threadIdx.x < 2) {
+        double s = 0.0;
+        for (int c = 0; c < n_chunks; ++c)
+            s = s + chunksum[2 * (size_t)c + threadIdx.x];
+        sums[threadIdx.x] = s;
+    }
+    __syncthreads();
     const double old_cost = sums[0] / (double)n, new_cost = sums[1] / (double)n;
     const bool acc = new_cost < old_cost;
     if (!acc)
@@ -928,44 +1074,6 @@ feat_decide_kernel(FeatPamCtl *__restrict__ ctl, const double *__restrict__ sums
         if (acc)
             med[cid] = idx[0];
     }
-}
-
-// an accepted trial state becomes the state (kmedoids.py:684-690)
-__global__ void __launch_bounds__(EK_BLOCK)
-feat_commit_kernel(const FeatPamCtl *__restrict__ ctl, long long n,
-                   const double *__restrict__ ndist, const int32_t *__restrict__ nassign,
-                   double *__restrict__ dist, int32_t *__restrict__ assign)
-{
-    if (ctl->status || !ctl->acc)
-        return;
-    const long long f = (long long)blockIdx.x * EK_BLOCK + threadIdx.x;
-    if (f < n) {
-        dist[f] = ndist[f];
-        assign[f] = nassign[f];
-    }
-}
-
-// (the proposal's kernel, with the sweep's stop flag in front)
-template <typename T>
-__global__ void __launch_bounds__(EK_BLOCK)
-feat_propose_async_kernel(const FeatPamCtl *__restrict__ ctl,
-                          const T *__restrict__ tiles, int F,
-                          const int64_t *__restrict__ idx, int cid, int Kcap,
-                          T *__restrict__ MT, T *__restrict__ col, T *__restrict__ y,
-                          unsigned int *__restrict__ counters)
-{
-    if (ctl->status)
-        return;
-    const int64_t f = idx[0];
-    const T *p = tiles + (size_t)(f / EK_TILE) * (size_t)F * EK_TILE + (f % EK_TILE);
-    for (int j = threadIdx.x; j < F; j += EK_BLOCK) {
-        const T v = p[(size_t)j * EK_TILE];
-        col[j] = MT[(size_t)j * Kcap + cid];
-        MT[(size_t)j * Kcap + cid] = v;
-        y[j] = v;
-    }
-    if (threadIdx.x == 0)
-        counters[0] = 0;
 }
 
 // numpy's leaf (ek_pam.hip, "cost sums in numpy's order") over the squares of
@@ -1179,27 +1287,28 @@ extern "C" int ek_feat_pam_sweep(ek_feat *k, int32_t metric, int32_t n_medoids,
         while (cid < K) {
             const int32_t stop = std::min(K, cid + 128);
             for (; cid < stop; ++cid) {
+                // eight launches: [commit of the proposal before + member count],
+                // scan, [draw + member + proposal], [distances + classification],
+                // the ambiguous members' search, leaf sums, chunk sums, [totals +
+                // verdict]
+                hipLaunchKernelGGL(feat_commit_count_kernel, dim3(blocks), dim3(EK_BLOCK), 0,
+                                   k->s, p.ctl, (long long)k->n, p.ndist, p.nassign,
+                                   k->kdist, k->kassign, cid > cid_start ? 1 : 0,
+                                   proposals ? -1 : cid, p.blockcnt);
                 if (!proposals)
-                    ek_launch_count_members_multi(k->kassign, k->n, cid, 1, p.blockcnt,
-                                                  p.scan, p.total, k->s);
-                hipLaunchKernelGGL(feat_draw_kernel, dim3(1), dim3(1), 0, k->s, p.ctl, cid,
-                                   p.total, p.raw_dev, (long long)raw_left,
-                                   proposals ? p.props_dev : (const int64_t *)nullptr,
-                                   p.jdev, p.idx, p.counters);
-                if (!proposals)
-                    ek_launch_select_member_multi(k->kassign, k->n, cid, 1, p.scan, p.jdev,
-                                                  p.idx, k->s);
+                    ek_launch_scan_counts(p.blockcnt, k->n, p.scan, p.total, k->s);
 #define FA_T(T, M)                                                             \
     do {                                                                       \
-        hipLaunchKernelGGL((feat_propose_async_kernel<T>), dim3(1), dim3(EK_BLOCK), 0, \
-                           k->s, p.ctl, (const T *)k->tiles, k->F, p.idx, cid, p.Kcap, \
-                           (T *)p.MT, (T *)p.col, (T *)k->y, p.counters);      \
-        hipLaunchKernelGGL((feat_distance_kernel<T, M>), dim3(blocks),         \
+        hipLaunchKernelGGL((feat_pick_kernel<T>), dim3(1), dim3(EK_BLOCK), 0, k->s, \
+                           p.ctl, cid, p.total, p.raw_dev, (long long)raw_left, \
+                           proposals ? p.props_dev : (const int64_t *)nullptr, \
+                           k->kassign, (long long)k->n, p.scan, nb,            \
+                           (const T *)k->tiles, k->F, p.Kcap, (T *)p.MT, (T *)p.col, \
+                           (T *)k->y, p.idx, p.counters);                      \
+        hipLaunchKernelGGL((feat_dist_classify_kernel<T, M>), dim3(blocks),    \
                            dim3(EK_BLOCK), 0, k->s, (const T *)k->tiles,       \
-                           (const T *)k->y, k->n, k->F, k->out);               \
-        hipLaunchKernelGGL(feat_pam_classify_kernel, dim3(blocks), dim3(EK_BLOCK), 0, \
-                           k->s, k->kdist, k->kassign, k->out, k->n, cid, p.ndist, \
-                           p.nassign, p.amb, p.counters);                      \
+                           (const T *)k->y, k->n, k->F, k->kdist, k->kassign, cid, \
+                           p.ndist, p.nassign, p.amb, p.counters);             \
         hipLaunchKernelGGL((feat_pam_nearest_kernel<T, M>), dim3(near_blocks), \
                            dim3(EK_BLOCK), 0, k->s, (const T *)k->tiles, k->F, \
                            p.amb, p.counters, (const T *)p.MT, K, p.Kcap,      \
@@ -1207,14 +1316,11 @@ extern "C" int ek_feat_pam_sweep(ek_feat *k, int32_t metric, int32_t n_medoids,
         hipLaunchKernelGGL(feat_pw_leaf_kernel, dim3((p.n_leaves + per - 1) / per), \
                            dim3(EK_BLOCK), 0, k->s, k->kdist, p.ndist, p.shapes, \
                            p.n_full, p.n_leaves, p.part);                      \
-        ek_launch_pw_chunks_total(p.part, p.shapes, p.n_full, p.n_leaves, p.n_chunks, \
-                                  p.out2, k->s);                               \
-        hipLaunchKernelGGL((feat_decide_kernel<T>), dim3(1), dim3(EK_BLOCK), 0, k->s, \
-                           p.ctl, p.out2, (long long)k->n, cid, p.idx, p.accept_dev, \
-                           p.med, k->F, p.Kcap, (T *)p.MT, (const T *)p.col);  \
-        hipLaunchKernelGGL(feat_commit_kernel, dim3(blocks), dim3(EK_BLOCK), 0, k->s, \
-                           p.ctl, (long long)k->n, p.ndist, p.nassign, k->kdist, \
-                           k->kassign);                                        \
+        ek_launch_pw_chunks(p.part, p.shapes, p.n_full, p.n_leaves, p.n_chunks, k->s); \
+        hipLaunchKernelGGL((feat_total_decide_kernel<T>), dim3(1), dim3(EK_BLOCK), 0, \
+                           k->s, p.ctl, p.part + 2 * (size_t)p.n_leaves, p.n_chunks, \
+                           (long long)k->n, cid, p.idx, p.accept_dev, p.med, k->F, \
+                           p.Kcap, (T *)p.MT, (const T *)p.col);               \
     } while (0)
                 if (k->kind == 0) {
                     if (metric == 0)
@@ -1229,6 +1335,10 @@ extern "C" int ek_feat_pam_sweep(ek_feat *k, int32_t metric, int32_t n_medoids,
                 }
 #undef FA_T
             }
+            // (the verdict on the batch's last proposal)
+            hipLaunchKernelGGL(feat_commit_count_kernel, dim3(blocks), dim3(EK_BLOCK), 0,
+                               k->s, p.ctl, (long long)k->n, p.ndist, p.nassign, k->kdist,
+                               k->kassign, 1, -1, p.blockcnt);
             FE_HIP(hipGetLastError());
             FE_HIP(hipMemcpyAsync(&hc, p.ctl, sizeof(hc), hipMemcpyDeviceToHost, k->s));
             FE_HIP(hipStreamSynchronize(k->s));

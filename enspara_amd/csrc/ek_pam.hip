@@ -296,6 +296,15 @@ void ek_launch_count_members_multi(const int32_t *assign, int64_t n, int32_t cid
                        blockcnt, nblocks, scan, total);
 }
 
+// the scan alone (the per-workgroup counts were written by another kernel)
+void ek_launch_scan_counts(const int32_t *blockcnt, int64_t n, int64_t *scan,
+                           int64_t *total, hipStream_t s)
+{
+    const int nblocks = (int)((n + EK_BLOCK - 1) / EK_BLOCK);
+    hipLaunchKernelGGL(ek_scan_counts_multi_kernel, dim3(1), dim3(1024), 0, s,
+                       blockcnt, nblocks, scan, total);
+}
+
 void ek_launch_select_member_multi(const int32_t *assign, int64_t n, int32_t cid0,
                                    int count, const int64_t *scan,
                                    const int64_t *js_dev, int64_t *out,
@@ -1523,6 +1532,16 @@ ek_pw_total_kernel(const double *__restrict__ chunksum, int n_chunks,
     for (int c = 0; c < n_chunks; ++c)
         s = s + chunksum[2 * (size_t)c + threadIdx.x];
     out2[threadIdx.x] = s;
+}
+
+// the chunk sums alone (the caller adds them left to right itself)
+void ek_launch_pw_chunks(double *part, const EkPwShape *shapes, int n_full,
+                         int n_leaves_total, int n_chunks, hipStream_t s)
+{
+    double *chunksum = part + 2 * (size_t)n_leaves_total;
+    if (n_leaves_total > 0)
+        hipLaunchKernelGGL(ek_pw_chunk_kernel, dim3(n_chunks), dim3(128), 0, s, part,
+                           shapes, n_full, chunksum);
 }
 
 void ek_launch_pw_chunks_total(double *part, const EkPwShape *shapes, int n_full,
