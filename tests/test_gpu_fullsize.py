@@ -91,3 +91,28 @@ def test_whole_pam_sweep_at_the_bench_shape(world):
     assert sum(int(a) != int(b) for a, b in zip(med, world["centers"])) > K // 4
     np.testing.assert_array_equal(a1, wa)
     np.testing.assert_array_equal(np.asarray(d1, dtype=np.float64), wd)
+
+
+def test_rounds_at_500_atoms():
+    """BASELINE.json configs[3]'s atom count on a slice of its per-GPU shard --
+    300 000 frames x 500 atoms, 600 centers through the default ladder (rounds of
+    16 on the quad copy: 125 trips of 4 atoms, 7 groups of 16 + 13 atoms for the
+    candidates' broadcast layout) -- every center, label and distance against
+    the oracle's loop"""
+    from enspara_amd.cluster.kcenters import kcenters
+    from oracle import qcp
+    qcp.set_num_threads(_threads())
+    n, A5, K5 = 300_000, 500, 600
+    x = synth.synth(n, A5, 2000, seed=3)
+    P = qcp.Prepared(x)
+    dist = np.full(n, np.inf, dtype=np.float32)
+    assign = np.full(n, -1, dtype=np.int32)
+    centers, nxt = [], 0
+    for k in range(K5):
+        centers.append(nxt)
+        _, nxt = P.kcenters_step(P.c[nxt], P.G[nxt], k, dist, assign)
+    r = kcenters(x, "rmsd", n_clusters=K5)
+    assert [int(i) for i in r.center_indices] == centers
+    np.testing.assert_array_equal(r.assignments, assign)
+    np.testing.assert_array_equal(r.distances.astype(np.float32), dist)
+    qcp.set_num_threads(int(os.environ.get("OMP_NUM_THREADS", "8")))
