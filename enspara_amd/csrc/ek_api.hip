@@ -295,7 +295,12 @@ extern "C" int ek_ctx_create(int device, int64_t n_frames, int32_t n_atoms,
     EK_ALLOC(c->hdr, sizeof(EkMaxHdr));
     EK_ALLOC(c->pend, sizeof(EkPend));
     EK_ALLOC(c->ord, sizeof(EkChainOrd));
+#ifdef EK_P16_STATS
+    EK_ALLOC(c->tick, (256 + 64 * 16 + 2048) * sizeof(unsigned int));
+    (void)hipMemset(c->tick, 0, (256 + 64 * 16 + 2048) * sizeof(unsigned int));
+#else
     EK_ALLOC(c->tick, 256 * sizeof(unsigned int));
+#endif
     EK_ALLOC(c->rows, EK_MAX_CANDS * sizeof(EkChainRow));
     EK_ALLOC(c->vmask, (nt * EK_TILE / EK_WAVE) * sizeof(uint32_t));
     EK_ALLOC(c->ctile, ek_ctile_bytes(n_atoms));

@@ -49,12 +49,13 @@ typedef float ek_v4f __attribute__((ext_vector_type(4)));
 // frames apart)
 #define EK_P16_DSTRIDE 65
 // the queue of pairs the float32 certificate does not settle: entries of nine
-// floats + (candidate, frame) per wave; beyond the capacity a wave solves all
-// its pairs the old way
+// floats + (candidate, frame) per wave, 48 bytes apart (three 16-byte stores);
+// beyond the capacity a wave solves all its pairs the old way
 #ifndef EK_P16_QUEUE
 #define EK_P16_QUEUE 1
 #endif
 #define EK_P16_QCAP 256
+#define EK_P16_QSTRIDE 12
 // the workgroups resident at the start of a launch (256 CUs x 2), and how long
 // the second of a CU waits before it starts: ~20 us in s_sleep(127) units of
 // 64 x 127 cycles
@@ -62,6 +63,55 @@ typedef float ek_v4f __attribute__((ext_vector_type(4)));
 #ifndef EK_P16_STAGGER
 #define EK_P16_STAGGER 6
 #endif
+
+// LDS traffic between the lanes of ONE wave is in order; this only keeps the
+// compiler from moving accesses across the point
+__device__ __forceinline__ void ek_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// The last workgroup of a fused single-shard pass: the presumed acceptance order
+// (see ek_pass2_kernel), by NT threads -- the whole workgroup (t = threadIdx.x)
+// or one wave of it (t = lane).
+template <int NT>
+__device__ __forceinline__ void ek_p16_order_tail(int t, const EkPlan *plan, const EkFuse &fz,
+                                                  EkChainRow *rows, int *s_chain, int *s_cn,
+                                                  int teff, int label)
+{
+    for (int e = t; e < EK_MAX_CANDS * (EK_MAX_CANDS + 2); e += NT) {
+        const int j = e / (EK_MAX_CANDS + 2), u = e % (EK_MAX_CANDS + 2);
+        const bool live = j >= 1 && j < teff;
+        if (u == 0)
+            rows[j].cur = live ? ek_coh_load(&fz.rows[j].cur) : 0.f;
+        else if (u == 1)
+            rows[j].valid = live ? ek_coh_load(&fz.rows[j].valid) : 0;
+        else
+            rows[j].d[u - 2] = (live && u - 2 >= 1 && u - 2 < teff)
+                                   ? ek_coh_load(&fz.rows[j].d[u - 2])
+                                   : 0.f;
+    }
+    if (NT == EK_WAVE) ek_wave_sync(); else __syncthreads();
+    if (t < EK_MAX_CANDS)       // the rows are one round's: clear them
+        fz.rows[t].valid = 0;
+    if (t < EK_WAVE)
+        ek_chain_simulate_wave(plan, rows, s_chain, s_cn);
+    if (NT == EK_WAVE) ek_wave_sync(); else __syncthreads();
+    if (t < EK_MAX_CANDS)
+        fz.ord->cand[t] = t < *s_cn ? s_chain[t] : 0;
+    if (t == 0) {
+        fz.ord->n = *s_cn;
+        // candidate 0 is a center now (kcenters.py:306-309)
+        fz.hist[label].gidx = plan->gidx[0];
+        fz.hist[label].dist = plan->maxdist[0];
+        fz.hist[label].set = 1;
+        fz.ctl->n_done = label + 1;
+        fz.ctl->n_rounds = fz.ctl->n_rounds + 1;
+        *fz.tick = 0;
+    }
+}
 
 template <bool FUSE>
 __global__ void __launch_bounds__(EK_BLOCK, 2)
@@ -77,11 +127,14 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
     const EkPend *__restrict__ pend = fz.pend;
     __shared__ float red_v[EK_BLOCK / EK_WAVE];
     __shared__ uint32_t red_i[EK_BLOCK / EK_WAVE];
+    __shared__ unsigned int s_arrive, s_ticket;
     __shared__ double s_G[EK_BLOCK];
     __shared__ float s_cur[EK_BLOCK];
     __shared__ float s_D[EK_BLOCK / EK_WAVE][T * EK_P16_DSTRIDE];
 #if EK_P16_QUEUE
-    __shared__ uint32_t s_Q[EK_BLOCK / EK_WAVE][EK_P16_QCAP * 10];
+    __shared__ float s_t[EK_BLOCK];     // the frame's share of the certificate's far test
+    __shared__ __attribute__((aligned(16)))
+    uint32_t s_Q[EK_BLOCK / EK_WAVE][EK_P16_QCAP * EK_P16_QSTRIDE];
 #endif
     if (!plan->go)
         return;
@@ -104,6 +157,34 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
     }
     const int tid = threadIdx.x;
     const int lane = tid & (EK_WAVE - 1), wave = tid / EK_WAVE;
+#ifdef EK_P16_STATS     // (measurement build: where a wave's cycles go, s_memtime)
+    unsigned long long stamp[6];
+#define EK_P16_STAMP(k) stamp[k] = __builtin_amdgcn_s_memtime()
+#else
+#define EK_P16_STAMP(k)
+#endif
+#ifndef EK_P16_PRIO
+#define EK_P16_PRIO 0
+#endif
+    if (EK_P16_PRIO)
+        __builtin_amdgcn_s_setprio(EK_P16_PRIO);
+    EK_P16_STAMP(0);
+#ifdef EK_P16_STATS
+    const unsigned long long real0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
+    __shared__ unsigned int s_endt[EK_BLOCK / EK_WAVE];
+    // this CU's entry of the table of workgroup ends: XCC_ID (register 20), and
+    // SE_ID [15:13], SH_ID [12], CU_ID [11:8] of HW_ID (register 4)
+    const unsigned hwid = __builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4);
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);
+    unsigned int *cu_end = fz.tick + 256 + 64 * 16 + ((xcc & 7u) << 8 | ((hwid >> 8) & 255u));
+    if (FUSE && tid == 0) {
+        const unsigned gap = (unsigned)real0 - *(volatile unsigned int *)cu_end;
+        if (gap < 6000u) {      // (else: the launch's first workgroups)
+            atomicAdd(fz.tick + 256 + 16 * (blockIdx.x & 63) + 11, gap);
+            atomicAdd(fz.tick + 256 + 16 * (blockIdx.x & 63) + 12, 1u);
+        }
+    }
+#endif
     const int teff = plan->teff;
     const int label = plan->label;
     static_assert(EK_BLOCK == EK_TILE, "one workgroup per tile");
@@ -123,43 +204,7 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
             ticket = __hip_atomic_fetch_add(fz.tick, 1u, __ATOMIC_RELAXED,
                                             __HIP_MEMORY_SCOPE_AGENT);
     }
-    // ---- this frame's state on the way in ---------------------------------------
-    float cur0 = 0.f;
-    int32_t lab = -1;           // >= 0: the frame's state changes in this pass
-    int own = 0;                // order: this frame is candidate `own` (>= 1)
-    {
-        double Gf = 0.0;
-        if (f < n) {
-            Gf = G[f];
-            cur0 = dist[f];
-            if (FUSE) {
-                if (order) {
-#pragma unroll
-                    for (int j = 1; j < T; ++j)
-                        if (j < teff && plan->gidx[j] - fz.goff == f)
-                            own = j;
-                }
-                // kcenters.py:304-306 for the pending chain, in order (a vector
-                // is stored only where a wave holds a finite value)
-                const int pn = pend->n;
-                const uint32_t vm = pn > 0 ? fz.vmask[f >> 6] : 0u;
-                for (int k = 0; k < pn; ++k) {
-                    const int slot = pend->slot[k];
-                    if (!((vm >> (slot + 1)) & 1u))
-                        continue;
-                    const float d = vecs[(size_t)slot * n_pad + f];
-                    if (d < cur0) {
-                        cur0 = d;
-                        lab = pend->label0 + k;
-                    }
-                }
-            }
-        }
-        s_G[tid] = Gf;
-        s_cur[tid] = cur0;      // read back after the loop, by this wave only
-    }
-
-    // ---- the contraction ------------------------------------------------------------
+    // ---- the first requests of the contraction, before anything else waits --------
     // rows: this tile of the quad copy; a trip of 4 atoms = 3 loads (x, y, z),
     // 16 bytes per lane; candidates: [16 atoms][3 loads][lane group][candidate][4]
     const int n_trip = A / 4;           // whole trips; A % 4 atoms follow
@@ -186,15 +231,82 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
     ((EK_P16_ABLATE & 4) ? ablate_v :                                          \
     __builtin_bit_cast(ek_v4f, __builtin_amdgcn_raw_buffer_load_b128(          \
                                    cs, co, ((SS) * 3 + (I)) * (EK_WAVE * 16), 0)))
+    constexpr int DR = 3;               // trips the row loads run ahead; DR + 1 buffers
+    ek_v4f R[DR + 1][3];                // [trip % 4][xyz] -> 4 atoms
+    ek_v4f Cq[2][3];                    // [super-trip % 2][load] -> 4 atoms
+    // (asked for HERE: the frame's state below takes one trip to memory or two, the
+    // first rows arrive meanwhile)
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        Cq[0][i] = EK_LDC(0, i);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < DR; ++k) {
+#pragma unroll
+        for (int x = 0; x < 3; ++x)
+            R[k][x] = EK_LDR(k, x);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ... and the frame's state: everything that does not depend on something
+    // loaded is asked for before the first wait
+    double Gf = 0.0;
+    float cur0 = 0.f;
+    uint32_t vm = 0u;           // FUSE: which distance vectors this wave stored
+    if (f < n) {
+        Gf = G[f];
+        cur0 = dist[f];
+        if (FUSE)
+            vm = fz.vmask[f >> 6];
+    }
+    // (the only point where the four waves meet, while all of them wait for memory
+    // anyway: from here on each wave runs to its end on its own -- its tables in
+    // LDS are its own, and the workgroup's business at the end is done by
+    // whichever wave arrives last)
+    if (tid == 0)
+        s_arrive = 0;
+    __syncthreads();
+    // ---- this frame's state on the way in ---------------------------------------
+    int32_t lab = -1;           // >= 0: the frame's state changes in this pass
+    int own = 0;                // order: this frame is candidate `own` (>= 1)
+    {
+        if (FUSE && f < n) {
+            if (order) {
+#pragma unroll
+                for (int j = 1; j < T; ++j)
+                    if (j < teff && plan->gidx[j] - fz.goff == f)
+                        own = j;
+            }
+        }
+        // kcenters.py:304-306 for the pending chain, in order.  A vector is stored
+        // only where a wave holds a finite value: five waves in six have none
+        // (lane 0's word is the wave's) and skip the walk over the chain.
+        const int pn = FUSE ? pend->n : 0;
+        if (FUSE && pn > 0 && __builtin_amdgcn_readfirstlane(vm) != 0u) {
+            for (int k = 0; k < pn; ++k) {
+                const int slot = pend->slot[k];
+                if (f >= n || !((vm >> (slot + 1)) & 1u))
+                    continue;
+                const float d = vecs[(size_t)slot * n_pad + f];
+                if (d < cur0) {
+                    cur0 = d;
+                    lab = pend->label0 + k;
+                }
+            }
+        }
+        s_G[tid] = Gf;
+        s_cur[tid] = cur0;      // read back after the loop, by this wave only
+#if EK_P16_QUEUE
+        s_t[tid] = ek_far_t_frame((float)Gf, A, cur0);
+#endif
+    }
+
+    // ---- the contraction ------------------------------------------------------------
     ek_v16f acc[9];
 #pragma unroll
     for (int q = 0; q < 9; ++q)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
             acc[q][r] = 0.f;
-    constexpr int DR = 3;               // trips the row loads run ahead; DR + 1 buffers
-    ek_v4f R[DR + 1][3];                // [trip % 4][xyz] -> 4 atoms
-    ek_v4f Cq[2][3];                    // [super-trip % 2][load] -> 4 atoms
     // three of the nine matrix instructions of one atom: S_ij += x_i * y_j, j
     // fixed; the candidates come from lane group G of the register
 #define EK_MFMA3(J, XX, YY, ZZ, CC, G)                                         \
@@ -233,17 +345,10 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
             __builtin_amdgcn_sched_barrier(0);                                 \
         }                                                                      \
     }
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-        Cq[0][i] = EK_LDC(0, i);
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int k = 0; k < DR; ++k) {
-#pragma unroll
-        for (int x = 0; x < 3; ++x)
-            R[k][x] = EK_LDR(k, x);
-    }
-    __builtin_amdgcn_sched_barrier(0);
+    EK_P16_STAMP(1);
+    if (EK_P16_PRIO)
+        __builtin_amdgcn_s_setprio(0);
     int t0 = 0;
     for (; t0 + 8 <= n_trip; t0 += 8) {
         EK_TRIP16(0, t0 + 0)
@@ -303,6 +408,9 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
     // whose queue overflows (the first passes of a fit, where little is far yet)
     // takes the old path for all its pairs.  Same results either way: a
     // certified pair is +inf for every consumer, the others are solved as before.
+    EK_P16_STAMP(2);
+    if (EK_P16_PRIO)
+        __builtin_amdgcn_s_setprio(EK_P16_PRIO);
     {
         const int cand = lane & 15;
         const double Gc = ctrace[cand];
@@ -310,13 +418,16 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
 #if EK_P16_QUEUE
         uint32_t *Q = s_Q[wave];
         int qn = 0;                     // wave-uniform
-        // (two pairs at a time, their certificates in one basic block: the
-        // chains are long and dependent, two of them interleave)
+        // (two pairs at a time in one basic block; a frame outside the shard or
+        // a candidate outside the plan asks for nothing)
+        const float tc = ek_far_t_center((float)Gc);
+        const int n_here = (int)std::min<int64_t>(n - f0 - wave * EK_WAVE, EK_WAVE);
+        const int fr_lim = cand < teff ? n_here : 0;
 #pragma unroll
         for (int r0 = 0; r0 < 16; r0 += 2) {
-            float S[2][9];
+            float S[2][9], t[2];
             int fr[2];
-            bool need[2];
+            bool far[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int r = r0 + u;
@@ -324,41 +435,37 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
 #pragma unroll
                 for (int q = 0; q < 9; ++q)
                     S[u][q] = acc[q][r];
+                t[u] = s_t[wave * EK_WAVE + fr[u]] + tc;
             }
-            {
-                float gs[2], cu[2];
-                bool far[2];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    gs[u] = (float)(s_G[wave * EK_WAVE + fr[u]] + Gc);
-                    cu[u] = s_cur[wave * EK_WAVE + fr[u]];
-                }
-                ek_far_certified_f32_w<2>(S, gs, A, cu, far);
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-                    need[u] = cand < teff && f0 + wave * EK_WAVE + fr[u] < n && !far[u];
-            }
+            ek_far_certified_f32_w<2>(S, t, far);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
+                const bool need = fr[u] < fr_lim && !far[u];
                 Dw[cand * EK_P16_DSTRIDE + fr[u]] = __builtin_inff();
-                const unsigned long long m = __ballot(need[u]);
-                const int pos = qn + __popcll(m & ((1ull << lane) - 1ull));
-                if (need[u] && pos < EK_P16_QCAP) {
-                    uint32_t *e = Q + pos * 10;
-#pragma unroll
-                    for (int q = 0; q < 9; ++q)
-                        e[q] = __float_as_uint(S[u][q]);
-                    e[9] = (uint32_t)(cand << 8 | fr[u]);
+                const unsigned long long m = __ballot(need);
+                if (m) {                // wave-uniform
+                    const int pos = qn + __popcll(m & ((1ull << lane) - 1ull));
+                    if (need && pos < EK_P16_QCAP) {
+                        uint4 *e = (uint4 *)(Q + pos * EK_P16_QSTRIDE);
+                        e[0] = make_uint4(__float_as_uint(S[u][0]), __float_as_uint(S[u][1]),
+                                          __float_as_uint(S[u][2]), __float_as_uint(S[u][3]));
+                        e[1] = make_uint4(__float_as_uint(S[u][4]), __float_as_uint(S[u][5]),
+                                          __float_as_uint(S[u][6]), __float_as_uint(S[u][7]));
+                        e[2] = make_uint4(__float_as_uint(S[u][8]),
+                                          (uint32_t)(cand << 8 | fr[u]), 0u, 0u);
+                    }
+                    qn += __popcll(m);
                 }
-                qn += __popcll(m);
             }
         }
+        EK_P16_STAMP(3);
 #ifdef EK_P16_STATS     // (measurement build: waves, overflowing waves, queued pairs)
         if (FUSE && lane == 0) {
-            atomicAdd(fz.tick + 240, 1u);
-            atomicAdd(fz.tick + 241, qn > EK_P16_QCAP ? 1u : 0u);
-            atomicAdd(fz.tick + 242, (unsigned)qn);
-            atomicAdd(fz.tick + 243, (unsigned)((qn + 63) / 64));
+            unsigned int *t = fz.tick + 256 + 16 * (blockIdx.x & 63);
+            atomicAdd(t + 0, 1u);
+            atomicAdd(t + 1, qn > EK_P16_QCAP ? 1u : 0u);
+            atomicAdd(t + 2, (unsigned)qn);
+            atomicAdd(t + 3, (unsigned)((qn + 63) / 64));
         }
 #endif
         if (qn <= EK_P16_QCAP) {
@@ -366,12 +473,13 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
             for (int base = 0; base < qn; base += EK_WAVE) {
                 const int e = base + lane;
                 if (e < qn) {
-                    const uint32_t *ent = Q + e * 10;
-                    float S[9];
-#pragma unroll
-                    for (int q = 0; q < 9; ++q)
-                        S[q] = __uint_as_float(ent[q]);
-                    const int c2 = (int)(ent[9] >> 8), fr = (int)(ent[9] & 255u);
+                    const uint4 *ent = (const uint4 *)(Q + e * EK_P16_QSTRIDE);
+                    const uint4 e0 = ent[0], e1 = ent[1], e2 = ent[2];
+                    const float S[9] = {
+                        __uint_as_float(e0.x), __uint_as_float(e0.y), __uint_as_float(e0.z),
+                        __uint_as_float(e0.w), __uint_as_float(e1.x), __uint_as_float(e1.y),
+                        __uint_as_float(e1.z), __uint_as_float(e1.w), __uint_as_float(e2.x)};
+                    const int c2 = (int)(e2.y >> 8), fr = (int)(e2.y & 255u);
                     Dw[c2 * EK_P16_DSTRIDE + fr] =
                         ek_rmsd_from_S_below(S, s_G[wave * EK_WAVE + fr], ctrace[c2], A,
                                              s_cur[wave * EK_WAVE + fr]);
@@ -407,7 +515,8 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
         }
         }
     }
-    __syncthreads();
+    EK_P16_STAMP(4);
+    ek_wave_sync();             // (s_D[wave] is written and read by this wave alone)
     // ---- lane = frame again -------------------------------------------------------
     float bestv = -__builtin_inff();
     uint32_t besti = 0xffffffffu;
@@ -457,12 +566,72 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
             fz.vmask[f >> 6] = wmask;
     }
     ek_wave_argmax(bestv, besti);
+#ifdef EK_P16_STATS
+    EK_P16_STAMP(5);
+    if (FUSE && lane == 0)
+        for (int k = 0; k < 5; ++k)     // units of 64 cycles
+            atomicAdd(fz.tick + 256 + 16 * (blockIdx.x & 63) + 4 + k,
+                      (unsigned)((stamp[k + 1] - stamp[k]) >> 6));
+    if (FUSE && lane == 0)      // the wave's life in 10 ns ticks
+        atomicAdd(fz.tick + 256 + 16 * (blockIdx.x & 63) + 9,
+                  (unsigned)(__builtin_amdgcn_s_memrealtime() - real0));
+#endif
+    __shared__ EkChainRow rows[EK_MAX_CANDS];
+    __shared__ int s_chain[EK_MAX_CANDS];
+    __shared__ int s_cn;
     if (lane == 0) {
         red_v[wave] = bestv;
         red_i[wave] = besti;
     }
-    __syncthreads();
-    if (tid == 0) {
+    if (order && owner_blk) {
+        // The few workgroups that hold a candidate frame: their rows have to be in
+        // place before they count as arrived, all four waves go on together.
+        __syncthreads();
+        if (tid == 0) {
+            float v = red_v[0];
+            uint32_t i = red_i[0];
+#pragma unroll
+            for (int w = 1; w < EK_BLOCK / EK_WAVE; ++w)
+                if (ek_better(red_v[w], red_i[w], v, i)) {
+                    v = red_v[w];
+                    i = red_i[w];
+                }
+            blockmax[blockIdx.x].val = v;
+            blockmax[blockIdx.x].idx = i;
+        }
+        if (ek_arrive_last(fz.tick))
+            ek_p16_order_tail<EK_BLOCK>(tid, plan, fz, rows, s_chain, &s_cn, teff, label);
+        return;
+    }
+    // Every other workgroup: no wave waits for another (a barrier here held each
+    // wave for ~20 us, the matrix pipe of its SIMD idle whenever the other
+    // resident wave was not in its loop either: profiles/r04/README.md).  A wave
+    // leaves its maximum in LDS and counts itself; the one that counts last
+    // finishes the workgroup's business alone.
+    if (tid == 0)
+        s_ticket = ticket;      // (before wave 0 counts itself: LDS is in order)
+#ifdef EK_P16_STATS
+    if (lane == 0)
+        s_endt[wave] = (unsigned)__builtin_amdgcn_s_memrealtime();
+#endif
+    unsigned int arrived = 0;
+    if (lane == 0)
+        arrived = __hip_atomic_fetch_add(&s_arrive, 1u, __ATOMIC_ACQ_REL,
+                                         __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (__builtin_amdgcn_readfirstlane(arrived) != EK_BLOCK / EK_WAVE - 1)
+        return;
+#ifdef EK_P16_STATS
+    if (FUSE && lane == 0) {    // first to last wave of the workgroup, 10 ns ticks
+        unsigned lo = s_endt[0], hi = s_endt[0];
+        for (int w = 1; w < EK_BLOCK / EK_WAVE; ++w) {
+            lo = min(lo, s_endt[w]);
+            hi = max(hi, s_endt[w]);
+        }
+        atomicAdd(fz.tick + 256 + 16 * (blockIdx.x & 63) + 10, hi - lo);
+        *(volatile unsigned int *)cu_end = (unsigned)__builtin_amdgcn_s_memrealtime();
+    }
+#endif
+    if (lane == 0) {
         float v = red_v[0];
         uint32_t i = red_i[0];
 #pragma unroll
@@ -474,61 +643,10 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
         blockmax[blockIdx.x].val = v;
         blockmax[blockIdx.x].idx = i;
     }
-    if (order) {
-        // the last workgroup: the presumed acceptance order (see ek_pass2_kernel)
-        __shared__ EkChainRow rows[EK_MAX_CANDS];
-        __shared__ int s_chain[EK_MAX_CANDS];
-        __shared__ int s_cn;
-        __shared__ bool early_last;
-        bool last;
-        if (owner_blk) {            // after its rows are in place
-            last = ek_arrive_last(fz.tick);
-        } else {
-            if (tid == 0)
-                early_last = ticket == gridDim.x - 1;
-            __syncthreads();
-            last = early_last;
-        }
-        if (!last)
-            return;
-        for (int e = tid; e < EK_MAX_CANDS * (EK_MAX_CANDS + 2); e += EK_BLOCK) {
-            const int j = e / (EK_MAX_CANDS + 2), u = e % (EK_MAX_CANDS + 2);
-            const bool live = j >= 1 && j < teff;
-            if (u == 0)
-                rows[j].cur = live ? ek_coh_load(&fz.rows[j].cur) : 0.f;
-            else if (u == 1)
-                rows[j].valid = live ? ek_coh_load(&fz.rows[j].valid) : 0;
-            else
-                rows[j].d[u - 2] = (live && u - 2 >= 1 && u - 2 < teff)
-                                       ? ek_coh_load(&fz.rows[j].d[u - 2])
-                                       : 0.f;
-        }
-        __syncthreads();
-        if (tid < EK_MAX_CANDS)     // the rows are one round's: clear them
-            fz.rows[tid].valid = 0;
-        if (tid < EK_WAVE)
-            ek_chain_simulate_wave(plan, rows, s_chain, &s_cn);
-        __syncthreads();
-        if (tid < EK_MAX_CANDS)
-            fz.ord->cand[tid] = tid < s_cn ? s_chain[tid] : 0;
-        if (tid == 0) {
-            fz.ord->n = s_cn;
-            // candidate 0 is a center now (kcenters.py:306-309)
-            fz.hist[label].gidx = plan->gidx[0];
-            fz.hist[label].dist = plan->maxdist[0];
-            fz.hist[label].set = 1;
-            fz.ctl->n_done = label + 1;
-            fz.ctl->n_rounds = fz.ctl->n_rounds + 1;
-            *fz.tick = 0;
-#ifdef EK_P16_STATS
-            if ((fz.ctl->n_rounds & 15) == 0)
-                printf("pass16 round %d label %d: waves %u overflow %u queued %u drains %u\n",
-                       fz.ctl->n_rounds, label, fz.tick[240], fz.tick[241], fz.tick[242],
-                       fz.tick[243]);
-            fz.tick[240] = fz.tick[241] = fz.tick[242] = fz.tick[243] = 0;
-#endif
-        }
-    }
+    // the workgroup that drew the last ticket (at its start: every owner had
+    // finished by then) works out the presumed order
+    if (order && s_ticket == gridDim.x - 1)
+        ek_p16_order_tail<EK_WAVE>(lane, plan, fz, rows, s_chain, &s_cn, teff, label);
 }
 
 void ek_launch_pass16(bool fuse, const float *qtiles, const double *G, float *dist,

@@ -13,9 +13,11 @@
 #if defined(__HIP_DEVICE_COMPILE__)
 #define EK_RCPF(x) __builtin_amdgcn_rcpf(x)
 #define EK_SQRTF(x) __builtin_amdgcn_sqrtf(x)
+#define EK_RSQF(x) __builtin_amdgcn_rsqf(x)
 #else
 #define EK_RCPF(x) (1.0f / (x))
 #define EK_SQRTF(x) __builtin_sqrtf(x)
+#define EK_RSQF(x) (1.0f / __builtin_sqrtf(x))
 #endif
 
 #define EK_EVALPREC 1e-11
@@ -128,96 +130,73 @@ __device__ __forceinline__ float ek_rmsd_from_S(const float (&S)[9], double Gx,
 //
 // Most distances a pass computes are never used: the pair is far, all a strict
 // "<" needs to know.  The early-stopped solve below still pays the float64
-// coefficients, the discriminant and two or three Newton steps with their
-// float64 divisions for such a pair (~240 vector instructions, most of them
-// half rate).  This test answers the same question from float32 arithmetic on
-// S alone (~140 full-rate instructions, no division), for about 99 % of the far
-// pairs of the bench's data; where it cannot, the solve below runs as before,
-// so results never depend on it.
+// coefficients and the discriminant for such a pair (~270 vector instructions).
+// This test answers the same question from float32 arithmetic on S alone, in
+// closed form: ~80 instructions, five of them quarter rate, no iteration, no
+// branch.  Where it cannot decide, the solve below runs as before, so results
+// never depend on it.
 //
-// With singular values s1 >= s2 >= |s3| of S, s3 signed like det S:
-//   q = sum S_ij^2 = s1^2 + s2^2 + s3^2,  b = |cof S|_F^2 = sum (si sj)^2,
-//   d = det S = s1 s2 s3;  x = s1^2 is the largest root of
-//   c(x) = x^3 - q x^2 + b x - d^2,  s2^2 + s3^2 = (b - d^2 / x) / x,
-//   (s2 + s3)^2 = s2^2 + s3^2 + 2 d / s1 =: G2,  lambda_max = s1 + sqrt(G2),
+// With singular values s1 >= s2 >= |s3| of S, s3 signed like det S, and
+// everything divided by the matching power of q = sum S_ij^2 = s1^2 + s2^2 + s3^2:
+//   x = s1^2, y = s2^2 + s3^2 = 1 - x, p = s2^2 s3^2 <= y^2 / 4,
+//   b = |cof S|_F^2 = x y + p,  d = det S,  sqrt(p) = |d| / sqrt(x),
+//   (s2 + s3)^2 = y + 2 d / sqrt(x) =: G2,  lambda_max = s1 + s2 + s3,
 // and the quartic's largest root is apart from the next one by 2 (s2 + s3).
-// (1) x is bracketed, x_lo <= s1^2 <= x_up: five Newton steps on c from
-//     q - b / q >= s1^2, then SIGN checks of c at (1 +- 1e-3) times the
-//     iterate with the float32 evaluation error as margin -- c increases beyond
-//     its larger critical point x+ = (q + sqrt(q^2 - 3 b)) / 3 <= s1^2, so
-//     x > x+ with c(x) > 0 is above s1^2 and x > x+ with c(x) < 0 below it;
-//     x+ itself is a lower bound that needs no check;
-// (2) SEPARATION: G2 >= 2e-4 q from the bracket, i.e. the two largest roots at
-//     least ~0.03 sqrt(q) apart -- a hundred times what the discriminant test
-//     below asks for: the reference iteration then converges (from above,
-//     monotonically, by at least a quarter of its distance per step) to
-//     lambda_max within 1e-6 (Gx + Gy) in its fifty steps;
-// (3) FAR: Gx + Gy - 2 U > n_atoms cur^2 (1 + 1e-4) + 4e-6 (Gx + Gy) with
-//     U >= lambda_max from the bracket.
+// (1) x is BRACKETED by b alone.  p >= 0 gives x^2 - x + b >= 0, and x >= 1/3
+//     is then on the upper branch whenever b < 2/9:  x >= (1 + sqrt(1 - 4 b)) / 2
+//     (exact for rank two); p <= y^2 / 4 gives 3 x^2 - 2 x + 4 b - 1 <= 0:
+//     x <= (1 + 2 sqrt(1 - 3 b)) / 3 (exact for s2^2 = s3^2).
+// (2) SEPARATION: G2 >= (1 - x_up) - 2 max(-d, 0) / sqrt(x_lo) >= 2e-4, i.e. the
+//     two largest roots at least ~0.03 sqrt(q) apart -- a hundred times what the
+//     discriminant test below asks for: the reference iteration then converges
+//     (from above, monotonically, by at least a quarter of its distance per
+//     step) to lambda_max within 1e-6 (Gx + Gy) in its fifty steps.
+// (3) FAR: lambda_max^2 = q + 2 e2, e2 = s1 s2 + s1 s3 + s2 s3, e2^2 = b + 2 d
+//     lambda_max <= b + 2 max(d, 0) sqrt(3 q): with U the bound this gives,
+//     Gx + Gy - 2 U > n_atoms cur^2 (1 + 1e-4) + 5e-6 (Gx + Gy), asked as
+//     t > 0 and t^2 > 4 U^2 for t = (Gx + Gy)(1 - 6e-6) - n_atoms cur^2 1.00011
+//     (the caller's: ek_far_t; float32 roundings of t are inside the 1e-6).
 // Every rounding of the float32 evaluation is covered by an explicit slack
-// (1e-6 relative on b, d and the roots/reciprocals, 4e-6 q^3 on c); an
-// overflow, a NaN or q = 0 fails the comparisons and certifies nothing.
-// Quantities are normalised by q so that the slacks are plain numbers.
-// Measured (round 4, profiles/r04/README.md): sound, and NOT faster.  float64
-// multiply-adds issue at the float32 rate on this chip, so the test costs
-// ~0.6-0.8 of the path it replaces, and a wave pays the old path as well as soon
-// as ONE of its 64 pairs is not certified (0.989^64: half the waves).  Off by
-// default; tests/test_qcp_host.py keeps it honest.
+// (3e-6 absolute on b / q^2, 2e-6 on d / q^1.5 -- the cofactors are differences
+// of products below q / 2 --, 2e-6 relative on roots and reciprocals); q outside
+// [1e-12, 1e12] (where the raw cofactors could leave the float32 range), an
+// overflow or a NaN fails a comparison and certifies nothing.
+// Yield on the bench's data: 98.3 % of the far pairs (the iterated bracket of
+// round 4's first version: 98.9 %, at ~190 instructions).  Alone it would still
+// not pay -- a wave runs the float64 path as soon as ONE of its 64 pairs is not
+// certified --: ek_pass16_kernel compacts the uncertified pairs into a queue.
+// tests/test_qcp_host.py keeps it honest.
 #ifndef EK_FAR_F32
 #define EK_FAR_F32 0
 #endif
 
-// W pairs at once, statement by statement: the chains below are long and
-// dependent (each step waits out the latency of the one before), W = 2 of them
-// interleaved in program order fill the gaps.  Straight-line code, no early
-// exit: a wave does not branch on its slowest lane.
-#define EK_W_ for (int u = 0; u < W; ++u)
-// (after every statement its W results pass through one empty asm statement:
-// both are computed by then, and the next statement starts from both -- the
-// compiler otherwise sinks each pair's chain to where its result is used, one
-// chain after the other)
-#if defined(__HIP_DEVICE_COMPILE__)
-template <int W> __device__ __forceinline__ void ek_tie(float (&v)[W])
+// the caller's side of (3): t for a pair from the two traces and the frame's
+// current distance (ek_pass16_kernel splits it into a per-frame and a
+// per-candidate part, computed once each)
+__device__ __forceinline__ float ek_far_t_frame(float G, int n_atoms, float cur)
 {
-    if constexpr (W == 2)
-        asm volatile("" : "+v"(v[0]), "+v"(v[1]));
-    else
-        asm volatile("" : "+v"(v[0]));
+    return __builtin_fmaf(G, 0.999994f, -(((float)n_atoms * (cur * cur)) * 1.00011f));
 }
-#define EK_TIE_(V) ek_tie<W>(V);
-#else
-#define EK_TIE_(V)
-#endif
+__device__ __forceinline__ float ek_far_t_center(float G) { return G * 0.999994f; }
+
+// W pairs at once, statement by statement (straight-line code, no early exit:
+// a wave does not branch on its slowest lane)
+#define EK_W_ for (int u = 0; u < W; ++u)
 template <int W>
 __device__ __forceinline__ void ek_far_certified_f32_w(const float (&S)[W][9],
-                                                       const float (&Gsum)[W], int n_atoms,
-                                                       const float (&cur)[W], bool (&far)[W])
+                                                       const float (&t)[W], bool (&far)[W])
 {
-    float q[W], rs[W], N[W][9], bn[W], dn[W], dn2[W];
-    bool ok[W];
+    float q[W], c[W][9], b[W], d[W];
 #pragma unroll
     EK_W_ q[u] = S[u][0] * S[u][0];
-    EK_TIE_(q)
 #pragma unroll
     for (int j = 1; j < 9; ++j)
 #pragma unroll
         EK_W_ q[u] = __builtin_fmaf(S[u][j], S[u][j], q[u]);
-    EK_TIE_(q)
-#pragma unroll
-    EK_W_ ok[u] = q[u] > 1e-30f && q[u] < 1e30f;    // (false for NaN too)
-    // N = S / sqrt(q): |N|_F^2 = 1 within 1.5e-6, nothing below under- or overflows
-#pragma unroll
-    EK_W_ rs[u] = EK_SQRTF(EK_RCPF(q[u]));
-    EK_TIE_(rs)
-#pragma unroll
-    for (int j = 0; j < 9; ++j)
-#pragma unroll
-        EK_W_ N[u][j] = S[u][j] * rs[u];
-    // cofactors, b = |cof N|_F^2 <= 1/3, d = det N; absolute errors below 1e-6
-    float c[W][9];
+    // cofactors, b = |cof S|_F^2 <= q^2 / 3, d = det S
 #define EK_COF_(K, A0, A1, B0, B1)                                             \
     _Pragma("unroll") EK_W_ c[u][K] =                                         \
-        __builtin_fmaf(N[u][A0], N[u][A1], -(N[u][B0] * N[u][B1]));
+        __builtin_fmaf(S[u][A0], S[u][A1], -(S[u][B0] * S[u][B1]));
     EK_COF_(0, 4, 8, 5, 7)
     EK_COF_(1, 5, 6, 3, 8)
     EK_COF_(2, 3, 7, 4, 6)
@@ -229,138 +208,47 @@ __device__ __forceinline__ void ek_far_certified_f32_w(const float (&S)[W][9],
     EK_COF_(8, 0, 4, 1, 3)
 #undef EK_COF_
 #pragma unroll
-    EK_W_ bn[u] = c[u][0] * c[u][0];
-    EK_TIE_(bn)
+    EK_W_ b[u] = c[u][0] * c[u][0];
 #pragma unroll
     for (int j = 1; j < 9; ++j)
 #pragma unroll
-        EK_W_ bn[u] = __builtin_fmaf(c[u][j], c[u][j], bn[u]);
-    EK_TIE_(bn)
+        EK_W_ b[u] = __builtin_fmaf(c[u][j], c[u][j], b[u]);
 #pragma unroll
-    EK_W_ dn[u] = N[u][0] * c[u][0];
-    EK_TIE_(dn)
+    EK_W_ d[u] = __builtin_fmaf(
+        S[u][2], c[u][2], __builtin_fmaf(S[u][1], c[u][1], S[u][0] * c[u][0]));
 #pragma unroll
-    EK_W_ dn[u] = __builtin_fmaf(N[u][1], c[u][1], dn[u]);
-    EK_TIE_(dn)
-#pragma unroll
-    EK_W_ dn[u] = __builtin_fmaf(N[u][2], c[u][2], dn[u]);
-    EK_TIE_(dn)
-#pragma unroll
-    EK_W_ dn2[u] = dn[u] * dn[u];
-    EK_TIE_(dn2)
-    // c(x) = x^3 - x^2 + bn x - dn^2, x = s1^2 / q in [1/3, 1]; evaluated with an
-    // absolute error below 8e-6 (the unit coefficient stands for 1 +- 1.5e-6)
-    // x+ from above (guard) and from below (a lower bound of x that needs no check)
-    float disc[W], xg[W], xpl[W], x[W];
-#pragma unroll
-    EK_W_ disc[u] = __builtin_fmaf(-3.0f, bn[u], 1.0f);
-    EK_TIE_(disc)
-#pragma unroll
-    EK_W_ xg[u] = (1.0f + EK_SQRTF(__builtin_fmaxf(disc[u] + 1e-5f, 0.0f))) *
-                  (0.33333334f * 1.000003f);
-    EK_TIE_(xg)
-#pragma unroll
-    EK_W_ xpl[u] = (1.0f + EK_SQRTF(__builtin_fmaxf(disc[u] - 1e-5f, 0.0f))) *
-                   (0.33333331f * 0.999997f);
-    EK_TIE_(xpl)
-#pragma unroll
-    EK_W_ x[u] = 1.0f - bn[u];
-    EK_TIE_(x)
-#pragma unroll
-    for (int it = 0; it < 5; ++it) {
-        float cv[W], cp[W];
-#pragma unroll
-        EK_W_ cv[u] = __builtin_fmaf(__builtin_fmaf(x[u] - 1.0f, x[u], bn[u]), x[u], -dn2[u]);
-    EK_TIE_(cv)
-#pragma unroll
-        EK_W_ cp[u] = __builtin_fmaf(__builtin_fmaf(3.0f, x[u], -2.0f), x[u], bn[u]);
-    EK_TIE_(cp)
-#pragma unroll
-        EK_W_ x[u] = __builtin_fmaf(-cv[u], EK_RCPF(cp[u]), x[u]);
-    EK_TIE_(x)
+    EK_W_
+    {
+        const float s = EK_RSQF(q[u]), rq = s * s;
+        const float bn = (b[u] * rq) * rq;          // b / q^2 within 3e-6
+        const float dn = (d[u] * rq) * s;           // d / q^1.5 within 2e-6
+        // (1) the bracket of x = s1^2 / q
+        const float h3 = EK_SQRTF(__builtin_fmaxf(__builtin_fmaf(-3.0f, bn, 1.00001f), 0.0f));
+        const float x_up = __builtin_fmaf(h3, 0.666668f, 0.333334f);
+        const float h4 = EK_SQRTF(__builtin_fmaxf(__builtin_fmaf(-4.0f, bn, 0.99998f), 0.0f));
+        const float x_lo = bn < 0.22f ? __builtin_fmaf(h4, 0.499999f, 0.499999f) : 0.333333f;
+        // (2) (s2 + s3)^2 / q from below
+        const float nd = __builtin_fmaxf(2e-6f - dn, 0.0f);
+        const float g_lo = __builtin_fmaf(-2.000006f * nd, EK_RSQF(x_lo), 1.0f - x_up);
+        // (3) (2 lambda_max)^2 from above
+        const float pd = __builtin_fmaxf(dn + 2e-6f, 0.0f);
+        const float e2 = EK_SQRTF(__builtin_fmaf(pd, 3.464109f, bn + 3e-6f)) * 1.000001f;
+        const float U2 = q[u] * __builtin_fmaf(e2, 8.00004f, 4.00002f);
+        far[u] = q[u] > 1e-12f && q[u] < 1e12f &&   // (false for NaN too)
+                 g_lo >= 2e-4f && t[u] > 0.0f && t[u] * t[u] > U2;
     }
-    float x_up[W], c_up[W], x_try[W], c_lo[W], x_lo[W];
-#pragma unroll
-    EK_W_ x_up[u] = __builtin_fmaxf(x[u] * 1.001f, xg[u]);
-    EK_TIE_(x_up)
-#pragma unroll
-    EK_W_ c_up[u] = __builtin_fmaf(__builtin_fmaf(x_up[u] - 1.0f, x_up[u], bn[u]), x_up[u],
-                                   -dn2[u]);
-    EK_TIE_(c_up)
-#pragma unroll
-    EK_W_ ok[u] = ok[u] && c_up[u] > 8e-6f;         // (false for NaN too)
-#pragma unroll
-    EK_W_ x_try[u] = x[u] * 0.999f;
-    EK_TIE_(x_try)
-#pragma unroll
-    EK_W_ c_lo[u] = __builtin_fmaf(__builtin_fmaf(x_try[u] - 1.0f, x_try[u], bn[u]),
-                                   x_try[u], -dn2[u]);
-    EK_TIE_(c_lo)
-#pragma unroll
-    EK_W_ x_lo[u] = (x_try[u] > xg[u] && c_lo[u] < -8e-6f) ? x_try[u] : xpl[u];
-    EK_TIE_(x_lo)
-    // bounds of (s2^2 + s3^2) / q and of 2 |d| / (s1 q)
-    float dl[W], du[W], rx_lo[W], rx_up[W], y_lo[W], y_up[W], rs_lo[W], rs_up[W];
-    float g_lo[W], g_up[W];
-#pragma unroll
-    EK_W_ dl[u] = __builtin_fmaxf(__builtin_fabsf(dn[u]) - 1e-6f, 0.0f);
-    EK_TIE_(dl)
-#pragma unroll
-    EK_W_ du[u] = __builtin_fabsf(dn[u]) + 1e-6f;
-    EK_TIE_(du)
-#pragma unroll
-    EK_W_ rx_lo[u] = EK_RCPF(x_lo[u]) * 1.000001f;      // >= 1 / x_lo
-    EK_TIE_(rx_lo)
-#pragma unroll
-    EK_W_ rx_up[u] = EK_RCPF(x_up[u]) * 0.999999f;      // <= 1 / x_up
-    EK_TIE_(rx_up)
-#pragma unroll
-    EK_W_ y_lo[u] = ((bn[u] - 1e-6f) - du[u] * du[u] * rx_lo[u]) * rx_up[u];
-    EK_TIE_(y_lo)
-#pragma unroll
-    EK_W_ y_up[u] = ((bn[u] + 1e-6f) - dl[u] * dl[u] * rx_up[u]) * rx_lo[u];
-    EK_TIE_(y_up)
-#pragma unroll
-    EK_W_ rs_lo[u] = EK_SQRTF(rx_lo[u]) * 1.000001f;    // >= sqrt(q) / s1
-    EK_TIE_(rs_lo)
-#pragma unroll
-    EK_W_ rs_up[u] = EK_SQRTF(rx_up[u]) * 0.999999f;    // <= sqrt(q) / s1
-    EK_TIE_(rs_up)
-#pragma unroll
-    EK_W_ g_lo[u] = dn[u] > 0.0f ? __builtin_fmaf(2.0f * dl[u], rs_up[u], y_lo[u])
-                                 : __builtin_fmaf(-2.0f * du[u], rs_lo[u], y_lo[u]);
-    EK_TIE_(g_lo)
-#pragma unroll
-    EK_W_ g_up[u] = dn[u] > 0.0f ? __builtin_fmaf(2.0f * du[u], rs_lo[u], y_up[u])
-                                 : __builtin_fmaf(-2.0f * dl[u], rs_up[u], y_up[u]);
-    EK_TIE_(g_up)
-#pragma unroll
-    EK_W_ ok[u] = ok[u] && g_lo[u] >= 2e-4f;    // else: the largest root is not certainly separated
-    // lambda_max <= sqrt(q) (s1_up + sqrt(G2_up)) / sqrt(q_n)
-    float U[W];
-#pragma unroll
-    EK_W_ U[u] = (EK_SQRTF(x_up[u]) + EK_SQRTF(__builtin_fmaxf(g_up[u], 0.0f))) * 1.000003f;
-    EK_TIE_(U)
-#pragma unroll
-    EK_W_ U[u] = U[u] * EK_SQRTF(q[u]) * 1.000002f;
-    EK_TIE_(U)
-#pragma unroll
-    EK_W_ far[u] = ok[u] && __builtin_fmaf(-2.0f, U[u], Gsum[u]) >
-                                __builtin_fmaf((float)n_atoms * (cur[u] * cur[u]), 1.0001f,
-                                               5e-6f * Gsum[u]);
 }
 #undef EK_W_
-#undef EK_TIE_
 
 __device__ __forceinline__ bool ek_far_certified_f32(const float (&S)[9], float Gsum,
                                                      int n_atoms, float cur)
 {
-    float S1[1][9], G1[1] = {Gsum}, c1[1] = {cur};
+    float S1[1][9], t1[1] = {ek_far_t_frame(Gsum, n_atoms, cur)};
     bool f1[1];
 #pragma unroll
     for (int j = 0; j < 9; ++j)
         S1[0][j] = S[j];
-    ek_far_certified_f32_w<1>(S1, G1, n_atoms, c1, f1);
+    ek_far_certified_f32_w<1>(S1, t1, f1);
     return f1[0];
 }
 

@@ -267,6 +267,28 @@ ek_round_next_kernel(EkRound r, int bootstrap)
     if (!bootstrap && !r.plan->go)
         return;
     const int tid = threadIdx.x;
+#ifdef EK_P16_STATS     // (measurement build: what ek_pass16_kernel's waves counted)
+    if (blockIdx.x == 0 && tid == 0) {
+        unsigned int *t = r.tick + 256, v[13];
+        for (int k = 0; k < 13; ++k) {
+            v[k] = 0;
+            for (int sl = 0; sl < 64; ++sl)
+                v[k] += t[16 * sl + k];
+        }
+        if (v[0] >= 16 * 15000u) {
+            printf("pass16 label %d: waves %u overflow %u queued %u drains %u; cycles per "
+                   "wave: head %u loop %u certificates %u drain %u tail %u; a wave lives %u ns; "
+                   "first to last wave of a workgroup %u ns; from a workgroup's end to the "
+                   "next one's start on its CU %u ns (%u samples)\n",
+                   r.ctl->n_done, v[0], v[1], v[2], v[3], 64 * (v[4] / v[0]),
+                   64 * (v[5] / v[0]), 64 * (v[6] / v[0]), 64 * (v[7] / v[0]),
+                   64 * (v[8] / v[0]), 10 * (v[9] / v[0]), 10 * (v[10] / (v[0] / 4)),
+                   10 * (v[11] / (v[12] ? v[12] : 1)), v[12]);
+            for (int k = 0; k < 64 * 16; ++k)
+                t[k] = 0;
+        }
+    }
+#endif
     const EkTop *top = (const EkTop *)r.top;
     const bool done = r.ctl->stopped || r.ctl->n_done >= r.ctl->limit;
     if (!done) {
