@@ -152,11 +152,6 @@ void ek_launch_assign(const float *tiles, const double *G, int64_t n, int A,
 // (distance bits, center index): lowest index wins ties, as util.py:199-203.
 // ===========================================================================
 typedef float ek_f16v __attribute__((ext_vector_type(16)));
-#ifndef EK_ASSIGN_QUEUE
-#define EK_ASSIGN_QUEUE 1
-#endif
-#define EK_AQ_CAP 256
-#define EK_AQ_STRIDE 12
 
 __global__ void __launch_bounds__(EK_BLOCK, 2)
 ek_assign_mfma_kernel(const float *__restrict__ tiles,
@@ -173,14 +168,6 @@ ek_assign_mfma_kernel(const float *__restrict__ tiles,
 #endif
     constexpr int ablate = EK_ASSIGN_ABLATE;
     __shared__ unsigned long long best[64];
-    // the block's 64 traces, and per wave the queue of the pairs the float32
-    // certificate does not settle (see ek_pass16_kernel: nine floats + (frame,
-    // center) in 48 bytes; beyond the capacity a wave solves all its pairs)
-    __shared__ double s_G[64];
-#if EK_ASSIGN_QUEUE
-    __shared__ __attribute__((aligned(16)))
-    uint32_t s_Q[EK_BLOCK / EK_WAVE][EK_AQ_CAP * EK_AQ_STRIDE];
-#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -189,11 +176,8 @@ ek_assign_mfma_kernel(const float *__restrict__ tiles,
     // (+inf, no center): every real key is smaller, and the first look at a
     // frame's best-so-far reads +inf -- which ek_rmsd_from_S_below never
     // abandons against -- not a NaN bit pattern
-    if (tid < 64) {
+    if (tid < 64)
         best[tid] = 0x7f800000ffffffffull;
-        const int64_t f = (int64_t)blockIdx.x * 64 + tid;
-        s_G[tid] = f < n ? G[f] : 0.0;
-    }
     __syncthreads();
 
     const int64_t f0 = (int64_t)blockIdx.x * 64 + wf * 32;   // wave's frames
@@ -272,86 +256,11 @@ ek_assign_mfma_kernel(const float *__restrict__ tiles,
 
             const int c = c0 + fl;
             const double gc = (c < K) ? Gc[c] : 0.0;
-            // Most of a lane's 16 distances are never used: the pair is farther
-            // than the frame's best so far, all the minimum asks.  As in
-            // ek_pass16_kernel every pair first takes the float32 certificate
-            // (ek_qcp.h: sound, ~98 % of the far pairs, no float64), straight
-            // line; the others are queued in LDS and solved afterwards densely,
-            // one per lane -- one float64 solve per wave instead of sixteen.  The
-            // first centers of a frame (best so far +inf: nothing is far) and a
-            // wave whose queue overflows take the plain loop.  Same result: a
-            // certified pair's distance is above the frame's best by a margin,
-            // it could never have become the minimum nor tied with it.
-            const int64_t n_here = n - f0;          // frames of this wave below it
-            bool plain = true;
-#if EK_ASSIGN_QUEUE
-            if (!ablate && cg > 0) {                // wave-uniform
-                uint32_t *Q = s_Q[wave];
-                const float tc = ek_far_t_center((float)gc);
-                const int fr_lim = c < K ? (int)(n_here < 32 ? n_here : 32) : 0;
-                int qn = 0;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    const int f_l = (r & 3) + 8 * (r >> 2) + 4 * kh;
-                    float S[1][9] = {{acc[0][0][r], acc[0][1][r], acc[0][2][r],
-                                      acc[1][0][r], acc[1][1][r], acc[1][2][r],
-                                      acc[2][0][r], acc[2][1][r], acc[2][2][r]}};
-                    const float seen = __uint_as_float(
-                        ((volatile unsigned int *)&best[wf * 32 + f_l])[1]);
-                    const float t[1] = {
-                        ek_far_t_frame((float)((volatile double *)s_G)[wf * 32 + f_l], A, seen) + tc};
-                    bool far[1];
-                    ek_far_certified_f32_w<1>(S, t, far);
-                    const bool need = f_l < fr_lim && !far[0];
-                    const unsigned long long m = __ballot(need);
-                    if (m) {                        // wave-uniform
-                        const int pos = qn + __popcll(m & ((1ull << lane) - 1ull));
-                        if (need && pos < EK_AQ_CAP) {
-                            uint4 *e = (uint4 *)(Q + pos * EK_AQ_STRIDE);
-                            e[0] = make_uint4(__float_as_uint(S[0][0]), __float_as_uint(S[0][1]),
-                                              __float_as_uint(S[0][2]), __float_as_uint(S[0][3]));
-                            e[1] = make_uint4(__float_as_uint(S[0][4]), __float_as_uint(S[0][5]),
-                                              __float_as_uint(S[0][6]), __float_as_uint(S[0][7]));
-                            e[2] = make_uint4(__float_as_uint(S[0][8]),
-                                              (uint32_t)(fl << 8 | f_l), 0u, 0u);
-                        }
-                        qn += __popcll(m);
-                    }
-                }
-                if (qn <= EK_AQ_CAP) {
-                    plain = false;
-                    // (one wave: its LDS accesses are in order, no barrier)
-                    for (int base = 0; base < qn; base += EK_WAVE) {
-                        const int e = base + lane;
-                        if (e < qn) {
-                            const uint4 *ent = (const uint4 *)(Q + e * EK_AQ_STRIDE);
-                            const uint4 e0 = ent[0], e1 = ent[1], e2 = ent[2];
-                            const float S[9] = {
-                                __uint_as_float(e0.x), __uint_as_float(e0.y),
-                                __uint_as_float(e0.z), __uint_as_float(e0.w),
-                                __uint_as_float(e1.x), __uint_as_float(e1.y),
-                                __uint_as_float(e1.z), __uint_as_float(e1.w),
-                                __uint_as_float(e2.x)};
-                            const int cl = (int)(e2.y >> 8), f_l = (int)(e2.y & 255u);
-                            const float seen = __uint_as_float(
-                                ((volatile unsigned int *)&best[wf * 32 + f_l])[1]);
-                            const float d = ek_rmsd_from_S_below(S, ((volatile double *)s_G)[wf * 32 + f_l],
-                                                                 Gc[c0 + cl], A, seen);
-                            const unsigned long long key =
-                                ((unsigned long long)__float_as_uint(d) << 32) |
-                                (unsigned int)(c0 + cl);
-                            atomicMin(&best[wf * 32 + f_l], key);
-                        }
-                    }
-                }
-            }
-#endif
-            if (plain) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int f_l = (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (f_l < n_here && c < K) {
+                const int64_t f = f0 + f_l;
+                if (f < n && c < K) {
                     const float S[9] = {acc[0][0][r], acc[0][1][r], acc[0][2][r],
                                         acc[1][0][r], acc[1][1][r], acc[1][2][r],
                                         acc[2][0][r], acc[2][1][r], acc[2][2][r]};
@@ -366,14 +275,13 @@ ek_assign_mfma_kernel(const float *__restrict__ tiles,
                         // lower center index must still win them)
                         const float seen = __uint_as_float(
                             ((volatile unsigned int *)&best[wf * 32 + f_l])[1]);
-                        d = ek_rmsd_from_S_below(S, ((volatile double *)s_G)[wf * 32 + f_l], gc, A, seen);
+                        d = ek_rmsd_from_S_below(S, G[f], gc, A, seen);
                     }
                     const unsigned long long key =
                         ((unsigned long long)__float_as_uint(d) << 32) |
                         (unsigned int)c;
                     atomicMin(&best[wf * 32 + f_l], key);
                 }
-            }
             }
         }
     }

@@ -144,10 +144,12 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
     // to arrive, the one that got the second wave slot of its SIMDs therefore
     // starts ~20 us late (every later workgroup inherits the offset from the
     // one whose slot it takes): 147 -> 133 us per pass at 125 k frames, 2 % at
-    // 10^6.  (What this does NOT buy: f32 matrix instructions and another
-    // wave's vector instructions do not overlap on a SIMD -- tools/probes/
-    // coexec.hip: phases of 2700 MFMAs and 6000 FMAs of two waves take the sum
-    // of both, staggered or not -- so the quartic solves are paid in full.)
+    // 10^6.  (What the wave stamps of the measurement build say about the two
+    // waves of a SIMD, -DEK_P16_STATS, profiles/r04/README.md: a wave's 2700
+    // matrix instructions take 88.5 k cycles -- 32.8 each, the pipe's rate --
+    // while the other wave is outside its loop, whatever that one executes; the
+    // phases outside the loop are waits, ~100 k cycles a tile, and the pipe idles
+    // whenever both waves are in one.)
     if (gridDim.x > EK_P16_FIRST_WGS / 2 && blockIdx.x < EK_P16_FIRST_WGS) {
         // HW_REG_HW_ID (4), bits [3:0]: the wave's slot on its SIMD
         const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
@@ -234,8 +236,19 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
     constexpr int DR = 3;               // trips the row loads run ahead; DR + 1 buffers
     ek_v4f R[DR + 1][3];                // [trip % 4][xyz] -> 4 atoms
     ek_v4f Cq[2][3];                    // [super-trip % 2][load] -> 4 atoms
-    // (asked for HERE: the frame's state below takes one trip to memory or two, the
-    // first rows arrive meanwhile)
+    // The frame's state first (vector loads return in order: what is asked for
+    // before it is waited for with it), then the first rows: everything that does
+    // not depend on something loaded is on its way before the first wait.
+    double Gf = 0.0;
+    float cur0 = 0.f;
+    uint32_t vm = 0u;           // FUSE: which distance vectors this wave stored
+    if (f < n) {
+        Gf = G[f];
+        cur0 = dist[f];
+        if (FUSE)
+            vm = fz.vmask[f >> 6];
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < 3; ++i)
         Cq[0][i] = EK_LDC(0, i);
@@ -247,17 +260,6 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
             R[k][x] = EK_LDR(k, x);
     }
     __builtin_amdgcn_sched_barrier(0);
-    // ... and the frame's state: everything that does not depend on something
-    // loaded is asked for before the first wait
-    double Gf = 0.0;
-    float cur0 = 0.f;
-    uint32_t vm = 0u;           // FUSE: which distance vectors this wave stored
-    if (f < n) {
-        Gf = G[f];
-        cur0 = dist[f];
-        if (FUSE)
-            vm = fz.vmask[f >> 6];
-    }
     // (the only point where the four waves meet, while all of them wait for memory
     // anyway: from here on each wave runs to its end on its own -- its tables in
     // LDS are its own, and the workgroup's business at the end is done by
@@ -269,19 +271,19 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
     int32_t lab = -1;           // >= 0: the frame's state changes in this pass
     int own = 0;                // order: this frame is candidate `own` (>= 1)
     {
-        if (FUSE && f < n) {
-            if (order) {
+        if (order && owner_blk && f < n) {  // (15 workgroups of a pass at most)
 #pragma unroll
-                for (int j = 1; j < T; ++j)
-                    if (j < teff && plan->gidx[j] - fz.goff == f)
-                        own = j;
-            }
+            for (int j = 1; j < T; ++j)
+                if (j < teff && plan->gidx[j] - fz.goff == f)
+                    own = j;
         }
         // kcenters.py:304-306 for the pending chain, in order.  A vector is stored
-        // only where a wave holds a finite value: five waves in six have none
-        // (lane 0's word is the wave's) and skip the walk over the chain.
-        const int pn = FUSE ? pend->n : 0;
+        // only where a wave holds a finite value: a wave that stored none (lane
+        // 0's word is the wave's) skips the walk over the chain -- fifteen
+        // dependent trips to memory otherwise.
+        const int pn = FUSE ? __builtin_amdgcn_readfirstlane(pend->n) : 0;
         if (FUSE && pn > 0 && __builtin_amdgcn_readfirstlane(vm) != 0u) {
+            const int label0 = __builtin_amdgcn_readfirstlane(pend->label0);
             for (int k = 0; k < pn; ++k) {
                 const int slot = pend->slot[k];
                 if (f >= n || !((vm >> (slot + 1)) & 1u))
@@ -289,7 +291,7 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
                 const float d = vecs[(size_t)slot * n_pad + f];
                 if (d < cur0) {
                     cur0 = d;
-                    lab = pend->label0 + k;
+                    lab = label0 + k;
                 }
             }
         }
@@ -423,13 +425,17 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
         const float tc = ek_far_t_center((float)Gc);
         const int n_here = (int)std::min<int64_t>(n - f0 - wave * EK_WAVE, EK_WAVE);
         const int fr_lim = cand < teff ? n_here : 0;
+#ifndef EK_P16_W
+#define EK_P16_W 2
+#endif
+        constexpr int W = EK_P16_W;     // pairs whose certificates share a basic block
 #pragma unroll
-        for (int r0 = 0; r0 < 16; r0 += 2) {
-            float S[2][9], t[2];
-            int fr[2];
-            bool far[2];
+        for (int r0 = 0; r0 < 16; r0 += W) {
+            float S[W][9], t[W];
+            int fr[W];
+            bool far[W];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < W; ++u) {
                 const int r = r0 + u;
                 fr[u] = 16 * (r >> 2) + 4 * (lane >> 4) + (r & 3);
 #pragma unroll
@@ -437,9 +443,25 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
                     S[u][q] = acc[q][r];
                 t[u] = s_t[wave * EK_WAVE + fr[u]] + tc;
             }
-            ek_far_certified_f32_w<2>(S, t, far);
+            ek_far_certified_f32_w<W>(S, t, far);
+            // (all W verdicts before the first of them is acted on: the compiler
+            // otherwise sinks each pair's chain behind the branch of the pair
+            // before, one dependent chain after the other)
+            {
+                int fi[W];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+                for (int u = 0; u < W; ++u)
+                    fi[u] = far[u];
+                if constexpr (W == 4)
+                    asm volatile("" : "+v"(fi[0]), "+v"(fi[1]), "+v"(fi[2]), "+v"(fi[3]));
+                else if constexpr (W == 2)
+                    asm volatile("" : "+v"(fi[0]), "+v"(fi[1]));
+#pragma unroll
+                for (int u = 0; u < W; ++u)
+                    far[u] = fi[u] != 0;
+            }
+#pragma unroll
+            for (int u = 0; u < W; ++u) {
                 const bool need = fr[u] < fr_lim && !far[u];
                 Dw[cand * EK_P16_DSTRIDE + fr[u]] = __builtin_inff();
                 const unsigned long long m = __ballot(need);

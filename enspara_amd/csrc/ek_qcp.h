@@ -234,8 +234,9 @@ __device__ __forceinline__ void ek_far_certified_f32_w(const float (&S)[W][9],
         const float pd = __builtin_fmaxf(dn + 2e-6f, 0.0f);
         const float e2 = EK_SQRTF(__builtin_fmaf(pd, 3.464109f, bn + 3e-6f)) * 1.000001f;
         const float U2 = q[u] * __builtin_fmaf(e2, 8.00004f, 4.00002f);
-        far[u] = q[u] > 1e-12f && q[u] < 1e12f &&   // (false for NaN too)
-                 g_lo >= 2e-4f && t[u] > 0.0f && t[u] * t[u] > U2;
+        // (false for NaN too; "&", not "&&": no branch, no lane waits for another)
+        far[u] = (q[u] > 1e-12f) & (q[u] < 1e12f) & (g_lo >= 2e-4f) & (t[u] > 0.0f) &
+                 (t[u] * t[u] > U2);
     }
 }
 #undef EK_W_
