@@ -405,19 +405,15 @@ void ek_launch_pam_active(const float *dist, const int32_t *assign, int64_t n,
 // Where (atom a, candidate c, coordinate k) of a round's T candidates sits in the
 // candidate tile the pass kernel reads: T <= 8 [atom][pair][xyz][2] (pairs of
 // candidates as scalar operands of v_pk_fma_f32, ek_spec.hip); T = 16
-// [16 atoms][load 0..2][lane group 0..3][candidate][atom % 4]: the twelve
-// (trip of 4 atoms, xyz) slices of 16 atoms are numbered quad = 3 * trip + k;
-// slice `quad` is load quad / 4, lane group quad % 4, so that one 16-byte load
-// per lane fetches four slices of the 16 candidates and the matrix instruction
-// picks its slice with B's lane-group broadcast (ek_pass16.hip).  The tile
-// holds A + EK_CTILE_PAD atoms rounded up to whole groups of 16, zeros past the
-// last.
+// [16 atoms][xyz][lane][trip]: the B operand of v_mfma_f32_16x16x4_f32 for one
+// trip of 4 atoms and one coordinate has atom (lane / 16) of the trip and
+// candidate (lane % 16) in each lane; one 16-byte load per lane fetches that
+// operand for the four trips of 16 atoms (ek_pass16.hip).  The tile holds A +
+// EK_CTILE_PAD atoms rounded up to whole groups of 16, zeros past the last.
 static inline __host__ __device__ size_t ek_ctile_index(int T, int a, int c, int k)
 {
-    if (T == 16) {
-        const int quad = ((a >> 2) & 3) * 3 + k;
-        return ((((size_t)(a >> 4) * 3 + quad / 4) * 4 + quad % 4) * 16 + c) * 4 + (a & 3);
-    }
+    if (T == 16)    // [16 atoms][xyz][lane = (a % 4) * 16 + c][trip of 4 atoms]
+        return ((((size_t)(a >> 4) * 3 + k) * 4 + (a & 3)) * 16 + c) * 4 + ((a >> 2) & 3);
     return (size_t)a * (3 * T) + (c / 2) * 6 + k * 2 + (c & 1);
 }
 static inline __host__ __device__ int ek_ctile_atoms(int A)  // incl. padding

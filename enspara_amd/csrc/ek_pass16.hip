@@ -209,7 +209,6 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
     // ---- the first requests of the contraction, before anything else waits --------
     // rows: this tile of the quad copy; a trip of 4 atoms = 3 loads (x, y, z),
     // 16 bytes per lane; candidates: [16 atoms][3 loads][lane group][candidate][4]
-    const int n_trip = A / 4;           // whole trips; A % 4 atoms follow
     const int NQ = (A + 3) / 4;
     const float *tb = qtiles + (size_t)(f0 / EK_TILE) * (size_t)NQ * (3 * EK_TILE * 4);
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -248,6 +247,11 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
         if (FUSE)
             vm = fz.vmask[f >> 6];
     }
+    int pn_v = 0, label0_v = 0; // (the pending chain's length and first label: with them)
+    if (FUSE) {
+        pn_v = pend->n;
+        label0_v = pend->label0;
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < 3; ++i)
@@ -281,9 +285,9 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
         // only where a wave holds a finite value: a wave that stored none (lane
         // 0's word is the wave's) skips the walk over the chain -- fifteen
         // dependent trips to memory otherwise.
-        const int pn = FUSE ? __builtin_amdgcn_readfirstlane(pend->n) : 0;
+        const int pn = __builtin_amdgcn_readfirstlane(pn_v);
         if (FUSE && pn > 0 && __builtin_amdgcn_readfirstlane(vm) != 0u) {
-            const int label0 = __builtin_amdgcn_readfirstlane(pend->label0);
+            const int label0 = __builtin_amdgcn_readfirstlane(label0_v);
             for (int k = 0; k < pn; ++k) {
                 const int slot = pend->slot[k];
                 if (f >= n || !((vm >> (slot + 1)) & 1u))
@@ -303,54 +307,49 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
     }
 
     // ---- the contraction ------------------------------------------------------------
-    ek_v16f acc[9];
+    // 9 x 4 accumulators of 16 frames x 16 candidates: acc[3 i + j][g] is S_ij of the
+    // frames 16 g .. 16 g + 15 of the wave (lane l, register r: frame 16 g + 4 (l / 16)
+    // + r, candidate l % 16)
+    ek_v4f acc[9][4];
 #pragma unroll
     for (int q = 0; q < 9; ++q)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            acc[q][r] = 0.f;
-    // three of the nine matrix instructions of one atom: S_ij += x_i * y_j, j
-    // fixed; the candidates come from lane group G of the register
-#define EK_MFMA3(J, XX, YY, ZZ, CC, G)                                         \
-    {                                                                          \
-        acc[0 + J] = __builtin_amdgcn_mfma_f32_16x16x1f32(XX, CC, acc[0 + J], 0, 0, 4 + (G)); \
-        acc[3 + J] = __builtin_amdgcn_mfma_f32_16x16x1f32(YY, CC, acc[3 + J], 0, 0, 4 + (G)); \
-        acc[6 + J] = __builtin_amdgcn_mfma_f32_16x16x1f32(ZZ, CC, acc[6 + J], 0, 0, 4 + (G)); \
-    }
-    // slice (trip-in-super-trip TT, axis J) of the candidates is quad TT * 3 + J
-    // of its 16 atoms: load (quad / 4), lane group (quad % 4)
+        for (int g = 0; g < 4; ++g)
+            acc[q][g] = ek_v4f{0.f, 0.f, 0.f, 0.f};
     // One trip K (0 .. 7 of the unrolled pair of super-trips) at trip index TT:
-    // the 36 matrix instructions of its 4 atoms with the requests for the
-    // candidates of the NEXT 16 atoms (first trip of a super-trip, asked for
-    // before the rows of the same trip: vector loads are counted in order) and
-    // for the rows of trip TT + DR spread among them.
+    // the 36 matrix instructions of its 4 atoms -- frames' group g, coordinates i
+    // (rows) and j (candidates) -- with the requests for the candidates of the
+    // NEXT 16 atoms (first trip of a super-trip, asked for before the rows of the
+    // same trip: vector loads are counted in order) and for the rows of trip
+    // TT + DR spread among them.
 #define EK_TRIP16(K, TT)                                                       \
     {                                                                          \
         constexpr int SB = ((K) / 4) % 2;                                      \
-        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                        \
-            EK_MFMA3(0, R[(K) % 4][0][e], R[(K) % 4][1][e], R[(K) % 4][2][e],  \
-                     Cq[SB][(((K) % 4) * 3 + 0) / 4][e], (((K) % 4) * 3 + 0) % 4) \
-            __builtin_amdgcn_sched_barrier(0);                                 \
-            if ((K) % 4 == 0 && e < 3) {                                       \
-                Cq[1 - SB][e] = EK_LDC((TT) / 4 + 1, e);                       \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g) {                        \
+            _Pragma("unroll") for (int j = 0; j < 3; ++j) {                    \
+                _Pragma("unroll") for (int i = 0; i < 3; ++i)                  \
+                    acc[3 * i + j][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(  \
+                        R[(K) % 4][i][g], Cq[SB][j][(K) % 4], acc[3 * i + j][g], 0, 0, 0); \
                 __builtin_amdgcn_sched_barrier(0);                             \
+                if ((K) % 4 == 0 && g == 0) {                                  \
+                    Cq[1 - SB][j] = EK_LDC((TT) / 4 + 1, j);                   \
+                    __builtin_amdgcn_sched_barrier(0);                         \
+                }                                                              \
+                if (g == 1) {                                                  \
+                    R[((K) + DR) % 4][j] = EK_LDR((TT) + DR, j);               \
+                    __builtin_amdgcn_sched_barrier(0);                         \
+                }                                                              \
             }                                                                  \
-            EK_MFMA3(1, R[(K) % 4][0][e], R[(K) % 4][1][e], R[(K) % 4][2][e],  \
-                     Cq[SB][(((K) % 4) * 3 + 1) / 4][e], (((K) % 4) * 3 + 1) % 4) \
-            __builtin_amdgcn_sched_barrier(0);                                 \
-            if (e < 3) {                                                       \
-                R[((K) + DR) % 4][e] = EK_LDR((TT) + DR, e);                   \
-                __builtin_amdgcn_sched_barrier(0);                             \
-            }                                                                  \
-            EK_MFMA3(2, R[(K) % 4][0][e], R[(K) % 4][1][e], R[(K) % 4][2][e],  \
-                     Cq[SB][(((K) % 4) * 3 + 2) / 4][e], (((K) % 4) * 3 + 2) % 4) \
-            __builtin_amdgcn_sched_barrier(0);                                 \
         }                                                                      \
     }
     __builtin_amdgcn_sched_barrier(0);
     EK_P16_STAMP(1);
     if (EK_P16_PRIO)
         __builtin_amdgcn_s_setprio(0);
+    // (the last trip's atoms past A are zeros in rows and candidates alike: a
+    // product +0 added to an accumulator leaves its bits -- an accumulator is never
+    // -0, it starts at +0 and +0 + -0 = +0 -- so every chain is the A atoms' own)
+    const int n_trip = NQ;
     int t0 = 0;
     for (; t0 + 8 <= n_trip; t0 += 8) {
         EK_TRIP16(0, t0 + 0)
@@ -373,29 +372,8 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
     EK_REST16(4)
     EK_REST16(5)
     EK_REST16(6)
-    // the A % 4 atoms after the last whole trip, one at a time (their rows and
-    // candidates fetched for themselves, every lane its own candidate's: a
-    // product with the zeros of the padding is never issued, the chain of an
-    // accumulator is exactly the A atoms)
-    for (int a = 4 * n_trip; a < A; ++a) {
-        const float *rq = tb + (size_t)n_trip * (3 * EK_TILE * 4) + tid * 4 + (a & 3);
-        const float x = rq[0], y = rq[EK_TILE * 4], z = rq[2 * EK_TILE * 4];
-        const float c0 = ctile[ek_ctile_index(16, a, lane & 15, 0)];
-        const float c1 = ctile[ek_ctile_index(16, a, lane & 15, 1)];
-        const float c2 = ctile[ek_ctile_index(16, a, lane & 15, 2)];
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x1f32(x, c0, acc[0], 0, 0, 0);
-        acc[3] = __builtin_amdgcn_mfma_f32_16x16x1f32(y, c0, acc[3], 0, 0, 0);
-        acc[6] = __builtin_amdgcn_mfma_f32_16x16x1f32(z, c0, acc[6], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x1f32(x, c1, acc[1], 0, 0, 0);
-        acc[4] = __builtin_amdgcn_mfma_f32_16x16x1f32(y, c1, acc[4], 0, 0, 0);
-        acc[7] = __builtin_amdgcn_mfma_f32_16x16x1f32(z, c1, acc[7], 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f32_16x16x1f32(x, c2, acc[2], 0, 0, 0);
-        acc[5] = __builtin_amdgcn_mfma_f32_16x16x1f32(y, c2, acc[5], 0, 0, 0);
-        acc[8] = __builtin_amdgcn_mfma_f32_16x16x1f32(z, c2, acc[8], 0, 0, 0);
-    }
 #undef EK_REST16
 #undef EK_TRIP16
-#undef EK_MFMA3
 #undef EK_LDC
 #undef EK_LDR
 
@@ -440,7 +418,7 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
                 fr[u] = 16 * (r >> 2) + 4 * (lane >> 4) + (r & 3);
 #pragma unroll
                 for (int q = 0; q < 9; ++q)
-                    S[u][q] = acc[q][r];
+                    S[u][q] = acc[q][r >> 2][r & 3];
                 t[u] = s_t[wave * EK_WAVE + fr[u]] + tc;
             }
             ek_far_certified_f32_w<W>(S, t, far);
@@ -517,7 +495,7 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
             float S[9];
 #pragma unroll
             for (int q = 0; q < 9; ++q)
-                S[q] = acc[q][r];
+                S[q] = acc[q][r >> 2][r & 3];
             // (the bound is the frame's distance before this pass: what candidate 0
             // makes of it is only known in the frame's own lane, below)
             float d = __builtin_inff();
@@ -542,11 +520,16 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
     // ---- lane = frame again -------------------------------------------------------
     float bestv = -__builtin_inff();
     uint32_t besti = 0xffffffffu;
+    // (the frame's sixteen new distances in one go: read one by one behind the
+    // branches below, each is a trip to LDS of its own)
+    float dcs[T];
+#pragma unroll
+    for (int c = 0; c < T; ++c)
+        dcs[c] = s_D[wave][c * EK_P16_DSTRIDE + lane];
     if (f < n) {
-        const float *Dw = s_D[wave];
         // candidate 0: the new center of this iteration (kcenters.py:298-306)
         float cur = cur0;
-        const float d0 = Dw[lane];
+        const float d0 = dcs[0];
         if (d0 < cur) {
             cur = d0;
             lab = label;
@@ -569,7 +552,7 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
 #pragma unroll
         for (int c = 1; c < T; ++c) {
             if (c < teff) {
-                float dc = Dw[c * EK_P16_DSTRIDE + lane];
+                float dc = dcs[c];
                 if (!(dc < cur))
                     dc = __builtin_inff();
                 if (FUSE) {
@@ -691,26 +674,29 @@ void ek_launch_pass16(bool fuse, const float *qtiles, const double *G, float *di
 
 
 // ---- the quad copy of the frames ----------------------------------------------------
-// qtiles[((tile * NQ + a / 4) * 3 + k) * 256 + f % 256][a % 4], NQ = ceil(A / 4),
-// zeros for the atoms past the last: made once per loaded shard from the
-// frame-minor tiles (reads of 1 KB rows, 16-byte-per-lane writes).
+// For tile t, trip q (atoms 4 q .. 4 q + 3), coordinate k: 256 slots of 16 bytes,
+// slot 64 w + 16 e + f16 = the A operands of wave w of the tile for atom 4 q + e:
+// the four floats are frames 64 w + 16 g + f16, g = 0 .. 3 (one per group of 16
+// frames) -- what lane 16 e + f16 of that wave hands v_mfma_f32_16x16x4_f32 for
+// the groups' four matrix instructions.  Zeros for the atoms past the last.  Made
+// once per loaded shard from the frame-minor tiles.
 __global__ void __launch_bounds__(EK_BLOCK)
 ek_quad_tiles_kernel(const float *__restrict__ tiles, int A, int NQ,
                      float *__restrict__ qtiles)
 {
     const int l = threadIdx.x;
+    const int w = l >> 6, e = (l >> 4) & 3, f16 = l & 15;
     const size_t tile = blockIdx.x;
-    const float *src = tiles + tile * 3 * (size_t)A * EK_TILE + l;
+    const float *src = tiles + tile * 3 * (size_t)A * EK_TILE + 64 * w + f16;
     ek_v4f *dst = (ek_v4f *)qtiles + tile * (size_t)NQ * 3 * EK_TILE + l;
     for (int q = blockIdx.y; q < NQ; q += gridDim.y) {
+        const int a = 4 * q + e;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             ek_v4f v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int a = 4 * q + e;
-                v[e] = a < A ? src[(size_t)(3 * a + k) * EK_TILE] : 0.f;
-            }
+            for (int g = 0; g < 4; ++g)
+                v[g] = a < A ? src[(size_t)(3 * a + k) * EK_TILE + 16 * g] : 0.f;
             dst[(size_t)(q * 3 + k) * EK_TILE] = v;
         }
     }
