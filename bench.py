@@ -770,8 +770,9 @@ def main():
                 "algorithmic_flops_per_launch": launch_flops,
                 "why": "16 candidates per frame read: 24 flop per byte, the f32 "
                        "matrix pipe (86 GFLOP per pass) and HBM (3.7 GB) are "
-                       "both ~60-70 % busy; the quartic solves do not overlap "
-                       "with matrix instructions (DESIGN.md 4a)",
+                       "both ~60-70 % busy, and with both the chip is at its power "
+                       "limit: it holds ~2.3 GHz under this kernel, not 2.4 "
+                       "(DESIGN.md 4a)",
                 "hbm": hbm}
     else:
         roof = dict(hbm)

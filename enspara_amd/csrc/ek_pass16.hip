@@ -5,31 +5,34 @@
 // HBM-bound, ek_kcenters.hip).  Every frame against SIXTEEN candidates is a
 // dense contraction -- S[frame][cand][i][j] = sum_a x[frame][a][i] y[cand][a][j],
 // M = frames x 3, N = candidates x 3, K = atoms -- with 24 flop per byte.  Here
-// the sums run on v_mfma_f32_16x16x1_4b_f32:
+// the sums run on v_mfma_f32_16x16x4_f32:
 //
-//   * 4 blocks of 16 x 16 per instruction, ONE k per instruction: the A
-//     operand is a frame row (lane = frame, 64 frames = 4 blocks of 16), the B
-//     operand 16 candidates' coordinate j of the same atom; nine instructions
-//     per atom (i, j = x, y, z), 144 accumulators per lane.
+//   * 16 frames x 16 candidates x FOUR atoms per instruction: the A operand
+//     has (frame l % 16 of a group of 16, atom l / 16 of the trip) in lane l,
+//     the B operand (candidate l % 16, atom l / 16); a wave's 64 frames are
+//     four groups, so a trip of 4 atoms is 4 groups x 3 x 3 coordinate pairs
+//     = 36 instructions, 36 accumulators of 4 registers = 144 per lane.
 //   * every accumulator is the IEEE FMA chain over the atoms in ascending
-//     order -- one k per instruction, a fused multiply-add per element
-//     (tools/probes/mfma16_probe.hip: bit-identical to fmaf in k order) -- so
-//     the distances are the bits the one-center kernel and the CPU checker
-//     produce.
-//   * rows (round 4): the frames' QUAD copy, [tile][atom / 4][xyz][frame %
-//     256][atom % 4] -- one 16-byte load per lane is atoms a .. a + 3 of one
-//     axis of the lane's frame = the A operands of four consecutive atoms;
-//     three loads of 1 KB per wave and trip of 4 atoms where the frame-minor
-//     tiles took twelve of 256 B.  The per-wave queue of outstanding loads was
-//     what bounded the bytes in flight (profiles/r03/README.md).
-//   * candidates (round 4): B's lane-group broadcast (blgp 4 + g: lanes
-//     16 g .. 16 g + 15 feed all four blocks; tools/probes/mfma_bcast_probe.hip)
-//     lets ONE 16-byte load per lane carry four different (trip, axis) slices
-//     of the 16 candidates -- three loads per 16 atoms, every byte of them
-//     used, where every lane of all four groups used to fetch the same 16
-//     values: three loads per 4 atoms.
+//     order -- a fused multiply-add per element and atom, the four of an
+//     instruction in order (tools/probes/mfma16x4_probe.hip: bit-identical to
+//     fmaf in k order) -- so the distances are the bits the one-center kernel
+//     and the CPU checker produce.  Round 3's form, 16x16x1 in 4 blocks, took
+//     ONE atom per instruction and read and wrote all 16 accumulator registers
+//     of a coordinate pair for it: four times the register traffic for the
+//     same products.  The pass is POWER-limited (profiles/r04/README.md): with
+//     a quarter of that traffic the chip holds 2.30 GHz under it instead of
+//     2.08, 0.847 -> 0.780 ms.
+//   * rows: the frames' QUAD copy (ek_quad_tiles_kernel below) -- one 16-byte
+//     load per lane is the lane's A operand for the wave's four groups: three
+//     loads of 1 KB per wave and trip of 4 atoms where the frame-minor tiles
+//     took twelve of 256 B.  The per-wave queue of outstanding loads was what
+//     bounded the bytes in flight (profiles/r03/README.md).
+//   * candidates: one 16-byte load per lane is the lane's B operand of one
+//     coordinate for FOUR trips (ek_ctile_index) -- three loads per 16 atoms,
+//     every byte of them used.
 //   * a lane ends up with 16 (frame, candidate) pairs, all of ONE candidate
-//     (l % 16) and 16 frames: it solves their quartics (early stop against the
+//     (l % 16) and 16 frames (16 g + 4 (l / 16) + r): the float32 certificate
+//     settles the far ones, the rest are solved (early stop against the
 //     frame's distance BEFORE this pass), the results cross an LDS transposition
 //     into the frame-per-lane domain, and from there on the epilogue is
 //     ek_pass2_kernel's: candidate 0 updates the state (kcenters.py:298-306),
@@ -41,7 +44,6 @@
 #include "ek_reduce.h"
 #include "ek_chain_dev.h"
 
-typedef float ek_v16f __attribute__((ext_vector_type(16)));
 typedef float ek_v4f __attribute__((ext_vector_type(4)));
 
 // LDS per wave: the frames' traces and current distances, then the 16 x 64
