@@ -161,6 +161,7 @@ int ek_free_all(ek_ctx *c)
     (void)hipFree(c->cen_aos);
     (void)hipFree(c->cen_G);
     (void)hipFree(c->cen_tiles);
+    (void)hipFree(c->cen_blocks);
     (void)hipFree(c->bat_blockcnt);
     (void)hipFree(c->bat_scan);
     (void)hipFree(c->bat_sel);
@@ -427,8 +428,8 @@ extern "C" int ek_set_option(ek_ctx *c, int32_t key, int32_t value)
         c->sp_max_pairs = value;
         return EK_OK;
     case 2:
-        if (value < 0 || value > 2)
-            return ek_fail(EK_EARG, "ek_set_option: assign variant 0..2");
+        if (value < 0 || value > 3)
+            return ek_fail(EK_EARG, "ek_set_option: assign variant 0..3");
         c->assign_variant = value;
         return EK_OK;
     default:
@@ -1351,10 +1352,34 @@ extern "C" int ek_assign_nearest(ek_ctx *c, const float *centers_xyz,
             return rc;
     }
     // frames x centers is a dense contraction: matrix cores unless the problem
-    // is too small to fill 32 x 32 tiles (results are bit-identical)
-    const bool mfma = c->assign_variant == 2 ||
+    // is too small to fill 32 x 32 tiles (results are bit-identical).  With
+    // blocks of 64 centers to fill and room for the frames' quad copy: the
+    // 16x16x4 form (ek_assign16_kernel), else 32x32x2 on the frame-minor tiles.
+    const bool mfma = c->assign_variant == 2 || c->assign_variant == 3 ||
                       (c->assign_variant == 0 && n_centers >= 24 && c->n >= 64);
-    if (mfma && n_centers > 0) {
+    bool k4 = c->assign_variant == 3 ||
+              (c->assign_variant == 0 && n_centers >= 64 && c->n >= 64 && !c->no_qtiles);
+    if (k4 && n_centers > 0) {
+        const int eq = ek_ensure_qtiles(c);
+        if (eq == EK_ENOMEM && c->assign_variant == 0)
+            k4 = false;         // (no room for a third copy of the frames)
+        else if (eq != EK_OK)
+            return eq;
+    }
+    if (k4 && n_centers > 0) {
+        const size_t need = ek_cblocks16_bytes(n_centers, c->A);
+        if (need > c->cen_blocks_cap) {
+            EK_HIP(ek_wait(c));
+            (void)hipFree(c->cen_blocks);
+            c->cen_blocks = nullptr;
+            c->cen_blocks_cap = 0;
+            EK_HIP(hipMalloc((void **)&c->cen_blocks, need));
+            c->cen_blocks_cap = need;
+        }
+        ek_launch_cblocks16(c->cen_aos, n_centers, c->A, c->cen_blocks, c->stream);
+        ek_launch_assign16(c->qtiles, c->G, c->n, c->A, c->cen_blocks, c->cen_G,
+                           n_centers, c->dist, c->assign, c->stream);
+    } else if (mfma && n_centers > 0) {
         const int32_t need = (n_centers + EK_TILE - 1) / EK_TILE * EK_TILE;
         if (need > c->cen_tiles_cap) {
             EK_HIP(ek_wait(c));

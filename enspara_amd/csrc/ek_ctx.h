@@ -145,7 +145,9 @@ struct ek_ctx {
     int32_t cen_cap = 0;
     float *cen_tiles = nullptr;  // the same centers, frame-minor tiles
     int32_t cen_tiles_cap = 0;   // in centers (multiple of EK_TILE)
-    int assign_variant = 0;      // 0 auto, 1 vector FMA, 2 MFMA
+    int assign_variant = 0;      // 0 auto, 1 vector FMA, 2 MFMA 32x32x2, 3 MFMA 16x16x4
+    float *cen_blocks = nullptr; // the same centers in blocks of 16, candidate-tile layout
+    size_t cen_blocks_cap = 0;   // in bytes
 
     // PAM working set (allocated by ek_pam_begin)
     float *ndist = nullptr;
@@ -288,6 +290,14 @@ int ek_pick_fpl(const ek_ctx *c);
 int ek_pick_nt(const ek_ctx *c);
 int ek_pick_cands(const ek_ctx *c);
 int ek_ensure_qtiles(ek_ctx *c);
+// nearest centers on v_mfma_f32_16x16x4_f32 (ek_assign.hip): the centers in blocks of
+// 16 laid out like a pass's candidate tile, the frames from the quad copy
+size_t ek_cblocks16_bytes(int32_t K, int A);
+void ek_launch_cblocks16(const float *cen_aos, int32_t K, int A, float *cblocks,
+                         hipStream_t s);
+void ek_launch_assign16(const float *qtiles, const double *G, int64_t n, int A,
+                        const float *cblocks, const double *Gc, int32_t K, float *dist,
+                        int32_t *assign, hipStream_t s);
 int ek_form_slot(int T);
 int ek_spec_alloc(ek_ctx *c);
 int ek_ensure_hist(ek_ctx *c, int32_t label);

@@ -556,7 +556,8 @@ int ek_set_frames_per_lane(ek_ctx *ctx, int fpl);
  * on when the shard is larger than the Infinity Cache)
  * key 4: candidate centers per pass of ek_kcenters_run / ek_spec_*: -1
  * automatic (up to 16, see key 8), 1 = one-center passes, 4, 8, 16
- * key 2: nearest-center kernel: 0 automatic, 1 vector FMA, 2 MFMA (identical
+ * key 2: nearest-center kernel: 0 automatic, 1 vector FMA, 2 MFMA 32x32x2, 3 MFMA
+ * 16x16x4 on the quad copy of the frames (identical
  * results)
  * key 5: cheap steps of a round in ek_kcenters_run: 1 chained (default), 0 one
  * launch pair per accepted center (identical results)

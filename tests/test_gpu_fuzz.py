@@ -76,7 +76,7 @@ def test_assign_and_warm_start_random_small_cases():
             ctr = (x[rng.randint(0, n, size=K)] if rng.rand() < 0.5
                    else synth.synth(K, A, K, seed=case))
             a, d = oc.assign_to_nearest_center(x, ctr)
-            for variant in (1, 2):
+            for variant in (1, 2, 3):
                 with FrameStore.from_array(x) as st:
                     st.set_option(2, variant)
                     st.assign_nearest(ctr)

@@ -151,16 +151,19 @@ def test_sampled_parity_at_scale(qcp):
 
 
 @pytest.mark.parametrize("n,A,K", [(1000, 35, 21), (64, 22, 32), (777, 301, 97),
-                                   (2500, 100, 64), (130, 7, 300), (5, 3, 2)])
+                                   (2500, 100, 64), (130, 7, 300), (5, 3, 2),
+                                   (4100, 50, 333), (300, 13, 1000)])
 def test_assign_variants_bit_identical(qcp, n, A, K):
-    """vector-FMA and MFMA nearest-center kernels against the checker"""
+    """vector-FMA and both MFMA nearest-center kernels (32x32x2 on the
+    frame-minor tiles, 16x16x4 on the quad copy with the centers in blocks of
+    16) against the checker"""
     x = synth.synth(n, A, 6, seed=n + K)
     ctrs = synth.synth(K, A, K, seed=A + K)
     P = qcp.Prepared(x)
     cc, Gc = qcp.center_and_trace(ctrs)
     wa, wd = qcp.assign_nearest(P.c, P.G, cc, Gc)
     with _store(x) as st:
-        for variant in (1, 2, 0):
+        for variant in (1, 2, 3, 0):
             st.set_option(2, variant)
             st.assign_nearest(ctrs)
             d, a = st.download_state()
@@ -169,7 +172,7 @@ def test_assign_variants_bit_identical(qcp, n, A, K):
     # duplicated centers: the lower index must win in both kernels
     dup = np.concatenate([ctrs[:3], ctrs[:3], ctrs[3:]])
     with _store(x) as st:
-        for variant in (1, 2):
+        for variant in (1, 2, 3):
             st.set_option(2, variant)
             st.assign_nearest(dup)
             d, a = st.download_state()

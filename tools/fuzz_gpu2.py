@@ -34,7 +34,7 @@ for case in range(cases):
             src = rng.randint(0, n, size=K)
             ctr = x[src] if rng.rand() < 0.5 else synth.synth(K, A, max(K, 1), seed=case)
             a, d = oc.assign_to_nearest_center(x, ctr)
-            for variant in (1, 2):
+            for variant in (1, 2, 3):
                 with FrameStore.from_array(x) as st:
                     st.set_option(2, variant)
                     st.assign_nearest(ctr)

@@ -21,7 +21,7 @@ if "assign" in what or "pam" in what:
 if "assign" in what:
     ctr = x[idx]
     # (timing-only ablations of the MFMA kernel need a -DEK_ASSIGN_ABLATE=n build)
-    for variant, kk, abl in [(2, K, 0), (1, K, 0)]:
+    for variant, kk, abl in [(3, K, 0), (2, K, 0), (1, K, 0)]:
         st.set_option(2, variant)
         st.assign_nearest(ctr[:kk]); st.sync()
         t = time.time()
