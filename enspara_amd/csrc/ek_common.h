@@ -72,7 +72,7 @@ struct EkPlan {
     int32_t apply_label;
     int32_t miss;          // the farthest point was not a stored candidate
     uint32_t used;         // bitmask of candidates already applied
-    int32_t pad;
+    int32_t n_rec;         // records chosen for the round (ek_round_ctile16_kernel)
     int32_t src[EK_MAX_CANDS];      // record index of each candidate
     int64_t gidx[EK_MAX_CANDS];
     float maxdist[EK_MAX_CANDS];
@@ -85,6 +85,9 @@ struct EkPlan {
     int32_t chain_label0;
     int32_t pad2;
     int32_t chain[EK_MAX_CANDS];
+    // multi-shard rounds: which of the offered records each candidate is
+    // (ek_ms_ctile16_kernel reads their coordinates out of the mailboxes)
+    int32_t offer[EK_MAX_CANDS];
 };
 
 // one candidate frame as seen by the shard that owns it: its current distance

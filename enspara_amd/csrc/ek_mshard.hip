@@ -642,8 +642,10 @@ ek_ms_plan_kernel(EkRound r, EkMsState *ms, EkMsXchg x, float *D)
                 h[u] = u == 0 ? __float_as_uint(-__builtin_inff())
                               : ((u == 2 || u == 3) ? 0xffffffffu : 0u);
         }
+        // (T = 16: the coordinates are ek_ms_ctile16_kernel's, a launch of its own --
+        // written by this one workgroup they were most of the kernel's tail)
         const int cpr_c = (A3 + 3) / 4;         // 16-byte chunks of coordinates
-        for (int e0 = tid; e0 < T * cpr_c; e0 += 4 * EK_BLOCK) {
+        for (int e0 = tid; T != 16 && e0 < T * cpr_c; e0 += 4 * EK_BLOCK) {
             const void *p[4];
             ek_f4 v[4];
 #pragma unroll
@@ -674,13 +676,14 @@ ek_ms_plan_kernel(EkRound r, EkMsState *ms, EkMsXchg x, float *D)
                 }
             }
         }
-        if (go)                                     // the atoms of padding
+        if (go && T != 16)                          // the atoms of padding
             for (int k = tid; k < (ek_ctile_atoms(A) - A) * 3 * T; k += EK_BLOCK)
                 r.ctile[ek_ctile_index(T, A + k / (3 * T), (k % (3 * T)) / 3, k % 3)] =
                     0.f;
         if (tid < T) {
             EkPlan *plan = r.plan;
             double tr = 0.0;
+            plan->offer[tid] = tid < ns ? sel[tid] : 0;
             if (tid < ns) {
                 const uint32_t *rr = ek_ms_rec<SYS>(x, sel[tid], seq, A);
                 tr = __longlong_as_double(
@@ -698,6 +701,7 @@ ek_ms_plan_kernel(EkRound r, EkMsState *ms, EkMsXchg x, float *D)
     }
     if (tid == 0) {
         EkPlan *plan = r.plan;
+        plan->n_rec = repick ? 0 : ns;
         plan->apply = -1;
         plan->chain_n = 0;
         if (!repick && !s_short && ns > 0)  // (the offers describe the state as it is)
@@ -728,6 +732,53 @@ ek_ms_plan_kernel(EkRound r, EkMsState *ms, EkMsXchg x, float *D)
     }
 }
 
+// The chosen records' coordinates of a round of 16, out of the mailboxes: into the
+// round's records and, in 16-byte pieces, into the candidate tile of the next pass
+// (as ek_round_ctile16_kernel does for a single shard).  It reads the exchange
+// the plan kernel has just closed (ms->seq - 1); after a plan kernel that had
+// nothing to do it writes the same bytes again.
+template <bool SYS>
+__global__ void __launch_bounds__(EK_BLOCK)
+ek_ms_ctile16_kernel(EkRound r, EkMsState *ms, EkMsXchg x)
+{
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    __shared__ int soff[16];
+    const EkPlan *plan = r.plan;
+    const int tid = threadIdx.x;
+    const int ns = plan->n_rec, go = plan->go;
+    if (ns <= 0)
+        return;
+    const uint32_t seq = ms->seq - 1u;
+    if (tid < 16)
+        soff[tid] = tid < ns ? plan->offer[tid] : 0;
+    __syncthreads();
+    const int A = r.A, A3 = 3 * A;
+    const int n_ct = ek_ctile_atoms(A) / 16 * 3;        // (16 atoms, axis) blocks of 1 KB
+    const int ct_wgs = (n_ct + 3) / 4;
+    if ((int)blockIdx.x < ct_wgs) {
+        const int blk = blockIdx.x * 4 + (tid >> 6), lane = tid & 63;
+        if (!go || blk >= n_ct)
+            return;
+        const int S = blk / 3, k = blk % 3, kk = lane >> 4, c = lane & 15;
+        const float *src = (const float *)(ek_ms_rec<SYS>(x, soff[c], seq, A) + 8) + k;
+        v4 v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int a = 16 * S + 4 * q + kk;
+            v[q] = (a < A && c < ns) ? ek_msg_loadf<SYS>(src + 3 * a) : 0.f;
+        }
+        *(v4 *)(r.ctile + ek_ctile_index(16, 16 * S + kk, c, k)) = v;
+    } else {
+        const int c = blockIdx.x - ct_wgs;              // one record per workgroup
+        if (c >= ns)
+            return;
+        const float *src = (const float *)(ek_ms_rec<SYS>(x, soff[c], seq, A) + 8);
+        float *rec = (float *)(r.recs + (size_t)c * ek_rec_bytes(A) + sizeof(EkRecHdr));
+        for (int row = tid; row < A3; row += EK_BLOCK)
+            rec[row] = ek_msg_loadf<SYS>(src + row);
+    }
+}
+
 void ek_launch_ms_plan(const EkRound &r, EkMsState *ms, const EkMsXchg &x, float *D,
                        hipStream_t s)
 {
@@ -741,9 +792,16 @@ void ek_launch_ms_plan(const EkRound &r, EkMsState *ms, const EkMsXchg &x, float
             hipLaunchKernelGGL((ek_ms_plan_kernel<TT, false>), dim3(blocks),   \
                                dim3(EK_BLOCK), 0, s, r, ms, x, D);             \
     } while (0)
-    if (r.T == 16)
+    if (r.T == 16) {
         EK_MS_PLAN(16);
-    else if (r.T == 8)
+        const unsigned wgs = (unsigned)((ek_ctile_atoms(r.A) / 16 * 3 + 3) / 4 + 16);
+        if (x.sys)
+            hipLaunchKernelGGL((ek_ms_ctile16_kernel<true>), dim3(wgs), dim3(EK_BLOCK), 0, s,
+                               r, ms, x);
+        else
+            hipLaunchKernelGGL((ek_ms_ctile16_kernel<false>), dim3(wgs), dim3(EK_BLOCK), 0, s,
+                               r, ms, x);
+    } else if (r.T == 8)
         EK_MS_PLAN(8);
     else
         EK_MS_PLAN(4);

@@ -420,8 +420,12 @@ ek_round_next_kernel(EkRound r, int bootstrap)
     // (ek_ctile_index), zeros for unused slots and the atoms of padding.
     // All of a trip's loads (T candidates x 4 rows per thread) go out before
     // the first store: the stores may alias them as far as the compiler knows.
+    // (T = 16: the coordinates are ek_round_ctile16_kernel's, a launch of its own
+    // -- written by this one workgroup they were 20 of the kernel's 39 us)
     const int A3 = 3 * r.A;
-    for (int k0 = 0; k0 * EK_BLOCK < A3; k0 += 4) {
+    if (T == 16 && tid == 0)
+        r.plan->n_rec = ns;
+    for (int k0 = 0; T != 16 && k0 * EK_BLOCK < A3; k0 += 4) {
         float v[T][4];
 #pragma unroll
         for (int c = 0; c < T; ++c) {
@@ -447,7 +451,7 @@ ek_round_next_kernel(EkRound r, int bootstrap)
             }
         }
     }
-    if (go)                                     // the atoms of padding
+    if (go && T != 16)                          // the atoms of padding
         for (int k = tid; k < (ek_ctile_atoms(r.A) - r.A) * 3 * T; k += EK_BLOCK)
             r.ctile[ek_ctile_index(T, r.A + k / (3 * T), (k % (3 * T)) / 3, k % 3)] =
                 0.f;
@@ -476,15 +480,61 @@ ek_round_next_kernel(EkRound r, int bootstrap)
     }
 }
 
+// The chosen frames' coordinates of a round of 16: into the round's records and,
+// in 16-byte pieces, into the candidate tile of the next pass (ek_ctile_index:
+// one piece = the four trips of (16 atoms, axis, lane)).  Some thirty workgroups
+// side by side instead of the planning kernel's last one alone.
+__global__ void __launch_bounds__(EK_BLOCK)
+ek_round_ctile16_kernel(EkRound r)
+{
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    __shared__ uint32_t sfr[16];
+    const EkPlan *plan = r.plan;
+    const int tid = threadIdx.x;
+    const int ns = plan->n_rec, go = plan->go;
+    if (ns <= 0)
+        return;
+    if (tid < 16)
+        sfr[tid] = tid < ns ? (uint32_t)(plan->gidx[tid] - r.goff) : 0u;
+    __syncthreads();
+    const int A = r.A, A3 = 3 * A;
+    const int n_ct = ek_ctile_atoms(A) / 16 * 3;        // (16 atoms, axis) blocks of 1 KB
+    const int ct_wgs = (n_ct + 3) / 4;
+    if ((int)blockIdx.x < ct_wgs) {
+        const int blk = blockIdx.x * 4 + (tid >> 6), lane = tid & 63;
+        if (!go || blk >= n_ct)
+            return;
+        const int S = blk / 3, k = blk % 3, kk = lane >> 4, c = lane & 15;
+        const float *src = r.aos + (size_t)sfr[c] * A3 + k;
+        v4 v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int a = 16 * S + 4 * q + kk;
+            v[q] = (a < A && c < ns) ? src[3 * a] : 0.f;
+        }
+        *(v4 *)(r.ctile + ek_ctile_index(16, 16 * S + kk, c, k)) = v;
+    } else {
+        const int c = blockIdx.x - ct_wgs;              // one record per workgroup
+        if (c >= ns)
+            return;
+        const float *src = r.aos + (size_t)sfr[c] * A3;
+        float *rec = (float *)(r.recs + (size_t)c * ek_rec_bytes(A) + sizeof(EkRecHdr));
+        for (int row = tid; row < A3; row += EK_BLOCK)
+            rec[row] = src[row];
+    }
+}
+
 void ek_launch_round_next(const EkRound &r, int bootstrap, hipStream_t s)
 {
     if (r.n <= 0)
         return;
     const unsigned blocks = (unsigned)(EK_TOP_M * EK_TOP_M / (EK_BLOCK / EK_WAVE));
-    if (r.T == 16)
+    if (r.T == 16) {
         hipLaunchKernelGGL((ek_round_next_kernel<16>), dim3(blocks), dim3(EK_BLOCK), 0,
                            s, r, bootstrap);
-    else if (r.T == 8)
+        const unsigned wgs = (unsigned)((ek_ctile_atoms(r.A) / 16 * 3 + 3) / 4 + 16);
+        hipLaunchKernelGGL(ek_round_ctile16_kernel, dim3(wgs), dim3(EK_BLOCK), 0, s, r);
+    } else if (r.T == 8)
         hipLaunchKernelGGL((ek_round_next_kernel<8>), dim3(blocks), dim3(EK_BLOCK), 0,
                            s, r, bootstrap);
     else
