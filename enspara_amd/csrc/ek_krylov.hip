@@ -186,6 +186,8 @@ extern "C" int ek_krylov_create(int device, int64_t n, const int64_t *indptr,
     KA(k->q, (size_t)(m_max + 1) * (m_max + 1) * sizeof(double));
     KA(k->hcols, (size_t)m_max * (m_max + 2) * sizeof(double));
 #undef KA
+    if (e == hipSuccess)        // (ek_krylov_expand copies whole columns out)
+        e = hipMemsetAsync(k->hcols, 0, (size_t)m_max * (m_max + 2) * sizeof(double), k->s);
     if (e == hipSuccess)
         e = hipMemcpyAsync(k->indptr, indptr, (size_t)(n + 1) * sizeof(int64_t),
                            hipMemcpyHostToDevice, k->s);
@@ -480,11 +482,16 @@ extern "C" int ek_krylov_expand(ek_krylov *k, int32_t j0, int32_t m,
                            k->s, w_prev, k->part, nb, n, k->V + (size_t)m * n,
                            k->hcols + (size_t)(m - 1) * ld + m);
     KR_HIP(hipGetLastError());
-    for (int j = j0; j < m; ++j)
-        KR_HIP(hipMemcpyAsync(H_out + (size_t)j * ldh,
-                              k->hcols + (size_t)j * ld,
-                              (size_t)(j + 2) * sizeof(double),
-                              hipMemcpyDeviceToHost, k->s));
+    // all columns j0 .. m - 1 in ONE copy (forty small ones cost 0.2-0.3 ms per
+    // restart): m + 1 entries each -- column j has j + 2, the rest of a column is
+    // zero since the allocation and never written.  (The ~200 launches of a
+    // restart replayed from a captured hipGraph took the same 0.73 ms: the time
+    // is the dependent kernels' own turn-around, not the host's launches.)
+    if (m > j0)
+        KR_HIP(hipMemcpy2DAsync(H_out + (size_t)j0 * ldh, (size_t)ldh * sizeof(double),
+                                k->hcols + (size_t)j0 * ld, (size_t)ld * sizeof(double),
+                                (size_t)(m + 1) * sizeof(double), (size_t)(m - j0),
+                                hipMemcpyDeviceToHost, k->s));
     KR_HIP(hipStreamSynchronize(k->s));
     return EK_OK;
 }
