@@ -324,6 +324,8 @@ extern "C" int ek_ctx_create(int device, int64_t n_frames, int32_t n_atoms,
         e = hipMemsetAsync(c->rec, 0, recb, c->stream);
     if (e == hipSuccess)
         e = hipMemsetAsync(c->pend, 0, sizeof(EkPend), c->stream);
+    if (e == hipSuccess)    // (n_rec = 0: no record chosen yet, ek_round_ctile16_kernel)
+        e = hipMemsetAsync(c->plan, 0, sizeof(EkPlan), c->stream);
     if (e == hipSuccess)
         e = hipMemsetAsync(c->ord, 0, sizeof(EkChainOrd), c->stream);
     if (e == hipSuccess)
