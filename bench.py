@@ -23,8 +23,8 @@ The frames are streamed once per ROUND against up to 16 candidate centers and
 further centers are accepted from the stored distances while the farthest
 point is one of them (csrc/ek_spec.hip, ek_pass16.hip): the same
 sequential algorithm and bit-identical results with fewer passes over HBM.
-The fit moves between 1, 8 and 16 candidates per pass by the centers per
-millisecond each achieves (`--candidates 1|4|8|16` pins one form; 1 is the HBM
+The fit moves between 1, 8, 16 and 32 candidates per round by the centers per
+millisecond each achieves (`--candidates 1|4|8|16|32` pins one form; 1 is the HBM
 roofline case of BASELINE.md).  Every reported pair is a distance the result
 depends on; guesses that were never used are not counted ("pairs_computed" has
 the total).  `roofline` describes the kernel most passes ran: the 16-candidate
@@ -94,7 +94,8 @@ def parse():
                    help="frames per lane of the one-center kernel (0 = auto)")
     p.add_argument("--candidates", type=int, default=-1,
                    help="candidate centers per pass: -1 by measured rate "
-                        "(1, 8, 16), or pin 1, 4, 8 or 16")
+                        "(1, 8, 16, 32), or pin 1, 4, 8, 16 or 32 (32: "
+                        "two passes of 16 behind one plan and chain)")
     p.add_argument("--transport", choices=["mailbox", "gather"], default="mailbox",
                    help="N > 1 / --sharded: a round's exchange through peer "
                         "mailboxes on the device, or one all-gather per round")
@@ -637,7 +638,7 @@ def main():
     t_load = time.perf_counter() - t0
     store.set_frames_per_lane(args.fpl)
     store.set_option(4, args.candidates)
-    cands = store.candidates
+    cands = store.round_candidates
 
     shard = sharded.DeviceShard(store) if use_dist else None
     transport = None
@@ -724,11 +725,12 @@ def main():
         if not mix:
             rounds = store.spec_rounds() if cands > 1 else centers_total
             mix = {cands: (rounds, centers_total)}
-        rounds = sum(p for p, _ in mix.values())
+        rounds = sum(p * (2 if T == 32 else 1) for T, (p, _) in mix.items())
     else:
         mix = {T: pc for T, pc in store.run_stats().items() if pc[0]} \
             if cands > 1 else {1: (centers_total, centers_total)}
-        rounds = sum(p for p, _ in mix.values())
+        # (passes over the frames: a round of 32 is two)
+        rounds = sum(p * (2 if T == 32 else 1) for T, (p, _) in mix.items())
 
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=ctl)
@@ -738,18 +740,32 @@ def main():
     pairs = float(n_total) * centers_total
     value = pairs / elapsed
     bpp = bytes_per_pair(args.atoms)
-    # the dominant kernel: the form most of the sampled passes ran
+    # the dominant kernel: the form most of the sampled rounds ran.  A round of
+    # 32 candidates is TWO launches of the 16-candidate kernel (candidates 0..15,
+    # then 16..31 against the state the first left): the sampled duration spans
+    # both, the roofline is quoted per launch (half of it, half the work).
     dom = timed_form if timed_form >= 1 else (cands if cands > 1 else 1)
-    launch_bytes = n_local * (bytes_per_frame_pass(args.atoms, dom)
-                              if dom > 1 else bpp)
+    launches_per_round = 2 if dom == 32 else 1
+    round_ms = kern_ms
+    kern_ms = kern_ms / launches_per_round
+    if dom == 32:
+        # first launch: the 16-form's bytes; second: coordinates, trace,
+        # distance read, 16 kept distances + the mask word
+        launch_bytes = n_local * (bytes_per_frame_pass(args.atoms, 16) +
+                                  12 * args.atoms + 12 + 4 * 16) / 2.0
+    else:
+        launch_bytes = n_local * (bytes_per_frame_pass(args.atoms, dom)
+                                  if dom > 1 else bpp)
     achieved = (launch_bytes / (kern_ms * 1e-3)) / 1e9 if kern_ms > 0 else None
     # 16 candidates: a dense contraction, 18 A flop per frame x candidate pair
-    launch_flops = float(n_local) * dom * 18 * args.atoms
+    launch_flops = float(n_local) * min(dom, 16) * 18 * args.atoms
     tflops = (launch_flops / (kern_ms * 1e-3)) / 1e12 if kern_ms > 0 else None
     traffic, traffic_src = load_traffic(args, n_local, dom)
     ceiling = copy_ceiling(min(x.nbytes, 4 << 30), local_rank)
-    if dom == 16:
-        kernel_name = "ek_pass16_kernel<true>"
+    if dom == 32:
+        kernel_name = "ek_pass16_kernel<true, 1> + <true, 2>"
+    elif dom == 16:
+        kernel_name = "ek_pass16_kernel<true, 0>"
     elif dom > 1:
         kernel_name = "ek_pass2_kernel<%d, true, true>" % dom
     else:
@@ -763,7 +779,7 @@ def main():
                                         if achieved and ceiling[1] else None,
         "algorithmic_bytes_per_launch": launch_bytes,
     }
-    if dom == 16:
+    if dom >= 16:
         roof = {"bound": "mfma", "kernel": kernel_name, "achieved": tflops,
                 "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": (tflops / MFMA_F32_PEAK_TFLOPS) if tflops else None,
@@ -779,8 +795,10 @@ def main():
         roof.update({"bound": "hbm", "kernel": kernel_name})
     roof.update({
         "bytes_per_pair_one_center_pass": bpp,
-        "pairs_per_launch": n_local * dom,
+        "pairs_per_launch": n_local * min(dom, 16),
         "avg_launch_ms": kern_ms,
+        "launches_per_round": launches_per_round,
+        "avg_round_stream_ms": round_ms,
         "launches_sampled": n_samp,
         "traffic": traffic,
         "traffic_source": traffic_src,
@@ -810,10 +828,12 @@ def main():
             "centers_per_step": cps,
             "warmup_centers": warm_centers,
             "candidates_per_pass": cands,
-            "passes_by_candidates": {str(T): {"passes": p, "centers": k}
+            "passes_by_candidates": {str(T): {"passes": p * (2 if T == 32 else 1),
+                                              "rounds": p, "centers": k}
                                      for T, (p, k) in sorted(mix.items())},
             "algorithm": "k-centers, up to %d candidate centers per pass over "
-                         "the frames (1, 8 or 16 by measured centers/ms), "
+                         "the frames (1, 8, 16 or 32 by measured centers/ms; a "
+                         "round of 32 streams the frames twice), "
                          "results identical to one pass per center" % cands
                          if cands > 1 else
                          "k-centers, one pass over the frames per center",

@@ -27,7 +27,7 @@ SYMBOLS = [
     "ek_record_bytes", "ek_local_candidate", "ek_own_record",
     "ek_kcenters_step", "ek_kcenters_run",
     "ek_history_download", "ek_history_reset",
-    "ek_spec_candidates", "ek_spec_begin", "ek_spec_round", "ek_spec_localmax",
+    "ek_spec_candidates", "ek_round_candidates", "ek_spec_begin", "ek_spec_round", "ek_spec_localmax",
     "ek_spec_apply", "ek_spec_round_end", "ek_spec_progress", "ek_spec_rounds",
     "ek_spec_chain_bytes", "ek_spec_chain_rows", "ek_spec_chain_max",
     "ek_spec_chain_apply", "ek_run_stats", "ek_ti_stats",
@@ -51,6 +51,7 @@ SYMBOLS = [
     "ek_feat_kcenters", "ek_feat_pam_sweep", "ek_feat_pam_release",
     "ek_set_frames_per_lane", "ek_set_option", "ek_last_run_timing",
     "ek_timing_begin", "ek_timing_end", "ek_timing_form", "ek_hbm_copy_rate",
+    "ek_qcp_probe",
 ]
 
 
@@ -110,6 +111,7 @@ def load():
     L.ek_history_download.argtypes = [vp, i32, i32, i64p, f32p, i32p]
     L.ek_history_reset.argtypes = [vp]
     L.ek_spec_candidates.argtypes = [vp]
+    L.ek_round_candidates.argtypes = [vp]
     L.ek_spec_begin.argtypes = [vp, i32, i32, vp]
     L.ek_spec_round.argtypes = [vp, vp, i32, C.c_double]
     L.ek_spec_localmax.argtypes = [vp, vp]
@@ -193,6 +195,7 @@ def load():
     L.ek_timing_end.argtypes = [vp, f32p, i32p]
     L.ek_timing_form.argtypes = [vp, i32p]
     L.ek_hbm_copy_rate.argtypes = [C.c_int, C.c_size_t, f64p]
+    L.ek_qcp_probe.argtypes = [C.c_int, vp, vp, vp, i32, vp, C.c_int64, vp, vp, vp]
     for name in SYMBOLS:
         getattr(L, name)
     _lib = L

@@ -24,13 +24,16 @@ class KMedoids(BaseEstimator, ClusterMixin, util.MolecularClusterMixin):
     """reference kmedoids.py:28-105"""
 
     def __init__(self, metric, n_clusters=None, n_iters=5, args=None,
-                 lengths=None, device=0):
+                 lengths=None, device=0, mpi_mode=None):
         self.metric = util._get_distance_method(metric)
         self.n_clusters = n_clusters
         self.n_iters = n_iters
         self.args = args
         self.lengths = lengths
         self.device = device
+        # None: like the reference, which asks mpi.size() (kmedoids.py:172) --
+        # here: an initialised torch.distributed group of more than one rank
+        self.mpi_mode = mpi_mode
 
     def fit(self, X, assignments=None, distances=None,
             cluster_center_inds=None, X_lengths=None, args=None):
@@ -39,9 +42,19 @@ class KMedoids(BaseEstimator, ClusterMixin, util.MolecularClusterMixin):
             X, distance_method=self.metric, n_clusters=self.n_clusters,
             n_iters=self.n_iters, assignments=assignments,
             distances=distances, cluster_center_inds=cluster_center_inds,
-            X_lengths=X_lengths, device=self.device)
+            X_lengths=X_lengths, device=self.device, mpi_mode=self.mpi_mode)
         self.runtime_ = time.perf_counter() - t0
         return self
+
+
+def _group_size():
+    try:
+        import torch.distributed as dist
+    except ImportError:
+        return 1
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size()
+    return 1
 
 
 def _resolve_inputs(X, distance_method, n_clusters, assignments, distances,
@@ -70,19 +83,40 @@ def _resolve_inputs(X, distance_method, n_clusters, assignments, distances,
 def kmedoids(X, distance_method, n_clusters=None, n_iters=5, assignments=None,
              distances=None, cluster_center_inds=None, proposals=None,
              X_lengths=None, args=None, lengths=None, random_state=None,
-             device=0):
-    """reference kmedoids.py:108-202 (single process)."""
+             device=0, mpi_mode=None):
+    """reference kmedoids.py:108-202.  ``mpi_mode``: None = as the reference,
+    which takes its MPI branch when ``mpi.size() > 1`` (:172) -- here when an
+    initialised torch.distributed group has more than one rank; True / False
+    force it.  In that mode every rank passes its own frames and the warm start
+    is (assignments, distances, cluster_center_inds, X_lengths), see
+    ``enspara_amd.sharded.kmedoids_sharded``."""
+    if mpi_mode is None:
+        mpi_mode = _group_size() > 1
     if cluster_center_inds is not None:
         if hasattr(cluster_center_inds[0], "__len__") and X_lengths is None:
             raise ImproperlyConfigured(
                 "If cluster_center_inds is given as [[global_traj_id, "
                 "frame_id],...] then X_lengths also needs to be supplied")
     if cluster_center_inds is None and n_clusters is None:
+        if mpi_mode:
+            raise ImproperlyConfigured(
+                "Must provide n_clusters or cluster_center_inds, assignments,"
+                "and distances for KMedoids in MPI mode.")
         if assignments is None and distances is None:
             raise ImproperlyConfigured(
                 "Must provide n_clusters or cluster_center_inds or "
                 " (assignments and distances) for KMedoids")
     distance_method = util._get_distance_method(distance_method)
+    if mpi_mode:
+        if not util.is_device_rmsd(distance_method):
+            raise ImproperlyConfigured(
+                "KMedoids in MPI mode runs metric 'rmsd' on the device; a "
+                "callable metric has no sharded form here")
+        from .. import sharded
+        return sharded.kmedoids_fit_sharded(
+            X, n_clusters=n_clusters, n_iters=n_iters, assignments=assignments,
+            distances=distances, cluster_center_inds=cluster_center_inds,
+            X_lengths=X_lengths, proposals=proposals, random_state=random_state)
     inds = _resolve_inputs(X, distance_method, n_clusters, assignments,
                            distances, cluster_center_inds, X_lengths,
                            random_state)

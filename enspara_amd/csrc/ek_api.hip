@@ -1,5 +1,6 @@
 // ek_api.hip -- the C ABI of include/enspara_hip.h (host side).
 #include "ek_ctx.h"
+#include "ek_qcp.h"
 
 static thread_local char g_err[512] = "";
 
@@ -59,12 +60,16 @@ int ek_pick_nt(const ek_ctx *c)
 
 // the widest form of a round this context may use (candidates per pass):
 // EK_MAX_CANDS unless option key 4 pins it; 1 = one-center passes only
-int ek_pick_cands(const ek_ctx *c)
+// (wide: the fused single-shard rounds and the one-exchange rounds across shards
+// know rounds of 32; the one-launch-per-step forms stop at EK_LEGACY_CANDS)
+int ek_pick_cands(const ek_ctx *c, bool wide)
 {
     int t = c->cands == -1 ? EK_MAX_CANDS : c->cands;
-    if (t == 16 && c->no_qtiles)    // (ek_ensure_qtiles found no room)
+    if (t == 32 && !wide)
+        t = EK_LEGACY_CANDS;
+    if (t >= 16 && c->no_qtiles)    // (ek_ensure_qtiles found no room)
         t = 8;
-    return (t == 16 || t == 8 || t == 4) ? t : 1;
+    return (t == 32 || t == 16 || t == 8 || t == 4) ? t : 1;
 }
 
 // The quad copy of the frames (ek_pass16.hip) is made when a 16-candidate pass
@@ -95,8 +100,11 @@ int ek_ensure_qtiles(ek_ctx *c)
     return EK_OK;
 }
 
-// slot of a form in the run statistics: passes run as 1 / 4 / 8 / 16 candidates
-int ek_form_slot(int T) { return T <= 1 ? 0 : (T == 4 ? 1 : (T == 8 ? 2 : 3)); }
+// slot of a form in the run statistics: rounds run as 1 / 4 / 8 / 16 / 32 candidates
+int ek_form_slot(int T)
+{
+    return T <= 1 ? 0 : (T == 4 ? 1 : (T == 8 ? 2 : (T == 16 ? 3 : 4)));
+}
 
 int ek_spec_alloc(ek_ctx *c)
 {
@@ -109,6 +117,7 @@ int ek_spec_alloc(ek_ctx *c)
                           EK_BLOCK;
         EK_HIP(hipMalloc((void **)&c->pm,
                          (size_t)(EK_MAX_CANDS - 1) * nb * sizeof(EkBlockMax)));
+        EK_HIP(hipMalloc((void **)&c->fm, 4 * nb * sizeof(EkBlockMax)));
     }
     if (!c->vecs) {
         EK_HIP(hipMalloc((void **)&c->vecs, (size_t)(EK_MAX_CANDS - 1) *
@@ -205,6 +214,7 @@ int ek_free_all(ek_ctx *c)
     (void)hipFree(c->vecs);
     (void)hipFree(c->hdr);
     (void)hipFree(c->pm);
+    (void)hipFree(c->fm);
     (void)hipFree(c->top);
     (void)hipFree(c->planD);
     (void)hipFree(c->ndist);
@@ -375,9 +385,10 @@ extern "C" int ek_set_option(ek_ctx *c, int32_t key, int32_t value)
         c->nt = value < 0 ? -1 : (value ? 1 : 0);
         return EK_OK;
     case 4:
-        if (value != -1 && value != 1 && value != 4 && value != 8 && value != 16)
-            return ek_fail(EK_EARG, "ek_set_option: candidates per pass must "
-                                    "be -1 (auto), 1, 4, 8 or 16");
+        if (value != -1 && value != 1 && value != 4 && value != 8 && value != 16 &&
+            value != 32)
+            return ek_fail(EK_EARG, "ek_set_option: candidates per round must "
+                                    "be -1 (auto), 1, 4, 8, 16 or 32");
         c->cands = value;
         return EK_OK;
     case 5:
@@ -428,6 +439,11 @@ extern "C" int ek_set_option(ek_ctx *c, int32_t key, int32_t value)
         if (value < 0)
             return ek_fail(EK_EARG, "ek_set_option: pairs one workgroup searches >= 0");
         c->sp_max_pairs = value;
+        return EK_OK;
+    case 15:
+        if (value != 0 && value != 1)
+            return ek_fail(EK_EARG, "ek_set_option: maxima per 64 frames for the pick 0 or 1");
+        c->fine_pick = value;
         return EK_OK;
     case 2:
         if (value < 0 || value > 3)
@@ -868,7 +884,7 @@ static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
     EK_HIP(hipMemcpyAsync(c->ctl, &ctlw, sizeof(ctlw), hipMemcpyHostToDevice,
                           c->stream));
     EK_HIP(ek_wait(c));
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < EK_N_FORMS; ++m)
         c->st_rounds[m] = c->st_centers[m] = 0;
     const int nb = (int)((c->n + EK_BLOCK - 1) / EK_BLOCK);
     // Triangle inequality (option key 11; reference `use_triangle_inequality`,
@@ -895,7 +911,12 @@ static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
                               c->stream));
     }
     c->ti_tiles = c->ti_skipped = 0;
-    if (Tmax == 16 && !tri) {
+    // three launches per round (ek_round.hip) when the pieces it is built from
+    // are the ones selected; rounds of 32 exist in that form only
+    const bool fused = c->fused && c->chain == 1;
+    if (Tmax == 32 && !fused)
+        Tmax = EK_LEGACY_CANDS;
+    if (Tmax >= 16 && !tri) {
         const int eq = ek_ensure_qtiles(c);
         if (eq == EK_ENOMEM)
             Tmax = 8;
@@ -907,12 +928,14 @@ static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
     const int fpl = ek_pick_fpl(c);
     const int nt = ek_pick_nt(c);
     // the forms the run moves between, by candidates per pass
-    int ladder[3], n_ladder = 0;
+    int ladder[4], n_ladder = 0;
     if (adaptive || tri)
         ladder[n_ladder++] = 1;
     if (!tri) {
-        if (adaptive && Tmax == 16)
+        if (adaptive && Tmax >= 16)
             ladder[n_ladder++] = 8;
+        if (adaptive && Tmax == 32)
+            ladder[n_ladder++] = 16;
         ladder[n_ladder++] = Tmax;
     }
     int home = 0;               // ladder index of the form being run
@@ -923,9 +946,6 @@ static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
     double rate_home = 0.0;     // centers per ms of the home form
     int32_t gap = 8;            // centers until another form is tried again
     int32_t since = 0;          // centers since one last was
-    // three launches per round (ek_round.hip) when the pieces it is built from
-    // are the ones selected
-    const bool fused = c->fused && c->chain == 1;
     EkRound R;
     R.dist = c->dist;
     R.assign = c->assign;
@@ -945,6 +965,7 @@ static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
     R.ord = c->ord;
     R.blockmax = c->blockmax;
     R.pm = c->pm;
+    R.fm = c->fine_pick ? c->fm : nullptr;
     R.top = c->top;
     R.ctile = c->ctile;
     R.ctrace = c->ctrace;
@@ -999,7 +1020,7 @@ static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
         if (one)    // (never past the goal: a step has no limit check of its own)
             batch = std::min(left, probing ? 4 : std::min(due, 256));
         else if (probing)
-            batch = 3;
+            batch = form == 32 ? 2 : 3;
         else
             batch = std::max(2, std::min(256, (int32_t)(std::min(left, due) /
                                                         per_round) + 1));
@@ -1108,8 +1129,12 @@ static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
                 rate_home = rate;
                 gap = 8;
             } else {                    // back, and wait twice as long
+                // (a round of 32 that lost to rounds of 16: its second sixteen
+                // guesses are accepted far less often than the first -- measured,
+                // DESIGN.md 4a -- and three such rounds are a dear look: much longer)
+                const bool wide_lost = form == 32;
                 form = ladder[home];
-                gap = std::min(gap * 2, 1024);
+                gap = std::min(wide_lost ? std::max(gap * 4, 512) : gap * 2, 1024);
             }
             continue;
         }
@@ -1173,7 +1198,9 @@ static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
                               hipMemcpyDeviceToDevice, c->stream));
     EK_HIP(ek_wait(c));
     const int32_t added_t = std::min(max_new, std::max(0, cr.n_done - first_label));
-    const int64_t passes = c->st_rounds[0] + c->st_rounds[1] + c->st_rounds[2];
+    // (passes over the frames: a round of 32 is two)
+    const int64_t passes = c->st_rounds[0] + c->st_rounds[1] + c->st_rounds[2] +
+                           c->st_rounds[3] + 2 * c->st_rounds[4];
     c->last_launches = (int32_t)passes;
     c->last_passes = (int32_t)passes;
     if (n_added)
@@ -1212,7 +1239,7 @@ extern "C" int ek_kcenters_run(ek_ctx *c, int32_t first_label, int32_t max_new,
                           hipMemcpyHostToDevice, c->stream));
     EK_HIP(ek_wait(c));
 
-    const int T = ek_pick_cands(c);
+    const int T = ek_pick_cands(c, true);
     if (T > 1 && c->n > 0)
         return ek_run_rounds(c, T, first_label, max_new, dist_cutoff, n_added,
                              center_index_out, center_dist_out, final_maxdist);
@@ -1506,3 +1533,69 @@ extern "C" int ek_hbm_copy_rate(int device, size_t bytes, double *gbytes_per_s)
     return EK_OK;
 }
 
+
+// ---- the QCP arithmetic as a kernel, on the caller's matrices (tests) -----------------
+__global__ void __launch_bounds__(EK_BLOCK)
+ek_qcp_probe_kernel(const float *__restrict__ S, const double *__restrict__ Gx,
+                    const double *__restrict__ Gy, int n_atoms,
+                    const float *__restrict__ cur, int64_t m, float *__restrict__ full,
+                    float *__restrict__ below, unsigned char *__restrict__ cert)
+{
+    const int64_t i = (int64_t)blockIdx.x * EK_BLOCK + threadIdx.x;
+    if (i >= m)
+        return;
+    float s[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j)
+        s[j] = S[9 * i + j];
+    full[i] = ek_rmsd_from_S(s, Gx[i], Gy[i], n_atoms);
+    below[i] = ek_rmsd_from_S_below(s, Gx[i], Gy[i], n_atoms, cur[i]);
+    cert[i] = ek_far_certified_f32(s, (float)(Gx[i] + Gy[i]), n_atoms, cur[i]) ? 1 : 0;
+}
+
+extern "C" int ek_qcp_probe(int device, const float *S, const double *Gx, const double *Gy,
+                            int32_t n_atoms, const float *cur, int64_t m, float *full,
+                            float *below, unsigned char *cert)
+{
+    if (!S || !Gx || !Gy || !cur || !full || !below || !cert || m < 0 || n_atoms < 1)
+        return ek_fail(EK_EARG, "ek_qcp_probe: bad argument");
+    if (m == 0)
+        return EK_OK;
+    EK_HIP(hipSetDevice(device));
+    const size_t mm = (size_t)m;
+    unsigned char *buf = nullptr;
+    // S | Gx | Gy | cur | full | below | cert
+    const size_t off_S = 0, off_Gx = off_S + mm * 36, off_Gy = off_Gx + mm * 8,
+                 off_cur = off_Gy + mm * 8, off_full = off_cur + mm * 4,
+                 off_below = off_full + mm * 4, off_cert = off_below + mm * 4,
+                 total = off_cert + mm;
+    EK_HIP(hipMalloc((void **)&buf, total));
+    hipError_t e = hipMemcpy(buf + off_S, S, mm * 36, hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = hipMemcpy(buf + off_Gx, Gx, mm * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = hipMemcpy(buf + off_Gy, Gy, mm * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = hipMemcpy(buf + off_cur, cur, mm * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(ek_qcp_probe_kernel, dim3((unsigned)((m + EK_BLOCK - 1) / EK_BLOCK)),
+                           dim3(EK_BLOCK), 0, 0, (const float *)(buf + off_S),
+                           (const double *)(buf + off_Gx), (const double *)(buf + off_Gy),
+                           (int)n_atoms, (const float *)(buf + off_cur), m,
+                           (float *)(buf + off_full), (float *)(buf + off_below),
+                           buf + off_cert);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess)
+        e = hipDeviceSynchronize();
+    if (e == hipSuccess)
+        e = hipMemcpy(full, buf + off_full, mm * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess)
+        e = hipMemcpy(below, buf + off_below, mm * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess)
+        e = hipMemcpy(cert, buf + off_cert, mm, hipMemcpyDeviceToHost);
+    (void)hipFree(buf);
+    if (e != hipSuccess)
+        return ek_fail(EK_EHIP, "ek_qcp_probe: %s", hipGetErrorString(e));
+    return EK_OK;
+}

@@ -8,6 +8,11 @@ extern "C" int ek_spec_candidates(ek_ctx *c)
     return c ? ek_pick_cands(c) : 0;
 }
 
+extern "C" int ek_round_candidates(ek_ctx *c)
+{
+    return c ? ek_pick_cands(c, true) : 0;
+}
+
 extern "C" int ek_spec_begin(ek_ctx *c, int32_t first_label, int32_t limit,
                              void *recs_out)
 {
@@ -208,7 +213,7 @@ extern "C" int ek_run_stats(ek_ctx *c, int64_t *passes, int64_t *centers)
 {
     if (!c || !passes || !centers)
         return ek_fail(EK_EARG, "ek_run_stats: NULL argument");
-    for (int m = 0; m < 4; ++m) {
+    for (int m = 0; m < EK_N_FORMS; ++m) {
         passes[m] = c->st_rounds[m];
         centers[m] = c->st_centers[m];
     }
@@ -254,6 +259,7 @@ static void ek_round_of(ek_ctx *c, int T, double cutoff, EkRound &R)
     R.ord = c->ord;
     R.blockmax = c->blockmax;
     R.pm = c->pm;
+    R.fm = c->fine_pick ? c->fm : nullptr;
     R.top = c->top;
     R.ctile = c->ctile;
     R.ctrace = c->ctrace;
@@ -381,7 +387,8 @@ extern "C" int ek_ms_begin(ek_ctx *c, int32_t first_label, int32_t limit)
         return rc;
     if (first_label < 0 || limit < first_label)
         return ek_fail(EK_EARG, "ek_ms_begin: bad label range");
-    const int T = ek_pick_cands(c);
+    // (the caller's loop has no ladder: rounds of 32 only where option key 4 asks)
+    const int T = ek_pick_cands(c, c->cands == 32);
     if (T < 4)
         return ek_fail(EK_ESTATE, "ek_ms_begin: multi-candidate rounds are off "
                                   "(option key 4 = 1: use ek_kcenters_step)");
@@ -401,7 +408,7 @@ static int ek_ms_begin_T(ek_ctx *c, int32_t first_label, int32_t limit, int T)
     if (rc)
         return rc;
     c->ms_T = T;
-    if (T == 16) {
+    if (T >= 16) {
         const int eq = ek_ensure_qtiles(c);
         if (eq != EK_OK)
             return eq;
@@ -562,11 +569,15 @@ extern "C" int ek_ms_run(ek_ctx *c, int32_t first_label, int32_t max_new,
     // goes back to 8 and the next try waits twice as many batches.  A change of
     // form costs one exchange without a pass (the state's farthest frames are
     // offered again).  Results do not depend on the form.
-    const int Tmax = ek_pick_cands(c);
+    // Round 5: rounds of 32 -- two passes of 16 behind ONE plan, chain and
+    // exchange -- once rounds of 16 are usually accepted whole (>= 14 per round);
+    // back to 16 when a batch of them accepts fewer than 22 per round (what 16
+    // would accept at most, with half the passes), the next try twice as far off.
+    const int Tmax = ek_pick_cands(c, true);
     if (Tmax < 4)
         return ek_fail(EK_ESTATE, "ek_ms_run: multi-candidate rounds are off "
                                   "(option key 4 = 1: use ek_kcenters_step)");
-    const bool ladder = Tmax == 16 && c->cands == -1 && c->adapt;
+    const bool ladder = Tmax >= 16 && c->cands == -1 && c->adapt;
     int T = ladder ? 8 : Tmax;
     rc = ek_ms_begin_T(c, first_label, first_label + max_new, T);
     if (rc)
@@ -586,14 +597,14 @@ extern "C" int ek_ms_run(ek_ctx *c, int32_t first_label, int32_t max_new,
     memset(&st, 0, sizeof(st));
     double per_round = 0.6 * T;
     int32_t rounds_before = 0, passes = 0;
-    int wait16 = 0, next_wait = 1;
-    for (int k = 0; k < 4; ++k)
+    int wait16 = 0, next_wait = 1, wait32 = 0, next_wait32 = 1;
+    for (int k = 0; k < EK_N_FORMS; ++k)
         c->st_rounds[k] = c->st_centers[k] = 0;
     while (max_new > 0) {
         const int32_t left = goal - cr.n_done;
         int32_t batch = std::max(2, std::min(256, (int32_t)(left / per_round) + 2));
         if (ladder)
-            batch = std::min(batch, T == 8 ? 24 : 64);
+            batch = std::min(batch, T == 8 ? 24 : (T == 16 ? 64 : 48));
         for (int32_t r = 0; r < batch; ++r) {
             rc = ek_ms_enqueue_local(c, R, x);
             if (rc)
@@ -609,7 +620,7 @@ extern "C" int ek_ms_run(ek_ctx *c, int32_t first_label, int32_t max_new,
         EK_HIP(ek_wait(c));
         const int32_t ran = cr.n_rounds - rounds_before;
         rounds_before = cr.n_rounds;
-        passes += ran;
+        passes += (T == 32 ? 2 : 1) * ran;      // (a round of 32 streams the frames twice)
         c->st_rounds[ek_form_slot(T)] += ran;
         c->st_centers[ek_form_slot(T)] += cr.n_done - before;
         if (st.err || st.mode == 0 || cr.stopped || cr.n_done >= goal)
@@ -622,12 +633,24 @@ extern "C" int ek_ms_run(ek_ctx *c, int32_t first_label, int32_t max_new,
                     --wait16;
                 else if (per_round >= 6.5)
                     want = 16;
-            } else if (per_round < 8.5) {
-                want = 8;
-                wait16 = next_wait;
-                next_wait = std::min(2 * next_wait, 64);
+            } else if (T == 16) {
+                if (per_round < 8.5) {
+                    want = 8;
+                    wait16 = next_wait;
+                    next_wait = std::min(2 * next_wait, 64);
+                } else {
+                    next_wait = 1;
+                    if (wait32 > 0)
+                        --wait32;
+                    else if (Tmax == 32 && per_round >= 14.0)
+                        want = 32;
+                }
+            } else if (per_round < 22.0) {
+                want = 16;
+                wait32 = next_wait32;
+                next_wait32 = std::min(2 * next_wait32, 64);
             } else {
-                next_wait = 1;
+                next_wait32 = 1;
             }
             if (want != T) {
                 ek_launch_round_flush(R, c->stream);    // the chain still pending

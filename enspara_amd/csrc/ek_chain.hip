@@ -129,9 +129,9 @@ ek_chain_max_kernel(const float *__restrict__ dist,
     const bool whole = f0 + EK_CHAIN_FPT <= n;      // 16-byte loads
     // all loads first: the running minimum would otherwise serialise them
     float run[EK_CHAIN_FPT];
-    float dv[EK_MAX_CANDS][EK_CHAIN_FPT];
+    float dv[EK_LEGACY_CANDS][EK_CHAIN_FPT];    // (these forms run <= 16 candidates)
 #pragma unroll
-    for (int k = 1; k < EK_MAX_CANDS - 1; ++k) {
+    for (int k = 1; k < EK_LEGACY_CANDS - 1; ++k) {
 #pragma unroll
         for (int q = 0; q < EK_CHAIN_FPT; ++q)
             dv[k][q] = __builtin_inff();
@@ -157,7 +157,7 @@ ek_chain_max_kernel(const float *__restrict__ dist,
             run[q] = (f0 + q < n) ? dist[f0 + q] : 0.f;
     }
 #pragma unroll
-    for (int k = 1; k < EK_MAX_CANDS - 1; ++k) {
+    for (int k = 1; k < EK_LEGACY_CANDS - 1; ++k) {
         if (k < cn) {                       // uniform
             float v = -__builtin_inff();
             uint32_t i = 0xffffffffu;
@@ -270,10 +270,10 @@ ek_chain_max2_kernel(const float *__restrict__ dist, const float *__restrict__ v
         const int64_t f0 = ((int64_t)blockIdx.x * EK_CM2_THREADS + tid) * EK_CM2_FPT;
         const bool whole = f0 + EK_CM2_FPT <= n;
         float run[EK_CM2_FPT];
-        float dv[EK_MAX_CANDS][EK_CM2_FPT];
+        float dv[EK_LEGACY_CANDS][EK_CM2_FPT];
         // all loads first: the running minimum would otherwise serialise them
 #pragma unroll
-        for (int k = 1; k < EK_MAX_CANDS - 1; ++k) {
+        for (int k = 1; k < EK_LEGACY_CANDS - 1; ++k) {
 #pragma unroll
             for (int q = 0; q < EK_CM2_FPT; ++q)
                 dv[k][q] = __builtin_inff();
@@ -300,7 +300,7 @@ ek_chain_max2_kernel(const float *__restrict__ dist, const float *__restrict__ v
         }
         const int64_t wg = ((int64_t)blockIdx.x * EK_CM2_THREADS + tid) / EK_WAVE;
 #pragma unroll
-        for (int k = 1; k < EK_MAX_CANDS - 1; ++k) {
+        for (int k = 1; k < EK_LEGACY_CANDS - 1; ++k) {
             if (k < cn) {                       // uniform
                 float v = -__builtin_inff();
                 uint32_t i = 0xffffffffu;

@@ -122,9 +122,10 @@ __device__ __forceinline__ void ek_chain_rows_local(const EkPlan *plan,
 }
 
 // the workgroup's 16 waves reduce the per-workgroup maxima of states 0 .. cn - 1:
-// two waves per state while there are at most 8 states, one each beyond (cn <=
-// EK_MAX_CANDS - 1 = 15); the loads of a trip are issued together (the entries
-// are independent).  Called by 1024 threads.
+// two waves per state while there are at most 8 states, one each up to 16, and
+// beyond (rounds of 32: cn <= EK_MAX_CANDS - 1 = 31) a wave takes states w and
+// w + 16 one after the other; the loads of a trip are issued together (the
+// entries are independent).  Called by 1024 threads.
 template <bool COH = false>
 __device__ __forceinline__ void ek_chain_reduce(const EkBlockMax *blockmax,
                                                 const EkBlockMax *pm, int nb,
@@ -135,11 +136,12 @@ __device__ __forceinline__ void ek_chain_reduce(const EkBlockMax *blockmax,
     __shared__ uint32_t half_i[2 * EK_MAX_CANDS];
     const int tid = threadIdx.x;
     const int wv = tid / EK_WAVE, lane = tid & (EK_WAVE - 1);
-    static_assert(EK_MAX_CANDS <= EK_CHAIN_THREADS / EK_WAVE, "a wave per state");
-    const int parts = cn <= EK_CHAIN_THREADS / EK_WAVE / 2 ? 2 : 1;
-    const int w = wv / parts, part = wv % parts;
+    constexpr int NW = EK_CHAIN_THREADS / EK_WAVE;
+    static_assert(EK_MAX_CANDS <= 2 * NW, "two states per wave at most");
+    const int parts = cn <= NW / 2 ? 2 : 1;
     constexpr int U = 16;
-    if (w < cn) {
+    for (int w = wv / parts; w < cn; w += NW / parts) {
+        const int part = wv % parts;
         const EkBlockMax *src = (w == 0) ? blockmax : pm + (size_t)(w - 1) * nbp;
         const int cnt = (w == 0) ? nb : nbp;
         float v = -__builtin_inff();
@@ -162,8 +164,8 @@ __device__ __forceinline__ void ek_chain_reduce(const EkBlockMax *blockmax,
         }
         ek_wave_argmax(v, i);
         if (lane == 0) {
-            half_v[wv] = v;
-            half_i[wv] = i;
+            half_v[parts * w + part] = v;
+            half_i[parts * w + part] = i;
         }
     }
     __syncthreads();

@@ -57,9 +57,14 @@ struct EkMaxHdr {
 static_assert(sizeof(EkMaxHdr) == 16, "max header is 16 bytes");
 
 typedef float ek_v2f __attribute__((ext_vector_type(2)));
-// candidates per pass of a k-centers round: 4, 8 or 16 (a run-time choice,
-// ek_run_rounds); the structures below are sized for the most
-#define EK_MAX_CANDS 16
+// candidates per round of k-centers: 4, 8, 16 or 32 (a run-time choice,
+// ek_run_rounds / ek_ms_run); the structures below are sized for the most.  A
+// round of 32 is TWO passes of 16 over the frames (ek_pass16.hip) behind one
+// plan, one chain and -- across shards -- one exchange (round 5).
+#define EK_MAX_CANDS 32
+// the widest form of the one-launch-per-step kernels (ek_chain.hip, the ek_spec_*
+// protocol, option key 10 = 0): their per-thread arrays are sized for this
+#define EK_LEGACY_CANDS 16
 // PAM: proposals per prefetch pass / columns per workgroup of the pairs kernel
 #define EK_PAM_GROUP 8
 // plan of one multi-candidate round (ek_spec.hip); written only by the
@@ -140,6 +145,7 @@ struct EkRound {
     EkChainOrd *ord;
     EkBlockMax *blockmax;       // per 256 frames, state after the pass
     EkBlockMax *pm;             // [EK_MAX_CANDS][nb] states after each chain prefix
+    EkBlockMax *fm;             // [4 nb] per 64 frames: the state after the whole chain
     unsigned char *top;         // scratch of the candidate pick
     float *ctile;
     double *ctrace;
@@ -413,15 +419,22 @@ void ek_launch_pam_active(const float *dist, const int32_t *assign, int64_t n,
 // candidate (lane % 16) in each lane; one 16-byte load per lane fetches that
 // operand for the four trips of 16 atoms (ek_pass16.hip).  The tile holds A +
 // EK_CTILE_PAD atoms rounded up to whole groups of 16, zeros past the last.
+// T = 32: two such tiles, candidate c in tile c / 16 (ek_ctile_half_floats).
 static inline __host__ __device__ size_t ek_ctile_index(int T, int a, int c, int k)
 {
-    if (T == 16)    // [16 atoms][xyz][lane = (a % 4) * 16 + c][trip of 4 atoms]
-        return ((((size_t)(a >> 4) * 3 + k) * 4 + (a & 3)) * 16 + c) * 4 + ((a >> 2) & 3);
+    if (T >= 16)    // [16 atoms][xyz][lane = (a % 4) * 16 + c][trip of 4 atoms]
+        return ((((size_t)(a >> 4) * 3 + k) * 4 + (a & 3)) * 16 + (c & 15)) * 4 + ((a >> 2) & 3);
     return (size_t)a * (3 * T) + (c / 2) * 6 + k * 2 + (c & 1);
 }
 static inline __host__ __device__ int ek_ctile_atoms(int A)  // incl. padding
 {
     return (A + EK_CTILE_PAD + 15) / 16 * 16;
+}
+// a round of 32: candidates 16 .. 31 in a second tile of the 16-form, this many
+// floats behind the first (what the round's second pass reads)
+static inline __host__ __device__ size_t ek_ctile_half_floats(int A)
+{
+    return (size_t)ek_ctile_atoms(A) * 3 * 16;
 }
 void ek_launch_pam_setup(const float *aos, const double *G, int A,
                          const int64_t *frames, int count, int64_t global_offset,
@@ -495,7 +508,8 @@ void ek_launch_quad_tiles(const float *tiles, int64_t n_tiles, int A, float *qti
 void ek_launch_pass16(bool fuse, const float *qtiles, const double *G, float *dist,
                       int32_t *assign, float *vecs, int64_t n, int64_t n_pad, int A,
                       const float *ctile, const double *ctrace, const EkPlan *plan,
-                      EkBlockMax *blockmax, const EkFuse &fz, hipStream_t s);
+                      EkBlockMax *blockmax, const EkFuse &fz, hipStream_t s,
+                      bool wide = false);
 // distances only: vecs[j][f] = rmsd(frame f, record j), j < count <= 8
 void ek_launch_pass_dist(int count, const float *tiles, const double *G,
                          float *vecs, int64_t n, int64_t n_pad, int A,

@@ -19,6 +19,8 @@
 
 void ek_msm_scratch_free(void *w);      // ek_msm.hip
 
+#define EK_N_FORMS 5        // forms of a round in the run statistics: 1 / 4 / 8 / 16 / 32
+
 // (thread-local message behind ek_last_error; defined in ek_api.hip)
 int ek_set_error(int code, const char *fmt, ...);
 #define ek_fail ek_set_error
@@ -224,6 +226,8 @@ struct ek_ctx {
     float *vecs = nullptr;       // [EK_MAX_CANDS-1][n_pad] stored distance vectors
     EkMaxHdr *hdr = nullptr;
     EkBlockMax *pm = nullptr;    // [EK_MAX_CANDS-1][nb] per-prefix maxima (ek_chain.hip)
+    EkBlockMax *fm = nullptr;    // [4 nb] maxima per 64 frames of a round's last prefix
+    int fine_pick = 1;           // the candidate pick reads them (option key 15)
     unsigned char *top = nullptr;    // scratch of the candidate pick (ek_spec.hip)
     float *planD = nullptr;          // [64][64] distances between the records on offer
     int fused = 1;               // single-shard rounds in three launches (ek_round.hip)
@@ -250,8 +254,8 @@ struct ek_ctx {
     int64_t n_pad = 0;
     int32_t last_passes = 0;
     int adapt = 1;               // choose the candidates per pass from measured rates
-    int64_t st_rounds[4] = {0, 0, 0, 0};    // passes run as 1 / 4 / 8 / 16 candidates (last run)
-    int64_t st_centers[4] = {0, 0, 0, 0};   // centers they accepted
+    int64_t st_rounds[EK_N_FORMS] = {0, 0, 0, 0, 0};    // rounds run as 1 / 4 / 8 / 16 / 32 candidates (last run)
+    int64_t st_centers[EK_N_FORMS] = {0, 0, 0, 0, 0};   // centers they accepted
     hipEvent_t evb0 = nullptr, evb1 = nullptr;   // per-batch timing
 
     // rounds across shards (ek_mshard.hip)
@@ -288,7 +292,7 @@ struct ek_ctx {
 hipError_t ek_wait(ek_ctx *c);
 int ek_pick_fpl(const ek_ctx *c);
 int ek_pick_nt(const ek_ctx *c);
-int ek_pick_cands(const ek_ctx *c);
+int ek_pick_cands(const ek_ctx *c, bool wide = false);
 int ek_ensure_qtiles(ek_ctx *c);
 // nearest centers on v_mfma_f32_16x16x4_f32 (ek_assign.hip): the centers in blocks of
 // 16 laid out like a pass's candidate tile, the frames from the quad copy

@@ -256,30 +256,12 @@ ek_ms_chain_kernel(EkRound r, EkMsState *ms, EkMsXchg x, int nblk)
     if (cn > 0) {
         // pm[(k - 1) * nb + w] = first-index arg-max over frames [256 w, 256 w + 256)
         // of min(dist, vec[order[0]], .., vec[order[k-1]]), k = 1 .. cn (state 0
-        // is what the pass left in blockmax): as ek_round_chain_kernel
+        // is what the pass left in blockmax): as ek_round_chain_kernel, sixteen
+        // prefixes at a time
         const int64_t f0 = ((int64_t)blockIdx.x * EK_MS_THREADS + tid) * EK_MS_FPT;
         const bool whole = f0 + EK_MS_FPT <= r.n;
         float run[EK_MS_FPT];
-        float dv[EK_MAX_CANDS][EK_MS_FPT];
         const uint32_t vm = f0 < r.n ? r.vmask[f0 >> 6] : 0u;
-#pragma unroll
-        for (int k = 1; k < EK_MAX_CANDS; ++k) {
-#pragma unroll
-            for (int q = 0; q < EK_MS_FPT; ++q)
-                dv[k][q] = __builtin_inff();
-            if (k <= cn && ((vm >> r.ord->cand[k - 1]) & 1u)) {
-                const float *v = r.vecs + (size_t)(r.ord->cand[k - 1] - 1) * r.n_pad + f0;
-                if (whole) {
-                    const float4 t = *(const float4 *)v;
-                    dv[k][0] = t.x; dv[k][1] = t.y; dv[k][2] = t.z; dv[k][3] = t.w;
-                } else {
-#pragma unroll
-                    for (int q = 0; q < EK_MS_FPT; ++q)
-                        if (f0 + q < r.n)
-                            dv[k][q] = v[q];
-                }
-            }
-        }
         if (whole) {
             const float4 t = *(const float4 *)(r.dist + f0);
             run[0] = t.x; run[1] = t.y; run[2] = t.z; run[3] = t.w;
@@ -290,24 +272,55 @@ ek_ms_chain_kernel(EkRound r, EkMsState *ms, EkMsXchg x, int nblk)
         }
         const int64_t wg = ((int64_t)blockIdx.x * EK_MS_THREADS + tid) / EK_WAVE;
 #pragma unroll
-        for (int k = 1; k < EK_MAX_CANDS; ++k) {
-            if (k <= cn) {                  // uniform
-                float v = -__builtin_inff();
-                uint32_t i = 0xffffffffu;
+        for (int kb = 0; kb < EK_MAX_CANDS; kb += 16) {
+            if (kb >= cn + 1)               // uniform
+                break;
+            float dv[16][EK_MS_FPT];
 #pragma unroll
-                for (int q = 0; q < EK_MS_FPT; ++q) {
-                    if (f0 + q < r.n) {
-                        if (dv[k][q] < run[q])      // kcenters.py:304
-                            run[q] = dv[k][q];
-                        if (ek_better(run[q], (uint32_t)(f0 + q), v, i)) {
-                            v = run[q];
-                            i = (uint32_t)(f0 + q);
-                        }
+            for (int kk = 0; kk < 16; ++kk) {
+                const int k = kb + kk;
+#pragma unroll
+                for (int q = 0; q < EK_MS_FPT; ++q)
+                    dv[kk][q] = __builtin_inff();
+                if (k >= 1 && k <= cn && ((vm >> r.ord->cand[k - 1]) & 1u)) {
+                    const float *v = r.vecs + (size_t)(r.ord->cand[k - 1] - 1) * r.n_pad + f0;
+                    if (whole) {
+                        const float4 t = *(const float4 *)v;
+                        dv[kk][0] = t.x; dv[kk][1] = t.y; dv[kk][2] = t.z; dv[kk][3] = t.w;
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < EK_MS_FPT; ++q)
+                            if (f0 + q < r.n)
+                                dv[kk][q] = v[q];
                     }
                 }
-                ek_wave_argmax(v, i);
-                if ((tid & (EK_WAVE - 1)) == 0 && wg < nb)
-                    ek_coh_store_bm(&r.pm[(size_t)(k - 1) * nb + wg], v, i);
+            }
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                const int k = kb + kk;
+                if (k >= 1 && k <= cn) {        // uniform
+                    float v = -__builtin_inff();
+                    uint32_t i = 0xffffffffu;
+#pragma unroll
+                    for (int q = 0; q < EK_MS_FPT; ++q) {
+                        if (f0 + q < r.n) {
+                            if (dv[kk][q] < run[q])     // kcenters.py:304
+                                run[q] = dv[kk][q];
+                            if (ek_better(run[q], (uint32_t)(f0 + q), v, i)) {
+                                v = run[q];
+                                i = (uint32_t)(f0 + q);
+                            }
+                        }
+                    }
+                    // (the rows of 16 lanes first: of the state the whole chain would
+                    // leave, the maxima per 64 frames are kept for the offers)
+                    ek_row_argmax(v, i);
+                    if (k == cn && r.fm && (tid & 15) == 0 && wg < nb)
+                        ek_coh_store_bm(&r.fm[4 * (size_t)wg + ((tid >> 4) & 3)], v, i);
+                    ek_rows_to_wave_argmax(v, i);
+                    if ((tid & (EK_WAVE - 1)) == 0 && wg < nb)
+                        ek_coh_store_bm(&r.pm[(size_t)(k - 1) * nb + wg], v, i);
+                }
             }
         }
     }
@@ -321,9 +334,12 @@ ek_ms_chain_kernel(EkRound r, EkMsState *ms, EkMsXchg x, int nblk)
     // its farthest frames of the state the offers are for: the one the whole
     // chain would leave, or (the chain broke) the one it did leave
     const int ps = mode == 1 ? cn : ms->pick_state;
-    const EkBlockMax *state = ps == 0 ? r.blockmax : r.pm + (size_t)(ps - 1) * nb;
+    // (the state the whole chain would leave: its maxima per 64 frames)
+    const bool fine = r.fm && mode == 1 && cn > 0;
+    const EkBlockMax *state = fine ? r.fm
+                                   : (ps == 0 ? r.blockmax : r.pm + (size_t)(ps - 1) * nb);
     EkTop *top = (EkTop *)r.top;
-    ek_pick_top_body<true>(state, nb, top, skip, r.assign);
+    ek_pick_top_body<true>(state, fine ? 4 * nb : nb, top, skip, r.assign);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     // the list for the helpers, and the head of the message: this workgroup's part
@@ -642,10 +658,10 @@ ek_ms_plan_kernel(EkRound r, EkMsState *ms, EkMsXchg x, float *D)
                 h[u] = u == 0 ? __float_as_uint(-__builtin_inff())
                               : ((u == 2 || u == 3) ? 0xffffffffu : 0u);
         }
-        // (T = 16: the coordinates are ek_ms_ctile16_kernel's, a launch of its own --
+        // (T >= 16: the coordinates are ek_ms_ctile16_kernel's, a launch of its own --
         // written by this one workgroup they were most of the kernel's tail)
         const int cpr_c = (A3 + 3) / 4;         // 16-byte chunks of coordinates
-        for (int e0 = tid; T != 16 && e0 < T * cpr_c; e0 += 4 * EK_BLOCK) {
+        for (int e0 = tid; T < 16 && e0 < T * cpr_c; e0 += 4 * EK_BLOCK) {
             const void *p[4];
             ek_f4 v[4];
 #pragma unroll
@@ -676,7 +692,7 @@ ek_ms_plan_kernel(EkRound r, EkMsState *ms, EkMsXchg x, float *D)
                 }
             }
         }
-        if (go && T != 16)                          // the atoms of padding
+        if (go && T < 16)                           // the atoms of padding
             for (int k = tid; k < (ek_ctile_atoms(A) - A) * 3 * T; k += EK_BLOCK)
                 r.ctile[ek_ctile_index(T, A + k / (3 * T), (k % (3 * T)) / 3, k % 3)] =
                     0.f;
@@ -732,34 +748,35 @@ ek_ms_plan_kernel(EkRound r, EkMsState *ms, EkMsXchg x, float *D)
     }
 }
 
-// The chosen records' coordinates of a round of 16, out of the mailboxes: into the
-// round's records and, in 16-byte pieces, into the candidate tile of the next pass
-// (as ek_round_ctile16_kernel does for a single shard).  It reads the exchange
-// the plan kernel has just closed (ms->seq - 1); after a plan kernel that had
-// nothing to do it writes the same bytes again.
+// The chosen records' coordinates of a round of 16 or 32, out of the mailboxes: into
+// the round's records and, in 16-byte pieces, into the candidate tile(s) of the
+// next pass (as ek_round_ctile16_kernel does for a single shard).  It reads the
+// exchange the plan kernel has just closed (ms->seq - 1); after a plan kernel that
+// had nothing to do it writes the same bytes again.
 template <bool SYS>
 __global__ void __launch_bounds__(EK_BLOCK)
-ek_ms_ctile16_kernel(EkRound r, EkMsState *ms, EkMsXchg x)
+ek_ms_ctile16_kernel(EkRound r, EkMsState *ms, EkMsXchg x, int halves)
 {
     typedef float v4 __attribute__((ext_vector_type(4)));
-    __shared__ int soff[16];
+    __shared__ int soff[EK_MAX_CANDS];
     const EkPlan *plan = r.plan;
     const int tid = threadIdx.x;
     const int ns = plan->n_rec, go = plan->go;
     if (ns <= 0)
         return;
     const uint32_t seq = ms->seq - 1u;
-    if (tid < 16)
+    if (tid < EK_MAX_CANDS)
         soff[tid] = tid < ns ? plan->offer[tid] : 0;
     __syncthreads();
     const int A = r.A, A3 = 3 * A;
     const int n_ct = ek_ctile_atoms(A) / 16 * 3;        // (16 atoms, axis) blocks of 1 KB
     const int ct_wgs = (n_ct + 3) / 4;
-    if ((int)blockIdx.x < ct_wgs) {
-        const int blk = blockIdx.x * 4 + (tid >> 6), lane = tid & 63;
-        if (!go || blk >= n_ct)
+    if ((int)blockIdx.x < halves * ct_wgs) {
+        const int half = blockIdx.x / ct_wgs;
+        const int blk = (blockIdx.x % ct_wgs) * 4 + (tid >> 6), lane = tid & 63;
+        if (!go || blk >= n_ct || 16 * half >= ns)
             return;
-        const int S = blk / 3, k = blk % 3, kk = lane >> 4, c = lane & 15;
+        const int S = blk / 3, k = blk % 3, kk = lane >> 4, c = 16 * half + (lane & 15);
         const float *src = (const float *)(ek_ms_rec<SYS>(x, soff[c], seq, A) + 8) + k;
         v4 v;
 #pragma unroll
@@ -767,9 +784,10 @@ ek_ms_ctile16_kernel(EkRound r, EkMsState *ms, EkMsXchg x)
             const int a = 16 * S + 4 * q + kk;
             v[q] = (a < A && c < ns) ? ek_msg_loadf<SYS>(src + 3 * a) : 0.f;
         }
-        *(v4 *)(r.ctile + ek_ctile_index(16, 16 * S + kk, c, k)) = v;
+        *(v4 *)(r.ctile + half * ek_ctile_half_floats(A) +
+                ek_ctile_index(16, 16 * S + kk, c, k)) = v;
     } else {
-        const int c = blockIdx.x - ct_wgs;              // one record per workgroup
+        const int c = blockIdx.x - halves * ct_wgs;     // one record per workgroup
         if (c >= ns)
             return;
         const float *src = (const float *)(ek_ms_rec<SYS>(x, soff[c], seq, A) + 8);
@@ -792,15 +810,20 @@ void ek_launch_ms_plan(const EkRound &r, EkMsState *ms, const EkMsXchg &x, float
             hipLaunchKernelGGL((ek_ms_plan_kernel<TT, false>), dim3(blocks),   \
                                dim3(EK_BLOCK), 0, s, r, ms, x, D);             \
     } while (0)
-    if (r.T == 16) {
-        EK_MS_PLAN(16);
-        const unsigned wgs = (unsigned)((ek_ctile_atoms(r.A) / 16 * 3 + 3) / 4 + 16);
+    if (r.T >= 16) {
+        const int halves = r.T / 16;
+        if (r.T == 32)
+            EK_MS_PLAN(32);
+        else
+            EK_MS_PLAN(16);
+        const unsigned wgs =
+            (unsigned)(halves * ((ek_ctile_atoms(r.A) / 16 * 3 + 3) / 4) + r.T);
         if (x.sys)
             hipLaunchKernelGGL((ek_ms_ctile16_kernel<true>), dim3(wgs), dim3(EK_BLOCK), 0, s,
-                               r, ms, x);
+                               r, ms, x, halves);
         else
             hipLaunchKernelGGL((ek_ms_ctile16_kernel<false>), dim3(wgs), dim3(EK_BLOCK), 0, s,
-                               r, ms, x);
+                               r, ms, x, halves);
     } else if (r.T == 8)
         EK_MS_PLAN(8);
     else

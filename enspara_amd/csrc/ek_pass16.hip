@@ -78,22 +78,42 @@ __device__ __forceinline__ void ek_wave_sync()
 // The last workgroup of a fused single-shard pass: the presumed acceptance order
 // (see ek_pass2_kernel), by NT threads -- the whole workgroup (t = threadIdx.x)
 // or one wave of it (t = lane).
-template <int NT>
+template <int NT, int NC>
 __device__ __forceinline__ void ek_p16_order_tail(int t, const EkPlan *plan, const EkFuse &fz,
                                                   EkChainRow *rows, int *s_chain, int *s_cn,
                                                   int teff, int label)
 {
-    for (int e = t; e < EK_MAX_CANDS * (EK_MAX_CANDS + 2); e += NT) {
-        const int j = e / (EK_MAX_CANDS + 2), u = e % (EK_MAX_CANDS + 2);
-        const bool live = j >= 1 && j < teff;
+    // (all of a thread's loads first, then its LDS stores: every one is a trip to
+    // the L2 of ~2.5 us, and behind one another that is what they would cost)
+    constexpr int ENT = NC * (NC + 2), PER = (ENT + NT - 1) / NT;
+    float val[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int e = t + q * NT;
+        const int j = e / (NC + 2), u = e % (NC + 2);
+        const bool live = e < ENT && j >= 1 && j < teff;
+        val[q] = 0.f;
+        if (u == 0) {
+            if (live)
+                val[q] = ek_coh_load(&fz.rows[j].cur);
+        } else if (u == 1) {
+            if (live)
+                val[q] = __int_as_float(ek_coh_load(&fz.rows[j].valid));
+        } else if (live && u - 2 >= 1 && u - 2 < teff)
+            val[q] = ek_coh_load(&fz.rows[j].d[u - 2]);
+    }
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int e = t + q * NT;
+        const int j = e / (NC + 2), u = e % (NC + 2);
+        if (e >= ENT)
+            continue;
         if (u == 0)
-            rows[j].cur = live ? ek_coh_load(&fz.rows[j].cur) : 0.f;
+            rows[j].cur = val[q];
         else if (u == 1)
-            rows[j].valid = live ? ek_coh_load(&fz.rows[j].valid) : 0;
+            rows[j].valid = __float_as_int(val[q]);
         else
-            rows[j].d[u - 2] = (live && u - 2 >= 1 && u - 2 < teff)
-                                   ? ek_coh_load(&fz.rows[j].d[u - 2])
-                                   : 0.f;
+            rows[j].d[u - 2] = val[q];
     }
     if (NT == EK_WAVE) ek_wave_sync(); else __syncthreads();
     if (t < EK_MAX_CANDS)       // the rows are one round's: clear them
@@ -115,7 +135,14 @@ __device__ __forceinline__ void ek_p16_order_tail(int t, const EkPlan *plan, con
     }
 }
 
-template <bool FUSE>
+// MODE 0: a round of 16.  A round of 32 candidates (round 5) is two launches over
+// the frames behind one plan and one chain: MODE 1 takes candidates 0 .. 15 --
+// everything a round of 16 does except the presumed order, which needs the
+// other sixteen columns of the candidate frames' rows --, MODE 2 candidates
+// 16 .. 31 against the state MODE 1 left: no pending chain (applied), no update
+// (candidate 0 was MODE 1's), sixteen kept vectors more (slots 15 .. 30, mask
+// bits 16 .. 31), the rows' other half, and the presumed order at its end.
+template <bool FUSE, int MODE>
 __global__ void __launch_bounds__(EK_BLOCK, 2)
 ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
                  float *__restrict__ dist, int32_t *__restrict__ assign,
@@ -140,6 +167,14 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
 #endif
     if (!plan->go)
         return;
+    constexpr int CB = MODE == 2 ? 16 : 0;      // the first candidate of this launch
+    constexpr int NC = MODE == 0 ? 16 : EK_MAX_CANDS;   // candidates of the round, at most
+    if (MODE == 2) {
+        if (plan->teff <= 16)
+            return;             // (the round has no second half)
+        ctile += ek_ctile_half_floats(A);
+        ctrace += 16;
+    }
     // Two workgroups share a CU (two waves per SIMD).  Launched together and
     // equally long they stay in step for the whole pass: both ask HBM for their
     // rows in the same microseconds, then both solve.  Of the first workgroups
@@ -189,22 +224,26 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
         }
     }
 #endif
-    const int teff = plan->teff;
+    const int teff_all = plan->teff;            // candidates of the round
+    const int teff = teff_all - CB < 16 ? teff_all - CB : 16;   // ... of this launch
     const int label = plan->label;
     static_assert(EK_BLOCK == EK_TILE, "one workgroup per tile");
     const int64_t f0 = (int64_t)blockIdx.x * EK_BLOCK;
     const int64_t f = f0 + tid;
     // the arrival tickets of a fused single-shard round: see ek_pass2_kernel
-    const bool order = FUSE && fz.ord != nullptr;
+    // rows_wr: the candidate frames' rows are wanted (single shard); order: this
+    // launch ends with the presumed order (the round's last pass)
+    const bool rows_wr = FUSE && fz.ord != nullptr;
+    const bool order = rows_wr && (MODE != 1 || teff_all <= 16);
     bool owner_blk = false;
     unsigned int ticket = 0;
-    if (order) {
+    if (rows_wr) {
 #pragma unroll
-        for (int j = 1; j < T; ++j) {
+        for (int j = 1; j < NC; ++j) {
             const int64_t l = plan->gidx[j] - fz.goff - f0;
-            owner_blk |= j < teff && l >= 0 && l < EK_BLOCK;
+            owner_blk |= j < teff_all && l >= 0 && l < EK_BLOCK;
         }
-        if (!owner_blk && tid == 0)
+        if (order && !owner_blk && tid == 0)
             ticket = __hip_atomic_fetch_add(fz.tick, 1u, __ATOMIC_RELAXED,
                                             __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -250,7 +289,7 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
             vm = fz.vmask[f >> 6];
     }
     int pn_v = 0, label0_v = 0; // (the pending chain's length and first label: with them)
-    if (FUSE) {
+    if (FUSE && MODE != 2) {
         pn_v = pend->n;
         label0_v = pend->label0;
     }
@@ -277,10 +316,10 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
     int32_t lab = -1;           // >= 0: the frame's state changes in this pass
     int own = 0;                // order: this frame is candidate `own` (>= 1)
     {
-        if (order && owner_blk && f < n) {  // (15 workgroups of a pass at most)
+        if (rows_wr && owner_blk && f < n) {    // (31 workgroups of a pass at most)
 #pragma unroll
-            for (int j = 1; j < T; ++j)
-                if (j < teff && plan->gidx[j] - fz.goff == f)
+            for (int j = 1; j < NC; ++j)
+                if (j < teff_all && plan->gidx[j] - fz.goff == f)
                     own = j;
         }
         // kcenters.py:304-306 for the pending chain, in order.  A vector is stored
@@ -288,7 +327,7 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
         // 0's word is the wave's) skips the walk over the chain -- fifteen
         // dependent trips to memory otherwise.
         const int pn = __builtin_amdgcn_readfirstlane(pn_v);
-        if (FUSE && pn > 0 && __builtin_amdgcn_readfirstlane(vm) != 0u) {
+        if (FUSE && MODE != 2 && pn > 0 && __builtin_amdgcn_readfirstlane(vm) != 0u) {
             const int label0 = __builtin_amdgcn_readfirstlane(label0_v);
             for (int k = 0; k < pn; ++k) {
                 const int slot = pend->slot[k];
@@ -531,42 +570,44 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
     if (f < n) {
         // candidate 0: the new center of this iteration (kcenters.py:298-306)
         float cur = cur0;
-        const float d0 = dcs[0];
-        if (d0 < cur) {
-            cur = d0;
-            lab = label;
-        }
-        if (lab >= 0) {
-            dist[f] = cur;
-            assign[f] = lab;
-        }
-        bestv = cur;
-        besti = (uint32_t)f;
-        if (order && own) {
-            ek_coh_store(&fz.rows[own].cur, cur);
-            ek_coh_store(&fz.rows[own].valid, 1);
+        if (MODE != 2) {
+            const float d0 = dcs[0];
+            if (d0 < cur) {
+                cur = d0;
+                lab = label;
+            }
+            if (lab >= 0) {
+                dist[f] = cur;
+                assign[f] = lab;
+            }
+            bestv = cur;
+            besti = (uint32_t)f;
+            if (rows_wr && own) {
+                ek_coh_store(&fz.rows[own].cur, cur);
+                ek_coh_store(&fz.rows[own].valid, 1);
+            }
         }
         // a kept distance that is not below the frame's own can never be used
         // (strict <, against a value that only shrinks): it is +inf, and a wave
         // stores a vector only if one of its frames has a finite value -- one
         // word per wave says which it stored, readers take the others as +inf
-        uint32_t wmask = 0;
+        uint32_t wmask = MODE == 2 ? vm : 0u;
 #pragma unroll
-        for (int c = 1; c < T; ++c) {
+        for (int c = (MODE == 2 ? 0 : 1); c < T; ++c) {
             if (c < teff) {
                 float dc = dcs[c];
                 if (!(dc < cur))
                     dc = __builtin_inff();
                 if (FUSE) {
                     if (__ballot(dc != __builtin_inff())) {     // wave-uniform
-                        vecs[(size_t)(c - 1) * n_pad + f] = dc;
-                        wmask |= 1u << c;
+                        vecs[(size_t)(CB + c - 1) * n_pad + f] = dc;
+                        wmask |= 1u << (CB + c);
                     }
                 } else {
                     vecs[(size_t)(c - 1) * n_pad + f] = dc;
                 }
-                if (order && own)
-                    ek_coh_store(&fz.rows[own].d[c], dc);
+                if (rows_wr && own)
+                    ek_coh_store(&fz.rows[own].d[CB + c], dc);
             }
         }
         if (FUSE && (f & (EK_WAVE - 1)) == 0)
@@ -603,11 +644,14 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
                     v = red_v[w];
                     i = red_i[w];
                 }
-            blockmax[blockIdx.x].val = v;
-            blockmax[blockIdx.x].idx = i;
+            if (MODE != 2) {    // (the state is the first pass's)
+                blockmax[blockIdx.x].val = v;
+                blockmax[blockIdx.x].idx = i;
+            }
         }
         if (ek_arrive_last(fz.tick))
-            ek_p16_order_tail<EK_BLOCK>(tid, plan, fz, rows, s_chain, &s_cn, teff, label);
+            ek_p16_order_tail<EK_BLOCK, NC>(tid, plan, fz, rows, s_chain, &s_cn, teff_all,
+                                            label);
         return;
     }
     // Every other workgroup: no wave waits for another (a barrier here held each
@@ -638,7 +682,7 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
         *(volatile unsigned int *)cu_end = (unsigned)__builtin_amdgcn_s_memrealtime();
     }
 #endif
-    if (lane == 0) {
+    if (MODE != 2 && lane == 0) {
         float v = red_v[0];
         uint32_t i = red_i[0];
 #pragma unroll
@@ -653,23 +697,32 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
     // the workgroup that drew the last ticket (at its start: every owner had
     // finished by then) works out the presumed order
     if (order && s_ticket == gridDim.x - 1)
-        ek_p16_order_tail<EK_WAVE>(lane, plan, fz, rows, s_chain, &s_cn, teff, label);
+        ek_p16_order_tail<EK_WAVE, NC>(lane, plan, fz, rows, s_chain, &s_cn, teff_all, label);
 }
 
+// wide: a round of 32 candidates -- the same stream twice, candidates 0 .. 15 and
+// 16 .. 31 (the second launch returns at once when the plan holds 16 or fewer)
 void ek_launch_pass16(bool fuse, const float *qtiles, const double *G, float *dist,
                       int32_t *assign, float *vecs, int64_t n, int64_t n_pad, int A,
                       const float *ctile, const double *ctrace, const EkPlan *plan,
-                      EkBlockMax *blockmax, const EkFuse &fz, hipStream_t s)
+                      EkBlockMax *blockmax, const EkFuse &fz, hipStream_t s, bool wide)
 {
     if (n <= 0)
         return;
     const unsigned blocks = (unsigned)((n + EK_BLOCK - 1) / EK_BLOCK);
-    if (fuse)
-        hipLaunchKernelGGL((ek_pass16_kernel<true>), dim3(blocks), dim3(EK_BLOCK), 0,
+    if (wide) {
+        hipLaunchKernelGGL((ek_pass16_kernel<true, 1>), dim3(blocks), dim3(EK_BLOCK), 0,
+                           s, qtiles, G, dist, assign, vecs, n, n_pad, A, ctile,
+                           ctrace, plan, blockmax, fz);
+        hipLaunchKernelGGL((ek_pass16_kernel<true, 2>), dim3(blocks), dim3(EK_BLOCK), 0,
+                           s, qtiles, G, dist, assign, vecs, n, n_pad, A, ctile,
+                           ctrace, plan, blockmax, fz);
+    } else if (fuse)
+        hipLaunchKernelGGL((ek_pass16_kernel<true, 0>), dim3(blocks), dim3(EK_BLOCK), 0,
                            s, qtiles, G, dist, assign, vecs, n, n_pad, A, ctile,
                            ctrace, plan, blockmax, fz);
     else
-        hipLaunchKernelGGL((ek_pass16_kernel<false>), dim3(blocks), dim3(EK_BLOCK), 0,
+        hipLaunchKernelGGL((ek_pass16_kernel<false, 0>), dim3(blocks), dim3(EK_BLOCK), 0,
                            s, qtiles, G, dist, assign, vecs, n, n_pad, A, ctile,
                            ctrace, plan, blockmax, fz);
 }

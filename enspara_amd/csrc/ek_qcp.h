@@ -320,8 +320,13 @@ __device__ __forceinline__ float ek_rmsd_from_S_below(const float (&S)[9],
         // 99.8 %: the two or three Newton steps (each with a float64 division) a
         // far pair took to pass its iterate bound are skipped.  Square roots in
         // float32, every rounding covered by a factor; an overflow gives inf or
-        // NaN and fails the comparison.
-        if (t > 0.0) {
+        // NaN and fails the comparison.  An UNDERFLOW does not: with q below
+        // ~1e-19 (coordinates in metres, say) b = O(q^2) is zero in float32, U
+        // comes out as sqrt(q), below the root, and a pair at exactly `cur` was
+        // abandoned (round 5: tests/test_gpu_qcp_device.py, family "tiny", found
+        // it; the host test only asked the certificate).  The bound is used only
+        // where the certificate accepts q: [1e-12, 1e12].
+        if (t > 0.0 && q > 1e-12 && q < 1e12) {
             const float qf = (float)q * 1.000001f;
             const float bf = __builtin_fmaxf((float)(0.25 * __builtin_fma(q, q, -C0) +
                                                      1e-12 * (q * q)), 0.0f) * 1.000001f;

@@ -35,6 +35,36 @@ __device__ __forceinline__ void ek_argmax_dpp_step(float &v, uint32_t &i)
     }
 }
 
+// the arg-max of every ROW of 16 lanes, in all lanes of the row (the first half of
+// ek_wave_argmax: what a finer-grained maximum costs is nothing)
+__device__ __forceinline__ void ek_row_argmax(float &v, uint32_t &i)
+{
+    ek_argmax_dpp_step<0xB1>(v, i);     // quad_perm [1,0,3,2]
+    ek_argmax_dpp_step<0x4E>(v, i);     // quad_perm [2,3,0,1]
+    ek_argmax_dpp_step<0x141>(v, i);    // row_half_mirror
+    ek_argmax_dpp_step<0x140>(v, i);    // row_mirror
+}
+
+// the rows' results -> the wave's, in every lane
+__device__ __forceinline__ void ek_rows_to_wave_argmax(float &v, uint32_t &i)
+{
+    float bv = __builtin_bit_cast(
+        float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    uint32_t bi = (uint32_t)__builtin_amdgcn_readlane((int)i, 0);
+#pragma unroll
+    for (int row = 1; row < 4; ++row) {
+        const float rv = __builtin_bit_cast(
+            float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16 * row));
+        const uint32_t ri = (uint32_t)__builtin_amdgcn_readlane((int)i, 16 * row);
+        if (ek_better(rv, ri, bv, bi)) {
+            bv = rv;
+            bi = ri;
+        }
+    }
+    v = bv;
+    i = bi;
+}
+
 __device__ __forceinline__ void ek_wave_argmax(float &v, uint32_t &i)
 {
     ek_argmax_dpp_step<0xB1>(v, i);     // quad_perm [1,0,3,2]

@@ -43,7 +43,6 @@ __device__ unsigned int ek_stamp_count;
 #endif
 
 #define EK_ROUND_THREADS 1024       // chain kernel: also the width of its tail
-#define EK_ROUND_FPT 4              // frames per thread there (16-byte loads)
 
 // ---------------------------------------------------------------------------
 // chain: states after the prefixes, decide, farthest block maxima
@@ -51,13 +50,15 @@ __device__ unsigned int ek_stamp_count;
 // pm[(k - 1) * nb + w] = first-index arg-max over frames [256 w, 256 w + 256) of
 // min(dist, vec[order[0]], .., vec[order[k-1]]), k = 1 .. cn (state 0 is what the
 // pass left in blockmax).  A wave covers 256 consecutive frames.
+template <int NV>
 __global__ void __launch_bounds__(EK_ROUND_THREADS)
 ek_round_chain_kernel(EkRound r, int bootstrap)
 {
+    constexpr int EK_ROUND_FPT = 4;     // frames per thread (16-byte loads)
     __shared__ float sv[EK_MAX_CANDS];
     __shared__ uint32_t si[EK_MAX_CANDS];
-    __shared__ int s_napply;
-    extern __shared__ uint32_t skip[];      // pick fallback for very large shards
+    __shared__ int s_napply, s_fine;
+    extern __shared__ uint32_t skip[];      // (unused since round 5)
     const int tid = threadIdx.x;
     const int nb = (int)((r.n + EK_BLOCK - 1) / EK_BLOCK);
 #ifdef EK_ROUND_STAMPS
@@ -73,29 +74,7 @@ ek_round_chain_kernel(EkRound r, int bootstrap)
                                EK_ROUND_FPT;
             const bool whole = f0 + EK_ROUND_FPT <= r.n;
             float run[EK_ROUND_FPT];
-            float dv[EK_MAX_CANDS][EK_ROUND_FPT];
             const uint32_t vm = f0 < r.n ? r.vmask[f0 >> 6] : 0u;
-            // all loads first: the running minimum would serialise them
-#pragma unroll
-            for (int k = 1; k < EK_MAX_CANDS; ++k) {
-#pragma unroll
-                for (int q = 0; q < EK_ROUND_FPT; ++q)
-                    dv[k][q] = __builtin_inff();
-                // (a vector the pass did not store for these frames is all +inf)
-                if (k <= cn && ((vm >> r.ord->cand[k - 1]) & 1u)) {
-                    const float *v = r.vecs +
-                                     (size_t)(r.ord->cand[k - 1] - 1) * r.n_pad + f0;
-                    if (whole) {
-                        const float4 t = *(const float4 *)v;
-                        dv[k][0] = t.x; dv[k][1] = t.y; dv[k][2] = t.z; dv[k][3] = t.w;
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < EK_ROUND_FPT; ++q)
-                            if (f0 + q < r.n)
-                                dv[k][q] = v[q];
-                    }
-                }
-            }
             if (whole) {
                 const float4 t = *(const float4 *)(r.dist + f0);
                 run[0] = t.x; run[1] = t.y; run[2] = t.z; run[3] = t.w;
@@ -106,26 +85,63 @@ ek_round_chain_kernel(EkRound r, int bootstrap)
             }
             const int64_t wg = ((int64_t)blockIdx.x * EK_ROUND_THREADS + tid) /
                                EK_WAVE;        // = 256-frame block of this wave
+            // sixteen prefixes at a time (a thread holds a value per frame and
+            // vector of them: rounds of 32 take two turns)
 #pragma unroll
-            for (int k = 1; k < EK_MAX_CANDS; ++k) {
-                if (k <= cn) {                  // uniform
-                    float v = -__builtin_inff();
-                    uint32_t i = 0xffffffffu;
+            for (int kb = 0; kb < NV; kb += 16) {
+                if (kb >= cn + 1)               // uniform
+                    break;
+                float dv[16][EK_ROUND_FPT];
+                // all loads first: the running minimum would serialise them
 #pragma unroll
-                    for (int q = 0; q < EK_ROUND_FPT; ++q) {
-                        if (f0 + q < r.n) {
-                            if (dv[k][q] < run[q])      // kcenters.py:304
-                                run[q] = dv[k][q];
-                            if (ek_better(run[q], (uint32_t)(f0 + q), v, i)) {
-                                v = run[q];
-                                i = (uint32_t)(f0 + q);
-                            }
+                for (int kk = 0; kk < 16; ++kk) {
+                    const int k = kb + kk;
+#pragma unroll
+                    for (int q = 0; q < EK_ROUND_FPT; ++q)
+                        dv[kk][q] = __builtin_inff();
+                    // (a vector the pass did not store for these frames is all +inf)
+                    if (k >= 1 && k <= cn && ((vm >> r.ord->cand[k - 1]) & 1u)) {
+                        const float *v = r.vecs +
+                                         (size_t)(r.ord->cand[k - 1] - 1) * r.n_pad + f0;
+                        if (whole) {
+                            const float4 t = *(const float4 *)v;
+                            dv[kk][0] = t.x; dv[kk][1] = t.y; dv[kk][2] = t.z; dv[kk][3] = t.w;
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < EK_ROUND_FPT; ++q)
+                                if (f0 + q < r.n)
+                                    dv[kk][q] = v[q];
                         }
                     }
-                    ek_wave_argmax(v, i);
-                    // (read by the last workgroup of this launch: coherent store)
-                    if ((tid & (EK_WAVE - 1)) == 0 && wg < nb)
-                        ek_coh_store_bm(&r.pm[(size_t)(k - 1) * nb + wg], v, i);
+                }
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk) {
+                    const int k = kb + kk;
+                    if (k >= 1 && k <= cn) {        // uniform
+                        float v = -__builtin_inff();
+                        uint32_t i = 0xffffffffu;
+#pragma unroll
+                        for (int q = 0; q < EK_ROUND_FPT; ++q) {
+                            if (f0 + q < r.n) {
+                                if (dv[kk][q] < run[q])     // kcenters.py:304
+                                    run[q] = dv[kk][q];
+                                if (ek_better(run[q], (uint32_t)(f0 + q), v, i)) {
+                                    v = run[q];
+                                    i = (uint32_t)(f0 + q);
+                                }
+                            }
+                        }
+                        // (the rows of 16 lanes first: 64 frames each -- of the state the
+                        // whole chain would leave, the finer maxima are kept for the
+                        // candidate pick, "hidden frames" in ek_top_dev.h)
+                        ek_row_argmax(v, i);
+                        if (k == cn && r.fm && (tid & 15) == 0 && wg < nb)
+                            ek_coh_store_bm(&r.fm[4 * (size_t)wg + ((tid >> 4) & 3)], v, i);
+                        ek_rows_to_wave_argmax(v, i);
+                        // (read by the last workgroup of this launch: coherent store)
+                        if ((tid & (EK_WAVE - 1)) == 0 && wg < nb)
+                            ek_coh_store_bm(&r.pm[(size_t)(k - 1) * nb + wg], v, i);
+                    }
                 }
             }
         }
@@ -202,6 +218,7 @@ ek_round_chain_kernel(EkRound r, int bootstrap)
             r.pend->n = na;
             r.pend->label0 = label0;
             s_napply = na;
+            s_fine = (r.fm && na > 0 && na == cn) ? 1 : 0;
             r.tick[1] = 0;
         }
         __syncthreads();
@@ -211,15 +228,20 @@ ek_round_chain_kernel(EkRound r, int bootstrap)
         if (tid == 0) {
             r.pend->n = 0;
             s_napply = 0;
+            s_fine = 0;
         }
         __syncthreads();
     }
     // ---- the farthest block maxima of the state the accepted prefix leaves -------
     const int na = s_napply;
-    const EkBlockMax *state = na == 0 ? r.blockmax : r.pm + (size_t)(na - 1) * nb;
+    // (the whole chain accepted -- most rounds --: the maxima per 64 frames of that
+    // state; else the maxima per 256 of the state the accepted prefix leaves)
+    const bool fine = s_fine != 0;
+    const EkBlockMax *state = fine ? r.fm
+                                   : (na == 0 ? r.blockmax : r.pm + (size_t)(na - 1) * nb);
     EkTop *top = (EkTop *)r.top;
     EK_STAMP(4);
-    ek_pick_top_body<true>(state, nb, top, skip, r.assign);
+    ek_pick_top_body<true>(state, fine ? 4 * nb : nb, top, skip, r.assign);
 #ifdef EK_ROUND_STAMPS
     __syncthreads();
     EK_STAMP(5);
@@ -247,12 +269,16 @@ void ek_launch_round_chain(const EkRound &r, int bootstrap, hipStream_t s)
 {
     if (r.n <= 0)
         return;
-    const int64_t per = (int64_t)EK_ROUND_THREADS * EK_ROUND_FPT;
+    const int64_t per = (int64_t)EK_ROUND_THREADS * 4;
     const unsigned blocks = bootstrap ? 1u : (unsigned)((r.n + per - 1) / per);
     const int nb = (int)((r.n + EK_BLOCK - 1) / EK_BLOCK);
     const size_t lds = (size_t)((nb + 31) / 32 + 1) * sizeof(uint32_t);
-    hipLaunchKernelGGL(ek_round_chain_kernel, dim3(blocks), dim3(EK_ROUND_THREADS),
-                       lds, s, r, bootstrap);
+    if (r.T > 16)
+        hipLaunchKernelGGL(ek_round_chain_kernel<32>, dim3(blocks), dim3(EK_ROUND_THREADS),
+                           lds, s, r, bootstrap);
+    else
+        hipLaunchKernelGGL(ek_round_chain_kernel<16>, dim3(blocks), dim3(EK_ROUND_THREADS),
+                           lds, s, r, bootstrap);
 }
 
 // ---------------------------------------------------------------------------
@@ -420,12 +446,12 @@ ek_round_next_kernel(EkRound r, int bootstrap)
     // (ek_ctile_index), zeros for unused slots and the atoms of padding.
     // All of a trip's loads (T candidates x 4 rows per thread) go out before
     // the first store: the stores may alias them as far as the compiler knows.
-    // (T = 16: the coordinates are ek_round_ctile16_kernel's, a launch of its own
+    // (T >= 16: the coordinates are ek_round_ctile16_kernel's, a launch of its own
     // -- written by this one workgroup they were 20 of the kernel's 39 us)
     const int A3 = 3 * r.A;
-    if (T == 16 && tid == 0)
+    if (T >= 16 && tid == 0)
         r.plan->n_rec = ns;
-    for (int k0 = 0; T != 16 && k0 * EK_BLOCK < A3; k0 += 4) {
+    for (int k0 = 0; T < 16 && k0 * EK_BLOCK < A3; k0 += 4) {
         float v[T][4];
 #pragma unroll
         for (int c = 0; c < T; ++c) {
@@ -451,7 +477,7 @@ ek_round_next_kernel(EkRound r, int bootstrap)
             }
         }
     }
-    if (go && T != 16)                          // the atoms of padding
+    if (go && T < 16)                           // the atoms of padding
         for (int k = tid; k < (ek_ctile_atoms(r.A) - r.A) * 3 * T; k += EK_BLOCK)
             r.ctile[ek_ctile_index(T, r.A + k / (3 * T), (k % (3 * T)) / 3, k % 3)] =
                 0.f;
@@ -480,31 +506,34 @@ ek_round_next_kernel(EkRound r, int bootstrap)
     }
 }
 
-// The chosen frames' coordinates of a round of 16: into the round's records and,
-// in 16-byte pieces, into the candidate tile of the next pass (ek_ctile_index:
-// one piece = the four trips of (16 atoms, axis, lane)).  Some thirty workgroups
-// side by side instead of the planning kernel's last one alone.
+// The chosen frames' coordinates of a round of 16 or 32: into the round's records
+// and, in 16-byte pieces, into the candidate tile(s) of the next pass
+// (ek_ctile_index: one piece = the four trips of (16 atoms, axis, lane); candidates
+// 16 .. 31 in a second tile).  Some thirty workgroups (sixty) side by side instead
+// of the planning kernel's last one alone.  Grid: [tile blocks of the first
+// tile | of the second | one workgroup per record].
 __global__ void __launch_bounds__(EK_BLOCK)
-ek_round_ctile16_kernel(EkRound r)
+ek_round_ctile16_kernel(EkRound r, int halves)
 {
     typedef float v4 __attribute__((ext_vector_type(4)));
-    __shared__ uint32_t sfr[16];
+    __shared__ uint32_t sfr[EK_MAX_CANDS];
     const EkPlan *plan = r.plan;
     const int tid = threadIdx.x;
     const int ns = plan->n_rec, go = plan->go;
     if (ns <= 0)
         return;
-    if (tid < 16)
+    if (tid < EK_MAX_CANDS)
         sfr[tid] = tid < ns ? (uint32_t)(plan->gidx[tid] - r.goff) : 0u;
     __syncthreads();
     const int A = r.A, A3 = 3 * A;
     const int n_ct = ek_ctile_atoms(A) / 16 * 3;        // (16 atoms, axis) blocks of 1 KB
     const int ct_wgs = (n_ct + 3) / 4;
-    if ((int)blockIdx.x < ct_wgs) {
-        const int blk = blockIdx.x * 4 + (tid >> 6), lane = tid & 63;
-        if (!go || blk >= n_ct)
+    if ((int)blockIdx.x < halves * ct_wgs) {
+        const int half = blockIdx.x / ct_wgs;
+        const int blk = (blockIdx.x % ct_wgs) * 4 + (tid >> 6), lane = tid & 63;
+        if (!go || blk >= n_ct || 16 * half >= ns)
             return;
-        const int S = blk / 3, k = blk % 3, kk = lane >> 4, c = lane & 15;
+        const int S = blk / 3, k = blk % 3, kk = lane >> 4, c = 16 * half + (lane & 15);
         const float *src = r.aos + (size_t)sfr[c] * A3 + k;
         v4 v;
 #pragma unroll
@@ -512,9 +541,10 @@ ek_round_ctile16_kernel(EkRound r)
             const int a = 16 * S + 4 * q + kk;
             v[q] = (a < A && c < ns) ? src[3 * a] : 0.f;
         }
-        *(v4 *)(r.ctile + ek_ctile_index(16, 16 * S + kk, c, k)) = v;
+        *(v4 *)(r.ctile + half * ek_ctile_half_floats(A) +
+                ek_ctile_index(16, 16 * S + kk, c, k)) = v;
     } else {
-        const int c = blockIdx.x - ct_wgs;              // one record per workgroup
+        const int c = blockIdx.x - halves * ct_wgs;     // one record per workgroup
         if (c >= ns)
             return;
         const float *src = r.aos + (size_t)sfr[c] * A3;
@@ -529,11 +559,18 @@ void ek_launch_round_next(const EkRound &r, int bootstrap, hipStream_t s)
     if (r.n <= 0)
         return;
     const unsigned blocks = (unsigned)(EK_TOP_M * EK_TOP_M / (EK_BLOCK / EK_WAVE));
-    if (r.T == 16) {
-        hipLaunchKernelGGL((ek_round_next_kernel<16>), dim3(blocks), dim3(EK_BLOCK), 0,
-                           s, r, bootstrap);
-        const unsigned wgs = (unsigned)((ek_ctile_atoms(r.A) / 16 * 3 + 3) / 4 + 16);
-        hipLaunchKernelGGL(ek_round_ctile16_kernel, dim3(wgs), dim3(EK_BLOCK), 0, s, r);
+    if (r.T >= 16) {
+        const int halves = r.T / 16;
+        if (r.T == 32)
+            hipLaunchKernelGGL((ek_round_next_kernel<32>), dim3(blocks), dim3(EK_BLOCK), 0,
+                               s, r, bootstrap);
+        else
+            hipLaunchKernelGGL((ek_round_next_kernel<16>), dim3(blocks), dim3(EK_BLOCK), 0,
+                               s, r, bootstrap);
+        const unsigned wgs =
+            (unsigned)(halves * ((ek_ctile_atoms(r.A) / 16 * 3 + 3) / 4) + r.T);
+        hipLaunchKernelGGL(ek_round_ctile16_kernel, dim3(wgs), dim3(EK_BLOCK), 0, s, r,
+                           halves);
     } else if (r.T == 8)
         hipLaunchKernelGGL((ek_round_next_kernel<8>), dim3(blocks), dim3(EK_BLOCK), 0,
                            s, r, bootstrap);

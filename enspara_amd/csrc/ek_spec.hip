@@ -619,8 +619,8 @@ ek_pass2_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
         }
         if (!last)
             return;
-        for (int e = tid; e < EK_MAX_CANDS * (EK_MAX_CANDS + 2); e += EK_BLOCK) {
-            const int j = e / (EK_MAX_CANDS + 2), u = e % (EK_MAX_CANDS + 2);
+        for (int e = tid; e < T * (T + 2); e += EK_BLOCK) {
+            const int j = e / (T + 2), u = e % (T + 2);
             const bool live = j >= 1 && j < teff;
             if (u == 0)
                 rows[j].cur = live ? ek_coh_load(&fz.rows[j].cur) : 0.f;
@@ -681,9 +681,9 @@ void ek_launch_round_pass(const EkRound &r, hipStream_t s, bool with_order)
     fz.ctl = r.ctl;
     fz.rows = r.rows;
     fz.vmask = r.vmask;
-    if (r.T == 16) {
+    if (r.T >= 16) {        // (32: the stream twice, ek_pass16.hip)
         ek_launch_pass16(true, r.qtiles, r.G, r.dist, r.assign, r.vecs, r.n, r.n_pad,
-                         r.A, r.ctile, r.ctrace, r.plan, r.blockmax, fz, s);
+                         r.A, r.ctile, r.ctrace, r.plan, r.blockmax, fz, s, r.T == 32);
         return;
     }
     EK_BY_T(r.T, hipLaunchKernelGGL((ek_pass2_kernel<T_, true, true>), dim3(blocks),

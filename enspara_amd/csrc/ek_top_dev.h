@@ -138,21 +138,19 @@ __device__ __forceinline__ void ek_pick_top_body(const EkBlockMax *blockmax, int
                                                  EkTop *top, uint32_t *skip,
                                                  const int32_t *assign = nullptr)
 {
+    // (`skip` is not used any more: round 5 keeps a thread's PICK_PER largest
+    // entries whatever the number of entries, where a list of more than 8192 used
+    // to fall back to 64 sequential looks)
     EK_PSTAMP(0);
     __shared__ uint32_t top_i[EK_TOP_M];
     __shared__ float top_v[EK_TOP_M];
     __shared__ int n_top;
     const int tid = threadIdx.x;
     constexpr int PICK_PER = 8;
-    const bool cached = nb <= PICK_PER * EK_RED_THREADS;
-    if (!cached)
-        for (int w = tid; w < (nb + 31) / 32; w += EK_RED_THREADS)
-            skip[w] = 0;
     if (tid == 0)
         n_top = 0;
     __syncthreads();
-    const int max_looks = EK_TOP_M;
-    if (cached) {
+    {
         static_assert(EK_RED_THREADS % EK_PICK_POOL == 0 &&
                           EK_PICK_BUCKETS == EK_RED_THREADS &&
                           PICK_PER * EK_RED_THREADS <= (1 << 13),
@@ -164,10 +162,15 @@ __device__ __forceinline__ void ek_pick_top_body(const EkBlockMax *blockmax, int
         __shared__ float sel_v[EK_PICK_POOL];
         __shared__ uint32_t sel_i[EK_PICK_POOL];
         __shared__ int sel_rank[EK_PICK_POOL];
-        // The per-workgroup maxima are read once, up to PICK_PER per thread, and
-        // with them the labels of those frames
+        // The maxima are read once, PICK_PER per thread, and with them the labels
+        // of those frames.  A list longer than PICK_PER x 1024 entries (maxima per
+        // 64 frames of a million-frame shard: 15 625): a thread keeps the PICK_PER
+        // LARGEST of its strided share -- the pool below holds ~128 entries of the
+        // whole list, and more than eight of them in one thread's share of sixteen
+        // do not happen; if they did it would cost a guess, never a result.
         // entries per thread actually in use (uniform: the loops skip the rest)
-        const int per = (nb + EK_RED_THREADS - 1) / EK_RED_THREADS;
+        const int per = nb >= PICK_PER * EK_RED_THREADS
+                            ? PICK_PER : (nb + EK_RED_THREADS - 1) / EK_RED_THREADS;
         float cv[PICK_PER];
         uint32_t ci[PICK_PER];
         int32_t lab[PICK_PER];
@@ -180,6 +183,41 @@ __device__ __forceinline__ void ek_pick_top_body(const EkBlockMax *blockmax, int
                 const EkBlockMax m = ek_ld_bm<COH>(&blockmax[bb]);
                 cv[k] = m.val;
                 ci[k] = m.idx;
+            }
+        }
+        for (int b0 = tid + PICK_PER * EK_RED_THREADS; b0 < nb;
+             b0 += PICK_PER * EK_RED_THREADS) {
+            EkBlockMax m[PICK_PER];     // (a batch of loads in flight)
+#pragma unroll
+            for (int u = 0; u < PICK_PER; ++u) {
+                const int bb = b0 + u * EK_RED_THREADS;
+                m[u] = ek_ld_bm<COH>(&blockmax[bb < nb ? bb : nb - 1]);
+                if (bb >= nb)
+                    m[u].idx = 0xffffffffu;
+            }
+#pragma unroll
+            for (int u = 0; u < PICK_PER; ++u) {
+                if (m[u].idx == 0xffffffffu)
+                    continue;
+                // the slot holding the smallest value (an empty one first)
+                int lo = 0;
+                float lv = ci[0] == 0xffffffffu ? -__builtin_inff() : cv[0];
+#pragma unroll
+                for (int k = 1; k < PICK_PER; ++k) {
+                    const float kv = ci[k] == 0xffffffffu ? -__builtin_inff() : cv[k];
+                    if (kv < lv) {
+                        lv = kv;
+                        lo = k;
+                    }
+                }
+                if (m[u].val > lv) {
+#pragma unroll
+                    for (int k = 0; k < PICK_PER; ++k)
+                        if (k == lo) {
+                            cv[k] = m[u].val;
+                            ci[k] = m[u].idx;
+                        }
+                }
             }
         }
 #pragma unroll
@@ -347,22 +385,6 @@ __device__ __forceinline__ void ek_pick_top_body(const EkBlockMax *blockmax, int
             n_top = L < EK_TOP_M ? L : EK_TOP_M;
         __syncthreads();
         EK_PSTAMP(3);
-    } else {
-        for (int look = 0; look < max_looks; ++look) {
-            float v;
-            uint32_t i;
-            int b;
-            ek_block_argmax<COH>(blockmax, nb, skip, v, i, b);
-            if (b < 0)
-                break;
-            if (tid == 0) {
-                skip[b >> 5] |= 1u << (b & 31);
-                top_i[n_top] = i;
-                top_v[n_top] = v;
-                n_top = n_top + 1;
-            }
-            __syncthreads();
-        }
     }
     __syncthreads();
     if (tid < EK_TOP_M) {

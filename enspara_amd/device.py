@@ -348,6 +348,11 @@ class FrameStore:
     def candidates(self):
         return int(self.lib.ek_spec_candidates(self._h))
 
+    @property
+    def round_candidates(self):
+        """the widest round kcenters_run / ms_run may use (32 by default)"""
+        return int(self.lib.ek_round_candidates(self._h))
+
     def spec_begin(self, first_label, limit, recs_out_ptr):
         _lib.check(self.lib.ek_spec_begin(self._h, int(first_label), int(limit),
                                           C.c_void_p(int(recs_out_ptr))))
@@ -491,12 +496,13 @@ class FrameStore:
         return idx[:k].copy(), cd[:k].copy(), fmax.value
 
     def run_stats(self):
-        """How the last kcenters_run spent its passes over the frames:
-        -> {candidates per pass: (passes, centers accepted)}"""
-        p = np.zeros(4, dtype=np.int64)
-        k = np.zeros(4, dtype=np.int64)
+        """How the last kcenters_run / ms_run spent its rounds:
+        -> {candidates per round: (rounds, centers accepted)} (a round of 32
+        streams the frames twice, every other form once)"""
+        p = np.zeros(5, dtype=np.int64)
+        k = np.zeros(5, dtype=np.int64)
         _lib.check(self.lib.ek_run_stats(self._h, _lib.i64p(p), _lib.i64p(k)))
-        return {T: (int(p[i]), int(k[i])) for i, T in enumerate((1, 4, 8, 16))}
+        return {T: (int(p[i]), int(k[i])) for i, T in enumerate((1, 4, 8, 16, 32))}
 
     def ti_stats(self):
         """Triangle inequality (set_option(11, 1)): (center, tile) pairs the last

@@ -68,6 +68,15 @@ class DeviceShard:
         """-> (distances float32 [n_local], labels int32 [n_local]) on the host"""
         return self.store.download_state()
 
+    def set_state(self, distances, assignments):
+        """the caller's per-frame state (a warm start, kmedoids.py:133-146)"""
+        self.store.upload_state(distances, assignments)
+
+    def set_exact(self, on):
+        """every frame's distance IS the one to the medoid its label names
+        (option key 7: lets the PAM search use the triangle inequality)"""
+        self.store.set_option(7, 1 if on else 0)
+
     def progress(self):
         """-> number of centers so far; synchronises"""
         _, _, n_done = self.store.history(0, 0)
@@ -751,8 +760,225 @@ def khybrid_sharded(shard, n_clusters, dist_cutoff=0.0, n_iters=5,
 
 
 # ---------------------------------------------------------------------------
+# k-medoids across shards with a warm start (reference kmedoids.py, MPI mode)
+# ---------------------------------------------------------------------------
+def ctr_ids_mpi(cluster_center_inds, lengths, world):
+    """The reference's ``ctr_ids_mpi`` (kmedoids.py:365-407): cluster centers
+    given with respect to ALL data -- flat frame indices into the
+    concatenation of all trajectories, or (global trajectory, frame) pairs --
+    -> (rank, index into that rank's concatenated frames) pairs, for the
+    reference's distribution of trajectories over ranks: trajectory t lives on
+    rank ``t % world`` (mpi/io.py:126, load_trajectory_as_striped), a rank's
+    frames are its trajectories t = rank, rank + world, .. one after the
+    other.  A pure function of ``world`` (the reference reads mpi.size())."""
+    lengths = [int(v) for v in lengths]
+    starts = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
+    if len(cluster_center_inds) == 0:
+        return []
+    pairs = cluster_center_inds
+    if not hasattr(cluster_center_inds[0], "__len__"):
+        # [global frame index, ...] -> [[global trajectory, frame], ...]
+        pairs = []
+        for c in cluster_center_inds:
+            c = int(c)
+            if c < 0 or c >= starts[-1]:
+                raise IndexError("cluster center index %d outside the %d frames "
+                                 "X_lengths describes" % (c, int(starts[-1])))
+            t = int(np.searchsorted(starts, c, side="right") - 1)
+            pairs.append((t, c - int(starts[t])))
+    out = []
+    for t, f in pairs:
+        t, f = int(t), int(f)
+        if t < 0 or t >= len(lengths) or f < 0 or f >= lengths[t]:
+            raise IndexError("cluster center (%d, %d) outside X_lengths" % (t, f))
+        r = t % world
+        owned = lengths[r::world]
+        out.append((r, int(sum(owned[:t // world])) + f))
+    return out
+
+
+def _gather_rows_f32(shard, K, width, rows, values, group, collective):
+    """A float32 table [K, width] of which this rank knows ``rows`` (their
+    ``values``): every row is filled by exactly one rank, the integer sum of
+    the bit patterns over ranks reproduces it everywhere (cf. _share_rows)."""
+    import torch
+    import torch.distributed as dist
+    like = shard.new_buffer(4)
+    tab = torch.zeros((max(K, 1), width), dtype=torch.float32, device=like.device)
+    if len(rows):
+        src = torch.from_numpy(np.ascontiguousarray(values, dtype=np.float32)
+                               .reshape(len(rows), width))
+        tab[torch.as_tensor(list(rows), device=like.device)] = src.to(like.device)
+    if collective:
+        dist.all_reduce(tab.view(torch.int32), op=dist.ReduceOp.SUM, group=group)
+    return np.array(_to_host(shard, tab))[:K]
+
+
+def kmedoids_sharded(shard, xyz_local, n_iters=5, assignments=None,
+                     distances=None, cluster_center_inds=None, X_lengths=None,
+                     proposals=None, random_state=None, n_clusters=None,
+                     group=None):
+    """k-medoids over all ranks' shards, the reference's MPI mode
+    (kmedoids.py:133-146 dispatch, :225-283 ``_kmedoids_inputs_tree_mpi``,
+    :365-407 ``ctr_ids_mpi``, sweeps :410-476 / :575-699).
+
+    Warm start (what the reference supports there): every rank passes the
+    ``assignments`` / ``distances`` of ITS frames and the same
+    ``cluster_center_inds`` with respect to all data -- flat indices or
+    (trajectory, frame) pairs -- with ``X_lengths`` = the lengths of ALL
+    trajectories; the ranks hold the trajectories striped (t % world).
+    Supplying only some of the three raises the reference's
+    ImproperlyConfigured.  Cold start (none of the three; the reference's own
+    branch, :247-262, cannot run -- ``np.arange(X)``, ``.append`` on None):
+    ``n_clusters`` distinct frames drawn over ALL frames from
+    ``np.random.default_rng(random_state)`` like the single-process path
+    (kmedoids.py:345-352), the same on every rank (rank 0's seed when
+    ``random_state`` is None), then every frame to its nearest.
+
+    ``proposals``: (rank, local index) pairs, one per cluster (:581-623).
+    Returns (medoids as (rank, local index) pairs, centers float32 [K, A, 3]);
+    labels and distances stay on the shard.  Collective: every rank calls it."""
+    import torch.distributed as dist
+    from .cluster.kcenters import check_random_state
+    from .exception import DataInvalid, ImproperlyConfigured
+    world, rank = _world(group)
+    collective = dist.is_available() and dist.is_initialized()
+    lay = _gather_i64(shard, [shard.offset, shard.n_local], group, world, collective)
+    offs = [int(v) for v in lay[:, 0]]
+    counts = [int(v) for v in lay[:, 1]]
+    n_total = int(sum(counts))
+    A = shard.n_atoms
+    xyz_local = np.asarray(xyz_local, dtype=np.float32).reshape(-1, A, 3)
+    given = [assignments is not None, distances is not None,
+             cluster_center_inds is not None]
+    if all(given):
+        if X_lengths is None:
+            raise ImproperlyConfigured(
+                "If cluster_center_inds is given with respect to all data then "
+                "X_lengths (the lengths of ALL trajectories) also needs to be "
+                "supplied")
+        if sum(int(v) for v in X_lengths[rank::world]) != counts[rank]:
+            raise DataInvalid(
+                "rank %d holds %d frames, but the trajectories X_lengths gives it "
+                "(t %% %d == %d) have %d" % (rank, counts[rank], world, rank,
+                                            sum(int(v) for v in X_lengths[rank::world])))
+        pairs = ctr_ids_mpi(cluster_center_inds, X_lengths, world)
+        med = [offs[r] + i for r, i in pairs]
+        shard.set_state(np.asarray(distances), np.asarray(assignments))
+        mine = [i for r, i in pairs if r == rank]
+        # the medoids must sit at (numerically) zero distance (kmedoids.py:185-187)
+        assert np.all(np.asarray(distances)[mine] < 0.001)
+    elif not any(given):
+        if n_clusters is None:
+            raise ImproperlyConfigured(
+                "Must provide n_clusters or cluster_center_inds, assignments,"
+                "and distances for KMedoids in MPI mode.")
+        seed = random_state
+        if seed is None or not isinstance(seed, (int, np.integer)):
+            draw = np.random.SeedSequence().entropy % (2 ** 62) if seed is None \
+                else int(check_random_state(seed).randint(0, 2 ** 31 - 1))
+            seed = int(_gather_i64(shard, [draw], group, world, collective)[0, 0])
+        rng = np.random.default_rng(seed=int(seed))
+        med = np.array([])
+        while len(np.unique(med)) < int(n_clusters):
+            med = rng.integers(0, n_total, int(n_clusters))
+        # (global index in the ranks' order: rank r's frames after rank r-1's)
+        bounds = np.cumsum([0] + counts)
+        med = [offs[int(np.searchsorted(bounds, g, side="right") - 1)] +
+               int(g - bounds[int(np.searchsorted(bounds, g, side="right") - 1)])
+               for g in med]
+        rows = [k for k, g in enumerate(med)
+                if offs[rank] <= g < offs[rank] + counts[rank]]
+        ctr = _gather_rows_f32(shard, len(med), 3 * A, rows,
+                               xyz_local[[med[k] - offs[rank] for k in rows]],
+                               group, collective)
+        shard.assign_nearest(ctr.reshape(len(med), A, 3))
+        if hasattr(shard, "set_exact"):
+            shard.set_exact(True)
+    else:
+        raise ImproperlyConfigured(
+            "For KMedoids, MPI mode can start from scratch without "
+            "assignments, distances, or cluster_center_inds. "
+            "Or, it requires that all are supplied.")
+    prop = None
+    if proposals is not None:
+        if len(proposals) != len(med):
+            raise DataInvalid(
+                "Length of 'proposals' didn't match length of 'medoid_inds' "
+                "({} != {}).".format(len(proposals), len(med)))
+        if not hasattr(proposals[0], "__len__"):
+            raise DataInvalid(
+                "Depth of 'proposals' didn't match 'medoid_inds' "
+                "(proposals[0] == {}, whereas medoid_inds[0] == {})".format(
+                    proposals[0], (0, 0)))
+        prop = [offs[int(r)] + int(i) for r, i in proposals]
+    rs = check_random_state(random_state)
+    for _ in range(int(n_iters)):
+        med = pam_sweep_sharded(shard, med, proposals=prop, random_state=rs,
+                                group=group)
+    pairs = []
+    for g in med:
+        r = max(q for q in range(world) if offs[q] <= g and counts[q] > 0
+                and g < offs[q] + counts[q])
+        pairs.append((r, int(g - offs[r])))
+    rows = [k for k, (r, _) in enumerate(pairs) if r == rank]
+    ctr = _gather_rows_f32(shard, len(med), 3 * A, rows,
+                           xyz_local[[pairs[k][1] for k in rows]], group, collective)
+    return pairs, ctr.reshape(len(med), A, 3)
+
+
+# ---------------------------------------------------------------------------
 # estimator-level entry: the reference's mpi_mode
 # ---------------------------------------------------------------------------
+def kmedoids_fit_sharded(traj, n_clusters=None, n_iters=5, assignments=None,
+                         distances=None, cluster_center_inds=None,
+                         X_lengths=None, proposals=None, random_state=None,
+                         group=None):
+    """``kmedoids()`` / ``KMedoids.fit`` when the process group has more than one
+    rank (the reference decides by ``mpi.size() > 1``, kmedoids.py:172): every
+    rank passes ITS OWN frames (the trajectories t % world == rank, one after
+    the other), see ``kmedoids_sharded``.  One process per GPU; the current CUDA
+    device holds the shard.  Returns a ClusterResult like the reference's MPI
+    mode: ``center_indices`` as (rank, local frame index) pairs, this rank's
+    ``assignments`` / ``distances``, the medoids' coordinates on every rank."""
+    import torch
+    import torch.distributed as dist
+    from .cluster import util
+    from .device import FrameStore, as_xyz
+    from .exception import ImproperlyConfigured
+    if not (dist.is_available() and dist.is_initialized()):
+        raise ImproperlyConfigured(
+            "mpi_mode needs an initialised torch.distributed process group "
+            "(one process per GPU, e.g. under torchrun)")
+    xyz = as_xyz(traj)
+    n_local, A = int(xyz.shape[0]), int(xyz.shape[1])
+    world, rank = _world(group)
+    device = torch.cuda.current_device()
+    tstream = torch.cuda.Stream(device=device)
+    with torch.cuda.stream(tstream):
+        mine = torch.tensor([n_local], dtype=torch.int64, device="cuda")
+        everyone = torch.empty(world, dtype=torch.int64, device="cuda")
+        dist.all_gather_into_tensor(everyone, mine, group=group)
+        counts = [int(c) for c in everyone.cpu().numpy()]
+    starts = np.concatenate([[0], np.cumsum(counts)])
+    with FrameStore(n_local, A, device=device, global_offset=int(starts[rank]),
+                    stream=tstream.cuda_stream) as store:
+        store.load(xyz)
+        store.reset_state()
+        shard = DeviceShard(store)
+        with torch.cuda.stream(tstream):
+            pairs, ctr = kmedoids_sharded(
+                shard, xyz, n_iters=n_iters, assignments=assignments,
+                distances=distances, cluster_center_inds=cluster_center_inds,
+                X_lengths=X_lengths, proposals=proposals,
+                random_state=random_state, n_clusters=n_clusters, group=group)
+        d, a = store.download_state()
+    return util.ClusterResult(
+        center_indices=pairs, assignments=a.astype(np.int64),
+        distances=d.astype(np.float64),
+        centers=[ctr[k].copy() for k in range(len(pairs))])
+
+
 def fit_sharded(traj, n_clusters=None, dist_cutoff=0.0, n_iters=0,
                 random_state=None, group=None, use_triangle_inequality=False,
                 init_centers=None):

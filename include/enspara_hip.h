@@ -154,6 +154,9 @@ int ek_kcenters_run(ek_ctx *ctx, int32_t first_label, int32_t max_new,
  * synchronises and reports how many centers exist and whether the stop rule
  * (maximum distance <= dist_cutoff, kcenters.py:217) fired. */
 int ek_spec_candidates(ek_ctx *ctx);
+/* the widest round ek_kcenters_run / ek_ms_run may use (option key 4; 32 by
+ * default): ek_spec_candidates is the same for the ek_spec_* protocol (<= 16) */
+int ek_round_candidates(ek_ctx *ctx);
 int ek_spec_begin(ek_ctx *ctx, int32_t first_label, int32_t limit,
                   void *recs_out);
 int ek_spec_round(ek_ctx *ctx, const void *recs_all, int32_t n_recs,
@@ -218,9 +221,12 @@ int ek_spec_chain_apply(ek_ctx *ctx, const void *hdrs_all, int32_t n_shards,
  * on every shard at the same time.  A message that does not arrive within 10 s
  * (of the device's constant 100 MHz clock) is reported as an error (a peer
  * died), not waited for.  With the default option key 4 = -1 the run moves
- * between rounds of 8 and of 16 candidates by the centers the rounds of a batch
+ * between rounds of 8, 16 and 32 candidates by the centers the rounds of a batch
  * accepted -- numbers every shard sees alike, so every shard takes the same
- * decision at the same round; ek_run_stats reports the mix. */
+ * decision at the same round; ek_run_stats reports the mix.  A round of 32 is
+ * two passes of 16 over the frames behind ONE plan, chain and exchange (the
+ * message carries EK_MAX_CANDS = 32 per-prefix headers).  ek_ms_begin's loop
+ * (exchange by the caller) runs one form: 16 unless key 4 names another. */
 int ek_ms_setup(ek_ctx *ctx, int32_t world, int32_t rank, size_t *message_bytes);
 int ek_ms_mailbox(ek_ctx *ctx, void **mbox, void **flags, void *ipc_mbox,
                   void *ipc_flags);
@@ -238,9 +244,11 @@ int ek_ms_run(ek_ctx *ctx, int32_t first_label, int32_t max_new,
 /* rounds (passes over the frames) that really ran since ek_spec_begin /
  * ek_kcenters_run started */
 int ek_spec_rounds(ek_ctx *ctx, int32_t *rounds);
-/* How the last ek_kcenters_run spent its passes over the frames:
- * passes[i] / centers[i] = passes run with 1, 4, 8, 16 candidate centers
- * (i = 0 .. 3) and the centers those passes accepted.  The loop of
+/* How the last ek_kcenters_run / ek_ms_run spent its rounds:
+ * passes[i] / centers[i] = rounds run with 1, 4, 8, 16, 32 candidate centers
+ * (i = 0 .. 4: both arrays hold FIVE entries since round 5) and the centers
+ * those rounds accepted.  A round of 32 streams the frames twice (two passes of
+ * 16 behind one plan, one chain and one exchange); every other form once.  The loop of
  * kcenters.py:217-231 has no such notion (one metric call per center); the
  * forms give identical centers, labels and distances, and the run moves
  * between them by the centers per millisecond each achieves. */
@@ -554,8 +562,10 @@ void ek_feat_pam_release(ek_feat *k);
 int ek_set_frames_per_lane(ek_ctx *ctx, int fpl);
 /* key 1: non-temporal loads of the frame stream (0/1; -1 = automatic:
  * on when the shard is larger than the Infinity Cache)
- * key 4: candidate centers per pass of ek_kcenters_run / ek_spec_*: -1
- * automatic (up to 16, see key 8), 1 = one-center passes, 4, 8, 16
+ * key 4: candidate centers per round of ek_kcenters_run / ek_ms_* / ek_spec_*:
+ * -1 automatic (up to 32, see key 8), 1 = one-center passes, 4, 8, 16, 32 (32:
+ * the frames streamed twice per round, candidates 0..15 and 16..31; the
+ * one-launch-per-step forms -- ek_spec_*, key 5 = 0, key 10 = 0 -- stop at 16)
  * key 2: nearest-center kernel: 0 automatic, 1 vector FMA, 2 MFMA 32x32x2, 3 MFMA
  * 16x16x4 on the quad copy of the frames (identical
  * results)
@@ -568,9 +578,13 @@ int ek_set_frames_per_lane(ek_ctx *ctx, int fpl);
  * ek_state_reset + k-centers, false after ek_state_upload / ek_assign_nearest
  * key 7: assert (1) or withdraw (0) that property, e.g. after
  * ek_assign_nearest with the medoid frames themselves as centers
- * key 8: with key 4 = -1, let ek_kcenters_run move between 1, 8 and 16
- * candidates per pass by measured centers per millisecond: 1 (default) / 0
+ * key 8: with key 4 = -1, let ek_kcenters_run move between 1, 8, 16 and 32
+ * candidates per round by measured centers per millisecond: 1 (default) / 0
  * (always the widest form); identical results either way
+ * key 15: the next round's candidates are chosen among the farthest frames per
+ * 64 frames of the state the whole chain leaves (1, default) or per 256 (0: what
+ * rounds 2-4 did; a far frame behind a farther one of its 256 is then invisible
+ * and the chain breaks when its turn comes); guesses only, identical results
  * key 11: triangle inequality in ek_kcenters_run (0 default / 1): one center
  * per pass; before each, the distances of the existing centers to the new one
  * mark the tiles of 256 frames none of whose frames can move (own center at
@@ -619,6 +633,19 @@ int ek_timing_form(ek_ctx *ctx, int32_t *candidates);
  * distance kernels do); best of four each: the measured ceilings bench.py quotes
  * beside the nominal HBM peak */
 int ek_hbm_copy_rate(int device, size_t bytes, double *gbytes_per_s);
+/* Test entry: the QCP arithmetic of csrc/ek_qcp.h evaluated by a KERNEL on m
+ * inner-product matrices handed over by the caller (host arrays: S [m][9] f32,
+ * Gx / Gy [m] f64 traces, cur [m] f32 the distance each solve may stop above) --
+ * full[i] = ek_rmsd_from_S, below[i] = ek_rmsd_from_S_below(.., cur[i]),
+ * cert[i] = ek_far_certified_f32(S, (float)(Gx + Gy), n_atoms, cur[i]) -- so that
+ * the soundness tests of the early-stopped solve and of the float32 certificate
+ * run through the instructions that ship (v_rcp_f32 / v_sqrt_f32 / v_rsq_f32:
+ * 1 ulp, where the host build of the header rounds correctly).  Stands where
+ * mdtraj.rmsd's own per-pair solve would (cluster/util.py:289-291); not used by
+ * the product path. */
+int ek_qcp_probe(int device, const float *S, const double *Gx, const double *Gy,
+                 int32_t n_atoms, const float *cur, int64_t m, float *full,
+                 float *below, unsigned char *cert);
 
 #ifdef __cplusplus
 }

@@ -212,6 +212,14 @@ class HostShard(_PamMixin):
     def state(self):
         return self.dist, self.assign
 
+    def set_state(self, distances, assignments):
+        self.dist[:] = np.asarray(distances, dtype=np.float32)
+        self.assign[:] = np.asarray(assignments, dtype=np.int32)
+
+    @property
+    def n_atoms(self):
+        return self.A
+
     def history(self, first, count):
         idx = np.full(max(count, 1), -1, dtype=np.int64)
         cd = np.zeros(max(count, 1), dtype=np.float32)
@@ -426,13 +434,13 @@ class HostShardChain(HostShardRounds):
 
 
 MS_MSG = np.dtype([("n_recs", "<i4"), ("cn", "<i4"), ("pad", "<i4", (2,))])
-MAX_CANDS = 16
+MAX_CANDS = 32      # EK_MAX_CANDS: the per-prefix headers of a message
 
 
 class HostShardMs(HostShard):
     """The shard speaking the one-exchange-per-round protocol of
     csrc/ek_mshard.hip (ek_ms_setup / _begin / _local / _global / _end), with
-    the device's message layout: EkMsMsg | 16 x EkMaxHdr | `offer` records.
+    the device's message layout: EkMsMsg | 32 x EkMaxHdr | `offer` records.
     Restated on the CPU with the checker's distances so that the product's
     driver loop (enspara_amd/sharded.py, gather transport) and the protocol's
     decisions -- per-prefix global maxima, lowest global index on ties, the

@@ -179,7 +179,7 @@ def test_assign_variants_bit_identical(qcp, n, A, K):
             assert not np.isin(a, [3, 4, 5]).any()
 
 
-@pytest.mark.parametrize("cands", [1, 4, 8, 16])
+@pytest.mark.parametrize("cands", [1, 4, 8, 16, 32])
 @pytest.mark.parametrize("chain", [1, 0])
 def test_candidates_per_pass_do_not_change_results(ocl, cands, chain):
     """multi-candidate rounds are the same algorithm: identical centers,
@@ -213,19 +213,22 @@ def test_candidates_per_pass_do_not_change_results(ocl, cands, chain):
     np.testing.assert_array_equal(r.assignments, a)
 
 
+@pytest.mark.parametrize("T", [16, 32])
 @pytest.mark.parametrize("A", [1, 2, 3, 5, 7, 13, 16, 17, 31, 47, 61])
-def test_rounds_of_16_at_every_atom_count_mod_4(ocl, A):
+def test_rounds_of_16_at_every_atom_count_mod_4(ocl, A, T):
     """the 16-candidate pass takes FOUR atoms per matrix instruction
     (v_mfma_f32_16x16x4_f32) and 16 atoms per candidate load: atom counts that
     leave the last trip, and the last group of 16, partly empty -- the zeros of
     the padding must not change a bit of any sum (A = 1, 2: S has rank one,
-    nothing may be abandoned early either)"""
+    nothing may be abandoned early either).  T = 32: a round is two such
+    passes behind one plan and one chain (candidates 16 .. 31 from a second
+    candidate tile, sixteen more kept vectors)"""
     from enspara_amd.cluster import kcenters as kc
     x = synth.synth(3000, A, 60, seed=100 + A)
     inds, a, d = ocl.kcenters(x, n_clusters=90)
     with _store(x) as st:
         st.set_option(8, 0)           # no ladder: every round with ...
-        st.set_option(4, 16)          # ... 16 candidates
+        st.set_option(4, T)           # ... 16 / 32 candidates
         r = kc._kcenters_device(x, 90, 0, None, 0, store=st)
     assert list(r.center_indices) == [int(i) for i in inds]
     np.testing.assert_array_equal(r.assignments, a)

@@ -184,6 +184,10 @@ dist.destroy_process_group()
     # (hipIpc): the exchange of a round happens on the device
     (6000, 14, 45, 9, 2, 16, "ipc"),
     (40000, 500, 200, 300, 0, 16, "ipc"),
+    # rounds of 32 candidates, both transports
+    (6000, 14, 80, 9, 1, 32, "gather"),
+    (6000, 14, 80, 9, 1, 32, "ipc"),
+    (40000, 500, 200, 300, 0, 32, "ipc"),
 ])
 def test_two_device_shards_on_one_gpu(tmp_path, n, A, K, tmpl, iters, cands,
                                       transport):
@@ -213,7 +217,8 @@ def test_two_device_shards_on_one_gpu(tmp_path, n, A, K, tmpl, iters, cands,
 
 
 @pytest.mark.parametrize("world,n,A,K,tmpl,iters,cands", [
-    (8, 60000, 30, 260, 400, 1, -1),    # the ladder of 8 / 16 candidates per round
+    (8, 60000, 30, 260, 400, 1, -1),    # the ladder of 8 / 16 / 32 candidates per round
+    (8, 60000, 30, 260, 400, 0, 32),    # every round with 32
     (8, 3000, 12, 40, 9, 0, 16),        # shards of one or two tiles, some empty
     (8, 3000, 12, 60, 9, 1, -1),        # ... and the ladder's decisions with empty shards
 ])
@@ -320,7 +325,9 @@ print("ok", len(inds), stores[0].ms_state())
 @pytest.mark.parametrize("shards,n,A,K,cutoff,cands", [
     (2, 9000, 21, 70, 0.0, 16), (3, 7000, 10, 0, 0.3, 8),
     (3, 600, 5, 40, 0.0, 16),           # the third shard is empty
-    (2, 30000, 33, 300, 0.0, 16), (8, 40000, 20, 400, 0.0, 16)])
+    (2, 30000, 33, 300, 0.0, 16), (8, 40000, 20, 400, 0.0, 16),
+    (2, 9000, 21, 70, 0.0, 32), (3, 600, 5, 40, 0.0, 32),
+    (2, 30000, 33, 300, 0.0, 32), (8, 40000, 20, 400, 0.0, 32)])
 def test_mailbox_rounds_between_contexts(shards, n, A, K, cutoff, cands):
     """the rounds of csrc/ek_mshard.hip with the exchange on the device: the
     shards are contexts of ONE process on the one GPU, their mailboxes plain
@@ -520,6 +527,99 @@ def test_estimators_in_mpi_mode(tmp_path, world, backend, n, K):
             np.concatenate([p[key + "_a"] for p in parts]), want_a)
         np.testing.assert_array_equal(
             np.concatenate([p[key + "_d"] for p in parts]), want_d)
+
+
+# ---- KMedoids / kmedoids() in MPI mode: a warm start w.r.t. all data ---------------
+_CHILD4 = _CHILD3[:_CHILD3.index("from enspara_amd import sharded, synth")] + r"""
+from enspara_amd import synth
+from enspara_amd.cluster import KMedoids
+from enspara_amd.cluster.kmedoids import kmedoids
+lengths = [int(v) for v in sys.argv[7].split(",")]
+inp = np.load(sys.argv[8])
+x = synth.synth(sum(lengths), 14, 11, seed=33)
+starts = np.concatenate([[0], np.cumsum(lengths)])
+held = np.concatenate([np.arange(starts[t], starts[t + 1])
+                       for t in range(rank, len(lengths), world)]
+                      or [np.zeros(0, dtype=np.int64)]).astype(np.int64)
+lo = int(inp["los"][rank])
+mine = x[held]
+a, d = inp["a"][lo:lo + len(mine)], inp["d"][lo:lo + len(mine)]
+# the estimator decides by the group's size (the reference: mpi.size() > 1)
+km = KMedoids("rmsd", n_iters=2, mpi_mode=True if world == 1 else None)
+np.random.seed(0)
+r1 = kmedoids(mine, "rmsd", n_iters=2, assignments=a, distances=d,
+              cluster_center_inds=[int(i) for i in inp["flat"]], X_lengths=lengths,
+              random_state=np.random.RandomState(4), mpi_mode=True)
+r2 = kmedoids(mine, "rmsd", n_iters=2, assignments=a, distances=d,
+              cluster_center_inds=[tuple(int(v) for v in p) for p in inp["pairs"]],
+              X_lengths=lengths, random_state=np.random.RandomState(4),
+              mpi_mode=True if world == 1 else None)
+np.savez(out + ".%d.npz" % rank, lo=lo,
+         r1_ci=np.array(r1.center_indices), r1_a=r1.assignments, r1_d=r1.distances,
+         r1_c=np.array(r1.centers),
+         r2_ci=np.array(r2.center_indices), r2_a=r2.assignments, r2_d=r2.distances,
+         r2_c=np.array(r2.centers))
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("world,backend", [(1, "nccl"), (2, "gloo"), (3, "gloo")])
+def test_kmedoids_in_mpi_mode(tmp_path, world, backend):
+    """kmedoids() with the reference's MPI-mode warm start (kmedoids.py:133-146,
+    :264-283, :365-407): cluster centers as flat indices and as (trajectory,
+    frame) pairs w.r.t. all data, the ranks holding the trajectories striped;
+    two sweeps on the device; equal to the single-process oracle on the frames in
+    the ranks' order"""
+    import socket
+    from oracle import cluster as oc
+    lengths = [300, 120, 260, 200, 180]
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = str(s.getsockname()[1])
+    s.close()
+    x = synth.synth(sum(lengths), 14, 11, seed=33)
+    starts = np.concatenate([[0], np.cumsum(lengths)])
+    held = [np.concatenate([np.arange(starts[t], starts[t + 1])
+                            for t in range(r, len(lengths), world)]
+                           or [np.zeros(0, dtype=np.int64)]).astype(np.int64)
+            for r in range(world)]
+    perm = np.concatenate(held)
+    los = np.concatenate([[0], np.cumsum([len(h) for h in held])])[:-1]
+    xp = x[perm]
+    K = 9
+    inds, a, d = oc.kcenters(xp, n_clusters=K)
+    flat = perm[[int(i) for i in inds]]
+    traj = np.searchsorted(starts, flat, side="right") - 1
+    pairs = np.stack([traj, flat - starts[traj]], axis=1)
+    rs = np.random.RandomState(4)
+    wi, wd, wa = [int(i) for i in inds], d.copy(), a.copy()
+    for _ in range(2):
+        wi, wd, wa = oc.pam_update(xp, wi, wa, wd, random_state=rs)
+    inp = str(tmp_path / "in.npz")
+    np.savez(inp, flat=flat, pairs=pairs, a=a, d=d, los=los)
+    out = str(tmp_path / "r")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = [subprocess.Popen([sys.executable, "-c", _CHILD4, ROOT, str(r),
+                               str(world), port, out, backend,
+                               ",".join(str(v) for v in lengths), inp],
+                              env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True)
+             for r in range(world)]
+    logs = [p.communicate(timeout=900)[0] for p in procs]
+    for p, log in zip(procs, logs):
+        assert p.returncode == 0, log[-4000:]
+    parts = [np.load(out + ".%d.npz" % r) for r in range(world)]
+    for key in ("r1", "r2"):
+        for p in parts:
+            got = [int(los[int(r)]) + int(i) for r, i in p[key + "_ci"]]
+            assert got == [int(i) for i in wi]
+            np.testing.assert_array_equal(p[key + "_c"], xp[[int(i) for i in wi]])
+        np.testing.assert_array_equal(
+            np.concatenate([p[key + "_a"] for p in parts]), wa)
+        np.testing.assert_array_equal(
+            np.concatenate([p[key + "_d"] for p in parts]), wd)
 
 
 def test_bench_two_ranks_on_one_device():

@@ -19,6 +19,8 @@ import numpy as np
 import pytest
 
 from oracle import qcp
+from _qcp_cases import (FAMILIES, coincident_case, family_case,
+                        structure_pairs as _pairs_of)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(HERE), "enspara_amd", "csrc")
@@ -72,15 +74,7 @@ def host(tmp_path_factory):
 
 
 def _pairs(rng, A, m, squash):
-    """m (frame, center) pairs of A atoms; squash < 1 flattens y and z."""
-    scale = rng.uniform(0.5, 3.5, size=(m, 1, 1))
-    shape = np.array([1.0, squash, squash])
-    x = rng.normal(size=(m, A, 3)) * scale * shape
-    similar = rng.random(m) < 0.5
-    y = np.where(similar[:, None, None],
-                 x + 0.05 * rng.normal(size=(m, A, 3)) * shape,
-                 rng.normal(size=(m, A, 3)) * scale * shape)
-    return x.astype(np.float32), y.astype(np.float32)
+    return _pairs_of(rng, A, m, squash)
 
 
 def _run(host, rng, A, m, squash=1.0):
@@ -135,33 +129,14 @@ def test_nearly_collinear_structures(host, squash):
         _run(host, rng, A, 1500, squash)
 
 
-def _rotations(rng, m):
-    q = rng.normal(size=(m, 4))
-    q /= np.linalg.norm(q, axis=1, keepdims=True)
-    w, x, y, z = q.T
-    return np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
-                     2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
-                     2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)],
-                    axis=1).reshape(m, 3, 3)
-
-
 @pytest.mark.parametrize("eps", [0.0, 1e-12, 1e-9, 1e-7, 1e-5, 1e-3, 1e-1])
 def test_coincident_largest_roots(host, eps):
     """S = U diag(s1, s2, -s2 (1+eps)) V^T: the two largest roots of the quartic,
     s1+s2+s3 and s1-s2-s3, differ by 2 s2 eps.  A version of the early stop that
     trusted the iterates here returned +inf for ~1e-6 of these pairs although the
     full iteration ends below `cur`."""
-    rng = np.random.default_rng(int(eps * 1e13) + 5)
     m, A = 200000, 30
-    s1 = A * rng.uniform(0.5, 3.5, m)
-    s2 = s1 * rng.random(m)
-    s3 = -s2 * (1 + eps)
-    sig = np.stack([s1, s2, s3], axis=1)
-    S = np.einsum("mik,mk,mjk->mij", _rotations(rng, m), sig, _rotations(rng, m))
-    S = np.ascontiguousarray(S.reshape(m, 9), dtype=np.float32)
-    top = np.maximum(s1 + s2 + s3, s1 - s2 - s3)
-    Gsum = 2 * top + A * 10.0 ** rng.uniform(-6, 0.5, m)
-    Gx = np.ascontiguousarray(Gsum / 2)
+    S, Gx = coincident_case(eps, m, A)
     Gy = Gx.copy()
     full = np.empty(m, dtype=np.float32)
     below = np.empty(m, dtype=np.float32)
@@ -188,9 +163,7 @@ def test_coincident_largest_roots(host, eps):
         assert stops > m           # separated again: most far solves stop early
 
 
-@pytest.mark.parametrize("family", ["generic", "s1~s2", "s2~-s3", "s2~s3", "rank1",
-                                    "rank2", "isotropic", "small", "large", "tiny",
-                                    "huge"])
+@pytest.mark.parametrize("family", FAMILIES)
 def test_float32_far_certificate_is_sound(host, family):
     """ek_far_certified_f32: S = U diag(s1, s2, s3) V^T with the spectrum drawn
     from the family named -- generic, and every way two roots of the quartic
@@ -200,41 +173,8 @@ def test_float32_far_certificate_is_sound(host, family):
     float64 SVD); on generic spectra -- also scaled by 1e-5 and 1e4, inside the
     range of q it accepts -- it certifies most pairs that are far by a margin;
     scaled by 1e-15 or 1e9 (raw cofactors outside the float32 range) nothing."""
-    rng = np.random.default_rng(abs(hash(family)) % 10**6)
     m, A = 300000, 30
-    s1 = A * 10.0 ** rng.uniform(-1, 1, m)
-    u, v = rng.random(m), rng.random(m)
-    tiny = 10.0 ** rng.uniform(-9, -1, m)
-    sign = np.where(rng.random(m) < 0.5, -1.0, 1.0)
-    if family == "generic":
-        s2, s3 = s1 * u, s1 * u * v * sign
-    elif family == "s1~s2":
-        s2, s3 = s1 * (1 - tiny), s1 * u * sign
-    elif family == "s2~-s3":
-        s2 = s1 * u
-        s3 = -s2 * (1 - tiny)
-    elif family == "s2~s3":
-        s2 = s1 * u
-        s3 = s2 * (1 - tiny)
-    elif family == "rank1":
-        s2, s3 = s1 * tiny, s1 * tiny * v * sign
-    elif family == "rank2":
-        s2, s3 = s1 * u, s1 * tiny * u * sign
-    elif family == "isotropic":
-        s2, s3 = s1 * (1 - tiny), s1 * (1 - tiny * (1 + v)) * sign
-    else:
-        s1 = s1 * {"small": 1e-5, "large": 1e4, "tiny": 1e-15, "huge": 1e9}[family]
-        s2, s3 = s1 * u, s1 * u * v * sign
-    sig = np.stack([s1, s2, s3], axis=1)
-    S = np.einsum("mik,mk,mjk->mij", _rotations(rng, m), sig, _rotations(rng, m))
-    S = np.ascontiguousarray(S.reshape(m, 9), dtype=np.float32)
-    # the spectrum of the float32 matrix the kernels would hold
-    M = S.astype(np.float64).reshape(m, 3, 3)
-    sv = np.linalg.svd(M, compute_uv=False)
-    t3 = np.where(np.linalg.det(M) < 0, -sv[:, 2], sv[:, 2])
-    lam = sv[:, 0] + sv[:, 1] + t3
-    q = (sv ** 2).sum(1)
-    Gsum = 2 * lam + A * lam.clip(1e-300) / A * 10.0 ** rng.uniform(-7, 1, m)
+    S, Gsum, sv, t3, q, lam = family_case(family, m, A)
     Gx = np.ascontiguousarray(Gsum / 2)
     full = np.empty(m, dtype=np.float32)
     below = np.empty(m, dtype=np.float32)
@@ -252,6 +192,18 @@ def test_float32_far_certificate_is_sound(host, family):
                     cert.ctypes.data_as(C.c_void_p))
         yes = cert.astype(bool)
         assert not np.any(full[yes] < cur[yes])
+        # the early-stopped solve on the same matrices: the same bits or +inf, +inf
+        # never where the distance is below `cur` (round 5: at scale 1e-15 the
+        # closed-form bound of round 4 underflowed in float32 and was not sound)
+        f2 = np.empty(m, dtype=np.float32)
+        host.h_batch(S.ctypes.data_as(C.c_void_p), Gx.ctypes.data_as(C.c_void_p),
+                     Gx.ctypes.data_as(C.c_void_p), A, cur.ctypes.data_as(C.c_void_p),
+                     C.c_int64(m), f2.ctypes.data_as(C.c_void_p),
+                     below.ctypes.data_as(C.c_void_p))
+        gave_up = np.isinf(below) & ~np.isinf(full)
+        assert not np.any(full[gave_up] < cur[gave_up])
+        np.testing.assert_array_equal(below[~gave_up].view(np.uint32),
+                                      full[~gave_up].view(np.uint32))
         assert np.all((sv[yes, 1] + t3[yes]) ** 2 >= 1e-4 * q[yes])
         if factor >= 1.0:
             assert not np.any(yes & (full > 0))

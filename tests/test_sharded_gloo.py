@@ -131,7 +131,10 @@ def test_larger_groups_chained_rounds(world, n, K):
 
 @pytest.mark.parametrize("world,n,K,cutoff,cands", [
     (2, 1500, 40, 0.0, 8), (2, 1200, None, 0.45, 8), (3, 300, 12, 0.0, 16),
-    (8, 2600, 50, 0.0, 16)])
+    (8, 2600, 50, 0.0, 16),
+    # rounds of 32 candidates: two passes behind one exchange (round 5)
+    (2, 1500, 70, 0.0, 32), (2, 1200, None, 0.45, 32), (3, 300, 40, 0.0, 32),
+    (8, 2600, 90, 0.0, 32)])
 def test_one_exchange_per_round(world, n, K, cutoff, cands):
     """the round protocol of csrc/ek_mshard.hip (one message per shard and
     round: per-prefix maxima + speculative offers, a broken chain re-offered)
@@ -404,3 +407,138 @@ def test_connect_mailboxes_is_collective_whatever_fails(fail_export_on, fail_ope
     if not healthy:
         bad = {fail_export_on, fail_open_on} - {-1}
         assert all(bool(parts[r]["had_error"]) for r in bad)
+
+
+# ---- k-medoids with a warm start across ranks (reference kmedoids.py MPI mode) --------
+_KM_LENGTHS = [300, 120, 260, 200, 180]
+
+
+def _striped(x, lengths, world):
+    """the reference's distribution (mpi/io.py:126): trajectory t on rank
+    t % world, a rank's trajectories one after the other -> per rank the frame
+    indices (into the concatenation of all trajectories) it holds, in order"""
+    starts = np.concatenate([[0], np.cumsum(lengths)])
+    return [np.concatenate([np.arange(starts[t], starts[t + 1])
+                            for t in range(r, len(lengths), world)] or
+                           [np.zeros(0, dtype=np.int64)]).astype(np.int64)
+            for r in range(world)]
+
+
+def _km_worker(rank, world, port, seed, K, n_iters, form, outdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["OMP_NUM_THREADS"] = "2"
+    from enspara_amd import sharded, synth
+    from _host_shard import HostShard
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port,
+                            rank=rank, world_size=world)
+    inp = np.load(os.path.join(outdir, "in.npz"))
+    x = synth.synth(sum(_KM_LENGTHS), 18, 11, seed=seed)
+    held = _striped(x, _KM_LENGTHS, world)
+    lo = sum(len(h) for h in held[:rank])
+    mine = x[held[rank]]
+    shard = HostShard(mine, lo)
+    ctr = inp["flat"] if form == "flat" else [tuple(p) for p in inp["pairs"]]
+    a = inp["a"][lo:lo + len(mine)]
+    d = inp["d"][lo:lo + len(mine)]
+    pairs, coords = sharded.kmedoids_sharded(
+        shard, mine, n_iters=n_iters, assignments=a, distances=d,
+        cluster_center_inds=list(ctr), X_lengths=_KM_LENGTHS,
+        random_state=np.random.RandomState(4))
+    np.savez(os.path.join(outdir, "r%d.npz" % rank), pairs=np.array(pairs),
+             coords=coords, dist=shard.dist, assign=shard.assign, lo=lo)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,form", [(2, "flat"), (2, "pairs"), (3, "flat"),
+                                        (3, "pairs")])
+def test_kmedoids_warm_start_across_ranks(world, form):
+    """kmedoids() in MPI mode (kmedoids.py:133-146, :264-283, :365-407): every
+    rank passes its frames' assignments and distances and the cluster centers
+    with respect to ALL data -- flat indices or (trajectory, frame) pairs with
+    X_lengths -- the ranks holding the trajectories striped; two PAM sweeps;
+    equal to the single-process oracle on the frames in the ranks' order"""
+    from oracle import cluster as oc
+    from enspara_amd import synth
+    seed, K, n_iters = 33, 9, 2
+    x = synth.synth(sum(_KM_LENGTHS), 18, 11, seed=seed)
+    held = _striped(x, _KM_LENGTHS, world)
+    perm = np.concatenate(held)             # rank order -> original index
+    xp = x[perm]
+    inds, a, d = oc.kcenters(xp, n_clusters=K)
+    flat = perm[[int(i) for i in inds]]     # the centers, w.r.t. all data
+    starts = np.concatenate([[0], np.cumsum(_KM_LENGTHS)])
+    traj = np.searchsorted(starts, flat, side="right") - 1
+    pairs = np.stack([traj, flat - starts[traj]], axis=1)
+    rs = np.random.RandomState(4)
+    wi, wd, wa = [int(i) for i in inds], d.copy(), a.copy()
+    for _ in range(n_iters):
+        wi, wd, wa = oc.pam_update(xp, wi, wa, wd, random_state=rs)
+    with tempfile.TemporaryDirectory() as dd:
+        np.savez(os.path.join(dd, "in.npz"), flat=flat, pairs=pairs, a=a, d=d)
+        mp.spawn(_km_worker, args=(world, _free_port(), seed, K, n_iters, form, dd),
+                 nprocs=world, join=True)
+        parts = [np.load(os.path.join(dd, "r%d.npz" % r)) for r in range(world)]
+    los = [int(p["lo"]) for p in parts]
+    for p in parts:                         # (rank, local index) pairs
+        got = [los[int(r)] + int(i) for r, i in p["pairs"]]
+        assert got == [int(i) for i in wi]
+        np.testing.assert_array_equal(p["coords"], xp[[int(i) for i in wi]])
+    np.testing.assert_array_equal(np.concatenate([p["assign"] for p in parts]), wa)
+    np.testing.assert_array_equal(
+        np.concatenate([p["dist"] for p in parts]).astype(np.float64), wd)
+
+
+def test_ctr_ids_mpi_is_the_references_mapping():
+    """sharded.ctr_ids_mpi against the reference's own construction
+    (kmedoids.py:365-407: ragged arrays of global and per-rank indices)"""
+    from enspara_amd import sharded
+    lengths = [5, 3, 7, 2, 6, 4]
+    starts = np.concatenate([[0], np.cumsum(lengths)])
+    for world in (1, 2, 3, 4):
+        want = {}
+        for t, L in enumerate(lengths):
+            r = t % world
+            owned = lengths[r::world]
+            base = sum(owned[:t // world])
+            for f in range(L):
+                want[(t, f)] = (r, base + f)
+        pairs = sorted(want)
+        assert sharded.ctr_ids_mpi(pairs, lengths, world) == [want[p] for p in pairs]
+        flat = [int(starts[t] + f) for t, f in pairs]
+        assert sharded.ctr_ids_mpi(flat, lengths, world) == [want[p] for p in pairs]
+    with pytest.raises(IndexError):
+        sharded.ctr_ids_mpi([(1, 3)], lengths, 2)
+    with pytest.raises(IndexError):
+        sharded.ctr_ids_mpi([27], lengths, 2)
+
+
+def test_kmedoids_mpi_mode_input_errors():
+    """the half-supplied cases of _kmedoids_inputs_tree_mpi (kmedoids.py:277-281)
+    and of kmedoids() itself (:156-166), without a process group"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _host_shard import HostShard
+    from enspara_amd import sharded, synth
+    from enspara_amd.exception import DataInvalid, ImproperlyConfigured
+    from enspara_amd.cluster.kmedoids import kmedoids
+    x = synth.synth(300, 8, 4, seed=2)
+    a = np.zeros(300, dtype=np.int64)
+    d = np.zeros(300)
+    for kw in (dict(assignments=a), dict(distances=d), dict(cluster_center_inds=[0]),
+               dict(assignments=a, distances=d),
+               dict(assignments=a, cluster_center_inds=[0])):
+        with pytest.raises(ImproperlyConfigured, match="can start from scratch"):
+            sharded.kmedoids_sharded(HostShard(x, 0), x, X_lengths=[300], **kw)
+    with pytest.raises(ImproperlyConfigured, match="X_lengths"):
+        sharded.kmedoids_sharded(HostShard(x, 0), x, assignments=a, distances=d,
+                                 cluster_center_inds=[0])
+    with pytest.raises(DataInvalid, match="holds 300 frames"):
+        sharded.kmedoids_sharded(HostShard(x, 0), x, assignments=a, distances=d,
+                                 cluster_center_inds=[0], X_lengths=[100, 100])
+    with pytest.raises(ImproperlyConfigured, match="in MPI mode"):
+        sharded.kmedoids_sharded(HostShard(x, 0), x)
+    with pytest.raises(ImproperlyConfigured, match="in MPI mode"):
+        kmedoids(x, "rmsd", mpi_mode=True)
+    with pytest.raises(ImproperlyConfigured, match="X_lengths also needs"):
+        kmedoids(x, "rmsd", cluster_center_inds=[(0, 1)], mpi_mode=True)
