@@ -27,7 +27,8 @@ SYMBOLS = [
     "ek_record_bytes", "ek_local_candidate", "ek_own_record",
     "ek_kcenters_step", "ek_kcenters_run",
     "ek_history_download", "ek_history_reset",
-    "ek_spec_candidates", "ek_round_candidates", "ek_spec_begin", "ek_spec_round", "ek_spec_localmax",
+    "ek_spec_candidates", "ek_round_candidates", "ek_quad_copy_ready",
+    "ek_spec_begin", "ek_spec_round", "ek_spec_localmax",
     "ek_spec_apply", "ek_spec_round_end", "ek_spec_progress", "ek_spec_rounds",
     "ek_spec_chain_bytes", "ek_spec_chain_rows", "ek_spec_chain_max",
     "ek_spec_chain_apply", "ek_run_stats", "ek_ti_stats",
@@ -112,6 +113,7 @@ def load():
     L.ek_history_reset.argtypes = [vp]
     L.ek_spec_candidates.argtypes = [vp]
     L.ek_round_candidates.argtypes = [vp]
+    L.ek_quad_copy_ready.argtypes = [vp]
     L.ek_spec_begin.argtypes = [vp, i32, i32, vp]
     L.ek_spec_round.argtypes = [vp, vp, i32, C.c_double]
     L.ek_spec_localmax.argtypes = [vp, vp]

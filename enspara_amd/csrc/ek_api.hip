@@ -62,12 +62,17 @@ int ek_pick_nt(const ek_ctx *c)
 // EK_MAX_CANDS unless option key 4 pins it; 1 = one-center passes only
 // (wide: the fused single-shard rounds and the one-exchange rounds across shards
 // know rounds of 32; the one-launch-per-step forms stop at EK_LEGACY_CANDS)
-int ek_pick_cands(const ek_ctx *c, bool wide)
+// (group: a shard of a group never narrows its rounds on its own -- its peers
+// would plan sixteen candidates where it plans eight; without room for the quad
+// copy the multi-shard entry points fail with EK_ENOMEM instead, and
+// sharded.kcenters_sharded agrees on the form before anything runs: every rank
+// asks ek_quad_copy_ready, one that says no pins key 4 to 8 on all)
+int ek_pick_cands(const ek_ctx *c, bool wide, bool group)
 {
     int t = c->cands == -1 ? EK_MAX_CANDS : c->cands;
     if (t == 32 && !wide)
         t = EK_LEGACY_CANDS;
-    if (t >= 16 && c->no_qtiles)    // (ek_ensure_qtiles found no room)
+    if (t >= 16 && c->no_qtiles && !group)  // (ek_ensure_qtiles found no room)
         t = 8;
     return (t == 32 || t == 16 || t == 8 || t == 4) ? t : 1;
 }
@@ -81,8 +86,24 @@ int ek_ensure_qtiles(ek_ctx *c)
     if (c->qt_valid)
         return EK_OK;
     if (!c->qtiles) {
-        const hipError_t e = hipMalloc(
+        hipError_t e = hipMalloc(
             (void **)&c->qtiles, ek_quad_tiles_bytes(std::max<int64_t>(c->n_tiles, 1), c->A));
+        if (e == hipErrorOutOfMemory && c->stage_frames > 0) {
+            // the upload's staging buffers (two pinned, two on the device, up to
+            // 256 MiB each) are only needed while frames are loaded: give them
+            // back and try once more (the next load allocates them again)
+            (void)hipGetLastError();
+            (void)hipStreamSynchronize(c->stream);
+            for (int b = 0; b < 2; ++b) {
+                (void)hipFree(c->stage[b]);
+                (void)hipHostFree(c->pin[b]);
+                c->stage[b] = c->pin[b] = nullptr;
+                c->up_busy[b] = false;
+            }
+            c->stage_frames = 0;
+            e = hipMalloc((void **)&c->qtiles,
+                          ek_quad_tiles_bytes(std::max<int64_t>(c->n_tiles, 1), c->A));
+        }
         if (e == hipErrorOutOfMemory) {
             // no room for a third copy of the coordinates: a single shard then
             // runs rounds of 8 (ek_pick_cands), which stream the frame-minor tiles
@@ -98,6 +119,20 @@ int ek_ensure_qtiles(ek_ctx *c)
     EK_CHECK_LAUNCH();
     c->qt_valid = true;
     return EK_OK;
+}
+
+extern "C" int ek_quad_copy_ready(ek_ctx *c)
+{
+    if (!c)
+        return ek_fail(EK_EARG, "NULL context");
+    if (!c->loaded)
+        return ek_fail(EK_ESTATE, "ek_quad_copy_ready: no frames loaded");
+    EK_HIP(hipSetDevice(c->device));
+    c->no_qtiles = false;           // (memory may have been given back since)
+    const int eq = ek_ensure_qtiles(c);
+    if (eq == EK_ENOMEM)
+        return 0;
+    return eq == EK_OK ? 1 : eq;
 }
 
 // slot of a form in the run statistics: rounds run as 1 / 4 / 8 / 16 / 32 candidates
@@ -520,9 +555,13 @@ extern "C" int ek_load_frames(ek_ctx *c, const float *xyz, int64_t first,
             c->stage_frames = chunk;
         }
         int n_thr = 8;
-        if (const char *e = getenv("EK_UPLOAD_THREADS"))
-            n_thr = atoi(e);
-        n_thr = std::max(1, std::min(n_thr, 64));
+        if (const char *e = getenv("EK_UPLOAD_THREADS")) {
+            char *end = nullptr;
+            const long v = strtol(e, &end, 10);
+            if (end == e || *end != '\0' || v < 1 || v > 64)
+                return ek_fail(EK_EARG, "EK_UPLOAD_THREADS='%s': an integer 1 .. 64", e);
+            n_thr = (int)v;
+        }
         int k = 0;
         for (int64_t done = 0; done < count; done += chunk, ++k) {
             const int b = k & 1;
@@ -535,12 +574,22 @@ extern "C" int ek_load_frames(ek_ctx *c, const float *xyz, int64_t first,
             if (bytes < ((size_t)4 << 20) || n_thr == 1) {
                 memcpy(dst, src, bytes);
             } else {
-                if (!c->pool)
-                    c->pool = new (std::nothrow) EkCopyPool();
-                if (!c->pool)
-                    return ek_fail(EK_EARG, "ek_load_frames: out of host memory");
-                c->pool->start(n_thr);
-                c->pool->copy(dst, src, bytes);
+                // (no C++ exception may cross the C ABI: a thread that cannot be
+                // started -- std::system_error -- or a failed allocation leaves the
+                // copy to this thread alone)
+                bool pooled = false;
+                try {
+                    if (!c->pool)
+                        c->pool = new EkCopyPool();
+                    c->pool->start(n_thr);
+                    pooled = !c->pool->th.empty();
+                } catch (...) {
+                    pooled = c->pool && !c->pool->th.empty();
+                }
+                if (pooled)
+                    c->pool->copy(dst, src, bytes);
+                else
+                    memcpy(dst, src, bytes);
             }
             EK_HIP(hipMemcpyAsync(c->stage[b], c->pin[b], bytes, hipMemcpyHostToDevice,
                                   c->stream));
@@ -553,6 +602,7 @@ extern "C" int ek_load_frames(ek_ctx *c, const float *xyz, int64_t first,
     }
     c->loaded = true;
     c->qt_valid = false;
+    c->no_qtiles = false;       // (another load, another try)
     return EK_OK;
 }
 

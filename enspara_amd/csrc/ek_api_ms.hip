@@ -5,7 +5,7 @@
 // ---- multi-candidate rounds across shards --------------------------------------------
 extern "C" int ek_spec_candidates(ek_ctx *c)
 {
-    return c ? ek_pick_cands(c) : 0;
+    return c ? ek_pick_cands(c, false, true) : 0;
 }
 
 extern "C" int ek_round_candidates(ek_ctx *c)
@@ -29,7 +29,7 @@ extern "C" int ek_spec_begin(ek_ctx *c, int32_t first_label, int32_t limit,
     rc = ek_spec_alloc(c);
     if (rc)
         return rc;
-    const int T = std::max(ek_pick_cands(c), 1);
+    const int T = std::max(ek_pick_cands(c, false, true), 1);
     EkCtl w;
     memset(&w, 0, sizeof(w));
     w.n_done = first_label;
@@ -52,7 +52,7 @@ extern "C" int ek_spec_round(ek_ctx *c, const void *recs_all, int32_t n_recs,
     if (!c || !recs_all || n_recs < 1 || n_recs > 64)
         return ek_fail(EK_EARG, "ek_spec_round: bad argument (1..64 records)");
     EK_HIP(hipSetDevice(c->device));
-    const int T = ek_pick_cands(c);
+    const int T = ek_pick_cands(c, false, true);
     if (T < 4)
         return ek_fail(EK_ESTATE, "ek_spec_round: multi-candidate rounds are "
                                   "off (use ek_kcenters_step)");
@@ -169,7 +169,7 @@ extern "C" int ek_spec_round_end(ek_ctx *c, void *recs_out)
     if (!c)
         return ek_fail(EK_EARG, "NULL context");
     EK_HIP(hipSetDevice(c->device));
-    const int T = std::max(ek_pick_cands(c), 1);
+    const int T = std::max(ek_pick_cands(c, false, true), 1);
     const int nb = (int)((c->n + EK_BLOCK - 1) / EK_BLOCK);
     ek_launch_pickT(c->blockmax, nb, c->tiles, c->G, c->assign, c->A, T, c->goff,
                     recs_out ? (unsigned char *)recs_out : c->recsT, c->ctl, c->top,
@@ -388,7 +388,7 @@ extern "C" int ek_ms_begin(ek_ctx *c, int32_t first_label, int32_t limit)
     if (first_label < 0 || limit < first_label)
         return ek_fail(EK_EARG, "ek_ms_begin: bad label range");
     // (the caller's loop has no ladder: rounds of 32 only where option key 4 asks)
-    const int T = ek_pick_cands(c, c->cands == 32);
+    const int T = ek_pick_cands(c, c->cands == 32, true);
     if (T < 4)
         return ek_fail(EK_ESTATE, "ek_ms_begin: multi-candidate rounds are off "
                                   "(option key 4 = 1: use ek_kcenters_step)");
@@ -573,7 +573,7 @@ extern "C" int ek_ms_run(ek_ctx *c, int32_t first_label, int32_t max_new,
     // exchange -- once rounds of 16 are usually accepted whole (>= 14 per round);
     // back to 16 when a batch of them accepts fewer than 22 per round (what 16
     // would accept at most, with half the passes), the next try twice as far off.
-    const int Tmax = ek_pick_cands(c, true);
+    const int Tmax = ek_pick_cands(c, true, true);
     if (Tmax < 4)
         return ek_fail(EK_ESTATE, "ek_ms_run: multi-candidate rounds are off "
                                   "(option key 4 = 1: use ek_kcenters_step)");

@@ -292,7 +292,7 @@ struct ek_ctx {
 hipError_t ek_wait(ek_ctx *c);
 int ek_pick_fpl(const ek_ctx *c);
 int ek_pick_nt(const ek_ctx *c);
-int ek_pick_cands(const ek_ctx *c, bool wide = false);
+int ek_pick_cands(const ek_ctx *c, bool wide = false, bool group = false);
 int ek_ensure_qtiles(ek_ctx *c);
 // nearest centers on v_mfma_f32_16x16x4_f32 (ek_assign.hip): the centers in blocks of
 // 16 laid out like a pass's candidate tile, the frames from the quad copy

@@ -791,11 +791,17 @@ feat_pam_nearest_kernel(const T *__restrict__ tiles, int F,
                         const uint32_t *__restrict__ amb,
                         const unsigned int *__restrict__ counters,
                         const T *__restrict__ MT, int K, int Kcap,
-                        double *__restrict__ ndist, int32_t *__restrict__ nassign)
+                        double *__restrict__ ndist, int32_t *__restrict__ nassign,
+                        const int32_t *__restrict__ halt = nullptr)
 {
     __shared__ T xs[FY_CHUNK];
     __shared__ double rv[EK_BLOCK / EK_WAVE];
     __shared__ int32_t rc[EK_BLOCK / EK_WAVE];
+    // (the asynchronous sweep: the stream of draws ran out, or a cluster was
+    // empty, earlier in this batch of proposals -- nothing of the batch's rest
+    // is kept, so nothing of it is computed either)
+    if (halt && *halt)
+        return;
     // (any grid: workgroup b takes members b, b + gridDim.x, ..)
     for (unsigned int mem = blockIdx.x; mem < counters[0]; mem += gridDim.x) {
     __syncthreads();        // (rv / rc of the member before are read by then)
@@ -1006,9 +1012,12 @@ feat_dist_classify_kernel(const T *__restrict__ tiles, const T *__restrict__ y,
                           int64_t n, int F, const double *__restrict__ dist,
                           const int32_t *__restrict__ assign, int32_t cid,
                           double *__restrict__ ndist, int32_t *__restrict__ nassign,
-                          uint32_t *__restrict__ amb, unsigned int *__restrict__ counters)
+                          uint32_t *__restrict__ amb, unsigned int *__restrict__ counters,
+                          const int32_t *__restrict__ halt)
 {
     __shared__ T ys[FY_CHUNK];
+    if (halt && *halt)          // (see feat_pam_nearest_kernel: up to 127 passes over
+        return;                 // all samples for nothing otherwise)
     const int64_t f = (int64_t)blockIdx.x * EK_BLOCK + threadIdx.x;
     const T *p = tiles + (size_t)(f / EK_TILE) * (size_t)F * EK_TILE + (f % EK_TILE);
     double acc = 0.0;
@@ -1081,8 +1090,11 @@ feat_total_decide_kernel(FeatPamCtl *__restrict__ ctl, const double *__restrict_
 __global__ void __launch_bounds__(EK_BLOCK)
 feat_pw_leaf_kernel(const double *__restrict__ a, const double *__restrict__ b,
                     const EkPwShape *__restrict__ shapes, int n_full,
-                    int n_leaves_total, double *__restrict__ leafsum)
+                    int n_leaves_total, double *__restrict__ leafsum,
+                    const int32_t *__restrict__ halt = nullptr)
 {
+    if (halt && *halt)
+        return;
     const int g = blockIdx.x * (EK_BLOCK / 8) + threadIdx.x / 8;
     const int l8 = threadIdx.x & 7;
     if (g >= n_leaves_total)
@@ -1308,14 +1320,14 @@ extern "C" int ek_feat_pam_sweep(ek_feat *k, int32_t metric, int32_t n_medoids,
         hipLaunchKernelGGL((feat_dist_classify_kernel<T, M>), dim3(blocks),    \
                            dim3(EK_BLOCK), 0, k->s, (const T *)k->tiles,       \
                            (const T *)k->y, k->n, k->F, k->kdist, k->kassign, cid, \
-                           p.ndist, p.nassign, p.amb, p.counters);             \
+                           p.ndist, p.nassign, p.amb, p.counters, &p.ctl->status); \
         hipLaunchKernelGGL((feat_pam_nearest_kernel<T, M>), dim3(near_blocks), \
                            dim3(EK_BLOCK), 0, k->s, (const T *)k->tiles, k->F, \
                            p.amb, p.counters, (const T *)p.MT, K, p.Kcap,      \
-                           p.ndist, p.nassign);                                \
+                           p.ndist, p.nassign, &p.ctl->status);                \
         hipLaunchKernelGGL(feat_pw_leaf_kernel, dim3((p.n_leaves + per - 1) / per), \
                            dim3(EK_BLOCK), 0, k->s, k->kdist, p.ndist, p.shapes, \
-                           p.n_full, p.n_leaves, p.part);                      \
+                           p.n_full, p.n_leaves, p.part, &p.ctl->status);      \
         ek_launch_pw_chunks(p.part, p.shapes, p.n_full, p.n_leaves, p.n_chunks, k->s); \
         hipLaunchKernelGGL((feat_total_decide_kernel<T>), dim3(1), dim3(EK_BLOCK), 0, \
                            k->s, p.ctl, p.part + 2 * (size_t)p.n_leaves, p.n_chunks, \

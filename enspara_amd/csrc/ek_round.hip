@@ -194,9 +194,12 @@ ek_round_chain_kernel(EkRound r, int bootstrap)
                     // hidden behind a farther frame of its own workgroup of 256?
                     // (state 0 of this round: after candidate 0 alone)
                     const bool hidden = r.blockmax[si[k] / EK_BLOCK].idx != si[k];
+                    // above the list's smallest value (it was cut by the per-label
+                    // cap or the pool) or below it (the list was too short)?
+                    const int above = tp->n > 0 && sv[k] > tp->val[tp->n - 1] ? 1 : 0;
                     printf("miss at %d of %d: farthest point rank %d in the list, "
-                           "candidate %d, hidden %d\n", k, cn, pos, other,
-                           hidden ? 1 : 0);
+                           "candidate %d, hidden %d, above the list's last %d\n", k, cn,
+                           pos, other, hidden ? 1 : 0, above);
 #endif
                     break;
                 }

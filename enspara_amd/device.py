@@ -348,6 +348,14 @@ class FrameStore:
     def candidates(self):
         return int(self.lib.ek_spec_candidates(self._h))
 
+    def quad_copy_ready(self):
+        """True if the third copy of the frames that rounds of 16 / 32 candidates
+        stream exists or could be made now (False: no memory for it)"""
+        rc = int(self.lib.ek_quad_copy_ready(self._h))
+        if rc < 0:
+            _lib.check(rc)
+        return rc == 1
+
     @property
     def round_candidates(self):
         """the widest round kcenters_run / ms_run may use (32 by default)"""

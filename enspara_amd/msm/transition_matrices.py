@@ -281,9 +281,19 @@ def _leading_eigs(space, k, tol=1e-12, max_restarts=500):
                 select[drop - 1] = 0
         out = scipy.linalg.lapack.dtrsen(select, S, Z, job="N", wantq=1)
         S, Z, p, info = out[0], out[1], int(out[4]), out[-1]
-        if info != 0 or p < 1 or p >= m:
+        if info not in (0, 1):
             raise np.linalg.LinAlgError("dtrsen failed (info %d, %d selected)"
                                         % (info, p))
+        if info == 1 or p < 1 or p >= m:
+            # info 1: eigenvalues too close to swap (the leading eigenvalues of
+            # a metastable chain cluster at 1) -- S, Z are still a Schur form of
+            # the projected matrix, only partly reordered.  Go on with what it
+            # kept (or the plain truncation after k), not splitting a 2 x 2
+            # block: a restart from a Schur form that is not perfectly sorted
+            # converges a little later, it does not fail.
+            p = p if 1 <= p < m else max(1, min(m - 1, k))
+            if p < m_eff and S[p, p - 1] != 0.0:
+                p = p + 1 if p + 1 < m else p - 1
         bz = b @ Z
         # residuals of the wanted Ritz pairs
         sv, sy = scipy.linalg.eig(S[:p, :p])

@@ -59,6 +59,12 @@ class DeviceShard:
     def set_triangle_inequality(self, on):
         self.store.set_option(11, 1 if on else 0)
 
+    def quad_copy_ready(self):
+        return self.store.quad_copy_ready()
+
+    def pin_candidates(self, T):
+        self.store.set_option(4, int(T))
+
     def assign_nearest(self, centers_xyz):
         """every local frame against the given centers (float32 [K, A, 3]):
         the state becomes (nearest center, distance), util.py:199-203"""
@@ -259,6 +265,8 @@ def kcenters_sharded(shard, first_label, max_new, dist_cutoff=0.0, group=None,
         shard.set_triangle_inequality(bool(use_triangle_inequality))
     if use_triangle_inequality:
         T = 1               # (the test is per center: one-center passes)
+    if T > 8 and hasattr(shard, "quad_copy_ready"):
+        T = _agree_on_form(shard, T, group, world, collective)
     if T > 1 and world <= MAX_ROUND_RECORDS and hasattr(shard, "ms_local"):
         return _kcenters_sharded_ms(shard, first_label, max_new, dist_cutoff,
                                     group, fresh, world, T, collective)
@@ -302,6 +310,29 @@ def kcenters_sharded(shard, first_label, max_new, dist_cutoff=0.0, group=None,
 # records a round's plan can choose its candidates from (the device keeps a
 # 64 x 64 table of their pairwise distances, csrc/ek_spec.hip)
 MAX_ROUND_RECORDS = 64
+
+
+def _agree_on_form(shard, T, group, world, collective):
+    """Every shard of a group has to run rounds of the same width: they plan
+    the same candidates from the same messages.  Rounds of 16 / 32 need a third
+    copy of the frames on the device; a rank without room for it would, on its
+    own, run rounds of 8 beside peers running 16 -- diverging plans, a mailbox
+    time-out.  So the ranks ask first (the copy is made here if it can be) and
+    if ANY has no room, ALL pin their rounds to 8 candidates (option key 4)."""
+    try:
+        ok = 1 if shard.quad_copy_ready() else 0
+    except Exception:           # reported by the run itself; here: narrow rounds
+        ok = 0
+    everyone = _gather_i64(shard, [ok], group, world, collective)
+    if int(everyone.min()) == 1:
+        return T
+    import logging
+    logging.getLogger(__name__).warning(
+        "rank(s) %s have no memory for the quad copy of their frames: every "
+        "rank runs rounds of 8 candidates",
+        [int(r) for r in np.flatnonzero(everyone[:, 0] == 0)])
+    shard.pin_candidates(8)
+    return 8
 
 
 def _kcenters_sharded_ms(shard, first_label, max_new, dist_cutoff, group, fresh,
@@ -1065,7 +1096,22 @@ def fit_sharded(traj, n_clusters=None, dist_cutoff=0.0, n_iters=0,
     for g in med:
         r = int(np.searchsorted(starts, g, side="right") - 1)
         pairs.append((r, int(g - starts[r])))
+    centers = [centers_xyz[k].reshape(A, 3).copy() for k in range(len(med))]
+    if init_centers is not None and int(n_iters) == 0:
+        # k-centers alone returns the caller's initial centers followed by the
+        # new ones (kcenters.py:200-240: `centers` starts as init_centers, and
+        # the labels and distances of a warm start are measured to THEM), as the
+        # single-process path does; `center_indices` stays the occupied labels'
+        # closest members + the new centers' frames (kcenters.py:205).  (An
+        # initial center that attracts no frame leaves `center_indices` shorter
+        # than `centers` and the new labels start at len(center_indices),
+        # kcenters.py:306: the reference's own misalignment, reproduced like the
+        # single-process path does)
+        n_new = len(idx)
+        centers = ([np.asarray(as_xyz(c_)[0] if np.ndim(c_) == 3 else c_,
+                               dtype=np.float32).reshape(A, 3).copy()
+                    for c_ in init_centers] +
+                   (centers[len(med) - n_new:] if n_new else []))
     return util.ClusterResult(
         center_indices=pairs, assignments=a.astype(np.int64),
-        distances=d.astype(np.float64),
-        centers=[centers_xyz[k].reshape(A, 3).copy() for k in range(len(med))])
+        distances=d.astype(np.float64), centers=centers)

@@ -157,6 +157,14 @@ int ek_spec_candidates(ek_ctx *ctx);
 /* the widest round ek_kcenters_run / ek_ms_run may use (option key 4; 32 by
  * default): ek_spec_candidates is the same for the ek_spec_* protocol (<= 16) */
 int ek_round_candidates(ek_ctx *ctx);
+/* Rounds of 16 / 32 candidates stream a third copy of the frames (the quad copy,
+ * 12 * n_atoms bytes per frame), made when first needed.  1: it exists or could
+ * be made now; 0: no memory for it (a single shard then runs rounds of 8 on its
+ * own).  Shards of a GROUP must all run the same form: the multi-shard entry
+ * points (ek_ms_*, ek_spec_*) never narrow their rounds on their own -- they fail
+ * with EK_ENOMEM -- and the caller agrees on the form first: every rank asks
+ * this, and if any says 0 all set option key 4 to 8 (sharded.kcenters_sharded). */
+int ek_quad_copy_ready(ek_ctx *ctx);
 int ek_spec_begin(ek_ctx *ctx, int32_t first_label, int32_t limit,
                   void *recs_out);
 int ek_spec_round(ek_ctx *ctx, const void *recs_all, int32_t n_recs,

@@ -88,6 +88,56 @@ def test_reducible_matrix_breakdown():
     assert abs(vals[1] - 1.0) < 1e-10          # eigenvalue 1 twice
 
 
+def _metastable(n_blocks, size, eps, seed):
+    """n_blocks nearly uncoupled chains: the leading n_blocks eigenvalues
+    cluster at 1 within ~eps"""
+    blocks = [_rowstoch(size, 0.05, seed + b).toarray() for b in range(n_blocks)]
+    T = scipy.linalg.block_diag(*blocks) * (1.0 - eps)
+    n = n_blocks * size
+    rng = np.random.RandomState(seed)
+    for i in range(n):                  # eps of every row's weight anywhere
+        T[i, rng.randint(0, n)] += eps
+    return scipy.sparse.csr_matrix(T / T.sum(axis=1, keepdims=True))
+
+
+@pytest.mark.parametrize("eps", [1e-6, 1e-9])
+def test_eigenvalues_clustered_at_one(eps):
+    """six metastable blocks coupled at 1e-6 / 1e-9: six eigenvalues within
+    ~eps of 1 -- where a Schur form's eigenvalues may be "too close to swap"
+    (dtrsen info = 1); the restarts must go on, not raise"""
+    T = _metastable(6, 250, eps, 11)
+    vals, vecs = tm.eigenspectrum(T, n_eigs=8, _space_factory=_factory)
+    w = np.sort(np.linalg.eigvals(T.toarray().T).real)[::-1]
+    np.testing.assert_allclose(vals, w[:8], atol=1e-8)
+    assert np.all(vals[:6] > 1 - 100 * eps)
+    pi = vecs[:, 0]
+    np.testing.assert_allclose(T.T @ pi, pi, atol=1e-9)
+
+
+def test_restart_survives_a_partial_reordering(monkeypatch):
+    """dtrsen reports info = 1 (eigenvalues too close to swap: the Schur form is
+    only partly reordered): round 4 raised LinAlgError there; the restart goes
+    on with what was kept and converges to the same eigenvalues"""
+    real = scipy.linalg.lapack.dtrsen
+    calls = {"n": 0}
+
+    def flaky(select, S, Z, **kw):
+        out = list(real(select, S, Z, **kw))
+        calls["n"] += 1
+        if calls["n"] % 3 == 1:         # every third restart: info 1, one fewer kept
+            out[-1] = 1
+            out[4] = max(1, int(out[4]) - 1)
+        return tuple(out)
+
+    monkeypatch.setattr(scipy.linalg.lapack, "dtrsen", flaky)
+    T = _rowstoch(3000, 0.002, 3)
+    vals, _ = tm.eigenspectrum(T, n_eigs=8, _space_factory=_factory)
+    assert calls["n"] > 1
+    ref = scipy.sparse.linalg.eigs(scipy.sparse.csr_matrix(T.T), 8,
+                                   which="LR", tol=1e-12)[0]
+    np.testing.assert_allclose(vals, np.sort(ref.real)[::-1], atol=1e-8)
+
+
 # ---- ergodic trimming (host-side graph work) ----------------------------------
 TRIM_ARR_TYPES = [np.array, scipy.sparse.lil_matrix, scipy.sparse.csr_matrix,
                   scipy.sparse.coo_matrix, scipy.sparse.csc_matrix,

@@ -542,3 +542,51 @@ def test_kmedoids_mpi_mode_input_errors():
         kmedoids(x, "rmsd", mpi_mode=True)
     with pytest.raises(ImproperlyConfigured, match="X_lengths also needs"):
         kmedoids(x, "rmsd", cluster_center_inds=[(0, 1)], mpi_mode=True)
+
+
+# ---- the ranks agree on the width of their rounds (round-4 advisor finding) -----------
+def _form_worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["OMP_NUM_THREADS"] = "2"
+    from enspara_amd import sharded, synth
+    from _host_shard import HostShardMs
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port,
+                            rank=rank, world_size=world)
+
+    class Tight(HostShardMs):
+        """a shard whose rank 1 has no room for the quad copy of its frames"""
+        pinned = None
+
+        def quad_copy_ready(self):
+            return rank != 1
+
+        def pin_candidates(self, T):
+            self.pinned = T
+            self.candidates = T
+
+    x = synth.synth(1500, 20, 9, seed=5)
+    lo, cnt = sharded.shard_bounds(len(x), world, rank)
+    shard = Tight(x[lo:lo + cnt], lo, 16)
+    idx, _ = sharded.kcenters_sharded(shard, 0, 30, 0.0)
+    np.savez(os.path.join(outdir, "r%d.npz" % rank), idx=idx,
+             pinned=-1 if shard.pinned is None else shard.pinned,
+             cands=shard.candidates)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ranks_agree_on_the_width_of_their_rounds():
+    """one rank without memory for the quad copy: EVERY rank pins its rounds to 8
+    candidates before anything runs (sharded._agree_on_form), instead of that
+    rank alone narrowing its rounds beside peers that plan sixteen"""
+    from oracle import cluster as oc
+    from enspara_amd import synth
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_form_worker, args=(2, _free_port(), d), nprocs=2, join=True)
+        parts = [np.load(os.path.join(d, "r%d.npz" % r)) for r in range(2)]
+    x = synth.synth(1500, 20, 9, seed=5)
+    inds, _, _ = oc.kcenters(x, n_clusters=30)
+    for p in parts:
+        assert int(p["pinned"]) == 8 and int(p["cands"]) == 8
+        np.testing.assert_array_equal(p["idx"], np.array(inds))
