@@ -89,6 +89,10 @@ def parse():
                    help="templates: noisy copies of --templates chains in random "
                         "order (BASELINE's synthetic set); walk: one time-ordered "
                         "trajectory on a continuous landscape (one GPU only)")
+    p.add_argument("--triangle", type=int, default=0, choices=[0, 1],
+                   help="the reference's use_triangle_inequality (kcenters.py:287-296): "
+                        "rounds leave out the tiles none of their candidates can change; "
+                        "`pairs_evaluated` then counts what was really streamed")
     p.add_argument("--seed", type=int, default=1)
     p.add_argument("--fpl", type=int, default=0,
                    help="frames per lane of the one-center kernel (0 = auto)")
@@ -638,6 +642,7 @@ def main():
     t_load = time.perf_counter() - t0
     store.set_frames_per_lane(args.fpl)
     store.set_option(4, args.candidates)
+    store.set_option(11, args.triangle)
     cands = store.round_candidates
 
     shard = sharded.DeviceShard(store) if use_dist else None
@@ -717,6 +722,14 @@ def main():
         raise SystemExit("only %d of %d centers" % (len(idx), centers_total))
     kern_ms, n_samp = store.timing_end()
     timed_form = store.timing_form()
+    ti_report = None
+    if args.triangle:
+        # (tile, candidate) pairs of 256 frames each the rounds of 16 / 32 looked at
+        # and left out (a tile is left out only if NO candidate can change it)
+        looked, left_out = store.ti_stats()
+        ti_report = {"tile_candidate_pairs": looked, "left_out": left_out,
+                     "pairs_evaluated_in_those_rounds":
+                         float(looked - left_out) * 256.0}
     if use_dist:
         # (the mailbox loop moves between rounds of 8 and of 16 and counts both;
         # the gather loop runs one form)
@@ -731,6 +744,38 @@ def main():
             if cands > 1 else {1: (centers_total, centers_total)}
         # (passes over the frames: a round of 32 is two)
         rounds = sum(p * (2 if T == 32 else 1) for T, (p, _) in mix.items())
+
+    # ---- N > 1: what every rank spent where, so that a scaling curve comes with
+    # its cause attached (round-4 review): the sampled pass / chain (its exchange's
+    # wait inside) / plan kernel times of this rank's rounds, how long it waited for
+    # its peers' messages, exchanges without a pass, the transport really used and
+    # which devices can reach which (mailboxes need peer access)
+    per_rank = None
+    if use_dist:
+        mine = {"rank": rank, "device": local_rank, "frames": n_local,
+                "elapsed_s": elapsed, "transport": transport,
+                "rounds_by_candidates": {str(T): {"rounds": p_, "centers": k_}
+                                         for T, (p_, k_) in sorted(mix.items())},
+                "pass_kernel_ms_by_events": kern_ms}
+        if transport == "mailbox" and cands > 1:
+            dg = store.ms_diag()
+            ex = max(dg["exchanges"], 1)
+            mine.update({
+                "exchanges": dg["exchanges"], "exchanges_without_a_pass": dg["reoffers"],
+                "wait_for_peers_us_per_exchange": dg["wait_peers_us"] / ex,
+                "wait_for_own_flag_us_per_exchange": dg["wait_own_flag_us"] / ex,
+                "sampled_round_us": {"pass": dg["pass_us"],
+                                     "chain_with_exchange": dg["chain_with_exchange_us"],
+                                     "plan": dg["plan_us"],
+                                     "rounds_sampled": dg["rounds_sampled"]}})
+        try:
+            ndev = torch.cuda.device_count()
+            mine["can_access_peer"] = [bool(torch.cuda.can_device_access_peer(local_rank, d))
+                                       if d != local_rank else True for d in range(ndev)]
+        except Exception as e:      # (not every build exposes it)
+            mine["can_access_peer"] = "unknown: %s" % e
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
 
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=ctl)
@@ -853,6 +898,8 @@ def main():
         "centers_per_pass": centers_total / rounds if rounds else None,
         "pairs_computed": float(n_total) * sum(T * p for T, (p, _) in
                                                mix.items()),
+        "triangle_inequality": ti_report,
+        "per_rank": per_rank,
         "setup": {"synth_s": t_gen, "context_and_hbm_allocation_s": t_alloc,
                   "upload_center_layout_s": t_load,
                   "upload_center_layout_first_s": t_load_first,

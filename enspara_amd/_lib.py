@@ -33,7 +33,7 @@ SYMBOLS = [
     "ek_spec_chain_bytes", "ek_spec_chain_rows", "ek_spec_chain_max",
     "ek_spec_chain_apply", "ek_run_stats", "ek_ti_stats",
     "ek_ms_setup", "ek_ms_mailbox", "ek_ms_connect", "ek_ms_begin", "ek_ms_local",
-    "ek_ms_global", "ek_ms_end", "ek_ms_run", "ek_ms_state",
+    "ek_ms_global", "ek_ms_end", "ek_ms_run", "ek_ms_state", "ek_ms_diag",
     "ek_assign_nearest",
     "ek_pam_begin", "ek_pam_count_members", "ek_pam_select_member",
     "ek_pam_propose", "ek_pam_propose_member", "ek_pam_commit",
@@ -138,6 +138,7 @@ def load():
     L.ek_ti_stats.argtypes = [vp, i64p, i64p]
     L.ek_assign_nearest.argtypes = [vp, f32p, i32]
     f64p = C.POINTER(C.c_double)
+    L.ek_ms_diag.argtypes = [vp, i64p, f64p]
     L.ek_pam_begin.argtypes = [vp, i64p, i32]
     L.ek_pam_count_members.argtypes = [vp, i32, i64p]
     L.ek_pam_select_member.argtypes = [vp, i32, i64, i64p]

@@ -69,7 +69,11 @@ int ek_pick_nt(const ek_ctx *c)
 // asks ek_quad_copy_ready, one that says no pins key 4 to 8 on all)
 int ek_pick_cands(const ek_ctx *c, bool wide, bool group)
 {
-    int t = c->cands == -1 ? EK_MAX_CANDS : c->cands;
+    // (automatic: up to 16.  Rounds of 32 are built, tested and measured -- a round
+    // of 32 accepts 18.8 of its guesses at 10^6 x 300 where one of 16 accepts 15.2,
+    // 20 / 32 against 13 / 16 on 125 000-frame shards: 0.090 against 0.062 ms per
+    // center, DESIGN.md 4a -- and lose everywhere measured; key 4 = 32 asks for them)
+    int t = c->cands == -1 ? EK_LEGACY_CANDS : c->cands;
     if (t == 32 && !wide)
         t = EK_LEGACY_CANDS;
     if (t >= 16 && c->no_qtiles && !group)  // (ek_ensure_qtiles found no room)
@@ -249,6 +253,9 @@ int ek_free_all(ek_ctx *c)
     (void)hipFree(c->vecs);
     (void)hipFree(c->hdr);
     (void)hipFree(c->pm);
+    (void)hipFree(c->ti_rtab);
+    (void)hipFree(c->ti_tmask);
+    (void)hipFree(c->pam_dprop);
     (void)hipFree(c->fm);
     (void)hipFree(c->top);
     (void)hipFree(c->planD);
@@ -474,6 +481,11 @@ extern "C" int ek_set_option(ek_ctx *c, int32_t key, int32_t value)
         if (value < 0)
             return ek_fail(EK_EARG, "ek_set_option: pairs one workgroup searches >= 0");
         c->sp_max_pairs = value;
+        return EK_OK;
+    case 16:
+        if (value != 0 && value != 1)
+            return ek_fail(EK_EARG, "ek_set_option: PAM tables as bounds 0 or 1");
+        c->pam_bounds = value;
         return EK_OK;
     case 15:
         if (value != 0 && value != 1)
@@ -959,6 +971,18 @@ static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
         }
         EK_HIP(hipMemsetAsync(c->ti_stats, 0, 2 * sizeof(unsigned long long),
                               c->stream));
+        if (first_label + max_new > c->ti_rtab_cap) {
+            EK_HIP(ek_wait(c));
+            (void)hipFree(c->ti_rtab);
+            c->ti_rtab = nullptr;
+            c->ti_rtab_cap = 0;
+            EK_HIP(hipMalloc((void **)&c->ti_rtab, (size_t)(first_label + max_new + 1) *
+                                                       EK_MAX_CANDS * sizeof(float)));
+            c->ti_rtab_cap = first_label + max_new + 1;
+        }
+        if (!c->ti_tmask)
+            EK_HIP(hipMalloc((void **)&c->ti_tmask,
+                             (size_t)std::max<int64_t>(c->n_tiles, 1) * sizeof(uint32_t)));
     }
     c->ti_tiles = c->ti_skipped = 0;
     // three launches per round (ek_round.hip) when the pieces it is built from
@@ -966,7 +990,7 @@ static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
     const bool fused = c->fused && c->chain == 1;
     if (Tmax == 32 && !fused)
         Tmax = EK_LEGACY_CANDS;
-    if (Tmax >= 16 && !tri) {
+    if (Tmax >= 16) {
         const int eq = ek_ensure_qtiles(c);
         if (eq == EK_ENOMEM)
             Tmax = 8;
@@ -974,14 +998,19 @@ static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
             return eq;
     }
     // an explicit request (option key 4 = 4, 8 or 16) pins the wide form
-    const bool adaptive = c->cands == -1 && c->adapt && !tri;
+    const bool adaptive = c->cands == -1 && c->adapt;
     const int fpl = ek_pick_fpl(c);
     const int nt = ek_pick_nt(c);
     // the forms the run moves between, by candidates per pass
     int ladder[4], n_ladder = 0;
-    if (adaptive || tri)
+    // (triangle inequality, round 5: the rounds of 4 .. 32 candidates leave out
+    // the tiles none of their candidates can change -- ek_round_ti_* --, the
+    // one-center steps the tiles the new center cannot.
+    // Round 4 ran one center per pass with the option on, 3.7 x slower than
+    // without it on data where nothing can be left out.)
+    if (adaptive || (tri && Tmax <= 1))
         ladder[n_ladder++] = 1;
-    if (!tri) {
+    if (Tmax > 1) {
         if (adaptive && Tmax >= 16)
             ladder[n_ladder++] = 8;
         if (adaptive && Tmax == 32)
@@ -1025,7 +1054,12 @@ static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
     R.rows = c->rows;
     R.vmask = c->vmask;
     R.cutoff = dist_cutoff;
+    R.ti_tab = tri ? c->ti_rtab : nullptr;
+    R.ti_stats = tri ? c->ti_stats : nullptr;
     bool pending = false;       // a fused round may have left a chain to apply
+    int ti_pause = 0, ti_pause_next = 2;            // batches without masks / the next pause
+    bool masks_fresh = false;   // ti_tmask describes the plan the next pass will run
+    unsigned long long ti_seen[2] = {0, 0};         // the counters at the last look
     EK_HIP(hipEventRecord(c->ev0, c->stream));
     EkCtl cr;
     memset(&cr, 0, sizeof(cr));
@@ -1037,6 +1071,11 @@ static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
         const int32_t left = goal - cr.n_done;
         const bool one = form == 1;
         R.T = form;
+        // (the masks cost two small launches per round; where they leave nothing
+        // out -- frames in no order: the bench's data -- they pause, for twice as
+        // many batches each time a look finds nothing again)
+        const bool masks = tri && fused && form >= 4 && ti_pause == 0;
+        R.tmask = masks ? c->ti_tmask : nullptr;
         // ---- the record(s) this form starts from -------------------------------------
         if (held != form) {
             if (pending) {      // leaving a fused form: the state as it stands
@@ -1052,6 +1091,8 @@ static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
             } else if (fused) {
                 ek_launch_round_chain(R, 1, c->stream);
                 ek_launch_round_next(R, 1, c->stream);
+                ek_launch_round_ti(R, goal, c->stream);
+                masks_fresh = R.tmask != nullptr;
             } else {
                 ek_launch_pickT(c->blockmax, nb, c->tiles, c->G, c->assign, c->A,
                                 form, c->goff, c->recsT, c->ctl, c->top,
@@ -1075,6 +1116,12 @@ static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
             batch = std::max(2, std::min(256, (int32_t)(std::min(left, due) /
                                                         per_round) + 1));
         EK_HIP(hipEventRecord(c->evb0, c->stream));
+        if (R.tmask && !masks_fresh) {  // (after a pause: the masks of the plan at hand)
+            ek_launch_round_ti(R, goal, c->stream);
+            masks_fresh = true;
+        }
+        if (!R.tmask)
+            masks_fresh = false;        // (this batch's rounds do not make any)
         for (int32_t r = 0; r < batch; ++r) {
             if (one) {
                 const int label = cr.n_done + r;
@@ -1111,6 +1158,7 @@ static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
                 }
                 ek_launch_round_chain(R, 0, c->stream);
                 ek_launch_round_next(R, 0, c->stream);
+                ek_launch_round_ti(R, goal, c->stream);
                 EK_CHECK_LAUNCH();
                 pending = true;
                 continue;
@@ -1152,7 +1200,25 @@ static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
         const int32_t before = cr.n_done;
         EK_HIP(hipMemcpyAsync(&cr, c->ctl, sizeof(cr), hipMemcpyDeviceToHost,
                               c->stream));
+        unsigned long long ti_now[2] = {ti_seen[0], ti_seen[1]};
+        if (R.tmask)
+            EK_HIP(hipMemcpyAsync(ti_now, c->ti_stats, sizeof(ti_now),
+                                  hipMemcpyDeviceToHost, c->stream));
         EK_HIP(ek_wait(c));
+        if (R.tmask) {
+            const unsigned long long looked = ti_now[0] - ti_seen[0],
+                                     left = ti_now[1] - ti_seen[1];
+            ti_seen[0] = ti_now[0];
+            ti_seen[1] = ti_now[1];
+            if (looked > 0 && left * 50 < looked) {     // under 2 % left out
+                ti_pause = ti_pause_next;
+                ti_pause_next = std::min(2 * ti_pause_next, 64);
+            } else {
+                ti_pause_next = 2;
+            }
+        } else if (ti_pause > 0 && !one) {
+            --ti_pause;
+        }
         const int32_t got = cr.n_done - before;
         // passes that really ran (a step that finds the stop rule met returns at once)
         const int32_t ran = one ? got : cr.n_rounds - rounds_before;
@@ -1290,7 +1356,9 @@ extern "C" int ek_kcenters_run(ek_ctx *c, int32_t first_label, int32_t max_new,
     EK_HIP(ek_wait(c));
 
     const int T = ek_pick_cands(c, true);
-    if (T > 1 && c->n > 0)
+    // (the triangle inequality's bookkeeping lives in ek_run_rounds, also for one
+    // center per pass)
+    if ((T > 1 || c->tri) && c->n > 0)
         return ek_run_rounds(c, T, first_label, max_new, dist_cutoff, n_added,
                              center_index_out, center_dist_out, final_maxdist);
 

@@ -432,7 +432,8 @@ static int ek_ms_begin_T(ek_ctx *c, int32_t first_label, int32_t limit, int T)
 }
 
 // the launches of a round before its exchange: pass, chain (message out)
-static int ek_ms_enqueue_local(ek_ctx *c, const EkRound &R, const EkMsXchg &x)
+static int ek_ms_enqueue_local(ek_ctx *c, const EkRound &R, const EkMsXchg &x,
+                               hipEvent_t *ev = nullptr)
 {
     const bool sample = c->samp_every > 0 &&
                         (c->samp_count++ % c->samp_every) == 0 &&
@@ -441,12 +442,18 @@ static int ek_ms_enqueue_local(ek_ctx *c, const EkRound &R, const EkMsXchg &x)
         c->samp_form[c->samp_used] = R.T;
         EK_HIP(hipEventRecord(c->samp_ev[2 * c->samp_used], c->stream));
     }
+    if (ev)
+        EK_HIP(hipEventRecord(ev[0], c->stream));
     ek_launch_round_pass(R, c->stream, false);
     if (sample) {
         EK_HIP(hipEventRecord(c->samp_ev[2 * c->samp_used + 1], c->stream));
         c->samp_used++;
     }
+    if (ev)
+        EK_HIP(hipEventRecord(ev[1], c->stream));
     ek_launch_ms_chain(R, c->ms, x, c->stream);
+    if (ev)
+        EK_HIP(hipEventRecord(ev[2], c->stream));
     EK_CHECK_LAUNCH();
     return EK_OK;
 }
@@ -600,16 +607,26 @@ extern "C" int ek_ms_run(ek_ctx *c, int32_t first_label, int32_t max_new,
     int wait16 = 0, next_wait = 1, wait32 = 0, next_wait32 = 1;
     for (int k = 0; k < EK_N_FORMS; ++k)
         c->st_rounds[k] = c->st_centers[k] = 0;
+    // (the run's own counters: ek_ms_diag)
+    EK_HIP(hipMemsetAsync(&c->ms->n_reoffer, 0,
+                          sizeof(EkMsState) - offsetof(EkMsState, n_reoffer), c->stream));
+    for (int k = 0; k < 4; ++k)
+        if (!c->ms_ev[k])
+            EK_HIP(hipEventCreate(&c->ms_ev[k]));
+    c->ms_t[0] = c->ms_t[1] = c->ms_t[2] = 0.0;
+    c->ms_t_n = 0;
     while (max_new > 0) {
         const int32_t left = goal - cr.n_done;
         int32_t batch = std::max(2, std::min(256, (int32_t)(left / per_round) + 2));
         if (ladder)
             batch = std::min(batch, T == 8 ? 24 : (T == 16 ? 64 : 48));
         for (int32_t r = 0; r < batch; ++r) {
-            rc = ek_ms_enqueue_local(c, R, x);
+            rc = ek_ms_enqueue_local(c, R, x, r == 0 ? c->ms_ev : nullptr);
             if (rc)
                 return rc;
             ek_launch_ms_plan(R, c->ms, x, c->planD, c->stream);
+            if (r == 0)
+                EK_HIP(hipEventRecord(c->ms_ev[3], c->stream));
             EK_CHECK_LAUNCH();
         }
         const int32_t before = cr.n_done;
@@ -620,6 +637,15 @@ extern "C" int ek_ms_run(ek_ctx *c, int32_t first_label, int32_t max_new,
         EK_HIP(ek_wait(c));
         const int32_t ran = cr.n_rounds - rounds_before;
         rounds_before = cr.n_rounds;
+        if (ran > 0) {          // the batch's first round really ran: where its time went
+            for (int k = 0; k < 3; ++k) {
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, c->ms_ev[k], c->ms_ev[k + 1]) == hipSuccess)
+                    c->ms_t[k] += ms;
+            }
+            ++c->ms_t_n;
+        }
+        c->ms_last = st;
         passes += (T == 32 ? 2 : 1) * ran;      // (a round of 32 streams the frames twice)
         c->st_rounds[ek_form_slot(T)] += ran;
         c->st_centers[ek_form_slot(T)] += cr.n_done - before;
@@ -688,3 +714,24 @@ extern "C" int ek_ms_run(ek_ctx *c, int32_t first_label, int32_t max_new,
     return EK_OK;
 }
 
+
+// What the last ek_ms_run spent where, for a run that has to explain itself
+// (bench.py reports it per rank).  counts: [0] exchanges, [1] of them without a
+// pass (a chain that broke: its state offered again), [2] 10 ns ticks the shard
+// waited for its peers' messages (per exchange the longest wait, summed), [3] ...
+// for its OWN flag (a store that goes nowhere: the floor of [2]), [4] rounds
+// sampled for `ms`; ms: mean milliseconds of a sampled round's pass, chain kernel
+// (the exchange's wait is inside it) and plan kernel(s).
+extern "C" int ek_ms_diag(ek_ctx *c, int64_t *counts, double *ms)
+{
+    if (!c || !counts || !ms)
+        return ek_fail(EK_EARG, "ek_ms_diag: NULL argument");
+    counts[0] = (int64_t)c->ms_last.seq;
+    counts[1] = (int64_t)c->ms_last.n_reoffer;
+    counts[2] = (int64_t)c->ms_last.wait_ticks_max;
+    counts[3] = (int64_t)c->ms_last.wait_ticks_own;
+    counts[4] = c->ms_t_n;
+    for (int k = 0; k < 3; ++k)
+        ms[k] = c->ms_t_n > 0 ? c->ms_t[k] / (double)c->ms_t_n : 0.0;
+    return EK_OK;
+}

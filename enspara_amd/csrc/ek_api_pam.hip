@@ -573,6 +573,7 @@ static int ek_pam_vecs_alloc(ek_ctx *c)
         EK_HIP(hipMalloc((void **)&c->pam_recs,
                          (size_t)EK_PAM_WIN * ek_rec_bytes(c->A)));
         EK_HIP(hipMalloc((void **)&c->pam_plan, sizeof(EkPlan)));
+        EK_HIP(hipMalloc((void **)&c->pam_dprop, EK_PAM_WIN * sizeof(float)));
     }
     return EK_OK;
 }
@@ -605,11 +606,16 @@ static int ek_pam_prefetch_vectors(ek_ctx *c, int count, int32_t win_lo,
         const bool slots = local && win_count == count;
         const size_t tb = (size_t)EK_PAM_WIN * (c->med_cap + 1);
         const int groups = (count + EK_PAM_GROUP - 1) / EK_PAM_GROUP;
-        ek_launch_pam_tables(c->med_aos, c->med_G, c->A, K, c->pam_restore,
-                             c->pam_recs, count, win_lo, slots ? count : 0, c->dtab,
-                             c->dtab + tb, c->dtab + 2 * tb, c->stream);
-        c->tab_lo = win_lo;
-        c->tab_n = slots ? count : 0;
+        // (proposals drawn among their clusters' members, ek_pam_sweep: the
+        // proposal-to-medoid table only as the lower bounds the old medoids'
+        // table gives, half the pairs -- ek_pam_pairs_kernel<0>.  Where the bounds
+        // are too loose -- few atoms, clusters as wide as they are apart: more than
+        // a quarter of the frames "within reach" -- the window's tables are made
+        // again exactly, and the next windows' right away)
+        bool bounds = slots && prepared && c->pf_members && c->pam_bounds &&
+                      c->pam_bounds_off == 0;
+        if (c->pam_bounds_off > 0)
+            --c->pam_bounds_off;
         if (!c->act_list)
             EK_HIP(hipMalloc((void **)&c->act_list,
                              (size_t)std::max<int64_t>(c->n, 1) * sizeof(uint32_t)));
@@ -620,13 +626,27 @@ static int ek_pam_prefetch_vectors(ek_ctx *c, int count, int32_t win_lo,
             ek_launch_pam_vecs_reset(c->act_list, c->vecs_rows, c->vecs_cols, c->n_pad,
                                      c->pam_vecs, c->stream);
         c->vecs_rows = -1;
-        ek_launch_pam_active(c->dist, c->assign, c->n, c->dtab + 2 * tb, groups, K,
-                             win_lo, win_count, c->act_list, c->amb_count + 3,
-                             c->stream, prepared);
-        EK_CHECK_LAUNCH();
-        EK_HIP(hipMemcpyAsync(c->act_n_host, c->amb_count + 3, sizeof(unsigned int),
-                              hipMemcpyDeviceToHost, c->stream));
-        EK_HIP(ek_wait(c));
+        for (int attempt = 0;; ++attempt) {
+            ek_launch_pam_tables(c->med_aos, c->med_G, c->A, K, c->pam_restore,
+                                 c->pam_recs, count, win_lo, slots ? count : 0, c->dtab,
+                                 c->dtab + tb, c->dtab + 2 * tb, c->stream,
+                                 bounds ? c->pam_dprop : nullptr);
+            c->tab_lo = win_lo;
+            c->tab_n = slots ? count : 0;
+            if (attempt > 0)    // (the counter the set-up kernel cleared has been used)
+                EK_HIP(hipMemsetAsync(c->amb_count + 3, 0, sizeof(unsigned int), c->stream));
+            ek_launch_pam_active(c->dist, c->assign, c->n, c->dtab + 2 * tb, groups, K,
+                                 win_lo, win_count, c->act_list, c->amb_count + 3,
+                                 c->stream, prepared || attempt > 0);
+            EK_CHECK_LAUNCH();
+            EK_HIP(hipMemcpyAsync(c->act_n_host, c->amb_count + 3, sizeof(unsigned int),
+                                  hipMemcpyDeviceToHost, c->stream));
+            EK_HIP(ek_wait(c));
+            if (!bounds || (int64_t)*c->act_n_host * 4 <= c->n)
+                break;
+            bounds = false;
+            c->pam_bounds_off = 32;
+        }
         const int64_t n_act = *c->act_n_host;
         if (n_act * 4 <= c->n) {
             // a short list: straight from the frame-major copy, 64 frames x the
@@ -710,7 +730,7 @@ static int ek_pam_prefetch_frames(ek_ctx *c, const int64_t *frames, int32_t coun
     if (prepared)
         ek_launch_pam_setup(c->aos, c->G, c->A, frames, count, c->goff, c->pam_recs,
                             c->ctile, c->ctrace, c->pam_plan, c->amb_count + 3,
-                            c->stream);
+                            c->stream, c->dist, c->pam_dprop);
     else
         ek_launch_records_from_frames(c->aos, c->G, c->A, frames, count, c->goff,
                                       c->pam_recs, c->stream);
@@ -1109,7 +1129,10 @@ extern "C" int ek_pam_sweep(ek_ctx *c, int32_t K, int32_t width, const uint32_t 
             for (int32_t s = 0; s < cnt; ++s)
                 frames[s] = proposals[cid + s];
         }
+        // (drawn proposals are members of their clusters: see ek_pam_prefetch_vectors)
+        c->pf_members = !proposals;
         rc = ek_pam_prefetch_window(c, frames, n_slots, cid, cnt);
+        c->pf_members = false;
         if (rc)
             return rc;
         int32_t n_done = 0;

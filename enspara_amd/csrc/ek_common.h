@@ -127,6 +127,8 @@ struct EkFuse {
     EkCtl *ctl = nullptr;
     EkChainRow *rows = nullptr;     // [EK_MAX_CANDS] the candidate frames' rows
     uint32_t *vmask = nullptr;      // per 64 frames: bit c = vector c - 1 stored
+    const uint32_t *tmask = nullptr;    // triangle inequality (ek_round_ti_*): per tile,
+                                    //   bit c = candidate c can still change a frame of it
 };
 // everything a fused round works on besides the frames
 struct EkRound {
@@ -155,7 +157,14 @@ struct EkRound {
     uint32_t *vmask;            // [n_pad / 64], see EkFuse
     unsigned int *tick;         // [3] arrival counters of the three kernels
     double cutoff;
+    // triangle inequality for rounds (option key 11, ek_round.hip "ek_round_ti_*"):
+    // null = off
+    float *ti_tab = nullptr;    // [labels][EK_MAX_CANDS] center-to-candidate distances
+    uint32_t *tmask = nullptr;  // [tiles] candidates that can still change the tile
+    unsigned long long *ti_stats = nullptr; // [0] (tile, candidate) pairs looked at, [1] left out
 };
+// the masks of the round the plan describes (after ek_launch_round_next)
+void ek_launch_round_ti(const EkRound &r, int max_labels, hipStream_t s);
 // with_order: the pass's last workgroup works out the presumed order (single shard)
 void ek_launch_round_pass(const EkRound &r, hipStream_t s, bool with_order = true);
 // bootstrap != 0: no chain to decide, candidates from blockmax as it is
@@ -188,6 +197,14 @@ struct EkMsState {
     uint32_t seq;           // exchanges completed (mailbox sequence number)
     int32_t err;            // a peer's message did not arrive
     uint32_t err_seq;       // ... in this exchange
+    // what a run across shards spent waiting (ek_ms_diag; bench.py reports them per
+    // rank): 10 ns ticks the last helper workgroup of the chain kernel waited for
+    // the peers' flags (summed over the peers' waits, which overlap: the longest
+    // of an exchange is what counts -- kept apart), exchanges, exchanges without a
+    // pass (a chain that broke is offered again)
+    uint32_t n_reoffer;
+    unsigned long long wait_ticks_max;      // sum over exchanges of the longest wait
+    unsigned long long wait_ticks_own;      // ... of the wait for this shard's OWN flag
 };
 // where a round's messages go and come from
 struct EkMsXchg {
@@ -396,7 +413,7 @@ void ek_launch_pam_apply(const int32_t *flag, float *dist, const float *ndist,
 void ek_launch_pam_tables(const float *aos, const double *Gm, int A, int K, int held,
                           const unsigned char *recs, int n_prop, int old_lo,
                           int n_old, float *T, float *O, float *dmin,
-                          hipStream_t s);
+                          hipStream_t s, const float *dprop = nullptr);
 // vecs[j * n_pad + list[i]] = rmsd(frame list[i], record j): the listed frames
 // straight from the frame-major copy, results scattered into the full vectors
 void ek_launch_pam_list_dist(const float *aos, const double *G, int A,
@@ -439,7 +456,8 @@ static inline __host__ __device__ size_t ek_ctile_half_floats(int A)
 void ek_launch_pam_setup(const float *aos, const double *G, int A,
                          const int64_t *frames, int count, int64_t global_offset,
                          unsigned char *recs, float *ctile, double *ctrace,
-                         EkPlan *plan, unsigned int *counter, hipStream_t s);
+                         EkPlan *plan, unsigned int *counter, hipStream_t s,
+                         const float *dist = nullptr, float *dprop = nullptr);
 static inline int ek_pass_dist_T(int count)     // the pass width ek_launch_pass_dist picks
 {
     return (count <= 4) ? 4 : 8;

@@ -183,6 +183,11 @@ struct ek_ctx {
     int64_t *bat_sel = nullptr;      // [0..8) counts, [8..16) selected frames
     int32_t bat_cid0 = -1, bat_count = 0;
     float *pam_vecs = nullptr;       // [EK_PAM_WIN][n_pad]
+    float *pam_dprop = nullptr;      // [EK_PAM_WIN] the proposals' distances to their medoids
+    bool pf_members = false;         // the window's proposals are members of its clusters
+                                     //   (drawn by ek_pam_sweep): tables as bounds
+    int pam_bounds = 1;              // use that (option key 16)
+    int pam_bounds_off = 0;          // windows to go with exact tables (the bounds were too loose)
     unsigned char *pam_recs = nullptr;
     EkPlan *pam_plan = nullptr;
     unsigned int *moved = nullptr;
@@ -237,6 +242,9 @@ struct ek_ctx {
     uint8_t *ti_skip = nullptr;  // [n_tiles]
     unsigned long long *ti_stats = nullptr;  // [2] tiles looked at, skipped
     int64_t ti_tiles = 0, ti_skipped = 0;    // of the last run
+    float *ti_rtab = nullptr;    // rounds: [ti_rtab_cap][EK_MAX_CANDS] center-to-candidate distances
+    int32_t ti_rtab_cap = 0;
+    uint32_t *ti_tmask = nullptr;    // rounds: [n_tiles] candidates that can change the tile
     float *ti_tab = nullptr;     // sharded steps: the accepted centers, [ti_tab_cap][3A]
     double *ti_tabG = nullptr;
     int32_t ti_tab_cap = 0;
@@ -266,6 +274,12 @@ struct ek_ctx {
     int ms_peers = 0;                // peers connected (mailbox transport on at == world)
     std::vector<void *> ms_ipc;      // mappings opened with hipIpcOpenMemHandle
     int ms_T = 0;                    // candidates per pass of the run in progress
+    // what the last ek_ms_run spent where (ek_ms_diag): the first round of every
+    // batch is bracketed by events -- pass | chain (with the exchange) | plan
+    hipEvent_t ms_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    double ms_t[3] = {0.0, 0.0, 0.0};    // milliseconds, summed over the sampled rounds
+    int64_t ms_t_n = 0;              // rounds sampled
+    EkMsState ms_last;               // the device-side counters when the run ended
 
     void *msm_scratch = nullptr;     // ek_msm.hip: buffers of ek_msm_counts_ctx
 

@@ -217,7 +217,9 @@ ek_ms_chain_kernel(EkRound r, EkMsState *ms, EkMsXchg x, int nblk)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         __shared__ int s_last;
+        __shared__ unsigned long long s_wait;
         if (tid == 0) {
+            s_wait = 0;
             s_last = __hip_atomic_fetch_add(r.tick + 6, 1u, __ATOMIC_RELAXED,
                                             __HIP_MEMORY_SCOPE_AGENT) ==
                      EK_MS_HELPERS - 1;
@@ -248,7 +250,17 @@ ek_ms_chain_kernel(EkRound r, EkMsState *ms, EkMsXchg x, int nblk)
                     break;
                 }
             }
+            // how long this exchange kept the shard waiting (ek_ms_diag): the
+            // longest wait over the peers, and the wait for its own flag (the
+            // latency of a store that goes nowhere: the floor)
+            const unsigned long long waited = wall_clock64() - t_start;
+            atomicMax(&s_wait, waited);
+            if (tid == x.rank)
+                atomicAdd(&ms->wait_ticks_own, waited);
         }
+        __syncthreads();
+        if (s_last && x.sys && tid == 0)
+            atomicAdd(&ms->wait_ticks_max, s_wait);
         return;
     }
     const int nb = (int)((r.n + EK_BLOCK - 1) / EK_BLOCK);
@@ -607,8 +619,10 @@ ek_ms_plan_kernel(EkRound r, EkMsState *ms, EkMsXchg x, float *D)
         // (a message that never came: the run ends here, on every later launch too)
         s_over = (c.stopped || c.n_done >= c.limit || ms->err) ? 1 : 0;
         s_repick = (!s_over && mode == 1 && na < cn) ? 1 : 0;
-        if (s_repick)
+        if (s_repick) {
             ms->pick_state = na;
+            ms->n_reoffer = ms->n_reoffer + 1u;
+        }
     }
     __syncthreads();
     const bool over = s_over != 0, repick = s_repick != 0;

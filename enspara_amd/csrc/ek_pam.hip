@@ -1643,6 +1643,14 @@ void ek_pw_build_shape(int len, EkPwShape *sh)
 //                  (ek_pam_prune_kernel / the classification's last workgroup)
 //   `held` is the row a rejected proposal still occupies (its medoid is in row
 //   K), or -1.  grid (ceil(K / 64), column groups of proposals + of old medoids).
+//   Round 5, `dprop` given (proposal j is a MEMBER of cluster old_lo + j, at
+//   dprop[j] from its medoid, n_old == n_prop): every use of T is a lower bound
+//   -- "a medoid farther than .. cannot matter", "a frame whose medoid is at
+//   least twice its distance from the proposal cannot move" -- and the triangle
+//   inequality gives one from O alone: rmsd(medoid c, proposal j) >=
+//   O[j][c] - dprop[j].  Only the old medoids' columns are computed (half the
+//   pairs), T[j][c] = max(O[j][c] - dprop[j], 0), dmin from those; a looser bound
+//   lists a few more frames and medoids, results cannot change.
 // MODE 1, a window's proposals against the frames they can touch (rows: the
 //   listed frames of the frame-major copy):
 //   vecs[j * n_pad + list[i]] = rmsd(frame list[i], proposal j)
@@ -1656,6 +1664,7 @@ struct EkPairArgs {
     // MODE 0
     int32_t K, held, old_lo, n_old;
     float *T, *O, *dmin;
+    const float *dprop;         // != nullptr: T and dmin as lower bounds from O (below)
     // MODE 1
     const uint32_t *list;
     int64_t n_rows, n_pad;
@@ -1777,8 +1786,13 @@ ek_pam_pairs_kernel(EkPairArgs p)
     const int c = blockIdx.x * EK_WAVE + lane;
     if (live && ok)
         (old ? p.O : p.T)[(size_t)j * p.K + c] = D;
-    if (old)
+    if (old && !p.dprop)
         return;
+    if (old) {                  // (bounds: see above)
+        D = (live && ok) ? fmaxf(D - p.dprop[j], 0.f) : __builtin_inff();
+        if (live && ok)
+            p.T[(size_t)j * p.K + c] = D;
+    }
     tmin[jw][lane] = D;
     __syncthreads();
     if (jw == 0 && ok) {
@@ -1803,8 +1817,27 @@ static void ek_pairs_launch(const EkPairArgs &p, dim3 grid, hipStream_t s)
 void ek_launch_pam_tables(const float *aos, const double *Gm, int A, int K, int held,
                           const unsigned char *recs, int n_prop, int old_lo,
                           int n_old, float *T, float *O, float *dmin,
-                          hipStream_t s)
+                          hipStream_t s, const float *dprop)
 {
+    if (dprop && n_old == n_prop) {     // T and dmin as bounds from O: old columns only
+        EkPairArgs q = {};
+        q.aos = aos;
+        q.G = Gm;
+        q.A = A;
+        q.recs = recs;
+        q.n_col = 0;
+        q.K = K;
+        q.held = held;
+        q.old_lo = old_lo;
+        q.n_old = n_old;
+        q.T = T;
+        q.O = O;
+        q.dmin = dmin;
+        q.dprop = dprop;
+        ek_pairs_launch<0>(q, dim3((K + EK_WAVE - 1) / EK_WAVE,
+                                   (n_old + EK_PAM_GROUP - 1) / EK_PAM_GROUP), s);
+        return;
+    }
     EkPairArgs p = {};
     p.aos = aos;
     p.G = Gm;
@@ -1989,10 +2022,13 @@ ek_pam_setup_kernel(const float *__restrict__ aos, const double *__restrict__ G,
                     int64_t global_offset,
                     unsigned char *__restrict__ recs, float *__restrict__ ctile,
                     double *__restrict__ ctrace, EkPlan *__restrict__ plan,
-                    unsigned int *__restrict__ counter)
+                    unsigned int *__restrict__ counter, const float *__restrict__ dist,
+                    float *__restrict__ dprop)
 {
     if ((int)blockIdx.x < count) {
         const int64_t idx = fl.f[blockIdx.x];
+        if (dprop && threadIdx.x == 0)  // (how far the proposal is from its medoid)
+            dprop[blockIdx.x] = dist[idx];
         EkRecHdr *h = (EkRecHdr *)(recs + (size_t)blockIdx.x * ek_rec_bytes(A));
         float *coords = (float *)(h + 1);
         if (threadIdx.x == 0) {
@@ -2031,7 +2067,8 @@ ek_pam_setup_kernel(const float *__restrict__ aos, const double *__restrict__ G,
 void ek_launch_pam_setup(const float *aos, const double *G, int A,
                          const int64_t *frames, int count, int64_t global_offset,
                          unsigned char *recs, float *ctile, double *ctrace,
-                         EkPlan *plan, unsigned int *counter, hipStream_t s)
+                         EkPlan *plan, unsigned int *counter, hipStream_t s,
+                         const float *dist, float *dprop)
 {
     if (count <= 0)
         return;
@@ -2043,7 +2080,7 @@ void ek_launch_pam_setup(const float *aos, const double *G, int A,
     const int cb = (ek_ctile_atoms(A) * 3 * T + EK_BLOCK - 1) / EK_BLOCK;
     hipLaunchKernelGGL(ek_pam_setup_kernel, dim3(std::max(count, cb)),
                        dim3(EK_BLOCK), 0, s, aos, G, A, fl, count, cg, T,
-                       global_offset, recs, ctile, ctrace, plan, counter);
+                       global_offset, recs, ctile, ctrace, plan, counter, dist, dprop);
 }
 
 

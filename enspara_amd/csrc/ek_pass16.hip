@@ -282,6 +282,11 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
     double Gf = 0.0;
     float cur0 = 0.f;
     uint32_t vm = 0u;           // FUSE: which distance vectors this wave stored
+    // triangle inequality (ek_round_ti_tiles_kernel): the candidates that can still
+    // change a frame of this tile; none: the tile is not read
+    uint32_t tm_v = 0xffffffffu;
+    if (FUSE && fz.tmask)
+        tm_v = fz.tmask[blockIdx.x];
     if (f < n) {
         Gf = G[f];
         cur0 = dist[f];
@@ -312,6 +317,10 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
     if (tid == 0)
         s_arrive = 0;
     __syncthreads();
+    // (this launch's sixteen candidates of the mask; a tile that holds a candidate
+    // frame is never without: a frame is at distance 0 from itself)
+    const uint32_t tm = (__builtin_amdgcn_readfirstlane(tm_v) >> CB) & 0xffffu;
+    const bool tile_off = FUSE && tm == 0u;
     // ---- this frame's state on the way in ---------------------------------------
     int32_t lab = -1;           // >= 0: the frame's state changes in this pass
     int own = 0;                // order: this frame is candidate `own` (>= 1)
@@ -390,7 +399,8 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
     // (the last trip's atoms past A are zeros in rows and candidates alike: a
     // product +0 added to an accumulator leaves its bits -- an accumulator is never
     // -0, it starts at +0 and +0 + -0 = +0 -- so every chain is the A atoms' own)
-    const int n_trip = NQ;
+    const int n_trip = tile_off ? 0 : NQ;   // (no candidate can change this tile: nothing
+                                            // is multiplied, nothing more is asked for)
     int t0 = 0;
     for (; t0 + 8 <= n_trip; t0 += 8) {
         EK_TRIP16(0, t0 + 0)
@@ -443,11 +453,17 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
         // a candidate outside the plan asks for nothing)
         const float tc = ek_far_t_center((float)Gc);
         const int n_here = (int)std::min<int64_t>(n - f0 - wave * EK_WAVE, EK_WAVE);
-        const int fr_lim = cand < teff ? n_here : 0;
+        const int fr_lim = (cand < teff && ((tm >> cand) & 1u)) ? n_here : 0;
 #ifndef EK_P16_W
 #define EK_P16_W 2
 #endif
         constexpr int W = EK_P16_W;     // pairs whose certificates share a basic block
+        if (tile_off) {         // (triangle inequality: every pair of the tile is far)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                Dw[cand * EK_P16_DSTRIDE + 16 * (r >> 2) + 4 * (lane >> 4) + (r & 3)] =
+                    __builtin_inff();
+        } else {
 #pragma unroll
         for (int r0 = 0; r0 < 16; r0 += W) {
             float S[W][9], t[W];
@@ -499,6 +515,7 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
                 }
             }
         }
+        }
         EK_P16_STAMP(3);
 #ifdef EK_P16_STATS     // (measurement build: waves, overflowing waves, queued pairs)
         if (FUSE && lane == 0) {
@@ -549,7 +566,7 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
                     t += S[q];
                 if (t > 3e38f)
                     d = 0.f;
-            } else if (cand < teff && f0 + wave * EK_WAVE + fr < n)
+            } else if (cand < teff && ((tm >> cand) & 1u) && f0 + wave * EK_WAVE + fr < n)
                 d = ek_rmsd_from_S_below(S, s_G[wave * EK_WAVE + fr], Gc, A,
                                          s_cur[wave * EK_WAVE + fr]);
             Dw[cand * EK_P16_DSTRIDE + fr] = d;

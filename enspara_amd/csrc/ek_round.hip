@@ -643,3 +643,129 @@ void ek_launch_round_flush(const EkRound &r, hipStream_t s)
     // nothing is pending any more
     (void)hipMemsetAsync(&r.pend->n, 0, sizeof(int32_t), s);
 }
+
+// ---------------------------------------------------------------------------
+// triangle inequality for rounds (reference kcenters.py:287-296, `use_triangle_
+// inequality`; round 5)
+// ---------------------------------------------------------------------------
+// The reference skips, per new center, the frames whose own center is at least
+// twice their distance away from it.  For a ROUND of T candidates the unit that
+// can be left out is a (tile of 256 frames, candidate) pair: candidate c cannot
+// change any frame of the tile if D(center of f, candidate c) >= 2 d(f) for every
+// frame f of it (margin 0.1 % + 1e-3, as in the one-center form) -- neither as
+// the new center (candidate 0) nor as a kept distance (a kept distance that is
+// not below the frame's own is +inf for every reader).  The certificate holds
+// for a label and distance that are STALE too (the accepted chain still pending,
+// EkPend): d(f) is the frame's distance to the center its label names whatever
+// came later, and the frame's current distance is no larger.
+//   ek_round_ti_centers_kernel   D[label][c] for all centers so far x the round's
+//                                candidates: a wave per center, lane = (candidate,
+//                                quarter of the atoms); summation order free
+//   ek_round_ti_tiles_kernel     per tile the candidates that may still matter
+// A tile with an empty mask is not read by the pass (ek_pass16_kernel: pending
+// chain and maxima only); in a partly masked tile the masked candidates' pairs
+// skip their certificates and solves.  Masks never change a result: a pair that
+// is not masked is simply computed.
+__global__ void __launch_bounds__(EK_BLOCK)
+ek_round_ti_centers_kernel(EkRound r)
+{
+    const EkPlan *plan = r.plan;
+    if (!plan->go)
+        return;
+    const int lane = threadIdx.x & (EK_WAVE - 1);
+    const int l = blockIdx.x * (EK_BLOCK / EK_WAVE) + threadIdx.x / EK_WAVE;
+    const int k = plan->label;          // labels 0 .. k - 1 exist (candidate 0 gets k)
+    if (l >= k)
+        return;
+    const int A = r.A, teff = plan->teff;
+    const int64_t f = r.hist[l].gidx - r.goff;
+    const float *x = r.aos + (size_t)f * 3 * A;
+    const double Gx = r.G[f];
+    const size_t rstride = ek_rec_bytes(A);
+    const int c16 = lane & 15, s = lane >> 4;
+    for (int cb = 0; cb < teff; cb += 16) {
+        const int c = cb + c16;
+        const bool live = c < teff;
+        const float *y = (const float *)(r.recs + (size_t)(live ? c : 0) * rstride +
+                                         sizeof(EkRecHdr));
+        float S[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int a = s; a < A; a += 4) {
+            const float x0 = x[3 * a], x1 = x[3 * a + 1], x2 = x[3 * a + 2];
+            const float y0 = y[3 * a], y1 = y[3 * a + 1], y2 = y[3 * a + 2];
+            S[0] += x0 * y0; S[1] += x0 * y1; S[2] += x0 * y2;
+            S[3] += x1 * y0; S[4] += x1 * y1; S[5] += x1 * y2;
+            S[6] += x2 * y0; S[7] += x2 * y1; S[8] += x2 * y2;
+        }
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            S[q] += __shfl_xor(S[q], 16, 64);
+            S[q] += __shfl_xor(S[q], 32, 64);
+        }
+        if (s == 0 && live)
+            r.ti_tab[(size_t)l * EK_MAX_CANDS + c] =
+                ek_rmsd_from_S(S, Gx, plan->trace[c], A);
+    }
+}
+
+__global__ void __launch_bounds__(EK_BLOCK)
+ek_round_ti_tiles_kernel(EkRound r)
+{
+    __shared__ uint32_t s_need;
+    const EkPlan *plan = r.plan;
+    if (!plan->go)
+        return;
+    if (threadIdx.x == 0)
+        s_need = 0;
+    __syncthreads();
+    const int k = plan->label, teff = plan->teff;
+    const uint32_t all = teff >= 32 ? 0xffffffffu : ((1u << teff) - 1u);
+    const int64_t f = (int64_t)blockIdx.x * EK_BLOCK + threadIdx.x;
+    uint32_t need = 0;
+    if (f < r.n) {
+        const int32_t a = r.assign[f];
+        if (a < 0 || a >= k) {
+            need = all;         // (no center yet, or a label this table does not have)
+        } else {
+            const float thr = 2.0f * r.dist[f] * 1.001f + 1e-3f;
+            const float4 *row = (const float4 *)(r.ti_tab + (size_t)a * EK_MAX_CANDS);
+#pragma unroll
+            for (int q = 0; q < EK_MAX_CANDS / 4; ++q) {
+                if (4 * q >= teff)
+                    break;
+                const float4 v = row[q];
+                need |= (!(v.x >= thr) ? 1u : 0u) << (4 * q);
+                need |= (!(v.y >= thr) ? 2u : 0u) << (4 * q);
+                need |= (!(v.z >= thr) ? 4u : 0u) << (4 * q);
+                need |= (!(v.w >= thr) ? 8u : 0u) << (4 * q);
+            }
+            need &= all;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+        need |= (uint32_t)__shfl_xor((int)need, off, 64);
+    if ((threadIdx.x & (EK_WAVE - 1)) == 0 && need)
+        atomicOr(&s_need, need);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t m = s_need;
+        r.tmask[blockIdx.x] = m;
+        // (honest counts: a partly masked tile is still streamed for all its
+        // candidates; only a tile nobody can change is left out)
+        atomicAdd(&r.ti_stats[0], (unsigned long long)teff);
+        if (m == 0)
+            atomicAdd(&r.ti_stats[1], (unsigned long long)teff);
+    }
+}
+
+void ek_launch_round_ti(const EkRound &r, int max_labels, hipStream_t s)
+{
+    if (r.n <= 0 || !r.tmask || max_labels <= 0)
+        return;
+    const int per = EK_BLOCK / EK_WAVE;
+    hipLaunchKernelGGL(ek_round_ti_centers_kernel, dim3((max_labels + per - 1) / per),
+                       dim3(EK_BLOCK), 0, s, r);
+    hipLaunchKernelGGL(ek_round_ti_tiles_kernel,
+                       dim3((unsigned)((r.n + EK_BLOCK - 1) / EK_BLOCK)), dim3(EK_BLOCK), 0,
+                       s, r);
+}

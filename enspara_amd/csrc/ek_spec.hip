@@ -393,9 +393,18 @@ ek_pass2_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
         }
     }
 
+    // triangle inequality (ek_round_ti_tiles_kernel, round 5): the candidates that
+    // can still change a frame of this tile.  None: the tile's buffer descriptor
+    // gets a length of zero -- every row load then returns zeros without touching
+    // memory -- and no trip runs; masked candidates of a partly masked tile skip
+    // their solves.
+    uint32_t tm = 0xffffffffu;
+    if (UPD && FUSE && fz.tmask)
+        tm = __builtin_amdgcn_readfirstlane(fz.tmask[blockIdx.x]) | (T < 32 ? ~((1u << T) - 1u) : 0u);
+    const bool tile_off = UPD && FUSE && (tm & ((1u << T) - 1u)) == 0u;
     const float *tb = tiles + (size_t)(f0 / EK_TILE) * 3 * (size_t)A * EK_TILE;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)tb, 0, 3 * A * EK_TILE * 4, 0x00020000);
+        (void *)tb, 0, tile_off ? 0 : 3 * A * EK_TILE * 4, 0x00020000);
     const int vo = ((int)(f0 % EK_TILE) + tid) * 4;
     // non-temporal (aux bit 1): the frame stream is read once per pass
 #define EK_LD(SO, K)                                                           \
@@ -427,7 +436,7 @@ ek_pass2_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
         Z[B][h][e] = EK_LD(so, 2);                                             \
         __builtin_amdgcn_sched_barrier(0);  /* same issue order everywhere */  \
     }
-    const int n_trip = A / 4;           // whole trips; A % 4 atoms follow
+    const int n_trip = tile_off ? 0 : A / 4;    // whole trips; A % 4 atoms follow
     const ek_cfp cp = (ek_cfp)ctile;
 #pragma unroll
     for (int k = 0; k < DIST; ++k)
@@ -489,7 +498,7 @@ ek_pass2_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
     }
 #undef EK_TRIP2
     // the A % 4 atoms after the last whole trip
-    for (int a = 4 * n_trip; a < A; ++a) {
+    for (int a = tile_off ? A : 4 * n_trip; a < A; ++a) {
         const int so = a * (3 * EK_TILE * 4);
         ek_v2f x, y, z;
         x[0] = EK_LD(so, 0);
@@ -533,7 +542,8 @@ ek_pass2_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
         for (int j = 0; j < 9; ++j)
             S0[j] = s2[0][j][0];
         float cur = cur0;
-        const float d0 = ek_rmsd_from_S_below(S0, Gf, ctrace[0], A, cur);
+        const float d0 = (tm & 1u) ? ek_rmsd_from_S_below(S0, Gf, ctrace[0], A, cur)
+                                   : __builtin_inff();
         if (d0 < cur) {
             cur = d0;
             lab = label;
@@ -563,7 +573,9 @@ ek_pass2_kernel(const float *__restrict__ tiles, const double *__restrict__ G,
 #pragma unroll
                 for (int j = 0; j < 9; ++j)
                     S[j] = s2[c / 2][j][c & 1];
-                const float dc = ek_rmsd_from_S_below(S, Gf, ctrace[c], A, cur);
+                const float dc = ((tm >> c) & 1u)
+                                     ? ek_rmsd_from_S_below(S, Gf, ctrace[c], A, cur)
+                                     : __builtin_inff();
                 if (FUSE) {
                     if (__ballot(dc != __builtin_inff())) {     // wave-uniform
                         vecs[(size_t)(c - 1) * n_pad + f] = dc;
@@ -681,6 +693,7 @@ void ek_launch_round_pass(const EkRound &r, hipStream_t s, bool with_order)
     fz.ctl = r.ctl;
     fz.rows = r.rows;
     fz.vmask = r.vmask;
+    fz.tmask = r.tmask;
     if (r.T >= 16) {        // (32: the stream twice, ek_pass16.hip)
         ek_launch_pass16(true, r.qtiles, r.G, r.dist, r.assign, r.vecs, r.n, r.n_pad,
                          r.A, r.ctile, r.ctrace, r.plan, r.blockmax, fz, s, r.T == 32);

@@ -348,6 +348,18 @@ class FrameStore:
     def candidates(self):
         return int(self.lib.ek_spec_candidates(self._h))
 
+    def ms_diag(self):
+        """what the last ms_run spent where -> dict (exchanges, re-offers, microseconds
+        waited for the peers' messages / for the own flag, mean microseconds of a
+        sampled round's pass, chain kernel with its exchange, plan kernels)"""
+        cnt = np.zeros(5, dtype=np.int64)
+        ms = np.zeros(3, dtype=np.float64)
+        _lib.check(self.lib.ek_ms_diag(self._h, _lib.i64p(cnt), _lib.f64p(ms)))
+        return {"exchanges": int(cnt[0]), "reoffers": int(cnt[1]),
+                "wait_peers_us": cnt[2] * 0.01, "wait_own_flag_us": cnt[3] * 0.01,
+                "rounds_sampled": int(cnt[4]), "pass_us": ms[0] * 1e3,
+                "chain_with_exchange_us": ms[1] * 1e3, "plan_us": ms[2] * 1e3}
+
     def quad_copy_ready(self):
         """True if the third copy of the frames that rounds of 16 / 32 candidates
         stream exists or could be made now (False: no memory for it)"""

@@ -154,8 +154,9 @@ int ek_kcenters_run(ek_ctx *ctx, int32_t first_label, int32_t max_new,
  * synchronises and reports how many centers exist and whether the stop rule
  * (maximum distance <= dist_cutoff, kcenters.py:217) fired. */
 int ek_spec_candidates(ek_ctx *ctx);
-/* the widest round ek_kcenters_run / ek_ms_run may use (option key 4; 32 by
- * default): ek_spec_candidates is the same for the ek_spec_* protocol (<= 16) */
+/* the widest round ek_kcenters_run / ek_ms_run may use (option key 4; 16 by
+ * default, 32 on request): ek_spec_candidates is the same for the ek_spec_*
+ * protocol (<= 16) */
 int ek_round_candidates(ek_ctx *ctx);
 /* Rounds of 16 / 32 candidates stream a third copy of the frames (the quad copy,
  * 12 * n_atoms bytes per frame), made when first needed.  1: it exists or could
@@ -229,7 +230,7 @@ int ek_spec_chain_apply(ek_ctx *ctx, const void *hdrs_all, int32_t n_shards,
  * on every shard at the same time.  A message that does not arrive within 10 s
  * (of the device's constant 100 MHz clock) is reported as an error (a peer
  * died), not waited for.  With the default option key 4 = -1 the run moves
- * between rounds of 8, 16 and 32 candidates by the centers the rounds of a batch
+ * between rounds of 8 and 16 (with key 4 = 32: and 32) candidates by the centers the rounds of a batch
  * accepted -- numbers every shard sees alike, so every shard takes the same
  * decision at the same round; ek_run_stats reports the mix.  A round of 32 is
  * two passes of 16 over the frames behind ONE plan, chain and exchange (the
@@ -244,6 +245,13 @@ int ek_ms_begin(ek_ctx *ctx, int32_t first_label, int32_t limit);
 int ek_ms_local(ek_ctx *ctx, double dist_cutoff, void *message_out);
 int ek_ms_global(ek_ctx *ctx, double dist_cutoff, const void *messages_all);
 int ek_ms_end(ek_ctx *ctx);
+/* What the last ek_ms_run spent where -- counts[5]: exchanges, exchanges without a
+ * pass (a broken chain offered again), 10 ns ticks waited for the peers' messages
+ * (per exchange the longest wait), ... for the shard's own flag (the floor),
+ * rounds sampled; ms[3]: mean milliseconds of a sampled round's pass, chain
+ * kernel (the exchange's wait inside) and plan kernels.  No reference counterpart
+ * (its MPI iteration, kcenters.py:314-378, is not instrumented). */
+int ek_ms_diag(ek_ctx *ctx, int64_t *counts, double *ms);
 /* mode (0: the run is over), exchanges completed since ek_ms_setup, error */
 int ek_ms_state(ek_ctx *ctx, int32_t *mode, int32_t *exchanges, int32_t *err);
 int ek_ms_run(ek_ctx *ctx, int32_t first_label, int32_t max_new,
@@ -571,7 +579,8 @@ int ek_set_frames_per_lane(ek_ctx *ctx, int fpl);
 /* key 1: non-temporal loads of the frame stream (0/1; -1 = automatic:
  * on when the shard is larger than the Infinity Cache)
  * key 4: candidate centers per round of ek_kcenters_run / ek_ms_* / ek_spec_*:
- * -1 automatic (up to 32, see key 8), 1 = one-center passes, 4, 8, 16, 32 (32:
+ * -1 automatic (up to 16, see key 8), 1 = one-center passes, 4, 8, 16, 32 (32:
+ * only on request -- measured, its second sixteen guesses are accepted too rarely --:
  * the frames streamed twice per round, candidates 0..15 and 16..31; the
  * one-launch-per-step forms -- ek_spec_*, key 5 = 0, key 10 = 0 -- stop at 16)
  * key 2: nearest-center kernel: 0 automatic, 1 vector FMA, 2 MFMA 32x32x2, 3 MFMA
@@ -586,9 +595,13 @@ int ek_set_frames_per_lane(ek_ctx *ctx, int fpl);
  * ek_state_reset + k-centers, false after ek_state_upload / ek_assign_nearest
  * key 7: assert (1) or withdraw (0) that property, e.g. after
  * ek_assign_nearest with the medoid frames themselves as centers
- * key 8: with key 4 = -1, let ek_kcenters_run move between 1, 8, 16 and 32
+ * key 8: with key 4 = -1, let ek_kcenters_run move between 1, 8 and 16
  * candidates per round by measured centers per millisecond: 1 (default) / 0
  * (always the widest form); identical results either way
+ * key 16: ek_pam_sweep's windows of drawn proposals take the proposal-to-medoid
+ * distance table as the lower bounds the medoid-to-medoid table and the
+ * proposals' own distances give (triangle inequality; half the pairs of a
+ * window's tables): 1 (default) / 0 exact distances; identical results
  * key 15: the next round's candidates are chosen among the farthest frames per
  * 64 frames of the state the whole chain leaves (1, default) or per 256 (0: what
  * rounds 2-4 did; a far frame behind a farther one of its 256 is then invisible

@@ -285,14 +285,52 @@ def test_triangle_inequality_is_invisible(ocl):
                 assert list(r.center_indices) == [int(i) for i in want[0]]
                 np.testing.assert_array_equal(r.assignments, want[1])
                 np.testing.assert_array_equal(r.distances, want[2])
-    # the blocks-of-one-template order really skips tiles
+    # the blocks-of-one-template order really skips tiles (one center per pass:
+    # the accounting of round 2 -- a (center, tile) pair per tile and step)
     with FrameStore.from_array(x) as st:
         st.set_option(11, 1)
+        st.set_option(4, 1)
         st.reset_state()
         st.kcenters_run(0, 60, 0.0)
         tiles, skipped = st.ti_stats()
     assert tiles == 59 * ((len(x) + 255) // 256)
     assert skipped > 0.5 * tiles
+
+
+@pytest.mark.parametrize("cands", [16, 32, -1])
+def test_triangle_inequality_in_rounds(ocl, cands):
+    """round 5: with the option on, rounds of 16 / 32 candidates leave out the
+    tiles none of their candidates can change (ek_round_ti_*) instead of falling
+    back to one center per pass.  200 templates of 256 consecutive frames each (a
+    tile per template): once every template has a center a candidate matters to
+    its own tile only.  Same centers, labels, distances as the plain run and the
+    oracle -- time-ordered and shuffled, count and cut-off -- and most (tile,
+    candidate) pairs are left out on the ordered frames."""
+    from enspara_amd.cluster import kcenters as kc
+    from enspara_amd.device import FrameStore
+    rng = np.random.RandomState(4)
+    A, T, per = 20, 200, 256
+    tmpl = synth.templates(T, A, 9)
+    x = np.concatenate([tmpl[t] + rng.normal(scale=0.05, size=(per, A, 3))
+                        for t in range(T)]).astype(np.float32)
+    for ordered, order in ((True, np.arange(len(x))), (False, rng.permutation(len(x)))):
+        xx = np.ascontiguousarray(x[order])
+        for n_clusters, cutoff in ((500, 0.0), (np.inf, 0.17)):
+            want = ocl.kcenters(xx, n_clusters=None if np.isinf(n_clusters) else n_clusters,
+                                dist_cutoff=cutoff or None)
+            for tri in (0, 1):
+                with FrameStore.from_array(xx) as st:
+                    st.set_option(4, cands)
+                    r = kc._kcenters_device(xx, n_clusters, cutoff, None, 0, store=st,
+                                            use_triangle_inequality=bool(tri))
+                    tiles, skipped = st.ti_stats()
+                assert list(r.center_indices) == [int(i) for i in want[0]]
+                np.testing.assert_array_equal(r.assignments, want[1])
+                np.testing.assert_array_equal(r.distances, want[2])
+                if tri and ordered and cutoff == 0.0:
+                    assert tiles > 0 and skipped > 0.5 * tiles, (tiles, skipped)
+                if not tri:
+                    assert tiles == 0
 
 
 def test_adaptive_run_never_passes_its_goal(ocl):

@@ -653,3 +653,15 @@ def test_bench_two_ranks_on_one_device():
     assert d["config"]["world_size"] == 2 and d["value"] > 0
     assert "mailbox" in d["config"]["sharding"]
     assert d["roofline"]["frac"] > 0 and d["config"]["frames_total"] == 120000
+    # what every rank spent where (round 5): a scaling curve that explains itself
+    pr = d["per_rank"]
+    assert [r["rank"] for r in pr] == [0, 1]
+    for r in pr:
+        assert r["transport"] == "mailbox" and r["frames"] > 0
+        assert r["exchanges"] > 0 and r["exchanges_without_a_pass"] >= 0
+        assert r["wait_for_peers_us_per_exchange"] >= r["wait_for_own_flag_us_per_exchange"] >= 0
+        sr = r["sampled_round_us"]
+        assert sr["rounds_sampled"] > 0 and sr["pass"] > 0
+        assert sr["chain_with_exchange"] > 0 and sr["plan"] > 0
+        assert sum(v["centers"] for v in r["rounds_by_candidates"].values()) == 600
+        assert len(r["can_access_peer"]) >= 1

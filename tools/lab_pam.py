@@ -52,7 +52,17 @@ def child(path, K, reps, sweeps):
     for p in PHASES:
         timed(p)
     sums = set()
-    for rep in range(reps):
+    # LAB_PAM_OPTS="key=value,..;key=value,.." : a run per option set (ek_set_option),
+    # e.g. "16=1;16=0" = the window tables as bounds / exact
+    optsets = [dict((int(kv.split("=")[0]), int(kv.split("=")[1]))
+                    for kv in o.split(",") if kv)
+               for o in os.environ.get("LAB_PAM_OPTS", "").split(";")]
+    for rep in range(reps * len(optsets)):
+        opts = optsets[rep % len(optsets)]
+        for k_, v_ in opts.items():
+            st.set_option(k_, v_)
+        name = os.path.basename(os.environ.get("ENSPARA_HIP_LIB", "default")) + \
+            (" " + str(opts) if opts else "")
         st.reset_state()
         idx, cd, mx = st.kcenters_run(0, K, 0.0)
         med = [int(i) for i in idx]

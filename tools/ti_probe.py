@@ -20,9 +20,10 @@ for t in range(T):
     x[t * per:(t + 1) * per] = tmpl[t] + rng.normal(scale=0.05, size=(per, A, 3))
 with FrameStore.from_array(x) as st:
     res = {}
-    for name, tri in (("default", 0), ("triangle", 1), ("one center per pass", 2)):
-        st.set_option(11, 1 if tri == 1 else 0)
-        st.set_option(4, 1 if tri == 2 else -1)
+    for name, tri in (("default", 0), ("triangle", 1), ("one center per pass", 2),
+                      ("triangle, one center per pass (round 4)", 3)):
+        st.set_option(11, 1 if tri in (1, 3) else 0)
+        st.set_option(4, 1 if tri >= 2 else -1)
         st.reset_state()
         st.sync()
         t0 = time.perf_counter()
@@ -31,11 +32,11 @@ with FrameStore.from_array(x) as st:
         d, a = st.download_state()
         res[name] = (idx, d, a)
         extra = ""
-        if tri == 1:
+        if tri in (1, 3):
             tiles, skipped = st.ti_stats()
             extra = "  tiles %d, skipped %d (%.1f %%)" % (tiles, skipped,
                                                           100.0 * skipped / max(tiles, 1))
-        print("%-20s %d frames x %d atoms, %d centers: %.3f s  %.3e pairs/s%s"
+        print("%-40s %d frames x %d atoms, %d centers: %.3f s  %.3e pairs/s%s"
               % (name, len(x), A, K, dt, len(x) * K / dt, extra), flush=True)
     a0 = res["default"]
     for k, v in res.items():
