@@ -482,6 +482,12 @@ extern "C" int ek_set_option(ek_ctx *c, int32_t key, int32_t value)
             return ek_fail(EK_EARG, "ek_set_option: pairs one workgroup searches >= 0");
         c->sp_max_pairs = value;
         return EK_OK;
+    case 17:
+        if (value < 0 || value > 16)
+            return ek_fail(EK_EARG, "ek_set_option: far frames per label on the pick's list "
+                                    "0 (by the yield) or 1 .. 16");
+        c->pick_cap = value;
+        return EK_OK;
     case 16:
         if (value != 0 && value != 1)
             return ek_fail(EK_EARG, "ek_set_option: PAM tables as bounds 0 or 1");
@@ -1059,6 +1065,16 @@ static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
     bool pending = false;       // a fused round may have left a chain to apply
     int ti_pause = 0, ti_pause_next = 2;            // batches without masks / the next pause
     bool masks_fresh = false;   // ti_tmask describes the plan the next pass will run
+    // How many far frames per label the candidate pick keeps (ek_top_dev.h): 4 suits
+    // frames in clouds around templates, 16 a continuous landscape (round 5: the
+    // walk 1.3e10 -> 2.5e10 pairs/s).  By the yield the rounds show: a batch that
+    // accepts under 80 % of its guesses lets the next batch of the same form try the
+    // other value; the better one stays, a look that loses waits twice as long.
+    int cap = c->pick_cap > 0 ? c->pick_cap : 4;
+    const bool cap_adaptive = c->pick_cap <= 0;
+    bool cap_probing = false;
+    int cap_wait = 0, cap_next_wait = 1, cap_form = 0;
+    double cap_yield_home = 0.0;
     unsigned long long ti_seen[2] = {0, 0};         // the counters at the last look
     EK_HIP(hipEventRecord(c->ev0, c->stream));
     EkCtl cr;
@@ -1076,6 +1092,7 @@ static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
         // many batches each time a look finds nothing again)
         const bool masks = tri && fused && form >= 4 && ti_pause == 0;
         R.tmask = masks ? c->ti_tmask : nullptr;
+        R.pick_cap = cap;
         // ---- the record(s) this form starts from -------------------------------------
         if (held != form) {
             if (pending) {      // leaving a fused form: the state as it stands
@@ -1229,6 +1246,26 @@ static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
             break;
         if (!one)
             per_round = std::max(1.0, (double)got / std::max(ran, 1));
+        if (cap_adaptive && !one && fused && ran > 0 && !probing) {
+            const double yield = (double)got / ((double)ran * form);
+            if (cap_probing) {
+                cap_probing = false;
+                if (form == cap_form && yield > cap_yield_home + 0.05) {
+                    cap_next_wait = 1;          // the other value is home now
+                } else {
+                    cap = cap == 4 ? 16 : 4;    // back
+                    cap_wait = cap_next_wait;
+                    cap_next_wait = std::min(2 * cap_next_wait, 64);
+                }
+            } else if (cap_wait > 0) {
+                --cap_wait;
+            } else if (yield < 0.8 && left > 4 * form) {
+                cap_yield_home = yield;
+                cap_form = form;
+                cap = cap == 4 ? 16 : 4;
+                cap_probing = true;
+            }
+        }
         if (!adaptive)
             continue;
         // ---- which form next ---------------------------------------------------------

@@ -269,6 +269,7 @@ static void ek_round_of(ek_ctx *c, int T, double cutoff, EkRound &R)
     R.rows = c->rows;
     R.vmask = c->vmask;
     R.cutoff = cutoff;
+    R.pick_cap = c->pick_cap > 0 ? c->pick_cap : 4;
 }
 
 extern "C" int ek_ms_setup(ek_ctx *c, int32_t world, int32_t rank,
@@ -605,6 +606,14 @@ extern "C" int ek_ms_run(ek_ctx *c, int32_t first_label, int32_t max_new,
     double per_round = 0.6 * T;
     int32_t rounds_before = 0, passes = 0;
     int wait16 = 0, next_wait = 1, wait32 = 0, next_wait32 = 1;
+    // (far frames per label on the pick's list, 4 <-> 16 by the yield: as in
+    // ek_run_rounds, from numbers every shard sees alike)
+    int cap = c->pick_cap > 0 ? c->pick_cap : 4;
+    const bool cap_adaptive = c->pick_cap <= 0;
+    bool cap_probing = false;
+    int cap_wait = 0, cap_next_wait = 1, cap_form = 0;
+    double cap_yield_home = 0.0;
+    R.pick_cap = cap;
     for (int k = 0; k < EK_N_FORMS; ++k)
         c->st_rounds[k] = c->st_centers[k] = 0;
     // (the run's own counters: ek_ms_diag)
@@ -652,6 +661,27 @@ extern "C" int ek_ms_run(ek_ctx *c, int32_t first_label, int32_t max_new,
         if (st.err || st.mode == 0 || cr.stopped || cr.n_done >= goal)
             break;
         per_round = std::max(1.0, (double)(cr.n_done - before) / std::max(ran, 1));
+        if (cap_adaptive && ran > 0) {
+            const double yield = (double)(cr.n_done - before) / ((double)ran * T);
+            if (cap_probing) {
+                cap_probing = false;
+                if (T == cap_form && yield > cap_yield_home + 0.05) {
+                    cap_next_wait = 1;
+                } else {
+                    cap = cap == 4 ? 16 : 4;
+                    cap_wait = cap_next_wait;
+                    cap_next_wait = std::min(2 * cap_next_wait, 64);
+                }
+            } else if (cap_wait > 0) {
+                --cap_wait;
+            } else if (yield < 0.8 && goal - cr.n_done > 4 * T) {
+                cap_yield_home = yield;
+                cap_form = T;
+                cap = cap == 4 ? 16 : 4;
+                cap_probing = true;
+            }
+            R.pick_cap = cap;
+        }
         if (ladder && ran > 0) {
             int want = T;
             if (T == 8) {
@@ -686,6 +716,7 @@ extern "C" int ek_ms_run(ek_ctx *c, int32_t first_label, int32_t max_new,
                     return rc;
                 T = want;
                 ek_round_of(c, T, dist_cutoff, R);
+                R.pick_cap = cap;
                 rounds_before = 0;
                 per_round = std::max(per_round, 0.6 * T);
             }

@@ -162,6 +162,7 @@ struct EkRound {
     float *ti_tab = nullptr;    // [labels][EK_MAX_CANDS] center-to-candidate distances
     uint32_t *tmask = nullptr;  // [tiles] candidates that can still change the tile
     unsigned long long *ti_stats = nullptr; // [0] (tile, candidate) pairs looked at, [1] left out
+    int pick_cap = 4;           // far frames kept per label by the candidate pick (ek_top_dev.h)
 };
 // the masks of the round the plan describes (after ek_launch_round_next)
 void ek_launch_round_ti(const EkRound &r, int max_labels, hipStream_t s);

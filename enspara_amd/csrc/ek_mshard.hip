@@ -351,7 +351,7 @@ ek_ms_chain_kernel(EkRound r, EkMsState *ms, EkMsXchg x, int nblk)
     const EkBlockMax *state = fine ? r.fm
                                    : (ps == 0 ? r.blockmax : r.pm + (size_t)(ps - 1) * nb);
     EkTop *top = (EkTop *)r.top;
-    ek_pick_top_body<true>(state, fine ? 4 * nb : nb, top, skip, r.assign);
+    ek_pick_top_body<true>(state, fine ? 4 * nb : nb, top, skip, r.assign, r.pick_cap);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     // the list for the helpers, and the head of the message: this workgroup's part

@@ -244,7 +244,7 @@ ek_round_chain_kernel(EkRound r, int bootstrap)
                                    : (na == 0 ? r.blockmax : r.pm + (size_t)(na - 1) * nb);
     EkTop *top = (EkTop *)r.top;
     EK_STAMP(4);
-    ek_pick_top_body<true>(state, fine ? 4 * nb : nb, top, skip, r.assign);
+    ek_pick_top_body<true>(state, fine ? 4 * nb : nb, top, skip, r.assign, r.pick_cap);
 #ifdef EK_ROUND_STAMPS
     __syncthreads();
     EK_STAMP(5);

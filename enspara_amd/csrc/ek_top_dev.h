@@ -136,8 +136,16 @@ __device__ unsigned long long ek_pick_st[8];
 template <bool COH = false>
 __device__ __forceinline__ void ek_pick_top_body(const EkBlockMax *blockmax, int nb,
                                                  EkTop *top, uint32_t *skip,
-                                                 const int32_t *assign = nullptr)
+                                                 const int32_t *assign = nullptr,
+                                                 int cap = EK_PICK_PER_LABEL)
 {
+    // `cap`: maxima kept per label, 1 .. 16 (round 5: a run-time choice.  Four is
+    // right where frames come in clouds around templates -- more floods the list
+    // with one cloud's frames --, sixteen where they lie on a continuous landscape
+    // and a label's region holds many far directions: bench.py --data walk 1.3e10 ->
+    // 2.5e10 pairs/s; the drivers choose by the yield they see, ek_run_rounds)
+    cap = cap < 1 ? 1 : (cap > 16 ? 16 : cap);
+    const unsigned int slots = (unsigned int)(EK_PICK_PER_LABEL * EK_PICK_SLOTS) / (unsigned int)cap;
     // (`skip` is not used any more: round 5 keeps a thread's PICK_PER largest
     // entries whatever the number of entries, where a list of more than 8192 used
     // to fall back to 64 sequential looks)
@@ -255,20 +263,17 @@ __device__ __forceinline__ void ek_pick_top_body(const EkBlockMax *blockmax, int
         }
         if (mine > 0.f)
             atomicMax(&s_maxbits, __float_as_uint(mine));
-#pragma unroll
-        for (int r = 0; r < EK_PICK_PER_LABEL; ++r) {
+        for (int r = 0; r < cap; ++r) {
 #pragma unroll
             for (int k = 0; k < PICK_PER && k < per; ++k)
                 if (key[k] && won[k] < 0)
-                    atomicMax(&tab[EK_PICK_PER_LABEL *
-                                       ((unsigned int)lab[k] % EK_PICK_SLOTS) + r],
+                    atomicMax(&tab[(unsigned int)cap * ((unsigned int)lab[k] % slots) + r],
                               key[k]);
             __syncthreads();
 #pragma unroll
             for (int k = 0; k < PICK_PER && k < per; ++k)
                 if (key[k] && won[k] < 0 &&
-                    tab[EK_PICK_PER_LABEL * ((unsigned int)lab[k] % EK_PICK_SLOTS) +
-                        r] == key[k])
+                    tab[(unsigned int)cap * ((unsigned int)lab[k] % slots) + r] == key[k])
                     won[k] = r;
         }
         // the overall first-index arg-max, exactly: the keys round the values,

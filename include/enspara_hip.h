@@ -598,6 +598,11 @@ int ek_set_frames_per_lane(ek_ctx *ctx, int fpl);
  * key 8: with key 4 = -1, let ek_kcenters_run move between 1, 8 and 16
  * candidates per round by measured centers per millisecond: 1 (default) / 0
  * (always the widest form); identical results either way
+ * key 17: how many of a label's farthest frames the candidate pick of a round may
+ * list (the list of 64 the guesses are chosen from): 0 (default) = 4 or 16 by the
+ * share of its guesses the run sees accepted (4 suits frames in clouds around
+ * templates, 16 a continuous landscape), 1 .. 16 fixed; guesses only, identical
+ * results
  * key 16: ek_pam_sweep's windows of drawn proposals take the proposal-to-medoid
  * distance table as the lower bounds the medoid-to-medoid table and the
  * proposals' own distances give (triangle inequality; half the pairs of a
