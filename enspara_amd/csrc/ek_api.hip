@@ -1068,12 +1068,14 @@ static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
     // How many far frames per label the candidate pick keeps (ek_top_dev.h): 4 suits
     // frames in clouds around templates, 16 a continuous landscape (round 5: the
     // walk 1.3e10 -> 2.5e10 pairs/s).  By the yield the rounds show: a batch that
-    // accepts under 80 % of its guesses lets the next batch of the same form try the
-    // other value; the better one stays, a look that loses waits twice as long.
+    // accepts under 65 % of its guesses lets the next batch of the same form try the
+    // other value; it stays if it accepts a tenth more, a look that loses waits twice
+    // as long (80 % and a twentieth cost the ladder on template data 9 % at 125 000
+    // frames: the early rounds of 8 sit just under 80 % there).
     int cap = c->pick_cap > 0 ? c->pick_cap : 4;
     const bool cap_adaptive = c->pick_cap <= 0;
     bool cap_probing = false;
-    int cap_wait = 0, cap_next_wait = 1, cap_form = 0;
+    int cap_wait = 0, cap_next_wait = 2, cap_form = 0;
     double cap_yield_home = 0.0;
     unsigned long long ti_seen[2] = {0, 0};         // the counters at the last look
     EK_HIP(hipEventRecord(c->ev0, c->stream));
@@ -1250,8 +1252,8 @@ static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
             const double yield = (double)got / ((double)ran * form);
             if (cap_probing) {
                 cap_probing = false;
-                if (form == cap_form && yield > cap_yield_home + 0.05) {
-                    cap_next_wait = 1;          // the other value is home now
+                if (form == cap_form && yield > cap_yield_home + 0.1) {
+                    cap_next_wait = 2;          // the other value is home now
                 } else {
                     cap = cap == 4 ? 16 : 4;    // back
                     cap_wait = cap_next_wait;
@@ -1259,7 +1261,7 @@ static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
                 }
             } else if (cap_wait > 0) {
                 --cap_wait;
-            } else if (yield < 0.8 && left > 4 * form) {
+            } else if (yield < 0.65 && left > 4 * form) {
                 cap_yield_home = yield;
                 cap_form = form;
                 cap = cap == 4 ? 16 : 4;

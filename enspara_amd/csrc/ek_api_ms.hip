@@ -573,8 +573,10 @@ extern "C" int ek_ms_run(ek_ctx *c, int32_t first_label, int32_t max_new,
     // the forms by measured centers per ms; here every shard has to take the
     // SAME decision at the same round, so it is taken from what they all see
     // alike: the centers the rounds of a batch accepted.  Rounds of 8 while they
-    // accept fewer than 6.5; a batch of 16 that accepts fewer than 8.5 per round
-    // goes back to 8 and the next try waits twice as many batches.  A change of
+    // accept fewer than 4.5; a batch of 16 that accepts fewer than 5.5 per round
+    // goes back to 8 and the next try waits twice as many batches (round 4: 6.5 and
+    // 8.5 -- with the exchange's tails a round of 16 costs only 1.3 x a round of 8 on
+    // a 125 000-frame shard, and the ladder lost 7 % to staying narrow too long).  A change of
     // form costs one exchange without a pass (the state's farthest frames are
     // offered again).  Results do not depend on the form.
     // Round 5: rounds of 32 -- two passes of 16 behind ONE plan, chain and
@@ -611,7 +613,7 @@ extern "C" int ek_ms_run(ek_ctx *c, int32_t first_label, int32_t max_new,
     int cap = c->pick_cap > 0 ? c->pick_cap : 4;
     const bool cap_adaptive = c->pick_cap <= 0;
     bool cap_probing = false;
-    int cap_wait = 0, cap_next_wait = 1, cap_form = 0;
+    int cap_wait = 0, cap_next_wait = 2, cap_form = 0;
     double cap_yield_home = 0.0;
     R.pick_cap = cap;
     for (int k = 0; k < EK_N_FORMS; ++k)
@@ -665,8 +667,8 @@ extern "C" int ek_ms_run(ek_ctx *c, int32_t first_label, int32_t max_new,
             const double yield = (double)(cr.n_done - before) / ((double)ran * T);
             if (cap_probing) {
                 cap_probing = false;
-                if (T == cap_form && yield > cap_yield_home + 0.05) {
-                    cap_next_wait = 1;
+                if (T == cap_form && yield > cap_yield_home + 0.1) {
+                    cap_next_wait = 2;
                 } else {
                     cap = cap == 4 ? 16 : 4;
                     cap_wait = cap_next_wait;
@@ -674,7 +676,7 @@ extern "C" int ek_ms_run(ek_ctx *c, int32_t first_label, int32_t max_new,
                 }
             } else if (cap_wait > 0) {
                 --cap_wait;
-            } else if (yield < 0.8 && goal - cr.n_done > 4 * T) {
+            } else if (yield < 0.65 && goal - cr.n_done > 4 * T) {
                 cap_yield_home = yield;
                 cap_form = T;
                 cap = cap == 4 ? 16 : 4;
@@ -687,10 +689,10 @@ extern "C" int ek_ms_run(ek_ctx *c, int32_t first_label, int32_t max_new,
             if (T == 8) {
                 if (wait16 > 0)
                     --wait16;
-                else if (per_round >= 6.5)
+                else if (per_round >= 4.5)
                     want = 16;
             } else if (T == 16) {
-                if (per_round < 8.5) {
+                if (per_round < 5.5) {
                     want = 8;
                     wait16 = next_wait;
                     next_wait = std::min(2 * next_wait, 64);

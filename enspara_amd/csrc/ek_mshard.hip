@@ -128,7 +128,7 @@ __device__ __forceinline__ const unsigned char *ek_ms_src(const EkMsXchg &x, int
 // workgroups they wait for, which in turn wait for nobody: no residency
 // assumption.)
 #define EK_MS_HELPERS 16
-struct EkMsPub {            // the list, published for the helpers (in r.top + 1024)
+struct EkMsPub {            // the list, published for the helpers (in r.top + 2048)
     int32_t n_off;
     int32_t pad[3];
     uint32_t idx[EK_TOP_M];
@@ -152,7 +152,7 @@ ek_ms_chain_kernel(EkRound r, EkMsState *ms, EkMsXchg x, int nblk)
     const int n_dst = x.sys ? x.world : 1;
     const size_t slot = x.sys ? (size_t)(seq & 1u) * x.world + x.rank : 0;
     const size_t head_bytes = sizeof(EkMsMsg) + EK_MAX_CANDS * sizeof(EkMaxHdr);
-    EkMsPub *pub = (EkMsPub *)(r.top + 1024);
+    EkMsPub *pub = (EkMsPub *)(r.top + 2048);
     if ((int)blockIdx.x >= nblk) {
         // ---- a helper: records h, h + H, .. of the list, to every destination ----------
         const int h = (int)blockIdx.x - nblk;

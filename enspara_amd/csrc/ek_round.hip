@@ -244,7 +244,7 @@ ek_round_chain_kernel(EkRound r, int bootstrap)
                                    : (na == 0 ? r.blockmax : r.pm + (size_t)(na - 1) * nb);
     EkTop *top = (EkTop *)r.top;
     EK_STAMP(4);
-    ek_pick_top_body<true>(state, fine ? 4 * nb : nb, top, skip, r.assign, r.pick_cap);
+    ek_pick_top_body<true>(state, fine ? 4 * nb : nb, top, skip, r.assign, r.pick_cap, EK_LIST_M);
 #ifdef EK_ROUND_STAMPS
     __syncthreads();
     EK_STAMP(5);
@@ -325,7 +325,7 @@ ek_round_next_kernel(EkRound r, int bootstrap)
         // stride over the atoms (summation order is free)
         const int lane = tid & (EK_WAVE - 1);
         const int w = blockIdx.x * (EK_BLOCK / EK_WAVE) + tid / EK_WAVE;
-        const int i = w / EK_TOP_M, j = w % EK_TOP_M;
+        const int i = w / EK_LIST_M, j = w % EK_LIST_M;
         if (i < j && j < top->n) {
             const int A = r.A;
             // straight from the frame-major copy: 12 A contiguous bytes each
@@ -349,65 +349,92 @@ ek_round_next_kernel(EkRound r, int bootstrap)
                                                r.G[top->idx[j]], A);
                 // (read by the last workgroup of this launch: coherent stores)
                 float *D = ek_top_D(r.top, A);
-                ek_coh_store(&D[i * EK_TOP_M + j], d);
-                ek_coh_store(&D[j * EK_TOP_M + i], d);
+                ek_coh_store(&D[i * EK_LIST_M + j], d);
+                ek_coh_store(&D[j * EK_LIST_M + i], d);
             }
         }
     }
     if (!ek_arrive_last_tree(r.tick + 2, r.tick + 64))
         return;
     // ---- the next round ----------------------------------------------------------
-    __shared__ float sD[EK_TOP_M * EK_TOP_M];
-    __shared__ float sval[EK_TOP_M];
-    __shared__ uint32_t sidx[EK_TOP_M];
+    extern __shared__ float sD[];               // [EK_LIST_M][EK_LIST_M]
+    __shared__ float sval[EK_LIST_M];
+    __shared__ uint32_t sidx[EK_LIST_M];
     __shared__ int sel[EK_MAX_CANDS];
     __shared__ int n_sel;
     {
-        // the table of pairwise distances: 16 coherent loads per thread, all in
-        // flight before the first is used
+        // the table of pairwise distances: coherent loads, all in flight before the
+        // first is used
         const float *D = ek_top_D(r.top, r.A);
-        constexpr int PER = EK_TOP_M * EK_TOP_M / EK_BLOCK;
-        float dreg[PER];
+        constexpr int PER = EK_LIST_M * EK_LIST_M / EK_BLOCK;
+        constexpr int CHUNK = PER < 16 ? PER : 16;
+        for (int u0 = 0; u0 < PER; u0 += CHUNK) {
+            float dreg[CHUNK];
 #pragma unroll
-        for (int u = 0; u < PER; ++u)
-            dreg[u] = ek_coh_load(&D[tid + u * EK_BLOCK]);
-        if (tid < EK_TOP_M) {
+            for (int u = 0; u < CHUNK; ++u)
+                dreg[u] = ek_coh_load(&D[tid + (u0 + u) * EK_BLOCK]);
+#pragma unroll
+            for (int u = 0; u < CHUNK; ++u)
+                sD[tid + (u0 + u) * EK_BLOCK] = dreg[u];
+        }
+        if (tid < EK_LIST_M) {
             sval[tid] = top->val[tid];
             sidx[tid] = top->idx[tid];
         }
         if (tid < EK_MAX_CANDS)
             sel[tid] = 0;
-#pragma unroll
-        for (int u = 0; u < PER; ++u)
-            sD[tid + u * EK_BLOCK] = dreg[u];
     }
     __syncthreads();
     if (tid < EK_WAVE) {
         // greedy order (ek_top_records_kernel): the frame with the largest
         // remaining distance, then every other one's is lowered by its distance
         // to it.  Entry 0 is the shard's first-index arg-max whatever D says.
+        // (a lane holds entries lane, lane + 64, ..)
+        constexpr int EPL = EK_LIST_M / EK_WAVE;
         const int nt = top->n;
         const int lane = tid;
-        bool open = lane < nt;
-        float cur = open ? sval[lane] : 0.f;
-        const uint32_t ix = sidx[lane];
+        bool open[EPL];
+        float cur[EPL];
+        uint32_t ix[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            open[e] = lane + e * EK_WAVE < nt;
+            cur[e] = open[e] ? sval[lane + e * EK_WAVE] : 0.f;
+            ix[e] = sidx[lane + e * EK_WAVE];
+        }
         int ns = 0;
         while (ns < T) {
-            float v = open ? cur : -__builtin_inff();
-            uint32_t i = open ? ix : 0xffffffffu;
+            float v = -__builtin_inff();
+            uint32_t i = 0xffffffffu;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e)
+                if (open[e] && ek_better(cur[e], ix[e], v, i)) {
+                    v = cur[e];
+                    i = ix[e];
+                }
             ek_wave_argmax(v, i);
             if (i == 0xffffffffu)
                 break;
-            const unsigned long long who = __ballot(open && ix == i);
-            const int best = __ffsll((long long)who) - 1;
-            if (lane == best)
-                open = false;
+            int best = -1;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                const unsigned long long who = __ballot(open[e] && ix[e] == i);
+                if (who && best < 0)
+                    best = e * EK_WAVE + (__ffsll((long long)who) - 1);
+            }
+#pragma unroll
+            for (int e = 0; e < EPL; ++e)
+                if (lane + e * EK_WAVE == best)
+                    open[e] = false;
             if (lane == 0)
                 sel[ns] = best;
             ++ns;
-            const float d = sD[best * EK_TOP_M + lane];
-            if (open && d < cur)
-                cur = d;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                const float d = sD[best * EK_LIST_M + lane + e * EK_WAVE];
+                if (open[e] && d < cur[e])
+                    cur[e] = d;
+            }
         }
         if (lane == 0)
             n_sel = ns;
@@ -561,25 +588,37 @@ void ek_launch_round_next(const EkRound &r, int bootstrap, hipStream_t s)
 {
     if (r.n <= 0)
         return;
-    const unsigned blocks = (unsigned)(EK_TOP_M * EK_TOP_M / (EK_BLOCK / EK_WAVE));
+    const unsigned blocks = (unsigned)(EK_LIST_M * EK_LIST_M / (EK_BLOCK / EK_WAVE));
+    const size_t lds = (size_t)EK_LIST_M * EK_LIST_M * sizeof(float);
+#define EK_NEXT_LDS(TT)                                                        \
+    if (lds > 48 * 1024)                                                       \
+        (void)hipFuncSetAttribute((const void *)ek_round_next_kernel<TT>,      \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
     if (r.T >= 16) {
         const int halves = r.T / 16;
-        if (r.T == 32)
-            hipLaunchKernelGGL((ek_round_next_kernel<32>), dim3(blocks), dim3(EK_BLOCK), 0,
+        if (r.T == 32) {
+            EK_NEXT_LDS(32);
+            hipLaunchKernelGGL((ek_round_next_kernel<32>), dim3(blocks), dim3(EK_BLOCK), lds,
                                s, r, bootstrap);
-        else
-            hipLaunchKernelGGL((ek_round_next_kernel<16>), dim3(blocks), dim3(EK_BLOCK), 0,
+        } else {
+            EK_NEXT_LDS(16);
+            hipLaunchKernelGGL((ek_round_next_kernel<16>), dim3(blocks), dim3(EK_BLOCK), lds,
                                s, r, bootstrap);
+        }
         const unsigned wgs =
             (unsigned)(halves * ((ek_ctile_atoms(r.A) / 16 * 3 + 3) / 4) + r.T);
         hipLaunchKernelGGL(ek_round_ctile16_kernel, dim3(wgs), dim3(EK_BLOCK), 0, s, r,
                            halves);
-    } else if (r.T == 8)
-        hipLaunchKernelGGL((ek_round_next_kernel<8>), dim3(blocks), dim3(EK_BLOCK), 0,
+    } else if (r.T == 8) {
+        EK_NEXT_LDS(8);
+        hipLaunchKernelGGL((ek_round_next_kernel<8>), dim3(blocks), dim3(EK_BLOCK), lds,
                            s, r, bootstrap);
-    else
-        hipLaunchKernelGGL((ek_round_next_kernel<4>), dim3(blocks), dim3(EK_BLOCK), 0,
+    } else {
+        EK_NEXT_LDS(4);
+        hipLaunchKernelGGL((ek_round_next_kernel<4>), dim3(blocks), dim3(EK_BLOCK), lds,
                            s, r, bootstrap);
+    }
+#undef EK_NEXT_LDS
 }
 
 // ---------------------------------------------------------------------------

@@ -1034,9 +1034,10 @@ void ek_launch_apply(const float *vecs, const double *G, int64_t n,
 // labels.)
 size_t ek_top_scratch_bytes(int A)
 {
-    // EkTop | coords [M][3A] f32 | traces [M] f64 | D [M][M] f32
-    return 1024 + (size_t)EK_TOP_M * 3 * A * sizeof(float) +
-           EK_TOP_M * sizeof(double) + (size_t)EK_TOP_M * EK_TOP_M * sizeof(float);
+    // EkTop | EkMsPub | coords [M][3A] f32 | traces [M] f64 | D [L][L] f32 (L = the
+    // fused round's list, >= M)
+    return EK_TOP_HEAD + (size_t)EK_TOP_M * 3 * A * sizeof(float) +
+           EK_TOP_M * sizeof(double) + (size_t)EK_LIST_M * EK_LIST_M * sizeof(float);
 }
 
 __global__ void __launch_bounds__(EK_RED_THREADS)

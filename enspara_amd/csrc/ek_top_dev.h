@@ -74,25 +74,35 @@ __device__ __forceinline__ void ek_block_argmax(const EkBlockMax *blockmax,
 }
 
 #define EK_TOP_M 64
+// the list the fused single-shard round chooses its candidates from (ek_round.hip):
+// EK_TOP_M, or 128 in measurement builds (-DEK_LIST_M=128: the greedy choice then
+// runs over 128 entries with 8128 pairwise distances; the one-launch-per-step forms
+// and the rounds across shards keep 64)
+#ifndef EK_LIST_M
+#define EK_LIST_M 64
+#endif
+static_assert(EK_LIST_M == 64 || EK_LIST_M == 128, "one or two list entries per lane");
+#define EK_TOP_HEAD 4096    // bytes of the scratch area before the coordinates
 
 struct EkTop {
     int32_t n;
     int32_t pad;
-    uint32_t idx[EK_TOP_M];
-    float val[EK_TOP_M];
+    uint32_t idx[EK_LIST_M];
+    float val[EK_LIST_M];
 };
+static_assert(sizeof(EkTop) <= 2048, "EkMsPub sits at + 2048");
 
 __device__ __forceinline__ float *ek_top_coords(unsigned char *scr)
 {
-    return (float *)(scr + 1024);
+    return (float *)(scr + EK_TOP_HEAD);
 }
 __device__ __forceinline__ double *ek_top_traces(unsigned char *scr, int A)
 {
-    return (double *)(scr + 1024 + (size_t)EK_TOP_M * 3 * A * sizeof(float));
+    return (double *)(scr + EK_TOP_HEAD + (size_t)EK_TOP_M * 3 * A * sizeof(float));
 }
 __device__ __forceinline__ float *ek_top_D(unsigned char *scr, int A)
 {
-    return (float *)(scr + 1024 + (size_t)EK_TOP_M * 3 * A * sizeof(float) +
+    return (float *)(scr + EK_TOP_HEAD + (size_t)EK_TOP_M * 3 * A * sizeof(float) +
                      EK_TOP_M * sizeof(double));
 }
 
@@ -123,7 +133,7 @@ __device__ unsigned long long ek_pick_st[8];
 // always the overall first-index arg-max: it holds slot 0 of the pool by
 // construction.
 #ifndef EK_PICK_POOL
-#define EK_PICK_POOL 128
+#define EK_PICK_POOL (2 * EK_LIST_M)
 #endif
 #ifndef EK_PICK_PER_LABEL
 #define EK_PICK_PER_LABEL 4     // maxima kept per label
@@ -137,7 +147,8 @@ template <bool COH = false>
 __device__ __forceinline__ void ek_pick_top_body(const EkBlockMax *blockmax, int nb,
                                                  EkTop *top, uint32_t *skip,
                                                  const int32_t *assign = nullptr,
-                                                 int cap = EK_PICK_PER_LABEL)
+                                                 int cap = EK_PICK_PER_LABEL,
+                                                 int list_m = EK_TOP_M)
 {
     // `cap`: maxima kept per label, 1 .. 16 (round 5: a run-time choice.  Four is
     // right where frames come in clouds around templates -- more floods the list
@@ -150,8 +161,8 @@ __device__ __forceinline__ void ek_pick_top_body(const EkBlockMax *blockmax, int
     // entries whatever the number of entries, where a list of more than 8192 used
     // to fall back to 64 sequential looks)
     EK_PSTAMP(0);
-    __shared__ uint32_t top_i[EK_TOP_M];
-    __shared__ float top_v[EK_TOP_M];
+    __shared__ uint32_t top_i[EK_LIST_M];
+    __shared__ float top_v[EK_LIST_M];
     __shared__ int n_top;
     const int tid = threadIdx.x;
     constexpr int PICK_PER = 8;
@@ -382,17 +393,17 @@ __device__ __forceinline__ void ek_pick_top_body(const EkBlockMax *blockmax, int
                 atomicAdd(&sel_rank[e], rank);
         }
         __syncthreads();
-        if (tid < L && sel_rank[tid] < EK_TOP_M) {
+        if (tid < L && sel_rank[tid] < list_m) {
             top_i[sel_rank[tid]] = sel_i[tid];
             top_v[sel_rank[tid]] = sel_v[tid];
         }
         if (tid == 0)
-            n_top = L < EK_TOP_M ? L : EK_TOP_M;
+            n_top = L < list_m ? L : list_m;
         __syncthreads();
         EK_PSTAMP(3);
     }
     __syncthreads();
-    if (tid < EK_TOP_M) {
+    if (tid < EK_LIST_M) {
         top->idx[tid] = (tid < n_top) ? top_i[tid] : 0xffffffffu;
         top->val[tid] = (tid < n_top) ? top_v[tid] : -__builtin_inff();
     }
