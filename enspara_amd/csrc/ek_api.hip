@@ -482,6 +482,11 @@ extern "C" int ek_set_option(ek_ctx *c, int32_t key, int32_t value)
             return ek_fail(EK_EARG, "ek_set_option: pairs one workgroup searches >= 0");
         c->sp_max_pairs = value;
         return EK_OK;
+    case 18:
+        if (value != 0 && value != 1)
+            return ek_fail(EK_EARG, "ek_set_option: small shards 0 or 1");
+        c->ms_small = value;
+        return EK_OK;
     case 17:
         if (value < 0 || value > 16)
             return ek_fail(EK_EARG, "ek_set_option: far frames per label on the pick's list "
@@ -1707,7 +1712,11 @@ ek_qcp_probe_kernel(const float *__restrict__ S, const double *__restrict__ Gx,
         s[j] = S[9 * i + j];
     full[i] = ek_rmsd_from_S(s, Gx[i], Gy[i], n_atoms);
     below[i] = ek_rmsd_from_S_below(s, Gx[i], Gy[i], n_atoms, cur[i]);
-    cert[i] = ek_far_certified_f32(s, (float)(Gx[i] + Gy[i]), n_atoms, cur[i]) ? 1 : 0;
+    // bit 0: the closed-form certificate; bit 1: the second level (two Newton steps
+    // from its bound), what ek_pass16_kernel asks of the pairs the first leaves
+    cert[i] = (ek_far_certified_f32(s, (float)(Gx[i] + Gy[i]), n_atoms, cur[i]) ? 1 : 0) |
+              (ek_far_certified2_f32(s, ek_far_t_frame((float)(Gx[i] + Gy[i]), n_atoms,
+                                                       cur[i])) ? 2 : 0);
 }
 
 extern "C" int ek_qcp_probe(int device, const float *S, const double *Gx, const double *Gy,

@@ -573,10 +573,14 @@ extern "C" int ek_ms_run(ek_ctx *c, int32_t first_label, int32_t max_new,
     // the forms by measured centers per ms; here every shard has to take the
     // SAME decision at the same round, so it is taken from what they all see
     // alike: the centers the rounds of a batch accepted.  Rounds of 8 while they
-    // accept fewer than 4.5; a batch of 16 that accepts fewer than 5.5 per round
-    // goes back to 8 and the next try waits twice as many batches (round 4: 6.5 and
-    // 8.5 -- with the exchange's tails a round of 16 costs only 1.3 x a round of 8 on
-    // a 125 000-frame shard, and the ladder lost 7 % to staying narrow too long).  A change of
+    // accept fewer than 6.5; a batch of 16 that accepts fewer than 8.5 per round
+    // goes back to 8 and the next try waits twice as many batches.  On SMALL shards
+    // (option key 18 = 1, set by sharded.kcenters_sharded for every rank alike when
+    // the largest shard has under 300 000 frames) 4.5 and 5.5: with the exchange's
+    // tails a round of 16 costs only 1.3 x a round of 8 on a 125 000-frame shard and
+    // the ladder lost 7 % there to staying narrow too long -- while at 10^6 frames
+    // per shard the lower thresholds cost 8 % (a third of the early rounds of 16
+    // break and are offered again, 0.2 ms each).  A change of
     // form costs one exchange without a pass (the state's farthest frames are
     // offered again).  Results do not depend on the form.
     // Round 5: rounds of 32 -- two passes of 16 behind ONE plan, chain and
@@ -588,6 +592,7 @@ extern "C" int ek_ms_run(ek_ctx *c, int32_t first_label, int32_t max_new,
         return ek_fail(EK_ESTATE, "ek_ms_run: multi-candidate rounds are off "
                                   "(option key 4 = 1: use ek_kcenters_step)");
     const bool ladder = Tmax >= 16 && c->cands == -1 && c->adapt;
+    const double up16 = c->ms_small ? 4.5 : 6.5, down16 = c->ms_small ? 5.5 : 8.5;
     int T = ladder ? 8 : Tmax;
     rc = ek_ms_begin_T(c, first_label, first_label + max_new, T);
     if (rc)
@@ -689,10 +694,10 @@ extern "C" int ek_ms_run(ek_ctx *c, int32_t first_label, int32_t max_new,
             if (T == 8) {
                 if (wait16 > 0)
                     --wait16;
-                else if (per_round >= 4.5)
+                else if (per_round >= up16)
                     want = 16;
             } else if (T == 16) {
-                if (per_round < 5.5) {
+                if (per_round < down16) {
                     want = 8;
                     wait16 = next_wait;
                     next_wait = std::min(2 * next_wait, 64);

@@ -276,6 +276,8 @@ struct ek_ctx {
     int ms_peers = 0;                // peers connected (mailbox transport on at == world)
     std::vector<void *> ms_ipc;      // mappings opened with hipIpcOpenMemHandle
     int ms_T = 0;                    // candidates per pass of the run in progress
+    int ms_small = 0;                // the group's shards are small: ek_ms_run's ladder moves
+                                     //   to rounds of 16 earlier (option key 18)
     // what the last ek_ms_run spent where (ek_ms_diag): the first round of every
     // batch is bracketed by events -- pass | chain (with the exchange) | plan
     hipEvent_t ms_ev[4] = {nullptr, nullptr, nullptr, nullptr};

@@ -265,6 +265,9 @@ ek_ms_chain_kernel(EkRound r, EkMsState *ms, EkMsXchg x, int nblk)
     }
     const int nb = (int)((r.n + EK_BLOCK - 1) / EK_BLOCK);
     const int cn = mode == 1 ? r.ord->n : 0;
+    // (maxima per 64 frames for the offers: on shards up to ~half a million frames,
+    // see ek_round_chain_kernel)
+    const bool fine_ok = r.fm != nullptr && 4 * nb <= 8 * EK_RED_THREADS;
     if (cn > 0) {
         // pm[(k - 1) * nb + w] = first-index arg-max over frames [256 w, 256 w + 256)
         // of min(dist, vec[order[0]], .., vec[order[k-1]]), k = 1 .. cn (state 0
@@ -327,7 +330,7 @@ ek_ms_chain_kernel(EkRound r, EkMsState *ms, EkMsXchg x, int nblk)
                     // (the rows of 16 lanes first: of the state the whole chain would
                     // leave, the maxima per 64 frames are kept for the offers)
                     ek_row_argmax(v, i);
-                    if (k == cn && r.fm && (tid & 15) == 0 && wg < nb)
+                    if (k == cn && fine_ok && (tid & 15) == 0 && wg < nb)
                         ek_coh_store_bm(&r.fm[4 * (size_t)wg + ((tid >> 4) & 3)], v, i);
                     ek_rows_to_wave_argmax(v, i);
                     if ((tid & (EK_WAVE - 1)) == 0 && wg < nb)
@@ -347,7 +350,7 @@ ek_ms_chain_kernel(EkRound r, EkMsState *ms, EkMsXchg x, int nblk)
     // chain would leave, or (the chain broke) the one it did leave
     const int ps = mode == 1 ? cn : ms->pick_state;
     // (the state the whole chain would leave: its maxima per 64 frames)
-    const bool fine = r.fm && mode == 1 && cn > 0;
+    const bool fine = fine_ok && mode == 1 && cn > 0;
     const EkBlockMax *state = fine ? r.fm
                                    : (ps == 0 ? r.blockmax : r.pm + (size_t)(ps - 1) * nb);
     EkTop *top = (EkTop *)r.top;

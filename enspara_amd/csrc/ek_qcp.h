@@ -241,6 +241,77 @@ __device__ __forceinline__ void ek_far_certified_f32_w(const float (&S)[W][9],
 }
 #undef EK_W_
 
+// ---- second level (round 5): the same verdict from a TIGHTER upper bound -----------------
+// The pairs the closed form above does not settle are, almost all of them, still
+// far: its bound U of the largest root is a crude one (it replaces lambda_max by
+// sqrt(3 q) inside a square root).  Dividing the quartic by q^2,
+//   p(x) = x^4 - 2 x^2 - 8 dn x + 1 - 4 bn,   x = lambda / sqrt(q),
+// is convex and increasing beyond its largest root x_max >= 1 (p'' = 12 x^2 - 4), so
+// a Newton step from any u >= x_max lands in [x_max, u]: two steps from U / sqrt(q)
+// bring the bound within ~1e-4 of the root.  For soundness a step must not be
+// LONGER than the true one: p(u) is taken from below (dn, bn at the upper ends of
+// their error intervals -- the slacks of the certificate above --, 1e-5 for the
+// roundings of terms below 10) and p'(u) from above, and the quotient is shortened
+// by 1e-5 more.  The separation test and the range of q are the certificate's, so
+// the reference iteration is known to end at lambda_max here too.  ~110
+// instructions.  Measured in ek_pass16_kernel (-DEK_P16_LEVEL2=1: densely over a
+// wave's queue, the float64 path only if a lane is still undecided) and NOT
+// faster -- 0.7906 against 0.7888 ms per pass --, so no kernel calls it by
+// default; it stays with its soundness tests (tests/test_qcp_host.py,
+// tests/test_gpu_qcp_device.py through ek_qcp_probe: the same adversarial
+// families as the first level) for the form of the pass that could use it.
+__device__ __forceinline__ bool ek_far_certified2_f32(const float (&S)[9], float t)
+{
+    float q = S[0] * S[0];
+#pragma unroll
+    for (int j = 1; j < 9; ++j)
+        q = __builtin_fmaf(S[j], S[j], q);
+    float c[9];
+#define EK_COF2_(K, A0, A1, B0, B1) c[K] = __builtin_fmaf(S[A0], S[A1], -(S[B0] * S[B1]));
+    EK_COF2_(0, 4, 8, 5, 7)
+    EK_COF2_(1, 5, 6, 3, 8)
+    EK_COF2_(2, 3, 7, 4, 6)
+    EK_COF2_(3, 2, 7, 1, 8)
+    EK_COF2_(4, 0, 8, 2, 6)
+    EK_COF2_(5, 1, 6, 0, 7)
+    EK_COF2_(6, 1, 5, 2, 4)
+    EK_COF2_(7, 2, 3, 0, 5)
+    EK_COF2_(8, 0, 4, 1, 3)
+#undef EK_COF2_
+    float b = c[0] * c[0];
+#pragma unroll
+    for (int j = 1; j < 9; ++j)
+        b = __builtin_fmaf(c[j], c[j], b);
+    const float d = __builtin_fmaf(S[2], c[2], __builtin_fmaf(S[1], c[1], S[0] * c[0]));
+    const float s = EK_RSQF(q), rq = s * s;
+    const float bn = (b * rq) * rq;             // b / q^2 within 3e-6
+    const float dn = (d * rq) * s;              // d / q^1.5 within 2e-6
+    // the separation of the two largest roots, as in the first level
+    const float h3 = EK_SQRTF(__builtin_fmaxf(__builtin_fmaf(-3.0f, bn, 1.00001f), 0.0f));
+    const float x_up = __builtin_fmaf(h3, 0.666668f, 0.333334f);
+    const float h4 = EK_SQRTF(__builtin_fmaxf(__builtin_fmaf(-4.0f, bn, 0.99998f), 0.0f));
+    const float x_lo = bn < 0.22f ? __builtin_fmaf(h4, 0.499999f, 0.499999f) : 0.333333f;
+    const float nd = __builtin_fmaxf(2e-6f - dn, 0.0f);
+    const float g_lo = __builtin_fmaf(-2.000006f * nd, EK_RSQF(x_lo), 1.0f - x_up);
+    // u >= x_max: the closed form's bound, (U / sqrt(q))^2 = 1 + 2 e2
+    const float pd = __builtin_fmaxf(dn + 2e-6f, 0.0f);
+    const float e2 = EK_SQRTF(__builtin_fmaf(pd, 3.464109f, bn + 3e-6f)) * 1.000001f;
+    float u = EK_SQRTF(__builtin_fmaf(e2, 2.00001f, 1.000005f)) * 1.000001f;
+    const float dn_hi = dn + 2e-6f, dn_lo = dn - 2e-6f, bn_hi = bn + 3e-6f;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const float x2 = u * u;
+        // p(u) from below, p'(u) from above
+        const float pl = __builtin_fmaf(x2, x2 - 2.0f, 1.0f) - 8.0f * dn_hi * u -
+                         4.0f * bn_hi - 1e-5f;
+        const float dp = (4.0f * u * (x2 - 1.0f) - 8.0f * dn_lo) * 1.00001f + 1e-5f;
+        const float step = (dp > 0.0f && pl > 0.0f) ? pl * EK_RCPF(dp) * 0.99999f : 0.0f;
+        u = u - step;
+    }
+    const float U2 = (4.000016f * q) * (u * u);         // (2 lambda_up)^2
+    return (q > 1e-12f) & (q < 1e12f) & (g_lo >= 2e-4f) & (t > 0.0f) & (t * t > U2);
+}
+
 __device__ __forceinline__ bool ek_far_certified_f32(const float (&S)[9], float Gsum,
                                                      int n_atoms, float cur)
 {

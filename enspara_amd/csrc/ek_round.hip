@@ -61,6 +61,11 @@ ek_round_chain_kernel(EkRound r, int bootstrap)
     extern __shared__ uint32_t skip[];      // (unused since round 5)
     const int tid = threadIdx.x;
     const int nb = (int)((r.n + EK_BLOCK - 1) / EK_BLOCK);
+    // (the maxima per 64 frames pay on shards of up to ~half a million frames -- 8 %
+    // fewer rounds at 125 000 --; at 10^6 they changed 358 rounds to 355 and cost the
+    // pick 10 us per round, two batches of loads instead of one: there it reads the
+    // maxima per 256)
+    const bool fine_ok = r.fm != nullptr && 4 * nb <= 8 * EK_RED_THREADS;
 #ifdef EK_ROUND_STAMPS
     unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -135,7 +140,7 @@ ek_round_chain_kernel(EkRound r, int bootstrap)
                         // whole chain would leave, the finer maxima are kept for the
                         // candidate pick, "hidden frames" in ek_top_dev.h)
                         ek_row_argmax(v, i);
-                        if (k == cn && r.fm && (tid & 15) == 0 && wg < nb)
+                        if (k == cn && fine_ok && (tid & 15) == 0 && wg < nb)
                             ek_coh_store_bm(&r.fm[4 * (size_t)wg + ((tid >> 4) & 3)], v, i);
                         ek_rows_to_wave_argmax(v, i);
                         // (read by the last workgroup of this launch: coherent store)
@@ -221,7 +226,7 @@ ek_round_chain_kernel(EkRound r, int bootstrap)
             r.pend->n = na;
             r.pend->label0 = label0;
             s_napply = na;
-            s_fine = (r.fm && na > 0 && na == cn) ? 1 : 0;
+            s_fine = (fine_ok && na > 0 && na == cn) ? 1 : 0;
             r.tick[1] = 0;
         }
         __syncthreads();

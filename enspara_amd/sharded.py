@@ -65,6 +65,9 @@ class DeviceShard:
     def pin_candidates(self, T):
         self.store.set_option(4, int(T))
 
+    def set_small_shards(self, on):
+        self.store.set_option(18, 1 if on else 0)
+
     def assign_nearest(self, centers_xyz):
         """every local frame against the given centers (float32 [K, A, 3]):
         the state becomes (nearest center, distance), util.py:199-203"""
@@ -323,8 +326,12 @@ def _agree_on_form(shard, T, group, world, collective):
         ok = 1 if shard.quad_copy_ready() else 0
     except Exception:           # reported by the run itself; here: narrow rounds
         ok = 0
-    everyone = _gather_i64(shard, [ok], group, world, collective)
-    if int(everyone.min()) == 1:
+    everyone = _gather_i64(shard, [ok, shard.n_local], group, world, collective)
+    # (the ladder of the rounds across shards: earlier to 16 candidates where the
+    # shards are small -- the same answer on every rank, from the same numbers)
+    if hasattr(shard, "set_small_shards"):
+        shard.set_small_shards(int(everyone[:, 1].max()) < 300000)
+    if int(everyone[:, 0].min()) == 1:
         return T
     import logging
     logging.getLogger(__name__).warning(

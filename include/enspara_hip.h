@@ -598,6 +598,10 @@ int ek_set_frames_per_lane(ek_ctx *ctx, int fpl);
  * key 8: with key 4 = -1, let ek_kcenters_run move between 1, 8 and 16
  * candidates per round by measured centers per millisecond: 1 (default) / 0
  * (always the widest form); identical results either way
+ * key 18: ek_ms_run's ladder moves from rounds of 8 to 16 once they accept 4.5 (1)
+ * or 6.5 (0, default) centers: 1 suits shards of up to ~300 000 frames, where the
+ * exchange's tails make a narrow round dear; every rank of a group must set the
+ * same value (sharded.kcenters_sharded does, from the gathered shard sizes)
  * key 17: how many of a label's farthest frames the candidate pick of a round may
  * list (the list of 64 the guesses are chosen from): 0 (default) = 4 or 16 by the
  * share of its guesses the run sees accepted (4 suits frames in clouds around
@@ -663,7 +667,8 @@ int ek_hbm_copy_rate(int device, size_t bytes, double *gbytes_per_s);
  * inner-product matrices handed over by the caller (host arrays: S [m][9] f32,
  * Gx / Gy [m] f64 traces, cur [m] f32 the distance each solve may stop above) --
  * full[i] = ek_rmsd_from_S, below[i] = ek_rmsd_from_S_below(.., cur[i]),
- * cert[i] = ek_far_certified_f32(S, (float)(Gx + Gy), n_atoms, cur[i]) -- so that
+ * cert[i] = ek_far_certified_f32(S, (float)(Gx + Gy), n_atoms, cur[i]) in bit 0 and
+ * ek_far_certified2_f32 (the second level) in bit 1 -- so that
  * the soundness tests of the early-stopped solve and of the float32 certificate
  * run through the instructions that ship (v_rcp_f32 / v_sqrt_f32 / v_rsq_f32:
  * 1 ulp, where the host build of the header rounds correctly).  Stands where
