@@ -535,7 +535,13 @@ def load_traffic(args, n_local, cands):
     why = None
     try:
         with open(path) as fh:
-            t = json.load(fh).get("cands%d" % cands)
+            entries = json.load(fh)
+        # "cands16" is the default shape; other shapes sit beside it ("cands16_a500")
+        t = entries.get("cands%d" % cands)
+        for key, e in entries.items():
+            if (key.startswith("cands%d_" % cands) and e.get("frames") == n_local
+                    and e.get("atoms") == args.atoms):
+                t = e
         if t is None:
             why = "no entry for %d candidates per pass" % cands
         elif t.get("frames") != n_local or t.get("atoms") != args.atoms:
