@@ -256,6 +256,7 @@ int ek_free_all(ek_ctx *c)
     (void)hipFree(c->ti_rtab);
     (void)hipFree(c->ti_tmask);
     (void)hipFree(c->pam_dprop);
+    (void)hipHostFree(c->sel_host);
     (void)hipFree(c->fm);
     (void)hipFree(c->top);
     (void)hipFree(c->planD);

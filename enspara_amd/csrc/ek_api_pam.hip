@@ -589,8 +589,10 @@ static int ek_pam_vecs_alloc(ek_ctx *c)
 // cleared active-frame counter come with them)
 static int ek_pam_prefetch_vectors(ek_ctx *c, int count, int32_t win_lo,
                                    int32_t win_count, bool local,
-                                   bool prepared = false)
+                                   bool prepared = false, bool *waited = nullptr)
 {
+    if (waited)
+        *waited = false;
     c->tab_n = 0;
     c->sp_ready = false;
     const int K = c->med_K;
@@ -642,6 +644,8 @@ static int ek_pam_prefetch_vectors(ek_ctx *c, int count, int32_t win_lo,
             EK_HIP(hipMemcpyAsync(c->act_n_host, c->amb_count + 3, sizeof(unsigned int),
                                   hipMemcpyDeviceToHost, c->stream));
             EK_HIP(ek_wait(c));
+            if (waited)
+                *waited = true;
             if (!bounds || (int64_t)*c->act_n_host * 4 <= c->n)
                 break;
             bounds = false;
@@ -742,6 +746,58 @@ static int ek_pam_prefetch_frames(ek_ctx *c, const int64_t *frames, int32_t coun
     }
     for (int32_t j = 0; j < count; ++j)
         c->pf_frames[j] = frames[j];
+    c->pf_count = count;
+    c->pf_external = false;
+    return EK_OK;
+}
+
+// Round 5: the window's proposals without a wait of their own.  The selected frames
+// stay where ek_select_member_multi_kernel leaves them -- the set-up kernel reads
+// them there -- and travel to the host behind it; they have arrived when the
+// prefetch's own wait (the length of the list of frames within reach) is over, or
+// one is made here.  Then they are checked like ek_pam_select_members_batch and
+// ek_pam_prefetch do.  One wait per window less (three were two thirds of the
+// ~60 us a window spends outside its kernels).
+static int ek_pam_select_prefetch(ek_ctx *c, int32_t cid0, int32_t count,
+                                  const int64_t *js, int32_t win_count, int64_t *frames)
+{
+    if (c->bat_cid0 != cid0 || count < 1 || count > c->bat_count)
+        return ek_fail(EK_ESTATE, "ek_pam_sweep: member counts of clusters [%d,+%d) "
+                                  "are not the ones at hand", cid0, count);
+    EK_HIP(hipSetDevice(c->device));
+    int rc = ek_pam_vecs_alloc(c);
+    if (rc)
+        return rc;
+    if (!c->sel_host)
+        EK_HIP(hipHostMalloc((void **)&c->sel_host, EK_PAM_WIN * sizeof(int64_t),
+                             hipHostMallocDefault));
+    EK_HIP(hipMemcpyAsync(c->bat_sel + 2 * EK_PAM_WIN, js, (size_t)count * sizeof(int64_t),
+                          hipMemcpyHostToDevice, c->stream));
+    ek_launch_select_member_multi(c->assign, c->n, cid0, count, c->bat_scan,
+                                  c->bat_sel + 2 * EK_PAM_WIN, c->bat_sel + EK_PAM_WIN,
+                                  c->stream);
+    EK_CHECK_LAUNCH();
+    EK_HIP(hipMemcpyAsync(c->sel_host, c->bat_sel + EK_PAM_WIN,
+                          (size_t)count * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    c->bat_cid0 = -1;           // the scans describe the state at count time only
+    c->bat_count = 0;
+    c->pf_count = 0;
+    ek_launch_pam_setup_dev(c->aos, c->G, c->A, c->bat_sel + EK_PAM_WIN, count, c->goff,
+                            c->pam_recs, c->ctile, c->ctrace, c->pam_plan, c->amb_count + 3,
+                            c->stream, c->dist, c->pam_dprop);
+    bool waited = false;
+    rc = ek_pam_prefetch_vectors(c, count, cid0, win_count, true, true, &waited);
+    if (rc)
+        return rc;
+    if (!waited)
+        EK_HIP(ek_wait(c));
+    for (int32_t j = 0; j < count; ++j) {
+        frames[j] = c->sel_host[j];
+        if (frames[j] < 0 || frames[j] >= c->n)
+            return ek_fail(EK_EARG, "ek_pam_sweep: cluster %d has no member %lld",
+                           cid0 + j, (long long)js[j]);
+        c->pf_frames[j] = frames[j];
+    }
     c->pf_count = count;
     c->pf_external = false;
     return EK_OK;
@@ -1119,11 +1175,6 @@ extern "C" int ek_pam_sweep(ek_ctx *c, int32_t K, int32_t width, const uint32_t 
                     *status = 1;
                     return EK_OK;
                 }
-            if (n_slots > 0) {
-                rc = ek_pam_select_members_batch(c, cid, n_slots, js, frames);
-                if (rc)
-                    return rc;
-            }
         } else {
             n_slots = cnt;
             for (int32_t s = 0; s < cnt; ++s)
@@ -1131,7 +1182,14 @@ extern "C" int ek_pam_sweep(ek_ctx *c, int32_t K, int32_t width, const uint32_t 
         }
         // (drawn proposals are members of their clusters: see ek_pam_prefetch_vectors)
         c->pf_members = !proposals;
-        rc = ek_pam_prefetch_window(c, frames, n_slots, cid, cnt);
+        if (!proposals && n_slots > 0 && c->ctile)
+            rc = ek_pam_select_prefetch(c, cid, n_slots, js, cnt, frames);
+        else {
+            if (!proposals && n_slots > 0)
+                rc = ek_pam_select_members_batch(c, cid, n_slots, js, frames);
+            if (!rc)
+                rc = ek_pam_prefetch_window(c, frames, n_slots, cid, cnt);
+        }
         c->pf_members = false;
         if (rc)
             return rc;

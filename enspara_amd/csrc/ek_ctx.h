@@ -184,6 +184,7 @@ struct ek_ctx {
     int32_t bat_cid0 = -1, bat_count = 0;
     float *pam_vecs = nullptr;       // [EK_PAM_WIN][n_pad]
     float *pam_dprop = nullptr;      // [EK_PAM_WIN] the proposals' distances to their medoids
+    int64_t *sel_host = nullptr;     // pinned [EK_PAM_WIN]: the selected frames on their way back
     bool pf_members = false;         // the window's proposals are members of its clusters
                                      //   (drawn by ek_pam_sweep): tables as bounds
     int pam_bounds = 1;              // use that (option key 16)
@@ -320,6 +321,11 @@ void ek_launch_cblocks16(const float *cen_aos, int32_t K, int A, float *cblocks,
 void ek_launch_assign16(const float *qtiles, const double *G, int64_t n, int A,
                         const float *cblocks, const double *Gc, int32_t K, float *dist,
                         int32_t *assign, hipStream_t s);
+void ek_launch_pam_setup_dev(const float *aos, const double *G, int A,
+                             const int64_t *frames_dev, int count, int64_t global_offset,
+                             unsigned char *recs, float *ctile, double *ctrace,
+                             EkPlan *plan, unsigned int *counter, hipStream_t s,
+                             const float *dist, float *dprop);
 int ek_form_slot(int T);
 int ek_spec_alloc(ek_ctx *c);
 int ek_ensure_hist(ek_ctx *c, int32_t label);

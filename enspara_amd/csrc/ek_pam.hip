@@ -2023,10 +2023,15 @@ ek_pam_setup_kernel(const float *__restrict__ aos, const double *__restrict__ G,
                     unsigned char *__restrict__ recs, float *__restrict__ ctile,
                     double *__restrict__ ctrace, EkPlan *__restrict__ plan,
                     unsigned int *__restrict__ counter, const float *__restrict__ dist,
-                    float *__restrict__ dprop)
+                    float *__restrict__ dprop, const int64_t *__restrict__ frames_dev)
 {
+    // frames_dev (round 5): the proposed frames where ek_select_member_multi_kernel
+    // left them -- the sweep no longer waits for them to reach the host before the
+    // window's set-up goes out (a frame that does not exist, -1: row 0, and the
+    // host refuses the window when the list arrives)
+#define EK_SETUP_FRAME(J) (frames_dev ? (frames_dev[J] < 0 ? 0 : frames_dev[J]) : fl.f[J])
     if ((int)blockIdx.x < count) {
-        const int64_t idx = fl.f[blockIdx.x];
+        const int64_t idx = EK_SETUP_FRAME(blockIdx.x);
         if (dprop && threadIdx.x == 0)  // (how far the proposal is from its medoid)
             dprop[blockIdx.x] = dist[idx];
         EkRecHdr *h = (EkRecHdr *)(recs + (size_t)blockIdx.x * ek_rec_bytes(A));
@@ -2047,12 +2052,12 @@ ek_pam_setup_kernel(const float *__restrict__ aos, const double *__restrict__ G,
         const int a = j / (3 * T), c = (j % (3 * T)) / 3, k = j % 3;
         float v = 0.f;
         if (a < A && c < cg)
-            v = aos[(size_t)fl.f[c] * 3 * A + 3 * a + k];
+            v = aos[(size_t)EK_SETUP_FRAME(c) * 3 * A + 3 * a + k];
         ctile[ek_ctile_index(T, a, c, k)] = v;
     }
     if (blockIdx.x == 0) {
         if ((int)threadIdx.x < T)
-            ctrace[threadIdx.x] = (int)threadIdx.x < cg ? G[fl.f[threadIdx.x]] : 0.0;
+            ctrace[threadIdx.x] = (int)threadIdx.x < cg ? G[EK_SETUP_FRAME(threadIdx.x)] : 0.0;
         if (threadIdx.x == 0) {
             plan->go = 1;
             plan->teff = cg;
@@ -2080,7 +2085,27 @@ void ek_launch_pam_setup(const float *aos, const double *G, int A,
     const int cb = (ek_ctile_atoms(A) * 3 * T + EK_BLOCK - 1) / EK_BLOCK;
     hipLaunchKernelGGL(ek_pam_setup_kernel, dim3(std::max(count, cb)),
                        dim3(EK_BLOCK), 0, s, aos, G, A, fl, count, cg, T,
-                       global_offset, recs, ctile, ctrace, plan, counter, dist, dprop);
+                       global_offset, recs, ctile, ctrace, plan, counter, dist, dprop,
+                       (const int64_t *)nullptr);
+}
+
+// the same with the frames read on the device (frames_dev[count])
+void ek_launch_pam_setup_dev(const float *aos, const double *G, int A,
+                             const int64_t *frames_dev, int count, int64_t global_offset,
+                             unsigned char *recs, float *ctile, double *ctrace,
+                             EkPlan *plan, unsigned int *counter, hipStream_t s,
+                             const float *dist, float *dprop)
+{
+    if (count <= 0)
+        return;
+    EkFrameList fl = {};
+    const int cg = std::min(count, EK_PAM_GROUP);
+    const int T = ek_pass_dist_T(cg);
+    const int cb = (ek_ctile_atoms(A) * 3 * T + EK_BLOCK - 1) / EK_BLOCK;
+    hipLaunchKernelGGL(ek_pam_setup_kernel, dim3(std::max(count, cb)),
+                       dim3(EK_BLOCK), 0, s, aos, G, A, fl, count, cg, T,
+                       global_offset, recs, ctile, ctrace, plan, counter, dist, dprop,
+                       frames_dev);
 }
 
 
