@@ -39,7 +39,7 @@ SYMBOLS = [
     "ek_pam_propose", "ek_pam_propose_member", "ek_pam_commit",
     "ek_pam_count_members_batch", "ek_pam_select_members_batch",
     "ek_pam_prefetch", "ek_pam_propose_ex", "ek_pam_prefetch_stats",
-    "ek_pam_prefetch_window", "ek_pam_prefetch_passes", "ek_pam_sparse_stats", "ek_pam_window_run", "ek_pam_sweep", "ek_np_choice_draws",
+    "ek_pam_prefetch_window", "ek_pam_prefetch_passes", "ek_pam_sparse_stats", "ek_pam_ahead_stats", "ek_pam_window_run", "ek_pam_sweep", "ek_np_choice_draws",
     "ek_pam_window_max",
     "ek_pam_prefetch_centers_window",
     "ek_centered_frames", "ek_pam_begin_table", "ek_pam_prefetch_centers",
@@ -158,6 +158,7 @@ def load():
     L.ek_pam_prefetch_window.argtypes = [vp, i64p, i32, i32, i32]
     L.ek_pam_prefetch_passes.argtypes = [vp, i64p, i64p]
     L.ek_pam_sparse_stats.argtypes = [vp, i64p, i64p]
+    L.ek_pam_ahead_stats.argtypes = [vp, i64p]
     L.ek_np_choice_draws.argtypes = [C.POINTER(C.c_uint32), i64, i64p, i64p, i64, i64p]
     L.ek_np_choice_draws.restype = i64
     L.ek_pam_sweep.argtypes = [vp, i32, i32, C.POINTER(C.c_uint32), i64, i64p, i64p, i32p, i64p,

@@ -257,6 +257,7 @@ int ek_free_all(ek_ctx *c)
     (void)hipFree(c->ti_tmask);
     (void)hipFree(c->pam_dprop);
     (void)hipHostFree(c->sel_host);
+    (void)hipFree(c->sp_bmask);
     (void)hipFree(c->fm);
     (void)hipFree(c->top);
     (void)hipFree(c->planD);
@@ -482,6 +483,11 @@ extern "C" int ek_set_option(ek_ctx *c, int32_t key, int32_t value)
         if (value < 0)
             return ek_fail(EK_EARG, "ek_set_option: pairs one workgroup searches >= 0");
         c->sp_max_pairs = value;
+        return EK_OK;
+    case 19:
+        if (value != 0 && value != 1)
+            return ek_fail(EK_EARG, "ek_set_option: PAM slots evaluated ahead 0 or 1");
+        c->pam_spec = value;
         return EK_OK;
     case 18:
         if (value != 0 && value != 1)

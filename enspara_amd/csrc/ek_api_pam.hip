@@ -814,8 +814,13 @@ static int ek_pam_window_sparse(ek_ctx *c, int32_t cid0, int32_t count,
     const size_t cap = EK_SP_CAP;
     const size_t o_bucket = 0;
     const size_t o_bcnt = o_bucket + (size_t)EK_PAM_WIN * cap * sizeof(uint2);
+    const size_t o_spec = o_bcnt + 256;
     if (!c->sp_buf)
-        EK_HIP(hipMalloc((void **)&c->sp_buf, o_bcnt + 256));
+        EK_HIP(hipMalloc((void **)&c->sp_buf, o_spec + ek_sp_spec_bytes()));
+    if (c->pam_spec && !c->sp_bmask) {
+        EK_HIP(hipMalloc((void **)&c->sp_bmask, (size_t)c->n * sizeof(uint32_t)));
+        EK_HIP(hipMemsetAsync(c->sp_bmask, 0, (size_t)c->n * sizeof(uint32_t), c->stream));
+    }
     const int K = c->med_K;
     const size_t tb = (size_t)EK_PAM_WIN * (c->med_cap + 1);
     // the state's cost tree, the slots' frames
@@ -858,6 +863,12 @@ static int ek_pam_window_sparse(ek_ctx *c, int32_t cid0, int32_t count,
     a.max_pairs = c->sp_max_pairs;
     a.exact_always = c->sp_exact;
     a.win = c->pam_win_dev;
+    // every slot evaluated at once on the state the window opens with (not while a
+    // rejected proposal's row of the medoid table is still to be put back)
+    a.use_spec = (c->pam_spec && c->pam_restore < 0 && count > 1) ? 1 : 0;
+    a.spec = (EkSpSpecRec *)(c->sp_buf + o_spec);
+    a.spec_lists = (uint32_t *)(c->sp_buf + o_spec + EK_PAM_WIN * sizeof(EkSpSpecRec));
+    a.bmask = c->sp_bmask;
 #ifdef EK_SP_PROF
     static unsigned long long *prof_dev = nullptr;
     static unsigned long long prof_tot[16];
@@ -877,6 +888,8 @@ static int ek_pam_window_sparse(ek_ctx *c, int32_t cid0, int32_t count,
                 prof_tot[6] * 1e-5, prof_tot[7] * 1e-5, prof_tot[8] * 1e-5, prof_tot[9] * 1e-5);
     }
 #endif
+    if (a.use_spec)
+        ek_launch_sp_spec(a, c->stream);
     ek_launch_sp_window(a, c->stream);
     EK_CHECK_LAUNCH();
     c->pam_restore = -1;
@@ -1023,7 +1036,8 @@ static int ek_pam_window_run_impl(ek_ctx *c, int32_t cid0, int32_t count,
     c->cnt_cid = -1;
     c->pf_hits -= count - w.stop;       // the slots past the stop were not served
     if (sparse) {
-        if (w.pad) {
+        c->sp_ahead += w.pad >> 8;      // slots taken over as evaluated ahead
+        if (w.pad & 0xff) {
             ++c->sp_bailed;
             c->sp_backoff = c->sp_backoff_next;
             c->sp_backoff_next = std::min(256, 2 * c->sp_backoff_next);
@@ -1417,6 +1431,15 @@ extern "C" int ek_pam_sparse_stats(ek_ctx *c, int64_t *windows, int64_t *ended_e
         *windows = c->sp_windows;
     if (ended_early)
         *ended_early = c->sp_bailed;
+    return EK_OK;
+}
+
+extern "C" int ek_pam_ahead_stats(ek_ctx *c, int64_t *slots_taken_over)
+{
+    if (!c)
+        return ek_fail(EK_EARG, "NULL context");
+    if (slots_taken_over)
+        *slots_taken_over = c->sp_ahead;
     return EK_OK;
 }
 

@@ -223,6 +223,9 @@ struct ek_ctx {
     int64_t sp_nact = 0;
     unsigned char *sp_buf = nullptr; // the slots' buckets and their lengths
     int64_t sp_windows = 0, sp_bailed = 0;
+    int pam_spec = 1;                // a window's slots evaluated at once, ahead of their turn (option key 19)
+    uint32_t *sp_bmask = nullptr;    // [n] which slots' buckets a frame is in (zero between windows)
+    int64_t sp_ahead = 0;            // slots whose evaluation ahead was taken over
     int32_t sp_backoff = 0, sp_backoff_next = 8;    // windows to go the three-launch way after one ended early
 
     // multi-candidate rounds (ek_spec.hip)

@@ -12,6 +12,18 @@
 // chunks of 8192 frames whose sums the workgroup keeps in LDS (shards of up to
 // 8.4 million frames)
 #define EK_SP_MAX_CHUNKS 1024
+// frames a proposal may change (a proposal with more ends the window)
+#define EK_SP_CAP_CHG 2048
+
+// What the speculative evaluation of a slot leaves (ek_sp_spec_kernel: every slot
+// of the window at once, each on the state the window opens with); the window's
+// workgroup takes it over where no accepted earlier slot touched what it read.
+struct EkSpSpecRec {
+    uint32_t n_chg, n_amb;
+    uint32_t status;            // 0: lists below are complete; else the slot is evaluated in turn
+    uint32_t tabconf;           // earlier slots whose old or new medoid is within the members' reach
+    double delta, dab;          // sum and sum of magnitudes of new^2 - old^2 over the changes
+};
 
 struct EkSpArgs {
     float *dist;                // the state; trial values are written into it and
@@ -39,6 +51,11 @@ struct EkSpArgs {
     int64_t max_pairs;
     int32_t exact_always;       // take both cost sums for every proposal (ek_set_option key 14)
     EkPamWin *win;
+    // speculative evaluation (round 5; use_spec = 0: every slot in turn, as before)
+    int32_t use_spec;
+    EkSpSpecRec *spec;          // [EK_PAM_WIN]
+    uint32_t *spec_lists;       // [slot][5][EK_SP_CAP_CHG]: frame, old d, new d, old label, new label
+    uint32_t *bmask;            // [n] bit j: the frame is in slot j's bucket (zero between windows)
     unsigned long long *prof;   // measurement builds (EK_SP_PROF): 10 ns ticks per step
 };
 
@@ -46,4 +63,6 @@ void ek_launch_sp_bucket(const uint32_t *list, int64_t n_act, const float *dist,
                          const int32_t *assign, const float *vecs, int64_t n_pad,
                          int32_t cid0, int count, uint2 *bucket,
                          unsigned int *bcnt, int64_t bcap, hipStream_t s);
+void ek_launch_sp_spec(const EkSpArgs &p, hipStream_t s);
 void ek_launch_sp_window(const EkSpArgs &p, hipStream_t s);
+size_t ek_sp_spec_bytes();      // of EkSpArgs::spec + ::spec_lists

@@ -361,7 +361,7 @@ __device__ __forceinline__ bool ek_sp_readd_chunks(const EkSpArgs &p, const uint
 // the lists of a proposal are kept in LDS: a dependent trip to memory costs about
 // a microsecond, and that -- not arithmetic -- is what a proposal's time is made of
 #define SP_KU 10        // table entries a thread asks for ahead of the search
-#define SP_CAP_CHG 2048 // frames a proposal may change
+#define SP_CAP_CHG EK_SP_CAP_CHG // frames a proposal may change
 #define SP_CAP_AMB 1024 // members it may leave behind
 #define SP_CAP_COLS 256 // medoids within their reach
 
@@ -385,20 +385,382 @@ struct EkSpLds {        // byte offsets into the dynamic LDS block
     static constexpr size_t end = cols + (size_t)SP_CAP_COLS * 4;
 };
 static_assert(EkSpLds::chunk % 8 == 0 && EkSpLds::amb_key % 8 == 0, "doubles");
-static_assert(EkSpLds::end + 2048 <= 160 * 1024, "one workgroup's LDS");
+static_assert(EkSpLds::end + 4096 <= 160 * 1024, "one workgroup's LDS");
 static_assert((size_t)3 * SP_CH * SP_LD * 4 >= 2 * EK_PW_MAX_LEAVES * 8,
               "the last chunk's tree shares the search's tile");
+
+// the lists and counters of the slot being worked on (all in LDS)
+struct EkSpShared {
+    float *tile, *ytile;
+    unsigned long long *amb_key;
+    uint32_t *chg_f;
+    float *chg_od, *chg_nd;
+    int32_t *chg_oa, *chg_na;
+    uint32_t *amb_f;
+    float *amb_d;
+    int32_t *cols;
+    unsigned long long *best;   // [EK_WAVE]
+    uint32_t *rowf;             // [EK_WAVE]
+    unsigned int *n_chg, *n_amb, *reach, *n_col;
+    float *T;                   // [EK_PAM_WIN] accepted earlier slots' proposals to this slot's medoid
+    const int *acc;             // [EK_PAM_WIN] slots accepted so far
+    const unsigned int *bcnt;   // [EK_PAM_WIN + 1] bucket lengths
+};
+
+// ---- a slot's evaluation: classification, medoids within reach, search ----------------------
+// Leaves the frames the proposal would change in L.chg_* (*L.n_chg of them) and
+// the members it is farther from in L.amb_*; -> 0: complete, 1: more than one
+// workgroup should take on, 2: more members stay put than were declared.
+// SPEC: on the state the window opens with, no earlier slot taken as accepted
+// (ek_sp_spec_kernel).  have_first: f_first is this thread's first bucket entry
+// (asked for while the slot before was worked on); *f_next, if given, gets the
+// next slot's.
+template <bool SPEC>
+__device__ __forceinline__ int ek_sp_evaluate(const EkSpArgs &p, const EkSpShared &L, int slot,
+                                              bool have_first, uint2 f_first, uint2 *f_next,
+                                              unsigned int *n_amb_out)
+{
+    const int t = threadIdx.x, lane = t & (EK_WAVE - 1),
+              wv = __builtin_amdgcn_readfirstlane(t / EK_WAVE);
+    const int A = p.A, K = p.K;
+    const int32_t cid = p.cid0 + slot;
+    // ---- classification (kmedoids.py:644-658) of this slot's frames ------------------
+    const unsigned int nb = L.bcnt[slot];
+    if (!have_first && (unsigned int)t < nb)
+        f_first = p.bucket[(size_t)slot * p.bcap + t];
+    // (what the search may need of the tables, see below: asked for now, there
+    // when the classification is through)
+    // (loads come back in the order they were asked for: the state of this
+    // thread's first frame goes before the tables and the next slot's frames)
+    float d_first = 0.f;
+    int32_t a_first = 0;
+    if ((unsigned int)t < nb) {
+        d_first = p.dist[f_first.x];
+        a_first = p.assign[f_first.x];
+    }
+    float t_reg = 0.f;      // (into LDS after the classification: no wait for it here)
+    if (!SPEC && t < slot && L.acc[t])
+        t_reg = p.T[(size_t)t * K + cid];
+    float Dtab[SP_KU];
+    {
+        const float *O = p.O + (size_t)slot * K;
+#pragma unroll
+        for (int u = 0; u < SP_KU; ++u) {
+            const int c = t + u * SP_NT;
+            Dtab[u] = (c < K) ? O[c] : 0.f;
+        }
+    }
+    if (f_next && (unsigned int)t < L.bcnt[slot + 1])
+        *f_next = p.bucket[(size_t)(slot + 1) * p.bcap + t];
+    for (unsigned int e0 = 0; e0 < nb; e0 += SP_NT) {      // (uniform over the wave)
+        const unsigned int e = e0 + t;
+        const bool in = e < nb;
+        uint2 fe = f_first;
+        if (in && e0 > 0)
+            fe = p.bucket[(size_t)slot * p.bcap + e];
+        const uint32_t f = fe.x;
+        const float nd = __uint_as_float(fe.y);
+        const float d = (e0 == 0) ? d_first : (in ? p.dist[f] : 0.f);
+        const int32_t a = (e0 == 0) ? a_first : (in ? p.assign[f] : 0);
+        const bool closer = in && d > nd;
+        const bool member = in && !closer && a == cid;
+        const unsigned int q1 = ek_sp_append(L.n_chg, closer, lane);
+        if (closer && q1 < SP_CAP_CHG) {
+            L.chg_f[q1] = f;
+            L.chg_od[q1] = d;
+            L.chg_oa[q1] = a;
+            L.chg_nd[q1] = nd;
+            L.chg_na[q1] = cid;
+        }
+        const unsigned int q2 = ek_sp_append(L.n_amb, member, lane);
+        if (member) {
+            if (q2 < SP_CAP_AMB) {
+                L.amb_f[q2] = f;
+                L.amb_d[q2] = d;
+                L.amb_key[q2] = ek_sp_key(nd, cid);
+            }
+            // how far a medoid may be from the old one and still matter to
+            // this frame; non-negative floats order like their bits
+            atomicMax(L.reach, __float_as_uint(d + nd));
+        }
+    }
+    if (!SPEC && t < slot && L.acc[t])
+        L.T[t] = t_reg;
+    ek_lds_barrier();
+    const unsigned int n_amb = *L.n_amb;
+    *n_amb_out = n_amb;
+    const bool too_many = (int64_t)n_amb > p.max_amb[slot];
+    bool bail = n_amb > SP_CAP_AMB;
+    if (n_amb > 0 && !too_many && !bail) {
+        // ---- the medoids within reach of those members (ek_pam_prune_kernel's
+        // test, from the window's tables) -------------------------------------------
+        const float lim = __uint_as_float(*L.reach) * 1.001f + 1e-3f;
+        const float *O = p.O + (size_t)slot * K;
+        for (int c0 = t; c0 < K; c0 += SP_KU * SP_NT) {
+            float D[SP_KU];                 // the table reads in flight
+#pragma unroll
+            for (int u = 0; u < SP_KU; ++u) {
+                const int c = c0 + u * SP_NT;
+                D[u] = (c0 == t) ? Dtab[u] : ((c < K) ? O[c] : 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < SP_KU; ++u) {
+                const int c = c0 + u * SP_NT;
+                if (c >= K)
+                    continue;
+                const int i = c - p.cid0;
+                if (!SPEC && i >= 0 && i < slot && L.acc[i])
+                    D[u] = L.T[i];  // its proposal sits there now: T[i][cid]
+                if (c != cid && !(D[u] > lim)) {
+                    const unsigned int q = atomicAdd(L.n_col, 1u);
+                    if (q < SP_CAP_COLS)
+                        L.cols[q] = c;
+                }
+            }
+        }
+        ek_lds_barrier();
+        const unsigned int n_col = *L.n_col;
+        bail = n_col > SP_CAP_COLS || (uint64_t)n_amb * n_col > (uint64_t)p.max_pairs;
+        // ---- kmedoids.py:666 over them: rows = members, columns = medoids ------------
+        for (unsigned int r0 = 0; !bail && n_col > 0 && r0 < n_amb; r0 += EK_WAVE) {
+            if (t < EK_WAVE) {
+                const bool ok = r0 + t < n_amb;
+                L.rowf[t] = ok ? L.amb_f[r0 + t] : 0u;
+                L.best[t] = ok ? L.amb_key[r0 + t] : ~0ull;
+            }
+            __syncthreads();
+            const bool rok = r0 + lane < n_amb;
+            constexpr int TPR = SP_NT / EK_WAVE;            // threads per row
+            constexpr int NLD = 3 * SP_CH / TPR;
+            const int lm = t / TPR, le = t % TPR;
+            const bool lok = r0 + lm < n_amb;
+            const float *lrow = p.frames_aos + (size_t)L.rowf[lm] * 3 * A;
+            for (unsigned int k0 = 0; k0 < n_col; k0 += SP_WAVES) {
+                const bool live = k0 + wv < n_col;
+                const int32_t col = live ? L.cols[k0 + wv] : 0;
+                // (a medoid accepted in this window: its row of the table is
+                // written when the window is over)
+                const int ci = col - p.cid0;
+                const bool moved_in = !SPEC && live && ci >= 0 && ci < slot && L.acc[ci];
+                const float *y = moved_in
+                                     ? p.frames_aos + (size_t)p.frames[ci] * 3 * A
+                                     : p.med_aos + (size_t)col * 3 * A;
+                float S[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                for (int a0 = 0; a0 < A; a0 += SP_CH) {
+                    const int ch = (A - a0 < SP_CH) ? A - a0 : SP_CH;
+                    float v[NLD], vy[3];
+#pragma unroll
+                    for (int k = 0; k < NLD; ++k) {
+                        const int e = le + TPR * k;
+                        v[k] = (3 * a0 + e < 3 * A && lok) ? lrow[3 * a0 + e] : 0.f;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const int e = lane + EK_WAVE * k;
+                        vy[k] = (live && 3 * a0 + e < 3 * A) ? y[3 * a0 + e] : 0.f;
+                    }
+                    __syncthreads();                // the slice before is done with
+#pragma unroll
+                    for (int k = 0; k < NLD; ++k)
+                        L.tile[(le + TPR * k) * SP_LD + lm] = v[k];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+                        L.ytile[wv * 3 * SP_CH + lane + EK_WAVE * k] = vy[k];
+                    __syncthreads();
+                    if (live) {
+                        const float *yt = L.ytile + wv * 3 * SP_CH;
+#pragma unroll 8
+                        for (int a = 0; a < ch; ++a) {
+                            const float x0 = L.tile[(3 * a + 0) * SP_LD + lane],
+                                        x1 = L.tile[(3 * a + 1) * SP_LD + lane],
+                                        x2 = L.tile[(3 * a + 2) * SP_LD + lane];
+                            const float y0 = yt[3 * a], y1 = yt[3 * a + 1],
+                                        y2 = yt[3 * a + 2];
+                            S[0] = fmaf(x0, y0, S[0]); S[1] = fmaf(x0, y1, S[1]);
+                            S[2] = fmaf(x0, y2, S[2]); S[3] = fmaf(x1, y0, S[3]);
+                            S[4] = fmaf(x1, y1, S[4]); S[5] = fmaf(x1, y2, S[5]);
+                            S[6] = fmaf(x2, y0, S[6]); S[7] = fmaf(x2, y1, S[7]);
+                            S[8] = fmaf(x2, y2, S[8]);
+                        }
+                    }
+                }
+                if (live && rok) {
+                    const double Gy = moved_in ? p.G[p.frames[ci]] : p.med_G[col];
+                    const float D = ek_rmsd_from_S(S, p.G[L.rowf[lane]], Gy, A);
+                    // equal distances: the lowest medoid index, util.py:199-203's
+                    // strict-< scan in ascending order
+                    atomicMin(&L.best[lane], ek_sp_key(D, col));
+                }
+            }
+            __syncthreads();
+            if (t < EK_WAVE && r0 + t < n_amb)
+                L.amb_key[r0 + t] = L.best[t];
+            __syncthreads();
+        }
+        // the members' new labels and distances
+        for (unsigned int r0 = 0; !bail && r0 < n_amb; r0 += SP_NT) {
+            const unsigned int r = r0 + t;
+            const bool in = r < n_amb;
+            const unsigned long long key = in ? L.amb_key[r] : 0ull;
+            const float d = in ? L.amb_d[r] : 0.f;
+            const float ndv = __uint_as_float((unsigned int)(key >> 32));
+            const int32_t na = (int32_t)(key & 0xffffffffu);
+            const bool moved = in && (na != cid ||
+                                      __float_as_uint(ndv) != __float_as_uint(d));
+            const unsigned int q = ek_sp_append(L.n_chg, moved, lane);
+            if (moved && q < SP_CAP_CHG) {
+                L.chg_f[q] = L.amb_f[r];
+                L.chg_od[q] = d;
+                L.chg_oa[q] = cid;
+                L.chg_nd[q] = ndv;
+                L.chg_na[q] = na;
+            }
+        }
+    }
+    ek_lds_barrier();
+    if (too_many)
+        return 2;
+    return (bail || *L.n_chg > SP_CAP_CHG) ? 1 : 0;
+}
+
+// ---- what the proposal would change in the sum of squares -----------------------------------
+// Both sums are numpy's pairwise sums of ~n terms: each within (chunks + 30)
+// eps of the exact value, eps = 1.1e-16 -- 1.2e-13 relative at the 1024 chunks
+// a window may have.  The sum of (new^2 - old^2) over the frames the proposal
+// changes is exact to 2048 eps of the sum of its terms' magnitudes at worst
+// (each square of a float32 is exact in float64).  If it is four orders of
+// magnitude beyond what the rounding of the two big sums can amount to, its
+// sign IS the outcome of kmedoids.py:683's comparison and neither sum has to
+// be taken; otherwise (a two-member cluster swapping its medoid changes
+// nothing in exact arithmetic) both are, in numpy's order.
+__device__ __forceinline__ void ek_sp_delta(const EkSpShared &L, unsigned int n_chg,
+                                            double *s_part, double *delta_out, double *dab_out)
+{
+    const int t = threadIdx.x, lane = t & (EK_WAVE - 1),
+              wv = __builtin_amdgcn_readfirstlane(t / EK_WAVE);
+    double dsum = 0.0, dabs = 0.0;
+    for (unsigned int q = t; q < n_chg; q += SP_NT) {
+        const double od = L.chg_od[q], nd = L.chg_nd[q];
+        const double term = nd * nd - od * od;
+        dsum += term;
+        dabs += fabs(term);
+    }
+    dsum = ek_tree_sum64(dsum);             // (any order will do)
+    dabs = ek_tree_sum64(dabs);
+    if (lane == 0) {
+        s_part[wv] = dsum;
+        s_part[SP_WAVES + wv] = dabs;
+    }
+    ek_lds_barrier();
+    double delta = 0.0, dab = 0.0;
+#pragma unroll
+    for (int w = 0; w < SP_WAVES; ++w) {    // the same order in every thread
+        delta += s_part[w];
+        dab += s_part[SP_WAVES + w];
+    }
+    *delta_out = delta;
+    *dab_out = dab;
+}
+
+#define SP_SHARED_FROM(lds)                                                             \
+    {(float *)((lds) + EkSpLds::tile), (float *)((lds) + EkSpLds::ytile),                \
+     (unsigned long long *)((lds) + EkSpLds::amb_key), (uint32_t *)((lds) + EkSpLds::chg_f), \
+     (float *)((lds) + EkSpLds::chg_od), (float *)((lds) + EkSpLds::chg_nd),              \
+     (int32_t *)((lds) + EkSpLds::chg_oa), (int32_t *)((lds) + EkSpLds::chg_na),          \
+     (uint32_t *)((lds) + EkSpLds::amb_f), (float *)((lds) + EkSpLds::amb_d),             \
+     (int32_t *)((lds) + EkSpLds::cols), s_best, s_rowf, &s_n_chg, &s_n_amb, &s_reach,    \
+     &s_n_col, s_T, s_acc, s_bcnt}
+
+__device__ __forceinline__ uint32_t *ek_sp_list(const EkSpArgs &p, int slot, int k)
+{
+    return p.spec_lists + ((size_t)slot * 5 + k) * SP_CAP_CHG;
+}
+
+// ---- every slot of the window at once, on the state the window opens with ---------------------
+// One workgroup per slot.  A proposal reads the labels and distances of its
+// bucket's frames and -- where members stay behind -- the medoids within their
+// reach; the frames it would change and the two sums over them go to memory.
+// The window's workgroup (below) takes a slot's lists as they are unless an
+// earlier slot it ACCEPTED changed a frame of this slot's bucket (`bmask`: which
+// slots' buckets a frame is in) or put a medoid within the members' reach, or
+// had one there (`tabconf`); then the slot is evaluated in its turn as before.
+__global__ void __launch_bounds__(SP_NT)
+ek_sp_spec_kernel(EkSpArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char sp_lds[];
+    __shared__ unsigned long long s_best[EK_WAVE];
+    __shared__ uint32_t s_rowf[EK_WAVE];
+    __shared__ unsigned int s_n_chg, s_n_amb, s_reach, s_n_col, s_tabconf;
+    __shared__ float s_T[EK_PAM_WIN];
+    __shared__ double s_part[2 * SP_WAVES];
+    __shared__ unsigned int s_bcnt[EK_PAM_WIN + 1];
+    __shared__ int s_acc[EK_PAM_WIN];
+    const EkSpShared L = SP_SHARED_FROM(sp_lds);
+    const int t = threadIdx.x;
+    const int slot = blockIdx.x;
+    if (t <= EK_PAM_WIN)
+        s_bcnt[t] = (t < p.count) ? min(p.bcnt[t], (unsigned int)p.bcap) : 0u;
+    if (t < EK_PAM_WIN)
+        s_acc[t] = 0;
+    if (t == 0) {
+        s_n_chg = 0;
+        s_n_amb = 0;
+        s_reach = 0;
+        s_n_col = 0;
+        s_tabconf = 0;
+    }
+    __syncthreads();
+    unsigned int n_amb = 0;
+    const int status = ek_sp_evaluate<true>(p, L, slot, false, make_uint2(0u, 0u), nullptr,
+                                            &n_amb);
+    // this slot's bucket, for the slots before it
+    const unsigned int nb = s_bcnt[slot];
+    for (unsigned int e = t; e < nb; e += SP_NT)
+        atomicOr(&p.bmask[p.bucket[(size_t)slot * p.bcap + e].x], 1u << slot);
+    const unsigned int n_chg = s_n_chg;
+    double delta = 0.0, dab = 0.0;
+    if (status == 0) {
+        ek_sp_delta(L, n_chg, s_part, &delta, &dab);
+        uint32_t *gf = ek_sp_list(p, slot, 0), *god = ek_sp_list(p, slot, 1),
+                 *gnd = ek_sp_list(p, slot, 2), *goa = ek_sp_list(p, slot, 3),
+                 *gna = ek_sp_list(p, slot, 4);
+        for (unsigned int q = t; q < n_chg; q += SP_NT) {
+            gf[q] = L.chg_f[q];
+            god[q] = __float_as_uint(L.chg_od[q]);
+            gnd[q] = __float_as_uint(L.chg_nd[q]);
+            goa[q] = (uint32_t)L.chg_oa[q];
+            gna[q] = (uint32_t)L.chg_na[q];
+        }
+        // the search's columns depend on which earlier slots are accepted where
+        // the old medoid of one or its proposal is within the members' reach
+        if (n_amb > 0 && t < slot) {
+            const float lim = __uint_as_float(s_reach) * 1.001f + 1e-3f;
+            const float d_old = p.O[(size_t)slot * p.K + p.cid0 + t];
+            const float d_new = p.T[(size_t)t * p.K + p.cid0 + slot];
+            if (!(d_old > lim) || !(d_new > lim))
+                atomicOr(&s_tabconf, 1u << t);
+        }
+        ek_lds_barrier();
+    }
+    if (t == 0) {
+        EkSpSpecRec r;
+        r.n_chg = n_chg;
+        r.n_amb = n_amb;
+        r.status = (uint32_t)status;
+        r.tabconf = s_tabconf;
+        r.delta = delta;
+        r.dab = dab;
+        p.spec[slot] = r;
+    }
+}
 
 __global__ void __launch_bounds__(SP_NT)
 ek_sp_window_kernel(EkSpArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sp_lds[];
-    float *tile = (float *)(sp_lds + EkSpLds::tile);            // [3 CH][LD]
-    float *ytile = (float *)(sp_lds + EkSpLds::ytile);          // [waves][3 CH]
     double *la = (double *)(sp_lds + EkSpLds::tile);            // (outside the search)
     double *s_chunk = (double *)(sp_lds + EkSpLds::chunk);
     double *s_chunk_old = (double *)(sp_lds + EkSpLds::chunk_old);
-    unsigned long long *amb_key = (unsigned long long *)(sp_lds + EkSpLds::amb_key);
     uint32_t *s_lbits = (uint32_t *)(sp_lds + EkSpLds::lbits);
     uint32_t *s_dirty = (uint32_t *)(sp_lds + EkSpLds::dirty);  // leaves whose sum is out of date
     uint32_t *chg_f = (uint32_t *)(sp_lds + EkSpLds::chg_f);
@@ -406,10 +768,7 @@ ek_sp_window_kernel(EkSpArgs p)
     float *chg_nd = (float *)(sp_lds + EkSpLds::chg_nd);
     int32_t *chg_oa = (int32_t *)(sp_lds + EkSpLds::chg_oa);
     int32_t *chg_na = (int32_t *)(sp_lds + EkSpLds::chg_na);
-    uint32_t *amb_f = (uint32_t *)(sp_lds + EkSpLds::amb_f);
-    float *amb_d = (float *)(sp_lds + EkSpLds::amb_d);
     int32_t *tleaf = (int32_t *)(sp_lds + EkSpLds::tleaf);
-    int32_t *cols = (int32_t *)(sp_lds + EkSpLds::cols);
     __shared__ unsigned long long s_best[EK_WAVE];
     __shared__ uint32_t s_rowf[EK_WAVE];
     __shared__ uint32_t s_cbits[EK_SP_MAX_CHUNKS / 32];
@@ -420,6 +779,9 @@ ek_sp_window_kernel(EkSpArgs p)
     __shared__ int s_stop, s_acc[EK_PAM_WIN];
     __shared__ uint32_t s_stale;
     __shared__ EkPamWin s_win;
+    __shared__ EkSpSpecRec s_rec[EK_PAM_WIN];
+    __shared__ uint32_t s_conf[EK_PAM_WIN];     // later slots whose bucket a slot's changes are in
+    const EkSpShared L = SP_SHARED_FROM(sp_lds);
     const int t = threadIdx.x, lane = t & (EK_WAVE - 1),
               wv = __builtin_amdgcn_readfirstlane(t / EK_WAVE);
     const int A = p.A, K = p.K;
@@ -442,10 +804,15 @@ ek_sp_window_kernel(EkSpArgs p)
     bool tree_fresh = true;     // leaf and chunk sums are those of the state
     if (t < EK_SP_MAX_CHUNKS / 32)
         s_cbits[t] = 0;
-    if (t < EK_PAM_WIN)
+    if (t < EK_PAM_WIN) {
         s_acc[t] = 0;
+        s_conf[t] = 0;
+    }
     if (t <= EK_PAM_WIN)
         s_bcnt[t] = (t < p.count) ? min(p.bcnt[t], (unsigned int)p.bcap) : 0u;
+    if (p.use_spec)
+        for (int i = t; i < (int)(EK_PAM_WIN * sizeof(EkSpSpecRec) / 4); i += SP_NT)
+            ((uint32_t *)s_rec)[i] = ((const uint32_t *)p.spec)[i];
     if (t == 0) {
         s_stop = p.count;
         s_stale = 0;
@@ -456,223 +823,98 @@ ek_sp_window_kernel(EkSpArgs p)
         s_mask = 0;
         s_n_leaf = 0;
     }
-    // the first slot's frames; every slot fetches the next one's while it works
+    // the first slot's frames; every slot evaluated here fetches the next one's while it works
     uint2 f_pre = make_uint2(0u, 0u);
-    if ((unsigned int)t < min(p.bcnt[0], (unsigned int)p.bcap))
-        f_pre = p.bucket[t];
+    int pre_slot = -1;
+    if (!p.use_spec) {
+        if ((unsigned int)t < min(p.bcnt[0], (unsigned int)p.bcap))
+            f_pre = p.bucket[t];
+        pre_slot = 0;
+    }
     __syncthreads();
+    if (p.use_spec) {
+        // ---- which later slots' buckets the frames a slot would change are in -----------
+        constexpr int G = 16;                   // slots whose loads are in flight together
+        for (int g0 = 0; g0 < p.count; g0 += G) {
+            uint32_t f[G], m[G];
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+                const int i = g0 + u;
+                const bool ok = i < p.count && s_rec[i].status == 0 &&
+                                (unsigned int)t < s_rec[i].n_chg;
+                f[u] = ok ? ek_sp_list(p, i, 0)[t] : 0xffffffffu;
+            }
+#pragma unroll
+            for (int u = 0; u < G; ++u)
+                m[u] = (f[u] != 0xffffffffu) ? p.bmask[f[u]] : 0u;
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+                const int i = g0 + u;
+                const uint32_t later = (i >= 31) ? 0u : (m[u] & ~((2u << i) - 1u));
+                if (later)
+                    atomicOr(&s_conf[i], later);
+            }
+        }
+        for (int i = 0; i < p.count; ++i) {     // (lists longer than the workgroup: rare)
+            if (s_rec[i].status != 0 || i >= 31)
+                continue;
+            uint32_t later = 0;
+            for (unsigned int q = SP_NT + t; q < s_rec[i].n_chg; q += SP_NT)
+                later |= p.bmask[ek_sp_list(p, i, 0)[q]] & ~((2u << i) - 1u);
+            if (later)
+                atomicOr(&s_conf[i], later);
+        }
+        __syncthreads();
+    }
     double total = ek_sp_total(s_chunk, p.n_chunks);      // the state's sum of squares
 #ifdef EK_SP_PROF
     unsigned long long sp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long sp_t0 = wall_clock64();
 #endif
 
+    // (the same in every thread)
+    uint32_t acc_mask = 0;      // slots accepted so far
+    uint32_t poison = 0;        // slots whose speculative evaluation read what those changed
+    bool in_turn = !p.use_spec; // every slot from here on is evaluated in its turn
+    int n_spec = 0;
     int slot = 0;
     for (; slot < p.count; ++slot) {
-        const int32_t cid = p.cid0 + slot;
         if (slot >= s_stop)
             break;
-        // ---- classification (kmedoids.py:644-658) of this slot's frames ------------------
-        const unsigned int nb = s_bcnt[slot];
-        const uint2 f_first = f_pre;
-        // (what the search may need of the tables, see below: asked for now, there
-        // when the classification is through)
-        // (loads come back in the order they were asked for: the state of this
-        // thread's first frame goes before the tables and the next slot's frames)
-        float d_first = 0.f;
-        int32_t a_first = 0;
-        if ((unsigned int)t < nb) {
-            d_first = p.dist[f_first.x];
-            a_first = p.assign[f_first.x];
+        const bool spec_ok = !in_turn && s_rec[slot].status == 0 &&
+                             !((poison >> slot) & 1u) && !(s_rec[slot].tabconf & acc_mask);
+        unsigned int n_amb = 0;
+        int status = 0;
+        if (spec_ok) {
+            // ---- evaluated ahead, and nothing it read has changed: its lists ---------------
+            const unsigned int n = s_rec[slot].n_chg;
+            n_amb = s_rec[slot].n_amb;
+            const uint32_t *gf = ek_sp_list(p, slot, 0), *god = ek_sp_list(p, slot, 1),
+                           *gnd = ek_sp_list(p, slot, 2), *goa = ek_sp_list(p, slot, 3),
+                           *gna = ek_sp_list(p, slot, 4);
+            for (unsigned int q = t; q < n; q += SP_NT) {
+                chg_f[q] = gf[q];
+                chg_od[q] = __uint_as_float(god[q]);
+                chg_nd[q] = __uint_as_float(gnd[q]);
+                chg_oa[q] = (int32_t)goa[q];
+                chg_na[q] = (int32_t)gna[q];
+            }
+            if (t == 0)
+                s_n_chg = n;
+            ++n_spec;
+            __syncthreads();
+        } else {
+            uint2 f_next = make_uint2(0u, 0u);
+            status = ek_sp_evaluate<false>(p, L, slot, pre_slot == slot, f_pre, &f_next, &n_amb);
+            f_pre = f_next;
+            pre_slot = slot + 1;
         }
-        float t_reg = 0.f;      // (into LDS after the classification: no wait for it here)
-        if (t < slot && s_acc[t])
-            t_reg = p.T[(size_t)t * K + cid];
-        float Dtab[SP_KU];
-        {
-            const float *O = p.O + (size_t)slot * K;
-#pragma unroll
-            for (int u = 0; u < SP_KU; ++u) {
-                const int c = t + u * SP_NT;
-                Dtab[u] = (c < K) ? O[c] : 0.f;
-            }
-        }
-        if ((unsigned int)t < s_bcnt[slot + 1])
-            f_pre = p.bucket[(size_t)(slot + 1) * p.bcap + t];
-        SP_T(8);
-        for (unsigned int e0 = 0; e0 < nb; e0 += SP_NT) {      // (uniform over the wave)
-            const unsigned int e = e0 + t;
-            const bool in = e < nb;
-            uint2 fe = f_first;
-            if (in && e0 > 0)
-                fe = p.bucket[(size_t)slot * p.bcap + e];
-            const uint32_t f = fe.x;
-            const float nd = __uint_as_float(fe.y);
-            const float d = (e0 == 0) ? d_first : (in ? p.dist[f] : 0.f);
-            const int32_t a = (e0 == 0) ? a_first : (in ? p.assign[f] : 0);
-            const bool closer = in && d > nd;
-            const bool member = in && !closer && a == cid;
-            const unsigned int q1 = ek_sp_append(&s_n_chg, closer, lane);
-            if (closer && q1 < SP_CAP_CHG) {
-                chg_f[q1] = f;
-                chg_od[q1] = d;
-                chg_oa[q1] = a;
-                chg_nd[q1] = nd;
-                chg_na[q1] = cid;
-            }
-            const unsigned int q2 = ek_sp_append(&s_n_amb, member, lane);
-            if (member) {
-                if (q2 < SP_CAP_AMB) {
-                    amb_f[q2] = f;
-                    amb_d[q2] = d;
-                    amb_key[q2] = ek_sp_key(nd, cid);
-                }
-                // how far a medoid may be from the old one and still matter to
-                // this frame; non-negative floats order like their bits
-                atomicMax(&s_reach, __float_as_uint(d + nd));
-            }
-        }
-        if (t < slot && s_acc[t])
-            s_T[t] = t_reg;
-        SP_T(9);
-        ek_lds_barrier();
-        SP_T(0);
-        const unsigned int n_amb = s_n_amb;
-        const bool too_many = (int64_t)n_amb > p.max_amb[slot];
-        bool bail = n_amb > SP_CAP_AMB;
-        if (n_amb > 0 && !too_many && !bail) {
-            // ---- the medoids within reach of those members (ek_pam_prune_kernel's
-            // test, from the window's tables) -------------------------------------------
-            const float lim = __uint_as_float(s_reach) * 1.001f + 1e-3f;
-            const float *O = p.O + (size_t)slot * K;
-            for (int c0 = t; c0 < K; c0 += SP_KU * SP_NT) {
-                float D[SP_KU];                 // the table reads in flight
-#pragma unroll
-                for (int u = 0; u < SP_KU; ++u) {
-                    const int c = c0 + u * SP_NT;
-                    D[u] = (c0 == t) ? Dtab[u] : ((c < K) ? O[c] : 0.f);
-                }
-#pragma unroll
-                for (int u = 0; u < SP_KU; ++u) {
-                    const int c = c0 + u * SP_NT;
-                    if (c >= K)
-                        continue;
-                    const int i = c - p.cid0;
-                    if (i >= 0 && i < slot && s_acc[i])
-                        D[u] = s_T[i];  // its proposal sits there now: T[i][cid]
-                    if (c != cid && !(D[u] > lim)) {
-                        const unsigned int q = atomicAdd(&s_n_col, 1u);
-                        if (q < SP_CAP_COLS)
-                            cols[q] = c;
-                    }
-                }
-            }
-            ek_lds_barrier();
-            const unsigned int n_col = s_n_col;
-            bail = n_col > SP_CAP_COLS || (uint64_t)n_amb * n_col > (uint64_t)p.max_pairs;
-            // ---- kmedoids.py:666 over them: rows = members, columns = medoids ------------
-            for (unsigned int r0 = 0; !bail && n_col > 0 && r0 < n_amb; r0 += EK_WAVE) {
-                if (t < EK_WAVE) {
-                    const bool ok = r0 + t < n_amb;
-                    s_rowf[t] = ok ? amb_f[r0 + t] : 0u;
-                    s_best[t] = ok ? amb_key[r0 + t] : ~0ull;
-                }
-                __syncthreads();
-                const bool rok = r0 + lane < n_amb;
-                constexpr int TPR = SP_NT / EK_WAVE;            // threads per row
-                constexpr int NLD = 3 * SP_CH / TPR;
-                const int lm = t / TPR, le = t % TPR;
-                const bool lok = r0 + lm < n_amb;
-                const float *lrow = p.frames_aos + (size_t)s_rowf[lm] * 3 * A;
-                for (unsigned int k0 = 0; k0 < n_col; k0 += SP_WAVES) {
-                    const bool live = k0 + wv < n_col;
-                    const int32_t col = live ? cols[k0 + wv] : 0;
-                    // (a medoid accepted in this window: its row of the table is
-                    // written when the window is over)
-                    const int ci = col - p.cid0;
-                    const bool moved_in = live && ci >= 0 && ci < slot && s_acc[ci];
-                    const float *y = moved_in
-                                         ? p.frames_aos + (size_t)p.frames[ci] * 3 * A
-                                         : p.med_aos + (size_t)col * 3 * A;
-                    float S[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                    for (int a0 = 0; a0 < A; a0 += SP_CH) {
-                        const int ch = (A - a0 < SP_CH) ? A - a0 : SP_CH;
-                        float v[NLD], vy[3];
-#pragma unroll
-                        for (int k = 0; k < NLD; ++k) {
-                            const int e = le + TPR * k;
-                            v[k] = (3 * a0 + e < 3 * A && lok) ? lrow[3 * a0 + e] : 0.f;
-                        }
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) {
-                            const int e = lane + EK_WAVE * k;
-                            vy[k] = (live && 3 * a0 + e < 3 * A) ? y[3 * a0 + e] : 0.f;
-                        }
-                        __syncthreads();                // the slice before is done with
-#pragma unroll
-                        for (int k = 0; k < NLD; ++k)
-                            tile[(le + TPR * k) * SP_LD + lm] = v[k];
-#pragma unroll
-                        for (int k = 0; k < 3; ++k)
-                            ytile[wv * 3 * SP_CH + lane + EK_WAVE * k] = vy[k];
-                        __syncthreads();
-                        if (live) {
-                            const float *yt = ytile + wv * 3 * SP_CH;
-#pragma unroll 8
-                            for (int a = 0; a < ch; ++a) {
-                                const float x0 = tile[(3 * a + 0) * SP_LD + lane],
-                                            x1 = tile[(3 * a + 1) * SP_LD + lane],
-                                            x2 = tile[(3 * a + 2) * SP_LD + lane];
-                                const float y0 = yt[3 * a], y1 = yt[3 * a + 1],
-                                            y2 = yt[3 * a + 2];
-                                S[0] = fmaf(x0, y0, S[0]); S[1] = fmaf(x0, y1, S[1]);
-                                S[2] = fmaf(x0, y2, S[2]); S[3] = fmaf(x1, y0, S[3]);
-                                S[4] = fmaf(x1, y1, S[4]); S[5] = fmaf(x1, y2, S[5]);
-                                S[6] = fmaf(x2, y0, S[6]); S[7] = fmaf(x2, y1, S[7]);
-                                S[8] = fmaf(x2, y2, S[8]);
-                            }
-                        }
-                    }
-                    if (live && rok) {
-                        const double Gy = moved_in ? p.G[p.frames[ci]] : p.med_G[col];
-                        const float D = ek_rmsd_from_S(S, p.G[s_rowf[lane]], Gy, A);
-                        // equal distances: the lowest medoid index, util.py:199-203's
-                        // strict-< scan in ascending order
-                        atomicMin(&s_best[lane], ek_sp_key(D, col));
-                    }
-                }
-                __syncthreads();
-                if (t < EK_WAVE && r0 + t < n_amb)
-                    amb_key[r0 + t] = s_best[t];
-                __syncthreads();
-            }
-            // the members' new labels and distances
-            for (unsigned int r0 = 0; !bail && r0 < n_amb; r0 += SP_NT) {
-                const unsigned int r = r0 + t;
-                const bool in = r < n_amb;
-                const unsigned long long key = in ? amb_key[r] : 0ull;
-                const float d = in ? amb_d[r] : 0.f;
-                const float ndv = __uint_as_float((unsigned int)(key >> 32));
-                const int32_t na = (int32_t)(key & 0xffffffffu);
-                const bool moved = in && (na != cid ||
-                                          __float_as_uint(ndv) != __float_as_uint(d));
-                const unsigned int q = ek_sp_append(&s_n_chg, moved, lane);
-                if (moved && q < SP_CAP_CHG) {
-                    chg_f[q] = amb_f[r];
-                    chg_od[q] = d;
-                    chg_oa[q] = cid;
-                    chg_nd[q] = ndv;
-                    chg_na[q] = na;
-                }
-            }
-        }
-        ek_lds_barrier();
         const unsigned int n_chg = s_n_chg;
-        if (bail || too_many || n_chg > SP_CAP_CHG) {
+        if (status != 0) {
             // more than one workgroup should take on (or more members than
             // declared): the window ends before this slot, nothing of it is kept
             if (t == 0) {
-                if (too_many)
+                if (status == 2)
                     s_win.err = 1 + slot;
                 else
                     s_win.pad = 1 + slot;
@@ -681,35 +923,13 @@ ek_sp_window_kernel(EkSpArgs p)
             break;
         }
         SP_T(1);
-        // ---- what the proposal would change in the sum of squares -------------------------
-        // Both sums are numpy's pairwise sums of ~n terms: each within (chunks + 30)
-        // eps of the exact value, eps = 1.1e-16 -- 1.2e-13 relative at the 1024 chunks
-        // a window may have.  The sum of (new^2 - old^2) over the frames the proposal
-        // changes is exact to 2048 eps of the sum of its terms' magnitudes at worst
-        // (each square of a float32 is exact in float64).  If it is four orders of
-        // magnitude beyond what the rounding of the two big sums can amount to, its
-        // sign IS the outcome of kmedoids.py:683's comparison and neither sum has to
-        // be taken; otherwise (a two-member cluster swapping its medoid changes
-        // nothing in exact arithmetic) both are, in numpy's order, below.
-        double dsum = 0.0, dabs = 0.0;
-        for (unsigned int q = t; q < n_chg; q += SP_NT) {
-            const double od = chg_od[q], nd = chg_nd[q];
-            const double term = nd * nd - od * od;
-            dsum += term;
-            dabs += fabs(term);
-        }
-        dsum = ek_tree_sum64(dsum);             // (any fixed order will do)
-        dabs = ek_tree_sum64(dabs);
-        if (lane == 0) {
-            s_part[wv] = dsum;
-            s_part[SP_WAVES + wv] = dabs;
-        }
-        ek_lds_barrier();
-        double delta = 0.0, dab = 0.0;
-#pragma unroll
-        for (int w = 0; w < SP_WAVES; ++w) {    // the same order in every thread
-            delta += s_part[w];
-            dab += s_part[SP_WAVES + w];
+        // ---- what the proposal would change in the sum of squares (ek_sp_delta) ------------
+        double delta, dab;
+        if (spec_ok) {
+            delta = s_rec[slot].delta;
+            dab = s_rec[slot].dab;
+        } else {
+            ek_sp_delta(L, n_chg, s_part, &delta, &dab);
         }
         const bool obvious = !p.exact_always && fabs(delta) > 1e-9 * total + 1e-11 * dab;
         bool accept, wrote = false;
@@ -846,6 +1066,11 @@ ek_sp_window_kernel(EkSpArgs p)
         SP_T(6);
         if (accept) {
             total = total_new;
+            acc_mask |= 1u << slot;
+            if (spec_ok)
+                poison |= s_conf[slot];
+            else if (p.use_spec)
+                in_turn = true;         // what it changed was never held against the buckets
         } else if (!obvious) {
             for (unsigned int q = t; q < n_chg; q += SP_NT) {
                 const uint32_t f = chg_f[q];
@@ -894,6 +1119,14 @@ ek_sp_window_kernel(EkSpArgs p)
                 p.med_idx[cid] = p.frames[i];
         }
     }
+    if (p.use_spec) {
+        // the buckets' marks, for the next window
+        for (int j = 0; j < p.count; ++j)
+            for (unsigned int e = t; e < s_bcnt[j]; e += SP_NT)
+                p.bmask[p.bucket[(size_t)j * p.bcap + e].x] = 0u;
+        if (t == 0)
+            s_win.pad |= n_spec << 8;   // (slots taken over as evaluated ahead: a diagnostic)
+    }
     for (int i = t; i < (int)(sizeof(EkPamWin) / 4); i += SP_NT)
         ((uint32_t *)p.win)[i] = ((const uint32_t *)&s_win)[i];
 #ifdef EK_SP_PROF
@@ -906,6 +1139,19 @@ ek_sp_window_kernel(EkSpArgs p)
 size_t ek_sp_lds_bytes()
 {
     return EkSpLds::end;
+}
+
+size_t ek_sp_spec_bytes()
+{
+    return EK_PAM_WIN * sizeof(EkSpSpecRec) + (size_t)EK_PAM_WIN * 5 * SP_CAP_CHG * 4;
+}
+
+void ek_launch_sp_spec(const EkSpArgs &p, hipStream_t s)
+{
+    const size_t lds = ek_sp_lds_bytes();
+    (void)hipFuncSetAttribute((const void *)ek_sp_spec_kernel,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(ek_sp_spec_kernel, dim3(p.count), dim3(SP_NT), lds, s, p);
 }
 
 void ek_launch_sp_window(const EkSpArgs &p, hipStream_t s)

@@ -232,6 +232,13 @@ class FrameStore:
         _lib.check(self.lib.ek_pam_sparse_stats(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def pam_ahead_stats(self):
+        """-> slots of those windows whose evaluation ahead of their turn was
+        taken over (ek_set_option key 19)"""
+        a = C.c_int64()
+        _lib.check(self.lib.ek_pam_ahead_stats(self._h, C.byref(a)))
+        return a.value
+
     def pam_propose_ex(self, cid, frame_index, n_members, win_lo=0,
                        win_count=0):
         """-> (old cost, new cost, number of ambiguous frames, moved mask)"""

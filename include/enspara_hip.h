@@ -389,6 +389,15 @@ int ek_pam_prefetch_stats(ek_ctx *ctx, int64_t *hits, int64_t *misses);
  * 12), and how many of them ended early because a proposal's ambiguous members
  * had more medoids within reach than one workgroup should search */
 int ek_pam_sparse_stats(ek_ctx *ctx, int64_t *windows, int64_t *ended_early);
+/* slots of those windows whose evaluation AHEAD of their turn was taken over
+ * (ek_set_option key 19): every slot of a window is evaluated at once, one
+ * workgroup each, on the state the window opens with; the window's workgroup
+ * then goes through the slots in order (kmedoids.py:575-699 is sequential: a
+ * proposal sees what the accepted ones before it changed) and takes a slot's
+ * evaluation as it is unless an earlier slot it accepted changed a frame that
+ * slot read or a medoid within its members' reach -- then the slot is
+ * evaluated in its turn, as all were before round 5.  Same results either way. */
+int ek_pam_ahead_stats(ek_ctx *ctx, int64_t *slots_taken_over);
 /* the most proposals a window / a local-frame prefetch may hold */
 int32_t ek_pam_window_max(void);
 int ek_pam_window_run(ek_ctx *ctx, int32_t cid0, int32_t count,
@@ -598,6 +607,8 @@ int ek_set_frames_per_lane(ek_ctx *ctx, int fpl);
  * key 8: with key 4 = -1, let ek_kcenters_run move between 1, 8 and 16
  * candidates per round by measured centers per millisecond: 1 (default) / 0
  * (always the widest form); identical results either way
+ * key 19: a PAM window's slots evaluated at once ahead of their turn: 1 (default)
+ * / 0 (each in its turn, round 4's form); identical results (ek_pam_ahead_stats)
  * key 18: ek_ms_run's ladder moves from rounds of 8 to 16 once they accept 4.5 (1)
  * or 6.5 (0, default) centers: 1 suits shards of up to ~300 000 frames, where the
  * exchange's tails make a narrow round dear; every rank of a group must set the

@@ -1,6 +1,6 @@
 """PAM sweep timing on one box (measurement only).
 
-  lab_pam.py [lib.so ...] [--n N] [--atoms A] [--centers K] [--reps R] [--sweeps S]
+  lab_pam.py [lib.so ...] [--n N] [--atoms A] [--centers K] [--reps R] [--sweeps S] [--walk 1]
 
 For every library given (default: the in-tree build) a child process loads the
 same frames, runs k-centers to K centers and then S PAM sweeps
@@ -83,8 +83,11 @@ def child(path, K, reps, sweeps):
                                           v[1] // sweeps)
                           for k, v in spent.items())
         moved = sum(1 for u, w in zip(med0, med) if u != w)
-        print("%-24s sweep %.4f s  %.1f us/proposal  [%s]  %d of %d medoids moved  sum %s"
-              % (name, dt, dt / K * 1e6, parts, moved, K, h), flush=True)
+        ahead = st.pam_ahead_stats() if hasattr(st, "pam_ahead_stats") else 0
+        print("%-24s sweep %.4f s  %.1f us/proposal  [%s]  %d of %d medoids moved  "
+              "windows %s  slots taken over as evaluated ahead (so far) %d  sum %s"
+              % (name, dt, dt / K * 1e6, parts, moved, K, st.pam_sparse_stats(), ahead, h),
+              flush=True)
     print("%-24s checksums agree: %s" % (name, len(sums) == 1), flush=True)
 
 
@@ -101,9 +104,10 @@ if __name__ == "__main__":
     reps, sweeps = opt("--reps", 3), opt("--sweeps", 1)
     import numpy as np
     from enspara_amd import synth
-    path = "/tmp/lab_frames_%d_%d.npy" % (n, A)
+    walk = opt("--walk", 0)                 # one time-ordered trajectory instead of templates
+    path = "/tmp/lab_frames_%d_%d%s.npy" % (n, A, "_walk" if walk else "")
     if not os.path.exists(path):
-        np.save(path, synth.synth(n, A, 5000, 1))
+        np.save(path, synth.walk(n, A, seed=1) if walk else synth.synth(n, A, 5000, 1))
     for lib in (libs or [None]):
         env = dict(os.environ)
         if lib:
