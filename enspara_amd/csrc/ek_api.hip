@@ -257,7 +257,9 @@ int ek_free_all(ek_ctx *c)
     (void)hipFree(c->ti_tmask);
     (void)hipFree(c->pam_dprop);
     (void)hipHostFree(c->sel_host);
-    (void)hipFree(c->sp_bmask);
+    (void)hipFree(c->sp_marks);
+    if (c->win_ev)
+        (void)hipEventDestroy(c->win_ev);
     (void)hipFree(c->fm);
     (void)hipFree(c->top);
     (void)hipFree(c->planD);

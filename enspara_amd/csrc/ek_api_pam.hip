@@ -809,7 +809,7 @@ static int ek_pam_select_prefetch(ek_ctx *c, int32_t cid0, int32_t count,
 // window record back.
 static int ek_pam_window_sparse(ek_ctx *c, int32_t cid0, int32_t count,
                                 const int64_t *frames, const int64_t *n_members,
-                                int32_t win_count)
+                                int32_t win_count, EkSpArgs *args)
 {
     const size_t cap = EK_SP_CAP;
     const size_t o_bucket = 0;
@@ -817,9 +817,10 @@ static int ek_pam_window_sparse(ek_ctx *c, int32_t cid0, int32_t count,
     const size_t o_spec = o_bcnt + 256;
     if (!c->sp_buf)
         EK_HIP(hipMalloc((void **)&c->sp_buf, o_spec + ek_sp_spec_bytes()));
-    if (c->pam_spec && !c->sp_bmask) {
-        EK_HIP(hipMalloc((void **)&c->sp_bmask, (size_t)c->n * sizeof(uint32_t)));
-        EK_HIP(hipMemsetAsync(c->sp_bmask, 0, (size_t)c->n * sizeof(uint32_t), c->stream));
+    if (c->pam_spec && !c->sp_marks) {
+        EK_HIP(hipMalloc((void **)&c->sp_marks, (size_t)c->n * sizeof(unsigned long long)));
+        EK_HIP(hipMemsetAsync(c->sp_marks, 0, (size_t)c->n * sizeof(unsigned long long),
+                              c->stream));
     }
     const int K = c->med_K;
     const size_t tb = (size_t)EK_PAM_WIN * (c->med_cap + 1);
@@ -868,7 +869,8 @@ static int ek_pam_window_sparse(ek_ctx *c, int32_t cid0, int32_t count,
     a.use_spec = (c->pam_spec && c->pam_restore < 0 && count > 1) ? 1 : 0;
     a.spec = (EkSpSpecRec *)(c->sp_buf + o_spec);
     a.spec_lists = (uint32_t *)(c->sp_buf + o_spec + EK_PAM_WIN * sizeof(EkSpSpecRec));
-    a.bmask = c->sp_bmask;
+    a.marks = c->sp_marks;
+    a.finish_later = a.use_spec;
 #ifdef EK_SP_PROF
     static unsigned long long *prof_dev = nullptr;
     static unsigned long long prof_tot[16];
@@ -881,17 +883,21 @@ static int ek_pam_window_sparse(ek_ctx *c, int32_t cid0, int32_t count,
     if (++prof_n % 100 == 0) {
         EK_HIP(ek_wait(c));
         EK_HIP(hipMemcpy(prof_tot, prof_dev, sizeof(prof_tot), hipMemcpyDeviceToHost));
-        fprintf(stderr, "sp prof after %d windows (ms): classify %.2f search %.2f apply %.2f "
-                        "leaves %.2f chunks %.2f total %.2f verdict %.2f keep/undo %.2f [issue %.2f loop %.2f]\n",
-                prof_n, prof_tot[0] * 1e-5, prof_tot[1] * 1e-5, prof_tot[2] * 1e-5,
-                prof_tot[3] * 1e-5, prof_tot[4] * 1e-5, prof_tot[5] * 1e-5,
-                prof_tot[6] * 1e-5, prof_tot[7] * 1e-5, prof_tot[8] * 1e-5, prof_tot[9] * 1e-5);
+        fprintf(stderr, "sp prof after %d windows (us per window): before the slots %.1f  "
+                        "evaluation / take-over %.1f  apply %.1f  leaves %.1f  chunks %.1f  "
+                        "total %.1f  verdict %.1f  end of slot %.1f  loop exit %.1f  after the slots %.1f\n",
+                prof_n, prof_tot[8] * 1e-2 / prof_n, prof_tot[1] * 1e-2 / prof_n,
+                prof_tot[2] * 1e-2 / prof_n, prof_tot[3] * 1e-2 / prof_n,
+                prof_tot[4] * 1e-2 / prof_n, prof_tot[5] * 1e-2 / prof_n,
+                prof_tot[6] * 1e-2 / prof_n, prof_tot[7] * 1e-2 / prof_n,
+                prof_tot[0] * 1e-2 / prof_n, prof_tot[9] * 1e-2 / prof_n);
     }
 #endif
     if (a.use_spec)
         ek_launch_sp_spec(a, c->stream);
     ek_launch_sp_window(a, c->stream);
     EK_CHECK_LAUNCH();
+    *args = a;
     c->pam_restore = -1;
     c->sp_ready = false;
     c->pf_hits += count;
@@ -965,8 +971,9 @@ static int ek_pam_window_run_impl(ek_ctx *c, int32_t cid0, int32_t count,
                   (c->sp_backoff == 0 || c->sp_max_pairs == 0);
     for (int32_t i = 0; sparse && i < count; ++i)
         sparse = newd[i] == c->pam_vecs + (size_t)i * c->n_pad;
+    EkSpArgs sp_args = {};
     if (sparse) {
-        rc = ek_pam_window_sparse(c, cid0, count, frames, n_members, win_count);
+        rc = ek_pam_window_sparse(c, cid0, count, frames, n_members, win_count, &sp_args);
         if (rc)
             return rc;
     } else {
@@ -1027,7 +1034,24 @@ static int ek_pam_window_run_impl(ek_ctx *c, int32_t cid0, int32_t count,
         EK_HIP(hipMemcpyAsync(next_counts, c->bat_sel, (size_t)next_count * sizeof(int64_t),
                               hipMemcpyDeviceToHost, c->stream));
     }
-    EK_HIP(ek_wait(c));
+    if (sparse && sp_args.finish_later) {
+        // the accepted proposals' rows of the medoid table and the slots' marks: behind
+        // what the host waits for
+        if (!c->win_ev)
+            EK_HIP(hipEventCreateWithFlags(&c->win_ev, hipEventDisableTiming));
+        EK_HIP(hipEventRecord(c->win_ev, c->stream));
+        ek_launch_sp_finish(sp_args, c->stream);
+        EK_CHECK_LAUNCH();
+        for (;;) {
+            const hipError_t e = hipEventQuery(c->win_ev);
+            if (e == hipSuccess)
+                break;
+            if (e != hipErrorNotReady)
+                return ek_fail(EK_EHIP, "ek_pam_window_run: %s", hipGetErrorString(e));
+        }
+    } else {
+        EK_HIP(ek_wait(c));
+    }
     c->bat_cid0 = -1;
     c->bat_count = 0;
     const EkPamWin &w = *c->pam_win_host;

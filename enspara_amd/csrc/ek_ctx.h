@@ -224,7 +224,9 @@ struct ek_ctx {
     unsigned char *sp_buf = nullptr; // the slots' buckets and their lengths
     int64_t sp_windows = 0, sp_bailed = 0;
     int pam_spec = 1;                // a window's slots evaluated at once, ahead of their turn (option key 19)
-    uint32_t *sp_bmask = nullptr;    // [n] which slots' buckets a frame is in (zero between windows)
+    unsigned long long *sp_marks = nullptr;  // [n] which slots' buckets a frame is in and which
+                                     //   would change it (zero between windows)
+    hipEvent_t win_ev = nullptr;     // a window's record is on the host
     int64_t sp_ahead = 0;            // slots whose evaluation ahead was taken over
     int32_t sp_backoff = 0, sp_backoff_next = 8;    // windows to go the three-launch way after one ended early
 

@@ -22,6 +22,10 @@ struct EkSpSpecRec {
     uint32_t n_chg, n_amb;
     uint32_t status;            // 0: lists below are complete; else the slot is evaluated in turn
     uint32_t tabconf;           // earlier slots whose old or new medoid is within the members' reach
+    uint32_t conf_in;           // earlier slots that would change a frame of this slot's bucket,
+    uint32_t conf_out;          // later slots whose bucket holds a frame this one would change
+                                // (of every such pair at least one of the two has the bit: the
+                                // one that marked the frame second, see ek_sp_spec_kernel)
     double delta, dab;          // sum and sum of magnitudes of new^2 - old^2 over the changes
 };
 
@@ -55,7 +59,10 @@ struct EkSpArgs {
     int32_t use_spec;
     EkSpSpecRec *spec;          // [EK_PAM_WIN]
     uint32_t *spec_lists;       // [slot][5][EK_SP_CAP_CHG]: frame, old d, new d, old label, new label
-    uint32_t *bmask;            // [n] bit j: the frame is in slot j's bucket (zero between windows)
+    unsigned long long *marks;  // [n] bit j: the frame is in slot j's bucket, bit 32 + j: slot j
+                                //   would change it (zero between windows)
+    int32_t finish_later;       // the accepted proposals' rows of the medoid table and the marks
+                                //   are left to ek_launch_sp_finish
     unsigned long long *prof;   // measurement builds (EK_SP_PROF): 10 ns ticks per step
 };
 
@@ -65,4 +72,5 @@ void ek_launch_sp_bucket(const uint32_t *list, int64_t n_act, const float *dist,
                          unsigned int *bcnt, int64_t bcap, hipStream_t s);
 void ek_launch_sp_spec(const EkSpArgs &p, hipStream_t s);
 void ek_launch_sp_window(const EkSpArgs &p, hipStream_t s);
+void ek_launch_sp_finish(const EkSpArgs &p, hipStream_t s);
 size_t ek_sp_spec_bytes();      // of EkSpArgs::spec + ::spec_lists

@@ -690,7 +690,7 @@ ek_sp_spec_kernel(EkSpArgs p)
     extern __shared__ __attribute__((aligned(16))) unsigned char sp_lds[];
     __shared__ unsigned long long s_best[EK_WAVE];
     __shared__ uint32_t s_rowf[EK_WAVE];
-    __shared__ unsigned int s_n_chg, s_n_amb, s_reach, s_n_col, s_tabconf;
+    __shared__ unsigned int s_n_chg, s_n_amb, s_reach, s_n_col, s_tabconf, s_cin, s_cout;
     __shared__ float s_T[EK_PAM_WIN];
     __shared__ double s_part[2 * SP_WAVES];
     __shared__ unsigned int s_bcnt[EK_PAM_WIN + 1];
@@ -708,15 +708,13 @@ ek_sp_spec_kernel(EkSpArgs p)
         s_reach = 0;
         s_n_col = 0;
         s_tabconf = 0;
+        s_cin = 0;
+        s_cout = 0;
     }
     __syncthreads();
     unsigned int n_amb = 0;
     const int status = ek_sp_evaluate<true>(p, L, slot, false, make_uint2(0u, 0u), nullptr,
                                             &n_amb);
-    // this slot's bucket, for the slots before it
-    const unsigned int nb = s_bcnt[slot];
-    for (unsigned int e = t; e < nb; e += SP_NT)
-        atomicOr(&p.bmask[p.bucket[(size_t)slot * p.bcap + e].x], 1u << slot);
     const unsigned int n_chg = s_n_chg;
     double delta = 0.0, dab = 0.0;
     if (status == 0) {
@@ -740,14 +738,41 @@ ek_sp_spec_kernel(EkSpArgs p)
             if (!(d_old > lim) || !(d_new > lim))
                 atomicOr(&s_tabconf, 1u << t);
         }
-        ek_lds_barrier();
     }
+    // ---- which slots read what which slots would change ----------------------------------------
+    // One 64-bit word per frame: bit j = in slot j's bucket, bit 32 + j = slot j would
+    // change it.  Every mark is an atomic OR that returns the word before it, and the
+    // marks of one word happen one after the other: of a slot's change mark and
+    // another slot's bucket mark on the same frame, the one made second sees the first.
+    {
+        const unsigned int nb = s_bcnt[slot];
+        uint32_t cin = 0, cout = 0;
+        for (unsigned int e = t; e < nb; e += SP_NT) {
+            const unsigned long long old =
+                atomicOr(&p.marks[p.bucket[(size_t)slot * p.bcap + e].x], 1ull << slot);
+            cin |= (uint32_t)(old >> 32);
+        }
+        if (status == 0)
+            for (unsigned int q = t; q < n_chg; q += SP_NT) {
+                const unsigned long long old = atomicOr(&p.marks[L.chg_f[q]], 1ull << (32 + slot));
+                cout |= (uint32_t)old;
+            }
+        cin &= (1u << slot) - 1u;                               // the slots before this one
+        cout &= (slot >= 31) ? 0u : ~((2u << slot) - 1u);       // the slots after it
+        if (cin)
+            atomicOr(&s_cin, cin);
+        if (cout)
+            atomicOr(&s_cout, cout);
+    }
+    __syncthreads();
     if (t == 0) {
         EkSpSpecRec r;
         r.n_chg = n_chg;
         r.n_amb = n_amb;
         r.status = (uint32_t)status;
         r.tabconf = s_tabconf;
+        r.conf_in = s_cin;
+        r.conf_out = s_cout;
         r.delta = delta;
         r.dab = dab;
         p.spec[slot] = r;
@@ -780,11 +805,14 @@ ek_sp_window_kernel(EkSpArgs p)
     __shared__ uint32_t s_stale;
     __shared__ EkPamWin s_win;
     __shared__ EkSpSpecRec s_rec[EK_PAM_WIN];
-    __shared__ uint32_t s_conf[EK_PAM_WIN];     // later slots whose bucket a slot's changes are in
     const EkSpShared L = SP_SHARED_FROM(sp_lds);
     const int t = threadIdx.x, lane = t & (EK_WAVE - 1),
               wv = __builtin_amdgcn_readfirstlane(t / EK_WAVE);
     const int A = p.A, K = p.K;
+#ifdef EK_SP_PROF
+    unsigned long long sp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long sp_t0 = wall_clock64();
+#endif
 
     // ---- the window record; a row a rejected proposal still sits in --------------------
     for (int i = t; i < (int)(sizeof(EkPamWin) / 4); i += SP_NT)
@@ -804,10 +832,8 @@ ek_sp_window_kernel(EkSpArgs p)
     bool tree_fresh = true;     // leaf and chunk sums are those of the state
     if (t < EK_SP_MAX_CHUNKS / 32)
         s_cbits[t] = 0;
-    if (t < EK_PAM_WIN) {
+    if (t < EK_PAM_WIN)
         s_acc[t] = 0;
-        s_conf[t] = 0;
-    }
     if (t <= EK_PAM_WIN)
         s_bcnt[t] = (t < p.count) ? min(p.bcnt[t], (unsigned int)p.bcap) : 0u;
     if (p.use_spec)
@@ -832,59 +858,33 @@ ek_sp_window_kernel(EkSpArgs p)
         pre_slot = 0;
     }
     __syncthreads();
-    if (p.use_spec) {
-        // ---- which later slots' buckets the frames a slot would change are in -----------
-        constexpr int G = 16;                   // slots whose loads are in flight together
-        for (int g0 = 0; g0 < p.count; g0 += G) {
-            uint32_t f[G], m[G];
-#pragma unroll
-            for (int u = 0; u < G; ++u) {
-                const int i = g0 + u;
-                const bool ok = i < p.count && s_rec[i].status == 0 &&
-                                (unsigned int)t < s_rec[i].n_chg;
-                f[u] = ok ? ek_sp_list(p, i, 0)[t] : 0xffffffffu;
-            }
-#pragma unroll
-            for (int u = 0; u < G; ++u)
-                m[u] = (f[u] != 0xffffffffu) ? p.bmask[f[u]] : 0u;
-#pragma unroll
-            for (int u = 0; u < G; ++u) {
-                const int i = g0 + u;
-                const uint32_t later = (i >= 31) ? 0u : (m[u] & ~((2u << i) - 1u));
-                if (later)
-                    atomicOr(&s_conf[i], later);
-            }
-        }
-        for (int i = 0; i < p.count; ++i) {     // (lists longer than the workgroup: rare)
-            if (s_rec[i].status != 0 || i >= 31)
-                continue;
-            uint32_t later = 0;
-            for (unsigned int q = SP_NT + t; q < s_rec[i].n_chg; q += SP_NT)
-                later |= p.bmask[ek_sp_list(p, i, 0)[q]] & ~((2u << i) - 1u);
-            if (later)
-                atomicOr(&s_conf[i], later);
-        }
-        __syncthreads();
-    }
     double total = ek_sp_total(s_chunk, p.n_chunks);      // the state's sum of squares
-#ifdef EK_SP_PROF
-    unsigned long long sp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long sp_t0 = wall_clock64();
-#endif
+    SP_T(8);
 
     // (the same in every thread)
     uint32_t acc_mask = 0;      // slots accepted so far
-    uint32_t poison = 0;        // slots whose speculative evaluation read what those changed
+    uint32_t poison = 0;        // slots whose evaluation ahead read what those changed (as
+                                //   seen from the changing slot: conf_out; from the reading
+                                //   one: conf_in & acc_mask)
     bool in_turn = !p.use_spec; // every slot from here on is evaluated in its turn
+    bool stores_pending = false;// the state was written and nobody has waited for the stores
     int n_spec = 0;
+    // this thread's entry of a slot's lists (slots evaluated ahead; most change fewer
+    // frames than the workgroup has threads): asked for while the slot before is decided
+    uint32_t nx_f = 0, nx_od = 0, nx_nd = 0, nx_oa = 0, nx_na = 0;
+    int nx_slot = -1;
     int slot = 0;
     for (; slot < p.count; ++slot) {
         if (slot >= s_stop)
             break;
         const bool spec_ok = !in_turn && s_rec[slot].status == 0 &&
-                             !((poison >> slot) & 1u) && !(s_rec[slot].tabconf & acc_mask);
+                             !((poison >> slot) & 1u) &&
+                             !((s_rec[slot].tabconf | s_rec[slot].conf_in) & acc_mask);
         unsigned int n_amb = 0;
         int status = 0;
+        bool in_regs = false;
+        uint32_t cf = 0, coa = 0, cna = 0;
+        float cod = 0.f, cnd = 0.f;
         if (spec_ok) {
             // ---- evaluated ahead, and nothing it read has changed: its lists ---------------
             const unsigned int n = s_rec[slot].n_chg;
@@ -892,24 +892,57 @@ ek_sp_window_kernel(EkSpArgs p)
             const uint32_t *gf = ek_sp_list(p, slot, 0), *god = ek_sp_list(p, slot, 1),
                            *gnd = ek_sp_list(p, slot, 2), *goa = ek_sp_list(p, slot, 3),
                            *gna = ek_sp_list(p, slot, 4);
-            for (unsigned int q = t; q < n; q += SP_NT) {
-                chg_f[q] = gf[q];
-                chg_od[q] = __uint_as_float(god[q]);
-                chg_nd[q] = __uint_as_float(gnd[q]);
-                chg_oa[q] = (int32_t)goa[q];
-                chg_na[q] = (int32_t)gna[q];
-            }
-            if (t == 0)
-                s_n_chg = n;
             ++n_spec;
-            __syncthreads();
+            if (n <= SP_NT) {
+                in_regs = true;
+                if (nx_slot != slot && (unsigned int)t < n) {
+                    nx_f = gf[t];
+                    nx_od = god[t];
+                    nx_nd = gnd[t];
+                    nx_oa = goa[t];
+                    nx_na = gna[t];
+                }
+                cf = nx_f;
+                cod = __uint_as_float(nx_od);
+                cnd = __uint_as_float(nx_nd);
+                coa = nx_oa;
+                cna = nx_na;
+            } else {
+                for (unsigned int q = t; q < n; q += SP_NT) {
+                    chg_f[q] = gf[q];
+                    chg_od[q] = __uint_as_float(god[q]);
+                    chg_nd[q] = __uint_as_float(gnd[q]);
+                    chg_oa[q] = (int32_t)goa[q];
+                    chg_na[q] = (int32_t)gna[q];
+                }
+                if (t == 0)
+                    s_n_chg = n;
+                __syncthreads();
+                stores_pending = false;
+            }
         } else {
+            if (stores_pending) {       // it reads the state
+                __syncthreads();
+                stores_pending = false;
+            }
             uint2 f_next = make_uint2(0u, 0u);
             status = ek_sp_evaluate<false>(p, L, slot, pre_slot == slot, f_pre, &f_next, &n_amb);
             f_pre = f_next;
             pre_slot = slot + 1;
         }
-        const unsigned int n_chg = s_n_chg;
+        // the next slot's entry
+        if (p.use_spec && !in_turn && slot + 1 < p.count && s_rec[slot + 1].status == 0 &&
+            s_rec[slot + 1].n_chg <= SP_NT) {
+            if ((unsigned int)t < s_rec[slot + 1].n_chg) {
+                nx_f = ek_sp_list(p, slot + 1, 0)[t];
+                nx_od = ek_sp_list(p, slot + 1, 1)[t];
+                nx_nd = ek_sp_list(p, slot + 1, 2)[t];
+                nx_oa = ek_sp_list(p, slot + 1, 3)[t];
+                nx_na = ek_sp_list(p, slot + 1, 4)[t];
+            }
+            nx_slot = slot + 1;
+        }
+        const unsigned int n_chg = in_regs ? s_rec[slot].n_chg : s_n_chg;
         if (status != 0) {
             // more than one workgroup should take on (or more members than
             // declared): the window ends before this slot, nothing of it is kept
@@ -941,10 +974,13 @@ ek_sp_window_kernel(EkSpArgs p)
             if (accept) {
                 // the trial state becomes the state; its leaves' sums are out of date
                 unsigned int m = 0;
-                for (unsigned int q = t; q < n_chg; q += SP_NT) {
-                    const uint32_t f = chg_f[q];
-                    const int32_t oa = chg_oa[q], na = chg_na[q];
-                    p.dist[f] = chg_nd[q];
+                const unsigned int q_end = in_regs ? (((unsigned int)t < n_chg) ? t + 1 : 0u)
+                                                   : n_chg;
+                for (unsigned int q = t; q < q_end; q += SP_NT) {
+                    const uint32_t f = in_regs ? cf : chg_f[q];
+                    const int32_t oa = in_regs ? (int32_t)coa : chg_oa[q],
+                                  na = in_regs ? (int32_t)cna : chg_na[q];
+                    p.dist[f] = in_regs ? cnd : chg_nd[q];
                     p.assign[f] = na;
                     if (oa != na) {
                         const int32_t ia = oa - p.cid0, ib = na - p.cid0;
@@ -959,11 +995,27 @@ ek_sp_window_kernel(EkSpArgs p)
                 if (m)
                     atomicOr(&s_mask, m);
                 tree_fresh = false;
-                wrote = true;
+                // (nobody waits for these stores here: a slot taken over as evaluated
+                // ahead neither reads nor writes a frame an accepted one changed --
+                // `poison` -- and whoever reads the state waits first)
+                stores_pending = true;
             }
             ek_lds_barrier();
             SP_T(2);
         } else {
+            if (in_regs) {
+                if ((unsigned int)t < n_chg) {
+                    chg_f[t] = cf;
+                    chg_od[t] = cod;
+                    chg_nd[t] = cnd;
+                    chg_oa[t] = (int32_t)coa;
+                    chg_na[t] = (int32_t)cna;
+                }
+            }
+            if (stores_pending || in_regs) {    // the sums below read the state
+                __syncthreads();
+                stores_pending = false;
+            }
             if (!tree_fresh) {
                 // ---- the leaves changed since the tree was last brought up to date -------
                 for (;;) {
@@ -1068,7 +1120,7 @@ ek_sp_window_kernel(EkSpArgs p)
             total = total_new;
             acc_mask |= 1u << slot;
             if (spec_ok)
-                poison |= s_conf[slot];
+                poison |= s_rec[slot].conf_out;
             else if (p.use_spec)
                 in_turn = true;         // what it changed was never held against the buckets
         } else if (!obvious) {
@@ -1104,36 +1156,82 @@ ek_sp_window_kernel(EkSpArgs p)
         ek_lds_barrier();
         SP_T(7);
     }
+    SP_T(0);
     // ---- the accepted proposals are their clusters' medoids (kmedoids.py:684-690) ---------
+    // a wave per accepted slot, its loads in flight together (one slot after the
+    // other, each a trip to memory, was a quarter of a short window's time)
     __syncthreads();
-    for (int i = 0; i < p.count; ++i) {
-        if (!s_acc[i])
-            continue;
-        const int32_t cid = p.cid0 + i;
-        const float *src = p.frames_aos + (size_t)p.frames[i] * 3 * A;
-        for (int r = t; r < 3 * A; r += SP_NT)
-            p.med_aos[(size_t)cid * 3 * A + r] = src[r];
-        if (t == 0) {
-            p.med_G[cid] = p.G[p.frames[i]];
-            if (p.med_idx)
-                p.med_idx[cid] = p.frames[i];
+    if (!p.finish_later) {
+        int rank = 0;
+        for (int i = 0; i < p.count; ++i) {
+            if (!s_acc[i])
+                continue;
+            if ((rank++ % SP_WAVES) != wv)
+                continue;
+            const int32_t cid = p.cid0 + i;
+            const float *src = p.frames_aos + (size_t)p.frames[i] * 3 * A;
+            float *dst = p.med_aos + (size_t)cid * 3 * A;
+            for (int r0 = 0; r0 < 3 * A; r0 += 8 * EK_WAVE) {
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int r = r0 + k * EK_WAVE + lane;
+                    v[k] = (r < 3 * A) ? src[r] : 0.f;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int r = r0 + k * EK_WAVE + lane;
+                    if (r < 3 * A)
+                        dst[r] = v[k];
+                }
+            }
+            if (lane == 0) {
+                p.med_G[cid] = p.G[p.frames[i]];
+                if (p.med_idx)
+                    p.med_idx[cid] = p.frames[i];
+            }
         }
     }
-    if (p.use_spec) {
-        // the buckets' marks, for the next window
-        for (int j = 0; j < p.count; ++j)
-            for (unsigned int e = t; e < s_bcnt[j]; e += SP_NT)
-                p.bmask[p.bucket[(size_t)j * p.bcap + e].x] = 0u;
-        if (t == 0)
-            s_win.pad |= n_spec << 8;   // (slots taken over as evaluated ahead: a diagnostic)
-    }
+    if (p.use_spec && t == 0)
+        s_win.pad |= n_spec << 8;       // (slots taken over as evaluated ahead: a diagnostic)
     for (int i = t; i < (int)(sizeof(EkPamWin) / 4); i += SP_NT)
         ((uint32_t *)p.win)[i] = ((const uint32_t *)&s_win)[i];
+    SP_T(9);
 #ifdef EK_SP_PROF
     if (t == 0 && p.prof)
         for (int k = 0; k < 10; ++k)
             p.prof[k] += sp_acc[k];
 #endif
+}
+
+// ---- after a window whose slots were evaluated ahead: one workgroup per slot ----------------------
+// takes the slot's marks back and, if its proposal was accepted, puts it into the
+// medoid table (kmedoids.py:684-690) -- off the window's own workgroup, which did
+// these one slot after the other, a trip to memory each
+__global__ void __launch_bounds__(256)
+ek_sp_finish_kernel(EkSpArgs p)
+{
+    const int t = threadIdx.x, slot = blockIdx.x;
+    const unsigned int nb = min(p.bcnt[slot], (unsigned int)p.bcap);
+    for (unsigned int e = t; e < nb; e += 256)
+        p.marks[p.bucket[(size_t)slot * p.bcap + e].x] = 0ull;
+    if (slot >= p.win->stop || !p.win->accept[slot])
+        return;
+    const int32_t cid = p.cid0 + slot;
+    const float *src = p.frames_aos + (size_t)p.frames[slot] * 3 * p.A;
+    float *dst = p.med_aos + (size_t)cid * 3 * p.A;
+    for (int r = t; r < 3 * p.A; r += 256)
+        dst[r] = src[r];
+    if (t == 0) {
+        p.med_G[cid] = p.G[p.frames[slot]];
+        if (p.med_idx)
+            p.med_idx[cid] = p.frames[slot];
+    }
+}
+
+void ek_launch_sp_finish(const EkSpArgs &p, hipStream_t s)
+{
+    hipLaunchKernelGGL(ek_sp_finish_kernel, dim3(p.count), dim3(256), 0, s, p);
 }
 
 size_t ek_sp_lds_bytes()
