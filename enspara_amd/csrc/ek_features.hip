@@ -20,6 +20,7 @@
 // LDS in chunks and read as wave-wide broadcasts.  HBM-bound: 4 or 8 bytes per
 // (sample, feature) and ~2 flops.
 #include "ek_common.h"
+#include "ek_reduce.h"
 
 #include <stdlib.h>
 
@@ -674,14 +675,43 @@ struct FeatPam {
     int64_t *props_dev = nullptr;       // [Kcap] explicit proposals
     int32_t *accept_dev = nullptr;      // [Kcap]
     int32_t Kcap_async = 0;
+    // windows of proposals (round 5): one pass over the samples for a window's distances
+    struct FeatWin *win = nullptr;      // device: the window's draws and proposals
+    void *Y = nullptr;                  // [FEAT_WIN][F] the proposals' features
+    double *vecs = nullptr;             // [FEAT_WIN][n] every sample's distance to each
+    int32_t *blockcntW = nullptr;       // [FEAT_WIN][workgroups] member counts
+    int64_t *scanW = nullptr, *totalW = nullptr;
+    int64_t n_windows = 0, n_stale = 0; // (since the context was made: a diagnostic)
+    int win_width = 8;                  // slots of the next window of drawn proposals
+    int plain_left = 0;                 // proposals to go one at a time before the next window
+    // the ambiguous members' search, tiled (round 5)
+    double *near_d = nullptr;           // [n][chunks of 256 medoids] a chunk's nearest
+    int32_t *near_c = nullptr;
+    unsigned int *near_tick = nullptr;  // [n / FN_MB + 1] arrivals per batch of members
+    int32_t near_kc = 0;
+};
+
+#define FEAT_WIN 32     // proposals per window
+#define FEAT_MD_CH 32   // features per LDS slice of the window's distance kernel
+// a window's draws (numpy's choice on the raw outputs, one cluster after the other,
+// from the member counts the window opens with) and proposals
+struct FeatWin {
+    long long pos_before[FEAT_WIN + 1]; // stream position before slot j's draw
+    int64_t want[FEAT_WIN];             // the member drawn (-1: none)
+    int64_t prop[FEAT_WIN];             // the proposed samples
+    int32_t slot_status[FEAT_WIN];      // 0 drawn; 1 the raw outputs ran out; 2 empty
+                                        // cluster; 3 not drawn (a slot before failed)
 };
 
 // device-side state of an asynchronous sweep
 struct FeatPamCtl {
     long long pos;      // next raw output to use
-    int32_t status;     // 0 ok; 1 the raw outputs ran out; 2 an empty cluster
+    int32_t status;     // 0 ok; 1 the raw outputs ran out; 2 an empty cluster; 3 (windows)
+                        // the window's draw for cluster win_stop no longer holds
     int32_t fail_cid;   // the cluster at which status was set
     int32_t acc;        // the last proposal was accepted
+    uint32_t moved;     // (windows) clusters of the window whose member lists changed
+    int32_t win_stop;
     int32_t pad;
 };
 
@@ -711,6 +741,15 @@ extern "C" void ek_feat_pam_release(ek_feat *k)
     (void)hipFree(p.jdev);
     (void)hipFree(p.props_dev);
     (void)hipFree(p.accept_dev);
+    (void)hipFree(p.win);
+    (void)hipFree(p.Y);
+    (void)hipFree(p.vecs);
+    (void)hipFree(p.blockcntW);
+    (void)hipFree(p.scanW);
+    (void)hipFree(p.totalW);
+    (void)hipFree(p.near_d);
+    (void)hipFree(p.near_c);
+    (void)hipFree(p.near_tick);
     delete k->pam;
     k->pam = nullptr;
 }
@@ -763,10 +802,11 @@ feat_pam_classify_kernel(const double *__restrict__ dist,
                          const int32_t *__restrict__ assign,
                          const double *__restrict__ nd, int64_t n, int32_t cid,
                          double *__restrict__ ndist, int32_t *__restrict__ nassign,
-                         uint32_t *__restrict__ amb, unsigned int *__restrict__ counters)
+                         uint32_t *__restrict__ amb, unsigned int *__restrict__ counters,
+                         const int32_t *__restrict__ halt = nullptr)
 {
     const int64_t f = (int64_t)blockIdx.x * EK_BLOCK + threadIdx.x;
-    if (f >= n)
+    if (f >= n || (halt && *halt))
         return;
     const double d = dist[f], x = nd[f];
     const int32_t a = assign[f];
@@ -857,6 +897,137 @@ feat_pam_nearest_kernel(const T *__restrict__ tiles, int F,
         ndist[f] = best;
         nassign[f] = bc;
     }
+    }
+}
+
+// The same search tiled (round 5): one workgroup per member read the whole medoid
+// table again -- a quarter of a gigabyte through the L2 per proposal at 1000 members
+// x 1000 medoids x 64 features, 67 us.  Here a workgroup takes FN_MB members and 256
+// medoids (thread = medoid, the members' features in LDS, FN_MB chains per thread,
+// each still FeatAcc's chain over the features in order), a table column is read
+// once per FN_MB members; the chunks' nearest go through memory to the workgroup
+// that arrives last for the batch (ek_arrive_last), which takes the smallest
+// distance, the lowest medoid index among equal ones.
+#define FN_MB 8
+#define FN_FC 128
+template <typename T, int METRIC>
+__global__ void __launch_bounds__(EK_BLOCK)
+feat_pam_nearest_tiled_kernel(const T *__restrict__ tiles, int F,
+                              const uint32_t *__restrict__ amb,
+                              const unsigned int *__restrict__ counters,
+                              const T *__restrict__ MT, int K, int Kcap,
+                              double *__restrict__ ndist, int32_t *__restrict__ nassign,
+                              const int32_t *__restrict__ halt, double *__restrict__ part_d,
+                              int32_t *__restrict__ part_c, unsigned int *__restrict__ ticks)
+{
+    __shared__ T xs[FN_MB][FN_FC];
+    __shared__ double rv[FN_MB][EK_BLOCK / EK_WAVE];
+    __shared__ int32_t rc[FN_MB][EK_BLOCK / EK_WAVE];
+    if (halt && *halt)
+        return;
+    const unsigned int n_amb = counters[0];
+    const int KC = gridDim.y, kc = blockIdx.y;
+    const int c = kc * EK_BLOCK + threadIdx.x;
+    const int lane = threadIdx.x & (EK_WAVE - 1), wv = threadIdx.x / EK_WAVE;
+    for (unsigned int b = blockIdx.x; (size_t)b * FN_MB < n_amb; b += gridDim.x) {
+        const unsigned int m0 = b * FN_MB;
+        double acc[FN_MB];
+#pragma unroll
+        for (int m = 0; m < FN_MB; ++m)
+            acc[m] = 0.0;
+        for (int j0 = 0; j0 < F; j0 += FN_FC) {
+            const int w = (F - j0 < FN_FC) ? (F - j0) : FN_FC;
+            __syncthreads();
+            for (int e = threadIdx.x; e < FN_MB * FN_FC; e += EK_BLOCK) {
+                const int m = e / FN_FC, j = e % FN_FC;
+                T v = (T)0;
+                if (m0 + m < n_amb && j < w) {
+                    const uint32_t f = amb[m0 + m];
+                    v = tiles[(size_t)(f / EK_TILE) * (size_t)F * EK_TILE +
+                              (size_t)(j0 + j) * EK_TILE + (f % EK_TILE)];
+                }
+                xs[m][j] = v;
+            }
+            __syncthreads();
+            if (c < K) {
+#pragma unroll 16
+                for (int j = 0; j < w; ++j) {
+                    const T y = MT[(size_t)(j0 + j) * Kcap + c];
+#pragma unroll
+                    for (int m = 0; m < FN_MB; ++m)
+                        FeatAcc<T, METRIC>::add(acc[m], xs[m][j], y);
+                }
+            }
+        }
+        // this chunk's nearest medoid per member (label 0 where no distance is below
+        // +inf -- overflowed squares --: what util.py:186-203's zeros + strict < leave)
+#pragma unroll
+        for (int m = 0; m < FN_MB; ++m) {
+            double best = __builtin_inf();
+            int32_t bc = 0;
+            if (c < K) {
+                const double a = (METRIC == 0) ? __builtin_sqrt(acc[m]) : acc[m];
+                if (a < best) {
+                    best = a;
+                    bc = c;
+                }
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const double ov = __shfl_xor(best, off, 64);
+                const int32_t oc = __shfl_xor(bc, off, 64);
+                if (ov < best || (ov == best && oc < bc)) {
+                    best = ov;
+                    bc = oc;
+                }
+            }
+            if (lane == 0) {
+                rv[m][wv] = best;
+                rc[m][wv] = bc;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < FN_MB && m0 + threadIdx.x < n_amb) {
+            const int m = threadIdx.x;
+            double best = rv[m][0];
+            int32_t bc = rc[m][0];
+            for (int q = 1; q < EK_BLOCK / EK_WAVE; ++q)
+                if (rv[m][q] < best || (rv[m][q] == best && rc[m][q] < bc)) {
+                    best = rv[m][q];
+                    bc = rc[m][q];
+                }
+            if (KC == 1) {
+                const uint32_t f = amb[m0 + m];
+                ndist[f] = best;
+                nassign[f] = bc;
+            } else {
+                __hip_atomic_store(&part_d[(size_t)(m0 + m) * KC + kc], best, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+                ek_coh_store(&part_c[(size_t)(m0 + m) * KC + kc], bc);
+            }
+        }
+        if (KC > 1 && ek_arrive_last(&ticks[b], (unsigned int)KC)) {
+            if (threadIdx.x < FN_MB && m0 + threadIdx.x < n_amb) {
+                const int m = threadIdx.x;
+                double best = __builtin_inf();
+                int32_t bc = 0;
+                for (int q = 0; q < KC; ++q) {
+                    const double ov = __hip_atomic_load(&part_d[(size_t)(m0 + m) * KC + q],
+                                                        __ATOMIC_RELAXED,
+                                                        __HIP_MEMORY_SCOPE_AGENT);
+                    const int32_t oc = ek_coh_load(&part_c[(size_t)(m0 + m) * KC + q]);
+                    if (ov < best || (ov == best && oc < bc)) {
+                        best = ov;
+                        bc = oc;
+                    }
+                }
+                const uint32_t f = amb[m0 + m];
+                ndist[f] = best;
+                nassign[f] = bc;
+            }
+            if (threadIdx.x == 0)
+                __hip_atomic_store(&ticks[b], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -1062,14 +1233,24 @@ feat_total_decide_kernel(FeatPamCtl *__restrict__ ctl, const double *__restrict_
                          const T *__restrict__ col)
 {
     __shared__ double sums[2];
+    __shared__ double cs[2 * EK_BLOCK];
     if (ctl->status)
         return;
-    if (threadIdx.x < 2) {
-        double s = 0.0;
-        for (int c = 0; c < n_chunks; ++c)
-            s = s + chunksum[2 * (size_t)c + threadIdx.x];
-        sums[threadIdx.x] = s;
+    // (the chunk sums through LDS, EK_BLOCK chunks at a time: one after the other from
+    // memory, a trip each, this was 12 us at 123 chunks)
+    double run = 0.0;
+    for (int c0 = 0; c0 < n_chunks; c0 += EK_BLOCK) {
+        const int w = (n_chunks - c0 < EK_BLOCK) ? (n_chunks - c0) : EK_BLOCK;
+        __syncthreads();
+        for (int e = threadIdx.x; e < 2 * w; e += EK_BLOCK)
+            cs[e] = chunksum[2 * (size_t)c0 + e];
+        __syncthreads();
+        if (threadIdx.x < 2)
+            for (int c = 0; c < w; ++c)
+                run = run + cs[2 * c + threadIdx.x];
     }
+    if (threadIdx.x < 2)
+        sums[threadIdx.x] = run;
     __syncthreads();
     const double old_cost = sums[0] / (double)n, new_cost = sums[1] / (double)n;
     const bool acc = new_cost < old_cost;
@@ -1138,6 +1319,204 @@ feat_pw_leaf_kernel(const double *__restrict__ a, const double *__restrict__ b,
     }
 }
 
+// ---- windows of proposals (round 5) ------------------------------------------------------------
+// A proposal's pass over all samples for its distances was three quarters of its
+// time; a window's proposals are known when it opens -- drawn from the member
+// counts of its clusters as they stand then -- so ONE pass gives every sample's
+// distance to each of them (FeatAcc's chain per pair, as before).  A draw stops
+// holding when an accepted earlier proposal of the window moved a sample into or
+// out of its cluster (kmedoids.py:611-614 draws from the member list of the
+// moment): the commit keeps a mask of such clusters, the slot's first kernel
+// stops the window there (status 3) and the host opens the next one at that cluster.
+
+// one thread: the window's draws, in cluster order, on the counts it opens with
+__global__ void feat_window_draw_kernel(FeatPamCtl *__restrict__ ctl, FeatWin *__restrict__ win,
+                                        int cid0, int cnt, const int64_t *__restrict__ total,
+                                        const uint32_t *__restrict__ raw, long long n_raw,
+                                        const int64_t *__restrict__ props)
+{
+    if (threadIdx.x != 0 || ctl->status)
+        return;
+    ctl->moved = 0;
+    long long pos = ctl->pos;
+    bool failed = false;
+    for (int j = 0; j < cnt; ++j) {
+        win->pos_before[j] = pos;
+        win->want[j] = -1;
+        win->slot_status[j] = failed ? 3 : 0;
+        if (failed)
+            continue;
+        if (props) {
+            win->prop[j] = props[cid0 + j];
+            continue;
+        }
+        const long long m = total[j];
+        if (m <= 0) {
+            win->slot_status[j] = 2;
+            failed = true;
+            continue;
+        }
+        const unsigned long long rng = (unsigned long long)(m - 1);
+        if (rng == 0) {
+            win->want[j] = 0;
+            continue;
+        }
+        unsigned long long mask = rng;
+        mask |= mask >> 1;
+        mask |= mask >> 2;
+        mask |= mask >> 4;
+        mask |= mask >> 8;
+        mask |= mask >> 16;
+        for (;;) {
+            if (pos >= n_raw) {
+                win->slot_status[j] = 1;
+                failed = true;
+                break;
+            }
+            const unsigned long long v = raw[pos++] & mask;
+            if (v <= rng) {
+                win->want[j] = (long long)v;
+                break;
+            }
+        }
+        if (failed)
+            pos = win->pos_before[j];
+    }
+    win->pos_before[cnt] = pos;
+}
+
+// Y[j][:] = the features of slot j's proposal
+template <typename T>
+__global__ void __launch_bounds__(EK_BLOCK)
+feat_window_gather_kernel(const T *__restrict__ tiles, int F, const FeatWin *__restrict__ win,
+                          T *__restrict__ Y, const int32_t *__restrict__ halt)
+{
+    if (*halt)
+        return;
+    const int j = blockIdx.x;
+    const int64_t f = win->prop[j];
+    const bool ok = win->slot_status[j] == 0 && f >= 0;
+    const T *p = tiles + (size_t)((ok ? f : 0) / EK_TILE) * (size_t)F * EK_TILE +
+                 ((ok ? f : 0) % EK_TILE);
+    for (int q = threadIdx.x; q < F; q += EK_BLOCK)
+        Y[(size_t)j * F + q] = ok ? p[(size_t)q * EK_TILE] : (T)0;
+}
+
+// vecs[g][f] = distance of sample f to proposal g: one read of the samples for the
+// whole window, every pair one thread's FeatAcc chain over the features in order
+template <typename T, int METRIC, int W>
+__global__ void __launch_bounds__(EK_BLOCK)
+feat_multi_distance_kernel(const T *__restrict__ tiles, const T *__restrict__ Y, int64_t n,
+                           int F, int cnt, double *__restrict__ vecs,
+                           const int32_t *__restrict__ halt)
+{
+    __shared__ T ys[FEAT_MD_CH][W];
+    if (*halt)
+        return;
+    const int64_t f = (int64_t)blockIdx.x * EK_BLOCK + threadIdx.x;
+    const T *p = tiles + (size_t)(f / EK_TILE) * (size_t)F * EK_TILE + (f % EK_TILE);
+    double acc[W];
+#pragma unroll
+    for (int g = 0; g < W; ++g)
+        acc[g] = 0.0;
+    for (int j0 = 0; j0 < F; j0 += FEAT_MD_CH) {
+        const int w = (F - j0 < FEAT_MD_CH) ? (F - j0) : FEAT_MD_CH;
+        __syncthreads();
+        for (int e = threadIdx.x; e < FEAT_MD_CH * W; e += EK_BLOCK) {
+            const int g = e / FEAT_MD_CH, j = e % FEAT_MD_CH;
+            ys[j][g] = (g < cnt && j < w) ? Y[(size_t)g * F + j0 + j] : (T)0;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int j = 0; j < w; ++j) {
+            const T x = __builtin_nontemporal_load(p + (size_t)(j0 + j) * EK_TILE);
+#pragma unroll
+            for (int g = 0; g < W; ++g)
+                FeatAcc<T, METRIC>::add(acc[g], x, ys[j][g]);
+        }
+    }
+    if (f >= n)
+        return;
+#pragma unroll
+    for (int g = 0; g < W; ++g)
+        if (g < cnt)
+            vecs[(size_t)g * n + f] = (METRIC == 0) ? __builtin_sqrt(acc[g]) : acc[g];
+}
+
+// a slot's first kernel (one workgroup): does its draw still hold, did it succeed;
+// then the proposal into the medoid table (feat_propose_kernel)
+template <typename T>
+__global__ void __launch_bounds__(EK_BLOCK)
+feat_slot_begin_kernel(FeatPamCtl *__restrict__ ctl, const FeatWin *__restrict__ win,
+                       int cid0, int j, int check_stale, int F, int Kcap,
+                       T *__restrict__ MT, T *__restrict__ col, const T *__restrict__ Y,
+                       int64_t *__restrict__ idx, unsigned int *__restrict__ counters)
+{
+    __shared__ int s_go;
+    if (threadIdx.x == 0) {
+        s_go = 0;
+        if (!ctl->status) {
+            if (check_stale && ((ctl->moved >> j) & 1u)) {
+                ctl->status = 3;
+                ctl->win_stop = cid0 + j;
+                ctl->pos = win->pos_before[j];
+            } else if (win->slot_status[j] != 0) {
+                ctl->status = win->slot_status[j];
+                ctl->fail_cid = cid0 + j;
+                ctl->pos = win->pos_before[j];
+            } else {
+                ctl->pos = win->pos_before[j + 1];
+                idx[0] = win->prop[j];
+                counters[0] = 0;
+                s_go = 1;
+            }
+        }
+    }
+    __syncthreads();
+    if (!s_go)
+        return;
+    const int cid = cid0 + j;
+    for (int q = threadIdx.x; q < F; q += EK_BLOCK) {
+        col[q] = MT[(size_t)q * Kcap + cid];
+        MT[(size_t)q * Kcap + cid] = Y[(size_t)j * F + q];
+    }
+}
+
+// an accepted trial state becomes the state (kmedoids.py:684-690); the clusters of the
+// window that lose or gain a sample by it are marked
+__global__ void __launch_bounds__(EK_BLOCK)
+feat_commit_mask_kernel(FeatPamCtl *__restrict__ ctl, long long n,
+                        const double *__restrict__ ndist, const int32_t *__restrict__ nassign,
+                        double *__restrict__ dist, int32_t *__restrict__ assign, int cid0,
+                        int cnt)
+{
+    __shared__ uint32_t s_m;
+    if (ctl->status || !ctl->acc)
+        return;
+    if (threadIdx.x == 0)
+        s_m = 0;
+    __syncthreads();
+    const long long f = (long long)blockIdx.x * EK_BLOCK + threadIdx.x;
+    uint32_t m = 0;
+    if (f < n) {
+        const int32_t a = assign[f], na = nassign[f];
+        dist[f] = ndist[f];
+        if (a != na) {
+            assign[f] = na;
+            const int ia = a - cid0, ib = na - cid0;
+            if (ia >= 0 && ia < cnt)
+                m |= 1u << ia;
+            if (ib >= 0 && ib < cnt)
+                m |= 1u << ib;
+        }
+    }
+    if (m)
+        atomicOr(&s_m, m);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_m)
+        atomicOr(&ctl->moved, s_m);
+}
+
 static int feat_pam_alloc(ek_feat *k, FeatPam &p, int32_t K)
 {
     const size_t n = (size_t)std::max<int64_t>(k->n, 1);
@@ -1182,6 +1561,24 @@ static int feat_pam_alloc(ek_feat *k, FeatPam &p, int32_t K)
         p.Kcap = K;
     }
     p.K = K;
+    // the tiled search's hand-over between the chunks of 256 medoids
+    const int KC = (K + EK_BLOCK - 1) / EK_BLOCK;
+    if (!p.near_tick) {
+        const size_t nt = n / FN_MB + 2;
+        FE_HIP(hipMalloc((void **)&p.near_tick, nt * sizeof(unsigned int)));
+        FE_HIP(hipMemsetAsync(p.near_tick, 0, nt * sizeof(unsigned int), k->s));
+    }
+    if (KC > 1 && KC > p.near_kc) {
+        FE_HIP(hipStreamSynchronize(k->s));
+        (void)hipFree(p.near_d);
+        (void)hipFree(p.near_c);
+        p.near_d = nullptr;
+        p.near_c = nullptr;
+        p.near_kc = 0;
+        FE_HIP(hipMalloc((void **)&p.near_d, n * (size_t)KC * sizeof(double)));
+        FE_HIP(hipMalloc((void **)&p.near_c, n * (size_t)KC * sizeof(int32_t)));
+        p.near_kc = KC;
+    }
     return EK_OK;
 }
 
@@ -1192,6 +1589,68 @@ static int feat_pam_alloc(ek_feat *k, FeatPam &p, int32_t K)
 // accept[c] set where proposal c was accepted.
 // *status: 0 done; 1 `raw` ran out at cluster *cid (call again with more: the
 // state stays on the device); 2 cluster *cid has no member (choice raises).
+// proposals c0 .. c1 - 1 in round 4's form (a pass over the samples each), the last
+// one's verdict applied: eight launches per proposal -- [commit of the proposal before
+// + member count], scan, [draw + member + proposal], [distances + classification], the
+// ambiguous members' search, leaf sums, chunk sums, [totals + verdict]
+template <typename T, int M>
+static void feat_enqueue_plain(ek_feat *k, FeatPam &p, int32_t K, int32_t c0, int32_t c1,
+                               bool have_props, int64_t raw_left, dim3 near_grid)
+{
+    const int nb = (int)((k->n + EK_BLOCK - 1) / EK_BLOCK);
+    const unsigned blocks = (unsigned)nb;
+    const int per = EK_BLOCK / 8;
+    for (int32_t cid = c0; cid < c1; ++cid) {
+        hipLaunchKernelGGL(feat_commit_count_kernel, dim3(blocks), dim3(EK_BLOCK), 0, k->s,
+                           p.ctl, (long long)k->n, p.ndist, p.nassign, k->kdist, k->kassign,
+                           cid > c0 ? 1 : 0, have_props ? -1 : cid, p.blockcnt);
+        if (!have_props)
+            ek_launch_scan_counts(p.blockcnt, k->n, p.scan, p.total, k->s);
+        hipLaunchKernelGGL((feat_pick_kernel<T>), dim3(1), dim3(EK_BLOCK), 0, k->s, p.ctl, cid,
+                           p.total, p.raw_dev, (long long)raw_left,
+                           have_props ? p.props_dev : (const int64_t *)nullptr, k->kassign,
+                           (long long)k->n, p.scan, nb, (const T *)k->tiles, k->F, p.Kcap,
+                           (T *)p.MT, (T *)p.col, (T *)k->y, p.idx, p.counters);
+        hipLaunchKernelGGL((feat_dist_classify_kernel<T, M>), dim3(blocks), dim3(EK_BLOCK), 0,
+                           k->s, (const T *)k->tiles, (const T *)k->y, k->n, k->F, k->kdist,
+                           k->kassign, cid, p.ndist, p.nassign, p.amb, p.counters,
+                           &p.ctl->status);
+        hipLaunchKernelGGL((feat_pam_nearest_tiled_kernel<T, M>), near_grid, dim3(EK_BLOCK), 0,
+                           k->s, (const T *)k->tiles, k->F, p.amb, p.counters,
+                           (const T *)p.MT, K, p.Kcap, p.ndist, p.nassign, &p.ctl->status,
+                           p.near_d, p.near_c, p.near_tick);
+        hipLaunchKernelGGL(feat_pw_leaf_kernel, dim3((p.n_leaves + per - 1) / per),
+                           dim3(EK_BLOCK), 0, k->s, k->kdist, p.ndist, p.shapes, p.n_full,
+                           p.n_leaves, p.part, &p.ctl->status);
+        ek_launch_pw_chunks(p.part, p.shapes, p.n_full, p.n_leaves, p.n_chunks, k->s);
+        hipLaunchKernelGGL((feat_total_decide_kernel<T>), dim3(1), dim3(EK_BLOCK), 0, k->s,
+                           p.ctl, p.part + 2 * (size_t)p.n_leaves, p.n_chunks, (long long)k->n,
+                           cid, p.idx, p.accept_dev, p.med, k->F, p.Kcap, (T *)p.MT,
+                           (const T *)p.col);
+    }
+    // (the verdict on the batch's last proposal)
+    hipLaunchKernelGGL(feat_commit_count_kernel, dim3(blocks), dim3(EK_BLOCK), 0, k->s, p.ctl,
+                       (long long)k->n, p.ndist, p.nassign, k->kdist, k->kassign, 1, -1,
+                       p.blockcnt);
+}
+
+static void feat_enqueue_plain_any(ek_feat *k, int32_t metric, FeatPam &p, int32_t K,
+                                   int32_t c0, int32_t c1, bool have_props, int64_t raw_left,
+                                   dim3 near_grid)
+{
+    if (k->kind == 0) {
+        if (metric == 0)
+            feat_enqueue_plain<float, 0>(k, p, K, c0, c1, have_props, raw_left, near_grid);
+        else
+            feat_enqueue_plain<float, 1>(k, p, K, c0, c1, have_props, raw_left, near_grid);
+    } else {
+        if (metric == 0)
+            feat_enqueue_plain<double, 0>(k, p, K, c0, c1, have_props, raw_left, near_grid);
+        else
+            feat_enqueue_plain<double, 1>(k, p, K, c0, c1, have_props, raw_left, near_grid);
+    }
+}
+
 extern "C" int ek_feat_pam_sweep(ek_feat *k, int32_t metric, int32_t n_medoids,
                                  int64_t *medoids, const int64_t *proposals,
                                  const uint32_t *raw, int64_t n_raw, int64_t *pos,
@@ -1253,6 +1712,223 @@ extern "C" int ek_feat_pam_sweep(ek_feat *k, int32_t metric, int32_t n_medoids,
         FE_HIP(hipStreamSynchronize(k->s));
     }
     const unsigned blocks = (unsigned)nb;
+    // ---- round 5: windows of FEAT_WIN proposals, their distances in one pass ------------
+    // (EK_FEAT_PAM_WINDOWS=0: round 4's form below, a pass over the samples per proposal)
+    // Given proposals: always.  Drawn ones: only on request (EK_FEAT_PAM_WINDOWS=1) --
+    // on the data measured a draw stops holding every 5 to 8 proposals, and a window
+    // that short costs more to open than its one pass over the samples saves.
+    const char *fw_env = getenv("EK_FEAT_PAM_WINDOWS");
+    const bool fw_forced = fw_env && fw_env[0] == '1';
+    // (a window pays where the pass over the samples is most of a proposal: the samples
+    // well beyond the caches.  Drawn proposals: while the draws hold -- a window that
+    // ends within its first slots costs more to open than its one pass saves, the next
+    // hundred proposals then go one at a time before a window is tried again)
+    const bool fw_big = (int64_t)k->n * k->F * k->esize >= (64ll << 20);
+    if (!getenv("EK_FEAT_PAM_SYNC") && !(fw_env && fw_env[0] == '0')) {
+        if (!p.ctl) {
+            FE_HIP(hipMalloc((void **)&p.ctl, sizeof(FeatPamCtl)));
+            FE_HIP(hipMalloc((void **)&p.jdev, sizeof(int64_t)));
+            FE_HIP(hipMemsetAsync(p.jdev, 0, sizeof(int64_t), k->s));
+        }
+        if (!p.win) {
+            FE_HIP(hipMalloc((void **)&p.win, sizeof(FeatWin)));
+            FE_HIP(hipMalloc((void **)&p.Y, (size_t)FEAT_WIN * k->F * k->esize));
+            FE_HIP(hipMalloc((void **)&p.vecs, (size_t)FEAT_WIN * k->n * sizeof(double)));
+            FE_HIP(hipMalloc((void **)&p.blockcntW, (size_t)FEAT_WIN * nb * sizeof(int32_t)));
+            FE_HIP(hipMalloc((void **)&p.scanW, (size_t)FEAT_WIN * nb * sizeof(int64_t)));
+            FE_HIP(hipMalloc((void **)&p.totalW, FEAT_WIN * sizeof(int64_t)));
+        }
+        if (!p.accept_dev || K > p.Kcap_async) {
+            FE_HIP(hipStreamSynchronize(k->s));
+            (void)hipFree(p.accept_dev);
+            (void)hipFree(p.props_dev);
+            p.accept_dev = nullptr;
+            p.props_dev = nullptr;
+            FE_HIP(hipMalloc((void **)&p.accept_dev, (size_t)K * sizeof(int32_t)));
+            FE_HIP(hipMalloc((void **)&p.props_dev, (size_t)K * sizeof(int64_t)));
+            p.Kcap_async = K;
+        }
+        const int64_t raw_left = proposals ? 0 : std::max<int64_t>(n_raw - *pos, 0);
+        if (raw_left > p.raw_cap) {
+            FE_HIP(hipStreamSynchronize(k->s));
+            (void)hipFree(p.raw_dev);
+            p.raw_dev = nullptr;
+            p.raw_cap = 0;
+            FE_HIP(hipMalloc((void **)&p.raw_dev, (size_t)raw_left * sizeof(uint32_t)));
+            p.raw_cap = raw_left;
+        }
+        if (raw_left > 0)       // (positions on the device count from *pos)
+            FE_HIP(hipMemcpyAsync(p.raw_dev, raw + *pos, (size_t)raw_left * sizeof(uint32_t),
+                                  hipMemcpyHostToDevice, k->s));
+        if (proposals)
+            FE_HIP(hipMemcpyAsync(p.props_dev, proposals, (size_t)K * sizeof(int64_t),
+                                  hipMemcpyHostToDevice, k->s));
+        FeatPamCtl hc;
+        memset(&hc, 0, sizeof(hc));
+        FE_HIP(hipMemcpyAsync(p.ctl, &hc, sizeof(hc), hipMemcpyHostToDevice, k->s));
+        FE_HIP(hipMemsetAsync(p.accept_dev, 0, (size_t)K * sizeof(int32_t), k->s));
+        const int32_t cid_start = cid;
+        const dim3 near_grid((unsigned)std::min<int64_t>((k->n + FN_MB - 1) / FN_MB, 512),
+                             (unsigned)((K + EK_BLOCK - 1) / EK_BLOCK));
+        const int per = EK_BLOCK / 8;
+        const int32_t *halt = &p.ctl->status;
+        while (cid < K) {
+            // given proposals: nothing can end a window early, four of them are enqueued
+            // before the control block is read; drawn ones: one window, as wide as
+            // the draws have lately held (an accepted proposal that takes samples
+            // from or gives samples to a later cluster of the window ends it there)
+            const bool use_win = fw_forced || (fw_big && (proposals || p.plain_left <= 0));
+            if (!use_win) {
+                const int32_t c1 = std::min<int32_t>(
+                    K, cid + (p.plain_left > 0 ? std::min(128, p.plain_left) : 128));
+                feat_enqueue_plain_any(k, metric, p, K, cid, c1, proposals != nullptr, raw_left,
+                                       near_grid);
+                FE_HIP(hipGetLastError());
+                FE_HIP(hipMemcpyAsync(&hc, p.ctl, sizeof(hc), hipMemcpyDeviceToHost, k->s));
+                FE_HIP(hipStreamSynchronize(k->s));
+                if (hc.status)
+                    break;
+                p.plain_left -= c1 - cid;
+                cid = c1;
+                continue;
+            }
+            int32_t enq = cid;
+            const int first_cid0 = cid;
+            for (int w = 0; w < (proposals ? 4 : 1) && enq < K; ++w) {
+                const int32_t cid0 = enq;
+                const int cnt = std::min<int32_t>(proposals ? FEAT_WIN : p.win_width, K - cid0);
+                ++p.n_windows;
+                if (!proposals)
+                    ek_launch_count_members_multi(k->kassign, k->n, cid0, cnt, p.blockcntW,
+                                                  p.scanW, p.totalW, k->s);
+                hipLaunchKernelGGL(feat_window_draw_kernel, dim3(1), dim3(EK_WAVE), 0, k->s,
+                                   p.ctl, p.win, cid0, cnt, p.totalW, p.raw_dev,
+                                   (long long)raw_left,
+                                   proposals ? p.props_dev : (const int64_t *)nullptr);
+                if (!proposals)
+                    ek_launch_select_member_multi(k->kassign, k->n, cid0, cnt, p.scanW,
+                                                  p.win->want, p.win->prop, k->s);
+#define FW_OPEN(T, M)                                                          \
+    do {                                                                       \
+        hipLaunchKernelGGL((feat_window_gather_kernel<T>), dim3(cnt), dim3(EK_BLOCK), 0, \
+                           k->s, (const T *)k->tiles, k->F, p.win, (T *)p.Y, halt); \
+        if (cnt <= 4)                                                          \
+            hipLaunchKernelGGL((feat_multi_distance_kernel<T, M, 4>), dim3(blocks), \
+                               dim3(EK_BLOCK), 0, k->s, (const T *)k->tiles,   \
+                               (const T *)p.Y, k->n, k->F, cnt, p.vecs, halt); \
+        else if (cnt <= 8)                                                     \
+            hipLaunchKernelGGL((feat_multi_distance_kernel<T, M, 8>), dim3(blocks), \
+                               dim3(EK_BLOCK), 0, k->s, (const T *)k->tiles,   \
+                               (const T *)p.Y, k->n, k->F, cnt, p.vecs, halt); \
+        else if (cnt <= 16)                                                    \
+            hipLaunchKernelGGL((feat_multi_distance_kernel<T, M, 16>), dim3(blocks), \
+                               dim3(EK_BLOCK), 0, k->s, (const T *)k->tiles,   \
+                               (const T *)p.Y, k->n, k->F, cnt, p.vecs, halt); \
+        else                                                                   \
+            hipLaunchKernelGGL((feat_multi_distance_kernel<T, M, FEAT_WIN>), dim3(blocks), \
+                               dim3(EK_BLOCK), 0, k->s, (const T *)k->tiles,   \
+                               (const T *)p.Y, k->n, k->F, cnt, p.vecs, halt); \
+    } while (0)
+#define FW_SLOT(T, M)                                                          \
+    do {                                                                       \
+        hipLaunchKernelGGL((feat_slot_begin_kernel<T>), dim3(1), dim3(EK_BLOCK), 0, k->s, \
+                           p.ctl, p.win, cid0, j, proposals ? 0 : 1, k->F, p.Kcap, \
+                           (T *)p.MT, (T *)p.col, (const T *)p.Y, p.idx, p.counters); \
+        hipLaunchKernelGGL(feat_pam_classify_kernel, dim3(blocks), dim3(EK_BLOCK), 0, \
+                           k->s, k->kdist, k->kassign, p.vecs + (size_t)j * k->n, k->n, \
+                           cid0 + j, p.ndist, p.nassign, p.amb, p.counters, halt); \
+        hipLaunchKernelGGL((feat_pam_nearest_tiled_kernel<T, M>), near_grid,   \
+                           dim3(EK_BLOCK), 0, k->s, (const T *)k->tiles, k->F, \
+                           p.amb, p.counters, (const T *)p.MT, K, p.Kcap,      \
+                           p.ndist, p.nassign, halt, p.near_d, p.near_c, p.near_tick); \
+        hipLaunchKernelGGL(feat_pw_leaf_kernel, dim3((p.n_leaves + per - 1) / per), \
+                           dim3(EK_BLOCK), 0, k->s, k->kdist, p.ndist, p.shapes, \
+                           p.n_full, p.n_leaves, p.part, halt);                \
+        ek_launch_pw_chunks(p.part, p.shapes, p.n_full, p.n_leaves, p.n_chunks, k->s); \
+        hipLaunchKernelGGL((feat_total_decide_kernel<T>), dim3(1), dim3(EK_BLOCK), 0, \
+                           k->s, p.ctl, p.part + 2 * (size_t)p.n_leaves, p.n_chunks, \
+                           (long long)k->n, cid0 + j, p.idx, p.accept_dev, p.med, k->F, \
+                           p.Kcap, (T *)p.MT, (const T *)p.col);               \
+        hipLaunchKernelGGL(feat_commit_mask_kernel, dim3(blocks), dim3(EK_BLOCK), 0, k->s, \
+                           p.ctl, (long long)k->n, p.ndist, p.nassign, k->kdist, \
+                           k->kassign, cid0, cnt);                             \
+    } while (0)
+#define FW_ALL(T, M)                                                           \
+    do {                                                                       \
+        FW_OPEN(T, M);                                                         \
+        for (int j = 0; j < cnt; ++j)                                          \
+            FW_SLOT(T, M);                                                     \
+    } while (0)
+                if (k->kind == 0) {
+                    if (metric == 0)
+                        FW_ALL(float, 0);
+                    else
+                        FW_ALL(float, 1);
+                } else {
+                    if (metric == 0)
+                        FW_ALL(double, 0);
+                    else
+                        FW_ALL(double, 1);
+                }
+#undef FW_ALL
+#undef FW_SLOT
+#undef FW_OPEN
+                enq += cnt;
+            }
+            FE_HIP(hipGetLastError());
+            FE_HIP(hipMemcpyAsync(&hc, p.ctl, sizeof(hc), hipMemcpyDeviceToHost, k->s));
+            FE_HIP(hipStreamSynchronize(k->s));
+            if (!proposals && hc.status != 3)
+                p.win_width = std::min(FEAT_WIN, 2 * p.win_width);
+            if (hc.status == 3) {
+                // a draw no longer held: the next window opens at that cluster
+                ++p.n_stale;
+                p.win_width = std::max(2, std::min(FEAT_WIN, hc.win_stop - first_cid0 + 1));
+                if (!fw_forced && hc.win_stop - first_cid0 < 6) {
+                    p.plain_left = 96;
+                    p.win_width = 8;
+                }
+                cid = hc.win_stop;
+                hc.status = 0;
+                hc.moved = 0;
+                FE_HIP(hipMemcpyAsync(p.ctl, &hc, sizeof(hc), hipMemcpyHostToDevice, k->s));
+                continue;
+            }
+            if (hc.status)
+                break;
+            cid = enq;
+        }
+        if (getenv("EK_FEAT_PAM_VERBOSE"))
+            fprintf(stderr, "ek_feat_pam_sweep: %lld windows so far, %lld ended where a draw "
+                            "no longer held\n", (long long)p.n_windows, (long long)p.n_stale);
+        // what was decided: clusters cid_start .. (the stop)
+        const int32_t cid_end = hc.status ? hc.fail_cid : K;
+        if (cid_end > cid_start) {
+            std::vector<int64_t> hm((size_t)K);
+            FE_HIP(hipMemcpyAsync(accept + cid_start, p.accept_dev + cid_start,
+                                  (size_t)(cid_end - cid_start) * sizeof(int32_t),
+                                  hipMemcpyDeviceToHost, k->s));
+            FE_HIP(hipMemcpyAsync(hm.data(), p.med, (size_t)K * sizeof(int64_t),
+                                  hipMemcpyDeviceToHost, k->s));
+            FE_HIP(hipStreamSynchronize(k->s));
+            for (int32_t c = cid_start; c < cid_end; ++c)
+                if (accept[c])
+                    medoids[c] = hm[(size_t)c];
+        }
+        *pos += hc.pos;
+        if (hc.status) {
+            *cid_io = hc.fail_cid;
+            *status = hc.status;
+            return EK_OK;
+        }
+        FE_HIP(hipMemcpyAsync(dist_io, k->kdist, (size_t)k->n * sizeof(double),
+                              hipMemcpyDeviceToHost, k->s));
+        FE_HIP(hipMemcpyAsync(assign_io, k->kassign, (size_t)k->n * sizeof(int32_t),
+                              hipMemcpyDeviceToHost, k->s));
+        FE_HIP(hipStreamSynchronize(k->s));
+        *cid_io = K;
+        return EK_OK;
+    }
     // ---- round 4: the whole sweep enqueued, no host round trip per proposal ----------
     // The draw (numpy's choice on the raw outputs), the choice of the member, the
     // verdict and the commit are kernels; the host reads the control block every
@@ -1294,63 +1970,13 @@ extern "C" int ek_feat_pam_sweep(ek_feat *k, int32_t metric, int32_t n_medoids,
         FE_HIP(hipMemcpyAsync(p.ctl, &hc, sizeof(hc), hipMemcpyHostToDevice, k->s));
         FE_HIP(hipMemsetAsync(p.accept_dev, 0, (size_t)K * sizeof(int32_t), k->s));
         const int32_t cid_start = cid;
-        const unsigned near_blocks = (unsigned)std::min<int64_t>(k->n, 1024);
-        const int per = EK_BLOCK / 8;
+        const dim3 near_grid((unsigned)std::min<int64_t>((k->n + FN_MB - 1) / FN_MB, 512),
+                             (unsigned)((K + EK_BLOCK - 1) / EK_BLOCK));
         while (cid < K) {
             const int32_t stop = std::min(K, cid + 128);
-            for (; cid < stop; ++cid) {
-                // eight launches: [commit of the proposal before + member count],
-                // scan, [draw + member + proposal], [distances + classification],
-                // the ambiguous members' search, leaf sums, chunk sums, [totals +
-                // verdict]
-                hipLaunchKernelGGL(feat_commit_count_kernel, dim3(blocks), dim3(EK_BLOCK), 0,
-                                   k->s, p.ctl, (long long)k->n, p.ndist, p.nassign,
-                                   k->kdist, k->kassign, cid > cid_start ? 1 : 0,
-                                   proposals ? -1 : cid, p.blockcnt);
-                if (!proposals)
-                    ek_launch_scan_counts(p.blockcnt, k->n, p.scan, p.total, k->s);
-#define FA_T(T, M)                                                             \
-    do {                                                                       \
-        hipLaunchKernelGGL((feat_pick_kernel<T>), dim3(1), dim3(EK_BLOCK), 0, k->s, \
-                           p.ctl, cid, p.total, p.raw_dev, (long long)raw_left, \
-                           proposals ? p.props_dev : (const int64_t *)nullptr, \
-                           k->kassign, (long long)k->n, p.scan, nb,            \
-                           (const T *)k->tiles, k->F, p.Kcap, (T *)p.MT, (T *)p.col, \
-                           (T *)k->y, p.idx, p.counters);                      \
-        hipLaunchKernelGGL((feat_dist_classify_kernel<T, M>), dim3(blocks),    \
-                           dim3(EK_BLOCK), 0, k->s, (const T *)k->tiles,       \
-                           (const T *)k->y, k->n, k->F, k->kdist, k->kassign, cid, \
-                           p.ndist, p.nassign, p.amb, p.counters, &p.ctl->status); \
-        hipLaunchKernelGGL((feat_pam_nearest_kernel<T, M>), dim3(near_blocks), \
-                           dim3(EK_BLOCK), 0, k->s, (const T *)k->tiles, k->F, \
-                           p.amb, p.counters, (const T *)p.MT, K, p.Kcap,      \
-                           p.ndist, p.nassign, &p.ctl->status);                \
-        hipLaunchKernelGGL(feat_pw_leaf_kernel, dim3((p.n_leaves + per - 1) / per), \
-                           dim3(EK_BLOCK), 0, k->s, k->kdist, p.ndist, p.shapes, \
-                           p.n_full, p.n_leaves, p.part, &p.ctl->status);      \
-        ek_launch_pw_chunks(p.part, p.shapes, p.n_full, p.n_leaves, p.n_chunks, k->s); \
-        hipLaunchKernelGGL((feat_total_decide_kernel<T>), dim3(1), dim3(EK_BLOCK), 0, \
-                           k->s, p.ctl, p.part + 2 * (size_t)p.n_leaves, p.n_chunks, \
-                           (long long)k->n, cid, p.idx, p.accept_dev, p.med, k->F, \
-                           p.Kcap, (T *)p.MT, (const T *)p.col);               \
-    } while (0)
-                if (k->kind == 0) {
-                    if (metric == 0)
-                        FA_T(float, 0);
-                    else
-                        FA_T(float, 1);
-                } else {
-                    if (metric == 0)
-                        FA_T(double, 0);
-                    else
-                        FA_T(double, 1);
-                }
-#undef FA_T
-            }
-            // (the verdict on the batch's last proposal)
-            hipLaunchKernelGGL(feat_commit_count_kernel, dim3(blocks), dim3(EK_BLOCK), 0,
-                               k->s, p.ctl, (long long)k->n, p.ndist, p.nassign, k->kdist,
-                               k->kassign, 1, -1, p.blockcnt);
+            feat_enqueue_plain_any(k, metric, p, K, cid, stop, proposals != nullptr, raw_left,
+                                   near_grid);
+            cid = stop;
             FE_HIP(hipGetLastError());
             FE_HIP(hipMemcpyAsync(&hc, p.ctl, sizeof(hc), hipMemcpyDeviceToHost, k->s));
             FE_HIP(hipStreamSynchronize(k->s));
