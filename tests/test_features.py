@@ -231,6 +231,78 @@ def test_resident_feature_pam_equals_the_host_loop():
 
 
 @pytest.mark.gpu
+def test_feature_pam_windows_equal_one_proposal_at_a_time(monkeypatch):
+    """Round 5: a window of proposals takes every sample's distance to each of them
+    in one pass (EK_FEAT_PAM_WINDOWS=1 forces the form; by itself the library takes
+    it for samples beyond 64 MB).  A drawn proposal's window ends where an accepted
+    earlier one moved a sample into or out of its cluster -- noise in few dimensions
+    does that every few proposals, tight clusters hardly ever.  Same medoids, labels,
+    float64 distances and random stream as one proposal at a time (=0), which the
+    test above holds against the reference-shaped loop; also where the raw random
+    outputs run out inside a window and where a cluster of a window is empty."""
+    from enspara_amd.cluster import kmedoids as km
+    from enspara_amd.cluster.kcenters import kcenters
+    rng = np.random.RandomState(21)
+    tight = (rng.normal(size=(90, 6))[rng.randint(0, 90, size=6000)] +
+             0.02 * rng.normal(size=(6000, 6))).astype(np.float32)
+    cases = [
+        (rng.normal(size=(5000, 4)).astype(np.float32), 100),     # draws stop holding
+        (tight, 90),                                              # windows run to their end
+        (rng.randint(0, 4, size=(1500, 6)).astype(np.int64), 70), # exact ties
+        (rng.normal(size=(3000, 300)), 37),                       # float64, several LDS slices
+    ]
+    for X, K in cases:
+        for name in ("euclidean", "manhattan"):
+            r = kcenters(X, name, n_clusters=K)
+            for explicit in (False, True):
+                props = None
+                if explicit:
+                    props = [int(v) for v in rng.randint(0, len(X), size=K)]
+                out = {}
+                for w in ("1", "0"):
+                    monkeypatch.setenv("EK_FEAT_PAM_WINDOWS", w)
+                    rs = np.random.RandomState(4)
+                    inds = [int(i) for i in r.center_indices]
+                    d, a = r.distances.copy(), r.assignments.copy()
+                    for _ in range(2):
+                        inds, d, a, _c = km._kmedoids_pam_update(
+                            X, name, inds, a, d, proposals=props, random_state=rs)
+                    out[w] = (list(inds), d, a, rs.randint(1 << 30, size=3))
+                assert out["1"][0] == out["0"][0], (name, X.shape, explicit)
+                np.testing.assert_array_equal(out["1"][1], out["0"][1])
+                np.testing.assert_array_equal(out["1"][2], out["0"][2])
+                np.testing.assert_array_equal(out["1"][3], out["0"][3])
+    # the raw outputs run out inside windows, again and again
+    X, K = cases[0]
+    r = kcenters(X, "euclidean", n_clusters=K)
+    out = {}
+    for w, ahead in (("1", 2), ("0", None)):
+        monkeypatch.setenv("EK_FEAT_PAM_WINDOWS", w)
+        old_ahead, block = km.FEATURE_RAW_AHEAD, km._DrawStream.BLOCK
+        km.FEATURE_RAW_AHEAD = ahead
+        km._DrawStream.BLOCK = 4096 if ahead is None else 3
+        try:
+            rs = np.random.RandomState(9)
+            inds, d, a, _c = km._kmedoids_pam_update(
+                X, "euclidean", [int(i) for i in r.center_indices],
+                r.assignments.copy(), r.distances.copy(), random_state=rs)
+            out[w] = (list(inds), d, a, rs.randint(1 << 30, size=3))
+        finally:
+            km.FEATURE_RAW_AHEAD, km._DrawStream.BLOCK = old_ahead, block
+    assert out["1"][0] == out["0"][0]
+    for i in (1, 2, 3):
+        np.testing.assert_array_equal(out["1"][i], out["0"][i])
+    # an empty cluster in the middle of a window: choice([]) raises
+    monkeypatch.setenv("EK_FEAT_PAM_WINDOWS", "1")
+    a = r.assignments.copy()
+    a[a == 5] = 3
+    with pytest.raises(ValueError):
+        km._kmedoids_pam_update(X, "euclidean", [int(i) for i in r.center_indices],
+                                a.copy(), r.distances.copy(),
+                                random_state=np.random.RandomState(1))
+
+
+@pytest.mark.gpu
 def test_nan_features_keep_the_reference_loop():
     """np.argmax / .max() treat a NaN distance as the maximum and the
     reference's loop (kcenters.py:217, :282) stops on it; the device arg-max
