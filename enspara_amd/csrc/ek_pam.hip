@@ -1677,15 +1677,25 @@ static inline size_t ek_pair_lds_bytes()
            sizeof(float);
 }
 
+// A wave takes EK_PAIR_CPW columns, a workgroup is EK_PAM_GROUP / EK_PAIR_CPW waves.
+// Two columns per wave (the rows' coordinates read from LDS once for both) were
+// measured in round 5 and lost: 42 -> 51 us (tables), 46 -> 56 us (listed frames) --
+// with half the waves the rows' loads, sixteen 16-byte pieces per instruction, are
+// what the kernel waits for, not the LDS reads (profiles/r05/pam_pairs_cpw2.log).
+#ifndef EK_PAIR_CPW
+#define EK_PAIR_CPW 1
+#endif
 template <int MODE>
-__global__ void __launch_bounds__(EK_PAM_GROUP *EK_WAVE)
+__global__ void __launch_bounds__(EK_PAM_GROUP / EK_PAIR_CPW *EK_WAVE)
 ek_pam_pairs_kernel(EkPairArgs p)
 {
-    constexpr int NT = EK_PAM_GROUP * EK_WAVE;
+    constexpr int CPW = EK_PAIR_CPW;
+    constexpr int NT = EK_PAM_GROUP / CPW * EK_WAVE;
     constexpr int LD = EK_WAVE + 1;             // padded: conflict-free both ways
     constexpr int TPR = NT / EK_WAVE;           // threads per row
     constexpr int NLD = 3 * EK_PAIR_CH / TPR;   // loads per thread and slice
     constexpr int NY = (3 * EK_PAIR_CH + EK_WAVE - 1) / EK_WAVE;
+    static_assert(EK_PAM_GROUP % CPW == 0 && (3 * EK_PAIR_CH) % TPR == 0, "tiling");
     extern __shared__ __attribute__((aligned(16))) float pair_lds[];
     float *tile = pair_lds;                                 // [3 CH][LD]
     float *ytile = pair_lds + 3 * EK_PAIR_CH * LD;          // [columns][3 CH]
@@ -1698,21 +1708,28 @@ ek_pam_pairs_kernel(EkPairArgs p)
     const bool old = MODE == 0 && (int)blockIdx.y >= gp;
     const int grp = old ? (int)blockIdx.y - gp : (int)blockIdx.y;
     const int jw = __builtin_amdgcn_readfirstlane(threadIdx.x / EK_WAVE);
-    const int j = grp * EK_PAM_GROUP + jw;      // this wave's column
     const int ncol = old ? p.n_old : p.n_col;
-    const bool live = j < ncol;
-    // this wave's column
-    const float *y = p.aos;
-    double Gy = 0.0;
-    if (live) {
-        if (old) {
-            const int r = (p.old_lo + j == p.held) ? p.K : p.old_lo + j;
-            y = p.aos + (size_t)r * 3 * A;
-            Gy = p.G[r];
-        } else {
-            const size_t rstride = ek_rec_bytes(A);
-            y = (const float *)(p.recs + (size_t)j * rstride + sizeof(EkRecHdr));
-            Gy = ((const EkRecHdr *)(p.recs + (size_t)j * rstride))->trace;
+    // this wave's columns
+    int jc[CPW];
+    bool live[CPW];
+    const float *y[CPW];
+    double Gy[CPW];
+#pragma unroll
+    for (int u = 0; u < CPW; ++u) {
+        jc[u] = grp * EK_PAM_GROUP + jw * CPW + u;
+        live[u] = jc[u] < ncol;
+        y[u] = p.aos;
+        Gy[u] = 0.0;
+        if (live[u]) {
+            if (old) {
+                const int r = (p.old_lo + jc[u] == p.held) ? p.K : p.old_lo + jc[u];
+                y[u] = p.aos + (size_t)r * 3 * A;
+                Gy[u] = p.G[r];
+            } else {
+                const size_t rstride = ek_rec_bytes(A);
+                y[u] = (const float *)(p.recs + (size_t)jc[u] * rstride + sizeof(EkRecHdr));
+                Gy[u] = ((const EkRecHdr *)(p.recs + (size_t)jc[u] * rstride))->trace;
+            }
         }
     }
     // row `m` of the workgroup: where it lives, whether it exists
@@ -1730,17 +1747,23 @@ ek_pam_pairs_kernel(EkPairArgs p)
     const int lm = threadIdx.x / TPR, le = threadIdx.x % TPR;
     bool lok;
     const float *lrow = p.aos + (size_t)row_of(lm, lok) * 3 * A;
-    float S[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    float v[NLD], vy[NY];       // the slice after the one being worked on
+    float S[CPW][9];
+#pragma unroll
+    for (int u = 0; u < CPW; ++u)
+#pragma unroll
+        for (int q = 0; q < 9; ++q)
+            S[u][q] = 0.f;
+    float v[NLD], vy[CPW][NY];  // the slice after the one being worked on
 #define EK_PAIR_LOAD(A0)                                                       \
     _Pragma("unroll") for (int k = 0; k < NLD; ++k) {                          \
         const int e = le + TPR * k;                                            \
         v[k] = (3 * (A0) + e < 3 * A && lok) ? lrow[3 * (A0) + e] : 0.f;       \
     }                                                                          \
+    _Pragma("unroll") for (int u = 0; u < CPW; ++u)                            \
     _Pragma("unroll") for (int k = 0; k < NY; ++k) {                           \
         const int e = lane + EK_WAVE * k;                                      \
-        vy[k] = (live && e < 3 * EK_PAIR_CH && 3 * (A0) + e < 3 * A)           \
-                    ? y[3 * (A0) + e] : 0.f;                                   \
+        vy[u][k] = (live[u] && e < 3 * EK_PAIR_CH && 3 * (A0) + e < 3 * A)     \
+                       ? y[u][3 * (A0) + e] : 0.f;                             \
     }
     EK_PAIR_LOAD(0)
     for (int a0 = 0; a0 < A; a0 += EK_PAIR_CH) {
@@ -1750,50 +1773,69 @@ ek_pam_pairs_kernel(EkPairArgs p)
         for (int k = 0; k < NLD; ++k)
             tile[(le + TPR * k) * LD + lm] = v[k];
 #pragma unroll
-        for (int k = 0; k < NY; ++k)
-            if (lane + EK_WAVE * k < 3 * EK_PAIR_CH)
-                ytile[jw * 3 * EK_PAIR_CH + lane + EK_WAVE * k] = vy[k];
+        for (int u = 0; u < CPW; ++u)
+#pragma unroll
+            for (int k = 0; k < NY; ++k)
+                if (lane + EK_WAVE * k < 3 * EK_PAIR_CH)
+                    ytile[(jw * CPW + u) * 3 * EK_PAIR_CH + lane + EK_WAVE * k] = vy[u][k];
         __syncthreads();
         if (a0 + EK_PAIR_CH < A)                // in flight during the FMAs
             EK_PAIR_LOAD(a0 + EK_PAIR_CH)
-        if (live) {
-            const float *yt = ytile + jw * 3 * EK_PAIR_CH;
-#pragma unroll 8
+        if (live[0]) {                          // (the wave's first column: the others follow it)
+            const float *yt = ytile + jw * CPW * 3 * EK_PAIR_CH;
+#pragma unroll 4
             for (int a = 0; a < ch; ++a) {
                 const float x0 = tile[(3 * a + 0) * LD + lane],
                             x1 = tile[(3 * a + 1) * LD + lane],
                             x2 = tile[(3 * a + 2) * LD + lane];
-                const float y0 = yt[3 * a], y1 = yt[3 * a + 1], y2 = yt[3 * a + 2];
-                S[0] = fmaf(x0, y0, S[0]); S[1] = fmaf(x0, y1, S[1]);
-                S[2] = fmaf(x0, y2, S[2]); S[3] = fmaf(x1, y0, S[3]);
-                S[4] = fmaf(x1, y1, S[4]); S[5] = fmaf(x1, y2, S[5]);
-                S[6] = fmaf(x2, y0, S[6]); S[7] = fmaf(x2, y1, S[7]);
-                S[8] = fmaf(x2, y2, S[8]);
+#pragma unroll
+                for (int u = 0; u < CPW; ++u) {
+                    const float y0 = yt[u * 3 * EK_PAIR_CH + 3 * a],
+                                y1 = yt[u * 3 * EK_PAIR_CH + 3 * a + 1],
+                                y2 = yt[u * 3 * EK_PAIR_CH + 3 * a + 2];
+                    S[u][0] = fmaf(x0, y0, S[u][0]); S[u][1] = fmaf(x0, y1, S[u][1]);
+                    S[u][2] = fmaf(x0, y2, S[u][2]); S[u][3] = fmaf(x1, y0, S[u][3]);
+                    S[u][4] = fmaf(x1, y1, S[u][4]); S[u][5] = fmaf(x1, y2, S[u][5]);
+                    S[u][6] = fmaf(x2, y0, S[u][6]); S[u][7] = fmaf(x2, y1, S[u][7]);
+                    S[u][8] = fmaf(x2, y2, S[u][8]);
+                }
             }
         }
     }
 #undef EK_PAIR_LOAD
     bool ok;
     const int64_t row = row_of(lane, ok);
-    float D = __builtin_inff();
-    if (live && ok)
-        D = ek_rmsd_from_S(S, p.G[row], Gy, A);
+    const double Gx = ok ? p.G[row] : 0.0;
+    float D[CPW];
+#pragma unroll
+    for (int u = 0; u < CPW; ++u) {
+        D[u] = __builtin_inff();
+        if (live[u] && ok)
+            D[u] = ek_rmsd_from_S(S[u], Gx, Gy[u], A);
+    }
     if (MODE == 1) {
-        if (live && ok)
-            p.vecs[(size_t)j * p.n_pad + row] = D;
+#pragma unroll
+        for (int u = 0; u < CPW; ++u)
+            if (live[u] && ok)
+                p.vecs[(size_t)jc[u] * p.n_pad + row] = D[u];
         return;
     }
     const int c = blockIdx.x * EK_WAVE + lane;
-    if (live && ok)
-        (old ? p.O : p.T)[(size_t)j * p.K + c] = D;
+#pragma unroll
+    for (int u = 0; u < CPW; ++u)
+        if (live[u] && ok)
+            (old ? p.O : p.T)[(size_t)jc[u] * p.K + c] = D[u];
     if (old && !p.dprop)
         return;
-    if (old) {                  // (bounds: see above)
-        D = (live && ok) ? fmaxf(D - p.dprop[j], 0.f) : __builtin_inff();
-        if (live && ok)
-            p.T[(size_t)j * p.K + c] = D;
+#pragma unroll
+    for (int u = 0; u < CPW; ++u) {
+        if (old) {              // (bounds: see above)
+            D[u] = (live[u] && ok) ? fmaxf(D[u] - p.dprop[jc[u]], 0.f) : __builtin_inff();
+            if (live[u] && ok)
+                p.T[(size_t)jc[u] * p.K + c] = D[u];
+        }
+        tmin[jw * CPW + u][lane] = D[u];
     }
-    tmin[jw][lane] = D;
     __syncthreads();
     if (jw == 0 && ok) {
         float m = tmin[0][lane];
@@ -1810,8 +1852,8 @@ static void ek_pairs_launch(const EkPairArgs &p, dim3 grid, hipStream_t s)
     const size_t lds = ek_pair_lds_bytes();     // above the 64 KB a kernel gets unasked
     (void)hipFuncSetAttribute((const void *)ek_pam_pairs_kernel<MODE>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(ek_pam_pairs_kernel<MODE>, grid, dim3(EK_PAM_GROUP * EK_WAVE),
-                       lds, s, p);
+    hipLaunchKernelGGL(ek_pam_pairs_kernel<MODE>, grid,
+                       dim3(EK_PAM_GROUP / EK_PAIR_CPW * EK_WAVE), lds, s, p);
 }
 
 void ek_launch_pam_tables(const float *aos, const double *Gm, int A, int K, int held,
