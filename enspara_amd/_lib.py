@@ -47,7 +47,7 @@ SYMBOLS = [
     "ek_msm_counts", "ek_msm_counts_ctx", "ek_msm_row_normalize",
     "ek_krylov_create", "ek_krylov_destroy", "ek_krylov_set_vector",
     "ek_krylov_get_vector", "ek_krylov_step", "ek_krylov_rotate",
-    "ek_krylov_combine", "ek_krylov_expand",
+    "ek_krylov_combine", "ek_krylov_expand", "ek_krylov_set_filter",
     "ek_feat_create", "ek_feat_destroy", "ek_feat_load", "ek_feat_distance",
     "ek_feat_kcenters", "ek_feat_pam_sweep", "ek_feat_pam_release",
     "ek_set_frames_per_lane", "ek_set_option", "ek_last_run_timing",
@@ -179,6 +179,7 @@ def load():
     L.ek_krylov_set_vector.argtypes = [vp, i32, f64p]
     L.ek_krylov_get_vector.argtypes = [vp, i32, f64p]
     L.ek_krylov_step.argtypes = [vp, i32, i32, f64p]
+    L.ek_krylov_set_filter.argtypes = [vp, i32, C.c_double, C.c_double]
     L.ek_krylov_rotate.argtypes = [vp, i32, i32, f64p, i32]
     L.ek_krylov_combine.argtypes = [vp, i32, i32, f64p, f64p]
     L.ek_krylov_expand.argtypes = [vp, i32, i32, f64p, i32]

@@ -34,6 +34,11 @@ struct ek_krylov {
     double *h = nullptr;      // [m_max + 2] coefficients of one pass
     double *q = nullptr;      // [(m_max+1) * (m_max+1)] rotation matrix
     double *hcols = nullptr;  // [m_max][m_max + 2] Hessenberg columns (expand)
+    // the operator of the steps: A itself (fdeg 0) or the Chebyshev polynomial of
+    // degree fdeg of (A - fc) / fe (ek_krylov_set_filter)
+    int32_t fdeg = 0;
+    double fc = 0.0, fe = 1.0;
+    double *t[2] = {nullptr, nullptr};  // [n] each: the recurrence's other vectors
 };
 
 #define KR_HIP(call)                                                           \
@@ -125,6 +130,20 @@ kr_rotate_kernel(const double *__restrict__ V, const double *__restrict__ Q,
     out[(size_t)c * n + e] = x;
 }
 
+// out = alpha (A x - c x) + beta z, x = x_raw / ||x_raw|| where `part` is given (the
+// norm's partial sums of the step before, as in kr_spmv_norm_kernel: then V_out
+// receives x and *col_last the norm).  z may be `out` itself (a row reads its own
+// element before it writes it).  One wave per row.
+__global__ void __launch_bounds__(EK_BLOCK)
+kr_spmv_cheb_kernel(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                    const double *__restrict__ data, const double *x_raw,
+                    const double *__restrict__ part, int nb, int64_t n, double c,
+                    double alpha, const double *z, double beta, double *out,
+                    double *V_out, double *col_last);
+
+static double *kr_apply_filter(ek_krylov *k, const double *x_raw, double *Vj, double *col_last,
+                               int nb, double *avoid);
+
 static inline unsigned kr_blocks(int64_t n)
 {
     return (unsigned)std::max<int64_t>(1, (n + EK_BLOCK - 1) / EK_BLOCK);
@@ -148,6 +167,8 @@ extern "C" int ek_krylov_destroy(ek_krylov *k)
     (void)hipFree(k->h);
     (void)hipFree(k->q);
     (void)hipFree(k->hcols);
+    (void)hipFree(k->t[0]);
+    (void)hipFree(k->t[1]);
     if (k->s)
         (void)hipStreamDestroy(k->s);
     delete k;
@@ -185,6 +206,8 @@ extern "C" int ek_krylov_create(int device, int64_t n, const int64_t *indptr,
     KA(k->h, (size_t)(m_max + 2) * sizeof(double));
     KA(k->q, (size_t)(m_max + 1) * (m_max + 1) * sizeof(double));
     KA(k->hcols, (size_t)m_max * (m_max + 2) * sizeof(double));
+    KA(k->t[0], (size_t)n * sizeof(double));
+    KA(k->t[1], (size_t)n * sizeof(double));
 #undef KA
     if (e == hipSuccess)        // (ek_krylov_expand copies whole columns out)
         e = hipMemsetAsync(k->hcols, 0, (size_t)m_max * (m_max + 2) * sizeof(double), k->s);
@@ -245,7 +268,11 @@ extern "C" int ek_krylov_step(ek_krylov *k, int32_t j, int32_t apply,
     KR_HIP(hipSetDevice(k->device));
     const int64_t n = k->n;
     const int cnt = j + 1;
-    if (apply) {
+    if (apply && k->fdeg >= 2) {
+        double *r = kr_apply_filter(k, nullptr, k->V + (size_t)j * n, nullptr, 0, k->w);
+        KR_HIP(hipMemcpyAsync(k->w, r, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice,
+                              k->s));
+    } else if (apply) {
         hipLaunchKernelGGL(kr_spmv_kernel, dim3((unsigned)((n + 3) / 4)),
                            dim3(EK_BLOCK), 0, k->s, k->indptr, k->indices,
                            k->data, k->V + (size_t)j * n, n, k->w);
@@ -357,6 +384,88 @@ __device__ __forceinline__ double kr_total(const double *__restrict__ part, int 
     return t;
 }
 
+__global__ void __launch_bounds__(EK_BLOCK)
+kr_spmv_cheb_kernel(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                    const double *__restrict__ data, const double *x_raw,
+                    const double *__restrict__ part, int nb, int64_t n, double c,
+                    double alpha, const double *z, double beta, double *out,
+                    double *V_out, double *col_last)
+{
+    const int64_t row = (int64_t)blockIdx.x * (EK_BLOCK / EK_WAVE) +
+                        threadIdx.x / EK_WAVE;
+    const int lane = threadIdx.x & (EK_WAVE - 1);
+    if (row >= n)
+        return;
+    const double nrm = part ? sqrt(kr_total(part, nb)) : 1.0;
+    double acc = 0.0;
+    for (int64_t j = indptr[row] + lane; j < indptr[row + 1]; j += EK_WAVE) {
+        const double v = part ? ((nrm > 0.0) ? x_raw[indices[j]] / nrm : 0.0)
+                              : x_raw[indices[j]];
+        acc = __builtin_fma(data[j], v, acc);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+        acc = acc + __shfl_xor(acc, off, 64);
+    if (lane == 0) {
+        const double xr = part ? ((nrm > 0.0) ? x_raw[row] / nrm : 0.0) : x_raw[row];
+        if (V_out) {
+            V_out[row] = xr;
+            if (row == 0)
+                *col_last = nrm;
+        }
+        double r = alpha * (acc - c * xr);
+        if (z)
+            r = r + beta * z[row];
+        out[row] = r;
+    }
+}
+
+// w = T_d((A - c) / e) x by the three-term recurrence, d launches: y_1 = (A - c) y_0 / e,
+// y_{k+1} = 2 (A - c) y_k / e - y_{k-1}.  x is V[j] (x_raw = nullptr) or x_raw / its
+// norm (then V[j] and the column's last entry are written on the way).  -> where the
+// result is (one of k->w, k->w2, k->t[0], k->t[1], never x_raw)
+static double *kr_apply_filter(ek_krylov *k, const double *x_raw, double *Vj, double *col_last,
+                               int nb, double *avoid)
+{
+    const int64_t n = k->n;
+    double *bufs[4] = {k->w, k->w2, k->t[0], k->t[1]};
+    double *free2[2];
+    int nf = 0;
+    for (int i = 0; i < 4 && nf < 2; ++i)
+        if (bufs[i] != x_raw && bufs[i] != avoid)
+            free2[nf++] = bufs[i];
+    double *cur = free2[0], *other = free2[1];
+    const dim3 grid((unsigned)((n + 3) / 4));
+    // y_1 -> cur
+    hipLaunchKernelGGL(kr_spmv_cheb_kernel, grid, dim3(EK_BLOCK), 0, k->s, k->indptr,
+                       k->indices, k->data, x_raw ? x_raw : (const double *)Vj,
+                       x_raw ? k->part : (const double *)nullptr, nb, n, k->fc, 1.0 / k->fe,
+                       (const double *)nullptr, 0.0, cur, x_raw ? Vj : (double *)nullptr,
+                       col_last);
+    for (int d = 2; d <= k->fdeg; ++d) {
+        // y_d = 2 (A - c) y_{d-1} / e - y_{d-2}: y_{d-1} is in cur, y_{d-2} in Vj (d == 2)
+        // or in other, which the result overwrites
+        hipLaunchKernelGGL(kr_spmv_cheb_kernel, grid, dim3(EK_BLOCK), 0, k->s, k->indptr,
+                           k->indices, k->data, (const double *)cur,
+                           (const double *)nullptr, nb, n, k->fc, 2.0 / k->fe,
+                           d == 2 ? (const double *)Vj : (const double *)other, -1.0, other,
+                           (double *)nullptr, (double *)nullptr);
+        std::swap(cur, other);
+    }
+    return cur;
+}
+
+extern "C" int ek_krylov_set_filter(ek_krylov *k, int32_t degree, double a, double b)
+{
+    if (!k || degree < 0 || degree == 1 || degree > 4096 || (degree > 0 && !(b > a)))
+        return ek_set_error(EK_EARG, "ek_krylov_set_filter: degree 0 (none) or 2 .. 4096 "
+                                     "on an interval a < b");
+    k->fdeg = degree;
+    k->fc = degree ? 0.5 * (a + b) : 0.0;
+    k->fe = degree ? 0.5 * (b - a) : 1.0;
+    return EK_OK;
+}
+
 // w_out = A (w_prev / ||w_prev||), and on the way V_out = w_prev / ||w_prev||,
 // *col_last = ||w_prev||: the normalisation of the step before folded into the
 // sparse product of this one (the product reads w_prev / nrm, the very values
@@ -458,7 +567,14 @@ extern "C" int ek_krylov_expand(ek_krylov *k, int32_t j0, int32_t m,
     for (int j = j0; j < m; ++j) {
         const int cnt = j + 1;
         double *col = k->hcols + (size_t)j * ld;
-        if (j == j0)
+        if (k->fdeg >= 2) {
+            // (the result lands in one of four vectors; the orthogonalisation below
+            // works on it in place, the next step reads it as w_prev)
+            w = (j == j0)
+                    ? kr_apply_filter(k, nullptr, k->V + (size_t)j * n, nullptr, nb, nullptr)
+                    : kr_apply_filter(k, w_prev, k->V + (size_t)j * n,
+                                      k->hcols + (size_t)(j - 1) * ld + j, nb, nullptr);
+        } else if (j == j0)
             hipLaunchKernelGGL(kr_spmv_kernel, dim3((unsigned)((n + 3) / 4)),
                                dim3(EK_BLOCK), 0, k->s, k->indptr, k->indices,
                                k->data, k->V + (size_t)j * n, n, w);

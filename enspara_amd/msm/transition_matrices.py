@@ -149,6 +149,12 @@ class DeviceKrylov:
         _lib.check(self.L.ek_krylov_get_vector(self._h, int(j), _lib.f64p(v)))
         return v
 
+    def set_filter(self, degree, a=0.0, b=1.0):
+        """the operator of step() / expand(): A (degree 0) or the Chebyshev
+        polynomial of that degree on [a, b] (ek_krylov_set_filter)"""
+        _lib.check(self.L.ek_krylov_set_filter(self._h, int(degree), float(a),
+                                               float(b)))
+
     def step(self, j, apply=True):
         h = np.empty(j + 2, dtype=np.float64)
         _lib.check(self.L.ek_krylov_step(self._h, int(j), 1 if apply else 0,
@@ -234,8 +240,115 @@ def _expand(space, H, j0, m, rng_seed=1):
     return m
 
 
-def _leading_eigs(space, k, tol=1e-12, max_restarts=500):
-    """k eigenpairs of largest real part.  -> (vals complex [k], vecs [n, k])"""
+# The restarted iteration on a polynomial of the matrix (round 5).  1: once the first
+# cycle has shown where the wanted eigenvalues end, the steps apply the Chebyshev
+# polynomial that keeps everything below that within [-1, 1] and pulls what is above
+# apart; 0: the plain iteration (round 4's).  Same eigenpairs: they are the
+# MATRIX's, by Rayleigh-Ritz on the converged subspace, residuals checked.
+FILTER = 1
+LAST_RUN = {}           # (diagnostics of the last _leading_eigs call)
+
+
+def _cheb(z, d):
+    return np.cosh(d * np.arccosh(np.asarray(z, dtype=complex)))
+
+
+def _degree_for(top, a, b):
+    """Chebyshev degree on [a, b] that amplifies `top` about thirtyfold (cosh 4)"""
+    w1 = (top - 0.5 * (a + b)) / (0.5 * (b - a))
+    if not (w1 > 1.0 + 1e-10):
+        return None
+    return int(np.clip(np.ceil(4.0 / np.arccosh(w1)), 4, 64))
+
+
+def _plan_filter(theta, k, scout=None):
+    """theta: estimates of the leading eigenvalues (the Ritz values of a cycle on the
+    matrix, or _unfilter's of a cycle on a polynomial).  -> (degree, a, b, kf):
+    Chebyshev degree, damped interval, how many pairs to converge; or None.
+    scout = (n, m): the first plan, from the Ritz values of ONE cycle on the matrix.
+    Where the leading eigenvalues cluster those place the end of the wanted ones far
+    too low (the 26th of 60 at 0.54 for eigenvalues within 0.003 of 1), but they
+    sample the spectrum the way Chebyshev nodes do: the j-th largest sits near the
+    n sin^2(pi j / 2m)-th eigenvalue.  The interval ends at the one that stands for
+    somewhat more eigenvalues than a restart keeps; if that was too high -- fewer
+    pairs above it than wanted -- the cycle on the polynomial shows it and the
+    interval is lowered (_leading_eigs)."""
+    th = theta[np.argsort(-theta.real, kind="stable")]
+    kf = min(len(th) - 2, k + max(4, k // 4))
+    if kf < k or kf < 1:
+        return None
+    top = float(th[0].real)
+    lo = float(th.real.min())
+    a = min(-1.0, lo - 0.05 * (top - lo))
+    keep = min(len(th) - 2, kf + (len(th) - kf) // 2)   # what a restart keeps
+    if scout is not None:
+        n, m = scout
+        j = int(np.ceil(2.0 * m / np.pi * np.arcsin(np.sqrt(min(1.0, 1.3 * keep / n))))) + 1
+        j = int(np.clip(j, 2, kf))
+        b = float(th[j].real)
+        d = _degree_for(top, a, b) if top > b > a else None
+        if not d:
+            return None
+        # Eigenvalues off the real axis grow under the polynomial with their distance
+        # from [a, b] in ANY direction: a pair at 0.1 +- 0.7 i would pass the real ones
+        # at 0.67.  The cycle's Ritz values show the periphery of the spectrum; none
+        # below the interval's end may come out of the polynomial beyond the band the
+        # real ones there are confined to (else: the plain iteration)
+        pv = _cheb((th - 0.5 * (a + b)) / (0.5 * (b - a)), d)
+        below = th.real <= b
+        if below.any() and np.abs(pv[below]).max() > 1.5:
+            return None
+        return d, a, b, kf
+    # b: the highest of the estimates below what a restart keeps (each is, at worst, a
+    # lower bound of its eigenvalue: the wanted ones stay outside the interval, and so
+    # does what they converge against) for which a polynomial of reasonable degree
+    # lifts ALL the pairs to converge well clear of [-1, 1], where everything else ends
+    # up, and keeps their order by real part (eigenvalues off the real axis turn with
+    # the degree)
+    for idx in range(keep, len(th) - 1):
+        b = float(th[idx].real)
+        d = _degree_for(top, a, b) if top > b > a else None
+        if not d:
+            continue
+        c, e = 0.5 * (a + b), 0.5 * (b - a)
+        pv = _cheb((th[:kf] - c) / e, d).real
+        if np.all(np.diff(pv) <= 1e-6 * abs(pv[0])) and pv[kf - 1] >= 4.0:
+            return d, a, b, kf
+    return None
+
+
+def _unfilter(theta_b, flt):
+    """Estimates of the matrix's eigenvalues from the Ritz values of its polynomial:
+    the Chebyshev map inverted where it is one to one (beyond 1); what lies in the
+    damped band is only known to be below b."""
+    d, a, b = flt
+    c, e = 0.5 * (a + b), 0.5 * (b - a)
+    z = np.asarray(theta_b, dtype=complex)
+    out = np.full(z.shape, b, dtype=complex)
+    up = z.real > 1.0
+    out[up] = c + e * np.cosh(np.arccosh(z[up]) / d)
+    return out
+
+
+def _rayleigh_ritz(A, X):
+    """Eigenpairs of A restricted to span(X) (complex [n, q], an approximately
+    invariant subspace).  -> (values, vectors [n, r], relative residuals)"""
+    import scipy.linalg
+    Z = np.concatenate([X.real, X.imag], axis=1)
+    U, sv, _ = np.linalg.svd(Z, full_matrices=False)
+    r = int((sv > 1e-9 * sv[0]).sum())
+    Q = U[:, :r]
+    AQ = A @ Q
+    lam, W = scipy.linalg.eig(Q.T @ AQ)
+    Xn = Q @ W
+    res = np.linalg.norm(AQ @ W - Xn * lam, axis=0) / np.linalg.norm(Xn, axis=0)
+    return lam, Xn, res
+
+
+def _leading_eigs(space, k, tol=1e-12, max_restarts=500, A=None):
+    """k eigenpairs of largest real part.  -> (vals complex [k], vecs [n, k]).
+    A: the matrix itself (scipy sparse), for the filtered iteration's Rayleigh-Ritz;
+    None: the plain iteration only."""
     import scipy.linalg
     n = space.n
     m = space.m_max
@@ -245,7 +358,17 @@ def _leading_eigs(space, k, tol=1e-12, max_restarts=500):
     H = np.zeros((m + 1, m))
     space.set_vector(0, _start_vector(n))
     j0 = 0
-    for restart in range(max_restarts):
+    can_filter = bool(FILTER) and A is not None and not full and hasattr(space, "set_filter")
+    phase = 0               # 0: on the matrix; 1: on the polynomial; 2: on the matrix again
+    k_want = k
+    flt = None              # (degree, a, b) of the polynomial in use
+    stats = {"restarts": [0, 0, 0], "filter": None, "fallback": False, "plans": 0}
+    LAST_RUN.clear()
+    LAST_RUN.update(stats)
+    restart = 0
+    while restart < max_restarts:
+        restart += 1
+        LAST_RUN["restarts"][phase] += 1
         m_eff = _expand(space, H, j0, m)
         Hm = H[:m_eff, :m_eff]
         b = H[m_eff, :m_eff].copy() if m_eff < H.shape[0] else np.zeros(m_eff)
@@ -260,11 +383,10 @@ def _leading_eigs(space, k, tol=1e-12, max_restarts=500):
             lambda re, im: False, np.asfortranarray(Hm), sort_t=0)
         if info != 0:
             raise np.linalg.LinAlgError("dgees failed (info %d)" % info)
-        vals = wr + 1j * wi
         order = np.argsort(-wr, kind="stable")
         # keep k wanted + some extra, never splitting a conjugate pair (the two
         # rows of a 2 x 2 block are neighbours: wi > 0 then wi < 0)
-        p = min(m - 1, k + max(1, (m - k) // 2))
+        p = min(m - 1, k_want + max(1, (m - k_want) // 2))
         select = np.zeros(m_eff, dtype=np.int32)
         select[order[:p]] = 1
         for i in np.flatnonzero(select):
@@ -291,22 +413,109 @@ def _leading_eigs(space, k, tol=1e-12, max_restarts=500):
             # kept (or the plain truncation after k), not splitting a 2 x 2
             # block: a restart from a Schur form that is not perfectly sorted
             # converges a little later, it does not fail.
-            p = p if 1 <= p < m else max(1, min(m - 1, k))
+            p = p if 1 <= p < m else max(1, min(m - 1, k_want))
             if p < m_eff and S[p, p - 1] != 0.0:
                 p = p + 1 if p + 1 < m else p - 1
         bz = b @ Z
         # residuals of the wanted Ritz pairs
         sv, sy = scipy.linalg.eig(S[:p, :p])
-        o2 = np.argsort(-sv.real, kind="stable")[:k]
+        o2 = np.argsort(-sv.real, kind="stable")[:k_want]
         res = np.abs(bz[:p] @ sy[:, o2])
-        if np.all(res <= tol * np.maximum(np.abs(sv[o2]), 1e-3)):
+        converged = np.all(res <= tol * np.maximum(np.abs(sv[o2]), 1e-3))
+        if converged and phase != 1:
             break
+        if (phase == 0 and can_filter) or (phase == 1 and not converged and
+                                           LAST_RUN["plans"] < 4):
+            # ---- a cycle is through: go on with a (better) polynomial of the matrix? ----
+            plan = None
+            if phase == 0:
+                plan = _plan_filter(wr + 1j * wi, k, scout=(n, m))
+                phase = 2
+            else:
+                top = float(_unfilter(np.array([wr.max()]), flt)[0].real)
+                if int((wr > 1.5).sum()) < k_want + 2:
+                    # fewer pairs above the interval than are to converge: it ends too
+                    # high -- four times as far below the largest eigenvalue
+                    fb = top - 4.0 * (top - flt[2])
+                    d = _degree_for(top, flt[1], fb) if fb > flt[1] else None
+                    plan = (d, flt[1], fb, k_want) if d else None
+                    if plan is None:
+                        # (no interval left to try: the plain iteration from here)
+                        LAST_RUN["fallback"] = True
+                        y = (Z[:, :p] @ sy[:, o2]).real.sum(axis=1)
+                        x0 = space.combine(m_eff, y.reshape(-1, 1))[0]
+                        space.set_filter(0)
+                        space.set_vector(0, x0 / np.linalg.norm(x0))
+                        H[:] = 0.0
+                        j0 = 0
+                        k_want = k
+                        phase = 2
+                        continue
+                else:
+                    # every change of polynomial starts the basis over from one vector:
+                    # only for an interval that leaves less than half as much above it
+                    # (and only away from a weak one: past a degree of 16 what a higher
+                    # interval gains in restarts it pays in products, measured)
+                    plan = _plan_filter(_unfilter(wr + 1j * wi, flt), k) if flt[0] < 16 \
+                        else None
+                    if plan is not None and not (top - plan[2] < 0.5 * (top - flt[2])):
+                        plan = None
+            if plan is not None:
+                d, fa, fb, kf = plan
+                LAST_RUN["plans"] += 1
+                flt = (d, fa, fb)
+                LAST_RUN["filter"] = {"degree": d, "a": fa, "b": fb, "pairs": kf}
+                # a start vector rich in the wanted directions: the sum of the
+                # leading Ritz vectors (x = V Z y)
+                y = (Z[:, :p] @ sy[:, np.argsort(-sv.real, kind="stable")[:kf]]).real.sum(axis=1)
+                x0 = space.combine(m_eff, y.reshape(-1, 1))[0]
+                nx = np.linalg.norm(x0)
+                if nx > 0 and np.all(np.isfinite(x0)):
+                    space.set_filter(d, fa, fb)
+                    space.set_vector(0, x0 / nx)
+                    H[:] = 0.0
+                    j0 = 0
+                    k_want = kf
+                    phase = 1
+                    continue
+        if phase == 1 and converged:
+            # ---- the polynomial's leading invariant subspace: the matrix's pairs in it ---
+            Y = Z[:, :p] @ sy[:, o2]
+            X = space.combine(m_eff, np.concatenate([Y.real, Y.imag], axis=1))
+            kk = Y.shape[1]
+            lam, Xn, rr = _rayleigh_ritz(A, (X[:kk] + 1j * X[kk:]).T)
+            o3 = np.argsort(-lam.real, kind="stable")[:k]
+            # (every pair converged on lies clear of the band everything else is damped
+            # into: they ARE the polynomial's leading ones, hence the matrix's)
+            # ... and every one of the matrix's pairs found lies beyond the interval: none
+            # came in from off the real axis)
+            clear = sv[o2].real.min() > 1.5 and \
+                not np.any((rr <= 1e-6) & (lam.real <= flt[2]))
+            if clear and len(o3) == k and \
+                    np.all(rr[o3] <= 1e-9 * np.maximum(np.abs(lam[o3]), 1e-3)):
+                space.set_filter(0)
+                return lam[o3], Xn[:, o3]
+            # not the matrix's pairs to the accuracy asked: the plain iteration from
+            # here (it converges from whatever it is given)
+            LAST_RUN["fallback"] = True
+            space.set_filter(0)
+            x0 = Xn[:, o3].real.sum(axis=1)
+            space.set_vector(0, x0 / np.linalg.norm(x0))
+            H[:] = 0.0
+            j0 = 0
+            k_want = k
+            phase = 2
+            continue
         # restart: V <- V Z[:, :p], residual direction moves to slot p
         space.rotate(m, Z[:, :p], True)
         H[:] = 0.0
         H[:p, :p] = S[:p, :p]
         H[p, :p] = bz[:p]
         j0 = p
+    if phase == 1:          # (the restarts ran out on the polynomial)
+        space.set_filter(0)
+        raise np.linalg.LinAlgError("eigenspectrum: no convergence in %d restarts"
+                                    % max_restarts)
     # Ritz pairs of the final projected matrix
     Hm = H[:m_eff, :m_eff]
     vals, Y = scipy.linalg.eig(Hm)
@@ -348,7 +557,7 @@ def eigenspectrum(T, n_eigs=None, left=True, maxiter=100000, tol=1E-30,
     space = make(A, m_max)
     try:
         vals, vecs = _leading_eigs(space, k, tol=max(tol, 1e-13),
-                                   max_restarts=max(10, min(maxiter, 2000)))
+                                   max_restarts=max(10, min(maxiter, 2000)), A=A)
     finally:
         if hasattr(space, "close"):
             space.close()

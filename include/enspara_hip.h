@@ -523,6 +523,16 @@ int ek_krylov_rotate(ek_krylov *k, int32_t m, int32_t kk, const double *Q,
  * h[0..j+1].  The caller checks the sub-diagonal for breakdowns. */
 int ek_krylov_expand(ek_krylov *k, int32_t j0, int32_t m, double *H_out,
                      int32_t ldh);
+/* The operator of ek_krylov_step / _expand from here on: A itself (degree 0) or
+ * T_degree((A - c) / e), the Chebyshev polynomial on [a, b] = [c - e, c + e] (degree
+ * >= 2: `degree` sparse products per step by the three-term recurrence).  What
+ * eigenspectrum's restarted iteration uses once it has seen where the wanted
+ * eigenvalues end (reference transition_matrices.py:173-233 leaves this to ARPACK):
+ * eigenvalues above b are amplified and pulled apart, the rest stay within [-1, 1],
+ * so the restarts -- and with them the orthogonalisations, most of the launches --
+ * drop by an order of magnitude where the leading eigenvalues cluster at 1.  The
+ * eigenpairs returned are A's: Rayleigh-Ritz on the converged subspace (host). */
+int ek_krylov_set_filter(ek_krylov *k, int32_t degree, double a, double b);
 /* out_host[c][0..n) = V[0..m) Q[:, c], c < kk <= m_max + 1; basis unchanged */
 int ek_krylov_combine(ek_krylov *k, int32_t m, int32_t kk, const double *Q,
                       double *out_host);

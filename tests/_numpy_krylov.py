@@ -11,6 +11,20 @@ class NumpyKrylov:
         self.n = self.A.shape[0]
         self.m_max = m_max
         self.V = np.zeros((m_max + 1, self.n))
+        self.filter = None
+
+    def set_filter(self, degree, a=0.0, b=1.0):
+        """the operator of step(): A, or T_degree((A - c) / e) on [a, b]"""
+        self.filter = (int(degree), 0.5 * (a + b), 0.5 * (b - a)) if degree else None
+
+    def _apply(self, x):
+        if self.filter is None:
+            return self.A @ x
+        d, c, e = self.filter
+        y0, y1 = x, (self.A @ x - c * x) / e
+        for _ in range(2, d + 1):
+            y0, y1 = y1, 2.0 * (self.A @ y1 - c * y1) / e - y0
+        return y1
 
     def set_vector(self, j, v):
         self.V[j] = v
@@ -19,7 +33,7 @@ class NumpyKrylov:
         return self.V[j].copy()
 
     def step(self, j, apply=True):
-        w = self.A @ self.V[j] if apply else self.V[j + 1].copy()
+        w = self._apply(self.V[j]) if apply else self.V[j + 1].copy()
         h = np.zeros(j + 2)
         for _ in range(2):
             c = self.V[:j + 1] @ w

@@ -77,6 +77,61 @@ def test_restarted_krylov_schur_matches_arpack():
     np.testing.assert_allclose(T.T @ pi, pi, atol=1e-9)
 
 
+def _hopping_blocks(n_blocks, size, seed, frames=400000):
+    """the bench's kind of chain: a symmetric banded walk inside blocks, rare hops
+    from block to block in ONE direction -- n_blocks eigenvalues in a tight, slightly
+    complex cluster at 1, a real bulk below"""
+    rng = np.random.RandomState(seed)
+    steps = rng.choice(np.array([-3, -2, -1, 0, 0, 1, 2, 3]), size=frames)
+    inb = (rng.randint(size) + np.cumsum(steps)) % size
+    blk = (rng.randint(n_blocks) + 7 * np.cumsum(rng.rand(frames) < 0.002)) % n_blocks
+    a = blk * size + inb
+    K = n_blocks * size
+    C = scipy.sparse.coo_matrix((np.ones(frames - 1), (a[:-1], a[1:])), shape=(K, K)).tocsr()
+    C = C + scipy.sparse.diags(np.full(K, 1e-3))        # (no empty rows)
+    return scipy.sparse.diags(1.0 / np.asarray(C.sum(axis=1)).ravel()) @ C
+
+
+def test_polynomial_filter_same_eigenpairs_fewer_restarts(monkeypatch):
+    """Round 5: once a cycle has shown where the wanted eigenvalues end, the restarted
+    iteration goes on with a Chebyshev polynomial of the matrix (FILTER = 1) and takes
+    the MATRIX's pairs from the converged subspace by Rayleigh-Ritz.  Same eigenvalues
+    as ARPACK and as the plain iteration (FILTER = 0) where the leading ones cluster at
+    1 -- in a fraction of the restarts --, an interval that starts out too high is
+    lowered, and a spectrum with a complex periphery (a polynomial on a real interval
+    would lift that above the wanted real ones) is left to the plain iteration."""
+    T = _hopping_blocks(15, 100, 5)
+    ref = np.sort(scipy.sparse.linalg.eigs(scipy.sparse.csr_matrix(T.T), 10, which="LR",
+                                           tol=1e-12)[0].real)[::-1]
+    runs = {}
+    for f in (0, 1):
+        monkeypatch.setattr(tm, "FILTER", f)
+        vals, vecs = tm.eigenspectrum(T, n_eigs=10, _space_factory=_factory)
+        np.testing.assert_allclose(vals, ref, atol=1e-10)
+        runs[f] = dict(tm.LAST_RUN)
+    assert runs[0]["filter"] is None and runs[1]["filter"] is not None
+    assert not runs[1]["fallback"]
+    assert sum(runs[1]["restarts"]) * 3 <= sum(runs[0]["restarts"])
+    # the first vector is the stationary distribution either way
+    assert abs(vecs[:, 0].sum() - 1.0) < 1e-9 and np.all(vecs[:, 0] > -1e-12)
+    # an interval that ends above wanted eigenvalues: found out, lowered
+    plan = tm._plan_filter
+    monkeypatch.setattr(tm, "_plan_filter",
+                        lambda th, k, scout=None: (48, -1.0, 0.9999, k + 4)
+                        if scout is not None else plan(th, k, scout))
+    vals, _ = tm.eigenspectrum(T, n_eigs=10, _space_factory=_factory)
+    np.testing.assert_allclose(vals, ref, atol=1e-10)
+    assert tm.LAST_RUN["plans"] >= 2 and tm.LAST_RUN["filter"]["b"] < 0.9999
+    monkeypatch.setattr(tm, "_plan_filter", plan)
+    # complex periphery: no polynomial
+    T2 = _rowstoch(3000, 0.002, 3)
+    ref2 = np.sort(scipy.sparse.linalg.eigs(scipy.sparse.csr_matrix(T2.T), 8, which="LR",
+                                            tol=1e-12)[0].real)[::-1]
+    vals2, _ = tm.eigenspectrum(T2, n_eigs=8, _space_factory=_factory)
+    np.testing.assert_allclose(vals2, ref2, atol=1e-8)
+    assert tm.LAST_RUN["filter"] is None
+
+
 def test_reducible_matrix_breakdown():
     # two disconnected blocks: Arnoldi breaks down, must continue
     A = _rowstoch(40, 0.2, 1)
