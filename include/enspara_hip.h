@@ -583,7 +583,14 @@ int ek_feat_kcenters(ek_feat *k, int32_t metric, int32_t first_label,
  * next 32-bit outputs of the caller's RandomState (*pos: outputs consumed).
  * medoids[c] is replaced and accept[c] = 1 where proposal c was accepted.
  * *status: 0 done; 1 `raw` ran out at cluster *cid (call again with more; the
- * state stays on the device); 2 cluster *cid has no member (choice raises). */
+ * state stays on the device); 2 cluster *cid has no member (choice raises).
+ * Round 5: for samples beyond 64 MB the proposals go in windows of up to 32 --
+ * drawn when the window opens, every sample's distance to each of them in ONE
+ * pass; a drawn proposal's window ends where an accepted earlier one moved a
+ * sample into or out of its cluster (:611-614 draws from the member list of the
+ * moment).  Environment EK_FEAT_PAM_WINDOWS=1 / 0 forces / forbids the form,
+ * EK_FEAT_PAM_SYNC=1 is round 3's loop with two waits per proposal; same
+ * results in all of them. */
 int ek_feat_pam_sweep(ek_feat *k, int32_t metric, int32_t n_medoids, int64_t *medoids,
                       const int64_t *proposals, const uint32_t *raw, int64_t n_raw,
                       int64_t *pos, double *dist_io, int32_t *assign_io,
