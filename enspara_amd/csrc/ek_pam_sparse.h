@@ -23,6 +23,8 @@ struct EkSpSpecRec {
     uint32_t status;            // 0: lists below are complete; else the slot is evaluated in turn
     uint32_t tabconf;           // earlier slots whose old or new medoid is within the members' reach
     uint32_t conf_in;           // earlier slots that would change a frame of this slot's bucket,
+    uint32_t moved;             // clusters of the window that would lose or gain a frame
+    uint32_t pad;
     uint32_t conf_out;          // later slots whose bucket holds a frame this one would change
                                 // (of every such pair at least one of the two has the bit: the
                                 // one that marked the frame second, see ek_sp_spec_kernel)

@@ -690,7 +690,7 @@ ek_sp_spec_kernel(EkSpArgs p)
     extern __shared__ __attribute__((aligned(16))) unsigned char sp_lds[];
     __shared__ unsigned long long s_best[EK_WAVE];
     __shared__ uint32_t s_rowf[EK_WAVE];
-    __shared__ unsigned int s_n_chg, s_n_amb, s_reach, s_n_col, s_tabconf, s_cin, s_cout;
+    __shared__ unsigned int s_n_chg, s_n_amb, s_reach, s_n_col, s_tabconf, s_cin, s_cout, s_moved;
     __shared__ float s_T[EK_PAM_WIN];
     __shared__ double s_part[2 * SP_WAVES];
     __shared__ unsigned int s_bcnt[EK_PAM_WIN + 1];
@@ -710,6 +710,7 @@ ek_sp_spec_kernel(EkSpArgs p)
         s_tabconf = 0;
         s_cin = 0;
         s_cout = 0;
+        s_moved = 0;
     }
     __syncthreads();
     unsigned int n_amb = 0;
@@ -722,13 +723,23 @@ ek_sp_spec_kernel(EkSpArgs p)
         uint32_t *gf = ek_sp_list(p, slot, 0), *god = ek_sp_list(p, slot, 1),
                  *gnd = ek_sp_list(p, slot, 2), *goa = ek_sp_list(p, slot, 3),
                  *gna = ek_sp_list(p, slot, 4);
+        unsigned int mv = 0;
         for (unsigned int q = t; q < n_chg; q += SP_NT) {
             gf[q] = L.chg_f[q];
             god[q] = __float_as_uint(L.chg_od[q]);
             gnd[q] = __float_as_uint(L.chg_nd[q]);
             goa[q] = (uint32_t)L.chg_oa[q];
             gna[q] = (uint32_t)L.chg_na[q];
+            if (L.chg_oa[q] != L.chg_na[q]) {   // (the stale-window mask of the window kernel)
+                const int32_t ia = L.chg_oa[q] - p.cid0, ib = L.chg_na[q] - p.cid0;
+                if (ia >= 0 && ia < p.win_count)
+                    mv |= 1u << ia;
+                if (ib >= 0 && ib < p.win_count)
+                    mv |= 1u << ib;
+            }
         }
+        if (mv)
+            atomicOr(&s_moved, mv);
         // the search's columns depend on which earlier slots are accepted where
         // the old medoid of one or its proposal is within the members' reach
         if (n_amb > 0 && t < slot) {
@@ -773,6 +784,8 @@ ek_sp_spec_kernel(EkSpArgs p)
         r.tabconf = s_tabconf;
         r.conf_in = s_cin;
         r.conf_out = s_cout;
+        r.moved = s_moved;
+        r.pad = 0;
         r.delta = delta;
         r.dab = dab;
         p.spec[slot] = r;
@@ -877,6 +890,103 @@ ek_sp_window_kernel(EkSpArgs p)
     for (; slot < p.count; ++slot) {
         if (slot >= s_stop)
             break;
+        if (p.use_spec && !in_turn) {
+            // ---- a run of slots whose evaluation ahead stands and whose sum of changes
+            // decides: their verdicts need nothing but the slots' records (every thread
+            // works them out alike), and what the accepted ones change -- disjoint
+            // frames: none reads or writes what another accepted one changed -- is
+            // written afterwards with the lists' loads in flight together, not slot
+            // after slot at a trip to memory each
+            const int run0 = slot;
+            uint32_t run_acc = 0;
+            int stop_r = s_stop;
+            uint32_t stale_r = s_stale;
+            while (slot < p.count && slot < stop_r) {
+                const EkSpSpecRec &r = s_rec[slot];
+                if (r.status != 0 || ((poison >> slot) & 1u) ||
+                    ((r.tabconf | r.conf_in) & acc_mask))
+                    break;
+                const bool obv = !p.exact_always && fabs(r.delta) > 1e-9 * total + 1e-11 * r.dab;
+                if (!obv)
+                    break;
+                const bool acc = r.delta < 0.0;
+                const double total_new = total + r.delta;
+                if (t == 0) {
+                    EkPamOut o;
+                    o.sum_old = total;
+                    o.sum_new = total_new;
+                    o.n_frames = p.n;
+                    o.n_amb = r.n_amb;
+                    o.moved = acc ? r.moved : 0u;
+                    s_win.out[slot] = o;
+                    s_acc[slot] = acc ? 1 : 0;
+                    s_win.accept[slot] = acc ? 1 : 0;
+                }
+                if (acc) {
+                    total = total_new;
+                    acc_mask |= 1u << slot;
+                    poison |= r.conf_out;
+                    run_acc |= 1u << slot;
+                    stale_r |= r.moved;
+                    const uint32_t later = (slot >= 31) ? 0u : (stale_r >> (slot + 1));
+                    if (later) {
+                        const int first = slot + 1 + (__ffs((int)later) - 1);
+                        if (first < stop_r)
+                            stop_r = first;
+                    }
+                }
+                ++n_spec;
+                ++slot;
+            }
+            if (t == 0 && slot > run0) {
+                s_stop = stop_r;
+                s_stale = stale_r;
+                s_win.stale = stale_r;
+                s_win.stop = stop_r;
+            }
+            if (run_acc) {
+                constexpr int G = 8;            // slots whose lists are in flight together
+                for (int base = run0; base < slot; base += G) {
+                    uint32_t f[G], na[G];
+                    float nd[G];
+#pragma unroll
+                    for (int u = 0; u < G; ++u) {
+                        const int j = base + u;
+                        const bool ok = j < slot && ((run_acc >> j) & 1u) &&
+                                        (unsigned int)t < s_rec[j].n_chg;
+                        f[u] = ok ? ek_sp_list(p, j, 0)[t] : 0xffffffffu;
+                        nd[u] = ok ? __uint_as_float(ek_sp_list(p, j, 2)[t]) : 0.f;
+                        na[u] = ok ? ek_sp_list(p, j, 4)[t] : 0u;
+                    }
+#pragma unroll
+                    for (int u = 0; u < G; ++u) {
+                        if (f[u] == 0xffffffffu)
+                            continue;
+                        p.dist[f[u]] = nd[u];
+                        p.assign[f[u]] = (int32_t)na[u];
+                        const int g = ek_sp_leaf_of(f[u], p);
+                        atomicOr(&s_dirty[g >> 5], 1u << (g & 31));
+                    }
+                }
+                for (int j = run0; j < slot; ++j) {     // (lists longer than the workgroup)
+                    if (!((run_acc >> j) & 1u))
+                        continue;
+                    for (unsigned int q = SP_NT + t; q < s_rec[j].n_chg; q += SP_NT) {
+                        const uint32_t f = ek_sp_list(p, j, 0)[q];
+                        p.dist[f] = __uint_as_float(ek_sp_list(p, j, 2)[q]);
+                        p.assign[f] = (int32_t)ek_sp_list(p, j, 4)[q];
+                        const int g = ek_sp_leaf_of(f, p);
+                        atomicOr(&s_dirty[g >> 5], 1u << (g & 31));
+                    }
+                }
+                tree_fresh = false;
+                stores_pending = true;
+            }
+            if (slot > run0)
+                ek_lds_barrier();
+            if (slot >= p.count || slot >= s_stop)
+                break;
+        }
         const bool spec_ok = !in_turn && s_rec[slot].status == 0 &&
                              !((poison >> slot) & 1u) &&
                              !((s_rec[slot].tabconf | s_rec[slot].conf_in) & acc_mask);
@@ -929,18 +1039,6 @@ ek_sp_window_kernel(EkSpArgs p)
             status = ek_sp_evaluate<false>(p, L, slot, pre_slot == slot, f_pre, &f_next, &n_amb);
             f_pre = f_next;
             pre_slot = slot + 1;
-        }
-        // the next slot's entry
-        if (p.use_spec && !in_turn && slot + 1 < p.count && s_rec[slot + 1].status == 0 &&
-            s_rec[slot + 1].n_chg <= SP_NT) {
-            if ((unsigned int)t < s_rec[slot + 1].n_chg) {
-                nx_f = ek_sp_list(p, slot + 1, 0)[t];
-                nx_od = ek_sp_list(p, slot + 1, 1)[t];
-                nx_nd = ek_sp_list(p, slot + 1, 2)[t];
-                nx_oa = ek_sp_list(p, slot + 1, 3)[t];
-                nx_na = ek_sp_list(p, slot + 1, 4)[t];
-            }
-            nx_slot = slot + 1;
         }
         const unsigned int n_chg = in_regs ? s_rec[slot].n_chg : s_n_chg;
         if (status != 0) {

@@ -12,3 +12,5 @@ f=$(find $out/trace -name "*kernel_trace.csv" | head -1)
 python3 tools/summarize_profile.py trace $f $out/kernel_summary.csv
 rm -rf $out/trace
 grep -E "pam|sp_|pw_|count_members|scan_counts|select_member" $out/kernel_summary.csv | cut -c1-110
+LAB_PAM_OPTS="19=1" timeout 900 python3 tools/lab_pam.py enspara_amd/_variants/libspprof.so --reps 1 --sweeps 2 2>&1 | grep -v amdgpu.ids | tee $out/lab_pam_prof.log
+timeout 1500 python3 tools/fuzz_gpu3.py 30 9 2>&1 | grep -v amdgpu.ids | tail -3 | tee $out/fuzz_gpu3.log
