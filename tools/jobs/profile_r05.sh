@@ -92,6 +92,9 @@ if has ms; then
 fi
 if has pam; then
   LAB_PAM_OPTS="16=1;16=0" python3 tools/lab_pam.py --reps 2 2>&1 | grep -v amdgpu.ids > $out/pam_sweep_1m.log; cat $out/pam_sweep_1m.log
+  # every slot of a window evaluated ahead of its turn (key 19) against round 4's form
+  LAB_PAM_OPTS="19=1;19=0" python3 tools/lab_pam.py --reps 3 2>&1 | grep -v amdgpu.ids > $out/pam_ahead_ab_1m.log; cat $out/pam_ahead_ab_1m.log
+  LAB_PAM_OPTS="19=1;19=0" python3 tools/lab_pam.py --reps 2 --n 200000 --centers 2000 --walk 1 2>&1 | grep -v amdgpu.ids > $out/pam_ahead_ab_walk200k.log; cat $out/pam_ahead_ab_walk200k.log
 fi
 if has ti; then
   python3 tools/ti_probe.py 2000 500 300 3000 2>&1 | grep -v amdgpu.ids > $out/ti_probe.log; cat $out/ti_probe.log
@@ -101,4 +104,5 @@ if has up; then
 fi
 if has msm; then
   python3 tools/msm_probe.py 2>&1 | grep -v amdgpu.ids > $out/msm_probe.log; cat $out/msm_probe.log
+  python3 tools/eig_probe.py 1000 2>&1 | grep -v amdgpu.ids > $out/eig_probe.log; cat $out/eig_probe.log
 fi
