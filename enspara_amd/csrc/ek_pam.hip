@@ -1655,6 +1655,9 @@ void ek_pw_build_shape(int len, EkPwShape *sh)
 //   listed frames of the frame-major copy):
 //   vecs[j * n_pad + list[i]] = rmsd(frame list[i], proposal j)
 #define EK_PAIR_CH 48
+#ifndef EK_PAIR_LD
+#define EK_PAIR_LD (EK_WAVE + 8)
+#endif
 struct EkPairArgs {
     const float *aos;           // rows: [.][3A]
     const double *G;            // their traces
@@ -1673,7 +1676,7 @@ struct EkPairArgs {
 
 static inline size_t ek_pair_lds_bytes()
 {
-    return (size_t)(3 * EK_PAIR_CH * (EK_WAVE + 1) + EK_PAM_GROUP * 3 * EK_PAIR_CH) *
+    return (size_t)(3 * EK_PAIR_CH * EK_PAIR_LD + EK_PAM_GROUP * 3 * EK_PAIR_CH) *
            sizeof(float);
 }
 
@@ -1691,7 +1694,13 @@ ek_pam_pairs_kernel(EkPairArgs p)
 {
     constexpr int CPW = EK_PAIR_CPW;
     constexpr int NT = EK_PAM_GROUP / CPW * EK_WAVE;
-    constexpr int LD = EK_WAVE + 1;             // padded: conflict-free both ways
+    // (a slice's element e of row m sits at e * LD + m.  Reads take consecutive rows:
+    // conflict-free with any LD.  The stores of a wave are 8 rows x 8 consecutive
+    // elements: with LD = 65 their banks are (e + m) % 32, fifteen of them for 64
+    // lanes -- SQ_LDS_BANK_CONFLICT as large as the LDS's active cycles, round 5;
+    // with LD = 64 + 8 they are (8 e + m) % 32: two lanes per bank, what 64 lanes cost
+    // anyway)
+    constexpr int LD = EK_PAIR_LD;
     constexpr int TPR = NT / EK_WAVE;           // threads per row
     constexpr int NLD = 3 * EK_PAIR_CH / TPR;   // loads per thread and slice
     constexpr int NY = (3 * EK_PAIR_CH + EK_WAVE - 1) / EK_WAVE;
