@@ -1654,7 +1654,9 @@ void ek_pw_build_shape(int len, EkPwShape *sh)
 // MODE 1, a window's proposals against the frames they can touch (rows: the
 //   listed frames of the frame-major copy):
 //   vecs[j * n_pad + list[i]] = rmsd(frame list[i], proposal j)
+#ifndef EK_PAIR_CH
 #define EK_PAIR_CH 48
+#endif
 #ifndef EK_PAIR_LD
 #define EK_PAIR_LD (EK_WAVE + 8)
 #endif
