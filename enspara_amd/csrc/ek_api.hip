@@ -257,6 +257,7 @@ int ek_free_all(ek_ctx *c)
     (void)hipFree(c->ti_tmask);
     (void)hipFree(c->pam_dprop);
     (void)hipHostFree(c->sel_host);
+    (void)hipHostFree(c->cnt_host);
     (void)hipFree(c->sp_marks);
     if (c->win_ev)
         (void)hipEventDestroy(c->win_ev);
@@ -485,6 +486,11 @@ extern "C" int ek_set_option(ek_ctx *c, int32_t key, int32_t value)
         if (value < 0)
             return ek_fail(EK_EARG, "ek_set_option: pairs one workgroup searches >= 0");
         c->sp_max_pairs = value;
+        return EK_OK;
+    case 20:
+        if (value != 0 && value != 1)
+            return ek_fail(EK_EARG, "ek_set_option: PAM results into mapped host memory 0 or 1");
+        c->pam_zero_copy = value;
         return EK_OK;
     case 19:
         if (value != 0 && value != 1)

@@ -68,8 +68,9 @@ static int ek_pam_alloc(ek_ctx *c, int32_t K)
         EK_HIP(hipHostMalloc((void **)&c->pam_out_host, sizeof(EkPamOut),
                              hipHostMallocDefault));
         EK_HIP(hipMalloc((void **)&c->pam_win_dev, sizeof(EkPamWin)));
+        // (coherent and mapped: the window's kernel writes the record there itself)
         EK_HIP(hipHostMalloc((void **)&c->pam_win_host, sizeof(EkPamWin),
-                             hipHostMallocDefault));
+                             hipHostMallocCoherent | hipHostMallocMapped));
     }
     c->pam_restore = -1;
     c->pf_backoff = 0;
@@ -770,15 +771,25 @@ static int ek_pam_select_prefetch(ek_ctx *c, int32_t cid0, int32_t count,
         return rc;
     if (!c->sel_host)
         EK_HIP(hipHostMalloc((void **)&c->sel_host, EK_PAM_WIN * sizeof(int64_t),
-                             hipHostMallocDefault));
+                             hipHostMallocCoherent | hipHostMallocMapped));
     EK_HIP(hipMemcpyAsync(c->bat_sel + 2 * EK_PAM_WIN, js, (size_t)count * sizeof(int64_t),
                           hipMemcpyHostToDevice, c->stream));
+    int64_t *sel_dev_view = nullptr;
+    if (c->pam_zero_copy) {
+        void *dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, c->sel_host, 0) == hipSuccess)
+            sel_dev_view = (int64_t *)dp;
+        else
+            (void)hipGetLastError();
+    }
     ek_launch_select_member_multi(c->assign, c->n, cid0, count, c->bat_scan,
                                   c->bat_sel + 2 * EK_PAM_WIN, c->bat_sel + EK_PAM_WIN,
-                                  c->stream);
+                                  c->stream, sel_dev_view);
     EK_CHECK_LAUNCH();
-    EK_HIP(hipMemcpyAsync(c->sel_host, c->bat_sel + EK_PAM_WIN,
-                          (size_t)count * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    if (!sel_dev_view)
+        EK_HIP(hipMemcpyAsync(c->sel_host, c->bat_sel + EK_PAM_WIN,
+                              (size_t)count * sizeof(int64_t), hipMemcpyDeviceToHost,
+                              c->stream));
     c->bat_cid0 = -1;           // the scans describe the state at count time only
     c->bat_count = 0;
     c->pf_count = 0;
@@ -864,6 +875,14 @@ static int ek_pam_window_sparse(ek_ctx *c, int32_t cid0, int32_t count,
     a.max_pairs = c->sp_max_pairs;
     a.exact_always = c->sp_exact;
     a.win = c->pam_win_dev;
+    a.win_host = nullptr;
+    if (c->pam_zero_copy) {
+        void *dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, c->pam_win_host, 0) == hipSuccess)
+            a.win_host = (EkPamWin *)dp;
+        else
+            (void)hipGetLastError();
+    }
     // every slot evaluated at once on the state the window opens with (not while a
     // rejected proposal's row of the medoid table is still to be put back)
     a.use_spec = (c->pam_spec && c->pam_restore < 0 && count > 1) ? 1 : 0;
@@ -1025,14 +1044,31 @@ static int ek_pam_window_run_impl(ek_ctx *c, int32_t cid0, int32_t count,
         ek_launch_pam_apply(&c->pam_win_dev->accept[count - 1], c->dist, c->ndist,
                             c->assign, c->nassign, c->n, c->stream);
     EK_CHECK_LAUNCH();
-    EK_HIP(hipMemcpyAsync(c->pam_win_host, c->pam_win_dev, sizeof(EkPamWin),
-                          hipMemcpyDeviceToHost, c->stream));
-    if (next_count > 0) {
-        ek_launch_count_members_multi(c->assign, c->n, next_cid0, next_count,
-                                      c->bat_blockcnt, c->bat_scan, c->bat_sel, c->stream);
-        EK_CHECK_LAUNCH();
-        EK_HIP(hipMemcpyAsync(next_counts, c->bat_sel, (size_t)next_count * sizeof(int64_t),
+    // (the window's kernel and the scan write their results into mapped host memory
+    // themselves where they can: a copy kernel each, in the chain the host waits for)
+    if (!(sparse && sp_args.win_host))
+        EK_HIP(hipMemcpyAsync(c->pam_win_host, c->pam_win_dev, sizeof(EkPamWin),
                               hipMemcpyDeviceToHost, c->stream));
+    int64_t *cnt_dev_view = nullptr;
+    if (next_count > 0) {
+        if (c->pam_zero_copy) {
+            if (!c->cnt_host)
+                EK_HIP(hipHostMalloc((void **)&c->cnt_host, EK_PAM_WIN * sizeof(int64_t),
+                                     hipHostMallocCoherent | hipHostMallocMapped));
+            void *dp = nullptr;
+            if (hipHostGetDevicePointer(&dp, c->cnt_host, 0) == hipSuccess)
+                cnt_dev_view = (int64_t *)dp;
+            else
+                (void)hipGetLastError();
+        }
+        ek_launch_count_members_multi(c->assign, c->n, next_cid0, next_count,
+                                      c->bat_blockcnt, c->bat_scan, c->bat_sel, c->stream,
+                                      cnt_dev_view);
+        EK_CHECK_LAUNCH();
+        if (!cnt_dev_view)
+            EK_HIP(hipMemcpyAsync(next_counts, c->bat_sel,
+                                  (size_t)next_count * sizeof(int64_t),
+                                  hipMemcpyDeviceToHost, c->stream));
     }
     if (sparse && sp_args.finish_later) {
         // the accepted proposals' rows of the medoid table and the slots' marks: behind
@@ -1054,6 +1090,9 @@ static int ek_pam_window_run_impl(ek_ctx *c, int32_t cid0, int32_t count,
     }
     c->bat_cid0 = -1;
     c->bat_count = 0;
+    if (cnt_dev_view)
+        for (int32_t i = 0; i < next_count; ++i)
+            next_counts[i] = c->cnt_host[i];
     const EkPamWin &w = *c->pam_win_host;
     c->tab_n = 0;            // the medoid table has moved on
     c->pam_cid = -1;

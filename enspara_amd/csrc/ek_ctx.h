@@ -185,6 +185,9 @@ struct ek_ctx {
     float *pam_vecs = nullptr;       // [EK_PAM_WIN][n_pad]
     float *pam_dprop = nullptr;      // [EK_PAM_WIN] the proposals' distances to their medoids
     int64_t *sel_host = nullptr;     // pinned [EK_PAM_WIN]: the selected frames on their way back
+    int64_t *cnt_host = nullptr;     // pinned [EK_PAM_WIN]: the next window's member counts
+    int pam_zero_copy = 1;           // kernels write the window's small results into mapped
+                                     //   host memory themselves (option key 20)
     bool pf_members = false;         // the window's proposals are members of its clusters
                                      //   (drawn by ek_pam_sweep): tables as bounds
     int pam_bounds = 1;              // use that (option key 16)

@@ -191,7 +191,7 @@ ek_count_members_multi_kernel(const int32_t *__restrict__ assign, int64_t n,
 __global__ void __launch_bounds__(1024)
 ek_scan_counts_multi_kernel(const int32_t *__restrict__ blockcnt, int nblocks,
                             int64_t *__restrict__ scan,
-                            int64_t *__restrict__ total)
+                            int64_t *__restrict__ total, int64_t *total_host)
 {
     __shared__ int64_t part[1024];
     const int j = blockIdx.x;
@@ -225,8 +225,11 @@ ek_scan_counts_multi_kernel(const int32_t *__restrict__ blockcnt, int nblocks,
 #pragma unroll
         for (int q = 0; q < 1024 / EK_WAVE; ++q)
             part[t * (1024 / EK_WAVE) + q] = excl + loc[q];
-        if (t == EK_WAVE - 1)
+        if (t == EK_WAVE - 1) {
             total[j] = incl;
+            if (total_host)     // (mapped host memory: no copy kernel behind this one)
+                total_host[j] = incl;
+        }
     }
     __syncthreads();
     int64_t run = part[t];
@@ -241,15 +244,19 @@ __global__ void __launch_bounds__(EK_BLOCK)
 ek_select_member_multi_kernel(const int32_t *__restrict__ assign, int64_t n,
                               int32_t cid0, const int64_t *__restrict__ scan,
                               int nblocks, const int64_t *__restrict__ js,
-                              int64_t *__restrict__ out)
+                              int64_t *__restrict__ out, int64_t *out_host)
 {
     __shared__ int lo_s;
+    __shared__ long long f_s;
     __shared__ int wcnt[EK_BLOCK / EK_WAVE];
     const int j = blockIdx.x;
     const int64_t want = js[j];
     if (want < 0) {
-        if (threadIdx.x == 0)
+        if (threadIdx.x == 0) {
             out[j] = -1;
+            if (out_host)
+                out_host[j] = -1;
+        }
         return;
     }
     const int32_t cid = cid0 + j;
@@ -264,7 +271,7 @@ ek_select_member_multi_kernel(const int32_t *__restrict__ assign, int64_t n,
                 hi = mid - 1;
         }
         lo_s = lo;
-        out[j] = -1;
+        f_s = -1;
     }
     __syncthreads();
     const int lo = lo_s;
@@ -280,12 +287,18 @@ ek_select_member_multi_kernel(const int32_t *__restrict__ assign, int64_t n,
     for (int w = 0; w < wv; ++w)
         before += wcnt[w];
     if (hit && before + __popcll(m & ((1ull << lane) - 1ull)) == rank)
-        out[j] = f;
+        f_s = f;
+    __syncthreads();
+    if (threadIdx.x == 0) {     // (one write each: the host's copy is mapped host memory)
+        out[j] = f_s;
+        if (out_host)
+            out_host[j] = f_s;
+    }
 }
 
 void ek_launch_count_members_multi(const int32_t *assign, int64_t n, int32_t cid0,
                                    int count, int32_t *blockcnt, int64_t *scan,
-                                   int64_t *total, hipStream_t s)
+                                   int64_t *total, hipStream_t s, int64_t *total_host)
 {
     const int nblocks = (int)((n + EK_BLOCK - 1) / EK_BLOCK);
     if (nblocks > 0)
@@ -293,7 +306,7 @@ void ek_launch_count_members_multi(const int32_t *assign, int64_t n, int32_t cid
                            dim3(EK_BLOCK), 0, s, assign, n, cid0, count, nblocks,
                            blockcnt);
     hipLaunchKernelGGL(ek_scan_counts_multi_kernel, dim3(count), dim3(1024), 0, s,
-                       blockcnt, nblocks, scan, total);
+                       blockcnt, nblocks, scan, total, total_host);
 }
 
 // the scan alone (the per-workgroup counts were written by another kernel)
@@ -302,17 +315,17 @@ void ek_launch_scan_counts(const int32_t *blockcnt, int64_t n, int64_t *scan,
 {
     const int nblocks = (int)((n + EK_BLOCK - 1) / EK_BLOCK);
     hipLaunchKernelGGL(ek_scan_counts_multi_kernel, dim3(1), dim3(1024), 0, s,
-                       blockcnt, nblocks, scan, total);
+                       blockcnt, nblocks, scan, total, (int64_t *)nullptr);
 }
 
 void ek_launch_select_member_multi(const int32_t *assign, int64_t n, int32_t cid0,
                                    int count, const int64_t *scan,
                                    const int64_t *js_dev, int64_t *out,
-                                   hipStream_t s)
+                                   hipStream_t s, int64_t *out_host)
 {
     const int nblocks = (int)((n + EK_BLOCK - 1) / EK_BLOCK);
     hipLaunchKernelGGL(ek_select_member_multi_kernel, dim3(count), dim3(EK_BLOCK),
-                       0, s, assign, n, cid0, scan, nblocks, js_dev, out);
+                       0, s, assign, n, cid0, scan, nblocks, js_dev, out, out_host);
 }
 
 // ---- classification (kmedoids.py:639-658) ---------------------------------------

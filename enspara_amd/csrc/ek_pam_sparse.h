@@ -57,6 +57,7 @@ struct EkSpArgs {
     int64_t max_pairs;
     int32_t exact_always;       // take both cost sums for every proposal (ek_set_option key 14)
     EkPamWin *win;
+    EkPamWin *win_host;         // mapped host memory that receives the record too (or nullptr)
     // speculative evaluation (round 5; use_spec = 0: every slot in turn, as before)
     int32_t use_spec;
     EkSpSpecRec *spec;          // [EK_PAM_WIN]

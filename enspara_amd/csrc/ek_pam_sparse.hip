@@ -1292,8 +1292,11 @@ ek_sp_window_kernel(EkSpArgs p)
     }
     if (p.use_spec && t == 0)
         s_win.pad |= n_spec << 8;       // (slots taken over as evaluated ahead: a diagnostic)
-    for (int i = t; i < (int)(sizeof(EkPamWin) / 4); i += SP_NT)
+    for (int i = t; i < (int)(sizeof(EkPamWin) / 4); i += SP_NT) {
         ((uint32_t *)p.win)[i] = ((const uint32_t *)&s_win)[i];
+        if (p.win_host)
+            ((uint32_t *)p.win_host)[i] = ((const uint32_t *)&s_win)[i];
+    }
     SP_T(9);
 #ifdef EK_SP_PROF
     if (t == 0 && p.prof)

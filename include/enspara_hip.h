@@ -624,6 +624,9 @@ int ek_set_frames_per_lane(ek_ctx *ctx, int fpl);
  * key 8: with key 4 = -1, let ek_kcenters_run move between 1, 8 and 16
  * candidates per round by measured centers per millisecond: 1 (default) / 0
  * (always the widest form); identical results either way
+ * key 20: a PAM window's record, the next window's member counts and the drawn
+ * frames written into mapped host memory by the kernels that make them (1,
+ * default) or copied back behind them (0)
  * key 19: a PAM window's slots evaluated at once ahead of their turn: 1 (default)
  * / 0 (each in its turn, round 4's form); identical results (ek_pam_ahead_stats)
  * key 18: ek_ms_run's ladder moves from rounds of 8 to 16 once they accept 4.5 (1)
