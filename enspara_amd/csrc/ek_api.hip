@@ -258,6 +258,7 @@ int ek_free_all(ek_ctx *c)
     (void)hipFree(c->pam_dprop);
     (void)hipHostFree(c->sel_host);
     (void)hipHostFree(c->cnt_host);
+    (void)hipHostFree(c->js_host);
     (void)hipFree(c->sp_marks);
     if (c->win_ev)
         (void)hipEventDestroy(c->win_ev);

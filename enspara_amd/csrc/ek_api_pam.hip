@@ -772,19 +772,32 @@ static int ek_pam_select_prefetch(ek_ctx *c, int32_t cid0, int32_t count,
     if (!c->sel_host)
         EK_HIP(hipHostMalloc((void **)&c->sel_host, EK_PAM_WIN * sizeof(int64_t),
                              hipHostMallocCoherent | hipHostMallocMapped));
-    EK_HIP(hipMemcpyAsync(c->bat_sel + 2 * EK_PAM_WIN, js, (size_t)count * sizeof(int64_t),
-                          hipMemcpyHostToDevice, c->stream));
+    // (the drawn ranks are read by the selection from mapped host memory, the selected
+    // frames written into it: no copy either way)
     int64_t *sel_dev_view = nullptr;
+    const int64_t *js_dev_view = nullptr;
     if (c->pam_zero_copy) {
-        void *dp = nullptr;
-        if (hipHostGetDevicePointer(&dp, c->sel_host, 0) == hipSuccess)
+        if (!c->js_host)
+            EK_HIP(hipHostMalloc((void **)&c->js_host, EK_PAM_WIN * sizeof(int64_t),
+                                 hipHostMallocCoherent | hipHostMallocMapped));
+        void *dp = nullptr, *dj = nullptr;
+        if (hipHostGetDevicePointer(&dp, c->sel_host, 0) == hipSuccess &&
+            hipHostGetDevicePointer(&dj, c->js_host, 0) == hipSuccess) {
             sel_dev_view = (int64_t *)dp;
-        else
+            js_dev_view = (const int64_t *)dj;
+            for (int32_t j = 0; j < count; ++j)
+                c->js_host[j] = js[j];
+        } else {
             (void)hipGetLastError();
+        }
     }
+    if (!js_dev_view)
+        EK_HIP(hipMemcpyAsync(c->bat_sel + 2 * EK_PAM_WIN, js,
+                              (size_t)count * sizeof(int64_t), hipMemcpyHostToDevice,
+                              c->stream));
     ek_launch_select_member_multi(c->assign, c->n, cid0, count, c->bat_scan,
-                                  c->bat_sel + 2 * EK_PAM_WIN, c->bat_sel + EK_PAM_WIN,
-                                  c->stream, sel_dev_view);
+                                  js_dev_view ? js_dev_view : c->bat_sel + 2 * EK_PAM_WIN,
+                                  c->bat_sel + EK_PAM_WIN, c->stream, sel_dev_view);
     EK_CHECK_LAUNCH();
     if (!sel_dev_view)
         EK_HIP(hipMemcpyAsync(c->sel_host, c->bat_sel + EK_PAM_WIN,
@@ -826,8 +839,10 @@ static int ek_pam_window_sparse(ek_ctx *c, int32_t cid0, int32_t count,
     const size_t o_bucket = 0;
     const size_t o_bcnt = o_bucket + (size_t)EK_PAM_WIN * cap * sizeof(uint2);
     const size_t o_spec = o_bcnt + 256;
-    if (!c->sp_buf)
+    if (!c->sp_buf) {
         EK_HIP(hipMalloc((void **)&c->sp_buf, o_spec + ek_sp_spec_bytes()));
+        c->sp_bcnt_clean = false;
+    }
     if (c->pam_spec && !c->sp_marks) {
         EK_HIP(hipMalloc((void **)&c->sp_marks, (size_t)c->n * sizeof(unsigned long long)));
         EK_HIP(hipMemsetAsync(c->sp_marks, 0, (size_t)c->n * sizeof(unsigned long long),
@@ -840,7 +855,9 @@ static int ek_pam_window_sparse(ek_ctx *c, int32_t cid0, int32_t count,
                       c->pw_leaves, c->pw_chunks, c->sq_part, c->moved, c->stream);
     ek_launch_sp_bucket(c->act_list, c->sp_nact, c->dist, c->assign, c->pam_vecs, c->n_pad,
                         cid0, count, (uint2 *)(c->sp_buf + o_bucket),
-                        (unsigned int *)(c->sp_buf + o_bcnt), (int64_t)cap, c->stream);
+                        (unsigned int *)(c->sp_buf + o_bcnt), (int64_t)cap, c->stream,
+                        c->sp_bcnt_clean);
+    c->sp_bcnt_clean = false;
     EkSpArgs a = {};
     a.dist = c->dist;
     a.assign = c->assign;
@@ -1078,6 +1095,7 @@ static int ek_pam_window_run_impl(ek_ctx *c, int32_t cid0, int32_t count,
         EK_HIP(hipEventRecord(c->win_ev, c->stream));
         ek_launch_sp_finish(sp_args, c->stream);
         EK_CHECK_LAUNCH();
+        c->sp_bcnt_clean = sp_args.count == EK_PAM_WIN;  // (all of the lengths)
         for (;;) {
             const hipError_t e = hipEventQuery(c->win_ev);
             if (e == hipSuccess)

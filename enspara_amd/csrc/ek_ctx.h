@@ -186,6 +186,7 @@ struct ek_ctx {
     float *pam_dprop = nullptr;      // [EK_PAM_WIN] the proposals' distances to their medoids
     int64_t *sel_host = nullptr;     // pinned [EK_PAM_WIN]: the selected frames on their way back
     int64_t *cnt_host = nullptr;     // pinned [EK_PAM_WIN]: the next window's member counts
+    int64_t *js_host = nullptr;      // pinned [EK_PAM_WIN]: the drawn member ranks on their way in
     int pam_zero_copy = 1;           // kernels write the window's small results into mapped
                                      //   host memory themselves (option key 20)
     bool pf_members = false;         // the window's proposals are members of its clusters
@@ -231,6 +232,7 @@ struct ek_ctx {
                                      //   would change it (zero between windows)
     hipEvent_t win_ev = nullptr;     // a window's record is on the host
     int64_t sp_ahead = 0;            // slots whose evaluation ahead was taken over
+    bool sp_bcnt_clean = false;      // the buckets' lengths are zero (the finish kernel's doing)
     int32_t sp_backoff = 0, sp_backoff_next = 8;    // windows to go the three-launch way after one ended early
 
     // multi-candidate rounds (ek_spec.hip)

@@ -72,7 +72,8 @@ struct EkSpArgs {
 void ek_launch_sp_bucket(const uint32_t *list, int64_t n_act, const float *dist,
                          const int32_t *assign, const float *vecs, int64_t n_pad,
                          int32_t cid0, int count, uint2 *bucket,
-                         unsigned int *bcnt, int64_t bcap, hipStream_t s);
+                         unsigned int *bcnt, int64_t bcap, hipStream_t s,
+                         bool cleared = false);
 void ek_launch_sp_spec(const EkSpArgs &p, hipStream_t s);
 void ek_launch_sp_window(const EkSpArgs &p, hipStream_t s);
 void ek_launch_sp_finish(const EkSpArgs &p, hipStream_t s);

@@ -125,9 +125,10 @@ ek_sp_bucket_kernel(const uint32_t *__restrict__ list, int64_t n_act,
 void ek_launch_sp_bucket(const uint32_t *list, int64_t n_act, const float *dist,
                          const int32_t *assign, const float *vecs, int64_t n_pad,
                          int32_t cid0, int count, uint2 *bucket,
-                         unsigned int *bcnt, int64_t bcap, hipStream_t s)
+                         unsigned int *bcnt, int64_t bcap, hipStream_t s, bool cleared)
 {
-    (void)hipMemsetAsync(bcnt, 0, EK_PAM_WIN * sizeof(unsigned int), s);
+    if (!cleared)       // (ek_sp_finish_kernel of the window before leaves them at zero)
+        (void)hipMemsetAsync(bcnt, 0, EK_PAM_WIN * sizeof(unsigned int), s);
     if (n_act <= 0)
         return;
     hipLaunchKernelGGL(ek_sp_bucket_kernel,
@@ -1316,6 +1317,9 @@ ek_sp_finish_kernel(EkSpArgs p)
     const unsigned int nb = min(p.bcnt[slot], (unsigned int)p.bcap);
     for (unsigned int e = t; e < nb; e += 256)
         p.marks[p.bucket[(size_t)slot * p.bcap + e].x] = 0ull;
+    __syncthreads();            // (everybody has read the bucket's length)
+    if (t == 0)                 // ... which the next window's buckets start from
+        ((unsigned int *)p.bcnt)[slot] = 0u;
     if (slot >= p.win->stop || !p.win->accept[slot])
         return;
     const int32_t cid = p.cid0 + slot;
