@@ -305,16 +305,13 @@ void ek_launch_count_members(const int32_t *assign, int64_t n, int32_t cid,
 void ek_launch_select_member(const int32_t *assign, int64_t n, int32_t cid,
                              const int64_t *scan, int64_t j, int64_t *out,
                              hipStream_t s);
-// (total_host / out_host: mapped host memory that receives the same values -- no copy
-// kernel behind the launch)
 void ek_launch_count_members_multi(const int32_t *assign, int64_t n, int32_t cid0,
                                    int count, int32_t *blockcnt, int64_t *scan,
-                                   int64_t *total, hipStream_t s,
-                                   int64_t *total_host = nullptr);
+                                   int64_t *total, hipStream_t s);
 void ek_launch_select_member_multi(const int32_t *assign, int64_t n, int32_t cid0,
                                    int count, const int64_t *scan,
                                    const int64_t *js_dev, int64_t *out,
-                                   hipStream_t s, int64_t *out_host = nullptr);
+                                   hipStream_t s);
 void ek_launch_pam_classify(const float *dist, const int32_t *assign,
                             const float *newd, int64_t n, int32_t cid,
                             float *ndist, int32_t *nassign, uint32_t *amb,

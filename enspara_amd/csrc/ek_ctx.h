@@ -336,6 +336,15 @@ void ek_launch_pam_setup_dev(const float *aos, const double *G, int A,
                              unsigned char *recs, float *ctile, double *ctrace,
                              EkPlan *plan, unsigned int *counter, hipStream_t s,
                              const float *dist, float *dprop);
+// (as in ek_common.h, with mapped host memory that receives the same values -- no copy
+// kernel behind the launch)
+void ek_launch_count_members_multi(const int32_t *assign, int64_t n, int32_t cid0,
+                                   int count, int32_t *blockcnt, int64_t *scan,
+                                   int64_t *total, hipStream_t s, int64_t *total_host);
+void ek_launch_select_member_multi(const int32_t *assign, int64_t n, int32_t cid0,
+                                   int count, const int64_t *scan,
+                                   const int64_t *js_dev, int64_t *out,
+                                   hipStream_t s, int64_t *out_host);
 int ek_form_slot(int T);
 int ek_spec_alloc(ek_ctx *c);
 int ek_ensure_hist(ek_ctx *c, int32_t label);

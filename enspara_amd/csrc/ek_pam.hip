@@ -309,6 +309,14 @@ void ek_launch_count_members_multi(const int32_t *assign, int64_t n, int32_t cid
                        blockcnt, nblocks, scan, total, total_host);
 }
 
+void ek_launch_count_members_multi(const int32_t *assign, int64_t n, int32_t cid0,
+                                   int count, int32_t *blockcnt, int64_t *scan,
+                                   int64_t *total, hipStream_t s)
+{
+    ek_launch_count_members_multi(assign, n, cid0, count, blockcnt, scan, total, s,
+                                  (int64_t *)nullptr);
+}
+
 // the scan alone (the per-workgroup counts were written by another kernel)
 void ek_launch_scan_counts(const int32_t *blockcnt, int64_t n, int64_t *scan,
                            int64_t *total, hipStream_t s)
@@ -326,6 +334,15 @@ void ek_launch_select_member_multi(const int32_t *assign, int64_t n, int32_t cid
     const int nblocks = (int)((n + EK_BLOCK - 1) / EK_BLOCK);
     hipLaunchKernelGGL(ek_select_member_multi_kernel, dim3(count), dim3(EK_BLOCK),
                        0, s, assign, n, cid0, scan, nblocks, js_dev, out, out_host);
+}
+
+void ek_launch_select_member_multi(const int32_t *assign, int64_t n, int32_t cid0,
+                                   int count, const int64_t *scan,
+                                   const int64_t *js_dev, int64_t *out,
+                                   hipStream_t s)
+{
+    ek_launch_select_member_multi(assign, n, cid0, count, scan, js_dev, out, s,
+                                  (int64_t *)nullptr);
 }
 
 // ---- classification (kmedoids.py:639-658) ---------------------------------------
