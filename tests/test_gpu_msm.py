@@ -104,6 +104,42 @@ def test_eigenspectrum_matches_reference(M):
     np.testing.assert_allclose(vecs[:, 0], M["eig_vecs"][:, 0], atol=1e-9)
 
 
+def test_polynomial_filter_on_the_device():
+    """Round 5: the restarted iteration applies a Chebyshev polynomial of the matrix
+    inside its Arnoldi steps (ek_krylov_set_filter, kr_spmv_cheb_kernel) where the
+    leading eigenvalues cluster at 1 -- the bench's kind of chain: banded walks inside
+    blocks, rare one-way hops between them.  Same eigenvalues as ARPACK and as the
+    plain iteration on the device, in a fraction of the restarts; the same plan and
+    restarts as the numpy stand-in makes (tests/test_msm_host.py holds that one
+    against ARPACK on the CPU)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_msm_host import _hopping_blocks, _factory
+    from enspara_amd.msm import transition_matrices as tm
+    T = _hopping_blocks(15, 100, 5)
+    ref = np.sort(scipy.sparse.linalg.eigs(scipy.sparse.csr_matrix(T.T), 10, which="LR",
+                                           tol=1e-12)[0].real)[::-1]
+    runs = {}
+    old = tm.FILTER
+    try:
+        for f in (0, 1):
+            tm.FILTER = f
+            vals, vecs = tm.eigenspectrum(T, n_eigs=10)
+            np.testing.assert_allclose(vals, ref, atol=1e-10)
+            runs[f] = dict(tm.LAST_RUN)
+        assert abs(vecs[:, 0].sum() - 1.0) < 1e-9 and np.all(vecs[:, 0] > -1e-12)
+        tm.FILTER = 1
+        tm.eigenspectrum(T, n_eigs=10, _space_factory=_factory)
+        host = dict(tm.LAST_RUN)
+    finally:
+        tm.FILTER = old
+    assert runs[0]["filter"] is None and runs[1]["filter"] is not None
+    assert not runs[1]["fallback"]
+    assert sum(runs[1]["restarts"]) * 3 <= sum(runs[0]["restarts"])
+    assert runs[1]["filter"]["degree"] == host["filter"]["degree"]
+    assert abs(runs[1]["filter"]["b"] - host["filter"]["b"]) < 1e-9
+
+
 def test_msm_build_at_scale():
     """seeded 2000-state, 1e6-frame synthetic assignments: counts equal a
     scipy construction exactly; top-10 eigenvalues equal ARPACK's to 1e-8"""
