@@ -488,6 +488,11 @@ extern "C" int ek_set_option(ek_ctx *c, int32_t key, int32_t value)
             return ek_fail(EK_EARG, "ek_set_option: pairs one workgroup searches >= 0");
         c->sp_max_pairs = value;
         return EK_OK;
+    case 21:
+        if (value != 0 && value != 1)
+            return ek_fail(EK_EARG, "ek_set_option: PAM pairs kernels on the matrix cores 0 or 1");
+        ek_pam_pairs_form = value;      // (process-wide: a measurement switch)
+        return EK_OK;
     case 20:
         if (value != 0 && value != 1)
             return ek_fail(EK_EARG, "ek_set_option: PAM results into mapped host memory 0 or 1");

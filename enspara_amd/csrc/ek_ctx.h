@@ -345,6 +345,7 @@ void ek_launch_select_member_multi(const int32_t *assign, int64_t n, int32_t cid
                                    int count, const int64_t *scan,
                                    const int64_t *js_dev, int64_t *out,
                                    hipStream_t s, int64_t *out_host);
+extern int ek_pam_pairs_form;    // ek_pam.hip: the pairs kernels through the matrix cores (key 21)
 int ek_form_slot(int T);
 int ek_spec_alloc(ek_ctx *c);
 int ek_ensure_hist(ek_ctx *c, int32_t label);

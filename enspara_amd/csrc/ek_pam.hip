@@ -1887,6 +1887,179 @@ ek_pam_pairs_kernel(EkPairArgs p)
     }
 }
 
+// ---- the same distances through the matrix cores (round 5) -------------------------------------
+// The kernel above spends a quarter of a wave's time in its FMAs and the rest waiting
+// (slices through LDS, two barriers each; SQ counters in profiles/r05); 64 rows x 8
+// columns per workgroup are barely one workgroup per CU for a window's few thousand
+// rows.  Here a WAVE takes 16 rows x 16 columns and v_mfma_f32_16x16x4_f32 does four
+// atoms per instruction (ek_pass16.hip: every accumulator is the oracle's FMA chain in
+// atom order, atoms past the last are zeros in both operands): lane l holds atom
+// l / 16 of the trip for row l % 16 (A operand) and for column l % 16 (B operand), both
+// as the 12 contiguous bytes of that atom in the frame-major rows -- no LDS, no
+// barrier, the loads of the trips ahead in flight; nine instructions per trip, one per
+// (row coordinate, column coordinate).  A lane ends with S of four (row, column)
+// pairs of ONE column.  Four waves per workgroup (64 rows), columns in groups of 16
+// (grid.y: the proposals' groups first, then -- MODE 0 -- the old medoids').
+typedef float ek_p4 __attribute__((ext_vector_type(4)));
+struct EkF3 {
+    float x, y, z;
+};
+#define EK_P16_DEPTH 8
+template <int MODE>
+__global__ void __launch_bounds__(4 * EK_WAVE)
+ek_pam_pairs16_kernel(EkPairArgs p)
+{
+    const int A = p.A;
+    const int lane = threadIdx.x & (EK_WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / EK_WAVE);
+    const int gp = (p.n_col + 15) / 16;
+    const bool old = MODE == 0 && (int)blockIdx.y >= gp;
+    const int cg = old ? (int)blockIdx.y - gp : (int)blockIdx.y;
+    const int ncol = old ? p.n_old : p.n_col;
+    // this lane's column (B operand, and the column of its four results)
+    const int jc = cg * 16 + (lane & 15);
+    const bool clive = jc < ncol;
+    const float *y = p.aos;
+    double Gy = 0.0;
+    if (clive) {
+        if (old) {
+            const int r = (p.old_lo + jc == p.held) ? p.K : p.old_lo + jc;
+            y = p.aos + (size_t)r * 3 * A;
+            Gy = p.G[r];
+        } else {
+            const size_t rstride = ek_rec_bytes(A);
+            y = (const float *)(p.recs + (size_t)jc * rstride + sizeof(EkRecHdr));
+            Gy = ((const EkRecHdr *)(p.recs + (size_t)jc * rstride))->trace;
+        }
+    }
+    // row `i` of the launch: where it lives, whether it exists
+    auto row_of = [&](int64_t i, bool &ok) -> int64_t {
+        if (MODE == 0) {
+            ok = i < p.K;
+            return (i == p.held) ? p.K : (ok ? i : 0);
+        }
+        ok = i < p.n_rows;
+        return ok ? (int64_t)p.list[i] : 0;
+    };
+    const int64_t i0 = (int64_t)blockIdx.x * EK_WAVE + wave * 16;
+    if (i0 >= (MODE == 0 ? (int64_t)p.K : p.n_rows))
+        return;                                 // (a whole wave: no barrier in this kernel)
+    bool lok;
+    const float *x = p.aos + (size_t)row_of(i0 + (lane & 15), lok) * 3 * A;
+    const int ka = lane >> 4;                   // this lane's atom of a trip
+    const int NQ = (A + 3) / 4;
+    ek_p4 acc[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q)
+        acc[q] = ek_p4{0.f, 0.f, 0.f, 0.f};
+    // (the loads of trip t + DEPTH are issued before the instructions of trip t and
+    // stay there -- scheduling barriers: left alone the compiler sinks every load to
+    // just before its use and waits for it at full latency.  Addresses are clamped to
+    // the row's last atom and the value masked when it is used: no branch around a load)
+    typedef const __attribute__((address_space(1))) float *ek_gf;
+    const ek_gf xg = (ek_gf)x, yg = (ek_gf)y;
+    EkF3 xa[EK_P16_DEPTH], yb[EK_P16_DEPTH];
+#define EK_P16_LOAD(D_, T_)                                                    \
+    {                                                                          \
+        const int at = min(4 * (T_) + ka, A - 1);                              \
+        const ek_gf px = xg + 3 * at, py = yg + 3 * at;                        \
+        xa[D_].x = px[0];                                                      \
+        xa[D_].y = px[1];                                                      \
+        xa[D_].z = px[2];                                                      \
+        yb[D_].x = py[0];                                                      \
+        yb[D_].y = py[1];                                                      \
+        yb[D_].z = py[2];                                                      \
+    }
+#pragma unroll
+    for (int d = 0; d < EK_P16_DEPTH; ++d)
+        EK_P16_LOAD(d, d)
+    __builtin_amdgcn_sched_barrier(0);
+    for (int t0 = 0; t0 < NQ; t0 += EK_P16_DEPTH) {
+#pragma unroll
+        for (int d = 0; d < EK_P16_DEPTH; ++d) {
+            const bool in = 4 * (t0 + d) + ka < A;
+            EkF3 cx = xa[d], cy = yb[d];
+            if (!(in && lok))
+                cx.x = cx.y = cx.z = 0.f;
+            if (!(in && clive))
+                cy.x = cy.y = cy.z = 0.f;
+            EK_P16_LOAD(d, t0 + d + EK_P16_DEPTH)
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(cx.x, cy.x, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(cx.x, cy.y, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(cx.x, cy.z, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(cx.y, cy.x, acc[3], 0, 0, 0);
+            acc[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(cx.y, cy.y, acc[4], 0, 0, 0);
+            acc[5] = __builtin_amdgcn_mfma_f32_16x16x4f32(cx.y, cy.z, acc[5], 0, 0, 0);
+            acc[6] = __builtin_amdgcn_mfma_f32_16x16x4f32(cx.z, cy.x, acc[6], 0, 0, 0);
+            acc[7] = __builtin_amdgcn_mfma_f32_16x16x4f32(cx.z, cy.y, acc[7], 0, 0, 0);
+            acc[8] = __builtin_amdgcn_mfma_f32_16x16x4f32(cx.z, cy.z, acc[8], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#undef EK_P16_LOAD
+    // ---- this lane's four pairs: rows 4 (l / 16) + r, column l % 16 --------------------
+    float D[4];
+    int64_t rowv[4];
+    bool okv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t i = i0 + 4 * ka + r;
+        rowv[r] = row_of(i, okv[r]);
+        D[r] = __builtin_inff();
+        if (clive && okv[r]) {
+            float S[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q)
+                S[q] = acc[q][r];
+            D[r] = ek_rmsd_from_S(S, p.G[rowv[r]], Gy, A);
+        }
+    }
+    if (MODE == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (clive && okv[r])
+                p.vecs[(size_t)jc * p.n_pad + rowv[r]] = D[r];
+        return;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t c = i0 + 4 * ka + r;
+        if (clive && okv[r])
+            (old ? p.O : p.T)[(size_t)jc * p.K + c] = D[r];
+    }
+    if (old && !p.dprop)
+        return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t c = i0 + 4 * ka + r;
+        float m = D[r];
+        if (old) {              // (bounds: see above)
+            m = (clive && okv[r]) ? fmaxf(D[r] - p.dprop[jc], 0.f) : __builtin_inff();
+            if (clive && okv[r])
+                p.T[(size_t)jc * p.K + c] = m;
+        }
+        // the minimum over a group of EK_PAM_GROUP columns: eight neighbouring lanes
+        m = fminf(m, __shfl_xor(m, 1, 64));
+        m = fminf(m, __shfl_xor(m, 2, 64));
+        m = fminf(m, __shfl_xor(m, 4, 64));
+        if ((lane & 7) == 0 && okv[r] && cg * 16 + (lane & 15) < ((ncol + 7) / 8) * 8)
+            p.dmin[(size_t)(cg * 2 + ((lane & 15) >> 3)) * p.K + c] = m;
+    }
+}
+
+template <int MODE>
+static void ek_pairs16_launch(const EkPairArgs &p, int64_t n_rows, int n_prop, int n_old,
+                              hipStream_t s)
+{
+    const dim3 grid((unsigned)((n_rows + EK_WAVE - 1) / EK_WAVE),
+                    (unsigned)((n_prop + 15) / 16 + (n_old + 15) / 16));
+    hipLaunchKernelGGL(ek_pam_pairs16_kernel<MODE>, grid, dim3(4 * EK_WAVE), 0, s, p);
+}
+
+// 1: the matrix-core form above; 0: the LDS-staged kernel (ek_set_option key 21)
+int ek_pam_pairs_form = 1;
+
 template <int MODE>
 static void ek_pairs_launch(const EkPairArgs &p, dim3 grid, hipStream_t s)
 {
@@ -1917,8 +2090,11 @@ void ek_launch_pam_tables(const float *aos, const double *Gm, int A, int K, int 
         q.O = O;
         q.dmin = dmin;
         q.dprop = dprop;
-        ek_pairs_launch<0>(q, dim3((K + EK_WAVE - 1) / EK_WAVE,
-                                   (n_old + EK_PAM_GROUP - 1) / EK_PAM_GROUP), s);
+        if (ek_pam_pairs_form)
+            ek_pairs16_launch<0>(q, K, 0, n_old, s);
+        else
+            ek_pairs_launch<0>(q, dim3((K + EK_WAVE - 1) / EK_WAVE,
+                                       (n_old + EK_PAM_GROUP - 1) / EK_PAM_GROUP), s);
         return;
     }
     EkPairArgs p = {};
@@ -1934,6 +2110,10 @@ void ek_launch_pam_tables(const float *aos, const double *Gm, int A, int K, int 
     p.T = T;
     p.O = O;
     p.dmin = dmin;
+    if (ek_pam_pairs_form) {
+        ek_pairs16_launch<0>(p, K, n_prop, n_old, s);
+        return;
+    }
     const int groups = (n_prop + EK_PAM_GROUP - 1) / EK_PAM_GROUP +
                        (n_old + EK_PAM_GROUP - 1) / EK_PAM_GROUP;
     ek_pairs_launch<0>(p, dim3((K + EK_WAVE - 1) / EK_WAVE, groups), s);
@@ -1957,6 +2137,10 @@ void ek_launch_pam_list_dist(const float *aos, const double *G, int A,
     p.n_rows = n_rows;
     p.n_pad = n_pad;
     p.vecs = vecs;
+    if (ek_pam_pairs_form) {
+        ek_pairs16_launch<1>(p, n_rows, count, 0, s);
+        return;
+    }
     ek_pairs_launch<1>(p, dim3((unsigned)((n_rows + EK_WAVE - 1) / EK_WAVE),
                                (count + EK_PAM_GROUP - 1) / EK_PAM_GROUP), s);
 }

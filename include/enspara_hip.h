@@ -624,6 +624,9 @@ int ek_set_frames_per_lane(ek_ctx *ctx, int fpl);
  * key 8: with key 4 = -1, let ek_kcenters_run move between 1, 8 and 16
  * candidates per round by measured centers per millisecond: 1 (default) / 0
  * (always the widest form); identical results either way
+ * key 21: the distance kernels of a PAM window (tables, listed frames) on the matrix
+ * cores, 16 rows x 16 columns per wave (1, default) or LDS-staged 64 x 8 per workgroup
+ * (0, round 4's); process-wide; identical results
  * key 20: a PAM window's record, the next window's member counts and the drawn
  * frames written into mapped host memory by the kernels that make them (1,
  * default) or copied back behind them (0)
