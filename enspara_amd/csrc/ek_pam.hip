@@ -1904,7 +1904,9 @@ typedef float ek_p4 __attribute__((ext_vector_type(4)));
 struct EkF3 {
     float x, y, z;
 };
+#ifndef EK_P16_DEPTH
 #define EK_P16_DEPTH 8
+#endif
 template <int MODE>
 __global__ void __launch_bounds__(4 * EK_WAVE)
 ek_pam_pairs16_kernel(EkPairArgs p)
@@ -2012,7 +2014,11 @@ ek_pam_pairs16_kernel(EkPairArgs p)
 #pragma unroll
             for (int q = 0; q < 9; ++q)
                 S[q] = acc[q][r];
+#ifdef EK_P16_NOSOLVE          // (measurement builds: what the solves cost)
+            D[r] = S[0] + (float)p.G[rowv[r]];
+#else
             D[r] = ek_rmsd_from_S(S, p.G[rowv[r]], Gy, A);
+#endif
         }
     }
     if (MODE == 1) {
