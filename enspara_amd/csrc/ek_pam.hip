@@ -1904,8 +1904,8 @@ typedef float ek_p4 __attribute__((ext_vector_type(4)));
 struct EkF3 {
     float x, y, z;
 };
-#ifndef EK_P16_DEPTH
-#define EK_P16_DEPTH 8
+#ifndef EK_PP16_DEPTH
+#define EK_PP16_DEPTH 8
 #endif
 template <int MODE>
 __global__ void __launch_bounds__(4 * EK_WAVE)
@@ -1960,8 +1960,8 @@ ek_pam_pairs16_kernel(EkPairArgs p)
     // the row's last atom and the value masked when it is used: no branch around a load)
     typedef const __attribute__((address_space(1))) float *ek_gf;
     const ek_gf xg = (ek_gf)x, yg = (ek_gf)y;
-    EkF3 xa[EK_P16_DEPTH], yb[EK_P16_DEPTH];
-#define EK_P16_LOAD(D_, T_)                                                    \
+    EkF3 xa[EK_PP16_DEPTH], yb[EK_PP16_DEPTH];
+#define EK_PP16_LOAD(D_, T_)                                                    \
     {                                                                          \
         const int at = min(4 * (T_) + ka, A - 1);                              \
         const ek_gf px = xg + 3 * at, py = yg + 3 * at;                        \
@@ -1973,19 +1973,19 @@ ek_pam_pairs16_kernel(EkPairArgs p)
         yb[D_].z = py[2];                                                      \
     }
 #pragma unroll
-    for (int d = 0; d < EK_P16_DEPTH; ++d)
-        EK_P16_LOAD(d, d)
+    for (int d = 0; d < EK_PP16_DEPTH; ++d)
+        EK_PP16_LOAD(d, d)
     __builtin_amdgcn_sched_barrier(0);
-    for (int t0 = 0; t0 < NQ; t0 += EK_P16_DEPTH) {
+    for (int t0 = 0; t0 < NQ; t0 += EK_PP16_DEPTH) {
 #pragma unroll
-        for (int d = 0; d < EK_P16_DEPTH; ++d) {
+        for (int d = 0; d < EK_PP16_DEPTH; ++d) {
             const bool in = 4 * (t0 + d) + ka < A;
             EkF3 cx = xa[d], cy = yb[d];
             if (!(in && lok))
                 cx.x = cx.y = cx.z = 0.f;
             if (!(in && clive))
                 cy.x = cy.y = cy.z = 0.f;
-            EK_P16_LOAD(d, t0 + d + EK_P16_DEPTH)
+            EK_PP16_LOAD(d, t0 + d + EK_PP16_DEPTH)
             __builtin_amdgcn_sched_barrier(0);
             acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(cx.x, cy.x, acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(cx.x, cy.y, acc[1], 0, 0, 0);
@@ -1999,7 +1999,7 @@ ek_pam_pairs16_kernel(EkPairArgs p)
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-#undef EK_P16_LOAD
+#undef EK_PP16_LOAD
     // ---- this lane's four pairs: rows 4 (l / 16) + r, column l % 16 --------------------
     float D[4];
     int64_t rowv[4];
@@ -2014,7 +2014,7 @@ ek_pam_pairs16_kernel(EkPairArgs p)
 #pragma unroll
             for (int q = 0; q < 9; ++q)
                 S[q] = acc[q][r];
-#ifdef EK_P16_NOSOLVE          // (measurement builds: what the solves cost)
+#ifdef EK_PP16_NOSOLVE          // (measurement builds: what the solves cost)
             D[r] = S[0] + (float)p.G[rowv[r]];
 #else
             D[r] = ek_rmsd_from_S(S, p.G[rowv[r]], Gy, A);
