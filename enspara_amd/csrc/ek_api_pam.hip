@@ -907,6 +907,14 @@ static int ek_pam_window_sparse(ek_ctx *c, int32_t cid0, int32_t count,
     a.spec_lists = (uint32_t *)(c->sp_buf + o_spec + EK_PAM_WIN * sizeof(EkSpSpecRec));
     a.marks = c->sp_marks;
     a.finish_later = a.use_spec;
+    // (the vectors' reset rides in the finish kernel where every column written is one
+    // of the window's slots)
+    const bool reset_there = a.finish_later && c->vecs_rows == c->sp_nact &&
+                             c->vecs_cols == count;
+    a.act_list = c->act_list;
+    a.n_act = c->sp_nact;
+    a.n_pad = c->n_pad;
+    a.vecs = reset_there ? c->pam_vecs : nullptr;
 #ifdef EK_SP_PROF
     static unsigned long long *prof_dev = nullptr;
     static unsigned long long prof_tot[16];
@@ -1112,6 +1120,10 @@ static int ek_pam_window_run_impl(ek_ctx *c, int32_t cid0, int32_t count,
         for (int32_t i = 0; i < next_count; ++i)
             next_counts[i] = c->cnt_host[i];
     const EkPamWin &w = *c->pam_win_host;
+    if (sparse && sp_args.finish_later && sp_args.vecs && w.stop == count) {
+        c->vecs_rows = 0;       // (ek_sp_finish_kernel has put the vectors back to +inf)
+        c->pf_count = 0;        //  ... nothing of them is a prefetched vector any more
+    }
     c->tab_n = 0;            // the medoid table has moved on
     c->pam_cid = -1;
     c->cnt_cid = -1;

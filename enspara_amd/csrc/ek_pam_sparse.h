@@ -66,6 +66,11 @@ struct EkSpArgs {
                                 //   would change it (zero between windows)
     int32_t finish_later;       // the accepted proposals' rows of the medoid table and the marks
                                 //   are left to ek_launch_sp_finish
+    // (for ek_sp_finish_kernel: the window's distance vectors go back to +inf at the
+    // listed frames once the window has run to its end)
+    const uint32_t *act_list;
+    int64_t n_act, n_pad;
+    float *vecs;
     unsigned long long *prof;   // measurement builds (EK_SP_PROF): 10 ns ticks per step
 };
 

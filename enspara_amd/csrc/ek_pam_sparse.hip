@@ -1320,6 +1320,12 @@ ek_sp_finish_kernel(EkSpArgs p)
     __syncthreads();            // (everybody has read the bucket's length)
     if (t == 0)                 // ... which the next window's buckets start from
         ((unsigned int *)p.bcnt)[slot] = 0u;
+    // the slot's distance vector back to +inf at the listed frames -- what the next
+    // window's prefetch did in a launch of its own; only after a window that ran to its
+    // end (the proposal a window stopped at is made again from its vector)
+    if (p.vecs && p.win->stop == p.count)
+        for (int64_t i = t; i < p.n_act; i += 256)
+            p.vecs[(size_t)slot * p.n_pad + p.act_list[i]] = __builtin_inff();
     if (slot >= p.win->stop || !p.win->accept[slot])
         return;
     const int32_t cid = p.cid0 + slot;
