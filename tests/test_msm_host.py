@@ -132,6 +132,45 @@ def test_polynomial_filter_same_eigenpairs_fewer_restarts(monkeypatch):
     assert tm.LAST_RUN["filter"] is None
 
 
+def test_polynomial_filter_planning_units():
+    """The pieces of the filtered iteration on their own: the Chebyshev map and its
+    inverse beyond the interval, the first plan's interval from Ritz values read as
+    samples of the spectrum, and its refusal where eigenvalues off the real axis would
+    come out of the polynomial above the band the damped real ones are confined to."""
+    x = np.linspace(-2.0, 2.0, 41)
+    for d in (2, 5, 12):
+        want = np.polynomial.chebyshev.chebval(x, [0] * d + [1])
+        np.testing.assert_allclose(tm._cheb(x, d).real, want, rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(tm._cheb(x, d).imag, 0.0, atol=1e-9 * np.abs(want).max())
+    a, b, d = -1.0, 0.9, 14
+    c, e = 0.5 * (a + b), 0.5 * (b - a)
+    lam = np.array([0.91, 0.95, 0.999, 1.0, 0.97 + 0.002j])
+    back = tm._unfilter(tm._cheb((lam - c) / e, d), (d, a, b))
+    np.testing.assert_allclose(back, lam, atol=1e-10)
+    # what the polynomial leaves inside [-1, 1] is only known to lie below b
+    inside = tm._unfilter(tm._cheb((np.array([0.3, -0.5]) - c) / e, d), (d, a, b))
+    np.testing.assert_allclose(inside, b)
+    # the first plan: 60 Ritz values of a 5000-state matrix, 20 wanted
+    theta = np.concatenate([[1.0, 0.998, 0.998, 0.993, 0.99, 0.987, 0.97],
+                            np.linspace(0.95, -0.2, 53)]).astype(complex)
+    plan = tm._plan_filter(theta, 20, scout=(5000, 60))
+    assert plan is not None
+    deg, pa, pb, kf = plan
+    assert kf == 25 and pa <= -1.0 and 0.98 < pb < 0.995 and 4 <= deg <= 64
+    assert tm._cheb(np.array([(1.0 - 0.5 * (pa + pb)) / (0.5 * (pb - pa))]), deg).real[0] > 20
+    # a pair far off the real axis below the interval: no polynomial
+    theta2 = theta.copy()
+    theta2[-2:] = [0.1 + 0.7j, 0.1 - 0.7j]
+    assert tm._plan_filter(theta2, 20, scout=(5000, 60)) is None
+    # the plan after a cycle on a polynomial: from estimates, the interval below what a
+    # restart keeps, every pair to converge lifted well clear of the band
+    est = np.concatenate([np.linspace(1.0, 0.9979, 26), np.linspace(0.9972, 0.99, 34)])
+    plan2 = tm._plan_filter(est.astype(complex), 20)
+    assert plan2 is not None and plan2[2] < est[25]
+    c2, e2 = 0.5 * (plan2[1] + plan2[2]), 0.5 * (plan2[2] - plan2[1])
+    assert tm._cheb(np.array([(est[24] - c2) / e2]), plan2[0]).real[0] >= 4.0
+
+
 def test_reducible_matrix_breakdown():
     # two disconnected blocks: Arnoldi breaks down, must continue
     A = _rowstoch(40, 0.2, 1)
