@@ -414,7 +414,7 @@ def msm_block(args):
     Cr = scipy.sparse.coo_matrix((res[2], (res[0], res[1])), shape=(K, K)).tocsr()
     (Cn, T, _), t_norm = best_of(
         lambda: builders.normalize(C, calculate_eq_probs=False), reps=2)
-    (vals, vecs), t_eig = best_of(lambda: eigenspectrum(T, n_eigs=20), reps=1)
+    (vals, vecs), t_eig = best_of(lambda: eigenspectrum(T, n_eigs=20), reps=2)
     # CPU: the reference's own construction (a COO of ones, summed on conversion)
     t0 = time.perf_counter()
     rows, cols = [], []
