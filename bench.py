@@ -23,9 +23,9 @@ The frames are streamed once per ROUND against up to 16 candidate centers and
 further centers are accepted from the stored distances while the farthest
 point is one of them (csrc/ek_spec.hip, ek_pass16.hip): the same
 sequential algorithm and bit-identical results with fewer passes over HBM.
-The fit moves between 1, 8, 16 and 32 candidates per round by the centers per
+The fit moves between 1, 8 and 16 candidates per round by the centers per
 millisecond each achieves (`--candidates 1|4|8|16|32` pins one form; 1 is the HBM
-roofline case of BASELINE.md).  Every reported pair is a distance the result
+roofline case of BASELINE.md; rounds of 32 only when pinned: measured to lose).  Every reported pair is a distance the result
 depends on; guesses that were never used are not counted ("pairs_computed" has
 the total).  `roofline` describes the kernel most passes ran: the 16-candidate
 pass is a dense contraction on the matrix cores (bound "mfma", its HBM figures
@@ -98,8 +98,9 @@ def parse():
                    help="frames per lane of the one-center kernel (0 = auto)")
     p.add_argument("--candidates", type=int, default=-1,
                    help="candidate centers per pass: -1 by measured rate "
-                        "(1, 8, 16, 32), or pin 1, 4, 8, 16 or 32 (32: "
-                        "two passes of 16 behind one plan and chain)")
+                        "(1, 8, 16), or pin 1, 4, 8, 16 or 32 (32: two "
+                        "passes of 16 behind one plan and chain; never "
+                        "chosen automatically)")
     p.add_argument("--transport", choices=["mailbox", "gather"], default="mailbox",
                    help="N > 1 / --sharded: a round's exchange through peer "
                         "mailboxes on the device, or one all-gather per round")
@@ -647,8 +648,8 @@ def main():
     store.sync()
     t_load = time.perf_counter() - t0
     store.set_frames_per_lane(args.fpl)
-    store.set_option(4, args.candidates)
-    store.set_option(11, args.triangle)
+    store.set_option("candidates", args.candidates)
+    store.set_option("triangle", args.triangle)
     cands = store.round_candidates
 
     shard = sharded.DeviceShard(store) if use_dist else None

@@ -50,10 +50,35 @@ SYMBOLS = [
     "ek_krylov_combine", "ek_krylov_expand", "ek_krylov_set_filter",
     "ek_feat_create", "ek_feat_destroy", "ek_feat_load", "ek_feat_distance",
     "ek_feat_kcenters", "ek_feat_pam_sweep", "ek_feat_pam_release",
-    "ek_set_frames_per_lane", "ek_set_option", "ek_last_run_timing",
+    "ek_set_frames_per_lane", "ek_set_option", "ek_get_option", "ek_last_run_timing",
     "ek_timing_begin", "ek_timing_end", "ek_timing_form", "ek_hbm_copy_rate",
     "ek_qcp_probe",
 ]
+
+
+# enum ek_option of include/enspara_hip.h (tests/test_abi.py holds the two equal)
+EK_OPT_NONTEMPORAL = 1
+EK_OPT_ASSIGN_KERNEL = 2
+EK_OPT_CANDIDATES = 4
+EK_OPT_CHAINED = 5
+EK_OPT_PAM_PRUNE = 6
+EK_OPT_STATE_EXACT = 7
+EK_OPT_ADAPTIVE = 8
+EK_OPT_PASS_FORM = 9
+EK_OPT_FUSED_ROUNDS = 10
+EK_OPT_TRIANGLE = 11
+EK_OPT_PAM_ONE_WORKGROUP = 12
+EK_OPT_PAM_MAX_PAIRS = 13
+EK_OPT_PAM_BOTH_SUMS = 14
+EK_OPT_FINE_PICK = 15
+EK_OPT_PAM_BOUNDS = 16
+EK_OPT_PICK_CAP = 17
+EK_OPT_SMALL_SHARDS = 18
+EK_OPT_PAM_AHEAD = 19
+EK_OPT_PAM_ZERO_COPY = 20
+EK_OPT_PAM_PAIRS_MFMA = 21
+OPTIONS = {k[7:].lower(): v for k, v in list(globals().items())
+           if k.startswith("EK_OPT_")}
 
 
 class HipLibraryMissing(RuntimeError):
@@ -195,6 +220,7 @@ def load():
                                    i32p, f64p]
     L.ek_set_frames_per_lane.argtypes = [vp, C.c_int]
     L.ek_set_option.argtypes = [vp, i32, i32]
+    L.ek_get_option.argtypes = [vp, i32, i32p]
     L.ek_last_run_timing.argtypes = [vp, f32p, i32p]
     L.ek_timing_begin.argtypes = [vp, i32, i32]
     L.ek_timing_end.argtypes = [vp, f32p, i32p]

@@ -35,7 +35,7 @@ class KHybrid(BaseEstimator, ClusterMixin, util.MolecularClusterMixin):
         self.random_first_center = random_first_center
         self.metric = util._get_distance_method(metric)
         self.random_state = check_random_state(random_state)
-        self.mpi_mode = bool(mpi_mode) if mpi_mode is not None else False
+        self.mpi_mode = util.default_mpi_mode(mpi_mode)
         self.args = args
         self.lengths = lengths
         self.device = device

@@ -41,8 +41,10 @@ class KCenters(BaseEstimator, ClusterMixin, util.MolecularClusterMixin):
     Parameters are the reference's: ``metric`` ('rmsd' or a callable
     ``f(X, y) -> distances``), ``n_clusters``, ``cluster_radius``,
     ``random_first_center`` (not implemented there either),
-    ``random_state``, ``mpi_mode`` (accepted for signature parity; multi-GPU
-    runs go through :mod:`enspara_amd.sharded`).  ``device`` selects the GPU.
+    ``random_state``, ``mpi_mode`` (None: True when the torch.distributed group
+    has more than one rank, as the reference's ``mpi.size() != 1``,
+    kcenters.py:73; every rank then passes its own frames, see
+    :mod:`enspara_amd.sharded`).  ``device`` selects the GPU.
     """
 
     def __init__(self, metric, n_clusters=None, cluster_radius=None,
@@ -56,7 +58,7 @@ class KCenters(BaseEstimator, ClusterMixin, util.MolecularClusterMixin):
         self.cluster_radius = cluster_radius
         self.random_first_center = random_first_center
         self.random_state = check_random_state(random_state)
-        self.mpi_mode = bool(mpi_mode) if mpi_mode is not None else False
+        self.mpi_mode = util.default_mpi_mode(mpi_mode)
         self.device = device
 
     def fit(self, X, init_centers=None):
@@ -137,7 +139,7 @@ def _kcenters_device(traj, n_clusters, dist_cutoff, init_centers, device,
     if own:
         store = FrameStore.from_array(xyz, device=device)
     try:
-        store.set_option(11, 1 if use_triangle_inequality else 0)
+        store.set_option("triangle", 1 if use_triangle_inequality else 0)
         n = store.n
         if n == 0:
             raise ValueError("cannot cluster an empty trajectory")

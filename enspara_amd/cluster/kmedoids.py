@@ -47,16 +47,6 @@ class KMedoids(BaseEstimator, ClusterMixin, util.MolecularClusterMixin):
         return self
 
 
-def _group_size():
-    try:
-        import torch.distributed as dist
-    except ImportError:
-        return 1
-    if dist.is_available() and dist.is_initialized():
-        return dist.get_world_size()
-    return 1
-
-
 def _resolve_inputs(X, distance_method, n_clusters, assignments, distances,
                     cluster_center_inds, X_lengths, random_state):
     """reference _kmedoids_inputs_tree, kmedoids.py:285-363"""
@@ -90,8 +80,7 @@ def kmedoids(X, distance_method, n_clusters=None, n_iters=5, assignments=None,
     force it.  In that mode every rank passes its own frames and the warm start
     is (assignments, distances, cluster_center_inds, X_lengths), see
     ``enspara_amd.sharded.kmedoids_sharded``."""
-    if mpi_mode is None:
-        mpi_mode = _group_size() > 1
+    mpi_mode = util.default_mpi_mode(mpi_mode)
     if cluster_center_inds is not None:
         if hasattr(cluster_center_inds[0], "__len__") and X_lengths is None:
             raise ImproperlyConfigured(
@@ -112,6 +101,16 @@ def kmedoids(X, distance_method, n_clusters=None, n_iters=5, assignments=None,
             raise ImproperlyConfigured(
                 "KMedoids in MPI mode runs metric 'rmsd' on the device; a "
                 "callable metric has no sharded form here")
+        if args is not None or lengths is not None:
+            raise ImproperlyConfigured(
+                "KMedoids in MPI mode takes every rank's own frames; `args` / "
+                "`lengths` have no meaning there")
+        import torch
+        if device not in (0, None) and int(device) != torch.cuda.current_device():
+            raise ImproperlyConfigured(
+                "KMedoids in MPI mode runs on the process's current device "
+                "(%d); device=%r conflicts with it"
+                % (torch.cuda.current_device(), device))
         from .. import sharded
         return sharded.kmedoids_fit_sharded(
             X, n_clusters=n_clusters, n_iters=n_iters, assignments=assignments,
@@ -129,7 +128,7 @@ def kmedoids(X, distance_method, n_clusters=None, n_iters=5, assignments=None,
                 store.assign_nearest(xyz[inds])              # :360-361
                 # the centers were the medoid frames themselves: every frame's
                 # distance is the distance to the medoid its label names
-                store.set_option(7, 1)
+                store.set_option("state_exact", 1)
             else:
                 store.upload_state(distances, assignments)
             d0, _ = store.download_state()

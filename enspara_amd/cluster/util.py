@@ -289,3 +289,19 @@ def write_assignments_and_distances_with_reassign(result, args,
     if final:
         ra.save(args.distances, dist)
         ra.save(args.assignments, assig)
+
+
+def default_mpi_mode(mpi_mode=None):
+    """``mpi_mode=None`` of KCenters / KHybrid / KMedoids: the reference decides by
+    ``mpi.size() != 1`` (kcenters.py:73, hybrid.py:79, kmedoids.py:172); here: by
+    whether an initialised torch.distributed group has more than one rank.  The
+    three estimators share this rule; the FUNCTIONS ``kcenters`` / ``hybrid``
+    default to False as the reference's do (kcenters.py:110, hybrid.py:115)."""
+    if mpi_mode is not None:
+        return bool(mpi_mode)
+    try:
+        import torch.distributed as dist
+    except ImportError:
+        return False
+    return bool(dist.is_available() and dist.is_initialized()
+                and dist.get_world_size() > 1)

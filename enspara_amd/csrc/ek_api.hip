@@ -429,37 +429,37 @@ extern "C" int ek_set_option(ek_ctx *c, int32_t key, int32_t value)
     if (!c)
         return ek_fail(EK_EARG, "NULL context");
     switch (key) {
-    case 1:
+    case EK_OPT_NONTEMPORAL:
         c->nt = value < 0 ? -1 : (value ? 1 : 0);
         return EK_OK;
-    case 4:
+    case EK_OPT_CANDIDATES:
         if (value != -1 && value != 1 && value != 4 && value != 8 && value != 16 &&
             value != 32)
             return ek_fail(EK_EARG, "ek_set_option: candidates per round must "
                                     "be -1 (auto), 1, 4, 8, 16 or 32");
         c->cands = value;
         return EK_OK;
-    case 5:
+    case EK_OPT_CHAINED:
         if (value != 0 && value != 1)
             return ek_fail(EK_EARG, "ek_set_option: chained rounds 0 or 1");
         c->chain = value;
         return EK_OK;
-    case 6:
+    case EK_OPT_PAM_PRUNE:
         if (value != 0 && value != 1)
             return ek_fail(EK_EARG, "ek_set_option: PAM medoid pruning 0 or 1");
         c->prune = value;
         return EK_OK;
-    case 7:
+    case EK_OPT_STATE_EXACT:
         if (value != 0 && value != 1)
             return ek_fail(EK_EARG, "ek_set_option: state-is-exact flag 0 or 1");
         c->state_exact = value != 0;
         return EK_OK;
-    case 11:
+    case EK_OPT_TRIANGLE:
         if (value != 0 && value != 1)
             return ek_fail(EK_EARG, "ek_set_option: triangle inequality 0 or 1");
         c->tri = value;
         return EK_OK;
-    case 10:
+    case EK_OPT_FUSED_ROUNDS:
         if (value != 0 && value != 1)
             return ek_fail(EK_EARG, "ek_set_option: fused rounds 0 or 1");
         c->fused = value;
@@ -468,69 +468,99 @@ extern "C" int ek_set_option(ek_ctx *c, int32_t key, int32_t value)
         if (value != 1)
             return ek_fail(EK_EARG, "ek_set_option: pass kernel form must be 1");
         return EK_OK;
-    case 8:
+    case EK_OPT_ADAPTIVE:
         if (value != 0 && value != 1)
             return ek_fail(EK_EARG, "ek_set_option: adaptive candidates 0 or 1");
         c->adapt = value;
         return EK_OK;
-    case 12:
+    case EK_OPT_PAM_ONE_WORKGROUP:
         if (value != 0 && value != 1)
             return ek_fail(EK_EARG, "ek_set_option: one-workgroup PAM windows 0 or 1");
         c->pam_sparse = value;
         return EK_OK;
-    case 14:
+    case EK_OPT_PAM_BOTH_SUMS:
         if (value != 0 && value != 1)
             return ek_fail(EK_EARG, "ek_set_option: both cost sums for every proposal 0 or 1");
         c->sp_exact = value;
         return EK_OK;
-    case 13:
+    case EK_OPT_PAM_MAX_PAIRS:
         if (value < 0)
             return ek_fail(EK_EARG, "ek_set_option: pairs one workgroup searches >= 0");
         c->sp_max_pairs = value;
         return EK_OK;
-    case 21:
+    case EK_OPT_PAM_PAIRS_MFMA:
         if (value != 0 && value != 1)
             return ek_fail(EK_EARG, "ek_set_option: PAM pairs kernels on the matrix cores 0 or 1");
         ek_pam_pairs_form = value;      // (process-wide: a measurement switch)
         return EK_OK;
-    case 20:
+    case EK_OPT_PAM_ZERO_COPY:
         if (value != 0 && value != 1)
             return ek_fail(EK_EARG, "ek_set_option: PAM results into mapped host memory 0 or 1");
         c->pam_zero_copy = value;
         return EK_OK;
-    case 19:
+    case EK_OPT_PAM_AHEAD:
         if (value != 0 && value != 1)
             return ek_fail(EK_EARG, "ek_set_option: PAM slots evaluated ahead 0 or 1");
         c->pam_spec = value;
         return EK_OK;
-    case 18:
+    case EK_OPT_SMALL_SHARDS:
         if (value != 0 && value != 1)
             return ek_fail(EK_EARG, "ek_set_option: small shards 0 or 1");
         c->ms_small = value;
         return EK_OK;
-    case 17:
+    case EK_OPT_PICK_CAP:
         if (value < 0 || value > 16)
             return ek_fail(EK_EARG, "ek_set_option: far frames per label on the pick's list "
                                     "0 (by the yield) or 1 .. 16");
         c->pick_cap = value;
         return EK_OK;
-    case 16:
+    case EK_OPT_PAM_BOUNDS:
         if (value != 0 && value != 1)
             return ek_fail(EK_EARG, "ek_set_option: PAM tables as bounds 0 or 1");
         c->pam_bounds = value;
         return EK_OK;
-    case 15:
+    case EK_OPT_FINE_PICK:
         if (value != 0 && value != 1)
             return ek_fail(EK_EARG, "ek_set_option: maxima per 64 frames for the pick 0 or 1");
         c->fine_pick = value;
         return EK_OK;
-    case 2:
+    case EK_OPT_ASSIGN_KERNEL:
         if (value < 0 || value > 3)
             return ek_fail(EK_EARG, "ek_set_option: assign variant 0..3");
         c->assign_variant = value;
         return EK_OK;
     default:
         return ek_fail(EK_EARG, "ek_set_option: unknown key %d", key);
+    }
+}
+
+extern "C" int ek_get_option(ek_ctx *c, int32_t key, int32_t *value)
+{
+    if (!c || !value)
+        return ek_fail(EK_EARG, "ek_get_option: NULL argument");
+    switch (key) {
+    case EK_OPT_NONTEMPORAL: *value = c->nt; return EK_OK;
+    case EK_OPT_ASSIGN_KERNEL: *value = c->assign_variant; return EK_OK;
+    case EK_OPT_CANDIDATES: *value = c->cands; return EK_OK;
+    case EK_OPT_CHAINED: *value = c->chain; return EK_OK;
+    case EK_OPT_PAM_PRUNE: *value = c->prune; return EK_OK;
+    case EK_OPT_STATE_EXACT: *value = c->state_exact ? 1 : 0; return EK_OK;
+    case EK_OPT_ADAPTIVE: *value = c->adapt; return EK_OK;
+    case EK_OPT_PASS_FORM: *value = 1; return EK_OK;
+    case EK_OPT_FUSED_ROUNDS: *value = c->fused; return EK_OK;
+    case EK_OPT_TRIANGLE: *value = c->tri; return EK_OK;
+    case EK_OPT_PAM_ONE_WORKGROUP: *value = c->pam_sparse; return EK_OK;
+    case EK_OPT_PAM_MAX_PAIRS: *value = c->sp_max_pairs; return EK_OK;
+    case EK_OPT_PAM_BOTH_SUMS: *value = c->sp_exact; return EK_OK;
+    case EK_OPT_FINE_PICK: *value = c->fine_pick; return EK_OK;
+    case EK_OPT_PAM_BOUNDS: *value = c->pam_bounds; return EK_OK;
+    case EK_OPT_PICK_CAP: *value = c->pick_cap; return EK_OK;
+    case EK_OPT_SMALL_SHARDS: *value = c->ms_small; return EK_OK;
+    case EK_OPT_PAM_AHEAD: *value = c->pam_spec; return EK_OK;
+    case EK_OPT_PAM_ZERO_COPY: *value = c->pam_zero_copy; return EK_OK;
+    case EK_OPT_PAM_PAIRS_MFMA: *value = ek_pam_pairs_form; return EK_OK;
+    default:
+        return ek_fail(EK_EARG, "ek_get_option: unknown key %d", key);
     }
 }
 
@@ -1751,9 +1781,10 @@ extern "C" int ek_qcp_probe(int device, const float *S, const double *Gx, const 
     EK_HIP(hipSetDevice(device));
     const size_t mm = (size_t)m;
     unsigned char *buf = nullptr;
-    // S | Gx | Gy | cur | full | below | cert
-    const size_t off_S = 0, off_Gx = off_S + mm * 36, off_Gy = off_Gx + mm * 8,
-                 off_cur = off_Gy + mm * 8, off_full = off_cur + mm * 4,
+    // Gx | Gy | S | cur | full | below | cert  (the float64 arrays first: every
+    // offset is then a multiple of its element size whatever m is)
+    const size_t off_Gx = 0, off_Gy = off_Gx + mm * 8, off_S = off_Gy + mm * 8,
+                 off_cur = off_S + mm * 36, off_full = off_cur + mm * 4,
                  off_below = off_full + mm * 4, off_cert = off_below + mm * 4,
                  total = off_cert + mm;
     EK_HIP(hipMalloc((void **)&buf, total));

@@ -35,6 +35,16 @@ def as_xyz(X):
     return np.ascontiguousarray(X, dtype=np.float32)
 
 
+def _option_key(key):
+    if isinstance(key, str):
+        try:
+            return _lib.OPTIONS[key.lower()]
+        except KeyError:
+            raise ValueError("unknown option %r (one of %s)"
+                             % (key, sorted(_lib.OPTIONS)))
+    return int(key)
+
+
 class FrameStore:
     """One shard of frames on one GPU."""
 
@@ -377,7 +387,8 @@ class FrameStore:
 
     @property
     def round_candidates(self):
-        """the widest round kcenters_run / ms_run may use (32 by default)"""
+        """the widest round kcenters_run / ms_run may use: 16 unless the option
+        "candidates" pins another form (32 only on request)"""
         return int(self.lib.ek_round_candidates(self._h))
 
     def spec_begin(self, first_label, limit, recs_out_ptr):
@@ -555,7 +566,15 @@ class FrameStore:
         _lib.check(self.lib.ek_set_frames_per_lane(self._h, int(fpl)))
 
     def set_option(self, key, value):
-        _lib.check(self.lib.ek_set_option(self._h, int(key), int(value)))
+        """``key``: a member of include/enspara_hip.h's ``enum ek_option`` -- its
+        number, or its name without the prefix (``"candidates"``,
+        ``"triangle"`` ...: ``_lib.OPTIONS``)."""
+        _lib.check(self.lib.ek_set_option(self._h, _option_key(key), int(value)))
+
+    def get_option(self, key):
+        v = C.c_int32()
+        _lib.check(self.lib.ek_get_option(self._h, _option_key(key), C.byref(v)))
+        return v.value
 
     def last_run_timing(self):
         ms = C.c_float()

@@ -57,16 +57,20 @@ class DeviceShard:
                                  own_rec.data_ptr())
 
     def set_triangle_inequality(self, on):
-        self.store.set_option(11, 1 if on else 0)
+        self.store.set_option("triangle", 1 if on else 0)
 
     def quad_copy_ready(self):
         return self.store.quad_copy_ready()
 
     def pin_candidates(self, T):
-        self.store.set_option(4, int(T))
+        self.store.set_option("candidates", int(T))
+
+    def candidates_option(self):
+        """what the option holds (-1: automatic), to put it back afterwards"""
+        return self.store.get_option("candidates")
 
     def set_small_shards(self, on):
-        self.store.set_option(18, 1 if on else 0)
+        self.store.set_option("small_shards", 1 if on else 0)
 
     def assign_nearest(self, centers_xyz):
         """every local frame against the given centers (float32 [K, A, 3]):
@@ -84,7 +88,7 @@ class DeviceShard:
     def set_exact(self, on):
         """every frame's distance IS the one to the medoid its label names
         (option key 7: lets the PAM search use the triangle inequality)"""
-        self.store.set_option(7, 1 if on else 0)
+        self.store.set_option("state_exact", 1 if on else 0)
 
     def progress(self):
         """-> number of centers so far; synchronises"""
@@ -269,7 +273,18 @@ def kcenters_sharded(shard, first_label, max_new, dist_cutoff=0.0, group=None,
     if use_triangle_inequality:
         T = 1               # (the test is per center: one-center passes)
     if T > 8 and hasattr(shard, "quad_copy_ready"):
-        T = _agree_on_form(shard, T, group, world, collective)
+        # (a group that has to narrow its rounds does so for THIS run only: the
+        # caller's own setting of the option comes back afterwards)
+        before = (shard.candidates_option()
+                  if hasattr(shard, "candidates_option") else None)
+        T0, T = T, _agree_on_form(shard, T, group, world, collective)
+        if T != T0 and before is not None:
+            try:
+                return _kcenters_sharded_ms(shard, first_label, max_new,
+                                            dist_cutoff, group, fresh, world,
+                                            T, collective)
+            finally:
+                shard.pin_candidates(before)
     if T > 1 and world <= MAX_ROUND_RECORDS and hasattr(shard, "ms_local"):
         return _kcenters_sharded_ms(shard, first_label, max_new, dist_cutoff,
                                     group, fresh, world, T, collective)
@@ -905,7 +920,11 @@ def kmedoids_sharded(shard, xyz_local, n_iters=5, assignments=None,
         shard.set_state(np.asarray(distances), np.asarray(assignments))
         mine = [i for r, i in pairs if r == rank]
         # the medoids must sit at (numerically) zero distance (kmedoids.py:185-187)
-        assert np.all(np.asarray(distances)[mine] < 0.001)
+        if not np.all(np.asarray(distances)[mine] < 0.001):
+            raise DataInvalid(
+                "cluster_center_inds name frames that are not at distance 0 "
+                "from their cluster's center (max %g)"
+                % float(np.max(np.asarray(distances)[mine])))
     elif not any(given):
         if n_clusters is None:
             raise ImproperlyConfigured(
@@ -950,6 +969,12 @@ def kmedoids_sharded(shard, xyz_local, n_iters=5, assignments=None,
                 "(proposals[0] == {}, whereas medoid_inds[0] == {})".format(
                     proposals[0], (0, 0)))
         prop = [offs[int(r)] + int(i) for r, i in proposals]
+    if random_state is None and prop is None:
+        # every rank must draw the same member ranks (the reference agrees on
+        # each draw across ranks, mpi/ops.py randind): rank 0's seed for all
+        draw = int(np.random.SeedSequence().entropy % (2 ** 31 - 1))
+        random_state = int(_gather_i64(shard, [draw], group, world,
+                                       collective)[0, 0])
     rs = check_random_state(random_state)
     for _ in range(int(n_iters)):
         med = pam_sweep_sharded(shard, med, proposals=prop, random_state=rs,

@@ -602,81 +602,108 @@ void ek_feat_pam_release(ek_feat *k);
 /* frames per lane of the distance kernel: 1, 2 or 4; 0 = choose from the
  * shard size */
 int ek_set_frames_per_lane(ek_ctx *ctx, int fpl);
-/* key 1: non-temporal loads of the frame stream (0/1; -1 = automatic:
- * on when the shard is larger than the Infinity Cache)
- * key 4: candidate centers per round of ek_kcenters_run / ek_ms_* / ek_spec_*:
- * -1 automatic (up to 16, see key 8), 1 = one-center passes, 4, 8, 16, 32 (32:
- * only on request -- measured, its second sixteen guesses are accepted too rarely --:
- * the frames streamed twice per round, candidates 0..15 and 16..31; the
- * one-launch-per-step forms -- ek_spec_*, key 5 = 0, key 10 = 0 -- stop at 16)
- * key 2: nearest-center kernel: 0 automatic, 1 vector FMA, 2 MFMA 32x32x2, 3 MFMA
- * 16x16x4 on the quad copy of the frames (identical
- * results)
- * key 5: cheap steps of a round in ek_kcenters_run: 1 chained (default), 0 one
- * launch pair per accepted center (identical results)
- * key 6: PAM proposals search the ambiguous members' new medoid only among
- * the medoids within their reach (triangle inequality, identical results):
- * 1 (default) / 0.  Used only while the state is known to hold, for every
- * frame, the distance to the medoid its label names: true after
- * ek_state_reset + k-centers, false after ek_state_upload / ek_assign_nearest
- * key 7: assert (1) or withdraw (0) that property, e.g. after
- * ek_assign_nearest with the medoid frames themselves as centers
- * key 8: with key 4 = -1, let ek_kcenters_run move between 1, 8 and 16
- * candidates per round by measured centers per millisecond: 1 (default) / 0
- * (always the widest form); identical results either way
- * key 21: the distance kernels of a PAM window (tables, listed frames) on the matrix
- * cores, 16 rows x 16 columns per wave (1, default) or LDS-staged 64 x 8 per workgroup
- * (0, round 4's); process-wide; identical results
- * key 20: a PAM window's record, the next window's member counts and the drawn
- * frames written into mapped host memory by the kernels that make them (1,
- * default) or copied back behind them (0)
- * key 19: a PAM window's slots evaluated at once ahead of their turn: 1 (default)
- * / 0 (each in its turn, round 4's form); identical results (ek_pam_ahead_stats)
- * key 18: ek_ms_run's ladder moves from rounds of 8 to 16 once they accept 4.5 (1)
- * or 6.5 (0, default) centers: 1 suits shards of up to ~300 000 frames, where the
- * exchange's tails make a narrow round dear; every rank of a group must set the
- * same value (sharded.kcenters_sharded does, from the gathered shard sizes)
- * key 17: how many of a label's farthest frames the candidate pick of a round may
- * list (the list of 64 the guesses are chosen from): 0 (default) = 4 or 16 by the
- * share of its guesses the run sees accepted (4 suits frames in clouds around
- * templates, 16 a continuous landscape), 1 .. 16 fixed; guesses only, identical
- * results
- * key 16: ek_pam_sweep's windows of drawn proposals take the proposal-to-medoid
- * distance table as the lower bounds the medoid-to-medoid table and the
- * proposals' own distances give (triangle inequality; half the pairs of a
- * window's tables): 1 (default) / 0 exact distances; identical results
- * key 15: the next round's candidates are chosen among the farthest frames per
- * 64 frames of the state the whole chain leaves (1, default) or per 256 (0: what
- * rounds 2-4 did; a far frame behind a farther one of its 256 is then invisible
- * and the chain breaks when its turn comes); guesses only, identical results
- * key 11: triangle inequality in ek_kcenters_run (0 default / 1): one center
- * per pass; before each, the distances of the existing centers to the new one
- * mark the tiles of 256 frames none of whose frames can move (own center at
- * least twice the frame's distance away, with a margin), and those tiles'
- * coordinates are not read.  Used only from a fresh state (ek_state_reset) and
- * for >= 3 atoms; identical results.  Also in the sharded one-center iteration
- * (ek_kcenters_step with gathered records; reference kcenters.py:351-364):
- * every shard keeps a table of the accepted centers -- other shards' frames as
- * often as its own -- filled from the winning records
- * key 10: ek_kcenters_run's rounds in three launches (the single-workgroup
- * steps ride at the end of the launch that produces their input): 1 (default)
- * / 0 (one launch per step); identical results
- * key 9: retired (round 1's pass kernel with the candidates staged in LDS);
- * only the value 1 is accepted
- * key 12: ek_pam_window_run works through a window whose prefetch was
- * restricted to a list of frames in ONE workgroup, no launch between two
- * proposals (1, default) or with three launches per proposal (0); identical
- * results
- * key 13: the (ambiguous member, medoid within reach) pairs such a workgroup
- * searches itself (default 16384); a proposal with more ends the window and goes
- * through the launches.  0 makes every proposal whose members have another
- * medoid within reach do so (tests)
- * key 14: such a workgroup takes both cost sums (numpy's order) for every
- * proposal (1) or only where the sum of the changes, new^2 - old^2 over the
- * frames the proposal moves, does not decide kmedoids.py:683's comparison by
- * four orders of magnitude more than the rounding of the sums can amount to
- * (0, default); identical decisions */
+/* Options of a context: ek_set_option(ctx, key, value) / ek_get_option.  Every
+ * option leaves centers, labels and distances unchanged (each form is tested
+ * against the oracle); the ones marked MEASUREMENT exist so that two forms can
+ * be timed against each other in one process and are not meant for callers. */
+enum ek_option {
+    /* non-temporal loads of the frame stream: 0 / 1; -1 = automatic (on when
+     * the shard is larger than the Infinity Cache).  MEASUREMENT */
+    EK_OPT_NONTEMPORAL = 1,
+    /* nearest-center kernel (ek_assign_nearest): 0 automatic, 1 vector FMA, 2
+     * MFMA 32x32x2, 3 MFMA 16x16x4 on the quad copy of the frames.
+     * MEASUREMENT */
+    EK_OPT_ASSIGN_KERNEL = 2,
+    /* candidate centers per round of ek_kcenters_run / ek_ms_* / ek_spec_*: -1
+     * automatic (up to 16, see EK_OPT_ADAPTIVE), 1 = one-center passes, 4, 8,
+     * 16, 32 (32 only on request -- measured, its second sixteen guesses are
+     * accepted too rarely --: the frames streamed twice per round, candidates
+     * 0..15 and 16..31; the one-launch-per-step forms -- ek_spec_*,
+     * EK_OPT_CHAINED = 0, EK_OPT_FUSED_ROUNDS = 0 -- stop at 16).  Every rank
+     * of a group must hold the same value (sharded._agree_on_form) */
+    EK_OPT_CANDIDATES = 4,
+    /* cheap steps of a round in ek_kcenters_run: 1 chained (default), 0 one
+     * launch pair per accepted center.  MEASUREMENT */
+    EK_OPT_CHAINED = 5,
+    /* PAM proposals search the ambiguous members' new medoid only among the
+     * medoids within their reach (triangle inequality): 1 (default) / 0.  Used
+     * only while the state is known to hold, for every frame, the distance to
+     * the medoid its label names: true after ek_state_reset + k-centers, false
+     * after ek_state_upload / ek_assign_nearest */
+    EK_OPT_PAM_PRUNE = 6,
+    /* assert (1) or withdraw (0) that property, e.g. after ek_assign_nearest
+     * with the medoid frames themselves as centers */
+    EK_OPT_STATE_EXACT = 7,
+    /* with EK_OPT_CANDIDATES = -1, let ek_kcenters_run move between 1, 8 and 16
+     * candidates per round by measured centers per millisecond: 1 (default) /
+     * 0 (always the widest form) */
+    EK_OPT_ADAPTIVE = 8,
+    /* retired (round 1's pass kernel with the candidates staged in LDS); only
+     * the value 1 is accepted */
+    EK_OPT_PASS_FORM = 9,
+    /* ek_kcenters_run's rounds in three launches (the single-workgroup steps
+     * ride at the end of the launch that produces their input): 1 (default) /
+     * 0 (one launch per step).  MEASUREMENT */
+    EK_OPT_FUSED_ROUNDS = 10,
+    /* the reference's `use_triangle_inequality` (kcenters.py:287-296 /
+     * :351-364), 0 default / 1: per round the distances of the existing
+     * centers to the candidates mark, per tile of 256 frames, the candidates
+     * none of whose frames can move (own center at least twice the frame's
+     * distance away, with a margin); such (tile, candidate) pairs are not
+     * computed and a tile without any is not read.  From a fresh state
+     * (ek_state_reset) and for >= 3 atoms.  Also in the sharded one-center
+     * iteration (ek_kcenters_step with gathered records): every shard keeps a
+     * table of the accepted centers filled from the winning records */
+    EK_OPT_TRIANGLE = 11,
+    /* ek_pam_window_run works through a window whose prefetch was restricted
+     * to a list of frames in ONE workgroup, no launch between two proposals
+     * (1, default) or with three launches per proposal (0).  MEASUREMENT */
+    EK_OPT_PAM_ONE_WORKGROUP = 12,
+    /* the (ambiguous member, medoid within reach) pairs such a workgroup
+     * searches itself (default 16384); a proposal with more ends the window
+     * and goes through the launches.  0 makes every proposal whose members
+     * have another medoid within reach do so (tests) */
+    EK_OPT_PAM_MAX_PAIRS = 13,
+    /* such a workgroup takes both cost sums (numpy's order) for every proposal
+     * (1) or only where the sum of the changes, new^2 - old^2 over the frames
+     * the proposal moves, does not decide kmedoids.py:683's comparison by four
+     * orders of magnitude more than the rounding of the sums can amount to (0,
+     * default).  MEASUREMENT */
+    EK_OPT_PAM_BOTH_SUMS = 14,
+    /* the next round's candidates are chosen among the farthest frames per 64
+     * frames of the state the whole chain leaves (1, default) or per 256 (0).
+     * MEASUREMENT */
+    EK_OPT_FINE_PICK = 15,
+    /* ek_pam_sweep's windows of drawn proposals take the proposal-to-medoid
+     * distance table as the lower bounds the medoid-to-medoid table and the
+     * proposals' own distances give (triangle inequality; half the pairs of a
+     * window's tables): 1 (default) / 0 exact distances.  MEASUREMENT */
+    EK_OPT_PAM_BOUNDS = 16,
+    /* how many of a label's farthest frames the candidate pick of a round may
+     * list (the list of 64 the guesses are chosen from): 0 (default) = 4 or 16
+     * by the share of its guesses the run sees accepted (4 suits frames in
+     * clouds around templates, 16 a continuous landscape), 1 .. 16 fixed */
+    EK_OPT_PICK_CAP = 17,
+    /* ek_ms_run's ladder moves from rounds of 8 to 16 once they accept 4.5 (1)
+     * or 6.5 (0, default) centers: 1 suits shards of up to ~300 000 frames;
+     * every rank of a group must set the same value (sharded.kcenters_sharded
+     * does, from the gathered shard sizes) */
+    EK_OPT_SMALL_SHARDS = 18,
+    /* a PAM window's slots evaluated at once ahead of their turn: 1 (default)
+     * / 0 (each in its turn; ek_pam_ahead_stats).  MEASUREMENT */
+    EK_OPT_PAM_AHEAD = 19,
+    /* a PAM window's record, the next window's member counts and the drawn
+     * frames written into mapped host memory by the kernels that make them (1,
+     * default) or copied back behind them (0).  MEASUREMENT */
+    EK_OPT_PAM_ZERO_COPY = 20,
+    /* the distance kernels of a PAM window (tables, listed frames) on the
+     * matrix cores, 16 rows x 16 columns per wave (1, default) or LDS-staged
+     * 64 x 8 per workgroup (0); process-wide.  MEASUREMENT */
+    EK_OPT_PAM_PAIRS_MFMA = 21
+};
 int ek_set_option(ek_ctx *ctx, int32_t key, int32_t value);
+/* the value an option holds (what ek_set_option stored, or its default) */
+int ek_get_option(ek_ctx *ctx, int32_t key, int32_t *value);
 /* time of the last ek_kcenters_run loop measured with HIP events on the
  * context's stream, milliseconds, and the number of distance-kernel launches
  * it covered */

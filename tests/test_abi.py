@@ -90,3 +90,18 @@ def test_product_does_not_import_the_oracle():
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text,
                                      flags=re.M), f
                 assert "liboracle" not in text, f
+
+
+def test_option_names_match_the_header():
+    """enspara_amd._lib's EK_OPT_* constants are include/enspara_hip.h's
+    `enum ek_option`, member for member"""
+    from enspara_amd import _lib
+    src = open(os.path.join(ROOT, "include", "enspara_hip.h")).read()
+    body = src[src.index("enum ek_option {"):]
+    body = re.sub(r"/\*.*?\*/", "", body[:body.index("};")], flags=re.S)
+    pairs = {n: int(v) for n, v in re.findall(r"(EK_OPT_[A-Z_0-9]+)\s*=\s*(-?\d+)", body)}
+    assert len(pairs) >= 20
+    mine = {k: v for k, v in vars(_lib).items() if k.startswith("EK_OPT_")}
+    assert mine == pairs
+    assert _lib.OPTIONS["candidates"] == pairs["EK_OPT_CANDIDATES"] == 4
+    assert len(set(pairs.values())) == len(pairs)

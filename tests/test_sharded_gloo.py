@@ -557,12 +557,18 @@ def _form_worker(rank, world, port, outdir):
     class Tight(HostShardMs):
         """a shard whose rank 1 has no room for the quad copy of its frames"""
         pinned = None
+        pins = ()
 
         def quad_copy_ready(self):
             return rank != 1
 
+        def candidates_option(self):
+            return 16
+
         def pin_candidates(self, T):
-            self.pinned = T
+            self.pins = self.pins + (T,)
+            if self.pinned is None:
+                self.pinned = T
             self.candidates = T
 
     x = synth.synth(1500, 20, 9, seed=5)
@@ -571,7 +577,7 @@ def _form_worker(rank, world, port, outdir):
     idx, _ = sharded.kcenters_sharded(shard, 0, 30, 0.0)
     np.savez(os.path.join(outdir, "r%d.npz" % rank), idx=idx,
              pinned=-1 if shard.pinned is None else shard.pinned,
-             cands=shard.candidates)
+             pins=np.array(shard.pins), cands=shard.candidates)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -588,5 +594,57 @@ def test_ranks_agree_on_the_width_of_their_rounds():
     x = synth.synth(1500, 20, 9, seed=5)
     inds, _, _ = oc.kcenters(x, n_clusters=30)
     for p in parts:
-        assert int(p["pinned"]) == 8 and int(p["cands"]) == 8
+        # narrowed for the run, and the caller's own setting back after it
+        assert int(p["pinned"]) == 8 and list(p["pins"]) == [8, 16]
+        assert int(p["cands"]) == 16
         np.testing.assert_array_equal(p["idx"], np.array(inds))
+
+
+def _km_none_worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["OMP_NUM_THREADS"] = "2"
+    from enspara_amd import sharded, synth
+    from _host_shard import HostShard
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port,
+                            rank=rank, world_size=world)
+    x = synth.synth(900, 18, 11, seed=8)
+    lo, cnt = sharded.shard_bounds(len(x), world, rank)
+    shard = HostShard(x[lo:lo + cnt], lo)
+    np.random.seed(1000 + rank)         # (nothing shared by accident)
+    pairs, coords = sharded.kmedoids_sharded(shard, x[lo:lo + cnt], n_clusters=7,
+                                             n_iters=3, random_state=None)
+    np.savez(os.path.join(outdir, "r%d.npz" % rank), pairs=np.array(pairs),
+             coords=coords, dist=shard.dist, assign=shard.assign, lo=lo)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_kmedoids_across_ranks_without_a_random_state(world):
+    """random_state=None (what KMedoids.fit passes in MPI mode): the ranks must
+    still draw the same proposals -- the reference agrees on every draw across
+    ranks (mpi/ops.py randind).  Round-5 advisor finding: each rank seeded its
+    own stream and the medoids diverged.  Here: identical medoids on every
+    rank, owned rows consistent, every frame's distance the RMSD to the medoid
+    its label names."""
+    from oracle import qcp
+    from enspara_amd import synth
+    with tempfile.TemporaryDirectory() as dd:
+        mp.spawn(_km_none_worker, args=(world, _free_port(), dd), nprocs=world,
+                 join=True)
+        parts = [np.load(os.path.join(dd, "r%d.npz" % r)) for r in range(world)]
+    x = synth.synth(900, 18, 11, seed=8)
+    los = [int(p["lo"]) for p in parts]
+    med = [los[int(r)] + int(i) for r, i in parts[0]["pairs"]]
+    assert len(set(med)) == 7
+    for p in parts:
+        assert [los[int(r)] + int(i) for r, i in p["pairs"]] == med
+        np.testing.assert_array_equal(p["coords"], x[med])
+    a = np.concatenate([p["assign"] for p in parts])
+    d = np.concatenate([p["dist"] for p in parts])
+    for k, g in enumerate(med):
+        sel = np.flatnonzero(a == k)
+        np.testing.assert_array_equal(
+            d[sel].astype(np.float32),
+            qcp.rmsd(x, x[int(g)])[sel].astype(np.float32))
