@@ -458,14 +458,18 @@ def msm_block(args):
     }
 
 
-def khybrid_check(x, store, start_medoids, gpu_medoids, seed, seconds):
+def khybrid_check(x, store, start_medoids, gpu_medoids, seed, seconds,
+                  second_sweep=None):
     """Full-size parity of the k-hybrid leg (BASELINE.json configs[2]): the
     first proposals of the sweep replayed by the oracle's PAM
     (oracle/cluster.py pam_update = enspara/cluster/kmedoids.py:575-699) on the
     same frames from the same k-centers state and the same random stream, as
     many as fit the time budget -- the medoids must be the GPU's --, and after
     the GPU's whole sweep a sample of frames: every one's distance must be, bit
-    for bit, its RMSD to the medoid its label names."""
+    for bit, its RMSD to the medoid its label names.  ``second_sweep`` (with no
+    budget): the GPU's medoids and state after the sweep that FOLLOWS from the
+    carried RandomState (kmedoids.py:410-476), replayed whole as well.
+    ``store`` holds the state the GPU's FIRST sweep left."""
     from oracle import cluster as oc
     from oracle import qcp
     usable, _, _ = host_threads()
@@ -474,9 +478,10 @@ def khybrid_check(x, store, start_medoids, gpu_medoids, seed, seconds):
     d0, a0 = start_medoids["dist"], start_medoids["assign"]
     done = []
     t0 = time.perf_counter()
+    rs_oracle = np.random.RandomState(seed)
     med, od, oa = oc.pam_update(P, list(start_medoids["medoids"]),
                                 a0.astype(np.int64), d0.astype(np.float64),
-                                random_state=np.random.RandomState(seed),
+                                random_state=rs_oracle,
                                 budget_s=seconds if seconds > 0 else None,
                                 done=done)
     wall = time.perf_counter() - t0
@@ -501,8 +506,25 @@ def khybrid_check(x, store, start_medoids, gpu_medoids, seed, seconds):
         whole = {"labels_equal": bool(np.array_equal(a, oa)),
                  "distances_equal": bool(np.array_equal(
                      np.asarray(d, dtype=np.float64), od))}
+    second = None
+    if k == len(gpu_medoids) and second_sweep is not None:
+        # the sweep AFTER it (kmedoids.py:410-476: the RandomState carried over,
+        # the state the first sweep left), replayed whole
+        m1, d1, a1, rs2 = med, od, oa, rs_oracle
+        t1 = time.perf_counter()
+        m2, d2, a2 = oc.pam_update(P, [int(m) for m in m1], a1, d1,
+                                   random_state=rs2)
+        second = {"medoids_match_gpu": [int(m) for m in m2] ==
+                  [int(m) for m in second_sweep["medoids"]],
+                  "labels_equal": bool(np.array_equal(second_sweep["assign"], a2)),
+                  "distances_equal": bool(np.array_equal(
+                      np.asarray(second_sweep["dist"], dtype=np.float64), d2)),
+                  "of_them_accepted": sum(1 for i in range(len(m2))
+                                          if int(m2[i]) != int(m1[i])),
+                  "oracle_s": time.perf_counter() - t1}
     return {"proposals_replayed_by_oracle": k, "medoids_match_gpu": bool(same),
             "whole_sweep_state_vs_oracle": whole,
+            "second_sweep_vs_oracle": second,
             "of_them_accepted": moved, "oracle_s": wall,
             "sampled_frames": int(len(sample)),
             "sampled_state_is_rmsd_to_own_medoid_bit_exact": bool(ok)}
@@ -558,6 +580,49 @@ def load_traffic(args, n_local, cands):
         why = "%s: %s" % (type(e).__name__, e)
     return None, {"file": "profiles/traffic.json", "unused_because": why,
                   "kernel_source_sha256_16": src}
+
+
+def one_center_leg(store, args, n_local, launches=48):
+    """BASELINE.md / SURVEY.md 8(d)'s roofline, measured in this run: the
+    ONE-center pass (ek_step_kernel -- one frame read serves one center, the
+    HBM-bound form north_star describes) for a few dozen launches from the
+    untouched state, each timed with HIP events on the context's stream.
+    Algorithmic bytes per pair 12 A + 16 (coordinates, trace as counted by
+    BASELINE.md, distance read + write, label write); the kernel's own traffic
+    is 12 A + 20 (its traces are float64)."""
+    before = store.get_option("candidates")
+    first = min(2000, max(args.centers - launches, 0))
+    try:
+        # (in mid-fit, where a fit spends its time: the first `first` centers in
+        # the default form, then `launches` one-center passes go on from there)
+        store.reset_state()
+        store.sync()
+        if first:
+            store.kcenters_run(0, first, 0.0)
+        store.set_option("candidates", 1)
+        store.timing_begin(sample_every=1, max_samples=launches)
+        t0 = time.perf_counter()
+        store.kcenters_run(first, launches, 0.0)
+        store.sync()
+        wall = time.perf_counter() - t0
+        ms, n_samp = store.timing_end()
+    finally:
+        store.set_option("candidates", before)
+    bpp = 12 * args.atoms + 16
+    ach = n_local * bpp / (ms * 1e-3) / 1e9 if ms > 0 else None
+    traffic, src = load_traffic(args, n_local, 1)
+    return {"kernel": "ek_step_kernel<FPL,0,NT>", "bound": "hbm",
+            "bytes_per_pair": bpp, "pairs_per_launch": n_local,
+            "avg_launch_ms": ms, "launches_sampled": n_samp,
+            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": ach / HBM_PEAK_GBS if ach else None,
+            "pairs_per_s_kernel": n_local / (ms * 1e-3) if ms > 0 else None,
+            "pairs_per_s_with_the_pick_between_launches": n_local * launches / wall,
+            "ceiling_pairs_per_s": HBM_PEAK_GBS * 1e9 / bpp,
+            "traffic": traffic, "traffic_source": src,
+            "centers_before_the_sampled_passes": first,
+            "what": "BASELINE.md's HBM roofline: one center per pass over the "
+                    "frames, 12 A + 16 algorithmic bytes per pair"}
 
 
 def main():
@@ -845,6 +910,11 @@ def main():
     else:
         roof = dict(hbm)
         roof.update({"bound": "hbm", "kernel": kernel_name})
+    if dom >= 16:
+        # (the driver's parser keeps top-level keys of `roofline`: the HBM side
+        # of the dominant kernel beside its matrix-core side)
+        roof.update({"hbm_frac": hbm["frac"], "hbm_achieved_GBps": hbm["achieved"],
+                     "hbm_algorithmic_bytes_per_launch": launch_bytes})
     roof.update({
         "bytes_per_pair_one_center_pass": bpp,
         "pairs_per_launch": n_local * min(dom, 16),
@@ -919,6 +989,11 @@ def main():
                          "ek_load_frames); PCIe-inclusive, never part of value"},
     }
 
+    # ---- SURVEY.md 8(d) / BASELINE.md: the one-center pass against HBM ---------
+    if world == 1 and not use_dist:
+        out["roofline_one_center"] = one_center_leg(store, args, n_local)
+        out["roofline"]["one_center_hbm_frac"] = out["roofline_one_center"]["frac"]
+
     # ---- k-hybrid refinement (configs[2]), outside the timed region -----------
     if args.pam_sweeps is None:
         args.pam_sweeps = 1 if world == 1 else 0
@@ -975,9 +1050,62 @@ def main():
             "windows_in_one_workgroup": store.pam_sparse_stats()[0] if world == 1 else None,
             "of_them_ended_early": store.pam_sparse_stats()[1] if world == 1 else None,
         }
+        # ---- configs[2] end to end: the fit + KHybrid's five default sweeps
+        # (hybrid.py:65), frames resident; then KHybrid.fit itself from the host
+        # array (upload, centring, result arrays and the centers' list included)
+        if world == 1:
+            n_it = 5
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            med5 = [int(i) for i in run(centers_total)]
+            t_fit = time.perf_counter() - t0
+            rs5 = np.random.RandomState(args.seed)
+            per = []
+            for _ in range(n_it):
+                t1 = time.perf_counter()
+                med5 = km._pam_sweep_device(store, med5, None, rs5)
+                per.append(time.perf_counter() - t1)
+            store.sync()
+            t_all = time.perf_counter() - t0
+            from enspara_amd.cluster import KHybrid
+            est = KHybrid("rmsd", n_clusters=centers_total, kmedoids_updates=n_it,
+                          random_state=np.random.RandomState(args.seed),
+                          device=local_rank).fit(x)
+            out["khybrid"]["five_sweeps"] = {
+                "what": "KHybrid('rmsd', n_clusters=%d).fit: k-centers + %d PAM sweeps "
+                        "(the reference's default kmedoids_updates, hybrid.py:65)"
+                        % (centers_total, n_it),
+                "frames_resident_total_s": t_all, "kcenters_s": t_fit,
+                "sweep_s": per,
+                "pairs_per_s_of_the_kcenters_part_alone": pairs / t_fit,
+                "estimator_fit_from_host_array_s": est.runtime_,
+                "estimator_medoids_equal_resident_run": [int(i) for i in
+                                                         est.center_indices_] == med5,
+                "medoids_moved_by_the_sweeps": sum(
+                    1 for a_, b_ in zip(med5, start["medoids"]) if a_ != b_)}
+            del est
+        second = None
+        if (start is not None and args.pam_sweeps == 1 and not args.no_cpu_baseline
+                and args.cpu_seconds <= 0):
+            # two consecutive sweeps on the GPU from the fit's state; the first one's
+            # state stays on `store` for the check, the second's is handed over
+            med = [int(i) for i in run(centers_total)]
+            rs = np.random.RandomState(args.seed)
+            med = km._pam_sweep_device(store, med, None, rs)
+            d1, a1 = store.download_state()
+            med2 = km._pam_sweep_device(store, list(med), None, rs)
+            d2, a2 = store.download_state()
+            store.upload_state(d1, a1)
+            second = {"medoids": med2, "dist": d2, "assign": a2}
         if start is not None and args.pam_sweeps == 1 and not args.no_cpu_baseline:
+            if second is None and world == 1:
+                # (`store` must hold the state of ONE sweep for the sampled check)
+                med = [int(i) for i in run(centers_total)]
+                med = km._pam_sweep_device(store, med, None,
+                                           np.random.RandomState(args.seed))
             out["khybrid"]["parity"] = khybrid_check(x, store, start, med, args.seed,
-                                                     min(40.0, 3 * args.cpu_seconds))
+                                                     min(40.0, 3 * args.cpu_seconds),
+                                                     second_sweep=second)
     gpu_state = start if (args.pam_sweeps > 0 and world == 1) else None
     if gpu_state is None and world == 1 and args.cpu_seconds <= 0 \
             and not args.no_cpu_baseline:

@@ -327,7 +327,8 @@ print("ok", len(inds), stores[0].ms_state())
     (3, 600, 5, 40, 0.0, 16),           # the third shard is empty
     (2, 30000, 33, 300, 0.0, 16), (8, 40000, 20, 400, 0.0, 16),
     (2, 9000, 21, 70, 0.0, 32), (3, 600, 5, 40, 0.0, 32),
-    (2, 30000, 33, 300, 0.0, 32), (8, 40000, 20, 400, 0.0, 32)])
+    (2, 30000, 33, 300, 0.0, 32), (8, 40000, 20, 400, 0.0, 32),
+    (4, 50000, 24, 20000, 0.0, -1)])     # configs[3]'s center count, the ladder
 def test_mailbox_rounds_between_contexts(shards, n, A, K, cutoff, cands):
     """the rounds of csrc/ek_mshard.hip with the exchange on the device: the
     shards are contexts of ONE process on the one GPU, their mailboxes plain
