@@ -51,6 +51,7 @@ SYMBOLS = [
     "ek_feat_create", "ek_feat_destroy", "ek_feat_load", "ek_feat_distance",
     "ek_feat_kcenters", "ek_feat_pam_sweep", "ek_feat_pam_release",
     "ek_set_frames_per_lane", "ek_set_option", "ek_get_option", "ek_last_run_timing",
+    "ek_reserve_centers",
     "ek_timing_begin", "ek_timing_end", "ek_timing_form", "ek_hbm_copy_rate",
     "ek_qcp_probe",
 ]
@@ -103,10 +104,11 @@ def load():
             "%s not found: the HIP extension is not built "
             "(run `python -m enspara_amd.build`); there is no CPU fallback."
             % LIB_PATH)
-    try:
-        import torch  # noqa: F401  (loads libamdhip64.so.7 first)
-    except Exception:  # pragma: no cover - torch is plumbing, not required
-        pass
+    if os.environ.get("ENSPARA_NO_TORCH") != "1":   # (measurement switch: the system's
+        try:                                        # HIP runtime instead of torch's copy)
+            import torch  # noqa: F401  (loads libamdhip64.so.7 first)
+        except Exception:  # pragma: no cover - torch is plumbing, not required
+            pass
     try:
         L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     except OSError as e:
@@ -221,6 +223,7 @@ def load():
     L.ek_set_frames_per_lane.argtypes = [vp, C.c_int]
     L.ek_set_option.argtypes = [vp, i32, i32]
     L.ek_get_option.argtypes = [vp, i32, i32p]
+    L.ek_reserve_centers.argtypes = [vp, i32]
     L.ek_last_run_timing.argtypes = [vp, f32p, i32p]
     L.ek_timing_begin.argtypes = [vp, i32, i32]
     L.ek_timing_end.argtypes = [vp, f32p, i32p]

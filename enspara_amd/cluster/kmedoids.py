@@ -499,12 +499,16 @@ FEATURE_RAW_AHEAD = None
 
 def _feature_sweep_applies(X, metric, distances, proposals, assignments=None):
     """A floating-point (or integer) sample matrix without NaN, a finite
-    float64 state with integer labels, one of the two resident metrics, the
-    default cost.  (The reference builds ``new_dist = zeros_like(distances)``,
+    float64 state with integer labels, one of the resident metrics (euclidean,
+    manhattan; hamming on integer samples since round 6), the default cost.  (The reference builds ``new_dist = zeros_like(distances)``,
     kmedoids.py:639: with float32 distances every accepted proposal rounds the
     new values to float32 before the next comparison -- the resident sweep
     works in float64 throughout, so it only takes float64 states.)"""
-    if getattr(metric, "device_metric_id", None) not in (0, 1):
+    mid = getattr(metric, "device_metric_id", None)
+    if mid not in (0, 1, 2):
+        return False
+    if mid == 2 and not (isinstance(X, np.ndarray)      # hamming (libdist.pyx:77-95):
+                         and np.issubdtype(X.dtype, np.integer)):   # integer samples only
         return False
     if np.asarray(distances).dtype != np.float64:
         return False

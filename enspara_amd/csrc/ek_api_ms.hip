@@ -368,6 +368,37 @@ extern "C" int ek_ms_connect(ek_ctx *c, int32_t peer, void *mbox, void *flags,
     return EK_OK;
 }
 
+// Everything a run of the rounds to `n_centers` centers allocates, now: the history
+// of the accepted centers, the rounds' working set, the quad copy of the frames for
+// rounds of 16.  hipMalloc / hipFree wait for the whole device: inside ek_ms_run --
+// peers already polling for this shard's message on the same GPU (contexts of one
+// process: tools/c4_one_gpu.py, the tests) or a collective in flight -- that is a
+// deadlock until the mailbox time-out (round 6: eight shards of one process, 3000
+// centers: the history grows beyond its first 1024 entries at the start of the run).
+extern "C" int ek_reserve_centers(ek_ctx *c, int32_t n_centers)
+{
+    if (!c || n_centers < 0)
+        return ek_fail(EK_EARG, "ek_reserve_centers: bad argument");
+    if (!c->loaded)
+        return ek_fail(EK_ESTATE, "ek_reserve_centers: no frames loaded");
+    EK_HIP(hipSetDevice(c->device));
+    int rc = ek_ensure_hist(c, n_centers);
+    if (rc)
+        return rc;
+    rc = ek_spec_alloc(c);
+    if (rc)
+        return rc;
+    if (ek_pick_cands(c, true, true) >= 16) {
+        const int eq = ek_ensure_qtiles(c);
+        if (eq != EK_OK && eq != EK_ENOMEM)     // (no room: the run itself reports it)
+            return eq;
+    }
+    for (int k = 0; k < 4; ++k)
+        if (!c->ms_ev[k])
+            EK_HIP(hipEventCreate(&c->ms_ev[k]));
+    return EK_OK;
+}
+
 static int ek_ms_check(ek_ctx *c, const char *who)
 {
     if (!c)

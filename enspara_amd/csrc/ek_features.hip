@@ -149,6 +149,16 @@ template <> struct FeatAcc<long long, 2> {
     }
 };
 
+// what libdist.pyx does with a row's sum: sqrt (:143), nothing (:119), / n_features (:93)
+template <int METRIC> __device__ __forceinline__ double feat_finish(double acc, int F)
+{
+    if (METRIC == 0)
+        return __builtin_sqrt(acc);
+    if (METRIC == 2)
+        return acc / (double)F;
+    return acc;
+}
+
 template <typename T, int METRIC>
 __global__ void __launch_bounds__(EK_BLOCK)
 feat_distance_kernel(const T *__restrict__ tiles, const T *__restrict__ y,
@@ -865,8 +875,7 @@ feat_pam_nearest_kernel(const T *__restrict__ tiles, int F,
                     FeatAcc<T, METRIC>::add(acc, xs[j], MT[(size_t)(j0 + j) * Kcap + c]);
         }
         if (c < K) {
-            if (METRIC == 0)
-                acc = __builtin_sqrt(acc);
+            acc = feat_finish<METRIC>(acc, F);
             if (acc < best) {               // ascending c per thread: strict <
                 best = acc;
                 bc = c;
@@ -966,7 +975,7 @@ feat_pam_nearest_tiled_kernel(const T *__restrict__ tiles, int F,
             double best = __builtin_inf();
             int32_t bc = 0;
             if (c < K) {
-                const double a = (METRIC == 0) ? __builtin_sqrt(acc[m]) : acc[m];
+                const double a = feat_finish<METRIC>(acc[m], F);
                 if (a < best) {
                     best = a;
                     bc = c;
@@ -1206,8 +1215,7 @@ feat_dist_classify_kernel(const T *__restrict__ tiles, const T *__restrict__ y,
     }
     if (f >= n)
         return;
-    if (METRIC == 0)
-        acc = __builtin_sqrt(acc);
+    acc = feat_finish<METRIC>(acc, F);
     const double d = dist[f], x = acc;
     const int32_t a = assign[f];
     if (d > x) {
@@ -1440,7 +1448,7 @@ feat_multi_distance_kernel(const T *__restrict__ tiles, const T *__restrict__ Y,
 #pragma unroll
     for (int g = 0; g < W; ++g)
         if (g < cnt)
-            vecs[(size_t)g * n + f] = (METRIC == 0) ? __builtin_sqrt(acc[g]) : acc[g];
+            vecs[(size_t)g * n + f] = feat_finish<METRIC>(acc[g], F);
 }
 
 // a slot's first kernel (one workgroup): does its draw still hold, did it succeed;
@@ -1638,7 +1646,9 @@ static void feat_enqueue_plain_any(ek_feat *k, int32_t metric, FeatPam &p, int32
                                    int32_t c0, int32_t c1, bool have_props, int64_t raw_left,
                                    dim3 near_grid)
 {
-    if (k->kind == 0) {
+    if (k->kind == 2) {      // hamming on integer samples (libdist.pyx:77-95)
+        feat_enqueue_plain<long long, 2>(k, p, K, c0, c1, have_props, raw_left, near_grid);
+    } else if (k->kind == 0) {
         if (metric == 0)
             feat_enqueue_plain<float, 0>(k, p, K, c0, c1, have_props, raw_left, near_grid);
         else
@@ -1658,12 +1668,14 @@ extern "C" int ek_feat_pam_sweep(ek_feat *k, int32_t metric, int32_t n_medoids,
                                  int32_t *accept, int32_t *cid_io, int32_t *status)
 {
     if (!k || !medoids || !dist_io || !assign_io || !accept || !cid_io || !status ||
-        !pos || n_medoids < 1 || metric < 0 || metric > 1)
+        !pos || n_medoids < 1 || metric < 0 || metric > 2)
         return ek_set_error(EK_EARG, "ek_feat_pam_sweep: bad argument (metrics: "
-                                     "euclidean 0, manhattan 1)");
-    if (!k->loaded || k->kind == 2)
-        return ek_set_error(EK_ESTATE, "ek_feat_pam_sweep: floating-point samples "
-                                       "have to be loaded");
+                                     "euclidean 0, manhattan 1, hamming 2)");
+    if (!k->loaded)
+        return ek_set_error(EK_ESTATE, "ek_feat_pam_sweep: samples have to be loaded");
+    if ((metric == 2) != (k->kind == 2))
+        return ek_set_error(EK_EARG, "ek_feat_pam_sweep: hamming needs integer "
+                                     "samples, the other metrics floating point");
     if (k->n < 1 || k->n > 0xffffffffLL)
         return ek_set_error(EK_EARG, "ek_feat_pam_sweep: %lld samples",
                             (long long)k->n);
@@ -1700,7 +1712,11 @@ extern "C" int ek_feat_pam_sweep(ek_feat *k, int32_t metric, int32_t n_medoids,
         // the medoids' features
         FE_HIP(hipMemcpyAsync(p.med, medoids, (size_t)K * sizeof(int64_t),
                               hipMemcpyHostToDevice, k->s));
-        if (k->kind == 0)
+        if (k->kind == 2)
+            hipLaunchKernelGGL(feat_medoid_table_kernel<long long>, dim3(K), dim3(EK_BLOCK),
+                               0, k->s, (const long long *)k->tiles, k->F, p.med, K,
+                               p.Kcap, (long long *)p.MT);
+        else if (k->kind == 0)
             hipLaunchKernelGGL(feat_medoid_table_kernel<float>, dim3(K), dim3(EK_BLOCK),
                                0, k->s, (const float *)k->tiles, k->F, p.med, K,
                                p.Kcap, (float *)p.MT);
@@ -1777,7 +1793,10 @@ extern "C" int ek_feat_pam_sweep(ek_feat *k, int32_t metric, int32_t n_medoids,
             // before the control block is read; drawn ones: one window, as wide as
             // the draws have lately held (an accepted proposal that takes samples
             // from or gives samples to a later cluster of the window ends it there)
-            const bool use_win = fw_forced || (fw_big && (proposals || p.plain_left <= 0));
+            // (hamming: one proposal at a time -- the windows' kernels are built for the
+            // floating-point metrics only)
+            const bool use_win = metric != 2 &&
+                                 (fw_forced || (fw_big && (proposals || p.plain_left <= 0)));
             if (!use_win) {
                 const int32_t c1 = std::min<int32_t>(
                     K, cid + (p.plain_left > 0 ? std::min(128, p.plain_left) : 128));
@@ -2051,7 +2070,9 @@ extern "C" int ek_feat_pam_sweep(ek_feat *k, int32_t metric, int32_t n_medoids,
                                p.amb, p.counters, (const T *)p.MT, K, p.Kcap,  \
                                p.ndist, p.nassign);                            \
     } while (0)
-        if (k->kind == 0) {
+        if (k->kind == 2) {
+            FP_T(long long, 2);
+        } else if (k->kind == 0) {
             if (metric == 0)
                 FP_T(float, 0);
             else
@@ -2085,7 +2106,11 @@ extern "C" int ek_feat_pam_sweep(ek_feat *k, int32_t metric, int32_t n_medoids,
             std::swap(k->kassign, p.nassign);
             medoids[cid] = prop;
         } else {
-            if (k->kind == 0)
+            if (k->kind == 2)
+                hipLaunchKernelGGL(feat_restore_kernel<long long>, dim3(1), dim3(EK_BLOCK), 0,
+                                   k->s, k->F, cid, p.Kcap, (long long *)p.MT,
+                                   (const long long *)p.col);
+            else if (k->kind == 0)
                 hipLaunchKernelGGL(feat_restore_kernel<float>, dim3(1), dim3(EK_BLOCK), 0,
                                    k->s, k->F, cid, p.Kcap, (float *)p.MT,
                                    (const float *)p.col);

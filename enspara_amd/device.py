@@ -519,6 +519,11 @@ class FrameStore:
                                         C.byref(r)))
         return m.value, e.value, r.value
 
+    def reserve_centers(self, n_centers):
+        """allocate now what a run of the rounds to ``n_centers`` centers needs
+        (nothing is allocated -- no device-wide wait -- inside ms_run then)"""
+        _lib.check(self.lib.ek_reserve_centers(self._h, int(n_centers)))
+
     def ms_run(self, first_label, max_new, dist_cutoff):
         """k-centers over all connected shards, exchange on the device; every
         shard calls it at the same time.  -> as kcenters_run"""

@@ -65,6 +65,9 @@ class DeviceShard:
     def pin_candidates(self, T):
         self.store.set_option("candidates", int(T))
 
+    def reserve_centers(self, n_centers):
+        self.store.reserve_centers(n_centers)
+
     def candidates_option(self):
         """what the option holds (-1: automatic), to put it back afterwards"""
         return self.store.get_option("candidates")
@@ -373,6 +376,10 @@ def _kcenters_sharded_ms(shard, first_label, max_new, dist_cutoff, group, fresh,
     if fresh:
         shard.reset_history()
     if getattr(shard, "ms_connected", 0) == world:
+        # (nothing is allocated inside the run: a hipMalloc / hipFree waits for the
+        # whole device, and the peers may be polling for this shard's message by then)
+        if hasattr(shard, "reserve_centers"):
+            shard.reserve_centers(first_label + max_new)
         if collective:      # (the shards wait for one another on the device from here on)
             dist.barrier(group=group)
         idx, cd = shard.ms_run(first_label, max_new, float(dist_cutoff))

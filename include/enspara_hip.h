@@ -241,6 +241,13 @@ int ek_ms_mailbox(ek_ctx *ctx, void **mbox, void **flags, void *ipc_mbox,
                   void *ipc_flags);
 int ek_ms_connect(ek_ctx *ctx, int32_t peer, void *mbox, void *flags,
                   const void *ipc_mbox, const void *ipc_flags);
+/* Allocates, NOW, everything a run of the rounds to n_centers centers needs (the
+ * accepted centers' history, the rounds' working set, the third copy of the
+ * frames for rounds of 16): an allocation inside ek_ms_run waits for the whole
+ * device, and with peers already polling for this shard's message on the same
+ * GPU that is a deadlock until the mailbox time-out.  Call it on every shard
+ * before the first of them enters ek_ms_run.  No reference counterpart. */
+int ek_reserve_centers(ek_ctx *ctx, int32_t n_centers);
 int ek_ms_begin(ek_ctx *ctx, int32_t first_label, int32_t limit);
 int ek_ms_local(ek_ctx *ctx, double dist_cutoff, void *message_out);
 int ek_ms_global(ek_ctx *ctx, double dist_cutoff, const void *messages_all);

@@ -479,7 +479,15 @@ void eko_pam_trial(const float *tiled, const float *frames, const double *G,
                    int64_t *new_assig, float *nd_scratch)
 {
     eko_rmsd_one_to_many_tiled(tiled, G, n, A, prop, Gp, nd_scratch);
-#pragma omp parallel for schedule(dynamic, 1024)
+    /* the members of cluster cid that stay behind (:658) are searched against all
+     * K trial medoids (:666).  They are few -- often one or two -- and K can be
+     * 20 000: the search of a member is spread over the medoids (every distance
+     * by the same scalar function, then util.py:199-203's scan in ascending
+     * order with its strict <), not over the members. */
+    int64_t n_amb = 0;
+    int64_t *amb = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n > 0 ? n : 1));
+    float *dcs = (float *)malloc(sizeof(float) * (size_t)(K > 0 ? K : 1));
+#pragma omp parallel for schedule(static)
     for (int64_t f = 0; f < n; ++f) {
         const double d = dist[f];
         const double nd = (double)nd_scratch[f];
@@ -493,29 +501,39 @@ void eko_pam_trial(const float *tiled, const float *frames, const double *G,
                 oa = assign[f];
                 od = d;
             } else {
-                const float *x = frames + (size_t)f * A * 3;
-                float best = INFINITY;
-                int64_t bi = 0;
-                for (int32_t c = 0; c < K; ++c) {
-                    float S[9];
-                    float dc;
-                    if (c == cid) {
-                        eko_accum_S(x, prop, A, S);
-                        dc = eko_rmsd_from_S(S, G[f], Gp, A);
-                    } else {
-                        eko_accum_S(x, medoids + (size_t)c * A * 3, A, S);
-                        dc = eko_rmsd_from_S(S, G[f], Gm[c], A);
-                    }
-                    if (dc < best) {
-                        best = dc;
-                        bi = c;
-                    }
-                }
-                oa = bi;
-                od = (double)best;
+                oa = -2;        /* searched below */
             }
         }
         new_dist[f] = od;
         new_assig[f] = oa;
     }
+    for (int64_t f = 0; f < n; ++f)
+        if (new_assig[f] == -2)
+            amb[n_amb++] = f;
+    for (int64_t m = 0; m < n_amb; ++m) {
+        const int64_t f = amb[m];
+        const float *x = frames + (size_t)f * A * 3;
+#pragma omp parallel for schedule(static)
+        for (int32_t c = 0; c < K; ++c) {
+            float S[9];
+            if (c == cid) {
+                eko_accum_S(x, prop, A, S);
+                dcs[c] = eko_rmsd_from_S(S, G[f], Gp, A);
+            } else {
+                eko_accum_S(x, medoids + (size_t)c * A * 3, A, S);
+                dcs[c] = eko_rmsd_from_S(S, G[f], Gm[c], A);
+            }
+        }
+        float best = INFINITY;
+        int64_t bi = 0;
+        for (int32_t c = 0; c < K; ++c)
+            if (dcs[c] < best) {
+                best = dcs[c];
+                bi = c;
+            }
+        new_assig[f] = bi;
+        new_dist[f] = (double)best;
+    }
+    free(amb);
+    free(dcs);
 }

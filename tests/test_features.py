@@ -319,3 +319,63 @@ def test_nan_features_keep_the_reference_loop():
     assert list(got.center_indices) == list(want.center_indices)
     np.testing.assert_array_equal(got.assignments, want.assignments)
     np.testing.assert_array_equal(got.distances, want.distances)
+
+
+@pytest.mark.gpu
+def test_hamming_clustering_on_the_device():
+    """libdist.hamming (libdist.pyx:77-95, :187-203) as a clustering metric on
+    integer samples: k-centers with the loop resident on the device
+    (ek_feat_kcenters, metric 2) and -- round 6 -- the PAM sweep resident too
+    (ek_feat_pam_sweep, metric 2: the proposal's distances, the three masks, the
+    ambiguous members against all medoids, numpy's cost sums), against the
+    reference-shaped host loops around the ORACLE's hamming (oracle/features.py,
+    pinned to the reference's compiled module by features_golden.npz).  Distances
+    are multiples of 1 / n_features: ties in distances and in costs
+    everywhere.  int8 ... uint64 inputs like the reference's fused type."""
+    from enspara_amd.cluster import kmedoids as km
+    from enspara_amd.cluster.kcenters import kcenters
+    from enspara_amd.geometry import libdist
+    rng = np.random.RandomState(21)
+    cases = [
+        (rng.randint(0, 3, size=(2500, 12)).astype(np.int64), 30),
+        (rng.randint(0, 2, size=(1800, 40)).astype(np.int8), 25),
+        (rng.randint(0, 5, size=(900, 7)).astype(np.uint16), 40),
+        (rng.randint(0, 4, size=(3100, 2100)).astype(np.int32), 9),
+        (rng.randint(0, 2, size=(8300, 5)).astype(np.uint64), 20),
+    ]
+    moved = 0
+    for X, K in cases:
+        got = kcenters(X, libdist.hamming, n_clusters=K)
+        want = kcenters(X, lambda A, y: of.hamming(np.asarray(A), np.asarray(y)),
+                        n_clusters=K)
+        assert list(got.center_indices) == list(want.center_indices), X.dtype
+        np.testing.assert_array_equal(got.assignments, want.assignments)
+        np.testing.assert_array_equal(got.distances, want.distances)
+        for explicit in (False, True):
+            props = None
+            if explicit:
+                props = [int(v) for v in rng.randint(0, len(X), size=K)]
+            assert km._feature_sweep_applies(X, libdist.hamming, want.distances, props,
+                                             want.assignments)
+            out = {}
+            for dev in (1, 0):
+                rs = np.random.RandomState(4)
+                inds = [int(i) for i in want.center_indices]
+                d, a = want.distances.copy(), want.assignments.copy()
+                metric = libdist.hamming if dev else \
+                    (lambda A, y: of.hamming(np.asarray(A), np.asarray(y)))
+                for _ in range(2):
+                    inds, d, a, ctrs = km._kmedoids_pam_update(
+                        X, metric, inds, a, d, proposals=props, random_state=rs)
+                out[dev] = (list(inds), d, a, ctrs, rs.randint(1 << 30, size=3))
+            assert out[1][0] == out[0][0], (X.dtype, explicit)
+            np.testing.assert_array_equal(out[1][1], out[0][1])
+            np.testing.assert_array_equal(out[1][2], out[0][2])
+            for x, y in zip(out[1][3], out[0][3]):
+                np.testing.assert_array_equal(x, y)
+            np.testing.assert_array_equal(out[1][4], out[0][4])
+            moved += out[1][0] != [int(i) for i in want.center_indices]
+    assert moved >= 5
+    # floating-point samples: hamming refuses them like the reference's fused type
+    with pytest.raises(TypeError):
+        libdist.hamming(np.zeros((4, 3), dtype=np.float32), np.zeros(3, dtype=np.float32))

@@ -273,6 +273,10 @@ for r in range(shards):
     st.load(x[lo:lo + cnt])
     st.set_option(4, cands)
     st.ms_setup(shards, r)
+    # (what the run needs is allocated before any shard enters it: an allocation
+    # inside ms_run waits for the whole device -- for the other shards' kernels
+    # too, which by then wait for this shard's message)
+    st.reserve_centers(K if K else n)
     stores.append(st)
 boxes = [st.ms_mailbox() for st in stores]
 for st in stores:

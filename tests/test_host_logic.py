@@ -229,7 +229,8 @@ def test_feature_sweep_on_the_device_only_where_it_is_the_same_computation():
     assert km._feature_sweep_applies(X, libdist.euclidean, d, None)
     assert km._feature_sweep_applies(X.astype(np.float64), libdist.manhattan, d, None)
     assert km._feature_sweep_applies((X * 10).astype(np.int64), libdist.euclidean, d, None)
-    assert not km._feature_sweep_applies(X, libdist.hamming, d, None)
+    assert not km._feature_sweep_applies(X, libdist.hamming, d, None)     # (float samples)
+    assert km._feature_sweep_applies((X * 10).astype(np.int64), libdist.hamming, d, None)
     assert not km._feature_sweep_applies(X, lambda A, y: libdist.euclidean(A, y), d, None)
     assert not km._feature_sweep_applies(X.tolist(), libdist.euclidean, d, None)
     assert not km._feature_sweep_applies(X[0], libdist.euclidean, d, None)

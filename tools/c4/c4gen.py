@@ -5,6 +5,7 @@ the device version.  Measurement infrastructure (tools/), not product code.
     templates_int(T, A, seed)          int32 [T, A, 3], units of 1e-6 nm
     frames(tmpl, seed, indices)        float32 [len(indices), A, 3]  (host, numpy)
     DeviceGenerator(tmpl).fill(ptr, first, count, seed, stream)      (device)
+    Hip()                              hipMalloc / hipMemcpy through ctypes
 """
 import ctypes as C
 import os
@@ -83,20 +84,65 @@ def build(force=False):
     return SO
 
 
-class DeviceGenerator:
-    """templates on the device (a torch tensor: plumbing), frames written into
-    device memory the caller names by address"""
+class Hip:
+    """the few runtime calls this tool needs, through ctypes (so that it can run
+    with or without torch in the process: EK_C4_NO_TORCH=1)"""
 
-    def __init__(self, tmpl, device=0):
-        import torch
+    def __init__(self):
+        # (by soname: the copy the process has loaded already -- torch's, or the
+        # system's -- not a second runtime beside it)
+        self.L = C.CDLL("libamdhip64.so.7")
+        self.L.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        self.L.hipFree.argtypes = [C.c_void_p]
+        self.L.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.L.hipMemGetInfo.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+
+    def check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed (hipError %d)" % (what, rc))
+
+    def malloc(self, nbytes):
+        p = C.c_void_p()
+        self.check(self.L.hipMalloc(C.byref(p), nbytes), "hipMalloc(%d)" % nbytes)
+        return p.value
+
+    def free(self, ptr):
+        self.L.hipFree(C.c_void_p(ptr))
+
+    def to_device(self, ptr, arr):
+        arr = np.ascontiguousarray(arr)
+        self.check(self.L.hipMemcpy(C.c_void_p(ptr), arr.ctypes.data_as(C.c_void_p),
+                                    arr.nbytes, 1), "hipMemcpy H2D")
+
+    def to_host(self, arr, ptr):
+        self.check(self.L.hipMemcpy(arr.ctypes.data_as(C.c_void_p), C.c_void_p(ptr),
+                                    arr.nbytes, 2), "hipMemcpy D2H")
+
+    def sync(self):
+        self.check(self.L.hipDeviceSynchronize(), "hipDeviceSynchronize")
+
+    def mem_info(self):
+        f, t = C.c_size_t(), C.c_size_t()
+        self.check(self.L.hipMemGetInfo(C.byref(f), C.byref(t)), "hipMemGetInfo")
+        return f.value, t.value
+
+
+class DeviceGenerator:
+    """templates on the device, frames written into device memory the caller
+    names by address"""
+
+    def __init__(self, tmpl, hip=None):
+        self.hip = hip or Hip()
         self.L = C.CDLL(build())
         self.L.c4gen_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
                                         C.c_int64, C.c_int64, C.c_uint64, C.c_void_p]
         self.T, self.A = int(tmpl.shape[0]), int(tmpl.shape[1])
-        self.tmpl = torch.from_numpy(np.ascontiguousarray(tmpl)).to("cuda:%d" % device)
+        t = np.ascontiguousarray(tmpl, dtype=np.int32)
+        self.tmpl = self.hip.malloc(t.nbytes)
+        self.hip.to_device(self.tmpl, t)
 
     def fill(self, out_ptr, first, count, seed, stream=None):
-        rc = self.L.c4gen_frames(C.c_void_p(int(out_ptr)), C.c_void_p(self.tmpl.data_ptr()),
+        rc = self.L.c4gen_frames(C.c_void_p(int(out_ptr)), C.c_void_p(self.tmpl),
                                  self.T, self.A, int(first), int(count), int(seed),
                                  C.c_void_p(stream) if stream else None)
         if rc != 0:

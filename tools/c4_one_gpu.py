@@ -61,9 +61,16 @@ def main():
     p.add_argument("--candidates", type=int, default=-1)
     p.add_argument("--seed", type=int, default=2)
     p.add_argument("--out", default=None)
+    p.add_argument("--pick-cap", type=int, default=0)
+    p.add_argument("--small-shards", type=int, default=-1)
+    p.add_argument("--no-oracle", action="store_true",
+                   help="the run and its size-independent properties only (debugging)")
     a = p.parse_args()
 
-    import torch
+    # (ENSPARA_NO_TORCH=1: no torch in the process -- the library then binds to the
+    # system's HIP runtime instead of the one torch bundles)
+    if os.environ.get("ENSPARA_NO_TORCH") != "1":
+        import torch  # noqa: F401
     import c4gen
     from enspara_amd.device import FrameStore
     from oracle import qcp
@@ -72,8 +79,10 @@ def main():
     if n_per % 256:
         raise SystemExit("--frames-per-shard must be a multiple of 256 (tile-aligned shards)")
     C1 = min(a.check_centers, K)
-    torch.cuda.set_device(0)
-    free0, total = torch.cuda.mem_get_info()
+    from enspara_amd import _lib
+    _lib.load()
+    hip = c4gen.Hip()
+    free0, total = hip.mem_info()
     raw_bytes = n_per * A * 12
     per_shard = 3 * raw_bytes + n_per * 200
     while S > 1 and S * per_shard + raw_bytes > 0.94 * free0:
@@ -91,34 +100,37 @@ def main():
     # ---- the frames: generated on the device, shard by shard --------------------
     t0 = time.perf_counter()
     tmpl = c4gen.templates_int(a.templates, A, a.seed)
-    gen = c4gen.DeviceGenerator(tmpl)
-    raw = torch.empty(n_per * A * 3, dtype=torch.float32, device="cuda")
+    gen = c4gen.DeviceGenerator(tmpl, hip)
+    raw = hip.malloc(n_per * A * 12)
     stores = []
     t_gen = t_load = 0.0
     for r in range(S):
         lo = r * n_per
         st = FrameStore(n_per, A, device=0, global_offset=lo)
         t1 = time.perf_counter()
-        gen.fill(raw.data_ptr(), lo, n_per, a.seed)
-        torch.cuda.synchronize()
+        gen.fill(raw, lo, n_per, a.seed)
+        hip.sync()
         t_gen += time.perf_counter() - t1
         t1 = time.perf_counter()
-        st.load_device(raw.data_ptr(), n_per)
+        st.load_device(raw, n_per)
         st.sync()
         t_load += time.perf_counter() - t1
         st.set_option("candidates", a.candidates)
-        st.set_option("small_shards", 1 if n_per < 300000 else 0)
+        st.set_option("small_shards", (1 if n_per < 300000 else 0)
+                      if a.small_shards < 0 else a.small_shards)
+        st.set_option("pick_cap", a.pick_cap)
         stores.append(st)
     for r, st in enumerate(stores):
         if a.candidates == -1 or a.candidates >= 16:
             if not st.quad_copy_ready():
                 raise SystemExit("shard %d: no room for the quad copy" % r)
         st.ms_setup(S, r)
+        st.reserve_centers(K)       # (no allocation -- no device-wide wait -- inside ms_run)
     boxes = [st.ms_mailbox() for st in stores]
     for st in stores:
         for q in range(S):
             st.ms_connect(q, boxes[q][0], boxes[q][1])
-    free1, _ = torch.cuda.mem_get_info()
+    free1, _ = hip.mem_info()
     report.update({"setup_s": time.perf_counter() - t0, "device_generation_s": t_gen,
                    "layout_s": t_load, "hbm_in_use_GB": (total - free1) / 1e9})
     print("setup %.1f s (generation %.2f, layouts %.2f); HBM in use %.1f GB"
@@ -142,7 +154,16 @@ def main():
             t.join()
         dt = time.perf_counter() - t1
         if any(err):
-            raise SystemExit("ek_ms_run failed: %s" % err)
+            for r_, st_ in enumerate(stores):      # what every shard knows of the run
+                try:
+                    print("shard %d: %s | state (mode, exchanges, err) %s | rounds %s | "
+                          "centers in its history %d | diag %s"
+                          % (r_, err[r_], st_.ms_state(),
+                             {k: v for k, v in st_.run_stats().items() if v[0]},
+                             st_.history(0, 1)[2], st_.ms_diag()), flush=True)
+                except Exception as e:      # noqa: BLE001
+                    print("shard %d: %s (%s)" % (r_, err[r_], e), flush=True)
+            raise SystemExit("ek_ms_run failed")
         for o in out[1:]:
             if not (np.array_equal(o[0], out[0][0]) and np.array_equal(o[1], out[0][1])):
                 raise SystemExit("the shards disagree on the centers")
@@ -202,6 +223,10 @@ def main():
     report["properties"] = props
     print("properties:", props, flush=True)
 
+    if a.no_oracle:
+        report["ok"] = bool(all(v for v in props.values()))
+        print(json.dumps(report))
+        return 0 if report["ok"] else 1
     # ---- the oracle, shard by shard ----------------------------------------------
     qcp.set_num_threads(threads())
     t0 = time.perf_counter()
@@ -215,9 +240,10 @@ def main():
     rng = np.random.RandomState(11)
     for r in range(S):
         lo = r * n_per
-        gen.fill(raw.data_ptr(), lo, n_per, a.seed)
-        torch.cuda.synchronize()
-        x = raw.cpu().numpy().reshape(n_per, A, 3)
+        gen.fill(raw, lo, n_per, a.seed)
+        hip.sync()
+        x = np.empty((n_per, A, 3), dtype=np.float32)
+        hip.to_host(x, raw)
         pick = np.sort(rng.choice(n_per, size=min(a.sample, n_per), replace=False))
         chk["generator_sample_equals_numpy"] &= bool(np.array_equal(
             x[pick[:256]], c4gen.frames(tmpl, a.seed, lo + pick[:256])))

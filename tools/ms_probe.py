@@ -47,6 +47,7 @@ for r in range(S):
     st.set_option(4, T)
     st.set_option(18, 1 if cnt < 300000 else 0)     # (what sharded.kcenters_sharded sets)
     st.ms_setup(S, r)
+    st.reserve_centers(K)
     stores.append(st)
 boxes = [st.ms_mailbox() for st in stores]
 for st in stores:
