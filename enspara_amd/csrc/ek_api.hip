@@ -524,6 +524,11 @@ extern "C" int ek_set_option(ek_ctx *c, int32_t key, int32_t value)
             return ek_fail(EK_EARG, "ek_set_option: maxima per 64 frames for the pick 0 or 1");
         c->fine_pick = value;
         return EK_OK;
+    case EK_OPT_PASS_SWEEP:
+        if (value != 0 && value != 1)
+            return ek_fail(EK_EARG, "ek_set_option: per-prefix maxima in the pass 0 or 1");
+        c->pass_sweep = value;
+        return EK_OK;
     case EK_OPT_ASSIGN_KERNEL:
         if (value < 0 || value > 3)
             return ek_fail(EK_EARG, "ek_set_option: assign variant 0..3");
@@ -553,6 +558,7 @@ extern "C" int ek_get_option(ek_ctx *c, int32_t key, int32_t *value)
     case EK_OPT_PAM_MAX_PAIRS: *value = c->sp_max_pairs; return EK_OK;
     case EK_OPT_PAM_BOTH_SUMS: *value = c->sp_exact; return EK_OK;
     case EK_OPT_FINE_PICK: *value = c->fine_pick; return EK_OK;
+    case EK_OPT_PASS_SWEEP: *value = c->pass_sweep; return EK_OK;
     case EK_OPT_PAM_BOUNDS: *value = c->pam_bounds; return EK_OK;
     case EK_OPT_PICK_CAP: *value = c->pick_cap; return EK_OK;
     case EK_OPT_SMALL_SHARDS: *value = c->ms_small; return EK_OK;
@@ -1107,6 +1113,7 @@ static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
     R.blockmax = c->blockmax;
     R.pm = c->pm;
     R.fm = c->fine_pick ? c->fm : nullptr;
+    R.sweep = (c->pass_sweep && fused) ? 1 : 0;
     R.top = c->top;
     R.ctile = c->ctile;
     R.ctrace = c->ctrace;

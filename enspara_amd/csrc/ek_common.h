@@ -129,6 +129,14 @@ struct EkFuse {
     uint32_t *vmask = nullptr;      // per 64 frames: bit c = vector c - 1 stored
     const uint32_t *tmask = nullptr;    // triangle inequality (ek_round_ti_*): per tile,
                                     //   bit c = candidate c can still change a frame of it
+    // round 6: the per-prefix maxima of the round's chain taken by the pass itself
+    // (ek_pass16_kernel<true, 0>): the presumed order is then the order of the
+    // candidates (the greedy choice's own), known before the pass; sweep_pm[(k - 1) * nb
+    // + tile] = first-index arg-max of the tile in the state candidates 0 .. k leave,
+    // sweep_fm (may be null): per 64 frames, the state all of them leave
+    EkBlockMax *sweep_pm = nullptr;
+    EkBlockMax *sweep_fm = nullptr;
+    int sweep_nb = 0;
 };
 // everything a fused round works on besides the frames
 struct EkRound {
@@ -163,6 +171,7 @@ struct EkRound {
     uint32_t *tmask = nullptr;  // [tiles] candidates that can still change the tile
     unsigned long long *ti_stats = nullptr; // [0] (tile, candidate) pairs looked at, [1] left out
     int pick_cap = 4;           // far frames kept per label by the candidate pick (ek_top_dev.h)
+    int sweep = 0;              // the pass takes the per-prefix maxima itself (EkFuse::sweep_pm)
 };
 // the masks of the round the plan describes (after ek_launch_round_next)
 void ek_launch_round_ti(const EkRound &r, int max_labels, hipStream_t s);

@@ -610,6 +610,8 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
 #pragma unroll
     for (int c = 0; c < T; ++c)
         dcs[c] = s_D[wave][c * EK_P16_DSTRIDE + lane];
+    float run0 = -__builtin_inff();     // (sweep) the frame's distance after candidate 0
+    uint32_t vm_out = 0u;               // (sweep) the wave's mask of vectors with a finite value
     if (f < n) {
         // candidate 0: the new center of this iteration (kcenters.py:298-306)
         float cur = cur0;
@@ -655,8 +657,44 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
         }
         if (FUSE && (f & (EK_WAVE - 1)) == 0)
             fz.vmask[f >> 6] = wmask;
+        run0 = cur;
+        vm_out = wmask;
     }
     ek_wave_argmax(bestv, besti);
+    // ---- round 6: the states the prefixes of the round's chain would leave ------------
+    // With the presumed order = the order of the candidates (what the greedy choice of
+    // the plan took them in), state k = min(cur, d_1 .. d_k) is at hand here, in
+    // registers: its first-index arg-max per wave costs one wave arg-max per candidate
+    // for which SOME frame of the wave holds a finite kept distance (a handful) -- the
+    // chain kernel's sweep over dist and fifteen vectors, and its ticket, go away.
+    __shared__ float s_pv[EK_BLOCK / EK_WAVE][T];
+    __shared__ uint32_t s_pi[EK_BLOCK / EK_WAVE][T];
+    const bool sweep = FUSE && MODE == 0 && fz.sweep_pm != nullptr;
+    if (sweep) {
+        const uint32_t fin = __builtin_amdgcn_readfirstlane(vm_out);
+        float run = run0, sv = bestv;
+        uint32_t si = besti;
+        if (lane == 0) {
+            s_pv[wave][0] = sv;
+            s_pi[wave][0] = si;
+        }
+#pragma unroll
+        for (int c = 1; c < T; ++c) {
+            if (c < teff) {                     // uniform
+                if ((fin >> c) & 1u) {          // uniform
+                    if (dcs[c] < run)           // kcenters.py:304
+                        run = dcs[c];
+                    sv = f < n ? run : -__builtin_inff();
+                    si = f < n ? (uint32_t)f : 0xffffffffu;
+                    ek_wave_argmax(sv, si);
+                }
+                if (lane == 0) {
+                    s_pv[wave][c] = sv;
+                    s_pi[wave][c] = si;
+                }
+            }
+        }
+    }
 #ifdef EK_P16_STATS
     EK_P16_STAMP(5);
     if (FUSE && lane == 0)
@@ -736,6 +774,26 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
             }
         blockmax[blockIdx.x].val = v;
         blockmax[blockIdx.x].idx = i;
+    }
+    if (sweep && lane >= 1 && lane < teff) {
+        // state `lane` of this tile: the four waves' entries (read by the next launch)
+        float v = s_pv[0][lane];
+        uint32_t i = s_pi[0][lane];
+#pragma unroll
+        for (int w = 1; w < EK_BLOCK / EK_WAVE; ++w)
+            if (ek_better(s_pv[w][lane], s_pi[w][lane], v, i)) {
+                v = s_pv[w][lane];
+                i = s_pi[w][lane];
+            }
+        EkBlockMax *o = fz.sweep_pm + (size_t)(lane - 1) * fz.sweep_nb + blockIdx.x;
+        o->val = v;
+        o->idx = i;
+    }
+    if (sweep && fz.sweep_fm && lane < EK_BLOCK / EK_WAVE) {
+        // per 64 frames, the state the whole chain leaves (the next pick's input)
+        EkBlockMax *o = fz.sweep_fm + 4 * (size_t)blockIdx.x + lane;
+        o->val = s_pv[lane][teff - 1];
+        o->idx = s_pi[lane][teff - 1];
     }
     // the workgroup that drew the last ticket (at its start: every owner had
     // finished by then) works out the presumed order

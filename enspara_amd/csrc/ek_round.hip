@@ -70,11 +70,14 @@ ek_round_chain_kernel(EkRound r, int bootstrap)
     unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     EK_STAMP(0);
+    // (round 6) the pass took the per-prefix maxima itself: one workgroup, no sweep,
+    // no ticket; candidate 0's entry in the history is made here
+    const bool swept = r.sweep && NV == 16 && r.T == 16;
     if (!bootstrap) {
         if (!r.plan->go)
             return;             // the run is over: nothing changes any more
         const int cn = r.ord->n;
-        if (cn > 0) {
+        if (cn > 0 && !swept) {
             const int64_t f0 = ((int64_t)blockIdx.x * EK_ROUND_THREADS + tid) *
                                EK_ROUND_FPT;
             const bool whole = f0 + EK_ROUND_FPT <= r.n;
@@ -151,7 +154,7 @@ ek_round_chain_kernel(EkRound r, int bootstrap)
             }
         }
         EK_STAMP(1);
-        if (!ek_arrive_last(r.tick + 1))
+        if (!swept && !ek_arrive_last(r.tick + 1))
             return;
         EK_STAMP(2);
         // ---- decide (ek_chain.hip steps 2-3) ------------------------------------
@@ -169,6 +172,16 @@ ek_round_chain_kernel(EkRound r, int bootstrap)
             // ek_chain_walk on a register copy of the control words: one read,
             // one write-back, no dependent global reads in between
             EkCtl c = *r.ctl;
+            if (swept) {
+                // candidate 0 is a center now (kcenters.py:306-309): what the pass's
+                // last workgroup wrote when it worked the order out
+                const int lb = r.plan->label;
+                r.hist[lb].gidx = r.plan->gidx[0];
+                r.hist[lb].dist = r.plan->maxdist[0];
+                r.hist[lb].set = 1;
+                c.n_done = lb + 1;
+                r.ctl->n_rounds = c.n_rounds + 1;
+            }
             const int label0 = c.n_done;
             uint32_t used = r.plan->used;
             int na = 0;
@@ -278,7 +291,8 @@ void ek_launch_round_chain(const EkRound &r, int bootstrap, hipStream_t s)
     if (r.n <= 0)
         return;
     const int64_t per = (int64_t)EK_ROUND_THREADS * 4;
-    const unsigned blocks = bootstrap ? 1u : (unsigned)((r.n + per - 1) / per);
+    const unsigned blocks = (bootstrap || (r.sweep && r.T == 16))
+                                ? 1u : (unsigned)((r.n + per - 1) / per);
     const int nb = (int)((r.n + EK_BLOCK - 1) / EK_BLOCK);
     const size_t lds = (size_t)((nb + 31) / 32 + 1) * sizeof(uint32_t);
     if (r.T > 16)
@@ -527,6 +541,14 @@ ek_round_next_kernel(EkRound r, int bootstrap)
             // its distances are in)
             plan->go = 1;
             plan->teff = ns;
+            if (r.sweep && T == 16) {
+                // the presumed order of the round's chain = the order the greedy
+                // choice above took the candidates in (round 6: known before the
+                // pass, which takes the per-prefix maxima along it)
+                r.ord->n = ns - 1;
+                for (int k = 0; k + 1 < ns; ++k)
+                    r.ord->cand[k] = k + 1;
+            }
             plan->label = r.ctl->n_done;
             plan->used = 1;
             plan->miss = 0;

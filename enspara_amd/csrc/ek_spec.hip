@@ -685,8 +685,18 @@ void ek_launch_round_pass(const EkRound &r, hipStream_t s, bool with_order)
         return;
     const unsigned blocks = (unsigned)((r.n + EK_BLOCK - 1) / EK_BLOCK);
     EkFuse fz;
+    // (round 6: a round of 16 takes its per-prefix maxima in the pass; the presumed
+    // order is then the candidates' own -- ek_round_next_kernel / ek_ms_plan_kernel
+    // write it -- and no workgroup works one out at the end of the pass)
+    const bool sweep = r.sweep && r.T == 16;
     fz.pend = r.pend;
-    fz.ord = with_order ? r.ord : nullptr;
+    fz.ord = (with_order && !sweep) ? r.ord : nullptr;
+    if (sweep) {
+        fz.sweep_pm = r.pm;
+        fz.sweep_nb = (int)blocks;
+        // (the maxima per 64 frames: where the pick reads them, ek_round_chain_kernel)
+        fz.sweep_fm = (r.fm && 4 * (int64_t)blocks <= 8 * 1024) ? r.fm : nullptr;
+    }
     fz.tick = r.tick + 0;
     fz.goff = r.goff;
     fz.hist = r.hist;

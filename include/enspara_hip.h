@@ -706,7 +706,14 @@ enum ek_option {
     /* the distance kernels of a PAM window (tables, listed frames) on the
      * matrix cores, 16 rows x 16 columns per wave (1, default) or LDS-staged
      * 64 x 8 per workgroup (0); process-wide.  MEASUREMENT */
-    EK_OPT_PAM_PAIRS_MFMA = 21
+    EK_OPT_PAM_PAIRS_MFMA = 21,
+    /* rounds of 16 candidates of ek_kcenters_run: the states every prefix of the
+     * round's chain would leave are reduced to their per-tile arg-max by the pass
+     * itself, from registers (1, default: the chain kernel is then one workgroup
+     * that decides and picks, and the presumed order is the order the plan's
+     * greedy choice took the candidates in) or by a sweep over the kept distance
+     * vectors in the chain kernel (0: rounds 3-5).  MEASUREMENT */
+    EK_OPT_PASS_SWEEP = 22
 };
 int ek_set_option(ek_ctx *ctx, int32_t key, int32_t value);
 /* the value an option holds (what ek_set_option stored, or its default) */

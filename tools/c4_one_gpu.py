@@ -7,7 +7,7 @@ csrc/ek_mshard.hip, the GPUs' streams time-sharing one chip instead of running
 side by side.  Reference: enspara/cluster/kcenters.py:314-378 (the MPI
 iteration) at the shape the reference names for it.
 
-  python3 tools/c4_one_gpu.py [--shards 8] [--frames-per-shard 1250000]
+  python3 tools/c4_one_gpu.py [--shards 8] [--frames 10000000]
         [--atoms 500] [--centers 20000] [--templates 20000]
         [--check-centers 200] [--sample 2000] [--out summary.json]
 
@@ -52,7 +52,11 @@ def threads():
 def main():
     p = argparse.ArgumentParser()
     p.add_argument("--shards", type=int, default=8)
-    p.add_argument("--frames-per-shard", type=int, default=1_250_000)
+    p.add_argument("--frames", type=int, default=10_000_000,
+                   help="frames in all: split into tile-aligned contiguous shards "
+                        "(sharded.shard_bounds, as the ranks of a job split them)")
+    p.add_argument("--frames-per-shard", type=int, default=0,
+                   help="instead of --frames: this many frames per shard")
     p.add_argument("--atoms", type=int, default=500)
     p.add_argument("--centers", type=int, default=20_000)
     p.add_argument("--templates", type=int, default=20_000)
@@ -75,9 +79,10 @@ def main():
     from enspara_amd.device import FrameStore
     from oracle import qcp
 
-    S, n_per, A, K = a.shards, a.frames_per_shard, a.atoms, a.centers
-    if n_per % 256:
-        raise SystemExit("--frames-per-shard must be a multiple of 256 (tile-aligned shards)")
+    from enspara_amd import sharded
+    S, A, K = a.shards, a.atoms, a.centers
+    n_all = a.frames_per_shard * S if a.frames_per_shard else a.frames
+    n_per = sharded.shard_bounds(n_all, S, 0)[1]        # (the largest shard)
     C1 = min(a.check_centers, K)
     from enspara_amd import _lib
     _lib.load()
@@ -86,11 +91,13 @@ def main():
     raw_bytes = n_per * A * 12
     per_shard = 3 * raw_bytes + n_per * 200
     while S > 1 and S * per_shard + raw_bytes > 0.94 * free0:
-        S //= 2
-    n = S * n_per
+        S //= 2         # (the same shards, fewer of them: a part of the data set)
+    bounds = [sharded.shard_bounds(n_all, a.shards, r) for r in range(S)]
+    n = sum(cnt for _, cnt in bounds)
     report = {"what": "BASELINE.json configs[3] on one MI355X: %d shards x %d frames x %d "
                       "atoms as contexts of one process, %d centers through ek_ms_run "
                       "(peer mailboxes, the %d-rank message layout)" % (S, n_per, A, K, S),
+              "shard_frames": [cnt for _, cnt in bounds],
               "shards": S, "shards_asked": a.shards, "frames": n, "atoms": A, "centers": K,
               "templates": a.templates, "seed": a.seed,
               "hbm_free_before_GB": free0 / 1e9, "hbm_total_GB": total / 1e9}
@@ -105,14 +112,14 @@ def main():
     stores = []
     t_gen = t_load = 0.0
     for r in range(S):
-        lo = r * n_per
-        st = FrameStore(n_per, A, device=0, global_offset=lo)
+        lo, cnt = bounds[r]
+        st = FrameStore(cnt, A, device=0, global_offset=lo)
         t1 = time.perf_counter()
-        gen.fill(raw, lo, n_per, a.seed)
+        gen.fill(raw, lo, cnt, a.seed)
         hip.sync()
         t_gen += time.perf_counter() - t1
         t1 = time.perf_counter()
-        st.load_device(raw, n_per)
+        st.load_device(raw, cnt)
         st.sync()
         t_load += time.perf_counter() - t1
         st.set_option("candidates", a.candidates)
@@ -214,7 +221,8 @@ def main():
     }
     own_ok = True
     for k, g in enumerate(centers):
-        r, i = int(g) // n_per, int(g) % n_per
+        r = max(q for q in range(S) if bounds[q][0] <= int(g))
+        i = int(g) - bounds[r][0]
         d, l = final[r]
         # (rmsd(x, x) cancels to ~1e-4 nm at worst, not to 0: DESIGN.md 2; the
         # reference's own check of its medoids is < 0.001, kmedoids.py:197)
@@ -239,21 +247,21 @@ def main():
            "sampled_frames": 0, "oracle_pairs": 0}
     rng = np.random.RandomState(11)
     for r in range(S):
-        lo = r * n_per
-        gen.fill(raw, lo, n_per, a.seed)
+        lo, cnt = bounds[r]
+        gen.fill(raw, lo, cnt, a.seed)
         hip.sync()
-        x = np.empty((n_per, A, 3), dtype=np.float32)
+        x = np.empty((cnt, A, 3), dtype=np.float32)
         hip.to_host(x, raw)
-        pick = np.sort(rng.choice(n_per, size=min(a.sample, n_per), replace=False))
+        pick = np.sort(rng.choice(cnt, size=min(a.sample, cnt), replace=False))
         chk["generator_sample_equals_numpy"] &= bool(np.array_equal(
             x[pick[:256]], c4gen.frames(tmpl, a.seed, lo + pick[:256])))
         P = qcp.Prepared(x)
-        dist = np.full(n_per, np.inf, dtype=np.float32)
-        assign = np.full(n_per, -1, dtype=np.int32)
+        dist = np.full(cnt, np.inf, dtype=np.float32)
+        assign = np.full(cnt, -1, dtype=np.int32)
         for k in range(C1):
             rec_v[r, k], am = P.kcenters_step(cc[k], cG[k], k, dist, assign)
             rec_i[r, k] = lo + am
-        chk["oracle_pairs"] += n_per * C1
+        chk["oracle_pairs"] += cnt * C1
         chk["phase1_labels_equal"] &= bool(np.array_equal(assign, state1[r][1]))
         chk["phase1_distances_equal"] &= bool(np.array_equal(dist, state1[r][0]))
         d, l = final[r]

@@ -6,7 +6,7 @@ For every library given (default: the in-tree build) a child process loads the
 same frames and times a k-centers run of K centers for each combination of
   form   (ignored: round 1's LDS form of the pass kernel is retired)
   adapt  0 = always the pinned / widest form, 1 = 1/8/16 by measured rate
-(LAB_CONFIGS="form,adapt,cands[,fused[,fine]];..." picks the combinations) printing seconds per run, the mean pass-kernel time (HIP events), the passes
+(LAB_CONFIGS="form,adapt,cands[,fused[,fine[,sweep]]];..." picks the combinations) printing seconds per run, the mean pass-kernel time (HIP events), the passes
 by candidates per pass, and a checksum of centers + final state (all
 combinations must agree: the forms are bit-identical by construction).
 Variants are built with enspara_amd.build.build(out=..., tag=..., extra_flags=[...]).
@@ -36,6 +36,8 @@ def child(path, K):
         form, adapt, cands = cfg[:3]
         fused = cfg[3] if len(cfg) > 3 else 1
         fine = cfg[4] if len(cfg) > 4 else 1
+        sweep = cfg[5] if len(cfg) > 5 else 1
+        st.set_option("pass_sweep", sweep)  # per-prefix maxima taken by the pass (round 6)
         st.set_option(15, fine)         # maxima per 64 frames for the pick
         st.set_option(10, fused)
         st.set_option(8, adapt)
@@ -57,9 +59,9 @@ def child(path, K):
         h = hashlib.sha256(idx.tobytes() + d.tobytes() + a.tobytes()).hexdigest()[:12]
         sums.add(h)
         stats = st.run_stats() if cands != 1 else {}
-        print("%-28s form %d adapt %d cands %2d fused %d fine %d: %.4f s  %.4f ms/center  pass %.4f ms "
+        print("%-28s form %d adapt %d cands %2d fused %d fine %d sweep %d: %.4f s  %.4f ms/center  pass %.4f ms "
               "(%d samples)  %s  sum %s%s"
-              % (name, form, adapt, cands, fused, fine, best[0], best[0] / K * 1e3, best[1], best[2],
+              % (name, form, adapt, cands, fused, fine, sweep, best[0], best[0] / K * 1e3, best[1], best[2],
                  {T: pc for T, pc in stats.items() if pc[0]}, h,
                  "  runs (s/pass ms): " + " ".join(every) if len(every) > 2 else ""),
               flush=True)
