@@ -268,7 +268,9 @@ ek_ms_chain_kernel(EkRound r, EkMsState *ms, EkMsXchg x, int nblk)
     // (maxima per 64 frames for the offers: on shards up to ~half a million frames,
     // see ek_round_chain_kernel)
     const bool fine_ok = r.fm != nullptr && 4 * nb <= 8 * EK_RED_THREADS;
-    if (cn > 0) {
+    // (round 6: a pass of 16 candidates took these maxima itself, EkFuse::sweep_pm)
+    const bool swept = r.sweep && r.T == 16;
+    if (cn > 0 && !swept) {
         // pm[(k - 1) * nb + w] = first-index arg-max over frames [256 w, 256 w + 256)
         // of min(dist, vec[order[0]], .., vec[order[k-1]]), k = 1 .. cn (state 0
         // is what the pass left in blockmax): as ek_round_chain_kernel, sixteen
@@ -339,7 +341,7 @@ ek_ms_chain_kernel(EkRound r, EkMsState *ms, EkMsXchg x, int nblk)
             }
         }
     }
-    if (!ek_arrive_last(r.tick + 1, (unsigned int)nblk))
+    if (nblk > 1 && !ek_arrive_last(r.tick + 1, (unsigned int)nblk))
         return;
     // ---- the last workgroup ---------------------------------------------------------
     // this shard's maximum of states 0 .. cn - 1 (what the decision looks at)
@@ -401,7 +403,9 @@ void ek_launch_ms_chain(const EkRound &r, EkMsState *ms, const EkMsXchg &x,
                         hipStream_t s)
 {
     const int64_t per = (int64_t)EK_MS_THREADS * EK_MS_FPT;
-    const unsigned blocks = (unsigned)std::max<int64_t>(1, (r.n + per - 1) / per);
+    // (nothing to sweep where the pass took the maxima: one workgroup + the helpers)
+    const unsigned blocks = (r.sweep && r.T == 16)
+                                ? 1u : (unsigned)std::max<int64_t>(1, (r.n + per - 1) / per);
     const int nb = (int)((r.n + EK_BLOCK - 1) / EK_BLOCK);
     const size_t lds = (size_t)((nb + 31) / 32 + 1) * sizeof(uint32_t);
     hipLaunchKernelGGL(ek_ms_chain_kernel, dim3(blocks + EK_MS_HELPERS),

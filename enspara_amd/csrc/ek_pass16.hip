@@ -667,27 +667,33 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
     // registers: its first-index arg-max per wave costs one wave arg-max per candidate
     // for which SOME frame of the wave holds a finite kept distance (a handful) -- the
     // chain kernel's sweep over dist and fifteen vectors, and its ticket, go away.
+    // Only the states that DIFFER from the one before are written (a wave's word of
+    // finite kept vectors says which: bit c = some frame of the wave holds a kept
+    // distance to candidate c below its own); the workgroup's last wave reads, for
+    // state k, every wave's last entry at or below k.  In the epilogue an instruction
+    // costs 13-20 cycles beside the other wave's matrix loop: fifteen unconditional
+    // table writes were 2 % of the pass.
     __shared__ float s_pv[EK_BLOCK / EK_WAVE][T];
     __shared__ uint32_t s_pi[EK_BLOCK / EK_WAVE][T];
+    __shared__ uint32_t s_fin[EK_BLOCK / EK_WAVE];
     const bool sweep = FUSE && MODE == 0 && fz.sweep_pm != nullptr;
     if (sweep) {
-        const uint32_t fin = __builtin_amdgcn_readfirstlane(vm_out);
-        float run = run0, sv = bestv;
-        uint32_t si = besti;
+        // (bit 0: state 0 is always there; bits at or above teff never are)
+        const uint32_t fin = (__builtin_amdgcn_readfirstlane(vm_out) & ~1u) | 1u;
         if (lane == 0) {
-            s_pv[wave][0] = sv;
-            s_pi[wave][0] = si;
+            s_pv[wave][0] = bestv;
+            s_pi[wave][0] = besti;
+            s_fin[wave] = fin;
         }
+        float run = run0;
 #pragma unroll
         for (int c = 1; c < T; ++c) {
-            if (c < teff) {                     // uniform
-                if ((fin >> c) & 1u) {          // uniform
-                    if (dcs[c] < run)           // kcenters.py:304
-                        run = dcs[c];
-                    sv = f < n ? run : -__builtin_inff();
-                    si = f < n ? (uint32_t)f : 0xffffffffu;
-                    ek_wave_argmax(sv, si);
-                }
+            if ((fin >> c) & 1u) {              // uniform (and c < teff: a kept vector)
+                if (dcs[c] < run)               // kcenters.py:304
+                    run = dcs[c];
+                float sv = f < n ? run : -__builtin_inff();
+                uint32_t si = f < n ? (uint32_t)f : 0xffffffffu;
+                ek_wave_argmax(sv, si);
                 if (lane == 0) {
                     s_pv[wave][c] = sv;
                     s_pi[wave][c] = si;
@@ -775,25 +781,32 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
         blockmax[blockIdx.x].val = v;
         blockmax[blockIdx.x].idx = i;
     }
-    if (sweep && lane >= 1 && lane < teff) {
-        // state `lane` of this tile: the four waves' entries (read by the next launch)
-        float v = s_pv[0][lane];
-        uint32_t i = s_pi[0][lane];
+    if (sweep && lane < teff) {
+        // state `lane` of this tile from the four waves' entries (read by the next
+        // launch); lanes 0 .. 3 also: wave `lane`'s state after ALL candidates, the
+        // maxima per 64 frames the next pick reads
+        float v = -__builtin_inff();
+        uint32_t i = 0xffffffffu;
 #pragma unroll
-        for (int w = 1; w < EK_BLOCK / EK_WAVE; ++w)
-            if (ek_better(s_pv[w][lane], s_pi[w][lane], v, i)) {
-                v = s_pv[w][lane];
-                i = s_pi[w][lane];
+        for (int w = 0; w < EK_BLOCK / EK_WAVE; ++w) {
+            const uint32_t m = s_fin[w] & ((2u << lane) - 1u);
+            const int e = 31 - __builtin_clz(m);        // (bit 0 is always set)
+            if (ek_better(s_pv[w][e], s_pi[w][e], v, i)) {
+                v = s_pv[w][e];
+                i = s_pi[w][e];
             }
-        EkBlockMax *o = fz.sweep_pm + (size_t)(lane - 1) * fz.sweep_nb + blockIdx.x;
-        o->val = v;
-        o->idx = i;
-    }
-    if (sweep && fz.sweep_fm && lane < EK_BLOCK / EK_WAVE) {
-        // per 64 frames, the state the whole chain leaves (the next pick's input)
-        EkBlockMax *o = fz.sweep_fm + 4 * (size_t)blockIdx.x + lane;
-        o->val = s_pv[lane][teff - 1];
-        o->idx = s_pi[lane][teff - 1];
+        }
+        if (lane >= 1) {
+            EkBlockMax *o = fz.sweep_pm + (size_t)(lane - 1) * fz.sweep_nb + blockIdx.x;
+            o->val = v;
+            o->idx = i;
+        }
+        if (fz.sweep_fm && lane < EK_BLOCK / EK_WAVE) {
+            const int e = 31 - __builtin_clz(s_fin[lane]);
+            EkBlockMax *o = fz.sweep_fm + 4 * (size_t)blockIdx.x + lane;
+            o->val = s_pv[lane][e];
+            o->idx = s_pi[lane][e];
+        }
     }
     // the workgroup that drew the last ticket (at its start: every owner had
     // finished by then) works out the presumed order

@@ -45,6 +45,7 @@ for r in range(S):
     st = FrameStore(cnt, A, device=0, global_offset=lo)
     st.load(x[lo:lo + cnt])
     st.set_option(4, T)
+    st.set_option("pass_sweep", int(os.environ.get("MS_SWEEP", "1")))
     st.set_option(18, 1 if cnt < 300000 else 0)     # (what sharded.kcenters_sharded sets)
     st.ms_setup(S, r)
     st.reserve_centers(K)
