@@ -525,8 +525,9 @@ extern "C" int ek_set_option(ek_ctx *c, int32_t key, int32_t value)
         c->fine_pick = value;
         return EK_OK;
     case EK_OPT_PASS_SWEEP:
-        if (value != 0 && value != 1)
-            return ek_fail(EK_EARG, "ek_set_option: per-prefix maxima in the pass 0 or 1");
+        if (value < 0 || value > 2)
+            return ek_fail(EK_EARG, "ek_set_option: per-prefix maxima in the pass 0, 1 "
+                                    "(by the shard's size) or 2 (always)");
         c->pass_sweep = value;
         return EK_OK;
     case EK_OPT_ASSIGN_KERNEL:
@@ -1113,7 +1114,11 @@ static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
     R.blockmax = c->blockmax;
     R.pm = c->pm;
     R.fm = c->fine_pick ? c->fm : nullptr;
-    R.sweep = (c->pass_sweep && fused) ? 1 : 0;
+    // (the per-prefix maxima in the pass: where they pay -- shards of up to ~half a
+    // million frames: 10 % of a fit at 125 000; at 10^6 the pass's extra instructions
+    // cost what the chain kernel's sweep did, profiles/r06/sweep_ab_*.log)
+    R.sweep = (fused && (c->pass_sweep == 2 ||
+                         (c->pass_sweep == 1 && c->n <= (int64_t)2048 * EK_TILE))) ? 1 : 0;
     R.top = c->top;
     R.ctile = c->ctile;
     R.ctrace = c->ctrace;

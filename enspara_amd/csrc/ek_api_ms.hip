@@ -260,7 +260,8 @@ static void ek_round_of(ek_ctx *c, int T, double cutoff, EkRound &R)
     R.blockmax = c->blockmax;
     R.pm = c->pm;
     R.fm = c->fine_pick ? c->fm : nullptr;
-    R.sweep = c->pass_sweep ? 1 : 0;
+    R.sweep = (c->pass_sweep == 2 ||
+               (c->pass_sweep == 1 && c->n <= (int64_t)2048 * EK_TILE)) ? 1 : 0;
     R.top = c->top;
     R.ctile = c->ctile;
     R.ctrace = c->ctrace;

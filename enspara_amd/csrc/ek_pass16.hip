@@ -783,8 +783,7 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
     }
     if (sweep && lane < teff) {
         // state `lane` of this tile from the four waves' entries (read by the next
-        // launch); lanes 0 .. 3 also: wave `lane`'s state after ALL candidates, the
-        // maxima per 64 frames the next pick reads
+        // launch)
         float v = -__builtin_inff();
         uint32_t i = 0xffffffffu;
 #pragma unroll
@@ -801,12 +800,13 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
             o->val = v;
             o->idx = i;
         }
-        if (fz.sweep_fm && lane < EK_BLOCK / EK_WAVE) {
-            const int e = 31 - __builtin_clz(s_fin[lane]);
-            EkBlockMax *o = fz.sweep_fm + 4 * (size_t)blockIdx.x + lane;
-            o->val = s_pv[lane][e];
-            o->idx = s_pi[lane][e];
-        }
+    }
+    if (sweep && fz.sweep_fm && lane < EK_BLOCK / EK_WAVE) {
+        // (whatever teff is: a round of one candidate has these four entries too)
+        const int e = 31 - __builtin_clz(s_fin[lane]);
+        EkBlockMax *o = fz.sweep_fm + 4 * (size_t)blockIdx.x + lane;
+        o->val = s_pv[lane][e];
+        o->idx = s_pi[lane][e];
     }
     // the workgroup that drew the last ticket (at its start: every owner had
     // finished by then) works out the presumed order

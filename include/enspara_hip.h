@@ -709,10 +709,12 @@ enum ek_option {
     EK_OPT_PAM_PAIRS_MFMA = 21,
     /* rounds of 16 candidates of ek_kcenters_run: the states every prefix of the
      * round's chain would leave are reduced to their per-tile arg-max by the pass
-     * itself, from registers (1, default: the chain kernel is then one workgroup
-     * that decides and picks, and the presumed order is the order the plan's
-     * greedy choice took the candidates in) or by a sweep over the kept distance
-     * vectors in the chain kernel (0: rounds 3-5).  MEASUREMENT */
+     * itself, from registers (the chain kernel is then one workgroup that decides
+     * and picks, and the presumed order is the order the plan's greedy choice took
+     * the candidates in) or by a sweep over the kept distance vectors in the chain
+     * kernel (rounds 3-5): 1 (default) the former on shards of up to 524 288 frames
+     * -- where it pays: 10 % of a fit at 125 000 frames, nothing at 10^6 --, 2
+     * always, 0 never.  MEASUREMENT */
     EK_OPT_PASS_SWEEP = 22
 };
 int ek_set_option(ek_ctx *ctx, int32_t key, int32_t value);

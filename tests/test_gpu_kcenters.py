@@ -395,3 +395,38 @@ def test_upload_paths_give_the_same_frames(ocl, monkeypatch):
         assert list(r.center_indices) == [int(i) for i in inds]
         np.testing.assert_array_equal(r.assignments, a)
         np.testing.assert_array_equal(r.distances, d)
+
+
+@pytest.mark.parametrize("sweep", [0, 2])
+@pytest.mark.parametrize("n,A,K", [(4000, 33, 120), (600, 5, 60), (260, 7, 200),
+                                   (70000, 21, 500)])
+def test_per_prefix_maxima_in_the_pass_or_in_the_chain_kernel(ocl, sweep, n, A, K):
+    """round 6: in a round of 16 the states every prefix of the round's chain would
+    leave are reduced to their per-tile arg-max by the pass itself (option
+    pass_sweep = 2; 1, the default, does so on shards of up to 524 288 frames) or by
+    the chain kernel's sweep over the kept vectors (0: rounds 3-5).  Same centers,
+    labels and distances -- also where a round has fewer than four candidates left
+    (few frames, many centers: the maxima per 64 frames are written whatever the
+    number of candidates), with the last tile partly and some waves wholly empty"""
+    from enspara_amd.cluster import kcenters as kc
+    x = synth.synth(n, A, 40, seed=n + A)
+    inds, a, d = ocl.kcenters(x, n_clusters=K)
+    for cands in (16, -1):
+        with _store(x) as st:
+            st.set_option("candidates", cands)
+            st.set_option("pass_sweep", sweep)
+            assert st.get_option("pass_sweep") == sweep
+            r = kc._kcenters_device(x, K, 0, None, 0, store=st)
+        assert list(r.center_indices) == [int(i) for i in inds]
+        np.testing.assert_array_equal(r.assignments, a)
+        np.testing.assert_array_equal(r.distances, d)
+    # the cut-off stop rule (kcenters.py:217) inside a round's chain
+    cut = float(d.max()) * 1.2
+    inds, a, d = ocl.kcenters(x, dist_cutoff=cut)
+    with _store(x) as st:
+        st.set_option("candidates", 16)
+        st.set_option("pass_sweep", sweep)
+        r = kc._kcenters_device(x, np.inf, cut, None, 0, store=st)
+    assert list(r.center_indices) == [int(i) for i in inds]
+    np.testing.assert_array_equal(r.assignments, a)
+    np.testing.assert_array_equal(r.distances, d)

@@ -287,6 +287,11 @@ def work(r):
     out[r] = stores[r].ms_run(0, K if K else n, cutoff)
 for rep in range(2):
     for st in stores:
+        # (round 6: the per-prefix maxima of a round of 16 taken by the pass, then by
+        # the chain kernel's sweep; a shard may choose for itself -- the messages are
+        # the same --, so the odd shards keep the default)
+        if st is stores[0] or len(stores) % 2 == 0:
+            st.set_option("pass_sweep", 2 if rep == 0 else 0)
         st.reset_state()
         st.sync()
     th = [threading.Thread(target=work, args=(r,)) for r in range(shards)]

@@ -36,7 +36,7 @@ def child(path, K):
         form, adapt, cands = cfg[:3]
         fused = cfg[3] if len(cfg) > 3 else 1
         fine = cfg[4] if len(cfg) > 4 else 1
-        sweep = cfg[5] if len(cfg) > 5 else 1
+        sweep = cfg[5] if len(cfg) > 5 else 1   # 0 never, 1 by size, 2 always
         st.set_option("pass_sweep", sweep)  # per-prefix maxima taken by the pass (round 6)
         st.set_option(15, fine)         # maxima per 64 frames for the pick
         st.set_option(10, fused)
