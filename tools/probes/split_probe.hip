@@ -9,9 +9,10 @@
 #include <cstdio>
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+template <int SELF>
 __global__ void __launch_bounds__(512, 1)
 split(float *out, unsigned long long *cyc, unsigned *ids, int tiles, int nm, int nv32,
-      int nv64, int nlds, int who)
+      int nv64, int nlds, int who, int prio = 0)
 {
     __shared__ float lds[8][64 * 16];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -29,16 +30,29 @@ split(float *out, unsigned long long *cyc, unsigned *ids, int tiles, int nm, int
             for (int q = 0; q < 36; ++q)
                 acc[q] = v4f{0.f, 0.f, 0.f, 0.f};
             float a = 1.f + lane, b = 2.f;
+            float g[8];
+            for (int k = 0; k < 8; ++k) g[k] = 1.f + lane + k;
             for (int t = 0; t < tiles; ++t)
                 for (int it = 0; it < nm / 36; ++it) {
 #pragma unroll
-                    for (int q = 0; q < 36; ++q)
+                    for (int q = 0; q < 36; ++q) {
                         acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[q], 0, 0, 0);
+                        // (SELF: the SAME wave issues that many independent f32 FMAs
+                        // behind every matrix instruction -- compile time, so that the
+                        // loop stays straight-line code)
+#pragma unroll
+                        for (int u = 0; u < SELF; ++u)
+                            g[(q + u) & 7] = __builtin_fmaf(g[(q + u) & 7], 1.0000001f, 0.5f);
+                    }
                 }
             for (int q = 0; q < 36; ++q)
                 res += acc[q][0] + acc[q][1] + acc[q][2] + acc[q][3];
+            for (int k = 0; k < 8; ++k) res += g[k];
         }
     } else if (who & 2) {
+        if (prio == 1) __builtin_amdgcn_s_setprio(1);
+        if (prio == 2) __builtin_amdgcn_s_setprio(2);
+        if (prio == 3) __builtin_amdgcn_s_setprio(3);
         float f[8];
         double d[4];
         for (int k = 0; k < 8; ++k) f[k] = 1.f + lane + k;
@@ -75,7 +89,7 @@ int main()
     hipMalloc(&d, wgs * 512 * 4);
     hipMalloc(&c, sizeof(h));
     hipMalloc(&ids, sizeof(hid));
-    split<<<wgs, 512>>>(d, c, ids, 1, 360, 80, 40, 8, 3);
+    split<0><<<wgs, 512>>>(d, c, ids, 1, 360, 80, 40, 8, 3);
     hipMemcpy(hid, ids, sizeof(hid), hipMemcpyDeviceToHost);
     printf("workgroup 0, HW_ID of waves 0..7 (SIMD = bits 5:4, slot = bits 3:0):");
     for (int w = 0; w < 8; ++w)
@@ -85,20 +99,32 @@ int main()
         for (int w = 0; w < 4; ++w)
             paired += ((hid[b * 8 + w] >> 4) & 3) == ((hid[b * 8 + w + 4] >> 4) & 3);
     printf("\nwaves w and w + 4 on the same SIMD: %d of %d\n", paired, wgs * 4);
-    struct { int nm, nv32, nv64, nlds, who; const char *what; } cfg[] = {
+    struct { int nm, nv32, nv64, nlds, who; const char *what; int prio; int self; } cfg[] = {
         {2700, 0, 0, 0, 1, "matrix wave alone"},
         {2700, 2400, 600, 150, 2, "vector wave alone (2400 f32 + 600 f64 + 150 LDS per tile)"},
         {2700, 2400, 600, 150, 3, "both"},
         {2700, 3000, 0, 150, 3, "both, vector work all f32"},
         {2700, 1200, 300, 150, 3, "both, half the vector work"},
         {2700, 4800, 1200, 300, 3, "both, twice the vector work"},
+        {2700, 2400, 600, 150, 3, "both, vector wave at s_setprio 1", 1},
+        {2700, 2400, 600, 150, 3, "both, vector wave at s_setprio 3", 3},
+        {2700, 3000, 0, 0, 3, "both, 3000 f32 only, s_setprio 3", 3},
+        {2700, 0, 750, 0, 3, "both, 750 f64 only, s_setprio 3", 3},
+        {2700, 0, 0, 300, 3, "both, 300 LDS reads only, s_setprio 3", 3},
+        {2700, 4800, 1200, 300, 3, "both, twice the vector work, s_setprio 3", 3},
+        {2700, 0, 0, 0, 1, "matrix wave alone, 1 f32 FMA of its own behind every MFMA", 0, 1},
+        {2700, 0, 0, 0, 1, "matrix wave alone, 2 f32 FMAs of its own behind every MFMA", 0, 2},
+        {2700, 0, 0, 0, 1, "matrix wave alone, 4 f32 FMAs of its own behind every MFMA", 0, 4},
+        {2700, 2400, 600, 150, 3, "both, matrix wave with 1 FMA of its own per MFMA", 3, 1},
     };
     for (auto &g : cfg) {
         hipEvent_t e0, e1;
         hipEventCreate(&e0); hipEventCreate(&e1);
-        split<<<wgs, 512>>>(d, c, nullptr, tiles, g.nm, g.nv32, g.nv64, g.nlds, g.who);
+#define GO(S) split<S><<<wgs, 512>>>(d, c, nullptr, tiles, g.nm, g.nv32, g.nv64, g.nlds, g.who, g.prio)
+#define GOS() do { if (g.self == 1) GO(1); else if (g.self == 2) GO(2); else if (g.self == 4) GO(4); else GO(0); } while (0)
+        GOS();
         hipEventRecord(e0);
-        split<<<wgs, 512>>>(d, c, nullptr, tiles, g.nm, g.nv32, g.nv64, g.nlds, g.who);
+        GOS();
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms;
