@@ -670,9 +670,7 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
     // Only the states that DIFFER from the one before are written (a wave's word of
     // finite kept vectors says which: bit c = some frame of the wave holds a kept
     // distance to candidate c below its own); the workgroup's last wave reads, for
-    // state k, every wave's last entry at or below k.  In the epilogue an instruction
-    // costs 13-20 cycles beside the other wave's matrix loop: fifteen unconditional
-    // table writes were 2 % of the pass.
+    // state k, every wave's last entry at or below k.
     __shared__ float s_pv[EK_BLOCK / EK_WAVE][T];
     __shared__ uint32_t s_pi[EK_BLOCK / EK_WAVE][T];
     __shared__ uint32_t s_fin[EK_BLOCK / EK_WAVE];
@@ -771,37 +769,46 @@ ek_pass16_kernel(const float *__restrict__ qtiles, const double *__restrict__ G,
         *(volatile unsigned int *)cu_end = (unsigned)__builtin_amdgcn_s_memrealtime();
     }
 #endif
-    if (MODE != 2 && lane == 0) {
-        float v = red_v[0];
-        uint32_t i = red_i[0];
+    // the tile's maximum after candidate 0 (every lane works it out: four LDS words)
+    float v0 = red_v[0];
+    uint32_t i0 = red_i[0];
 #pragma unroll
-        for (int w = 1; w < EK_BLOCK / EK_WAVE; ++w)
-            if (ek_better(red_v[w], red_i[w], v, i)) {
-                v = red_v[w];
-                i = red_i[w];
-            }
-        blockmax[blockIdx.x].val = v;
-        blockmax[blockIdx.x].idx = i;
+    for (int w = 1; w < EK_BLOCK / EK_WAVE; ++w)
+        if (ek_better(red_v[w], red_i[w], v0, i0)) {
+            v0 = red_v[w];
+            i0 = red_i[w];
+        }
+    if (MODE != 2 && lane == 0) {
+        blockmax[blockIdx.x].val = v0;
+        blockmax[blockIdx.x].idx = i0;
     }
     if (sweep && lane < teff) {
         // state `lane` of this tile from the four waves' entries (read by the next
-        // launch); a tile none of whose waves holds a finite kept distance: every
-        // state is state 0
+        // launch).  A tile none of whose waves holds a finite kept distance: every
+        // state is state 0, no walk over the waves' tables.  (Measured at 10^6 x 300:
+        // the pass is 14-17 us = 2 % slower with the sweep in it, with or without this
+        // shortcut and the one above -- as much as the chain kernel's own sweep cost
+        // there, hence EK_OPT_PASS_SWEEP's rule by the shard's size;
+        // profiles/r06/sweep_ab_1m.log.)
         uint32_t fw[EK_BLOCK / EK_WAVE];
 #pragma unroll
         for (int w = 0; w < EK_BLOCK / EK_WAVE; ++w)
             fw[w] = s_fin[w];
-        float v = -__builtin_inff();
-        uint32_t i = 0xffffffffu;
+        float v = v0;
+        uint32_t i = i0;
+        if ((fw[0] | fw[1] | fw[2] | fw[3]) != 1u) {        // uniform
+            v = -__builtin_inff();
+            i = 0xffffffffu;
 #pragma unroll
-        for (int w = 0; w < EK_BLOCK / EK_WAVE; ++w) {
-            const uint32_t m = fw[w] & ((2u << lane) - 1u);
-            const int e = 31 - __builtin_clz(m);        // (bit 0 is always set)
-            const float ev = s_pv[w][e];
-            const uint32_t ei = s_pi[w][e];
-            if (ek_better(ev, ei, v, i)) {
-                v = ev;
-                i = ei;
+            for (int w = 0; w < EK_BLOCK / EK_WAVE; ++w) {
+                const uint32_t m = fw[w] & ((2u << lane) - 1u);
+                const int e = 31 - __builtin_clz(m);        // (bit 0 is always set)
+                const float ev = s_pv[w][e];
+                const uint32_t ei = s_pi[w][e];
+                if (ek_better(ev, ei, v, i)) {
+                    v = ev;
+                    i = ei;
+                }
             }
         }
         if (lane >= 1) {
