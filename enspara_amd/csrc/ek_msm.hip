@@ -24,6 +24,7 @@
 
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include <algorithm>
 #include <new>
@@ -76,8 +77,19 @@ msm_scan_kernel(const int32_t *__restrict__ cnt, int64_t nb,
     const int64_t per = (nb + MSM_WG - 1) / MSM_WG;
     const int64_t lo = (int64_t)t * per, hi = (lo + per < nb) ? lo + per : nb;
     int64_t s = 0;
-    for (int64_t b = lo; b < hi; ++b)
-        s += cnt[b];
+    // (a thread's counts are read in batches of sixteen loads in flight: one after the
+    // other, each waiting for the one before, the 24 of a 5000-state table's scan were
+    // 25 us of nothing but latency -- twice per call)
+    constexpr int UB = 16;
+    for (int64_t b0 = lo; b0 < hi; b0 += UB) {
+        int32_t v[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u)
+            v[u] = b0 + u < hi ? cnt[b0 + u] : 0;
+#pragma unroll
+        for (int u = 0; u < UB; ++u)
+            s += v[u];
+    }
     // scan of the 1024 partial sums: inside the waves, then over the 16 waves
     int64_t incl = s;
     const int lane = t & (EK_WAVE - 1), wv = t / EK_WAVE;
@@ -96,9 +108,17 @@ msm_scan_kernel(const int32_t *__restrict__ cnt, int64_t nb,
     part[t] = base + incl - s;
     __syncthreads();
     int64_t run = part[t];
-    for (int64_t b = lo; b < hi; ++b) {
-        off[b] = run;
-        run += cnt[b];
+    for (int64_t b0 = lo; b0 < hi; b0 += UB) {
+        int32_t v[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u)
+            v[u] = b0 + u < hi ? cnt[b0 + u] : 0;
+#pragma unroll
+        for (int u = 0; u < UB; ++u)
+            if (b0 + u < hi) {
+                off[b0 + u] = run;
+                run += v[u];
+            }
     }
     if (t == MSM_WG - 1)
         off[nb] = base + incl;
@@ -197,6 +217,119 @@ msm_hist_kernel(const int32_t *__restrict__ c, const int64_t *__restrict__ cstar
     }
     atomicAdd(&table[(size_t)from * n_states + to], 1);
 }
+
+// The same counts with the additions of a stretch of the walk gathered in LDS first
+// (round 6).  A workgroup takes MSM_HCH consecutive transitions; a trajectory stays in
+// a neighbourhood of states for a while, so they hit far fewer different cells than
+// there are of them (the bench's walk: 3650 cells per 8192 transitions) -- an
+// open-addressed table in LDS (key = cell + 1, linear probing, atomicCAS + atomicAdd)
+// takes the additions, and what leaves the workgroup is ONE global atomic add per
+// different cell, with its count.  A transition that finds no slot within
+// MSM_HPROBE probes (transitions all over the table: nothing to gather) goes to the
+// global table directly, as in msm_hist_kernel.  The trajectory of a position: the
+// workgroup's first by one search, the next sixteen starts from LDS.  Integer adds
+// commute: the table is msm_hist_kernel's.
+#define MSM_HCH 8192
+#define MSM_HSLOTS 8192
+#define MSM_HPROBE 6
+#define MSM_HTRJ 16
+__global__ void __launch_bounds__(EK_BLOCK)
+msm_hist_lds_kernel(const int32_t *__restrict__ c, const int64_t *__restrict__ cstart,
+                    int64_t n_trj, int32_t lag, int sliding, int32_t n_states,
+                    int32_t *__restrict__ table, int32_t *__restrict__ bad)
+{
+    __shared__ unsigned int keys[MSM_HSLOTS];
+    __shared__ unsigned int vals[MSM_HSLOTS];
+    __shared__ long long s_cs[MSM_HTRJ + 1];
+    __shared__ long long s_t0;
+    const int tid = threadIdx.x;
+    const int64_t m = cstart[n_trj];
+    const int64_t base = (int64_t)blockIdx.x * MSM_HCH;
+    if (base >= m)
+        return;
+    for (int q = tid; q < MSM_HSLOTS; q += EK_BLOCK) {
+        keys[q] = 0u;
+        vals[q] = 0u;
+    }
+    if (tid == 0) {
+        // trajectory of position `base`: last t with cstart[t] <= base
+        int64_t lo = 0, hi = n_trj - 1;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi + 1) >> 1;
+            if (cstart[mid] <= base)
+                lo = mid;
+            else
+                hi = mid - 1;
+        }
+        s_t0 = lo;
+    }
+    __syncthreads();
+    const int64_t t0 = s_t0;
+    if (tid <= MSM_HTRJ)
+        s_cs[tid] = t0 + tid <= n_trj ? cstart[t0 + tid] : m;
+    __syncthreads();
+    for (int k = 0; k < MSM_HCH / EK_BLOCK; ++k) {
+        const int64_t p = base + tid + (int64_t)k * EK_BLOCK;
+        if (p >= m)
+            break;
+        const int32_t from = c[p];
+        if (from < 0 || from >= n_states) {
+            *bad = 1;
+            continue;
+        }
+        // start and end of p's trajectory: among the staged starts, else by search
+        int64_t ts, te;
+        if (p < s_cs[MSM_HTRJ]) {
+            int j = 0;
+#pragma unroll
+            for (int u = 1; u < MSM_HTRJ; ++u)
+                j += (s_cs[u] <= p) ? 1 : 0;
+            ts = s_cs[j];
+            te = s_cs[j + 1];
+        } else {
+            int64_t lo = t0, hi = n_trj - 1;
+            while (lo < hi) {
+                const int64_t mid = (lo + hi + 1) >> 1;
+                if (cstart[mid] <= p)
+                    lo = mid;
+                else
+                    hi = mid - 1;
+            }
+            ts = cstart[lo];
+            te = cstart[lo + 1];
+        }
+        bool ok = (p + lag < te);
+        if (ok && !sliding)
+            ok = ((p - ts) % lag) == 0;
+        if (!ok)
+            continue;
+        const int32_t to = c[p + lag];
+        if (to < 0 || to >= n_states) {
+            *bad = 1;
+            continue;
+        }
+        const unsigned int cell = (unsigned int)from * (unsigned int)n_states + (unsigned int)to;
+        unsigned int h = (cell * 2654435761u) >> (32 - 13);
+        bool placed = false;
+#pragma unroll 1
+        for (int pr = 0; pr < MSM_HPROBE; ++pr) {
+            const unsigned int old = atomicCAS(&keys[h], 0u, cell + 1u);
+            if (old == 0u || old == cell + 1u) {
+                atomicAdd(&vals[h], 1u);
+                placed = true;
+                break;
+            }
+            h = (h + 1u) & (MSM_HSLOTS - 1);
+        }
+        if (!placed)
+            atomicAdd(&table[cell], 1);
+    }
+    __syncthreads();
+    for (int q = tid; q < MSM_HSLOTS; q += EK_BLOCK)
+        if (keys[q])
+            atomicAdd(&table[keys[q] - 1u], (int32_t)vals[q]);
+}
+static_assert(MSM_HSLOTS == (1 << 13), "the hash keeps 13 bits");
 
 // the cells that are not zero, in index order
 __global__ void __launch_bounds__(MSM_WG)
@@ -336,9 +469,23 @@ static int msm_counts_device(hipStream_t s, EkMsmScratch &w, const int32_t *d_a,
                        s, d_a, n, w.start, w.off, nb, n_trj, w.cstart);
     // 2. the histogram (a launch over all frames; the survivors' count stays on
     //    the device)
-    hipLaunchKernelGGL(msm_hist_kernel, dim3(msm_blocks(n)), dim3(EK_BLOCK), 0, s,
-                       w.c, w.cstart, n_trj, lag_time, sliding_window, n_states,
-                       w.table, w.bad);
+    //    (the additions gathered per stretch of the walk in LDS first, where a cell
+    //    index fits 32 bits; EK_MSM_HIST_LDS=0: one global atomic per transition)
+    {
+        static const int use_lds = [] {
+            const char *e = getenv("EK_MSM_HIST_LDS");
+            return (e && e[0] == '0') ? 0 : 1;
+        }();
+        if (use_lds && n_cells < 0xffffffffll)
+            hipLaunchKernelGGL(msm_hist_lds_kernel,
+                               dim3((unsigned)((n + MSM_HCH - 1) / MSM_HCH)), dim3(EK_BLOCK),
+                               0, s, w.c, w.cstart, n_trj, lag_time, sliding_window,
+                               n_states, w.table, w.bad);
+        else
+            hipLaunchKernelGGL(msm_hist_kernel, dim3(msm_blocks(n)), dim3(EK_BLOCK), 0, s,
+                               w.c, w.cstart, n_trj, lag_time, sliding_window, n_states,
+                               w.table, w.bad);
+    }
     // 3. the cells that are not zero, in (row, col) order
     hipLaunchKernelGGL(msm_count_kernel<1>, dim3((unsigned)ncb), dim3(MSM_WG), 0, s,
                        w.table, n_cells, w.cnt);

@@ -303,3 +303,63 @@ def test_implied_timescales_with_trimming(golden_dir):
     got = implied_timescales(G["assigns"], [int(t) for t in G["implied_lags"]],
                              builders.normalize, n_times=3, trim=True)
     np.testing.assert_allclose(got, G["implied_times_trim"], rtol=1e-8)
+
+
+_HIST_CHILD = r"""
+import sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+from enspara_amd.msm import assigns_to_counts
+from enspara_amd import ra
+rng = np.random.RandomState(int(sys.argv[2]))
+out = []
+# (a) a banded walk: few cells per stretch; (b) transitions all over a 300 x 300 table:
+# the LDS table overflows and the global path takes over; (c) many short trajectories,
+# some empty, some all -1; (d) every lag-th frame instead of the sliding window
+K = 700
+steps = rng.choice([-2, -1, 0, 1, 2], size=(40, 30000))
+A = (rng.randint(K, size=(40, 1)) + np.cumsum(steps, axis=1)) % K
+A[rng.rand(*A.shape) < 0.002] = -1
+out.append(assigns_to_counts(A, lag_time=1, max_n_states=K))
+out.append(assigns_to_counts(A, lag_time=7, max_n_states=K, sliding_window=False))
+B = rng.randint(300, size=(6, 100000))
+out.append(assigns_to_counts(B, lag_time=3, max_n_states=300))
+lens = rng.randint(0, 90, size=4000)
+lens[::17] = 0
+flat = rng.randint(50, size=int(lens.sum()))
+flat[rng.rand(len(flat)) < 0.05] = -1
+R = ra.RaggedArray(flat, lengths=lens)
+out.append(assigns_to_counts(R, lag_time=2, max_n_states=50))
+out.append(assigns_to_counts(R, lag_time=40, max_n_states=50))
+np.savez(sys.argv[3], **{"c%d" % i: np.asarray(c.todense()) for i, c in enumerate(out)})
+"""
+
+
+def test_counts_gathered_in_lds_equal_one_atomic_per_transition(tmp_path):
+    """round 6: the histogram gathers a stretch of the walk's additions in an LDS hash
+    table and adds once per different cell (EK_MSM_HIST_LDS, default) -- against one
+    global atomic per transition (= 0: rounds 2-5) and against scipy, on a banded
+    walk, on transitions all over the table (the LDS table overflows), on thousands of
+    short, empty and all-(-1) trajectories, with and without the sliding window"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for form in ("1", "0"):
+        env = dict(os.environ)
+        env["EK_MSM_HIST_LDS"] = form
+        path = str(tmp_path / ("hist%s.npz" % form))
+        p = subprocess.run([sys.executable, "-c", _HIST_CHILD, root, "12", path], env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-3000:]
+        got[form] = np.load(path)
+    for k in got["1"].files:
+        np.testing.assert_array_equal(got["1"][k], got["0"][k])
+        assert got["1"][k].sum() > 0
+    # and scipy's construction of the first (the reference's own way)
+    rng = np.random.RandomState(12)
+    K = 700
+    steps = rng.choice([-2, -1, 0, 1, 2], size=(40, 30000))
+    A = (rng.randint(K, size=(40, 1)) + np.cumsum(steps, axis=1)) % K
+    A[rng.rand(*A.shape) < 0.002] = -1
+    np.testing.assert_array_equal(got["1"]["c0"], np.asarray(_scipy_counts(A, 1, K).todense()))
