@@ -181,36 +181,78 @@ msm_cstart2_kernel(const int32_t *__restrict__ a, int64_t n,
 }
 
 // one atomic add per transition (:310-321); *bad is set if a state lies
-// outside [0, n_states)
+// outside [0, n_states).  Round 6: the trajectory of a position -- which decides
+// whether position + lag is still inside it -- is no longer searched by every thread
+// (ten dependent loads each, beside two for the states): the workgroup's first
+// position is searched once, the next MSM_HTRJ starts are staged in LDS and a thread
+// counts how many of them lie at or before its position (a workgroup of 256
+// consecutive positions rarely spans more; one that does searches as before).
+#define MSM_HTRJ 16
 __global__ void __launch_bounds__(EK_BLOCK)
 msm_hist_kernel(const int32_t *__restrict__ c, const int64_t *__restrict__ cstart,
                 int64_t n_trj, int32_t lag, int sliding, int32_t n_states,
                 int32_t *__restrict__ table, int32_t *__restrict__ bad)
 {
+    __shared__ long long s_cs[MSM_HTRJ + 1];
+    __shared__ long long s_t0;
+    const int tid = threadIdx.x;
     const int64_t m = cstart[n_trj];
-    const int64_t p = (int64_t)blockIdx.x * EK_BLOCK + threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * EK_BLOCK;
+    if (base >= m)
+        return;
+    const int64_t p = base + tid;
+    // (asked for before the search below is waited for)
+    const int32_t from = p < m ? c[p] : 0;
+    const int32_t to_guess = p + lag < m ? c[p + lag] : 0;
+    if (tid == 0) {
+        // trajectory of position `base`: last t with cstart[t] <= base
+        int64_t lo = 0, hi = n_trj - 1;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi + 1) >> 1;
+            if (cstart[mid] <= base)
+                lo = mid;
+            else
+                hi = mid - 1;
+        }
+        s_t0 = lo;
+    }
+    __syncthreads();
+    const int64_t t0 = s_t0;
+    if (tid <= MSM_HTRJ)
+        s_cs[tid] = t0 + tid <= n_trj ? cstart[t0 + tid] : m;
+    __syncthreads();
     if (p >= m)
         return;
-    const int32_t from = c[p];
     if (from < 0 || from >= n_states) {
         *bad = 1;
         return;
     }
-    // trajectory of compacted position p: last t with cstart[t] <= p
-    int64_t lo = 0, hi = n_trj - 1;
-    while (lo < hi) {
-        const int64_t mid = (lo + hi + 1) >> 1;
-        if (cstart[mid] <= p)
-            lo = mid;
-        else
-            hi = mid - 1;
+    int64_t ts, te;
+    if (p < s_cs[MSM_HTRJ]) {
+        int j = 0;
+#pragma unroll
+        for (int u = 1; u < MSM_HTRJ; ++u)
+            j += (s_cs[u] <= p) ? 1 : 0;
+        ts = s_cs[j];
+        te = s_cs[j + 1];
+    } else {
+        int64_t lo = t0, hi = n_trj - 1;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi + 1) >> 1;
+            if (cstart[mid] <= p)
+                lo = mid;
+            else
+                hi = mid - 1;
+        }
+        ts = cstart[lo];
+        te = cstart[lo + 1];
     }
-    bool ok = (p + lag < cstart[lo + 1]);
+    bool ok = (p + lag < te);
     if (ok && !sliding)
-        ok = ((p - cstart[lo]) % lag) == 0;
+        ok = ((p - ts) % lag) == 0;
     if (!ok)
         return;
-    const int32_t to = c[p + lag];
+    const int32_t to = to_guess;        // (p + lag < te <= m: it was loaded)
     if (to < 0 || to >= n_states) {
         *bad = 1;
         return;
@@ -229,10 +271,14 @@ msm_hist_kernel(const int32_t *__restrict__ c, const int64_t *__restrict__ cstar
 // global table directly, as in msm_hist_kernel.  The trajectory of a position: the
 // workgroup's first by one search, the next sixteen starts from LDS.  Integer adds
 // commute: the table is msm_hist_kernel's.
+// MEASURED (profiles/r06/kernel_summary_msm_*.csv), and not the default: 296 us against
+// 290 for one atomic per transition on the bench's 10^7 transitions, 8 % slower on
+// transitions all over the table -- the histogram was never bound by its atomics but
+// by the dependent loads of every thread's trajectory search, which msm_hist_kernel
+// no longer makes.  EK_MSM_HIST_LDS=1 runs this form.
 #define MSM_HCH 8192
 #define MSM_HSLOTS 8192
 #define MSM_HPROBE 6
-#define MSM_HTRJ 16
 __global__ void __launch_bounds__(EK_BLOCK)
 msm_hist_lds_kernel(const int32_t *__restrict__ c, const int64_t *__restrict__ cstart,
                     int64_t n_trj, int32_t lag, int sliding, int32_t n_states,
@@ -469,12 +515,12 @@ static int msm_counts_device(hipStream_t s, EkMsmScratch &w, const int32_t *d_a,
                        s, d_a, n, w.start, w.off, nb, n_trj, w.cstart);
     // 2. the histogram (a launch over all frames; the survivors' count stays on
     //    the device)
-    //    (the additions gathered per stretch of the walk in LDS first, where a cell
-    //    index fits 32 bits; EK_MSM_HIST_LDS=0: one global atomic per transition)
+    //    (EK_MSM_HIST_LDS=1: the additions gathered per stretch of the walk in LDS
+    //    first -- built in round 6 and measured not to pay, see msm_hist_lds_kernel)
     {
         static const int use_lds = [] {
             const char *e = getenv("EK_MSM_HIST_LDS");
-            return (e && e[0] == '0') ? 0 : 1;
+            return (e && e[0] == '1') ? 1 : 0;
         }();
         if (use_lds && n_cells < 0xffffffffll)
             hipLaunchKernelGGL(msm_hist_lds_kernel,
