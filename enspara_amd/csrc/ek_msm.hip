@@ -185,9 +185,15 @@ msm_cstart2_kernel(const int32_t *__restrict__ a, int64_t n,
 // whether position + lag is still inside it -- is no longer searched by every thread
 // (ten dependent loads each, beside two for the states): the workgroup's first
 // position is searched once, the next MSM_HTRJ starts are staged in LDS and a thread
-// counts how many of them lie at or before its position (a workgroup of 256
-// consecutive positions rarely spans more; one that does searches as before).
+// counts how many of them lie at or before its position (a workgroup's 4096
+// consecutive positions rarely span more; a position beyond them searches as before).
 #define MSM_HTRJ 16
+#define MSM_HPER 16     // positions per thread: 4096 per workgroup
+// (Three forms of this kernel took 290-296 us for 10^7 transitions -- a search per
+// thread, the search per workgroup of 256 positions, additions gathered in LDS --:
+// what they shared was 39 000 workgroups of a dozen DEPENDENT trips to memory each,
+// nineteen generations of them per CU slot.  A workgroup now takes 4096 positions,
+// asks for all its states before it waits for anything, and searches once.)
 __global__ void __launch_bounds__(EK_BLOCK)
 msm_hist_kernel(const int32_t *__restrict__ c, const int64_t *__restrict__ cstart,
                 int64_t n_trj, int32_t lag, int sliding, int32_t n_states,
@@ -197,13 +203,16 @@ msm_hist_kernel(const int32_t *__restrict__ c, const int64_t *__restrict__ cstar
     __shared__ long long s_t0;
     const int tid = threadIdx.x;
     const int64_t m = cstart[n_trj];
-    const int64_t base = (int64_t)blockIdx.x * EK_BLOCK;
+    const int64_t base = (int64_t)blockIdx.x * (EK_BLOCK * MSM_HPER);
     if (base >= m)
         return;
-    const int64_t p = base + tid;
-    // (asked for before the search below is waited for)
-    const int32_t from = p < m ? c[p] : 0;
-    const int32_t to_guess = p + lag < m ? c[p + lag] : 0;
+    int32_t from[MSM_HPER], to[MSM_HPER];
+#pragma unroll
+    for (int k = 0; k < MSM_HPER; ++k) {
+        const int64_t p = base + tid + (int64_t)k * EK_BLOCK;
+        from[k] = p < m ? c[p] : 0;
+        to[k] = p + lag < m ? c[p + lag] : 0;
+    }
     if (tid == 0) {
         // trajectory of position `base`: last t with cstart[t] <= base
         int64_t lo = 0, hi = n_trj - 1;
@@ -221,43 +230,46 @@ msm_hist_kernel(const int32_t *__restrict__ c, const int64_t *__restrict__ cstar
     if (tid <= MSM_HTRJ)
         s_cs[tid] = t0 + tid <= n_trj ? cstart[t0 + tid] : m;
     __syncthreads();
-    if (p >= m)
-        return;
-    if (from < 0 || from >= n_states) {
-        *bad = 1;
-        return;
-    }
-    int64_t ts, te;
-    if (p < s_cs[MSM_HTRJ]) {
-        int j = 0;
 #pragma unroll
-        for (int u = 1; u < MSM_HTRJ; ++u)
-            j += (s_cs[u] <= p) ? 1 : 0;
-        ts = s_cs[j];
-        te = s_cs[j + 1];
-    } else {
-        int64_t lo = t0, hi = n_trj - 1;
-        while (lo < hi) {
-            const int64_t mid = (lo + hi + 1) >> 1;
-            if (cstart[mid] <= p)
-                lo = mid;
-            else
-                hi = mid - 1;
+    for (int k = 0; k < MSM_HPER; ++k) {
+        const int64_t p = base + tid + (int64_t)k * EK_BLOCK;
+        if (p >= m)
+            continue;
+        if (from[k] < 0 || from[k] >= n_states) {
+            *bad = 1;
+            continue;
         }
-        ts = cstart[lo];
-        te = cstart[lo + 1];
+        int64_t ts, te;
+        if (p < s_cs[MSM_HTRJ]) {
+            int j = 0;
+#pragma unroll
+            for (int u = 1; u < MSM_HTRJ; ++u)
+                j += (s_cs[u] <= p) ? 1 : 0;
+            ts = s_cs[j];
+            te = s_cs[j + 1];
+        } else {
+            int64_t lo = t0, hi = n_trj - 1;
+            while (lo < hi) {
+                const int64_t mid = (lo + hi + 1) >> 1;
+                if (cstart[mid] <= p)
+                    lo = mid;
+                else
+                    hi = mid - 1;
+            }
+            ts = cstart[lo];
+            te = cstart[lo + 1];
+        }
+        bool ok = (p + lag < te);
+        if (ok && !sliding)
+            ok = ((p - ts) % lag) == 0;
+        if (!ok)
+            continue;
+        if (to[k] < 0 || to[k] >= n_states) {       // (p + lag < te <= m: it was loaded)
+            *bad = 1;
+            continue;
+        }
+        atomicAdd(&table[(size_t)from[k] * n_states + to[k]], 1);
     }
-    bool ok = (p + lag < te);
-    if (ok && !sliding)
-        ok = ((p - ts) % lag) == 0;
-    if (!ok)
-        return;
-    const int32_t to = to_guess;        // (p + lag < te <= m: it was loaded)
-    if (to < 0 || to >= n_states) {
-        *bad = 1;
-        return;
-    }
-    atomicAdd(&table[(size_t)from * n_states + to], 1);
 }
 
 // The same counts with the additions of a stretch of the walk gathered in LDS first
@@ -274,8 +286,8 @@ msm_hist_kernel(const int32_t *__restrict__ c, const int64_t *__restrict__ cstar
 // MEASURED (profiles/r06/kernel_summary_msm_*.csv), and not the default: 296 us against
 // 290 for one atomic per transition on the bench's 10^7 transitions, 8 % slower on
 // transitions all over the table -- the histogram was never bound by its atomics but
-// by the dependent loads of every thread's trajectory search, which msm_hist_kernel
-// no longer makes.  EK_MSM_HIST_LDS=1 runs this form.
+// by dependent trips to memory in too many small workgroups (see msm_hist_kernel).
+// EK_MSM_HIST_LDS=1 runs this form.
 #define MSM_HCH 8192
 #define MSM_HSLOTS 8192
 #define MSM_HPROBE 6
@@ -528,9 +540,11 @@ static int msm_counts_device(hipStream_t s, EkMsmScratch &w, const int32_t *d_a,
                                0, s, w.c, w.cstart, n_trj, lag_time, sliding_window,
                                n_states, w.table, w.bad);
         else
-            hipLaunchKernelGGL(msm_hist_kernel, dim3(msm_blocks(n)), dim3(EK_BLOCK), 0, s,
-                               w.c, w.cstart, n_trj, lag_time, sliding_window, n_states,
-                               w.table, w.bad);
+            hipLaunchKernelGGL(msm_hist_kernel,
+                               dim3((unsigned)((n + EK_BLOCK * MSM_HPER - 1) /
+                                               (EK_BLOCK * MSM_HPER))),
+                               dim3(EK_BLOCK), 0, s, w.c, w.cstart, n_trj, lag_time,
+                               sliding_window, n_states, w.table, w.bad);
     }
     // 3. the cells that are not zero, in (row, col) order
     hipLaunchKernelGGL(msm_count_kernel<1>, dim3((unsigned)ncb), dim3(MSM_WG), 0, s,
