@@ -189,11 +189,16 @@ msm_cstart2_kernel(const int32_t *__restrict__ a, int64_t n,
 // consecutive positions rarely span more; a position beyond them searches as before).
 #define MSM_HTRJ 16
 #define MSM_HPER 16     // positions per thread: 4096 per workgroup
-// (Three forms of this kernel took 290-296 us for 10^7 transitions -- a search per
-// thread, the search per workgroup of 256 positions, additions gathered in LDS --:
-// what they shared was 39 000 workgroups of a dozen DEPENDENT trips to memory each,
-// nineteen generations of them per CU slot.  A workgroup now takes 4096 positions,
-// asks for all its states before it waits for anything, and searches once.)
+// (Round 6 measured FOUR forms of this kernel on the bench's 10^7 transitions -- a
+// trajectory search per thread; the search once per workgroup of 256 positions; this
+// one, 4096 positions per workgroup with every state asked for up front; the additions
+// gathered in LDS first, msm_hist_lds_kernel -- at 290, 291, 292 and 296 us: 3.4e10
+// atomic adds per second, 1.7 x what MI355X_MICROARCH.md gives for 64 lanes in 64
+// different rows.  The kernel is bound by the atomics themselves; a wave's 64
+// consecutive positions of a walk fall on a dozen neighbouring cells, which is why it
+// is above the scattered figure, and why gathering in a HASHED table does not pay: it
+// halves the additions and flushes them in hash order, every lane on a cell of its
+// own.  profiles/r06/kernel_summary_msm_*.csv)
 __global__ void __launch_bounds__(EK_BLOCK)
 msm_hist_kernel(const int32_t *__restrict__ c, const int64_t *__restrict__ cstart,
                 int64_t n_trj, int32_t lag, int sliding, int32_t n_states,
@@ -285,8 +290,9 @@ msm_hist_kernel(const int32_t *__restrict__ c, const int64_t *__restrict__ cstar
 // commute: the table is msm_hist_kernel's.
 // MEASURED (profiles/r06/kernel_summary_msm_*.csv), and not the default: 296 us against
 // 290 for one atomic per transition on the bench's 10^7 transitions, 8 % slower on
-// transitions all over the table -- the histogram was never bound by its atomics but
-// by dependent trips to memory in too many small workgroups (see msm_hist_kernel).
+// transitions all over the table: half the global additions, but flushed in hash
+// order -- 64 lanes on 64 cells of their own, the slowest shape an atomic has --
+// where a wave of msm_hist_kernel falls on a dozen neighbouring cells.
 // EK_MSM_HIST_LDS=1 runs this form.
 #define MSM_HCH 8192
 #define MSM_HSLOTS 8192
