@@ -272,7 +272,6 @@ static void ek_round_of(ek_ctx *c, int T, double cutoff, EkRound &R)
     R.vmask = c->vmask;
     R.cutoff = cutoff;
     R.pick_cap = c->pick_cap > 0 ? c->pick_cap : 4;
-    R.ms_inline = c->ms_inline ? 1 : 0;
 }
 
 extern "C" int ek_ms_setup(ek_ctx *c, int32_t world, int32_t rank,
@@ -792,8 +791,7 @@ extern "C" int ek_ms_run(ek_ctx *c, int32_t first_label, int32_t max_new,
 // pass (a chain that broke: its state offered again), [2] 10 ns ticks the shard
 // waited for its peers' messages (per exchange the longest wait, summed), [3] ...
 // for its OWN flag (a store that goes nowhere: the floor of [2]), [4] rounds
-// sampled for `ms`, [5] broken chains taken up at once (the threat record: no
-// exchange of their own); ms: mean milliseconds of a sampled round's pass, chain kernel
+// sampled for `ms`; ms: mean milliseconds of a sampled round's pass, chain kernel
 // (the exchange's wait is inside it) and plan kernel(s).
 extern "C" int ek_ms_diag(ek_ctx *c, int64_t *counts, double *ms)
 {
@@ -804,7 +802,6 @@ extern "C" int ek_ms_diag(ek_ctx *c, int64_t *counts, double *ms)
     counts[2] = (int64_t)c->ms_last.wait_ticks_max;
     counts[3] = (int64_t)c->ms_last.wait_ticks_own;
     counts[4] = c->ms_t_n;
-    counts[5] = (int64_t)c->ms_last.n_inline;
     for (int k = 0; k < 3; ++k)
         ms[k] = c->ms_t_n > 0 ? c->ms_t[k] / (double)c->ms_t_n : 0.0;
     return EK_OK;

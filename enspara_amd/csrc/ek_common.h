@@ -93,15 +93,6 @@ struct EkPlan {
     // multi-shard rounds: which of the offered records each candidate is
     // (ek_ms_ctile16_kernel reads their coordinates out of the mailboxes)
     int32_t offer[EK_MAX_CANDS];
-    // round 6, where a round follows a broken chain without an exchange in between:
-    // from[c] = 0 the offered record offer[c]; 1 the threat of shard offer[c]'s message;
-    // 2 record offer[c] of the round BEFORE (a candidate its chain did not reach).
-    // The rounds' records alternate between the two halves of the record buffer
-    // (rec_base = 0 / 16: a candidate kept from the round before is read from the one
-    // half while the other is written).
-    int32_t from[EK_MAX_CANDS];
-    int32_t rec_base;
-    int32_t rec_prev;
 };
 
 // one candidate frame as seen by the shard that owns it: its current distance
@@ -181,8 +172,6 @@ struct EkRound {
     unsigned long long *ti_stats = nullptr; // [0] (tile, candidate) pairs looked at, [1] left out
     int pick_cap = 4;           // far frames kept per label by the candidate pick (ek_top_dev.h)
     int sweep = 0;              // the pass takes the per-prefix maxima itself (EkFuse::sweep_pm)
-    int ms_inline = 0;          // rounds across shards: go on after a broken chain without a
-                                // re-offer where the threat record allows (EK_OPT_MS_INLINE)
 };
 // the masks of the round the plan describes (after ek_launch_round_next)
 void ek_launch_round_ti(const EkRound &r, int max_labels, hipStream_t s);
@@ -198,14 +187,7 @@ void ek_launch_round_flush(const EkRound &r, hipStream_t s);
 // One exchange per round: every shard's MESSAGE = the (max distance, global
 // index) of its frames in the state every prefix of the round's chain would
 // leave + its `offer` farthest frames of the state the whole chain would leave
-// (records).  EkMsMsg | EkMaxHdr[EK_MAX_CANDS] | offer records | the threat.
-// The THREAT (round 6): the first frame of the shard that is the arg-max of a prefix
-// state WITHOUT being one of the round's candidates -- the frame that breaks the
-// round's chain if it turns out to be the farthest of all shards.  With its record in
-// the message every shard can go on at once when the chain does break there: the
-// next round's candidates are that frame, the candidates the broken chain did not
-// reach, and the farthest of the offers (ek_ms_plan_kernel); without it the state the
-// chain left has to be offered again in an exchange of its own.
+// (records).  EkMsMsg | EkMaxHdr[EK_MAX_CANDS] | offer records.
 #define EK_MS_MAX_WORLD 64
 struct EkMsMsg {
     int32_t n_recs;         // valid records offered
@@ -215,7 +197,7 @@ struct EkMsMsg {
 static inline __host__ __device__ size_t ek_ms_msg_bytes(int A, int offer)
 {
     return sizeof(EkMsMsg) + EK_MAX_CANDS * sizeof(EkMaxHdr) +
-           (size_t)(offer + 1) * ek_rec_bytes(A);
+           (size_t)offer * ek_rec_bytes(A);
 }
 // device-side state of the rounds (one per context)
 struct EkMsState {
@@ -231,7 +213,6 @@ struct EkMsState {
     // of an exchange is what counts -- kept apart), exchanges, exchanges without a
     // pass (a chain that broke is offered again)
     uint32_t n_reoffer;
-    uint32_t n_inline;      // broken chains taken up at once (the threat record, round 6)
     unsigned long long wait_ticks_max;      // sum over exchanges of the longest wait
     unsigned long long wait_ticks_own;      // ... of the wait for this shard's OWN flag
 };

@@ -130,9 +130,7 @@ __device__ __forceinline__ const unsigned char *ek_ms_src(const EkMsXchg &x, int
 #define EK_MS_HELPERS 16
 struct EkMsPub {            // the list, published for the helpers (in r.top + 2048)
     int32_t n_off;
-    int32_t threat;         // this shard's threat (EkMsMsg layout): local frame, or -1
-    float threat_val;
-    int32_t pad;
+    int32_t pad[3];
     uint32_t idx[EK_TOP_M];
     float val[EK_TOP_M];
 };
@@ -209,51 +207,6 @@ ek_ms_chain_kernel(EkRound r, EkMsState *ms, EkMsXchg x, int nblk)
                 }
                 unsigned char *d = x.dst[p] + slot * x.msg_bytes + head_bytes +
                                    (size_t)j * ek_rec_bytes(r.A) + (size_t)q * 16;
-                if (x.sys)
-                    ek_sys_store4(d, v);
-                else
-                    *(ek_f4 *)d = v;
-            }
-        }
-        // the threat (EkMsMsg layout): one more record behind the offers, by helper 0;
-        // where there is none its header says so (the slot holds an exchange of two
-        // ago otherwise)
-        if (h == 0) {
-            __shared__ int s_thr;
-            __shared__ float s_thrv;
-            if (tid == 0) {
-                s_thr = s_ok ? ek_coh_load(&pub->threat) : -1;
-                s_thrv = ek_coh_load(&pub->threat_val);
-            }
-            __syncthreads();
-            const int thr = s_thr;
-            const uint32_t fi = thr >= 0 ? (uint32_t)thr : 0u;
-            const float *src = r.aos + (size_t)fi * A3;
-            const int items = thr >= 0 ? cpr : 1;       // (no threat: the header alone)
-            for (int item = tid; item < n_dst * items; item += EK_MS_THREADS) {
-                const int p = item / items, q = item % items;
-                ek_f4 v;
-                if (q == 0) {
-                    const long long g = r.goff + (long long)fi;
-                    v[0] = s_thrv;
-                    v[1] = __uint_as_float(thr >= 0 ? 1u : 0u);
-                    v[2] = __uint_as_float((uint32_t)((unsigned long long)g & 0xffffffffu));
-                    v[3] = __uint_as_float((uint32_t)((unsigned long long)g >> 32));
-                } else if (q == 1) {
-                    const unsigned long long tr = __double_as_longlong(r.G[fi]);
-                    v[0] = __uint_as_float((uint32_t)(tr & 0xffffffffu));
-                    v[1] = __uint_as_float((uint32_t)(tr >> 32));
-                    v[2] = 0.f;
-                    v[3] = 0.f;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int w = 4 * (q - 2) + e;
-                        v[e] = w < A3 ? src[w] : 0.f;
-                    }
-                }
-                unsigned char *d = x.dst[p] + slot * x.msg_bytes + head_bytes +
-                                   (size_t)x.offer * ek_rec_bytes(r.A) + (size_t)q * 16;
                 if (x.sys)
                     ek_sys_store4(d, v);
                 else
@@ -412,31 +365,8 @@ ek_ms_chain_kernel(EkRound r, EkMsState *ms, EkMsXchg x, int nblk)
         ek_coh_store(&pub->val[tid], top->val[tid]);
     }
     const int n_off = top->n < x.offer ? top->n : x.offer;
-    // the threat: the first prefix state whose arg-max on this shard is none of the
-    // round's candidates (sv / si: states 0 .. cn - 1, ek_chain_reduce above)
-    __shared__ long long s_cg[EK_MAX_CANDS];
-    __shared__ int s_teff;
-    if (tid < EK_MAX_CANDS)
-        s_cg[tid] = r.plan->gidx[tid];
     if (tid == 0)
-        s_teff = r.plan->teff;
-    __syncthreads();
-    if (tid < EK_WAVE) {
-        bool mine = false;          // state `tid`'s arg-max is a frame nobody else knows
-        if (mode == 1 && r.ms_inline && tid < cn && si[tid] != 0xffffffffu) {
-            const long long g = r.goff + (long long)si[tid];
-            mine = true;
-            for (int j = 0; j < s_teff && j < EK_MAX_CANDS; ++j)
-                mine = mine && s_cg[j] != g;
-        }
-        const unsigned long long who = __ballot(mine);
-        if (tid == 0) {
-            const int k = who ? __ffsll((long long)who) - 1 : -1;
-            ek_coh_store(&pub->n_off, (int32_t)n_off);
-            ek_coh_store(&pub->threat, k >= 0 ? (int32_t)si[k] : -1);
-            ek_coh_store(&pub->threat_val, k >= 0 ? sv[k] : 0.f);
-        }
-    }
+        ek_coh_store(&pub->n_off, (int32_t)n_off);
     const int head_words = (int)(head_bytes / 4);
     for (int item = tid; item < n_dst * head_words; item += EK_MS_THREADS) {
         const int p = item / head_words, w = item % head_words;
@@ -586,16 +516,7 @@ ek_ms_plan_kernel(EkRound r, EkMsState *ms, EkMsXchg x, float *D)
     __shared__ float gv[EK_MAX_CANDS];          // global maximum of state k
     __shared__ long long gg[EK_MAX_CANDS];
     __shared__ int gok[EK_MAX_CANDS];
-    __shared__ int grk[EK_MAX_CANDS];           // ... and the shard it is on
     __shared__ int s_over, s_repick, s_short;
-    // round 6: the round after a broken chain without an exchange of its own
-    // (EkMsMsg layout, "the threat"): s_inline = the shard whose threat record IS the
-    // farthest frame of the state the chain left, s_keep0 .. the candidates it did not
-    // reach
-    __shared__ int s_inline, s_keep0, s_nkeep;
-    __shared__ long long k_gidx[EK_MAX_CANDS];  // the kept candidates' entries of the plan
-    __shared__ float k_max[EK_MAX_CANDS];
-    __shared__ double k_trace[EK_MAX_CANDS];
     {
         constexpr int PER = 64 * 64 / EK_BLOCK;
         float dreg[PER];
@@ -626,11 +547,6 @@ ek_ms_plan_kernel(EkRound r, EkMsState *ms, EkMsXchg x, float *D)
         bool ok = false;
         float v = 0.f;
         long long g = 0;
-        int owner = 0;
-        // (the plan of the round that has just run: read before it is written below)
-        k_gidx[tid] = r.plan->gidx[tid];
-        k_max[tid] = r.plan->maxdist[tid];
-        k_trace[tid] = r.plan->trace[tid];
         if (tid < cn) {
             for (int rk = 0; rk < x.world; ++rk) {
                 const uint32_t *h = (const uint32_t *)(ek_ms_src(x, rk, seq) +
@@ -645,14 +561,12 @@ ek_ms_plan_kernel(EkRound r, EkMsState *ms, EkMsXchg x, float *D)
                     ok = true;
                     v = hv;
                     g = hg;
-                    owner = rk;
                 }
             }
         }
         gv[tid] = v;
         gg[tid] = g;
         gok[tid] = ok ? 1 : 0;
-        grk[tid] = owner;
     }
     __syncthreads();
     if (tid == 0) {
@@ -712,27 +626,6 @@ ek_ms_plan_kernel(EkRound r, EkMsState *ms, EkMsXchg x, float *D)
         // (a message that never came: the run ends here, on every later launch too)
         s_over = (c.stopped || c.n_done >= c.limit || ms->err) ? 1 : 0;
         s_repick = (!s_over && mode == 1 && na < cn) ? 1 : 0;
-        s_inline = -1;
-        s_keep0 = s_nkeep = 0;
-        if (s_repick && T == 16 && r.ms_inline && gok[na]) {
-            // the farthest frame of the state the chain left (state na): is it the
-            // threat its shard sent along?  (record slot x.offer of that message)
-            const uint32_t *tr = (const uint32_t *)(ek_ms_src(x, grk[na], seq) + sizeof(EkMsMsg) +
-                                                    EK_MAX_CANDS * sizeof(EkMaxHdr) +
-                                                    (size_t)x.offer * ek_rec_bytes(A));
-            const long long tg =
-                (long long)((unsigned long long)ek_msg_load<SYS>(tr + 2) |
-                            ((unsigned long long)ek_msg_load<SYS>(tr + 3) << 32));
-            if (ek_msg_load<SYS>(tr + 1) == 1u && tg == gg[na]) {
-                s_inline = grk[na];
-                s_repick = 0;
-                ms->n_inline = ms->n_inline + 1u;
-                // the candidates the chain did not reach: na + 1 .. teff - 1 of the
-                // plan that has just run (its presumed order was the candidates' own)
-                s_keep0 = na + 1;
-                s_nkeep = r.plan->teff - (na + 1);
-            }
-        }
         if (s_repick) {
             ms->pick_state = na;
             ms->n_reoffer = ms->n_reoffer + 1u;
@@ -740,23 +633,15 @@ ek_ms_plan_kernel(EkRound r, EkMsState *ms, EkMsXchg x, float *D)
     }
     __syncthreads();
     const bool over = s_over != 0, repick = s_repick != 0;
-    const int inl = s_inline, keep0 = s_keep0;
-    const int nkeep = inl >= 0 ? (s_nkeep < T - 1 ? s_nkeep : T - 1) : 0;
-    const int nfix = inl >= 0 ? 1 + nkeep : 0;  // candidates that are not offers
     // ---- the next round's candidates among the records on offer ----------------------
     // (greedy, as ek_round_next_kernel: the record with the largest remaining
     // distance, then every other one's is lowered by its distance to it; slot order
     // = (shard, local rank) breaks ties like the lowest global index does)
     if (tid < EK_WAVE) {
         const int lane = tid;
-        // (an offer that IS the threat would be the same frame twice)
-        bool open = !repick && sgidx[lane] >= 0 && !(inl >= 0 && sgidx[lane] == gg[keep0 - 1]);
+        bool open = !repick && sgidx[lane] >= 0;
         float cur = open ? sval[lane] : 0.f;
-        // (after a broken chain that is taken up at once: the threat and the candidates
-        // the chain did not reach come first, the offers fill what is left -- they
-        // describe the state the WHOLE chain would have left, where every frame is at
-        // most as far as it really is: guesses all the same)
-        int ns = nfix;
+        int ns = 0;
         while (ns < T) {
             float v = open ? cur : -__builtin_inff();
             uint32_t i = open ? (uint32_t)lane : 0xffffffffu;
@@ -778,43 +663,19 @@ ek_ms_plan_kernel(EkRound r, EkMsState *ms, EkMsXchg x, float *D)
     }
     __syncthreads();
     const int ns = n_sel;
-    // (taken up after a broken chain: candidate 0 is the farthest frame of the state the
-    // chain left, exactly -- state keep0 - 1's global maximum)
-    const float first_max = inl >= 0 ? gv[keep0 - 1]
-                                     : (ns > 0 ? sval[sel[0]] : -__builtin_inff());
+    const float first_max = ns > 0 ? sval[sel[0]] : -__builtin_inff();
     const bool go = !over && !repick && ns > 0 && (double)first_max > r.cutoff;
     const size_t rstride = ek_rec_bytes(A);
-    // where the round's records go: rounds of 16 alternate between the halves of the
-    // record buffer (a kept candidate is read from the one while the other is written)
-    const int rec_prev = r.plan->rec_base;
-    const int rec_base = T == 16 ? (rec_prev ^ 16) : 0;
-    // candidate c's record header: the threat of shard `inl`, record keep0 + c - 1 of the
-    // round before, or the offered record sel[c]
-    auto hdr_of = [&](int c) -> const uint32_t * {
-        if (c < nfix) {
-            if (c == 0)
-                return (const uint32_t *)(ek_ms_src(x, inl, seq) + sizeof(EkMsMsg) +
-                                          EK_MAX_CANDS * sizeof(EkMaxHdr) +
-                                          (size_t)x.offer * ek_rec_bytes(A));
-            return (const uint32_t *)(r.recs + (size_t)(rec_prev + keep0 + c - 1) * rstride);
-        }
-        return ek_ms_rec<SYS>(x, sel[c], seq, A);
-    };
     // the chosen records (kept for the other entry points: [0] = the farthest
     // point of the state) and the candidate tile of the next pass
     if (!repick) {
         const int A3 = 3 * A;
         for (int e = tid; e < T * 8; e += EK_BLOCK) {
             const int c = e / 8, u = e % 8;
-            uint32_t *h = (uint32_t *)(r.recs + (size_t)(rec_base + c) * rstride);
-            if (c < ns) {
-                const bool prev = c >= 1 && c < nfix;
-                uint32_t w = prev ? hdr_of(c)[u] : ek_msg_load<SYS>(hdr_of(c) + u);
-                if (c == 0 && inl >= 0 && u == 0)
-                    w = __float_as_uint(first_max);     // (its distance now, not the shard's
-                                                        // at the state it was its arg-max)
-                h[u] = w;
-            } else
+            uint32_t *h = (uint32_t *)(r.recs + (size_t)c * rstride);
+            if (c < ns)
+                h[u] = ek_msg_load<SYS>(ek_ms_rec<SYS>(x, sel[c], seq, A) + u);
+            else
                 h[u] = u == 0 ? __float_as_uint(-__builtin_inff())
                               : ((u == 2 || u == 3) ? 0xffffffffu : 0u);
         }
@@ -859,24 +720,15 @@ ek_ms_plan_kernel(EkRound r, EkMsState *ms, EkMsXchg x, float *D)
         if (tid < T) {
             EkPlan *plan = r.plan;
             double tr = 0.0;
-            const bool prev = tid >= 1 && tid < nfix;
-            plan->from[tid] = tid < nfix ? (tid == 0 ? 1 : 2) : 0;
-            plan->offer[tid] = tid >= ns ? 0
-                               : (tid < nfix ? (tid == 0 ? inl : keep0 + tid - 1) : sel[tid]);
+            plan->offer[tid] = tid < ns ? sel[tid] : 0;
             if (tid < ns) {
-                if (prev) {
-                    tr = k_trace[keep0 + tid - 1];
-                    plan->gidx[tid] = k_gidx[keep0 + tid - 1];
-                    plan->maxdist[tid] = k_max[keep0 + tid - 1];
-                } else {
-                    const uint32_t *rr = hdr_of(tid);
-                    tr = __longlong_as_double(
-                        (long long)((unsigned long long)ek_msg_load<SYS>(rr + 4) |
-                                    ((unsigned long long)ek_msg_load<SYS>(rr + 5) << 32)));
-                    plan->gidx[tid] = tid < nfix ? gg[keep0 - 1] : sgidx[sel[tid]];
-                    plan->maxdist[tid] = tid < nfix ? first_max : sval[sel[tid]];
-                }
+                const uint32_t *rr = ek_ms_rec<SYS>(x, sel[tid], seq, A);
+                tr = __longlong_as_double(
+                    (long long)((unsigned long long)ek_msg_load<SYS>(rr + 4) |
+                                ((unsigned long long)ek_msg_load<SYS>(rr + 5) << 32)));
                 plan->src[tid] = tid;
+                plan->gidx[tid] = sgidx[sel[tid]];
+                plan->maxdist[tid] = sval[sel[tid]];
                 plan->trace[tid] = tr;
             }
             r.ctrace[tid] = tr;
@@ -887,10 +739,6 @@ ek_ms_plan_kernel(EkRound r, EkMsState *ms, EkMsXchg x, float *D)
     if (tid == 0) {
         EkPlan *plan = r.plan;
         plan->n_rec = repick ? 0 : ns;
-        if (!repick) {
-            plan->rec_prev = rec_prev;
-            plan->rec_base = rec_base;
-        }
         plan->apply = -1;
         plan->chain_n = 0;
         if (!repick && !s_short && ns > 0)  // (the offers describe the state as it is)
@@ -932,34 +780,16 @@ ek_ms_ctile16_kernel(EkRound r, EkMsState *ms, EkMsXchg x, int halves)
 {
     typedef float v4 __attribute__((ext_vector_type(4)));
     __shared__ int soff[EK_MAX_CANDS];
-    __shared__ int sfrom[EK_MAX_CANDS];
     const EkPlan *plan = r.plan;
     const int tid = threadIdx.x;
     const int ns = plan->n_rec, go = plan->go;
     if (ns <= 0)
         return;
     const uint32_t seq = ms->seq - 1u;
-    if (tid < EK_MAX_CANDS) {
+    if (tid < EK_MAX_CANDS)
         soff[tid] = tid < ns ? plan->offer[tid] : 0;
-        sfrom[tid] = tid < ns ? plan->from[tid] : 0;
-    }
     __syncthreads();
     const int A = r.A, A3 = 3 * A;
-    const size_t rstride = ek_rec_bytes(A);
-    const int rec_base = plan->rec_base, rec_prev = plan->rec_prev;
-    // candidate c's coordinates: an offered record, a shard's threat (both in the
-    // mailboxes: system-scope loads), or a record of the round before (the other half
-    // of the record buffer: EkPlan::from)
-    auto coord = [&](int c, int w) -> float {
-        if (sfrom[c] == 2)
-            return ((const float *)(r.recs + (size_t)(rec_prev + soff[c]) * rstride +
-                                    sizeof(EkRecHdr)))[w];
-        const uint32_t *rec = sfrom[c] == 1
-            ? (const uint32_t *)(ek_ms_src(x, soff[c], seq) + sizeof(EkMsMsg) +
-                                 EK_MAX_CANDS * sizeof(EkMaxHdr) + (size_t)x.offer * rstride)
-            : ek_ms_rec<SYS>(x, soff[c], seq, A);
-        return ek_msg_loadf<SYS>((const float *)(rec + 8) + w);
-    };
     const int n_ct = ek_ctile_atoms(A) / 16 * 3;        // (16 atoms, axis) blocks of 1 KB
     const int ct_wgs = (n_ct + 3) / 4;
     if ((int)blockIdx.x < halves * ct_wgs) {
@@ -968,11 +798,12 @@ ek_ms_ctile16_kernel(EkRound r, EkMsState *ms, EkMsXchg x, int halves)
         if (!go || blk >= n_ct || 16 * half >= ns)
             return;
         const int S = blk / 3, k = blk % 3, kk = lane >> 4, c = 16 * half + (lane & 15);
+        const float *src = (const float *)(ek_ms_rec<SYS>(x, soff[c], seq, A) + 8) + k;
         v4 v;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int a = 16 * S + 4 * q + kk;
-            v[q] = (a < A && c < ns) ? coord(c, 3 * a + k) : 0.f;
+            v[q] = (a < A && c < ns) ? ek_msg_loadf<SYS>(src + 3 * a) : 0.f;
         }
         *(v4 *)(r.ctile + half * ek_ctile_half_floats(A) +
                 ek_ctile_index(16, 16 * S + kk, c, k)) = v;
@@ -980,9 +811,10 @@ ek_ms_ctile16_kernel(EkRound r, EkMsState *ms, EkMsXchg x, int halves)
         const int c = blockIdx.x - halves * ct_wgs;     // one record per workgroup
         if (c >= ns)
             return;
-        float *rec = (float *)(r.recs + (size_t)(rec_base + c) * rstride + sizeof(EkRecHdr));
+        const float *src = (const float *)(ek_ms_rec<SYS>(x, soff[c], seq, A) + 8);
+        float *rec = (float *)(r.recs + (size_t)c * ek_rec_bytes(A) + sizeof(EkRecHdr));
         for (int row = tid; row < A3; row += EK_BLOCK)
-            rec[row] = coord(c, row);
+            rec[row] = ek_msg_loadf<SYS>(src + row);
     }
 }
 

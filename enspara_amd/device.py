@@ -369,11 +369,10 @@ class FrameStore:
         """what the last ms_run spent where -> dict (exchanges, re-offers, microseconds
         waited for the peers' messages / for the own flag, mean microseconds of a
         sampled round's pass, chain kernel with its exchange, plan kernels)"""
-        cnt = np.zeros(6, dtype=np.int64)
+        cnt = np.zeros(5, dtype=np.int64)
         ms = np.zeros(3, dtype=np.float64)
         _lib.check(self.lib.ek_ms_diag(self._h, _lib.i64p(cnt), _lib.f64p(ms)))
         return {"exchanges": int(cnt[0]), "reoffers": int(cnt[1]),
-                "broken_chains_taken_up_at_once": int(cnt[5]),
                 "wait_peers_us": cnt[2] * 0.01, "wait_own_flag_us": cnt[3] * 0.01,
                 "rounds_sampled": int(cnt[4]), "pass_us": ms[0] * 1e3,
                 "chain_with_exchange_us": ms[1] * 1e3, "plan_us": ms[2] * 1e3}

@@ -252,10 +252,10 @@ int ek_ms_begin(ek_ctx *ctx, int32_t first_label, int32_t limit);
 int ek_ms_local(ek_ctx *ctx, double dist_cutoff, void *message_out);
 int ek_ms_global(ek_ctx *ctx, double dist_cutoff, const void *messages_all);
 int ek_ms_end(ek_ctx *ctx);
-/* What the last ek_ms_run spent where -- counts[6]: exchanges, exchanges without a
+/* What the last ek_ms_run spent where -- counts[5]: exchanges, exchanges without a
  * pass (a broken chain offered again), 10 ns ticks waited for the peers' messages
  * (per exchange the longest wait), ... for the shard's own flag (the floor),
- * rounds sampled, broken chains taken up at once (EK_OPT_MS_INLINE); ms[3]: mean milliseconds of a sampled round's pass, chain
+ * rounds sampled; ms[3]: mean milliseconds of a sampled round's pass, chain
  * kernel (the exchange's wait inside) and plan kernels.  No reference counterpart
  * (its MPI iteration, kcenters.py:314-378, is not instrumented). */
 int ek_ms_diag(ek_ctx *ctx, int64_t *counts, double *ms);
@@ -715,15 +715,7 @@ enum ek_option {
      * kernel (rounds 3-5): 1 (default) the former on shards of up to 524 288 frames
      * -- where it pays: 10 % of a fit at 125 000 frames, nothing at 10^6 --, 2
      * always, 0 never.  MEASUREMENT */
-    EK_OPT_PASS_SWEEP = 22,
-    /* rounds across shards (ek_ms_run, ek_ms_local / _global): every message carries,
-     * behind its offers, the record of the shard's THREAT -- its first frame that is the
-     * arg-max of a state some prefix of the round's chain would leave without being a
-     * candidate.  Where the chain breaks at exactly that frame, every shard goes on at
-     * once (the frame, the candidates the chain did not reach, the farthest offers)
-     * instead of offering the state again in an exchange of its own: 1 (default) / 0.
-     * Every rank of a group must hold the same value.  MEASUREMENT */
-    EK_OPT_MS_INLINE = 23
+    EK_OPT_PASS_SWEEP = 22
 };
 int ek_set_option(ek_ctx *ctx, int32_t key, int32_t value);
 /* the value an option holds (what ek_set_option stored, or its default) */

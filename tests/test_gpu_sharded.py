@@ -292,9 +292,6 @@ for rep in range(2):
         # the same --, so the odd shards keep the default)
         if st is stores[0] or len(stores) % 2 == 0:
             st.set_option("pass_sweep", 2 if rep == 0 else 0)
-        # (a broken chain taken up at once where the threat record allows, then offered
-        # again in an exchange of its own as in rounds 3-5: every shard alike)
-        st.set_option("ms_inline", 1 if rep == 0 else 0)
         st.reset_state()
         st.sync()
     th = [threading.Thread(target=work, args=(r,)) for r in range(shards)]
@@ -330,7 +327,7 @@ if K > 4:
     assert got == [int(i) for i in inds], (got, inds)
     parts = [st.download_state() for st in stores]
     np.testing.assert_array_equal(np.concatenate([p[1] for p in parts]), wa)
-print("ok", len(inds), stores[0].ms_state(), stores[0].ms_diag())
+print("ok", len(inds), stores[0].ms_state())
 """
 
 

@@ -46,7 +46,6 @@ for r in range(S):
     st.load(x[lo:lo + cnt])
     st.set_option(4, T)
     st.set_option("pass_sweep", int(os.environ.get("MS_SWEEP", "1")))
-    st.set_option("ms_inline", int(os.environ.get("MS_INLINE", "1")))
     st.set_option(18, 1 if cnt < 300000 else 0)     # (what sharded.kcenters_sharded sets)
     st.ms_setup(S, r)
     st.reserve_centers(K)
@@ -81,10 +80,7 @@ for rep in range(reps):
     mix = {k: v for k, v in stores[0].run_stats().items() if v[0]}
     rounds = sum(v[0] for v in mix.values())
     print("   passes by candidates:", mix, flush=True)
-    print("   exchanges per shard:", [st.ms_state() for st in stores],
-          " without a pass / broken chains taken up at once:",
-          [(st.ms_diag()["reoffers"], st.ms_diag()["broken_chains_taken_up_at_once"])
-           for st in stores], flush=True)
+    print("   exchanges per shard:", [st.ms_state() for st in stores], flush=True)
     print("%d shard(s) of %d frames, mailboxes: %.4f s  %d passes  %.2f centers/pass  %.2f us/center  %.1f us/round"
           % (S, stores[0].n, dt, rounds, K / max(rounds, 1), dt / K * 1e6, dt / max(rounds, 1) * 1e6), flush=True)
 ok = all(np.array_equal(o[0], ridx) and np.array_equal(o[1], rcd) for o in out)
