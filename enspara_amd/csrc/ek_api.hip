@@ -1080,10 +1080,10 @@ static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
     if (adaptive || (tri && Tmax <= 1))
         ladder[n_ladder++] = 1;
     if (Tmax > 1) {
+        // (the ladder is 1 / 8 / 16: rounds of 32 run only where the option pins them,
+        // and a pinned form has no ladder -- `adaptive` needs candidates = -1)
         if (adaptive && Tmax >= 16)
             ladder[n_ladder++] = 8;
-        if (adaptive && Tmax == 32)
-            ladder[n_ladder++] = 16;
         ladder[n_ladder++] = Tmax;
     }
     int home = 0;               // ladder index of the form being run
@@ -1198,7 +1198,7 @@ static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
         if (one)    // (never past the goal: a step has no limit check of its own)
             batch = std::min(left, probing ? 4 : std::min(due, 256));
         else if (probing)
-            batch = form == 32 ? 2 : 3;
+            batch = 3;
         else
             batch = std::max(2, std::min(256, (int32_t)(std::min(left, due) /
                                                         per_round) + 1));
@@ -1352,12 +1352,8 @@ static int ek_run_rounds(ek_ctx *c, int Tmax, int32_t first_label,
                 rate_home = rate;
                 gap = 8;
             } else {                    // back, and wait twice as long
-                // (a round of 32 that lost to rounds of 16: its second sixteen
-                // guesses are accepted far less often than the first -- measured,
-                // DESIGN.md 4a -- and three such rounds are a dear look: much longer)
-                const bool wide_lost = form == 32;
                 form = ladder[home];
-                gap = std::min(wide_lost ? std::max(gap * 4, 512) : gap * 2, 1024);
+                gap = std::min(gap * 2, 1024);
             }
             continue;
         }
