@@ -237,7 +237,12 @@ extern "C" int ek_spec_progress(ek_ctx *c, int32_t *n_done, int32_t *stopped)
 }
 
 // ---- rounds across shards: one exchange per round (ek_mshard.hip) ------------------------
-static int ek_ms_offer(int world) { return std::max(1, 64 / std::max(world, 1)); }
+// records a shard offers per exchange: EK_MS_SLOTS over all shards, at most the 64 its
+// pick lists (round 6: twice round 5's -- the plan kernel lets the 64 farthest compete)
+static int ek_ms_offer(int world)
+{
+    return std::max(1, std::min(64, EK_MS_SLOTS / std::max(world, 1)));
+}
 
 static void ek_round_of(ek_ctx *c, int T, double cutoff, EkRound &R)
 {

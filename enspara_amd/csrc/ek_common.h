@@ -189,6 +189,8 @@ void ek_launch_round_flush(const EkRound &r, hipStream_t s);
 // leave + its `offer` farthest frames of the state the whole chain would leave
 // (records).  EkMsMsg | EkMaxHdr[EK_MAX_CANDS] | offer records.
 #define EK_MS_MAX_WORLD 64
+// records on offer in an exchange, over all shards (the 64 farthest compete: round 6)
+#define EK_MS_SLOTS 128
 struct EkMsMsg {
     int32_t n_recs;         // valid records offered
     int32_t cn;             // states with a header

@@ -444,18 +444,51 @@ ek_ms_plan_kernel(EkRound r, EkMsState *ms, EkMsXchg x, float *D)
     if (tid < x.world)
         s_nrec[tid] = (int)ek_msg_load<SYS>((const uint32_t *)ek_ms_src(x, tid, seq));
     __syncthreads();
-    const int n_slots = x.world * x.offer;      // <= 64
+    // Round 6: up to 128 records are on offer (128 / world per shard, EK_MS_SLOTS), of
+    // which the 64 with the largest distances -- slot order on ties -- compete: the far
+    // frames of a state are not spread evenly over the shards (64 of them over 8 shards:
+    // 8 +- 2.6 per shard), and with 64 / world offers per shard the ones beyond a shard's
+    // quota were on no list -- 38 % of the rounds of the 10^6-frame fit's 8-way split
+    // broke and were offered again, against 5 % on one shard.  smap[i] = the slot of the
+    // i-th best; every workgroup works the map out for itself (128 headers, a rank each).
+    const int n_slots = x.world * x.offer;      // <= EK_MS_SLOTS
+    __shared__ float s_hv[EK_MS_SLOTS];
+    __shared__ int smap[64];
+    __shared__ int s_nval;
+    if (tid < 64)
+        smap[tid] = 0;
+    if (tid == 0)
+        s_nval = 0;
+    if (tid < EK_MS_SLOTS) {
+        float v = -__builtin_inff();
+        if (tid < n_slots && tid % x.offer < s_nrec[tid / x.offer])
+            v = __uint_as_float(ek_msg_load<SYS>(ek_ms_rec<SYS>(x, tid, seq, A)));
+        s_hv[tid] = v;
+    }
+    __syncthreads();
+    if (tid < EK_MS_SLOTS && tid < n_slots && tid % x.offer < s_nrec[tid / x.offer]) {
+        const float v = s_hv[tid];
+        int rank = 0;
+        for (int u = 0; u < n_slots; ++u) {
+            const float o = s_hv[u];
+            rank += (o > v || (o == v && u < tid)) ? 1 : 0;
+        }
+        if (rank < 64)
+            smap[rank] = tid;
+        atomicAdd(&s_nval, 1);
+    }
+    __syncthreads();
+    const int n_cmp = s_nval < 64 ? s_nval : 64;    // records that compete
     {
-        // one wave per pair of records on offer; the values only steer the guesses,
+        // one wave per pair of competing records; the values only steer the guesses,
         // so the lanes may stride over the atoms (but every shard computes the
         // same values from the same messages, and so the same plan)
         const int lane = tid & (EK_WAVE - 1);
         const int w = blockIdx.x * (EK_BLOCK / EK_WAVE) + tid / EK_WAVE;
         const int i = w / 64, j = w % 64;
-        if (i < j && j < n_slots && i % x.offer < s_nrec[i / x.offer] &&
-            j % x.offer < s_nrec[j / x.offer]) {
-            const uint32_t *ri = ek_ms_rec<SYS>(x, i, seq, A);
-            const uint32_t *rj = ek_ms_rec<SYS>(x, j, seq, A);
+        if (i < j && j < n_cmp) {
+            const uint32_t *ri = ek_ms_rec<SYS>(x, smap[i], seq, A);
+            const uint32_t *rj = ek_ms_rec<SYS>(x, smap[j], seq, A);
             const unsigned char *bi = (const unsigned char *)(ri + 8);
             const unsigned char *bj = (const unsigned char *)(rj + 8);
             const int cpr_c = (3 * A + 3) / 4;      // 16-byte chunks of coordinates
@@ -530,8 +563,8 @@ ek_ms_plan_kernel(EkRound r, EkMsState *ms, EkMsXchg x, float *D)
     if (tid < 64) {
         float v = -__builtin_inff();
         long long g = -1;
-        if (tid < n_slots && tid % x.offer < s_nrec[tid / x.offer]) {
-            const uint32_t *rr = ek_ms_rec<SYS>(x, tid, seq, A);
+        if (tid < n_cmp) {
+            const uint32_t *rr = ek_ms_rec<SYS>(x, smap[tid], seq, A);
             v = __uint_as_float(ek_msg_load<SYS>(rr));
             g = (long long)((unsigned long long)ek_msg_load<SYS>(rr + 2) |
                             ((unsigned long long)ek_msg_load<SYS>(rr + 3) << 32));
@@ -674,7 +707,7 @@ ek_ms_plan_kernel(EkRound r, EkMsState *ms, EkMsXchg x, float *D)
             const int c = e / 8, u = e % 8;
             uint32_t *h = (uint32_t *)(r.recs + (size_t)c * rstride);
             if (c < ns)
-                h[u] = ek_msg_load<SYS>(ek_ms_rec<SYS>(x, sel[c], seq, A) + u);
+                h[u] = ek_msg_load<SYS>(ek_ms_rec<SYS>(x, smap[sel[c]], seq, A) + u);
             else
                 h[u] = u == 0 ? __float_as_uint(-__builtin_inff())
                               : ((u == 2 || u == 3) ? 0xffffffffu : 0u);
@@ -689,7 +722,7 @@ ek_ms_plan_kernel(EkRound r, EkMsState *ms, EkMsXchg x, float *D)
             for (int u = 0; u < 4; ++u) {
                 const int e = min(e0 + u * EK_BLOCK, T * cpr_c - 1);
                 const int c = e / cpr_c, q = e % cpr_c;
-                p[u] = (const unsigned char *)(ek_ms_rec<SYS>(x, sel[c < ns ? c : 0],
+                p[u] = (const unsigned char *)(ek_ms_rec<SYS>(x, smap[sel[c < ns ? c : 0]],
                                                               seq, A) + 8) + 16 * q;
             }
             ek_msg_load4<SYS, 4>(p, v);
@@ -720,9 +753,9 @@ ek_ms_plan_kernel(EkRound r, EkMsState *ms, EkMsXchg x, float *D)
         if (tid < T) {
             EkPlan *plan = r.plan;
             double tr = 0.0;
-            plan->offer[tid] = tid < ns ? sel[tid] : 0;
+            plan->offer[tid] = tid < ns ? smap[sel[tid]] : 0;    // (the record's slot)
             if (tid < ns) {
-                const uint32_t *rr = ek_ms_rec<SYS>(x, sel[tid], seq, A);
+                const uint32_t *rr = ek_ms_rec<SYS>(x, smap[sel[tid]], seq, A);
                 tr = __longlong_as_double(
                     (long long)((unsigned long long)ek_msg_load<SYS>(rr + 4) |
                                 ((unsigned long long)ek_msg_load<SYS>(rr + 5) << 32)));
