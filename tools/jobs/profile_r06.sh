@@ -61,6 +61,10 @@ if has ms; then
   python3 tools/ms_probe.py 125000 300 3000 1 -1 3 2>&1 | grep -v amdgpu.ids > $out/ms_125k_ladder_untraced.log
   MS_SWEEP=0 python3 tools/ms_probe.py 125000 300 3000 1 16 3 2>&1 | grep -v amdgpu.ids > $out/ms_125k_untraced_sweep_in_chain_kernel.log
   python3 tools/ms_probe.py 250000 300 3000 2 16 2 2>&1 | grep -v amdgpu.ids > $out/ms_2x125k_untraced.log
+  # the 8-way split of the headline case, whole fit: the decisions eight GPUs would take
+  python3 tools/ms_probe.py 1000000 300 5000 8 -1 1 2>&1 | grep -v amdgpu.ids > $out/ms_8x125k.log
+  python3 tools/ms_probe.py 1000000 300 3000 8 16 1 2>&1 | grep -v amdgpu.ids >> $out/ms_8x125k.log
+  tail -8 $out/ms_8x125k.log | cut -c1-250
   rocprofv3 --kernel-trace --output-format csv -d $out/trace_ms -- python3 tools/ms_probe.py 125000 300 3000 1 16 2 > /dev/null 2>&1
   f=$(find $out/trace_ms -name "*kernel_trace.csv" | head -1)
   python3 tools/summarize_profile.py trace $f $out/kernel_summary_ms125k.csv
