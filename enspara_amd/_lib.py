@@ -79,6 +79,7 @@ EK_OPT_PAM_AHEAD = 19
 EK_OPT_PAM_ZERO_COPY = 20
 EK_OPT_PAM_PAIRS_MFMA = 21
 EK_OPT_PASS_SWEEP = 22
+EK_OPT_MS_TWO_PHASE = 23
 OPTIONS = {k[7:].lower(): v for k, v in list(globals().items())
            if k.startswith("EK_OPT_")}
 

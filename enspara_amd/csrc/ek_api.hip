@@ -524,6 +524,11 @@ extern "C" int ek_set_option(ek_ctx *c, int32_t key, int32_t value)
             return ek_fail(EK_EARG, "ek_set_option: maxima per 64 frames for the pick 0 or 1");
         c->fine_pick = value;
         return EK_OK;
+    case EK_OPT_MS_TWO_PHASE:
+        if (value != 0 && value != 1)
+            return ek_fail(EK_EARG, "ek_set_option: headers first in the mailbox rounds 0 or 1");
+        c->ms_two_phase = value;
+        return EK_OK;
     case EK_OPT_PASS_SWEEP:
         if (value < 0 || value > 2)
             return ek_fail(EK_EARG, "ek_set_option: per-prefix maxima in the pass 0, 1 "
@@ -560,6 +565,7 @@ extern "C" int ek_get_option(ek_ctx *c, int32_t key, int32_t *value)
     case EK_OPT_PAM_BOTH_SUMS: *value = c->sp_exact; return EK_OK;
     case EK_OPT_FINE_PICK: *value = c->fine_pick; return EK_OK;
     case EK_OPT_PASS_SWEEP: *value = c->pass_sweep; return EK_OK;
+    case EK_OPT_MS_TWO_PHASE: *value = c->ms_two_phase; return EK_OK;
     case EK_OPT_PAM_BOUNDS: *value = c->pam_bounds; return EK_OK;
     case EK_OPT_PICK_CAP: *value = c->pick_cap; return EK_OK;
     case EK_OPT_SMALL_SHARDS: *value = c->ms_small; return EK_OK;

@@ -639,6 +639,7 @@ extern "C" int ek_ms_run(ek_ctx *c, int32_t first_label, int32_t max_new,
     ek_round_of(c, T, dist_cutoff, R);
     EkMsXchg x = c->ms_x;
     x.sys = 1;
+    x.two_phase = c->ms_two_phase ? 1 : 0;
     x.src = c->ms_mbox;
     x.sflag = c->ms_flags;
     EK_HIP(hipEventRecord(c->ev0, c->stream));

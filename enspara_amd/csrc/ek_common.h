@@ -194,7 +194,9 @@ void ek_launch_round_flush(const EkRound &r, hipStream_t s);
 struct EkMsMsg {
     int32_t n_recs;         // valid records offered
     int32_t cn;             // states with a header
-    int32_t pad[2];
+    int32_t state;          // the state the offered records are the far frames of
+                            // (0 .. cn; -1: no chain, as the shard's state stands)
+    int32_t pad;
 };
 static inline __host__ __device__ size_t ek_ms_msg_bytes(int A, int offer)
 {
@@ -228,6 +230,10 @@ struct EkMsXchg {
     uint32_t *dflag[EK_MS_MAX_WORLD] = {};      // peer p's flags [2][world][16]
     const unsigned char *src = nullptr;         // own mailbox area / gathered messages
     const uint32_t *sflag = nullptr;            // own flags
+    // round 6 (mailbox transport only): the per-prefix headers travel FIRST, every shard
+    // decides the chain inside its chain kernel and offers the far frames of the state the
+    // chain really left -- a broken chain costs no exchange of its own (ek_ms_chain_kernel)
+    int32_t two_phase = 0;
 };
 // chain: per-prefix maxima (presumed order = pick order), this shard's headers,
 // its farthest frames of the speculated state, the message out

@@ -245,6 +245,7 @@ struct ek_ctx {
     EkBlockMax *fm = nullptr;    // [4 nb] maxima per 64 frames of a round's last prefix
     int fine_pick = 1;           // the candidate pick reads them (option key 15)
     int pass_sweep = 1;          // rounds of 16: per-prefix maxima taken by the pass (EK_OPT_PASS_SWEEP)
+    int ms_two_phase = 1;        // mailbox rounds: headers first, offers of the state the chain left (EK_OPT_MS_TWO_PHASE)
     int pick_cap = 0;            // far frames per label on the pick's list: 0 by the yield
                                  //   (4 <-> 16), else fixed 1 .. 16 (option key 17)
     unsigned char *top = nullptr;    // scratch of the candidate pick (ek_spec.hip)

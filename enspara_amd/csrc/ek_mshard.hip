@@ -64,6 +64,12 @@
 #ifndef EK_MS_WAIT_TICKS
 #define EK_MS_WAIT_TICKS (10ull * 100000000ull)
 #endif
+// ... and how long for the peers' per-prefix maxima before the offers go out as speculated
+// (headers first, round 6): 2 ms.  Shards of one fit finish a pass within microseconds of
+// one another; several contexts sharing ONE GPU (the tests) are the case that runs into it.
+#ifndef EK_MS_HDR_TICKS
+#define EK_MS_HDR_TICKS 200000ull
+#endif
 
 // ---- system-scope accesses (mailbox transport) ---------------------------------
 __device__ __forceinline__ void ek_sys_store(uint32_t *p, uint32_t v)
@@ -134,6 +140,44 @@ struct EkMsPub {            // the list, published for the helpers (in r.top + 2
     uint32_t idx[EK_TOP_M];
     float val[EK_TOP_M];
 };
+
+// Headers first (round 6): the walk of ek_ms_plan_kernel over the global per-prefix maxima,
+// read-only -- how many of the chain's cn candidates become centers.  One thread.
+__device__ __forceinline__ int ek_ms_walk(const EkRound &r, const EkMsState *ms,
+                                          const EkMsXchg &x, uint32_t seq, int cn)
+{
+    const EkCtl c = *r.ctl;
+    int n_done = r.plan->label + 1;     // (candidate 0 is a center by then)
+    int na = 0;
+    for (int k = 0; k < cn; ++k) {
+        bool ok = false;
+        float v = 0.f;
+        long long g = 0;
+        for (int rk = 0; rk < x.world; ++rk) {
+            const uint32_t *h = (const uint32_t *)(ek_ms_src(x, rk, seq) + sizeof(EkMsMsg)) +
+                                4 * k;
+            if (!ek_sys_load(h + 1))
+                continue;
+            const float hv = __uint_as_float(ek_sys_load(h));
+            const long long hg = (long long)((unsigned long long)ek_sys_load(h + 2) |
+                                             ((unsigned long long)ek_sys_load(h + 3) << 32));
+            if (!ok || hv > v || (hv == v && hg < g)) {
+                ok = true;
+                v = hv;
+                g = hg;
+            }
+        }
+        if (c.stopped || n_done >= c.limit || !ok || ms->err)
+            break;
+        if (!((double)v > r.cutoff))    // kcenters.py:217
+            break;
+        if (g != r.plan->gidx[r.ord->cand[k]])
+            break;                      // the farthest point is not stored
+        ++n_done;
+        ++na;
+    }
+    return na;
+}
 
 __global__ void __launch_bounds__(EK_MS_THREADS)
 ek_ms_chain_kernel(EkRound r, EkMsState *ms, EkMsXchg x, int nblk)
@@ -348,17 +392,101 @@ ek_ms_chain_kernel(EkRound r, EkMsState *ms, EkMsXchg x, int nblk)
     if (cn > 0)
         ek_chain_reduce<true>(r.blockmax, r.pm, nb, nb, cn, sv, si);
     __syncthreads();
-    // its farthest frames of the state the offers are for: the one the whole
-    // chain would leave, or (the chain broke) the one it did leave
-    const int ps = mode == 1 ? cn : ms->pick_state;
-    // (the state the whole chain would leave: its maxima per 64 frames)
-    const bool fine = fine_ok && mode == 1 && cn > 0;
-    const EkBlockMax *state = fine ? r.fm
-                                   : (ps == 0 ? r.blockmax : r.pm + (size_t)(ps - 1) * nb);
+    // ---- round 6, mailbox transport: the headers first, the decision here ---------------
+    // Every shard sends its per-prefix maxima (the head of its message), waits for the
+    // others', and walks the chain as the plan kernel will (ek_chain_walk on the global
+    // maxima): it then knows the state the chain REALLY leaves and offers that state's far
+    // frames.  Before, the offers speculated that the whole chain would hold, and a chain
+    // that broke -- 30 % of the rounds of the headline case split 8 ways -- was offered
+    // again in an exchange of its own (chain + plan + tile kernels on every shard).
+    __shared__ int s_na, s_late;
+    const int head_words = (int)(head_bytes / 4);
+    const bool two = x.sys && x.two_phase && mode == 1 && cn > 0;
+    if (two) {
+        for (int item = tid; item < n_dst * head_words; item += EK_MS_THREADS) {
+            const int p = item / head_words, w = item % head_words;
+            if (w < (int)(sizeof(EkMsMsg) / 4))
+                continue;               // (n_recs, cn: with the list, below)
+            const int k = (w - (int)(sizeof(EkMsMsg) / 4)) / 4;
+            const int u = (w - (int)(sizeof(EkMsMsg) / 4)) % 4;
+            const bool ok = k < cn && si[k] != 0xffffffffu;
+            const long long g = ok ? r.goff + (long long)si[k] : -1;
+            const uint32_t val = u == 0 ? __float_as_uint(ok ? sv[k] : -__builtin_inff())
+                               : u == 1 ? (ok ? 1u : 0u)
+                               : u == 2 ? (uint32_t)((unsigned long long)g & 0xffffffffu)
+                                        : (uint32_t)((unsigned long long)g >> 32);
+            ek_sys_store((uint32_t *)(x.dst[p] + slot * x.msg_bytes) + w, val);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // (word 1 of a flag slot: "its headers are in"; word 0 stays "its message is in")
+        if (tid < x.world)
+            ek_sys_store(x.dflag[tid] + (slot * 16) + 1, seq + 1u);
+    }
+    // its farthest frames of the state the offers are for: the one the whole chain would
+    // leave or (the chain broke before: mode 2) the one it did leave.  Headers first: if
+    // the peers' are in already (this shard was the last, or the only one) the chain is
+    // decided at once; if not, the pick for the whole chain's state runs while they travel,
+    // and a chain that then turns out to break (one round in five to three) is picked
+    // again for the state it leaves.
+    int ps = mode == 1 ? cn : ms->pick_state;
+    bool decided = false;
+    if (two) {
+        __shared__ int s_in;
+        if (tid == 0)
+            s_in = 1;
+        __syncthreads();
+        if (tid < x.world && tid != x.rank &&
+            ek_sys_load(x.sflag + ((size_t)(seq & 1u) * x.world + tid) * 16 + 1) != seq + 1u)
+            s_in = 0;
+        __syncthreads();
+        if (s_in) {
+            if (tid == 0)
+                s_na = ek_ms_walk(r, ms, x, seq, cn);
+            __syncthreads();
+            ps = s_na;
+            decided = true;
+        }
+    }
     EkTop *top = (EkTop *)r.top;
-    ek_pick_top_body<true>(state, fine ? 4 * nb : nb, top, skip, r.assign, r.pick_cap);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    for (;;) {
+        // (the state the whole chain would leave: its maxima per 64 frames)
+        const bool fine = fine_ok && mode == 1 && cn > 0 && ps == cn;
+        const EkBlockMax *state = fine ? r.fm
+                                       : (ps == 0 ? r.blockmax : r.pm + (size_t)(ps - 1) * nb);
+        ek_pick_top_body<true>(state, fine ? 4 * nb : nb, top, skip, r.assign, r.pick_cap);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (!two || decided)
+            break;
+        decided = true;
+        // (a BOUNDED wait: headers that are not in after EK_MS_HDR_TICKS -- a peer far behind
+        // -- leave the offers as speculated, and the plan kernel deals with a broken chain
+        // as rounds 3-5 did; sixteen helper workgroups are waiting for this one)
+        if (tid == 0)
+            s_late = 0;
+        __syncthreads();
+        if (tid < x.world && tid != x.rank) {
+            const uint32_t *f = x.sflag + ((size_t)(seq & 1u) * x.world + tid) * 16 + 1;
+            const uint64_t t_start = wall_clock64();
+            while (ek_sys_load(f) != seq + 1u) {
+                __builtin_amdgcn_s_sleep(2);
+                if (wall_clock64() - t_start > EK_MS_HDR_TICKS) {
+                    s_late = 1;
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+        if (s_late)
+            break;
+        if (tid == 0)
+            s_na = ek_ms_walk(r, ms, x, seq, cn);
+        __syncthreads();
+        if (s_na == cn)
+            break;
+        ps = s_na;
+    }
     // the list for the helpers, and the head of the message: this workgroup's part
     if (tid < EK_TOP_M) {
         ek_coh_store((int32_t *)&pub->idx[tid], (int32_t)top->idx[tid]);
@@ -367,12 +495,14 @@ ek_ms_chain_kernel(EkRound r, EkMsState *ms, EkMsXchg x, int nblk)
     const int n_off = top->n < x.offer ? top->n : x.offer;
     if (tid == 0)
         ek_coh_store(&pub->n_off, (int32_t)n_off);
-    const int head_words = (int)(head_bytes / 4);
     for (int item = tid; item < n_dst * head_words; item += EK_MS_THREADS) {
         const int p = item / head_words, w = item % head_words;
         uint32_t val = 0;
+        if (two && w >= (int)(sizeof(EkMsMsg) / 4))
+            continue;                   // (the headers went out first)
         if (w < (int)(sizeof(EkMsMsg) / 4)) {
-            val = w == 0 ? (uint32_t)n_off : (w == 1 ? (uint32_t)cn : 0u);
+            val = w == 0 ? (uint32_t)n_off
+                : (w == 1 ? (uint32_t)cn : (w == 2 ? (uint32_t)(mode == 1 ? ps : -1) : 0u));
         } else {
             const int k = (w - (int)(sizeof(EkMsMsg) / 4)) / 4;
             const int u = (w - (int)(sizeof(EkMsMsg) / 4)) % 4;
@@ -658,7 +788,13 @@ ek_ms_plan_kernel(EkRound r, EkMsState *ms, EkMsXchg x, float *D)
         r.ctl->last_max = c.last_max;
         // (a message that never came: the run ends here, on every later launch too)
         s_over = (c.stopped || c.n_done >= c.limit || ms->err) ? 1 : 0;
-        s_repick = (!s_over && mode == 1 && na < cn) ? 1 : 0;
+        // the offers describe the state this chain left on every shard (headers first:
+        // ek_ms_chain_kernel; or the whole chain held), or they are offered again
+        bool agree = true;
+        for (int rk = 0; rk < x.world; ++rk)
+            agree = agree && (int)ek_msg_load<SYS>((const uint32_t *)ek_ms_src(x, rk, seq) + 2)
+                                 == na;
+        s_repick = (!s_over && mode == 1 && !agree) ? 1 : 0;
         if (s_repick) {
             ms->pick_state = na;
             ms->n_reoffer = ms->n_reoffer + 1u;

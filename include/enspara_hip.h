@@ -715,7 +715,15 @@ enum ek_option {
      * kernel (rounds 3-5): 1 (default) the former on shards of up to 524 288 frames
      * -- where it pays: 10 % of a fit at 125 000 frames, nothing at 10^6 --, 2
      * always, 0 never.  MEASUREMENT */
-    EK_OPT_PASS_SWEEP = 22
+    EK_OPT_PASS_SWEEP = 22,
+    /* ek_ms_run (peer mailboxes): an exchange in two steps inside the chain kernel --
+     * every shard's per-prefix maxima first; every shard then walks the chain itself and
+     * offers the far frames of the state the chain REALLY left -- (1, default) or in one,
+     * the offers speculating that the whole chain holds and a chain that broke offered
+     * again in an exchange of its own (0: rounds 3-5; what ek_ms_local / ek_ms_global,
+     * whose exchange is the caller's collective, always do).  Every rank of a group must
+     * hold the same value.  MEASUREMENT */
+    EK_OPT_MS_TWO_PHASE = 23
 };
 int ek_set_option(ek_ctx *ctx, int32_t key, int32_t value);
 /* the value an option holds (what ek_set_option stored, or its default) */

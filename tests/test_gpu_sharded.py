@@ -292,6 +292,9 @@ for rep in range(2):
         # the same --, so the odd shards keep the default)
         if st is stores[0] or len(stores) % 2 == 0:
             st.set_option("pass_sweep", 2 if rep == 0 else 0)
+        # (the headers first and the offers of the state the chain really left, then the
+        # speculating offers with their exchanges without a pass: every shard alike)
+        st.set_option("ms_two_phase", 1 if rep == 0 else 0)
         st.reset_state()
         st.sync()
     th = [threading.Thread(target=work, args=(r,)) for r in range(shards)]

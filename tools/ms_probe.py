@@ -6,6 +6,7 @@ Prints seconds per run, rounds, microseconds per accepted center, and compares
 centers / labels / distances with the single-shard ek_kcenters_run of the same
 data (which the GPU tests compare with the oracle)."""
 import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # shards that wait for one another: a HW queue each
 import sys
 import threading
 import time
@@ -46,6 +47,7 @@ for r in range(S):
     st.load(x[lo:lo + cnt])
     st.set_option(4, T)
     st.set_option("pass_sweep", int(os.environ.get("MS_SWEEP", "1")))
+    st.set_option("ms_two_phase", int(os.environ.get("MS_TWO_PHASE", "1")))
     st.set_option(18, 1 if cnt < 300000 else 0)     # (what sharded.kcenters_sharded sets)
     st.ms_setup(S, r)
     st.reserve_centers(K)
@@ -80,7 +82,8 @@ for rep in range(reps):
     mix = {k: v for k, v in stores[0].run_stats().items() if v[0]}
     rounds = sum(v[0] for v in mix.values())
     print("   passes by candidates:", mix, flush=True)
-    print("   exchanges per shard:", [st.ms_state() for st in stores], flush=True)
+    print("   exchanges per shard:", [st.ms_state() for st in stores], " without a pass:",
+          [st.ms_diag()["reoffers"] for st in stores], flush=True)
     print("%d shard(s) of %d frames, mailboxes: %.4f s  %d passes  %.2f centers/pass  %.2f us/center  %.1f us/round"
           % (S, stores[0].n, dt, rounds, K / max(rounds, 1), dt / K * 1e6, dt / max(rounds, 1) * 1e6), flush=True)
 ok = all(np.array_equal(o[0], ridx) and np.array_equal(o[1], rcd) for o in out)
