@@ -71,6 +71,48 @@
 #define EK_MS_HDR_TICKS 200000ull
 #endif
 
+// measurement builds (-DEK_MS_STAMPS; tools/ms_stamps.py): where the chain and plan kernels'
+// single workgroups spend their time -- 10 ns ticks summed per phase, read by ek_ms_stamps
+#ifdef EK_MS_STAMPS
+__device__ unsigned long long ek_ms_acc[32];
+__device__ unsigned int ek_ms_cnt[32];
+#define EK_MST_BEGIN unsigned long long mst_prev = wall_clock64()
+#define EK_MST(k)                                                              \
+    do {                                                                       \
+        __syncthreads();                                                       \
+        if (threadIdx.x == 0) {                                                \
+            const unsigned long long mst_now = wall_clock64();                 \
+            ek_ms_acc[k] += mst_now - mst_prev;                                \
+            ek_ms_cnt[k] += 1u;                                                \
+            mst_prev = mst_now;                                                \
+        }                                                                      \
+    } while (0)
+extern "C" int ek_ms_stamps(double *mean_us, int64_t *counts, int clear)
+{
+    unsigned long long acc[32];
+    unsigned int cnt[32];
+    if (hipMemcpyFromSymbol(acc, HIP_SYMBOL(ek_ms_acc), sizeof(acc)) != hipSuccess ||
+        hipMemcpyFromSymbol(cnt, HIP_SYMBOL(ek_ms_cnt), sizeof(cnt)) != hipSuccess)
+        return -1;
+    for (int k = 0; k < 32; ++k) {
+        mean_us[k] = cnt[k] ? 0.01 * (double)acc[k] / cnt[k] : 0.0;
+        counts[k] = cnt[k];
+    }
+    if (clear) {
+        for (int k = 0; k < 32; ++k) {
+            acc[k] = 0;
+            cnt[k] = 0;
+        }
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(ek_ms_acc), acc, sizeof(acc));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(ek_ms_cnt), cnt, sizeof(cnt));
+    }
+    return 0;
+}
+#else
+#define EK_MST_BEGIN
+#define EK_MST(k)
+#endif
+
 // ---- system-scope accesses (mailbox transport) ---------------------------------
 __device__ __forceinline__ void ek_sys_store(uint32_t *p, uint32_t v)
 {
@@ -141,37 +183,113 @@ struct EkMsPub {            // the list, published for the helpers (in r.top + 2
     float val[EK_TOP_M];
 };
 
+// The global per-prefix maxima: state k's maximum over the shards -- the largest, the lowest
+// global index on ties (kcenters.py:337) -- out of the cn headers of every shard's message.
+// The whole workgroup (NT threads): one 16-byte load per (state, shard), all in flight at
+// once -- a thread that walked them one after the other spent 0.5 us per header on the
+// latency of uncached memory --, then an LDS max on the value's ordered bits and an LDS min
+// on the index among the holders of that value.  Also fetched here, in parallel: what the
+// walk compares them with (the stored frame of the presumed order's k-th candidate).
+struct EkMsMaxima {
+    float gv[EK_MAX_CANDS];         // global maximum of state k
+    long long gg[EK_MAX_CANDS];     // ... its frame
+    int gok[EK_MAX_CANDS];          // ... whether any shard has one
+    int cj[EK_MAX_CANDS];           // the presumed order's k-th candidate
+    long long cg[EK_MAX_CANDS];     // ... its frame
+    unsigned int key[EK_MAX_CANDS];
+    unsigned long long idx[EK_MAX_CANDS];
+};
+__device__ __forceinline__ unsigned int ek_ord_bits(float v)
+{
+    const unsigned int b = __float_as_uint(v == 0.f ? 0.f : v);     // (-0 ties with +0)
+    return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);
+}
+template <int NT> struct EkMsHdrRegs {
+    static constexpr int IT = (EK_MAX_CANDS * EK_MS_MAX_WORLD + NT - 1) / NT;
+    ek_f4 h[IT];
+};
+template <bool SYS, int NT>
+__device__ __forceinline__ void ek_ms_headers_load(const EkMsXchg &x, uint32_t seq, int cn,
+                                                   EkMsHdrRegs<NT> &hr)
+{
+    const int tid = threadIdx.x;
+    constexpr int IT = EkMsHdrRegs<NT>::IT;
+    const int total = cn * x.world;
+    const void *p[IT];
+#pragma unroll
+    for (int u = 0; u < IT; ++u) {
+        const int t = tid + u * NT < total ? tid + u * NT : 0;
+        p[u] = ek_ms_src(x, t % x.world, seq) + sizeof(EkMsMsg) + (size_t)(t / x.world) * 16;
+    }
+    if (tid < total)        // (the threads of a first stride that holds nothing skip it all)
+        ek_msg_load4<SYS, IT>(p, hr.h);
+}
+template <int NT>
+__device__ __forceinline__ void ek_ms_maxima_combine(const EkRound &r, const EkMsXchg &x,
+                                                     int cn, const EkMsHdrRegs<NT> &hr,
+                                                     EkMsMaxima &m)
+{
+    const int tid = threadIdx.x;
+    constexpr int IT = EkMsHdrRegs<NT>::IT;
+    const int total = cn * x.world;
+    const ek_f4 *h = hr.h;
+    if (tid < EK_MAX_CANDS) {
+        m.key[tid] = 0u;
+        m.idx[tid] = ~0ull;
+        if (tid < cn) {
+            const int j = r.ord->cand[tid];
+            m.cj[tid] = j;
+            m.cg[tid] = r.plan->gidx[j];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < IT; ++u)
+        if (tid + u * NT < total && __float_as_uint(h[u][1]) != 0u)
+            atomicMax(&m.key[(tid + u * NT) / x.world], ek_ord_bits(h[u][0]));
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < IT; ++u)
+        if (tid + u * NT < total && __float_as_uint(h[u][1]) != 0u &&
+            ek_ord_bits(h[u][0]) == m.key[(tid + u * NT) / x.world])
+            atomicMin(&m.idx[(tid + u * NT) / x.world],
+                      (unsigned long long)__float_as_uint(h[u][2]) |
+                          ((unsigned long long)__float_as_uint(h[u][3]) << 32));
+    __syncthreads();
+    if (tid < EK_MAX_CANDS) {
+        const unsigned int k = m.key[tid];
+        const unsigned int b = k ^ ((k >> 31) ? 0x80000000u : 0xffffffffu);
+        m.gok[tid] = (tid < cn && k != 0u) ? 1 : 0;
+        m.gv[tid] = m.gok[tid] ? __uint_as_float(b) : 0.f;
+        m.gg[tid] = m.gok[tid] ? (long long)m.idx[tid] : 0;
+    }
+    __syncthreads();
+}
+template <bool SYS, int NT>
+__device__ __forceinline__ void ek_ms_gather_maxima(const EkRound &r, const EkMsXchg &x,
+                                                    uint32_t seq, int cn, EkMsMaxima &m)
+{
+    EkMsHdrRegs<NT> hr;
+    ek_ms_headers_load<SYS, NT>(x, seq, cn, hr);
+    ek_ms_maxima_combine<NT>(r, x, cn, hr, m);
+}
+
 // Headers first (round 6): the walk of ek_ms_plan_kernel over the global per-prefix maxima,
 // read-only -- how many of the chain's cn candidates become centers.  One thread.
 __device__ __forceinline__ int ek_ms_walk(const EkRound &r, const EkMsState *ms,
-                                          const EkMsXchg &x, uint32_t seq, int cn)
+                                          const EkMsMaxima &m, int cn)
 {
     const EkCtl c = *r.ctl;
     int n_done = r.plan->label + 1;     // (candidate 0 is a center by then)
     int na = 0;
+    if (ms->err)
+        return 0;
     for (int k = 0; k < cn; ++k) {
-        bool ok = false;
-        float v = 0.f;
-        long long g = 0;
-        for (int rk = 0; rk < x.world; ++rk) {
-            const uint32_t *h = (const uint32_t *)(ek_ms_src(x, rk, seq) + sizeof(EkMsMsg)) +
-                                4 * k;
-            if (!ek_sys_load(h + 1))
-                continue;
-            const float hv = __uint_as_float(ek_sys_load(h));
-            const long long hg = (long long)((unsigned long long)ek_sys_load(h + 2) |
-                                             ((unsigned long long)ek_sys_load(h + 3) << 32));
-            if (!ok || hv > v || (hv == v && hg < g)) {
-                ok = true;
-                v = hv;
-                g = hg;
-            }
-        }
-        if (c.stopped || n_done >= c.limit || !ok || ms->err)
+        if (c.stopped || n_done >= c.limit || !m.gok[k])
             break;
-        if (!((double)v > r.cutoff))    // kcenters.py:217
+        if (!((double)m.gv[k] > r.cutoff))      // kcenters.py:217
             break;
-        if (g != r.plan->gidx[r.ord->cand[k]])
+        if (m.gg[k] != m.cg[k])
             break;                      // the farthest point is not stored
         ++n_done;
         ++na;
@@ -201,6 +319,7 @@ ek_ms_chain_kernel(EkRound r, EkMsState *ms, EkMsXchg x, int nblk)
         // ---- a helper: records h, h + H, .. of the list, to every destination ----------
         const int h = (int)blockIdx.x - nblk;
         __shared__ int s_ok;
+        EK_MST_BEGIN;
         if (tid == 0) {
             const uint64_t t_start = wall_clock64();
             s_ok = 1;
@@ -214,6 +333,8 @@ ek_ms_chain_kernel(EkRound r, EkMsState *ms, EkMsXchg x, int nblk)
             }
         }
         __syncthreads();
+        if (h == 0)
+            EK_MST(6);  // helper 0: from its start to the go-ahead (the tail's time)
         if (tid < EK_TOP_M) {
             t_idx[tid] = (uint32_t)ek_coh_load((const int32_t *)&pub->idx[tid]);
             t_val[tid] = ek_coh_load(&pub->val[tid]);
@@ -224,10 +345,16 @@ ek_ms_chain_kernel(EkRound r, EkMsState *ms, EkMsXchg x, int nblk)
         const int n_off = t_n;
         const int A3 = 3 * r.A;
         const int cpr = (int)(ek_rec_bytes(r.A) / 16);      // 16-byte chunks per record
-        for (int j = h; j < n_off; j += EK_MS_HELPERS) {
-            const uint32_t fi = t_idx[j];
-            const float *src = r.aos + (size_t)fi * A3;
-            for (int item = tid; item < n_dst * cpr; item += EK_MS_THREADS) {
+        // (its records x the destinations x the chunks as ONE index space: with few
+        // destinations a loop per record left most threads idle, four times over)
+        const int n_mine = h < n_off ? (n_off - h + EK_MS_HELPERS - 1) / EK_MS_HELPERS : 0;
+        const int per_rec = n_dst * cpr;
+        {
+            for (int item0 = tid; item0 < n_mine * per_rec; item0 += EK_MS_THREADS) {
+                const int j = h + (item0 / per_rec) * EK_MS_HELPERS;
+                const int item = item0 % per_rec;
+                const uint32_t fi = t_idx[j];
+                const float *src = r.aos + (size_t)fi * A3;
                 const int p = item / cpr, q = item % cpr;
                 ek_f4 v;
                 if (q == 0) {
@@ -260,6 +387,11 @@ ek_ms_chain_kernel(EkRound r, EkMsState *ms, EkMsXchg x, int nblk)
         // this helper's stores acknowledged; the one that finishes last tells the peers
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if (h == 0)
+            EK_MST(7);  // helper 0: its records written and acknowledged
+#ifdef EK_MS_STAMPS
+        const unsigned long long mst_t5 = wall_clock64();
+#endif
         __shared__ int s_last;
         __shared__ unsigned long long s_wait;
         if (tid == 0) {
@@ -305,6 +437,12 @@ ek_ms_chain_kernel(EkRound r, EkMsState *ms, EkMsXchg x, int nblk)
         __syncthreads();
         if (s_last && x.sys && tid == 0)
             atomicAdd(&ms->wait_ticks_max, s_wait);
+#ifdef EK_MS_STAMPS
+        if (s_last && tid == 0) {   // the last helper: its flags out, all peers' flags seen
+            ek_ms_acc[5] += wall_clock64() - mst_t5;
+            ek_ms_cnt[5] += 1u;
+        }
+#endif
         return;
     }
     const int nb = (int)((r.n + EK_BLOCK - 1) / EK_BLOCK);
@@ -388,10 +526,12 @@ ek_ms_chain_kernel(EkRound r, EkMsState *ms, EkMsXchg x, int nblk)
     if (nblk > 1 && !ek_arrive_last(r.tick + 1, (unsigned int)nblk))
         return;
     // ---- the last workgroup ---------------------------------------------------------
+    EK_MST_BEGIN;
     // this shard's maximum of states 0 .. cn - 1 (what the decision looks at)
     if (cn > 0)
         ek_chain_reduce<true>(r.blockmax, r.pm, nb, nb, cn, sv, si);
     __syncthreads();
+    EK_MST(0);      // per-prefix maxima reduced
     // ---- round 6, mailbox transport: the headers first, the decision here ---------------
     // Every shard sends its per-prefix maxima (the head of its message), waits for the
     // others', and walks the chain as the plan kernel will (ek_chain_walk on the global
@@ -400,6 +540,7 @@ ek_ms_chain_kernel(EkRound r, EkMsState *ms, EkMsXchg x, int nblk)
     // that broke -- 30 % of the rounds of the headline case split 8 ways -- was offered
     // again in an exchange of its own (chain + plan + tile kernels on every shard).
     __shared__ int s_na, s_late;
+    __shared__ EkMsMaxima s_mx;
     const int head_words = (int)(head_bytes / 4);
     const bool two = x.sys && x.two_phase && mode == 1 && cn > 0;
     if (two) {
@@ -423,6 +564,7 @@ ek_ms_chain_kernel(EkRound r, EkMsState *ms, EkMsXchg x, int nblk)
         if (tid < x.world)
             ek_sys_store(x.dflag[tid] + (slot * 16) + 1, seq + 1u);
     }
+    EK_MST(1);      // headers out
     // its farthest frames of the state the offers are for: the one the whole chain would
     // leave or (the chain broke before: mode 2) the one it did leave.  Headers first: if
     // the peers' are in already (this shard was the last, or the only one) the chain is
@@ -436,18 +578,22 @@ ek_ms_chain_kernel(EkRound r, EkMsState *ms, EkMsXchg x, int nblk)
         if (tid == 0)
             s_in = 1;
         __syncthreads();
+        // (the flags, THEN the headers: a header fetched before its flag was seen could
+        // be an older exchange's)
         if (tid < x.world && tid != x.rank &&
             ek_sys_load(x.sflag + ((size_t)(seq & 1u) * x.world + tid) * 16 + 1) != seq + 1u)
             s_in = 0;
         __syncthreads();
         if (s_in) {
+            ek_ms_gather_maxima<true, EK_MS_THREADS>(r, x, seq, cn, s_mx);
             if (tid == 0)
-                s_na = ek_ms_walk(r, ms, x, seq, cn);
+                s_na = ek_ms_walk(r, ms, s_mx, cn);
             __syncthreads();
             ps = s_na;
             decided = true;
         }
     }
+    EK_MST(2);      // the look at the peers' flags, the walk if they are in
     EkTop *top = (EkTop *)r.top;
     for (;;) {
         // (the state the whole chain would leave: its maxima per 64 frames)
@@ -480,13 +626,15 @@ ek_ms_chain_kernel(EkRound r, EkMsState *ms, EkMsXchg x, int nblk)
         __syncthreads();
         if (s_late)
             break;
+        ek_ms_gather_maxima<true, EK_MS_THREADS>(r, x, seq, cn, s_mx);
         if (tid == 0)
-            s_na = ek_ms_walk(r, ms, x, seq, cn);
+            s_na = ek_ms_walk(r, ms, s_mx, cn);
         __syncthreads();
         if (s_na == cn)
             break;
         ps = s_na;
     }
+    EK_MST(3);      // pick(s), the wait for the headers
     // the list for the helpers, and the head of the message: this workgroup's part
     if (tid < EK_TOP_M) {
         ek_coh_store((int32_t *)&pub->idx[tid], (int32_t)top->idx[tid]);
@@ -522,6 +670,7 @@ ek_ms_chain_kernel(EkRound r, EkMsState *ms, EkMsXchg x, int nblk)
     // all of that in place, then the helpers may go
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    EK_MST(4);      // list + head published
     if (tid == 0) {
         r.tick[1] = 0;
         __hip_atomic_store(r.tick + 5, seq + 1u, __ATOMIC_RELAXED,
@@ -566,13 +715,24 @@ ek_ms_plan_kernel(EkRound r, EkMsState *ms, EkMsXchg x, float *D)
     const uint32_t seq = ms->seq;
     const int A = r.A;
     __shared__ int s_nrec[EK_MS_MAX_WORLD];
+    __shared__ int s_state[EK_MS_MAX_WORLD];
+    EK_MST_BEGIN;
     // (mailbox transport: the chain kernel did not end before every peer's
     // message of this exchange was in)
     if (tid < x.world)
         s_nrec[tid] = 0;
     __syncthreads();
-    if (tid < x.world)
+    // (the values of all record slots are fetched with the counts, not after them: one
+    // round trip to uncached memory instead of two; a slot beyond a shard's count holds an
+    // older exchange's record and is masked below)
+    const int n_slots = x.world * x.offer;      // <= EK_MS_SLOTS
+    float hv_raw = -__builtin_inff();
+    if (tid < EK_MS_SLOTS && tid < n_slots)
+        hv_raw = __uint_as_float(ek_msg_load<SYS>(ek_ms_rec<SYS>(x, tid, seq, A)));
+    if (tid < x.world) {
         s_nrec[tid] = (int)ek_msg_load<SYS>((const uint32_t *)ek_ms_src(x, tid, seq));
+        s_state[tid] = (int)ek_msg_load<SYS>((const uint32_t *)ek_ms_src(x, tid, seq) + 2);
+    }
     __syncthreads();
     // Round 6: up to 128 records are on offer (128 / world per shard, EK_MS_SLOTS), of
     // which the 64 with the largest distances -- slot order on ties -- compete: the far
@@ -581,7 +741,6 @@ ek_ms_plan_kernel(EkRound r, EkMsState *ms, EkMsXchg x, float *D)
     // quota were on no list -- 38 % of the rounds of the 10^6-frame fit's 8-way split
     // broke and were offered again, against 5 % on one shard.  smap[i] = the slot of the
     // i-th best; every workgroup works the map out for itself (128 headers, a rank each).
-    const int n_slots = x.world * x.offer;      // <= EK_MS_SLOTS
     __shared__ float s_hv[EK_MS_SLOTS];
     __shared__ int smap[64];
     __shared__ int s_nval;
@@ -592,7 +751,7 @@ ek_ms_plan_kernel(EkRound r, EkMsState *ms, EkMsXchg x, float *D)
     if (tid < EK_MS_SLOTS) {
         float v = -__builtin_inff();
         if (tid < n_slots && tid % x.offer < s_nrec[tid / x.offer])
-            v = __uint_as_float(ek_msg_load<SYS>(ek_ms_rec<SYS>(x, tid, seq, A)));
+            v = hv_raw;
         s_hv[tid] = v;
     }
     __syncthreads();
@@ -609,6 +768,8 @@ ek_ms_plan_kernel(EkRound r, EkMsState *ms, EkMsXchg x, float *D)
     }
     __syncthreads();
     const int n_cmp = s_nval < 64 ? s_nval : 64;    // records that compete
+    if (blockIdx.x == 0)
+        EK_MST(8);      // workgroup 0: counts, values and ranks of the records on offer
     {
         // one wave per pair of competing records; the values only steer the guesses,
         // so the lanes may stride over the atoms (but every shard computes the
@@ -624,30 +785,36 @@ ek_ms_plan_kernel(EkRound r, EkMsState *ms, EkMsXchg x, float *D)
             const int cpr_c = (3 * A + 3) / 4;      // 16-byte chunks of coordinates
             float S[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             // a lane takes 4 atoms = three chunks of either record at a time
-            for (int a0 = 4 * lane; a0 < A; a0 += 4 * EK_WAVE) {
-                const void *p[6];
-                ek_f4 v[6];
+            // (two strides of the atoms in flight at once: 300 atoms are one round trip to
+            // the mailboxes, not two)
+            for (int a0 = 4 * lane; a0 < A; a0 += 8 * EK_WAVE) {
+                const void *p[12];
+                ek_f4 v[12];
 #pragma unroll
-                for (int u = 0; u < 3; ++u) {
-                    const int c = min(3 * (a0 / 4) + u, cpr_c - 1);
-                    p[u] = bi + 16 * c;
-                    p[3 + u] = bj + 16 * c;
-                }
-                ek_msg_load4<SYS, 6>(p, v);
+                for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (a0 + e < A) {
-                        const float x0 = v[(3 * e) / 4][(3 * e) % 4],
-                                    x1 = v[(3 * e + 1) / 4][(3 * e + 1) % 4],
-                                    x2 = v[(3 * e + 2) / 4][(3 * e + 2) % 4];
-                        const float y0 = v[3 + (3 * e) / 4][(3 * e) % 4],
-                                    y1 = v[3 + (3 * e + 1) / 4][(3 * e + 1) % 4],
-                                    y2 = v[3 + (3 * e + 2) / 4][(3 * e + 2) % 4];
-                        S[0] += x0 * y0; S[1] += x0 * y1; S[2] += x0 * y2;
-                        S[3] += x1 * y0; S[4] += x1 * y1; S[5] += x1 * y2;
-                        S[6] += x2 * y0; S[7] += x2 * y1; S[8] += x2 * y2;
+                    for (int u = 0; u < 3; ++u) {
+                        const int c = min(3 * ((a0 + t * 4 * EK_WAVE) / 4) + u, cpr_c - 1);
+                        p[6 * t + u] = bi + 16 * c;
+                        p[6 * t + 3 + u] = bj + 16 * c;
                     }
-                }
+                ek_msg_load4<SYS, 12>(p, v);
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (a0 + t * 4 * EK_WAVE + e < A) {
+                            const float x0 = v[6 * t + (3 * e) / 4][(3 * e) % 4],
+                                        x1 = v[6 * t + (3 * e + 1) / 4][(3 * e + 1) % 4],
+                                        x2 = v[6 * t + (3 * e + 2) / 4][(3 * e + 2) % 4];
+                            const float y0 = v[6 * t + 3 + (3 * e) / 4][(3 * e) % 4],
+                                        y1 = v[6 * t + 3 + (3 * e + 1) / 4][(3 * e + 1) % 4],
+                                        y2 = v[6 * t + 3 + (3 * e + 2) / 4][(3 * e + 2) % 4];
+                            S[0] += x0 * y0; S[1] += x0 * y1; S[2] += x0 * y2;
+                            S[3] += x1 * y0; S[4] += x1 * y1; S[5] += x1 * y2;
+                            S[6] += x2 * y0; S[7] += x2 * y1; S[8] += x2 * y2;
+                        }
+                    }
             }
 #pragma unroll
             for (int q = 0; q < 9; ++q)
@@ -668,17 +835,20 @@ ek_ms_plan_kernel(EkRound r, EkMsState *ms, EkMsXchg x, float *D)
             }
         }
     }
+    if (blockIdx.x == 0)
+        EK_MST(9);      // workgroup 0: its pairs
     if (!ek_arrive_last_tree(r.tick + 2, r.tick + 64))
         return;
     // ---- the last workgroup ---------------------------------------------------------
+#ifdef EK_MS_STAMPS
+    mst_prev = wall_clock64();
+#endif
     __shared__ float sD[64 * 64];
     __shared__ float sval[64];
     __shared__ long long sgidx[64];
     __shared__ int sel[EK_MAX_CANDS];
     __shared__ int n_sel;
-    __shared__ float gv[EK_MAX_CANDS];          // global maximum of state k
-    __shared__ long long gg[EK_MAX_CANDS];
-    __shared__ int gok[EK_MAX_CANDS];
+    __shared__ EkMsMaxima s_mx;
     __shared__ int s_over, s_repick, s_short;
     {
         constexpr int PER = 64 * 64 / EK_BLOCK;
@@ -703,52 +873,36 @@ ek_ms_plan_kernel(EkRound r, EkMsState *ms, EkMsXchg x, float *D)
         sgidx[tid] = g;
     }
     const int cn = mode == 1 ? r.ord->n : 0;
-    if (tid < EK_MAX_CANDS) {
-        // state k's maximum over the shards: the largest, the lowest global
-        // index on ties (kcenters.py:337)
+    if (tid < EK_MAX_CANDS)
         sel[tid] = 0;
-        bool ok = false;
-        float v = 0.f;
-        long long g = 0;
-        if (tid < cn) {
-            for (int rk = 0; rk < x.world; ++rk) {
-                const uint32_t *h = (const uint32_t *)(ek_ms_src(x, rk, seq) +
-                                                       sizeof(EkMsMsg)) + 4 * tid;
-                if (!ek_msg_load<SYS>(h + 1))
-                    continue;
-                const float hv = __uint_as_float(ek_msg_load<SYS>(h));
-                const long long hg =
-                    (long long)((unsigned long long)ek_msg_load<SYS>(h + 2) |
-                                ((unsigned long long)ek_msg_load<SYS>(h + 3) << 32));
-                if (!ok || hv > v || (hv == v && hg < g)) {
-                    ok = true;
-                    v = hv;
-                    g = hg;
-                }
-            }
-        }
-        gv[tid] = v;
-        gg[tid] = g;
-        gok[tid] = ok ? 1 : 0;
-    }
-    __syncthreads();
+    // state k's maximum over the shards: the largest, the lowest global index on ties
+    // (kcenters.py:337)
+    ek_ms_gather_maxima<SYS, EK_BLOCK>(r, x, seq, cn, s_mx);
+    const float *gv = s_mx.gv;
+    const long long *gg = s_mx.gg;
+    const int *gok = s_mx.gok;
+    EK_MST(10);     // last workgroup: distances into LDS, values, global maxima
     if (tid == 0) {
         // the decision: ek_chain_walk / ek_round_chain_kernel on the global maxima
+        // (everything it reads, before anything it writes: one trip to memory)
         EkCtl c = *r.ctl;
+        const int l0 = r.plan->label;
+        const long long g0 = r.plan->gidx[0];
+        const float m0 = r.plan->maxdist[0];
+        uint32_t used = r.plan->used;
+        const int run_err = ms->err;
         if (mode == 1) {
             // candidate 0 of the pass that has just run is a center now
             // (kcenters.py:306-309): the count and the history move when its
             // distances are in, not when it was planned -- the host stops
             // enqueuing rounds when the count reaches its goal
-            const int l0 = r.plan->label;
-            r.hist[l0].gidx = r.plan->gidx[0];
-            r.hist[l0].dist = r.plan->maxdist[0];
+            r.hist[l0].gidx = g0;
+            r.hist[l0].dist = m0;
             r.hist[l0].set = 1;
             c.n_done = l0 + 1;
             c.n_rounds = c.n_rounds + 1;
         }
         const int label0 = c.n_done;
-        uint32_t used = r.plan->used;
         int na = 0;
         for (int k = 0; k < cn; ++k) {
             if (c.stopped || c.n_done >= c.limit || !gok[k])
@@ -758,8 +912,8 @@ ek_ms_plan_kernel(EkRound r, EkMsState *ms, EkMsXchg x, float *D)
                 c.stopped = 1;
                 break;
             }
-            const int j = r.ord->cand[k];
-            if (gg[k] != r.plan->gidx[j])           // the farthest point is not stored
+            const int j = s_mx.cj[k];
+            if (gg[k] != s_mx.cg[k])                // the farthest point is not stored
                 break;
             const int label = c.n_done;
             r.hist[label].gidx = gg[k];
@@ -787,13 +941,12 @@ ek_ms_plan_kernel(EkRound r, EkMsState *ms, EkMsXchg x, float *D)
         r.ctl->stopped = c.stopped;
         r.ctl->last_max = c.last_max;
         // (a message that never came: the run ends here, on every later launch too)
-        s_over = (c.stopped || c.n_done >= c.limit || ms->err) ? 1 : 0;
+        s_over = (c.stopped || c.n_done >= c.limit || run_err) ? 1 : 0;
         // the offers describe the state this chain left on every shard (headers first:
         // ek_ms_chain_kernel; or the whole chain held), or they are offered again
         bool agree = true;
         for (int rk = 0; rk < x.world; ++rk)
-            agree = agree && (int)ek_msg_load<SYS>((const uint32_t *)ek_ms_src(x, rk, seq) + 2)
-                                 == na;
+            agree = agree && s_state[rk] == na;
         s_repick = (!s_over && mode == 1 && !agree) ? 1 : 0;
         if (s_repick) {
             ms->pick_state = na;
@@ -801,6 +954,7 @@ ek_ms_plan_kernel(EkRound r, EkMsState *ms, EkMsXchg x, float *D)
         }
     }
     __syncthreads();
+    EK_MST(11);     // the decision
     const bool over = s_over != 0, repick = s_repick != 0;
     // ---- the next round's candidates among the records on offer ----------------------
     // (greedy, as ek_round_next_kernel: the record with the largest remaining
@@ -812,12 +966,22 @@ ek_ms_plan_kernel(EkRound r, EkMsState *ms, EkMsXchg x, float *D)
         float cur = open ? sval[lane] : 0.f;
         int ns = 0;
         while (ns < T) {
-            float v = open ? cur : -__builtin_inff();
-            uint32_t i = open ? (uint32_t)lane : 0xffffffffu;
-            ek_wave_argmax(v, i);
-            if (i == 0xffffffffu)
+            // (largest remaining distance, lowest slot on ties -- ek_better's order --: a
+            // maximum over the values' ordered bits, then the first lane that holds it)
+            if (__ballot(open) == 0ull)
                 break;
-            const int best = (int)i;
+            const unsigned int key = open ? ek_ord_bits(cur) : 0u;
+            unsigned int mx = key;
+            mx = max(mx, (unsigned int)__builtin_amdgcn_update_dpp(0, (int)mx, 0xB1, 0xf, 0xf, false));
+            mx = max(mx, (unsigned int)__builtin_amdgcn_update_dpp(0, (int)mx, 0x4E, 0xf, 0xf, false));
+            mx = max(mx, (unsigned int)__builtin_amdgcn_update_dpp(0, (int)mx, 0x141, 0xf, 0xf, false));
+            mx = max(mx, (unsigned int)__builtin_amdgcn_update_dpp(0, (int)mx, 0x140, 0xf, 0xf, false));
+            const unsigned int top =
+                max(max((unsigned int)__builtin_amdgcn_readlane((int)mx, 0),
+                        (unsigned int)__builtin_amdgcn_readlane((int)mx, 16)),
+                    max((unsigned int)__builtin_amdgcn_readlane((int)mx, 32),
+                        (unsigned int)__builtin_amdgcn_readlane((int)mx, 48)));
+            const int best = __ffsll((unsigned long long)__ballot(open && key == top)) - 1;
             if (lane == best)
                 open = false;
             if (lane == 0)
@@ -831,6 +995,7 @@ ek_ms_plan_kernel(EkRound r, EkMsState *ms, EkMsXchg x, float *D)
             n_sel = ns;
     }
     __syncthreads();
+    EK_MST(12);     // the greedy choice
     const int ns = n_sel;
     const float first_max = ns > 0 ? sval[sel[0]] : -__builtin_inff();
     const bool go = !over && !repick && ns > 0 && (double)first_max > r.cutoff;
@@ -936,6 +1101,7 @@ ek_ms_plan_kernel(EkRound r, EkMsState *ms, EkMsXchg x, float *D)
         }
         ms->seq = seq + 1u;
     }
+    EK_MST(13);     // records, plan
 }
 
 // The chosen records' coordinates of a round of 16 or 32, out of the mailboxes: into

@@ -91,5 +91,26 @@ d = np.concatenate([st.download_state()[0] for st in stores])
 a = np.concatenate([st.download_state()[1] for st in stores])
 print("centers equal: %s  distances equal: %s  labels equal: %s  final max %r / %r"
       % (ok, np.array_equal(d, rd), np.array_equal(a, ra), out[0][2], rmx), flush=True)
+# (a measurement build, -DEK_MS_STAMPS: where the chain and plan kernels' single workgroups
+# spend their time; ENSPARA_HIP_LIB names the variant library)
+import ctypes as C
+from enspara_amd import _lib
+try:
+    fn = _lib.load().ek_ms_stamps
+except AttributeError:
+    fn = None
+if fn is not None:
+    mean = (C.c_double * 32)()
+    cnt = (C.c_int64 * 32)()
+    fn(mean, cnt, 1)
+    names = {0: "chain tail: per-prefix maxima reduced", 1: "chain tail: headers out",
+             2: "chain tail: look at the flags (+ walk)", 3: "chain tail: pick(s) (+ wait, walk)",
+             4: "chain tail: list + head published", 5: "last helper: flags out, peers' flags seen",
+             6: "helper 0: start -> go-ahead", 7: "helper 0: records written",
+             8: "plan wg 0: counts, values, ranks", 9: "plan wg 0: its pairs",
+             10: "plan last wg: D into LDS, values, maxima", 11: "plan last wg: decision",
+             12: "plan last wg: greedy choice", 13: "plan last wg: records, plan"}
+    for k in sorted(names):
+        print("   %-48s %7.2f us  x %d" % (names[k], mean[k], cnt[k]), flush=True)
 for st in stores:
     st.close()
