@@ -61,6 +61,14 @@ if has ms; then
   python3 tools/ms_probe.py 125000 300 3000 1 -1 3 2>&1 | grep -v amdgpu.ids > $out/ms_125k_ladder_untraced.log
   MS_SWEEP=0 python3 tools/ms_probe.py 125000 300 3000 1 16 3 2>&1 | grep -v amdgpu.ids > $out/ms_125k_untraced_sweep_in_chain_kernel.log
   python3 tools/ms_probe.py 250000 300 3000 2 16 2 2>&1 | grep -v amdgpu.ids > $out/ms_2x125k_untraced.log
+  # the exchange in one step (rounds 3-5: speculating offers, a broken chain offered again)
+  MS_TWO_PHASE=0 python3 tools/ms_probe.py 125000 300 3000 1 16 3 2>&1 | grep -v amdgpu.ids > $out/ms_125k_untraced_one_step.log
+  MS_TWO_PHASE=0 python3 tools/ms_probe.py 250000 300 3000 2 16 2 2>&1 | grep -v amdgpu.ids > $out/ms_2x125k_untraced_one_step.log
+  MS_TWO_PHASE=0 python3 tools/ms_probe.py 1000000 300 5000 8 -1 1 2>&1 | grep -v amdgpu.ids > $out/ms_8x125k_one_step.log
+  # where the chain and plan kernels' single workgroups spend their time (-DEK_MS_STAMPS)
+  if [ -f enspara_amd/libenspara_hip_stamps.so ]; then
+    ENSPARA_HIP_LIB=$PWD/enspara_amd/libenspara_hip_stamps.so python3 tools/ms_probe.py 125000 300 3000 1 16 2 2>&1 | grep -v amdgpu.ids > $out/ms_125k_stamps.log
+  fi
   # the 8-way split of the headline case, whole fit: the decisions eight GPUs would take
   python3 tools/ms_probe.py 1000000 300 5000 8 -1 1 2>&1 | grep -v amdgpu.ids > $out/ms_8x125k.log
   python3 tools/ms_probe.py 1000000 300 3000 8 16 1 2>&1 | grep -v amdgpu.ids >> $out/ms_8x125k.log
