@@ -1,0 +1,95 @@
+"""Scratch: randomized comparison with the oracle, part 4: the rounds ACROSS shards with the
+exchange on the device (csrc/ek_mshard.hip, ek_ms_run) -- the shards are contexts of this one
+process on the one GPU, mailboxes by address, every shard's loop in its own host thread.
+Random shard counts (ragged and empty shards), frame / atom / template counts (duplicates and
+ties when the templates are few), center counts or distance cut-offs, round widths (the
+ladder, 8, 16, 32), the per-prefix maxima in the pass or in the chain kernel, and the exchange
+in two steps (per-prefix maxima first) or in one.  Every center, label and distance against
+oracle.cluster.kcenters.  usage: fuzz_ms.py [n_cases] [seed]"""
+import os
+import sys
+import threading
+import time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")    # shards that wait for one another: a HW queue each
+os.environ.setdefault("OMP_NUM_THREADS", "8")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from enspara_amd import sharded, synth
+from enspara_amd.device import FrameStore
+from oracle import cluster as oc
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+base = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+bad = 0
+t0 = time.time()
+n_reoffer = n_exch = 0
+for case in range(cases):
+    if case and case % 50 == 0:
+        print("... %d cases, %d mismatches, %.0f s" % (case, bad, time.time() - t0), flush=True)
+    rng = np.random.RandomState(base * 100003 + case)
+    shards = int(rng.choice([1, 2, 3, 4, 5, 8]))
+    n = int(rng.choice([40, 300, 777, 2048, 5000, 12000, 30000]))
+    A = int(rng.choice([1, 3, 5, 16, 33, 100]))
+    nt = int(rng.choice([1, 3, 11, 40]))
+    cands = int(rng.choice([-1, 8, 16, 32]))
+    two = int(rng.randint(2))
+    sweep = int(rng.choice([0, 1, 2]))
+    x = synth.synth(n, A, nt, seed=int(rng.randint(1 << 30)))
+    if rng.randint(4) == 0:
+        K, cutoff = 0, float(rng.choice([0.2, 0.5, 1.0]))
+    else:
+        K, cutoff = int(min(n, rng.choice([1, 2, 17, 64, 200, 700]))), 0.0
+    tag = "case %d shards=%d n=%d A=%d nt=%d K=%d cutoff=%g cands=%d two=%d sweep=%d" % (
+        case, shards, n, A, nt, K, cutoff, cands, two, sweep)
+    inds, wa, wd = oc.kcenters(x, n_clusters=K or None, dist_cutoff=cutoff or None)
+    stores = []
+    try:
+        for r in range(shards):
+            lo, cnt = sharded.shard_bounds(n, shards, r)
+            st = FrameStore(cnt, A, device=0, global_offset=lo)
+            st.load(x[lo:lo + cnt])
+            st.set_option("candidates", cands)
+            st.set_option("pass_sweep", sweep)
+            st.set_option("ms_two_phase", two)
+            st.ms_setup(shards, r)
+            st.reserve_centers(K if K else n)
+            st.reset_state()
+            st.sync()
+            stores.append(st)
+        boxes = [st.ms_mailbox() for st in stores]
+        for st in stores:
+            for p in range(shards):
+                st.ms_connect(p, boxes[p][0], boxes[p][1])
+        out = [None] * shards
+        errs = []
+
+        def work(r):
+            try:
+                out[r] = stores[r].ms_run(0, K if K else n, cutoff)
+            except Exception as e:     # noqa: BLE001 (reported below)
+                errs.append("shard %d: %s" % (r, e))
+
+        th = [threading.Thread(target=work, args=(r,)) for r in range(shards)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        ok = not errs
+        if ok:
+            parts = [st.download_state() for st in stores]
+            ok = (all(np.array_equal(o[0], np.array(inds)) for o in out)
+                  and np.array_equal(np.concatenate([p[1] for p in parts]), wa)
+                  and np.array_equal(np.concatenate([p[0] for p in parts]).astype(np.float64), wd)
+                  and out[0][2] == np.float32(wd.max()))
+            dg = stores[0].ms_diag()
+            n_reoffer += dg["reoffers"]
+            n_exch += dg["exchanges"]
+        if not ok:
+            bad += 1
+            print("MISMATCH", tag, errs[:2], flush=True)
+    finally:
+        for st in stores:
+            st.close()
+print("%d cases, %d mismatches, %.0f s (%d exchanges, %d of them without a pass)"
+      % (cases, bad, time.time() - t0, n_exch, n_reoffer), flush=True)
+sys.exit(1 if bad else 0)
