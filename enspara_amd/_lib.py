@@ -52,6 +52,7 @@ SYMBOLS = [
     "ek_feat_kcenters", "ek_feat_pam_sweep", "ek_feat_pam_release",
     "ek_set_frames_per_lane", "ek_set_option", "ek_get_option", "ek_last_run_timing",
     "ek_reserve_centers",
+    "ek_debug_guards",
     "ek_timing_begin", "ek_timing_end", "ek_timing_form", "ek_hbm_copy_rate",
     "ek_qcp_probe",
 ]
@@ -226,6 +227,8 @@ def load():
     L.ek_set_option.argtypes = [vp, i32, i32]
     L.ek_get_option.argtypes = [vp, i32, i32p]
     L.ek_reserve_centers.argtypes = [vp, i32]
+    if os.environ.get("ENSPARA_HIP_LIB") is None or hasattr(L, "ek_debug_guards"):
+        L.ek_debug_guards.argtypes = [vp]     # (a variant library from before it: tools/)
     L.ek_last_run_timing.argtypes = [vp, f32p, i32p]
     L.ek_timing_begin.argtypes = [vp, i32, i32]
     L.ek_timing_end.argtypes = [vp, f32p, i32p]
@@ -233,6 +236,8 @@ def load():
     L.ek_hbm_copy_rate.argtypes = [C.c_int, C.c_size_t, f64p]
     L.ek_qcp_probe.argtypes = [C.c_int, vp, vp, vp, i32, vp, C.c_int64, vp, vp, vp]
     for name in SYMBOLS:
+        if name == "ek_debug_guards" and os.environ.get("ENSPARA_HIP_LIB"):
+            continue        # (a variant library from before it: tools/)
         getattr(L, name)
     _lib = L
     return L

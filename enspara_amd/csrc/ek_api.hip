@@ -145,23 +145,77 @@ int ek_form_slot(int T)
     return T <= 1 ? 0 : (T == 4 ? 1 : (T == 8 ? 2 : (T == 16 ? 3 : 4)));
 }
 
+// EK_POISON=1 in the environment (tools/fuzz_*.py): working buffers start as 0x5a bytes
+// (a huge distance, a frame number nobody has) instead of whatever the allocator hands out -- a fresh process
+// gets zeroed pages, which hide a read of something nobody wrote yet; the hundredth
+// context of a process gets the ninety-ninth's remains.
+bool ek_poison()
+{
+    static const bool on = getenv("EK_POISON") != nullptr;
+    return on;
+}
+// hipMalloc, or (EK_POISON) hipMalloc with the contents poisoned and a guard page behind
+hipError_t ek_malloc_named(ek_ctx *c, void **ptr, size_t bytes, const char *name)
+{
+    if (!ek_poison())
+        return hipMalloc(ptr, bytes);
+    hipError_t e = hipMalloc(ptr, bytes + EK_GUARD_BYTES);
+    // (not 0xff: an index of -1 and a NaN distance are what the kernels treat as "nothing
+    // there"; 0x5a5a5a5a is a frame number no shard has and 1.5e16 a distance that wins)
+    static const int fill = getenv("EK_POISON_BYTE") ? (int)strtol(getenv("EK_POISON_BYTE"), nullptr, 0)
+                                                     : 0x5a;
+    if (e == hipSuccess)
+        e = hipMemset(*ptr, fill, bytes);
+    if (e == hipSuccess)
+        e = hipMemset((unsigned char *)*ptr + bytes, 0xA5, EK_GUARD_BYTES);
+    if (e == hipSuccess)
+        e = hipDeviceSynchronize();
+    if (e == hipSuccess)
+        c->guards.push_back({name, (unsigned char *)*ptr + bytes});
+    return e;
+}
+extern "C" int ek_debug_guards(ek_ctx *c)
+{
+    if (!c)
+        return ek_fail(EK_EARG, "NULL context");
+    EK_HIP(hipSetDevice(c->device));
+    EK_HIP(hipDeviceSynchronize());
+    int bad = 0;
+    std::vector<unsigned char> h(EK_GUARD_BYTES);
+    for (const ek_ctx::Guard &g : c->guards) {
+        // (a buffer that was grown since -- the history -- is gone with its guard)
+        if (hipMemcpy(h.data(), g.at, EK_GUARD_BYTES, hipMemcpyDeviceToHost) != hipSuccess) {
+            (void)hipGetLastError();
+            continue;
+        }
+        for (size_t k = 0; k < h.size(); ++k)
+            if (h[k] != 0xA5) {
+                fprintf(stderr, "enspara_hip: buffer %s overrun: byte + %zu behind its end "
+                                "is 0x%02x\n", g.name, k, h[k]);
+                ++bad;
+                break;
+            }
+    }
+    return bad;
+}
+
 int ek_spec_alloc(ek_ctx *c)
 {
     if (!c->top)
-        EK_HIP(hipMalloc((void **)&c->top, ek_top_scratch_bytes(c->A)));
+        EK_HIP(ek_malloc_named(c, (void **)&c->top, ek_top_scratch_bytes(c->A), "top"));
     if (!c->planD)
-        EK_HIP(hipMalloc((void **)&c->planD, 64 * 64 * sizeof(float)));
+        EK_HIP(ek_malloc_named(c, (void **)&c->planD, 64 * 64 * sizeof(float), "planD"));
     if (!c->pm) {
         const size_t nb = ((size_t)std::max<int64_t>(c->n, 1) + EK_BLOCK - 1) /
                           EK_BLOCK;
-        EK_HIP(hipMalloc((void **)&c->pm,
-                         (size_t)(EK_MAX_CANDS - 1) * nb * sizeof(EkBlockMax)));
-        EK_HIP(hipMalloc((void **)&c->fm, 4 * nb * sizeof(EkBlockMax)));
+        EK_HIP(ek_malloc_named(c, (void **)&c->pm,
+                               (size_t)(EK_MAX_CANDS - 1) * nb * sizeof(EkBlockMax), "pm"));
+        EK_HIP(ek_malloc_named(c, (void **)&c->fm, 4 * nb * sizeof(EkBlockMax), "fm"));
     }
     if (!c->vecs) {
-        EK_HIP(hipMalloc((void **)&c->vecs, (size_t)(EK_MAX_CANDS - 1) *
-                                                std::max<int64_t>(c->n_pad, 1) *
-                                                sizeof(float)));
+        const size_t bytes = (size_t)(EK_MAX_CANDS - 1) * std::max<int64_t>(c->n_pad, 1) *
+                             sizeof(float);
+        EK_HIP(ek_malloc_named(c, (void **)&c->vecs, bytes, "vecs"));
     }
     return EK_OK;
 }
@@ -337,7 +391,7 @@ extern "C" int ek_ctx_create(int device, int64_t n_frames, int32_t n_atoms,
     hipError_t e = hipSuccess;
 #define EK_ALLOC(ptr, bytes)                                                   \
     if (e == hipSuccess)                                                       \
-        e = hipMalloc((void **)&(ptr), (bytes));
+        e = ek_malloc_named(c, (void **)&(ptr), (bytes), #ptr);
     EK_ALLOC(c->tiles, nt * tile_floats * sizeof(float));
     EK_ALLOC(c->aos, nn * (size_t)3 * n_atoms * sizeof(float));
     EK_ALLOC(c->G, nn * sizeof(double));

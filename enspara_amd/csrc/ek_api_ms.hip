@@ -239,6 +239,15 @@ extern "C" int ek_spec_progress(ek_ctx *c, int32_t *n_done, int32_t *stopped)
 // ---- rounds across shards: one exchange per round (ek_mshard.hip) ------------------------
 // records a shard offers per exchange: EK_MS_SLOTS over all shards, at most the 64 its
 // pick lists (round 6: twice round 5's -- the plan kernel lets the 64 farthest compete)
+// Rounds of 8 between two looks at the ladder.  Rounds 3-5: 24 exchanges, of which the
+// early ones were a third exchanges without a pass -- 17 to 19 passes.  With the headers
+// first (round 6) an exchange is a pass, and 24 of them kept the million-frame fit in
+// rounds of 8 for 74 passes instead of 56 (0.338 s against 0.321); 12: 47 passes, 0.318 s
+// (16: 0.340; the 125 000-frame shard does not care: 12.85 / 13.0 / 12.9 us per center).
+// -DEK_MS_BATCH8=.. builds the others.
+#ifndef EK_MS_BATCH8
+#define EK_MS_BATCH8 12
+#endif
 static int ek_ms_offer(int world)
 {
     return std::max(1, std::min(64, EK_MS_SLOTS / std::max(world, 1)));
@@ -311,10 +320,22 @@ extern "C" int ek_ms_setup(ek_ctx *c, int32_t world, int32_t rank,
     // too early, whatever scope the load names: measured, two shards on one GPU
     // that started an exchange at the same moment waited for each other's flag
     // until the time-out.
-    EK_HIP(hipExtMallocWithFlags((void **)&c->ms_mbox, mb, hipDeviceMallocUncached));
-    EK_HIP(hipExtMallocWithFlags((void **)&c->ms_flags, fb, hipDeviceMallocUncached));
+    const size_t guard = ek_poison() ? EK_GUARD_BYTES : 0;      // (EK_POISON: ek_debug_guards)
+    EK_HIP(hipExtMallocWithFlags((void **)&c->ms_mbox, mb + guard, hipDeviceMallocUncached));
+    EK_HIP(hipExtMallocWithFlags((void **)&c->ms_flags, fb + guard, hipDeviceMallocUncached));
     EK_HIP(hipMemsetAsync(c->ms_mbox, 0, mb, c->stream));
     EK_HIP(hipMemsetAsync(c->ms_flags, 0, fb, c->stream));
+    if (guard) {
+        EK_HIP(hipMemsetAsync((unsigned char *)c->ms_mbox + mb, 0xA5, guard, c->stream));
+        EK_HIP(hipMemsetAsync((unsigned char *)c->ms_flags + fb, 0xA5, guard, c->stream));
+        for (size_t k = 0; k < c->guards.size();)       // (a second ek_ms_setup)
+            if (!strcmp(c->guards[k].name, "mailbox") || !strcmp(c->guards[k].name, "flags"))
+                c->guards.erase(c->guards.begin() + k);
+            else
+                ++k;
+        c->guards.push_back({"mailbox", (unsigned char *)c->ms_mbox + mb});
+        c->guards.push_back({"flags", (unsigned char *)c->ms_flags + fb});
+    }
     // the sequence numbers restart with the mailboxes (and with them the
     // helpers' go-ahead word, which carries one)
     EK_HIP(hipMemsetAsync(c->ms, 0, 64 + sizeof(EkCtl), c->stream));
@@ -674,7 +695,8 @@ extern "C" int ek_ms_run(ek_ctx *c, int32_t first_label, int32_t max_new,
         const int32_t left = goal - cr.n_done;
         int32_t batch = std::max(2, std::min(256, (int32_t)(left / per_round) + 2));
         if (ladder)
-            batch = std::min(batch, T == 8 ? 24 : (T == 16 ? 64 : 48));
+            batch = std::min(batch, T == 8 ? EK_MS_BATCH8 : (T == 16 ? 64 : 48));
+
         for (int32_t r = 0; r < batch; ++r) {
             rc = ek_ms_enqueue_local(c, R, x, r == 0 ? c->ms_ev : nullptr);
             if (rc)

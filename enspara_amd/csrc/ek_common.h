@@ -189,8 +189,15 @@ void ek_launch_round_flush(const EkRound &r, hipStream_t s);
 // leave + its `offer` farthest frames of the state the whole chain would leave
 // (records).  EkMsMsg | EkMaxHdr[EK_MAX_CANDS] | offer records.
 #define EK_MS_MAX_WORLD 64
-// records on offer in an exchange, over all shards (the 64 farthest compete: round 6)
-#define EK_MS_SLOTS 128
+// records on offer in an exchange, over all shards: 64 -- all of them compete.  Round 6
+// tried 128 (128 / world per shard, the 64 farthest compete: 5 % fewer passes in the 8-way
+// split of the headline case) and WITHDREW it: with three or more shards, runs in a process
+// that had created a few hundred contexts before accepted wrong centers or faulted
+// (tools/fuzz_ms.py: 5 of 5 sequences; 0 of 8 with 64 slots, the same kernels otherwise).
+// -DEK_MS_SLOTS=128 builds it.
+#ifndef EK_MS_SLOTS
+#define EK_MS_SLOTS 64
+#endif
 struct EkMsMsg {
     int32_t n_recs;         // valid records offered
     int32_t cn;             // states with a header

@@ -268,6 +268,10 @@ struct ek_ctx {
     EkChainOrd *ord = nullptr;
     EkChainRow *rows = nullptr;      // [EK_MAX_CANDS] candidate frames' rows
     uint32_t *vmask = nullptr;       // [n_pad / 64] which vectors a wave stored
+    // EK_POISON=1: every working buffer is followed by a guard page of 0xA5 bytes
+    // (ek_debug_guards: which ones something wrote past their end)
+    struct Guard { const char *name; unsigned char *at; };
+    std::vector<Guard> guards;
     unsigned int *tick = nullptr;    // [256] arrival counters: [0] pass, [1] chain,
                                      // [2] + [64..96) next, [3] legacy chain maxima,
                                      // [5] [6] multi-shard helpers, [128] + [129..161) PAM
@@ -350,6 +354,8 @@ void ek_launch_select_member_multi(const int32_t *assign, int64_t n, int32_t cid
 extern int ek_pam_pairs_form;    // ek_pam.hip: the pairs kernels through the matrix cores (key 21)
 int ek_form_slot(int T);
 int ek_spec_alloc(ek_ctx *c);
+bool ek_poison();
+#define EK_GUARD_BYTES 4096
 int ek_ensure_hist(ek_ctx *c, int32_t label);
 void ek_pam_forget(ek_ctx *c);
 int ek_upload_centers(ek_ctx *c, const float *xyz, int32_t K);

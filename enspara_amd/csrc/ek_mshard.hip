@@ -536,7 +536,11 @@ ek_ms_chain_kernel(EkRound r, EkMsState *ms, EkMsXchg x, int nblk)
             }
         }
     }
-    if (nblk > 1 && !ek_arrive_last(r.tick + 1, (unsigned int)nblk))
+    // (a single workgroup that swept still has to see ALL its waves' maxima before it
+    // reduces them: round 6 skipped the arrival -- waitcnt + barrier -- for one workgroup
+    // and a shard of up to 4096 frames in rounds of 8 read maxima of the round before, or
+    // of nobody: tools/fuzz_ms.py)
+    if ((nblk > 1 || (cn > 0 && !swept)) && !ek_arrive_last(r.tick + 1, (unsigned int)nblk))
         return;
     // ---- the last workgroup ---------------------------------------------------------
     EK_MST_BEGIN;
@@ -747,13 +751,13 @@ ek_ms_plan_kernel(EkRound r, EkMsState *ms, EkMsXchg x, float *D)
         s_state[tid] = (int)ek_msg_load<SYS>((const uint32_t *)ek_ms_src(x, tid, seq) + 2);
     }
     __syncthreads();
-    // Round 6: up to 128 records are on offer (128 / world per shard, EK_MS_SLOTS), of
-    // which the 64 with the largest distances -- slot order on ties -- compete: the far
-    // frames of a state are not spread evenly over the shards (64 of them over 8 shards:
-    // 8 +- 2.6 per shard), and with 64 / world offers per shard the ones beyond a shard's
-    // quota were on no list -- 38 % of the rounds of the 10^6-frame fit's 8-way split
-    // broke and were offered again, against 5 % on one shard.  smap[i] = the slot of the
-    // i-th best; every workgroup works the map out for itself (128 headers, a rank each).
+    // EK_MS_SLOTS records are on offer (EK_MS_SLOTS / world per shard), of which the 64 with
+    // the largest distances -- slot order on ties -- compete; smap[i] = the slot of the i-th
+    // best, every workgroup works the map out for itself.  With the 64 slots of the default
+    // build that is every valid record, in the order of their distances.  (Round 6 measured
+    // 128: the far frames of a state are not spread evenly over the shards -- 64 of them over
+    // 8 shards are 8 +- 2.6 per shard, and what exceeds a shard's quota is on no list --,
+    // 5 % fewer passes in the 8-way split; withdrawn, see EK_MS_SLOTS.)
     __shared__ float s_hv[EK_MS_SLOTS];
     __shared__ int smap[64];
     __shared__ int s_nval;

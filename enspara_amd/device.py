@@ -524,6 +524,14 @@ class FrameStore:
         (nothing is allocated -- no device-wide wait -- inside ms_run then)"""
         _lib.check(self.lib.ek_reserve_centers(self._h, int(n_centers)))
 
+    def debug_guards(self):
+        """(EK_POISON=1 in the environment) how many of this context's buffers were
+        written past their end; their names go to stderr"""
+        rc = int(self.lib.ek_debug_guards(self._h))
+        if rc < 0:
+            _lib.check(rc)
+        return rc
+
     def ms_run(self, first_label, max_new, dist_cutoff):
         """k-centers over all connected shards, exchange on the device; every
         shard calls it at the same time.  -> as kcenters_run"""

@@ -763,6 +763,12 @@ int ek_qcp_probe(int device, const float *S, const double *Gx, const double *Gy,
                  int32_t n_atoms, const float *cur, int64_t m, float *full,
                  float *below, unsigned char *cert);
 
+/* DEBUG (tools/fuzz_*.py).  With EK_POISON=1 in the environment when the library starts,
+ * every working buffer of a context starts as 0x5a bytes (EK_POISON_BYTE) and is followed by a guard page;
+ * this returns the number of buffers something wrote past the end of (their names go to
+ * stderr), 0 without EK_POISON. */
+int ek_debug_guards(ek_ctx *ctx);
+
 #ifdef __cplusplus
 }
 #endif

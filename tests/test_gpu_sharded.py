@@ -340,7 +340,8 @@ print("ok", len(inds), stores[0].ms_state())
     (2, 30000, 33, 300, 0.0, 16), (8, 40000, 20, 400, 0.0, 16),
     (2, 9000, 21, 70, 0.0, 32), (3, 600, 5, 40, 0.0, 32),
     (2, 30000, 33, 300, 0.0, 32), (8, 40000, 20, 400, 0.0, 32),
-    (4, 50000, 24, 20000, 0.0, -1)])     # configs[3]'s center count, the ladder
+    (4, 50000, 24, 20000, 0.0, -1),     # configs[3]'s center count, the ladder
+    (1, 777, 3, 200, 0.0, 8), (2, 777, 3, 200, 0.0, 16)])   # one sweeping workgroup per shard
 def test_mailbox_rounds_between_contexts(shards, n, A, K, cutoff, cands):
     """the rounds of csrc/ek_mshard.hip with the exchange on the device: the
     shards are contexts of ONE process on the one GPU, their mailboxes plain
@@ -356,6 +357,22 @@ def test_mailbox_rounds_between_contexts(shards, n, A, K, cutoff, cands):
                        env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     assert p.stdout.strip().splitlines()[-1].startswith("ok")
+
+
+def test_mailbox_rounds_in_a_process_that_has_seen_many_contexts():
+    """tools/fuzz_ms.py: 120 randomized multi-shard runs in ONE process (1 .. 8 shards, ragged
+    and empty shards, 1 .. 100 atoms, center counts and cut-offs, the ladder and pinned round
+    widths, the exchange in one step and in two) against the oracle.  Round 6's review of its
+    own work: a shard of up to 4096 frames in rounds of 8 reduced its waves' maxima before all
+    of them were written (one workgroup: no arrival, so no barrier), and 128 records on offer
+    broke runs of three and more shards once a process had created a few hundred contexts --
+    neither shows in a process that runs one configuration."""
+    env = dict(os.environ)
+    env["GPU_MAX_HW_QUEUES"] = "16"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_ms.py"), "120", "0"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    assert "120 cases, 0 mismatches" in p.stdout, p.stdout[-2000:]
 
 
 _CHILD_TI = r"""

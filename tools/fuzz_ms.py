@@ -5,14 +5,16 @@ Random shard counts (ragged and empty shards), frame / atom / template counts (d
 ties when the templates are few), center counts or distance cut-offs, round widths (the
 ladder, 8, 16, 32), the per-prefix maxima in the pass or in the chain kernel, and the exchange
 in two steps (per-prefix maxima first) or in one.  Every center, label and distance against
-oracle.cluster.kcenters.  usage: fuzz_ms.py [n_cases] [seed]"""
+oracle.cluster.kcenters.  usage: fuzz_ms.py [n_cases] [seed] [first_case]; FUZZ_VERBOSE=1
+prints every case before it runs."""
 import os
 import sys
 import threading
 import time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")    # shards that wait for one another: a HW queue each
 os.environ.setdefault("OMP_NUM_THREADS", "8")
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.environ.get("FUZZ_ROOT") or      # (another tree's package: bisecting)
+                os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from enspara_amd import sharded, synth
 from enspara_amd.device import FrameStore
@@ -20,10 +22,11 @@ from oracle import cluster as oc
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 base = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+first = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 bad = 0
 t0 = time.time()
 n_reoffer = n_exch = 0
-for case in range(cases):
+for case in range(first, first + cases):
     if case and case % 50 == 0:
         print("... %d cases, %d mismatches, %.0f s" % (case, bad, time.time() - t0), flush=True)
     rng = np.random.RandomState(base * 100003 + case)
@@ -34,6 +37,14 @@ for case in range(cases):
     cands = int(rng.choice([-1, 8, 16, 32]))
     two = int(rng.randint(2))
     sweep = int(rng.choice([0, 1, 2]))
+    if os.environ.get("FUZZ_TWO"):      # (bisecting a failure)
+        two = int(os.environ["FUZZ_TWO"])
+    if os.environ.get("FUZZ_CANDS"):
+        cands = int(os.environ["FUZZ_CANDS"])
+    if os.environ.get("FUZZ_SHARDS"):
+        shards = int(os.environ["FUZZ_SHARDS"])
+    if os.environ.get("FUZZ_SWEEP"):
+        sweep = int(os.environ["FUZZ_SWEEP"])
     x = synth.synth(n, A, nt, seed=int(rng.randint(1 << 30)))
     if rng.randint(4) == 0:
         K, cutoff = 0, float(rng.choice([0.2, 0.5, 1.0]))
@@ -41,6 +52,8 @@ for case in range(cases):
         K, cutoff = int(min(n, rng.choice([1, 2, 17, 64, 200, 700]))), 0.0
     tag = "case %d shards=%d n=%d A=%d nt=%d K=%d cutoff=%g cands=%d two=%d sweep=%d" % (
         case, shards, n, A, nt, K, cutoff, cands, two, sweep)
+    if os.environ.get("FUZZ_VERBOSE"):
+        print(tag, flush=True)
     inds, wa, wd = oc.kcenters(x, n_clusters=K or None, dist_cutoff=cutoff or None)
     stores = []
     try:
@@ -48,11 +61,18 @@ for case in range(cases):
             lo, cnt = sharded.shard_bounds(n, shards, r)
             st = FrameStore(cnt, A, device=0, global_offset=lo)
             st.load(x[lo:lo + cnt])
-            st.set_option("candidates", cands)
-            st.set_option("pass_sweep", sweep)
-            st.set_option("ms_two_phase", two)
+            st.set_option(4, cands)
+            try:
+                st.set_option("pass_sweep", sweep)
+            except Exception:       # noqa: BLE001 (a tree from before the option)
+                pass
+            try:
+                st.set_option("ms_two_phase", two)
+            except Exception:       # noqa: BLE001 (a library from before the option, bisecting)
+                pass
             st.ms_setup(shards, r)
-            st.reserve_centers(K if K else n)
+            if hasattr(st, "reserve_centers"):
+                st.reserve_centers(K if K else n)
             st.reset_state()
             st.sync()
             stores.append(st)
@@ -81,12 +101,33 @@ for case in range(cases):
                   and np.array_equal(np.concatenate([p[1] for p in parts]), wa)
                   and np.array_equal(np.concatenate([p[0] for p in parts]).astype(np.float64), wd)
                   and out[0][2] == np.float32(wd.max()))
-            dg = stores[0].ms_diag()
-            n_reoffer += dg["reoffers"]
-            n_exch += dg["exchanges"]
+            try:
+                dg = stores[0].ms_diag()
+                n_reoffer += dg["reoffers"]
+                n_exch += dg["exchanges"]
+            except Exception:       # noqa: BLE001
+                pass
+        if os.environ.get("EK_POISON"):
+            over = [st.debug_guards() for st in stores]
+            if any(over):
+                print("OVERRUN", tag, over, flush=True)
+                ok = False
         if not ok:
             bad += 1
             print("MISMATCH", tag, errs[:2], flush=True)
+            if not errs:
+                got = np.asarray(out[0][0])
+                want = np.array(inds)
+                m = min(len(got), len(want))
+                neq = np.nonzero(got[:m] != want[:m])[0]
+                print("   centers: %d found, %d expected, first difference at %s; per shard equal: %s"
+                      % (len(got), len(want), neq[:1], [bool(np.array_equal(o[0], out[0][0])) for o in out]),
+                      flush=True)
+                a = np.concatenate([p[1] for p in parts])
+                d = np.concatenate([p[0] for p in parts]).astype(np.float64)
+                print("   labels differ at %d frames, distances at %d; final max %r / %r"
+                      % (int((a != wa).sum()), int((d != wd).sum()), out[0][2], np.float32(wd.max())),
+                      flush=True)
     finally:
         for st in stores:
             st.close()

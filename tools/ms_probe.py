@@ -48,7 +48,7 @@ for r in range(S):
     st.set_option(4, T)
     st.set_option("pass_sweep", int(os.environ.get("MS_SWEEP", "1")))
     st.set_option("ms_two_phase", int(os.environ.get("MS_TWO_PHASE", "1")))
-    st.set_option(18, 1 if cnt < 300000 else 0)     # (what sharded.kcenters_sharded sets)
+    st.set_option(18, int(os.environ.get("MS_SMALL", 1 if cnt < 300000 else 0)))     # (what sharded.kcenters_sharded sets)
     st.ms_setup(S, r)
     st.reserve_centers(K)
     stores.append(st)
