@@ -433,7 +433,9 @@ class HostShardChain(HostShardRounds):
             self._accept(cands[j], float(w["maxdist"]))
 
 
-MS_MSG = np.dtype([("n_recs", "<i4"), ("cn", "<i4"), ("pad", "<i4", (2,))])
+# (state: the state the offered records are the far frames of -- round 6; with the caller's
+# collective as the exchange that is the state the whole chain would leave, or -1 without one)
+MS_MSG = np.dtype([("n_recs", "<i4"), ("cn", "<i4"), ("state", "<i4"), ("pad", "<i4")])
 MAX_CANDS = 32      # EK_MAX_CANDS: the per-prefix headers of a message
 
 
@@ -521,6 +523,7 @@ class HostShardMs(HostShard):
             order = [first] + rest[:self.offer - 1]
         head = np.zeros(1, dtype=MS_MSG)
         head["n_recs"], head["cn"] = len(order), cn
+        head["state"] = ps if self.mode == 1 else -1
         buf[:16] = head.view(np.uint8)
         buf[16:16 + hdrs.nbytes] = hdrs.view(np.uint8)
         rb = self.record_bytes
@@ -577,7 +580,10 @@ class HostShardMs(HostShard):
         if over:
             self.mode = 0
             return
-        if self.mode == 1 and short:
+        # (the offers describe the state this chain left on every shard, or they are
+        # offered again: ek_ms_plan_kernel's `agree`)
+        if self.mode == 1 and not all(int(h["state"]) == na for h in heads):
+            assert short
             self.mode, self.pick_state = 2, na
             self.repicks += 1
             return
