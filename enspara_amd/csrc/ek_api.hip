@@ -1,5 +1,6 @@
 // ek_api.hip -- the C ABI of include/enspara_hip.h (host side).
 #include "ek_ctx.h"
+#include <mutex>
 #include "ek_qcp.h"
 
 static thread_local char g_err[512] = "";
@@ -145,6 +146,54 @@ int ek_form_slot(int T)
     return T <= 1 ? 0 : (T == 4 ? 1 : (T == 8 ? 2 : (T == 16 ? 3 : 4)));
 }
 
+// Uncached device memory (the mailboxes of ek_mshard.hip) is never given back to the
+// runtime: a block that a context is done with waits here for the next context that asks
+// for one of its size.  Round 6, tools/fuzz_ms.py: hipFree of memory that came from
+// hipExtMallocWithFlags(hipDeviceMallocUncached), followed by ordinary allocations, left a
+// process in which LATER allocations overlapped live ones -- a context's upload landed in
+// another context's frames (256 of 768 frames of shard 0 changed when shard 1 loaded its
+// own), runs accepted wrong centers or faulted, the more often the larger the blocks
+// (three or more shards, 300 - 500 atoms: 7 of 60 runs; with the blocks kept: 0).  A process
+// that sets its mailboxes up once (one per GPU: the product's case) never frees one.
+namespace {
+struct EkUcBlock { int device; void *ptr; size_t bytes; };
+std::mutex g_uc_mutex;
+std::vector<EkUcBlock> g_uc_free, g_uc_live;
+}
+hipError_t ek_uncached_alloc(int device, void **ptr, size_t bytes)
+{
+    std::lock_guard<std::mutex> lock(g_uc_mutex);
+    size_t best = (size_t)-1;
+    for (size_t k = 0; k < g_uc_free.size(); ++k)
+        if (g_uc_free[k].device == device && g_uc_free[k].bytes >= bytes &&
+            (best == (size_t)-1 || g_uc_free[k].bytes < g_uc_free[best].bytes))
+            best = k;
+    if (best != (size_t)-1) {
+        *ptr = g_uc_free[best].ptr;
+        g_uc_live.push_back(g_uc_free[best]);
+        g_uc_free.erase(g_uc_free.begin() + best);
+        return hipSuccess;
+    }
+    // (whole 64 KB: fewer sizes, more reuse)
+    const size_t rounded = (bytes + 65535) & ~(size_t)65535;
+    const hipError_t e = hipExtMallocWithFlags(ptr, rounded, hipDeviceMallocUncached);
+    if (e == hipSuccess)
+        g_uc_live.push_back({device, *ptr, rounded});
+    return e;
+}
+void ek_uncached_free(int device, void *ptr)
+{
+    if (!ptr)
+        return;
+    std::lock_guard<std::mutex> lock(g_uc_mutex);
+    for (size_t k = 0; k < g_uc_live.size(); ++k)
+        if (g_uc_live[k].ptr == ptr && g_uc_live[k].device == device) {
+            g_uc_free.push_back(g_uc_live[k]);
+            g_uc_live.erase(g_uc_live.begin() + k);
+            return;
+        }
+}
+
 // EK_POISON=1 in the environment (tools/fuzz_*.py): working buffers start as 0x5a bytes
 // (a huge distance, a frame number nobody has) instead of whatever the allocator hands out -- a fresh process
 // gets zeroed pages, which hide a read of something nobody wrote yet; the hundredth
@@ -288,8 +337,8 @@ int ek_free_all(ek_ctx *c)
     for (void *m : c->ms_ipc)
         (void)hipIpcCloseMemHandle(m);
     (void)hipFree(c->ms);
-    (void)hipFree(c->ms_mbox);
-    (void)hipFree(c->ms_flags);
+    ek_uncached_free(c->device, c->ms_mbox);
+    ek_uncached_free(c->device, c->ms_flags);
     (void)hipFree(c->recsT);
     (void)hipFree(c->ctile);
     (void)hipFree(c->ctrace);

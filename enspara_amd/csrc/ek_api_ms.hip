@@ -301,8 +301,8 @@ extern "C" int ek_ms_setup(ek_ctx *c, int32_t world, int32_t rank,
     for (void *m : c->ms_ipc)
         (void)hipIpcCloseMemHandle(m);
     c->ms_ipc.clear();
-    (void)hipFree(c->ms_mbox);
-    (void)hipFree(c->ms_flags);
+    ek_uncached_free(c->device, c->ms_mbox);
+    ek_uncached_free(c->device, c->ms_flags);
     c->ms_mbox = nullptr;
     c->ms_flags = nullptr;
     if (!c->ms)     // (+ a scratch control block for ek_ms_end's pick)
@@ -321,8 +321,8 @@ extern "C" int ek_ms_setup(ek_ctx *c, int32_t world, int32_t rank,
     // that started an exchange at the same moment waited for each other's flag
     // until the time-out.
     const size_t guard = ek_poison() ? EK_GUARD_BYTES : 0;      // (EK_POISON: ek_debug_guards)
-    EK_HIP(hipExtMallocWithFlags((void **)&c->ms_mbox, mb + guard, hipDeviceMallocUncached));
-    EK_HIP(hipExtMallocWithFlags((void **)&c->ms_flags, fb + guard, hipDeviceMallocUncached));
+    EK_HIP(ek_uncached_alloc(c->device, (void **)&c->ms_mbox, mb + guard));
+    EK_HIP(ek_uncached_alloc(c->device, (void **)&c->ms_flags, fb + guard));
     EK_HIP(hipMemsetAsync(c->ms_mbox, 0, mb, c->stream));
     EK_HIP(hipMemsetAsync(c->ms_flags, 0, fb, c->stream));
     if (guard) {

@@ -189,14 +189,16 @@ void ek_launch_round_flush(const EkRound &r, hipStream_t s);
 // leave + its `offer` farthest frames of the state the whole chain would leave
 // (records).  EkMsMsg | EkMaxHdr[EK_MAX_CANDS] | offer records.
 #define EK_MS_MAX_WORLD 64
-// records on offer in an exchange, over all shards: 64 -- all of them compete.  Round 6
-// tried 128 (128 / world per shard, the 64 farthest compete: 5 % fewer passes in the 8-way
-// split of the headline case) and WITHDREW it: with three or more shards, runs in a process
-// that had created a few hundred contexts before accepted wrong centers or faulted
-// (tools/fuzz_ms.py: 5 of 5 sequences; 0 of 8 with 64 slots, the same kernels otherwise).
-// -DEK_MS_SLOTS=128 builds it.
+// records on offer in an exchange, over all shards: 128 (128 / world per shard, at most the 64
+// a shard's pick lists), of which the plan kernel lets the 64 farthest compete -- the far
+// frames of a state are not spread evenly over the shards (64 of them over 8 shards: 8 +- 2.6
+// per shard), and with 64 / world offers per shard the ones beyond a shard's quota were on no
+// list: 420 -> 407 passes for the headline case split 8 ways.  (For half a day of round 6 this
+// stood accused of breaking runs of three and more shards in long-lived processes; what broke
+// them was hipFree of uncached memory -- ek_uncached_alloc in ek_api.hip --, which larger
+// mailboxes provoked sooner.  -DEK_MS_SLOTS=64 builds round 5's quota.)
 #ifndef EK_MS_SLOTS
-#define EK_MS_SLOTS 64
+#define EK_MS_SLOTS 128
 #endif
 struct EkMsMsg {
     int32_t n_recs;         // valid records offered

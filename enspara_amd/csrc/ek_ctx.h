@@ -355,6 +355,9 @@ extern int ek_pam_pairs_form;    // ek_pam.hip: the pairs kernels through the ma
 int ek_form_slot(int T);
 int ek_spec_alloc(ek_ctx *c);
 bool ek_poison();
+// uncached device memory, kept for reuse instead of freed (ek_api.hip)
+hipError_t ek_uncached_alloc(int device, void **ptr, size_t bytes);
+void ek_uncached_free(int device, void *ptr);
 #define EK_GUARD_BYTES 4096
 int ek_ensure_hist(ek_ctx *c, int32_t label);
 void ek_pam_forget(ek_ctx *c);

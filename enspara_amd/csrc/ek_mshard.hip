@@ -751,13 +751,11 @@ ek_ms_plan_kernel(EkRound r, EkMsState *ms, EkMsXchg x, float *D)
         s_state[tid] = (int)ek_msg_load<SYS>((const uint32_t *)ek_ms_src(x, tid, seq) + 2);
     }
     __syncthreads();
-    // EK_MS_SLOTS records are on offer (EK_MS_SLOTS / world per shard), of which the 64 with
-    // the largest distances -- slot order on ties -- compete; smap[i] = the slot of the i-th
-    // best, every workgroup works the map out for itself.  With the 64 slots of the default
-    // build that is every valid record, in the order of their distances.  (Round 6 measured
-    // 128: the far frames of a state are not spread evenly over the shards -- 64 of them over
-    // 8 shards are 8 +- 2.6 per shard, and what exceeds a shard's quota is on no list --,
-    // 5 % fewer passes in the 8-way split; withdrawn, see EK_MS_SLOTS.)
+    // Up to 128 records are on offer (EK_MS_SLOTS / world per shard), of which the 64 with the
+    // largest distances -- slot order on ties -- compete: the far frames of a state are not
+    // spread evenly over the shards (64 of them over 8 shards: 8 +- 2.6 per shard), and with
+    // 64 / world offers per shard the ones beyond a shard's quota were on no list.  smap[i] =
+    // the slot of the i-th best; every workgroup works the map out for itself.
     __shared__ float s_hv[EK_MS_SLOTS];
     __shared__ int smap[64];
     __shared__ int s_nval;

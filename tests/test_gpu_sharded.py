@@ -362,11 +362,13 @@ def test_mailbox_rounds_between_contexts(shards, n, A, K, cutoff, cands):
 def test_mailbox_rounds_in_a_process_that_has_seen_many_contexts():
     """tools/fuzz_ms.py: 120 randomized multi-shard runs in ONE process (1 .. 8 shards, ragged
     and empty shards, 1 .. 100 atoms, center counts and cut-offs, the ladder and pinned round
-    widths, the exchange in one step and in two) against the oracle.  Round 6's review of its
-    own work: a shard of up to 4096 frames in rounds of 8 reduced its waves' maxima before all
-    of them were written (one workgroup: no arrival, so no barrier), and 128 records on offer
-    broke runs of three and more shards once a process had created a few hundred contexts --
-    neither shows in a process that runs one configuration."""
+    widths, the exchange in one step and in two) against the oracle.  What round 6 found with
+    it: a shard of up to 4096 frames in rounds of 8 reduced its waves' maxima before all of
+    them were written (one workgroup: no arrival, so no barrier); and hipFree of the
+    mailboxes' uncached memory left the process with allocations that overlapped live ones
+    -- an upload landing in another context's frames, wrong centers, faults -- once a few
+    hundred contexts had come and gone (the blocks are kept for reuse now, ek_uncached_alloc).
+    Neither shows in a process that runs one configuration."""
     env = dict(os.environ)
     env["GPU_MAX_HW_QUEUES"] = "16"
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_ms.py"), "120", "0"],

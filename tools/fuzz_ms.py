@@ -43,6 +43,10 @@ for case in range(first, first + cases):
         cands = int(os.environ["FUZZ_CANDS"])
     if os.environ.get("FUZZ_SHARDS"):
         shards = int(os.environ["FUZZ_SHARDS"])
+    if os.environ.get("FUZZ_ATOMS"):        # (e.g. "300,500": the bench shapes' atom counts)
+        A = int(rng.choice([int(v) for v in os.environ["FUZZ_ATOMS"].split(",")]))
+    if os.environ.get("FUZZ_SHARDS_MIN"):
+        shards = max(shards, int(os.environ["FUZZ_SHARDS_MIN"]))
     if os.environ.get("FUZZ_SWEEP"):
         sweep = int(os.environ["FUZZ_SWEEP"])
     x = synth.synth(n, A, nt, seed=int(rng.randint(1 << 30)))
@@ -54,13 +58,40 @@ for case in range(first, first + cases):
         case, shards, n, A, nt, K, cutoff, cands, two, sweep)
     if os.environ.get("FUZZ_VERBOSE"):
         print(tag, flush=True)
+    if os.environ.get("FUZZ_MEM"):      # (free device memory before the case: a leak shows)
+        if case == first:
+            sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "c4"))
+            import c4gen
+            hip = c4gen.Hip()
+        print("   free %.3f GB" % (hip.mem_info()[0] / 1e9), flush=True)
     inds, wa, wd = oc.kcenters(x, n_clusters=K or None, dist_cutoff=cutoff or None)
     stores = []
     try:
         for r in range(shards):
             lo, cnt = sharded.shard_bounds(n, shards, r)
+            def watch(step):        # (FUZZ_WATCH: which step of a later store spoils an earlier one's frames)
+                if not os.environ.get("FUZZ_WATCH"):
+                    return
+                from oracle import qcp
+                Pw = qcp.Prepared(x)
+                for q, sq in enumerate(stores):
+                    l2, c2 = sharded.shard_bounds(n, shards, q)
+                    if c2 == 0:
+                        continue
+                    got = np.asarray(sq.rmsd_to_xyz(x[0]), dtype=np.float32)
+                    want = np.asarray(qcp.rmsd_centered(np.ascontiguousarray(Pw.c[l2:l2 + c2]),
+                                                        np.ascontiguousarray(Pw.G[l2:l2 + c2]),
+                                                        Pw.c[0], float(Pw.G[0])), dtype=np.float32)
+                    if not np.array_equal(got, want):
+                        print("WATCH", tag, "store", q, "is wrong after store", r, "did", step,
+                              int((got != want).sum()), "of", c2, flush=True)
+                    sq.reset_state()
+                    sq.sync()
             st = FrameStore(cnt, A, device=0, global_offset=lo)
+            watch("create")
             st.load(x[lo:lo + cnt])
+            st.sync()
+            watch("load")
             st.set_option(4, cands)
             try:
                 st.set_option("pass_sweep", sweep)
@@ -71,11 +102,41 @@ for case in range(first, first + cases):
             except Exception:       # noqa: BLE001 (a library from before the option, bisecting)
                 pass
             st.ms_setup(shards, r)
+            watch("ms_setup")
             if hasattr(st, "reserve_centers"):
                 st.reserve_centers(K if K else n)
+            watch("reserve_centers")
             st.reset_state()
             st.sync()
+            if os.environ.get("FUZZ_CHECK_LOAD") and cnt:
+                from oracle import qcp
+                Pq = qcp.Prepared(x)
+                got = np.asarray(st.rmsd_to_xyz(x[0]), dtype=np.float32)
+                want = np.asarray(qcp.rmsd_centered(np.ascontiguousarray(Pq.c[lo:lo + cnt]),
+                                                    np.ascontiguousarray(Pq.G[lo:lo + cnt]),
+                                                    Pq.c[0], float(Pq.G[0])), dtype=np.float32)
+                if not np.array_equal(got, want):
+                    print("LOAD0", tag, "shard", r, int((got != want).sum()), "of", cnt,
+                          "wrong right after its own load", flush=True)
+                st.reset_state()
+                st.sync()
             stores.append(st)
+        if os.environ.get("FUZZ_CHECK_LOAD"):   # (are the frames on the device the caller's?)
+            from oracle import qcp
+            P = qcp.Prepared(x)
+            for r, st in enumerate(stores):
+                lo, cnt = sharded.shard_bounds(n, shards, r)
+                if cnt == 0:
+                    continue
+                got = np.asarray(st.rmsd_to_xyz(x[0]), dtype=np.float32)
+                want = qcp.rmsd_centered(np.ascontiguousarray(P.c[lo:lo + cnt]),
+                                         np.ascontiguousarray(P.G[lo:lo + cnt]), P.c[0],
+                                         float(P.G[0]))
+                if not np.array_equal(got, np.asarray(want, dtype=np.float32)):
+                    print("LOAD", tag, "shard", r, int((got != want).sum()), "of", cnt,
+                          "distances to frame 0 differ right after the load", flush=True)
+                st.reset_state()
+                st.sync()
         boxes = [st.ms_mailbox() for st in stores]
         for st in stores:
             for p in range(shards):
