@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 6: the numbers DESIGN.md / profiles/r06 quote, from one box and HEAD.
 # usage: profile_r06.sh <outdir-under-gpurun_out> [part ...]
-#   parts: tests bench full trace pmc c3 ms sweep msm probe c4
+#   parts: tests bench full trace pmc c3 ms sweep msm probe driver fuzz c4
 out=gpurun_out/$1; shift
 parts=${@:-bench trace pmc c3 ms sweep msm probe}
 mkdir -p $out
@@ -91,6 +91,19 @@ if has msm; then
 fi
 if has probe; then
   ./tools/probes/split_probe 2>&1 | grep -v amdgpu.ids > $out/split_probe.log; cat $out/split_probe.log
+fi
+if has driver; then
+  # the driver's own command (the kernel sources' hash must match profiles/traffic.json)
+  python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_driver_command.json 2> $out/bench_driver_command.err
+  python3 -c "import json; d = json.load(open('$out/bench_driver_command.json')); print('driver command', d['value'], d['roofline']['frac'], d['roofline'].get('traffic'), d['roofline_one_center'].get('traffic'))"
+fi
+if has fuzz; then
+  mkdir -p $out/fuzz
+  python3 tools/fuzz_ms.py 400 61 2>&1 | grep -v amdgpu.ids > $out/fuzz/fuzz_ms_400_61.log; tail -1 $out/fuzz/fuzz_ms_400_61.log
+  FUZZ_ATOMS=300,500 FUZZ_SHARDS_MIN=3 python3 tools/fuzz_ms.py 150 50 2>&1 | grep -v amdgpu.ids > $out/fuzz/fuzz_ms_150_50_300_500_atoms.log; tail -1 $out/fuzz/fuzz_ms_150_50_300_500_atoms.log
+  EK_POISON=1 python3 tools/fuzz_ms.py 400 63 2>&1 | grep -v amdgpu.ids > $out/fuzz/fuzz_ms_400_63_poisoned.log; tail -1 $out/fuzz/fuzz_ms_400_63_poisoned.log
+  python3 tools/fuzz_gpu.py 2000 31 2>&1 | grep -v amdgpu.ids > $out/fuzz/fuzz_gpu_2000_31.log; tail -1 $out/fuzz/fuzz_gpu_2000_31.log
+  python3 tools/fuzz_gpu2.py 800 32 2>&1 | grep -v amdgpu.ids > $out/fuzz/fuzz_gpu2_800_32.log; tail -1 $out/fuzz/fuzz_gpu2_800_32.log
 fi
 if has c4; then
   bash tools/jobs/r6_c4.sh ${out#gpurun_out/}/c4
