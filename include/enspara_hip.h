@@ -209,7 +209,7 @@ int ek_spec_chain_apply(ek_ctx *ctx, const void *hdrs_all, int32_t n_shards,
  * allreduce of the stop test (mpi/ops.py:128-140).  A shard's message holds its
  * (max distance, global index) in the state every prefix of the round's chain
  * would leave and its farthest frames of the state the whole chain would leave
- * (16 + 16 * 16 + offer * ek_record_bytes bytes, offer = 64 / world).  Results are
+ * (16 + 32 * 16 + offer * ek_record_bytes bytes, offer = min(64, 128 / world)).  Results are
  * those of the single-shard run bit for bit: every accepted center is the
  * global first-index arg-max of the state before it (lowest rank on ties,
  * kcenters.py:337).
